@@ -1,0 +1,191 @@
+/* oprl_amd.h — C-ABI of the MI355X-native off-policy learner (liboprl_amd.so).
+ *
+ * The reference (schatty/oprl) has no FFI: its "operator API" for this path is
+ * two Python Protocols.  Each entry point below names the reference interface
+ * it sits under (paths relative to /root/reference/src/oprl):
+ *
+ *   oprl_learner_*   AlgorithmProtocol.update()           algos/protocols.py:21-41
+ *                    DDPG/TD3/SAC/TQC.update()            algos/ddpg.py:61, td3.py:71, sac.py:75, tqc.py:116
+ *   oprl_replay_*    ReplayBufferProtocol                 buffers/protocols.py:6-26
+ *                    EpisodicReplayBuffer.{add_transition,sample}  buffers/episodic_buffer.py:81-133
+ *   oprl_mlp_*       MLP / Critic / policies forward      algos/nn_models.py:27-194
+ *   oprl_adam_* / oprl_polyak   torch.optim.Adam.step / soft_update  algos/nn_functions.py:5-10
+ *
+ * Conventions: every function returns 0 on success or a negative oprl_status;
+ * oprl_last_error() returns the text of the last failure on the calling
+ * thread.  No exceptions cross the boundary.  All `float*`/`void*` data
+ * pointers are DEVICE pointers (HBM) unless the name ends in `_host`.  `stream`
+ * is a hipStream_t passed as void* (0 = default stream); all work is enqueued
+ * asynchronously on it.  The library never frees caller memory; it allocates
+ * only its own workspace in *_create and frees it in *_destroy.  A handle is
+ * used from one host thread at a time; distinct handles are independent.
+ */
+#ifndef OPRL_AMD_H
+#define OPRL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPRL_ABI_VERSION 1
+#define OPRL_MAX_LAYERS 4   /* linear layers per MLP (TQC critic has 4) */
+#define OPRL_MAX_CRITICS 5  /* TQC n_nets */
+
+typedef enum oprl_status {
+  OPRL_OK = 0,
+  OPRL_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+  OPRL_ERR_HIP = -2,       /* a HIP runtime call failed */
+  OPRL_ERR_STATE = -3,     /* handle not ready (e.g. empty replay) */
+  OPRL_ERR_NOMEM = -4
+} oprl_status;
+
+typedef enum oprl_algo { OPRL_DDPG = 0, OPRL_TD3 = 1, OPRL_SAC = 2, OPRL_TQC = 3 } oprl_algo;
+
+/* Arithmetic mode of the MLP GEMMs.  F32 = exact-fp32 MFMA
+ * (v_mfma_f32_16x16x4_f32), the parity mode.  */
+typedef enum oprl_precision { OPRL_PREC_F32 = 0 } oprl_precision;
+
+/* One MLP (ReLU hidden layers, identity output), parameters laid out exactly
+ * like the reference module's state_dict: W0[out0,in0] row-major, b0, W1, b1...
+ * (algos/nn_models.py:84-107).  theta is the trainable master copy; the other
+ * arenas use the same layout and may be NULL when the net has no target / is
+ * not trained. */
+typedef struct oprl_net {
+  int32_t n_layers;                     /* number of Linear layers, 2..OPRL_MAX_LAYERS */
+  int32_t dims[OPRL_MAX_LAYERS + 1];    /* dims[0]=input ... dims[n_layers]=output */
+  float* theta;
+  float* theta_target;
+  float* adam_m;
+  float* adam_v;
+  float* grad;                          /* written when grads are exported (DP / tests) */
+} oprl_net;
+
+typedef struct oprl_hparams {
+  float gamma, tau;
+  float lr_actor, lr_critic, lr_alpha;
+  float beta1, beta2, adam_eps;         /* torch defaults .9 / .999 / 1e-8 */
+  float policy_noise, noise_clip, max_action;   /* TD3 (td3.py:98-103) */
+  int32_t policy_freq;                          /* TD3 (td3.py:81) */
+  float alpha_init;                             /* SAC fixed alpha (sac.py:64) */
+  int32_t tune_alpha;                           /* SAC (sac.py:65-70); TQC always 1 */
+  float target_entropy;                         /* -action_dim */
+  int32_t n_quantiles, top_quantiles_to_drop;   /* TQC (tqc.py:71-73) */
+} oprl_hparams;
+
+typedef struct oprl_learner_config {
+  int32_t abi_version;      /* OPRL_ABI_VERSION */
+  int32_t algo;             /* oprl_algo */
+  int32_t precision;        /* oprl_precision */
+  int32_t state_dim, action_dim;
+  int32_t max_batch;        /* workspace is sized for this many rows */
+  int32_t n_critics;        /* 1 DDPG, 2 TD3/SAC, n_nets TQC */
+  int32_t export_grads;     /* 1: update() stops before Adam and leaves grads in
+                               net.grad (data-parallel learner reduces them, then
+                               calls oprl_learner_apply); 0: fused dW+Adam+Polyak */
+  oprl_net actor;
+  oprl_net critics[OPRL_MAX_CRITICS];
+  double* log_alpha;        /* device scalar (float64 like the reference), or NULL */
+  double* log_alpha_m;      /* its Adam state (device), or NULL */
+  double* log_alpha_v;
+  oprl_hparams hp;
+} oprl_learner_config;
+
+typedef struct oprl_learner oprl_learner;
+typedef struct oprl_replay oprl_replay;
+
+const char* oprl_last_error(void);
+int oprl_abi_version(void);
+
+/* ---- learner: AlgorithmProtocol.update() ------------------------------- */
+int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner** out);
+int oprl_learner_destroy(oprl_learner* h);
+
+/* One reference-semantics update() on a caller-supplied minibatch (row-major
+ * fp32: s[B,S] a[B,A] r[B] d[B] s2[B,S]).  noise0/noise1 are the N(0,1) draws
+ * the reference takes inside update() (TD3: randn_like(action), td3.py:98;
+ * SAC/TQC: next-state draw then actor-step draw, nn_models.py:213), each
+ * [B,A]; NULL = draw on device (Philox, keyed by seed and the update counter).*/
+int oprl_learner_update(oprl_learner* h, const float* s, const float* a, const float* r,
+                        const float* d, const float* s2, int32_t B,
+                        const float* noise0, const float* noise1, void* stream);
+
+/* Second half of an export_grads update: Adam (+Polyak) from net.grad after the
+ * caller has all-reduced it.  phase 0 = critic(s), 1 = actor (+alpha). */
+int oprl_learner_apply(oprl_learner* h, int32_t phase, float grad_scale, void* stream);
+/* In export_grads mode update() is split so the reduction can sit between the
+ * halves exactly where the reference's optimizer.step() sits:
+ *   oprl_learner_update_phase(h, 0, batch...) -> critic grads in net.grad
+ *   <all-reduce> ; oprl_learner_apply(h, 0, 1/world)
+ *   oprl_learner_update_phase(h, 1, ...)      -> actor grads
+ *   <all-reduce> ; oprl_learner_apply(h, 1, 1/world)                        */
+int oprl_learner_update_phase(oprl_learner* h, int32_t phase, const float* s, const float* a,
+                              const float* r, const float* d, const float* s2, int32_t B,
+                              const float* noise0, const float* noise1, void* stream);
+
+/* K back-to-back sample()+update() iterations with the minibatch drawn on
+ * device from `replay` (the 4000-update loop of
+ * distrib/policy_update_worker.py:65-68 as one call). */
+int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t K, int32_t B,
+                        uint64_t seed, void* stream);
+
+/* Diagnostics of the most recent update, read without forcing a sync inside
+ * update(): out_host[0]=critic_loss, [1]=actor_loss, [2]=mean q, [3]=mean
+ * target, [4]=alpha, [5]=update_step.  Synchronises `stream`. */
+int oprl_learner_read_scalars(oprl_learner* h, float* out_host, int32_t n, void* stream);
+int oprl_learner_update_count(oprl_learner* h, int64_t* out_host);
+int oprl_learner_set_update_count(oprl_learner* h, int64_t count);
+/* device pointer to the per-row Q / TD-target of the last critic step ([B] each,
+ * critic 0), for parity tests. */
+int oprl_learner_debug_ptrs(oprl_learner* h, const float** q, const float** y);
+
+/* ---- building blocks (nn_models.py forward; used by Module.__call__) ----- */
+/* out[B,dims[L]] = MLP([x0 | x1]) with x0[B,k0], x1[B,k1] (x1 may be NULL,
+ * k0+k1 == dims[0]); out_act: 0 identity, 1 tanh.  use_target selects
+ * theta_target. */
+int oprl_mlp_forward(const oprl_net* net, int32_t use_target, const float* x0, int32_t k0,
+                     const float* x1, int32_t k1, int32_t B, int32_t out_act, float* out,
+                     void* stream);
+/* Gradient of sum(out * dout) wrt every parameter (into net->grad) and, if
+ * dx != NULL, wrt the concatenated input [B,dims[0]].  Test/debug entry that
+ * exercises the same backward + dW kernels update() uses. */
+int oprl_mlp_backward(const oprl_net* net, const float* x0, int32_t k0, const float* x1,
+                      int32_t k1, int32_t B, const float* dout, float* dx, void* stream);
+/* torch.optim.Adam.step over a flat arena of n floats; step = 1-based count. */
+int oprl_adam_step(float* theta, float* m, float* v, const float* grad, int64_t n, int32_t step,
+                   float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* target <- (1-tau)*target + tau*source  (nn_functions.py:5-10) */
+int oprl_polyak(float* target, const float* source, int64_t n, float tau, void* stream);
+
+/* ---- replay: ReplayBufferProtocol --------------------------------------- */
+/* Storage tensors are owned by the caller (torch) with the reference layout
+ * (buffers/episodic_buffer.py:29-55): states[E,L+1,S] actions[E,L,A]
+ * rewards[E,L,1] dones[E,L,1], fp32, HBM resident. */
+int oprl_replay_create(int32_t n_episodes, int32_t max_ep_len, int32_t state_dim,
+                       int32_t action_dim, float* states, float* actions, float* rewards,
+                       float* dones, oprl_replay** out);
+int oprl_replay_destroy(oprl_replay* h);
+/* add_transition's data movement: stage one transition (host pointers) for slot
+ * [ep, t]; staged rows reach HBM in one batched copy + scatter at the next
+ * flush/sample.  Index bookkeeping stays with the caller (it is host logic). */
+int oprl_replay_write(oprl_replay* h, int32_t ep, int32_t t, const float* state_host,
+                      const float* action_host, float reward, float done);
+int oprl_replay_flush(oprl_replay* h, void* stream);
+/* Upload ep_lens[0:episodes_counter] (episodic_buffer.py:114-116); the device
+ * keeps the cumulative ends for the flat-index -> (episode, step) map. */
+int oprl_replay_set_lens(oprl_replay* h, const int32_t* ep_lens_host, int32_t episodes_counter,
+                         void* stream);
+/* sample(): gather B transitions.  idx (device int64[B], flat indices as
+ * np.random.randint would give, episodic_buffer.py:124) or NULL to draw them
+ * on device from (seed, counter).  Outputs: s[B,S] a[B,A] r[B,1] d[B,1] s2[B,S].
+ * If out_ep/out_step are non-NULL the (episode, step) pairs are written too. */
+int oprl_replay_sample(oprl_replay* h, int32_t B, const int64_t* idx, uint64_t seed,
+                       uint64_t counter, float* out_s, float* out_a, float* out_r, float* out_d,
+                       float* out_s2, int32_t* out_ep, int32_t* out_step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPRL_AMD_H */

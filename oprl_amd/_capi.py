@@ -1,0 +1,135 @@
+"""ctypes binding of include/oprl_amd.h (liboprl_amd.so).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError
+carrying ``oprl_last_error()`` is raised.  Build it with ``oprl_amd.build.build()``
+(or ``python -m oprl_amd.build``), which drives ``hipcc --offload-arch=gfx950``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+OPRL_ABI_VERSION = 1
+OPRL_MAX_LAYERS = 4
+OPRL_MAX_CRITICS = 5
+ALGO = {"ddpg": 0, "td3": 1, "sac": 2, "tqc": 3}
+ACT_NONE, ACT_TANH, ACT_GAUSS_MEAN = 0, 1, 4
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "liboprl_amd.so"
+
+
+class OprlNet(C.Structure):
+    _fields_ = [
+        ("n_layers", C.c_int32),
+        ("dims", C.c_int32 * (OPRL_MAX_LAYERS + 1)),
+        ("theta", C.c_void_p),
+        ("theta_target", C.c_void_p),
+        ("adam_m", C.c_void_p),
+        ("adam_v", C.c_void_p),
+        ("grad", C.c_void_p),
+    ]
+
+
+class OprlHparams(C.Structure):
+    _fields_ = [
+        ("gamma", C.c_float), ("tau", C.c_float),
+        ("lr_actor", C.c_float), ("lr_critic", C.c_float), ("lr_alpha", C.c_float),
+        ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+        ("policy_noise", C.c_float), ("noise_clip", C.c_float), ("max_action", C.c_float),
+        ("policy_freq", C.c_int32),
+        ("alpha_init", C.c_float),
+        ("tune_alpha", C.c_int32),
+        ("target_entropy", C.c_float),
+        ("n_quantiles", C.c_int32), ("top_quantiles_to_drop", C.c_int32),
+    ]
+
+
+class OprlLearnerConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("algo", C.c_int32),
+        ("precision", C.c_int32),
+        ("state_dim", C.c_int32), ("action_dim", C.c_int32),
+        ("max_batch", C.c_int32),
+        ("n_critics", C.c_int32),
+        ("export_grads", C.c_int32),
+        ("actor", OprlNet),
+        ("critics", OprlNet * OPRL_MAX_CRITICS),
+        ("log_alpha", C.c_void_p),
+        ("log_alpha_m", C.c_void_p),
+        ("log_alpha_v", C.c_void_p),
+        ("hp", OprlHparams),
+    ]
+
+
+# every symbol the header declares: name -> (restype, argtypes)
+_P, _I32, _I64, _U64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+SIGNATURES = {
+    "oprl_last_error": (C.c_char_p, []),
+    "oprl_abi_version": (C.c_int, []),
+    "oprl_learner_create": (C.c_int, [C.POINTER(OprlLearnerConfig), C.POINTER(_P)]),
+    "oprl_learner_destroy": (C.c_int, [_P]),
+    "oprl_learner_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P]),
+    "oprl_learner_apply": (C.c_int, [_P, _I32, _F, _P]),
+    "oprl_learner_update_phase": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _P]),
+    "oprl_learner_step_n": (C.c_int, [_P, _P, _I32, _I32, _U64, _P]),
+    "oprl_learner_read_scalars": (C.c_int, [_P, C.POINTER(C.c_float), _I32, _P]),
+    "oprl_learner_update_count": (C.c_int, [_P, C.POINTER(_I64)]),
+    "oprl_learner_set_update_count": (C.c_int, [_P, _I64]),
+    "oprl_learner_debug_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
+    "oprl_mlp_forward": (C.c_int, [C.POINTER(OprlNet), _I32, _P, _I32, _P, _I32, _I32, _I32, _P, _P]),
+    "oprl_mlp_backward": (C.c_int, [C.POINTER(OprlNet), _P, _I32, _P, _I32, _I32, _P, _P, _P]),
+    "oprl_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _F, _F, _F, _F, _F, _P]),
+    "oprl_polyak": (C.c_int, [_P, _P, _I64, _F, _P]),
+    "oprl_replay_create": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _P, _P, C.POINTER(_P)]),
+    "oprl_replay_destroy": (C.c_int, [_P]),
+    "oprl_replay_write": (C.c_int, [_P, _I32, _I32, _P, _P, _F, _F]),
+    "oprl_replay_flush": (C.c_int, [_P, _P]),
+    "oprl_replay_set_lens": (C.c_int, [_P, C.POINTER(C.c_int32), _I32, _P]),
+    "oprl_replay_sample": (C.c_int, [_P, _I32, _P, _U64, _U64, _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("OPRL_AMD_LIB", str(LIB_PATH)))
+
+
+def load() -> C.CDLL:
+    """Load the library and bind every declared symbol (AttributeError if one is
+    missing).  Does not touch the GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not p.exists():
+        raise RuntimeError(
+            f"{p} not found: the MI355X HIP extension is not built. Run "
+            "`python -m oprl_amd.build` (needs hipcc). There is no CPU fallback.")
+    lib = C.CDLL(str(p))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.oprl_abi_version() != OPRL_ABI_VERSION:
+        raise RuntimeError("liboprl_amd.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().oprl_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"liboprl_amd {what} failed (status {rc}): {msg}")
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t) -> C.c_void_p:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())

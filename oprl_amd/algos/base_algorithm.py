@@ -1,0 +1,210 @@
+"""Common base of the four algorithms + the binding between the torch-owned
+parameter arenas and the HIP learner handle.
+
+Reference: /root/reference/src/oprl/algos/base_algorithm.py:7-15 (guard +
+``get_policy_state_dict``).  Everything below ``HipLearner`` is new: it replaces
+autograd + torch.optim.Adam + the per-tensor Polyak loops of the reference's
+``update()`` bodies with one call into liboprl_amd.so."""
+from __future__ import annotations
+
+import ctypes as C
+from abc import ABC
+from typing import Any, Sequence
+
+import torch as t
+import torch.nn as nn
+
+from oprl_amd import _capi
+from oprl_amd.algos.nn_models import MLP, flatten_module_, is_flat
+
+
+class OffPolicyAlgorithm(ABC):
+    _created: bool = False
+
+    def check_created(self) -> None:
+        if not self._created:
+            raise RuntimeError(
+                f"Algorithm {type(self).__name__} has not been created with `create()`."
+            )
+
+    def get_policy_state_dict(self) -> dict[str, Any]:
+        return self.actor.state_dict()
+
+
+def require_gpu(device: str) -> t.device:
+    dev = t.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError(
+            f"device={device!r}: the oprl_amd learner runs only on an MI355X (device='cuda'); "
+            "it has no CPU path")
+    if not t.cuda.is_available():
+        raise RuntimeError("no GPU visible to torch; the oprl_amd learner has no CPU path")
+    _capi.load()
+    return dev if dev.index is not None else t.device("cuda", t.cuda.current_device())
+
+
+class HipLearner:
+    """Owns the C handle.  ``actor_mlp`` / ``critic_mlps`` are the trainable MLPs,
+    ``*_targets`` their target twins (or None); each group (actor, all critics)
+    must already be flat so one Adam-state arena per group lines up with it."""
+
+    def __init__(self, algo: str, state_dim: int, action_dim: int, device: t.device,
+                 actor_group: nn.Module, actor_mlp: MLP, actor_target_mlp: MLP | None,
+                 critic_group: nn.Module, critic_mlps: Sequence[MLP],
+                 critic_target_group: nn.Module, critic_target_mlps: Sequence[MLP],
+                 hp: dict, max_batch: int, export_grads: bool = False,
+                 log_alpha: t.Tensor | None = None):
+        self.lib = _capi.load()
+        self.device = device
+        self.S, self.A = state_dim, action_dim
+        self.max_batch = int(max_batch)
+        self.export_grads = bool(export_grads)
+        self._groups = [actor_group, critic_group, critic_target_group]
+        for g in self._groups:
+            if not is_flat(g):
+                flatten_module_(g)
+        if actor_target_mlp is not None and not is_flat(actor_target_mlp):
+            flatten_module_(actor_target_mlp)
+        self.actor_arena = actor_group._oprl_arena
+        self.critic_arena = critic_group._oprl_arena
+        self.actor_m = t.zeros_like(self.actor_arena)
+        self.actor_v = t.zeros_like(self.actor_arena)
+        self.critic_m = t.zeros_like(self.critic_arena)
+        self.critic_v = t.zeros_like(self.critic_arena)
+        self.actor_grad = t.zeros_like(self.actor_arena) if export_grads else None
+        self.critic_grad = t.zeros_like(self.critic_arena) if export_grads else None
+        self.log_alpha = log_alpha
+        self.log_alpha_m = t.zeros((), dtype=t.float64, device=device) if log_alpha is not None else None
+        self.log_alpha_v = t.zeros((), dtype=t.float64, device=device) if log_alpha is not None else None
+
+        cfg = _capi.OprlLearnerConfig()
+        cfg.abi_version = _capi.OPRL_ABI_VERSION
+        cfg.algo = _capi.ALGO[algo]
+        cfg.precision = 0
+        cfg.state_dim, cfg.action_dim = state_dim, action_dim
+        cfg.max_batch = self.max_batch
+        cfg.n_critics = len(critic_mlps)
+        cfg.export_grads = int(export_grads)
+
+        def off(arena: t.Tensor, mlp: MLP) -> int:
+            return mlp.theta_ptr() - arena.data_ptr()
+
+        def fill(dst: _capi.OprlNet, mlp: MLP, target: MLP | None, arena, m, v, g):
+            o = off(arena, mlp)
+            dst.n_layers = len(mlp.dims) - 1
+            for i, x in enumerate(mlp.dims):
+                dst.dims[i] = x
+            dst.theta = mlp.theta_ptr()
+            dst.theta_target = target.theta_ptr() if target is not None else None
+            dst.adam_m = m.data_ptr() + o
+            dst.adam_v = v.data_ptr() + o
+            dst.grad = (g.data_ptr() + o) if g is not None else None
+
+        fill(cfg.actor, actor_mlp, actor_target_mlp, self.actor_arena, self.actor_m, self.actor_v,
+             self.actor_grad)
+        for j, (c, ct) in enumerate(zip(critic_mlps, critic_target_mlps)):
+            fill(cfg.critics[j], c, ct, self.critic_arena, self.critic_m, self.critic_v, self.critic_grad)
+        if log_alpha is not None:
+            cfg.log_alpha = log_alpha.data_ptr()
+            cfg.log_alpha_m = self.log_alpha_m.data_ptr()
+            cfg.log_alpha_v = self.log_alpha_v.data_ptr()
+        for k, v in hp.items():
+            setattr(cfg.hp, k, v)
+        self._cfg = cfg
+        self._mlps = (actor_mlp, actor_target_mlp, list(critic_mlps), list(critic_target_mlps))
+        self._ptrs = self._snapshot_ptrs()
+        h = C.c_void_p()
+        with t.cuda.device(device):
+            _capi.check(self.lib.oprl_learner_create(C.byref(cfg), C.byref(h)), "oprl_learner_create")
+        self.handle = h
+
+    def _snapshot_ptrs(self):
+        a, at, cs, cts = self._mlps
+        return tuple(next(m.parameters()).data_ptr() for m in [a, *( [at] if at is not None else []), *cs, *cts])
+
+    def check_bound(self) -> None:
+        """The kernels hold raw pointers into the arenas: refuse to run if a
+        module was moved/re-allocated behind our back (e.g. ``actor.to(...)``)."""
+        if self._snapshot_ptrs() != self._ptrs:
+            raise RuntimeError("a network's parameters were re-allocated after create(); "
+                               "the HIP learner is bound to the original arenas")
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.oprl_learner_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ update
+    def _prep(self, state, action, reward, done, next_state):
+        dev = self.device
+        B = state.shape[0]
+
+        def f(x, cols):
+            x = t.as_tensor(x).to(device=dev, dtype=t.float32).reshape(B, cols)
+            return x.contiguous()
+
+        return B, f(state, self.S), f(action, self.A), f(reward, 1), f(done, 1), f(next_state, self.S)
+
+    def update(self, state, action, reward, done, next_state, noise0=None, noise1=None) -> None:
+        self.check_bound()
+        B, s, a, r, d, s2 = self._prep(state, action, reward, done, next_state)
+        n0 = None if noise0 is None else noise0.to(device=self.device, dtype=t.float32).reshape(B, self.A).contiguous()
+        n1 = None if noise1 is None else noise1.to(device=self.device, dtype=t.float32).reshape(B, self.A).contiguous()
+        with t.cuda.device(self.device):
+            _capi.check(self.lib.oprl_learner_update(
+                self.handle, _capi.ptr(s), _capi.ptr(a), _capi.ptr(r), _capi.ptr(d), _capi.ptr(s2), B,
+                _capi.ptr(n0), _capi.ptr(n1), _capi.current_stream()), "oprl_learner_update")
+
+    def update_phase(self, phase, state, action, reward, done, next_state, noise0=None, noise1=None):
+        self.check_bound()
+        B, s, a, r, d, s2 = self._prep(state, action, reward, done, next_state)
+        n0 = None if noise0 is None else noise0.to(device=self.device, dtype=t.float32).reshape(B, self.A).contiguous()
+        n1 = None if noise1 is None else noise1.to(device=self.device, dtype=t.float32).reshape(B, self.A).contiguous()
+        with t.cuda.device(self.device):
+            _capi.check(self.lib.oprl_learner_update_phase(
+                self.handle, phase, _capi.ptr(s), _capi.ptr(a), _capi.ptr(r), _capi.ptr(d), _capi.ptr(s2),
+                B, _capi.ptr(n0), _capi.ptr(n1), _capi.current_stream()), "oprl_learner_update_phase")
+
+    def apply(self, phase: int, grad_scale: float) -> None:
+        with t.cuda.device(self.device):
+            _capi.check(self.lib.oprl_learner_apply(self.handle, phase, float(grad_scale),
+                                                    _capi.current_stream()), "oprl_learner_apply")
+
+    def step_n(self, replay_handle, K: int, B: int, seed: int) -> None:
+        self.check_bound()
+        with t.cuda.device(self.device):
+            _capi.check(self.lib.oprl_learner_step_n(self.handle, replay_handle, K, B, seed,
+                                                     _capi.current_stream()), "oprl_learner_step_n")
+
+    def read_scalars(self) -> dict[str, float]:
+        buf = (C.c_float * 6)()
+        with t.cuda.device(self.device):
+            _capi.check(self.lib.oprl_learner_read_scalars(self.handle, buf, 6, _capi.current_stream()),
+                        "oprl_learner_read_scalars")
+        keys = ("critic_loss", "actor_loss", "q_mean", "q_target_mean", "alpha", "update_step")
+        return dict(zip(keys, (float(x) for x in buf)))
+
+    @property
+    def update_count(self) -> int:
+        n = C.c_int64()
+        _capi.check(self.lib.oprl_learner_update_count(self.handle, C.byref(n)))
+        return int(n.value)
+
+    def debug_q_y(self, B: int) -> tuple[t.Tensor, t.Tensor]:
+        """Per-row Q(s,a) and TD target of the last critic step (critic 0)."""
+        q, y = C.c_void_p(), C.c_void_p()
+        _capi.check(self.lib.oprl_learner_debug_ptrs(self.handle, C.byref(q), C.byref(y)))
+        out = []
+        for p in (q, y):
+            buf = t.empty(B, dtype=t.float32, device=self.device)
+            t.cuda.synchronize(self.device)
+            C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(
+                C.c_void_p(buf.data_ptr()), p, C.c_size_t(4 * B), C.c_int(3))
+            out.append(buf)
+        return out[0], out[1]

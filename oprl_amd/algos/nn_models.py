@@ -1,0 +1,295 @@
+"""Networks of the off-policy learner, arena-backed.
+
+Same classes, constructor arguments and state_dict keys as the reference
+(/root/reference/src/oprl/algos/nn_models.py: MLP :84-107, Critic :27-49,
+DoubleCritic :52-81, DeterministicPolicy :110-150, GaussianActor :153-194), so
+``actor.state_dict()``, ``t.save(actor)`` and ``load_state_dict`` interoperate
+with a plain reference module.  What differs is underneath:
+
+* every module's Parameters are *views into one flat fp32 arena* laid out in
+  state_dict order (W0,b0,W1,b1,...) — the layout the HIP learner binds to
+  (``oprl_net.theta``) and updates in place;
+* on a GPU tensor ``forward`` runs the hand-written gfx950 slice kernel through
+  ``oprl_mlp_forward`` (cat-free: state and action are read from two pointers).
+  On CPU tensors (actor processes of the distributed setup, which only ever do
+  B=1 explore/exploit) it is plain torch arithmetic; the learner itself has no
+  CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Final, Sequence
+
+import numpy as np
+import numpy.typing as npt
+import torch as t
+import torch.nn as nn
+from torch.nn.functional import logsigmoid
+
+from oprl_amd import _capi
+
+LOG_STD_MIN_MAX: Final[tuple[float, float]] = (-20, 2)
+
+
+def initialize_weight_orthogonal(m: nn.Module, gain: float = nn.init.calculate_gain("relu")) -> None:
+    """Orthogonal weights (gain sqrt(2)) and zero bias for Linear layers
+    (reference nn_models.py:14-24; its conv branch is unused on this path)."""
+    if isinstance(m, nn.Linear):
+        nn.init.orthogonal_(m.weight.data, gain)
+        m.bias.data.zero_()
+
+
+# --------------------------------------------------------------------------- #
+# flat parameter arenas                                                       #
+# --------------------------------------------------------------------------- #
+def flatten_module_(module: nn.Module) -> t.Tensor:
+    """Re-home all parameters of ``module`` as views of one contiguous fp32
+    tensor (parameters() order == state_dict order) and return that tensor.
+    Values are preserved.  Call again after ``module.to(device)``."""
+    params = list(module.parameters())
+    if not params:
+        raise ValueError("module has no parameters")
+    dev = params[0].device
+    flat = t.empty(sum(p.numel() for p in params), dtype=t.float32, device=dev)
+    off = 0
+    for p in params:
+        n = p.numel()
+        flat[off:off + n].copy_(p.data.reshape(-1))
+        p.data = flat[off:off + n].view(p.shape)
+        off += n
+    module._oprl_arena = flat  # keeps the storage alive with the module
+    return flat
+
+
+def is_flat(module: nn.Module) -> bool:
+    """True if the parameters are contiguous, in order, in one storage."""
+    arena = getattr(module, "_oprl_arena", None)
+    if arena is None:
+        return False
+    expect = arena.data_ptr()
+    for p in module.parameters():
+        if p.data_ptr() != expect or p.dtype != t.float32:
+            return False
+        expect += p.numel() * 4
+    return True
+
+
+def ensure_flat(module: nn.Module) -> t.Tensor:
+    if not is_flat(module):
+        flatten_module_(module)
+    return module._oprl_arena
+
+
+def _net_desc(dims: Sequence[int], theta_ptr: int, target_ptr: int = 0, m_ptr: int = 0,
+              v_ptr: int = 0, grad_ptr: int = 0) -> _capi.OprlNet:
+    d = _capi.OprlNet()
+    d.n_layers = len(dims) - 1
+    for i, x in enumerate(dims):
+        d.dims[i] = int(x)
+    d.theta, d.theta_target, d.adam_m, d.adam_v, d.grad = (
+        C.c_void_p(theta_ptr), C.c_void_p(target_ptr), C.c_void_p(m_ptr), C.c_void_p(v_ptr),
+        C.c_void_p(grad_ptr))
+    return d
+
+
+class MLP(nn.Module):
+    """Linear -> act -> ... -> Linear -> out_act, registered as ``self.nn``
+    (an ``nn.Sequential``) so parameter keys are ``nn.{0,2,4,..}.{weight,bias}``."""
+
+    def __init__(
+        self,
+        input_dim: int,
+        output_dim: int,
+        hidden_units: tuple[int, ...] = (64, 64),
+        hidden_activation: nn.Module = nn.Tanh(),
+        output_activation: nn.Module = nn.Identity(),
+    ):
+        super().__init__()
+        self.dims = [int(input_dim), *[int(h) for h in hidden_units], int(output_dim)]
+        mods: list[nn.Module] = []
+        for fan_in, fan_out in zip(self.dims[:-2], self.dims[1:-1]):
+            mods += [nn.Linear(fan_in, fan_out), hidden_activation]
+        mods += [nn.Linear(self.dims[-2], self.dims[-1]), output_activation]
+        self.nn = nn.Sequential(*mods)
+        self._hip_ok = isinstance(hidden_activation, nn.ReLU) and isinstance(output_activation, nn.Identity)
+
+    # -- HIP path ------------------------------------------------------------
+    def theta_ptr(self) -> int:
+        """Device pointer of this MLP's W0 (its parameters must be flat; they
+        are when the MLP or an ancestor went through flatten_module_)."""
+        ps = list(self.parameters())
+        expect = ps[0].data_ptr()
+        for p in ps:
+            if p.data_ptr() != expect:
+                flatten_module_(self)
+                return next(self.parameters()).data_ptr()
+            expect += p.numel() * 4
+        return ps[0].data_ptr()
+
+    def hip_forward(self, x0: t.Tensor, x1: t.Tensor | None = None, out_act: int = _capi.ACT_NONE) -> t.Tensor:
+        if not self._hip_ok:
+            raise RuntimeError("the HIP MLP kernels implement ReLU hidden / identity output only")
+        lib = _capi.load()
+        x0 = x0.detach().to(t.float32).contiguous()
+        k0 = x0.shape[-1]
+        k1 = 0
+        if x1 is not None:
+            x1 = x1.detach().to(t.float32).contiguous()
+            k1 = x1.shape[-1]
+        B = x0.shape[0]
+        n_out = self.dims[-1] // 2 if out_act == _capi.ACT_GAUSS_MEAN else self.dims[-1]
+        out = t.empty((B, n_out), dtype=t.float32, device=x0.device)
+        desc = _net_desc(self.dims, self.theta_ptr())
+        with t.cuda.device(x0.device):
+            _capi.check(lib.oprl_mlp_forward(C.byref(desc), 0, _capi.ptr(x0), k0, _capi.ptr(x1), k1,
+                                             B, out_act, _capi.ptr(out), _capi.current_stream()),
+                        "oprl_mlp_forward")
+        return out
+
+    def forward(self, x: t.Tensor) -> t.Tensor:
+        if x.is_cuda:
+            return self.hip_forward(x)
+        return self.nn(x)
+
+
+def _forward_sa(mlp: MLP, states: t.Tensor, actions: t.Tensor) -> t.Tensor:
+    if states.is_cuda:
+        return mlp.hip_forward(states, actions)
+    return mlp.nn(t.cat([states, actions], dim=-1))
+
+
+class Critic(nn.Module):
+    def __init__(
+        self,
+        state_dim: int,
+        action_dim: int,
+        hidden_units: tuple[int, ...] = (256, 256),
+        hidden_activation: nn.Module = nn.ReLU(inplace=True),
+    ) -> None:
+        super().__init__()
+        self.q1 = MLP(state_dim + action_dim, 1, hidden_units, hidden_activation)
+
+    def forward(self, states: t.Tensor, actions: t.Tensor) -> t.Tensor:
+        return _forward_sa(self.q1, states, actions)
+
+    def Q1(self, states: t.Tensor, actions: t.Tensor) -> t.Tensor:
+        return _forward_sa(self.q1, states, actions)
+
+
+class DoubleCritic(nn.Module):
+    def __init__(
+        self,
+        state_dim: int,
+        action_dim: int,
+        hidden_units: tuple[int, ...] = (256, 256),
+        hidden_activation: nn.Module = nn.ReLU(inplace=True),
+    ):
+        super().__init__()
+        self.q1 = MLP(state_dim + action_dim, 1, hidden_units, hidden_activation)
+        self.q2 = MLP(state_dim + action_dim, 1, hidden_units, hidden_activation)
+
+    def forward(self, states: t.Tensor, actions: t.Tensor) -> tuple[t.Tensor, t.Tensor]:
+        return _forward_sa(self.q1, states, actions), _forward_sa(self.q2, states, actions)
+
+    def Q1(self, states: t.Tensor, actions: t.Tensor) -> t.Tensor:
+        return _forward_sa(self.q1, states, actions)
+
+
+class DeterministicPolicy(nn.Module):
+    def __init__(
+        self,
+        state_dim: int,
+        action_dim: int,
+        hidden_units: tuple[int, ...] = (256, 256),
+        hidden_activation: nn.Module = nn.ReLU(inplace=True),
+        max_action: float = 1.0,
+        expl_noise: float = 0.1,
+        device: str = "cpu",
+    ):
+        super().__init__()
+        self.mlp = MLP(state_dim, action_dim, hidden_units, hidden_activation)
+        self.mlp.apply(initialize_weight_orthogonal)
+        self._device = device
+        self._action_shape = action_dim
+        self._max_action = max_action
+        self._expl_noise = expl_noise
+
+    def forward(self, states: t.Tensor) -> t.Tensor:
+        if states.is_cuda:
+            return self.mlp.hip_forward(states, out_act=_capi.ACT_TANH)
+        return t.tanh(self.mlp.nn(states))
+
+    def exploit(self, state: npt.NDArray) -> npt.NDArray:
+        s = t.as_tensor(state, dtype=t.float32, device=self._device).unsqueeze(0)
+        with t.no_grad():
+            return self.forward(s).cpu().numpy().reshape(-1)
+
+    def explore(self, state: npt.NDArray) -> npt.NDArray:
+        # reference quirk kept: NO tanh on the exploration path (nn_models.py:144-150)
+        s = t.as_tensor(state, dtype=t.float32, device=self._device).unsqueeze(0)
+        noise = t.randn(self._action_shape) * self._expl_noise
+        with t.no_grad():
+            raw = self.mlp(s).cpu()[0] + noise
+        return np.clip(raw.numpy(), -self._max_action, self._max_action)
+
+
+class TanhNormal:
+    """tanh-squashed diagonal Gaussian (reference nn_models.py:197-214)."""
+
+    def __init__(self, normal_mean: t.Tensor, normal_std: t.Tensor, device: str | None = None) -> None:
+        self.normal_mean = normal_mean
+        self.normal_std = normal_std
+
+    def rsample(self, eps: t.Tensor | None = None) -> tuple[t.Tensor, t.Tensor]:
+        if eps is None:
+            eps = t.randn_like(self.normal_mean)
+        pre = self.normal_mean + self.normal_std * eps
+        return t.tanh(pre), pre
+
+    def log_prob(self, pre_tanh: t.Tensor) -> t.Tensor:
+        var = self.normal_std ** 2
+        normal_lp = (-((pre_tanh - self.normal_mean) ** 2) / (2 * var) - self.normal_std.log()
+                     - float(np.log(np.sqrt(2 * np.pi))))
+        log_det = 2 * float(np.log(2)) + logsigmoid(2 * pre_tanh) + logsigmoid(-2 * pre_tanh)
+        return normal_lp - log_det
+
+
+class GaussianActor(nn.Module):
+    def __init__(
+        self,
+        state_dim: int,
+        action_dim: int,
+        hidden_units: tuple[int, ...],
+        hidden_activation: nn.Module,
+        device: str,
+    ):
+        super().__init__()
+        self.action_dim = action_dim
+        self.net = MLP(state_dim, 2 * action_dim, hidden_units, hidden_activation=hidden_activation)
+        self.device = device
+
+    def forward(self, obs: t.Tensor, eps: t.Tensor | None = None) -> tuple[t.Tensor, t.Tensor | None]:
+        """Train mode: (tanh(mu + sigma*eps), log pi); eval mode: (tanh(mu), None).
+        ``eps`` lets a caller inject the N(0,1) draw (parity tests)."""
+        raw = self.net(obs)
+        mean, log_std = raw[:, :self.action_dim], raw[:, self.action_dim:]
+        if not self.training:
+            return t.tanh(mean), None
+        std = t.exp(log_std.clamp(*LOG_STD_MIN_MAX))
+        dist = TanhNormal(mean, std)
+        action, pre = dist.rsample(eps)
+        return action, dist.log_prob(pre).sum(dim=1, keepdim=True)
+
+    def explore(self, state: npt.NDArray) -> npt.NDArray:
+        s = t.as_tensor(state, dtype=t.float32, device=self.device).unsqueeze(0)
+        with t.no_grad():
+            action, _ = self.forward(s)
+        return action.cpu().numpy()[0]
+
+    def exploit(self, state: npt.NDArray) -> npt.NDArray:
+        was_training = self.training
+        self.eval()
+        try:
+            return self.explore(state)
+        finally:
+            self.train(was_training)

@@ -1,0 +1,229 @@
+"""HBM-resident episodic replay buffer.
+
+API, storage shapes and ring/eviction semantics of the reference
+(/root/reference/src/oprl/buffers/episodic_buffer.py:13-140); the work is split
+differently:
+
+* index bookkeeping (episode ring pointer, per-episode lengths, live-transition
+  count) is host logic and stays in Python ints, exactly as in the reference
+  (:81-112), including its quirks: ``episodes_counter`` starts at 1, the slot
+  the pointer advances onto is evicted immediately, ``add_episode`` with a
+  terminal last row advances twice;
+* data movement goes through liboprl_amd.so: ``add_transition`` stages the row
+  in pinned host memory (``oprl_replay_write``) and rows reach HBM in one
+  batched copy + scatter kernel at the next ``sample``/tensor access;
+  ``sample`` is the gather kernel (``oprl_replay_sample``): uniform flat
+  indices -> (episode, step) by binary search over cumulative episode ends ->
+  one contiguous [s | s'] run + action + reward + done per sample, staged
+  through LDS and written coalesced.
+
+Storage is zero-filled instead of ``t.empty`` so the reference's reads of
+never-written ``t+1`` slots are at least deterministic.
+On ``device='cpu'`` the container and its bookkeeping work (host logic is
+testable without a GPU) but ``sample`` raises: there is no CPU sampler."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+import numpy.typing as npt
+import torch as t
+
+from oprl_amd import _capi
+from oprl_amd.buffers.protocols import ReplayBufferProtocol
+
+Transition = tuple[npt.NDArray, npt.NDArray, float, bool, npt.NDArray]
+
+
+@dataclass
+class EpisodicReplayBuffer(ReplayBufferProtocol):
+    buffer_size_transitions: int
+    state_dim: int
+    action_dim: int
+    gamma: float = 0.99
+    max_episode_lenth: int = 1000   # [sic] — the reference's spelling is the API
+    episodes_counter: int = 1
+    device: str = "cpu"
+    seed: int = 0                   # device sampler key (Philox); extension
+
+    _tensors: dict[str, t.Tensor] = field(init=False)
+    _max_episodes: int = field(init=False)
+    _ep_pointer: int = 0
+    _number_transitions = 0
+    _created: bool = False
+
+    def create(self) -> "EpisodicReplayBuffer":
+        E = self._max_episodes = self.buffer_size_transitions // self.max_episode_lenth
+        L, S, A = self.max_episode_lenth, self.state_dim, self.action_dim
+        dev = t.device(self.device)
+        self._tensors = {
+            "actions": t.zeros((E, L, A), dtype=t.float32, device=dev),
+            "rewards": t.zeros((E, L, 1), dtype=t.float32, device=dev),
+            "dones": t.zeros((E, L, 1), dtype=t.float32, device=dev),
+            "states": t.zeros((E, L + 1, S), dtype=t.float32, device=dev),
+        }
+        self.ep_lens = [0] * E
+        self._handle = None
+        self._lens_dirty = True
+        self._sample_counter = 0
+        self._on_gpu = dev.type == "cuda"
+        if self._on_gpu:
+            self._dev = dev if dev.index is not None else t.device("cuda", t.cuda.current_device())
+            lib = _capi.load()
+            h = C.c_void_p()
+            with t.cuda.device(self._dev):
+                _capi.check(lib.oprl_replay_create(
+                    E, L, S, A, _capi.ptr(self._tensors["states"]), _capi.ptr(self._tensors["actions"]),
+                    _capi.ptr(self._tensors["rewards"]), _capi.ptr(self._tensors["dones"]), C.byref(h)),
+                    "oprl_replay_create")
+            self._handle = h
+            self._lib = lib
+        self._created = True
+        return self
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            try:
+                self._lib.oprl_replay_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    def check_created(self) -> None:
+        if not self._created:
+            raise RuntimeError("Replay buffer has to be created with `.create()`.")
+
+    # storage views (flush staged rows first so they are observable) -----------
+    def _flush(self) -> None:
+        if self._handle is not None:
+            with t.cuda.device(self._dev):
+                _capi.check(self._lib.oprl_replay_flush(self._handle, _capi.current_stream()),
+                            "oprl_replay_flush")
+
+    def _tensor(self, name: str) -> t.Tensor:
+        self.check_created()
+        self._flush()
+        return self._tensors[name]
+
+    @property
+    def states(self) -> t.Tensor:
+        return self._tensor("states")
+
+    @property
+    def actions(self) -> t.Tensor:
+        return self._tensor("actions")
+
+    @property
+    def rewards(self) -> t.Tensor:
+        return self._tensor("rewards")
+
+    @property
+    def dones(self) -> t.Tensor:
+        return self._tensor("dones")
+
+    # write path -----------------------------------------------------------------
+    def add_transition(
+        self,
+        state: npt.NDArray,
+        action: npt.NDArray,
+        reward: float,
+        done: bool,
+        episode_done: bool | None = None,
+    ) -> None:
+        e, l = self._ep_pointer, self.ep_lens[self._ep_pointer]
+        if l >= self.max_episode_lenth:
+            raise IndexError(f"episode slot {e} is full ({l} steps, max_episode_lenth={self.max_episode_lenth})")
+        s = np.ascontiguousarray(state, dtype=np.float32).reshape(self.state_dim)
+        a = np.ascontiguousarray(action, dtype=np.float32).reshape(self.action_dim)  # f64 actions are cast
+        if self._handle is not None:
+            _capi.check(self._lib.oprl_replay_write(
+                self._handle, e, l, s.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p),
+                float(reward), float(done)), "oprl_replay_write")
+        else:  # host container only (no GPU): plain row stores
+            self._tensors["states"][e, l] = t.from_numpy(s)
+            self._tensors["actions"][e, l] = t.from_numpy(a)
+            self._tensors["rewards"][e, l] = float(reward)
+            self._tensors["dones"][e, l] = float(done)
+        self.ep_lens[e] += 1
+        self._number_transitions = min(self._number_transitions + 1, self.buffer_size_transitions)
+        self._lens_dirty = True
+        if episode_done:
+            self._inc_episode()
+
+    def _inc_episode(self) -> None:
+        self._ep_pointer = (self._ep_pointer + 1) % self._max_episodes
+        self.episodes_counter = min(self.episodes_counter + 1, self._max_episodes)
+        self._number_transitions -= self.ep_lens[self._ep_pointer]
+        self.ep_lens[self._ep_pointer] = 0
+        self._lens_dirty = True
+
+    def add_episode(self, episode: list[Transition]) -> None:
+        for s, a, r, d, _ in episode:
+            self.add_transition(s, a, r, d, episode_done=d)
+        self._inc_episode()
+
+    # read path ------------------------------------------------------------------
+    def _sync_lens(self) -> None:
+        if self._lens_dirty:
+            n = self.episodes_counter
+            arr = (C.c_int32 * max(n, 1))(*self.ep_lens[:n])
+            with t.cuda.device(self._dev):
+                _capi.check(self._lib.oprl_replay_set_lens(self._handle, arr, n, _capi.current_stream()),
+                            "oprl_replay_set_lens")
+            self._lens_dirty = False
+
+    @property
+    def handle(self):
+        """C handle with the device-side episode table up to date (for step_n)."""
+        self.check_created()
+        if self._handle is None:
+            raise RuntimeError("replay buffer is not on a GPU")
+        self._sync_lens()
+        return self._handle
+
+    def sample(self, batch_size: int, inds: t.Tensor | npt.NDArray | None = None,
+               return_indices: bool = False):
+        """Uniform (with replacement) minibatch of live transitions, including the
+        in-progress episode's tail — reference semantics (:123-133).  ``inds``:
+        optional injected flat indices (what ``np.random.randint(0, len, B)``
+        would return) for parity tests; None draws them on device."""
+        self.check_created()
+        if self._handle is None:
+            raise RuntimeError("sample() runs on the MI355X gather kernel; create the buffer with "
+                               "device='cuda' (there is no CPU sampler)")
+        if self._number_transitions <= 0:
+            raise ValueError("cannot sample from an empty replay buffer")
+        self._sync_lens()
+        B, S, A, dev = int(batch_size), self.state_dim, self.action_dim, self._dev
+        out_s = t.empty((B, S), dtype=t.float32, device=dev)
+        out_a = t.empty((B, A), dtype=t.float32, device=dev)
+        out_r = t.empty((B, 1), dtype=t.float32, device=dev)
+        out_d = t.empty((B, 1), dtype=t.float32, device=dev)
+        out_s2 = t.empty((B, S), dtype=t.float32, device=dev)
+        idx = None
+        if inds is not None:
+            idx = t.as_tensor(inds).to(device=dev, dtype=t.int64).contiguous()
+            if idx.numel() != B:
+                raise ValueError("inds must hold batch_size indices")
+        ep = st = None
+        if return_indices:
+            ep = t.empty(B, dtype=t.int32, device=dev)
+            st = t.empty(B, dtype=t.int32, device=dev)
+        with t.cuda.device(dev):
+            _capi.check(self._lib.oprl_replay_sample(
+                self._handle, B, _capi.ptr(idx), self.seed, self._sample_counter, _capi.ptr(out_s),
+                _capi.ptr(out_a), _capi.ptr(out_r), _capi.ptr(out_d), _capi.ptr(out_s2),
+                _capi.ptr(ep), _capi.ptr(st), _capi.current_stream()), "oprl_replay_sample")
+        self._sample_counter += 1
+        if return_indices:
+            return (out_s, out_a, out_r, out_d, out_s2), (ep, st)
+        return out_s, out_a, out_r, out_d, out_s2
+
+    @property
+    def last_episode_length(self) -> int:
+        return self.ep_lens[self._ep_pointer]
+
+    def __len__(self) -> int:
+        return self._number_transitions

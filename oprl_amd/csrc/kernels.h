@@ -1,0 +1,96 @@
+// kernels.h — argument blocks shared between the host orchestration (learner.hip)
+// and the device kernels (kernels.hip).
+#pragma once
+#include "engine.h"
+
+namespace oprl {
+
+// ---- output activation of the slice kernel's forward half ------------------
+enum OutAct : int {
+  ACT_NONE = 0,
+  ACT_TANH = 1,         // DeterministicPolicy.forward             nn_models.py:135-136
+  ACT_TANH_SMOOTH = 2,  // TD3 target smoothing                    td3.py:98-103
+  ACT_GAUSS = 3,        // GaussianActor train-mode forward        nn_models.py:168-178
+  ACT_GAUSS_MEAN = 4,   // GaussianActor eval: tanh(mean)          nn_models.py:179-181
+};
+
+// ---- how the backward half obtains dLoss/d(out) ----------------------------
+enum SeedMode : int {
+  SEED_PTR = 0,       // read from global
+  SEED_MSE_TD = 1,    // 2(q - y)/B with y = r + (1-d) gamma (min(qn1,qn2) - alpha logp')
+  SEED_CONST = 2,     // constant (actor loss through a critic: -1/B, TQC: -1/(B N Q))
+  SEED_MINQ = 3,      // SAC actor: -[q_j is the min]/B                 sac.py:126
+  SEED_TANH = 4,      // du = da (1 - a^2)                               ddpg.py:104
+  SEED_GAUSS = 5,     // tanh-Gaussian head backward
+  SEED_QHUBER = 6,    // quantile-Huber dL/dz                            tqc.py:14-36
+};
+
+struct SeedArgs {
+  const float* p0;   // PTR: dout | MSE_TD: qn1 | MINQ: q1 | TANH: da | GAUSS: da (net 0) | QHUBER: target[B,M]
+  const float* p1;   //             MSE_TD: qn2 or null | MINQ: q2 | TANH: a | GAUSS: raw out [B,2A]
+  const float* p2;   //             MSE_TD: logp' or null   (GAUSS eps comes from MlpArgs.noise / Philox)
+  const float* r;    // MSE_TD
+  const float* d;    // MSE_TD
+  const double* log_alpha;  // device scalar or null (then alpha_const)
+  float alpha_const;
+  float gamma;
+  float cval;        // CONST value; MINQ/GAUSS/MSE: 1/B ; QHUBER: 1/(B*N*Q*M)
+  int which;         // MINQ: 0/1 = which critic this is
+  int ld0;           // leading dim of p0 (PTR/TANH/GAUSS da)
+  int n_da;          // GAUSS: number of stacked da buffers to sum (critics), stride da_stride
+  long da_stride;
+  int M;             // QHUBER: samples per row
+  int Q;             // QHUBER: quantiles per net
+  float* y_out;      // MSE_TD: TD target [B] (debug / diagnostics), may be null
+  float* q_out;      // MSE_TD: current q [B], may be null
+};
+
+struct MlpArgs {
+  Net net;
+  int B;
+  int do_fwd, do_bwd;
+  // forward input [x0 | x1]
+  const float* x0; int k0;
+  const float* x1; int k1;
+  int out_act;
+  float* out; int ldo;            // activated output [B][ldo] (ACT_GAUSS*: action [B][A])
+  float* raw_out; int ldraw;      // ACT_GAUSS: raw net output [B][2A] for the backward
+  float* logp;                    // ACT_GAUSS: [B]
+  const float* noise;             // ACT_TANH_SMOOTH / ACT_GAUSS: N(0,1) draws [B][A] (null: Philox)
+  unsigned long long rng_seed, rng_ctr;
+  float policy_noise, noise_clip, max_action;
+  int action_dim;
+  // activation exchange with the dW kernel / a later backward launch
+  float* Xg[kMaxLayers]; int ldx0;   // Xg[0]: [B][ldx0] concatenated input; Xg[l>=1]: [B][WIDTH]
+  // backward
+  int seed_mode; SeedArgs seed;
+  float* dYg[kMaxLayers]; int lddo;  // dYg[l<L-1]: [B][WIDTH]; dYg[L-1]: [B][lddo]
+  int dact_col0, dact_cols; float* dact; int lddact;
+  float* partials;                   // [gridDim.x][4] per-slice sums: loss, q, y, (spare)
+};
+
+// ---- dW + Adam + Polyak ------------------------------------------------------
+struct DwItem {      // one Linear layer of one net
+  const float* X; int ldx; int K;      // layer input  [B][ldx]
+  const float* dY; int ldy; int N;     // grad wrt layer pre-activation output [B][ldy]
+  float *w, *w_t, *w_m, *w_v, *w_g;    // [N][K] views into theta / theta_target / m / v / grad
+  float *b, *b_t, *b_m, *b_v, *b_g;    // [N]
+  int tiles_k, tile_begin, tile_end;
+};
+
+struct AdamScalars {
+  float lr, beta1, beta2, eps;
+  int step_base; const int* step_dev;  // Adam step = step_base + (step_dev ? *step_dev : 0)
+  float tau; int do_polyak;
+  int do_adam;                         // 0: only export grads
+  float grad_scale;
+};
+
+struct DwArgs {
+  const DwItem* items; int n_items; int total_tiles; int B;
+  AdamScalars ad;
+};
+
+constexpr int kDwTile = 32;
+
+}  // namespace oprl

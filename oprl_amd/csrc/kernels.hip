@@ -1,0 +1,537 @@
+// kernels.hip — gfx950 kernels of the off-policy learner hot path.
+//
+//   k_mlp_slice<WIDTH>   one workgroup per 16-row minibatch slice: input assembly
+//                        -> whole-MLP forward -> policy-head / TD epilogue ->
+//                        loss-gradient seed -> whole-MLP backward (engine.h)
+//   k_dw_adam            dW = dY^T X on 32x32 tiles (fp32 MFMA) fused with
+//                        torch-semantics Adam, Polyak target update, grad export
+//   k_adam_flat / k_polyak_flat / k_alpha_step / k_reduce_partials   small fused
+//                        elementwise pieces
+//   k_tqc_target         row-wise bitonic sort of 125 quantiles + truncation + TD
+//
+// Reference op groups replaced: SURVEY.md §2.2 K2-K13.
+#include "kernels.h"
+#include "philox.h"
+
+namespace oprl {
+
+__device__ __forceinline__ float logsigmoidf(float x) {
+  // min(0,x) - log1p(exp(-|x|))   (ATen log_sigmoid_forward)
+  return fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+}
+
+__device__ __forceinline__ float alpha_of(const SeedArgs& s) {
+  return s.log_alpha != nullptr ? (float)exp(*s.log_alpha) : s.alpha_const;
+}
+
+constexpr float kLogStdMin = -20.f, kLogStdMax = 2.f;   // nn_models.py:11
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;  // log(sqrt(2*pi))
+constexpr float kTwoLog2 = 1.38629436111989061883f;     // 2*log(2)
+
+// N(0,1) draw for (row, col): injected array or counter-based Philox
+__device__ __forceinline__ float noise_at(const MlpArgs& A, int gr, int col) {
+  if (A.noise != nullptr) return A.noise[(size_t)gr * A.action_dim + col];
+  return philox_normal(A.rng_seed, A.rng_ctr, (unsigned)gr, (unsigned)col);
+}
+
+template <int WIDTH>
+__global__ __launch_bounds__(kThreads) void k_mlp_slice(const MlpArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using LY = SliceLds<WIDTH>;
+  constexpr int WL = lds_ld(WIDTH);
+  const int L = A.net.n_layers, nh = L - 1;
+  const int Nout = pick(A.net.dims, L);
+  float* x0s = smem;
+  float* hb = smem + LY::h_off;
+  float* outS = smem + LY::out_off(nh);
+  float* auxS = smem + LY::aux_off(nh);
+  float* scr = smem + LY::scr_off(nh);
+  const int row0 = blockIdx.x * kR;
+  const int B = A.B;
+  const int tid = threadIdx.x;
+
+  if (A.do_fwd) {
+    lds_zero(x0s, kR * kX0Ld);
+    __syncthreads();
+    load_rows(x0s, kX0Ld, 0, A.x0, A.k0, A.k0, row0, B);
+    if (A.x1 != nullptr) load_rows(x0s, kX0Ld, A.k0, A.x1, A.k1, A.k1, row0, B);
+    __syncthreads();
+    if (A.Xg[0] != nullptr) store_rows(x0s, kX0Ld, A.Xg[0], A.ldx0, A.net.dims[0], row0, B);
+    mlp_forward_slice<WIDTH>(A.net, x0s, hb, outS, scr, A.Xg, A.Xg[1] != nullptr, row0, B);
+    // ---- output head ------------------------------------------------------
+    if (A.out_act == ACT_GAUSS) {
+      const int Ad = A.action_dim;
+      const int row = tid >> 4, sub = tid & 15, gr = row0 + row;
+      float lp = 0.f;
+      if (gr < B) {
+        for (int col = sub; col < Ad; col += 16) {
+          const float mu = outS[row * kOutLd + col];
+          const float lsr = outS[row * kOutLd + Ad + col];
+          const float ls = fminf(fmaxf(lsr, kLogStdMin), kLogStdMax);
+          const float sd = expf(ls);
+          const float e = noise_at(A, gr, col);
+          const float u = mu + sd * e;
+          const float a = tanhf(u);
+          const float diff = u - mu;
+          lp += -(diff * diff) / (2.f * sd * sd) - logf(sd) - kHalfLog2Pi -
+                (kTwoLog2 + logsigmoidf(2.f * u) + logsigmoidf(-2.f * u));
+          if (A.out != nullptr) A.out[(size_t)gr * A.ldo + col] = a;
+          if (A.raw_out != nullptr) {
+            A.raw_out[(size_t)gr * A.ldraw + col] = mu;
+            A.raw_out[(size_t)gr * A.ldraw + Ad + col] = lsr;
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) lp += __shfl_xor(lp, m);
+      if (sub == 0 && gr < B && A.logp != nullptr) A.logp[gr] = lp;
+    } else if (A.out != nullptr) {
+      const int ncol = (A.out_act == ACT_GAUSS_MEAN) ? A.action_dim : Nout;
+      for (int idx = tid; idx < kR * ncol; idx += kThreads) {
+        const int row = idx / ncol, col = idx - row * ncol, gr = row0 + row;
+        if (gr >= B) continue;
+        float v = outS[row * kOutLd + col];
+        if (A.out_act == ACT_TANH || A.out_act == ACT_GAUSS_MEAN) {
+          v = tanhf(v);
+        } else if (A.out_act == ACT_TANH_SMOOTH) {
+          float n = noise_at(A, gr, col) * A.policy_noise;
+          n = fminf(fmaxf(n, -A.noise_clip), A.noise_clip);
+          v = fminf(fmaxf(tanhf(v) + n, -A.max_action), A.max_action);
+        }
+        A.out[(size_t)gr * A.ldo + col] = v;
+      }
+    }
+  } else if (A.do_bwd) {
+    _Pragma("unroll") for (int l = 1; l < kMaxLayers; ++l)
+      if (l < L) load_rows4(hb + (l - 1) * LY::hbuf, WL, A.Xg[l], WIDTH, WIDTH, row0, B);
+  }
+  if (!A.do_bwd) return;
+
+  // ---- loss-gradient seed -> auxS (zero padded) -----------------------------
+  lds_zero(auxS, kR * kOutLd);
+  __syncthreads();
+  const SeedArgs& S = A.seed;
+  float p_loss = 0.f, p_q = 0.f, p_y = 0.f;
+  switch (A.seed_mode) {
+    case SEED_PTR:
+      for (int idx = tid; idx < kR * Nout; idx += kThreads) {
+        const int row = idx / Nout, col = idx - row * Nout, gr = row0 + row;
+        if (gr < B) auxS[row * kOutLd + col] = S.p0[(size_t)gr * S.ld0 + col];
+      }
+      break;
+    case SEED_MSE_TD:
+      if (tid < kR) {
+        const int gr = row0 + tid;
+        if (gr < B) {
+          const float q = outS[tid * kOutLd];
+          float qn = S.p0[gr];
+          if (S.p1 != nullptr) qn = fminf(qn, S.p1[gr]);
+          if (S.p2 != nullptr) qn -= alpha_of(S) * S.p2[gr];
+          const float y = S.r[gr] + ((1.f - S.d[gr]) * S.gamma) * qn;
+          auxS[tid * kOutLd] = 2.f * (q - y) * S.cval;
+          if (S.y_out != nullptr) S.y_out[gr] = y;
+          if (S.q_out != nullptr) S.q_out[gr] = q;
+          p_loss = (q - y) * (q - y);
+          p_q = q;
+          p_y = y;
+        }
+      }
+      break;
+    case SEED_CONST:
+      for (int idx = tid; idx < kR * Nout; idx += kThreads) {
+        const int row = idx / Nout, col = idx - row * Nout;
+        if (row0 + row < B) auxS[row * kOutLd + col] = S.cval;
+      }
+      if (A.do_fwd && tid < kR && row0 + tid < B) p_q = outS[tid * kOutLd];  // diagnostic: mean q
+      break;
+    case SEED_MINQ:
+      if (tid < kR) {
+        const int gr = row0 + tid;
+        if (gr < B) {
+          const float q1 = S.p0[gr], q2 = S.p1[gr];
+          const float w1 = q1 < q2 ? 1.f : (q1 == q2 ? 0.5f : 0.f);
+          auxS[tid * kOutLd] = -(S.which == 0 ? w1 : 1.f - w1) * S.cval;
+          p_q = fminf(q1, q2);
+        }
+      }
+      break;
+    case SEED_TANH:
+      for (int idx = tid; idx < kR * Nout; idx += kThreads) {
+        const int row = idx / Nout, col = idx - row * Nout, gr = row0 + row;
+        if (gr < B) {
+          const float a = S.p1[(size_t)gr * Nout + col];
+          auxS[row * kOutLd + col] = S.p0[(size_t)gr * S.ld0 + col] * (1.f - a * a);
+        }
+      }
+      break;
+    case SEED_GAUSS: {
+      const int Ad = Nout >> 1;
+      const float alpha = alpha_of(S);
+      const float dlp = alpha * S.cval;
+      for (int idx = tid; idx < kR * Ad; idx += kThreads) {
+        const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
+        if (gr >= B) continue;
+        const float mu = S.p1[(size_t)gr * Nout + col];
+        const float lsr = S.p1[(size_t)gr * Nout + Ad + col];
+        const float ls = fminf(fmaxf(lsr, kLogStdMin), kLogStdMax);
+        const float sd = expf(ls);
+        const float e = noise_at(A, gr, col);   // same injected / Philox draw as the forward
+        const float a = tanhf(mu + sd * e);
+        float da = 0.f;
+        for (int n = 0; n < S.n_da; ++n) da += S.p0[n * S.da_stride + (size_t)gr * S.ld0 + col];
+        const float du = da * (1.f - a * a) + dlp * (2.f * a);
+        const bool in = (lsr >= kLogStdMin) && (lsr <= kLogStdMax);
+        auxS[row * kOutLd + col] = du;
+        auxS[row * kOutLd + Ad + col] = in ? (du * sd * e - dlp) : 0.f;
+      }
+    } break;
+    case SEED_QHUBER: {
+      const int Q = S.Q, M = S.M;
+      for (int idx = tid; idx < kR * Q; idx += kThreads) {
+        const int row = idx / Q, q = idx - row * Q, gr = row0 + row;
+        if (gr >= B) continue;
+        const float z = outS[row * kOutLd + q];
+        const float tau = ((float)q) / (float)Q + 0.5f / (float)Q;
+        const float* yrow = S.p0 + (size_t)gr * M;
+        float g = 0.f, ls = 0.f;
+        for (int s = 0; s < M; ++s) {
+          const float dl = yrow[s] - z;
+          const float ad = fabsf(dl);
+          const float w = fabsf(tau - (dl < 0.f ? 1.f : 0.f));
+          g += w * (ad > 1.f ? (dl > 0.f ? 1.f : -1.f) : dl);
+          ls += w * (ad > 1.f ? ad - 0.5f : dl * dl * 0.5f);
+        }
+        auxS[row * kOutLd + q] = -g * S.cval;
+        p_loss += ls;
+      }
+    } break;
+    default: break;
+  }
+  if (A.partials != nullptr) {  // per-slice diagnostics (block reduce through scr)
+    __syncthreads();
+    float v[3] = {p_loss, p_q, p_y};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) v[k] += __shfl_xor(v[k], m);
+      if ((tid & 63) == 0) scr[(tid >> 6) * 4 + k] = v[k];
+    }
+    __syncthreads();
+    if (tid < 3) A.partials[blockIdx.x * 4 + tid] = scr[tid] + scr[4 + tid] + scr[8 + tid] + scr[12 + tid];
+  }
+  __syncthreads();
+  {
+    float* dlast = pick(A.dYg, L - 1);
+    if (dlast != nullptr) store_rows(auxS, kOutLd, dlast, A.lddo, Nout, row0, B);
+  }
+  mlp_backward_slice<WIDTH>(A.net, auxS, hb, scr, A.dYg, row0, B, A.dact_col0, A.dact_cols, auxS);
+  if (A.dact_cols > 0 && A.dact != nullptr) store_rows(auxS, kOutLd, A.dact, A.lddact, A.dact_cols, row0, B);
+}
+
+template __global__ void k_mlp_slice<256>(const MlpArgs);
+template __global__ void k_mlp_slice<512>(const MlpArgs);
+
+// ---------------------------------------------------------------------------
+// dW[n,k] = sum_b dY[b,n] X[b,k]  on a 32x32 tile per workgroup; the 4 waves
+// split the minibatch; db = column sums of dY come for free from the A operand.
+// Epilogue (per element, torch.optim.Adam single-tensor semantics):
+//   m += (g-m)(1-b1);  v = b2 v + (1-b2) g g;  th -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps)
+//   th_t = (1-tau) th_t + tau th                       (Polyak, nn_functions.py:5-10)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void adam_polyak_elem(float g, float* th, float* m, float* v, float* tt,
+                                                 float* gout, const AdamScalars& ad,
+                                                 float step_size, float bc2_sqrt) {
+  g *= ad.grad_scale;
+  if (gout != nullptr) *gout = g;
+  if (!ad.do_adam) return;
+  float mm = *m, vv = *v, t = *th;
+  mm = mm + (g - mm) * (1.f - ad.beta1);
+  vv = vv * ad.beta2 + (1.f - ad.beta2) * g * g;
+  const float denom = sqrtf(vv) / bc2_sqrt + ad.eps;
+  t = t - step_size * (mm / denom);
+  *m = mm;
+  *v = vv;
+  *th = t;
+  if (ad.do_polyak && tt != nullptr) *tt = *tt * (1.f - ad.tau) + ad.tau * t;
+}
+
+__device__ __forceinline__ void adam_bias_corr(const AdamScalars& ad, float* step_size, float* bc2_sqrt) {
+  const int step = ad.step_base + (ad.step_dev != nullptr ? *ad.step_dev : 0);
+  const double bc1 = 1.0 - pow((double)ad.beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)ad.beta2, (double)step);
+  *step_size = (float)((double)ad.lr / bc1);
+  *bc2_sqrt = (float)sqrt(bc2);
+}
+
+__global__ __launch_bounds__(kThreads) void k_dw_adam(const DwArgs A) {
+  constexpr int T = kDwTile, LD = T + 4;
+  __shared__ __attribute__((aligned(16))) float part[kWaves][T][LD];
+  __shared__ float bpart[kWaves][T];
+  __shared__ float sc[2];
+  const int tile = blockIdx.x;
+  int it = 0;
+  while (it + 1 < A.n_items && tile >= A.items[it].tile_end) ++it;
+  const DwItem I = A.items[it];
+  const int lt = tile - I.tile_begin;
+  const int tn = lt / I.tiles_k, tk = lt - tn * I.tiles_k;
+  const int n_base = tn * T, k_base = tk * T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, c = lane >> 4;
+  if (tid == 0) adam_bias_corr(A.ad, &sc[0], &sc[1]);
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float sA[2] = {0.f, 0.f};
+  const int ncol = n_base + 2 * i, kcol = k_base + 2 * i;
+  const bool n_ok = ncol < I.ldy, k_ok = kcol < I.ldx;   // ld even -> pair in bounds
+  const bool n0v = ncol < I.N, n1v = ncol + 1 < I.N, k0v = kcol < I.K, k1v = kcol + 1 < I.K;
+  for (int b0 = 4 * wave; b0 < A.B; b0 += 4 * kWaves) {
+    const int b = b0 + c;
+    f32x2 a2 = f32x2{0.f, 0.f}, x2 = f32x2{0.f, 0.f};
+    if (b < A.B) {
+      if (n_ok) a2 = *reinterpret_cast<const f32x2*>(I.dY + (size_t)b * I.ldy + ncol);
+      if (k_ok) x2 = *reinterpret_cast<const f32x2*>(I.X + (size_t)b * I.ldx + kcol);
+    }
+    a2[0] = n0v ? a2[0] : 0.f;
+    a2[1] = n1v ? a2[1] : 0.f;
+    x2[0] = k0v ? x2[0] : 0.f;
+    x2[1] = k1v ? x2[1] : 0.f;
+    sA[0] += a2[0];
+    sA[1] += a2[1];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[t][u] = mfma4(a2[t], x2[u], acc[t][u]);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[wave][2 * (c * 4 + r) + t][2 * i + u] = acc[t][u][r];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float s = sA[t];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (c == 0) bpart[wave][2 * i + t] = s;
+  }
+  __syncthreads();
+  const float step_size = sc[0], bc2_sqrt = sc[1];
+  {
+    const int nl = tid >> 3, kl0 = (tid & 7) * 4;
+    const int n = n_base + nl;
+    if (n < I.N) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = k_base + kl0 + e;
+        if (k < I.K) {
+          const float g = part[0][nl][kl0 + e] + part[1][nl][kl0 + e] + part[2][nl][kl0 + e] +
+                          part[3][nl][kl0 + e];
+          const size_t o = (size_t)n * I.K + k;
+          adam_polyak_elem(g, I.w + o, I.w_m ? I.w_m + o : nullptr, I.w_v ? I.w_v + o : nullptr,
+                           I.w_t ? I.w_t + o : nullptr, I.w_g ? I.w_g + o : nullptr, A.ad,
+                           step_size, bc2_sqrt);
+        }
+      }
+    }
+  }
+  if (tk == 0 && tid < T) {
+    const int n = n_base + tid;
+    if (n < I.N) {
+      const float g = bpart[0][tid] + bpart[1][tid] + bpart[2][tid] + bpart[3][tid];
+      adam_polyak_elem(g, I.b + n, I.b_m ? I.b_m + n : nullptr, I.b_v ? I.b_v + n : nullptr,
+                       I.b_t ? I.b_t + n : nullptr, I.b_g ? I.b_g + n : nullptr, A.ad, step_size,
+                       bc2_sqrt);
+    }
+  }
+}
+
+// flat Adam over an arena (data-parallel apply after the all-reduce; alpha-free)
+__global__ void k_adam_flat(float* th, float* m, float* v, float* tt, const float* g, long n,
+                            const AdamScalars ad) {
+  __shared__ float sc[2];
+  if (threadIdx.x == 0) adam_bias_corr(ad, &sc[0], &sc[1]);
+  __syncthreads();
+  const float step_size = sc[0], bc2_sqrt = sc[1];
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+       idx += (long)gridDim.x * blockDim.x)
+    adam_polyak_elem(g[idx], th + idx, m + idx, v + idx, tt ? tt + idx : nullptr, nullptr, ad,
+                     step_size, bc2_sqrt);
+}
+
+__global__ void k_polyak_flat(float* tt, const float* th, long n, float tau) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+       idx += (long)gridDim.x * blockDim.x)
+    tt[idx] = tt[idx] * (1.f - tau) + tau * th[idx];
+}
+
+// log_alpha Adam step in float64 like the reference's 0-dim double tensor
+// (sac.py:65-70,132-141; tqc.py:105,163,175-177): grad = -(H_target + mean logp).
+// If grad_out != nullptr only the gradient is exported (data-parallel mode).
+__global__ void k_alpha_step(double* log_alpha, double* m, double* v, const float* logp, int B,
+                             float target_entropy, float lr, float beta1, float beta2, float eps,
+                             int step, double* grad_out, const double* grad_in, float grad_scale) {
+  __shared__ double red[kThreads];
+  double s = 0.0;
+  if (grad_in == nullptr)
+    for (int idx = threadIdx.x; idx < B; idx += blockDim.x) s += (double)logp[idx];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  double g;
+  if (grad_in != nullptr) {
+    g = *grad_in * (double)grad_scale;
+  } else {
+    // reference: mean of fp32 logp in fp32, then promoted
+    const float mean32 = (float)(red[0] / (double)B);
+    g = -((double)target_entropy + (double)mean32);
+  }
+  if (grad_out != nullptr) { *grad_out = g; return; }
+  const double b1 = beta1, b2 = beta2;
+  double mm = *m, vv = *v;
+  mm = mm + (g - mm) * (1.0 - b1);
+  vv = vv * b2 + (1.0 - b2) * g * g;
+  const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+  const double denom = sqrt(vv) / sqrt(bc2) + (double)eps;
+  *log_alpha = *log_alpha - ((double)lr / bc1) * (mm / denom);
+  *m = mm;
+  *v = vv;
+}
+
+// out[0..3] = sum over slices of partials[.][0..3]  (then scaled by the caller)
+__global__ void k_reduce_partials(const float* partials, int n_slices, float* out, int out_off,
+                                  float scale_loss, float scale_mean) {
+  if (threadIdx.x < 3) {
+    float s = 0.f;
+    for (int i = 0; i < n_slices; ++i) s += partials[i * 4 + threadIdx.x];
+    out[out_off + threadIdx.x] = s * (threadIdx.x == 0 ? scale_loss : scale_mean);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// TQC target (tqc.py:129-145): per row gather n_nets*Q quantiles of the target
+// critics, ascending bitonic sort in LDS (one wave per row, 128-slot network),
+// drop the top `drop`, target[b, s] = r + (1-d) gamma (z_sorted[s] - alpha logp').
+// z layout: [n_nets][B][ldz];  target: [B][M], M = n_nets*Q - drop.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_tqc_target(const float* z, long net_stride, int ldz,
+                                                         int n_nets, int Q, int drop,
+                                                         const float* r, const float* d,
+                                                         const float* logp, const double* log_alpha,
+                                                         float gamma, int B, float* target) {
+  __shared__ float buf[kWaves][128];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * kWaves + wave;
+  const int total = n_nets * Q, M = total - drop;
+  float* sb = buf[wave];
+  if (row < B) {
+    for (int e = lane; e < 128; e += 64) {
+      float v = __builtin_huge_valf();
+      if (e < total) {
+        const int n = e / Q, q = e - n * Q;
+        v = z[n * net_stride + (size_t)row * ldz + q];
+      }
+      sb[e] = v;
+    }
+  }
+  __syncthreads();
+  for (int k = 2; k <= 128; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (row < B) {
+        const int e = ((lane & ~(j - 1)) << 1) | (lane & (j - 1));  // lower index of the pair
+        const int p = e | j;
+        const bool up = (e & k) == 0;
+        const float a = sb[e], b = sb[p];
+        if ((a > b) == up) { sb[e] = b; sb[p] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  if (row < B) {
+    const float alpha = (float)exp(*log_alpha);
+    const float al = alpha * logp[row];
+    const float coef = (1.f - d[row]) * gamma;
+    const float rr = r[row];
+    for (int s = lane; s < M; s += 64) target[(size_t)row * M + s] = rr + coef * (sb[s] - al);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host-visible launchers
+// ---------------------------------------------------------------------------
+size_t mlp_slice_lds_bytes(int width, int n_layers) {
+  const int nh = n_layers - 1;
+  return sizeof(float) * (width == 256 ? SliceLds<256>::total(nh) : SliceLds<512>::total(nh));
+}
+
+hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st) {
+  const int grid = (a.B + kR - 1) / kR;
+  const size_t lds = mlp_slice_lds_bytes(width, a.net.n_layers);
+  if (width == 256) {
+    hipLaunchKernelGGL(k_mlp_slice<256>, dim3(grid), dim3(kThreads), lds, st, a);
+  } else {
+    hipLaunchKernelGGL(k_mlp_slice<512>, dim3(grid), dim3(kThreads), lds, st, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t init_kernel_attrs() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_slice<256>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_slice<512>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t launch_dw_adam(const DwArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_dw_adam, dim3(a.total_tiles), dim3(kThreads), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_adam_flat(float* th, float* m, float* v, float* tt, const float* g, long n,
+                            const AdamScalars& ad, hipStream_t st) {
+  const int grid = (int)((n + 4 * 256 - 1) / (4 * 256));
+  hipLaunchKernelGGL(k_adam_flat, dim3(grid < 1 ? 1 : grid), dim3(256), 0, st, th, m, v, tt, g, n, ad);
+  return hipGetLastError();
+}
+
+hipError_t launch_polyak_flat(float* tt, const float* th, long n, float tau, hipStream_t st) {
+  const int grid = (int)((n + 4 * 256 - 1) / (4 * 256));
+  hipLaunchKernelGGL(k_polyak_flat, dim3(grid < 1 ? 1 : grid), dim3(256), 0, st, tt, th, n, tau);
+  return hipGetLastError();
+}
+
+hipError_t launch_alpha_step(double* log_alpha, double* m, double* v, const float* logp, int B,
+                             float target_entropy, float lr, float beta1, float beta2, float eps,
+                             int step, double* grad_out, const double* grad_in, float grad_scale,
+                             hipStream_t st) {
+  hipLaunchKernelGGL(k_alpha_step, dim3(1), dim3(kThreads), 0, st, log_alpha, m, v, logp, B,
+                     target_entropy, lr, beta1, beta2, eps, step, grad_out, grad_in, grad_scale);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_partials(const float* partials, int n_slices, float* out, int out_off,
+                                  float scale_loss, float scale_mean, hipStream_t st) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, st, partials, n_slices, out, out_off,
+                     scale_loss, scale_mean);
+  return hipGetLastError();
+}
+
+hipError_t launch_tqc_target(const float* z, long net_stride, int ldz, int n_nets, int Q, int drop,
+                             const float* r, const float* d, const float* logp,
+                             const double* log_alpha, float gamma, int B, float* target,
+                             hipStream_t st) {
+  hipLaunchKernelGGL(k_tqc_target, dim3((B + kWaves - 1) / kWaves), dim3(kThreads), 0, st, z,
+                     net_stride, ldz, n_nets, Q, drop, r, d, logp, log_alpha, gamma, B, target);
+  return hipGetLastError();
+}
+
+}  // namespace oprl

@@ -1,0 +1,769 @@
+// learner.hip — host orchestration of update() for DDPG / TD3 / SAC / TQC and the
+// C-ABI of include/oprl_amd.h.  Each update() is a short fixed sequence of
+// k_mlp_slice / k_dw_adam launches on the caller's stream; no host sync inside.
+//
+// Order of operations follows the reference exactly (it matters: the actor
+// loss sees the post-Adam critic, Polyak sees both updated nets):
+//   DDPG  algos/ddpg.py:61-107      TD3  algos/td3.py:71-146
+//   SAC   algos/sac.py:75-155       TQC  algos/tqc.py:116-189
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/oprl_amd.h"
+#include "kernels.h"
+
+namespace oprl {
+
+static thread_local std::string g_err;
+void set_err(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+size_t mlp_slice_lds_bytes(int width, int n_layers);
+hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
+hipError_t init_kernel_attrs();
+hipError_t launch_dw_adam(const DwArgs& a, hipStream_t st);
+hipError_t launch_adam_flat(float* th, float* m, float* v, float* tt, const float* g, long n,
+                            const AdamScalars& ad, hipStream_t st);
+hipError_t launch_polyak_flat(float* tt, const float* th, long n, float tau, hipStream_t st);
+hipError_t launch_alpha_step(double* log_alpha, double* m, double* v, const float* logp, int B,
+                             float target_entropy, float lr, float beta1, float beta2, float eps,
+                             int step, double* grad_out, const double* grad_in, float grad_scale,
+                             hipStream_t st);
+hipError_t launch_reduce_partials(const float* partials, int n_slices, float* out, int out_off,
+                                  float scale_loss, float scale_mean, hipStream_t st);
+hipError_t launch_tqc_target(const float* z, long net_stride, int ldz, int n_nets, int Q, int drop,
+                             const float* r, const float* d, const float* logp,
+                             const double* log_alpha, float gamma, int B, float* target,
+                             hipStream_t st);
+int replay_dims(const oprl_replay* h, int* S, int* A);
+
+}  // namespace oprl
+
+using namespace oprl;
+
+#define HIPC(x)                                                                        \
+  do {                                                                                 \
+    hipError_t _e = (x);                                                               \
+    if (_e != hipSuccess) {                                                            \
+      set_err("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return OPRL_ERR_HIP;                                                             \
+    }                                                                                  \
+  } while (0)
+#define RC(x)                      \
+  do {                             \
+    int _rc = (x);                 \
+    if (_rc != OPRL_OK) return _rc; \
+  } while (0)
+
+namespace {
+
+long net_param_count(const oprl_net& n) {
+  long c = 0;
+  for (int l = 0; l < n.n_layers; ++l) c += (long)n.dims[l + 1] * n.dims[l] + n.dims[l + 1];
+  return c;
+}
+
+long w_off(const oprl_net& n, int l) {
+  long c = 0;
+  for (int j = 0; j < l; ++j) c += (long)n.dims[j + 1] * n.dims[j] + n.dims[j + 1];
+  return c;
+}
+long b_off(const oprl_net& n, int l) { return w_off(n, l) + (long)n.dims[l + 1] * n.dims[l]; }
+
+int check_net(const oprl_net& n, const char* name, int* width) {
+  if (n.n_layers < 2 || n.n_layers > OPRL_MAX_LAYERS) {
+    set_err("%s: n_layers=%d unsupported (2..%d)", name, n.n_layers, OPRL_MAX_LAYERS);
+    return OPRL_ERR_INVALID;
+  }
+  const int w = n.dims[1];
+  if (w != 256 && w != 512) { set_err("%s: hidden width %d unsupported (256 or 512)", name, w); return OPRL_ERR_INVALID; }
+  for (int l = 1; l < n.n_layers; ++l)
+    if (n.dims[l] != w) { set_err("%s: hidden widths must be equal", name); return OPRL_ERR_INVALID; }
+  if (n.dims[0] < 1 || n.dims[0] > 96) { set_err("%s: input dim %d unsupported (1..96)", name, n.dims[0]); return OPRL_ERR_INVALID; }
+  if (n.dims[n.n_layers] < 1 || n.dims[n.n_layers] > kNarrowMax) {
+    set_err("%s: output dim %d unsupported (1..%d)", name, n.dims[n.n_layers], kNarrowMax);
+    return OPRL_ERR_INVALID;
+  }
+  if (!n.theta) { set_err("%s: theta is null", name); return OPRL_ERR_INVALID; }
+  *width = w;
+  return OPRL_OK;
+}
+
+Net net_view(const oprl_net& n, bool target) {
+  Net v;
+  memset(&v, 0, sizeof v);
+  v.n_layers = n.n_layers;
+  for (int l = 0; l <= n.n_layers; ++l) v.dims[l] = n.dims[l];
+  const float* base = target ? n.theta_target : n.theta;
+  for (int l = 0; l < n.n_layers; ++l) {
+    v.W[l] = base + w_off(n, l);
+    v.b[l] = base + b_off(n, l);
+  }
+  return v;
+}
+
+// per-net activation / gradient exchange buffers (HBM, sized for max_batch rows)
+struct NetWs {
+  float* X[kMaxLayers] = {nullptr, nullptr, nullptr, nullptr};
+  float* dY[kMaxLayers] = {nullptr, nullptr, nullptr, nullptr};
+  int ldx0 = 0, lddo = 0, width = 0;
+};
+
+struct Pool {  // one hipMalloc, bump allocated
+  char* base = nullptr;
+  size_t cap = 0, used = 0;
+  template <class T>
+  T* take(size_t n) {
+    used = (used + 255) & ~(size_t)255;
+    T* p = reinterpret_cast<T*>(base + used);
+    used += n * sizeof(T);
+    return p;
+  }
+};
+
+}  // namespace
+
+struct oprl_learner {
+  oprl_learner_config cfg;
+  int S, A, Bmax, nc;
+  int w_actor = 0, w_critic = 0;
+  Pool pool;
+  NetWs ws_actor, ws_critic[OPRL_MAX_CRITICS];
+  DwItem* items_dev = nullptr;  // [critic items..., actor items...]
+  int n_items_critic = 0, n_items_actor = 0, tiles_critic = 0, tiles_actor = 0;
+  // batch-sized scratch
+  float *a2 = nullptr, *logp2 = nullptr, *qn = nullptr /*[nc][B][ldq]*/, *pi = nullptr,
+        *raw = nullptr, *logp = nullptr, *da = nullptr /*[nc][B][A]*/, *qpi = nullptr /*[nc][B]*/,
+        *target = nullptr, *ydbg = nullptr, *qdbg = nullptr;
+  int ldq = 0;
+  float *part_c = nullptr /*[nc][slices][4]*/, *part_a = nullptr, *scalars = nullptr;
+  double* alpha_grad = nullptr;
+  // step_n batch buffers
+  float *bs = nullptr, *ba = nullptr, *br = nullptr, *bd = nullptr, *bs2 = nullptr;
+  int64_t update_count = 0;
+  int opt_step_critic = 0, opt_step_actor = 0, opt_step_alpha = 0;
+  int last_B = 0;
+  bool actor_updated_last = false;
+};
+
+namespace {
+
+void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int* tiles) {
+  for (int l = 0; l < n.n_layers; ++l) {
+    DwItem it;
+    memset(&it, 0, sizeof it);
+    it.K = n.dims[l];
+    it.N = n.dims[l + 1];
+    it.X = ws.X[l];
+    it.ldx = (l == 0) ? ws.ldx0 : ws.width;
+    it.dY = ws.dY[l];
+    it.ldy = (l == n.n_layers - 1) ? ws.lddo : ws.width;
+    const long wo = w_off(n, l), bo = b_off(n, l);
+    it.w = n.theta + wo;                       it.b = n.theta + bo;
+    it.w_t = n.theta_target ? n.theta_target + wo : nullptr;
+    it.b_t = n.theta_target ? n.theta_target + bo : nullptr;
+    it.w_m = n.adam_m ? n.adam_m + wo : nullptr; it.b_m = n.adam_m ? n.adam_m + bo : nullptr;
+    it.w_v = n.adam_v ? n.adam_v + wo : nullptr; it.b_v = n.adam_v ? n.adam_v + bo : nullptr;
+    it.w_g = n.grad ? n.grad + wo : nullptr;     it.b_g = n.grad ? n.grad + bo : nullptr;
+    const int tn = (it.N + kDwTile - 1) / kDwTile;
+    it.tiles_k = (it.K + kDwTile - 1) / kDwTile;
+    it.tile_begin = *tiles;
+    *tiles += tn * it.tiles_k;
+    it.tile_end = *tiles;
+    v.push_back(it);
+  }
+}
+
+size_t net_ws_floats(const oprl_net& n, int B) {
+  size_t f = 0;
+  f += (size_t)B * round_up(n.dims[0], 4) + 64;
+  for (int l = 1; l < n.n_layers; ++l) f += (size_t)B * n.dims[1] + 64;
+  for (int l = 0; l < n.n_layers - 1; ++l) f += (size_t)B * n.dims[1] + 64;
+  f += (size_t)B * round_up(n.dims[n.n_layers], 4) + 64;
+  return f + 64 * 8;
+}
+
+void alloc_net_ws(Pool& p, const oprl_net& n, int B, NetWs* ws) {
+  ws->width = n.dims[1];
+  ws->ldx0 = round_up(n.dims[0], 4);
+  ws->lddo = round_up(n.dims[n.n_layers], 4);
+  ws->X[0] = p.take<float>((size_t)B * ws->ldx0);
+  for (int l = 1; l < n.n_layers; ++l) ws->X[l] = p.take<float>((size_t)B * ws->width);
+  for (int l = 0; l < n.n_layers - 1; ++l) ws->dY[l] = p.take<float>((size_t)B * ws->width);
+  ws->dY[n.n_layers - 1] = p.take<float>((size_t)B * ws->lddo);
+}
+
+AdamScalars adam_scalars(const oprl_learner* h, float lr, int step, bool polyak, float grad_scale) {
+  AdamScalars ad;
+  ad.lr = lr; ad.beta1 = h->cfg.hp.beta1; ad.beta2 = h->cfg.hp.beta2; ad.eps = h->cfg.hp.adam_eps;
+  ad.step_base = step; ad.step_dev = nullptr;
+  ad.tau = h->cfg.hp.tau; ad.do_polyak = polyak ? 1 : 0;
+  ad.do_adam = h->cfg.export_grads ? 0 : 1;
+  ad.grad_scale = grad_scale;
+  return ad;
+}
+
+MlpArgs base_args(const oprl_learner* h, const oprl_net& n, bool target, int B) {
+  MlpArgs a;
+  memset(&a, 0, sizeof a);
+  a.net = net_view(n, target);
+  a.B = B;
+  a.action_dim = h->A;
+  a.policy_noise = h->cfg.hp.policy_noise;
+  a.noise_clip = h->cfg.hp.noise_clip;
+  a.max_action = h->cfg.hp.max_action;
+  return a;
+}
+
+void with_store(MlpArgs& a, const NetWs& ws, bool x, bool dy) {
+  for (int l = 0; l < kMaxLayers; ++l) {
+    a.Xg[l] = x ? ws.X[l] : nullptr;
+    a.dYg[l] = dy ? ws.dY[l] : nullptr;
+  }
+  a.ldx0 = ws.ldx0;
+  a.lddo = ws.lddo;
+}
+
+int launch(const MlpArgs& a, int width, hipStream_t st) {
+  HIPC(launch_mlp_slice(a, width, st));
+  return OPRL_OK;
+}
+
+const double* alpha_ptr(const oprl_learner* h) {
+  const bool learned = h->cfg.algo == OPRL_TQC || (h->cfg.algo == OPRL_SAC && h->cfg.hp.tune_alpha);
+  return learned ? h->cfg.log_alpha : nullptr;
+}
+
+void seed_rng(MlpArgs& a, const oprl_learner* h, const float* noise, uint64_t stream_id) {
+  a.noise = noise;
+  a.rng_seed = 0x0b5e55edULL + stream_id;
+  a.rng_ctr = (unsigned long long)h->update_count;
+}
+
+// ------------------------------------------------------------ critic phase
+int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r, const float* d,
+                 const float* s2, int B, const float* noise0, hipStream_t st) {
+  const oprl_learner_config& c = h->cfg;
+  const int S = h->S, A = h->A, nc = h->nc;
+  const int algo = c.algo;
+  const int n_slices = (B + kR - 1) / kR;
+  // 1. next action
+  {
+    const bool use_target_actor = (algo == OPRL_DDPG || algo == OPRL_TD3);
+    MlpArgs f = base_args(h, c.actor, use_target_actor, B);
+    f.do_fwd = 1;
+    f.x0 = s2; f.k0 = S;
+    f.out = h->a2; f.ldo = A;
+    if (algo == OPRL_DDPG) f.out_act = ACT_TANH;
+    else if (algo == OPRL_TD3) { f.out_act = ACT_TANH_SMOOTH; seed_rng(f, h, noise0, 1); }
+    else { f.out_act = ACT_GAUSS; f.logp = h->logp2; seed_rng(f, h, noise0, 1); }
+    RC(launch(f, h->w_actor, st));
+  }
+  // 2. target critics on (s', a')
+  for (int j = 0; j < nc; ++j) {
+    MlpArgs f = base_args(h, c.critics[j], true, B);
+    f.do_fwd = 1;
+    f.x0 = s2; f.k0 = S; f.x1 = h->a2; f.k1 = A;
+    f.out = h->qn + (size_t)j * h->Bmax * h->ldq; f.ldo = h->ldq;
+    RC(launch(f, h->w_critic, st));
+  }
+  if (algo == OPRL_TQC) {
+    const int Q = c.hp.n_quantiles, drop = c.hp.top_quantiles_to_drop;
+    HIPC(launch_tqc_target(h->qn, (long)h->Bmax * h->ldq, h->ldq, nc, Q, drop, r, d, h->logp2,
+                           c.log_alpha, c.hp.gamma, B, h->target, st));
+  }
+  // 3. online critics: forward + loss seed + backward
+  for (int j = 0; j < nc; ++j) {
+    MlpArgs f = base_args(h, c.critics[j], false, B);
+    f.do_fwd = 1; f.do_bwd = 1;
+    f.x0 = s; f.k0 = S; f.x1 = a; f.k1 = A;
+    with_store(f, h->ws_critic[j], true, true);
+    f.partials = h->part_c + (size_t)j * n_slices * 4;
+    SeedArgs& sd = f.seed;
+    if (algo == OPRL_TQC) {
+      const int Q = c.hp.n_quantiles, M = nc * Q - c.hp.top_quantiles_to_drop;
+      f.seed_mode = SEED_QHUBER;
+      sd.p0 = h->target; sd.M = M; sd.Q = Q;
+      sd.cval = 1.0f / ((float)B * (float)nc * (float)Q * (float)M);
+    } else {
+      f.seed_mode = SEED_MSE_TD;
+      sd.p0 = h->qn;
+      sd.p1 = nc > 1 ? h->qn + (size_t)h->Bmax * h->ldq : nullptr;
+      sd.p2 = (algo == OPRL_SAC) ? h->logp2 : nullptr;
+      sd.log_alpha = alpha_ptr(h); sd.alpha_const = c.hp.alpha_init;
+      sd.r = r; sd.d = d; sd.gamma = c.hp.gamma;
+      sd.cval = 1.0f / (float)B;
+      if (j == 0) { sd.y_out = h->ydbg; sd.q_out = h->qdbg; }
+    }
+    RC(launch(f, h->w_critic, st));
+  }
+  // 4. dW + Adam (+ Polyak where the reference does it every step)
+  {
+    const bool polyak = (algo == OPRL_TD3) ? (h->update_count % c.hp.policy_freq == 0) : true;
+    h->opt_step_critic += 1;
+    DwArgs dw;
+    dw.items = h->items_dev; dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
+    dw.B = B;
+    dw.ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, 1.0f);
+    HIPC(launch_dw_adam(dw, st));
+  }
+  return OPRL_OK;
+}
+
+// ------------------------------------------------------------- actor phase
+int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hipStream_t st) {
+  const oprl_learner_config& c = h->cfg;
+  const int S = h->S, A = h->A, nc = h->nc;
+  const int algo = c.algo;
+  const bool gauss = (algo == OPRL_SAC || algo == OPRL_TQC);
+  const int n_slices = (B + kR - 1) / kR;
+  // 5. actor forward (activations kept for its backward)
+  {
+    MlpArgs f = base_args(h, c.actor, false, B);
+    f.do_fwd = 1;
+    f.x0 = s; f.k0 = S;
+    with_store(f, h->ws_actor, true, false);
+    f.out = h->pi; f.ldo = A;
+    if (gauss) {
+      f.out_act = ACT_GAUSS; f.raw_out = h->raw; f.ldraw = 2 * A; f.logp = h->logp;
+      seed_rng(f, h, noise1, 2);
+    } else {
+      f.out_act = ACT_TANH;
+    }
+    RC(launch(f, h->w_actor, st));
+  }
+  // 6./7. critics on (s, pi): gradient wrt the action columns
+  const int n_q = (algo == OPRL_TD3 || algo == OPRL_DDPG) ? 1 : nc;   // TD3 uses Q1 only
+  if (algo == OPRL_SAC) {
+    for (int j = 0; j < nc; ++j) {   // both q's are needed before either seed (min)
+      MlpArgs f = base_args(h, c.critics[j], false, B);
+      f.do_fwd = 1;
+      f.x0 = s; f.k0 = S; f.x1 = h->pi; f.k1 = A;
+      with_store(f, h->ws_critic[j], true, false);
+      f.out = h->qpi + (size_t)j * h->Bmax; f.ldo = 1;
+      RC(launch(f, h->w_critic, st));
+    }
+    for (int j = 0; j < nc; ++j) {
+      MlpArgs f = base_args(h, c.critics[j], false, B);
+      f.do_bwd = 1;
+      with_store(f, h->ws_critic[j], true, false);
+      f.seed_mode = SEED_MINQ;
+      f.seed.p0 = h->qpi; f.seed.p1 = h->qpi + h->Bmax; f.seed.which = j;
+      f.seed.cval = 1.0f / (float)B;
+      f.dact_col0 = S; f.dact_cols = A; f.dact = h->da + (size_t)j * h->Bmax * A; f.lddact = A;
+      if (j == 0) f.partials = h->part_a;
+      RC(launch(f, h->w_critic, st));
+    }
+  } else {
+    for (int j = 0; j < n_q; ++j) {
+      MlpArgs f = base_args(h, c.critics[j], false, B);
+      f.do_fwd = 1; f.do_bwd = 1;
+      f.x0 = s; f.k0 = S; f.x1 = h->pi; f.k1 = A;
+      f.seed_mode = SEED_CONST;
+      f.seed.cval = (algo == OPRL_TQC) ? -1.0f / ((float)B * (float)nc * (float)c.hp.n_quantiles)
+                                       : -1.0f / (float)B;
+      f.dact_col0 = S; f.dact_cols = A; f.dact = h->da + (size_t)j * h->Bmax * A; f.lddact = A;
+      if (j == 0) f.partials = h->part_a;
+      RC(launch(f, h->w_critic, st));
+    }
+  }
+  // 8. actor backward from the stored activations
+  {
+    MlpArgs f = base_args(h, c.actor, false, B);
+    f.do_bwd = 1;
+    with_store(f, h->ws_actor, true, true);
+    SeedArgs& sd = f.seed;
+    if (gauss) {
+      f.seed_mode = SEED_GAUSS;
+      sd.p0 = h->da; sd.ld0 = A; sd.n_da = n_q; sd.da_stride = (long)h->Bmax * A;
+      sd.p1 = h->raw;
+      seed_rng(f, h, noise1, 2);   // backward re-reads (or re-draws) the forward's eps
+      sd.log_alpha = alpha_ptr(h); sd.alpha_const = c.hp.alpha_init;
+      sd.cval = 1.0f / (float)B;
+    } else {
+      f.seed_mode = SEED_TANH;
+      sd.p0 = h->da; sd.ld0 = A; sd.p1 = h->pi;
+    }
+    RC(launch(f, h->w_actor, st));
+  }
+  // 9. dW + Adam (+ Polyak of the actor target for DDPG / TD3)
+  {
+    h->opt_step_actor += 1;
+    DwArgs dw;
+    dw.items = h->items_dev + h->n_items_critic; dw.n_items = h->n_items_actor;
+    dw.total_tiles = h->tiles_actor; dw.B = B;
+    dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, c.actor.theta_target != nullptr, 1.0f);
+    HIPC(launch_dw_adam(dw, st));
+  }
+  // 10. temperature
+  if (alpha_ptr(h) != nullptr) {
+    h->opt_step_alpha += 1;
+    HIPC(launch_alpha_step(c.log_alpha, c.log_alpha_m, c.log_alpha_v, h->logp, B,
+                           c.hp.target_entropy, c.hp.lr_alpha, c.hp.beta1, c.hp.beta2,
+                           c.hp.adam_eps, h->opt_step_alpha,
+                           c.export_grads ? h->alpha_grad : nullptr, nullptr, 1.0f, st));
+  }
+  (void)n_slices;
+  return OPRL_OK;
+}
+
+bool actor_due(const oprl_learner* h) {
+  return h->cfg.algo != OPRL_TD3 || (h->update_count % h->cfg.hp.policy_freq == 0);
+}
+
+int check_batch(const oprl_learner* h, const void* s, const void* a, const void* r, const void* d,
+                const void* s2, int B) {
+  if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
+  if (!s || !a || !r || !d || !s2) { set_err("update: null batch pointer"); return OPRL_ERR_INVALID; }
+  if (B < 1 || B > h->Bmax) { set_err("update: batch %d outside [1, max_batch=%d]", B, h->Bmax); return OPRL_ERR_INVALID; }
+  return OPRL_OK;
+}
+
+}  // namespace
+
+// =========================================================================== C-ABI
+extern "C" const char* oprl_last_error(void) { return g_err.c_str(); }
+extern "C" int oprl_abi_version(void) { return OPRL_ABI_VERSION; }
+
+extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner** out) {
+  if (!cfg || !out) { set_err("oprl_learner_create: null argument"); return OPRL_ERR_INVALID; }
+  if (cfg->abi_version != OPRL_ABI_VERSION) { set_err("ABI version mismatch: caller %d, library %d", cfg->abi_version, OPRL_ABI_VERSION); return OPRL_ERR_INVALID; }
+  if (cfg->algo < OPRL_DDPG || cfg->algo > OPRL_TQC) { set_err("unknown algo %d", cfg->algo); return OPRL_ERR_INVALID; }
+  if (cfg->precision != OPRL_PREC_F32) { set_err("precision %d not built", cfg->precision); return OPRL_ERR_INVALID; }
+  const int nc_expect = cfg->algo == OPRL_DDPG ? 1 : (cfg->algo == OPRL_TQC ? cfg->n_critics : 2);
+  if (cfg->n_critics != nc_expect || cfg->n_critics < 1 || cfg->n_critics > OPRL_MAX_CRITICS) {
+    set_err("n_critics=%d invalid for algo %d", cfg->n_critics, cfg->algo);
+    return OPRL_ERR_INVALID;
+  }
+  if (cfg->max_batch < 1 || cfg->state_dim < 1 || cfg->action_dim < 1) { set_err("bad dims"); return OPRL_ERR_INVALID; }
+  auto* h = new oprl_learner();
+  h->cfg = *cfg;
+  h->S = cfg->state_dim; h->A = cfg->action_dim; h->Bmax = cfg->max_batch; h->nc = cfg->n_critics;
+  int rc = check_net(cfg->actor, "actor", &h->w_actor);
+  for (int j = 0; rc == OPRL_OK && j < h->nc; ++j) {
+    int w = 0;
+    rc = check_net(cfg->critics[j], "critic", &w);
+    if (rc == OPRL_OK && j > 0 && w != h->w_critic) { set_err("critics differ in width"); rc = OPRL_ERR_INVALID; }
+    h->w_critic = w;
+    if (rc == OPRL_OK && cfg->critics[j].dims[0] != h->S + h->A) { set_err("critic input dim != S+A"); rc = OPRL_ERR_INVALID; }
+    if (rc == OPRL_OK && (!cfg->critics[j].theta_target || !cfg->critics[j].adam_m || !cfg->critics[j].adam_v)) {
+      set_err("critic %d: theta_target/adam_m/adam_v required", j); rc = OPRL_ERR_INVALID;
+    }
+  }
+  const bool gauss = cfg->algo == OPRL_SAC || cfg->algo == OPRL_TQC;
+  if (rc == OPRL_OK && cfg->actor.dims[0] != h->S) { set_err("actor input dim != S"); rc = OPRL_ERR_INVALID; }
+  if (rc == OPRL_OK && cfg->actor.dims[cfg->actor.n_layers] != (gauss ? 2 : 1) * h->A) { set_err("actor output dim mismatch"); rc = OPRL_ERR_INVALID; }
+  if (rc == OPRL_OK && (!cfg->actor.adam_m || !cfg->actor.adam_v)) { set_err("actor adam state required"); rc = OPRL_ERR_INVALID; }
+  if (rc == OPRL_OK && !gauss && !cfg->actor.theta_target) { set_err("actor target required for DDPG/TD3"); rc = OPRL_ERR_INVALID; }
+  if (rc == OPRL_OK && cfg->algo == OPRL_TQC) {
+    const int Q = cfg->hp.n_quantiles;
+    if (Q < 1 || Q > kNarrowMax || h->nc * Q > 128 || cfg->hp.top_quantiles_to_drop < 0 ||
+        cfg->hp.top_quantiles_to_drop >= h->nc * Q || cfg->critics[0].dims[cfg->critics[0].n_layers] != Q) {
+      set_err("TQC quantile configuration unsupported"); rc = OPRL_ERR_INVALID;
+    }
+  }
+  const bool learned_alpha = cfg->algo == OPRL_TQC || (cfg->algo == OPRL_SAC && cfg->hp.tune_alpha);
+  if (rc == OPRL_OK && learned_alpha && (!cfg->log_alpha || !cfg->log_alpha_m || !cfg->log_alpha_v)) {
+    set_err("log_alpha and its Adam state are required"); rc = OPRL_ERR_INVALID;
+  }
+  if (rc == OPRL_OK && cfg->export_grads) {
+    if (!cfg->actor.grad) { set_err("export_grads needs grad arenas"); rc = OPRL_ERR_INVALID; }
+    for (int j = 0; j < h->nc; ++j) if (!cfg->critics[j].grad) { set_err("export_grads needs grad arenas"); rc = OPRL_ERR_INVALID; }
+  }
+  if (rc != OPRL_OK) { delete h; return rc; }
+
+  hipError_t e = init_kernel_attrs();
+  if (e != hipSuccess) { set_err("hipFuncSetAttribute: %s", hipGetErrorString(e)); delete h; return OPRL_ERR_HIP; }
+
+  const int B = h->Bmax, S = h->S, A = h->A, nc = h->nc;
+  h->ldq = round_up(cfg->critics[0].dims[cfg->critics[0].n_layers], 4);
+  const int n_slices = (B + kR - 1) / kR;
+  size_t floats = net_ws_floats(cfg->actor, B);
+  for (int j = 0; j < nc; ++j) floats += net_ws_floats(cfg->critics[j], B);
+  floats += (size_t)B * A + B + (size_t)nc * B * h->ldq + (size_t)B * A + (size_t)B * 2 * A + B +
+            (size_t)nc * B * A + (size_t)nc * B + (size_t)B * 128 + 2 * (size_t)B;
+  floats += (size_t)(nc + 1) * n_slices * 4 + 16;
+  floats += (size_t)B * (2 * S + A + 2);
+  floats += 64 * 32;
+  const size_t bytes = floats * sizeof(float) + 4096 + sizeof(DwItem) * (size_t)(nc + 1) * kMaxLayers;
+  if (hipMalloc(&h->pool.base, bytes) != hipSuccess) { set_err("hipMalloc(%zu) failed", bytes); delete h; return OPRL_ERR_NOMEM; }
+  h->pool.cap = bytes;
+  (void)hipMemset(h->pool.base, 0, bytes);
+  Pool& p = h->pool;
+  alloc_net_ws(p, cfg->actor, B, &h->ws_actor);
+  for (int j = 0; j < nc; ++j) alloc_net_ws(p, cfg->critics[j], B, &h->ws_critic[j]);
+  h->a2 = p.take<float>((size_t)B * A);
+  h->logp2 = p.take<float>(B);
+  h->qn = p.take<float>((size_t)nc * B * h->ldq);
+  h->pi = p.take<float>((size_t)B * A);
+  h->raw = p.take<float>((size_t)B * 2 * A);
+  h->logp = p.take<float>(B);
+  h->da = p.take<float>((size_t)nc * B * A);
+  h->qpi = p.take<float>((size_t)nc * B);
+  h->target = p.take<float>((size_t)B * 128);
+  h->ydbg = p.take<float>(B);
+  h->qdbg = p.take<float>(B);
+  h->part_c = p.take<float>((size_t)nc * n_slices * 4);
+  h->part_a = p.take<float>((size_t)n_slices * 4);
+  h->scalars = p.take<float>(16);
+  h->alpha_grad = p.take<double>(2);
+  h->bs = p.take<float>((size_t)B * S);
+  h->ba = p.take<float>((size_t)B * A);
+  h->br = p.take<float>(B);
+  h->bd = p.take<float>(B);
+  h->bs2 = p.take<float>((size_t)B * S);
+  std::vector<DwItem> items;
+  for (int j = 0; j < nc; ++j) fill_items(cfg->critics[j], h->ws_critic[j], items, &h->tiles_critic);
+  h->n_items_critic = (int)items.size();
+  fill_items(cfg->actor, h->ws_actor, items, &h->tiles_actor);
+  h->n_items_actor = (int)items.size() - h->n_items_critic;
+  h->items_dev = p.take<DwItem>(items.size());
+  if (p.used > p.cap) { set_err("internal: workspace pool overflow (%zu > %zu)", p.used, p.cap); (void)hipFree(p.base); delete h; return OPRL_ERR_NOMEM; }
+  if (hipMemcpy(h->items_dev, items.data(), sizeof(DwItem) * items.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    set_err("hipMemcpy(items) failed"); (void)hipFree(p.base); delete h; return OPRL_ERR_HIP;
+  }
+  *out = h;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_learner_destroy(oprl_learner* h) {
+  if (!h) return OPRL_OK;
+  (void)hipDeviceSynchronize();
+  (void)hipFree(h->pool.base);
+  delete h;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_learner_update_phase(oprl_learner* h, int32_t phase, const float* s,
+                                         const float* a, const float* r, const float* d,
+                                         const float* s2, int32_t B, const float* noise0,
+                                         const float* noise1, void* stream) {
+  RC(check_batch(h, s, a, r, d, s2, B));
+  hipStream_t st = (hipStream_t)stream;
+  h->last_B = B;
+  if (phase == 0) return critic_phase(h, s, a, r, d, s2, B, noise0, st);
+  if (phase == 1) {
+    h->actor_updated_last = actor_due(h);
+    int rc = OPRL_OK;
+    if (h->actor_updated_last) rc = actor_phase(h, s, B, noise1, st);
+    if (rc == OPRL_OK) h->update_count += 1;
+    return rc;
+  }
+  set_err("phase must be 0 or 1");
+  return OPRL_ERR_INVALID;
+}
+
+extern "C" int oprl_learner_update(oprl_learner* h, const float* s, const float* a, const float* r,
+                                   const float* d, const float* s2, int32_t B, const float* noise0,
+                                   const float* noise1, void* stream) {
+  RC(oprl_learner_update_phase(h, 0, s, a, r, d, s2, B, noise0, noise1, stream));
+  return oprl_learner_update_phase(h, 1, s, a, r, d, s2, B, noise0, noise1, stream);
+}
+
+extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, float grad_scale, void* stream) {
+  if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
+  if (!h->cfg.export_grads) { set_err("oprl_learner_apply: learner was not created with export_grads"); return OPRL_ERR_STATE; }
+  hipStream_t st = (hipStream_t)stream;
+  const oprl_learner_config& c = h->cfg;
+  if (phase == 0) {
+    // update_count was not advanced yet for this update (phase 1 does that)
+    const bool polyak = (c.algo == OPRL_TD3) ? (h->update_count % c.hp.policy_freq == 0) : true;
+    for (int j = 0; j < h->nc; ++j) {
+      const oprl_net& n = c.critics[j];
+      AdamScalars ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, grad_scale);
+      ad.do_adam = 1;
+      HIPC(launch_adam_flat(n.theta, n.adam_m, n.adam_v, n.theta_target, n.grad, net_param_count(n), ad, st));
+    }
+    return OPRL_OK;
+  }
+  if (phase == 1) {
+    if (!h->actor_updated_last) return OPRL_OK;
+    const oprl_net& n = c.actor;
+    AdamScalars ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, n.theta_target != nullptr, grad_scale);
+    ad.do_adam = 1;
+    HIPC(launch_adam_flat(n.theta, n.adam_m, n.adam_v, n.theta_target, n.grad, net_param_count(n), ad, st));
+    if (alpha_ptr(h) != nullptr)
+      HIPC(launch_alpha_step(c.log_alpha, c.log_alpha_m, c.log_alpha_v, nullptr, 1, c.hp.target_entropy,
+                             c.hp.lr_alpha, c.hp.beta1, c.hp.beta2, c.hp.adam_eps, h->opt_step_alpha,
+                             nullptr, h->alpha_grad, grad_scale, st));
+    return OPRL_OK;
+  }
+  set_err("phase must be 0 or 1");
+  return OPRL_ERR_INVALID;
+}
+
+extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t K, int32_t B,
+                                   uint64_t seed, void* stream) {
+  if (!h || !replay) { set_err("oprl_learner_step_n: null handle"); return OPRL_ERR_INVALID; }
+  if (h->cfg.export_grads) { set_err("step_n is the single-GPU fused path; export_grads learners use update_phase/apply"); return OPRL_ERR_STATE; }
+  int S = 0, A = 0;
+  replay_dims(replay, &S, &A);
+  if (S != h->S || A != h->A) { set_err("replay dims (%d,%d) != learner dims (%d,%d)", S, A, h->S, h->A); return OPRL_ERR_INVALID; }
+  if (K < 0 || B < 1 || B > h->Bmax) { set_err("step_n: bad K/B"); return OPRL_ERR_INVALID; }
+  for (int k = 0; k < K; ++k) {
+    RC(oprl_replay_sample(replay, B, nullptr, seed, (uint64_t)h->update_count, h->bs, h->ba, h->br,
+                          h->bd, h->bs2, nullptr, nullptr, stream));
+    RC(oprl_learner_update(h, h->bs, h->ba, h->br, h->bd, h->bs2, B, nullptr, nullptr, stream));
+  }
+  return OPRL_OK;
+}
+
+extern "C" int oprl_learner_read_scalars(oprl_learner* h, float* out_host, int32_t n, void* stream) {
+  if (!h || !out_host || n < 1) { set_err("oprl_learner_read_scalars: invalid argument"); return OPRL_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  const int B = h->last_B > 0 ? h->last_B : 1;
+  const int n_slices = (B + kR - 1) / kR;
+  const oprl_learner_config& c = h->cfg;
+  float loss_scale = 1.0f / (float)B;
+  if (c.algo == OPRL_TQC) {
+    const int Q = c.hp.n_quantiles, M = h->nc * Q - c.hp.top_quantiles_to_drop;
+    loss_scale = 1.0f / ((float)B * (float)h->nc * (float)Q * (float)M);
+  }
+  // critic partials of all critics are contiguous: loss sums over critics (td1 + td2)
+  HIPC(launch_reduce_partials(h->part_c, n_slices * h->nc, h->scalars, 0, loss_scale,
+                              1.0f / ((float)B * (float)h->nc), st));
+  HIPC(launch_reduce_partials(h->part_a, n_slices, h->scalars, 4, 0.f, -1.0f / (float)B, st));
+  float host[8] = {0};
+  HIPC(hipMemcpyAsync(host, h->scalars, sizeof(float) * 8, hipMemcpyDeviceToHost, st));
+  double la = 0.0;
+  const double* lap = alpha_ptr(h);
+  if (lap) HIPC(hipMemcpyAsync(&la, lap, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPC(hipStreamSynchronize(st));
+  float res[6];
+  res[0] = host[0];                 // critic loss
+  res[1] = host[5];                 // actor loss (-mean q part)
+  res[2] = host[1];                 // mean q
+  res[3] = host[2];                 // mean TD target
+  res[4] = lap ? (float)exp(la) : c.hp.alpha_init;
+  res[5] = (float)h->update_count;
+  for (int i = 0; i < n && i < 6; ++i) out_host[i] = res[i];
+  return OPRL_OK;
+}
+
+extern "C" int oprl_learner_update_count(oprl_learner* h, int64_t* out_host) {
+  if (!h || !out_host) { set_err("null argument"); return OPRL_ERR_INVALID; }
+  *out_host = h->update_count;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_learner_set_update_count(oprl_learner* h, int64_t count) {
+  if (!h || count < 0) { set_err("invalid argument"); return OPRL_ERR_INVALID; }
+  h->update_count = count;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_learner_debug_ptrs(oprl_learner* h, const float** q, const float** y) {
+  if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
+  if (q) *q = h->qdbg;
+  if (y) *y = h->ydbg;
+  return OPRL_OK;
+}
+
+// ---------------------------------------------------------------- building blocks
+namespace {
+struct TmpBuf {  // small per-thread device scratch for the stand-alone MLP calls
+  float* p = nullptr;
+  size_t cap = 0;
+  float* get(size_t floats) {
+    if (floats > cap) {
+      if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; cap = 0; }
+      if (hipMalloc(&p, floats * sizeof(float)) != hipSuccess) return nullptr;
+      cap = floats;
+    }
+    return p;
+  }
+};
+thread_local TmpBuf g_tmp;
+bool g_attrs_done = false;
+}  // namespace
+
+extern "C" int oprl_mlp_forward(const oprl_net* net, int32_t use_target, const float* x0, int32_t k0,
+                                const float* x1, int32_t k1, int32_t B, int32_t out_act, float* out,
+                                void* stream) {
+  if (!net || !x0 || !out || B < 1) { set_err("oprl_mlp_forward: invalid argument"); return OPRL_ERR_INVALID; }
+  int width = 0;
+  RC(check_net(*net, "net", &width));
+  if (use_target && !net->theta_target) { set_err("oprl_mlp_forward: no target arena"); return OPRL_ERR_INVALID; }
+  if (k0 + (x1 ? k1 : 0) != net->dims[0]) { set_err("oprl_mlp_forward: k0+k1=%d != input dim %d", k0 + (x1 ? k1 : 0), net->dims[0]); return OPRL_ERR_INVALID; }
+  if (out_act != ACT_NONE && out_act != ACT_TANH && out_act != ACT_GAUSS_MEAN) { set_err("oprl_mlp_forward: out_act %d unsupported here", out_act); return OPRL_ERR_INVALID; }
+  if (!g_attrs_done) { HIPC(init_kernel_attrs()); g_attrs_done = true; }
+  MlpArgs a;
+  memset(&a, 0, sizeof a);
+  a.net = net_view(*net, use_target != 0);
+  a.B = B; a.do_fwd = 1;
+  a.x0 = x0; a.k0 = k0; a.x1 = x1; a.k1 = x1 ? k1 : 0;
+  a.out_act = out_act;
+  const int nout = net->dims[net->n_layers];
+  a.action_dim = nout / 2;
+  a.out = out; a.ldo = (out_act == ACT_GAUSS_MEAN) ? nout / 2 : nout;
+  return launch(a, width, (hipStream_t)stream);
+}
+
+extern "C" int oprl_mlp_backward(const oprl_net* net, const float* x0, int32_t k0, const float* x1,
+                                 int32_t k1, int32_t B, const float* dout, float* dx, void* stream) {
+  if (!net || !x0 || !dout || B < 1 || !net->grad) { set_err("oprl_mlp_backward: invalid argument (grad arena required)"); return OPRL_ERR_INVALID; }
+  int width = 0;
+  RC(check_net(*net, "net", &width));
+  if (k0 + (x1 ? k1 : 0) != net->dims[0]) { set_err("oprl_mlp_backward: input dims mismatch"); return OPRL_ERR_INVALID; }
+  if (!g_attrs_done) { HIPC(init_kernel_attrs()); g_attrs_done = true; }
+  hipStream_t st = (hipStream_t)stream;
+  NetWs ws;
+  float* base = g_tmp.get(net_ws_floats(*net, B) + sizeof(DwItem) * kMaxLayers / sizeof(float) + 2048);
+  if (!base) { set_err("oprl_mlp_backward: scratch allocation failed"); return OPRL_ERR_NOMEM; }
+  Pool p; p.base = (char*)base; p.cap = (size_t)-1;
+  alloc_net_ws(p, *net, B, &ws);
+  std::vector<DwItem> items;
+  int tiles = 0;
+  fill_items(*net, ws, items, &tiles);
+  DwItem* items_dev = p.take<DwItem>(items.size());
+  HIPC(hipMemcpyAsync(items_dev, items.data(), sizeof(DwItem) * items.size(), hipMemcpyHostToDevice, st));
+  HIPC(hipStreamSynchronize(st));  // items is a stack vector
+  MlpArgs a;
+  memset(&a, 0, sizeof a);
+  a.net = net_view(*net, false);
+  a.B = B; a.do_fwd = 1; a.do_bwd = 1;
+  a.x0 = x0; a.k0 = k0; a.x1 = x1; a.k1 = x1 ? k1 : 0;
+  with_store(a, ws, true, true);
+  a.seed_mode = SEED_PTR;
+  const int nout = net->dims[net->n_layers];
+  a.seed.p0 = dout; a.seed.ld0 = nout;
+  if (dx) { a.dact_col0 = 0; a.dact_cols = net->dims[0]; a.dact = dx; a.lddact = net->dims[0]; }
+  if (dx && net->dims[0] > kNarrowMax) { set_err("oprl_mlp_backward: dx supported for input dim <= %d", kNarrowMax); return OPRL_ERR_INVALID; }
+  RC(launch(a, width, st));
+  DwArgs dw;
+  dw.items = items_dev; dw.n_items = (int)items.size(); dw.total_tiles = tiles; dw.B = B;
+  memset(&dw.ad, 0, sizeof dw.ad);
+  dw.ad.beta1 = 0.9f; dw.ad.beta2 = 0.999f; dw.ad.step_base = 1; dw.ad.grad_scale = 1.0f; dw.ad.do_adam = 0;
+  HIPC(launch_dw_adam(dw, st));
+  return OPRL_OK;
+}
+
+extern "C" int oprl_adam_step(float* theta, float* m, float* v, const float* grad, int64_t n,
+                              int32_t step, float lr, float beta1, float beta2, float eps,
+                              float grad_scale, void* stream) {
+  if (!theta || !m || !v || !grad || n < 1 || step < 1) { set_err("oprl_adam_step: invalid argument"); return OPRL_ERR_INVALID; }
+  AdamScalars ad;
+  memset(&ad, 0, sizeof ad);
+  ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps; ad.step_base = step;
+  ad.do_adam = 1; ad.grad_scale = grad_scale;
+  HIPC(launch_adam_flat(theta, m, v, nullptr, grad, (long)n, ad, (hipStream_t)stream));
+  return OPRL_OK;
+}
+
+extern "C" int oprl_polyak(float* target, const float* source, int64_t n, float tau, void* stream) {
+  if (!target || !source || n < 1) { set_err("oprl_polyak: invalid argument"); return OPRL_ERR_INVALID; }
+  HIPC(launch_polyak_flat(target, source, (long)n, tau, (hipStream_t)stream));
+  return OPRL_OK;
+}

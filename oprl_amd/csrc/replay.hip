@@ -1,0 +1,291 @@
+// replay.hip — HBM-resident episodic replay: batched transition writes and the
+// uniform sampler as a gather kernel.
+//
+// Reference: buffers/episodic_buffer.py
+//   storage layout              :29-55   (states[E,L+1,S] actions[E,L,A] rewards/dones[E,L,1])
+//   add_transition data movement:81-96
+//   flat index -> (episode,step):114-121 (first episode whose cumulative end > index)
+//   sample                      :123-133 (5 advanced-index gathers)
+//
+// Because states is [E, L+1, S], state (e,t) and next_state (e,t+1) are ADJACENT
+// rows: one sample reads a single contiguous 2·S-float run, plus A + 1 + 1 floats.
+// A workgroup stages 32 samples' rows in LDS and writes the five output arrays
+// fully coalesced.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/oprl_amd.h"
+#include "philox.h"
+
+namespace oprl {
+void set_err(const char* fmt, ...);
+}
+using oprl::set_err;
+
+#define HIPC(x)                                                              \
+  do {                                                                       \
+    hipError_t _e = (x);                                                     \
+    if (_e != hipSuccess) {                                                  \
+      set_err("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return OPRL_ERR_HIP;                                                   \
+    }                                                                        \
+  } while (0)
+
+namespace {
+
+constexpr int kGatherThreads = 256;
+constexpr int kSamplesPerWg = 32;
+constexpr int kStageRows = 4096;  // transitions staged on the host between flushes
+
+struct GatherArgs {
+  const float *states, *actions, *rewards, *dones;
+  const int* ends;  // cumulative episode ends, [n_eps]
+  int n_eps, L, S, A, B;
+  long n_transitions;
+  const long long* idx;  // or null
+  unsigned long long seed, counter;
+  float *out_s, *out_a, *out_r, *out_d, *out_s2;
+  int *out_ep, *out_step;
+};
+
+__global__ __launch_bounds__(kGatherThreads) void k_replay_gather(const GatherArgs G) {
+  extern __shared__ float stage[];  // [kSamplesPerWg][2S + A + 2]
+  __shared__ int s_ep[kSamplesPerWg], s_t[kSamplesPerWg];
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * kSamplesPerWg;
+  const int S = G.S, A = G.A, W = 2 * S + A + 2;
+  if (tid < kSamplesPerWg) {
+    const int i = base + tid;
+    int e = 0, t = 0;
+    if (i < G.B) {
+      long ind;
+      if (G.idx != nullptr) {
+        ind = (long)G.idx[i];
+      } else {
+        const oprl::u32x4 r = oprl::philox4x32_10(
+            oprl::u32x4{(uint32_t)G.counter, (uint32_t)(G.counter >> 32), (uint32_t)i, 0x5a17u},
+            (uint32_t)G.seed, (uint32_t)(G.seed >> 32));
+        ind = (long)oprl::bounded_u32(r.x, (uint32_t)G.n_transitions);
+      }
+      // first episode with ends[e] > ind  (np.argmin over the >= mask; all-True -> 0)
+      int lo = 0, hi = G.n_eps;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((long)G.ends[mid] > ind) hi = mid; else lo = mid + 1;
+      }
+      e = lo < G.n_eps ? lo : 0;
+      const long start = e > 0 ? (long)G.ends[e - 1] : 0;
+      t = (int)(ind - start);
+      if (G.out_ep != nullptr) G.out_ep[i] = e;
+      if (G.out_step != nullptr) G.out_step[i] = t;
+    }
+    s_ep[tid] = e;
+    s_t[tid] = t;
+  }
+  __syncthreads();
+  const int n_here = min(kSamplesPerWg, G.B - base);
+  for (int idx = tid; idx < n_here * W; idx += kGatherThreads) {
+    const int smp = idx / W, c = idx - smp * W;
+    const long e = s_ep[smp], t = s_t[smp];
+    float v;
+    if (c < 2 * S) v = G.states[(e * (G.L + 1) + t) * S + c];            // s | s' contiguous
+    else if (c < 2 * S + A) v = G.actions[(e * G.L + t) * A + (c - 2 * S)];
+    else if (c == 2 * S + A) v = G.rewards[e * G.L + t];
+    else v = G.dones[e * G.L + t];
+    stage[idx] = v;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n_here * S; idx += kGatherThreads) {
+    const int smp = idx / S, c = idx - smp * S;
+    G.out_s[(size_t)(base + smp) * S + c] = stage[smp * W + c];
+    G.out_s2[(size_t)(base + smp) * S + c] = stage[smp * W + S + c];
+  }
+  for (int idx = tid; idx < n_here * A; idx += kGatherThreads) {
+    const int smp = idx / A, c = idx - smp * A;
+    G.out_a[(size_t)(base + smp) * A + c] = stage[smp * W + 2 * S + c];
+  }
+  if (tid < n_here) {
+    G.out_r[base + tid] = stage[tid * W + 2 * S + A];
+    G.out_d[base + tid] = stage[tid * W + 2 * S + A + 1];
+  }
+}
+
+// staged row: [ep, t] as two ints bit-cast into floats, then s[S], a[A], r, d
+__global__ void k_replay_scatter(const float* rows, int n, int rowlen, float* states,
+                                 float* actions, float* rewards, float* dones, int L, int S,
+                                 int A) {
+  for (int rix = blockIdx.x; rix < n; rix += gridDim.x) {
+    const float* row = rows + (size_t)rix * rowlen;
+    const long e = __float_as_int(row[0]), t = __float_as_int(row[1]);
+    for (int c = threadIdx.x; c < S + A + 2; c += blockDim.x) {
+      const float v = row[2 + c];
+      if (c < S) states[(e * (L + 1) + t) * S + c] = v;
+      else if (c < S + A) actions[(e * L + t) * A + (c - S)] = v;
+      else if (c == S + A) rewards[e * L + t] = v;
+      else dones[e * L + t] = v;
+    }
+  }
+}
+
+}  // namespace
+
+struct oprl_replay {
+  int E, L, S, A;
+  float *states, *actions, *rewards, *dones;
+  int* ends_dev = nullptr;
+  int n_eps = 0;
+  long n_transitions = 0;
+  // double-buffered pinned staging for add_transition rows and for ends uploads
+  int rowlen = 0;
+  float* stage_host[2] = {nullptr, nullptr};
+  float* stage_dev[2] = {nullptr, nullptr};
+  int* ends_host[2] = {nullptr, nullptr};
+  hipEvent_t stage_ev[2], ends_ev[2];
+  bool stage_busy[2] = {false, false}, ends_busy[2] = {false, false};
+  int cur = 0, ends_cur = 0, n_staged = 0;
+};
+
+extern "C" int oprl_replay_create(int32_t n_episodes, int32_t max_ep_len, int32_t state_dim,
+                                  int32_t action_dim, float* states, float* actions,
+                                  float* rewards, float* dones, oprl_replay** out) {
+  if (!out || n_episodes < 1 || max_ep_len < 1 || state_dim < 1 || action_dim < 1 || !states ||
+      !actions || !rewards || !dones) {
+    set_err("oprl_replay_create: invalid argument");
+    return OPRL_ERR_INVALID;
+  }
+  auto* h = new oprl_replay();
+  h->E = n_episodes; h->L = max_ep_len; h->S = state_dim; h->A = action_dim;
+  h->states = states; h->actions = actions; h->rewards = rewards; h->dones = dones;
+  h->rowlen = 2 + state_dim + action_dim + 2;
+  HIPC(hipMalloc(&h->ends_dev, sizeof(int) * n_episodes));
+  for (int i = 0; i < 2; ++i) {
+    HIPC(hipHostMalloc(&h->stage_host[i], sizeof(float) * h->rowlen * kStageRows));
+    HIPC(hipMalloc(&h->stage_dev[i], sizeof(float) * h->rowlen * kStageRows));
+    HIPC(hipHostMalloc(&h->ends_host[i], sizeof(int) * n_episodes));
+    HIPC(hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&h->ends_ev[i], hipEventDisableTiming));
+  }
+  *out = h;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_replay_destroy(oprl_replay* h) {
+  if (!h) return OPRL_OK;
+  (void)hipDeviceSynchronize();
+  (void)hipFree(h->ends_dev);
+  for (int i = 0; i < 2; ++i) {
+    (void)hipHostFree(h->stage_host[i]);
+    (void)hipFree(h->stage_dev[i]);
+    (void)hipHostFree(h->ends_host[i]);
+    (void)hipEventDestroy(h->stage_ev[i]);
+    (void)hipEventDestroy(h->ends_ev[i]);
+  }
+  delete h;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_replay_flush(oprl_replay* h, void* stream) {
+  if (!h) { set_err("null replay handle"); return OPRL_ERR_INVALID; }
+  if (h->n_staged == 0) return OPRL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int c = h->cur, n = h->n_staged;
+  HIPC(hipMemcpyAsync(h->stage_dev[c], h->stage_host[c], sizeof(float) * h->rowlen * n,
+                      hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_replay_scatter, dim3(n < 1024 ? n : 1024), dim3(64), 0, st,
+                     h->stage_dev[c], n, h->rowlen, h->states, h->actions, h->rewards, h->dones,
+                     h->L, h->S, h->A);
+  HIPC(hipGetLastError());
+  HIPC(hipEventRecord(h->stage_ev[c], st));
+  h->stage_busy[c] = true;
+  h->cur ^= 1;
+  h->n_staged = 0;
+  if (h->stage_busy[h->cur]) {  // the other buffer must have drained before we refill it
+    HIPC(hipEventSynchronize(h->stage_ev[h->cur]));
+    h->stage_busy[h->cur] = false;
+  }
+  return OPRL_OK;
+}
+
+extern "C" int oprl_replay_write(oprl_replay* h, int32_t ep, int32_t t, const float* state_host,
+                                 const float* action_host, float reward, float done) {
+  if (!h || !state_host || !action_host) { set_err("oprl_replay_write: null argument"); return OPRL_ERR_INVALID; }
+  if (ep < 0 || ep >= h->E || t < 0 || t >= h->L) {
+    set_err("oprl_replay_write: slot (%d,%d) outside [%d,%d)", ep, t, h->E, h->L);
+    return OPRL_ERR_INVALID;
+  }
+  if (h->n_staged == kStageRows) {
+    int rc = oprl_replay_flush(h, nullptr);
+    if (rc != OPRL_OK) return rc;
+  }
+  float* row = h->stage_host[h->cur] + (size_t)h->n_staged * h->rowlen;
+  memcpy(row, &ep, 4);
+  memcpy(row + 1, &t, 4);
+  memcpy(row + 2, state_host, sizeof(float) * h->S);
+  memcpy(row + 2 + h->S, action_host, sizeof(float) * h->A);
+  row[2 + h->S + h->A] = reward;
+  row[3 + h->S + h->A] = done;
+  ++h->n_staged;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_replay_set_lens(oprl_replay* h, const int32_t* ep_lens_host,
+                                    int32_t episodes_counter, void* stream) {
+  if (!h || !ep_lens_host || episodes_counter < 0 || episodes_counter > h->E) {
+    set_err("oprl_replay_set_lens: invalid argument");
+    return OPRL_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int c = h->ends_cur;
+  if (h->ends_busy[c]) { HIPC(hipEventSynchronize(h->ends_ev[c])); h->ends_busy[c] = false; }
+  long acc = 0;
+  for (int i = 0; i < episodes_counter; ++i) {
+    if (ep_lens_host[i] < 0 || ep_lens_host[i] > h->L) { set_err("ep_lens[%d]=%d out of range", i, ep_lens_host[i]); return OPRL_ERR_INVALID; }
+    acc += ep_lens_host[i];
+    h->ends_host[c][i] = (int)acc;
+  }
+  if (episodes_counter > 0)
+    HIPC(hipMemcpyAsync(h->ends_dev, h->ends_host[c], sizeof(int) * episodes_counter,
+                        hipMemcpyHostToDevice, st));
+  HIPC(hipEventRecord(h->ends_ev[c], st));
+  h->ends_busy[c] = true;
+  h->ends_cur ^= 1;
+  h->n_eps = episodes_counter;
+  h->n_transitions = acc;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_replay_sample(oprl_replay* h, int32_t B, const int64_t* idx, uint64_t seed,
+                                  uint64_t counter, float* out_s, float* out_a, float* out_r,
+                                  float* out_d, float* out_s2, int32_t* out_ep, int32_t* out_step,
+                                  void* stream) {
+  if (!h || B < 1 || !out_s || !out_a || !out_r || !out_d || !out_s2) {
+    set_err("oprl_replay_sample: invalid argument");
+    return OPRL_ERR_INVALID;
+  }
+  if (h->n_transitions <= 0 || h->n_eps <= 0) {
+    set_err("oprl_replay_sample: buffer is empty (np.random.randint(0, 0) raises in the reference)");
+    return OPRL_ERR_STATE;
+  }
+  int rc = oprl_replay_flush(h, stream);
+  if (rc != OPRL_OK) return rc;
+  GatherArgs G;
+  G.states = h->states; G.actions = h->actions; G.rewards = h->rewards; G.dones = h->dones;
+  G.ends = h->ends_dev; G.n_eps = h->n_eps; G.L = h->L; G.S = h->S; G.A = h->A; G.B = B;
+  G.n_transitions = h->n_transitions;
+  G.idx = (const long long*)idx; G.seed = seed; G.counter = counter;
+  G.out_s = out_s; G.out_a = out_a; G.out_r = out_r; G.out_d = out_d; G.out_s2 = out_s2;
+  G.out_ep = out_ep; G.out_step = out_step;
+  const int grid = (B + kSamplesPerWg - 1) / kSamplesPerWg;
+  const size_t lds = sizeof(float) * kSamplesPerWg * (2 * h->S + h->A + 2);
+  hipLaunchKernelGGL(k_replay_gather, dim3(grid), dim3(kGatherThreads), lds, (hipStream_t)stream, G);
+  HIPC(hipGetLastError());
+  return OPRL_OK;
+}
+
+// used by the learner's fused step_n
+namespace oprl {
+int replay_dims(const oprl_replay* h, int* S, int* A) { *S = h->S; *A = h->A; return 0; }
+}
