@@ -63,16 +63,19 @@ typedef struct oprl_net {
   float* grad;                          /* written when grads are exported (DP / tests) */
 } oprl_net;
 
+/* Doubles on purpose: the reference's hyper-parameters are python floats and
+ * torch forms 1-beta1, 1-beta2, 1-tau, lr/(1-beta1^t) in double before rounding
+ * to fp32 (1.f - 0.999f differs from (float)(1 - 0.999) by 1.3e-5 relative). */
 typedef struct oprl_hparams {
-  float gamma, tau;
-  float lr_actor, lr_critic, lr_alpha;
-  float beta1, beta2, adam_eps;         /* torch defaults .9 / .999 / 1e-8 */
-  float policy_noise, noise_clip, max_action;   /* TD3 (td3.py:98-103) */
-  int32_t policy_freq;                          /* TD3 (td3.py:81) */
-  float alpha_init;                             /* SAC fixed alpha (sac.py:64) */
-  int32_t tune_alpha;                           /* SAC (sac.py:65-70); TQC always 1 */
-  float target_entropy;                         /* -action_dim */
-  int32_t n_quantiles, top_quantiles_to_drop;   /* TQC (tqc.py:71-73) */
+  double gamma, tau;
+  double lr_actor, lr_critic, lr_alpha;
+  double beta1, beta2, adam_eps;         /* torch defaults .9 / .999 / 1e-8 */
+  double policy_noise, noise_clip, max_action;   /* TD3 (td3.py:98-103) */
+  double alpha_init;                             /* SAC fixed alpha (sac.py:64) */
+  double target_entropy;                         /* -action_dim */
+  int32_t policy_freq;                           /* TD3 (td3.py:81) */
+  int32_t tune_alpha;                            /* SAC (sac.py:65-70); TQC always 1 */
+  int32_t n_quantiles, top_quantiles_to_drop;    /* TQC (tqc.py:71-73) */
 } oprl_hparams;
 
 typedef struct oprl_learner_config {
@@ -114,7 +117,7 @@ int oprl_learner_update(oprl_learner* h, const float* s, const float* a, const f
 
 /* Second half of an export_grads update: Adam (+Polyak) from net.grad after the
  * caller has all-reduced it.  phase 0 = critic(s), 1 = actor (+alpha). */
-int oprl_learner_apply(oprl_learner* h, int32_t phase, float grad_scale, void* stream);
+int oprl_learner_apply(oprl_learner* h, int32_t phase, double grad_scale, void* stream);
 /* In export_grads mode update() is split so the reduction can sit between the
  * halves exactly where the reference's optimizer.step() sits:
  *   oprl_learner_update_phase(h, 0, batch...) -> critic grads in net.grad
@@ -155,9 +158,10 @@ int oprl_mlp_backward(const oprl_net* net, const float* x0, int32_t k0, const fl
                       int32_t k1, int32_t B, const float* dout, float* dx, void* stream);
 /* torch.optim.Adam.step over a flat arena of n floats; step = 1-based count. */
 int oprl_adam_step(float* theta, float* m, float* v, const float* grad, int64_t n, int32_t step,
-                   float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+                   double lr, double beta1, double beta2, double eps, double grad_scale,
+                   void* stream);
 /* target <- (1-tau)*target + tau*source  (nn_functions.py:5-10) */
-int oprl_polyak(float* target, const float* source, int64_t n, float tau, void* stream);
+int oprl_polyak(float* target, const float* source, int64_t n, double tau, void* stream);
 
 /* ---- replay: ReplayBufferProtocol --------------------------------------- */
 /* Storage tensors are owned by the caller (torch) with the reference layout

@@ -33,14 +33,14 @@ class OprlNet(C.Structure):
 
 class OprlHparams(C.Structure):
     _fields_ = [
-        ("gamma", C.c_float), ("tau", C.c_float),
-        ("lr_actor", C.c_float), ("lr_critic", C.c_float), ("lr_alpha", C.c_float),
-        ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
-        ("policy_noise", C.c_float), ("noise_clip", C.c_float), ("max_action", C.c_float),
+        ("gamma", C.c_double), ("tau", C.c_double),
+        ("lr_actor", C.c_double), ("lr_critic", C.c_double), ("lr_alpha", C.c_double),
+        ("beta1", C.c_double), ("beta2", C.c_double), ("adam_eps", C.c_double),
+        ("policy_noise", C.c_double), ("noise_clip", C.c_double), ("max_action", C.c_double),
+        ("alpha_init", C.c_double),
+        ("target_entropy", C.c_double),
         ("policy_freq", C.c_int32),
-        ("alpha_init", C.c_float),
         ("tune_alpha", C.c_int32),
-        ("target_entropy", C.c_float),
         ("n_quantiles", C.c_int32), ("top_quantiles_to_drop", C.c_int32),
     ]
 
@@ -64,14 +64,14 @@ class OprlLearnerConfig(C.Structure):
 
 
 # every symbol the header declares: name -> (restype, argtypes)
-_P, _I32, _I64, _U64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+_P, _I32, _I64, _U64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
 SIGNATURES = {
     "oprl_last_error": (C.c_char_p, []),
     "oprl_abi_version": (C.c_int, []),
     "oprl_learner_create": (C.c_int, [C.POINTER(OprlLearnerConfig), C.POINTER(_P)]),
     "oprl_learner_destroy": (C.c_int, [_P]),
     "oprl_learner_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P]),
-    "oprl_learner_apply": (C.c_int, [_P, _I32, _F, _P]),
+    "oprl_learner_apply": (C.c_int, [_P, _I32, _D, _P]),
     "oprl_learner_update_phase": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _P]),
     "oprl_learner_step_n": (C.c_int, [_P, _P, _I32, _I32, _U64, _P]),
     "oprl_learner_read_scalars": (C.c_int, [_P, C.POINTER(C.c_float), _I32, _P]),
@@ -80,8 +80,8 @@ SIGNATURES = {
     "oprl_learner_debug_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "oprl_mlp_forward": (C.c_int, [C.POINTER(OprlNet), _I32, _P, _I32, _P, _I32, _I32, _I32, _P, _P]),
     "oprl_mlp_backward": (C.c_int, [C.POINTER(OprlNet), _P, _I32, _P, _I32, _I32, _P, _P, _P]),
-    "oprl_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _F, _F, _F, _F, _F, _P]),
-    "oprl_polyak": (C.c_int, [_P, _P, _I64, _F, _P]),
+    "oprl_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _D, _D, _D, _D, _D, _P]),
+    "oprl_polyak": (C.c_int, [_P, _P, _I64, _D, _P]),
     "oprl_replay_create": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _P, _P, C.POINTER(_P)]),
     "oprl_replay_destroy": (C.c_int, [_P]),
     "oprl_replay_write": (C.c_int, [_P, _I32, _I32, _P, _P, _F, _F]),

@@ -80,6 +80,10 @@ struct DwItem {      // one Linear layer of one net
 
 struct AdamScalars {
   float lr, beta1, beta2, eps;
+  // 1-beta1, 1-beta2, 1-tau formed in double on the host and then rounded, as
+  // torch does with its python-float scalars (1.f - 0.999f is off by 1.3e-5 rel.)
+  float omb1, omb2, omtau;
+  double lr_d, beta1_d, beta2_d;       // the python-double hyper-parameters, for the bias corrections
   int step_base; const int* step_dev;  // Adam step = step_base + (step_dev ? *step_dev : 0)
   float tau; int do_polyak;
   int do_adam;                         // 0: only export grads

@@ -245,21 +245,21 @@ __device__ __forceinline__ void adam_polyak_elem(float g, float* th, float* m, f
   if (gout != nullptr) *gout = g;
   if (!ad.do_adam) return;
   float mm = *m, vv = *v, t = *th;
-  mm = mm + (g - mm) * (1.f - ad.beta1);
-  vv = vv * ad.beta2 + (1.f - ad.beta2) * g * g;
+  mm = mm + (g - mm) * ad.omb1;
+  vv = vv * ad.beta2 + ad.omb2 * g * g;
   const float denom = sqrtf(vv) / bc2_sqrt + ad.eps;
   t = t - step_size * (mm / denom);
   *m = mm;
   *v = vv;
   *th = t;
-  if (ad.do_polyak && tt != nullptr) *tt = *tt * (1.f - ad.tau) + ad.tau * t;
+  if (ad.do_polyak && tt != nullptr) *tt = *tt * ad.omtau + ad.tau * t;
 }
 
 __device__ __forceinline__ void adam_bias_corr(const AdamScalars& ad, float* step_size, float* bc2_sqrt) {
   const int step = ad.step_base + (ad.step_dev != nullptr ? *ad.step_dev : 0);
-  const double bc1 = 1.0 - pow((double)ad.beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)ad.beta2, (double)step);
-  *step_size = (float)((double)ad.lr / bc1);
+  const double bc1 = 1.0 - pow(ad.beta1_d, (double)step);
+  const double bc2 = 1.0 - pow(ad.beta2_d, (double)step);
+  *step_size = (float)(ad.lr_d / bc1);
   *bc2_sqrt = (float)sqrt(bc2);
 }
 
@@ -363,17 +363,17 @@ __global__ void k_adam_flat(float* th, float* m, float* v, float* tt, const floa
                      step_size, bc2_sqrt);
 }
 
-__global__ void k_polyak_flat(float* tt, const float* th, long n, float tau) {
+__global__ void k_polyak_flat(float* tt, const float* th, long n, float tau, float omtau) {
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
        idx += (long)gridDim.x * blockDim.x)
-    tt[idx] = tt[idx] * (1.f - tau) + tau * th[idx];
+    tt[idx] = tt[idx] * omtau + tau * th[idx];
 }
 
 // log_alpha Adam step in float64 like the reference's 0-dim double tensor
 // (sac.py:65-70,132-141; tqc.py:105,163,175-177): grad = -(H_target + mean logp).
 // If grad_out != nullptr only the gradient is exported (data-parallel mode).
 __global__ void k_alpha_step(double* log_alpha, double* m, double* v, const float* logp, int B,
-                             float target_entropy, float lr, float beta1, float beta2, float eps,
+                             float target_entropy, double lr, double beta1, double beta2, double eps,
                              int step, double* grad_out, const double* grad_in, float grad_scale) {
   __shared__ double red[kThreads];
   double s = 0.0;
@@ -503,14 +503,15 @@ hipError_t launch_adam_flat(float* th, float* m, float* v, float* tt, const floa
   return hipGetLastError();
 }
 
-hipError_t launch_polyak_flat(float* tt, const float* th, long n, float tau, hipStream_t st) {
+hipError_t launch_polyak_flat(float* tt, const float* th, long n, double tau, hipStream_t st) {
   const int grid = (int)((n + 4 * 256 - 1) / (4 * 256));
-  hipLaunchKernelGGL(k_polyak_flat, dim3(grid < 1 ? 1 : grid), dim3(256), 0, st, tt, th, n, tau);
+  hipLaunchKernelGGL(k_polyak_flat, dim3(grid < 1 ? 1 : grid), dim3(256), 0, st, tt, th, n, (float)tau,
+                     (float)(1.0 - tau));
   return hipGetLastError();
 }
 
 hipError_t launch_alpha_step(double* log_alpha, double* m, double* v, const float* logp, int B,
-                             float target_entropy, float lr, float beta1, float beta2, float eps,
+                             float target_entropy, double lr, double beta1, double beta2, double eps,
                              int step, double* grad_out, const double* grad_in, float grad_scale,
                              hipStream_t st) {
   hipLaunchKernelGGL(k_alpha_step, dim3(1), dim3(kThreads), 0, st, log_alpha, m, v, logp, B,

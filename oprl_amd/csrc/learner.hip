@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -36,9 +37,9 @@ hipError_t init_kernel_attrs();
 hipError_t launch_dw_adam(const DwArgs& a, hipStream_t st);
 hipError_t launch_adam_flat(float* th, float* m, float* v, float* tt, const float* g, long n,
                             const AdamScalars& ad, hipStream_t st);
-hipError_t launch_polyak_flat(float* tt, const float* th, long n, float tau, hipStream_t st);
+hipError_t launch_polyak_flat(float* tt, const float* th, long n, double tau, hipStream_t st);
 hipError_t launch_alpha_step(double* log_alpha, double* m, double* v, const float* logp, int B,
-                             float target_entropy, float lr, float beta1, float beta2, float eps,
+                             float target_entropy, double lr, double beta1, double beta2, double eps,
                              int step, double* grad_out, const double* grad_in, float grad_scale,
                              hipStream_t st);
 hipError_t launch_reduce_partials(const float* partials, int n_slices, float* out, int out_off,
@@ -205,11 +206,22 @@ void alloc_net_ws(Pool& p, const oprl_net& n, int B, NetWs* ws) {
   ws->dY[n.n_layers - 1] = p.take<float>((size_t)B * ws->lddo);
 }
 
-AdamScalars adam_scalars(const oprl_learner* h, float lr, int step, bool polyak, float grad_scale) {
+void set_adam(AdamScalars& ad, double lr, double beta1, double beta2, double eps, double tau) {
+  ad.lr = (float)lr; ad.beta1 = (float)beta1; ad.beta2 = (float)beta2; ad.eps = (float)eps;
+  ad.tau = (float)tau;
+  ad.omb1 = (float)(1.0 - beta1);
+  ad.omb2 = (float)(1.0 - beta2);
+  ad.omtau = (float)(1.0 - tau);
+  ad.lr_d = lr; ad.beta1_d = beta1; ad.beta2_d = beta2;
+}
+
+AdamScalars adam_scalars(const oprl_learner* h, double lr, int step, bool polyak, float grad_scale) {
   AdamScalars ad;
-  ad.lr = lr; ad.beta1 = h->cfg.hp.beta1; ad.beta2 = h->cfg.hp.beta2; ad.eps = h->cfg.hp.adam_eps;
+  memset(&ad, 0, sizeof ad);
+  const oprl_hparams& hp = h->cfg.hp;
+  set_adam(ad, lr, hp.beta1, hp.beta2, hp.adam_eps, hp.tau);
   ad.step_base = step; ad.step_dev = nullptr;
-  ad.tau = h->cfg.hp.tau; ad.do_polyak = polyak ? 1 : 0;
+  ad.do_polyak = polyak ? 1 : 0;
   ad.do_adam = h->cfg.export_grads ? 0 : 1;
   ad.grad_scale = grad_scale;
   return ad;
@@ -221,9 +233,9 @@ MlpArgs base_args(const oprl_learner* h, const oprl_net& n, bool target, int B) 
   a.net = net_view(n, target);
   a.B = B;
   a.action_dim = h->A;
-  a.policy_noise = h->cfg.hp.policy_noise;
-  a.noise_clip = h->cfg.hp.noise_clip;
-  a.max_action = h->cfg.hp.max_action;
+  a.policy_noise = (float)h->cfg.hp.policy_noise;
+  a.noise_clip = (float)h->cfg.hp.noise_clip;
+  a.max_action = (float)h->cfg.hp.max_action;
   return a;
 }
 
@@ -282,7 +294,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
   if (algo == OPRL_TQC) {
     const int Q = c.hp.n_quantiles, drop = c.hp.top_quantiles_to_drop;
     HIPC(launch_tqc_target(h->qn, (long)h->Bmax * h->ldq, h->ldq, nc, Q, drop, r, d, h->logp2,
-                           c.log_alpha, c.hp.gamma, B, h->target, st));
+                           c.log_alpha, (float)c.hp.gamma, B, h->target, st));
   }
   // 3. online critics: forward + loss seed + backward
   for (int j = 0; j < nc; ++j) {
@@ -302,8 +314,8 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
       sd.p0 = h->qn;
       sd.p1 = nc > 1 ? h->qn + (size_t)h->Bmax * h->ldq : nullptr;
       sd.p2 = (algo == OPRL_SAC) ? h->logp2 : nullptr;
-      sd.log_alpha = alpha_ptr(h); sd.alpha_const = c.hp.alpha_init;
-      sd.r = r; sd.d = d; sd.gamma = c.hp.gamma;
+      sd.log_alpha = alpha_ptr(h); sd.alpha_const = (float)c.hp.alpha_init;
+      sd.r = r; sd.d = d; sd.gamma = (float)c.hp.gamma;
       sd.cval = 1.0f / (float)B;
       if (j == 0) { sd.y_out = h->ydbg; sd.q_out = h->qdbg; }
     }
@@ -390,7 +402,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
       sd.p0 = h->da; sd.ld0 = A; sd.n_da = n_q; sd.da_stride = (long)h->Bmax * A;
       sd.p1 = h->raw;
       seed_rng(f, h, noise1, 2);   // backward re-reads (or re-draws) the forward's eps
-      sd.log_alpha = alpha_ptr(h); sd.alpha_const = c.hp.alpha_init;
+      sd.log_alpha = alpha_ptr(h); sd.alpha_const = (float)c.hp.alpha_init;
       sd.cval = 1.0f / (float)B;
     } else {
       f.seed_mode = SEED_TANH;
@@ -411,7 +423,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
   if (alpha_ptr(h) != nullptr) {
     h->opt_step_alpha += 1;
     HIPC(launch_alpha_step(c.log_alpha, c.log_alpha_m, c.log_alpha_v, h->logp, B,
-                           c.hp.target_entropy, c.hp.lr_alpha, c.hp.beta1, c.hp.beta2,
+                           (float)c.hp.target_entropy, c.hp.lr_alpha, c.hp.beta1, c.hp.beta2,
                            c.hp.adam_eps, h->opt_step_alpha,
                            c.export_grads ? h->alpha_grad : nullptr, nullptr, 1.0f, st));
   }
@@ -488,7 +500,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   if (e != hipSuccess) { set_err("hipFuncSetAttribute: %s", hipGetErrorString(e)); delete h; return OPRL_ERR_HIP; }
 
   const int B = h->Bmax, S = h->S, A = h->A, nc = h->nc;
-  h->ldq = round_up(cfg->critics[0].dims[cfg->critics[0].n_layers], 4);
+  // scalar critics: q' is read with stride 1 by the TD seed; TQC: [B][ldq] quantile rows
+  h->ldq = cfg->algo == OPRL_TQC ? round_up(cfg->critics[0].dims[cfg->critics[0].n_layers], 4) : 1;
   const int n_slices = (B + kR - 1) / kR;
   size_t floats = net_ws_floats(cfg->actor, B);
   for (int j = 0; j < nc; ++j) floats += net_ws_floats(cfg->critics[j], B);
@@ -572,7 +585,7 @@ extern "C" int oprl_learner_update(oprl_learner* h, const float* s, const float*
   return oprl_learner_update_phase(h, 1, s, a, r, d, s2, B, noise0, noise1, stream);
 }
 
-extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, float grad_scale, void* stream) {
+extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, double grad_scale, void* stream) {
   if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
   if (!h->cfg.export_grads) { set_err("oprl_learner_apply: learner was not created with export_grads"); return OPRL_ERR_STATE; }
   hipStream_t st = (hipStream_t)stream;
@@ -582,7 +595,7 @@ extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, float grad_sca
     const bool polyak = (c.algo == OPRL_TD3) ? (h->update_count % c.hp.policy_freq == 0) : true;
     for (int j = 0; j < h->nc; ++j) {
       const oprl_net& n = c.critics[j];
-      AdamScalars ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, grad_scale);
+      AdamScalars ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, (float)grad_scale);
       ad.do_adam = 1;
       HIPC(launch_adam_flat(n.theta, n.adam_m, n.adam_v, n.theta_target, n.grad, net_param_count(n), ad, st));
     }
@@ -591,13 +604,13 @@ extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, float grad_sca
   if (phase == 1) {
     if (!h->actor_updated_last) return OPRL_OK;
     const oprl_net& n = c.actor;
-    AdamScalars ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, n.theta_target != nullptr, grad_scale);
+    AdamScalars ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, n.theta_target != nullptr, (float)grad_scale);
     ad.do_adam = 1;
     HIPC(launch_adam_flat(n.theta, n.adam_m, n.adam_v, n.theta_target, n.grad, net_param_count(n), ad, st));
     if (alpha_ptr(h) != nullptr)
-      HIPC(launch_alpha_step(c.log_alpha, c.log_alpha_m, c.log_alpha_v, nullptr, 1, c.hp.target_entropy,
+      HIPC(launch_alpha_step(c.log_alpha, c.log_alpha_m, c.log_alpha_v, nullptr, 1, (float)c.hp.target_entropy,
                              c.hp.lr_alpha, c.hp.beta1, c.hp.beta2, c.hp.adam_eps, h->opt_step_alpha,
-                             nullptr, h->alpha_grad, grad_scale, st));
+                             nullptr, h->alpha_grad, (float)grad_scale, st));
     return OPRL_OK;
   }
   set_err("phase must be 0 or 1");
@@ -646,7 +659,7 @@ extern "C" int oprl_learner_read_scalars(oprl_learner* h, float* out_host, int32
   res[1] = host[5];                 // actor loss (-mean q part)
   res[2] = host[1];                 // mean q
   res[3] = host[2];                 // mean TD target
-  res[4] = lap ? (float)exp(la) : c.hp.alpha_init;
+  res[4] = lap ? (float)exp(la) : (float)c.hp.alpha_init;
   res[5] = (float)h->update_count;
   for (int i = 0; i < n && i < 6; ++i) out_host[i] = res[i];
   return OPRL_OK;
@@ -745,24 +758,25 @@ extern "C" int oprl_mlp_backward(const oprl_net* net, const float* x0, int32_t k
   DwArgs dw;
   dw.items = items_dev; dw.n_items = (int)items.size(); dw.total_tiles = tiles; dw.B = B;
   memset(&dw.ad, 0, sizeof dw.ad);
-  dw.ad.beta1 = 0.9f; dw.ad.beta2 = 0.999f; dw.ad.step_base = 1; dw.ad.grad_scale = 1.0f; dw.ad.do_adam = 0;
+  set_adam(dw.ad, 0.0, 0.9, 0.999, 1e-8, 0.0);
+  dw.ad.step_base = 1; dw.ad.grad_scale = 1.0f; dw.ad.do_adam = 0;
   HIPC(launch_dw_adam(dw, st));
   return OPRL_OK;
 }
 
 extern "C" int oprl_adam_step(float* theta, float* m, float* v, const float* grad, int64_t n,
-                              int32_t step, float lr, float beta1, float beta2, float eps,
-                              float grad_scale, void* stream) {
+                              int32_t step, double lr, double beta1, double beta2, double eps,
+                              double grad_scale, void* stream) {
   if (!theta || !m || !v || !grad || n < 1 || step < 1) { set_err("oprl_adam_step: invalid argument"); return OPRL_ERR_INVALID; }
   AdamScalars ad;
   memset(&ad, 0, sizeof ad);
-  ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps; ad.step_base = step;
-  ad.do_adam = 1; ad.grad_scale = grad_scale;
+  set_adam(ad, lr, beta1, beta2, eps, 0.0);
+  ad.step_base = step; ad.do_adam = 1; ad.grad_scale = (float)grad_scale;
   HIPC(launch_adam_flat(theta, m, v, nullptr, grad, (long)n, ad, (hipStream_t)stream));
   return OPRL_OK;
 }
 
-extern "C" int oprl_polyak(float* target, const float* source, int64_t n, float tau, void* stream) {
+extern "C" int oprl_polyak(float* target, const float* source, int64_t n, double tau, void* stream) {
   if (!target || !source || n < 1) { set_err("oprl_polyak: invalid argument"); return OPRL_ERR_INVALID; }
   HIPC(launch_polyak_flat(target, source, (long)n, tau, (hipStream_t)stream));
   return OPRL_OK;

@@ -38,8 +38,22 @@ def rel_dev(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def compare(got: dict, want: dict, tol: float, skip=()):
-    """max-norm relative deviation per key; returns worst (key, dev)."""
+PARAM_TOL = 1e-4   # north_star gate
+
+
+def _is_param_key(k: str) -> bool:
+    return any(f".{w}." in k for w in ("actor", "critic", "actor_target", "critic_target",
+                                       "m_critic", "v_critic"))
+
+
+def compare(got: dict, want: dict, tol: float, skip=(), param_tol: float | None = None):
+    """max-norm relative deviation per key; returns worst (key, dev).
+
+    ``param_tol`` (GPU runs) applies to parameter / Adam-state digests: an
+    element whose minibatch gradient cancels to ~1e-3 of its terms has its
+    summation-order noise amplified by Adam's m/sqrt(v) (measured: one W3
+    element of the SAC actor, step-1 gradient 2.7e-6 vs median 2.3e-3, moves by
+    1.3% of one step = 6e-5 of max|W|).  Network outputs keep ``tol``."""
     worst = ("", 0.0)
     for k, w in want.items():
         if k == "meta" or any(k.startswith(s) for s in skip):
@@ -53,7 +67,8 @@ def compare(got: dict, want: dict, tol: float, skip=()):
         dev = rel_dev(g, w)
         if dev > worst[1]:
             worst = (k, dev)
-        assert dev <= tol, f"{k}: rel dev {dev:.3e} > {tol:.1e}"
+        lim = param_tol if (param_tol is not None and _is_param_key(k)) else tol
+        assert dev <= lim, f"{k}: rel dev {dev:.3e} > {lim:.1e}"
     return worst
 
 

@@ -3,7 +3,9 @@ its Python API -> C-ABI) against (1) the golden vectors produced by running the
 reference and (2) the CPU oracle on the same scripted scenario.
 
 Gate: 1e-4 relative (north_star); fp32 MFMA vs torch-CPU differs only in
-summation order, measured deviations are ~1e-6, so the tests assert 2e-5."""
+summation order; measured output deviations (Q, pi, log pi) are ~1e-6 and are
+asserted at 2e-5; parameter digests are asserted at the 1e-4 gate (see
+scenarios.compare for why Adam amplifies summation noise on a few elements)."""
 import numpy as np
 import pytest
 import torch as t
@@ -17,8 +19,8 @@ TOL = 2e-5
 
 def _both(got, name, oracle_out, skip=()):
     gold = sc.load_golden(name)
-    w1 = sc.compare(got, gold, TOL, skip=skip)
-    w2 = sc.compare(got, {k: v for k, v in oracle_out.items()}, TOL, skip=skip)
+    w1 = sc.compare(got, gold, TOL, skip=skip, param_tol=sc.PARAM_TOL)
+    w2 = sc.compare(got, {k: v for k, v in oracle_out.items()}, TOL, skip=skip, param_tol=sc.PARAM_TOL)
     print(f"{name}: worst vs golden {w1}, vs oracle {w2}")
 
 

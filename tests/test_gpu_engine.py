@@ -111,14 +111,15 @@ def test_adam_and_polyak_match_oracle():
         _capi.check(lib.oprl_adam_step(_capi.ptr(thg), _capi.ptr(mg), _capi.ptr(vg), _capi.ptr(grg), n,
                                        step, 3e-4, 0.9, 0.999, 1e-8, 1.0, _capi.current_stream()))
     t.cuda.synchronize()
-    assert (thg.cpu() - ref[0]).abs().max().item() < 1e-7
+    # 1 ulp of fp32 at |theta| ~ 4 is 4.8e-7: fma contraction may differ from ATen by an ulp
+    assert (thg.cpu() - ref[0]).abs().max().item() < 5e-7
     assert rel_dev(mg.cpu().numpy(), opt.m[0].numpy()) < 1e-6
     assert rel_dev(vg.cpu().numpy(), opt.v[0].numpy()) < 1e-6
     tg = tgt.cuda()
     _capi.check(lib.oprl_polyak(_capi.ptr(tg), _capi.ptr(thg), n, 5e-3, _capi.current_stream()))
     want = [tgt.clone()]
     orc.polyak(want, [thg.cpu()], 5e-3)
-    assert (tg.cpu() - want[0]).abs().max().item() < 1e-7
+    assert (tg.cpu() - want[0]).abs().max().item() < 5e-7
 
 
 def test_errors_are_loud():
