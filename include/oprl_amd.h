@@ -93,6 +93,7 @@ typedef struct oprl_learner_config {
   double* log_alpha;        /* device scalar (float64 like the reference), or NULL */
   double* log_alpha_m;      /* its Adam state (device), or NULL */
   double* log_alpha_v;
+  double* log_alpha_grad;   /* export_grads: d(alpha loss)/d(log_alpha) lands here */
   oprl_hparams hp;
 } oprl_learner_config;
 
@@ -162,6 +163,16 @@ int oprl_adam_step(float* theta, float* m, float* v, const float* grad, int64_t 
                    void* stream);
 /* target <- (1-tau)*target + tau*source  (nn_functions.py:5-10) */
 int oprl_polyak(float* target, const float* source, int64_t n, double tau, void* stream);
+
+/* ---- measurement --------------------------------------------------------- */
+/* When enabled, every kernel launch of this library is bracketed by a pair of
+ * hipEvents recorded on the launch stream.  oprl_profile_read synchronises the
+ * device and returns, per kernel kind, the launch count and the summed
+ * hipEventElapsedTime (ms).  Kinds: 0 k_mlp_slice, 1 k_dw_adam, 2 k_replay_gather,
+ * 3 everything else.  bench.py's roofline uses this. */
+#define OPRL_PROFILE_KINDS 4
+int oprl_profile_enable(int32_t on);
+int oprl_profile_read(int64_t* counts_host, double* ms_host, int32_t reset);
 
 /* ---- replay: ReplayBufferProtocol --------------------------------------- */
 /* Storage tensors are owned by the caller (torch) with the reference layout

@@ -53,18 +53,19 @@ class HipLearner:
                  critic_group: nn.Module, critic_mlps: Sequence[MLP],
                  critic_target_group: nn.Module, critic_target_mlps: Sequence[MLP],
                  hp: dict, max_batch: int, export_grads: bool = False,
-                 log_alpha: t.Tensor | None = None):
+                 log_alpha: t.Tensor | None = None, actor_target_group: nn.Module | None = None):
         self.lib = _capi.load()
         self.device = device
         self.S, self.A = state_dim, action_dim
         self.max_batch = int(max_batch)
         self.export_grads = bool(export_grads)
+        if actor_target_mlp is not None and actor_target_group is None:
+            actor_target_group = actor_target_mlp
         self._groups = [actor_group, critic_group, critic_target_group]
-        for g in self._groups:
-            if not is_flat(g):
+        self._actor_target_group = actor_target_group
+        for g in [*self._groups, actor_target_group]:
+            if g is not None and not is_flat(g):
                 flatten_module_(g)
-        if actor_target_mlp is not None and not is_flat(actor_target_mlp):
-            flatten_module_(actor_target_mlp)
         self.actor_arena = actor_group._oprl_arena
         self.critic_arena = critic_group._oprl_arena
         self.actor_m = t.zeros_like(self.actor_arena)
@@ -76,6 +77,8 @@ class HipLearner:
         self.log_alpha = log_alpha
         self.log_alpha_m = t.zeros((), dtype=t.float64, device=device) if log_alpha is not None else None
         self.log_alpha_v = t.zeros((), dtype=t.float64, device=device) if log_alpha is not None else None
+        self.log_alpha_grad = (t.zeros((), dtype=t.float64, device=device)
+                               if (log_alpha is not None and export_grads) else None)
 
         cfg = _capi.OprlLearnerConfig()
         cfg.abi_version = _capi.OPRL_ABI_VERSION
@@ -108,15 +111,26 @@ class HipLearner:
             cfg.log_alpha = log_alpha.data_ptr()
             cfg.log_alpha_m = self.log_alpha_m.data_ptr()
             cfg.log_alpha_v = self.log_alpha_v.data_ptr()
+            if self.log_alpha_grad is not None:
+                cfg.log_alpha_grad = self.log_alpha_grad.data_ptr()
         for k, v in hp.items():
             setattr(cfg.hp, k, v)
         self._cfg = cfg
+        self.algo_name = algo
+        self.policy_freq = int(hp.get("policy_freq", 1))
         self._mlps = (actor_mlp, actor_target_mlp, list(critic_mlps), list(critic_target_mlps))
         self._ptrs = self._snapshot_ptrs()
         h = C.c_void_p()
         with t.cuda.device(device):
             _capi.check(self.lib.oprl_learner_create(C.byref(cfg), C.byref(h)), "oprl_learner_create")
         self.handle = h
+
+    def target_arenas(self):
+        """Flat target-network arenas (critic targets, then the actor target if any)."""
+        out = [self._groups[2]._oprl_arena]
+        if self._actor_target_group is not None:
+            out.append(self._actor_target_group._oprl_arena)
+        return out
 
     def _snapshot_ptrs(self):
         a, at, cs, cts = self._mlps

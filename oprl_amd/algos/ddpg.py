@@ -65,6 +65,7 @@ class DDPG(OffPolicyAlgorithm):
         self.learner = HipLearner(
             "ddpg", self.state_dim, self.action_dim, dev,
             actor_group=self.actor, actor_mlp=self.actor.mlp, actor_target_mlp=self.actor_target.mlp,
+            actor_target_group=self.actor_target,
             critic_group=self.critic, critic_mlps=[self.critic.q1],
             critic_target_group=self.critic_target, critic_target_mlps=[self.critic_target.q1],
             hp=hp, max_batch=self.max_batch, export_grads=self.export_grads)

@@ -70,6 +70,7 @@ class TD3(OffPolicyAlgorithm):
         self.learner = HipLearner(
             "td3", self.state_dim, self.action_dim, dev,
             actor_group=self.actor, actor_mlp=self.actor.mlp, actor_target_mlp=self.actor_target.mlp,
+            actor_target_group=self.actor_target,
             critic_group=self.critic, critic_mlps=[self.critic.q1, self.critic.q2],
             critic_target_group=self.critic_target,
             critic_target_mlps=[self.critic_target.q1, self.critic_target.q2],

@@ -31,6 +31,49 @@ void set_err(const char* fmt, ...) {
   g_err = buf;
 }
 
+// ---- HIP-event profiler (off by default; zero cost when off) ----------------
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> ev;      // pairs
+  std::vector<int> kind;
+  long counts[OPRL_PROFILE_KINDS] = {0, 0, 0, 0};
+  double ms[OPRL_PROFILE_KINDS] = {0, 0, 0, 0};
+};
+static Prof g_prof;
+static const size_t kProfMaxPairs = 1 << 16;
+
+void prof_fold() {
+  if (g_prof.ev.empty()) return;
+  (void)hipDeviceSynchronize();
+  for (size_t i = 0; i + 1 < g_prof.ev.size(); i += 2) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]) == hipSuccess) {
+      g_prof.counts[g_prof.kind[i / 2]] += 1;
+      g_prof.ms[g_prof.kind[i / 2]] += t;
+    }
+    (void)hipEventDestroy(g_prof.ev[i]);
+    (void)hipEventDestroy(g_prof.ev[i + 1]);
+  }
+  g_prof.ev.clear();
+  g_prof.kind.clear();
+}
+
+void prof_begin(int kind, hipStream_t st) {
+  if (!g_prof.on) return;
+  if (g_prof.ev.size() >= 2 * kProfMaxPairs) prof_fold();
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+  g_prof.ev.push_back(a);
+  g_prof.ev.push_back(b);
+  g_prof.kind.push_back(kind);
+  (void)hipEventRecord(a, st);
+}
+
+void prof_end(hipStream_t st) {
+  if (!g_prof.on || g_prof.ev.empty()) return;
+  (void)hipEventRecord(g_prof.ev.back(), st);
+}
+
 size_t mlp_slice_lds_bytes(int width, int n_layers);
 hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
 hipError_t init_kernel_attrs();
@@ -249,8 +292,18 @@ void with_store(MlpArgs& a, const NetWs& ws, bool x, bool dy) {
 }
 
 int launch(const MlpArgs& a, int width, hipStream_t st) {
-  HIPC(launch_mlp_slice(a, width, st));
+  prof_begin(0, st);
+  hipError_t e = launch_mlp_slice(a, width, st);
+  prof_end(st);
+  HIPC(e);
   return OPRL_OK;
+}
+
+hipError_t launch_dw_prof(const DwArgs& a, hipStream_t st) {
+  prof_begin(1, st);
+  hipError_t e = launch_dw_adam(a, st);
+  prof_end(st);
+  return e;
 }
 
 const double* alpha_ptr(const oprl_learner* h) {
@@ -329,7 +382,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     dw.items = h->items_dev; dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
     dw.B = B;
     dw.ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, 1.0f);
-    HIPC(launch_dw_adam(dw, st));
+    HIPC(launch_dw_prof(dw, st));
   }
   return OPRL_OK;
 }
@@ -417,7 +470,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     dw.items = h->items_dev + h->n_items_critic; dw.n_items = h->n_items_actor;
     dw.total_tiles = h->tiles_actor; dw.B = B;
     dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, c.actor.theta_target != nullptr, 1.0f);
-    HIPC(launch_dw_adam(dw, st));
+    HIPC(launch_dw_prof(dw, st));
   }
   // 10. temperature
   if (alpha_ptr(h) != nullptr) {
@@ -447,6 +500,23 @@ int check_batch(const oprl_learner* h, const void* s, const void* a, const void*
 
 // =========================================================================== C-ABI
 extern "C" const char* oprl_last_error(void) { return g_err.c_str(); }
+
+extern "C" int oprl_profile_enable(int32_t on) {
+  if (!on) prof_fold();
+  g_prof.on = on != 0;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_profile_read(int64_t* counts_host, double* ms_host, int32_t reset) {
+  if (!counts_host || !ms_host) { set_err("oprl_profile_read: null argument"); return OPRL_ERR_INVALID; }
+  prof_fold();
+  for (int k = 0; k < OPRL_PROFILE_KINDS; ++k) {
+    counts_host[k] = g_prof.counts[k];
+    ms_host[k] = g_prof.ms[k];
+    if (reset) { g_prof.counts[k] = 0; g_prof.ms[k] = 0; }
+  }
+  return OPRL_OK;
+}
 extern "C" int oprl_abi_version(void) { return OPRL_ABI_VERSION; }
 
 extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner** out) {
@@ -490,6 +560,9 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   if (rc == OPRL_OK && learned_alpha && (!cfg->log_alpha || !cfg->log_alpha_m || !cfg->log_alpha_v)) {
     set_err("log_alpha and its Adam state are required"); rc = OPRL_ERR_INVALID;
   }
+  if (rc == OPRL_OK && cfg->export_grads && learned_alpha && !cfg->log_alpha_grad) {
+    set_err("export_grads with a learned temperature needs log_alpha_grad"); rc = OPRL_ERR_INVALID;
+  }
   if (rc == OPRL_OK && cfg->export_grads) {
     if (!cfg->actor.grad) { set_err("export_grads needs grad arenas"); rc = OPRL_ERR_INVALID; }
     for (int j = 0; j < h->nc; ++j) if (!cfg->critics[j].grad) { set_err("export_grads needs grad arenas"); rc = OPRL_ERR_INVALID; }
@@ -531,7 +604,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   h->part_c = p.take<float>((size_t)nc * n_slices * 4);
   h->part_a = p.take<float>((size_t)n_slices * 4);
   h->scalars = p.take<float>(16);
-  h->alpha_grad = p.take<double>(2);
+  h->alpha_grad = cfg->log_alpha_grad ? cfg->log_alpha_grad : p.take<double>(2);
   h->bs = p.take<float>((size_t)B * S);
   h->ba = p.take<float>((size_t)B * A);
   h->br = p.take<float>(B);
@@ -760,7 +833,7 @@ extern "C" int oprl_mlp_backward(const oprl_net* net, const float* x0, int32_t k
   memset(&dw.ad, 0, sizeof dw.ad);
   set_adam(dw.ad, 0.0, 0.9, 0.999, 1e-8, 0.0);
   dw.ad.step_base = 1; dw.ad.grad_scale = 1.0f; dw.ad.do_adam = 0;
-  HIPC(launch_dw_adam(dw, st));
+  HIPC(launch_dw_prof(dw, st));
   return OPRL_OK;
 }
 

@@ -22,6 +22,8 @@
 
 namespace oprl {
 void set_err(const char* fmt, ...);
+void prof_begin(int kind, hipStream_t st);
+void prof_end(hipStream_t st);
 }
 using oprl::set_err;
 
@@ -280,7 +282,9 @@ extern "C" int oprl_replay_sample(oprl_replay* h, int32_t B, const int64_t* idx,
   G.out_ep = out_ep; G.out_step = out_step;
   const int grid = (B + kSamplesPerWg - 1) / kSamplesPerWg;
   const size_t lds = sizeof(float) * kSamplesPerWg * (2 * h->S + h->A + 2);
+  oprl::prof_begin(2, (hipStream_t)stream);
   hipLaunchKernelGGL(k_replay_gather, dim3(grid), dim3(kGatherThreads), lds, (hipStream_t)stream, G);
+  oprl::prof_end((hipStream_t)stream);
   HIPC(hipGetLastError());
   return OPRL_OK;
 }
