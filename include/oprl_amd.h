@@ -174,6 +174,14 @@ int oprl_polyak(float* target, const float* source, int64_t n, double tau, void*
 int oprl_profile_enable(int32_t on);
 int oprl_profile_read(int64_t* counts_host, double* ms_host, int32_t reset);
 
+/* Debug tracing: when buf != NULL every k_mlp_slice launch of this learner writes
+ * per-workgroup phase timestamps (shader cycle counter, 100 MHz realtime) to
+ * buf[launch_slot][64 workgroups][OPRL_TRACE_STAMPS][2] (int64, device memory);
+ * launch_slot restarts at 0 with each update().  NULL disables. */
+#define OPRL_TRACE_STAMPS 12
+#define OPRL_TRACE_SLOTS 24
+int oprl_learner_set_trace(oprl_learner* h, int64_t* buf);
+
 /* ---- replay: ReplayBufferProtocol --------------------------------------- */
 /* Storage tensors are owned by the caller (torch) with the reference layout
  * (buffers/episodic_buffer.py:29-55): states[E,L+1,S] actions[E,L,A]

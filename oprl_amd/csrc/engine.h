@@ -52,18 +52,29 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // ---------------------------------------------------------------------------
-// Y[kR, WIDTH] = act(X[kR, K] · W[WIDTH, K]^T + b)      (wide output)
-// Wave w owns output columns [w*WIDTH/4, (w+1)*WIDTH/4).  X in LDS, zero padded
-// to round_up(K,16) columns.  GUARD: K is not a multiple of 16 / rows of W are
-// not 16-byte aligned (first layer) -> predicated scalar weight loads.
-// Caller syncs before (X complete) and after (Y complete).
+// Memory-level parallelism.  A slice workgroup streams each weight matrix once,
+// straight from L2/HBM into MFMA operands, and the weights were rewritten by the
+// previous step's Adam kernel, so most of these loads miss the XCD's L2.  With
+// one wave per SIMD nothing else hides that latency: every GEMM below therefore
+// keeps a deep register ring of B fragments in flight (we have 512 VGPRs per
+// lane at this occupancy) or, for the short loops, issues every load up front.
+// Measured before this change: 19.7 us per slice launch against a ~4 us MFMA
+// floor (profiles/r01_*).
 // ---------------------------------------------------------------------------
-template <int WIDTH, bool GUARD>
-__device__ __forceinline__ void gemm_fwd_wide(const float* __restrict__ Xs, int ldx, int K,
-                                              const float* __restrict__ W,
-                                              const float* __restrict__ bias, bool relu,
-                                              float* __restrict__ Ys, int ldy) {
+
+// ---------------------------------------------------------------------------
+// First layer: Y[kR, WIDTH] = relu(X[kR, K] · W[WIDTH, K]^T + b), K <= 96 and
+// not necessarily a multiple of 4 (rows of W are then not 16-byte aligned), so
+// weights come in as predicated scalar loads; X is zero padded to 16 columns.
+// Wave w owns output columns [w*WIDTH/4, (w+1)*WIDTH/4).
+// ---------------------------------------------------------------------------
+template <int WIDTH, int VEC>
+__device__ __forceinline__ void gemm_fwd_first_v(const float* __restrict__ Xs, int ldx, int K,
+                                                 const float* __restrict__ W,
+                                                 const float* __restrict__ bias,
+                                                 float* __restrict__ Ys, int ldy) {
   constexpr int TPW = WIDTH / 64;  // 16-wide tiles per wave
+  constexpr int CH = 3;            // macro steps preloaded per chunk (K <= 96 -> <= 2 chunks)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
   const int n0w = wave * (WIDTH / 4);
@@ -72,40 +83,43 @@ __device__ __forceinline__ void gemm_fwd_wide(const float* __restrict__ Xs, int 
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
     acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    wrow[q] = W + (size_t)(n0w + 16 * q + i) * K + 4 * kk;
+    wrow[q] = W + (size_t)(n0w + 16 * q + i) * K;
   }
   const float* xrow = Xs + i * ldx + 4 * kk;
-  const int Kp = round_up(K, 16);
-  if constexpr (!GUARD) {
-    f32x4 bn[TPW];
+  const int nstep = round_up(K, 16) >> 4;
+  for (int c0 = 0; c0 < nstep; c0 += CH) {
+    f32x4 b[CH][TPW];
 #pragma unroll
-    for (int q = 0; q < TPW; ++q) bn[q] = ld4(wrow[q]);
-    for (int k0 = 0; k0 < Kp; k0 += 16) {
-      f32x4 b4[TPW];
+    for (int c = 0; c < CH; ++c) {
+      const int k = 16 * (c0 + c) + 4 * kk;
 #pragma unroll
-      for (int q = 0; q < TPW; ++q) b4[q] = bn[q];
-      const int kn = (k0 + 16 < Kp) ? k0 + 16 : k0;  // prefetch next macro step
+      for (int q = 0; q < TPW; ++q) {
+        if constexpr (VEC == 4) {         // K % 4 == 0: rows are 16-byte aligned
+          b[c][q] = (k < K) ? ld4(wrow[q] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else if constexpr (VEC == 2) {  // K % 2 == 0: 8-byte aligned pairs
 #pragma unroll
-      for (int q = 0; q < TPW; ++q) bn[q] = ld4(wrow[q] + kn);
-      const f32x4 a4 = ld4(xrow + k0);
+          for (int h = 0; h < 2; ++h) {
+            f32x2 v = f32x2{0.f, 0.f};
+            if (k + 2 * h < K) v = *reinterpret_cast<const f32x2*>(wrow[q] + k + 2 * h);
+            b[c][q][2 * h] = v[0];
+            b[c][q][2 * h + 1] = v[1];
+          }
+        } else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int q = 0; q < TPW; ++q) acc[q] = mfma4(a4[t], b4[q][t], acc[q]);
+          for (int t = 0; t < 4; ++t) b[c][q][t] = (k + t < K) ? wrow[q][k + t] : 0.f;
+        }
+      }
     }
-  } else {
-    for (int k0 = 0; k0 < Kp; k0 += 16) {
-      const f32x4 a4 = ld4(xrow + k0);
-      const int k = k0 + 4 * kk;
-      f32x4 b4[TPW];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < TPW; ++q)
+    for (int c = 0; c < CH; ++c) {
+      if (c0 + c < nstep) {
+        const f32x4 a4 = ld4(xrow + 16 * (c0 + c));
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b4[q][t] = (k + t < K) ? wrow[q][k0 + t] : 0.f;
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int q = 0; q < TPW; ++q) acc[q] = mfma4(a4[t], b4[q][t], acc[q]);
+          for (int q = 0; q < TPW; ++q) acc[q] = mfma4(a4[t], b[c][q][t], acc[q]);
+      }
     }
   }
 #pragma unroll
@@ -113,19 +127,92 @@ __device__ __forceinline__ void gemm_fwd_wide(const float* __restrict__ Xs, int 
     const int col = n0w + 16 * q + i;
     const float bv = bias[col];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = acc[q][r] + bv;
-      if (relu) v = fmaxf(v, 0.f);
-      Ys[(kk * 4 + r) * ldy + col] = v;
+    for (int r = 0; r < 4; ++r) Ys[(kk * 4 + r) * ldy + col] = fmaxf(acc[q][r] + bv, 0.f);
+  }
+}
+
+template <int WIDTH>
+__device__ __forceinline__ void gemm_fwd_first(const float* __restrict__ Xs, int ldx, int K,
+                                               const float* __restrict__ W,
+                                               const float* __restrict__ bias,
+                                               float* __restrict__ Ys, int ldy) {
+  // W's base is 16-byte aligned (arena offsets are multiples of 4 floats only when
+  // every earlier tensor is; check the pointer, not just K)
+  const bool a16 = ((reinterpret_cast<uintptr_t>(W) & 15) == 0) && (K % 4 == 0);
+  const bool a8 = ((reinterpret_cast<uintptr_t>(W) & 7) == 0) && (K % 2 == 0);
+  if (a16) gemm_fwd_first_v<WIDTH, 4>(Xs, ldx, K, W, bias, Ys, ldy);
+  else if (a8) gemm_fwd_first_v<WIDTH, 2>(Xs, ldx, K, W, bias, Ys, ldy);
+  else gemm_fwd_first_v<WIDTH, 1>(Xs, ldx, K, W, bias, Ys, ldy);
+}
+
+// ---------------------------------------------------------------------------
+// Hidden layer: Y[kR, WIDTH] = relu(X[kR, WIDTH] · W[WIDTH, WIDTH]^T + b).
+// Register ring of D macro steps (D*TPW = 32 b128 fragments = 128 VGPRs) keeps
+// 8 KB per wave in flight.
+// ---------------------------------------------------------------------------
+template <int WIDTH>
+__device__ __forceinline__ void gemm_fwd_hidden(const float* __restrict__ Xs,
+                                                const float* __restrict__ W,
+                                                const float* __restrict__ bias,
+                                                float* __restrict__ Ys) {
+  constexpr int TPW = WIDTH / 64;
+  constexpr int NSTEP = WIDTH / 16;
+  constexpr int D = 32 / TPW;
+  constexpr int LD = lds_ld(WIDTH);
+  static_assert(NSTEP % D == 0, "ring depth must divide the step count");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  const int n0w = wave * (WIDTH / 4);
+  f32x4 acc[TPW];
+  const float* wrow[TPW];
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    wrow[q] = W + (size_t)(n0w + 16 * q + i) * WIDTH + 4 * kk;
+  }
+  const float* xrow = Xs + i * LD + 4 * kk;
+  // hipcc's scheduler sinks loads next to their first use (observed: effective
+  // prefetch distance of one macro step, every step paying a full ~1100-cycle
+  // miss).  sched_barrier(0) pins "issue step s+D's loads, then run step s".
+  f32x4 ring[D][TPW];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) ring[d][q] = ld4(wrow[q] + 16 * d);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    constexpr int dummy = 0; (void)dummy;
+    const int d = s % D;
+    f32x4 b4[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) b4[q] = ring[d][q];
+    if (s + D < NSTEP) {
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) ring[d][q] = ld4(wrow[q] + 16 * (s + D));
     }
+    const f32x4 a4 = ld4(xrow + 16 * s);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) acc[q] = mfma4(a4[t], b4[q][t], acc[q]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int col = n0w + 16 * q + i;
+    const float bv = bias[col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ys[(kk * 4 + r) * LD + col] = fmaxf(acc[q][r] + bv, 0.f);
   }
 }
 
 // ---------------------------------------------------------------------------
 // Y[kR, N] = X[kR, WIDTH] · W[N, WIDTH]^T + b,  N <= kNarrowMax  (narrow output)
-// The 4 waves split the contraction; partial tiles meet in `scratch`
-// ([kWaves][kR][kNarrowMax] floats of LDS).  Contains its own barriers; Y is
-// complete (and visible) on return.
+// The 4 waves split the contraction (WIDTH/64 macro steps each, all B fragments
+// loaded up front); partial tiles meet in `scratch` ([kWaves][kR][kNarrowMax]
+// floats of LDS).  Contains its own barriers; Y is complete on return.
 // ---------------------------------------------------------------------------
 template <int WIDTH>
 __device__ __forceinline__ void gemm_fwd_narrow(const float* __restrict__ Xs, int ldx,
@@ -134,33 +221,35 @@ __device__ __forceinline__ void gemm_fwd_narrow(const float* __restrict__ Xs, in
                                                 float* __restrict__ scratch,
                                                 float* __restrict__ Ys, int ldy) {
   constexpr int TMAX = kNarrowMax / 16;
+  constexpr int NS = WIDTH / 64;  // macro steps per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
   const int T = (N + 15) >> 4;
+  const int kbeg = wave * (WIDTH / 4);
   f32x4 acc[TMAX];
-  const float* wrow[TMAX];
-  bool valid[TMAX];
+  f32x4 b[NS][TMAX];
 #pragma unroll
   for (int q = 0; q < TMAX; ++q) {
     acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int n = 16 * q + i;
-    valid[q] = n < N;
-    wrow[q] = W + (size_t)(valid[q] ? n : N - 1) * WIDTH + 4 * kk;
-  }
-  const int kbeg = wave * (WIDTH / 4), kend = kbeg + WIDTH / 4;
-  const float* xrow = Xs + i * ldx + 4 * kk;
-#pragma unroll 2
-  for (int k0 = kbeg; k0 < kend; k0 += 16) {
-    const f32x4 a4 = ld4(xrow + k0);
+    const bool valid = n < N;
+    const float* wrow = W + (size_t)(valid ? n : N - 1) * WIDTH + kbeg + 4 * kk;
 #pragma unroll
-    for (int q = 0; q < TMAX; ++q) {
-      if (q < T) {
-        f32x4 b4 = ld4(wrow[q] + k0);
-        if (!valid[q]) b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[q] = mfma4(a4[t], b4[t], acc[q]);
-      }
+    for (int s = 0; s < NS; ++s) {
+      b[s][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (q < T && valid) b[s][q] = ld4(wrow + 16 * s);
     }
+  }
+  const float* xrow = Xs + i * ldx + kbeg + 4 * kk;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const f32x4 a4 = ld4(xrow + 16 * s);
+#pragma unroll
+    for (int q = 0; q < TMAX; ++q)
+      if (q < T) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[q] = mfma4(a4[t], b[s][q][t], acc[q]);
+      }
   }
   float* part = scratch + wave * (kR * kNarrowMax);
 #pragma unroll
@@ -185,8 +274,8 @@ __device__ __forceinline__ void gemm_fwd_narrow(const float* __restrict__ Xs, in
 // W past Ncon are clamped, not skipped).  H = the ReLU output this gradient
 // flows into (mask), read from LDS.  Output column of tile t / lane j is
 // c0 + 4*j + t, so each lane ends up with 4 consecutive columns (one b128).
-// Writes dXs (LDS) and, when dXg != nullptr, rows < nrows of the global
-// [.,WIDTH] buffer.
+// Register ring of D macro steps (16*G*D VGPRs).  Writes dXs (LDS, may alias Hs)
+// and, when dXg != nullptr, rows < nrows of the global [.,WIDTH] buffer.
 // ---------------------------------------------------------------------------
 template <int WIDTH>
 __device__ __forceinline__ void gemm_bwd_wide(const float* __restrict__ dYs, int ldy, int Ncon,
@@ -195,6 +284,7 @@ __device__ __forceinline__ void gemm_bwd_wide(const float* __restrict__ dYs, int
                                               float* dXs, int ldx,
                                               float* __restrict__ dXg, int nrows) {
   constexpr int G = WIDTH / 256;  // 64-column groups per wave
+  constexpr int D = 8 / G;        // ring depth in macro steps
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, c = lane >> 4;
   const int c0w = wave * (WIDTH / 4);
@@ -205,23 +295,43 @@ __device__ __forceinline__ void gemm_bwd_wide(const float* __restrict__ dYs, int
     for (int t = 0; t < 4; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* yrow = dYs + j * ldy + 4 * c;
   const float* wcol = W + c0w + 4 * j;
-  const int Np = round_up(Ncon, 16);
-  for (int n0 = 0; n0 < Np; n0 += 16) {
-    const f32x4 a4 = ld4(yrow + n0);
-    f32x4 b4[4][G];
+  const int nstep = round_up(Ncon, 16) >> 4;
+  f32x4 ring[D][4][G];
+  auto fetch = [&](int d, int step) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      int n = n0 + 4 * c + s;
+      int n = 16 * step + 4 * c + s;
       n = n < Ncon ? n : Ncon - 1;
 #pragma unroll
-      for (int g = 0; g < G; ++g) b4[s][g] = ld4(wcol + (size_t)n * WIDTH + 64 * g);
+      for (int g = 0; g < G; ++g) ring[d][s][g] = ld4(wcol + (size_t)n * WIDTH + 64 * g);
     }
+  };
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+  for (int d = 0; d < D; ++d)
+    if (d < nstep) fetch(d, d);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int s0 = 0; s0 < nstep; s0 += D) {
 #pragma unroll
-      for (int g = 0; g < G; ++g)
+    for (int d = 0; d < D; ++d) {
+      const int step = s0 + d;
+      if (step < nstep) {
+        f32x4 b4[4][G];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[g][t] = mfma4(a4[s], b4[s][g][t], acc[g][t]);
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int g = 0; g < G; ++g) b4[s][g] = ring[d][s][g];
+        if (step + D < nstep) fetch(d, step + D);
+        const f32x4 a4 = ld4(yrow + 16 * step);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[g][t] = mfma4(a4[s], b4[s][g][t], acc[g][t]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   }
 #pragma unroll
   for (int g = 0; g < G; ++g)
@@ -240,7 +350,8 @@ __device__ __forceinline__ void gemm_bwd_wide(const float* __restrict__ dYs, int
 // ---------------------------------------------------------------------------
 // out[kR, ncols] = dY[kR, WIDTH] · W1[WIDTH, Kin][:, col0 : col0+ncols]
 // (gradient wrt a column range of the first layer's input — the action columns
-// of a critic).  ncols <= kNarrowMax.  Waves split the contraction.
+// of a critic).  ncols <= kNarrowMax.  Waves split the contraction; all weight
+// elements are fetched (predicated scalar loads) before the MFMA chain.
 // ---------------------------------------------------------------------------
 template <int WIDTH>
 __device__ __forceinline__ void gemm_bwd_narrow(const float* __restrict__ dYs, int ldy,
@@ -248,27 +359,33 @@ __device__ __forceinline__ void gemm_bwd_narrow(const float* __restrict__ dYs, i
                                                 int ncols, float* __restrict__ scratch,
                                                 float* __restrict__ outS, int ldo) {
   constexpr int TMAX = kNarrowMax / 16;
+  constexpr int NS = WIDTH / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, c = lane >> 4;
   const int T = (ncols + 15) >> 4;
+  const int nbeg = wave * (WIDTH / 4);
   f32x4 acc[TMAX];
+  float b[NS][4][TMAX];
 #pragma unroll
-  for (int q = 0; q < TMAX; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nbeg = wave * (WIDTH / 4), nend = nbeg + WIDTH / 4;
-  const float* yrow = dYs + j * ldy + 4 * c;
-  for (int n0 = nbeg; n0 < nend; n0 += 16) {
-    const f32x4 a4 = ld4(yrow + n0);
+  for (int q = 0; q < TMAX; ++q) {
+    acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int col = 16 * q + j;
+    const bool ok = q < T && col < ncols;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float* wr = W1 + (size_t)(n0 + 4 * c + s) * Kin + col0;
+    for (int st = 0; st < NS; ++st)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        b[st][s][q] = ok ? W1[(size_t)(nbeg + 16 * st + 4 * c + s) * Kin + col0 + col] : 0.f;
+  }
+  const float* yrow = dYs + j * ldy + nbeg + 4 * c;
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    const f32x4 a4 = ld4(yrow + 16 * st);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int q = 0; q < TMAX; ++q)
-        if (q < T) {
-          const int col = 16 * q + j;
-          const float b = col < ncols ? wr[col] : 0.f;
-          acc[q] = mfma4(a4[s], b, acc[q]);
-        }
-    }
+        if (q < T) acc[q] = mfma4(a4[s], b[st][s][q], acc[q]);
   }
   float* part = scratch + wave * (kR * kNarrowMax);
 #pragma unroll
@@ -383,22 +500,23 @@ __device__ __forceinline__ T pick(const T (&arr)[N], int idx) {
 // Hidden layer l's output goes to hbase + l*kR*WL.  If store_x the inputs of
 // layers 1.. (the hidden activations) are also stored to Xg[l] ([B, WIDTH]).
 // Result: outS[kR][kOutLd] columns [0, dims[L]).
-template <int WIDTH>
+template <int WIDTH, class Stamp>
 __device__ __forceinline__ void mlp_forward_slice(const Net& net, const float* x0s, float* hbase,
                                                   float* outS, float* scr,
                                                   float* const (&Xg)[kMaxLayers], bool store_x,
-                                                  int row0, int B) {
+                                                  int row0, int B, Stamp&& stamp) {
   constexpr int WL = lds_ld(WIDTH);
   constexpr int HB = kR * WL;
   const int L = net.n_layers;
-  gemm_fwd_wide<WIDTH, true>(x0s, kX0Ld, net.dims[0], net.W[0], net.b[0], true, hbase, WL);
+  gemm_fwd_first<WIDTH>(x0s, kX0Ld, net.dims[0], net.W[0], net.b[0], hbase, WL);
   __syncthreads();
+  stamp();
 #pragma unroll
   for (int l = 1; l < kMaxLayers - 1; ++l) {
     if (l < L - 1) {
-      gemm_fwd_wide<WIDTH, false>(hbase + (l - 1) * HB, WL, WIDTH, net.W[l], net.b[l], true,
-                                  hbase + l * HB, WL);
+      gemm_fwd_hidden<WIDTH>(hbase + (l - 1) * HB, net.W[l], net.b[l], hbase + l * HB);
       __syncthreads();
+      stamp();
     }
   }
   if (store_x) {
@@ -418,12 +536,12 @@ __device__ __forceinline__ void mlp_forward_slice(const Net& net, const float* x
 // kernel; the caller stores dY[L-1] = dout itself.  If dact_cols > 0 the
 // gradient wrt input columns [dact_col0, +dact_cols) lands in dactS[kR][kOutLd]
 // (may alias doutS).
-template <int WIDTH>
+template <int WIDTH, class Stamp>
 __device__ __forceinline__ void mlp_backward_slice(const Net& net, const float* doutS,
                                                    float* hbase, float* scr,
                                                    float* const (&dYg)[kMaxLayers], int row0,
                                                    int B, int dact_col0, int dact_cols,
-                                                   float* dactS) {
+                                                   float* dactS, Stamp&& stamp) {
   constexpr int WL = lds_ld(WIDTH);
   constexpr int HB = kR * WL;
   const int L = net.n_layers;
@@ -439,6 +557,7 @@ __device__ __forceinline__ void mlp_backward_slice(const Net& net, const float* 
                            dYg[l - 1] != nullptr ? dYg[l - 1] + (size_t)row0 * WIDTH : nullptr,
                            nrows);
       __syncthreads();
+      stamp();
       dy = dx;
       ldy = WL;
       ncon = WIDTH;

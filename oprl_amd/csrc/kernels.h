@@ -67,6 +67,7 @@ struct MlpArgs {
   float* dYg[kMaxLayers]; int lddo;  // dYg[l<L-1]: [B][WIDTH]; dYg[L-1]: [B][lddo]
   int dact_col0, dact_cols; float* dact; int lddact;
   float* partials;                   // [gridDim.x][4] per-slice sums: loss, q, y, (spare)
+  long long* trace;                  // debug: [gridDim.x][kTraceStamps][2] (shader clock, 100 MHz realtime)
 };
 
 // ---- dW + Adam + Polyak ------------------------------------------------------
@@ -96,5 +97,6 @@ struct DwArgs {
 };
 
 constexpr int kDwTile = 32;
+constexpr int kTraceStamps = 12;
 
 }  // namespace oprl

@@ -200,6 +200,8 @@ struct oprl_learner {
   int opt_step_critic = 0, opt_step_actor = 0, opt_step_alpha = 0;
   int last_B = 0;
   bool actor_updated_last = false;
+  long long* trace = nullptr;
+  int trace_slot = 0;
 };
 
 namespace {
@@ -270,9 +272,11 @@ AdamScalars adam_scalars(const oprl_learner* h, double lr, int step, bool polyak
   return ad;
 }
 
-MlpArgs base_args(const oprl_learner* h, const oprl_net& n, bool target, int B) {
+MlpArgs base_args(oprl_learner* h, const oprl_net& n, bool target, int B) {
   MlpArgs a;
   memset(&a, 0, sizeof a);
+  if (h->trace != nullptr && h->trace_slot < OPRL_TRACE_SLOTS)
+    a.trace = h->trace + (size_t)(h->trace_slot++) * 64 * kTraceStamps * 2;
   a.net = net_view(n, target);
   a.B = B;
   a.action_dim = h->A;
@@ -639,6 +643,7 @@ extern "C" int oprl_learner_update_phase(oprl_learner* h, int32_t phase, const f
   RC(check_batch(h, s, a, r, d, s2, B));
   hipStream_t st = (hipStream_t)stream;
   h->last_B = B;
+  if (phase == 0) h->trace_slot = 0;
   if (phase == 0) return critic_phase(h, s, a, r, d, s2, B, noise0, st);
   if (phase == 1) {
     h->actor_updated_last = actor_due(h);
@@ -735,6 +740,12 @@ extern "C" int oprl_learner_read_scalars(oprl_learner* h, float* out_host, int32
   res[4] = lap ? (float)exp(la) : (float)c.hp.alpha_init;
   res[5] = (float)h->update_count;
   for (int i = 0; i < n && i < 6; ++i) out_host[i] = res[i];
+  return OPRL_OK;
+}
+
+extern "C" int oprl_learner_set_trace(oprl_learner* h, int64_t* buf) {
+  if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
+  h->trace = (long long*)buf;
   return OPRL_OK;
 }
 

@@ -40,7 +40,8 @@ namespace {
 
 constexpr int kGatherThreads = 256;
 constexpr int kSamplesPerWg = 32;
-constexpr int kStageRows = 4096;  // transitions staged on the host between flushes
+constexpr int kStageRows = 4096;
+constexpr int kMaxEndsLds = 2048; // episode-end table entries staged in LDS by the gather  // transitions staged on the host between flushes
 
 struct GatherArgs {
   const float *states, *actions, *rewards, *dones;
@@ -56,7 +57,16 @@ struct GatherArgs {
 __global__ __launch_bounds__(kGatherThreads) void k_replay_gather(const GatherArgs G) {
   extern __shared__ float stage[];  // [kSamplesPerWg][2S + A + 2]
   __shared__ int s_ep[kSamplesPerWg], s_t[kSamplesPerWg];
+  __shared__ int s_ends[kMaxEndsLds];
   const int tid = threadIdx.x;
+  // the episode table (<= 4 KB at the reference's 1000 episodes) goes to LDS in
+  // one coalesced pass; a binary search over global memory is 10 dependent
+  // round trips to L2/HBM (measured 7.4 us for this kernel before)
+  const bool ends_in_lds = G.n_eps <= kMaxEndsLds;
+  if (ends_in_lds)
+    for (int e = tid; e < G.n_eps; e += kGatherThreads) s_ends[e] = G.ends[e];
+  __syncthreads();
+  const int* ends = ends_in_lds ? s_ends : G.ends;
   const int base = blockIdx.x * kSamplesPerWg;
   const int S = G.S, A = G.A, W = 2 * S + A + 2;
   if (tid < kSamplesPerWg) {
@@ -76,10 +86,10 @@ __global__ __launch_bounds__(kGatherThreads) void k_replay_gather(const GatherAr
       int lo = 0, hi = G.n_eps;
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if ((long)G.ends[mid] > ind) hi = mid; else lo = mid + 1;
+        if ((long)ends[mid] > ind) hi = mid; else lo = mid + 1;
       }
       e = lo < G.n_eps ? lo : 0;
-      const long start = e > 0 ? (long)G.ends[e - 1] : 0;
+      const long start = e > 0 ? (long)ends[e - 1] : 0;
       t = (int)(ind - start);
       if (G.out_ep != nullptr) G.out_ep[i] = e;
       if (G.out_step != nullptr) G.out_step[i] = t;

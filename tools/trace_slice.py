@@ -1,0 +1,41 @@
+"""Debug tool: per-phase timestamps inside k_mlp_slice for one DDPG update
+(needs a GPU).  Prints, per launch, the phase durations of workgroup 0 and the
+spread over workgroups, in shader cycles and in microseconds."""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import numpy as np
+import torch as t
+from oprl_amd import _capi
+from oprl_amd.algos.ddpg import DDPG
+from oprl_amd.logging import NullLogger
+
+S, A, B = 24, 6, 256
+t.manual_seed(0)
+algo = DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device="cuda", max_batch=B).create()
+L = algo.learner
+NS, NST = 24, 12
+buf = t.zeros((NS, 64, NST, 2), dtype=t.int64, device="cuda")
+batch = [t.randn(B, S, device="cuda"), t.rand(B, A, device="cuda") * 2 - 1, t.rand(B, 1, device="cuda"),
+         t.zeros(B, 1, device="cuda"), t.randn(B, S, device="cuda")]
+for _ in range(50):
+    algo.update(*batch)
+_capi.check(L.lib.oprl_learner_set_trace(L.handle, _capi.ptr(buf)))
+for _ in range(3):
+    buf.zero_()
+    algo.update(*batch)
+t.cuda.synchronize()
+tr = buf.cpu().numpy()
+names = ["actor_t fwd", "critic_t fwd", "critic fwd+bwd", "actor fwd", "critic(s,pi) fwd+bwd", "actor bwd"]
+for slot in range(6):
+    x = tr[slot, :16]                       # 16 workgroups
+    n = int((x[0, :, 0] != 0).sum())
+    cyc = x[:, :n, 0].astype(np.float64)
+    rt = x[:, :n, 1].astype(np.float64)     # 100 MHz ticks
+    d_cyc = np.diff(cyc, axis=1)
+    d_us = np.diff(rt, axis=1) / 100.0
+    tot_us = (rt[:, -1] - rt[:, 0]) / 100.0
+    clk = (cyc[:, -1] - cyc[:, 0]) / np.maximum(tot_us, 1e-9) / 1e3
+    print(f"{names[slot]:22s} stamps={n} wg0 phases(us)={np.round(d_us[0], 2).tolist()} total wg0={tot_us[0]:.2f}us "
+          f"max-wg={tot_us.max():.2f}us  cyc/us~{clk.mean():.2f} GHz  start spread={(rt[:,0].max()-rt[:,0].min())/100:.2f}us")
+    print(f"{'':22s} wg0 phases(cycles)={d_cyc[0].astype(int).tolist()}")
