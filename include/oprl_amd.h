@@ -61,6 +61,13 @@ typedef struct oprl_net {
   float* adam_m;
   float* adam_v;
   float* grad;                          /* written when grads are exported (DP / tests) */
+  /* Fragment-order weight packs (device, caller-owned, oprl_net_pack_floats()
+   * floats each, zero-initialised by the caller): the layout the MFMA kernels
+   * stream (csrc/engine.h).  The library keeps them in step with theta /
+   * theta_target whenever IT changes those (update, apply); after an outside
+   * change of the master (load_state_dict ...) call oprl_net_repack(). */
+  float* pack;
+  float* pack_target;                   /* NULL when there is no target */
 } oprl_net;
 
 /* Doubles on purpose: the reference's hyper-parameters are python floats and
@@ -139,6 +146,9 @@ int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t K, int32_t
  * update(): out_host[0]=critic_loss, [1]=actor_loss, [2]=mean q, [3]=mean
  * target, [4]=alpha, [5]=update_step.  Synchronises `stream`. */
 int oprl_learner_read_scalars(oprl_learner* h, float* out_host, int32_t n, void* stream);
+/* Rebuild every pack of the learner's nets from their masters (after the caller
+ * changed parameters from outside, e.g. load_state_dict). */
+int oprl_learner_sync_params(oprl_learner* h, void* stream);
 int oprl_learner_update_count(oprl_learner* h, int64_t* out_host);
 int oprl_learner_set_update_count(oprl_learner* h, int64_t count);
 /* device pointer to the per-row Q / TD-target of the last critic step ([B] each,
@@ -146,6 +156,10 @@ int oprl_learner_set_update_count(oprl_learner* h, int64_t count);
 int oprl_learner_debug_ptrs(oprl_learner* h, const float** q, const float** y);
 
 /* ---- building blocks (nn_models.py forward; used by Module.__call__) ----- */
+/* floats needed for ONE pack buffer of this net (dims only are read) */
+int64_t oprl_net_pack_floats(const oprl_net* net);
+/* rebuild pack from theta (which & 1) and/or pack_target from theta_target (which & 2) */
+int oprl_net_repack(const oprl_net* net, int32_t which, void* stream);
 /* out[B,dims[L]] = MLP([x0 | x1]) with x0[B,k0], x1[B,k1] (x1 may be NULL,
  * k0+k1 == dims[0]); out_act: 0 identity, 1 tanh.  use_target selects
  * theta_target. */

@@ -28,6 +28,8 @@ class OprlNet(C.Structure):
         ("adam_m", C.c_void_p),
         ("adam_v", C.c_void_p),
         ("grad", C.c_void_p),
+        ("pack", C.c_void_p),
+        ("pack_target", C.c_void_p),
     ]
 
 
@@ -79,6 +81,9 @@ SIGNATURES = {
     "oprl_learner_update_count": (C.c_int, [_P, C.POINTER(_I64)]),
     "oprl_learner_set_update_count": (C.c_int, [_P, _I64]),
     "oprl_learner_debug_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
+    "oprl_net_pack_floats": (_I64, [C.POINTER(OprlNet)]),
+    "oprl_net_repack": (C.c_int, [C.POINTER(OprlNet), _I32, _P]),
+    "oprl_learner_sync_params": (C.c_int, [_P, _P]),
     "oprl_mlp_forward": (C.c_int, [C.POINTER(OprlNet), _I32, _P, _I32, _P, _I32, _I32, _I32, _P, _P]),
     "oprl_mlp_backward": (C.c_int, [C.POINTER(OprlNet), _P, _I32, _P, _I32, _I32, _P, _P, _P]),
     "oprl_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _D, _D, _D, _D, _D, _P]),

@@ -99,6 +99,8 @@ class HipLearner:
                 dst.dims[i] = x
             dst.theta = mlp.theta_ptr()
             dst.theta_target = target.theta_ptr() if target is not None else None
+            dst.pack = mlp.pack_tensor().data_ptr()
+            dst.pack_target = target.pack_tensor().data_ptr() if target is not None else None
             dst.adam_m = m.data_ptr() + o
             dst.adam_v = v.data_ptr() + o
             dst.grad = (g.data_ptr() + o) if g is not None else None
@@ -124,6 +126,11 @@ class HipLearner:
         with t.cuda.device(device):
             _capi.check(self.lib.oprl_learner_create(C.byref(cfg), C.byref(h)), "oprl_learner_create")
         self.handle = h
+        self._all_mlps = [m for m in [actor_mlp, actor_target_mlp, *critic_mlps, *critic_target_mlps]
+                          if m is not None]
+        for m in self._all_mlps:       # oprl_learner_create built every pack from the masters
+            m.mark_packed()
+        self._versions = self._snapshot_versions()
 
     def target_arenas(self):
         """Flat target-network arenas (critic targets, then the actor target if any)."""
@@ -136,12 +143,28 @@ class HipLearner:
         a, at, cs, cts = self._mlps
         return tuple(next(m.parameters()).data_ptr() for m in [a, *( [at] if at is not None else []), *cs, *cts])
 
+    def _snapshot_versions(self):
+        return tuple(p._version for m in self._all_mlps for p in m.parameters())
+
+    def sync_params(self) -> None:
+        """Rebuild the fragment-order packs from the master parameters.  Called
+        automatically when torch reports an in-place change (load_state_dict,
+        ``param.copy_``); call it yourself after writing through ``.data``."""
+        with t.cuda.device(self.device):
+            _capi.check(self.lib.oprl_learner_sync_params(self.handle, _capi.current_stream()),
+                        "oprl_learner_sync_params")
+        for m in self._all_mlps:
+            m.mark_packed()
+        self._versions = self._snapshot_versions()
+
     def check_bound(self) -> None:
         """The kernels hold raw pointers into the arenas: refuse to run if a
         module was moved/re-allocated behind our back (e.g. ``actor.to(...)``)."""
         if self._snapshot_ptrs() != self._ptrs:
             raise RuntimeError("a network's parameters were re-allocated after create(); "
                                "the HIP learner is bound to the original arenas")
+        if self._snapshot_versions() != self._versions or any(m._pack_key is None for m in self._all_mlps):
+            self.sync_params()
 
     def close(self) -> None:
         if getattr(self, "handle", None):

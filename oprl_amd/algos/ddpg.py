@@ -57,7 +57,13 @@ class DDPG(OffPolicyAlgorithm):
         for m in (self.actor, self.actor_target, self.critic, self.critic_target):
             flatten_module_(m)
         self.actor_target._oprl_arena.copy_(self.actor._oprl_arena)
+        for m in self.actor_target.modules():
+            if hasattr(m, "mark_dirty"):
+                m.mark_dirty()
         self.critic_target._oprl_arena.copy_(self.critic._oprl_arena)
+        for m in self.critic_target.modules():
+            if hasattr(m, "mark_dirty"):
+                m.mark_dirty()
         disable_gradient(self.actor_target)
         disable_gradient(self.critic_target)
         hp = dict(gamma=self.gamma, tau=self.tau, lr_actor=self.lr_actor, lr_critic=self.lr_critic,

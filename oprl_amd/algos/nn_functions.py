@@ -23,6 +23,9 @@ def soft_update(target: nn.Module, source: nn.Module, tau: float) -> None:
             with t.cuda.device(tp.device):
                 _capi.check(_capi.load().oprl_polyak(_capi.ptr(ta), _capi.ptr(sa), ta.numel(),
                                                      float(tau), _capi.current_stream()), "oprl_polyak")
+            for m in target.modules():       # the master changed behind torch's back
+                if hasattr(m, "mark_dirty"):
+                    m.mark_dirty()
         else:
             for tgt, src in zip(target.parameters(), source.parameters()):
                 tgt.data.mul_(1.0 - tau).add_(tau * src.data)

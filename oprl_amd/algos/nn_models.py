@@ -58,6 +58,9 @@ def flatten_module_(module: nn.Module) -> t.Tensor:
         p.data = flat[off:off + n].view(p.shape)
         off += n
     module._oprl_arena = flat  # keeps the storage alive with the module
+    for m in module.modules():
+        if isinstance(m, MLP):
+            m.mark_dirty()
     return flat
 
 
@@ -81,15 +84,22 @@ def ensure_flat(module: nn.Module) -> t.Tensor:
 
 
 def _net_desc(dims: Sequence[int], theta_ptr: int, target_ptr: int = 0, m_ptr: int = 0,
-              v_ptr: int = 0, grad_ptr: int = 0) -> _capi.OprlNet:
+              v_ptr: int = 0, grad_ptr: int = 0, pack_ptr: int = 0,
+              pack_target_ptr: int = 0) -> _capi.OprlNet:
     d = _capi.OprlNet()
     d.n_layers = len(dims) - 1
     for i, x in enumerate(dims):
         d.dims[i] = int(x)
-    d.theta, d.theta_target, d.adam_m, d.adam_v, d.grad = (
+    d.theta, d.theta_target, d.adam_m, d.adam_v, d.grad, d.pack, d.pack_target = (
         C.c_void_p(theta_ptr), C.c_void_p(target_ptr), C.c_void_p(m_ptr), C.c_void_p(v_ptr),
-        C.c_void_p(grad_ptr))
+        C.c_void_p(grad_ptr), C.c_void_p(pack_ptr), C.c_void_p(pack_target_ptr))
     return d
+
+
+def pack_floats(dims: Sequence[int]) -> int:
+    """Size of one fragment-order pack buffer (csrc/engine.h): per layer a forward
+    pack of W and a backward pack of W^T, each ceil(out/16)*ceil(in/16) KB."""
+    return sum(2 * (-(-o // 16)) * (-(-i // 16)) * 256 for i, o in zip(dims[:-1], dims[1:]))
 
 
 class MLP(nn.Module):
@@ -112,6 +122,8 @@ class MLP(nn.Module):
         mods += [nn.Linear(self.dims[-2], self.dims[-1]), output_activation]
         self.nn = nn.Sequential(*mods)
         self._hip_ok = isinstance(hidden_activation, nn.ReLU) and isinstance(output_activation, nn.Identity)
+        self._pack: t.Tensor | None = None   # fragment-order weight packs (device)
+        self._pack_key = None
 
     # -- HIP path ------------------------------------------------------------
     def theta_ptr(self) -> int:
@@ -126,6 +138,40 @@ class MLP(nn.Module):
             expect += p.numel() * 4
         return ps[0].data_ptr()
 
+    # -- fragment-order packs ---------------------------------------------------
+    def _param_key(self):
+        ps = list(self.parameters())
+        return tuple(p.data_ptr() for p in ps) + tuple(p._version for p in ps)
+
+    def mark_dirty(self) -> None:
+        """Call after changing parameters through an alias torch cannot see
+        (``p.data``, the flat arena): forces a repack before the next HIP use."""
+        self._pack_key = None
+
+    def mark_packed(self) -> None:
+        """The packs were just rebuilt/updated by the library (learner kernels)."""
+        self._pack_key = self._param_key()
+
+    def pack_tensor(self) -> t.Tensor:
+        """The pack buffer (allocated on first use, on the parameters' device)."""
+        dev = next(self.parameters()).device
+        if self._pack is None or self._pack.device != dev:
+            self._pack = t.zeros(pack_floats(self.dims), dtype=t.float32, device=dev)
+            self._pack_key = None
+        return self._pack
+
+    def ensure_packed(self) -> t.Tensor:
+        pk = self.pack_tensor()
+        theta = self.theta_ptr()
+        key = self._param_key()
+        if key != self._pack_key:
+            desc = _net_desc(self.dims, theta, pack_ptr=pk.data_ptr())
+            with t.cuda.device(pk.device):
+                _capi.check(_capi.load().oprl_net_repack(C.byref(desc), 1, _capi.current_stream()),
+                            "oprl_net_repack")
+            self._pack_key = self._param_key()
+        return pk
+
     def hip_forward(self, x0: t.Tensor, x1: t.Tensor | None = None, out_act: int = _capi.ACT_NONE) -> t.Tensor:
         if not self._hip_ok:
             raise RuntimeError("the HIP MLP kernels implement ReLU hidden / identity output only")
@@ -139,7 +185,8 @@ class MLP(nn.Module):
         B = x0.shape[0]
         n_out = self.dims[-1] // 2 if out_act == _capi.ACT_GAUSS_MEAN else self.dims[-1]
         out = t.empty((B, n_out), dtype=t.float32, device=x0.device)
-        desc = _net_desc(self.dims, self.theta_ptr())
+        pk = self.ensure_packed()
+        desc = _net_desc(self.dims, self.theta_ptr(), pack_ptr=pk.data_ptr())
         with t.cuda.device(x0.device):
             _capi.check(lib.oprl_mlp_forward(C.byref(desc), 0, _capi.ptr(x0), k0, _capi.ptr(x1), k1,
                                              B, out_act, _capi.ptr(out), _capi.current_stream()),

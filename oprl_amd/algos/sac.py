@@ -53,6 +53,9 @@ class SAC(OffPolicyAlgorithm):
         for m in (self.actor, self.critic, self.critic_target):
             flatten_module_(m)
         self.critic_target._oprl_arena.copy_(self.critic._oprl_arena)
+        for m in self.critic_target.modules():
+            if hasattr(m, "mark_dirty"):
+                m.mark_dirty()
         disable_gradient(self.critic_target)
         self.log_alpha = None
         if self.tune_alpha:

@@ -82,6 +82,9 @@ class TQC(OffPolicyAlgorithm):
         for m in (self.actor, self.critic, self.critic_target):
             flatten_module_(m)
         self.critic_target._oprl_arena.copy_(self.critic._oprl_arena)
+        for m in self.critic_target.modules():
+            if hasattr(m, "mark_dirty"):
+                m.mark_dirty()
         self.log_alpha = t.tensor(math.log(0.2), dtype=t.float64, device=dev)
         self.quantiles_total = self.n_quantiles * self.n_nets
         hp = dict(gamma=self.gamma, tau=self.tau, lr_actor=self.lr_actor, lr_critic=self.lr_critic,

@@ -76,7 +76,14 @@ struct DwItem {      // one Linear layer of one net
   const float* dY; int ldy; int N;     // grad wrt layer pre-activation output [B][ldy]
   float *w, *w_t, *w_m, *w_v, *w_g;    // [N][K] views into theta / theta_target / m / v / grad
   float *b, *b_t, *b_m, *b_v, *b_g;    // [N]
+  float *pf, *pb, *tpf;                // fragment-order packs: W (fwd), W^T (bwd), target W (fwd)
   int tiles_k, tile_begin, tile_end;
+};
+
+struct RepackItem {  // one Linear layer: master -> packs
+  const float* w; int N, K;
+  float *pf, *pb;    // pb may be null (target nets are never differentiated)
+  int blk_begin, blk_end;   // 256-element blocks of the N*K index space
 };
 
 struct AdamScalars {
@@ -97,6 +104,8 @@ struct DwArgs {
 };
 
 constexpr int kDwTile = 32;
+constexpr int kDwThreads = 256;
+constexpr int kDwWaves = 4;
 constexpr int kTraceStamps = 12;
 
 }  // namespace oprl

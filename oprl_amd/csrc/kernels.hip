@@ -73,9 +73,10 @@ __global__ __launch_bounds__(kThreads) void k_mlp_slice(const MlpArgs A) {
     // ---- output head ------------------------------------------------------
     if (A.out_act == ACT_GAUSS) {
       const int Ad = A.action_dim;
-      const int row = tid >> 4, sub = tid & 15, gr = row0 + row;
+      const int row = (tid >> 4) & (kR - 1), sub = tid & 15, gr = row0 + row;
+      const bool mine = tid < kR * 16;      // 16 lanes per row, first 256 threads
       float lp = 0.f;
-      if (gr < B) {
+      if (mine && gr < B) {
         for (int col = sub; col < Ad; col += 16) {
           const float mu = outS[row * kOutLd + col];
           const float lsr = outS[row * kOutLd + Ad + col];
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(kThreads) void k_mlp_slice(const MlpArgs A) {
       }
 #pragma unroll
       for (int m = 1; m < 16; m <<= 1) lp += __shfl_xor(lp, m);
-      if (sub == 0 && gr < B && A.logp != nullptr) A.logp[gr] = lp;
+      if (mine && sub == 0 && gr < B && A.logp != nullptr) A.logp[gr] = lp;
     } else if (A.out != nullptr) {
       const int ncol = (A.out_act == ACT_GAUSS_MEAN) ? A.action_dim : Nout;
       for (int idx = tid; idx < kR * ncol; idx += kThreads) {
@@ -230,7 +231,11 @@ __global__ __launch_bounds__(kThreads) void k_mlp_slice(const MlpArgs A) {
       if ((tid & 63) == 0) scr[(tid >> 6) * 4 + k] = v[k];
     }
     __syncthreads();
-    if (tid < 3) A.partials[blockIdx.x * 4 + tid] = scr[tid] + scr[4 + tid] + scr[8 + tid] + scr[12 + tid];
+    if (tid < 3) {
+      float sum = 0.f;
+      for (int w = 0; w < kWaves; ++w) sum += scr[w * 4 + tid];
+      A.partials[blockIdx.x * 4 + tid] = sum;
+    }
   }
   __syncthreads();
   {
@@ -253,12 +258,14 @@ template __global__ void k_mlp_slice<512>(const MlpArgs);
 //   m += (g-m)(1-b1);  v = b2 v + (1-b2) g g;  th -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps)
 //   th_t = (1-tau) th_t + tau th                       (Polyak, nn_functions.py:5-10)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void adam_polyak_elem(float g, float* th, float* m, float* v, float* tt,
-                                                 float* gout, const AdamScalars& ad,
-                                                 float step_size, float bc2_sqrt) {
+// returns bit0: theta written (*th_new), bit1: target written (*tt_new)
+__device__ __forceinline__ int adam_polyak_elem(float g, float* th, float* m, float* v, float* tt,
+                                                float* gout, const AdamScalars& ad,
+                                                float step_size, float bc2_sqrt, float* th_new,
+                                                float* tt_new) {
   g *= ad.grad_scale;
   if (gout != nullptr) *gout = g;
-  if (!ad.do_adam) return;
+  if (!ad.do_adam) return 0;
   float mm = *m, vv = *v, t = *th;
   mm = mm + (g - mm) * ad.omb1;
   vv = vv * ad.beta2 + ad.omb2 * g * g;
@@ -267,7 +274,14 @@ __device__ __forceinline__ void adam_polyak_elem(float g, float* th, float* m, f
   *m = mm;
   *v = vv;
   *th = t;
-  if (ad.do_polyak && tt != nullptr) *tt = *tt * ad.omtau + ad.tau * t;
+  *th_new = t;
+  if (ad.do_polyak && tt != nullptr) {
+    const float u = *tt * ad.omtau + ad.tau * t;
+    *tt = u;
+    *tt_new = u;
+    return 3;
+  }
+  return 1;
 }
 
 __device__ __forceinline__ void adam_bias_corr(const AdamScalars& ad, float* step_size, float* bc2_sqrt) {
@@ -278,10 +292,10 @@ __device__ __forceinline__ void adam_bias_corr(const AdamScalars& ad, float* ste
   *bc2_sqrt = (float)sqrt(bc2);
 }
 
-__global__ __launch_bounds__(kThreads) void k_dw_adam(const DwArgs A) {
+__global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwArgs A) {
   constexpr int T = kDwTile, LD = T + 4;
-  __shared__ __attribute__((aligned(16))) float part[kWaves][T][LD];
-  __shared__ float bpart[kWaves][T];
+  __shared__ __attribute__((aligned(16))) float part[kDwWaves][T][LD];
+  __shared__ float bpart[kDwWaves][T];
   __shared__ float sc[2];
   const int tile = blockIdx.x;
   int it = 0;
@@ -292,6 +306,7 @@ __global__ __launch_bounds__(kThreads) void k_dw_adam(const DwArgs A) {
   const int n_base = tn * T, k_base = tk * T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, c = lane >> 4;
+  const int NSk = cdiv(I.K, 16), NSn = cdiv(I.N, 16);
   if (tid == 0) adam_bias_corr(A.ad, &sc[0], &sc[1]);
 
   f32x4 acc[2][2];
@@ -359,9 +374,17 @@ __global__ __launch_bounds__(kThreads) void k_dw_adam(const DwArgs A) {
           const float g = part[0][nl][kl0 + e] + part[1][nl][kl0 + e] + part[2][nl][kl0 + e] +
                           part[3][nl][kl0 + e];
           const size_t o = (size_t)n * I.K + k;
-          adam_polyak_elem(g, I.w + o, I.w_m ? I.w_m + o : nullptr, I.w_v ? I.w_v + o : nullptr,
-                           I.w_t ? I.w_t + o : nullptr, I.w_g ? I.w_g + o : nullptr, A.ad,
-                           step_size, bc2_sqrt);
+          float th_new, tt_new;
+          const int wrote = adam_polyak_elem(g, I.w + o, I.w_m ? I.w_m + o : nullptr,
+                                             I.w_v ? I.w_v + o : nullptr,
+                                             I.w_t ? I.w_t + o : nullptr,
+                                             I.w_g ? I.w_g + o : nullptr, A.ad, step_size, bc2_sqrt,
+                                             &th_new, &tt_new);
+          if (wrote & 1) {   // keep the fragment-order packs in step with the master
+            if (I.pf != nullptr) I.pf[pack_index(n, k, NSk)] = th_new;
+            if (I.pb != nullptr) I.pb[pack_index(k, n, NSn)] = th_new;
+          }
+          if ((wrote & 2) && I.tpf != nullptr) I.tpf[pack_index(n, k, NSk)] = tt_new;
         }
       }
     }
@@ -370,9 +393,10 @@ __global__ __launch_bounds__(kThreads) void k_dw_adam(const DwArgs A) {
     const int n = n_base + tid;
     if (n < I.N) {
       const float g = bpart[0][tid] + bpart[1][tid] + bpart[2][tid] + bpart[3][tid];
-      adam_polyak_elem(g, I.b + n, I.b_m ? I.b_m + n : nullptr, I.b_v ? I.b_v + n : nullptr,
-                       I.b_t ? I.b_t + n : nullptr, I.b_g ? I.b_g + n : nullptr, A.ad, step_size,
-                       bc2_sqrt);
+      float t0, t1;
+      (void)adam_polyak_elem(g, I.b + n, I.b_m ? I.b_m + n : nullptr, I.b_v ? I.b_v + n : nullptr,
+                             I.b_t ? I.b_t + n : nullptr, I.b_g ? I.b_g + n : nullptr, A.ad, step_size,
+                             bc2_sqrt, &t0, &t1);
     }
   }
 }
@@ -386,8 +410,11 @@ __global__ void k_adam_flat(float* th, float* m, float* v, float* tt, const floa
   const float step_size = sc[0], bc2_sqrt = sc[1];
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
        idx += (long)gridDim.x * blockDim.x)
-    adam_polyak_elem(g[idx], th + idx, m + idx, v + idx, tt ? tt + idx : nullptr, nullptr, ad,
-                     step_size, bc2_sqrt);
+  {
+    float t0, t1;
+    (void)adam_polyak_elem(g[idx], th + idx, m + idx, v + idx, tt ? tt + idx : nullptr, nullptr, ad,
+                           step_size, bc2_sqrt, &t0, &t1);
+  }
 }
 
 __global__ void k_polyak_flat(float* tt, const float* th, long n, float tau, float omtau) {
@@ -402,7 +429,7 @@ __global__ void k_polyak_flat(float* tt, const float* th, long n, float tau, flo
 __global__ void k_alpha_step(double* log_alpha, double* m, double* v, const float* logp, int B,
                              float target_entropy, double lr, double beta1, double beta2, double eps,
                              int step, double* grad_out, const double* grad_in, float grad_scale) {
-  __shared__ double red[kThreads];
+  __shared__ double red[256];
   double s = 0.0;
   if (grad_in == nullptr)
     for (int idx = threadIdx.x; idx < B; idx += blockDim.x) s += (double)logp[idx];
@@ -449,14 +476,15 @@ __global__ void k_reduce_partials(const float* partials, int n_slices, float* ou
 // drop the top `drop`, target[b, s] = r + (1-d) gamma (z_sorted[s] - alpha logp').
 // z layout: [n_nets][B][ldz];  target: [B][M], M = n_nets*Q - drop.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_tqc_target(const float* z, long net_stride, int ldz,
+constexpr int kTqcWaves = 4;
+__global__ __launch_bounds__(64 * kTqcWaves) void k_tqc_target(const float* z, long net_stride, int ldz,
                                                          int n_nets, int Q, int drop,
                                                          const float* r, const float* d,
                                                          const float* logp, const double* log_alpha,
                                                          float gamma, int B, float* target) {
-  __shared__ float buf[kWaves][128];
+  __shared__ float buf[kTqcWaves][128];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * kWaves + wave;
+  const int row = blockIdx.x * kTqcWaves + wave;
   const int total = n_nets * Q, M = total - drop;
   float* sb = buf[wave];
   if (row < B) {
@@ -491,6 +519,21 @@ __global__ __launch_bounds__(kThreads) void k_tqc_target(const float* z, long ne
   }
 }
 
+// master (row-major [N][K]) -> fragment-order packs; one 256-thread block per 256
+// consecutive elements of a layer.  Pad positions are never written (the pack
+// buffers are zeroed once at allocation).
+__global__ void k_repack(const RepackItem* items, int n_items) {
+  int it = 0;
+  while (it + 1 < n_items && (int)blockIdx.x >= items[it].blk_end) ++it;
+  const RepackItem I = items[it];
+  const long e = (long)(blockIdx.x - I.blk_begin) * 256 + threadIdx.x;
+  if (e >= (long)I.N * I.K) return;
+  const int n = (int)(e / I.K), k = (int)(e - (long)n * I.K);
+  const float w = I.w[e];
+  if (I.pf != nullptr) I.pf[pack_index(n, k, cdiv(I.K, 16))] = w;
+  if (I.pb != nullptr) I.pb[pack_index(k, n, cdiv(I.N, 16))] = w;
+}
+
 // ---------------------------------------------------------------------------
 // host-visible launchers
 // ---------------------------------------------------------------------------
@@ -519,7 +562,13 @@ hipError_t init_kernel_attrs() {
 }
 
 hipError_t launch_dw_adam(const DwArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_dw_adam, dim3(a.total_tiles), dim3(kThreads), 0, st, a);
+  hipLaunchKernelGGL(k_dw_adam, dim3(a.total_tiles), dim3(kDwThreads), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_repack(const RepackItem* items_dev, int n_items, int total_blocks, hipStream_t st) {
+  if (total_blocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_repack, dim3(total_blocks), dim3(256), 0, st, items_dev, n_items);
   return hipGetLastError();
 }
 
@@ -541,7 +590,7 @@ hipError_t launch_alpha_step(double* log_alpha, double* m, double* v, const floa
                              float target_entropy, double lr, double beta1, double beta2, double eps,
                              int step, double* grad_out, const double* grad_in, float grad_scale,
                              hipStream_t st) {
-  hipLaunchKernelGGL(k_alpha_step, dim3(1), dim3(kThreads), 0, st, log_alpha, m, v, logp, B,
+  hipLaunchKernelGGL(k_alpha_step, dim3(1), dim3(256), 0, st, log_alpha, m, v, logp, B,
                      target_entropy, lr, beta1, beta2, eps, step, grad_out, grad_in, grad_scale);
   return hipGetLastError();
 }
@@ -557,7 +606,7 @@ hipError_t launch_tqc_target(const float* z, long net_stride, int ldz, int n_net
                              const float* r, const float* d, const float* logp,
                              const double* log_alpha, float gamma, int B, float* target,
                              hipStream_t st) {
-  hipLaunchKernelGGL(k_tqc_target, dim3((B + kWaves - 1) / kWaves), dim3(kThreads), 0, st, z,
+  hipLaunchKernelGGL(k_tqc_target, dim3((B + kTqcWaves - 1) / kTqcWaves), dim3(64 * kTqcWaves), 0, st, z,
                      net_stride, ldz, n_nets, Q, drop, r, d, logp, log_alpha, gamma, B, target);
   return hipGetLastError();
 }

@@ -78,6 +78,7 @@ size_t mlp_slice_lds_bytes(int width, int n_layers);
 hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
 hipError_t init_kernel_attrs();
 hipError_t launch_dw_adam(const DwArgs& a, hipStream_t st);
+hipError_t launch_repack(const RepackItem* items_dev, int n_items, int total_blocks, hipStream_t st);
 hipError_t launch_adam_flat(float* th, float* m, float* v, float* tt, const float* g, long n,
                             const AdamScalars& ad, hipStream_t st);
 hipError_t launch_polyak_flat(float* tt, const float* th, long n, double tau, hipStream_t st);
@@ -141,9 +142,20 @@ int check_net(const oprl_net& n, const char* name, int* width) {
     return OPRL_ERR_INVALID;
   }
   if (!n.theta) { set_err("%s: theta is null", name); return OPRL_ERR_INVALID; }
+  if (!n.pack) { set_err("%s: pack buffer is null (see oprl_net_pack_floats)", name); return OPRL_ERR_INVALID; }
+  if (n.theta_target && !n.pack_target) { set_err("%s: pack_target is null", name); return OPRL_ERR_INVALID; }
   *width = w;
   return OPRL_OK;
 }
+
+// offsets (floats) of layer l's forward / backward pack inside a pack buffer
+long pack_off_fwd(const oprl_net& n, int l) {
+  long c = 0;
+  for (int j = 0; j < l; ++j) c += 2 * pack_floats(n.dims[j + 1], n.dims[j]);
+  return c;
+}
+long pack_off_bwd(const oprl_net& n, int l) { return pack_off_fwd(n, l) + pack_floats(n.dims[l + 1], n.dims[l]); }
+long net_pack_floats(const oprl_net& n) { return pack_off_fwd(n, n.n_layers); }
 
 Net net_view(const oprl_net& n, bool target) {
   Net v;
@@ -151,9 +163,11 @@ Net net_view(const oprl_net& n, bool target) {
   v.n_layers = n.n_layers;
   for (int l = 0; l <= n.n_layers; ++l) v.dims[l] = n.dims[l];
   const float* base = target ? n.theta_target : n.theta;
+  const float* pk = target ? n.pack_target : n.pack;
   for (int l = 0; l < n.n_layers; ++l) {
-    v.W[l] = base + w_off(n, l);
     v.b[l] = base + b_off(n, l);
+    v.pf[l] = pk + pack_off_fwd(n, l);
+    v.pb[l] = pk + pack_off_bwd(n, l);
   }
   return v;
 }
@@ -223,6 +237,9 @@ void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int*
     it.w_m = n.adam_m ? n.adam_m + wo : nullptr; it.b_m = n.adam_m ? n.adam_m + bo : nullptr;
     it.w_v = n.adam_v ? n.adam_v + wo : nullptr; it.b_v = n.adam_v ? n.adam_v + bo : nullptr;
     it.w_g = n.grad ? n.grad + wo : nullptr;     it.b_g = n.grad ? n.grad + bo : nullptr;
+    it.pf = n.pack + pack_off_fwd(n, l);
+    it.pb = n.pack + pack_off_bwd(n, l);
+    it.tpf = n.pack_target ? n.pack_target + pack_off_fwd(n, l) : nullptr;
     const int tn = (it.N + kDwTile - 1) / kDwTile;
     it.tiles_k = (it.K + kDwTile - 1) / kDwTile;
     it.tile_begin = *tiles;
@@ -488,6 +505,42 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
   return OPRL_OK;
 }
 
+// master -> packs for a list of nets (which: bit0 online, bit1 target).  The item
+// table goes through a small device scratch; synchronous on `st` only.
+int repack_nets(const oprl_net* const* nets, int n_nets, int which, hipStream_t st) {
+  std::vector<RepackItem> items;
+  int blocks = 0;
+  for (int i = 0; i < n_nets; ++i) {
+    const oprl_net& n = *nets[i];
+    for (int pass = 0; pass < 2; ++pass) {
+      if (!(which & (1 << pass))) continue;
+      const float* base = pass == 0 ? n.theta : n.theta_target;
+      float* pk = pass == 0 ? n.pack : n.pack_target;
+      if (!base || !pk) continue;
+      for (int l = 0; l < n.n_layers; ++l) {
+        RepackItem it;
+        it.w = base + w_off(n, l);
+        it.N = n.dims[l + 1]; it.K = n.dims[l];
+        it.pf = pk + pack_off_fwd(n, l);
+        it.pb = pass == 0 ? pk + pack_off_bwd(n, l) : nullptr;
+        it.blk_begin = blocks;
+        blocks += (int)(((long)it.N * it.K + 255) / 256);
+        it.blk_end = blocks;
+        items.push_back(it);
+      }
+    }
+  }
+  if (items.empty()) return OPRL_OK;
+  RepackItem* dev = nullptr;
+  HIPC(hipMalloc(&dev, sizeof(RepackItem) * items.size()));
+  hipError_t e = hipMemcpyAsync(dev, items.data(), sizeof(RepackItem) * items.size(), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = launch_repack(dev, (int)items.size(), blocks, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(dev);
+  HIPC(e);
+  return OPRL_OK;
+}
+
 bool actor_due(const oprl_learner* h) {
   return h->cfg.algo != OPRL_TD3 || (h->update_count % h->cfg.hp.policy_freq == 0);
 }
@@ -624,8 +677,36 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   if (hipMemcpy(h->items_dev, items.data(), sizeof(DwItem) * items.size(), hipMemcpyHostToDevice) != hipSuccess) {
     set_err("hipMemcpy(items) failed"); (void)hipFree(p.base); delete h; return OPRL_ERR_HIP;
   }
+  {
+    const oprl_net* nets[OPRL_MAX_CRITICS + 1];
+    for (int j = 0; j < nc; ++j) nets[j] = &h->cfg.critics[j];
+    nets[nc] = &h->cfg.actor;
+    int prc = repack_nets(nets, nc + 1, 3, nullptr);
+    if (prc != OPRL_OK) { (void)hipFree(p.base); delete h; return prc; }
+  }
   *out = h;
   return OPRL_OK;
+}
+
+extern "C" int oprl_learner_sync_params(oprl_learner* h, void* stream) {
+  if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
+  const oprl_net* nets[OPRL_MAX_CRITICS + 1];
+  for (int j = 0; j < h->nc; ++j) nets[j] = &h->cfg.critics[j];
+  nets[h->nc] = &h->cfg.actor;
+  return repack_nets(nets, h->nc + 1, 3, (hipStream_t)stream);
+}
+
+extern "C" int64_t oprl_net_pack_floats(const oprl_net* net) {
+  if (!net || net->n_layers < 1 || net->n_layers > OPRL_MAX_LAYERS) return -1;
+  return net_pack_floats(*net);
+}
+
+extern "C" int oprl_net_repack(const oprl_net* net, int32_t which, void* stream) {
+  if (!net) { set_err("oprl_net_repack: null net"); return OPRL_ERR_INVALID; }
+  int width = 0;
+  RC(check_net(*net, "net", &width));
+  const oprl_net* nets[1] = {net};
+  return repack_nets(nets, 1, which, (hipStream_t)stream);
 }
 
 extern "C" int oprl_learner_destroy(oprl_learner* h) {
@@ -677,7 +758,9 @@ extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, double grad_sc
       ad.do_adam = 1;
       HIPC(launch_adam_flat(n.theta, n.adam_m, n.adam_v, n.theta_target, n.grad, net_param_count(n), ad, st));
     }
-    return OPRL_OK;
+    const oprl_net* nets[OPRL_MAX_CRITICS];
+    for (int j = 0; j < h->nc; ++j) nets[j] = &c.critics[j];
+    return repack_nets(nets, h->nc, polyak ? 3 : 1, st);
   }
   if (phase == 1) {
     if (!h->actor_updated_last) return OPRL_OK;
@@ -685,6 +768,10 @@ extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, double grad_sc
     AdamScalars ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, n.theta_target != nullptr, (float)grad_scale);
     ad.do_adam = 1;
     HIPC(launch_adam_flat(n.theta, n.adam_m, n.adam_v, n.theta_target, n.grad, net_param_count(n), ad, st));
+    {
+      const oprl_net* nets[1] = {&n};
+      RC(repack_nets(nets, 1, 3, st));
+    }
     if (alpha_ptr(h) != nullptr)
       HIPC(launch_alpha_step(c.log_alpha, c.log_alpha_m, c.log_alpha_v, nullptr, 1, (float)c.hp.target_entropy,
                              c.hp.lr_alpha, c.hp.beta1, c.hp.beta2, c.hp.adam_eps, h->opt_step_alpha,

@@ -19,7 +19,7 @@ def load_params(module, params):
     with t.no_grad():
         for dst, src in zip(ps, params):
             assert dst.shape == src.shape, (dst.shape, src.shape)
-            dst.data.copy_(src)          # in place: parameters stay views of the arena
+            dst.copy_(src)               # in place (bumps _version): parameters stay arena views
 
 
 def cpu_params(module):

@@ -38,8 +38,9 @@ def _mk(dims, seed):
     p = fx.make_net(seed, dims)
     mlp = nnm.MLP(dims[0], dims[-1], tuple(dims[1:-1]), hidden_activation=nn.ReLU()).cuda()
     nnm.flatten_module_(mlp)
-    for dst, src in zip(mlp.parameters(), p):
-        dst.data.copy_(src)
+    with t.no_grad():
+        for dst, src in zip(mlp.parameters(), p):
+            dst.copy_(src)
     return p, mlp
 
 
@@ -78,7 +79,8 @@ def test_mlp_backward_matches_oracle(dims, B):
     grads, dx = orc.mlp_backward(p, acts, dout, need_dx=want_dx)
     arena = mlp._oprl_arena
     grad = t.zeros_like(arena)
-    desc = nnm._net_desc(dims, arena.data_ptr(), grad_ptr=grad.data_ptr())
+    desc = nnm._net_desc(dims, arena.data_ptr(), grad_ptr=grad.data_ptr(),
+                         pack_ptr=mlp.ensure_packed().data_ptr())
     xg, dg = x.cuda(), dout.cuda().contiguous()
     dxg = t.zeros((B, dims[0]), device="cuda") if want_dx else None
     _capi.check(lib.oprl_mlp_backward(C.byref(desc), _capi.ptr(xg), dims[0], None, 0, B, _capi.ptr(dg),
