@@ -94,9 +94,14 @@ __device__ __forceinline__ T pick(const T (&arr)[N], int idx) {
 // next to its use (observed: one miss latency per macro step), hence the
 // sched_barriers.
 // ---------------------------------------------------------------------------
+// `sync_first`: the workgroup barrier that makes X visible is taken AFTER the
+// first ring of weight loads has been issued (weights do not depend on X), so
+// the miss latency of a layer's first fragments overlaps the previous layer's
+// tail instead of following it.  All waves of the workgroup must call with the
+// same flag, exactly once per GEMM (callers pass it for a wave's first tile).
 __device__ __forceinline__ void tile_mac(const float* __restrict__ Xs, int ldx,
                                          const float* __restrict__ ptile, int s0, int s1,
-                                         f32x4& acc) {
+                                         f32x4& acc, bool sync_first) {
   const int lane = threadIdx.x & 63;
   const float* xrow = Xs + (lane & 15) * ldx + 4 * (lane >> 4);
   const float* pl = ptile + lane * 4;
@@ -107,6 +112,10 @@ __device__ __forceinline__ void tile_mac(const float* __restrict__ Xs, int ldx,
     for (int d = 0; d < kRing; ++d)
       if (sb + d < s1) b[d] = ld4(pl + (size_t)(sb + d) * 256);
     __builtin_amdgcn_sched_barrier(0);
+    if (sync_first && sb == s0) {
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int d = 0; d < kRing; ++d) {
       if (sb + d < s1) {
@@ -126,8 +135,10 @@ __device__ __forceinline__ void tile_mac(const float* __restrict__ Xs, int ldx,
 //   NT <  kWaves ("narrow", NT <= 8): the waves split the contraction of each
 //       tile, partial tiles meet in `scratch` ([kWaves][kR][16] floats), then
 //       epi runs once per element.  Contains the barriers it needs for that.
-// X must be zero padded to 16*NS columns.  Caller syncs before (X complete) and
-// after (OUT complete) in the wide case; the narrow case ends with a barrier.
+// X must be zero padded to 16*NS columns.  The routine takes the barrier that
+// makes X visible itself (after issuing its first weight loads, see tile_mac);
+// the caller syncs after (OUT complete) in the wide case, the narrow case ends
+// with a barrier.  OUT must not alias X.
 // ---------------------------------------------------------------------------
 template <class Epi>
 __device__ __forceinline__ void gemm_packed(const float* __restrict__ Xs, int ldx,
@@ -139,7 +150,7 @@ __device__ __forceinline__ void gemm_packed(const float* __restrict__ Xs, int ld
 #pragma unroll 1
     for (int tile = wave; tile < NT; tile += kWaves) {
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      tile_mac(Xs, ldx, pack + (size_t)tile * NS * 256, 0, NS, acc);
+      tile_mac(Xs, ldx, pack + (size_t)tile * NS * 256, 0, NS, acc, tile == wave);
 #pragma unroll
       for (int r = 0; r < 4; ++r) epi(kk * 4 + r, 16 * tile + i, acc[r]);
     }
@@ -147,10 +158,12 @@ __device__ __forceinline__ void gemm_packed(const float* __restrict__ Xs, int ld
     const int wpt = kWaves / NT;            // waves per tile
     const int tile = wave / wpt, part = wave - tile * wpt;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tile < NT) {
-      const int per = cdiv(NS, wpt);
-      const int s0 = part * per, s1 = min(NS, s0 + per);
-      if (s0 < s1) tile_mac(Xs, ldx, pack + (size_t)tile * NS * 256, s0, s1, acc);
+    const int per = cdiv(NS, wpt);
+    const int s0 = part * per, s1 = min(NS, s0 + per);
+    if (tile < NT && s0 < s1) {
+      tile_mac(Xs, ldx, pack + (size_t)tile * NS * 256, s0, s1, acc, true);
+    } else {
+      __syncthreads();   // idle wave: still owes the X-visibility barrier
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) scratch[(wave * kR + kk * 4 + r) * 16 + i] = acc[r];
@@ -246,7 +259,8 @@ struct SliceLds {
   __host__ __device__ static constexpr int total(int n_h) { return scr_off(n_h) + kWaves * kR * 16; }
 };
 
-// Forward.  x0 must be loaded (and zero padded) by the caller, barrier included.
+// Forward.  x0 must be loaded (and zero padded) by the caller; NO barrier is
+// needed after that (the first GEMM takes it).
 // Hidden layer l's output goes to hbase + l*kR*WL.  If store_x the inputs of
 // layers 1.. (the hidden activations) are also stored to Xg[l] ([B, WIDTH]).
 // Result: outS[kR][kOutLd] columns [0, dims[L]); pad columns up to the next
@@ -266,7 +280,6 @@ __device__ __forceinline__ void mlp_forward_slice(const Net& net, const float* x
     gemm_packed(x0s, kX0Ld, net.pf[0], NTW, cdiv(net.dims[0], 16), scr,
                 [&](int row, int col, float v) { Ys[row * WL + col] = fmaxf(v + bias[col], 0.f); });
   }
-  __syncthreads();
   stamp();
 #pragma unroll
   for (int l = 1; l < kMaxLayers - 1; ++l) {
@@ -275,14 +288,8 @@ __device__ __forceinline__ void mlp_forward_slice(const Net& net, const float* x
       float* Ys = hbase + l * HB;
       gemm_packed(hbase + (l - 1) * HB, WL, net.pf[l], NTW, NTW, scr,
                   [&](int row, int col, float v) { Ys[row * WL + col] = fmaxf(v + bias[col], 0.f); });
-      __syncthreads();
       stamp();
     }
-  }
-  if (store_x) {
-#pragma unroll
-    for (int l = 1; l < kMaxLayers; ++l)
-      if (l < L) store_rows4(hbase + (l - 1) * HB, WL, Xg[l], WIDTH, WIDTH, row0, B);
   }
   {
     const int N = pick(net.dims, L);
@@ -290,11 +297,17 @@ __device__ __forceinline__ void mlp_forward_slice(const Net& net, const float* x
     gemm_packed(hbase + (L - 2) * HB, WL, pick(net.pf, L - 1), cdiv(N, 16), NTW, scr,
                 [&](int row, int col, float v) { outS[row * kOutLd + col] = col < N ? v + bias[col] : 0.f; });
   }
+  // (the narrow GEMM ended with a barrier: every hidden buffer is complete)
+  if (store_x) {
+#pragma unroll
+    for (int l = 1; l < kMaxLayers; ++l)
+      if (l < L) store_rows4(hbase + (l - 1) * HB, WL, Xg[l], WIDTH, WIDTH, row0, B);
+  }
 }
 
 // Backward.  On entry doutS[kR][kOutLd] holds dLoss/d(out) with ZERO padding up
-// to round_up(dims[L],16) columns and the hidden buffers hold the forward
-// activations.  The gradient wrt hidden layer l's pre-activation output is
+// to round_up(dims[L],16) columns (no barrier needed after writing it) and the
+// hidden buffers hold the forward activations.  The gradient wrt hidden layer l's pre-activation output is
 // written IN PLACE over hidden buffer l (each element's ReLU mask is read by the
 // lane that overwrites it) and, if dYg[l] != nullptr, to dYg[l] ([B,WIDTH]) for
 // the dW kernel; the caller stores dY[L-1] = dout itself.  If dact_cols > 0 the
@@ -321,8 +334,10 @@ __device__ __forceinline__ void mlp_backward_slice(const Net& net, const float* 
         float* p = dx + row * WL + col;
         *p = *p > 0.f ? v : 0.f;
       });
-      __syncthreads();
-      if (dYg[l - 1] != nullptr) store_rows4(dx, WL, dYg[l - 1], WIDTH, WIDTH, row0, B);
+      if (dYg[l - 1] != nullptr) {
+        __syncthreads();
+        store_rows4(dx, WL, dYg[l - 1], WIDTH, WIDTH, row0, B);
+      }
       stamp();
       dy = dx;
       ldy = WL;

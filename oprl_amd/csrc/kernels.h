@@ -92,6 +92,7 @@ struct AdamScalars {
   // torch does with its python-float scalars (1.f - 0.999f is off by 1.3e-5 rel.)
   float omb1, omb2, omtau;
   double lr_d, beta1_d, beta2_d;       // the python-double hyper-parameters, for the bias corrections
+  float step_size_host, bc2_sqrt_host; // lr/(1-b1^t), sqrt(1-b2^t) when the host knows t
   int step_base; const int* step_dev;  // Adam step = step_base + (step_dev ? *step_dev : 0)
   float tau; int do_polyak;
   int do_adam;                         // 0: only export grads

@@ -65,10 +65,9 @@ __global__ __launch_bounds__(kThreads) void k_mlp_slice(const MlpArgs A) {
     __syncthreads();
     load_rows(x0s, kX0Ld, 0, A.x0, A.k0, A.k0, row0, B);
     if (A.x1 != nullptr) load_rows(x0s, kX0Ld, A.k0, A.x1, A.k1, A.k1, row0, B);
-    __syncthreads();
-    if (A.Xg[0] != nullptr) store_rows(x0s, kX0Ld, A.Xg[0], A.ldx0, A.net.dims[0], row0, B);
     stamp();  // 1: inputs in LDS
     mlp_forward_slice<WIDTH>(A.net, x0s, hb, outS, scr, A.Xg, A.Xg[1] != nullptr, row0, B, stamp);
+    if (A.Xg[0] != nullptr) store_rows(x0s, kX0Ld, A.Xg[0], A.ldx0, A.net.dims[0], row0, B);
     stamp();  // after narrow output layer
     // ---- output head ------------------------------------------------------
     if (A.out_act == ACT_GAUSS) {
@@ -285,7 +284,12 @@ __device__ __forceinline__ int adam_polyak_elem(float g, float* th, float* m, fl
 }
 
 __device__ __forceinline__ void adam_bias_corr(const AdamScalars& ad, float* step_size, float* bc2_sqrt) {
-  const int step = ad.step_base + (ad.step_dev != nullptr ? *ad.step_dev : 0);
+  if (ad.step_dev == nullptr) {   // host knows the step: corrections arrive precomputed (double math)
+    *step_size = ad.step_size_host;
+    *bc2_sqrt = ad.bc2_sqrt_host;
+    return;
+  }
+  const int step = ad.step_base + *ad.step_dev;
   const double bc1 = 1.0 - pow(ad.beta1_d, (double)step);
   const double bc2 = 1.0 - pow(ad.beta2_d, (double)step);
   *step_size = (float)(ad.lr_d / bc1);

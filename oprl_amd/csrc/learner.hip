@@ -277,12 +277,18 @@ void set_adam(AdamScalars& ad, double lr, double beta1, double beta2, double eps
   ad.lr_d = lr; ad.beta1_d = beta1; ad.beta2_d = beta2;
 }
 
+void set_step(AdamScalars& ad, int step) {
+  ad.step_base = step; ad.step_dev = nullptr;
+  ad.step_size_host = (float)(ad.lr_d / (1.0 - pow(ad.beta1_d, (double)step)));
+  ad.bc2_sqrt_host = (float)sqrt(1.0 - pow(ad.beta2_d, (double)step));
+}
+
 AdamScalars adam_scalars(const oprl_learner* h, double lr, int step, bool polyak, float grad_scale) {
   AdamScalars ad;
   memset(&ad, 0, sizeof ad);
   const oprl_hparams& hp = h->cfg.hp;
   set_adam(ad, lr, hp.beta1, hp.beta2, hp.adam_eps, hp.tau);
-  ad.step_base = step; ad.step_dev = nullptr;
+  set_step(ad, step);
   ad.do_polyak = polyak ? 1 : 0;
   ad.do_adam = h->cfg.export_grads ? 0 : 1;
   ad.grad_scale = grad_scale;
@@ -930,7 +936,7 @@ extern "C" int oprl_mlp_backward(const oprl_net* net, const float* x0, int32_t k
   dw.items = items_dev; dw.n_items = (int)items.size(); dw.total_tiles = tiles; dw.B = B;
   memset(&dw.ad, 0, sizeof dw.ad);
   set_adam(dw.ad, 0.0, 0.9, 0.999, 1e-8, 0.0);
-  dw.ad.step_base = 1; dw.ad.grad_scale = 1.0f; dw.ad.do_adam = 0;
+  set_step(dw.ad, 1); dw.ad.grad_scale = 1.0f; dw.ad.do_adam = 0;
   HIPC(launch_dw_prof(dw, st));
   return OPRL_OK;
 }
@@ -942,7 +948,7 @@ extern "C" int oprl_adam_step(float* theta, float* m, float* v, const float* gra
   AdamScalars ad;
   memset(&ad, 0, sizeof ad);
   set_adam(ad, lr, beta1, beta2, eps, 0.0);
-  ad.step_base = step; ad.do_adam = 1; ad.grad_scale = (float)grad_scale;
+  set_step(ad, step); ad.do_adam = 1; ad.grad_scale = (float)grad_scale;
   HIPC(launch_adam_flat(theta, m, v, nullptr, grad, (long)n, ad, (hipStream_t)stream));
   return OPRL_OK;
 }

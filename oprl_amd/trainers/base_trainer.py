@@ -1,0 +1,101 @@
+"""Single-process training loop: env step -> buffer.add_transition ->
+buffer.sample -> algo.update, once per env step — the caller of the hot path
+(reference: /root/reference/src/oprl/trainers/base_trainer.py:38-120, row N1 of
+SURVEY.md §8f).  Same fields and call order; the per-step work underneath
+(sample + update) is the HIP path.  Logging reads GPU scalars only at the
+logging cadence, so there is no per-step host sync."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable
+
+import numpy as np
+import torch as t
+
+from oprl_amd.algos.protocols import AlgorithmProtocol
+from oprl_amd.buffers.protocols import ReplayBufferProtocol
+from oprl_amd.environment.protocols import EnvProtocol
+from oprl_amd.logging import LoggerProtocol, create_stdout_logger
+from oprl_amd.trainers.protocols import TrainerProtocol
+
+logger = create_stdout_logger()
+
+
+@dataclass
+class BaseTrainer(TrainerProtocol):
+    logger: LoggerProtocol
+    env: EnvProtocol
+    make_env_test: Callable[[int], EnvProtocol]
+    replay_buffer: ReplayBufferProtocol
+    algo: AlgorithmProtocol
+    gamma: float = 0.99
+    num_steps: int = int(1e6)
+    start_steps: int = int(10e3)
+    batch_size: int = 128          # the reference's effective batch (SURVEY.md §8d caveat)
+    eval_interval: int = int(2e3)
+    num_eval_episodes: int = 10
+    save_buffer_every: int = 0
+    save_policy_every: int = int(100_000)
+    estimate_q_every: int = 0
+    stdout_log_every: int = int(1e5)
+    device: str = "cuda"
+    seed: int = 0
+
+    def train(self) -> None:
+        self.algo.check_created()
+        self.replay_buffer.check_created()
+        state, _ = self.env.reset()
+        for env_step in range(self.num_steps + 1):
+            if env_step <= self.start_steps:
+                action = self.env.sample_action()
+            else:
+                action = self.algo.actor.explore(state)
+            next_state, reward, terminated, truncated, _ = self.env.step(action)
+            self.replay_buffer.add_transition(state, action, reward, terminated,
+                                              episode_done=terminated or truncated)
+            if terminated or truncated:
+                next_state, _ = self.env.reset()
+            state = next_state
+            if len(self.replay_buffer) < self.batch_size:
+                continue
+            batch = self.replay_buffer.sample(self.batch_size)
+            self.algo.update(*batch)
+            rewards = batch[2]
+            self._log_evaluation(env_step, rewards)
+            self._save_policy(env_step)
+            self._log_stdout(env_step, rewards)
+
+    def _log_evaluation(self, env_step: int, rewards: t.Tensor) -> None:
+        if env_step % self.eval_interval != 0:
+            return
+        metrics = self.evaluate()
+        rb = self.replay_buffer
+        self.logger.log_scalar("trainer/ep_reward", metrics["return"], env_step)
+        self.logger.log_scalar("trainer/avg_reward", rewards.mean().item(), env_step)
+        self.logger.log_scalar("trainer/buffer_transitions", len(rb), env_step)
+        self.logger.log_scalar("trainer/buffer_episodes", rb.episodes_counter, env_step)
+        self.logger.log_scalar("trainer/buffer_last_ep_len", rb.last_episode_length, env_step)
+
+    def evaluate(self) -> dict[str, float]:
+        returns = []
+        for i_ep in range(self.num_eval_episodes):
+            env_test = self.make_env_test(self.seed + i_ep)
+            state, _ = env_test.reset()
+            total, done = 0.0, False
+            while not done:
+                state, reward, terminated, truncated, _ = env_test.step(self.algo.actor.exploit(state))
+                total += reward
+                done = terminated or truncated
+            returns.append(total)
+        return {"return": float(np.mean(returns))}
+
+    def _save_policy(self, env_step: int) -> None:
+        if self.save_policy_every > 0 and env_step % self.save_policy_every == 0:
+            path = self.logger.log_dir / "weights" / f"{env_step}.w"
+            path.parent.mkdir(parents=True, exist_ok=True)
+            t.save(self.algo.actor, path)
+
+    def _log_stdout(self, env_step: int, rewards: t.Tensor) -> None:
+        if env_step % self.stdout_log_every == 0:
+            perc = int(env_step / max(self.num_steps, 1) * 100)
+            logger.info(f"Env step {env_step:8d} ({perc:2d}%) Avg Reward {rewards.mean().item():10.3f}")

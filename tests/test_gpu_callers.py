@@ -1,0 +1,162 @@
+"""GPU tests of the callers either side of the hot path:
+trainer loop end to end, fused step_n == python sample()+update() loop,
+export_grads split == fused update, policy save / load interop."""
+import io
+
+import numpy as np
+import pytest
+import torch as t
+
+from oracle import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+
+def _ddpg(**kw):
+    from oprl_amd.algos.ddpg import DDPG
+    from oprl_amd.logging import NullLogger
+    t.manual_seed(0)
+    return DDPG(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", **kw).create()
+
+
+def _filled_buffer(n_eps=6, L=50, seed=3):
+    from oprl_amd.buffers.episodic_buffer import EpisodicReplayBuffer
+    buf = EpisodicReplayBuffer(buffer_size_transitions=n_eps * L, state_dim=24, action_dim=6,
+                               max_episode_lenth=L, device="cuda", seed=seed).create()
+    rs = np.random.RandomState(0)
+    for e in range(n_eps - 1):
+        for i in range(L - e):
+            buf.add_transition(rs.standard_normal(24).astype(np.float32), rs.uniform(-1, 1, 6),
+                               float(rs.uniform()), False, episode_done=(i == L - e - 1))
+    return buf
+
+
+def test_step_n_equals_python_loop_bitwise():
+    K, B = 12, 64
+    a1, a2 = _ddpg(max_batch=B), _ddpg(max_batch=B)
+    assert t.equal(a1.actor._oprl_arena, a2.actor._oprl_arena)
+    buf = _filled_buffer()
+    a1.learner.step_n(buf.handle, K, B, seed=7)
+    buf.seed = 7
+    for k in range(K):
+        buf._sample_counter = k
+        a2.update(*buf.sample(B))
+    t.cuda.synchronize()
+    for m in ("actor", "critic", "actor_target", "critic_target"):
+        assert t.equal(getattr(a1, m)._oprl_arena, getattr(a2, m)._oprl_arena), m
+    assert a1.update_step == a2.update_step == K
+
+
+def test_export_grads_split_equals_fused_update():
+    fused, split = _ddpg(), _ddpg(export_grads=True)
+    for step in range(3):
+        batch = [x.cuda() for x in fx.make_batch(50 + step, 256, 24, 6)]
+        fused.update(*batch)
+        L = split.learner
+        L.update_phase(0, *batch); L.apply(0, 1.0)
+        L.update_phase(1, *batch); L.apply(1, 1.0)
+    t.cuda.synchronize()
+    for m in ("actor", "critic", "actor_target", "critic_target"):
+        a, b = getattr(fused, m)._oprl_arena, getattr(split, m)._oprl_arena
+        assert (a - b).abs().max().item() <= 1e-7 * max(1.0, a.abs().max().item()), m
+    # packs were rebuilt by apply(): the module forward (reads packs) agrees with the masters
+    s, a, *_ = (x.cuda() for x in fx.make_batch(99, 64, 24, 6))
+    q_split = split.critic(s, a)
+    split.critic.q1.mark_dirty()          # force a rebuild from the master
+    assert t.equal(q_split, split.critic(s, a))
+
+
+def test_load_state_dict_is_picked_up_by_the_learner():
+    algo = _ddpg()
+    other = _ddpg()
+    with t.no_grad():
+        for p in other.actor.parameters():
+            p.mul_(0.5)
+    algo.actor.load_state_dict(other.actor.state_dict())       # bumps versions -> packs resync
+    s = t.randn(32, 24, device="cuda")
+    assert t.equal(algo.actor(s), other.actor(s))
+    batch = [x.cuda() for x in fx.make_batch(5, 256, 24, 6)]
+    algo.update(*batch)                                        # must see the loaded weights
+    ref = _ddpg()
+    ref.actor.load_state_dict(other.actor.state_dict())
+    ref.update(*batch)
+    t.cuda.synchronize()
+    assert t.equal(algo.actor._oprl_arena, ref.actor._oprl_arena)
+
+
+def test_policy_save_load_interop_with_plain_cpu_module():
+    from oprl_amd.algos.nn_models import DeterministicPolicy
+    algo = _ddpg()
+    algo.update(*[x.cuda() for x in fx.make_batch(1, 128, 24, 6)])
+    buf = io.BytesIO()
+    t.save(algo.actor, buf)                 # whole-module pickle, like base_trainer.py:113-120
+    buf.seek(0)
+    loaded = t.load(buf, weights_only=False)
+    obs = np.random.RandomState(0).standard_normal(24).astype(np.float32)
+    assert np.allclose(loaded.exploit(obs), algo.actor.exploit(obs), atol=1e-6)
+    cpu_policy = DeterministicPolicy(24, 6, device="cpu")      # what an actor process holds
+    cpu_policy.load_state_dict({k: v.cpu() for k, v in algo.get_policy_state_dict().items()})
+    assert np.allclose(cpu_policy.exploit(obs), algo.actor.exploit(obs), atol=1e-5)
+    assert list(algo.actor.state_dict()) == [f"mlp.nn.{i}.{w}" for i in (0, 2, 4) for w in ("weight", "bias")]
+
+
+def test_trainer_end_to_end_on_synthetic_env():
+    from oprl_amd.buffers.episodic_buffer import EpisodicReplayBuffer
+    from oprl_amd.environment import make_env
+    from oprl_amd.logging import NullLogger
+    from oprl_amd.trainers.base_trainer import BaseTrainer
+    algo = _ddpg()
+    before = algo.actor._oprl_arena.clone()
+    buf = EpisodicReplayBuffer(buffer_size_transitions=2000, state_dim=24, action_dim=6,
+                               max_episode_lenth=100, device="cuda").create()
+    env = lambda seed: __import__("oprl_amd.environment.synthetic", fromlist=["SyntheticEnv"]).SyntheticEnv(
+        "walker-walk", seed=seed, episode_length=100)
+    BaseTrainer(logger=NullLogger("/tmp/oprl_amd_test"), env=env(0), make_env_test=env, replay_buffer=buf,
+                algo=algo, num_steps=400, start_steps=150, batch_size=32, eval_interval=250,
+                num_eval_episodes=1, save_policy_every=0, stdout_log_every=10 ** 9).train()
+    t.cuda.synchronize()
+    assert algo.update_step == 401 - 31
+    assert t.isfinite(algo.actor._oprl_arena).all() and not t.equal(before, algo.actor._oprl_arena)
+    assert len(buf) == 401 and buf.episodes_counter == 5
+
+
+def test_distributed_learner_with_in_host_actors():
+    """Two CPU actor processes feed the GPU learner through the in-host queues."""
+    from oprl_amd.algos.nn_models import DeterministicPolicy
+    from oprl_amd.buffers.episodic_buffer import EpisodicReplayBuffer
+    from oprl_amd.environment.synthetic import SyntheticEnv
+    from oprl_amd.logging import NullLogger
+    from oprl_amd.runners.config import DistribConfig
+    from oprl_amd.runners.train_distrib import run_distrib_training
+    from tests import test_gpu_callers as me
+    cfg = DistribConfig(batch_size=32, num_env_workers=2, episodes_per_worker=4, warmup_epochs=0,
+                        episode_length=40, learner_num_waits=20, warmup_env_steps=40)
+    run_distrib_training(make_env=me._mk_env, make_algo=me._mk_algo, make_policy=me._mk_policy,
+                         make_replay_buffer=me._mk_buffer, make_logger=me._mk_logger, config=cfg,
+                         max_epochs=4)
+
+
+def _mk_env(seed=0):
+    from oprl_amd.environment.synthetic import SyntheticEnv
+    return SyntheticEnv("walker-walk", seed=seed, episode_length=40)
+
+
+def _mk_policy():
+    from oprl_amd.algos.nn_models import DeterministicPolicy
+    return DeterministicPolicy(24, 6, device="cpu")
+
+
+def _mk_algo(logger):
+    from oprl_amd.algos.ddpg import DDPG
+    return DDPG(logger=logger, state_dim=24, action_dim=6, device="cuda").create()
+
+
+def _mk_buffer():
+    from oprl_amd.buffers.episodic_buffer import EpisodicReplayBuffer
+    return EpisodicReplayBuffer(buffer_size_transitions=4000, state_dim=24, action_dim=6,
+                                max_episode_lenth=40, device="cuda").create()
+
+
+def _mk_logger():
+    from oprl_amd.logging import NullLogger
+    return NullLogger("/tmp/oprl_amd_test")
