@@ -92,6 +92,8 @@ typedef struct oprl_learner_config {
   int32_t state_dim, action_dim;
   int32_t max_batch;        /* workspace is sized for this many rows */
   int32_t n_critics;        /* 1 DDPG, 2 TD3/SAC, n_nets TQC */
+  int32_t no_fuse;          /* 1: always use the generic per-net launch sequence (DDPG
+                               otherwise runs the fused two-kernel path, csrc/fused_ddpg.hip) */
   int32_t export_grads;     /* 1: update() stops before Adam and leaves grads in
                                net.grad (data-parallel learner reduces them, then
                                calls oprl_learner_apply); 0: fused dW+Adam+Polyak */

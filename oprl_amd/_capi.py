@@ -55,6 +55,7 @@ class OprlLearnerConfig(C.Structure):
         ("state_dim", C.c_int32), ("action_dim", C.c_int32),
         ("max_batch", C.c_int32),
         ("n_critics", C.c_int32),
+        ("no_fuse", C.c_int32),
         ("export_grads", C.c_int32),
         ("actor", OprlNet),
         ("critics", OprlNet * OPRL_MAX_CRITICS),

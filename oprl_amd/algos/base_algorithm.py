@@ -53,7 +53,8 @@ class HipLearner:
                  critic_group: nn.Module, critic_mlps: Sequence[MLP],
                  critic_target_group: nn.Module, critic_target_mlps: Sequence[MLP],
                  hp: dict, max_batch: int, export_grads: bool = False,
-                 log_alpha: t.Tensor | None = None, actor_target_group: nn.Module | None = None):
+                 log_alpha: t.Tensor | None = None, actor_target_group: nn.Module | None = None,
+                 no_fuse: bool = False):
         self.lib = _capi.load()
         self.device = device
         self.S, self.A = state_dim, action_dim
@@ -88,6 +89,7 @@ class HipLearner:
         cfg.max_batch = self.max_batch
         cfg.n_critics = len(critic_mlps)
         cfg.export_grads = int(export_grads)
+        cfg.no_fuse = int(no_fuse)
 
         def off(arena: t.Tensor, mlp: MLP) -> int:
             return mlp.theta_ptr() - arena.data_ptr()

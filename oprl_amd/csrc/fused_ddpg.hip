@@ -1,0 +1,276 @@
+// fused_ddpg.hip — the DDPG update() as two slice kernels + two dW/Adam launches.
+//
+// The generic path (learner.hip) spends 6 k_mlp_slice launches + a gather per
+// update; every launch pays dispatch, an input-load latency chain and an LDS
+// re-zero, and the actor's forward — which does not depend on the critic step —
+// sits on the critical path.  Here:
+//
+//   k_ddpg_phase1, grid (slices, 2):
+//     y = 0  [gather 16 rows] -> actor_target(s') -> critic_target(s', a')
+//            -> y = r + (1-d) gamma q' -> critic(s, a) forward -> 2(q-y)/B
+//            -> critic backward                       (ddpg.py:86-101)
+//     y = 1  [gather the same rows] -> actor(s) forward, activations and
+//            pi = tanh(.) to HBM                      (first half of ddpg.py:104)
+//   k_dw_adam(critic)          dW + Adam + Polyak     (ddpg.py:99-101, 72-77)
+//   k_ddpg_phase2, grid (slices):
+//            critic(s, pi) forward with the UPDATED critic -> -1/B -> critic
+//            backward to the action columns -> du = da (1 - pi^2) -> actor
+//            backward                                  (ddpg.py:103-107)
+//   k_dw_adam(actor)           dW + Adam + Polyak     (ddpg.py:105-107, 79-84)
+//
+// Arithmetic and summation order are those of the generic kernels (same
+// engine.h routines, same seeds), so the two paths agree bit for bit
+// (tests/test_gpu_fused.py).  The minibatch either comes from caller pointers
+// (update()) or is gathered in-kernel from the HBM replay with the same Philox
+// draw and index map as k_replay_gather (step_n).
+#include "kernels.h"
+#include "philox.h"
+
+namespace oprl {
+
+constexpr int kMaxEnds = 2048;
+
+template <int WIDTH>
+struct FusedLds {   // floats
+  static constexpr int WL = lds_ld(WIDTH);
+  static constexpr int xa = 0;                       // [s | a] (phase 2: [s | pi])
+  static constexpr int xb = xa + kR * kX0Ld;         // [s' | a']
+  static constexpr int h = xb + kR * kX0Ld;          // 4 hidden buffers
+  static constexpr int out = h + 4 * kR * WL;
+  static constexpr int aux = out + kR * kOutLd;
+  static constexpr int scr = aux + kR * kOutLd;
+  static constexpr int misc = scr + kWaves * kR * 16;   // r[16] d[16] y[16] ep[16] t[16] + ends
+  static constexpr int total = misc + 96 + kMaxEnds;
+};
+
+// rows [row0, row0+kR) of the minibatch -> xa = [s | a | 0], xb = [s' | 0], r, d (LDS)
+__device__ __forceinline__ void load_batch(const BatchSrc& P, int row0, int B, int S, int A,
+                                           float* xa, float* xb, float* rS, float* dS, int* meta,
+                                           int* endsS) {
+  const int tid = threadIdx.x;
+  lds_zero(xa, 2 * kR * kX0Ld);   // xa and xb are adjacent
+  if (P.gather) {
+    const bool in_lds = P.n_eps <= kMaxEnds;
+    if (in_lds)
+      for (int e = tid; e < P.n_eps; e += kThreads) endsS[e] = P.ends[e];
+    __syncthreads();
+    const int* ends = in_lds ? endsS : P.ends;
+    if (tid < kR) {
+      const int i = row0 + tid;
+      int e = 0, t = 0;
+      if (i < B) {
+        const u32x4 rnd = philox4x32_10(
+            u32x4{(uint32_t)P.counter, (uint32_t)(P.counter >> 32), (uint32_t)i, 0x5a17u},
+            (uint32_t)P.seed, (uint32_t)(P.seed >> 32));
+        const long ind = (long)bounded_u32(rnd.x, (uint32_t)P.n_transitions);
+        int lo = 0, hi = P.n_eps;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if ((long)ends[mid] > ind) hi = mid; else lo = mid + 1;
+        }
+        e = lo < P.n_eps ? lo : 0;
+        t = (int)(ind - (e > 0 ? (long)ends[e - 1] : 0));
+      }
+      meta[tid] = e;
+      meta[kR + tid] = t;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < kR * (2 * S + A + 2); idx += kThreads) {
+      const int W = 2 * S + A + 2;
+      const int row = idx / W, c = idx - row * W;
+      if (row0 + row >= B) continue;
+      const long e = meta[row], t = meta[kR + row];
+      if (c < S) xa[row * kX0Ld + c] = P.states[(e * (P.L + 1) + t) * S + c];
+      else if (c < 2 * S) xb[row * kX0Ld + (c - S)] = P.states[(e * (P.L + 1) + t) * S + c];
+      else if (c < 2 * S + A) xa[row * kX0Ld + S + (c - 2 * S)] = P.actions[(e * P.L + t) * A + (c - 2 * S)];
+      else if (c == 2 * S + A) rS[row] = P.rewards[e * P.L + t];
+      else dS[row] = P.dones[e * P.L + t];
+    }
+  } else {
+    __syncthreads();
+    load_rows(xa, kX0Ld, 0, P.s, S, S, row0, B);
+    load_rows(xa, kX0Ld, S, P.a, A, A, row0, B);
+    load_rows(xb, kX0Ld, 0, P.s2, S, S, row0, B);
+    if (tid < kR) {
+      const int gr = row0 + tid;
+      rS[tid] = gr < B ? P.r[gr] : 0.f;
+      dS[tid] = gr < B ? P.d[gr] : 0.f;
+    }
+  }
+}
+
+template <int WIDTH>
+__global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using LY = FusedLds<WIDTH>;
+  constexpr int WL = lds_ld(WIDTH);
+  float* xa = smem + LY::xa;
+  float* xb = smem + LY::xb;
+  float* hb = smem + LY::h;
+  float* outS = smem + LY::out;
+  float* auxS = smem + LY::aux;
+  float* scr = smem + LY::scr;
+  float* rS = smem + LY::misc;
+  float* dS = rS + kR;
+  float* yS = dS + kR;
+  int* meta = reinterpret_cast<int*>(yS + kR);
+  int* endsS = reinterpret_cast<int*>(smem + LY::misc + 96);
+  const int row0 = blockIdx.x * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
+  float* const none[kMaxLayers] = {nullptr, nullptr, nullptr, nullptr};
+  auto nostamp = []() {};
+
+  load_batch(A.src, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
+
+  if (blockIdx.y == 1) {
+    // ---- actor(s) forward: pack rows beyond S are zero, so [s | a] serves as input
+    mlp_forward_slice<WIDTH>(A.actor, xa, hb, outS, scr, A.aX, true, row0, B, nostamp);
+    for (int idx = tid; idx < kR * Ad; idx += kThreads) {
+      const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
+      if (gr < B) A.pi[(size_t)gr * Ad + col] = tanhf(outS[row * kOutLd + col]);
+    }
+    store_rows(xa, kX0Ld, A.aX[0], A.aldx0, S, row0, B);
+    return;
+  }
+
+  // ---- a' = tanh(actor_target(s'))
+  mlp_forward_slice<WIDTH>(A.actor_t, xb, hb, outS, scr, none, false, row0, B, nostamp);
+  for (int idx = tid; idx < kR * Ad; idx += kThreads) {
+    const int row = idx / Ad, col = idx - row * Ad;
+    xb[row * kX0Ld + S + col] = (row0 + row < B) ? tanhf(outS[row * kOutLd + col]) : 0.f;
+  }
+  // ---- q' = critic_target(s', a')   (the GEMM's own barrier publishes xb)
+  mlp_forward_slice<WIDTH>(A.critic_t, xb, hb, outS, scr, none, false, row0, B, nostamp);
+  if (tid < kR) yS[tid] = rS[tid] + ((1.f - dS[tid]) * A.gamma) * outS[tid * kOutLd];
+  // ---- q = critic(s, a), activations kept (LDS) and stored (HBM) for dW
+  mlp_forward_slice<WIDTH>(A.critic, xa, hb, outS, scr, A.cX, true, row0, B, nostamp);
+  store_rows(xa, kX0Ld, A.cX[0], A.cldx0, S + Ad, row0, B);
+  // ---- seed 2(q - y)/B, diagnostics
+  lds_zero(auxS, kR * kOutLd);
+  __syncthreads();
+  float p_loss = 0.f, p_q = 0.f, p_y = 0.f;
+  if (tid < kR) {
+    const int gr = row0 + tid;
+    if (gr < B) {
+      const float q = outS[tid * kOutLd], y = yS[tid];
+      auxS[tid * kOutLd] = 2.f * (q - y) * A.inv_B;
+      if (A.y_out != nullptr) A.y_out[gr] = y;
+      if (A.q_out != nullptr) A.q_out[gr] = q;
+      p_loss = (q - y) * (q - y);
+      p_q = q;
+      p_y = y;
+    }
+  }
+  if (A.partials_c != nullptr) {
+    __syncthreads();
+    float v[3] = {p_loss, p_q, p_y};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) v[k] += __shfl_xor(v[k], m);
+      if ((tid & 63) == 0) scr[(tid >> 6) * 4 + k] = v[k];
+    }
+    __syncthreads();
+    if (tid < 3) {
+      float sum = 0.f;
+      for (int w = 0; w < kWaves; ++w) sum += scr[w * 4 + tid];
+      A.partials_c[blockIdx.x * 4 + tid] = sum;
+    }
+  }
+  __syncthreads();
+  store_rows(auxS, kOutLd, pick(A.cdY, A.critic.n_layers - 1), A.clddo, 1, row0, B);
+  mlp_backward_slice<WIDTH>(A.critic, auxS, hb, scr, A.cdY, row0, B, 0, 0, auxS, nostamp);
+}
+
+template <int WIDTH>
+__global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using LY = FusedLds<WIDTH>;
+  constexpr int WL = lds_ld(WIDTH);
+  constexpr int HB = kR * WL;
+  float* xa = smem + LY::xa;
+  float* hb = smem + LY::h;          // critic hidden (2 buffers), then actor hidden (2 buffers)
+  float* ha = hb + 2 * HB;
+  float* outS = smem + LY::out;
+  float* auxS = smem + LY::aux;
+  float* scr = smem + LY::scr;
+  float* piS = smem + LY::xb;        // [kR][kX0Ld] tile reused for pi
+  const int row0 = blockIdx.x * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
+  float* const none[kMaxLayers] = {nullptr, nullptr, nullptr, nullptr};
+  auto nostamp = []() {};
+
+  // [s | pi] and the actor's forward activations (for its ReLU masks)
+  lds_zero(xa, 2 * kR * kX0Ld);
+  __syncthreads();
+  load_rows(xa, kX0Ld, 0, A.aX[0], A.aldx0, S, row0, B);
+  load_rows(xa, kX0Ld, S, A.pi, Ad, Ad, row0, B);
+  load_rows(piS, kX0Ld, 0, A.pi, Ad, Ad, row0, B);
+#pragma unroll
+  for (int l = 1; l < kMaxLayers; ++l)
+    if (l < A.actor.n_layers) load_rows4(ha + (l - 1) * HB, WL, A.aX[l], WIDTH, WIDTH, row0, B);
+  // ---- q = critic(s, pi) with the updated critic
+  mlp_forward_slice<WIDTH>(A.critic, xa, hb, outS, scr, none, false, row0, B, nostamp);
+  lds_zero(auxS, kR * kOutLd);
+  __syncthreads();
+  float p_q = 0.f;
+  if (tid < kR && row0 + tid < B) {
+    auxS[tid * kOutLd] = -A.inv_B;
+    p_q = outS[tid * kOutLd];
+  }
+  if (A.partials_a != nullptr) {
+    __syncthreads();
+    float v = p_q;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    if ((tid & 63) == 0) scr[(tid >> 6) * 4 + 1] = v;
+    __syncthreads();
+    if (tid == 0) {
+      float sum = 0.f;
+      for (int w = 0; w < kWaves; ++w) sum += scr[w * 4 + 1];
+      A.partials_a[blockIdx.x * 4 + 0] = 0.f;
+      A.partials_a[blockIdx.x * 4 + 1] = sum;
+      A.partials_a[blockIdx.x * 4 + 2] = 0.f;
+    }
+  }
+  // ---- critic backward down to the action columns: da -> auxS[:, 0:A]
+  mlp_backward_slice<WIDTH>(A.critic, auxS, hb, scr, none, row0, B, S, Ad, auxS, nostamp);
+  // ---- du = da (1 - pi^2), zero padded
+  float du = 0.f;
+  const int r_ = tid / Ad, c_ = tid - r_ * Ad;
+  const bool mine = tid < kR * Ad;
+  if (mine && row0 + r_ < B) {
+    const float p = piS[r_ * kX0Ld + c_];
+    du = auxS[r_ * kOutLd + c_] * (1.f - p * p);
+  }
+  __syncthreads();
+  lds_zero(auxS, kR * kOutLd);
+  __syncthreads();
+  if (mine) auxS[r_ * kOutLd + c_] = du;
+  __syncthreads();
+  store_rows(auxS, kOutLd, pick(A.adY, A.actor.n_layers - 1), A.alddo, Ad, row0, B);
+  // ---- actor backward over its stored activations
+  mlp_backward_slice<WIDTH>(A.actor, auxS, ha, scr, A.adY, row0, B, 0, 0, auxS, nostamp);
+}
+
+size_t fused_ddpg_lds_bytes() { return sizeof(float) * FusedLds<256>::total; }
+
+hipError_t init_fused_attrs() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddpg_phase1<256>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddpg_phase2<256>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st) {
+  const int slices = (a.B + kR - 1) / kR;
+  hipLaunchKernelGGL(k_ddpg_phase1<256>, dim3(slices, 2), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st) {
+  const int slices = (a.B + kR - 1) / kR;
+  hipLaunchKernelGGL(k_ddpg_phase2<256>, dim3(slices), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  return hipGetLastError();
+}
+
+}  // namespace oprl

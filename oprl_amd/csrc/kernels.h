@@ -104,6 +104,33 @@ struct DwArgs {
   AdamScalars ad;
 };
 
+struct BatchSrc {
+  // mode 0: caller-supplied rows
+  const float *s, *a, *r, *d, *s2;
+  // mode 1: gather from the replay (reference: buffers/episodic_buffer.py:114-133)
+  int gather;
+  const float *states, *actions, *rewards, *dones;
+  const int* ends;
+  int n_eps, L;
+  long n_transitions;
+  unsigned long long seed, counter;
+};
+
+struct DdpgArgs {
+  Net actor, actor_t, critic, critic_t;
+  int B, S, A;
+  BatchSrc src;
+  float gamma, inv_B;
+  float* cX[kMaxLayers]; int cldx0;    // critic layer inputs ([s|a], h1, h2) for dW
+  float* cdY[kMaxLayers]; int clddo;   // critic pre-activation grads
+  float* aX[kMaxLayers]; int aldx0;    // actor layer inputs (s, h1, h2)
+  float* adY[kMaxLayers]; int alddo;
+  float* pi;                           // [B][A]
+  float *y_out, *q_out;                // [B] diagnostics / parity
+  float *partials_c, *partials_a;      // [slices][4]
+  long long* trace;
+};
+
 constexpr int kDwTile = 32;
 constexpr int kDwThreads = 256;
 constexpr int kDwWaves = 4;

@@ -93,6 +93,12 @@ hipError_t launch_tqc_target(const float* z, long net_stride, int ldz, int n_net
                              const double* log_alpha, float gamma, int B, float* target,
                              hipStream_t st);
 int replay_dims(const oprl_replay* h, int* S, int* A);
+int replay_view(const oprl_replay* h, const float** states, const float** actions,
+                const float** rewards, const float** dones, const int** ends, int* n_eps, int* L,
+                long* n_transitions);
+hipError_t init_fused_attrs();
+hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st);
+hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st);
 
 }  // namespace oprl
 
@@ -216,6 +222,11 @@ struct oprl_learner {
   bool actor_updated_last = false;
   long long* trace = nullptr;
   int trace_slot = 0;
+  bool fused = false;          // DDPG two-kernel path
+  BatchSrc src;                // where the current update's minibatch comes from
+  // prebuilt device repack tables: [0] critics online, [1] critics online+target, [2] actor (+target)
+  RepackItem* rp_dev[3] = {nullptr, nullptr, nullptr};
+  int rp_n[3] = {0, 0, 0}, rp_blocks[3] = {0, 0, 0};
 };
 
 namespace {
@@ -344,10 +355,61 @@ void seed_rng(MlpArgs& a, const oprl_learner* h, const float* noise, uint64_t st
   a.rng_ctr = (unsigned long long)h->update_count;
 }
 
+// ------------------------------------------------------------ fused DDPG
+DdpgArgs ddpg_args(oprl_learner* h, int B) {
+  const oprl_learner_config& c = h->cfg;
+  DdpgArgs a;
+  memset(&a, 0, sizeof a);
+  a.actor = net_view(c.actor, false);
+  a.actor_t = net_view(c.actor, true);
+  a.critic = net_view(c.critics[0], false);
+  a.critic_t = net_view(c.critics[0], true);
+  a.B = B; a.S = h->S; a.A = h->A;
+  a.src = h->src;
+  a.gamma = (float)c.hp.gamma;
+  a.inv_B = 1.0f / (float)B;
+  for (int l = 0; l < kMaxLayers; ++l) {
+    a.cX[l] = h->ws_critic[0].X[l]; a.cdY[l] = h->ws_critic[0].dY[l];
+    a.aX[l] = h->ws_actor.X[l];     a.adY[l] = h->ws_actor.dY[l];
+  }
+  a.cldx0 = h->ws_critic[0].ldx0; a.clddo = h->ws_critic[0].lddo;
+  a.aldx0 = h->ws_actor.ldx0;     a.alddo = h->ws_actor.lddo;
+  a.pi = h->pi;
+  a.y_out = h->ydbg; a.q_out = h->qdbg;
+  a.partials_c = h->part_c; a.partials_a = h->part_a;
+  return a;
+}
+
+int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st) {
+  const oprl_learner_config& c = h->cfg;
+  DwArgs dw;
+  if (critic) {
+    h->opt_step_critic += 1;
+    dw.items = h->items_dev; dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
+    dw.ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, 1.0f);
+  } else {
+    h->opt_step_actor += 1;
+    dw.items = h->items_dev + h->n_items_critic; dw.n_items = h->n_items_actor;
+    dw.total_tiles = h->tiles_actor;
+    dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, polyak, 1.0f);
+  }
+  dw.B = B;
+  HIPC(launch_dw_prof(dw, st));
+  return OPRL_OK;
+}
+
 // ------------------------------------------------------------ critic phase
 int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r, const float* d,
                  const float* s2, int B, const float* noise0, hipStream_t st) {
   const oprl_learner_config& c = h->cfg;
+  if (h->fused) {
+    const DdpgArgs fa = ddpg_args(h, B);
+    prof_begin(0, st);
+    hipError_t e = launch_ddpg_phase1(fa, st);
+    prof_end(st);
+    HIPC(e);
+    return dw_step(h, true, B, true, st);
+  }
   const int S = h->S, A = h->A, nc = h->nc;
   const int algo = c.algo;
   const int n_slices = (B + kR - 1) / kR;
@@ -417,6 +479,14 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
 // ------------------------------------------------------------- actor phase
 int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hipStream_t st) {
   const oprl_learner_config& c = h->cfg;
+  if (h->fused) {
+    const DdpgArgs fa = ddpg_args(h, B);
+    prof_begin(0, st);
+    hipError_t e = launch_ddpg_phase2(fa, st);
+    prof_end(st);
+    HIPC(e);
+    return dw_step(h, false, B, true, st);
+  }
   const int S = h->S, A = h->A, nc = h->nc;
   const int algo = c.algo;
   const bool gauss = (algo == OPRL_SAC || algo == OPRL_TQC);
@@ -513,8 +583,8 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
 
 // master -> packs for a list of nets (which: bit0 online, bit1 target).  The item
 // table goes through a small device scratch; synchronous on `st` only.
-int repack_nets(const oprl_net* const* nets, int n_nets, int which, hipStream_t st) {
-  std::vector<RepackItem> items;
+void build_repack_items(const oprl_net* const* nets, int n_nets, int which,
+                        std::vector<RepackItem>& items, int* blocks_out) {
   int blocks = 0;
   for (int i = 0; i < n_nets; ++i) {
     const oprl_net& n = *nets[i];
@@ -536,6 +606,13 @@ int repack_nets(const oprl_net* const* nets, int n_nets, int which, hipStream_t 
       }
     }
   }
+  *blocks_out = blocks;
+}
+
+int repack_nets(const oprl_net* const* nets, int n_nets, int which, hipStream_t st) {
+  std::vector<RepackItem> items;
+  int blocks = 0;
+  build_repack_items(nets, n_nets, which, items, &blocks);
   if (items.empty()) return OPRL_OK;
   RepackItem* dev = nullptr;
   HIPC(hipMalloc(&dev, sizeof(RepackItem) * items.size()));
@@ -633,7 +710,11 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   if (rc != OPRL_OK) { delete h; return rc; }
 
   hipError_t e = init_kernel_attrs();
+  if (e == hipSuccess) e = init_fused_attrs();
   if (e != hipSuccess) { set_err("hipFuncSetAttribute: %s", hipGetErrorString(e)); delete h; return OPRL_ERR_HIP; }
+  memset(&h->src, 0, sizeof h->src);
+  h->fused = cfg->algo == OPRL_DDPG && !cfg->no_fuse && h->w_actor == 256 && h->w_critic == 256 &&
+             cfg->actor.n_layers == 3 && cfg->critics[0].n_layers == 3;
 
   const int B = h->Bmax, S = h->S, A = h->A, nc = h->nc;
   // scalar critics: q' is read with stride 1 by the TD seed; TQC: [B][ldq] quantile rows
@@ -646,7 +727,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   floats += (size_t)(nc + 1) * n_slices * 4 + 16;
   floats += (size_t)B * (2 * S + A + 2);
   floats += 64 * 32;
-  const size_t bytes = floats * sizeof(float) + 4096 + sizeof(DwItem) * (size_t)(nc + 1) * kMaxLayers;
+  const size_t bytes = floats * sizeof(float) + 8192 + sizeof(DwItem) * (size_t)(nc + 1) * kMaxLayers +
+                       sizeof(RepackItem) * (size_t)(4 * nc + 4) * kMaxLayers;
   if (hipMalloc(&h->pool.base, bytes) != hipSuccess) { set_err("hipMalloc(%zu) failed", bytes); delete h; return OPRL_ERR_NOMEM; }
   h->pool.cap = bytes;
   (void)hipMemset(h->pool.base, 0, bytes);
@@ -679,7 +761,22 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   fill_items(cfg->actor, h->ws_actor, items, &h->tiles_actor);
   h->n_items_actor = (int)items.size() - h->n_items_critic;
   h->items_dev = p.take<DwItem>(items.size());
+  std::vector<RepackItem> rp[3];
+  {
+    const oprl_net* cn[OPRL_MAX_CRITICS];
+    for (int j = 0; j < nc; ++j) cn[j] = &h->cfg.critics[j];
+    const oprl_net* an[1] = {&h->cfg.actor};
+    build_repack_items(cn, nc, 1, rp[0], &h->rp_blocks[0]);
+    build_repack_items(cn, nc, 3, rp[1], &h->rp_blocks[1]);
+    build_repack_items(an, 1, 3, rp[2], &h->rp_blocks[2]);
+    for (int k = 0; k < 3; ++k) {
+      h->rp_n[k] = (int)rp[k].size();
+      h->rp_dev[k] = p.take<RepackItem>(rp[k].size());
+    }
+  }
   if (p.used > p.cap) { set_err("internal: workspace pool overflow (%zu > %zu)", p.used, p.cap); (void)hipFree(p.base); delete h; return OPRL_ERR_NOMEM; }
+  for (int k = 0; k < 3; ++k)
+    if (!rp[k].empty()) (void)hipMemcpy(h->rp_dev[k], rp[k].data(), sizeof(RepackItem) * rp[k].size(), hipMemcpyHostToDevice);
   if (hipMemcpy(h->items_dev, items.data(), sizeof(DwItem) * items.size(), hipMemcpyHostToDevice) != hipSuccess) {
     set_err("hipMemcpy(items) failed"); (void)hipFree(p.base); delete h; return OPRL_ERR_HIP;
   }
@@ -731,6 +828,7 @@ extern "C" int oprl_learner_update_phase(oprl_learner* h, int32_t phase, const f
   hipStream_t st = (hipStream_t)stream;
   h->last_B = B;
   if (phase == 0) h->trace_slot = 0;
+  if (!h->src.gather) { h->src.s = s; h->src.a = a; h->src.r = r; h->src.d = d; h->src.s2 = s2; }
   if (phase == 0) return critic_phase(h, s, a, r, d, s2, B, noise0, st);
   if (phase == 1) {
     h->actor_updated_last = actor_due(h);
@@ -764,9 +862,9 @@ extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, double grad_sc
       ad.do_adam = 1;
       HIPC(launch_adam_flat(n.theta, n.adam_m, n.adam_v, n.theta_target, n.grad, net_param_count(n), ad, st));
     }
-    const oprl_net* nets[OPRL_MAX_CRITICS];
-    for (int j = 0; j < h->nc; ++j) nets[j] = &c.critics[j];
-    return repack_nets(nets, h->nc, polyak ? 3 : 1, st);
+    const int tbl = polyak ? 1 : 0;
+    HIPC(launch_repack(h->rp_dev[tbl], h->rp_n[tbl], h->rp_blocks[tbl], st));
+    return OPRL_OK;
   }
   if (phase == 1) {
     if (!h->actor_updated_last) return OPRL_OK;
@@ -774,10 +872,7 @@ extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, double grad_sc
     AdamScalars ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, n.theta_target != nullptr, (float)grad_scale);
     ad.do_adam = 1;
     HIPC(launch_adam_flat(n.theta, n.adam_m, n.adam_v, n.theta_target, n.grad, net_param_count(n), ad, st));
-    {
-      const oprl_net* nets[1] = {&n};
-      RC(repack_nets(nets, 1, 3, st));
-    }
+    HIPC(launch_repack(h->rp_dev[2], h->rp_n[2], h->rp_blocks[2], st));
     if (alpha_ptr(h) != nullptr)
       HIPC(launch_alpha_step(c.log_alpha, c.log_alpha_m, c.log_alpha_v, nullptr, 1, (float)c.hp.target_entropy,
                              c.hp.lr_alpha, c.hp.beta1, c.hp.beta2, c.hp.adam_eps, h->opt_step_alpha,
@@ -796,6 +891,24 @@ extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t
   replay_dims(replay, &S, &A);
   if (S != h->S || A != h->A) { set_err("replay dims (%d,%d) != learner dims (%d,%d)", S, A, h->S, h->A); return OPRL_ERR_INVALID; }
   if (K < 0 || B < 1 || B > h->Bmax) { set_err("step_n: bad K/B"); return OPRL_ERR_INVALID; }
+  if (h->fused) {
+    // the slice kernels gather their own rows (same Philox draw / index map as k_replay_gather)
+    BatchSrc& sc = h->src;
+    RC(oprl_replay_flush(replay, stream));
+    long n_tr = 0;
+    replay_view(replay, &sc.states, &sc.actions, &sc.rewards, &sc.dones, &sc.ends, &sc.n_eps, &sc.L, &n_tr);
+    if (n_tr <= 0 || sc.n_eps <= 0) { set_err("step_n: replay buffer is empty"); return OPRL_ERR_STATE; }
+    sc.n_transitions = n_tr;
+    sc.seed = seed;
+    sc.gather = 1;
+    int rc = OPRL_OK;
+    for (int k = 0; k < K && rc == OPRL_OK; ++k) {
+      sc.counter = (unsigned long long)h->update_count;
+      rc = oprl_learner_update(h, h->bs, h->ba, h->br, h->bd, h->bs2, B, nullptr, nullptr, stream);
+    }
+    sc.gather = 0;
+    return rc;
+  }
   for (int k = 0; k < K; ++k) {
     RC(oprl_replay_sample(replay, B, nullptr, seed, (uint64_t)h->update_count, h->bs, h->ba, h->br,
                           h->bd, h->bs2, nullptr, nullptr, stream));

@@ -302,4 +302,12 @@ extern "C" int oprl_replay_sample(oprl_replay* h, int32_t B, const int64_t* idx,
 // used by the learner's fused step_n
 namespace oprl {
 int replay_dims(const oprl_replay* h, int* S, int* A) { *S = h->S; *A = h->A; return 0; }
+// raw view for kernels that gather in-place (fused_ddpg.hip)
+int replay_view(const oprl_replay* h, const float** states, const float** actions,
+                const float** rewards, const float** dones, const int** ends, int* n_eps, int* L,
+                long* n_transitions) {
+  *states = h->states; *actions = h->actions; *rewards = h->rewards; *dones = h->dones;
+  *ends = h->ends_dev; *n_eps = h->n_eps; *L = h->L; *n_transitions = h->n_transitions;
+  return 0;
+}
 }
