@@ -5,12 +5,15 @@
 // re-zero, and the actor's forward — which does not depend on the critic step —
 // sits on the critical path.  Here:
 //
-//   k_ddpg_phase1, grid (slices, 2):
-//     y = 0  [gather 16 rows] -> actor_target(s') -> critic_target(s', a')
-//            -> y = r + (1-d) gamma q' -> critic(s, a) forward -> 2(q-y)/B
-//            -> critic backward                       (ddpg.py:86-101)
-//     y = 1  [gather the same rows] -> actor(s) forward, activations and
-//            pi = tanh(.) to HBM                      (first half of ddpg.py:104)
+//   k_ddpg_phase1, grid (slices, 3) — three concurrent roles per 16-row slice, each
+//   on its own CU, each gathering the same rows:
+//     A  actor_target(s') -> critic_target(s', a') -> y = r + (1-d) gamma q'
+//        -> y handed to role B as 8-byte {epoch, value} granules   (ddpg.py:94-95)
+//     B  critic(s, a) forward (concurrently with A) -> wait for y -> 2(q-y)/B
+//        -> critic backward                                        (ddpg.py:96-100)
+//     C  actor(s) forward, activations and pi = tanh(.) to HBM     (first half of ddpg.py:104)
+//   All 3*slices workgroups are co-resident (48 on 256 CUs at B=256); B's wait is a
+//   bounded spin.
 //   k_dw_adam(critic)          dW + Adam + Polyak     (ddpg.py:99-101, 72-77)
 //   k_ddpg_phase2, grid (slices):
 //            critic(s, pi) forward with the UPDATED critic -> -1/B -> critic
@@ -121,8 +124,8 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
 
   load_batch(A.src, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
 
-  if (blockIdx.y == 1) {
-    // ---- actor(s) forward: pack rows beyond S are zero, so [s | a] serves as input
+  if (blockIdx.y == 2) {
+    // ---- role C: actor(s) forward.  Pack rows beyond S are zero, so [s | a] serves as input.
     mlp_forward_slice<WIDTH>(A.actor, xa, hb, outS, scr, A.aX, true, row0, B, nostamp);
     for (int idx = tid; idx < kR * Ad; idx += kThreads) {
       const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
@@ -132,18 +135,47 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
     return;
   }
 
-  // ---- a' = tanh(actor_target(s'))
-  mlp_forward_slice<WIDTH>(A.actor_t, xb, hb, outS, scr, none, false, row0, B, nostamp);
-  for (int idx = tid; idx < kR * Ad; idx += kThreads) {
-    const int row = idx / Ad, col = idx - row * Ad;
-    xb[row * kX0Ld + S + col] = (row0 + row < B) ? tanhf(outS[row * kOutLd + col]) : 0.f;
+  if (blockIdx.y == 0) {
+    // ---- role A: a' = tanh(actor_target(s')), q' = critic_target(s', a'), TD target
+    mlp_forward_slice<WIDTH>(A.actor_t, xb, hb, outS, scr, none, false, row0, B, nostamp);
+    for (int idx = tid; idx < kR * Ad; idx += kThreads) {
+      const int row = idx / Ad, col = idx - row * Ad;
+      xb[row * kX0Ld + S + col] = (row0 + row < B) ? tanhf(outS[row * kOutLd + col]) : 0.f;
+    }
+    // (the next GEMM's own barrier publishes xb)
+    mlp_forward_slice<WIDTH>(A.critic_t, xb, hb, outS, scr, none, false, row0, B, nostamp);
+    if (tid < kR && row0 + tid < B) {
+      const float y = rS[tid] + ((1.f - dS[tid]) * A.gamma) * outS[tid * kOutLd];
+      // hand-off to role B of this slice: ONE aligned 8-byte {epoch, value} granule per
+      // row, written through (agent-scope relaxed atomic = sc1 store); the tag makes the
+      // data its own flag, no fence needed (cdna guide, G16 R2).
+      const unsigned long long g = ((unsigned long long)A.epoch << 32) | (unsigned long long)__float_as_uint(y);
+      __hip_atomic_store(A.y_granules + row0 + tid, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
   }
-  // ---- q' = critic_target(s', a')   (the GEMM's own barrier publishes xb)
-  mlp_forward_slice<WIDTH>(A.critic_t, xb, hb, outS, scr, none, false, row0, B, nostamp);
-  if (tid < kR) yS[tid] = rS[tid] + ((1.f - dS[tid]) * A.gamma) * outS[tid * kOutLd];
-  // ---- q = critic(s, a), activations kept (LDS) and stored (HBM) for dW
+
+  // ---- role B: q = critic(s, a) forward (runs while role A computes the target)
   mlp_forward_slice<WIDTH>(A.critic, xa, hb, outS, scr, A.cX, true, row0, B, nostamp);
   store_rows(xa, kX0Ld, A.cX[0], A.cldx0, S + Ad, row0, B);
+  // wait for this slice's TD targets: lanes 0..15 of wave 0 poll their granule (relaxed,
+  // L1-bypassing) with a sleep in between; the spin is BOUNDED — on give-up the target
+  // becomes NaN, which the parity tests and the loss diagnostics expose, instead of a hang.
+  if (tid < 64) {
+    float y = 0.f;
+    if (tid < kR && row0 + tid < B) {
+      unsigned long long g = 0;
+      bool ok = false;
+      for (int spin = 0; spin < (1 << 20); ++spin) {
+        g = __hip_atomic_load(A.y_granules + row0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = (unsigned)(g >> 32) == A.epoch;
+        if (ok) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      y = ok ? __uint_as_float((unsigned)g) : __builtin_nanf("");
+    }
+    if (tid < kR) yS[tid] = y;
+  }
   // ---- seed 2(q - y)/B, diagnostics
   lds_zero(auxS, kR * kOutLd);
   __syncthreads();
@@ -263,7 +295,7 @@ hipError_t init_fused_attrs() {
 
 hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
-  hipLaunchKernelGGL(k_ddpg_phase1<256>, dim3(slices, 2), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  hipLaunchKernelGGL(k_ddpg_phase1<256>, dim3(slices, 3), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
   return hipGetLastError();
 }
 

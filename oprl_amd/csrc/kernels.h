@@ -127,13 +127,15 @@ struct DdpgArgs {
   float* adY[kMaxLayers]; int alddo;
   float* pi;                           // [B][A]
   float *y_out, *q_out;                // [B] diagnostics / parity
+  unsigned long long* y_granules;      // [B] {epoch<<32 | float bits}: TD target hand-off between roles
+  unsigned epoch;                      // monotonically increasing per update, never 0
   float *partials_c, *partials_a;      // [slices][4]
   long long* trace;
 };
 
 constexpr int kDwTile = 32;
-constexpr int kDwThreads = 256;
-constexpr int kDwWaves = 4;
+constexpr int kDwThreads = 512;
+constexpr int kDwWaves = 8;
 constexpr int kTraceStamps = 12;
 
 }  // namespace oprl

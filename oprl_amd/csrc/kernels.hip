@@ -301,17 +301,43 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwArgs A) {
   __shared__ __attribute__((aligned(16))) float part[kDwWaves][T][LD];
   __shared__ float bpart[kDwWaves][T];
   __shared__ float sc[2];
+  __shared__ int s_item;
   const int tile = blockIdx.x;
-  int it = 0;
-  while (it + 1 < A.n_items && tile >= A.items[it].tile_end) ++it;
-  const DwItem I = A.items[it];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // which layer owns this tile: one parallel probe of the table instead of a chain
+  // of dependent global loads
+  if (tid < 64) {
+    const bool mine = tid < A.n_items && tile >= A.items[tid].tile_begin && tile < A.items[tid].tile_end;
+    const unsigned long long m = __ballot(mine);
+    if (tid == 0) s_item = m ? __ffsll((long long)m) - 1 : 0;
+  }
+  if (tid == 64) adam_bias_corr(A.ad, &sc[0], &sc[1]);
+  __syncthreads();
+  const DwItem I = A.items[s_item];
   const int lt = tile - I.tile_begin;
   const int tn = lt / I.tiles_k, tk = lt - tn * I.tiles_k;
   const int n_base = tn * T, k_base = tk * T;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, c = lane >> 4;
   const int NSk = cdiv(I.K, 16), NSn = cdiv(I.N, 16);
-  if (tid == 0) adam_bias_corr(A.ad, &sc[0], &sc[1]);
+
+  // this thread's share of the epilogue: 2 consecutive k of one row n.  Its Adam
+  // state is requested NOW so the round trip overlaps the GEMM.
+  const int nl = tid >> 4, kl0 = (tid & 15) * 2;
+  const int en = n_base + nl;
+  float p_th[2] = {0.f, 0.f}, p_m[2] = {0.f, 0.f}, p_v[2] = {0.f, 0.f}, p_tt[2] = {0.f, 0.f};
+  bool e_ok[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int k = k_base + kl0 + e;
+    e_ok[e] = en < I.N && k < I.K;
+    if (e_ok[e] && A.ad.do_adam) {
+      const size_t o = (size_t)en * I.K + k;
+      p_th[e] = I.w[o];
+      p_m[e] = I.w_m[o];
+      p_v[e] = I.w_v[o];
+      if (A.ad.do_polyak && I.w_t != nullptr) p_tt[e] = I.w_t[o];
+    }
+  }
 
   f32x4 acc[2][2];
 #pragma unroll
@@ -323,13 +349,14 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwArgs A) {
   const bool n_ok = ncol < I.ldy, k_ok = kcol < I.ldx;   // ld even -> pair in bounds
   const bool n0v = ncol < I.N, n1v = ncol + 1 < I.N, k0v = kcol < I.K, k1v = kcol + 1 < I.K;
   // all loads of U batch chunks are issued before the first MFMA (latency-bound
-  // otherwise: 16 dependent trips to L2/HBM per wave, measured 12 us per launch)
-  constexpr int U = 16;
-  for (int it0 = 0; it0 * 16 < A.B; it0 += U) {
+  // otherwise: dependent trips to L2/HBM per wave)
+  constexpr int U = 8;
+  constexpr int RPI = 4 * kDwWaves;   // minibatch rows per iteration of the workgroup
+  for (int it0 = 0; it0 * RPI < A.B; it0 += U) {
     f32x2 a2[U], x2[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int b = 16 * (it0 + u) + 4 * wave + c;
+      const int b = RPI * (it0 + u) + 4 * wave + c;
       a2[u] = f32x2{0.f, 0.f};
       x2[u] = f32x2{0.f, 0.f};
       if (b < A.B) {
@@ -367,36 +394,40 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwArgs A) {
   }
   __syncthreads();
   const float step_size = sc[0], bc2_sqrt = sc[1];
-  {
-    const int nl = tid >> 3, kl0 = (tid & 7) * 4;
-    const int n = n_base + nl;
-    if (n < I.N) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = k_base + kl0 + e;
-        if (k < I.K) {
-          const float g = part[0][nl][kl0 + e] + part[1][nl][kl0 + e] + part[2][nl][kl0 + e] +
-                          part[3][nl][kl0 + e];
-          const size_t o = (size_t)n * I.K + k;
-          float th_new, tt_new;
-          const int wrote = adam_polyak_elem(g, I.w + o, I.w_m ? I.w_m + o : nullptr,
-                                             I.w_v ? I.w_v + o : nullptr,
-                                             I.w_t ? I.w_t + o : nullptr,
-                                             I.w_g ? I.w_g + o : nullptr, A.ad, step_size, bc2_sqrt,
-                                             &th_new, &tt_new);
-          if (wrote & 1) {   // keep the fragment-order packs in step with the master
-            if (I.pf != nullptr) I.pf[pack_index(n, k, NSk)] = th_new;
-            if (I.pb != nullptr) I.pb[pack_index(k, n, NSn)] = th_new;
-          }
-          if ((wrote & 2) && I.tpf != nullptr) I.tpf[pack_index(n, k, NSk)] = tt_new;
-        }
+  for (int e = 0; e < 2; ++e) {
+    if (!e_ok[e]) continue;
+    const int k = k_base + kl0 + e;
+    float g = 0.f;
+#pragma unroll
+    for (int w = 0; w < kDwWaves; ++w) g += part[w][nl][kl0 + e];
+    g *= A.ad.grad_scale;
+    const size_t o = (size_t)en * I.K + k;
+    if (I.w_g != nullptr) I.w_g[o] = g;
+    if (A.ad.do_adam) {
+      float mm = p_m[e], vv = p_v[e], th = p_th[e];
+      mm = mm + (g - mm) * A.ad.omb1;
+      vv = vv * A.ad.beta2 + A.ad.omb2 * g * g;
+      th = th - step_size * (mm / (sqrtf(vv) / bc2_sqrt + A.ad.eps));
+      I.w_m[o] = mm;
+      I.w_v[o] = vv;
+      I.w[o] = th;
+      // keep the fragment-order packs in step with the master
+      if (I.pf != nullptr) I.pf[pack_index(en, k, NSk)] = th;
+      if (I.pb != nullptr) I.pb[pack_index(k, en, NSn)] = th;
+      if (A.ad.do_polyak && I.w_t != nullptr) {
+        const float u = p_tt[e] * A.ad.omtau + A.ad.tau * th;
+        I.w_t[o] = u;
+        if (I.tpf != nullptr) I.tpf[pack_index(en, k, NSk)] = u;
       }
     }
   }
   if (tk == 0 && tid < T) {
     const int n = n_base + tid;
     if (n < I.N) {
-      const float g = bpart[0][tid] + bpart[1][tid] + bpart[2][tid] + bpart[3][tid];
+      float g = 0.f;
+#pragma unroll
+      for (int w = 0; w < kDwWaves; ++w) g += bpart[w][tid];
       float t0, t1;
       (void)adam_polyak_elem(g, I.b + n, I.b_m ? I.b_m + n : nullptr, I.b_v ? I.b_v + n : nullptr,
                              I.b_t ? I.b_t + n : nullptr, I.b_g ? I.b_g + n : nullptr, A.ad, step_size,

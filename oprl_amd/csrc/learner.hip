@@ -223,6 +223,8 @@ struct oprl_learner {
   long long* trace = nullptr;
   int trace_slot = 0;
   bool fused = false;          // DDPG two-kernel path
+  unsigned long long* y_granules = nullptr;   // [Bmax] TD-target hand-off (fused DDPG)
+  unsigned epoch = 0;          // monotonically increasing, never reset
   BatchSrc src;                // where the current update's minibatch comes from
   // prebuilt device repack tables: [0] critics online, [1] critics online+target, [2] actor (+target)
   RepackItem* rp_dev[3] = {nullptr, nullptr, nullptr};
@@ -376,6 +378,8 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   a.aldx0 = h->ws_actor.ldx0;     a.alddo = h->ws_actor.lddo;
   a.pi = h->pi;
   a.y_out = h->ydbg; a.q_out = h->qdbg;
+  a.y_granules = h->y_granules;
+  a.epoch = h->epoch;
   a.partials_c = h->part_c; a.partials_a = h->part_a;
   return a;
 }
@@ -403,6 +407,8 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
                  const float* s2, int B, const float* noise0, hipStream_t st) {
   const oprl_learner_config& c = h->cfg;
   if (h->fused) {
+    h->epoch += 1;
+    if (h->epoch == 0) h->epoch = 1;
     const DdpgArgs fa = ddpg_args(h, B);
     prof_begin(0, st);
     hipError_t e = launch_ddpg_phase1(fa, st);
@@ -726,7 +732,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
             (size_t)nc * B * A + (size_t)nc * B + (size_t)B * 128 + 2 * (size_t)B;
   floats += (size_t)(nc + 1) * n_slices * 4 + 16;
   floats += (size_t)B * (2 * S + A + 2);
-  floats += 64 * 32;
+  floats += 64 * 32 + 2 * (size_t)B;
   const size_t bytes = floats * sizeof(float) + 8192 + sizeof(DwItem) * (size_t)(nc + 1) * kMaxLayers +
                        sizeof(RepackItem) * (size_t)(4 * nc + 4) * kMaxLayers;
   if (hipMalloc(&h->pool.base, bytes) != hipSuccess) { set_err("hipMalloc(%zu) failed", bytes); delete h; return OPRL_ERR_NOMEM; }
@@ -750,6 +756,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   h->part_a = p.take<float>((size_t)n_slices * 4);
   h->scalars = p.take<float>(16);
   h->alpha_grad = cfg->log_alpha_grad ? cfg->log_alpha_grad : p.take<double>(2);
+  h->y_granules = p.take<unsigned long long>((size_t)B);
   h->bs = p.take<float>((size_t)B * S);
   h->ba = p.take<float>((size_t)B * A);
   h->br = p.take<float>(B);
