@@ -120,30 +120,51 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   int* endsS = reinterpret_cast<int*>(smem + LY::misc + 96);
   const int row0 = blockIdx.x * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
   float* const none[kMaxLayers] = {nullptr, nullptr, nullptr, nullptr};
-  auto nostamp = []() {};
-
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if (A.trace != nullptr && tid == 0 && n_stamp < kTraceStamps) {
+      long long* tr = A.trace + (((size_t)blockIdx.y * 64 + blockIdx.x) * kTraceStamps + n_stamp) * 2;
+      tr[0] = (long long)__builtin_readcyclecounter();
+      tr[1] = (long long)wall_clock64();
+    }
+    ++n_stamp;
+  };
+  stamp();   // entry
+  constexpr int NTW = WIDTH / 16;
+  // this role's first layer-0 fragments are requested before the minibatch rows
+  const Net& first = blockIdx.y == 0 ? A.actor_t : (blockIdx.y == 1 ? A.critic : A.actor);
+  const Frag f0 = prefetch_frags(first.pf[0], NTW, cdiv(first.dims[0], 16));
+  Frag fnext, sink;
+#pragma unroll
+  for (int d = 0; d < kFrag; ++d) { fnext.b[d] = f32x4{0.f, 0.f, 0.f, 0.f}; sink.b[d] = fnext.b[d]; }
   load_batch(A.src, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
+  stamp();   // batch rows requested
 
   if (blockIdx.y == 2) {
     // ---- role C: actor(s) forward.  Pack rows beyond S are zero, so [s | a] serves as input.
-    mlp_forward_slice<WIDTH>(A.actor, xa, hb, outS, scr, A.aX, true, row0, B, nostamp);
+    mlp_forward_slice<WIDTH>(A.actor, xa, hb, outS, scr, A.aX, true, row0, B, stamp, true, f0,
+                             nullptr, 0, 0, sink);
     for (int idx = tid; idx < kR * Ad; idx += kThreads) {
       const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
       if (gr < B) A.pi[(size_t)gr * Ad + col] = tanhf(outS[row * kOutLd + col]);
     }
     store_rows(xa, kX0Ld, A.aX[0], A.aldx0, S, row0, B);
+    stamp();
     return;
   }
 
   if (blockIdx.y == 0) {
     // ---- role A: a' = tanh(actor_target(s')), q' = critic_target(s', a'), TD target
-    mlp_forward_slice<WIDTH>(A.actor_t, xb, hb, outS, scr, none, false, row0, B, nostamp);
+    // (critic_target's layer-0 fragments are requested behind actor_target's hidden GEMM)
+    mlp_forward_slice<WIDTH>(A.actor_t, xb, hb, outS, scr, none, false, row0, B, stamp, true, f0,
+                             A.critic_t.pf[0], NTW, cdiv(A.critic_t.dims[0], 16), fnext);
     for (int idx = tid; idx < kR * Ad; idx += kThreads) {
       const int row = idx / Ad, col = idx - row * Ad;
       xb[row * kX0Ld + S + col] = (row0 + row < B) ? tanhf(outS[row * kOutLd + col]) : 0.f;
     }
     // (the next GEMM's own barrier publishes xb)
-    mlp_forward_slice<WIDTH>(A.critic_t, xb, hb, outS, scr, none, false, row0, B, nostamp);
+    mlp_forward_slice<WIDTH>(A.critic_t, xb, hb, outS, scr, none, false, row0, B, stamp, true, fnext,
+                             nullptr, 0, 0, sink);
     if (tid < kR && row0 + tid < B) {
       const float y = rS[tid] + ((1.f - dS[tid]) * A.gamma) * outS[tid * kOutLd];
       // hand-off to role B of this slice: ONE aligned 8-byte {epoch, value} granule per
@@ -152,11 +173,15 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
       const unsigned long long g = ((unsigned long long)A.epoch << 32) | (unsigned long long)__float_as_uint(y);
       __hip_atomic_store(A.y_granules + row0 + tid, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    stamp();
     return;
   }
 
   // ---- role B: q = critic(s, a) forward (runs while role A computes the target)
-  mlp_forward_slice<WIDTH>(A.critic, xa, hb, outS, scr, A.cX, true, row0, B, nostamp);
+  // (the output layer's BACKWARD fragments are requested behind the hidden GEMM too)
+  const int Lc = A.critic.n_layers;
+  mlp_forward_slice<WIDTH>(A.critic, xa, hb, outS, scr, A.cX, true, row0, B, stamp, true, f0,
+                           pick(A.critic.pb, Lc - 1), NTW, cdiv(pick(A.critic.dims, Lc), 16), fnext);
   store_rows(xa, kX0Ld, A.cX[0], A.cldx0, S + Ad, row0, B);
   // wait for this slice's TD targets: lanes 0..15 of wave 0 poll their granule (relaxed,
   // L1-bypassing) with a sleep in between; the spin is BOUNDED — on give-up the target
@@ -176,6 +201,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
     }
     if (tid < kR) yS[tid] = y;
   }
+  stamp();   // TD target received
   // ---- seed 2(q - y)/B, diagnostics
   lds_zero(auxS, kR * kOutLd);
   __syncthreads();
@@ -210,7 +236,9 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   }
   __syncthreads();
   store_rows(auxS, kOutLd, pick(A.cdY, A.critic.n_layers - 1), A.clddo, 1, row0, B);
-  mlp_backward_slice<WIDTH>(A.critic, auxS, hb, scr, A.cdY, row0, B, 0, 0, auxS, nostamp);
+  mlp_backward_slice<WIDTH>(A.critic, auxS, hb, scr, A.cdY, row0, B, 0, 0, auxS, stamp, true, fnext,
+                            nullptr, 0, 0, sink);
+  stamp();
 }
 
 template <int WIDTH>
@@ -228,8 +256,22 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   float* piS = smem + LY::xb;        // [kR][kX0Ld] tile reused for pi
   const int row0 = blockIdx.x * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
   float* const none[kMaxLayers] = {nullptr, nullptr, nullptr, nullptr};
-  auto nostamp = []() {};
-
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if (A.trace != nullptr && tid == 0 && n_stamp < kTraceStamps) {
+      long long* tr = A.trace + (((size_t)blockIdx.y * 64 + blockIdx.x) * kTraceStamps + n_stamp) * 2;
+      tr[0] = (long long)__builtin_readcyclecounter();
+      tr[1] = (long long)wall_clock64();
+    }
+    ++n_stamp;
+  };
+  stamp();
+  constexpr int NTW = WIDTH / 16;
+  const int Lc = A.critic.n_layers, La = A.actor.n_layers;
+  const Frag f0 = prefetch_frags(A.critic.pf[0], NTW, cdiv(A.critic.dims[0], 16));
+  Frag fcb, fab, sink;
+#pragma unroll
+  for (int d = 0; d < kFrag; ++d) { fcb.b[d] = f32x4{0.f, 0.f, 0.f, 0.f}; fab.b[d] = fcb.b[d]; sink.b[d] = fcb.b[d]; }
   // [s | pi] and the actor's forward activations (for its ReLU masks)
   lds_zero(xa, 2 * kR * kX0Ld);
   __syncthreads();
@@ -240,7 +282,8 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   for (int l = 1; l < kMaxLayers; ++l)
     if (l < A.actor.n_layers) load_rows4(ha + (l - 1) * HB, WL, A.aX[l], WIDTH, WIDTH, row0, B);
   // ---- q = critic(s, pi) with the updated critic
-  mlp_forward_slice<WIDTH>(A.critic, xa, hb, outS, scr, none, false, row0, B, nostamp);
+  mlp_forward_slice<WIDTH>(A.critic, xa, hb, outS, scr, none, false, row0, B, stamp, true, f0,
+                           pick(A.critic.pb, Lc - 1), NTW, cdiv(pick(A.critic.dims, Lc), 16), fcb);
   lds_zero(auxS, kR * kOutLd);
   __syncthreads();
   float p_q = 0.f;
@@ -264,7 +307,10 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
     }
   }
   // ---- critic backward down to the action columns: da -> auxS[:, 0:A]
-  mlp_backward_slice<WIDTH>(A.critic, auxS, hb, scr, none, row0, B, S, Ad, auxS, nostamp);
+  // (the ACTOR's output-layer backward fragments ride behind the critic's hidden backward)
+  mlp_backward_slice<WIDTH>(A.critic, auxS, hb, scr, none, row0, B, S, Ad, auxS, stamp, true, fcb,
+                            pick(A.actor.pb, La - 1), NTW, cdiv(pick(A.actor.dims, La), 16), fab);
+  stamp();   // da ready
   // ---- du = da (1 - pi^2), zero padded
   float du = 0.f;
   const int r_ = tid / Ad, c_ = tid - r_ * Ad;
@@ -280,7 +326,9 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   __syncthreads();
   store_rows(auxS, kOutLd, pick(A.adY, A.actor.n_layers - 1), A.alddo, Ad, row0, B);
   // ---- actor backward over its stored activations
-  mlp_backward_slice<WIDTH>(A.actor, auxS, ha, scr, A.adY, row0, B, 0, 0, auxS, nostamp);
+  mlp_backward_slice<WIDTH>(A.actor, auxS, ha, scr, A.adY, row0, B, 0, 0, auxS, stamp, true, fab,
+                            nullptr, 0, 0, sink);
+  stamp();
 }
 
 size_t fused_ddpg_lds_bytes() { return sizeof(float) * FusedLds<256>::total; }

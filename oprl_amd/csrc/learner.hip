@@ -380,6 +380,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   a.y_out = h->ydbg; a.q_out = h->qdbg;
   a.y_granules = h->y_granules;
   a.epoch = h->epoch;
+  a.trace = nullptr;
   a.partials_c = h->part_c; a.partials_a = h->part_a;
   return a;
 }
@@ -409,7 +410,8 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
   if (h->fused) {
     h->epoch += 1;
     if (h->epoch == 0) h->epoch = 1;
-    const DdpgArgs fa = ddpg_args(h, B);
+    DdpgArgs fa = ddpg_args(h, B);
+    if (h->trace != nullptr) fa.trace = h->trace;   // roles use slots 0,1,2
     prof_begin(0, st);
     hipError_t e = launch_ddpg_phase1(fa, st);
     prof_end(st);
@@ -486,7 +488,8 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
 int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hipStream_t st) {
   const oprl_learner_config& c = h->cfg;
   if (h->fused) {
-    const DdpgArgs fa = ddpg_args(h, B);
+    DdpgArgs fa = ddpg_args(h, B);
+    if (h->trace != nullptr) fa.trace = h->trace + (size_t)3 * 64 * kTraceStamps * 2;   // slot 3
     prof_begin(0, st);
     hipError_t e = launch_ddpg_phase2(fa, st);
     prof_end(st);

@@ -12,7 +12,8 @@ from oprl_amd.logging import NullLogger
 
 S, A, B = 24, 6, 256
 t.manual_seed(0)
-algo = DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device="cuda", max_batch=B).create()
+algo = DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device="cuda", max_batch=B,
+            no_fuse="--generic" in sys.argv).create()
 L = algo.learner
 NS, NST = 24, 12
 buf = t.zeros((NS, 64, NST, 2), dtype=t.int64, device="cuda")
@@ -26,8 +27,10 @@ for _ in range(3):
     algo.update(*batch)
 t.cuda.synchronize()
 tr = buf.cpu().numpy()
-names = ["actor_t fwd", "critic_t fwd", "critic fwd+bwd", "actor fwd", "critic(s,pi) fwd+bwd", "actor bwd"]
-for slot in range(6):
+fused = "--generic" not in sys.argv
+names = (["P1 role A target chain", "P1 role B critic f+b", "P1 role C actor fwd", "P2 critic f+b, actor bwd"]
+         if fused else ["actor_t fwd", "critic_t fwd", "critic fwd+bwd", "actor fwd", "critic(s,pi) fwd+bwd", "actor bwd"])
+for slot in range(len(names)):
     x = tr[slot, :16]                       # 16 workgroups
     n = int((x[0, :, 0] != 0).sum())
     cyc = x[:, :n, 0].astype(np.float64)
@@ -36,6 +39,6 @@ for slot in range(6):
     d_us = np.diff(rt, axis=1) / 100.0
     tot_us = (rt[:, -1] - rt[:, 0]) / 100.0
     clk = (cyc[:, -1] - cyc[:, 0]) / np.maximum(tot_us, 1e-9) / 1e3
-    print(f"{names[slot]:22s} stamps={n} wg0 phases(us)={np.round(d_us[0], 2).tolist()} total wg0={tot_us[0]:.2f}us "
+    print(f"{names[slot]:26s} stamps={n} wg0 phases(us)={np.round(d_us[0], 2).tolist()} total wg0={tot_us[0]:.2f}us "
           f"max-wg={tot_us.max():.2f}us  cyc/us~{clk.mean():.2f} GHz  start spread={(rt[:,0].max()-rt[:,0].min())/100:.2f}us")
     print(f"{'':22s} wg0 phases(cycles)={d_cyc[0].astype(int).tolist()}")
