@@ -194,7 +194,7 @@ int oprl_profile_read(int64_t* counts_host, double* ms_host, int32_t reset);
  * per-workgroup phase timestamps (shader cycle counter, 100 MHz realtime) to
  * buf[launch_slot][64 workgroups][OPRL_TRACE_STAMPS][2] (int64, device memory);
  * launch_slot restarts at 0 with each update().  NULL disables. */
-#define OPRL_TRACE_STAMPS 12
+#define OPRL_TRACE_STAMPS 24
 #define OPRL_TRACE_SLOTS 24
 int oprl_learner_set_trace(oprl_learner* h, int64_t* buf);
 

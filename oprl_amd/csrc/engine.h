@@ -105,26 +105,35 @@ __device__ __forceinline__ void tile_mac(const float* __restrict__ Xs, int ldx,
   const int lane = threadIdx.x & 63;
   const float* xrow = Xs + (lane & 15) * ldx + 4 * (lane >> 4);
   const float* pl = ptile + lane * 4;
+  // software pipeline: kRing fragments in flight at all times — slot d is
+  // re-requested (macro step s + kRing) right after step s's MFMAs are issued.
+  // (A first version loaded a ring, computed it, then loaded the next: the
+  // second ring's miss was fully exposed and the 256x256 layer took 6.2 us;
+  // tools/ubench_gemm.hip: this structure 4.9 us, MFMA+LDS alone 3.75, stream alone 3.1.)
+  f32x4 b[kRing];
+#pragma unroll
+  for (int d = 0; d < kRing; ++d)
+    if (s0 + d < s1) b[d] = ld4(pl + (size_t)(s0 + d) * 256);
+  __builtin_amdgcn_sched_barrier(0);
+  if (sync_first) {
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll 1
   for (int sb = s0; sb < s1; sb += kRing) {
-    f32x4 b[kRing];
-#pragma unroll
-    for (int d = 0; d < kRing; ++d)
-      if (sb + d < s1) b[d] = ld4(pl + (size_t)(sb + d) * 256);
-    __builtin_amdgcn_sched_barrier(0);
-    if (sync_first && sb == s0) {
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
-    }
 #pragma unroll
     for (int d = 0; d < kRing; ++d) {
-      if (sb + d < s1) {
-        const f32x4 a4 = ld4(xrow + 16 * (sb + d));
+      const int s = sb + d;
+      if (s < s1) {
+        const f32x4 a4 = ld4(xrow + 16 * s);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc = mfma4(a4[t], b[d][t], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + kRing < s1) b[d] = ld4(pl + (size_t)(s + kRing) * 256);   // refill the slot just consumed
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -139,6 +148,9 @@ __device__ __forceinline__ void tile_mac(const float* __restrict__ Xs, int ldx,
 // GEMMs with ceil(NS / (kWaves/NT)) <= kFrag (use frag_fits()).
 // ---------------------------------------------------------------------------
 constexpr int kFrag = 4;
+// Measured on MI355X: prefetching the small GEMMs' fragments changes nothing (their cost is
+// barrier skew + issue, not the weight miss) and costs 16-32 VGPRs, so it is compiled out.
+constexpr bool kUseFrag = false;
 struct Frag {
   f32x4 b[kFrag];
 };
@@ -206,12 +218,14 @@ __device__ __forceinline__ void tile_mac_pre(const float* __restrict__ Xs, int l
 // `bias` (nullable, `nbias` valid entries) is added to the result before epi; it is
 // loaded BEFORE the MFMA loop — a load issued in the epilogue sits behind the
 // sched_barriers and costs a full exposed round trip per GEMM.
-template <class Epi>
+struct NoStamp { __device__ __forceinline__ void operator()() const {} };
+
+template <class Epi, class DStamp = NoStamp>
 __device__ __forceinline__ void gemm_packed(const float* __restrict__ Xs, int ldx,
                                             const float* __restrict__ pack, int NT, int NS,
                                             float* __restrict__ scratch,
                                             const float* __restrict__ bias, int nbias, Epi&& epi,
-                                            bool use_pre, const Frag& pre) {
+                                            bool use_pre, const Frag& pre, DStamp dstamp = DStamp()) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
   if (NT >= kWaves) {
@@ -259,8 +273,10 @@ __device__ __forceinline__ void gemm_packed(const float* __restrict__ Xs, int ld
     const int rrow = rrem >> 4, rcol = 16 * rt + (rrem & 15);
     const float rb = (bias != nullptr && rmine && rcol < nbias) ? bias[rcol] : 0.f;
     __builtin_amdgcn_sched_barrier(0);
+    dstamp();
     if (use_pre) {
       __syncthreads();
+      dstamp();
       if (tile < NT && s0 < s1) tile_mac_pre(Xs, ldx, pre, 0, s0, s1, acc);
     } else if (tile < NT && s0 < s1) {
       tile_mac(Xs, ldx, pack + (size_t)tile * NS * 256, s0, s1, acc, true);
@@ -269,7 +285,9 @@ __device__ __forceinline__ void gemm_packed(const float* __restrict__ Xs, int ld
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) scratch[(wave * kR + kk * 4 + r) * 16 + i] = acc[r];
+    dstamp();
     __syncthreads();
+    dstamp();
     if (rmine) {
       float v = 0.f;
       const float* sp = scratch + ((rt * wpt) * kR + rrow) * 16 + (rrem & 15);
@@ -285,7 +303,9 @@ __device__ __forceinline__ void gemm_packed(const float* __restrict__ Xs, int ld
       for (int p = 0; p < wpt; ++p) v += scratch[((t * wpt + p) * kR + row) * 16 + (rem & 15)];
       epi(row, col, v);
     }
+    dstamp();
     __syncthreads();
+    dstamp();
   }
 }
 
@@ -406,20 +426,20 @@ __device__ __forceinline__ void mlp_forward_slice(const Net& net, const float* x
   const int N = pick(net.dims, L);
   const int NTo = cdiv(N, 16);
   const float* pf_out = pick(net.pf, L - 1);
-  const bool pre_out = frag_fits(NTo, NTW);
+  const bool pre_out = kUseFrag && frag_fits(NTo, NTW);
   Frag fo;
 #pragma unroll
   for (int d = 0; d < kFrag; ++d) fo.b[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (L == 2) {   // no hidden GEMM to hide behind: request now, before layer 0
     if (pre_out) fo = prefetch_frags(pf_out, NTo, NTW);
-    if (next_pack != nullptr) next_out = prefetch_frags(next_pack, next_NT, next_NS);
+    if (kUseFrag && next_pack != nullptr) next_out = prefetch_frags(next_pack, next_NT, next_NS);
   }
   {
     const float* bias = net.b[0];
     float* Ys = hbase;
     gemm_packed(x0s, kX0Ld, net.pf[0], NTW, cdiv(net.dims[0], 16), scr, bias, WIDTH,
                 [&](int row, int col, float v) { Ys[row * WL + col] = fmaxf(v, 0.f); },
-                have_l0, l0);
+                kUseFrag && have_l0, l0);
   }
   stamp();
 #pragma unroll
@@ -427,7 +447,7 @@ __device__ __forceinline__ void mlp_forward_slice(const Net& net, const float* x
     if (l < L - 1) {
       if (l == L - 2) {   // last hidden GEMM: the small GEMMs that follow it load now
         if (pre_out) fo = prefetch_frags(pf_out, NTo, NTW);
-        if (next_pack != nullptr) next_out = prefetch_frags(next_pack, next_NT, next_NS);
+        if (kUseFrag && next_pack != nullptr) next_out = prefetch_frags(next_pack, next_NT, next_NS);
       }
       const float* bias = net.b[l];
       float* Ys = hbase + l * HB;
@@ -440,7 +460,11 @@ __device__ __forceinline__ void mlp_forward_slice(const Net& net, const float* x
     const float* bias = pick(net.b, L - 1);
     gemm_packed(hbase + (L - 2) * HB, WL, pf_out, NTo, NTW, scr, bias, N,
                 [&](int row, int col, float v) { outS[row * kOutLd + col] = col < N ? v : 0.f; },
-                pre_out, fo);
+                pre_out, fo
+#ifdef OPRL_TRACE_NARROW
+                , [&]() { stamp(); }
+#endif
+    );
   }
   // (the narrow GEMM ended with a barrier: every hidden buffer is complete)
   if (store_x) {
@@ -488,7 +512,7 @@ __device__ __forceinline__ void mlp_backward_slice(const Net& net, const float* 
   int ns = cdiv(pick(net.dims, L), 16);
   const int K0 = net.dims[0];
   const int NT0 = cdiv(K0, 16);
-  const bool pre_dact = dact_cols > 0 && frag_fits(NT0, NTW);
+  const bool pre_dact = kUseFrag && dact_cols > 0 && frag_fits(NT0, NTW);
   Frag fd;
 #pragma unroll
   for (int d = 0; d < kFrag; ++d) fd.b[d] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -497,13 +521,13 @@ __device__ __forceinline__ void mlp_backward_slice(const Net& net, const float* 
     if (l <= L - 1) {
       if (l == 1) {   // last wide GEMM of this backward: what follows it loads now
         if (pre_dact) fd = prefetch_frags(net.pb[0], NT0, NTW);
-        if (next_pack != nullptr) next_out = prefetch_frags(next_pack, next_NT, next_NS);
+        if (kUseFrag && next_pack != nullptr) next_out = prefetch_frags(next_pack, next_NT, next_NS);
       }
       float* dx = hbase + (l - 1) * HB;   // holds H (mask) now, dX afterwards
       gemm_packed(dy, ldy, net.pb[l], NTW, ns, scr, nullptr, 0, [&](int row, int col, float v) {
         float* p = dx + row * WL + col;
         *p = *p > 0.f ? v : 0.f;
-      }, have_out && l == L - 1, out_bwd);
+      }, kUseFrag && have_out && l == L - 1, out_bwd);
       if (dYg[l - 1] != nullptr) {
         __syncthreads();
         store_rows4(dx, WL, dYg[l - 1], WIDTH, WIDTH, row0, B);

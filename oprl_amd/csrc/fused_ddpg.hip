@@ -133,8 +133,10 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   constexpr int NTW = WIDTH / 16;
   // this role's first layer-0 fragments are requested before the minibatch rows
   const Net& first = blockIdx.y == 0 ? A.actor_t : (blockIdx.y == 1 ? A.critic : A.actor);
-  const Frag f0 = prefetch_frags(first.pf[0], NTW, cdiv(first.dims[0], 16));
-  Frag fnext, sink;
+  Frag f0, fnext, sink;
+#pragma unroll
+  for (int d = 0; d < kFrag; ++d) f0.b[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (kUseFrag) f0 = prefetch_frags(first.pf[0], NTW, cdiv(first.dims[0], 16));
 #pragma unroll
   for (int d = 0; d < kFrag; ++d) { fnext.b[d] = f32x4{0.f, 0.f, 0.f, 0.f}; sink.b[d] = fnext.b[d]; }
   load_batch(A.src, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
@@ -268,8 +270,10 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   stamp();
   constexpr int NTW = WIDTH / 16;
   const int Lc = A.critic.n_layers, La = A.actor.n_layers;
-  const Frag f0 = prefetch_frags(A.critic.pf[0], NTW, cdiv(A.critic.dims[0], 16));
-  Frag fcb, fab, sink;
+  Frag f0, fcb, fab, sink;
+#pragma unroll
+  for (int d = 0; d < kFrag; ++d) f0.b[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (kUseFrag) f0 = prefetch_frags(A.critic.pf[0], NTW, cdiv(A.critic.dims[0], 16));
 #pragma unroll
   for (int d = 0; d < kFrag; ++d) { fcb.b[d] = f32x4{0.f, 0.f, 0.f, 0.f}; fab.b[d] = fcb.b[d]; sink.b[d] = fcb.b[d]; }
   // [s | pi] and the actor's forward activations (for its ReLU masks)

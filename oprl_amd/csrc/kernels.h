@@ -136,6 +136,6 @@ struct DdpgArgs {
 constexpr int kDwTile = 32;
 constexpr int kDwThreads = 512;
 constexpr int kDwWaves = 8;
-constexpr int kTraceStamps = 12;
+constexpr int kTraceStamps = 24;
 
 }  // namespace oprl

@@ -15,7 +15,7 @@ t.manual_seed(0)
 algo = DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device="cuda", max_batch=B,
             no_fuse="--generic" in sys.argv).create()
 L = algo.learner
-NS, NST = 24, 12
+NS, NST = 24, 24
 buf = t.zeros((NS, 64, NST, 2), dtype=t.int64, device="cuda")
 batch = [t.randn(B, S, device="cuda"), t.rand(B, A, device="cuda") * 2 - 1, t.rand(B, 1, device="cuda"),
          t.zeros(B, 1, device="cuda"), t.randn(B, S, device="cuda")]
