@@ -222,6 +222,10 @@ struct oprl_learner {
   bool actor_updated_last = false;
   long long* trace = nullptr;
   int trace_slot = 0;
+  // side streams: independent per-net launches (twin / quantile critics) run concurrently
+  hipStream_t side[OPRL_MAX_CRITICS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[OPRL_MAX_CRITICS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool have_side = false;
   bool fused = false;          // DDPG two-kernel path
   unsigned long long* y_granules = nullptr;   // [Bmax] TD-target hand-off (fused DDPG)
   unsigned epoch = 0;          // monotonically increasing, never reset
@@ -346,6 +350,28 @@ hipError_t launch_dw_prof(const DwArgs& a, hipStream_t st) {
   return e;
 }
 
+// Run launch_j(j, stream) for j in [0, n): net 0 on the caller's stream, the others on
+// side streams forked from / joined back into it, so independent nets overlap on the GPU
+// (each k_mlp_slice launch occupies only ceil(B/16) of the 256 CUs).
+template <class F>
+int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
+  // measured: the event fork/join costs more than it saves for 2 nets (TD3 8.8k -> 7.7k/s),
+  // pays for the 5 quantile critics of TQC (673 -> 1206/s)
+  if (n <= 2 || !h->have_side) {
+    for (int j = 0; j < n; ++j) RC(launch_j(j, st));
+    return OPRL_OK;
+  }
+  HIPC(hipEventRecord(h->ev_fork, st));
+  for (int j = 1; j < n; ++j) HIPC(hipStreamWaitEvent(h->side[j], h->ev_fork, 0));
+  for (int j = 0; j < n; ++j) {
+    hipStream_t sj = j == 0 ? st : h->side[j];
+    RC(launch_j(j, sj));
+    if (j > 0) HIPC(hipEventRecord(h->ev_join[j], sj));
+  }
+  for (int j = 1; j < n; ++j) HIPC(hipStreamWaitEvent(st, h->ev_join[j], 0));
+  return OPRL_OK;
+}
+
 const double* alpha_ptr(const oprl_learner* h) {
   const bool learned = h->cfg.algo == OPRL_TQC || (h->cfg.algo == OPRL_SAC && h->cfg.hp.tune_alpha);
   return learned ? h->cfg.log_alpha : nullptr;
@@ -433,21 +459,21 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     else { f.out_act = ACT_GAUSS; f.logp = h->logp2; seed_rng(f, h, noise0, 1); }
     RC(launch(f, h->w_actor, st));
   }
-  // 2. target critics on (s', a')
-  for (int j = 0; j < nc; ++j) {
+  // 2. target critics on (s', a')   (independent: one stream each)
+  RC(for_each_net(h, nc, st, [&](int j, hipStream_t sj) {
     MlpArgs f = base_args(h, c.critics[j], true, B);
     f.do_fwd = 1;
     f.x0 = s2; f.k0 = S; f.x1 = h->a2; f.k1 = A;
     f.out = h->qn + (size_t)j * h->Bmax * h->ldq; f.ldo = h->ldq;
-    RC(launch(f, h->w_critic, st));
-  }
+    return launch(f, h->w_critic, sj);
+  }));
   if (algo == OPRL_TQC) {
     const int Q = c.hp.n_quantiles, drop = c.hp.top_quantiles_to_drop;
     HIPC(launch_tqc_target(h->qn, (long)h->Bmax * h->ldq, h->ldq, nc, Q, drop, r, d, h->logp2,
                            c.log_alpha, (float)c.hp.gamma, B, h->target, st));
   }
-  // 3. online critics: forward + loss seed + backward
-  for (int j = 0; j < nc; ++j) {
+  // 3. online critics: forward + loss seed + backward   (independent: one stream each)
+  RC(for_each_net(h, nc, st, [&](int j, hipStream_t sj) {
     MlpArgs f = base_args(h, c.critics[j], false, B);
     f.do_fwd = 1; f.do_bwd = 1;
     f.x0 = s; f.k0 = S; f.x1 = a; f.k1 = A;
@@ -469,8 +495,8 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
       sd.cval = 1.0f / (float)B;
       if (j == 0) { sd.y_out = h->ydbg; sd.q_out = h->qdbg; }
     }
-    RC(launch(f, h->w_critic, st));
-  }
+    return launch(f, h->w_critic, sj);
+  }));
   // 4. dW + Adam (+ Polyak where the reference does it every step)
   {
     const bool polyak = (algo == OPRL_TD3) ? (h->update_count % c.hp.policy_freq == 0) : true;
@@ -518,15 +544,15 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
   // 6./7. critics on (s, pi): gradient wrt the action columns
   const int n_q = (algo == OPRL_TD3 || algo == OPRL_DDPG) ? 1 : nc;   // TD3 uses Q1 only
   if (algo == OPRL_SAC) {
-    for (int j = 0; j < nc; ++j) {   // both q's are needed before either seed (min)
+    RC(for_each_net(h, nc, st, [&](int j, hipStream_t sj) {   // both q's before either seed (min)
       MlpArgs f = base_args(h, c.critics[j], false, B);
       f.do_fwd = 1;
       f.x0 = s; f.k0 = S; f.x1 = h->pi; f.k1 = A;
       with_store(f, h->ws_critic[j], true, false);
       f.out = h->qpi + (size_t)j * h->Bmax; f.ldo = 1;
-      RC(launch(f, h->w_critic, st));
-    }
-    for (int j = 0; j < nc; ++j) {
+      return launch(f, h->w_critic, sj);
+    }));
+    RC(for_each_net(h, nc, st, [&](int j, hipStream_t sj) {
       MlpArgs f = base_args(h, c.critics[j], false, B);
       f.do_bwd = 1;
       with_store(f, h->ws_critic[j], true, false);
@@ -535,10 +561,10 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
       f.seed.cval = 1.0f / (float)B;
       f.dact_col0 = S; f.dact_cols = A; f.dact = h->da + (size_t)j * h->Bmax * A; f.lddact = A;
       if (j == 0) f.partials = h->part_a;
-      RC(launch(f, h->w_critic, st));
-    }
+      return launch(f, h->w_critic, sj);
+    }));
   } else {
-    for (int j = 0; j < n_q; ++j) {
+    RC(for_each_net(h, n_q, st, [&](int j, hipStream_t sj) {
       MlpArgs f = base_args(h, c.critics[j], false, B);
       f.do_fwd = 1; f.do_bwd = 1;
       f.x0 = s; f.k0 = S; f.x1 = h->pi; f.k1 = A;
@@ -547,8 +573,8 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
                                        : -1.0f / (float)B;
       f.dact_col0 = S; f.dact_cols = A; f.dact = h->da + (size_t)j * h->Bmax * A; f.lddact = A;
       if (j == 0) f.partials = h->part_a;
-      RC(launch(f, h->w_critic, st));
-    }
+      return launch(f, h->w_critic, sj);
+    }));
   }
   // 8. actor backward from the stored activations
   {
@@ -722,6 +748,13 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   if (e == hipSuccess) e = init_fused_attrs();
   if (e != hipSuccess) { set_err("hipFuncSetAttribute: %s", hipGetErrorString(e)); delete h; return OPRL_ERR_HIP; }
   memset(&h->src, 0, sizeof h->src);
+  if (h->nc > 2 && getenv("OPRL_AMD_NO_SIDE_STREAMS") == nullptr) {
+    bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int j = 1; ok && j < h->nc; ++j)
+      ok = hipStreamCreateWithFlags(&h->side[j], hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&h->ev_join[j], hipEventDisableTiming) == hipSuccess;
+    h->have_side = ok;
+  }
   h->fused = cfg->algo == OPRL_DDPG && !cfg->no_fuse && h->w_actor == 256 && h->w_critic == 256 &&
              cfg->actor.n_layers == 3 && cfg->critics[0].n_layers == 3;
 
@@ -825,6 +858,11 @@ extern "C" int oprl_net_repack(const oprl_net* net, int32_t which, void* stream)
 extern "C" int oprl_learner_destroy(oprl_learner* h) {
   if (!h) return OPRL_OK;
   (void)hipDeviceSynchronize();
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  for (int j = 1; j < OPRL_MAX_CRITICS; ++j) {
+    if (h->ev_join[j]) (void)hipEventDestroy(h->ev_join[j]);
+    if (h->side[j]) (void)hipStreamDestroy(h->side[j]);
+  }
   (void)hipFree(h->pool.base);
   delete h;
   return OPRL_OK;

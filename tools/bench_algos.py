@@ -1,0 +1,35 @@
+"""update() throughput of all four algorithms at the BASELINE.json configs
+(parity-test cases 2-4 + DDPG), fixed synthetic minibatch resident in HBM, noise
+drawn on device.  Not the headline bench (bench.py); numbers for DESIGN.md."""
+import sys
+import time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch as t
+from oprl_amd.algos.ddpg import DDPG
+from oprl_amd.algos.sac import SAC
+from oprl_amd.algos.td3 import TD3
+from oprl_amd.algos.tqc import TQC
+from oprl_amd.logging import NullLogger
+
+CASES = [("DDPG walker B=256", DDPG, 24, 6, 256, {}),
+         ("TD3 cheetah B=256", TD3, 17, 6, 256, dict(log_every=10 ** 9)),
+         ("SAC humanoid B=1024", SAC, 67, 21, 1024, dict(log_every=10 ** 9)),
+         ("SAC walker tuned B=256", SAC, 24, 6, 256, dict(log_every=10 ** 9, tune_alpha=True)),
+         ("TQC walker B=256", TQC, 24, 6, 256, dict(log_every=10 ** 9))]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+for name, cls, S, A, B, kw in CASES:
+    t.manual_seed(0)
+    algo = cls(logger=NullLogger(), state_dim=S, action_dim=A, device="cuda", max_batch=B, **kw).create()
+    batch = [t.randn(B, S, device="cuda"), t.rand(B, A, device="cuda") * 2 - 1, t.rand(B, 1, device="cuda"),
+             t.zeros(B, 1, device="cuda"), t.randn(B, S, device="cuda")]
+    L = algo.learner
+    for _ in range(100):
+        L.update(*batch)
+    t.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        L.update(*batch)
+    t.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"{name:26s} {n / dt:9.1f} updates/s  {dt / n * 1e6:8.1f} us/update", flush=True)
