@@ -168,10 +168,10 @@ def main():
         from oprl_amd.parallel import DataParallelLearner
         dp = DataParallelLearner(algo, dist.group.WORLD)
         dp.broadcast_parameters()
+        dp.init_native_comm()
 
         def run(n):
-            for _ in range(n):
-                dp.update(*replay.sample(B))
+            dp.step_n(replay.handle, n, B, seed=0)
 
     def barrier():
         t.cuda.synchronize(dev)
@@ -225,7 +225,7 @@ def main():
                                    f"{E}x{L} transitions resident in HBM, device-side uniform sampling, "
                                    "exact-fp32 MFMA (parity mode)",
                        "path": "oprl_learner_step_n" if not use_dp else
-                               "update_phase/apply + RCCL all-reduce of critic and actor grads per step",
+                               "oprl_learner_dp_step_n: update_phase/apply + 2 RCCL all-reduces (critic, actor grads) per step, all in C",
                        "parallelism": f"dp{world}", "global_batch": B * world},
             "roofline": roof, "cpu_baseline": cpu,
             "flop_per_step": 2.0 * B * (MACS_SLICE + MACS_DW), "state_bytes_per_step": STATE_BYTES,

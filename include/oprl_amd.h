@@ -180,6 +180,26 @@ int oprl_adam_step(float* theta, float* m, float* v, const float* grad, int64_t 
 /* target <- (1-tau)*target + tau*source  (nn_functions.py:5-10) */
 int oprl_polyak(float* target, const float* source, int64_t n, double tau, void* stream);
 
+/* ---- data parallel over RCCL (xGMI) ---------------------------------------- */
+/* One process per GPU.  The library binds RCCL at run time from `rccl_path`
+ * (dlopen; e.g. torch's bundled librccl.so) — it does not link it.  Rank 0 obtains
+ * a 128-byte unique id, the host distributes it (any side channel, e.g.
+ * torch.distributed's store), every rank calls oprl_comm_init on a learner created
+ * with export_grads = 1.  oprl_learner_dp_update / dp_step_n then run the
+ * synchronous data-parallel update entirely in C: critic phase -> ncclAllReduce of
+ * the critic gradient arena -> Adam with grads scaled by 1/world -> actor phase ->
+ * ncclAllReduce of the actor gradient arena (and the temperature gradient) -> Adam.
+ * New functionality (the reference has a single learner). */
+#define OPRL_COMM_ID_BYTES 128
+int oprl_comm_unique_id(const char* rccl_path, char id_out[OPRL_COMM_ID_BYTES]);
+int oprl_comm_init(oprl_learner* h, const char* rccl_path, int32_t rank, int32_t world,
+                   const char id[OPRL_COMM_ID_BYTES]);
+int oprl_learner_dp_update(oprl_learner* h, const float* s, const float* a, const float* r,
+                           const float* d, const float* s2, int32_t B, const float* noise0,
+                           const float* noise1, void* stream);
+int oprl_learner_dp_step_n(oprl_learner* h, oprl_replay* replay, int32_t K, int32_t B,
+                           uint64_t seed, void* stream);
+
 /* ---- measurement --------------------------------------------------------- */
 /* When enabled, every kernel launch of this library is bracketed by a pair of
  * hipEvents recorded on the launch stream.  oprl_profile_read synchronises the

@@ -90,6 +90,10 @@ SIGNATURES = {
     "oprl_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _D, _D, _D, _D, _D, _P]),
     "oprl_polyak": (C.c_int, [_P, _P, _I64, _D, _P]),
     "oprl_learner_set_trace": (C.c_int, [_P, _P]),
+    "oprl_comm_unique_id": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "oprl_comm_init": (C.c_int, [_P, C.c_char_p, _I32, _I32, C.c_char_p]),
+    "oprl_learner_dp_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P]),
+    "oprl_learner_dp_step_n": (C.c_int, [_P, _P, _I32, _I32, _U64, _P]),
     "oprl_profile_enable": (C.c_int, [_I32]),
     "oprl_profile_read": (C.c_int, [C.POINTER(_I64), C.POINTER(C.c_double), _I32]),
     "oprl_replay_create": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _P, _P, C.POINTER(_P)]),

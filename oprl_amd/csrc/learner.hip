@@ -6,6 +6,7 @@
 // loss sees the post-Adam critic, Polyak sees both updated nets):
 //   DDPG  algos/ddpg.py:61-107      TD3  algos/td3.py:71-146
 //   SAC   algos/sac.py:75-155       TQC  algos/tqc.py:116-189
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>
@@ -103,6 +104,44 @@ hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st);
 }  // namespace oprl
 
 using namespace oprl;
+
+// ---- minimal run-time binding of RCCL (NCCL API; enum values are the API's) ----
+namespace {
+struct NcclId { char internal[OPRL_COMM_ID_BYTES]; };
+typedef int (*fn_get_unique_id)(NcclId*);
+typedef int (*fn_comm_init_rank)(void**, int, NcclId, int);
+typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_comm_destroy)(void*);
+typedef const char* (*fn_get_error_string)(int);
+constexpr int kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0;
+
+struct Rccl {
+  void* lib = nullptr;
+  fn_get_unique_id get_unique_id = nullptr;
+  fn_comm_init_rank comm_init_rank = nullptr;
+  fn_all_reduce all_reduce = nullptr;
+  fn_comm_destroy comm_destroy = nullptr;
+  fn_get_error_string err_str = nullptr;
+  void* comm = nullptr;
+  int rank = 0, world = 1;
+};
+
+int rccl_bind(Rccl& r, const char* path) {
+  if (r.lib) return OPRL_OK;
+  r.lib = dlopen(path && path[0] ? path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!r.lib) { set_err("dlopen(%s) failed: %s", path ? path : "librccl.so", dlerror()); return OPRL_ERR_INVALID; }
+  r.get_unique_id = (fn_get_unique_id)dlsym(r.lib, "ncclGetUniqueId");
+  r.comm_init_rank = (fn_comm_init_rank)dlsym(r.lib, "ncclCommInitRank");
+  r.all_reduce = (fn_all_reduce)dlsym(r.lib, "ncclAllReduce");
+  r.comm_destroy = (fn_comm_destroy)dlsym(r.lib, "ncclCommDestroy");
+  r.err_str = (fn_get_error_string)dlsym(r.lib, "ncclGetErrorString");
+  if (!r.get_unique_id || !r.comm_init_rank || !r.all_reduce) {
+    set_err("%s does not export the NCCL API", path ? path : "librccl.so");
+    return OPRL_ERR_INVALID;
+  }
+  return OPRL_OK;
+}
+}  // namespace
 
 #define HIPC(x)                                                                        \
   do {                                                                                 \
@@ -222,6 +261,8 @@ struct oprl_learner {
   bool actor_updated_last = false;
   long long* trace = nullptr;
   int trace_slot = 0;
+  Rccl rccl;
+  long n_critic_params = 0, n_actor_params = 0;
   // side streams: independent per-net launches (twin / quantile critics) run concurrently
   hipStream_t side[OPRL_MAX_CRITICS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[OPRL_MAX_CRITICS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -676,6 +717,104 @@ int check_batch(const oprl_learner* h, const void* s, const void* a, const void*
 // =========================================================================== C-ABI
 extern "C" const char* oprl_last_error(void) { return g_err.c_str(); }
 
+#define NCCLC(h, x)                                                                   \
+  do {                                                                                 \
+    int _r = (x);                                                                      \
+    if (_r != 0) {                                                                     \
+      set_err("%s failed: %s", #x, (h)->rccl.err_str ? (h)->rccl.err_str(_r) : "nccl error"); \
+      return OPRL_ERR_HIP;                                                             \
+    }                                                                                  \
+  } while (0)
+
+extern "C" int oprl_comm_unique_id(const char* rccl_path, char id_out[OPRL_COMM_ID_BYTES]) {
+  if (!id_out) { set_err("oprl_comm_unique_id: null output"); return OPRL_ERR_INVALID; }
+  static Rccl r;
+  RC(rccl_bind(r, rccl_path));
+  NcclId id;
+  const int rc = r.get_unique_id(&id);
+  if (rc != 0) { set_err("ncclGetUniqueId failed (%d)", rc); return OPRL_ERR_HIP; }
+  memcpy(id_out, id.internal, OPRL_COMM_ID_BYTES);
+  return OPRL_OK;
+}
+
+extern "C" int oprl_comm_init(oprl_learner* h, const char* rccl_path, int32_t rank, int32_t world,
+                              const char id[OPRL_COMM_ID_BYTES]) {
+  if (!h || !id || world < 1 || rank < 0 || rank >= world) { set_err("oprl_comm_init: invalid argument"); return OPRL_ERR_INVALID; }
+  if (!h->cfg.export_grads) { set_err("oprl_comm_init: learner was not created with export_grads"); return OPRL_ERR_STATE; }
+  // the gradient arenas must be contiguous per group (critics back to back)
+  long off = 0;
+  for (int j = 0; j < h->nc; ++j) {
+    if (h->cfg.critics[j].grad != h->cfg.critics[0].grad + off) { set_err("critic gradient arenas are not contiguous"); return OPRL_ERR_INVALID; }
+    off += net_param_count(h->cfg.critics[j]);
+  }
+  h->n_critic_params = off;
+  h->n_actor_params = net_param_count(h->cfg.actor);
+  RC(rccl_bind(h->rccl, rccl_path));
+  NcclId nid;
+  memcpy(nid.internal, id, OPRL_COMM_ID_BYTES);
+  NCCLC(h, h->rccl.comm_init_rank(&h->rccl.comm, world, nid, rank));
+  h->rccl.rank = rank;
+  h->rccl.world = world;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_learner_dp_update(oprl_learner* h, const float* s, const float* a, const float* r,
+                                      const float* d, const float* s2, int32_t B, const float* noise0,
+                                      const float* noise1, void* stream) {
+  if (!h || !h->rccl.comm) { set_err("oprl_learner_dp_update: call oprl_comm_init first"); return OPRL_ERR_STATE; }
+  hipStream_t st = (hipStream_t)stream;
+  const oprl_learner_config& c = h->cfg;
+  const double scale = 1.0 / (double)h->rccl.world;
+  RC(oprl_learner_update_phase(h, 0, s, a, r, d, s2, B, noise0, noise1, stream));
+  NCCLC(h, h->rccl.all_reduce(c.critics[0].grad, c.critics[0].grad, (size_t)h->n_critic_params,
+                              kNcclFloat32, kNcclSum, h->rccl.comm, st));
+  RC(oprl_learner_apply(h, 0, scale, stream));
+  RC(oprl_learner_update_phase(h, 1, s, a, r, d, s2, B, noise0, noise1, stream));
+  if (h->actor_updated_last) {
+    NCCLC(h, h->rccl.all_reduce(c.actor.grad, c.actor.grad, (size_t)h->n_actor_params, kNcclFloat32,
+                                kNcclSum, h->rccl.comm, st));
+    if (alpha_ptr(h) != nullptr)
+      NCCLC(h, h->rccl.all_reduce(h->alpha_grad, h->alpha_grad, 1, kNcclFloat64, kNcclSum, h->rccl.comm, st));
+    RC(oprl_learner_apply(h, 1, scale, stream));
+  }
+  return OPRL_OK;
+}
+
+extern "C" int oprl_learner_dp_step_n(oprl_learner* h, oprl_replay* replay, int32_t K, int32_t B,
+                                      uint64_t seed, void* stream) {
+  if (!h || !replay) { set_err("oprl_learner_dp_step_n: null handle"); return OPRL_ERR_INVALID; }
+  if (!h->rccl.comm) { set_err("oprl_learner_dp_step_n: call oprl_comm_init first"); return OPRL_ERR_STATE; }
+  int S = 0, A = 0;
+  replay_dims(replay, &S, &A);
+  if (S != h->S || A != h->A) { set_err("replay dims (%d,%d) != learner dims (%d,%d)", S, A, h->S, h->A); return OPRL_ERR_INVALID; }
+  if (K < 0 || B < 1 || B > h->Bmax) { set_err("dp_step_n: bad K/B"); return OPRL_ERR_INVALID; }
+  // every rank samples its own shard: the Philox key mixes the rank in
+  const uint64_t rseed = seed * 0x9E3779B97F4A7C15ull + (uint64_t)h->rccl.rank;
+  if (h->fused) {
+    BatchSrc& sc = h->src;
+    RC(oprl_replay_flush(replay, stream));
+    long n_tr = 0;
+    replay_view(replay, &sc.states, &sc.actions, &sc.rewards, &sc.dones, &sc.ends, &sc.n_eps, &sc.L, &n_tr);
+    if (n_tr <= 0 || sc.n_eps <= 0) { set_err("dp_step_n: replay buffer is empty"); return OPRL_ERR_STATE; }
+    sc.n_transitions = n_tr;
+    sc.seed = rseed;
+    sc.gather = 1;
+    int rc = OPRL_OK;
+    for (int k = 0; k < K && rc == OPRL_OK; ++k) {
+      sc.counter = (unsigned long long)h->update_count;
+      rc = oprl_learner_dp_update(h, h->bs, h->ba, h->br, h->bd, h->bs2, B, nullptr, nullptr, stream);
+    }
+    sc.gather = 0;
+    return rc;
+  }
+  for (int k = 0; k < K; ++k) {
+    RC(oprl_replay_sample(replay, B, nullptr, rseed, (uint64_t)h->update_count, h->bs, h->ba, h->br,
+                          h->bd, h->bs2, nullptr, nullptr, stream));
+    RC(oprl_learner_dp_update(h, h->bs, h->ba, h->br, h->bd, h->bs2, B, nullptr, nullptr, stream));
+  }
+  return OPRL_OK;
+}
+
 extern "C" int oprl_profile_enable(int32_t on) {
   if (!on) prof_fold();
   g_prof.on = on != 0;
@@ -858,6 +997,7 @@ extern "C" int oprl_net_repack(const oprl_net* net, int32_t which, void* stream)
 extern "C" int oprl_learner_destroy(oprl_learner* h) {
   if (!h) return OPRL_OK;
   (void)hipDeviceSynchronize();
+  if (h->rccl.comm && h->rccl.comm_destroy) (void)h->rccl.comm_destroy(h->rccl.comm);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   for (int j = 1; j < OPRL_MAX_CRITICS; ++j) {
     if (h->ev_join[j]) (void)hipEventDestroy(h->ev_join[j]);

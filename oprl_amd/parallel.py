@@ -32,6 +32,42 @@ class DataParallelLearner:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
 
+    # ---- native (C) data-parallel loop -------------------------------------------
+    def init_native_comm(self, rccl_path: str | None = None) -> None:
+        """Give the C library its own RCCL communicator so the whole synchronous
+        update (phase -> all-reduce -> Adam -> phase -> all-reduce -> Adam) runs in C
+        (``oprl_learner_dp_update`` / ``dp_step_n``) without a python round trip per
+        collective.  The 128-byte unique id travels over torch.distributed."""
+        import ctypes as C
+        import os
+
+        from oprl_amd import _capi
+        lib = _capi.load()
+        if rccl_path is None:
+            rccl_path = os.path.join(os.path.dirname(t.__file__), "lib", "librccl.so")
+        path = rccl_path.encode()
+        box = [None]
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            _capi.check(lib.oprl_comm_unique_id(path, buf), "oprl_comm_unique_id")
+            box[0] = buf.raw
+        dist.broadcast_object_list(box, src=0, group=self.group)
+        with t.cuda.device(self.engine.device):
+            _capi.check(lib.oprl_comm_init(self.engine.handle, path, self.rank, self.world, box[0]),
+                        "oprl_comm_init")
+        self._native = True
+
+    def step_n(self, replay_handle, K: int, B: int, seed: int = 0) -> None:
+        """K synchronous data-parallel sample()+update() iterations in one C call."""
+        from oprl_amd import _capi
+        if not getattr(self, "_native", False):
+            raise RuntimeError("call init_native_comm() first")
+        e = self.engine
+        e.check_bound()
+        with t.cuda.device(e.device):
+            _capi.check(e.lib.oprl_learner_dp_step_n(e.handle, replay_handle, K, B, seed,
+                                                     _capi.current_stream()), "oprl_learner_dp_step_n")
+
     # ---- replica management ---------------------------------------------------
     def _state_tensors(self):
         e = self.engine

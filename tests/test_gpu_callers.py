@@ -160,3 +160,42 @@ def _mk_buffer():
 def _mk_logger():
     from oprl_amd.logging import NullLogger
     return NullLogger("/tmp/oprl_amd_test")
+
+
+def test_native_dp_single_rank_equals_export_split():
+    """World-size-1 RCCL communicator on this GPU: the C data-parallel loop
+    (dp_step_n: phase -> ncclAllReduce -> apply, twice per update) must reproduce the
+    python-driven export_grads split bit for bit."""
+    import os
+    import tempfile
+    import torch.distributed as dist
+    from oprl_amd.parallel import DataParallelLearner
+    created = False
+    if not dist.is_initialized():
+        f = tempfile.NamedTemporaryFile(delete=False)
+        dist.init_process_group("nccl", init_method=f"file://{f.name}", rank=0, world_size=1,
+                                device_id=t.device("cuda", 0))
+        created = True
+    try:
+        K, B = 6, 64
+        a1, a2 = _ddpg(max_batch=B, export_grads=True), _ddpg(max_batch=B, export_grads=True)
+        buf = _filled_buffer()
+        dp = DataParallelLearner(a1)
+        dp.broadcast_parameters()
+        dp.init_native_comm()
+        dp.step_n(buf.handle, K, B, seed=5)
+        # python-driven reference: same shard key as the C loop derives for rank 0
+        buf.seed = (5 * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+        L = a2.learner
+        for k in range(K):
+            buf._sample_counter = k
+            batch = buf.sample(B)
+            L.update_phase(0, *batch); L.apply(0, 1.0)
+            L.update_phase(1, *batch); L.apply(1, 1.0)
+        t.cuda.synchronize()
+        for m in ("actor", "critic", "actor_target", "critic_target"):
+            assert t.equal(getattr(a1, m)._oprl_arena, getattr(a2, m)._oprl_arena), m
+        assert float(dp.replica_checksum().abs().max()) == 0
+    finally:
+        if created:
+            dist.destroy_process_group()
