@@ -50,6 +50,12 @@ F_CRITIC = (S + A) * HID + HID * HID + HID * 1
 MACS_SLICE = (2 * F_ACTOR + 3 * F_CRITIC + (HID + HID * HID) + (HID + HID * HID + HID * A)
               + (A * HID + HID * HID))
 MACS_DW = F_ACTOR + F_CRITIC           # one dW pass per trained net
+# fused path (csrc/fused_ddpg.hip): phase 1 = actor_t, critic_t, critic, actor forwards +
+# critic hidden backward; phase 2 = critic forward, critic backward incl. action columns,
+# actor hidden backward
+MACS_P1 = 2 * F_ACTOR + 2 * F_CRITIC + (HID + HID * HID)
+MACS_P2 = F_CRITIC + (HID + HID * HID + HID * A) + (A * HID + HID * HID)
+assert MACS_P1 + MACS_P2 == MACS_SLICE
 STATE_BYTES = 32 * (F_ACTOR + HID * 2 + A + F_CRITIC + HID * 2 + 1)  # 32 B per trainable param
 
 
@@ -199,22 +205,35 @@ def main():
             P = max(1, min(args.profile_steps, K))
             lib.oprl_profile_enable(1)
             learner.step_n(replay.handle, P, B, seed=1)
-            cnt = (C.c_int64 * 4)()
-            ms = (C.c_double * 4)()
+            NK = 6
+            cnt = (C.c_int64 * NK)()
+            ms = (C.c_double * NK)()
             _capi.check(lib.oprl_profile_read(cnt, ms, 1))
             lib.oprl_profile_enable(0)
-            names = ["k_mlp_slice", "k_dw_adam", "k_replay_gather", "other"]
+            names = ["k_mlp_slice", "k_dw_adam", "k_replay_gather", "other", "k_ddpg_phase1", "k_ddpg_phase2"]
             kern = {names[i]: dict(launches_per_step=cnt[i] / P, us_per_launch=(ms[i] * 1e3 / cnt[i]) if cnt[i] else 0.0,
-                                   us_per_step=ms[i] * 1e3 / P) for i in range(4)}
-            flop_per_launch = 2.0 * B * MACS_SLICE / kern["k_mlp_slice"]["launches_per_step"]
-            ach = flop_per_launch / (kern["k_mlp_slice"]["us_per_launch"] * 1e-6) / 1e12
-            roof = dict(bound="mfma", kernel="k_mlp_slice<256> (exact-fp32 v_mfma_f32_16x16x4_f32)",
+                                   us_per_step=ms[i] * 1e3 / P) for i in range(NK) if cnt[i]}
+            # dominant kernel: phase 1 of the fused path (falls back to the generic slice kernel)
+            dom = "k_ddpg_phase1" if "k_ddpg_phase1" in kern else "k_mlp_slice"
+            macs = MACS_P1 if dom == "k_ddpg_phase1" else MACS_SLICE / kern[dom]["launches_per_step"]
+            flop_per_launch = 2.0 * B * macs
+            ach = flop_per_launch / (kern[dom]["us_per_launch"] * 1e-6) / 1e12
+            traffic = None
+            try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+                pmc = json.load(open(ROOT / "profiles" / "r01c_pmc_traffic.json"))
+                traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                pass
+            roof = dict(bound="mfma", kernel=f"{dom}<256> (exact-fp32 v_mfma_f32_16x16x4_f32)",
                         achieved=round(ach, 3), peak=PEAK_F32_MATRIX_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_F32_MATRIX_TFLOPS, 5), traffic=None,
+                        frac=round(ach / PEAK_F32_MATRIX_TFLOPS, 5), traffic=traffic,
                         flop_per_launch=flop_per_launch, kernels=kern,
                         note="durations from hipEvent pairs around each launch (serialised pass of "
                              f"{P} steps); sum of kernel time per step = "
-                             f"{sum(k['us_per_step'] for k in kern.values()):.1f} us")
+                             f"{sum(k['us_per_step'] for k in kern.values()):.1f} us; traffic = "
+                             "(2*FETCH_SIZE + WRITE_SIZE) KB from profiles/r01c_pmc_traffic.json; the "
+                             "launch occupies 48 of 256 CUs (3 roles x 16 slices), so the chip-level "
+                             "fraction is bounded by 48/256 = 0.19")
         cpu = None if args.no_cpu_baseline else cpu_baseline()
         out = {
             "metric": "learner gradient steps/sec, DDPG batch=256 walker-walk",

@@ -205,8 +205,8 @@ int oprl_learner_dp_step_n(oprl_learner* h, oprl_replay* replay, int32_t K, int3
  * hipEvents recorded on the launch stream.  oprl_profile_read synchronises the
  * device and returns, per kernel kind, the launch count and the summed
  * hipEventElapsedTime (ms).  Kinds: 0 k_mlp_slice, 1 k_dw_adam, 2 k_replay_gather,
- * 3 everything else.  bench.py's roofline uses this. */
-#define OPRL_PROFILE_KINDS 4
+ * 3 everything else, 4 k_ddpg_phase1, 5 k_ddpg_phase2.  bench.py's roofline uses this. */
+#define OPRL_PROFILE_KINDS 6
 int oprl_profile_enable(int32_t on);
 int oprl_profile_read(int64_t* counts_host, double* ms_host, int32_t reset);
 

@@ -37,8 +37,8 @@ struct Prof {
   bool on = false;
   std::vector<hipEvent_t> ev;      // pairs
   std::vector<int> kind;
-  long counts[OPRL_PROFILE_KINDS] = {0, 0, 0, 0};
-  double ms[OPRL_PROFILE_KINDS] = {0, 0, 0, 0};
+  long counts[OPRL_PROFILE_KINDS] = {0, 0, 0, 0, 0, 0};
+  double ms[OPRL_PROFILE_KINDS] = {0, 0, 0, 0, 0, 0};
 };
 static Prof g_prof;
 static const size_t kProfMaxPairs = 1 << 16;
@@ -479,7 +479,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     if (h->epoch == 0) h->epoch = 1;
     DdpgArgs fa = ddpg_args(h, B);
     if (h->trace != nullptr) fa.trace = h->trace;   // roles use slots 0,1,2
-    prof_begin(0, st);
+    prof_begin(4, st);
     hipError_t e = launch_ddpg_phase1(fa, st);
     prof_end(st);
     HIPC(e);
@@ -557,7 +557,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
   if (h->fused) {
     DdpgArgs fa = ddpg_args(h, B);
     if (h->trace != nullptr) fa.trace = h->trace + (size_t)3 * 64 * kTraceStamps * 2;   // slot 3
-    prof_begin(0, st);
+    prof_begin(5, st);
     hipError_t e = launch_ddpg_phase2(fa, st);
     prof_end(st);
     HIPC(e);
