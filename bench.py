@@ -123,6 +123,39 @@ def cpu_baseline(budget_s: float = 14.0):
                        f"torch {t.__version__}")
 
 
+def multi_learner(n, dev, local_rank, steps):
+    """Aggregate steps/s of n independent DDPG learners (own weights, own replay seed)
+    driven from one host thread on n streams — the reference's ``--seeds`` fan-out
+    (runners/train.py:36-50) without one process per seed.  Each learner's update is
+    4 asynchronous launches occupying <= 48 CUs, so several fit on the chip at once.
+    Reported beside the headline, never as it."""
+    from oprl_amd.algos.ddpg import DDPG
+    from oprl_amd.logging import NullLogger
+    algos, streams, replays = [], [], []
+    for i in range(n):
+        t.manual_seed(100 + i)
+        algos.append(DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device=f"cuda:{local_rank}",
+                          max_batch=B).create())
+        streams.append(t.cuda.Stream(device=dev))
+    shared = make_replay(dev, seed=7)          # one HBM replay, n sampler keys
+    chunk = 50
+
+    def run(k):
+        for _ in range(k // chunk):
+            for i, (a, st) in enumerate(zip(algos, streams)):
+                with t.cuda.stream(st):
+                    a.learner.step_n(shared.handle, chunk, B, seed=1000 + i)
+    run(chunk * 2)
+    t.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    run(steps)
+    t.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    done = (steps // chunk) * chunk * n
+    return dict(learners=n, value=round(done / dt, 1), unit="steps/s (aggregate)",
+                per_learner=round(done / dt / n, 1), steps_each=(steps // chunk) * chunk)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +163,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2000)
+    ap.add_argument("--learners", type=int, default=8,
+                    help="extra measurement: this many independent learners (seeds) on separate "
+                         "streams of the same GPU (multi-seed packing, runners/train.py --seeds); 0 = skip")
     ap.add_argument("--force-dp", action="store_true",
                     help="use the data-parallel path (RCCL all-reduce) even with one rank")
     args = ap.parse_args()
@@ -234,6 +270,9 @@ def main():
                              "(2*FETCH_SIZE + WRITE_SIZE) KB from profiles/r01c_pmc_traffic.json; the "
                              "launch occupies 48 of 256 CUs (3 roles x 16 slices), so the chip-level "
                              "fraction is bounded by 48/256 = 0.19")
+        multi = None
+        if not use_dp and args.learners > 1:
+            multi = multi_learner(args.learners, dev, local_rank, steps=max(200, min(K, 2000)))
         cpu = None if args.no_cpu_baseline else cpu_baseline()
         out = {
             "metric": "learner gradient steps/sec, DDPG batch=256 walker-walk",
@@ -246,7 +285,7 @@ def main():
                        "path": "oprl_learner_step_n" if not use_dp else
                                "oprl_learner_dp_step_n: update_phase/apply + 2 RCCL all-reduces (critic, actor grads) per step, all in C",
                        "parallelism": f"dp{world}", "global_batch": B * world},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "multi_learner": multi,
             "flop_per_step": 2.0 * B * (MACS_SLICE + MACS_DW), "state_bytes_per_step": STATE_BYTES,
         }
         print(json.dumps(out), flush=True)
