@@ -11,7 +11,8 @@ __global__ void k_touch(float* w, long n, float v) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) w[i] = w[i] * 0.5f + v;
 }
 
-// MODE 0 full; 1 no global loads (B from a register constant); 2 no LDS A reads; 3 no MFMA (adds)
+// MODE 0 full; 1 no global loads (B from a register constant); 2 no LDS A reads; 3 no MFMA (adds);
+// 4 full with the ring kept full ACROSS layers (last RING slots refilled with the next layer's head)
 template <int MODE, int RING, int NACC>
 __global__ __launch_bounds__(1024) void k_gemm(const float* __restrict__ packs, int n_layers, float* out, long long* cyc) {
   __shared__ __attribute__((aligned(16))) float X[2][kR * lds_ld(256)];
@@ -22,15 +23,24 @@ __global__ __launch_bounds__(1024) void k_gemm(const float* __restrict__ packs, 
   const float* xrow0 = &X[0][0] + (lane & 15) * WL + 4 * (lane >> 4);
   long long t0 = __builtin_readcyclecounter();
   int cur = 0;
+  f32x4 carry[RING];
+#pragma unroll
+  for (int d = 0; d < RING; ++d) carry[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int l = 0; l < n_layers; ++l) {
     const float* pl = packs + (size_t)l * 65536 + (size_t)wave * 16 * 256 + lane * 4;
     const float* xrow = xrow0 + cur * kR * WL;
     f32x4 acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    static_assert(MODE != 4 || true, "");
     f32x4 b[RING];
+    if (MODE != 4 || l == 0) {
 #pragma unroll
-    for (int d = 0; d < RING; ++d) b[d] = (MODE == 1) ? f32x4{1.f, 2.f, 3.f, 4.f} : ld4(pl + (size_t)d * 256);
+      for (int d = 0; d < RING; ++d) b[d] = (MODE == 1) ? f32x4{1.f, 2.f, 3.f, 4.f} : ld4(pl + (size_t)d * 256);
+    } else {
+#pragma unroll
+      for (int d = 0; d < RING; ++d) b[d] = carry[d];
+    }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
@@ -48,8 +58,13 @@ __global__ __launch_bounds__(1024) void k_gemm(const float* __restrict__ packs, 
         }
         __builtin_amdgcn_sched_barrier(0);
         if (MODE != 1 && s + RING < 16) b[d] = ld4(pl + (size_t)(s + RING) * 256);
+        else if (MODE == 4 && l + 1 < n_layers) b[d] = ld4(pl + 65536 + (size_t)(s + RING - 16) * 256);
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
+    if (MODE == 4) {
+#pragma unroll
+      for (int d = 0; d < RING; ++d) carry[d] = b[d];
     }
     f32x4 r = acc[0];
 #pragma unroll
@@ -95,6 +110,8 @@ int main() {
   run<1, 8, 4>("no global loads, 4 accumulators", packs, NL, 16, out, cyc);
   run<2, 8, 1>("no LDS A reads", packs, NL, 16, out, cyc);
   run<3, 8, 1>("no MFMA (VALU fma)", packs, NL, 16, out, cyc);
+  run<4, 8, 1>("full, ring kept full across layers", packs, NL, 16, out, cyc);
+  run<4, 4, 1>("full, ring kept full across layers", packs, NL, 16, out, cyc);
   run<0, 8, 1>("full, 1 workgroup", packs, NL, 1, out, cyc);
   return 0;
 }
