@@ -225,9 +225,13 @@ __device__ __forceinline__ void gemm_packed(const float* __restrict__ Xs, int ld
                                             const float* __restrict__ pack, int NT, int NS,
                                             float* __restrict__ scratch,
                                             const float* __restrict__ bias, int nbias, Epi&& epi,
-                                            bool use_pre, const Frag& pre, DStamp dstamp = DStamp()) {
+                                            bool use_pre, const Frag& pre, DStamp dstamp = DStamp(),
+                                            int tile_stride = 0) {
+  // tile_stride: floats between two tiles' step-0 blocks; 0 = NS*256 (a whole pack).  A
+  // caller contracting over a sub-range of a pack's steps passes the pack's full stride.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
+  const size_t tstride = tile_stride > 0 ? (size_t)tile_stride : (size_t)NS * 256;
   if (NT >= kWaves) {
     if (use_pre) {   // fragments already in registers: (tile-of-wave, step) order
       const int per = NT / kWaves;
@@ -256,7 +260,7 @@ __device__ __forceinline__ void gemm_packed(const float* __restrict__ Xs, int ld
       const int col = 16 * tile + i;
       const float bv = (bias != nullptr && col < nbias) ? bias[col] : 0.f;
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      tile_mac(Xs, ldx, pack + (size_t)tile * NS * 256, 0, NS, acc, tile == wave);
+      tile_mac(Xs, ldx, pack + (size_t)tile * tstride, 0, NS, acc, tile == wave);
 #pragma unroll
       for (int r = 0; r < 4; ++r) epi(kk * 4 + r, col, acc[r] + bv);
     }
@@ -279,7 +283,7 @@ __device__ __forceinline__ void gemm_packed(const float* __restrict__ Xs, int ld
       dstamp();
       if (tile < NT && s0 < s1) tile_mac_pre(Xs, ldx, pre, 0, s0, s1, acc);
     } else if (tile < NT && s0 < s1) {
-      tile_mac(Xs, ldx, pack + (size_t)tile * NS * 256, s0, s1, acc, true);
+      tile_mac(Xs, ldx, pack + (size_t)tile * tstride, s0, s1, acc, true);
     } else {
       __syncthreads();   // idle wave: still owes the X-visibility barrier
     }

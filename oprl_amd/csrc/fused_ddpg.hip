@@ -5,8 +5,12 @@
 // re-zero, and the actor's forward — which does not depend on the critic step —
 // sits on the critical path.  Here:
 //
-//   k_ddpg_phase1, grid (slices, 3) — three concurrent roles per 16-row slice, each
-//   on its own CU, each gathering the same rows:
+//   Every role below is a CLUSTER of nc = 4 workgroups sharing its 16-row slice
+//   tensor-parallel (csrc/tp3.h): the 256 KB hidden layer is split by columns, only
+//   [16 x N<=48] partial outputs are exchanged.
+//
+//   k_ddpg_phase1, grid (slices, 3*nc) — three concurrent roles per 16-row slice, each
+//   gathering the same rows:
 //     A  actor_target(s') -> critic_target(s', a') -> y = r + (1-d) gamma q'
 //        -> y handed to role B as 8-byte {epoch, value} granules   (ddpg.py:94-95)
 //     B  critic(s, a) forward (concurrently with A) -> wait for y -> 2(q-y)/B
@@ -28,6 +32,7 @@
 // draw and index map as k_replay_gather (step_n).
 #include "kernels.h"
 #include "philox.h"
+#include "tp3.h"
 
 namespace oprl {
 
@@ -107,9 +112,11 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<WIDTH>;
   constexpr int WL = lds_ld(WIDTH);
+  constexpr int HB = kR * WL;
   float* xa = smem + LY::xa;
   float* xb = smem + LY::xb;
-  float* hb = smem + LY::h;
+  float* h1 = smem + LY::h;
+  float* h2 = h1 + HB;
   float* outS = smem + LY::out;
   float* auxS = smem + LY::aux;
   float* scr = smem + LY::scr;
@@ -118,56 +125,53 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   float* yS = dS + kR;
   int* meta = reinterpret_cast<int*>(yS + kR);
   int* endsS = reinterpret_cast<int*>(smem + LY::misc + 96);
-  const int row0 = blockIdx.x * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
-  float* const none[kMaxLayers] = {nullptr, nullptr, nullptr, nullptr};
+  const int slice = blockIdx.x, row0 = slice * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
+  const int role = blockIdx.y / A.nc;          // 0 = A target chain, 1 = B critic, 2 = C actor forward
+  Tp tp{(int)blockIdx.y % A.nc, A.nc,
+        A.xbuf + ((size_t)role * gridDim.x + slice) * kTpStages * A.nc * kTpBlk, A.cluster_tag, 0};
+  const bool lead = tp.c == 0;                 // member 0 does the un-sliced global stores
   int n_stamp = 0;
   auto stamp = [&]() {
-    if (A.trace != nullptr && tid == 0 && n_stamp < kTraceStamps) {
-      long long* tr = A.trace + (((size_t)blockIdx.y * 64 + blockIdx.x) * kTraceStamps + n_stamp) * 2;
+    if (A.trace != nullptr && tid == 0 && lead && n_stamp < kTraceStamps) {
+      long long* tr = A.trace + (((size_t)role * 64 + slice) * kTraceStamps + n_stamp) * 2;
       tr[0] = (long long)__builtin_readcyclecounter();
       tr[1] = (long long)wall_clock64();
     }
     ++n_stamp;
   };
   stamp();   // entry
-  constexpr int NTW = WIDTH / 16;
-  // this role's first layer-0 fragments are requested before the minibatch rows
-  const Net& first = blockIdx.y == 0 ? A.actor_t : (blockIdx.y == 1 ? A.critic : A.actor);
-  Frag f0, fnext, sink;
-#pragma unroll
-  for (int d = 0; d < kFrag; ++d) f0.b[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (kUseFrag) f0 = prefetch_frags(first.pf[0], NTW, cdiv(first.dims[0], 16));
-#pragma unroll
-  for (int d = 0; d < kFrag; ++d) { fnext.b[d] = f32x4{0.f, 0.f, 0.f, 0.f}; sink.b[d] = fnext.b[d]; }
   load_batch(A.src, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
   stamp();   // batch rows requested
+  const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
 
-  if (blockIdx.y == 2) {
+  if (role == 2) {
     // ---- role C: actor(s) forward.  Pack rows beyond S are zero, so [s | a] serves as input.
-    mlp_forward_slice<WIDTH>(A.actor, xa, hb, outS, scr, A.aX, true, row0, B, stamp, true, f0,
-                             nullptr, 0, 0, sink);
-    for (int idx = tid; idx < kR * Ad; idx += kThreads) {
-      const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
-      if (gr < B) A.pi[(size_t)gr * Ad + col] = tanhf(outS[row * kOutLd + col]);
+    const Tp3Store st{A.aX[1], A.aX[2], nullptr, nullptr, 0};
+    tp3_forward<WIDTH>(A.actor, xa, h1, h2, outS, scr, tp, st, row0, B);
+    stamp();
+    if (lead) {
+      for (int idx = tid; idx < kR * Ad; idx += kThreads) {
+        const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
+        if (gr < B) A.pi[(size_t)gr * Ad + col] = tanhf(outS[row * kOutLd + col]);
+      }
+      store_rows(xa, kX0Ld, A.aX[0], A.aldx0, S, row0, B);
     }
-    store_rows(xa, kX0Ld, A.aX[0], A.aldx0, S, row0, B);
     stamp();
     return;
   }
 
-  if (blockIdx.y == 0) {
+  if (role == 0) {
     // ---- role A: a' = tanh(actor_target(s')), q' = critic_target(s', a'), TD target
-    // (critic_target's layer-0 fragments are requested behind actor_target's hidden GEMM)
-    mlp_forward_slice<WIDTH>(A.actor_t, xb, hb, outS, scr, none, false, row0, B, stamp, true, f0,
-                             A.critic_t.pf[0], NTW, cdiv(A.critic_t.dims[0], 16), fnext);
+    tp3_forward<WIDTH>(A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B);
+    stamp();
     for (int idx = tid; idx < kR * Ad; idx += kThreads) {
       const int row = idx / Ad, col = idx - row * Ad;
       xb[row * kX0Ld + S + col] = (row0 + row < B) ? tanhf(outS[row * kOutLd + col]) : 0.f;
     }
     // (the next GEMM's own barrier publishes xb)
-    mlp_forward_slice<WIDTH>(A.critic_t, xb, hb, outS, scr, none, false, row0, B, stamp, true, fnext,
-                             nullptr, 0, 0, sink);
-    if (tid < kR && row0 + tid < B) {
+    tp3_forward<WIDTH>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B);
+    stamp();
+    if (lead && tid < kR && row0 + tid < B) {
       const float y = rS[tid] + ((1.f - dS[tid]) * A.gamma) * outS[tid * kOutLd];
       // hand-off to role B of this slice: ONE aligned 8-byte {epoch, value} granule per
       // row, written through (agent-scope relaxed atomic = sc1 store); the tag makes the
@@ -180,11 +184,10 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   }
 
   // ---- role B: q = critic(s, a) forward (runs while role A computes the target)
-  // (the output layer's BACKWARD fragments are requested behind the hidden GEMM too)
-  const int Lc = A.critic.n_layers;
-  mlp_forward_slice<WIDTH>(A.critic, xa, hb, outS, scr, A.cX, true, row0, B, stamp, true, f0,
-                           pick(A.critic.pb, Lc - 1), NTW, cdiv(pick(A.critic.dims, Lc), 16), fnext);
-  store_rows(xa, kX0Ld, A.cX[0], A.cldx0, S + Ad, row0, B);
+  const Tp3Store st{A.cX[1], A.cX[2], A.cdY[1], A.cdY[0], A.cdY0_stride};
+  tp3_forward<WIDTH>(A.critic, xa, h1, h2, outS, scr, tp, st, row0, B);
+  stamp();
+  if (lead) store_rows(xa, kX0Ld, A.cX[0], A.cldx0, S + Ad, row0, B);
   // wait for this slice's TD targets: lanes 0..15 of wave 0 poll their granule (relaxed,
   // L1-bypassing) with a sleep in between; the spin is BOUNDED — on give-up the target
   // becomes NaN, which the parity tests and the loss diagnostics expose, instead of a hang.
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
     if (tid < kR) yS[tid] = y;
   }
   stamp();   // TD target received
-  // ---- seed 2(q - y)/B, diagnostics
+  // ---- seed 2(q - y)/B, diagnostics (every member computes the same seed)
   lds_zero(auxS, kR * kOutLd);
   __syncthreads();
   float p_loss = 0.f, p_q = 0.f, p_y = 0.f;
@@ -213,14 +216,14 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
     if (gr < B) {
       const float q = outS[tid * kOutLd], y = yS[tid];
       auxS[tid * kOutLd] = 2.f * (q - y) * A.inv_B;
-      if (A.y_out != nullptr) A.y_out[gr] = y;
-      if (A.q_out != nullptr) A.q_out[gr] = q;
+      if (lead && A.y_out != nullptr) A.y_out[gr] = y;
+      if (lead && A.q_out != nullptr) A.q_out[gr] = q;
       p_loss = (q - y) * (q - y);
       p_q = q;
       p_y = y;
     }
   }
-  if (A.partials_c != nullptr) {
+  if (A.partials_c != nullptr && lead) {
     __syncthreads();
     float v[3] = {p_loss, p_q, p_y};
 #pragma unroll
@@ -233,13 +236,12 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
     if (tid < 3) {
       float sum = 0.f;
       for (int w = 0; w < kWaves; ++w) sum += scr[w * 4 + tid];
-      A.partials_c[blockIdx.x * 4 + tid] = sum;
+      A.partials_c[slice * 4 + tid] = sum;
     }
   }
   __syncthreads();
-  store_rows(auxS, kOutLd, pick(A.cdY, A.critic.n_layers - 1), A.clddo, 1, row0, B);
-  mlp_backward_slice<WIDTH>(A.critic, auxS, hb, scr, A.cdY, row0, B, 0, 0, auxS, stamp, true, fnext,
-                            nullptr, 0, 0, sink);
+  if (lead) store_rows(auxS, kOutLd, A.cdY[2], A.clddo, 1, row0, B);
+  tp3_backward<WIDTH>(A.critic, auxS, h1, h2, scr, tp, st, row0, B, 0, 0, auxS);
   stamp();
 }
 
@@ -250,44 +252,40 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   constexpr int WL = lds_ld(WIDTH);
   constexpr int HB = kR * WL;
   float* xa = smem + LY::xa;
-  float* hb = smem + LY::h;          // critic hidden (2 buffers), then actor hidden (2 buffers)
-  float* ha = hb + 2 * HB;
+  float* h1 = smem + LY::h;          // critic hidden (2 buffers), then actor hidden (2 buffers)
+  float* h2 = h1 + HB;
+  float* ha1 = h2 + HB;
+  float* ha2 = ha1 + HB;
   float* outS = smem + LY::out;
   float* auxS = smem + LY::aux;
   float* scr = smem + LY::scr;
   float* piS = smem + LY::xb;        // [kR][kX0Ld] tile reused for pi
-  const int row0 = blockIdx.x * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
-  float* const none[kMaxLayers] = {nullptr, nullptr, nullptr, nullptr};
+  const int slice = blockIdx.x, row0 = slice * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
+  Tp tp{(int)blockIdx.y, A.nc, A.xbuf + (size_t)slice * kTpStages * A.nc * kTpBlk, A.cluster_tag, 0};
+  const bool lead = tp.c == 0;
   int n_stamp = 0;
   auto stamp = [&]() {
-    if (A.trace != nullptr && tid == 0 && n_stamp < kTraceStamps) {
-      long long* tr = A.trace + (((size_t)blockIdx.y * 64 + blockIdx.x) * kTraceStamps + n_stamp) * 2;
+    if (A.trace != nullptr && tid == 0 && lead && n_stamp < kTraceStamps) {
+      long long* tr = A.trace + ((size_t)slice * kTraceStamps + n_stamp) * 2;
       tr[0] = (long long)__builtin_readcyclecounter();
       tr[1] = (long long)wall_clock64();
     }
     ++n_stamp;
   };
   stamp();
-  constexpr int NTW = WIDTH / 16;
-  const int Lc = A.critic.n_layers, La = A.actor.n_layers;
-  Frag f0, fcb, fab, sink;
-#pragma unroll
-  for (int d = 0; d < kFrag; ++d) f0.b[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (kUseFrag) f0 = prefetch_frags(A.critic.pf[0], NTW, cdiv(A.critic.dims[0], 16));
-#pragma unroll
-  for (int d = 0; d < kFrag; ++d) { fcb.b[d] = f32x4{0.f, 0.f, 0.f, 0.f}; fab.b[d] = fcb.b[d]; sink.b[d] = fcb.b[d]; }
+  const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
   // [s | pi] and the actor's forward activations (for its ReLU masks)
   lds_zero(xa, 2 * kR * kX0Ld);
   __syncthreads();
   load_rows(xa, kX0Ld, 0, A.aX[0], A.aldx0, S, row0, B);
   load_rows(xa, kX0Ld, S, A.pi, Ad, Ad, row0, B);
   load_rows(piS, kX0Ld, 0, A.pi, Ad, Ad, row0, B);
-#pragma unroll
-  for (int l = 1; l < kMaxLayers; ++l)
-    if (l < A.actor.n_layers) load_rows4(ha + (l - 1) * HB, WL, A.aX[l], WIDTH, WIDTH, row0, B);
+  load_rows4(ha1, WL, A.aX[1], WIDTH, WIDTH, row0, B);
+  load_rows4(ha2, WL, A.aX[2], WIDTH, WIDTH, row0, B);
+  stamp();
   // ---- q = critic(s, pi) with the updated critic
-  mlp_forward_slice<WIDTH>(A.critic, xa, hb, outS, scr, none, false, row0, B, stamp, true, f0,
-                           pick(A.critic.pb, Lc - 1), NTW, cdiv(pick(A.critic.dims, Lc), 16), fcb);
+  tp3_forward<WIDTH>(A.critic, xa, h1, h2, outS, scr, tp, nostore, row0, B);
+  stamp();
   lds_zero(auxS, kR * kOutLd);
   __syncthreads();
   float p_q = 0.f;
@@ -295,7 +293,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
     auxS[tid * kOutLd] = -A.inv_B;
     p_q = outS[tid * kOutLd];
   }
-  if (A.partials_a != nullptr) {
+  if (A.partials_a != nullptr && lead) {
     __syncthreads();
     float v = p_q;
 #pragma unroll
@@ -305,15 +303,13 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
     if (tid == 0) {
       float sum = 0.f;
       for (int w = 0; w < kWaves; ++w) sum += scr[w * 4 + 1];
-      A.partials_a[blockIdx.x * 4 + 0] = 0.f;
-      A.partials_a[blockIdx.x * 4 + 1] = sum;
-      A.partials_a[blockIdx.x * 4 + 2] = 0.f;
+      A.partials_a[slice * 4 + 0] = 0.f;
+      A.partials_a[slice * 4 + 1] = sum;
+      A.partials_a[slice * 4 + 2] = 0.f;
     }
   }
   // ---- critic backward down to the action columns: da -> auxS[:, 0:A]
-  // (the ACTOR's output-layer backward fragments ride behind the critic's hidden backward)
-  mlp_backward_slice<WIDTH>(A.critic, auxS, hb, scr, none, row0, B, S, Ad, auxS, stamp, true, fcb,
-                            pick(A.actor.pb, La - 1), NTW, cdiv(pick(A.actor.dims, La), 16), fab);
+  tp3_backward<WIDTH>(A.critic, auxS, h1, h2, scr, tp, nostore, row0, B, S, Ad, auxS);
   stamp();   // da ready
   // ---- du = da (1 - pi^2), zero padded
   float du = 0.f;
@@ -328,14 +324,15 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   __syncthreads();
   if (mine) auxS[r_ * kOutLd + c_] = du;
   __syncthreads();
-  store_rows(auxS, kOutLd, pick(A.adY, A.actor.n_layers - 1), A.alddo, Ad, row0, B);
+  if (lead) store_rows(auxS, kOutLd, A.adY[2], A.alddo, Ad, row0, B);
   // ---- actor backward over its stored activations
-  mlp_backward_slice<WIDTH>(A.actor, auxS, ha, scr, A.adY, row0, B, 0, 0, auxS, stamp, true, fab,
-                            nullptr, 0, 0, sink);
+  const Tp3Store sta{nullptr, nullptr, A.adY[1], A.adY[0], A.adY0_stride};
+  tp3_backward<WIDTH>(A.actor, auxS, ha1, ha2, scr, tp, sta, row0, B, 0, 0, auxS);
   stamp();
 }
 
 size_t fused_ddpg_lds_bytes() { return sizeof(float) * FusedLds<256>::total; }
+size_t fused_xbuf_granules_per_cluster(int nc) { return (size_t)kTpStages * nc * kTpBlk; }
 
 hipError_t init_fused_attrs() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddpg_phase1<256>),
@@ -347,13 +344,13 @@ hipError_t init_fused_attrs() {
 
 hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
-  hipLaunchKernelGGL(k_ddpg_phase1<256>, dim3(slices, 3), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  hipLaunchKernelGGL(k_ddpg_phase1<256>, dim3(slices, 3 * a.nc), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
   return hipGetLastError();
 }
 
 hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
-  hipLaunchKernelGGL(k_ddpg_phase2<256>, dim3(slices), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  hipLaunchKernelGGL(k_ddpg_phase2<256>, dim3(slices, a.nc), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
   return hipGetLastError();
 }
 

@@ -78,6 +78,7 @@ struct DwItem {      // one Linear layer of one net
   float *b, *b_t, *b_m, *b_v, *b_g;    // [N]
   float *pf, *pb, *tpf;                // fragment-order packs: W (fwd), W^T (bwd), target W (fwd)
   int tiles_k, tile_begin, tile_end;
+  long dY_part_stride;                 // > 0: dY is the sum of DwArgs::n_part buffers this many floats apart
 };
 
 struct RepackItem {  // one Linear layer: master -> packs
@@ -101,6 +102,7 @@ struct AdamScalars {
 
 struct DwArgs {
   const DwItem* items; int n_items; int total_tiles; int B;
+  int n_part;                          // members of the tensor-parallel cluster that wrote dz1 partials
   AdamScalars ad;
 };
 
@@ -129,6 +131,10 @@ struct DdpgArgs {
   float *y_out, *q_out;                // [B] diagnostics / parity
   unsigned long long* y_granules;      // [B] {epoch<<32 | float bits}: TD target hand-off between roles
   unsigned epoch;                      // monotonically increasing per update, never 0
+  int nc;                              // CUs per slice cluster (tensor-parallel, csrc/tp3.h): 1, 2 or 4
+  unsigned long long* xbuf;            // cluster exchange areas: [role][slice][kTpStages][nc][kTpBlk] granules
+  unsigned cluster_tag;                // launch-unique
+  long cdY0_stride, adY0_stride;       // floats between the members' dz1 partial buffers
   float *partials_c, *partials_a;      // [slices][4]
   long long* trace;
 };

@@ -319,6 +319,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwArgs A) {
   const int n_base = tn * T, k_base = tk * T;
   const int i = lane & 15, c = lane >> 4;
   const int NSk = cdiv(I.K, 16), NSn = cdiv(I.N, 16);
+  const int npart = I.dY_part_stride > 0 ? A.n_part : 1;
 
   // this thread's share of the epilogue: 2 consecutive k of one row n.  Its Adam
   // state is requested NOW so the round trip overlaps the GEMM.
@@ -353,17 +354,32 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwArgs A) {
   constexpr int U = 8;
   constexpr int RPI = 4 * kDwWaves;   // minibatch rows per iteration of the workgroup
   for (int it0 = 0; it0 * RPI < A.B; it0 += U) {
-    f32x2 a2[U], x2[U];
+    f32x2 a2[U], x2[U], ap[U][3];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int b = RPI * (it0 + u) + 4 * wave + c;
       a2[u] = f32x2{0.f, 0.f};
       x2[u] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ap[u][p] = f32x2{0.f, 0.f};
       if (b < A.B) {
-        if (n_ok) a2[u] = *reinterpret_cast<const f32x2*>(I.dY + (size_t)b * I.ldy + ncol);
+        if (n_ok) {
+          const float* src = I.dY + (size_t)b * I.ldy + ncol;
+          a2[u] = *reinterpret_cast<const f32x2*>(src);
+          // tensor-parallel slices leave the first layer's dz as n_part (<= 4) partial
+          // buffers (csrc/tp3.h): all requested up front, summed below in member order
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            if (p + 1 < npart)
+              ap[u][p] = *reinterpret_cast<const f32x2*>(src + (size_t)(p + 1) * I.dY_part_stride);
+        }
         if (k_ok) x2[u] = *reinterpret_cast<const f32x2*>(I.X + (size_t)b * I.ldx + kcol);
       }
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a2[u] += ap[u][p];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       f32x2 av = a2[u], xv = x2[u];

@@ -98,6 +98,7 @@ int replay_view(const oprl_replay* h, const float** states, const float** action
                 const float** rewards, const float** dones, const int** ends, int* n_eps, int* L,
                 long* n_transitions);
 hipError_t init_fused_attrs();
+size_t fused_xbuf_granules_per_cluster(int nc);
 hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st);
 hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st);
 
@@ -218,10 +219,13 @@ Net net_view(const oprl_net& n, bool target) {
 }
 
 // per-net activation / gradient exchange buffers (HBM, sized for max_batch rows)
+constexpr int kMaxCluster = 4;   // CUs per tensor-parallel slice cluster (csrc/tp3.h)
+
 struct NetWs {
   float* X[kMaxLayers] = {nullptr, nullptr, nullptr, nullptr};
   float* dY[kMaxLayers] = {nullptr, nullptr, nullptr, nullptr};
   int ldx0 = 0, lddo = 0, width = 0;
+  long dY0_stride = 0;   // dY[0] is kMaxCluster buffers this many floats apart (dz1 partials)
 };
 
 struct Pool {  // one hipMalloc, bump allocated
@@ -270,6 +274,17 @@ struct oprl_learner {
   bool fused = false;          // DDPG two-kernel path
   unsigned long long* y_granules = nullptr;   // [Bmax] TD-target hand-off (fused DDPG)
   unsigned epoch = 0;          // monotonically increasing, never reset
+  int ncl = 1;                 // CUs per slice cluster in the fused path (csrc/tp3.h)
+  int n_cus = 256;
+  unsigned long long* xbuf = nullptr;
+  size_t xbuf_granules = 0;
+  // largest cluster whose phase-1 grid (3 roles) is fully co-resident, one workgroup per CU
+  int nc_cluster(int B) const {
+    const int slices = (B + kR - 1) / kR;
+    int c = ncl;
+    while (c > 1 && 3 * c * slices > n_cus) c >>= 1;
+    return c;
+  }
   BatchSrc src;                // where the current update's minibatch comes from
   // prebuilt device repack tables: [0] critics online, [1] critics online+target, [2] actor (+target)
   RepackItem* rp_dev[3] = {nullptr, nullptr, nullptr};
@@ -298,6 +313,7 @@ void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int*
     it.pf = n.pack + pack_off_fwd(n, l);
     it.pb = n.pack + pack_off_bwd(n, l);
     it.tpf = n.pack_target ? n.pack_target + pack_off_fwd(n, l) : nullptr;
+    it.dY_part_stride = (l == 0 && n.n_layers > 1) ? ws.dY0_stride : 0;
     const int tn = (it.N + kDwTile - 1) / kDwTile;
     it.tiles_k = (it.K + kDwTile - 1) / kDwTile;
     it.tile_begin = *tiles;
@@ -311,7 +327,7 @@ size_t net_ws_floats(const oprl_net& n, int B) {
   size_t f = 0;
   f += (size_t)B * round_up(n.dims[0], 4) + 64;
   for (int l = 1; l < n.n_layers; ++l) f += (size_t)B * n.dims[1] + 64;
-  for (int l = 0; l < n.n_layers - 1; ++l) f += (size_t)B * n.dims[1] + 64;
+  for (int l = 0; l < n.n_layers - 1; ++l) f += (size_t)B * n.dims[1] * (l == 0 ? kMaxCluster : 1) + 64;
   f += (size_t)B * round_up(n.dims[n.n_layers], 4) + 64;
   return f + 64 * 8;
 }
@@ -322,7 +338,9 @@ void alloc_net_ws(Pool& p, const oprl_net& n, int B, NetWs* ws) {
   ws->lddo = round_up(n.dims[n.n_layers], 4);
   ws->X[0] = p.take<float>((size_t)B * ws->ldx0);
   for (int l = 1; l < n.n_layers; ++l) ws->X[l] = p.take<float>((size_t)B * ws->width);
-  for (int l = 0; l < n.n_layers - 1; ++l) ws->dY[l] = p.take<float>((size_t)B * ws->width);
+  ws->dY0_stride = (long)B * ws->width;
+  for (int l = 0; l < n.n_layers - 1; ++l)
+    ws->dY[l] = p.take<float>((size_t)B * ws->width * (l == 0 ? kMaxCluster : 1));
   ws->dY[n.n_layers - 1] = p.take<float>((size_t)B * ws->lddo);
 }
 
@@ -448,6 +466,10 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   a.y_granules = h->y_granules;
   a.epoch = h->epoch;
   a.trace = nullptr;
+  a.nc = h->nc_cluster(B);
+  a.xbuf = h->xbuf;
+  a.cdY0_stride = h->ws_critic[0].dY0_stride;
+  a.adY0_stride = h->ws_actor.dY0_stride;
   a.partials_c = h->part_c; a.partials_a = h->part_a;
   return a;
 }
@@ -466,6 +488,7 @@ int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st) {
     dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, polyak, 1.0f);
   }
   dw.B = B;
+  dw.n_part = h->fused ? h->nc_cluster(B) : 1;
   HIPC(launch_dw_prof(dw, st));
   return OPRL_OK;
 }
@@ -476,8 +499,13 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
   const oprl_learner_config& c = h->cfg;
   if (h->fused) {
     h->epoch += 1;
-    if (h->epoch == 0) h->epoch = 1;
+    if ((h->epoch & 0x00FFFFFFu) == 0) {   // exchange tags about to wrap: retire every stale granule
+      if (h->epoch == 0) h->epoch = 1;
+      HIPC(hipMemsetAsync(h->xbuf, 0, h->xbuf_granules * sizeof(unsigned long long), st));
+      HIPC(hipMemsetAsync(h->y_granules, 0, (size_t)h->Bmax * sizeof(unsigned long long), st));
+    }
     DdpgArgs fa = ddpg_args(h, B);
+    fa.cluster_tag = (h->epoch << 1) & 0x03FFFFFFu;
     if (h->trace != nullptr) fa.trace = h->trace;   // roles use slots 0,1,2
     prof_begin(4, st);
     hipError_t e = launch_ddpg_phase1(fa, st);
@@ -544,7 +572,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     h->opt_step_critic += 1;
     DwArgs dw;
     dw.items = h->items_dev; dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
-    dw.B = B;
+    dw.B = B; dw.n_part = 1;
     dw.ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, 1.0f);
     HIPC(launch_dw_prof(dw, st));
   }
@@ -556,6 +584,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
   const oprl_learner_config& c = h->cfg;
   if (h->fused) {
     DdpgArgs fa = ddpg_args(h, B);
+    fa.cluster_tag = ((h->epoch << 1) | 1u) & 0x03FFFFFFu;
     if (h->trace != nullptr) fa.trace = h->trace + (size_t)3 * 64 * kTraceStamps * 2;   // slot 3
     prof_begin(5, st);
     hipError_t e = launch_ddpg_phase2(fa, st);
@@ -641,7 +670,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     h->opt_step_actor += 1;
     DwArgs dw;
     dw.items = h->items_dev + h->n_items_critic; dw.n_items = h->n_items_actor;
-    dw.total_tiles = h->tiles_actor; dw.B = B;
+    dw.total_tiles = h->tiles_actor; dw.B = B; dw.n_part = 1;
     dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, c.actor.theta_target != nullptr, 1.0f);
     HIPC(launch_dw_prof(dw, st));
   }
@@ -962,6 +991,22 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   if (hipMemcpy(h->items_dev, items.data(), sizeof(DwItem) * items.size(), hipMemcpyHostToDevice) != hipSuccess) {
     set_err("hipMemcpy(items) failed"); (void)hipFree(p.base); delete h; return OPRL_ERR_HIP;
   }
+  if (h->fused) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      h->n_cus = prop.multiProcessorCount;
+    const char* env = getenv("OPRL_AMD_CLUSTER");
+    h->ncl = env ? atoi(env) : kMaxCluster;
+    if (h->ncl != 1 && h->ncl != 2 && h->ncl != 4) h->ncl = kMaxCluster;
+    const size_t slices = (size_t)(h->Bmax + kR - 1) / kR;
+    h->xbuf_granules = 3 * slices * fused_xbuf_granules_per_cluster(kMaxCluster);
+    if (hipMalloc(&h->xbuf, h->xbuf_granules * sizeof(unsigned long long)) != hipSuccess) {
+      set_err("hipMalloc(cluster exchange area, %zu MB) failed", (h->xbuf_granules * 8) >> 20);
+      (void)hipFree(p.base); delete h; return OPRL_ERR_NOMEM;
+    }
+    (void)hipMemset(h->xbuf, 0, h->xbuf_granules * sizeof(unsigned long long));
+  }
   {
     const oprl_net* nets[OPRL_MAX_CRITICS + 1];
     for (int j = 0; j < nc; ++j) nets[j] = &h->cfg.critics[j];
@@ -998,6 +1043,7 @@ extern "C" int oprl_learner_destroy(oprl_learner* h) {
   if (!h) return OPRL_OK;
   (void)hipDeviceSynchronize();
   if (h->rccl.comm && h->rccl.comm_destroy) (void)h->rccl.comm_destroy(h->rccl.comm);
+  if (h->xbuf) (void)hipFree(h->xbuf);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   for (int j = 1; j < OPRL_MAX_CRITICS; ++j) {
     if (h->ev_join[j]) (void)hipEventDestroy(h->ev_join[j]);
@@ -1234,7 +1280,7 @@ extern "C" int oprl_mlp_backward(const oprl_net* net, const float* x0, int32_t k
   if (dx && net->dims[0] > kNarrowMax) { set_err("oprl_mlp_backward: dx supported for input dim <= %d", kNarrowMax); return OPRL_ERR_INVALID; }
   RC(launch(a, width, st));
   DwArgs dw;
-  dw.items = items_dev; dw.n_items = (int)items.size(); dw.total_tiles = tiles; dw.B = B;
+  dw.items = items_dev; dw.n_items = (int)items.size(); dw.total_tiles = tiles; dw.B = B; dw.n_part = 1;
   memset(&dw.ad, 0, sizeof dw.ad);
   set_adam(dw.ad, 0.0, 0.9, 0.999, 1e-8, 0.0);
   set_step(dw.ad, 1); dw.ad.grad_scale = 1.0f; dw.ad.do_adam = 0;
