@@ -6,8 +6,9 @@
 // sits on the critical path.  Here:
 //
 //   Every role below is a CLUSTER of nc = 4 workgroups sharing its 16-row slice
-//   tensor-parallel (csrc/tp3.h): the 256 KB hidden layer is split by columns, only
-//   [16 x N<=48] partial outputs are exchanged.
+//   tensor-parallel (csrc/tp3.h; csrc/tp4.h = the instruction-lean specialisation for
+//   nc = 4, width 256, used whenever the shapes allow): the 256 KB hidden layer is split by
+//   columns, only [16 x N<=48] partial outputs are exchanged.
 //
 //   k_ddpg_phase1, grid (slices, 3*nc) — three concurrent roles per 16-row slice, each
 //   gathering the same rows:
@@ -32,11 +33,26 @@
 // draw and index map as k_replay_gather (step_n).
 #include "kernels.h"
 #include "philox.h"
-#include "tp3.h"
+#include "tp4.h"
 
 namespace oprl {
 
 constexpr int kMaxEnds = 2048;
+
+// one MLP pass of a cluster: the lean tp4 routines or the generic tp3 ones
+template <int WIDTH, bool LEAN, class ST>
+__device__ __forceinline__ void tp_fwd(const Net& net, const float* x0s, float* h1, float* h2, float* outS,
+                                       float* scr, Tp& tp, const Tp3Store& st, int row0, int B, ST sf) {
+  if constexpr (LEAN) tp4_forward(net, x0s, h1, h2, outS, tp, st, row0, B, sf);
+  else tp3_forward<WIDTH>(net, x0s, h1, h2, outS, scr, tp, st, row0, B, sf);
+}
+template <int WIDTH, bool LEAN, class ST>
+__device__ __forceinline__ void tp_bwd(const Net& net, const float* doutS, float* h1, float* h2, float* scr,
+                                       Tp& tp, const Tp3Store& st, int row0, int B, int dact_col0,
+                                       int dact_cols, float* dactS, ST sf) {
+  if constexpr (LEAN) tp4_backward(net, doutS, h1, h2, scr, tp, st, row0, B, dact_col0, dact_cols, dactS, sf);
+  else tp3_backward<WIDTH>(net, doutS, h1, h2, scr, tp, st, row0, B, dact_col0, dact_cols, dactS, sf);
+}
 
 template <int WIDTH>
 struct FusedLds {   // floats
@@ -107,7 +123,7 @@ __device__ __forceinline__ void load_batch(const BatchSrc& P, int row0, int B, i
   }
 }
 
-template <int WIDTH>
+template <int WIDTH, bool LEAN>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<WIDTH>;
@@ -147,8 +163,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   if (role == 2) {
     // ---- role C: actor(s) forward.  Pack rows beyond S are zero, so [s | a] serves as input.
     const Tp3Store st{A.aX[1], A.aX[2], nullptr, nullptr, 0};
-    tp3_forward<WIDTH>(A.actor, xa, h1, h2, outS, scr, tp, st, row0, B);
-    stamp();
+    tp_fwd<WIDTH, LEAN>(A.actor, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
     if (lead) {
       for (int idx = tid; idx < kR * Ad; idx += kThreads) {
         const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
@@ -162,15 +177,13 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
 
   if (role == 0) {
     // ---- role A: a' = tanh(actor_target(s')), q' = critic_target(s', a'), TD target
-    tp3_forward<WIDTH>(A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B);
-    stamp();
+    tp_fwd<WIDTH, LEAN>(A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
     for (int idx = tid; idx < kR * Ad; idx += kThreads) {
       const int row = idx / Ad, col = idx - row * Ad;
       xb[row * kX0Ld + S + col] = (row0 + row < B) ? tanhf(outS[row * kOutLd + col]) : 0.f;
     }
     // (the next GEMM's own barrier publishes xb)
-    tp3_forward<WIDTH>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B);
-    stamp();
+    tp_fwd<WIDTH, LEAN>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
     if (lead && tid < kR && row0 + tid < B) {
       const float y = rS[tid] + ((1.f - dS[tid]) * A.gamma) * outS[tid * kOutLd];
       // hand-off to role B of this slice: ONE aligned 8-byte {epoch, value} granule per
@@ -185,8 +198,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
 
   // ---- role B: q = critic(s, a) forward (runs while role A computes the target)
   const Tp3Store st{A.cX[1], A.cX[2], A.cdY[1], A.cdY[0], A.cdY0_stride};
-  tp3_forward<WIDTH>(A.critic, xa, h1, h2, outS, scr, tp, st, row0, B);
-  stamp();
+  tp_fwd<WIDTH, LEAN>(A.critic, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
   if (lead) store_rows(xa, kX0Ld, A.cX[0], A.cldx0, S + Ad, row0, B);
   // wait for this slice's TD targets: lanes 0..15 of wave 0 poll their granule (relaxed,
   // L1-bypassing) with a sleep in between; the spin is BOUNDED — on give-up the target
@@ -241,11 +253,11 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   }
   __syncthreads();
   if (lead) store_rows(auxS, kOutLd, A.cdY[2], A.clddo, 1, row0, B);
-  tp3_backward<WIDTH>(A.critic, auxS, h1, h2, scr, tp, st, row0, B, 0, 0, auxS);
   stamp();
+  tp_bwd<WIDTH, LEAN>(A.critic, auxS, h1, h2, scr, tp, st, row0, B, 0, 0, auxS, stamp);
 }
 
-template <int WIDTH>
+template <int WIDTH, bool LEAN>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<WIDTH>;
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   load_rows4(ha2, WL, A.aX[2], WIDTH, WIDTH, row0, B);
   stamp();
   // ---- q = critic(s, pi) with the updated critic
-  tp3_forward<WIDTH>(A.critic, xa, h1, h2, outS, scr, tp, nostore, row0, B);
+  tp_fwd<WIDTH, LEAN>(A.critic, xa, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
   stamp();
   lds_zero(auxS, kR * kOutLd);
   __syncthreads();
@@ -309,7 +321,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
     }
   }
   // ---- critic backward down to the action columns: da -> auxS[:, 0:A]
-  tp3_backward<WIDTH>(A.critic, auxS, h1, h2, scr, tp, nostore, row0, B, S, Ad, auxS);
+  tp_bwd<WIDTH, LEAN>(A.critic, auxS, h1, h2, scr, tp, nostore, row0, B, S, Ad, auxS, stamp);
   stamp();   // da ready
   // ---- du = da (1 - pi^2), zero padded
   float du = 0.f;
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   if (lead) store_rows(auxS, kOutLd, A.adY[2], A.alddo, Ad, row0, B);
   // ---- actor backward over its stored activations
   const Tp3Store sta{nullptr, nullptr, A.adY[1], A.adY[0], A.adY0_stride};
-  tp3_backward<WIDTH>(A.actor, auxS, ha1, ha2, scr, tp, sta, row0, B, 0, 0, auxS);
+  tp_bwd<WIDTH, LEAN>(A.actor, auxS, ha1, ha2, scr, tp, sta, row0, B, 0, 0, auxS, stamp);
   stamp();
 }
 
@@ -335,22 +347,37 @@ size_t fused_ddpg_lds_bytes() { return sizeof(float) * FusedLds<256>::total; }
 size_t fused_xbuf_granules_per_cluster(int nc) { return (size_t)kTpStages * nc * kTpBlk; }
 
 hipError_t init_fused_attrs() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddpg_phase1<256>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddpg_phase2<256>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const void* ks[4] = {reinterpret_cast<const void*>(&k_ddpg_phase1<256, false>),
+                       reinterpret_cast<const void*>(&k_ddpg_phase1<256, true>),
+                       reinterpret_cast<const void*>(&k_ddpg_phase2<256, false>),
+                       reinterpret_cast<const void*>(&k_ddpg_phase2<256, true>)};
+  for (const void* k : ks) {
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+// the lean tp4 passes serve clusters of 4 whose four nets fit tp4_shape_ok
+static bool lean_ok(const DdpgArgs& a) {
+  return a.nc == 4 && !a.no_lean && tp4_shape_ok(256, a.S + a.A, 1) && tp4_shape_ok(256, a.S, a.A);
 }
 
 hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
-  hipLaunchKernelGGL(k_ddpg_phase1<256>, dim3(slices, 3 * a.nc), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  if (lean_ok(a))
+    hipLaunchKernelGGL((k_ddpg_phase1<256, true>), dim3(slices, 3 * a.nc), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  else
+    hipLaunchKernelGGL((k_ddpg_phase1<256, false>), dim3(slices, 3 * a.nc), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
   return hipGetLastError();
 }
 
 hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
-  hipLaunchKernelGGL(k_ddpg_phase2<256>, dim3(slices, a.nc), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  if (lean_ok(a))
+    hipLaunchKernelGGL((k_ddpg_phase2<256, true>), dim3(slices, a.nc), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  else
+    hipLaunchKernelGGL((k_ddpg_phase2<256, false>), dim3(slices, a.nc), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
   return hipGetLastError();
 }
 

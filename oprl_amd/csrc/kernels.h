@@ -132,6 +132,7 @@ struct DdpgArgs {
   unsigned long long* y_granules;      // [B] {epoch<<32 | float bits}: TD target hand-off between roles
   unsigned epoch;                      // monotonically increasing per update, never 0
   int nc;                              // CUs per slice cluster (tensor-parallel, csrc/tp3.h): 1, 2 or 4
+  int no_lean;                         // 1: never use the tp4.h specialisation (OPRL_AMD_NO_LEAN, tests)
   unsigned long long* xbuf;            // cluster exchange areas: [role][slice][kTpStages][nc][kTpBlk] granules
   unsigned cluster_tag;                // launch-unique
   long cdY0_stride, adY0_stride;       // floats between the members' dz1 partial buffers

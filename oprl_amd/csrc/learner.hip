@@ -276,6 +276,7 @@ struct oprl_learner {
   unsigned epoch = 0;          // monotonically increasing, never reset
   int ncl = 1;                 // CUs per slice cluster in the fused path (csrc/tp3.h)
   int n_cus = 256;
+  int no_lean = 0;
   unsigned long long* xbuf = nullptr;
   size_t xbuf_granules = 0;
   // largest cluster whose phase-1 grid (3 roles) is fully co-resident, one workgroup per CU
@@ -467,6 +468,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   a.epoch = h->epoch;
   a.trace = nullptr;
   a.nc = h->nc_cluster(B);
+  a.no_lean = h->no_lean;
   a.xbuf = h->xbuf;
   a.cdY0_stride = h->ws_critic[0].dY0_stride;
   a.adY0_stride = h->ws_actor.dY0_stride;
@@ -999,6 +1001,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     const char* env = getenv("OPRL_AMD_CLUSTER");
     h->ncl = env ? atoi(env) : kMaxCluster;
     if (h->ncl != 1 && h->ncl != 2 && h->ncl != 4) h->ncl = kMaxCluster;
+    const char* nl = getenv("OPRL_AMD_NO_LEAN");
+    h->no_lean = (nl != nullptr && atoi(nl) != 0) ? 1 : 0;
     const size_t slices = (size_t)(h->Bmax + kR - 1) / kR;
     h->xbuf_granules = 3 * slices * fused_xbuf_granules_per_cluster(kMaxCluster);
     if (hipMalloc(&h->xbuf, h->xbuf_granules * sizeof(unsigned long long)) != hipSuccess) {

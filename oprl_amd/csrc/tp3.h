@@ -108,10 +108,10 @@ struct Tp3Store {
 // Forward.  x0s: [kR][kX0Ld] input tile (zero padded; no barrier needed).  On return h1
 // holds relu(layer 0) (full), h2 the member's columns of relu(layer 1) (other columns
 // unspecified), outS[kR][kOutLd] columns [0,N) the network output, identical on all members.
-template <int WIDTH>
+template <int WIDTH, class ST = NoStamp>
 __device__ __forceinline__ void tp3_forward(const Net& net, const float* x0s, float* h1, float* h2,
                                             float* outS, float* scr, Tp& tp, const Tp3Store& st,
-                                            int row0, int B) {
+                                            int row0, int B, ST sf = ST()) {
   constexpr int WL = lds_ld(WIDTH);
   constexpr int NTW = WIDTH / 16;
   const int tpc = NTW / tp.nc;          // tiles (= macro steps) per member
@@ -133,6 +133,7 @@ __device__ __forceinline__ void tp3_forward(const Net& net, const float* x0s, fl
               [&](int row, int col, float v) { outS[row * kOutLd + col] = col < N ? v : 0.f; },
               false, none, NoStamp(), NTW * 256);
   tp_allreduce(outS, N, net.b[2], outS, tp);
+  sf();
 }
 
 // Backward.  doutS[kR][kOutLd]: dLoss/d(out), zero padded to a multiple of 16 columns (no
@@ -140,11 +141,11 @@ __device__ __forceinline__ void tp3_forward(const Net& net, const float* x0s, fl
 // and are overwritten by the gradients.  If dact_cols > 0, dactS[kR][kOutLd] columns
 // [0, dact_cols) receive the gradient wrt input columns [dact_col0, +dact_cols), reduced
 // over the cluster (identical on all members).
-template <int WIDTH>
+template <int WIDTH, class ST = NoStamp>
 __device__ __forceinline__ void tp3_backward(const Net& net, const float* doutS, float* h1,
                                              float* h2, float* scr, Tp& tp, const Tp3Store& st,
                                              int row0, int B, int dact_col0, int dact_cols,
-                                             float* dactS) {
+                                             float* dactS, ST sf = ST()) {
   constexpr int WL = lds_ld(WIDTH);
   constexpr int NTW = WIDTH / 16;
   const int tpc = NTW / tp.nc;
@@ -181,6 +182,7 @@ __device__ __forceinline__ void tp3_backward(const Net& net, const float* doutS,
                 });
     tp_allreduce(dactS, dact_cols, nullptr, dactS, tp);
   }
+  sf();
 }
 
 }  // namespace oprl

@@ -1,0 +1,305 @@
+// tp4.h — the tensor-parallel slice passes of tp3.h, specialised for the headline shape:
+// hidden width 256, cluster of 4 CUs, layer-0 fan-in <= 64, output width <= 48.
+//
+// Why a second implementation.  Stamps inside tp3_forward (tools/trace_slice.py,
+// profiles/r01d_stage_stamps.txt) show 1.5-1.8 us between entry and the first barrier of a
+// pass and ~1 us of non-MFMA time in every later stage: with 16 waves per CU (4 per SIMD,
+// a wave64 VALU op = 4 SIMD cycles) the kernel is bound by INSTRUCTION ISSUE — one generic
+// tp3_forward is ~3000 static instructions (runtime integer divisions, shape branches,
+// split-contraction scratch reduces, 9 barriers) around 28 executed MFMAs per wave.  Here
+// every shape is a compile-time constant, so a pass is a few hundred instructions:
+//   forward    [x0 visible] L0: wave w = tile w (<= 4 steps)            -> h1
+//              [h1 visible] L1: waves 0..3 own one of the member's 4 tiles over the whole
+//                               contraction (two accumulator chains, 64 MFMAs; no scratch
+//                               reduce) while waves 4.. store h1 for the dW kernel   -> h2
+//              [h2 visible] L2: wave 4+t = output tile t over the member's 64 columns, then
+//                               the cluster all-reduce STRAIGHT FROM ITS REGISTERS
+//                               (publish 4 granules per lane, poll the 3 peers)      -> out
+//              [out visible]
+//   backward   [dout visible] waves 0..3: dz2 tile (<= 3 steps), ReLU mask in place (h2)
+//              [dz2 visible]  all waves: dz1-partial tile w (4 steps), mask in place (h1)
+//              [dz1 visible]  stores for dW; optional input-column gradient: 4 waves per
+//                             tile split the contraction, one b128 scratch exchange, then
+//                             all-reduce from registers
+// The weight fragments of ALL stages of a pass are requested at entry (<= 24 b128 per lane).
+// Summation order: members in index order (as tp3.h), inside a member even/odd-step chains.
+#pragma once
+#include "tp3.h"
+
+namespace oprl {
+
+constexpr int kW4 = 256;
+constexpr int kWL4 = lds_ld(kW4);
+constexpr int kTpc4 = 4;                      // tiles (= macro steps) per member
+constexpr int kCols4 = kTpc4 * 16;            // hidden columns per member
+
+__host__ __device__ inline bool tp4_shape_ok(int width, int fan_in, int n_out) {
+  return width == kW4 && fan_in <= 64 && n_out <= kNarrowMax;
+}
+
+__device__ __forceinline__ void mac4(const f32x4 a, const f32x4 b, f32x4& acc) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc = mfma4(a[t], b[t], acc);
+}
+
+// All-reduce of one 16x16 tile held in MFMA accumulator layout (lane (kk,i): rows 4kk..4kk+3,
+// column i) over the 4 members; `valid` lanes take part, `col` (< kNarrowMax, distinct per
+// valid (tile, i)) names the lane's column.  Returns sum over members in member order.
+// Granule slot of (row = 4kk + r, col): ((r*4 + kk) * kNarrowMax + col)  (< kTpBlk).
+__device__ __forceinline__ f32x4 tp4_allreduce_regs(const f32x4 mine, int col, bool valid, const Tp& tp) {
+  const int kk = (threadIdx.x & 63) >> 4;
+  constexpr int kRs = 4 * kNarrowMax;   // granules between two r
+  const unsigned tag = (tp.tag << 6) | (unsigned)(tp.stage & 63);
+  unsigned long long* slot = tp.xbuf + (size_t)tp.stage * 4 * kTpBlk + (valid ? kk * kNarrowMax + col : 0);
+  f32x4 v[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) v[m] = mine;
+  if (valid) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      __hip_atomic_store(slot + (size_t)tp.c * kTpBlk + r * kRs,
+                         ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(mine[r]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool ok = false;
+    for (int spin = 0; spin < kTpSpin && !ok; ++spin) {
+      unsigned long long x[4][4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          x[m][r] = (m == tp.c) ? 0ull
+                                : __hip_atomic_load(slot + (size_t)m * kTpBlk + r * kRs, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+      ok = true;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (m != tp.c) {
+            ok = ok && (unsigned)(x[m][r] >> 32) == tag;
+            v[m][r] = __uint_as_float((unsigned)x[m][r]);
+          }
+      if (!ok) __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) {
+      const float nan = __builtin_nanf("");
+      v[0] = f32x4{nan, nan, nan, nan};
+    }
+  }
+  f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < 4; ++m) sum += v[m];
+  return sum;
+}
+
+template <class ST = NoStamp>
+__device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, float* h1, float* h2,
+                                            float* outS, Tp& tp, const Tp3Store& st, int row0, int B,
+                                            ST sf = ST()) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  const int c = tp.c, c0 = c * kCols4;
+  const int N = net.dims[3];
+  const int NS0 = (net.dims[0] + 15) >> 4, NTo = (N + 15) >> 4;
+  const int t2 = wave - 4;                    // output tile of waves 4..4+NTo-1
+  const bool l2_wave = t2 >= 0 && t2 < NTo;
+
+  // ---- requests for the whole pass
+  f32x4 w0[4], wq[16];
+  {
+    const float* p0 = net.pf[0] + ((size_t)wave * NS0 * 64 + lane) * 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) w0[s] = s < NS0 ? ld4(p0 + s * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float bias0 = net.b[0][16 * wave + i];
+  float bias12 = 0.f;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) wq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (wave < kTpc4) {
+    const float* p1 = net.pf[1] + ((size_t)(c * kTpc4 + wave) * 16 * 64 + lane) * 4;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) wq[s] = ld4(p1 + s * 256);
+    bias12 = net.b[1][c0 + 16 * wave + i];
+  } else if (l2_wave) {
+    const float* p2 = net.pf[2] + (((size_t)t2 * 16 + c * kTpc4) * 64 + lane) * 4;
+#pragma unroll
+    for (int s = 0; s < kTpc4; ++s) wq[s] = ld4(p2 + s * 256);
+    if (16 * t2 + i < N) bias12 = net.b[2][16 * t2 + i];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();   // x0 visible
+
+  // ---- L0: tile = wave
+  {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xr = x0s + i * kX0Ld + 4 * kk;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (s < NS0) mac4(ld4(xr + 16 * s), w0[s], acc);
+    float* o = h1 + (kk * 4) * kWL4 + 16 * wave + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r * kWL4] = fmaxf(acc[r] + bias0, 0.f);
+  }
+  sf();
+  __syncthreads();   // h1 visible
+
+  // ---- L1 on waves 0..3; the others store h1 (member 0) for the dW kernel
+  if (wave < kTpc4) {
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    const float* hr = h1 + i * kWL4 + 4 * kk;
+#pragma unroll
+    for (int s = 0; s < 16; s += 2) {
+      mac4(ld4(hr + 16 * s), wq[s], a0);
+      mac4(ld4(hr + 16 * s + 16), wq[s + 1], a1);
+    }
+    float* o = h2 + (kk * 4) * kWL4 + c0 + 16 * wave + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r * kWL4] = fmaxf((a0[r] + a1[r]) + bias12, 0.f);
+  } else if (st.X1 != nullptr && c == 0) {
+    for (int idx = (int)threadIdx.x - 64 * kTpc4; idx < kR * (kW4 / 4); idx += kThreads - 64 * kTpc4) {
+      const int row = idx >> 6, col = (idx & 63) * 4, gr = row0 + row;
+      if (gr < B) *reinterpret_cast<f32x4*>(st.X1 + (size_t)gr * kW4 + col) = ld4(h1 + row * kWL4 + col);
+    }
+  }
+  sf();
+  __syncthreads();   // the member's h2 columns visible
+
+  // ---- L2 partial + all-reduce from registers on waves 4..; waves 8..11 store the h2 columns
+  if (l2_wave) {
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    const float* hr = h2 + i * kWL4 + c0 + 4 * kk;
+    mac4(ld4(hr), wq[0], a0);
+    mac4(ld4(hr + 16), wq[1], a1);
+    mac4(ld4(hr + 32), wq[2], a0);
+    mac4(ld4(hr + 48), wq[3], a1);
+    const int col = 16 * t2 + i;
+    const bool valid = col < N;
+    const f32x4 sum = tp4_allreduce_regs(a0 + a1, col, valid, tp);
+    float* o = outS + (kk * 4) * kOutLd + col;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r * kOutLd] = valid ? sum[r] + bias12 : 0.f;
+  } else if (st.X2 != nullptr && wave >= 8 && wave < 12) {
+    const int idx = (int)threadIdx.x - 512;          // 16 rows x 16 float4
+    const int row = idx >> 4, col = c0 + (idx & 15) * 4, gr = row0 + row;
+    if (gr < B) *reinterpret_cast<f32x4*>(st.X2 + (size_t)gr * kW4 + col) = ld4(h2 + row * kWL4 + col);
+  }
+  tp.stage += 1;
+  sf();
+  __syncthreads();   // out visible
+  sf();
+}
+
+template <class ST = NoStamp>
+__device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS, float* h1, float* h2,
+                                             float* scr, Tp& tp, const Tp3Store& st, int row0, int B,
+                                             int dact_col0, int dact_cols, float* dactS, ST sf = ST()) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  const int c = tp.c, c0 = c * kCols4;
+  const int NSo = (net.dims[3] + 15) >> 4, NT0 = (net.dims[0] + 15) >> 4;
+  const bool dact = dact_cols > 0;
+  const int dt = wave >> 2, dpart = wave & 3;       // dact: tile, contraction quarter
+  const bool dact_wave = dact && dt < NT0;
+
+  // ---- requests
+  f32x4 wo[3], wz[4], wd[4];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) wo[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (wave < kTpc4) {
+    const float* q2 = net.pb[2] + ((size_t)(c * kTpc4 + wave) * NSo * 64 + lane) * 4;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      if (s < NSo) wo[s] = ld4(q2 + s * 256);
+  }
+  {
+    const float* q1 = net.pb[1] + (((size_t)wave * 16 + c * kTpc4) * 64 + lane) * 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wz[s] = ld4(q1 + s * 256);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) wd[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (dact_wave) {
+    const float* q0 = net.pb[0] + (((size_t)dt * 16 + dpart * 4) * 64 + lane) * 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wd[s] = ld4(q0 + s * 256);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();   // dout visible
+
+  // ---- dz2[:, mine] = (dout · W3^T)[:, mine] ⊙ (h2 > 0), in place (waves 0..3)
+  if (wave < kTpc4) {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* dr = doutS + i * kOutLd + 4 * kk;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      if (s < NSo) mac4(ld4(dr + 16 * s), wo[s], acc);
+    float* p = h2 + (kk * 4) * kWL4 + c0 + 16 * wave + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r * kWL4] = p[r * kWL4] > 0.f ? acc[r] : 0.f;
+  }
+  sf();
+  __syncthreads();   // dz2 visible
+
+  // ---- dz1 partial: tile = wave, contraction over the member's columns; mask in place (h1)
+  {
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    const float* hr = h2 + i * kWL4 + c0 + 4 * kk;
+    mac4(ld4(hr), wz[0], a0);
+    mac4(ld4(hr + 16), wz[1], a1);
+    mac4(ld4(hr + 32), wz[2], a0);
+    mac4(ld4(hr + 48), wz[3], a1);
+    float* p = h1 + (kk * 4) * kWL4 + 16 * wave + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r * kWL4] = p[r * kWL4] > 0.f ? a0[r] + a1[r] : 0.f;
+  }
+  if (st.dY1 != nullptr && wave >= 12) {
+    const int idx = (int)threadIdx.x - 768;          // 16 rows x 16 float4 of dz2
+    const int row = idx >> 4, col = c0 + (idx & 15) * 4, gr = row0 + row;
+    if (gr < B) *reinterpret_cast<f32x4*>(st.dY1 + (size_t)gr * kW4 + col) = ld4(h2 + row * kWL4 + col);
+  }
+  sf();
+  __syncthreads();   // dz1 partial visible
+
+  if (st.dY0 != nullptr) {
+    const int idx = threadIdx.x;                     // 16 rows x 64 float4
+    const int row = idx >> 6, col = (idx & 63) * 4, gr = row0 + row;
+    if (gr < B)
+      *reinterpret_cast<f32x4*>(st.dY0 + (size_t)c * st.dY0_stride + (size_t)gr * kW4 + col) =
+          ld4(h1 + row * kWL4 + col);
+  }
+  if (dact) {
+    // partial gradient wrt the input columns: tile dt, contraction quarter dpart
+    if (dact_wave) {
+      f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+      const float* hr = h1 + i * kWL4 + 64 * dpart + 4 * kk;
+      mac4(ld4(hr), wd[0], a0);
+      mac4(ld4(hr + 16), wd[1], a1);
+      mac4(ld4(hr + 32), wd[2], a0);
+      mac4(ld4(hr + 48), wd[3], a1);
+      *reinterpret_cast<f32x4*>(scr + wave * 256 + lane * 4) = a0 + a1;
+    }
+    sf();
+    __syncthreads();
+    if (wave < NT0) {        // wave t gathers tile t's four quarters, then the cluster all-reduce
+      f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part += ld4(scr + (wave * 4 + q) * 256 + lane * 4);
+      const int cc = 16 * wave + i - dact_col0;
+      const bool valid = cc >= 0 && cc < dact_cols;
+      const f32x4 sum = tp4_allreduce_regs(part, cc, valid, tp);
+      if (valid) {
+        float* o = dactS + (kk * 4) * kOutLd + cc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r * kOutLd] = sum[r];
+      }
+    }
+    tp.stage += 1;
+    sf();
+    __syncthreads();
+  }
+  sf();
+}
+
+}  // namespace oprl

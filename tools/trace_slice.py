@@ -41,4 +41,5 @@ for slot in range(len(names)):
     clk = (cyc[:, -1] - cyc[:, 0]) / np.maximum(tot_us, 1e-9) / 1e3
     print(f"{names[slot]:26s} stamps={n} wg0 phases(us)={np.round(d_us[0], 2).tolist()} total wg0={tot_us[0]:.2f}us "
           f"max-wg={tot_us.max():.2f}us  cyc/us~{clk.mean():.2f} GHz  start spread={(rt[:,0].max()-rt[:,0].min())/100:.2f}us")
-    print(f"{'':22s} wg0 phases(cycles)={d_cyc[0].astype(int).tolist()}")
+    if "--cycles" in sys.argv:
+        print(f"{'':22s} wg0 phases(cycles)={d_cyc[0].astype(int).tolist()}")
