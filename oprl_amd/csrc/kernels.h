@@ -100,10 +100,25 @@ struct AdamScalars {
   float grad_scale;
 };
 
-struct DwArgs {
-  const DwItem* items; int n_items; int total_tiles; int B;
+struct DwArgs {                         // host-side description of one k_dw_adam launch
+  const DwItem* items;                 // HOST array
+  int n_items; int total_tiles; int B;
   int n_part;                          // members of the tensor-parallel cluster that wrote dz1 partials
   AdamScalars ad;
+  long long* trace;                    // debug stamps (tools/trace_slice.py) or null
+};
+
+// What the kernel receives: the layer table travels BY VALUE in the kernel arguments (read
+// with scalar loads through the kernarg segment pointer), so a workgroup's first global
+// round trip is already its X / dY rows.  With the table in device memory the kernel
+// started with two dependent misses (probe, then the item) — 9.3 us per launch for ~3 MB
+// of traffic.  grid = (max tiles of an item, n_items).
+constexpr int kDwMaxItems = 20;        // 5 critics x 4 layers (TQC)
+struct DwKArgs {
+  DwItem items[kDwMaxItems];
+  int n_items, B, n_part;
+  AdamScalars ad;
+  long long* trace;
 };
 
 struct BatchSrc {

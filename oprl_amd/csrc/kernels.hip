@@ -296,25 +296,30 @@ __device__ __forceinline__ void adam_bias_corr(const AdamScalars& ad, float* ste
   *bc2_sqrt = (float)sqrt(bc2);
 }
 
-__global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwArgs A) {
+__global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
   constexpr int T = kDwTile, LD = T + 4;
   __shared__ __attribute__((aligned(16))) float part[kDwWaves][T][LD];
   __shared__ float bpart[kDwWaves][T];
   __shared__ float sc[2];
-  __shared__ int s_item;
-  const int tile = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // which layer owns this tile: one parallel probe of the table instead of a chain
-  // of dependent global loads
-  if (tid < 64) {
-    const bool mine = tid < A.n_items && tile >= A.items[tid].tile_begin && tile < A.items[tid].tile_end;
-    const unsigned long long m = __ballot(mine);
-    if (tid == 0) s_item = m ? __ffsll((long long)m) - 1 : 0;
-  }
+  // this workgroup's layer, straight from the kernel-argument segment (dynamic index into a
+  // by-value array: through the segment pointer it is a scalar load, not a scratch copy)
+  const DwKArgs* KA = (const DwKArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  const DwItem I = KA->items[blockIdx.y];
+  const int lt = blockIdx.x;
+  if (lt >= I.tile_end - I.tile_begin) return;
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    const int wg = blockIdx.y * 16 + blockIdx.x;   // the first 16 tiles of each item
+    if (A.trace != nullptr && tid == 0 && blockIdx.x < 16 && wg < 64 && n_stamp < kTraceStamps) {
+      long long* tr = A.trace + ((size_t)wg * kTraceStamps + n_stamp) * 2;
+      tr[0] = (long long)__builtin_readcyclecounter();
+      tr[1] = (long long)wall_clock64();
+    }
+    ++n_stamp;
+  };
+  stamp();
   if (tid == 64) adam_bias_corr(A.ad, &sc[0], &sc[1]);
-  __syncthreads();
-  const DwItem I = A.items[s_item];
-  const int lt = tile - I.tile_begin;
   const int tn = lt / I.tiles_k, tk = lt - tn * I.tiles_k;
   const int n_base = tn * T, k_base = tk * T;
   const int i = lane & 15, c = lane >> 4;
@@ -380,6 +385,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwArgs A) {
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int p = 0; p < 3; ++p) a2[u] += ap[u][p];
+    stamp();   // rows arrived
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       f32x2 av = a2[u], xv = x2[u];
@@ -408,33 +414,87 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwArgs A) {
     s += __shfl_xor(s, 32);
     if (c == 0) bpart[wave][2 * i + t] = s;
   }
+  stamp();   // MFMA done, partial tiles in LDS
   __syncthreads();
+  stamp();
   const float step_size = sc[0], bc2_sqrt = sc[1];
+  // ---- epilogue.  Each thread finishes 2 consecutive k of one row n; the updated tile then
+  // goes through LDS so that the packs are written IN PACK ORDER as 16-byte stores (the
+  // element-wise version issued 14 scattered 4-byte stores per thread: 2.2 us of the
+  // kernel's 5.6, tools/trace_slice.py).
+  f32x2 gsum = f32x2{0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < kDwWaves; ++w) gsum += *reinterpret_cast<const f32x2*>(&part[w][nl][kl0]);
+  float th2[2] = {0.f, 0.f}, tt2[2] = {0.f, 0.f}, mm2[2] = {0.f, 0.f}, vv2[2] = {0.f, 0.f}, g2[2];
+  const bool polyak = A.ad.do_polyak && I.w_t != nullptr;
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
-    if (!e_ok[e]) continue;
-    const int k = k_base + kl0 + e;
-    float g = 0.f;
-#pragma unroll
-    for (int w = 0; w < kDwWaves; ++w) g += part[w][nl][kl0 + e];
-    g *= A.ad.grad_scale;
-    const size_t o = (size_t)en * I.K + k;
-    if (I.w_g != nullptr) I.w_g[o] = g;
-    if (A.ad.do_adam) {
+    const float g = gsum[e] * A.ad.grad_scale;
+    g2[e] = g;
+    if (e_ok[e] && A.ad.do_adam) {
       float mm = p_m[e], vv = p_v[e], th = p_th[e];
       mm = mm + (g - mm) * A.ad.omb1;
       vv = vv * A.ad.beta2 + A.ad.omb2 * g * g;
       th = th - step_size * (mm / (sqrtf(vv) / bc2_sqrt + A.ad.eps));
-      I.w_m[o] = mm;
-      I.w_v[o] = vv;
-      I.w[o] = th;
-      // keep the fragment-order packs in step with the master
-      if (I.pf != nullptr) I.pf[pack_index(en, k, NSk)] = th;
-      if (I.pb != nullptr) I.pb[pack_index(k, en, NSn)] = th;
-      if (A.ad.do_polyak && I.w_t != nullptr) {
-        const float u = p_tt[e] * A.ad.omtau + A.ad.tau * th;
-        I.w_t[o] = u;
-        if (I.tpf != nullptr) I.tpf[pack_index(en, k, NSk)] = u;
+      mm2[e] = mm; vv2[e] = vv; th2[e] = th;
+      if (polyak) tt2[e] = p_tt[e] * A.ad.omtau + A.ad.tau * th;
+    }
+  }
+  {
+    const size_t o = (size_t)en * I.K + k_base + kl0;
+    if ((I.K & 1) == 0) {          // row starts stay 8-byte aligned: one store per array
+      if (e_ok[0]) {
+        if (I.w_g != nullptr) *reinterpret_cast<f32x2*>(I.w_g + o) = f32x2{g2[0], g2[1]};
+        if (A.ad.do_adam) {
+          *reinterpret_cast<f32x2*>(I.w_m + o) = f32x2{mm2[0], mm2[1]};
+          *reinterpret_cast<f32x2*>(I.w_v + o) = f32x2{vv2[0], vv2[1]};
+          *reinterpret_cast<f32x2*>(I.w + o) = f32x2{th2[0], th2[1]};
+          if (polyak) *reinterpret_cast<f32x2*>(I.w_t + o) = f32x2{tt2[0], tt2[1]};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (!e_ok[e]) continue;
+        if (I.w_g != nullptr) I.w_g[o + e] = g2[e];
+        if (A.ad.do_adam) {
+          I.w_m[o + e] = mm2[e];
+          I.w_v[o + e] = vv2[e];
+          I.w[o + e] = th2[e];
+          if (polyak) I.w_t[o + e] = tt2[e];
+        }
+      }
+    }
+  }
+  if (A.ad.do_adam && I.pf != nullptr) {
+    // keep the fragment-order packs in step with the master: stage the new 32x32 tile(s)
+    // (zero outside the matrix, like the packs' padding), then 3 x 256 float4 jobs
+    float (*tileW)[LD] = part[0];
+    float (*tileT)[LD] = part[1];
+    __syncthreads();               // every thread has read its partial sums
+    *reinterpret_cast<f32x2*>(&tileW[nl][kl0]) = f32x2{th2[0], th2[1]};
+    *reinterpret_cast<f32x2*>(&tileT[nl][kl0]) = f32x2{tt2[0], tt2[1]};
+    __syncthreads();
+    const int NTn = cdiv(I.N, 16), NTk = NSk;
+    for (int j = tid; j < 768; j += kDwThreads) {
+      const int which = j >> 8, q = j & 255;
+      const int blk = q >> 6, l = q & 63, bt = blk >> 1, bs = blk & 1, li = l & 15, lk = l >> 4;
+      if (which == 1) {            // W^T pack: tiles over k, steps over n
+        const int ktile = 2 * tk + bt, nstep = 2 * tn + bs;
+        if (I.pb != nullptr && ktile < NTk && nstep < NSn) {
+          f32x4 v;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = tileW[16 * bs + 4 * lk + t][16 * bt + li];
+          *reinterpret_cast<f32x4*>(I.pb + (((size_t)ktile * NSn + nstep) * 64 + l) * 4) = v;
+        }
+      } else {                     // W pack (online, target): tiles over n, steps over k
+        const int ntile = 2 * tn + bt, kstep = 2 * tk + bs;
+        float* dst = which == 0 ? I.pf : (polyak ? I.tpf : nullptr);
+        if (dst != nullptr && ntile < NTn && kstep < NTk) {
+          const float (*src)[LD] = which == 0 ? tileW : tileT;
+          *reinterpret_cast<f32x4*>(dst + (((size_t)ntile * NSk + kstep) * 64 + l) * 4) =
+              *reinterpret_cast<const f32x4*>(&src[16 * bt + li][16 * bs + 4 * lk]);
+        }
       }
     }
   }
@@ -450,6 +510,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwArgs A) {
                              bc2_sqrt, &t0, &t1);
     }
   }
+  stamp();   // stores issued
 }
 
 // flat Adam over an arena (data-parallel apply after the all-reduce; alpha-free)
@@ -613,7 +674,17 @@ hipError_t init_kernel_attrs() {
 }
 
 hipError_t launch_dw_adam(const DwArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_dw_adam, dim3(a.total_tiles), dim3(kDwThreads), 0, st, a);
+  if (a.n_items < 1 || a.n_items > kDwMaxItems) return hipErrorInvalidValue;
+  DwKArgs k;
+  int max_tiles = 0;
+  for (int j = 0; j < a.n_items; ++j) {
+    k.items[j] = a.items[j];
+    const int t = a.items[j].tile_end - a.items[j].tile_begin;
+    max_tiles = t > max_tiles ? t : max_tiles;
+  }
+  for (int j = a.n_items; j < kDwMaxItems; ++j) k.items[j] = a.items[0];
+  k.n_items = a.n_items; k.B = a.B; k.n_part = a.n_part; k.ad = a.ad; k.trace = a.trace;
+  hipLaunchKernelGGL(k_dw_adam, dim3(max_tiles, a.n_items), dim3(kDwThreads), 0, st, k);
   return hipGetLastError();
 }
 

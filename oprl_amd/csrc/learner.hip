@@ -248,7 +248,7 @@ struct oprl_learner {
   int w_actor = 0, w_critic = 0;
   Pool pool;
   NetWs ws_actor, ws_critic[OPRL_MAX_CRITICS];
-  DwItem* items_dev = nullptr;  // [critic items..., actor items...]
+  std::vector<DwItem> items_host;  // [critic items..., actor items...] (travel in the kernel arguments)
   int n_items_critic = 0, n_items_actor = 0, tiles_critic = 0, tiles_actor = 0;
   // batch-sized scratch
   float *a2 = nullptr, *logp2 = nullptr, *qn = nullptr /*[nc][B][ldq]*/, *pi = nullptr,
@@ -481,16 +481,17 @@ int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st) {
   DwArgs dw;
   if (critic) {
     h->opt_step_critic += 1;
-    dw.items = h->items_dev; dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
+    dw.items = h->items_host.data(); dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
     dw.ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, 1.0f);
   } else {
     h->opt_step_actor += 1;
-    dw.items = h->items_dev + h->n_items_critic; dw.n_items = h->n_items_actor;
+    dw.items = h->items_host.data() + h->n_items_critic; dw.n_items = h->n_items_actor;
     dw.total_tiles = h->tiles_actor;
     dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, polyak, 1.0f);
   }
   dw.B = B;
   dw.n_part = h->fused ? h->nc_cluster(B) : 1;
+  dw.trace = (h->fused && h->trace != nullptr) ? h->trace + (size_t)(critic ? 4 : 5) * 64 * kTraceStamps * 2 : nullptr;
   HIPC(launch_dw_prof(dw, st));
   return OPRL_OK;
 }
@@ -573,8 +574,8 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     const bool polyak = (algo == OPRL_TD3) ? (h->update_count % c.hp.policy_freq == 0) : true;
     h->opt_step_critic += 1;
     DwArgs dw;
-    dw.items = h->items_dev; dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
-    dw.B = B; dw.n_part = 1;
+    dw.items = h->items_host.data(); dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
+    dw.B = B; dw.n_part = 1; dw.trace = nullptr;
     dw.ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, 1.0f);
     HIPC(launch_dw_prof(dw, st));
   }
@@ -671,8 +672,8 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
   {
     h->opt_step_actor += 1;
     DwArgs dw;
-    dw.items = h->items_dev + h->n_items_critic; dw.n_items = h->n_items_actor;
-    dw.total_tiles = h->tiles_actor; dw.B = B; dw.n_part = 1;
+    dw.items = h->items_host.data() + h->n_items_critic; dw.n_items = h->n_items_actor;
+    dw.total_tiles = h->tiles_actor; dw.B = B; dw.n_part = 1; dw.trace = nullptr;
     dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, c.actor.theta_target != nullptr, 1.0f);
     HIPC(launch_dw_prof(dw, st));
   }
@@ -973,7 +974,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   h->n_items_critic = (int)items.size();
   fill_items(cfg->actor, h->ws_actor, items, &h->tiles_actor);
   h->n_items_actor = (int)items.size() - h->n_items_critic;
-  h->items_dev = p.take<DwItem>(items.size());
+  h->items_host = items;
   std::vector<RepackItem> rp[3];
   {
     const oprl_net* cn[OPRL_MAX_CRITICS];
@@ -990,9 +991,6 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   if (p.used > p.cap) { set_err("internal: workspace pool overflow (%zu > %zu)", p.used, p.cap); (void)hipFree(p.base); delete h; return OPRL_ERR_NOMEM; }
   for (int k = 0; k < 3; ++k)
     if (!rp[k].empty()) (void)hipMemcpy(h->rp_dev[k], rp[k].data(), sizeof(RepackItem) * rp[k].size(), hipMemcpyHostToDevice);
-  if (hipMemcpy(h->items_dev, items.data(), sizeof(DwItem) * items.size(), hipMemcpyHostToDevice) != hipSuccess) {
-    set_err("hipMemcpy(items) failed"); (void)hipFree(p.base); delete h; return OPRL_ERR_HIP;
-  }
   if (h->fused) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -1268,9 +1266,6 @@ extern "C" int oprl_mlp_backward(const oprl_net* net, const float* x0, int32_t k
   std::vector<DwItem> items;
   int tiles = 0;
   fill_items(*net, ws, items, &tiles);
-  DwItem* items_dev = p.take<DwItem>(items.size());
-  HIPC(hipMemcpyAsync(items_dev, items.data(), sizeof(DwItem) * items.size(), hipMemcpyHostToDevice, st));
-  HIPC(hipStreamSynchronize(st));  // items is a stack vector
   MlpArgs a;
   memset(&a, 0, sizeof a);
   a.net = net_view(*net, false);
@@ -1284,7 +1279,7 @@ extern "C" int oprl_mlp_backward(const oprl_net* net, const float* x0, int32_t k
   if (dx && net->dims[0] > kNarrowMax) { set_err("oprl_mlp_backward: dx supported for input dim <= %d", kNarrowMax); return OPRL_ERR_INVALID; }
   RC(launch(a, width, st));
   DwArgs dw;
-  dw.items = items_dev; dw.n_items = (int)items.size(); dw.total_tiles = tiles; dw.B = B; dw.n_part = 1;
+  dw.items = items.data(); dw.n_items = (int)items.size(); dw.total_tiles = tiles; dw.B = B; dw.n_part = 1; dw.trace = nullptr;
   memset(&dw.ad, 0, sizeof dw.ad);
   set_adam(dw.ad, 0.0, 0.9, 0.999, 1e-8, 0.0);
   set_step(dw.ad, 1); dw.ad.grad_scale = 1.0f; dw.ad.do_adam = 0;

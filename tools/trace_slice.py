@@ -28,10 +28,13 @@ for _ in range(3):
 t.cuda.synchronize()
 tr = buf.cpu().numpy()
 fused = "--generic" not in sys.argv
-names = (["P1 role A target chain", "P1 role B critic f+b", "P1 role C actor fwd", "P2 critic f+b, actor bwd"]
+names = (["P1 role A target chain", "P1 role B critic f+b", "P1 role C actor fwd", "P2 critic f+b, actor bwd",
+          "dW critic (wg0 = layer 0 tile 0)", "dW actor"]
          if fused else ["actor_t fwd", "critic_t fwd", "critic fwd+bwd", "actor fwd", "critic(s,pi) fwd+bwd", "actor bwd"])
 for slot in range(len(names)):
     x = tr[slot, :16]                       # 16 workgroups
+    if slot >= 4 and fused:
+        x = tr[slot, 16:32]                 # dW: the hidden layer's first 16 tiles
     n = int((x[0, :, 0] != 0).sum())
     cyc = x[:, :n, 0].astype(np.float64)
     rt = x[:, :n, 1].astype(np.float64)     # 100 MHz ticks
