@@ -59,8 +59,8 @@ struct FusedLds {   // floats
   static constexpr int WL = lds_ld(WIDTH);
   static constexpr int xa = 0;                       // [s | a] (phase 2: [s | pi])
   static constexpr int xb = xa + kR * kX0Ld;         // [s' | a']
-  static constexpr int h = xb + kR * kX0Ld;          // 4 hidden buffers
-  static constexpr int out = h + 4 * kR * WL;
+  static constexpr int h = xb + kR * kX0Ld;          // 5 hidden buffers
+  static constexpr int out = h + 5 * kR * WL;
   static constexpr int aux = out + kR * kOutLd;
   static constexpr int scr = aux + kR * kOutLd;
   static constexpr int misc = scr + kWaves * kR * 16;   // r[16] d[16] y[16] ep[16] t[16] + ends
@@ -198,8 +198,49 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
 
   // ---- role B: q = critic(s, a) forward (runs while role A computes the target)
   const Tp3Store st{A.cX[1], A.cX[2], A.cdY[1], A.cdY[0], A.cdY0_stride};
-  tp_fwd<WIDTH, LEAN>(A.critic, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
+  if constexpr (LEAN) {
+    // ... and, the critic being scalar-output, its whole backward with unit seed as well:
+    // k_dw_adam applies 2(q - y)/B per row (tp4_scalar_fb), so after y arrives only that
+    // vector is left to publish
+    tp4_scalar_fb(A.critic, xa, h1, h2, h1 + 2 * HB, outS, scr, tp, st, row0, B, 1.f, 0, 0, nullptr, stamp);
+  } else {
+    tp_fwd<WIDTH, LEAN>(A.critic, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
+  }
   if (lead) store_rows(xa, kX0Ld, A.cX[0], A.cldx0, S + Ad, row0, B);
+  if constexpr (LEAN) {
+    // only the seed vector and the diagnostics are left: one wave of the lead member, no LDS
+    if (!lead || tid >= 64) return;
+    float y = 0.f, q = 0.f;
+    const int gr = row0 + tid;
+    const bool row_ok = tid < kR && gr < B;
+    if (row_ok) {
+      unsigned long long g = 0;
+      bool ok = false;
+      for (int spin = 0; spin < (1 << 20); ++spin) {
+        g = __hip_atomic_load(A.y_granules + gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = (unsigned)(g >> 32) == A.epoch;
+        if (ok) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      y = ok ? __uint_as_float((unsigned)g) : __builtin_nanf("");
+      q = outS[tid * kOutLd];
+      A.cdY[2][(size_t)gr * A.clddo] = 2.f * (q - y) * A.inv_B;
+      if (A.y_out != nullptr) A.y_out[gr] = y;
+      if (A.q_out != nullptr) A.q_out[gr] = q;
+    }
+    stamp();   // TD target received, seed published
+    if (A.partials_c != nullptr) {
+      float v[3] = {row_ok ? (q - y) * (q - y) : 0.f, row_ok ? q : 0.f, row_ok ? y : 0.f};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) v[k] += __shfl_xor(v[k], m);
+        if (tid == 0) A.partials_c[slice * 4 + k] = v[k];
+      }
+    }
+    stamp();
+    return;
+  }
   // wait for this slice's TD targets: lanes 0..15 of wave 0 poll their granule (relaxed,
   // L1-bypassing) with a sleep in between; the spin is BOUNDED — on give-up the target
   // becomes NaN, which the parity tests and the loss diagnostics expose, instead of a hang.
@@ -254,7 +295,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   __syncthreads();
   if (lead) store_rows(auxS, kOutLd, A.cdY[2], A.clddo, 1, row0, B);
   stamp();
-  tp_bwd<WIDTH, LEAN>(A.critic, auxS, h1, h2, scr, tp, st, row0, B, 0, 0, auxS, stamp);
+  if constexpr (!LEAN) tp_bwd<WIDTH, LEAN>(A.critic, auxS, h1, h2, scr, tp, st, row0, B, 0, 0, auxS, stamp);
 }
 
 template <int WIDTH, bool LEAN>
@@ -295,19 +336,21 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   load_rows4(ha1, WL, A.aX[1], WIDTH, WIDTH, row0, B);
   load_rows4(ha2, WL, A.aX[2], WIDTH, WIDTH, row0, B);
   stamp();
-  // ---- q = critic(s, pi) with the updated critic
-  tp_fwd<WIDTH, LEAN>(A.critic, xa, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
-  stamp();
-  lds_zero(auxS, kR * kOutLd);
-  __syncthreads();
-  float p_q = 0.f;
-  if (tid < kR && row0 + tid < B) {
-    auxS[tid * kOutLd] = -A.inv_B;
-    p_q = outS[tid * kOutLd];
+  // ---- q = critic(s, pi) with the updated critic, and its backward down to the action
+  // columns: da -> auxS[:, 0:A].  The seed -1/B is a constant, so the lean path runs both
+  // as one pass (tp4_scalar_fb) in which q — only logged — is off the critical path.
+  if constexpr (LEAN) {
+    tp4_scalar_fb(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp);
+  } else {
+    tp_fwd<WIDTH, LEAN>(A.critic, xa, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
+    stamp();
+    lds_zero(auxS, kR * kOutLd);
+    __syncthreads();
+    if (tid < kR && row0 + tid < B) auxS[tid * kOutLd] = -A.inv_B;
   }
   if (A.partials_a != nullptr && lead) {
+    float v = (tid < kR && row0 + tid < B) ? outS[tid * kOutLd] : 0.f;
     __syncthreads();
-    float v = p_q;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
     if ((tid & 63) == 0) scr[(tid >> 6) * 4 + 1] = v;
@@ -320,8 +363,8 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
       A.partials_a[slice * 4 + 2] = 0.f;
     }
   }
-  // ---- critic backward down to the action columns: da -> auxS[:, 0:A]
-  tp_bwd<WIDTH, LEAN>(A.critic, auxS, h1, h2, scr, tp, nostore, row0, B, S, Ad, auxS, stamp);
+  if constexpr (!LEAN)
+    tp_bwd<WIDTH, LEAN>(A.critic, auxS, h1, h2, scr, tp, nostore, row0, B, S, Ad, auxS, stamp);
   stamp();   // da ready
   // ---- du = da (1 - pi^2), zero padded
   float du = 0.f;
@@ -359,7 +402,9 @@ hipError_t init_fused_attrs() {
 }
 
 // the lean tp4 passes serve clusters of 4 whose four nets fit tp4_shape_ok
-static bool lean_ok(const DdpgArgs& a) {
+bool fused_ddpg_is_lean(const DdpgArgs& a);
+static bool lean_ok(const DdpgArgs& a) { return fused_ddpg_is_lean(a); }
+bool fused_ddpg_is_lean(const DdpgArgs& a) {
   return a.nc == 4 && !a.no_lean && tp4_shape_ok(256, a.S + a.A, 1) && tp4_shape_ok(256, a.S, a.A);
 }
 

@@ -79,6 +79,7 @@ struct DwItem {      // one Linear layer of one net
   float *pf, *pb, *tpf;                // fragment-order packs: W (fwd), W^T (bwd), target W (fwd)
   int tiles_k, tile_begin, tile_end;
   long dY_part_stride;                 // > 0: dY is the sum of DwArgs::n_part buffers this many floats apart
+  int scaled;                          // 1: dY rows are unit-seed (tp4_scalar_fb): multiply row b by DwArgs::row_scale[b]
 };
 
 struct RepackItem {  // one Linear layer: master -> packs
@@ -106,19 +107,24 @@ struct DwArgs {                         // host-side description of one k_dw_ada
   int n_part;                          // members of the tensor-parallel cluster that wrote dz1 partials
   AdamScalars ad;
   long long* trace;                    // debug stamps (tools/trace_slice.py) or null
+  const float* row_scale; int row_scale_ld;   // per-row seed dLoss/dq for DwItem::scaled layers, or null
 };
 
 // What the kernel receives: the layer table travels BY VALUE in the kernel arguments (read
 // with scalar loads through the kernarg segment pointer), so a workgroup's first global
 // round trip is already its X / dY rows.  With the table in device memory the kernel
 // started with two dependent misses (probe, then the item) — 9.3 us per launch for ~3 MB
-// of traffic.  grid = (max tiles of an item, n_items).
+// of traffic.  grid = total tiles exactly (dispatch costs ~13 ns per workgroup, even one
+// that exits at once); a workgroup finds its layer by a scalar scan of tile_end[].
 constexpr int kDwMaxItems = 20;        // 5 critics x 4 layers (TQC)
 struct DwKArgs {
+  int tile_end[kDwMaxItems];           // exclusive prefix ends, relative to this launch
   DwItem items[kDwMaxItems];
   int n_items, B, n_part;
   AdamScalars ad;
   long long* trace;
+  const float* row_scale; int row_scale_ld;
+  const float* one;                    // device word holding 1.0f (row scale of unscaled layers)
 };
 
 struct BatchSrc {

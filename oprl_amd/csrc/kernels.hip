@@ -305,13 +305,14 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
   // this workgroup's layer, straight from the kernel-argument segment (dynamic index into a
   // by-value array: through the segment pointer it is a scalar load, not a scratch copy)
   const DwKArgs* KA = (const DwKArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-  const DwItem I = KA->items[blockIdx.y];
-  const int lt = blockIdx.x;
-  if (lt >= I.tile_end - I.tile_begin) return;
+  int item = 0;
+  for (int j = 0; j + 1 < A.n_items; ++j) item += (int)blockIdx.x >= KA->tile_end[j] ? 1 : 0;
+  const DwItem I = KA->items[item];
+  const int lt = (int)blockIdx.x - (item > 0 ? KA->tile_end[item - 1] : 0);
   int n_stamp = 0;
   auto stamp = [&]() {
-    const int wg = blockIdx.y * 16 + blockIdx.x;   // the first 16 tiles of each item
-    if (A.trace != nullptr && tid == 0 && blockIdx.x < 16 && wg < 64 && n_stamp < kTraceStamps) {
+    const int wg = item * 16 + lt;   // the first 16 tiles of each item
+    if (A.trace != nullptr && tid == 0 && lt < 16 && wg < 64 && n_stamp < kTraceStamps) {
       long long* tr = A.trace + ((size_t)wg * kTraceStamps + n_stamp) * 2;
       tr[0] = (long long)__builtin_readcyclecounter();
       tr[1] = (long long)wall_clock64();
@@ -360,11 +361,18 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
   constexpr int RPI = 4 * kDwWaves;   // minibatch rows per iteration of the workgroup
   for (int it0 = 0; it0 * RPI < A.B; it0 += U) {
     f32x2 a2[U], x2[U], ap[U][3];
+    float rs[U];
+    // per-row seed of unit-seed layers, or the constant 1 (stride 0): always a load, no branch
+    // between the row requests
+    const bool scaled = I.scaled != 0 && A.row_scale != nullptr;
+    const float* rsp = scaled ? A.row_scale : A.one;
+    const size_t rs_ld = scaled ? (size_t)A.row_scale_ld : 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int b = RPI * (it0 + u) + 4 * wave + c;
       a2[u] = f32x2{0.f, 0.f};
       x2[u] = f32x2{0.f, 0.f};
+      rs[u] = rsp[(size_t)(b < A.B ? b : 0) * rs_ld];
 #pragma unroll
       for (int p = 0; p < 3; ++p) ap[u][p] = f32x2{0.f, 0.f};
       if (b < A.B) {
@@ -385,10 +393,10 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int p = 0; p < 3; ++p) a2[u] += ap[u][p];
-    stamp();   // rows arrived
+    stamp();   // rows requested
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      f32x2 av = a2[u], xv = x2[u];
+      f32x2 av = a2[u] * rs[u], xv = x2[u];   // rs = 1 unless the rows are unit-seed (exact)
       av[0] = n0v ? av[0] : 0.f;
       av[1] = n1v ? av[1] : 0.f;
       xv[0] = k0v ? xv[0] : 0.f;
@@ -673,18 +681,28 @@ hipError_t init_kernel_attrs() {
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
+__device__ float g_one = 1.f;
+
 hipError_t launch_dw_adam(const DwArgs& a, hipStream_t st) {
   if (a.n_items < 1 || a.n_items > kDwMaxItems) return hipErrorInvalidValue;
+  static const float* one_dev = nullptr;
+  if (one_dev == nullptr) {
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_one));
+    if (e != hipSuccess) return e;
+    one_dev = (const float*)p;
+  }
   DwKArgs k;
-  int max_tiles = 0;
+  int total = 0;
   for (int j = 0; j < a.n_items; ++j) {
     k.items[j] = a.items[j];
-    const int t = a.items[j].tile_end - a.items[j].tile_begin;
-    max_tiles = t > max_tiles ? t : max_tiles;
+    total += a.items[j].tile_end - a.items[j].tile_begin;
+    k.tile_end[j] = total;
   }
-  for (int j = a.n_items; j < kDwMaxItems; ++j) k.items[j] = a.items[0];
+  for (int j = a.n_items; j < kDwMaxItems; ++j) { k.items[j] = a.items[0]; k.tile_end[j] = total; }
   k.n_items = a.n_items; k.B = a.B; k.n_part = a.n_part; k.ad = a.ad; k.trace = a.trace;
-  hipLaunchKernelGGL(k_dw_adam, dim3(max_tiles, a.n_items), dim3(kDwThreads), 0, st, k);
+  k.row_scale = a.row_scale; k.row_scale_ld = a.row_scale_ld; k.one = one_dev;
+  hipLaunchKernelGGL(k_dw_adam, dim3(total), dim3(kDwThreads), 0, st, k);
   return hipGetLastError();
 }
 

@@ -100,6 +100,7 @@ int replay_view(const oprl_replay* h, const float** states, const float** action
 hipError_t init_fused_attrs();
 size_t fused_xbuf_granules_per_cluster(int nc);
 hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st);
+bool fused_ddpg_is_lean(const DdpgArgs& a);
 hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st);
 
 }  // namespace oprl
@@ -315,6 +316,7 @@ void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int*
     it.pb = n.pack + pack_off_bwd(n, l);
     it.tpf = n.pack_target ? n.pack_target + pack_off_fwd(n, l) : nullptr;
     it.dY_part_stride = (l == 0 && n.n_layers > 1) ? ws.dY0_stride : 0;
+    it.scaled = (l < n.n_layers - 1) ? 1 : 0;
     const int tn = (it.N + kDwTile - 1) / kDwTile;
     it.tiles_k = (it.K + kDwTile - 1) / kDwTile;
     it.tile_begin = *tiles;
@@ -492,6 +494,13 @@ int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st) {
   dw.B = B;
   dw.n_part = h->fused ? h->nc_cluster(B) : 1;
   dw.trace = (h->fused && h->trace != nullptr) ? h->trace + (size_t)(critic ? 4 : 5) * 64 * kTraceStamps * 2 : nullptr;
+  dw.row_scale = nullptr; dw.row_scale_ld = 0;
+  if (critic && h->fused && fused_ddpg_is_lean(ddpg_args(h, B))) {
+    // the lean phase 1 left unit-seed dz rows (tp4_scalar_fb); the TD-error seed is dY of the output layer
+    const NetWs& ws = h->ws_critic[0];
+    dw.row_scale = ws.dY[c.critics[0].n_layers - 1];
+    dw.row_scale_ld = ws.lddo;
+  }
   HIPC(launch_dw_prof(dw, st));
   return OPRL_OK;
 }
@@ -575,7 +584,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     h->opt_step_critic += 1;
     DwArgs dw;
     dw.items = h->items_host.data(); dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
-    dw.B = B; dw.n_part = 1; dw.trace = nullptr;
+    dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.row_scale = nullptr; dw.row_scale_ld = 0;
     dw.ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, 1.0f);
     HIPC(launch_dw_prof(dw, st));
   }
@@ -673,7 +682,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     h->opt_step_actor += 1;
     DwArgs dw;
     dw.items = h->items_host.data() + h->n_items_critic; dw.n_items = h->n_items_actor;
-    dw.total_tiles = h->tiles_actor; dw.B = B; dw.n_part = 1; dw.trace = nullptr;
+    dw.total_tiles = h->tiles_actor; dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.row_scale = nullptr; dw.row_scale_ld = 0;
     dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, c.actor.theta_target != nullptr, 1.0f);
     HIPC(launch_dw_prof(dw, st));
   }
@@ -1279,7 +1288,7 @@ extern "C" int oprl_mlp_backward(const oprl_net* net, const float* x0, int32_t k
   if (dx && net->dims[0] > kNarrowMax) { set_err("oprl_mlp_backward: dx supported for input dim <= %d", kNarrowMax); return OPRL_ERR_INVALID; }
   RC(launch(a, width, st));
   DwArgs dw;
-  dw.items = items.data(); dw.n_items = (int)items.size(); dw.total_tiles = tiles; dw.B = B; dw.n_part = 1; dw.trace = nullptr;
+  dw.items = items.data(); dw.n_items = (int)items.size(); dw.total_tiles = tiles; dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.row_scale = nullptr; dw.row_scale_ld = 0;
   memset(&dw.ad, 0, sizeof dw.ad);
   set_adam(dw.ad, 0.0, 0.9, 0.999, 1e-8, 0.0);
   set_step(dw.ad, 1); dw.ad.grad_scale = 1.0f; dw.ad.do_adam = 0;

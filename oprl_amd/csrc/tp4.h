@@ -302,4 +302,199 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
   sf();
 }
 
+// ---------------------------------------------------------------------------------------
+// Forward AND backward of a SCALAR-OUTPUT net (a critic) in one pass, seeded with a constant.
+//
+// For N = 1 the backward is linear in the per-row seed d[row] = dLoss/dq[row]:
+//     dz2[row, j] = d[row] * W3[j] * (h2[row, j] > 0)          (elementwise, no GEMM)
+//     dz1[row, :] = d[row] * ((W3 ⊙ mask2[row]) · W2) ⊙ mask1[row]
+// so the pass runs with the constant `seed` in place of d:
+//   - DDPG phase 2 (actor loss -mean Q, d = -1/B for every row): exact, and q itself — the
+//     output layer + cluster all-reduce — is only logged, so it leaves the critical path;
+//   - DDPG phase 1 role B (d = 2(q - y)/B): seed = 1 BEFORE the TD target y has arrived;
+//     k_dw_adam multiplies the stored unit-seed dz rows by d[row] (DwItem::scaled).  The
+//     product order differs from autograd's by one rounding per element (<= 1.2e-7 rel.).
+// Stages: [x0] L0 -> h1   [h1] L1 -> h2 and g2 = unit dz2 (waves 0..3; the rest store h1)
+//         [h2,g2] dz1 partial, mask in place (h1); stores of h2 / g2 columns
+//         [dz1] dz1-partial store; input-column gradient quarters (if wanted); wave 12:
+//               output layer + all-reduce from registers -> outS
+//         [quarters] gather + all-reduce -> dactS            (if wanted)
+// g2: one more [kR][kWL4] LDS buffer.  tp.stage advances by 1 (2 with dact).
+// ---------------------------------------------------------------------------------------
+template <class ST = NoStamp>
+__device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, float* h1, float* h2,
+                                              float* g2, float* outS, float* scr, Tp& tp,
+                                              const Tp3Store& st, int row0, int B, float seed,
+                                              int dact_col0, int dact_cols, float* dactS, ST sf = ST()) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  const int c = tp.c, c0 = c * kCols4;
+  const int NS0 = (net.dims[0] + 15) >> 4;          // layer-0 steps = input-gradient tiles
+  const bool dact = dact_cols > 0;
+  const int dt = wave >> 2, dpart = wave & 3;
+  const bool dact_wave = dact && dt < NS0;
+  constexpr int kOutWave = 12;
+
+  // ---- requests
+  f32x4 w0[4], wq[16], wz[4], wd[4];
+  {
+    const float* p0 = net.pf[0] + ((size_t)wave * NS0 * 64 + lane) * 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) w0[s] = s < NS0 ? ld4(p0 + s * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float bias0 = net.b[0][16 * wave + i];
+  float bias12 = 0.f, w3 = 0.f;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) wq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (wave < kTpc4) {
+    const float* p1 = net.pf[1] + ((size_t)(c * kTpc4 + wave) * 16 * 64 + lane) * 4;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) wq[s] = ld4(p1 + s * 256);
+    bias12 = net.b[1][c0 + 16 * wave + i];
+    w3 = net.pb[2][((size_t)(c * kTpc4 + wave) * 64 + i) * 4];   // W3[c0 + 16 wave + i]  (NSo = 1)
+  } else if (wave == kOutWave) {
+    const float* p2 = net.pf[2] + (((size_t)c * kTpc4) * 64 + lane) * 4;
+#pragma unroll
+    for (int s = 0; s < kTpc4; ++s) wq[s] = ld4(p2 + s * 256);
+    if (i == 0) bias12 = net.b[2][0];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();   // x0 visible
+
+  // ---- L0
+  {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xr = x0s + i * kX0Ld + 4 * kk;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (s < NS0) mac4(ld4(xr + 16 * s), w0[s], acc);
+    float* o = h1 + (kk * 4) * kWL4 + 16 * wave + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r * kWL4] = fmaxf(acc[r] + bias0, 0.f);
+  }
+  {
+    const float* q1 = net.pb[1] + (((size_t)wave * 16 + c * kTpc4) * 64 + lane) * 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wz[s] = ld4(q1 + s * 256);
+  }
+  sf();
+  __syncthreads();   // h1 visible
+
+  // ---- L1 and the unit-seed dz2 on waves 0..3; the others store h1
+  if (wave < kTpc4) {
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    const float* hr = h1 + i * kWL4 + 4 * kk;
+#pragma unroll
+    for (int s = 0; s < 16; s += 2) {
+      mac4(ld4(hr + 16 * s), wq[s], a0);
+      mac4(ld4(hr + 16 * s + 16), wq[s + 1], a1);
+    }
+    const int off = (kk * 4) * kWL4 + c0 + 16 * wave + i;
+    const float gz = seed * w3;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = fmaxf((a0[r] + a1[r]) + bias12, 0.f);
+      h2[off + r * kWL4] = v;
+      g2[off + r * kWL4] = v > 0.f ? gz : 0.f;
+    }
+  } else if (st.X1 != nullptr && c == 0) {
+    for (int idx = (int)threadIdx.x - 64 * kTpc4; idx < kR * (kW4 / 4); idx += kThreads - 64 * kTpc4) {
+      const int row = idx >> 6, col = (idx & 63) * 4, gr = row0 + row;
+      if (gr < B) *reinterpret_cast<f32x4*>(st.X1 + (size_t)gr * kW4 + col) = ld4(h1 + row * kWL4 + col);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) wd[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (dact_wave) {
+    const float* q0 = net.pb[0] + (((size_t)dt * 16 + dpart * 4) * 64 + lane) * 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wd[s] = ld4(q0 + s * 256);
+  }
+  sf();
+  __syncthreads();   // h2, g2 (the member's columns) visible
+
+  // ---- dz1 partial (unit seed), mask in place over h1; then the h2 / g2 column stores
+  {
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    const float* gr_ = g2 + i * kWL4 + c0 + 4 * kk;
+    mac4(ld4(gr_), wz[0], a0);
+    mac4(ld4(gr_ + 16), wz[1], a1);
+    mac4(ld4(gr_ + 32), wz[2], a0);
+    mac4(ld4(gr_ + 48), wz[3], a1);
+    float* p = h1 + (kk * 4) * kWL4 + 16 * wave + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r * kWL4] = p[r * kWL4] > 0.f ? a0[r] + a1[r] : 0.f;
+  }
+  if (wave >= 4 && wave < 12) {
+    float* dstg = wave < 8 ? st.X2 : st.dY1;
+    if (dstg != nullptr) {
+      const float* src = wave < 8 ? h2 : g2;
+      const int idx = (int)threadIdx.x - (wave < 8 ? 256 : 512);   // 16 rows x 16 float4
+      const int row = idx >> 4, col = c0 + (idx & 15) * 4, gr = row0 + row;
+      if (gr < B) *reinterpret_cast<f32x4*>(dstg + (size_t)gr * kW4 + col) = ld4(src + row * kWL4 + col);
+    }
+  }
+  sf();
+  __syncthreads();   // dz1 partial visible
+
+  if (st.dY0 != nullptr) {
+    const int idx = threadIdx.x;
+    const int row = idx >> 6, col = (idx & 63) * 4, gr = row0 + row;
+    if (gr < B)
+      *reinterpret_cast<f32x4*>(st.dY0 + (size_t)c * st.dY0_stride + (size_t)gr * kW4 + col) =
+          ld4(h1 + row * kWL4 + col);
+  }
+  if (dact_wave) {
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    const float* hr = h1 + i * kWL4 + 64 * dpart + 4 * kk;
+    mac4(ld4(hr), wd[0], a0);
+    mac4(ld4(hr + 16), wd[1], a1);
+    mac4(ld4(hr + 32), wd[2], a0);
+    mac4(ld4(hr + 48), wd[3], a1);
+    *reinterpret_cast<f32x4*>(scr + wave * 256 + lane * 4) = a0 + a1;
+  }
+  if (dact) {
+    sf();
+    __syncthreads();   // quarters visible
+  }
+  // q (wave 12) and the input-column gradient (waves < NS0) finish side by side: both are one
+  // hop of the cluster exchange, neither waits for the other
+  if (wave == kOutWave) {
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    const float* hr = h2 + i * kWL4 + c0 + 4 * kk;
+    mac4(ld4(hr), wq[0], a0);
+    mac4(ld4(hr + 16), wq[1], a1);
+    mac4(ld4(hr + 32), wq[2], a0);
+    mac4(ld4(hr + 48), wq[3], a1);
+    const bool valid = i == 0;
+    const f32x4 sum = tp4_allreduce_regs(a0 + a1, i, valid, tp);
+    float* o = outS + (kk * 4) * kOutLd + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r * kOutLd] = valid ? sum[r] + bias12 : 0.f;
+  }
+  if (dact) {
+    if (wave < NS0) {
+      Tp tp2 = tp;
+      tp2.stage = tp.stage + 1;
+      f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part += ld4(scr + (wave * 4 + q) * 256 + lane * 4);
+      const int cc = 16 * wave + i - dact_col0;
+      const bool valid = cc >= 0 && cc < dact_cols;
+      const f32x4 sum = tp4_allreduce_regs(part, cc, valid, tp2);
+      if (valid) {
+        float* o = dactS + (kk * 4) * kOutLd + cc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r * kOutLd] = sum[r];
+      }
+    }
+    tp.stage += 1;
+  }
+  tp.stage += 1;
+  sf();
+  __syncthreads();   // outS (and dactS) visible
+  sf();
+}
+
 }  // namespace oprl
