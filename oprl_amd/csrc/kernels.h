@@ -161,7 +161,8 @@ struct DdpgArgs {
   long long* trace;
 };
 
-constexpr int kDwTile = 32;
+constexpr int kDwTile = 32;      // k (fan-in) extent of a dW tile
+constexpr int kDwTileN = 16;     // n (fan-out) extent: 16 rows keep a workgroup's bytes at X 32 KB + dY 16 KB
 constexpr int kDwThreads = 512;
 constexpr int kDwWaves = 8;
 constexpr int kTraceStamps = 24;

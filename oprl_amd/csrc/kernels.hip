@@ -3,7 +3,7 @@
 //   k_mlp_slice<WIDTH>   one workgroup per 16-row minibatch slice: input assembly
 //                        -> whole-MLP forward -> policy-head / TD epilogue ->
 //                        loss-gradient seed -> whole-MLP backward (engine.h)
-//   k_dw_adam            dW = dY^T X on 32x32 tiles (fp32 MFMA) fused with
+//   k_dw_adam            dW = dY^T X on 16x32 tiles (fp32 MFMA) fused with
 //                        torch-semantics Adam, Polyak target update, grad export
 //   k_adam_flat / k_polyak_flat / k_alpha_step / k_reduce_partials   small fused
 //                        elementwise pieces
@@ -297,9 +297,9 @@ __device__ __forceinline__ void adam_bias_corr(const AdamScalars& ad, float* ste
 }
 
 __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
-  constexpr int T = kDwTile, LD = T + 4;
-  __shared__ __attribute__((aligned(16))) float part[kDwWaves][T][LD];
-  __shared__ float bpart[kDwWaves][T];
+  constexpr int TN = kDwTileN, TK = kDwTile, LD = TK + 4;
+  __shared__ __attribute__((aligned(16))) float part[kDwWaves][TN][LD];
+  __shared__ float bpart[kDwWaves][TN];
   __shared__ float sc[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // this workgroup's layer, straight from the kernel-argument segment (dynamic index into a
@@ -322,198 +322,154 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
   stamp();
   if (tid == 64) adam_bias_corr(A.ad, &sc[0], &sc[1]);
   const int tn = lt / I.tiles_k, tk = lt - tn * I.tiles_k;
-  const int n_base = tn * T, k_base = tk * T;
+  const int n_base = tn * TN, k_base = tk * TK;
   const int i = lane & 15, c = lane >> 4;
   const int NSk = cdiv(I.K, 16), NSn = cdiv(I.N, 16);
   const int npart = I.dY_part_stride > 0 ? A.n_part : 1;
+  const bool polyak = A.ad.do_polyak && I.w_t != nullptr;
 
-  // this thread's share of the epilogue: 2 consecutive k of one row n.  Its Adam
-  // state is requested NOW so the round trip overlaps the GEMM.
-  const int nl = tid >> 4, kl0 = (tid & 15) * 2;
-  const int en = n_base + nl;
-  float p_th[2] = {0.f, 0.f}, p_m[2] = {0.f, 0.f}, p_v[2] = {0.f, 0.f}, p_tt[2] = {0.f, 0.f};
-  bool e_ok[2];
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int k = k_base + kl0 + e;
-    e_ok[e] = en < I.N && k < I.K;
-    if (e_ok[e] && A.ad.do_adam) {
-      const size_t o = (size_t)en * I.K + k;
-      p_th[e] = I.w[o];
-      p_m[e] = I.w_m[o];
-      p_v[e] = I.w_v[o];
-      if (A.ad.do_polyak && I.w_t != nullptr) p_tt[e] = I.w_t[o];
-    }
+  // this thread's element of the epilogue; its Adam state is requested NOW so the round
+  // trip overlaps the GEMM
+  const int nl = tid >> 5, kl = tid & 31;
+  const int en = n_base + nl, ek = k_base + kl;
+  const bool e_ok = en < I.N && ek < I.K;
+  const size_t eo = (size_t)en * I.K + ek;
+  float p_th = 0.f, p_m = 0.f, p_v = 0.f, p_tt = 0.f;
+  if (e_ok && A.ad.do_adam) {
+    p_th = I.w[eo];
+    p_m = I.w_m[eo];
+    p_v = I.w_v[eo];
+    if (polyak) p_tt = I.w_t[eo];
   }
 
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int u = 0; u < 2; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float sA[2] = {0.f, 0.f};
-  const int ncol = n_base + 2 * i, kcol = k_base + 2 * i;
-  const bool n_ok = ncol < I.ldy, k_ok = kcol < I.ldx;   // ld even -> pair in bounds
-  const bool n0v = ncol < I.N, n1v = ncol + 1 < I.N, k0v = kcol < I.K, k1v = kcol + 1 < I.K;
-  // all loads of U batch chunks are issued before the first MFMA (latency-bound
-  // otherwise: dependent trips to L2/HBM per wave)
+  // ---- dW tile = sum_b dY[b, n]^T X[b, k]: lane (c, i) feeds dY[b = 4 wave + c (+32 u)][n_base + i]
+  // as the A operand and X[b][k_base + 2i + {0,1}] as two B operands
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  float sA = 0.f;
+  const int ncol = n_base + i, kcol = k_base + 2 * i;
+  const bool n_ok = ncol < I.N, k_ok = kcol < I.ldx;       // ldx even -> the pair is in bounds
+  const bool k0v = kcol < I.K, k1v = kcol + 1 < I.K;
+  // per-row seed of unit-seed layers, or the constant 1 (stride 0): always a load, no branch
+  // between the row requests
+  const bool scaled = I.scaled != 0 && A.row_scale != nullptr;
+  const float* rsp = scaled ? A.row_scale : A.one;
+  const size_t rs_ld = scaled ? (size_t)A.row_scale_ld : 0;
+  // all loads of U batch chunks are issued before the first MFMA
   constexpr int U = 8;
-  constexpr int RPI = 4 * kDwWaves;   // minibatch rows per iteration of the workgroup
+  constexpr int RPI = 4 * kDwWaves;   // minibatch rows per chunk of the workgroup
   for (int it0 = 0; it0 * RPI < A.B; it0 += U) {
-    f32x2 a2[U], x2[U], ap[U][3];
-    float rs[U];
-    // per-row seed of unit-seed layers, or the constant 1 (stride 0): always a load, no branch
-    // between the row requests
-    const bool scaled = I.scaled != 0 && A.row_scale != nullptr;
-    const float* rsp = scaled ? A.row_scale : A.one;
-    const size_t rs_ld = scaled ? (size_t)A.row_scale_ld : 0;
+    float a1[U], ap[U][3], rs[U];
+    f32x2 x2[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int b = RPI * (it0 + u) + 4 * wave + c;
-      a2[u] = f32x2{0.f, 0.f};
+      a1[u] = 0.f;
       x2[u] = f32x2{0.f, 0.f};
       rs[u] = rsp[(size_t)(b < A.B ? b : 0) * rs_ld];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) ap[u][p] = f32x2{0.f, 0.f};
+      for (int p = 0; p < 3; ++p) ap[u][p] = 0.f;
       if (b < A.B) {
         if (n_ok) {
           const float* src = I.dY + (size_t)b * I.ldy + ncol;
-          a2[u] = *reinterpret_cast<const f32x2*>(src);
+          a1[u] = *src;
           // tensor-parallel slices leave the first layer's dz as n_part (<= 4) partial
           // buffers (csrc/tp3.h): all requested up front, summed below in member order
 #pragma unroll
           for (int p = 0; p < 3; ++p)
-            if (p + 1 < npart)
-              ap[u][p] = *reinterpret_cast<const f32x2*>(src + (size_t)(p + 1) * I.dY_part_stride);
+            if (p + 1 < npart) ap[u][p] = src[(size_t)(p + 1) * I.dY_part_stride];
         }
         if (k_ok) x2[u] = *reinterpret_cast<const f32x2*>(I.X + (size_t)b * I.ldx + kcol);
       }
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) a2[u] += ap[u][p];
     stamp();   // rows requested
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      f32x2 av = a2[u] * rs[u], xv = x2[u];   // rs = 1 unless the rows are unit-seed (exact)
-      av[0] = n0v ? av[0] : 0.f;
-      av[1] = n1v ? av[1] : 0.f;
+      const float av = (((a1[u] + ap[u][0]) + ap[u][1]) + ap[u][2]) * rs[u];   // rs = 1 unless unit-seed rows
+      f32x2 xv = x2[u];
       xv[0] = k0v ? xv[0] : 0.f;
       xv[1] = k1v ? xv[1] : 0.f;
-      sA[0] += av[0];
-      sA[1] += av[1];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int w = 0; w < 2; ++w) acc[t][w] = mfma4(av[t], xv[w], acc[t][w]);
+      sA += av;
+      acc[0] = mfma4(av, xv[0], acc[0]);
+      acc[1] = mfma4(av, xv[1], acc[1]);
     }
   }
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int w = 0; w < 2; ++w)
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) part[wave][2 * (c * 4 + r) + t][2 * i + u] = acc[t][u][r];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    float s = sA[t];
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    if (c == 0) bpart[wave][2 * i + t] = s;
+    for (int r = 0; r < 4; ++r) part[wave][c * 4 + r][2 * i + w] = acc[w][r];
+  {
+    float sb = sA;
+    sb += __shfl_xor(sb, 16);
+    sb += __shfl_xor(sb, 32);
+    if (c == 0) bpart[wave][i] = sb;
   }
   stamp();   // MFMA done, partial tiles in LDS
   __syncthreads();
   stamp();
   const float step_size = sc[0], bc2_sqrt = sc[1];
-  // ---- epilogue.  Each thread finishes 2 consecutive k of one row n; the updated tile then
-  // goes through LDS so that the packs are written IN PACK ORDER as 16-byte stores (the
-  // element-wise version issued 14 scattered 4-byte stores per thread: 2.2 us of the
-  // kernel's 5.6, tools/trace_slice.py).
-  f32x2 gsum = f32x2{0.f, 0.f};
+  // ---- epilogue: one element per thread; the updated tile then goes through LDS so that the
+  // packs are written IN PACK ORDER as 16-byte stores
+  float g = 0.f;
 #pragma unroll
-  for (int w = 0; w < kDwWaves; ++w) gsum += *reinterpret_cast<const f32x2*>(&part[w][nl][kl0]);
-  float th2[2] = {0.f, 0.f}, tt2[2] = {0.f, 0.f}, mm2[2] = {0.f, 0.f}, vv2[2] = {0.f, 0.f}, g2[2];
-  const bool polyak = A.ad.do_polyak && I.w_t != nullptr;
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const float g = gsum[e] * A.ad.grad_scale;
-    g2[e] = g;
-    if (e_ok[e] && A.ad.do_adam) {
-      float mm = p_m[e], vv = p_v[e], th = p_th[e];
+  for (int w = 0; w < kDwWaves; ++w) g += part[w][nl][kl];
+  g *= A.ad.grad_scale;
+  float th_new = 0.f, tt_new = 0.f;
+  if (e_ok) {
+    if (I.w_g != nullptr) I.w_g[eo] = g;
+    if (A.ad.do_adam) {
+      float mm = p_m, vv = p_v, th = p_th;
       mm = mm + (g - mm) * A.ad.omb1;
       vv = vv * A.ad.beta2 + A.ad.omb2 * g * g;
       th = th - step_size * (mm / (sqrtf(vv) / bc2_sqrt + A.ad.eps));
-      mm2[e] = mm; vv2[e] = vv; th2[e] = th;
-      if (polyak) tt2[e] = p_tt[e] * A.ad.omtau + A.ad.tau * th;
-    }
-  }
-  {
-    const size_t o = (size_t)en * I.K + k_base + kl0;
-    if ((I.K & 1) == 0) {          // row starts stay 8-byte aligned: one store per array
-      if (e_ok[0]) {
-        if (I.w_g != nullptr) *reinterpret_cast<f32x2*>(I.w_g + o) = f32x2{g2[0], g2[1]};
-        if (A.ad.do_adam) {
-          *reinterpret_cast<f32x2*>(I.w_m + o) = f32x2{mm2[0], mm2[1]};
-          *reinterpret_cast<f32x2*>(I.w_v + o) = f32x2{vv2[0], vv2[1]};
-          *reinterpret_cast<f32x2*>(I.w + o) = f32x2{th2[0], th2[1]};
-          if (polyak) *reinterpret_cast<f32x2*>(I.w_t + o) = f32x2{tt2[0], tt2[1]};
-        }
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        if (!e_ok[e]) continue;
-        if (I.w_g != nullptr) I.w_g[o + e] = g2[e];
-        if (A.ad.do_adam) {
-          I.w_m[o + e] = mm2[e];
-          I.w_v[o + e] = vv2[e];
-          I.w[o + e] = th2[e];
-          if (polyak) I.w_t[o + e] = tt2[e];
-        }
+      I.w_m[eo] = mm;
+      I.w_v[eo] = vv;
+      I.w[eo] = th;
+      th_new = th;
+      if (polyak) {
+        tt_new = p_tt * A.ad.omtau + A.ad.tau * th;
+        I.w_t[eo] = tt_new;
       }
     }
   }
   if (A.ad.do_adam && I.pf != nullptr) {
-    // keep the fragment-order packs in step with the master: stage the new 32x32 tile(s)
-    // (zero outside the matrix, like the packs' padding), then 3 x 256 float4 jobs
+    // keep the fragment-order packs in step with the master: stage the new 16x32 tile(s)
+    // (zero outside the matrix, like the packs' padding), then 3 x 128 float4 jobs
     float (*tileW)[LD] = part[0];
     float (*tileT)[LD] = part[1];
     __syncthreads();               // every thread has read its partial sums
-    *reinterpret_cast<f32x2*>(&tileW[nl][kl0]) = f32x2{th2[0], th2[1]};
-    *reinterpret_cast<f32x2*>(&tileT[nl][kl0]) = f32x2{tt2[0], tt2[1]};
+    tileW[nl][kl] = th_new;
+    tileT[nl][kl] = tt_new;
     __syncthreads();
-    const int NTn = cdiv(I.N, 16), NTk = NSk;
-    for (int j = tid; j < 768; j += kDwThreads) {
-      const int which = j >> 8, q = j & 255;
-      const int blk = q >> 6, l = q & 63, bt = blk >> 1, bs = blk & 1, li = l & 15, lk = l >> 4;
+    if (tid < 384) {
+      const int which = tid >> 7, q = tid & 127;
+      const int blk = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
       if (which == 1) {            // W^T pack: tiles over k, steps over n
-        const int ktile = 2 * tk + bt, nstep = 2 * tn + bs;
-        if (I.pb != nullptr && ktile < NTk && nstep < NSn) {
+        const int ktile = 2 * tk + blk;
+        if (I.pb != nullptr && ktile < NSk) {
           f32x4 v;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) v[t] = tileW[16 * bs + 4 * lk + t][16 * bt + li];
-          *reinterpret_cast<f32x4*>(I.pb + (((size_t)ktile * NSn + nstep) * 64 + l) * 4) = v;
+          for (int t = 0; t < 4; ++t) v[t] = tileW[4 * lk + t][16 * blk + li];
+          *reinterpret_cast<f32x4*>(I.pb + (((size_t)ktile * NSn + tn) * 64 + l) * 4) = v;
         }
       } else {                     // W pack (online, target): tiles over n, steps over k
-        const int ntile = 2 * tn + bt, kstep = 2 * tk + bs;
+        const int kstep = 2 * tk + blk;
         float* dst = which == 0 ? I.pf : (polyak ? I.tpf : nullptr);
-        if (dst != nullptr && ntile < NTn && kstep < NTk) {
+        if (dst != nullptr && kstep < NSk) {
           const float (*src)[LD] = which == 0 ? tileW : tileT;
-          *reinterpret_cast<f32x4*>(dst + (((size_t)ntile * NSk + kstep) * 64 + l) * 4) =
-              *reinterpret_cast<const f32x4*>(&src[16 * bt + li][16 * bs + 4 * lk]);
+          *reinterpret_cast<f32x4*>(dst + (((size_t)tn * NSk + kstep) * 64 + l) * 4) =
+              *reinterpret_cast<const f32x4*>(&src[li][16 * blk + 4 * lk]);
         }
       }
     }
   }
-  if (tk == 0 && tid < T) {
+  if (tk == 0 && tid < TN) {
     const int n = n_base + tid;
     if (n < I.N) {
-      float g = 0.f;
+      float gb = 0.f;
 #pragma unroll
-      for (int w = 0; w < kDwWaves; ++w) g += bpart[w][tid];
+      for (int w = 0; w < kDwWaves; ++w) gb += bpart[w][tid];
       float t0, t1;
-      (void)adam_polyak_elem(g, I.b + n, I.b_m ? I.b_m + n : nullptr, I.b_v ? I.b_v + n : nullptr,
+      (void)adam_polyak_elem(gb, I.b + n, I.b_m ? I.b_m + n : nullptr, I.b_v ? I.b_v + n : nullptr,
                              I.b_t ? I.b_t + n : nullptr, I.b_g ? I.b_g + n : nullptr, A.ad, step_size,
                              bc2_sqrt, &t0, &t1);
     }

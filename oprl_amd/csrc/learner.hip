@@ -317,7 +317,7 @@ void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int*
     it.tpf = n.pack_target ? n.pack_target + pack_off_fwd(n, l) : nullptr;
     it.dY_part_stride = (l == 0 && n.n_layers > 1) ? ws.dY0_stride : 0;
     it.scaled = (l < n.n_layers - 1) ? 1 : 0;
-    const int tn = (it.N + kDwTile - 1) / kDwTile;
+    const int tn = (it.N + kDwTileN - 1) / kDwTileN;
     it.tiles_k = (it.K + kDwTile - 1) / kDwTile;
     it.tile_begin = *tiles;
     *tiles += tn * it.tiles_k;

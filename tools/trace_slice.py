@@ -46,3 +46,27 @@ for slot in range(len(names)):
           f"max-wg={tot_us.max():.2f}us  cyc/us~{clk.mean():.2f} GHz  start spread={(rt[:,0].max()-rt[:,0].min())/100:.2f}us")
     if "--cycles" in sys.argv:
         print(f"{'':22s} wg0 phases(cycles)={d_cyc[0].astype(int).tolist()}")
+
+# absolute timeline on the shared 100 MHz clock: first/last stamp over all traced workgroups
+if fused:
+    print("timeline (us from the first stamp of the update; first-in .. last-out over traced workgroups):")
+    spans = []
+    for slot in range(len(names)):
+        x = tr[slot]
+        ok = x[:, 0, 1] != 0
+        if not ok.any():
+            continue
+        firsts = x[ok, 0, 1].astype(np.float64)
+        lasts = np.array([row[row[:, 1] != 0, 1].max() for row in x[ok]], dtype=np.float64)
+        spans.append((names[slot], firsts.min(), firsts.max(), lasts.min(), lasts.max()))
+    t0 = min(sp[1] for sp in spans)
+    for nm, f0, f1, l0, l1 in spans:
+        print(f"  {nm:34s} start {(f0-t0)/100:7.2f} .. {(f1-t0)/100:7.2f}   end {(l0-t0)/100:7.2f} .. {(l1-t0)/100:7.2f}")
+
+    if "--per-wg" in sys.argv:
+        for slot in range(len(names)):
+            x = tr[slot]
+            ok = np.nonzero(x[:, 0, 1] != 0)[0]
+            st_ = [(int(w), round((x[w, 0, 1] - t0) / 100, 2),
+                    round((x[w][x[w][:, 1] != 0, 1].max() - t0) / 100, 2)) for w in ok]
+            print(f"  {names[slot]}: (wg, start, end) {st_}")
