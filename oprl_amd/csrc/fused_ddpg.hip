@@ -325,6 +325,28 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
     }
     ++n_stamp;
   };
+  if ((int)blockIdx.y == A.nc) {
+    // ---- prefetch row: gather the next update's rows (same draw as load_batch will not have
+    // to make) and leave them contiguous for phase 1 of the next step
+    float* xb = smem + LY::xb;
+    float* rS = smem + LY::misc;
+    float* dS = rS + kR;
+    int* meta = reinterpret_cast<int*>(dS + 2 * kR);
+    int* endsS = reinterpret_cast<int*>(smem + LY::misc + 96);
+    load_batch(A.next, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
+    __syncthreads();
+    store_rows(xa, kX0Ld, const_cast<float*>(A.next.s), S, S, row0, B);
+    store_rows(xb, kX0Ld, const_cast<float*>(A.next.s2), S, S, row0, B);
+    for (int idx = tid; idx < kR * Ad; idx += kThreads) {
+      const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
+      if (gr < B) const_cast<float*>(A.next.a)[(size_t)gr * Ad + col] = xa[row * kX0Ld + S + col];
+    }
+    if (tid < kR && row0 + tid < B) {
+      const_cast<float*>(A.next.r)[row0 + tid] = rS[tid];
+      const_cast<float*>(A.next.d)[row0 + tid] = dS[tid];
+    }
+    return;
+  }
   stamp();
   const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
   // [s | pi] and the actor's forward activations (for its ReLU masks)
@@ -419,10 +441,11 @@ hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st) {
 
 hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
+  const int rows = a.nc + (a.prefetch_next ? 1 : 0);   // + the next-minibatch gather row
   if (lean_ok(a))
-    hipLaunchKernelGGL((k_ddpg_phase2<256, true>), dim3(slices, a.nc), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+    hipLaunchKernelGGL((k_ddpg_phase2<256, true>), dim3(slices, rows), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
   else
-    hipLaunchKernelGGL((k_ddpg_phase2<256, false>), dim3(slices, a.nc), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+    hipLaunchKernelGGL((k_ddpg_phase2<256, false>), dim3(slices, rows), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
   return hipGetLastError();
 }
 

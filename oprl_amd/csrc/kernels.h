@@ -143,6 +143,11 @@ struct DdpgArgs {
   Net actor, actor_t, critic, critic_t;
   int B, S, A;
   BatchSrc src;
+  // step_n: phase 2 carries one extra row of workgroups that gathers the NEXT update's
+  // minibatch (its Philox counter is known) into the staging rows next.s/a/r/d/s2 (writable
+  // here), so the ends-table -> search -> random-row chain leaves phase 1's critical path
+  BatchSrc next;
+  int prefetch_next;
   float gamma, inv_B;
   float* cX[kMaxLayers]; int cldx0;    // critic layer inputs ([s|a], h1, h2) for dW
   float* cdY[kMaxLayers]; int clddo;   // critic pre-activation grads

@@ -288,6 +288,8 @@ struct oprl_learner {
     return c;
   }
   BatchSrc src;                // where the current update's minibatch comes from
+  BatchSrc next_src;           // step_n: what phase 2 should gather for the next update
+  int prefetch_next = 0;
   // prebuilt device repack tables: [0] critics online, [1] critics online+target, [2] actor (+target)
   RepackItem* rp_dev[3] = {nullptr, nullptr, nullptr};
   int rp_n[3] = {0, 0, 0}, rp_blocks[3] = {0, 0, 0};
@@ -456,6 +458,8 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   a.critic_t = net_view(c.critics[0], true);
   a.B = B; a.S = h->S; a.A = h->A;
   a.src = h->src;
+  a.next = h->next_src;
+  a.prefetch_next = 0;
   a.gamma = (float)c.hp.gamma;
   a.inv_B = 1.0f / (float)B;
   for (int l = 0; l < kMaxLayers; ++l) {
@@ -598,6 +602,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     DdpgArgs fa = ddpg_args(h, B);
     fa.cluster_tag = ((h->epoch << 1) | 1u) & 0x03FFFFFFu;
     if (h->trace != nullptr) fa.trace = h->trace + (size_t)3 * 64 * kTraceStamps * 2;   // slot 3
+    fa.prefetch_next = h->prefetch_next;
     prof_begin(5, st);
     hipError_t e = launch_ddpg_phase2(fa, st);
     prof_end(st);
@@ -928,6 +933,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   if (e == hipSuccess) e = init_fused_attrs();
   if (e != hipSuccess) { set_err("hipFuncSetAttribute: %s", hipGetErrorString(e)); delete h; return OPRL_ERR_HIP; }
   memset(&h->src, 0, sizeof h->src);
+  memset(&h->next_src, 0, sizeof h->next_src);
   if (h->nc > 2 && getenv("OPRL_AMD_NO_SIDE_STREAMS") == nullptr) {
     bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int j = 1; ok && j < h->nc; ++j)
@@ -1146,12 +1152,21 @@ extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t
     sc.n_transitions = n_tr;
     sc.seed = seed;
     sc.gather = 1;
+    // The first update gathers in-kernel; every update's phase 2 also gathers the NEXT
+    // update's rows into the staging batch (h->bs ..), which phase 1 then reads as plain rows.
+    h->next_src = sc;
+    h->next_src.s = h->bs; h->next_src.a = h->ba; h->next_src.r = h->br; h->next_src.d = h->bd;
+    h->next_src.s2 = h->bs2;
     int rc = OPRL_OK;
     for (int k = 0; k < K && rc == OPRL_OK; ++k) {
       sc.counter = (unsigned long long)h->update_count;
+      h->next_src.counter = sc.counter + 1;
+      h->prefetch_next = (k + 1 < K) ? 1 : 0;
       rc = oprl_learner_update(h, h->bs, h->ba, h->br, h->bd, h->bs2, B, nullptr, nullptr, stream);
+      sc.gather = 0;     // from the second update on the rows are staged
     }
     sc.gather = 0;
+    h->prefetch_next = 0;
     return rc;
   }
   for (int k = 0; k < K; ++k) {

@@ -22,9 +22,17 @@ batch = [t.randn(B, S, device="cuda"), t.rand(B, A, device="cuda") * 2 - 1, t.ra
 for _ in range(50):
     algo.update(*batch)
 _capi.check(L.lib.oprl_learner_set_trace(L.handle, _capi.ptr(buf)))
+replay = None
+if "--step-n" in sys.argv:     # the benchmarked mode: in-kernel replay gather
+    import bench
+    replay = bench.make_replay(t.device("cuda"), seed=0)
+    L.step_n(replay.handle, 50, B, seed=3)
 for _ in range(3):
     buf.zero_()
-    algo.update(*batch)
+    if replay is not None:
+        L.step_n(replay.handle, 1, B, seed=5)
+    else:
+        algo.update(*batch)
 t.cuda.synchronize()
 tr = buf.cpu().numpy()
 fused = "--generic" not in sys.argv
