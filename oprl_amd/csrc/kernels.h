@@ -78,6 +78,7 @@ struct DwItem {      // one Linear layer of one net
   float *b, *b_t, *b_m, *b_v, *b_g;    // [N]
   float *pf, *pb, *tpf;                // fragment-order packs: W (fwd), W^T (bwd), target W (fwd)
   int tiles_k, tile_begin, tile_end;
+  int tile_n;                          // n rows per tile: kDwTileN, or 8 for a layer that sums dz1 partials
   long dY_part_stride;                 // > 0: dY is the sum of DwArgs::n_part buffers this many floats apart
   int scaled;                          // 1: dY rows are unit-seed (tp4_scalar_fb): multiply row b by DwArgs::row_scale[b]
 };

@@ -322,7 +322,9 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
   stamp();
   if (tid == 64) adam_bias_corr(A.ad, &sc[0], &sc[1]);
   const int tn = lt / I.tiles_k, tk = lt - tn * I.tiles_k;
-  const int n_base = tn * TN, k_base = tk * TK;
+  const int TNi = I.tile_n;                               // 16, or 8 (partial-sum layers)
+  const int n_base = tn * TNi, k_base = tk * TK;
+  const int ptile = n_base >> 4, n_off = n_base & 15;     // 16-row pack tile and our offset in it
   const int i = lane & 15, c = lane >> 4;
   const int NSk = cdiv(I.K, 16), NSn = cdiv(I.N, 16);
   const int npart = I.dY_part_stride > 0 ? A.n_part : 1;
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
   // trip overlaps the GEMM
   const int nl = tid >> 5, kl = tid & 31;
   const int en = n_base + nl, ek = k_base + kl;
-  const bool e_ok = en < I.N && ek < I.K;
+  const bool e_ok = nl < TNi && en < I.N && ek < I.K;
   const size_t eo = (size_t)en * I.K + ek;
   float p_th = 0.f, p_m = 0.f, p_v = 0.f, p_tt = 0.f;
   if (e_ok && A.ad.do_adam) {
@@ -342,56 +344,80 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
     if (polyak) p_tt = I.w_t[eo];
   }
 
-  // ---- dW tile = sum_b dY[b, n]^T X[b, k]: lane (c, i) feeds dY[b = 4 wave + c (+32 u)][n_base + i]
-  // as the A operand and X[b][k_base + 2i + {0,1}] as two B operands
+  // ---- dW tile = sum_b dY[b, n]^T X[b, k].  Each wave owns 32 consecutive minibatch rows per
+  // 256-row chunk.  Rows are fetched with 16-byte loads (16 rows of dY / 8 rows of X per
+  // instruction; the 4-byte, 4-rows-per-instruction version was bound by the NUMBER of load
+  // instructions: 48 per lane on a layer with four dz1 partials), partials are summed and the
+  // per-row seed applied in registers, then the wave stages its rows in wave-private LDS and
+  // reads them back in MFMA layout: lane (c, i) feeds dY[row 4u + c][n_base + i] as the A
+  // operand and X[row 4u + c][k_base + 2i + {0,1}] as two B operands.
+  __shared__ __attribute__((aligned(16))) float stA[kDwWaves][32][TN];
+  __shared__ __attribute__((aligned(16))) float stX[kDwWaves][32][LD];
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   float sA = 0.f;
-  const int ncol = n_base + i, kcol = k_base + 2 * i;
-  const bool n_ok = ncol < I.N, k_ok = kcol < I.ldx;       // ldx even -> the pair is in bounds
-  const bool k0v = kcol < I.K, k1v = kcol + 1 < I.K;
   // per-row seed of unit-seed layers, or the constant 1 (stride 0): always a load, no branch
   // between the row requests
   const bool scaled = I.scaled != 0 && A.row_scale != nullptr;
   const float* rsp = scaled ? A.row_scale : A.one;
   const size_t rs_ld = scaled ? (size_t)A.row_scale_ld : 0;
-  // all loads of U batch chunks are issued before the first MFMA
-  constexpr int U = 8;
-  constexpr int RPI = 4 * kDwWaves;   // minibatch rows per chunk of the workgroup
-  for (int it0 = 0; it0 * RPI < A.B; it0 += U) {
-    float a1[U], ap[U][3], rs[U];
-    f32x2 x2[U];
+  const int ar = lane >> 2, an = (lane & 3) * 4;      // dY: 16 rows x 4 lanes x float4
+  const int xr = lane >> 3, xk = (lane & 7) * 4;      // X :  8 rows x 8 lanes x float4
+  const bool an_ok = an < TNi && n_base + an < I.ldy;  // ldy, ldx are multiples of 4
+  const bool xk_ok = k_base + xk < I.ldx;
+  for (int chunk = 0; chunk * 256 < A.B; ++chunk) {
+    const int base = chunk * 256 + 32 * wave;
+    f32x4 va[2][4], vx[4];
+    float rs[2];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int b = RPI * (it0 + u) + 4 * wave + c;
-      a1[u] = 0.f;
-      x2[u] = f32x2{0.f, 0.f};
-      rs[u] = rsp[(size_t)(b < A.B ? b : 0) * rs_ld];
+    for (int h = 0; h < 2; ++h) {
+      const int bb = base + ar + 16 * h;
+      rs[h] = rsp[(size_t)(bb < A.B ? bb : 0) * rs_ld];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) ap[u][p] = 0.f;
-      if (b < A.B) {
-        if (n_ok) {
-          const float* src = I.dY + (size_t)b * I.ldy + ncol;
-          a1[u] = *src;
-          // tensor-parallel slices leave the first layer's dz as n_part (<= 4) partial
-          // buffers (csrc/tp3.h): all requested up front, summed below in member order
+      for (int m = 0; m < 4; ++m) va[h][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (bb < A.B && an_ok) {
+        const float* src = I.dY + (size_t)bb * I.ldy + n_base + an;
+        va[h][0] = ld4(src);
+        // tensor-parallel slices leave the first layer's dz as n_part (<= 4) partial buffers
+        // (csrc/tp3.h): all requested up front, summed below in member order
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
-            if (p + 1 < npart) ap[u][p] = src[(size_t)(p + 1) * I.dY_part_stride];
-        }
-        if (k_ok) x2[u] = *reinterpret_cast<const f32x2*>(I.X + (size_t)b * I.ldx + kcol);
+        for (int m = 1; m < 4; ++m)
+          if (m < npart) va[h][m] = ld4(src + (size_t)m * I.dY_part_stride);
       }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int bb = base + xr + 8 * j;
+      vx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (bb < A.B && xk_ok) vx[j] = ld4(I.X + (size_t)bb * I.ldx + k_base + xk);
     }
     stamp();   // rows requested
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float av = (((a1[u] + ap[u][0]) + ap[u][1]) + ap[u][2]) * rs[u];   // rs = 1 unless unit-seed rows
-      f32x2 xv = x2[u];
-      xv[0] = k0v ? xv[0] : 0.f;
-      xv[1] = k1v ? xv[1] : 0.f;
+    for (int h = 0; h < 2; ++h) {
+      f32x4 v = (((va[h][0] + va[h][1]) + va[h][2]) + va[h][3]) * rs[h];   // rs = 1 unless unit-seed rows
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = (n_base + an + t < I.N) ? v[t] : 0.f;
+      *reinterpret_cast<f32x4*>(&stA[wave][ar + 16 * h][an]) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 v = vx[j];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = (k_base + xk + t < I.K) ? v[t] : 0.f;
+      *reinterpret_cast<f32x4*>(&stX[wave][xr + 8 * j][xk]) = v;
+    }
+    // wave-private staging: the wave's own LDS writes are ordered before its reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float av = stA[wave][4 * u + c][i];
+      const f32x2 xv = *reinterpret_cast<const f32x2*>(&stX[wave][4 * u + c][2 * i]);
       sA += av;
       acc[0] = mfma4(av, xv[0], acc[0]);
       acc[1] = mfma4(av, xv[1], acc[1]);
     }
+    __builtin_amdgcn_wave_barrier();   // next chunk overwrites the staging rows
   }
 #pragma unroll
   for (int w = 0; w < 2; ++w)
@@ -437,32 +463,34 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
     float (*tileW)[LD] = part[0];
     float (*tileT)[LD] = part[1];
     __syncthreads();               // every thread has read its partial sums
-    tileW[nl][kl] = th_new;
-    tileT[nl][kl] = tt_new;
+    if (nl < TNi) {
+      tileW[n_off + nl][kl] = th_new;
+      tileT[n_off + nl][kl] = tt_new;
+    }
     __syncthreads();
     if (tid < 384) {
       const int which = tid >> 7, q = tid & 127;
       const int blk = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
-      if (which == 1) {            // W^T pack: tiles over k, steps over n
+      if (which == 1) {            // W^T pack: tiles over k, steps over n; we own n in [n_off, n_off + TNi)
         const int ktile = 2 * tk + blk;
-        if (I.pb != nullptr && ktile < NSk) {
+        if (I.pb != nullptr && ktile < NSk && 4 * lk >= n_off && 4 * lk < n_off + TNi) {
           f32x4 v;
 #pragma unroll
           for (int t = 0; t < 4; ++t) v[t] = tileW[4 * lk + t][16 * blk + li];
-          *reinterpret_cast<f32x4*>(I.pb + (((size_t)ktile * NSn + tn) * 64 + l) * 4) = v;
+          *reinterpret_cast<f32x4*>(I.pb + (((size_t)ktile * NSn + ptile) * 64 + l) * 4) = v;
         }
       } else {                     // W pack (online, target): tiles over n, steps over k
         const int kstep = 2 * tk + blk;
         float* dst = which == 0 ? I.pf : (polyak ? I.tpf : nullptr);
-        if (dst != nullptr && kstep < NSk) {
+        if (dst != nullptr && kstep < NSk && li >= n_off && li < n_off + TNi) {
           const float (*src)[LD] = which == 0 ? tileW : tileT;
-          *reinterpret_cast<f32x4*>(dst + (((size_t)tn * NSk + kstep) * 64 + l) * 4) =
+          *reinterpret_cast<f32x4*>(dst + (((size_t)ptile * NSk + kstep) * 64 + l) * 4) =
               *reinterpret_cast<const f32x4*>(&src[li][16 * blk + 4 * lk]);
         }
       }
     }
   }
-  if (tk == 0 && tid < TN) {
+  if (tk == 0 && tid < TNi) {
     const int n = n_base + tid;
     if (n < I.N) {
       float gb = 0.f;

@@ -297,7 +297,7 @@ struct oprl_learner {
 
 namespace {
 
-void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int* tiles) {
+void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int* tiles, bool small_partial_tiles = false) {
   for (int l = 0; l < n.n_layers; ++l) {
     DwItem it;
     memset(&it, 0, sizeof it);
@@ -319,7 +319,9 @@ void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int*
     it.tpf = n.pack_target ? n.pack_target + pack_off_fwd(n, l) : nullptr;
     it.dY_part_stride = (l == 0 && n.n_layers > 1) ? ws.dY0_stride : 0;
     it.scaled = (l < n.n_layers - 1) ? 1 : 0;
-    const int tn = (it.N + kDwTileN - 1) / kDwTileN;
+    // (8-row tiles for this layer were measured: no difference — profiles/r01b_experiments.txt)
+    it.tile_n = kDwTileN;
+    const int tn = (it.N + it.tile_n - 1) / it.tile_n;
     it.tiles_k = (it.K + kDwTile - 1) / kDwTile;
     it.tile_begin = *tiles;
     *tiles += tn * it.tiles_k;
@@ -332,7 +334,7 @@ size_t net_ws_floats(const oprl_net& n, int B) {
   size_t f = 0;
   f += (size_t)B * round_up(n.dims[0], 4) + 64;
   for (int l = 1; l < n.n_layers; ++l) f += (size_t)B * n.dims[1] + 64;
-  for (int l = 0; l < n.n_layers - 1; ++l) f += (size_t)B * n.dims[1] * (l == 0 ? kMaxCluster : 1) + 64;
+  for (int l = 0; l < n.n_layers - 1; ++l) f += ((size_t)B * n.dims[1] + 1088) * (l == 0 ? kMaxCluster : 1) + 64;
   f += (size_t)B * round_up(n.dims[n.n_layers], 4) + 64;
   return f + 64 * 8;
 }
@@ -343,9 +345,11 @@ void alloc_net_ws(Pool& p, const oprl_net& n, int B, NetWs* ws) {
   ws->lddo = round_up(n.dims[n.n_layers], 4);
   ws->X[0] = p.take<float>((size_t)B * ws->ldx0);
   for (int l = 1; l < n.n_layers; ++l) ws->X[l] = p.take<float>((size_t)B * ws->width);
-  ws->dY0_stride = (long)B * ws->width;
+  // the dz1 partial buffers are read together (k_dw_adam sums them on load): an odd multiple
+  // of 4 KB + 256 B between them keeps the four loads of one element off the same HBM channel
+  ws->dY0_stride = (long)B * ws->width + 1088;
   for (int l = 0; l < n.n_layers - 1; ++l)
-    ws->dY[l] = p.take<float>((size_t)B * ws->width * (l == 0 ? kMaxCluster : 1));
+    ws->dY[l] = p.take<float>(l == 0 ? (size_t)ws->dY0_stride * kMaxCluster : (size_t)B * ws->width);
   ws->dY[n.n_layers - 1] = p.take<float>((size_t)B * ws->lddo);
 }
 
@@ -985,9 +989,9 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   h->bd = p.take<float>(B);
   h->bs2 = p.take<float>((size_t)B * S);
   std::vector<DwItem> items;
-  for (int j = 0; j < nc; ++j) fill_items(cfg->critics[j], h->ws_critic[j], items, &h->tiles_critic);
+  for (int j = 0; j < nc; ++j) fill_items(cfg->critics[j], h->ws_critic[j], items, &h->tiles_critic, h->fused);
   h->n_items_critic = (int)items.size();
-  fill_items(cfg->actor, h->ws_actor, items, &h->tiles_actor);
+  fill_items(cfg->actor, h->ws_actor, items, &h->tiles_actor, h->fused);
   h->n_items_actor = (int)items.size() - h->n_items_critic;
   h->items_host = items;
   std::vector<RepackItem> rp[3];
