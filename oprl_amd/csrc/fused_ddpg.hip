@@ -148,8 +148,10 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   const bool lead = tp.c == 0;                 // member 0 does the un-sliced global stores
   int n_stamp = 0;
   auto stamp = [&]() {
-    if (A.trace != nullptr && tid == 0 && lead && n_stamp < kTraceStamps) {
-      long long* tr = A.trace + (((size_t)role * 64 + slice) * kTraceStamps + n_stamp) * 2;
+    // wave 0 of every slice -> slot `slice`; the other 15 waves of slice 0 -> slots 16 + wave
+    if (A.trace != nullptr && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
+      const int slot = tid == 0 ? slice : 16 + (tid >> 6);
+      long long* tr = A.trace + (((size_t)role * 64 + slot) * kTraceStamps + n_stamp) * 2;
       tr[0] = (long long)__builtin_readcyclecounter();
       tr[1] = (long long)wall_clock64();
     }
@@ -318,8 +320,9 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   const bool lead = tp.c == 0;
   int n_stamp = 0;
   auto stamp = [&]() {
-    if (A.trace != nullptr && tid == 0 && lead && n_stamp < kTraceStamps) {
-      long long* tr = A.trace + ((size_t)slice * kTraceStamps + n_stamp) * 2;
+    if (A.trace != nullptr && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
+      const int slot = tid == 0 ? slice : 16 + (tid >> 6);
+      long long* tr = A.trace + ((size_t)slot * kTraceStamps + n_stamp) * 2;
       tr[0] = (long long)__builtin_readcyclecounter();
       tr[1] = (long long)wall_clock64();
     }

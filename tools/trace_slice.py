@@ -78,3 +78,15 @@ if fused:
             st_ = [(int(w), round((x[w, 0, 1] - t0) / 100, 2),
                     round((x[w][x[w][:, 1] != 0, 1].max() - t0) / 100, 2)) for w in ok]
             print(f"  {names[slot]}: (wg, start, end) {st_}")
+
+    if "--per-wave" in sys.argv:
+        # slice 0, all 16 waves (wave 0 = slot 0, wave w = slot 16 + w): time of every stamp, us from
+        # that role's first stamp
+        for slot in range(4):
+            x = tr[slot]
+            rows = [x[0]] + [x[16 + w] for w in range(1, 16)]
+            base = min(r[0, 1] for r in rows if r[0, 1] != 0)
+            n = int((x[0][:, 1] != 0).sum())
+            print(f"  {names[slot]} — slice 0, stamp times per wave (us):")
+            for w, r in enumerate(rows):
+                print(f"    wave {w:2d}: " + " ".join(f"{(r[k, 1] - base) / 100:6.2f}" if r[k, 1] != 0 else "   -  " for k in range(n)))
