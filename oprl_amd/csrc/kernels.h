@@ -109,6 +109,7 @@ struct DwArgs {                         // host-side description of one k_dw_ada
   AdamScalars ad;
   long long* trace;                    // debug stamps (tools/trace_slice.py) or null
   const float* row_scale; int row_scale_ld;   // per-row seed dLoss/dq for DwItem::scaled layers, or null
+  int apply_only;                      // 1: no GEMM — the gradient is read from w_g / b_g (data-parallel apply after the all-reduce)
 };
 
 // What the kernel receives: the layer table travels BY VALUE in the kernel arguments (read
@@ -126,6 +127,7 @@ struct DwKArgs {
   long long* trace;
   const float* row_scale; int row_scale_ld;
   const float* one;                    // device word holding 1.0f (row scale of unscaled layers)
+  int apply_only;
 };
 
 struct BatchSrc {

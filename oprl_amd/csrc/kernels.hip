@@ -364,7 +364,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
   const int xr = lane >> 3, xk = (lane & 7) * 4;      // X :  8 rows x 8 lanes x float4
   const bool an_ok = an < TNi && n_base + an < I.ldy;  // ldy, ldx are multiples of 4
   const bool xk_ok = k_base + xk < I.ldx;
-  for (int chunk = 0; chunk * 256 < A.B; ++chunk) {
+  for (int chunk = 0; chunk * 256 < (A.apply_only ? 0 : A.B); ++chunk) {
     const int base = chunk * 256 + 32 * wave;
     f32x4 va[2][4], vx[4];
     float rs[2];
@@ -438,10 +438,11 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
   float g = 0.f;
 #pragma unroll
   for (int w = 0; w < kDwWaves; ++w) g += part[w][nl][kl];
+  if (A.apply_only) g = e_ok ? I.w_g[eo] : 0.f;   // the (all-reduced) gradient instead of this rank's GEMM
   g *= A.ad.grad_scale;
   float th_new = 0.f, tt_new = 0.f;
   if (e_ok) {
-    if (I.w_g != nullptr) I.w_g[eo] = g;
+    if (I.w_g != nullptr && !A.apply_only) I.w_g[eo] = g;
     if (A.ad.do_adam) {
       float mm = p_m, vv = p_v, th = p_th;
       mm = mm + (g - mm) * A.ad.omb1;
@@ -496,10 +497,11 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
       float gb = 0.f;
 #pragma unroll
       for (int w = 0; w < kDwWaves; ++w) gb += bpart[w][tid];
+      if (A.apply_only) gb = I.b_g[n];
       float t0, t1;
       (void)adam_polyak_elem(gb, I.b + n, I.b_m ? I.b_m + n : nullptr, I.b_v ? I.b_v + n : nullptr,
-                             I.b_t ? I.b_t + n : nullptr, I.b_g ? I.b_g + n : nullptr, A.ad, step_size,
-                             bc2_sqrt, &t0, &t1);
+                             I.b_t ? I.b_t + n : nullptr, (I.b_g && !A.apply_only) ? I.b_g + n : nullptr,
+                             A.ad, step_size, bc2_sqrt, &t0, &t1);
     }
   }
   stamp();   // stores issued
@@ -686,6 +688,7 @@ hipError_t launch_dw_adam(const DwArgs& a, hipStream_t st) {
   for (int j = a.n_items; j < kDwMaxItems; ++j) { k.items[j] = a.items[0]; k.tile_end[j] = total; }
   k.n_items = a.n_items; k.B = a.B; k.n_part = a.n_part; k.ad = a.ad; k.trace = a.trace;
   k.row_scale = a.row_scale; k.row_scale_ld = a.row_scale_ld; k.one = one_dev;
+  k.apply_only = a.apply_only;
   hipLaunchKernelGGL(k_dw_adam, dim3(total), dim3(kDwThreads), 0, st, k);
   return hipGetLastError();
 }

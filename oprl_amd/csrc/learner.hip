@@ -502,7 +502,7 @@ int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st) {
   dw.B = B;
   dw.n_part = h->fused ? h->nc_cluster(B) : 1;
   dw.trace = (h->fused && h->trace != nullptr) ? h->trace + (size_t)(critic ? 4 : 5) * 64 * kTraceStamps * 2 : nullptr;
-  dw.row_scale = nullptr; dw.row_scale_ld = 0;
+  dw.row_scale = nullptr; dw.row_scale_ld = 0; dw.apply_only = 0;
   if (critic && h->fused && fused_ddpg_is_lean(ddpg_args(h, B))) {
     // the lean phase 1 left unit-seed dz rows (tp4_scalar_fb); the TD-error seed is dY of the output layer
     const NetWs& ws = h->ws_critic[0];
@@ -592,7 +592,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     h->opt_step_critic += 1;
     DwArgs dw;
     dw.items = h->items_host.data(); dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
-    dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.row_scale = nullptr; dw.row_scale_ld = 0;
+    dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.row_scale = nullptr; dw.row_scale_ld = 0; dw.apply_only = 0; dw.apply_only = 0;
     dw.ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, 1.0f);
     HIPC(launch_dw_prof(dw, st));
   }
@@ -691,7 +691,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     h->opt_step_actor += 1;
     DwArgs dw;
     dw.items = h->items_host.data() + h->n_items_critic; dw.n_items = h->n_items_actor;
-    dw.total_tiles = h->tiles_actor; dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.row_scale = nullptr; dw.row_scale_ld = 0;
+    dw.total_tiles = h->tiles_actor; dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.row_scale = nullptr; dw.row_scale_ld = 0; dw.apply_only = 0; dw.apply_only = 0;
     dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, c.actor.theta_target != nullptr, 1.0f);
     HIPC(launch_dw_prof(dw, st));
   }
@@ -849,12 +849,20 @@ extern "C" int oprl_learner_dp_step_n(oprl_learner* h, oprl_replay* replay, int3
     sc.n_transitions = n_tr;
     sc.seed = rseed;
     sc.gather = 1;
+    // as in oprl_learner_step_n: phase 2 of every update gathers the next update's rows
+    h->next_src = sc;
+    h->next_src.s = h->bs; h->next_src.a = h->ba; h->next_src.r = h->br; h->next_src.d = h->bd;
+    h->next_src.s2 = h->bs2;
     int rc = OPRL_OK;
     for (int k = 0; k < K && rc == OPRL_OK; ++k) {
       sc.counter = (unsigned long long)h->update_count;
+      h->next_src.counter = sc.counter + 1;
+      h->prefetch_next = (k + 1 < K) ? 1 : 0;
       rc = oprl_learner_dp_update(h, h->bs, h->ba, h->br, h->bd, h->bs2, B, nullptr, nullptr, stream);
+      sc.gather = 0;
     }
     sc.gather = 0;
+    h->prefetch_next = 0;
     return rc;
   }
   for (int k = 0; k < K; ++k) {
@@ -1111,23 +1119,26 @@ extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, double grad_sc
   if (phase == 0) {
     // update_count was not advanced yet for this update (phase 1 does that)
     const bool polyak = (c.algo == OPRL_TD3) ? (h->update_count % c.hp.policy_freq == 0) : true;
-    for (int j = 0; j < h->nc; ++j) {
-      const oprl_net& n = c.critics[j];
-      AdamScalars ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, (float)grad_scale);
-      ad.do_adam = 1;
-      HIPC(launch_adam_flat(n.theta, n.adam_m, n.adam_v, n.theta_target, n.grad, net_param_count(n), ad, st));
-    }
-    const int tbl = polyak ? 1 : 0;
-    HIPC(launch_repack(h->rp_dev[tbl], h->rp_n[tbl], h->rp_blocks[tbl], st));
+    // one launch: k_dw_adam's epilogue (Adam, Polyak, packs written in pack order) fed from the
+    // all-reduced gradient arena instead of the GEMM — replaces k_adam_flat + k_repack
+    DwArgs dw;
+    dw.items = h->items_host.data(); dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
+    dw.B = 0; dw.n_part = 1; dw.trace = nullptr; dw.row_scale = nullptr; dw.row_scale_ld = 0; dw.apply_only = 1;
+    dw.ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, (float)grad_scale);
+    dw.ad.do_adam = 1;
+    HIPC(launch_dw_prof(dw, st));
     return OPRL_OK;
   }
   if (phase == 1) {
     if (!h->actor_updated_last) return OPRL_OK;
     const oprl_net& n = c.actor;
-    AdamScalars ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, n.theta_target != nullptr, (float)grad_scale);
-    ad.do_adam = 1;
-    HIPC(launch_adam_flat(n.theta, n.adam_m, n.adam_v, n.theta_target, n.grad, net_param_count(n), ad, st));
-    HIPC(launch_repack(h->rp_dev[2], h->rp_n[2], h->rp_blocks[2], st));
+    DwArgs dw;
+    dw.items = h->items_host.data() + h->n_items_critic; dw.n_items = h->n_items_actor;
+    dw.total_tiles = h->tiles_actor;
+    dw.B = 0; dw.n_part = 1; dw.trace = nullptr; dw.row_scale = nullptr; dw.row_scale_ld = 0; dw.apply_only = 1;
+    dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, n.theta_target != nullptr, (float)grad_scale);
+    dw.ad.do_adam = 1;
+    HIPC(launch_dw_prof(dw, st));
     if (alpha_ptr(h) != nullptr)
       HIPC(launch_alpha_step(c.log_alpha, c.log_alpha_m, c.log_alpha_v, nullptr, 1, (float)c.hp.target_entropy,
                              c.hp.lr_alpha, c.hp.beta1, c.hp.beta2, c.hp.adam_eps, h->opt_step_alpha,
@@ -1307,7 +1318,7 @@ extern "C" int oprl_mlp_backward(const oprl_net* net, const float* x0, int32_t k
   if (dx && net->dims[0] > kNarrowMax) { set_err("oprl_mlp_backward: dx supported for input dim <= %d", kNarrowMax); return OPRL_ERR_INVALID; }
   RC(launch(a, width, st));
   DwArgs dw;
-  dw.items = items.data(); dw.n_items = (int)items.size(); dw.total_tiles = tiles; dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.row_scale = nullptr; dw.row_scale_ld = 0;
+  dw.items = items.data(); dw.n_items = (int)items.size(); dw.total_tiles = tiles; dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.row_scale = nullptr; dw.row_scale_ld = 0; dw.apply_only = 0; dw.apply_only = 0;
   memset(&dw.ad, 0, sizeof dw.ad);
   set_adam(dw.ad, 0.0, 0.9, 0.999, 1e-8, 0.0);
   set_step(dw.ad, 1); dw.ad.grad_scale = 1.0f; dw.ad.do_adam = 0;
