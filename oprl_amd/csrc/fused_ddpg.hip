@@ -354,6 +354,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
   // [s | pi] and the actor's forward activations (for its ReLU masks)
   lds_zero(xa, 2 * kR * kX0Ld);
+  if constexpr (LEAN) lds_zero(auxS, kR * kOutLd);   // the gradient tile's padding columns stay zero
   __syncthreads();
   load_rows(xa, kX0Ld, 0, A.aX[0], A.aldx0, S, row0, B);
   load_rows(xa, kX0Ld, S, A.pi, Ad, Ad, row0, B);
@@ -399,12 +400,22 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
     const float p = piS[r_ * kX0Ld + c_];
     du = auxS[r_ * kOutLd + c_] * (1.f - p * p);
   }
-  __syncthreads();
-  lds_zero(auxS, kR * kOutLd);
-  __syncthreads();
-  if (mine) auxS[r_ * kOutLd + c_] = du;
-  __syncthreads();
-  if (lead) store_rows(auxS, kOutLd, A.adY[2], A.alddo, Ad, row0, B);
+  if constexpr (LEAN) {
+    // in place: the padding columns were zeroed in the prologue and the lean passes write only
+    // the valid ones; the backward's first barrier publishes du, the dW input goes out from
+    // registers
+    if (mine) {
+      auxS[r_ * kOutLd + c_] = du;
+      if (lead && row0 + r_ < B) A.adY[2][(size_t)(row0 + r_) * A.alddo + c_] = du;
+    }
+  } else {
+    __syncthreads();
+    lds_zero(auxS, kR * kOutLd);
+    __syncthreads();
+    if (mine) auxS[r_ * kOutLd + c_] = du;
+    __syncthreads();
+    if (lead) store_rows(auxS, kOutLd, A.adY[2], A.alddo, Ad, row0, B);
+  }
   // ---- actor backward over its stored activations
   const Tp3Store sta{nullptr, nullptr, A.adY[1], A.adY[0], A.adY0_stride};
   tp_bwd<WIDTH, LEAN>(A.actor, auxS, ha1, ha2, scr, tp, sta, row0, B, 0, 0, auxS, stamp);
