@@ -366,7 +366,12 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   // columns: da -> auxS[:, 0:A].  The seed -1/B is a constant, so the lean path runs both
   // as one pass (tp4_scalar_fb) in which q — only logged — is off the critical path.
   if constexpr (LEAN) {
-    tp4_scalar_fb(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp);
+    float* qsum = nullptr;   // mean-q diagnostics: written by the q wave of the lead member
+    if (A.partials_a != nullptr && lead) {
+      qsum = A.partials_a + slice * 4 + 1;
+      if (tid == 0) { A.partials_a[slice * 4 + 0] = 0.f; A.partials_a[slice * 4 + 2] = 0.f; }
+    }
+    tp4_scalar_fb(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum);
   } else {
     tp_fwd<WIDTH, LEAN>(A.critic, xa, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
     stamp();
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
     __syncthreads();
     if (tid < kR && row0 + tid < B) auxS[tid * kOutLd] = -A.inv_B;
   }
-  if (A.partials_a != nullptr && lead) {
+  if (!LEAN && A.partials_a != nullptr && lead) {
     float v = (tid < kR && row0 + tid < B) ? outS[tid * kOutLd] : 0.f;
     __syncthreads();
 #pragma unroll

@@ -325,7 +325,10 @@ template <class ST = NoStamp>
 __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, float* h1, float* h2,
                                               float* g2, float* outS, float* scr, Tp& tp,
                                               const Tp3Store& st, int row0, int B, float seed,
-                                              int dact_col0, int dact_cols, float* dactS, ST sf = ST()) {
+                                              int dact_col0, int dact_cols, float* dactS, ST sf = ST(),
+                                              float* q_sum_out = nullptr) {
+  // q_sum_out (optional, one float): sum of q over the slice's valid rows, written by the wave
+  // that finishes the q all-reduce (diagnostics without a barrier on the main path)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
@@ -472,6 +475,14 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
     float* o = outS + (kk * 4) * kOutLd + i;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r * kOutLd] = valid ? sum[r] + bias12 : 0.f;
+    if (q_sum_out != nullptr) {
+      float qs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) qs += (valid && row0 + kk * 4 + r < B) ? sum[r] + bias12 : 0.f;
+      qs += __shfl_xor(qs, 16);
+      qs += __shfl_xor(qs, 32);
+      if (lane == 0) *q_sum_out = qs;
+    }
   }
   if (dact) {
     if (wave < NS0) {
