@@ -35,6 +35,7 @@ class TD3(OffPolicyAlgorithm):
     device: str = "cuda"
     max_batch: int = 4096
     export_grads: bool = False
+    no_fuse: bool = False     # True: the generic per-net launch sequence instead of the fused kernels
 
     actor: PolicyProtocol = field(init=False)
     actor_target: PolicyProtocol = field(init=False)
@@ -80,7 +81,7 @@ class TD3(OffPolicyAlgorithm):
             critic_group=self.critic, critic_mlps=[self.critic.q1, self.critic.q2],
             critic_target_group=self.critic_target,
             critic_target_mlps=[self.critic_target.q1, self.critic_target.q2],
-            hp=hp, max_batch=self.max_batch, export_grads=self.export_grads)
+            hp=hp, max_batch=self.max_batch, export_grads=self.export_grads, no_fuse=self.no_fuse)
         self._created = True
         return self
 

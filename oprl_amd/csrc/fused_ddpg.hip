@@ -123,92 +123,31 @@ __device__ __forceinline__ void load_batch(const BatchSrc& P, int row0, int B, i
   }
 }
 
-template <int WIDTH, bool LEAN>
-__global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int WIDTH, bool LEAN, class ST>
+__device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, float* const* cX, float* const* cdY,
+                                       float* partials, bool diag, float* smem, Tp& tp, ST& stamp) {
   using LY = FusedLds<WIDTH>;
   constexpr int WL = lds_ld(WIDTH);
   constexpr int HB = kR * WL;
   float* xa = smem + LY::xa;
-  float* xb = smem + LY::xb;
   float* h1 = smem + LY::h;
   float* h2 = h1 + HB;
   float* outS = smem + LY::out;
   float* auxS = smem + LY::aux;
   float* scr = smem + LY::scr;
-  float* rS = smem + LY::misc;
-  float* dS = rS + kR;
-  float* yS = dS + kR;
-  int* meta = reinterpret_cast<int*>(yS + kR);
-  int* endsS = reinterpret_cast<int*>(smem + LY::misc + 96);
+  float* yS = smem + LY::misc + 2 * kR;
   const int slice = blockIdx.x, row0 = slice * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
-  const int role = blockIdx.y / A.nc;          // 0 = A target chain, 1 = B critic, 2 = C actor forward
-  Tp tp{(int)blockIdx.y % A.nc, A.nc,
-        A.xbuf + ((size_t)role * gridDim.x + slice) * kTpStages * A.nc * kTpBlk, A.cluster_tag, 0};
-  const bool lead = tp.c == 0;                 // member 0 does the un-sliced global stores
-  int n_stamp = 0;
-  auto stamp = [&]() {
-    // wave 0 of every slice -> slot `slice`; the other 15 waves of slice 0 -> slots 16 + wave
-    if (A.trace != nullptr && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
-      const int slot = tid == 0 ? slice : 16 + (tid >> 6);
-      long long* tr = A.trace + (((size_t)role * 64 + slot) * kTraceStamps + n_stamp) * 2;
-      tr[0] = (long long)__builtin_readcyclecounter();
-      tr[1] = (long long)wall_clock64();
-    }
-    ++n_stamp;
-  };
-  stamp();   // entry
-  load_batch(A.src, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
-  stamp();   // batch rows requested
-  const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
-
-  if (role == 2) {
-    // ---- role C: actor(s) forward.  Pack rows beyond S are zero, so [s | a] serves as input.
-    const Tp3Store st{A.aX[1], A.aX[2], nullptr, nullptr, 0};
-    tp_fwd<WIDTH, LEAN>(A.actor, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
-    if (lead) {
-      for (int idx = tid; idx < kR * Ad; idx += kThreads) {
-        const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
-        if (gr < B) A.pi[(size_t)gr * Ad + col] = tanhf(outS[row * kOutLd + col]);
-      }
-      store_rows(xa, kX0Ld, A.aX[0], A.aldx0, S, row0, B);
-    }
-    stamp();
-    return;
-  }
-
-  if (role == 0) {
-    // ---- role A: a' = tanh(actor_target(s')), q' = critic_target(s', a'), TD target
-    tp_fwd<WIDTH, LEAN>(A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
-    for (int idx = tid; idx < kR * Ad; idx += kThreads) {
-      const int row = idx / Ad, col = idx - row * Ad;
-      xb[row * kX0Ld + S + col] = (row0 + row < B) ? tanhf(outS[row * kOutLd + col]) : 0.f;
-    }
-    // (the next GEMM's own barrier publishes xb)
-    tp_fwd<WIDTH, LEAN>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
-    if (lead && tid < kR && row0 + tid < B) {
-      const float y = rS[tid] + ((1.f - dS[tid]) * A.gamma) * outS[tid * kOutLd];
-      // hand-off to role B of this slice: ONE aligned 8-byte {epoch, value} granule per
-      // row, written through (agent-scope relaxed atomic = sc1 store); the tag makes the
-      // data its own flag, no fence needed (cdna guide, G16 R2).
-      const unsigned long long g = ((unsigned long long)A.epoch << 32) | (unsigned long long)__float_as_uint(y);
-      __hip_atomic_store(A.y_granules + row0 + tid, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    stamp();
-    return;
-  }
-
-  // ---- role B: q = critic(s, a) forward (runs while role A computes the target)
-  const Tp3Store st{A.cX[1], A.cX[2], A.cdY[1], A.cdY[0], A.cdY0_stride};
+  const bool lead = tp.c == 0;
+  const Tp3Store st{cX[1], cX[2], cdY[1], cdY[0], A.cdY0_stride};
   if constexpr (LEAN) {
     // ... and, the critic being scalar-output, its whole backward with unit seed as well:
     // k_dw_adam applies 2(q - y)/B per row (tp4_scalar_fb), so after y arrives only that
     // vector is left to publish
-    tp4_scalar_fb(A.critic, xa, h1, h2, h1 + 2 * HB, outS, scr, tp, st, row0, B, 1.f, 0, 0, nullptr, stamp);
+    tp4_scalar_fb(critic, xa, h1, h2, h1 + 2 * HB, outS, scr, tp, st, row0, B, 1.f, 0, 0, nullptr, stamp);
   } else {
-    tp_fwd<WIDTH, LEAN>(A.critic, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
+    tp_fwd<WIDTH, LEAN>(critic, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
   }
-  if (lead) store_rows(xa, kX0Ld, A.cX[0], A.cldx0, S + Ad, row0, B);
+  if (lead) store_rows(xa, kX0Ld, cX[0], A.cldx0, S + Ad, row0, B);
   if constexpr (LEAN) {
     // only the seed vector and the diagnostics are left: one wave of the lead member, no LDS
     if (!lead || tid >= 64) return;
@@ -226,18 +165,18 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
       }
       y = ok ? __uint_as_float((unsigned)g) : __builtin_nanf("");
       q = outS[tid * kOutLd];
-      A.cdY[2][(size_t)gr * A.clddo] = 2.f * (q - y) * A.inv_B;
-      if (A.y_out != nullptr) A.y_out[gr] = y;
-      if (A.q_out != nullptr) A.q_out[gr] = q;
+      cdY[2][(size_t)gr * A.clddo] = 2.f * (q - y) * A.inv_B;
+      if (diag && A.y_out != nullptr) A.y_out[gr] = y;
+      if (diag && A.q_out != nullptr) A.q_out[gr] = q;
     }
     stamp();   // TD target received, seed published
-    if (A.partials_c != nullptr) {
+    if (partials != nullptr) {
       float v[3] = {row_ok ? (q - y) * (q - y) : 0.f, row_ok ? q : 0.f, row_ok ? y : 0.f};
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) v[k] += __shfl_xor(v[k], m);
-        if (tid == 0) A.partials_c[slice * 4 + k] = v[k];
+        if (tid == 0) partials[slice * 4 + k] = v[k];
       }
     }
     stamp();
@@ -271,14 +210,14 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
     if (gr < B) {
       const float q = outS[tid * kOutLd], y = yS[tid];
       auxS[tid * kOutLd] = 2.f * (q - y) * A.inv_B;
-      if (lead && A.y_out != nullptr) A.y_out[gr] = y;
-      if (lead && A.q_out != nullptr) A.q_out[gr] = q;
+      if (lead && diag && A.y_out != nullptr) A.y_out[gr] = y;
+      if (lead && diag && A.q_out != nullptr) A.q_out[gr] = q;
       p_loss = (q - y) * (q - y);
       p_q = q;
       p_y = y;
     }
   }
-  if (A.partials_c != nullptr && lead) {
+  if (partials != nullptr && lead) {
     __syncthreads();
     float v[3] = {p_loss, p_q, p_y};
 #pragma unroll
@@ -291,15 +230,118 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
     if (tid < 3) {
       float sum = 0.f;
       for (int w = 0; w < kWaves; ++w) sum += scr[w * 4 + tid];
-      A.partials_c[slice * 4 + tid] = sum;
+      partials[slice * 4 + tid] = sum;
     }
   }
   __syncthreads();
-  if (lead) store_rows(auxS, kOutLd, A.cdY[2], A.clddo, 1, row0, B);
+  if (lead) store_rows(auxS, kOutLd, cdY[2], A.clddo, 1, row0, B);
   stamp();
-  if constexpr (!LEAN) tp_bwd<WIDTH, LEAN>(A.critic, auxS, h1, h2, scr, tp, st, row0, B, 0, 0, auxS, stamp);
+  if constexpr (!LEAN) tp_bwd<WIDTH, LEAN>(critic, auxS, h1, h2, scr, tp, st, row0, B, 0, 0, auxS, stamp);
 }
 
+template <int WIDTH, bool LEAN>
+__global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using LY = FusedLds<WIDTH>;
+  constexpr int WL = lds_ld(WIDTH);
+  constexpr int HB = kR * WL;
+  float* xa = smem + LY::xa;
+  float* xb = smem + LY::xb;
+  float* h1 = smem + LY::h;
+  float* h2 = h1 + HB;
+  float* outS = smem + LY::out;
+  float* auxS = smem + LY::aux;
+  float* scr = smem + LY::scr;
+  float* rS = smem + LY::misc;
+  float* dS = rS + kR;
+  float* yS = dS + kR;
+  int* meta = reinterpret_cast<int*>(yS + kR);
+  int* endsS = reinterpret_cast<int*>(smem + LY::misc + 96);
+  const int slice = blockIdx.x, row0 = slice * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
+  // roles: 0 = A target chain, 1 .. n_critics = B (one per online critic), last = C actor forward
+  const int role = blockIdx.y / A.nc;
+  const int role_c = 1 + A.n_critics;
+  Tp tp{(int)blockIdx.y % A.nc, A.nc,
+        A.xbuf + ((size_t)role * gridDim.x + slice) * kTpStages * A.nc * kTpBlk, A.cluster_tag, 0};
+  const bool lead = tp.c == 0;                 // member 0 does the un-sliced global stores
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    // wave 0 of every slice -> slot `slice`; the other 15 waves of slice 0 -> slots 16 + wave
+    if (A.trace != nullptr && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
+      const int slot = tid == 0 ? slice : 16 + (tid >> 6);
+      long long* tr = A.trace + (((size_t)role * 64 + slot) * kTraceStamps + n_stamp) * 2;
+      tr[0] = (long long)__builtin_readcyclecounter();
+      tr[1] = (long long)wall_clock64();
+    }
+    ++n_stamp;
+  };
+  stamp();   // entry
+  load_batch(A.src, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
+  stamp();   // batch rows requested
+  const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
+
+  if (role == role_c) {
+    if (!A.do_actor) return;   // TD3: no actor step in this update
+    // ---- role C: actor(s) forward.  Pack rows beyond S are zero, so [s | a] serves as input.
+    const Tp3Store st{A.aX[1], A.aX[2], nullptr, nullptr, 0};
+    tp_fwd<WIDTH, LEAN>(A.actor, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
+    if (lead) {
+      for (int idx = tid; idx < kR * Ad; idx += kThreads) {
+        const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
+        if (gr < B) A.pi[(size_t)gr * Ad + col] = tanhf(outS[row * kOutLd + col]);
+      }
+      store_rows(xa, kX0Ld, A.aX[0], A.aldx0, S, row0, B);
+    }
+    stamp();
+    return;
+  }
+
+  if (role == 0) {
+    // ---- role A: a' = tanh(actor_target(s')) (TD3: + clipped noise), q' = critic_target(s', a')
+    // (TD3: min over the twin targets), TD target                    (ddpg.py:94-95, td3.py:83-101)
+    tp_fwd<WIDTH, LEAN>(A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
+    for (int idx = tid; idx < kR * Ad; idx += kThreads) {
+      const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
+      float v = 0.f;
+      if (gr < B) {
+        v = tanhf(outS[row * kOutLd + col]);
+        if (A.smooth) {
+          const float e = A.noise != nullptr ? A.noise[(size_t)gr * Ad + col]
+                                             : philox_normal(A.rng_seed, A.rng_ctr, (unsigned)gr, (unsigned)col);
+          const float n = fminf(fmaxf(e * A.policy_noise, -A.noise_clip), A.noise_clip);
+          v = fminf(fmaxf(v + n, -A.max_action), A.max_action);
+        }
+      }
+      xb[row * kX0Ld + S + col] = v;
+    }
+    // (the next GEMM's own barrier publishes xb)
+    tp_fwd<WIDTH, LEAN>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
+    float qn = (tid < kR) ? outS[tid * kOutLd] : 0.f;
+    if (A.n_critics == 2) {
+      tp_fwd<WIDTH, LEAN>(A.critic2_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
+      if (tid < kR) qn = fminf(qn, outS[tid * kOutLd]);
+    }
+    if (lead && tid < kR && row0 + tid < B) {
+      const float y = rS[tid] + ((1.f - dS[tid]) * A.gamma) * qn;
+      // hand-off to the B roles of this slice: ONE aligned 8-byte {epoch, value} granule per
+      // row, written through (agent-scope relaxed atomic = sc1 store); the tag makes the
+      // data its own flag, no fence needed (cdna guide, G16 R2).
+      const unsigned long long g = ((unsigned long long)A.epoch << 32) | (unsigned long long)__float_as_uint(y);
+      __hip_atomic_store(A.y_granules + row0 + tid, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    stamp();
+    return;
+  }
+
+  // ---- role B: q = critic_j(s, a) forward (runs while role A computes the target).  The twin
+  // critic gets its own copy of the code (a runtime-selected Net would leave the kernel-argument
+  // registers: profiles/r01b_experiments.txt #10).
+  const bool second = role == 2;
+  if (second) { role_b<WIDTH, LEAN>(A, A.critic2, A.c2X, A.c2dY, A.partials_c + (size_t)gridDim.x * 4, false, smem, tp, stamp); return; }
+  role_b<WIDTH, LEAN>(A, A.critic, A.cX, A.cdY, A.partials_c, true, smem, tp, stamp);
+}
+
+// Role B of phase 1 for one online critic (layer inputs X[], pre-activation grads dY[]).
 template <int WIDTH, bool LEAN>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -445,6 +487,8 @@ hipError_t init_fused_attrs() {
 // the lean tp4 passes serve clusters of 4 whose four nets fit tp4_shape_ok
 bool fused_ddpg_is_lean(const DdpgArgs& a);
 static bool lean_ok(const DdpgArgs& a) { return fused_ddpg_is_lean(a); }
+// (the twin-critic variant, TD3, exists in the lean form only: learner.hip falls back to the
+// generic launch sequence when this returns false)
 bool fused_ddpg_is_lean(const DdpgArgs& a) {
   return a.nc == 4 && !a.no_lean && tp4_shape_ok(256, a.S + a.A, 1) && tp4_shape_ok(256, a.S, a.A);
 }
@@ -452,9 +496,9 @@ bool fused_ddpg_is_lean(const DdpgArgs& a) {
 hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
   if (lean_ok(a))
-    hipLaunchKernelGGL((k_ddpg_phase1<256, true>), dim3(slices, 3 * a.nc), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+    hipLaunchKernelGGL((k_ddpg_phase1<256, true>), dim3(slices, (2 + a.n_critics) * a.nc), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
   else
-    hipLaunchKernelGGL((k_ddpg_phase1<256, false>), dim3(slices, 3 * a.nc), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+    hipLaunchKernelGGL((k_ddpg_phase1<256, false>), dim3(slices, (2 + a.n_critics) * a.nc), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
   return hipGetLastError();
 }
 

@@ -80,7 +80,8 @@ struct DwItem {      // one Linear layer of one net
   int tiles_k, tile_begin, tile_end;
   int tile_n;                          // n rows per tile: kDwTileN, or 8 for a layer that sums dz1 partials
   long dY_part_stride;                 // > 0: dY is the sum of DwArgs::n_part buffers this many floats apart
-  int scaled;                          // 1: dY rows are unit-seed (tp4_scalar_fb): multiply row b by DwArgs::row_scale[b]
+  int scaled;                          // 1: dY rows may be unit-seed (tp4_scalar_fb): with DwArgs::use_row_scale multiply row b by rs[b * rs_ld]
+  const float* rs; int rs_ld;          // the net's per-row seed dLoss/dq = dY of its output layer
 };
 
 struct RepackItem {  // one Linear layer: master -> packs
@@ -108,7 +109,7 @@ struct DwArgs {                         // host-side description of one k_dw_ada
   int n_part;                          // members of the tensor-parallel cluster that wrote dz1 partials
   AdamScalars ad;
   long long* trace;                    // debug stamps (tools/trace_slice.py) or null
-  const float* row_scale; int row_scale_ld;   // per-row seed dLoss/dq for DwItem::scaled layers, or null
+  int use_row_scale;                   // 1: the slice kernels left unit-seed dz rows (lean fused path)
   int apply_only;                      // 1: no GEMM — the gradient is read from w_g / b_g (data-parallel apply after the all-reduce)
 };
 
@@ -125,7 +126,7 @@ struct DwKArgs {
   int n_items, B, n_part;
   AdamScalars ad;
   long long* trace;
-  const float* row_scale; int row_scale_ld;
+  int use_row_scale;
   const float* one;                    // device word holding 1.0f (row scale of unscaled layers)
   int apply_only;
 };
@@ -142,8 +143,19 @@ struct BatchSrc {
   unsigned long long seed, counter;
 };
 
-struct DdpgArgs {
+struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   Net actor, actor_t, critic, critic_t;
+  // TD3 (n_critics == 2): the twin critic, its exchange buffers, target-policy smoothing
+  // (td3.py:83-93) and whether this update also steps the actor (policy_freq)
+  Net critic2, critic2_t;
+  int n_critics;                       // 1 (DDPG) or 2 (TD3)
+  int do_actor;                        // 0: role C (actor forward) has nothing to do in this update
+  int smooth;                          // 1: a' = clip(tanh(mu) + clip(sigma * N(0,1), +-c), +-max_action)
+  float policy_noise, noise_clip, max_action;
+  const float* noise;                  // injected N(0,1) draws [B][A], or null: Philox(rng_seed, rng_ctr)
+  unsigned long long rng_seed, rng_ctr;
+  float* c2X[kMaxLayers];              // critic 2 layer inputs / pre-activation grads (ld as critic 1)
+  float* c2dY[kMaxLayers];
   int B, S, A;
   BatchSrc src;
   // step_n: phase 2 carries one extra row of workgroups that gathers the NEXT update's

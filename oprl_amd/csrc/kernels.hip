@@ -357,9 +357,9 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
   float sA = 0.f;
   // per-row seed of unit-seed layers, or the constant 1 (stride 0): always a load, no branch
   // between the row requests
-  const bool scaled = I.scaled != 0 && A.row_scale != nullptr;
-  const float* rsp = scaled ? A.row_scale : A.one;
-  const size_t rs_ld = scaled ? (size_t)A.row_scale_ld : 0;
+  const bool scaled = I.scaled != 0 && A.use_row_scale != 0;
+  const float* rsp = scaled ? I.rs : A.one;
+  const size_t rs_ld = scaled ? (size_t)I.rs_ld : 0;
   const int ar = lane >> 2, an = (lane & 3) * 4;      // dY: 16 rows x 4 lanes x float4
   const int xr = lane >> 3, xk = (lane & 7) * 4;      // X :  8 rows x 8 lanes x float4
   const bool an_ok = an < TNi && n_base + an < I.ldy;  // ldy, ldx are multiples of 4
@@ -687,7 +687,7 @@ hipError_t launch_dw_adam(const DwArgs& a, hipStream_t st) {
   }
   for (int j = a.n_items; j < kDwMaxItems; ++j) { k.items[j] = a.items[0]; k.tile_end[j] = total; }
   k.n_items = a.n_items; k.B = a.B; k.n_part = a.n_part; k.ad = a.ad; k.trace = a.trace;
-  k.row_scale = a.row_scale; k.row_scale_ld = a.row_scale_ld; k.one = one_dev;
+  k.use_row_scale = a.use_row_scale; k.one = one_dev;
   k.apply_only = a.apply_only;
   hipLaunchKernelGGL(k_dw_adam, dim3(total), dim3(kDwThreads), 0, st, k);
   return hipGetLastError();

@@ -272,7 +272,8 @@ struct oprl_learner {
   hipStream_t side[OPRL_MAX_CRITICS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[OPRL_MAX_CRITICS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool have_side = false;
-  bool fused = false;          // DDPG two-kernel path
+  bool fused = false;          // DDPG / TD3 two-kernel path (csrc/fused_ddpg.hip) is built for this learner
+  bool staged_ready = false;   // step_n: the staging batch holds the next update's rows (written by phase 2)
   unsigned long long* y_granules = nullptr;   // [Bmax] TD-target hand-off (fused DDPG)
   unsigned epoch = 0;          // monotonically increasing, never reset
   int ncl = 1;                 // CUs per slice cluster in the fused path (csrc/tp3.h)
@@ -280,11 +281,13 @@ struct oprl_learner {
   int no_lean = 0;
   unsigned long long* xbuf = nullptr;
   size_t xbuf_granules = 0;
-  // largest cluster whose phase-1 grid (3 roles) is fully co-resident, one workgroup per CU
+  // largest cluster whose phase-1 grid (roles A, one B per critic, C) is fully co-resident, one
+  // workgroup per CU
   int nc_cluster(int B) const {
     const int slices = (B + kR - 1) / kR;
+    const int roles = 2 + nc;
     int c = ncl;
-    while (c > 1 && 3 * c * slices > n_cus) c >>= 1;
+    while (c > 1 && roles * c * slices > n_cus) c >>= 1;
     return c;
   }
   BatchSrc src;                // where the current update's minibatch comes from
@@ -319,6 +322,8 @@ void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int*
     it.tpf = n.pack_target ? n.pack_target + pack_off_fwd(n, l) : nullptr;
     it.dY_part_stride = (l == 0 && n.n_layers > 1) ? ws.dY0_stride : 0;
     it.scaled = (l < n.n_layers - 1) ? 1 : 0;
+    it.rs = ws.dY[n.n_layers - 1];
+    it.rs_ld = ws.lddo;
     // (8-row tiles for this layer were measured: no difference — profiles/r01b_experiments.txt)
     it.tile_n = kDwTileN;
     const int tn = (it.N + it.tile_n - 1) / it.tile_n;
@@ -451,7 +456,9 @@ void seed_rng(MlpArgs& a, const oprl_learner* h, const float* noise, uint64_t st
   a.rng_ctr = (unsigned long long)h->update_count;
 }
 
-// ------------------------------------------------------------ fused DDPG
+// ------------------------------------------------------------ fused DDPG / TD3
+bool actor_due(const oprl_learner* h);
+
 DdpgArgs ddpg_args(oprl_learner* h, int B) {
   const oprl_learner_config& c = h->cfg;
   DdpgArgs a;
@@ -460,6 +467,20 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   a.actor_t = net_view(c.actor, true);
   a.critic = net_view(c.critics[0], false);
   a.critic_t = net_view(c.critics[0], true);
+  a.n_critics = h->nc;
+  a.do_actor = 1;
+  if (h->nc == 2) {      // TD3: twin critic, target-policy smoothing (td3.py:83-93)
+    a.critic2 = net_view(c.critics[1], false);
+    a.critic2_t = net_view(c.critics[1], true);
+    for (int l = 0; l < kMaxLayers; ++l) { a.c2X[l] = h->ws_critic[1].X[l]; a.c2dY[l] = h->ws_critic[1].dY[l]; }
+    a.smooth = 1;
+    a.policy_noise = (float)c.hp.policy_noise;
+    a.noise_clip = (float)c.hp.noise_clip;
+    a.max_action = (float)c.hp.max_action;
+    a.rng_seed = 0x0b5e55edULL + 1;                       // the streams seed_rng() gives the generic path
+    a.rng_ctr = (unsigned long long)h->update_count;
+    a.do_actor = actor_due(h) ? 1 : 0;
+  }
   a.B = B; a.S = h->S; a.A = h->A;
   a.src = h->src;
   a.next = h->next_src;
@@ -486,6 +507,14 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   return a;
 }
 
+// DDPG runs fused for every batch size (generic tp3.h passes when the lean ones do not fit);
+// TD3's fused kernels exist in the lean form only, otherwise the generic launch sequence is used
+bool use_fused(oprl_learner* h, int B) {
+  if (!h->fused) return false;
+  if (h->cfg.algo == OPRL_DDPG) return true;
+  return fused_ddpg_is_lean(ddpg_args(h, B));
+}
+
 int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st) {
   const oprl_learner_config& c = h->cfg;
   DwArgs dw;
@@ -500,15 +529,13 @@ int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st) {
     dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, polyak, 1.0f);
   }
   dw.B = B;
-  dw.n_part = h->fused ? h->nc_cluster(B) : 1;
-  dw.trace = (h->fused && h->trace != nullptr) ? h->trace + (size_t)(critic ? 4 : 5) * 64 * kTraceStamps * 2 : nullptr;
-  dw.row_scale = nullptr; dw.row_scale_ld = 0; dw.apply_only = 0;
-  if (critic && h->fused && fused_ddpg_is_lean(ddpg_args(h, B))) {
-    // the lean phase 1 left unit-seed dz rows (tp4_scalar_fb); the TD-error seed is dY of the output layer
-    const NetWs& ws = h->ws_critic[0];
-    dw.row_scale = ws.dY[c.critics[0].n_layers - 1];
-    dw.row_scale_ld = ws.lddo;
-  }
+  const bool fused = use_fused(h, B);
+  dw.n_part = fused ? h->nc_cluster(B) : 1;
+  dw.trace = (fused && h->trace != nullptr) ? h->trace + (size_t)(critic ? 4 : 5) * 64 * kTraceStamps * 2 : nullptr;
+  dw.apply_only = 0;
+  // the lean phase 1 leaves unit-seed dz rows (tp4_scalar_fb): each critic's TD-error seed, dY of
+  // its output layer, is applied per row (DwItem::rs)
+  dw.use_row_scale = (critic && fused && fused_ddpg_is_lean(ddpg_args(h, B))) ? 1 : 0;
   HIPC(launch_dw_prof(dw, st));
   return OPRL_OK;
 }
@@ -517,7 +544,7 @@ int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st) {
 int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r, const float* d,
                  const float* s2, int B, const float* noise0, hipStream_t st) {
   const oprl_learner_config& c = h->cfg;
-  if (h->fused) {
+  if (use_fused(h, B)) {
     h->epoch += 1;
     if ((h->epoch & 0x00FFFFFFu) == 0) {   // exchange tags about to wrap: retire every stale granule
       if (h->epoch == 0) h->epoch = 1;
@@ -525,13 +552,15 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
       HIPC(hipMemsetAsync(h->y_granules, 0, (size_t)h->Bmax * sizeof(unsigned long long), st));
     }
     DdpgArgs fa = ddpg_args(h, B);
+    fa.noise = noise0;
     fa.cluster_tag = (h->epoch << 1) & 0x03FFFFFFu;
-    if (h->trace != nullptr) fa.trace = h->trace;   // roles use slots 0,1,2
+    if (h->trace != nullptr && c.algo == OPRL_DDPG) fa.trace = h->trace;   // roles use slots 0,1,2
     prof_begin(4, st);
     hipError_t e = launch_ddpg_phase1(fa, st);
     prof_end(st);
     HIPC(e);
-    return dw_step(h, true, B, true, st);
+    // TD3 moves its targets only on actor steps (td3.py:135-146)
+    return dw_step(h, true, B, c.algo == OPRL_TD3 ? actor_due(h) : true, st);
   }
   const int S = h->S, A = h->A, nc = h->nc;
   const int algo = c.algo;
@@ -592,7 +621,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     h->opt_step_critic += 1;
     DwArgs dw;
     dw.items = h->items_host.data(); dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
-    dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.row_scale = nullptr; dw.row_scale_ld = 0; dw.apply_only = 0; dw.apply_only = 0;
+    dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.use_row_scale = 0; dw.apply_only = 0; dw.apply_only = 0;
     dw.ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, 1.0f);
     HIPC(launch_dw_prof(dw, st));
   }
@@ -602,11 +631,12 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
 // ------------------------------------------------------------- actor phase
 int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hipStream_t st) {
   const oprl_learner_config& c = h->cfg;
-  if (h->fused) {
+  if (use_fused(h, B)) {
     DdpgArgs fa = ddpg_args(h, B);
     fa.cluster_tag = ((h->epoch << 1) | 1u) & 0x03FFFFFFu;
-    if (h->trace != nullptr) fa.trace = h->trace + (size_t)3 * 64 * kTraceStamps * 2;   // slot 3
+    if (h->trace != nullptr && c.algo == OPRL_DDPG) fa.trace = h->trace + (size_t)3 * 64 * kTraceStamps * 2;   // slot 3
     fa.prefetch_next = h->prefetch_next;
+    if (h->prefetch_next) h->staged_ready = true;
     prof_begin(5, st);
     hipError_t e = launch_ddpg_phase2(fa, st);
     prof_end(st);
@@ -691,7 +721,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     h->opt_step_actor += 1;
     DwArgs dw;
     dw.items = h->items_host.data() + h->n_items_critic; dw.n_items = h->n_items_actor;
-    dw.total_tiles = h->tiles_actor; dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.row_scale = nullptr; dw.row_scale_ld = 0; dw.apply_only = 0; dw.apply_only = 0;
+    dw.total_tiles = h->tiles_actor; dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.use_row_scale = 0; dw.apply_only = 0; dw.apply_only = 0;
     dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, c.actor.theta_target != nullptr, 1.0f);
     HIPC(launch_dw_prof(dw, st));
   }
@@ -840,7 +870,7 @@ extern "C" int oprl_learner_dp_step_n(oprl_learner* h, oprl_replay* replay, int3
   if (K < 0 || B < 1 || B > h->Bmax) { set_err("dp_step_n: bad K/B"); return OPRL_ERR_INVALID; }
   // every rank samples its own shard: the Philox key mixes the rank in
   const uint64_t rseed = seed * 0x9E3779B97F4A7C15ull + (uint64_t)h->rccl.rank;
-  if (h->fused) {
+  if (use_fused(h, B)) {
     BatchSrc& sc = h->src;
     RC(oprl_replay_flush(replay, stream));
     long n_tr = 0;
@@ -858,11 +888,13 @@ extern "C" int oprl_learner_dp_step_n(oprl_learner* h, oprl_replay* replay, int3
       sc.counter = (unsigned long long)h->update_count;
       h->next_src.counter = sc.counter + 1;
       h->prefetch_next = (k + 1 < K) ? 1 : 0;
+      sc.gather = h->staged_ready ? 0 : 1;
+      h->staged_ready = false;
       rc = oprl_learner_dp_update(h, h->bs, h->ba, h->br, h->bd, h->bs2, B, nullptr, nullptr, stream);
-      sc.gather = 0;
     }
     sc.gather = 0;
     h->prefetch_next = 0;
+    h->staged_ready = false;
     return rc;
   }
   for (int k = 0; k < K; ++k) {
@@ -953,8 +985,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
            hipEventCreateWithFlags(&h->ev_join[j], hipEventDisableTiming) == hipSuccess;
     h->have_side = ok;
   }
-  h->fused = cfg->algo == OPRL_DDPG && !cfg->no_fuse && h->w_actor == 256 && h->w_critic == 256 &&
-             cfg->actor.n_layers == 3 && cfg->critics[0].n_layers == 3;
+  h->fused = (cfg->algo == OPRL_DDPG || cfg->algo == OPRL_TD3) && !cfg->no_fuse && h->w_actor == 256 &&
+             h->w_critic == 256 && cfg->actor.n_layers == 3 && cfg->critics[0].n_layers == 3;
 
   const int B = h->Bmax, S = h->S, A = h->A, nc = h->nc;
   // scalar critics: q' is read with stride 1 by the TD seed; TQC: [B][ldq] quantile rows
@@ -1029,7 +1061,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     const char* nl = getenv("OPRL_AMD_NO_LEAN");
     h->no_lean = (nl != nullptr && atoi(nl) != 0) ? 1 : 0;
     const size_t slices = (size_t)(h->Bmax + kR - 1) / kR;
-    h->xbuf_granules = 3 * slices * fused_xbuf_granules_per_cluster(kMaxCluster);
+    h->xbuf_granules = (size_t)(2 + nc) * slices * fused_xbuf_granules_per_cluster(kMaxCluster);
     if (hipMalloc(&h->xbuf, h->xbuf_granules * sizeof(unsigned long long)) != hipSuccess) {
       set_err("hipMalloc(cluster exchange area, %zu MB) failed", (h->xbuf_granules * 8) >> 20);
       (void)hipFree(p.base); delete h; return OPRL_ERR_NOMEM;
@@ -1123,7 +1155,7 @@ extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, double grad_sc
     // all-reduced gradient arena instead of the GEMM — replaces k_adam_flat + k_repack
     DwArgs dw;
     dw.items = h->items_host.data(); dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
-    dw.B = 0; dw.n_part = 1; dw.trace = nullptr; dw.row_scale = nullptr; dw.row_scale_ld = 0; dw.apply_only = 1;
+    dw.B = 0; dw.n_part = 1; dw.trace = nullptr; dw.use_row_scale = 0; dw.apply_only = 1;
     dw.ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, (float)grad_scale);
     dw.ad.do_adam = 1;
     HIPC(launch_dw_prof(dw, st));
@@ -1135,7 +1167,7 @@ extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, double grad_sc
     DwArgs dw;
     dw.items = h->items_host.data() + h->n_items_critic; dw.n_items = h->n_items_actor;
     dw.total_tiles = h->tiles_actor;
-    dw.B = 0; dw.n_part = 1; dw.trace = nullptr; dw.row_scale = nullptr; dw.row_scale_ld = 0; dw.apply_only = 1;
+    dw.B = 0; dw.n_part = 1; dw.trace = nullptr; dw.use_row_scale = 0; dw.apply_only = 1;
     dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, n.theta_target != nullptr, (float)grad_scale);
     dw.ad.do_adam = 1;
     HIPC(launch_dw_prof(dw, st));
@@ -1157,7 +1189,7 @@ extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t
   replay_dims(replay, &S, &A);
   if (S != h->S || A != h->A) { set_err("replay dims (%d,%d) != learner dims (%d,%d)", S, A, h->S, h->A); return OPRL_ERR_INVALID; }
   if (K < 0 || B < 1 || B > h->Bmax) { set_err("step_n: bad K/B"); return OPRL_ERR_INVALID; }
-  if (h->fused) {
+  if (use_fused(h, B)) {
     // the slice kernels gather their own rows (same Philox draw / index map as k_replay_gather)
     BatchSrc& sc = h->src;
     RC(oprl_replay_flush(replay, stream));
@@ -1173,15 +1205,20 @@ extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t
     h->next_src.s = h->bs; h->next_src.a = h->ba; h->next_src.r = h->br; h->next_src.d = h->bd;
     h->next_src.s2 = h->bs2;
     int rc = OPRL_OK;
+    h->staged_ready = false;
     for (int k = 0; k < K && rc == OPRL_OK; ++k) {
       sc.counter = (unsigned long long)h->update_count;
       h->next_src.counter = sc.counter + 1;
       h->prefetch_next = (k + 1 < K) ? 1 : 0;
+      // rows staged by the previous update's phase 2 (it does not run on TD3's critic-only
+      // steps), else the slice kernels gather their own
+      sc.gather = h->staged_ready ? 0 : 1;
+      h->staged_ready = false;
       rc = oprl_learner_update(h, h->bs, h->ba, h->br, h->bd, h->bs2, B, nullptr, nullptr, stream);
-      sc.gather = 0;     // from the second update on the rows are staged
     }
     sc.gather = 0;
     h->prefetch_next = 0;
+    h->staged_ready = false;
     return rc;
   }
   for (int k = 0; k < K; ++k) {
@@ -1318,7 +1355,7 @@ extern "C" int oprl_mlp_backward(const oprl_net* net, const float* x0, int32_t k
   if (dx && net->dims[0] > kNarrowMax) { set_err("oprl_mlp_backward: dx supported for input dim <= %d", kNarrowMax); return OPRL_ERR_INVALID; }
   RC(launch(a, width, st));
   DwArgs dw;
-  dw.items = items.data(); dw.n_items = (int)items.size(); dw.total_tiles = tiles; dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.row_scale = nullptr; dw.row_scale_ld = 0; dw.apply_only = 0; dw.apply_only = 0;
+  dw.items = items.data(); dw.n_items = (int)items.size(); dw.total_tiles = tiles; dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.use_row_scale = 0; dw.apply_only = 0; dw.apply_only = 0;
   memset(&dw.ad, 0, sizeof dw.ad);
   set_adam(dw.ad, 0.0, 0.9, 0.999, 1e-8, 0.0);
   set_step(dw.ad, 1); dw.ad.grad_scale = 1.0f; dw.ad.do_adam = 0;

@@ -60,3 +60,72 @@ def test_fused_step_n_equals_generic_step_n():
     t.cuda.synchronize()
     for m in ("actor", "critic", "actor_target", "critic_target"):
         assert _close(getattr(fused, m)._oprl_arena, getattr(generic, m)._oprl_arena, 1e-4), m
+
+
+# ---- TD3: the same two kernels with twin critics (roles A | B1 | B2 | C) -------------------------
+def _td3(state_dim=17, **kw):
+    from oprl_amd.algos.td3 import TD3
+    from oprl_amd.logging import NullLogger
+    t.manual_seed(0)
+    return TD3(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=state_dim, action_dim=6, device="cuda", **kw).create()
+
+
+@pytest.mark.parametrize("inject", [True, False])
+def test_fused_td3_equals_generic(inject):
+    """6 updates = 3 critic-only + 3 actor steps (policy_freq 2); target-policy smoothing noise
+    injected (as the golden tests do) or drawn on device (same Philox stream in both paths)."""
+    fused, generic = _td3(), _td3(no_fuse=True)
+    for step in range(6):
+        batch = [x.cuda() for x in fx.make_batch(90 + step, 256, 17, 6)]
+        noise = fx.make_noise(190 + step, (256, 6)).cuda() if inject else None
+        fused.update(*batch, noise=noise)
+        generic.update(*batch, noise=noise)
+    t.cuda.synchronize()
+    assert t.isfinite(fused.actor._oprl_arena).all() and t.isfinite(fused.critic._oprl_arena).all()
+    for m in ("actor", "critic", "actor_target", "critic_target"):
+        assert _close(getattr(fused, m)._oprl_arena, getattr(generic, m)._oprl_arena, 1e-4), m
+    q_f, y_f = fused.learner.debug_q_y(256)
+    q_g, y_g = generic.learner.debug_q_y(256)
+    assert _close(q_f, q_g, 2e-5) and _close(y_f, y_g, 2e-5)
+    sf, sg = fused.learner.read_scalars(), generic.learner.read_scalars()
+    for k in ("critic_loss", "q_mean", "q_target_mean"):
+        assert abs(sf[k] - sg[k]) <= 1e-4 * max(abs(sg[k]), 1e-6), k
+
+
+def test_fused_td3_falls_back_without_lean_passes(monkeypatch):
+    """TD3's fused kernels exist in the lean (tp4.h) form only: with the lean passes switched off the
+    learner must run the generic launch sequence, i.e. be bit-identical to a no_fuse learner."""
+    monkeypatch.setenv("OPRL_AMD_NO_LEAN", "1")
+    fused, generic = _td3(), _td3(no_fuse=True)
+    for step in range(2):
+        batch = [x.cuda() for x in fx.make_batch(95 + step, 256, 17, 6)]
+        noise = fx.make_noise(195 + step, (256, 6)).cuda()
+        fused.update(*batch, noise=noise)
+        generic.update(*batch, noise=noise)
+    t.cuda.synchronize()
+    for m in ("actor", "critic"):
+        assert t.equal(getattr(fused, m)._oprl_arena, getattr(generic, m)._oprl_arena), m
+
+
+@pytest.mark.parametrize("B", [100, 8])
+def test_fused_td3_ragged_batches(B):
+    fused, generic = _td3(), _td3(no_fuse=True)
+    for step in range(4):
+        batch = [x.cuda() for x in fx.make_batch(97 + step, B, 17, 6)]
+        noise = fx.make_noise(197 + step, (B, 6)).cuda()
+        fused.update(*batch, noise=noise)
+        generic.update(*batch, noise=noise)
+    t.cuda.synchronize()
+    for m in ("actor", "critic", "actor_target", "critic_target"):
+        assert _close(getattr(fused, m)._oprl_arena, getattr(generic, m)._oprl_arena, 1e-4), m
+
+
+def test_fused_td3_step_n_equals_generic_step_n():
+    from tests.test_gpu_callers import _filled_buffer
+    fused, generic = _td3(24, max_batch=256), _td3(24, max_batch=256, no_fuse=True)
+    buf = _filled_buffer()
+    fused.learner.step_n(buf.handle, 6, 256, seed=11)
+    generic.learner.step_n(buf.handle, 6, 256, seed=11)
+    t.cuda.synchronize()
+    for m in ("actor", "critic", "actor_target", "critic_target"):
+        assert _close(getattr(fused, m)._oprl_arena, getattr(generic, m)._oprl_arena, 1e-4), m

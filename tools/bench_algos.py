@@ -1,6 +1,8 @@
 """update() throughput of all four algorithms at the BASELINE.json configs
 (parity-test cases 2-4 + DDPG), fixed synthetic minibatch resident in HBM, noise
-drawn on device.  Not the headline bench (bench.py); numbers for DESIGN.md."""
+drawn on device — one Python call per update, so the fast paths are bound by the
+call rate — and, second column, oprl_learner_step_n (sampling from an HBM replay +
+update, K steps per call).  Not the headline bench (bench.py); numbers for DESIGN.md."""
 import sys
 import time
 from pathlib import Path
@@ -32,4 +34,24 @@ for name, cls, S, A, B, kw in CASES:
         L.update(*batch)
     t.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"{name:26s} {n / dt:9.1f} updates/s  {dt / n * 1e6:8.1f} us/update", flush=True)
+    # step_n: device-side sampling from a replay of the same dims
+    from oprl_amd.buffers.episodic_buffer import EpisodicReplayBuffer
+    E, LEN = 200, 1000
+    buf = EpisodicReplayBuffer(buffer_size_transitions=E * LEN, state_dim=S, action_dim=A, device="cuda", seed=0).create()
+    g = t.Generator(device="cuda").manual_seed(5)
+    buf._tensors["states"].copy_(t.randn((E, LEN + 1, S), device="cuda", generator=g))
+    buf._tensors["actions"].copy_(t.rand((E, LEN, A), device="cuda", generator=g) * 2 - 1)
+    buf._tensors["rewards"].copy_(t.rand((E, LEN, 1), device="cuda", generator=g))
+    buf._tensors["dones"].zero_()
+    buf.ep_lens = [LEN] * E
+    buf.episodes_counter = E
+    buf._number_transitions = E * LEN
+    buf._lens_dirty = True
+    L.step_n(buf.handle, 100, B, seed=1)
+    t.cuda.synchronize()
+    t0 = time.perf_counter()
+    L.step_n(buf.handle, n, B, seed=2)
+    t.cuda.synchronize()
+    dt2 = time.perf_counter() - t0
+    print(f"{name:26s} update(): {n / dt:9.1f}/s {dt / n * 1e6:7.1f} us   step_n: {n / dt2:9.1f}/s {dt2 / n * 1e6:7.1f} us", flush=True)
+    del buf
