@@ -122,6 +122,10 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{p} not found: the MI355X HIP extension is not built. Run "
             "`python -m oprl_amd.build` (needs hipcc). There is no CPU fallback.")
+    # torch first: the process must run on ONE HIP runtime, the one torch bundles (device
+    # memory and streams are torch's).  Loading this library before torch pulled in
+    # /opt/rocm's libamdhip64 as well, and kernels then failed with "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = C.CDLL(str(p))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
