@@ -153,6 +153,14 @@ int oprl_learner_read_scalars(oprl_learner* h, float* out_host, int32_t n, void*
 int oprl_learner_sync_params(oprl_learner* h, void* stream);
 int oprl_learner_update_count(oprl_learner* h, int64_t* out_host);
 int oprl_learner_set_update_count(oprl_learner* h, int64_t count);
+/* Checkpoint / exact resume (reference: base_trainer.py:113-120 saves only the policy).  The
+ * learner's host-side state beyond the caller-owned arenas: {update_count, Adam step of the
+ * critics, of the actor, of log_alpha}.  Restoring the arenas (theta, theta_target, m, v,
+ * log_alpha + its m, v), these four counters and calling oprl_learner_sync_params resumes a
+ * run bit for bit (tests/test_gpu_callers.py). */
+#define OPRL_N_COUNTERS 4
+int oprl_learner_get_counters(oprl_learner* h, int64_t out_host[OPRL_N_COUNTERS]);
+int oprl_learner_set_counters(oprl_learner* h, const int64_t in_host[OPRL_N_COUNTERS]);
 /* device pointer to the per-row Q / TD-target of the last critic step ([B] each,
  * critic 0), for parity tests. */
 int oprl_learner_debug_ptrs(oprl_learner* h, const float** q, const float** y);

@@ -94,6 +94,8 @@ SIGNATURES = {
     "oprl_comm_init": (C.c_int, [_P, C.c_char_p, _I32, _I32, C.c_char_p]),
     "oprl_learner_dp_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P]),
     "oprl_learner_dp_step_n": (C.c_int, [_P, _P, _I32, _I32, _U64, _P]),
+    "oprl_learner_get_counters": (C.c_int, [_P, C.POINTER(_I64)]),
+    "oprl_learner_set_counters": (C.c_int, [_P, C.POINTER(_I64)]),
     "oprl_profile_enable": (C.c_int, [_I32]),
     "oprl_profile_read": (C.c_int, [C.POINTER(_I64), C.POINTER(C.c_double), _I32]),
     "oprl_replay_create": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _P, _P, C.POINTER(_P)]),

@@ -30,6 +30,13 @@ class OffPolicyAlgorithm(ABC):
     def get_policy_state_dict(self) -> dict[str, Any]:
         return self.actor.state_dict()
 
+    # full learner state (parameters, targets, optimiser moments, counters): exact resume
+    def state_dict(self) -> dict[str, Any]:
+        return self.learner.state_dict()
+
+    def load_state_dict(self, sd: dict[str, Any]) -> None:
+        self.learner.load_state_dict(sd)
+
 
 def require_gpu(device: str) -> t.device:
     dev = t.device(device)
@@ -158,6 +165,45 @@ class HipLearner:
         for m in self._all_mlps:
             m.mark_packed()
         self._versions = self._snapshot_versions()
+
+    # ---- checkpoint / exact resume (the reference saves only the policy,
+    # base_trainer.py:113-120) ---------------------------------------------------------------
+    def state_dict(self) -> dict[str, Any]:
+        """Everything a bit-exact resume needs: parameter / target / Adam arenas, the
+        temperature and its Adam state, and the learner's counters."""
+        cnt = (C.c_int64 * 4)()
+        _capi.check(self.lib.oprl_learner_get_counters(self.handle, cnt), "oprl_learner_get_counters")
+        t.cuda.synchronize(self.device)
+        sd: dict[str, Any] = {
+            "algo": self.algo_name,
+            "counters": [int(x) for x in cnt],
+            "actor": self.actor_arena.detach().cpu().clone(),
+            "actor_m": self.actor_m.cpu().clone(), "actor_v": self.actor_v.cpu().clone(),
+            "critic": self.critic_arena.detach().cpu().clone(),
+            "critic_m": self.critic_m.cpu().clone(), "critic_v": self.critic_v.cpu().clone(),
+            "targets": [a.detach().cpu().clone() for a in self.target_arenas()],
+        }
+        if self.log_alpha is not None:
+            sd["log_alpha"] = [x.detach().cpu().clone() for x in (self.log_alpha, self.log_alpha_m, self.log_alpha_v)]
+        return sd
+
+    def load_state_dict(self, sd: dict[str, Any]) -> None:
+        if sd.get("algo") != self.algo_name:
+            raise ValueError(f"checkpoint is for {sd.get('algo')!r}, this learner is {self.algo_name!r}")
+        pairs = [(self.actor_arena, sd["actor"]), (self.actor_m, sd["actor_m"]), (self.actor_v, sd["actor_v"]),
+                 (self.critic_arena, sd["critic"]), (self.critic_m, sd["critic_m"]), (self.critic_v, sd["critic_v"]),
+                 *zip(self.target_arenas(), sd["targets"])]
+        if self.log_alpha is not None:
+            pairs += list(zip((self.log_alpha, self.log_alpha_m, self.log_alpha_v), sd["log_alpha"]))
+        for dst, src in pairs:
+            if dst.shape != src.shape:
+                raise ValueError(f"checkpoint tensor shape {tuple(src.shape)} != {tuple(dst.shape)}")
+        with t.no_grad():
+            for dst, src in pairs:
+                dst.copy_(src.to(dst.device))
+        cnt = (C.c_int64 * 4)(*[int(x) for x in sd["counters"]])
+        _capi.check(self.lib.oprl_learner_set_counters(self.handle, cnt), "oprl_learner_set_counters")
+        self.sync_params()      # the fragment-order packs are derived state
 
     def check_bound(self) -> None:
         """The kernels hold raw pointers into the arenas: refuse to run if a

@@ -221,6 +221,35 @@ class EpisodicReplayBuffer(ReplayBufferProtocol):
             return (out_s, out_a, out_r, out_d, out_s2), (ep, st)
         return out_s, out_a, out_r, out_d, out_s2
 
+    # ---- checkpoint ------------------------------------------------------
+    def state_dict(self) -> dict:
+        """Storage tensors (host copies) and the bookkeeping that decides where the next
+        transition lands and which Philox counter the next sample() uses."""
+        self._flush()
+        return {
+            "dims": (self.buffer_size_transitions, self.max_episode_lenth, self.state_dim, self.action_dim),
+            "tensors": {k: v.detach().cpu().clone() for k, v in self._tensors.items()},
+            "ep_lens": list(self.ep_lens), "episodes_counter": self.episodes_counter,
+            "ep_pointer": self._ep_pointer, "number_transitions": self._number_transitions,
+            "sample_counter": self._sample_counter, "seed": self.seed,
+        }
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.check_created()
+        dims = (self.buffer_size_transitions, self.max_episode_lenth, self.state_dim, self.action_dim)
+        if tuple(sd["dims"]) != dims:
+            raise ValueError(f"replay checkpoint dims {tuple(sd['dims'])} != {dims}")
+        self._flush()
+        for k, v in sd["tensors"].items():
+            self._tensors[k].copy_(v.to(self._tensors[k].device))
+        self.ep_lens = list(sd["ep_lens"])
+        self.episodes_counter = int(sd["episodes_counter"])
+        self._ep_pointer = int(sd["ep_pointer"])
+        self._number_transitions = int(sd["number_transitions"])
+        self._sample_counter = int(sd["sample_counter"])
+        self.seed = int(sd["seed"])
+        self._lens_dirty = True
+
     @property
     def last_episode_length(self) -> int:
         return self.ep_lens[self._ep_pointer]

@@ -1279,6 +1279,26 @@ extern "C" int oprl_learner_set_update_count(oprl_learner* h, int64_t count) {
   return OPRL_OK;
 }
 
+extern "C" int oprl_learner_get_counters(oprl_learner* h, int64_t out_host[OPRL_N_COUNTERS]) {
+  if (!h || !out_host) { set_err("null argument"); return OPRL_ERR_INVALID; }
+  out_host[0] = h->update_count;
+  out_host[1] = h->opt_step_critic;
+  out_host[2] = h->opt_step_actor;
+  out_host[3] = h->opt_step_alpha;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_learner_set_counters(oprl_learner* h, const int64_t in_host[OPRL_N_COUNTERS]) {
+  if (!h || !in_host) { set_err("null argument"); return OPRL_ERR_INVALID; }
+  for (int k = 0; k < OPRL_N_COUNTERS; ++k)
+    if (in_host[k] < 0 || in_host[k] > 0x7fffffffLL) { set_err("counter %d out of range", k); return OPRL_ERR_INVALID; }
+  h->update_count = in_host[0];
+  h->opt_step_critic = (int)in_host[1];
+  h->opt_step_actor = (int)in_host[2];
+  h->opt_step_alpha = (int)in_host[3];
+  return OPRL_OK;
+}
+
 extern "C" int oprl_learner_debug_ptrs(oprl_learner* h, const float** q, const float** y) {
   if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
   if (q) *q = h->qdbg;

@@ -36,6 +36,7 @@ class BaseTrainer(TrainerProtocol):
     num_eval_episodes: int = 10
     save_buffer_every: int = 0
     save_policy_every: int = int(100_000)
+    save_checkpoint_every: int = 0      # > 0: full learner + replay state every so many env steps (N4)
     estimate_q_every: int = 0
     stdout_log_every: int = int(1e5)
     device: str = "cuda"
@@ -63,6 +64,8 @@ class BaseTrainer(TrainerProtocol):
             rewards = batch[2]
             self._log_evaluation(env_step, rewards)
             self._save_policy(env_step)
+            if self.save_checkpoint_every > 0 and env_step % self.save_checkpoint_every == 0:
+                self.save_checkpoint(self.logger.log_dir / "checkpoints" / f"{env_step}.ckpt", env_step)
             self._log_stdout(env_step, rewards)
 
     def _log_evaluation(self, env_step: int, rewards: t.Tensor) -> None:
@@ -94,6 +97,22 @@ class BaseTrainer(TrainerProtocol):
             path = self.logger.log_dir / "weights" / f"{env_step}.w"
             path.parent.mkdir(parents=True, exist_ok=True)
             t.save(self.algo.actor, path)
+
+    # Full-state checkpoint (the reference only pickles the policy, base_trainer.py:113-120):
+    # learner arenas + Adam moments + counters and the replay with its write / sample positions;
+    # restoring both resumes the update stream bit for bit (tests/test_gpu_callers.py).
+    def save_checkpoint(self, path, env_step: int = 0) -> None:
+        from pathlib import Path
+        path = Path(path)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        t.save({"env_step": int(env_step), "algo": self.algo.state_dict(),
+                "replay": self.replay_buffer.state_dict()}, path)
+
+    def load_checkpoint(self, path) -> int:
+        ck = t.load(path, weights_only=False)
+        self.algo.load_state_dict(ck["algo"])
+        self.replay_buffer.load_state_dict(ck["replay"])
+        return int(ck["env_step"])
 
     def _log_stdout(self, env_step: int, rewards: t.Tensor) -> None:
         if env_step % self.stdout_log_every == 0:
