@@ -66,6 +66,31 @@ def test_export_grads_split_equals_fused_update():
     assert t.equal(q_split, split.critic(s, a))
 
 
+def test_td3_export_grads_split_equals_fused_update():
+    """TD3 through the fused twin-critic kernels in data-parallel mode: update_phase / apply (the
+    k_dw_adam apply_only launch over both critics' layer tables) against the one-call update, over
+    critic-only and actor steps."""
+    from oprl_amd.algos.td3 import TD3
+    from oprl_amd.logging import NullLogger
+
+    def make(**kw):
+        t.manual_seed(0)
+        return TD3(logger=NullLogger(), state_dim=17, action_dim=6, device="cuda", max_batch=256, **kw).create()
+
+    fused, split = make(), make(export_grads=True)
+    for step in range(4):
+        batch = [x.cuda() for x in fx.make_batch(60 + step, 256, 17, 6)]
+        noise = fx.make_noise(160 + step, (256, 6)).cuda()
+        fused.update(*batch, noise=noise)
+        L = split.learner
+        L.update_phase(0, *batch, noise0=noise); L.apply(0, 1.0)
+        L.update_phase(1, *batch, noise0=noise); L.apply(1, 1.0)
+    t.cuda.synchronize()
+    for m in ("actor", "critic", "actor_target", "critic_target"):
+        a, b = getattr(fused, m)._oprl_arena, getattr(split, m)._oprl_arena
+        assert (a - b).abs().max().item() <= 1e-7 * max(1.0, a.abs().max().item()), m
+
+
 def test_load_state_dict_is_picked_up_by_the_learner():
     algo = _ddpg()
     other = _ddpg()
