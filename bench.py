@@ -127,8 +127,10 @@ def multi_learner(n, dev, local_rank, steps):
     """Aggregate steps/s of n independent DDPG learners (own weights, own replay seed)
     driven from one host thread on n streams — the reference's ``--seeds`` fan-out
     (runners/train.py:36-50) without one process per seed.  Each learner's update is
-    4 asynchronous launches occupying <= 48 CUs, so several fit on the chip at once.
-    Reported beside the headline, never as it."""
+    4 asynchronous launches; the launches of different learners overlap on the chip.
+    Reported beside the headline, never as it.  The fused kernels contain bounded
+    cross-workgroup waits, so the packed run is VERIFIED: every learner's parameters must be
+    finite and learner 0 must equal, bit for bit, a solo run with the same seeds."""
     from oprl_amd.algos.ddpg import DDPG
     from oprl_amd.logging import NullLogger
     algos, streams, replays = [], [], []
@@ -152,8 +154,20 @@ def multi_learner(n, dev, local_rank, steps):
     t.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     done = (steps // chunk) * chunk * n
+    finite = all(bool(t.isfinite(a.actor._oprl_arena).all()) and bool(t.isfinite(a.critic._oprl_arena).all())
+                 for a in algos)
+    # the same update stream, alone on the GPU
+    t.manual_seed(100)
+    solo = DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device=f"cuda:{local_rank}", max_batch=B).create()
+    total = chunk * 2 + (steps // chunk) * chunk
+    for _ in range(total // chunk):
+        solo.learner.step_n(shared.handle, chunk, B, seed=1000)
+    t.cuda.synchronize(dev)
+    same = bool(t.equal(solo.actor._oprl_arena, algos[0].actor._oprl_arena)) and \
+        bool(t.equal(solo.critic._oprl_arena, algos[0].critic._oprl_arena))
     return dict(learners=n, value=round(done / dt, 1), unit="steps/s (aggregate)",
-                per_learner=round(done / dt / n, 1), steps_each=(steps // chunk) * chunk)
+                per_learner=round(done / dt / n, 1), steps_each=(steps // chunk) * chunk,
+                verified=dict(all_finite=finite, learner0_equals_solo_run=same))
 
 
 def main():

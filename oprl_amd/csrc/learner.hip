@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/oprl_amd.h"
@@ -73,6 +74,54 @@ void prof_begin(int kind, hipStream_t st) {
 void prof_end(hipStream_t st) {
   if (!g_prof.on || g_prof.ev.empty()) return;
   (void)hipEventRecord(g_prof.ev.back(), st);
+}
+
+// ---- cross-learner ordering of the fused phase kernels --------------------------------
+// k_ddpg_phase1/2 contain bounded cross-workgroup waits (cluster all-reduce, TD-target hand-off)
+// that rely on a launch's workgroups becoming resident together.  One launch has the GPU to
+// itself; two learners launching such kernels from different streams could each get only part
+// of their grid resident and wait on each other until the spin bound poisons the results with
+// NaN.  OPRL_AMD_SERIALIZE_FUSED=1 makes every phase launch wait for the previous phase launch
+// of ANY learner of the process (event chain; dW / small kernels still overlap).  It is OFF by
+// default: measured on MI355X the chain costs more than it protects (8 packed learners 45k ->
+// 17.7k steps/s aggregate), and in practice the dispatcher places a launch's workgroups in
+// order, clusters first — bench.py's multi_learner run checks every packed learner's
+// parameters for NaN and learner 0 against a solo run, bit for bit.
+struct FusedChain {
+  int live = 0;                  // fused learners alive in this process
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  int cur = 0;
+  bool have = false;
+  hipStream_t last_stream = nullptr;
+};
+static FusedChain g_chain;
+static std::mutex g_chain_mu;   // learners may be driven from different host threads
+
+static bool chain_on() {
+  static const bool on = [] { const char* e = getenv("OPRL_AMD_SERIALIZE_FUSED"); return e != nullptr && e[0] == '1'; }();
+  return on;
+}
+static hipError_t chain_before(hipStream_t st) {
+  if (!chain_on()) return hipSuccess;
+  std::lock_guard<std::mutex> lk(g_chain_mu);
+  if (g_chain.live < 2 || !g_chain.have || g_chain.last_stream == st) return hipSuccess;
+  return hipStreamWaitEvent(st, g_chain.ev[g_chain.cur], 0);
+}
+static hipError_t chain_after(hipStream_t st) {
+  if (!chain_on()) return hipSuccess;
+  std::lock_guard<std::mutex> lk(g_chain_mu);
+  if (g_chain.live < 2) return hipSuccess;
+  const int nxt = g_chain.cur ^ 1;
+  if (g_chain.ev[nxt] == nullptr) {
+    hipError_t e = hipEventCreateWithFlags(&g_chain.ev[nxt], hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+  }
+  hipError_t e = hipEventRecord(g_chain.ev[nxt], st);
+  if (e != hipSuccess) return e;
+  g_chain.cur = nxt;
+  g_chain.have = true;
+  g_chain.last_stream = st;
+  return hipSuccess;
 }
 
 size_t mlp_slice_lds_bytes(int width, int n_layers);
@@ -555,10 +604,12 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     fa.noise = noise0;
     fa.cluster_tag = (h->epoch << 1) & 0x03FFFFFFu;
     if (h->trace != nullptr && c.algo == OPRL_DDPG) fa.trace = h->trace;   // roles use slots 0,1,2
+    HIPC(chain_before(st));
     prof_begin(4, st);
     hipError_t e = launch_ddpg_phase1(fa, st);
     prof_end(st);
     HIPC(e);
+    HIPC(chain_after(st));
     // TD3 moves its targets only on actor steps (td3.py:135-146)
     return dw_step(h, true, B, c.algo == OPRL_TD3 ? actor_due(h) : true, st);
   }
@@ -637,10 +688,12 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     if (h->trace != nullptr && c.algo == OPRL_DDPG) fa.trace = h->trace + (size_t)3 * 64 * kTraceStamps * 2;   // slot 3
     fa.prefetch_next = h->prefetch_next;
     if (h->prefetch_next) h->staged_ready = true;
+    HIPC(chain_before(st));
     prof_begin(5, st);
     hipError_t e = launch_ddpg_phase2(fa, st);
     prof_end(st);
     HIPC(e);
+    HIPC(chain_after(st));
     return dw_step(h, false, B, true, st);
   }
   const int S = h->S, A = h->A, nc = h->nc;
@@ -1067,6 +1120,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
       (void)hipFree(p.base); delete h; return OPRL_ERR_NOMEM;
     }
     (void)hipMemset(h->xbuf, 0, h->xbuf_granules * sizeof(unsigned long long));
+    { std::lock_guard<std::mutex> lk(g_chain_mu); g_chain.live += 1; }
   }
   {
     const oprl_net* nets[OPRL_MAX_CRITICS + 1];
@@ -1104,6 +1158,7 @@ extern "C" int oprl_learner_destroy(oprl_learner* h) {
   if (!h) return OPRL_OK;
   (void)hipDeviceSynchronize();
   if (h->rccl.comm && h->rccl.comm_destroy) (void)h->rccl.comm_destroy(h->rccl.comm);
+  if (h->fused) { std::lock_guard<std::mutex> lk(g_chain_mu); if (g_chain.live > 0) g_chain.live -= 1; }
   if (h->xbuf) (void)hipFree(h->xbuf);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   for (int j = 1; j < OPRL_MAX_CRITICS; ++j) {
