@@ -51,6 +51,22 @@ def test_fused_equals_generic(B, cluster, monkeypatch):
         assert abs(sf[k] - sg[k]) <= 1e-5 * max(abs(sg[k]), 1e-12), k
 
 
+@pytest.mark.parametrize("B", [1024, 4096])
+def test_fused_large_batches(B):
+    """Beyond 3 x 4 x ceil(B/16) <= CUs the clusters shrink (B=1024: 1 CU per slice, 192 workgroups;
+    B=4096 = the default max_batch: 768 workgroups, more than the chip holds at once — role B then
+    only ever waits for a role-A workgroup that was dispatched before it)."""
+    fused, generic = _ddpg(max_batch=B), _ddpg(max_batch=B, no_fuse=True)
+    for step in range(2):
+        batch = [x.cuda() for x in fx.make_batch(75 + step, B, 24, 6)]
+        fused.update(*batch)
+        generic.update(*batch)
+    t.cuda.synchronize()
+    assert t.isfinite(fused.critic._oprl_arena).all()
+    for m in ("actor", "critic", "actor_target", "critic_target"):
+        assert _close(getattr(fused, m)._oprl_arena, getattr(generic, m)._oprl_arena, 1e-4), m
+
+
 def test_fused_step_n_equals_generic_step_n():
     from tests.test_gpu_callers import _filled_buffer
     fused, generic = _ddpg(max_batch=64), _ddpg(max_batch=64, no_fuse=True)
