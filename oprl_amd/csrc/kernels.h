@@ -68,6 +68,12 @@ struct MlpArgs {
   int dact_col0, dact_cols; float* dact; int lddact;
   float* partials;                   // [gridDim.x][4] per-slice sums: loss, q, y, (spare)
   long long* trace;                  // debug: [gridDim.x][kTraceStamps][2] (shader clock, 100 MHz realtime)
+  // tensor-parallel launch (csrc/slice_tp.hip): cluster exchange area and launch-unique tag, and
+  // the distance between the members' dz1 partial buffers (dYg[0] + member * dY0_stride)
+  unsigned long long* tp_xbuf; unsigned tp_tag; long dY0_stride;
+  // host-side only (ignored by the kernels): where launch() draws the tag from, the exchange
+  // area's size for the wrap-around reset
+  unsigned* tp_tag_counter; size_t tp_xbuf_bytes;
 };
 
 // ---- dW + Adam + Polyak ------------------------------------------------------

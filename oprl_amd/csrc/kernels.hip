@@ -12,27 +12,9 @@
 // Reference op groups replaced: SURVEY.md §2.2 K2-K13.
 #include "kernels.h"
 #include "philox.h"
+#include "slice_head.h"
 
 namespace oprl {
-
-__device__ __forceinline__ float logsigmoidf(float x) {
-  // min(0,x) - log1p(exp(-|x|))   (ATen log_sigmoid_forward)
-  return fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
-}
-
-__device__ __forceinline__ float alpha_of(const SeedArgs& s) {
-  return s.log_alpha != nullptr ? (float)exp(*s.log_alpha) : s.alpha_const;
-}
-
-constexpr float kLogStdMin = -20.f, kLogStdMax = 2.f;   // nn_models.py:11
-constexpr float kHalfLog2Pi = 0.91893853320467274178f;  // log(sqrt(2*pi))
-constexpr float kTwoLog2 = 1.38629436111989061883f;     // 2*log(2)
-
-// N(0,1) draw for (row, col): injected array or counter-based Philox
-__device__ __forceinline__ float noise_at(const MlpArgs& A, int gr, int col) {
-  if (A.noise != nullptr) return A.noise[(size_t)gr * A.action_dim + col];
-  return philox_normal(A.rng_seed, A.rng_ctr, (unsigned)gr, (unsigned)col);
-}
 
 template <int WIDTH>
 __global__ __launch_bounds__(kThreads) void k_mlp_slice(const MlpArgs A) {
@@ -69,50 +51,7 @@ __global__ __launch_bounds__(kThreads) void k_mlp_slice(const MlpArgs A) {
     mlp_forward_slice<WIDTH>(A.net, x0s, hb, outS, scr, A.Xg, A.Xg[1] != nullptr, row0, B, stamp);
     if (A.Xg[0] != nullptr) store_rows(x0s, kX0Ld, A.Xg[0], A.ldx0, A.net.dims[0], row0, B);
     stamp();  // after narrow output layer
-    // ---- output head ------------------------------------------------------
-    if (A.out_act == ACT_GAUSS) {
-      const int Ad = A.action_dim;
-      const int row = (tid >> 4) & (kR - 1), sub = tid & 15, gr = row0 + row;
-      const bool mine = tid < kR * 16;      // 16 lanes per row, first 256 threads
-      float lp = 0.f;
-      if (mine && gr < B) {
-        for (int col = sub; col < Ad; col += 16) {
-          const float mu = outS[row * kOutLd + col];
-          const float lsr = outS[row * kOutLd + Ad + col];
-          const float ls = fminf(fmaxf(lsr, kLogStdMin), kLogStdMax);
-          const float sd = expf(ls);
-          const float e = noise_at(A, gr, col);
-          const float u = mu + sd * e;
-          const float a = tanhf(u);
-          const float diff = u - mu;
-          lp += -(diff * diff) / (2.f * sd * sd) - logf(sd) - kHalfLog2Pi -
-                (kTwoLog2 + logsigmoidf(2.f * u) + logsigmoidf(-2.f * u));
-          if (A.out != nullptr) A.out[(size_t)gr * A.ldo + col] = a;
-          if (A.raw_out != nullptr) {
-            A.raw_out[(size_t)gr * A.ldraw + col] = mu;
-            A.raw_out[(size_t)gr * A.ldraw + Ad + col] = lsr;
-          }
-        }
-      }
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1) lp += __shfl_xor(lp, m);
-      if (mine && sub == 0 && gr < B && A.logp != nullptr) A.logp[gr] = lp;
-    } else if (A.out != nullptr) {
-      const int ncol = (A.out_act == ACT_GAUSS_MEAN) ? A.action_dim : Nout;
-      for (int idx = tid; idx < kR * ncol; idx += kThreads) {
-        const int row = idx / ncol, col = idx - row * ncol, gr = row0 + row;
-        if (gr >= B) continue;
-        float v = outS[row * kOutLd + col];
-        if (A.out_act == ACT_TANH || A.out_act == ACT_GAUSS_MEAN) {
-          v = tanhf(v);
-        } else if (A.out_act == ACT_TANH_SMOOTH) {
-          float n = noise_at(A, gr, col) * A.policy_noise;
-          n = fminf(fmaxf(n, -A.noise_clip), A.noise_clip);
-          v = fminf(fmaxf(tanhf(v) + n, -A.max_action), A.max_action);
-        }
-        A.out[(size_t)gr * A.ldo + col] = v;
-      }
-    }
+    slice_head(A, outS, Nout, row0, true);
   } else if (A.do_bwd) {
     _Pragma("unroll") for (int l = 1; l < kMaxLayers; ++l)
       if (l < L) load_rows4(hb + (l - 1) * LY::hbuf, WL, A.Xg[l], WIDTH, WIDTH, row0, B);
@@ -120,127 +59,7 @@ __global__ __launch_bounds__(kThreads) void k_mlp_slice(const MlpArgs A) {
   stamp();  // head / reload done
   if (!A.do_bwd) return;
 
-  // ---- loss-gradient seed -> auxS (zero padded) -----------------------------
-  lds_zero(auxS, kR * kOutLd);
-  __syncthreads();
-  const SeedArgs& S = A.seed;
-  float p_loss = 0.f, p_q = 0.f, p_y = 0.f;
-  switch (A.seed_mode) {
-    case SEED_PTR:
-      for (int idx = tid; idx < kR * Nout; idx += kThreads) {
-        const int row = idx / Nout, col = idx - row * Nout, gr = row0 + row;
-        if (gr < B) auxS[row * kOutLd + col] = S.p0[(size_t)gr * S.ld0 + col];
-      }
-      break;
-    case SEED_MSE_TD:
-      if (tid < kR) {
-        const int gr = row0 + tid;
-        if (gr < B) {
-          const float q = outS[tid * kOutLd];
-          float qn = S.p0[gr];
-          if (S.p1 != nullptr) qn = fminf(qn, S.p1[gr]);
-          if (S.p2 != nullptr) qn -= alpha_of(S) * S.p2[gr];
-          const float y = S.r[gr] + ((1.f - S.d[gr]) * S.gamma) * qn;
-          auxS[tid * kOutLd] = 2.f * (q - y) * S.cval;
-          if (S.y_out != nullptr) S.y_out[gr] = y;
-          if (S.q_out != nullptr) S.q_out[gr] = q;
-          p_loss = (q - y) * (q - y);
-          p_q = q;
-          p_y = y;
-        }
-      }
-      break;
-    case SEED_CONST:
-      for (int idx = tid; idx < kR * Nout; idx += kThreads) {
-        const int row = idx / Nout, col = idx - row * Nout;
-        if (row0 + row < B) auxS[row * kOutLd + col] = S.cval;
-      }
-      if (A.do_fwd && tid < kR && row0 + tid < B) p_q = outS[tid * kOutLd];  // diagnostic: mean q
-      break;
-    case SEED_MINQ:
-      if (tid < kR) {
-        const int gr = row0 + tid;
-        if (gr < B) {
-          const float q1 = S.p0[gr], q2 = S.p1[gr];
-          const float w1 = q1 < q2 ? 1.f : (q1 == q2 ? 0.5f : 0.f);
-          auxS[tid * kOutLd] = -(S.which == 0 ? w1 : 1.f - w1) * S.cval;
-          p_q = fminf(q1, q2);
-        }
-      }
-      break;
-    case SEED_TANH:
-      for (int idx = tid; idx < kR * Nout; idx += kThreads) {
-        const int row = idx / Nout, col = idx - row * Nout, gr = row0 + row;
-        if (gr < B) {
-          const float a = S.p1[(size_t)gr * Nout + col];
-          auxS[row * kOutLd + col] = S.p0[(size_t)gr * S.ld0 + col] * (1.f - a * a);
-        }
-      }
-      break;
-    case SEED_GAUSS: {
-      const int Ad = Nout >> 1;
-      const float alpha = alpha_of(S);
-      const float dlp = alpha * S.cval;
-      for (int idx = tid; idx < kR * Ad; idx += kThreads) {
-        const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
-        if (gr >= B) continue;
-        const float mu = S.p1[(size_t)gr * Nout + col];
-        const float lsr = S.p1[(size_t)gr * Nout + Ad + col];
-        const float ls = fminf(fmaxf(lsr, kLogStdMin), kLogStdMax);
-        const float sd = expf(ls);
-        const float e = noise_at(A, gr, col);   // same injected / Philox draw as the forward
-        const float a = tanhf(mu + sd * e);
-        float da = 0.f;
-        for (int n = 0; n < S.n_da; ++n) da += S.p0[n * S.da_stride + (size_t)gr * S.ld0 + col];
-        const float du = da * (1.f - a * a) + dlp * (2.f * a);
-        const bool in = (lsr >= kLogStdMin) && (lsr <= kLogStdMax);
-        auxS[row * kOutLd + col] = du;
-        auxS[row * kOutLd + Ad + col] = in ? (du * sd * e - dlp) : 0.f;
-      }
-    } break;
-    case SEED_QHUBER: {
-      const int Q = S.Q, M = S.M;
-      for (int idx = tid; idx < kR * Q; idx += kThreads) {
-        const int row = idx / Q, q = idx - row * Q, gr = row0 + row;
-        if (gr >= B) continue;
-        const float z = outS[row * kOutLd + q];
-        const float tau = ((float)q) / (float)Q + 0.5f / (float)Q;
-        const float* yrow = S.p0 + (size_t)gr * M;
-        float g = 0.f, ls = 0.f;
-        for (int s = 0; s < M; ++s) {
-          const float dl = yrow[s] - z;
-          const float ad = fabsf(dl);
-          const float w = fabsf(tau - (dl < 0.f ? 1.f : 0.f));
-          g += w * (ad > 1.f ? (dl > 0.f ? 1.f : -1.f) : dl);
-          ls += w * (ad > 1.f ? ad - 0.5f : dl * dl * 0.5f);
-        }
-        auxS[row * kOutLd + q] = -g * S.cval;
-        p_loss += ls;
-      }
-    } break;
-    default: break;
-  }
-  if (A.partials != nullptr) {  // per-slice diagnostics (block reduce through scr)
-    __syncthreads();
-    float v[3] = {p_loss, p_q, p_y};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-#pragma unroll
-      for (int m = 1; m < 64; m <<= 1) v[k] += __shfl_xor(v[k], m);
-      if ((tid & 63) == 0) scr[(tid >> 6) * 4 + k] = v[k];
-    }
-    __syncthreads();
-    if (tid < 3) {
-      float sum = 0.f;
-      for (int w = 0; w < kWaves; ++w) sum += scr[w * 4 + tid];
-      A.partials[blockIdx.x * 4 + tid] = sum;
-    }
-  }
-  __syncthreads();
-  {
-    float* dlast = pick(A.dYg, L - 1);
-    if (dlast != nullptr) store_rows(auxS, kOutLd, dlast, A.lddo, Nout, row0, B);
-  }
+  slice_seed(A, outS, auxS, scr, Nout, L, row0, blockIdx.x, true);
   stamp();  // seed done
   mlp_backward_slice<WIDTH>(A.net, auxS, hb, scr, A.dYg, row0, B, A.dact_col0, A.dact_cols, auxS, stamp);
   if (A.dact_cols > 0 && A.dact != nullptr) store_rows(auxS, kOutLd, A.dact, A.lddact, A.dact_cols, row0, B);

@@ -126,6 +126,9 @@ static hipError_t chain_after(hipStream_t st) {
 
 size_t mlp_slice_lds_bytes(int width, int n_layers);
 hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
+hipError_t launch_mlp_slice_tp(const MlpArgs& a, hipStream_t st);
+hipError_t init_slice_tp_attrs();
+bool mlp_slice_tp_shape_ok(const MlpArgs& a, int width);
 hipError_t init_kernel_attrs();
 hipError_t launch_dw_adam(const DwArgs& a, hipStream_t st);
 hipError_t launch_repack(const RepackItem* items_dev, int n_items, int total_blocks, hipStream_t st);
@@ -322,6 +325,8 @@ struct oprl_learner {
   hipEvent_t ev_fork = nullptr, ev_join[OPRL_MAX_CRITICS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool have_side = false;
   bool fused = false;          // DDPG / TD3 two-kernel path (csrc/fused_ddpg.hip) is built for this learner
+  bool tp_generic_on = false;  // the generic per-net launches may run on clusters of 4 (csrc/slice_tp.hip)
+  unsigned tp_tag = 0;         // launch-unique tag source of the cluster exchanges (fused and generic)
   bool staged_ready = false;   // step_n: the staging batch holds the next update's rows (written by phase 2)
   unsigned long long* y_granules = nullptr;   // [Bmax] TD-target hand-off (fused DDPG)
   unsigned epoch = 0;          // monotonically increasing, never reset
@@ -434,9 +439,25 @@ AdamScalars adam_scalars(const oprl_learner* h, double lr, int step, bool polyak
   return ad;
 }
 
+// Does a slice launch of net `n` at batch B run on tensor-parallel clusters (slice_tp.hip)?  One
+// predicate for the launch and for the dW kernel that has to sum the dz1 partials it leaves.
+bool tp_generic(const oprl_learner* h, const oprl_net& n, int B) {
+  if (!h->tp_generic_on || h->xbuf == nullptr) return false;
+  if (n.n_layers != 3 || n.dims[1] != 256 || n.dims[2] != 256) return false;
+  if (n.dims[0] > 96 || n.dims[3] > kNarrowMax) return false;
+  if (((h->S & 15) + h->A - 1) / 16 >= 4) return false;          // input-gradient column span
+  const int slices = (B + kR - 1) / kR;
+  return slices * 4 <= h->n_cus;
+}
+
 MlpArgs base_args(oprl_learner* h, const oprl_net& n, bool target, int B) {
   MlpArgs a;
   memset(&a, 0, sizeof a);
+  if (tp_generic(h, n, B)) {
+    a.tp_xbuf = h->xbuf;
+    a.tp_tag_counter = &h->tp_tag;
+    a.tp_xbuf_bytes = h->xbuf_granules * sizeof(unsigned long long);
+  }
   if (h->trace != nullptr && h->trace_slot < OPRL_TRACE_SLOTS)
     a.trace = h->trace + (size_t)(h->trace_slot++) * 64 * kTraceStamps * 2;
   a.net = net_view(n, target);
@@ -455,9 +476,32 @@ void with_store(MlpArgs& a, const NetWs& ws, bool x, bool dy) {
   }
   a.ldx0 = ws.ldx0;
   a.lddo = ws.lddo;
+  a.dY0_stride = ws.dY0_stride;
 }
 
-int launch(const MlpArgs& a, int width, hipStream_t st) {
+// launch-unique 26-bit tag for the cluster exchanges of one learner; on wrap-around every stale
+// granule is retired
+int next_tp_tag(unsigned* counter, unsigned long long* xbuf, size_t xbuf_bytes, hipStream_t st, unsigned* out) {
+  *counter += 1;
+  if ((*counter & 0x03FFFFFFu) == 0) {
+    *counter += 1;
+    HIPC(hipMemsetAsync(xbuf, 0, xbuf_bytes, st));
+  }
+  *out = *counter & 0x03FFFFFFu;
+  return OPRL_OK;
+}
+
+int launch(const MlpArgs& a0, int width, hipStream_t st) {
+  if (a0.tp_xbuf != nullptr && mlp_slice_tp_shape_ok(a0, width)) {
+    MlpArgs a = a0;
+    RC(next_tp_tag(a.tp_tag_counter, a.tp_xbuf, a.tp_xbuf_bytes, st, &a.tp_tag));
+    prof_begin(0, st);
+    hipError_t e = launch_mlp_slice_tp(a, st);
+    prof_end(st);
+    HIPC(e);
+    return OPRL_OK;
+  }
+  const MlpArgs& a = a0;
   prof_begin(0, st);
   hipError_t e = launch_mlp_slice(a, width, st);
   prof_end(st);
@@ -595,14 +639,13 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
   const oprl_learner_config& c = h->cfg;
   if (use_fused(h, B)) {
     h->epoch += 1;
-    if ((h->epoch & 0x00FFFFFFu) == 0) {   // exchange tags about to wrap: retire every stale granule
-      if (h->epoch == 0) h->epoch = 1;
-      HIPC(hipMemsetAsync(h->xbuf, 0, h->xbuf_granules * sizeof(unsigned long long), st));
+    if (h->epoch == 0) {   // the TD-target tag wrapped: retire every stale granule
+      h->epoch = 1;
       HIPC(hipMemsetAsync(h->y_granules, 0, (size_t)h->Bmax * sizeof(unsigned long long), st));
     }
     DdpgArgs fa = ddpg_args(h, B);
     fa.noise = noise0;
-    fa.cluster_tag = (h->epoch << 1) & 0x03FFFFFFu;
+    RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &fa.cluster_tag));
     if (h->trace != nullptr && c.algo == OPRL_DDPG) fa.trace = h->trace;   // roles use slots 0,1,2
     HIPC(chain_before(st));
     prof_begin(4, st);
@@ -672,7 +715,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     h->opt_step_critic += 1;
     DwArgs dw;
     dw.items = h->items_host.data(); dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
-    dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.use_row_scale = 0; dw.apply_only = 0; dw.apply_only = 0;
+    dw.B = B; dw.n_part = tp_generic(h, c.critics[0], B) ? 4 : 1; dw.trace = nullptr; dw.use_row_scale = 0; dw.apply_only = 0;
     dw.ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, 1.0f);
     HIPC(launch_dw_prof(dw, st));
   }
@@ -684,7 +727,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
   const oprl_learner_config& c = h->cfg;
   if (use_fused(h, B)) {
     DdpgArgs fa = ddpg_args(h, B);
-    fa.cluster_tag = ((h->epoch << 1) | 1u) & 0x03FFFFFFu;
+    RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &fa.cluster_tag));
     if (h->trace != nullptr && c.algo == OPRL_DDPG) fa.trace = h->trace + (size_t)3 * 64 * kTraceStamps * 2;   // slot 3
     fa.prefetch_next = h->prefetch_next;
     if (h->prefetch_next) h->staged_ready = true;
@@ -774,7 +817,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     h->opt_step_actor += 1;
     DwArgs dw;
     dw.items = h->items_host.data() + h->n_items_critic; dw.n_items = h->n_items_actor;
-    dw.total_tiles = h->tiles_actor; dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.use_row_scale = 0; dw.apply_only = 0; dw.apply_only = 0;
+    dw.total_tiles = h->tiles_actor; dw.B = B; dw.n_part = tp_generic(h, c.actor, B) ? 4 : 1; dw.trace = nullptr; dw.use_row_scale = 0; dw.apply_only = 0;
     dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, c.actor.theta_target != nullptr, 1.0f);
     HIPC(launch_dw_prof(dw, st));
   }
@@ -1028,6 +1071,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
 
   hipError_t e = init_kernel_attrs();
   if (e == hipSuccess) e = init_fused_attrs();
+  if (e == hipSuccess) e = init_slice_tp_attrs();
   if (e != hipSuccess) { set_err("hipFuncSetAttribute: %s", hipGetErrorString(e)); delete h; return OPRL_ERR_HIP; }
   memset(&h->src, 0, sizeof h->src);
   memset(&h->next_src, 0, sizeof h->next_src);
@@ -1103,7 +1147,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   if (p.used > p.cap) { set_err("internal: workspace pool overflow (%zu > %zu)", p.used, p.cap); (void)hipFree(p.base); delete h; return OPRL_ERR_NOMEM; }
   for (int k = 0; k < 3; ++k)
     if (!rp[k].empty()) (void)hipMemcpy(h->rp_dev[k], rp[k].data(), sizeof(RepackItem) * rp[k].size(), hipMemcpyHostToDevice);
-  if (h->fused) {
+  {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -1113,6 +1157,13 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     if (h->ncl != 1 && h->ncl != 2 && h->ncl != 4) h->ncl = kMaxCluster;
     const char* nl = getenv("OPRL_AMD_NO_LEAN");
     h->no_lean = (nl != nullptr && atoi(nl) != 0) ? 1 : 0;
+    // the generic per-net launches on clusters of 4 (slice_tp.hip): any net of the common shape
+    const char* ng = getenv("OPRL_AMD_NO_TP_GENERIC");
+    const bool shape = h->w_actor == 256 && h->w_critic == 256 && cfg->actor.n_layers == 3 &&
+                       cfg->critics[0].n_layers == 3;
+    h->tp_generic_on = shape && !h->no_lean && h->ncl == 4 && !(ng != nullptr && atoi(ng) != 0);
+  }
+  if (h->fused || h->tp_generic_on) {
     const size_t slices = (size_t)(h->Bmax + kR - 1) / kR;
     h->xbuf_granules = (size_t)(2 + nc) * slices * fused_xbuf_granules_per_cluster(kMaxCluster);
     if (hipMalloc(&h->xbuf, h->xbuf_granules * sizeof(unsigned long long)) != hipSuccess) {
@@ -1120,7 +1171,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
       (void)hipFree(p.base); delete h; return OPRL_ERR_NOMEM;
     }
     (void)hipMemset(h->xbuf, 0, h->xbuf_granules * sizeof(unsigned long long));
-    { std::lock_guard<std::mutex> lk(g_chain_mu); g_chain.live += 1; }
+    if (h->fused) { std::lock_guard<std::mutex> lk(g_chain_mu); g_chain.live += 1; }
   }
   {
     const oprl_net* nets[OPRL_MAX_CRITICS + 1];

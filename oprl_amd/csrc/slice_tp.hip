@@ -1,0 +1,73 @@
+// slice_tp.hip — k_mlp_slice on tensor-parallel clusters.
+//
+// The generic per-net launches (what SAC, TD3's fallback, the data-parallel phases of those and
+// the stand-alone oprl_mlp_forward / backward use) carried one 16-row slice per CU through a whole
+// MLP with the generic engine (engine.h: ~3000 instructions per pass around 28 executed MFMAs per
+// wave — instruction-issue bound, profiles/r01d_stage_stamps.txt).  For the common shape — three
+// layers, width 256, fan-in <= 96, <= 48 outputs — and ceil(B/16) * 4 <= CUs (B <= 1024 on
+// MI355X) this kernel runs the same launch on clusters of 4 CUs per slice with the lean passes
+// of tp4.h; inputs, head, loss-gradient seed and outputs are those of k_mlp_slice (slice_head.h),
+// computed identically by every member, written by member 0.  The first layer's dz goes out as
+// four partial buffers, summed by k_dw_adam on load (DwArgs::n_part = 4).
+#include "slice_head.h"
+#include "tp4.h"
+
+namespace oprl {
+
+__global__ __launch_bounds__(kThreads) void k_mlp_slice_tp(const MlpArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using LY = SliceLds<256>;
+  constexpr int WL = lds_ld(256);
+  constexpr int L = 3;
+  float* x0s = smem;
+  float* h1 = smem + LY::h_off;
+  float* h2 = h1 + LY::hbuf;
+  float* outS = smem + LY::out_off(2);
+  float* auxS = smem + LY::aux_off(2);
+  float* scr = smem + LY::scr_off(2);
+  const int slice = blockIdx.x, row0 = slice * kR, B = A.B;
+  Tp tp{(int)blockIdx.y, 4, A.tp_xbuf + (size_t)slice * kTpStages * 4 * kTpBlk, A.tp_tag, 0};
+  const bool lead = tp.c == 0;
+  const int Nout = A.net.dims[3];
+
+  if (A.do_fwd) {
+    lds_zero(x0s, kR * kX0Ld);
+    __syncthreads();
+    load_rows(x0s, kX0Ld, 0, A.x0, A.k0, A.k0, row0, B);
+    if (A.x1 != nullptr) load_rows(x0s, kX0Ld, A.k0, A.x1, A.k1, A.k1, row0, B);
+    const Tp3Store st{A.Xg[1], A.Xg[2], nullptr, nullptr, 0};
+    tp4_forward(A.net, x0s, h1, h2, outS, tp, st, row0, B);
+    if (lead && A.Xg[0] != nullptr) store_rows(x0s, kX0Ld, A.Xg[0], A.ldx0, A.net.dims[0], row0, B);
+    slice_head(A, outS, Nout, row0, lead);
+  } else if (A.do_bwd) {
+    load_rows4(h1, WL, A.Xg[1], 256, 256, row0, B);
+    load_rows4(h2, WL, A.Xg[2], 256, 256, row0, B);
+  }
+  if (!A.do_bwd) return;
+
+  slice_seed(A, outS, auxS, scr, Nout, L, row0, slice, lead);
+  const Tp3Store sb{nullptr, nullptr, A.dYg[1], A.dYg[0], A.dY0_stride};
+  tp4_backward(A.net, auxS, h1, h2, scr, tp, sb, row0, B, A.dact_col0, A.dact_cols, auxS);
+  if (lead && A.dact_cols > 0 && A.dact != nullptr)
+    store_rows(auxS, kOutLd, A.dact, A.lddact, A.dact_cols, row0, B);
+}
+
+bool mlp_slice_tp_shape_ok(const MlpArgs& a, int width) {
+  return a.net.n_layers == 3 && a.net.dims[1] == 256 && a.net.dims[2] == 256 &&
+         tp4_shape_ok(width, a.net.dims[0], a.net.dims[3]) && a.dact_cols <= kNarrowMax &&
+         (a.dact_cols <= 0 || ((a.dact_col0 + a.dact_cols - 1) >> 4) - (a.dact_col0 >> 4) < 4);
+}
+
+hipError_t init_slice_tp_attrs() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_slice_tp),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t launch_mlp_slice_tp(const MlpArgs& a, hipStream_t st) {
+  const int slices = (a.B + kR - 1) / kR;
+  const size_t lds = sizeof(float) * SliceLds<256>::total(2);
+  hipLaunchKernelGGL(k_mlp_slice_tp, dim3(slices, 4), dim3(kThreads), lds, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace oprl

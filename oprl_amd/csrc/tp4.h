@@ -32,9 +32,10 @@ constexpr int kW4 = 256;
 constexpr int kWL4 = lds_ld(kW4);
 constexpr int kTpc4 = 4;                      // tiles (= macro steps) per member
 constexpr int kCols4 = kTpc4 * 16;            // hidden columns per member
+constexpr int kMaxS0 = 6;                     // layer-0 macro steps: fan-in <= 96 (humanoid S + A = 88)
 
 __host__ __device__ inline bool tp4_shape_ok(int width, int fan_in, int n_out) {
-  return width == kW4 && fan_in <= 64 && n_out <= kNarrowMax;
+  return width == kW4 && fan_in <= 16 * kMaxS0 && n_out <= kNarrowMax;
 }
 
 __device__ __forceinline__ void mac4(const f32x4 a, const f32x4 b, f32x4& acc) {
@@ -106,11 +107,11 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
   const bool l2_wave = t2 >= 0 && t2 < NTo;
 
   // ---- requests for the whole pass
-  f32x4 w0[4], wq[16];
+  f32x4 w0[kMaxS0], wq[16];
   {
     const float* p0 = net.pf[0] + ((size_t)wave * NS0 * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) w0[s] = s < NS0 ? ld4(p0 + s * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < kMaxS0; ++s) w0[s] = s < NS0 ? ld4(p0 + s * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float bias0 = net.b[0][16 * wave + i];
   float bias12 = 0.f;
@@ -135,7 +136,7 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* xr = x0s + i * kX0Ld + 4 * kk;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < kMaxS0; ++s)
       if (s < NS0) mac4(ld4(xr + 16 * s), w0[s], acc);
     float* o = h1 + (kk * 4) * kWL4 + 16 * wave + i;
 #pragma unroll
@@ -198,10 +199,13 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
   const int c = tp.c, c0 = c * kCols4;
-  const int NSo = (net.dims[3] + 15) >> 4, NT0 = (net.dims[0] + 15) >> 4;
+  const int NSo = (net.dims[3] + 15) >> 4;
   const bool dact = dact_cols > 0;
-  const int dt = wave >> 2, dpart = wave & 3;       // dact: tile, contraction quarter
-  const bool dact_wave = dact && dt < NT0;
+  // input-column gradient: only the 16-column tiles that overlap [dact_col0, +dact_cols)
+  // (at most 4: one wave per tile and contraction quarter)
+  const int dt0 = dact_col0 >> 4, dnt = dact ? ((dact_col0 + dact_cols - 1) >> 4) - dt0 + 1 : 0;
+  const int dt = wave >> 2, dpart = wave & 3;       // dact: tile (relative), contraction quarter
+  const bool dact_wave = dact && dt < dnt;
 
   // ---- requests
   f32x4 wo[3], wz[4], wd[4];
@@ -221,7 +225,7 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
 #pragma unroll
   for (int s = 0; s < 4; ++s) wd[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (dact_wave) {
-    const float* q0 = net.pb[0] + (((size_t)dt * 16 + dpart * 4) * 64 + lane) * 4;
+    const float* q0 = net.pb[0] + (((size_t)(dt0 + dt) * 16 + dpart * 4) * 64 + lane) * 4;
 #pragma unroll
     for (int s = 0; s < 4; ++s) wd[s] = ld4(q0 + s * 256);
   }
@@ -282,11 +286,11 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
     }
     sf();
     __syncthreads();
-    if (wave < NT0) {        // wave t gathers tile t's four quarters, then the cluster all-reduce
+    if (wave < dnt) {        // wave t gathers tile t's four quarters, then the cluster all-reduce
       f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 4; ++q) part += ld4(scr + (wave * 4 + q) * 256 + lane * 4);
-      const int cc = 16 * wave + i - dact_col0;
+      const int cc = 16 * (dt0 + wave) + i - dact_col0;
       const bool valid = cc >= 0 && cc < dact_cols;
       const f32x4 sum = tp4_allreduce_regs(part, cc, valid, tp);
       if (valid) {
@@ -333,18 +337,19 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
   const int c = tp.c, c0 = c * kCols4;
-  const int NS0 = (net.dims[0] + 15) >> 4;          // layer-0 steps = input-gradient tiles
+  const int NS0 = (net.dims[0] + 15) >> 4;          // layer-0 steps
   const bool dact = dact_cols > 0;
+  const int dt0 = dact_col0 >> 4, dnt = dact ? ((dact_col0 + dact_cols - 1) >> 4) - dt0 + 1 : 0;
   const int dt = wave >> 2, dpart = wave & 3;
-  const bool dact_wave = dact && dt < NS0;
+  const bool dact_wave = dact && dt < dnt;
   constexpr int kOutWave = 12;
 
   // ---- requests
-  f32x4 w0[4], wq[16], wz[4], wd[4];
+  f32x4 w0[kMaxS0], wq[16], wz[4], wd[4];
   {
     const float* p0 = net.pf[0] + ((size_t)wave * NS0 * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) w0[s] = s < NS0 ? ld4(p0 + s * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < kMaxS0; ++s) w0[s] = s < NS0 ? ld4(p0 + s * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float bias0 = net.b[0][16 * wave + i];
   float bias12 = 0.f, w3 = 0.f;
@@ -370,7 +375,7 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* xr = x0s + i * kX0Ld + 4 * kk;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < kMaxS0; ++s)
       if (s < NS0) mac4(ld4(xr + 16 * s), w0[s], acc);
     float* o = h1 + (kk * 4) * kWL4 + 16 * wave + i;
 #pragma unroll
@@ -410,7 +415,7 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
 #pragma unroll
   for (int s = 0; s < 4; ++s) wd[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (dact_wave) {
-    const float* q0 = net.pb[0] + (((size_t)dt * 16 + dpart * 4) * 64 + lane) * 4;
+    const float* q0 = net.pb[0] + (((size_t)(dt0 + dt) * 16 + dpart * 4) * 64 + lane) * 4;
 #pragma unroll
     for (int s = 0; s < 4; ++s) wd[s] = ld4(q0 + s * 256);
   }
@@ -461,7 +466,7 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
     sf();
     __syncthreads();   // quarters visible
   }
-  // q (wave 12) and the input-column gradient (waves < NS0) finish side by side: both are one
+  // q (wave 12) and the input-column gradient (waves < dnt) finish side by side: both are one
   // hop of the cluster exchange, neither waits for the other
   if (wave == kOutWave) {
     f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
@@ -485,13 +490,13 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
     }
   }
   if (dact) {
-    if (wave < NS0) {
+    if (wave < dnt) {
       Tp tp2 = tp;
       tp2.stage = tp.stage + 1;
       f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 4; ++q) part += ld4(scr + (wave * 4 + q) * 256 + lane * 4);
-      const int cc = 16 * wave + i - dact_col0;
+      const int cc = 16 * (dt0 + wave) + i - dact_col0;
       const bool valid = cc >= 0 && cc < dact_cols;
       const f32x4 sum = tp4_allreduce_regs(part, cc, valid, tp2);
       if (valid) {

@@ -145,3 +145,41 @@ def test_fused_td3_step_n_equals_generic_step_n():
     t.cuda.synchronize()
     for m in ("actor", "critic", "actor_target", "critic_target"):
         assert _close(getattr(fused, m)._oprl_arena, getattr(generic, m)._oprl_arena, 1e-4), m
+
+
+# ---- generic per-net launches: tensor-parallel clusters (slice_tp.hip) vs one CU per slice -------
+@pytest.mark.parametrize("algo", ["sac", "td3"])
+def test_generic_launches_cluster_vs_single_cu(algo, monkeypatch):
+    """OPRL_AMD_NO_TP_GENERIC=1 keeps the generic launch sequence on k_mlp_slice (one CU per slice);
+    the default runs the same launches on clusters of 4 with the lean passes.  Same results up to
+    summation order."""
+    from oprl_amd.logging import NullLogger
+
+    def make():
+        t.manual_seed(0)
+        if algo == "sac":
+            from oprl_amd.algos.sac import SAC
+            return SAC(logger=NullLogger(), state_dim=67, action_dim=21, device="cuda", max_batch=1024,
+                       tune_alpha=True).create()
+        from oprl_amd.algos.td3 import TD3
+        return TD3(logger=NullLogger(), state_dim=17, action_dim=6, device="cuda", max_batch=1024,
+                   no_fuse=True).create()
+
+    monkeypatch.setenv("OPRL_AMD_NO_TP_GENERIC", "0")
+    tp = make()
+    monkeypatch.setenv("OPRL_AMD_NO_TP_GENERIC", "1")
+    one = make()
+    B, S, A = (1024, 67, 21) if algo == "sac" else (512, 17, 6)
+    for step in range(4):
+        batch = [x.cuda() for x in fx.make_batch(300 + step, B, S, A)]
+        n0 = fx.make_noise(400 + step, (B, A)).cuda()
+        n1 = fx.make_noise(500 + step, (B, A)).cuda()
+        for a in (tp, one):
+            if algo == "sac":
+                a.update(*batch, noise=(n0, n1))
+            else:
+                a.update(*batch, noise=n0)
+    t.cuda.synchronize()
+    for m in ("actor", "critic", "critic_target"):
+        assert t.isfinite(getattr(tp, m)._oprl_arena).all()
+        assert _close(getattr(tp, m)._oprl_arena, getattr(one, m)._oprl_arena, 1e-4), m
