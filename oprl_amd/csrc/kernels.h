@@ -74,6 +74,7 @@ struct MlpArgs {
   // host-side only (ignored by the kernels): where launch() draws the tag from, the exchange
   // area's size for the wrap-around reset
   unsigned* tp_tag_counter; size_t tp_xbuf_bytes;
+  void* owner;                       // the learner: lets launch() pair two nets of one for_each_net
 };
 
 // ---- dW + Adam + Polyak ------------------------------------------------------

@@ -127,6 +127,7 @@ static hipError_t chain_after(hipStream_t st) {
 size_t mlp_slice_lds_bytes(int width, int n_layers);
 hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
 hipError_t launch_mlp_slice_tp(const MlpArgs& a, hipStream_t st);
+hipError_t launch_mlp_slice_tp2(const MlpArgs& a0, const MlpArgs& a1, hipStream_t st);
 hipError_t init_slice_tp_attrs();
 bool mlp_slice_tp_shape_ok(const MlpArgs& a, int width);
 hipError_t init_kernel_attrs();
@@ -327,6 +328,10 @@ struct oprl_learner {
   bool fused = false;          // DDPG / TD3 two-kernel path (csrc/fused_ddpg.hip) is built for this learner
   bool tp_generic_on = false;  // the generic per-net launches may run on clusters of 4 (csrc/slice_tp.hip)
   unsigned tp_tag = 0;         // launch-unique tag source of the cluster exchanges (fused and generic)
+  // for_each_net over two nets: their cluster launches are collected and go out as one (k_mlp_slice_tp2)
+  bool pair_collect = false;
+  int pair_n = 0;
+  MlpArgs pair_args[2];
   bool staged_ready = false;   // step_n: the staging batch holds the next update's rows (written by phase 2)
   unsigned long long* y_granules = nullptr;   // [Bmax] TD-target hand-off (fused DDPG)
   unsigned epoch = 0;          // monotonically increasing, never reset
@@ -457,6 +462,7 @@ MlpArgs base_args(oprl_learner* h, const oprl_net& n, bool target, int B) {
     a.tp_xbuf = h->xbuf;
     a.tp_tag_counter = &h->tp_tag;
     a.tp_xbuf_bytes = h->xbuf_granules * sizeof(unsigned long long);
+    a.owner = h;
   }
   if (h->trace != nullptr && h->trace_slot < OPRL_TRACE_SLOTS)
     a.trace = h->trace + (size_t)(h->trace_slot++) * 64 * kTraceStamps * 2;
@@ -495,6 +501,11 @@ int launch(const MlpArgs& a0, int width, hipStream_t st) {
   if (a0.tp_xbuf != nullptr && mlp_slice_tp_shape_ok(a0, width)) {
     MlpArgs a = a0;
     RC(next_tp_tag(a.tp_tag_counter, a.tp_xbuf, a.tp_xbuf_bytes, st, &a.tp_tag));
+    oprl_learner* own = (oprl_learner*)a.owner;
+    if (own != nullptr && own->pair_collect && own->pair_n < 2) {   // for_each_net over a pair: defer
+      own->pair_args[own->pair_n++] = a;
+      return OPRL_OK;
+    }
     prof_begin(0, st);
     hipError_t e = launch_mlp_slice_tp(a, st);
     prof_end(st);
@@ -523,6 +534,30 @@ template <class F>
 int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
   // measured: the event fork/join costs more than it saves for 2 nets (TD3 8.8k -> 7.7k/s),
   // pays for the 5 quantile critics of TQC (673 -> 1206/s)
+  if (n == 2) {
+    // twin nets on the same slices: their cluster launches (slice_tp.hip) go out as ONE launch
+    h->pair_collect = true;
+    h->pair_n = 0;
+    int rc = launch_j(0, st);
+    if (rc == OPRL_OK) rc = launch_j(1, st);
+    h->pair_collect = false;
+    RC(rc);
+    if (h->pair_n == 2 && h->pair_args[0].B == h->pair_args[1].B) {
+      prof_begin(0, st);
+      hipError_t e = launch_mlp_slice_tp2(h->pair_args[0], h->pair_args[1], st);
+      prof_end(st);
+      HIPC(e);
+    } else {
+      for (int k = 0; k < h->pair_n; ++k) {
+        prof_begin(0, st);
+        hipError_t e = launch_mlp_slice_tp(h->pair_args[k], st);
+        prof_end(st);
+        HIPC(e);
+      }
+    }
+    h->pair_n = 0;
+    return OPRL_OK;
+  }
   if (n <= 2 || !h->have_side) {
     for (int j = 0; j < n; ++j) RC(launch_j(j, st));
     return OPRL_OK;

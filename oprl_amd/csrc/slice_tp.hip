@@ -14,7 +14,7 @@
 
 namespace oprl {
 
-__global__ __launch_bounds__(kThreads) void k_mlp_slice_tp(const MlpArgs A) {
+__device__ __forceinline__ void slice_tp_body(const MlpArgs& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = SliceLds<256>;
   constexpr int WL = lds_ld(256);
@@ -52,6 +52,18 @@ __global__ __launch_bounds__(kThreads) void k_mlp_slice_tp(const MlpArgs A) {
     store_rows(auxS, kOutLd, A.dact, A.lddact, A.dact_cols, row0, B);
 }
 
+__global__ __launch_bounds__(kThreads) void k_mlp_slice_tp(const MlpArgs A) { slice_tp_body(A); }
+
+// Two nets on the same slices in one launch (twin critics: target pair forward, online pair
+// forward + backward): one boundary and one start-up instead of two.  Two by-value argument
+// structs and two copies of the body — a runtime-selected struct would leave the kernel-argument
+// registers.
+__global__ __launch_bounds__(kThreads) void k_mlp_slice_tp2(const MlpArgs A0, const MlpArgs A1) {
+  slice_tp_body(A0);
+  __syncthreads();
+  slice_tp_body(A1);
+}
+
 bool mlp_slice_tp_shape_ok(const MlpArgs& a, int width) {
   return a.net.n_layers == 3 && a.net.dims[1] == 256 && a.net.dims[2] == 256 &&
          tp4_shape_ok(width, a.net.dims[0], a.net.dims[3]) && a.dact_cols <= kNarrowMax &&
@@ -59,7 +71,10 @@ bool mlp_slice_tp_shape_ok(const MlpArgs& a, int width) {
 }
 
 hipError_t init_slice_tp_attrs() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_slice_tp),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_slice_tp),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_slice_tp2),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -67,6 +82,13 @@ hipError_t launch_mlp_slice_tp(const MlpArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
   const size_t lds = sizeof(float) * SliceLds<256>::total(2);
   hipLaunchKernelGGL(k_mlp_slice_tp, dim3(slices, 4), dim3(kThreads), lds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_mlp_slice_tp2(const MlpArgs& a0, const MlpArgs& a1, hipStream_t st) {
+  const int slices = (a0.B + kR - 1) / kR;
+  const size_t lds = sizeof(float) * SliceLds<256>::total(2);
+  hipLaunchKernelGGL(k_mlp_slice_tp2, dim3(slices, 4), dim3(kThreads), lds, st, a0, a1);
   return hipGetLastError();
 }
 
