@@ -20,7 +20,10 @@ CASES = [("DDPG walker B=256", DDPG, 24, 6, 256, {}),
          ("SAC walker tuned B=256", SAC, 24, 6, 256, dict(log_every=10 ** 9, tune_alpha=True)),
          ("TQC walker B=256", TQC, 24, 6, 256, dict(log_every=10 ** 9))]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+only = sys.argv[2] if len(sys.argv) > 2 else ""     # substring filter on the case name
 for name, cls, S, A, B, kw in CASES:
+    if only and only not in name:
+        continue
     t.manual_seed(0)
     algo = cls(logger=NullLogger(), state_dim=S, action_dim=A, device="cuda", max_batch=B, **kw).create()
     batch = [t.randn(B, S, device="cuda"), t.rand(B, A, device="cuda") * 2 - 1, t.rand(B, 1, device="cuda"),
