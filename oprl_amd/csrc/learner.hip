@@ -750,7 +750,8 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     h->opt_step_critic += 1;
     DwArgs dw;
     dw.items = h->items_host.data(); dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
-    dw.B = B; dw.n_part = tp_generic(h, c.critics[0], B) ? 4 : 1; dw.trace = nullptr; dw.use_row_scale = 0; dw.apply_only = 0;
+    dw.B = B; dw.n_part = tp_generic(h, c.critics[0], B) ? 4 : 1; dw.use_row_scale = 0; dw.apply_only = 0;
+    dw.trace = h->trace != nullptr ? h->trace + (size_t)4 * 64 * kTraceStamps * 2 : nullptr;   // slot 4
     dw.ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, 1.0f);
     HIPC(launch_dw_prof(dw, st));
   }
@@ -852,7 +853,8 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     h->opt_step_actor += 1;
     DwArgs dw;
     dw.items = h->items_host.data() + h->n_items_critic; dw.n_items = h->n_items_actor;
-    dw.total_tiles = h->tiles_actor; dw.B = B; dw.n_part = tp_generic(h, c.actor, B) ? 4 : 1; dw.trace = nullptr; dw.use_row_scale = 0; dw.apply_only = 0;
+    dw.total_tiles = h->tiles_actor; dw.B = B; dw.n_part = tp_generic(h, c.actor, B) ? 4 : 1; dw.use_row_scale = 0; dw.apply_only = 0;
+    dw.trace = h->trace != nullptr ? h->trace + (size_t)5 * 64 * kTraceStamps * 2 : nullptr;   // slot 5
     dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, c.actor.theta_target != nullptr, 1.0f);
     HIPC(launch_dw_prof(dw, st));
   }
