@@ -183,3 +183,20 @@ def test_generic_launches_cluster_vs_single_cu(algo, monkeypatch):
     for m in ("actor", "critic", "critic_target"):
         assert t.isfinite(getattr(tp, m)._oprl_arena).all()
         assert _close(getattr(tp, m)._oprl_arena, getattr(one, m)._oprl_arena, 1e-4), m
+
+
+@pytest.mark.parametrize("algo", ["ddpg", "td3"])
+def test_fused_runs_are_deterministic(algo):
+    """The cluster exchanges sum in member order and the hand-offs are data-tagged, so two runs of the
+    same update stream agree bit for bit (a timed-out exchange would also show up here as NaN)."""
+    from tests.test_gpu_callers import _filled_buffer
+    outs = []
+    for _ in range(2):
+        a = _ddpg(max_batch=256) if algo == "ddpg" else _td3(24, max_batch=256)
+        buf = _filled_buffer()
+        for _ in range(4):
+            a.learner.step_n(buf.handle, 500, 256, seed=21)
+        t.cuda.synchronize()
+        assert t.isfinite(a.actor._oprl_arena).all() and t.isfinite(a.critic._oprl_arena).all()
+        outs.append((a.actor._oprl_arena.clone(), a.critic._oprl_arena.clone()))
+    assert t.equal(outs[0][0], outs[1][0]) and t.equal(outs[0][1], outs[1][1])
