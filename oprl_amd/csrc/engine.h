@@ -138,72 +138,6 @@ __device__ __forceinline__ void tile_mac(const float* __restrict__ Xs, int ldx,
 }
 
 // ---------------------------------------------------------------------------
-// Small-GEMM prefetch.  The first layer, the narrow output layer, the backward of
-// the output layer and the action-column gradient stream only a few KB per wave,
-// so their cost is one exposed L2/HBM miss (~1-2.5 us measured), not bandwidth.
-// prefetch_frags() issues a wave's share of such a GEMM (the same (tile, steps)
-// assignment gemm_packed makes) one stage early, into kFrag registers; passing
-// the result to gemm_packed makes it skip its own loads.  Valid only when the
-// wave's share fits: wide GEMMs with NT/kWaves tiles x NS steps <= kFrag, narrow
-// GEMMs with ceil(NS / (kWaves/NT)) <= kFrag (use frag_fits()).
-// ---------------------------------------------------------------------------
-constexpr int kFrag = 4;
-// Measured on MI355X: prefetching the small GEMMs' fragments changes nothing (their cost is
-// barrier skew + issue, not the weight miss) and costs 16-32 VGPRs, so it is compiled out.
-constexpr bool kUseFrag = false;
-struct Frag {
-  f32x4 b[kFrag];
-};
-
-__host__ __device__ inline bool frag_fits(int NT, int NS) {
-  if (NT >= kWaves) return (NT / kWaves) * NS <= kFrag && NT % kWaves == 0;
-  return cdiv(NS, kWaves / NT) <= kFrag;
-}
-
-__device__ __forceinline__ Frag prefetch_frags(const float* __restrict__ pack, int NT, int NS) {
-  Frag f;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int d = 0; d < kFrag; ++d) f.b[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (NT >= kWaves) {
-    const int per = NT / kWaves;
-#pragma unroll
-    for (int d = 0; d < kFrag; ++d) {
-      const int tt = d / max(NS, 1), s = d - tt * NS;   // d enumerates (tile-of-wave, step)
-      if (tt < per) f.b[d] = ld4(pack + ((size_t)(wave + tt * kWaves) * NS + s) * 256 + lane * 4);
-    }
-  } else {
-    const int wpt = kWaves / NT;
-    const int tile = wave / wpt, part = wave - tile * wpt;
-    const int per = cdiv(NS, wpt);
-    const int s0 = part * per, s1 = min(NS, s0 + per);
-    if (tile < NT) {
-#pragma unroll
-      for (int d = 0; d < kFrag; ++d)
-        if (s0 + d < s1) f.b[d] = ld4(pack + ((size_t)tile * NS + s0 + d) * 256 + lane * 4);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE (hipcc would sink them to the use)
-  return f;
-}
-
-// acc += X[kR, 16*s0 .. 16*s1) · (preloaded fragments f.b[d0 ..])
-__device__ __forceinline__ void tile_mac_pre(const float* __restrict__ Xs, int ldx, const Frag& f,
-                                             int d0, int s0, int s1, f32x4& acc) {
-  const int lane = threadIdx.x & 63;
-  const float* xrow = Xs + (lane & 15) * ldx + 4 * (lane >> 4);
-#pragma unroll
-  for (int d = 0; d < kFrag; ++d) {
-    const int s = s0 + d - d0;
-    if (d >= d0 && s < s1) {
-      const f32x4 a4 = ld4(xrow + 16 * s);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc = mfma4(a4[t], f.b[d][t], acc);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
 // OUT[kR, 16*NT) = epilogue(X[kR, 16*NS) · pack)   — every GEMM of the slice.
 //   NT >= kWaves ("wide", NT a multiple of kWaves): wave w owns tiles w, w+16, ..
 //       over the whole contraction; epi(row, col, v) is applied from registers.
@@ -225,36 +159,13 @@ __device__ __forceinline__ void gemm_packed(const float* __restrict__ Xs, int ld
                                             const float* __restrict__ pack, int NT, int NS,
                                             float* __restrict__ scratch,
                                             const float* __restrict__ bias, int nbias, Epi&& epi,
-                                            bool use_pre, const Frag& pre, DStamp dstamp = DStamp(),
-                                            int tile_stride = 0) {
+                                            DStamp dstamp = DStamp(), int tile_stride = 0) {
   // tile_stride: floats between two tiles' step-0 blocks; 0 = NS*256 (a whole pack).  A
   // caller contracting over a sub-range of a pack's steps passes the pack's full stride.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
   const size_t tstride = tile_stride > 0 ? (size_t)tile_stride : (size_t)NS * 256;
   if (NT >= kWaves) {
-    if (use_pre) {   // fragments already in registers: (tile-of-wave, step) order
-      const int per = NT / kWaves;
-      float bv[kFrag];
-#pragma unroll
-      for (int tt = 0; tt < kFrag; ++tt) {
-        const int col = 16 * (wave + tt * kWaves) + i;
-        bv[tt] = (bias != nullptr && tt < per && col < nbias) ? bias[col] : 0.f;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();      // X visibility (the weight loads were issued long ago)
-#pragma unroll
-      for (int tt = 0; tt < kFrag; ++tt) {
-        if (tt < per) {
-          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-          tile_mac_pre(Xs, ldx, pre, tt * NS, 0, NS, acc);
-          const int tile = wave + tt * kWaves;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) epi(kk * 4 + r, 16 * tile + i, acc[r] + bv[tt]);
-        }
-      }
-      return;
-    }
 #pragma unroll 1
     for (int tile = wave; tile < NT; tile += kWaves) {
       const int col = 16 * tile + i;
@@ -278,11 +189,7 @@ __device__ __forceinline__ void gemm_packed(const float* __restrict__ Xs, int ld
     const float rb = (bias != nullptr && rmine && rcol < nbias) ? bias[rcol] : 0.f;
     __builtin_amdgcn_sched_barrier(0);
     dstamp();
-    if (use_pre) {
-      __syncthreads();
-      dstamp();
-      if (tile < NT && s0 < s1) tile_mac_pre(Xs, ldx, pre, 0, s0, s1, acc);
-    } else if (tile < NT && s0 < s1) {
+    if (tile < NT && s0 < s1) {
       tile_mac(Xs, ldx, pack + (size_t)tile * tstride, s0, s1, acc, true);
     } else {
       __syncthreads();   // idle wave: still owes the X-visibility barrier
@@ -311,17 +218,6 @@ __device__ __forceinline__ void gemm_packed(const float* __restrict__ Xs, int ld
     __syncthreads();
     dstamp();
   }
-}
-
-template <class Epi>
-__device__ __forceinline__ void gemm_packed(const float* __restrict__ Xs, int ldx,
-                                            const float* __restrict__ pack, int NT, int NS,
-                                            float* __restrict__ scratch,
-                                            const float* __restrict__ bias, int nbias, Epi&& epi) {
-  Frag none;
-#pragma unroll
-  for (int d = 0; d < kFrag; ++d) none.b[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  gemm_packed(Xs, ldx, pack, NT, NS, scratch, bias, nbias, static_cast<Epi&&>(epi), false, none);
 }
 
 // ---------------------------------------------------------------------------
@@ -410,19 +306,13 @@ struct SliceLds {
 // layers 1.. (the hidden activations) are also stored to Xg[l] ([B, WIDTH]).
 // Result: outS[kR][kOutLd] columns [0, dims[L]); pad columns up to the next
 // multiple of 16 are written as zero.
-// Latency hiding: `l0` (optional) holds layer 0's fragments, prefetched by the
-// caller before it loaded the inputs; the output layer's fragments are requested
-// before the last hidden GEMM; `next_pack`/`next_out` (optional) prefetch another
-// small GEMM (the next net's layer 0 in a chain, or this net's output-layer
-// backward) at the same point.
+// (Prefetching the small GEMMs' fragments a stage early was measured not to pay:
+// profiles/r01b_experiments.txt #2.)
 template <int WIDTH, class Stamp>
 __device__ __forceinline__ void mlp_forward_slice(const Net& net, const float* x0s, float* hbase,
                                                   float* outS, float* scr,
                                                   float* const (&Xg)[kMaxLayers], bool store_x,
-                                                  int row0, int B, Stamp&& stamp,
-                                                  bool have_l0, const Frag& l0,
-                                                  const float* next_pack, int next_NT, int next_NS,
-                                                  Frag& next_out) {
+                                                  int row0, int B, Stamp&& stamp) {
   constexpr int WL = lds_ld(WIDTH);
   constexpr int HB = kR * WL;
   constexpr int NTW = WIDTH / 16;
@@ -430,29 +320,16 @@ __device__ __forceinline__ void mlp_forward_slice(const Net& net, const float* x
   const int N = pick(net.dims, L);
   const int NTo = cdiv(N, 16);
   const float* pf_out = pick(net.pf, L - 1);
-  const bool pre_out = kUseFrag && frag_fits(NTo, NTW);
-  Frag fo;
-#pragma unroll
-  for (int d = 0; d < kFrag; ++d) fo.b[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (L == 2) {   // no hidden GEMM to hide behind: request now, before layer 0
-    if (pre_out) fo = prefetch_frags(pf_out, NTo, NTW);
-    if (kUseFrag && next_pack != nullptr) next_out = prefetch_frags(next_pack, next_NT, next_NS);
-  }
   {
     const float* bias = net.b[0];
     float* Ys = hbase;
     gemm_packed(x0s, kX0Ld, net.pf[0], NTW, cdiv(net.dims[0], 16), scr, bias, WIDTH,
-                [&](int row, int col, float v) { Ys[row * WL + col] = fmaxf(v, 0.f); },
-                kUseFrag && have_l0, l0);
+                [&](int row, int col, float v) { Ys[row * WL + col] = fmaxf(v, 0.f); });
   }
   stamp();
 #pragma unroll
   for (int l = 1; l < kMaxLayers - 1; ++l) {
     if (l < L - 1) {
-      if (l == L - 2) {   // last hidden GEMM: the small GEMMs that follow it load now
-        if (pre_out) fo = prefetch_frags(pf_out, NTo, NTW);
-        if (kUseFrag && next_pack != nullptr) next_out = prefetch_frags(next_pack, next_NT, next_NS);
-      }
       const float* bias = net.b[l];
       float* Ys = hbase + l * HB;
       gemm_packed(hbase + (l - 1) * HB, WL, net.pf[l], NTW, NTW, scr, bias, WIDTH,
@@ -463,12 +340,7 @@ __device__ __forceinline__ void mlp_forward_slice(const Net& net, const float* x
   {
     const float* bias = pick(net.b, L - 1);
     gemm_packed(hbase + (L - 2) * HB, WL, pf_out, NTo, NTW, scr, bias, N,
-                [&](int row, int col, float v) { outS[row * kOutLd + col] = col < N ? v : 0.f; },
-                pre_out, fo
-#ifdef OPRL_TRACE_NARROW
-                , [&]() { stamp(); }
-#endif
-    );
+                [&](int row, int col, float v) { outS[row * kOutLd + col] = col < N ? v : 0.f; });
   }
   // (the narrow GEMM ended with a barrier: every hidden buffer is complete)
   if (store_x) {
@@ -476,18 +348,6 @@ __device__ __forceinline__ void mlp_forward_slice(const Net& net, const float* x
     for (int l = 1; l < kMaxLayers; ++l)
       if (l < L) store_rows4(hbase + (l - 1) * HB, WL, Xg[l], WIDTH, WIDTH, row0, B);
   }
-}
-
-template <int WIDTH, class Stamp>
-__device__ __forceinline__ void mlp_forward_slice(const Net& net, const float* x0s, float* hbase,
-                                                  float* outS, float* scr,
-                                                  float* const (&Xg)[kMaxLayers], bool store_x,
-                                                  int row0, int B, Stamp&& stamp) {
-  Frag none, sink;
-#pragma unroll
-  for (int d = 0; d < kFrag; ++d) none.b[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  mlp_forward_slice<WIDTH>(net, x0s, hbase, outS, scr, Xg, store_x, row0, B, stamp, false, none,
-                           nullptr, 0, 0, sink);
 }
 
 // Backward.  On entry doutS[kR][kOutLd] holds dLoss/d(out) with ZERO padding up
@@ -503,10 +363,7 @@ __device__ __forceinline__ void mlp_backward_slice(const Net& net, const float* 
                                                    float* hbase, float* scr,
                                                    float* const (&dYg)[kMaxLayers], int row0,
                                                    int B, int dact_col0, int dact_cols,
-                                                   float* dactS, Stamp&& stamp,
-                                                   bool have_out, const Frag& out_bwd,
-                                                   const float* next_pack, int next_NT, int next_NS,
-                                                   Frag& next_out) {
+                                                   float* dactS, Stamp&& stamp) {
   constexpr int WL = lds_ld(WIDTH);
   constexpr int HB = kR * WL;
   constexpr int NTW = WIDTH / 16;
@@ -516,22 +373,14 @@ __device__ __forceinline__ void mlp_backward_slice(const Net& net, const float* 
   int ns = cdiv(pick(net.dims, L), 16);
   const int K0 = net.dims[0];
   const int NT0 = cdiv(K0, 16);
-  const bool pre_dact = kUseFrag && dact_cols > 0 && frag_fits(NT0, NTW);
-  Frag fd;
-#pragma unroll
-  for (int d = 0; d < kFrag; ++d) fd.b[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int l = kMaxLayers - 1; l >= 1; --l) {
     if (l <= L - 1) {
-      if (l == 1) {   // last wide GEMM of this backward: what follows it loads now
-        if (pre_dact) fd = prefetch_frags(net.pb[0], NT0, NTW);
-        if (kUseFrag && next_pack != nullptr) next_out = prefetch_frags(next_pack, next_NT, next_NS);
-      }
       float* dx = hbase + (l - 1) * HB;   // holds H (mask) now, dX afterwards
       gemm_packed(dy, ldy, net.pb[l], NTW, ns, scr, nullptr, 0, [&](int row, int col, float v) {
         float* p = dx + row * WL + col;
         *p = *p > 0.f ? v : 0.f;
-      }, kUseFrag && have_out && l == L - 1, out_bwd);
+      });
       if (dYg[l - 1] != nullptr) {
         __syncthreads();
         store_rows4(dx, WL, dYg[l - 1], WIDTH, WIDTH, row0, B);
@@ -547,21 +396,8 @@ __device__ __forceinline__ void mlp_backward_slice(const Net& net, const float* 
     gemm_packed(dy, WL, net.pb[0], NT0, NTW, scr, nullptr, 0, [&](int row, int col, float v) {
       const int c = col - dact_col0;
       if (c >= 0 && c < dact_cols) dactS[row * kOutLd + c] = v;
-    }, pre_dact, fd);
+    });
   }
-}
-
-template <int WIDTH, class Stamp>
-__device__ __forceinline__ void mlp_backward_slice(const Net& net, const float* doutS,
-                                                   float* hbase, float* scr,
-                                                   float* const (&dYg)[kMaxLayers], int row0,
-                                                   int B, int dact_col0, int dact_cols,
-                                                   float* dactS, Stamp&& stamp) {
-  Frag none, sink;
-#pragma unroll
-  for (int d = 0; d < kFrag; ++d) none.b[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  mlp_backward_slice<WIDTH>(net, doutS, hbase, scr, dYg, row0, B, dact_col0, dact_cols, dactS,
-                            stamp, false, none, nullptr, 0, 0, sink);
 }
 
 }  // namespace oprl

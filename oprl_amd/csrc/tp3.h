@@ -117,9 +117,6 @@ __device__ __forceinline__ void tp3_forward(const Net& net, const float* x0s, fl
   const int tpc = NTW / tp.nc;          // tiles (= macro steps) per member
   const int c0 = tp.c * tpc * 16;
   const int N = net.dims[3];
-  Frag none;
-#pragma unroll
-  for (int d = 0; d < kFrag; ++d) none.b[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   gemm_packed(x0s, kX0Ld, net.pf[0], NTW, cdiv(net.dims[0], 16), scr, net.b[0], WIDTH,
               [&](int row, int col, float v) { h1[row * WL + col] = fmaxf(v, 0.f); });
   // (the next GEMM takes the barrier that publishes h1)
@@ -131,7 +128,7 @@ __device__ __forceinline__ void tp3_forward(const Net& net, const float* x0s, fl
   // row-parallel output layer: contract over this member's columns only
   gemm_packed(h2 + c0, WL, net.pf[2] + (size_t)tp.c * tpc * 256, cdiv(N, 16), tpc, scr, nullptr, 0,
               [&](int row, int col, float v) { outS[row * kOutLd + col] = col < N ? v : 0.f; },
-              false, none, NoStamp(), NTW * 256);
+              NoStamp(), NTW * 256);
   tp_allreduce(outS, N, net.b[2], outS, tp);
   sf();
 }
@@ -151,9 +148,6 @@ __device__ __forceinline__ void tp3_backward(const Net& net, const float* doutS,
   const int tpc = NTW / tp.nc;
   const int c0 = tp.c * tpc * 16;
   const int N = net.dims[3], NSo = cdiv(N, 16);
-  Frag none;
-#pragma unroll
-  for (int d = 0; d < kFrag; ++d) none.b[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   // dz2[:, mine] = (dout · W3^T)[:, mine] ⊙ (h2 > 0), in place
   gemm_packed(doutS, kOutLd, net.pb[2] + (size_t)tp.c * tpc * NSo * 256, tpc, NSo, scr, nullptr, 0,
               [&](int row, int col, float v) {
@@ -169,7 +163,7 @@ __device__ __forceinline__ void tp3_backward(const Net& net, const float* doutS,
                 float* p = h1 + row * WL + col;
                 *p = *p > 0.f ? v : 0.f;
               },
-              false, none, NoStamp(), NTW * 256);
+              NoStamp(), NTW * 256);
   __syncthreads();
   if (st.dY0 != nullptr)
     store_rows4(h1, WL, st.dY0 + (size_t)tp.c * st.dY0_stride, WIDTH, WIDTH, row0, B);
