@@ -127,7 +127,7 @@ static hipError_t chain_after(hipStream_t st) {
 size_t mlp_slice_lds_bytes(int width, int n_layers);
 hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
 hipError_t launch_mlp_slice_tp(const MlpArgs& a, hipStream_t st);
-hipError_t launch_mlp_slice_tp2(const MlpArgs& a0, const MlpArgs& a1, hipStream_t st);
+hipError_t launch_mlp_slice_tp2(const MlpArgs& a0, const MlpArgs& a1, int n_cus, hipStream_t st);
 hipError_t init_slice_tp_attrs();
 bool mlp_slice_tp_shape_ok(const MlpArgs& a, int width);
 hipError_t init_kernel_attrs();
@@ -544,7 +544,7 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
     RC(rc);
     if (h->pair_n == 2 && h->pair_args[0].B == h->pair_args[1].B) {
       prof_begin(0, st);
-      hipError_t e = launch_mlp_slice_tp2(h->pair_args[0], h->pair_args[1], st);
+      hipError_t e = launch_mlp_slice_tp2(h->pair_args[0], h->pair_args[1], h->n_cus, st);
       prof_end(st);
       HIPC(e);
     } else {

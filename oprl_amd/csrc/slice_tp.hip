@@ -64,6 +64,13 @@ __global__ __launch_bounds__(kThreads) void k_mlp_slice_tp2(const MlpArgs A0, co
   slice_tp_body(A1);
 }
 
+// The same pair side by side (grid.z = net) when both fit on the chip at once: 2 x slices x 4
+// workgroups <= CUs (B <= 512 on MI355X).  Each net has its own exchange area.
+__global__ __launch_bounds__(kThreads) void k_mlp_slice_tp2z(const MlpArgs A0, const MlpArgs A1) {
+  if (blockIdx.z == 0) slice_tp_body(A0);
+  else slice_tp_body(A1);
+}
+
 bool mlp_slice_tp_shape_ok(const MlpArgs& a, int width) {
   return a.net.n_layers == 3 && a.net.dims[1] == 256 && a.net.dims[2] == 256 &&
          tp4_shape_ok(width, a.net.dims[0], a.net.dims[3]) && a.dact_cols <= kNarrowMax &&
@@ -74,7 +81,10 @@ hipError_t init_slice_tp_attrs() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_slice_tp),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_slice_tp2),
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_slice_tp2),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_slice_tp2z),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -85,10 +95,16 @@ hipError_t launch_mlp_slice_tp(const MlpArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_mlp_slice_tp2(const MlpArgs& a0, const MlpArgs& a1, hipStream_t st) {
+hipError_t launch_mlp_slice_tp2(const MlpArgs& a0, const MlpArgs& a1, int n_cus, hipStream_t st) {
   const int slices = (a0.B + kR - 1) / kR;
   const size_t lds = sizeof(float) * SliceLds<256>::total(2);
-  hipLaunchKernelGGL(k_mlp_slice_tp2, dim3(slices, 4), dim3(kThreads), lds, st, a0, a1);
+  if (2 * slices * 4 <= n_cus) {        // side by side; the second net's exchanges in their own area
+    MlpArgs b1 = a1;
+    b1.tp_xbuf = a1.tp_xbuf + (size_t)slices * kTpStages * 4 * kTpBlk;
+    hipLaunchKernelGGL(k_mlp_slice_tp2z, dim3(slices, 4, 2), dim3(kThreads), lds, st, a0, b1);
+  } else {
+    hipLaunchKernelGGL(k_mlp_slice_tp2, dim3(slices, 4), dim3(kThreads), lds, st, a0, a1);
+  }
   return hipGetLastError();
 }
 
