@@ -10,6 +10,7 @@
 //   k_tqc_target         row-wise bitonic sort of 125 quantiles + truncation + TD
 //
 // Reference op groups replaced: SURVEY.md §2.2 K2-K13.
+#include <cmath>
 #include "kernels.h"
 #include "philox.h"
 #include "slice_head.h"
@@ -351,17 +352,26 @@ __global__ void k_polyak_flat(float* tt, const float* th, long n, float tau, flo
 // log_alpha Adam step in float64 like the reference's 0-dim double tensor
 // (sac.py:65-70,132-141; tqc.py:105,163,175-177): grad = -(H_target + mean logp).
 // If grad_out != nullptr only the gradient is exported (data-parallel mode).
+__device__ __forceinline__ double shfl_xor_f64(double x, int m) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __shfl_xor(lo, m);
+  hi = __shfl_xor(hi, m);
+  return __hiloint2double(hi, lo);
+}
+
+// bc1 = 1 - beta1^step and bc2_sqrt = sqrt(1 - beta2^step) arrive from the host (it knows the
+// step; a device-side double pow() alone cost several microseconds of this scalar update).
 __global__ void k_alpha_step(double* log_alpha, double* m, double* v, const float* logp, int B,
                              float target_entropy, double lr, double beta1, double beta2, double eps,
-                             int step, double* grad_out, const double* grad_in, float grad_scale) {
-  __shared__ double red[256];
+                             double bc1, double bc2_sqrt, double* grad_out, const double* grad_in,
+                             float grad_scale) {
+  __shared__ double red[4];
   double s = 0.0;
-  if (grad_in == nullptr)
+  if (grad_in == nullptr) {
     for (int idx = threadIdx.x; idx < B; idx += blockDim.x) s += (double)logp[idx];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += shfl_xor_f64(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
   }
   if (threadIdx.x != 0) return;
@@ -370,17 +380,15 @@ __global__ void k_alpha_step(double* log_alpha, double* m, double* v, const floa
     g = *grad_in * (double)grad_scale;
   } else {
     // reference: mean of fp32 logp in fp32, then promoted
-    const float mean32 = (float)(red[0] / (double)B);
+    const float mean32 = (float)((((red[0] + red[1]) + red[2]) + red[3]) / (double)B);
     g = -((double)target_entropy + (double)mean32);
   }
   if (grad_out != nullptr) { *grad_out = g; return; }
-  const double b1 = beta1, b2 = beta2;
   double mm = *m, vv = *v;
-  mm = mm + (g - mm) * (1.0 - b1);
-  vv = vv * b2 + (1.0 - b2) * g * g;
-  const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
-  const double denom = sqrt(vv) / sqrt(bc2) + (double)eps;
-  *log_alpha = *log_alpha - ((double)lr / bc1) * (mm / denom);
+  mm = mm + (g - mm) * (1.0 - beta1);
+  vv = vv * beta2 + (1.0 - beta2) * g * g;
+  const double denom = sqrt(vv) / bc2_sqrt + eps;
+  *log_alpha = *log_alpha - (lr / bc1) * (mm / denom);
   *m = mm;
   *v = vv;
 }
@@ -536,8 +544,9 @@ hipError_t launch_alpha_step(double* log_alpha, double* m, double* v, const floa
                              float target_entropy, double lr, double beta1, double beta2, double eps,
                              int step, double* grad_out, const double* grad_in, float grad_scale,
                              hipStream_t st) {
+  const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2_sqrt = std::sqrt(1.0 - std::pow(beta2, (double)step));
   hipLaunchKernelGGL(k_alpha_step, dim3(1), dim3(256), 0, st, log_alpha, m, v, logp, B,
-                     target_entropy, lr, beta1, beta2, eps, step, grad_out, grad_in, grad_scale);
+                     target_entropy, lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_out, grad_in, grad_scale);
   return hipGetLastError();
 }
 

@@ -1196,9 +1196,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->no_lean = (nl != nullptr && atoi(nl) != 0) ? 1 : 0;
     // the generic per-net launches on clusters of 4 (slice_tp.hip): any net of the common shape
     const char* ng = getenv("OPRL_AMD_NO_TP_GENERIC");
-    const bool shape = h->w_actor == 256 && h->w_critic == 256 && cfg->actor.n_layers == 3 &&
-                       cfg->critics[0].n_layers == 3;
-    h->tp_generic_on = shape && !h->no_lean && h->ncl == 4 && !(ng != nullptr && atoi(ng) != 0);
+    // (decided per net by tp_generic(): TQC's 512-wide critics stay on k_mlp_slice, its actor moves)
+    h->tp_generic_on = !h->no_lean && h->ncl == 4 && !(ng != nullptr && atoi(ng) != 0);
   }
   if (h->fused || h->tp_generic_on) {
     const size_t slices = (size_t)(h->Bmax + kR - 1) / kR;
