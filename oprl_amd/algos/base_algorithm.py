@@ -148,12 +148,24 @@ class HipLearner:
             out.append(self._actor_target_group._oprl_arena)
         return out
 
+    # check_bound() runs on every update(): walking the module trees (``module.parameters()``) cost more
+    # host time than the four kernel launches, so the Parameter objects are looked up once.  They stay
+    # valid across ``module.to()`` / ``load_state_dict`` (which change ``.data`` / the version in place).
+    def _param_cache(self):
+        c = getattr(self, "_pcache", None)
+        if c is None:
+            a, at, cs, cts = self._mlps
+            mlps = [a, *([at] if at is not None else []), *cs, *cts]
+            first = [next(m.parameters()) for m in mlps]
+            every = [p for m in [a, at, *cs, *cts] if m is not None for p in m.parameters()]
+            c = self._pcache = (first, every)
+        return c
+
     def _snapshot_ptrs(self):
-        a, at, cs, cts = self._mlps
-        return tuple(next(m.parameters()).data_ptr() for m in [a, *( [at] if at is not None else []), *cs, *cts])
+        return tuple(p.data_ptr() for p in self._param_cache()[0])
 
     def _snapshot_versions(self):
-        return tuple(p._version for m in self._all_mlps for p in m.parameters())
+        return tuple(p._version for p in self._param_cache()[1])
 
     def sync_params(self) -> None:
         """Rebuild the fragment-order packs from the master parameters.  Called
@@ -231,6 +243,10 @@ class HipLearner:
         B = state.shape[0]
 
         def f(x, cols):
+            # fast path: a resident, contiguous fp32 batch (what the replay's sample() returns)
+            if (isinstance(x, t.Tensor) and x.dtype == t.float32 and x.device == dev and x.is_contiguous()
+                    and x.numel() == B * cols):
+                return x
             x = t.as_tensor(x).to(device=dev, dtype=t.float32).reshape(B, cols)
             return x.contiguous()
 
