@@ -39,7 +39,7 @@ using oprl::set_err;
 namespace {
 
 constexpr int kGatherThreads = 256;
-constexpr int kSamplesPerWg = 32;
+constexpr int kSamplesPerWg = 16;   // more workgroups, one copy round per thread at walker dims
 constexpr int kStageRows = 4096;
 constexpr int kMaxEndsLds = 2048; // episode-end table entries staged in LDS by the gather  // transitions staged on the host between flushes
 
@@ -99,15 +99,28 @@ __global__ __launch_bounds__(kGatherThreads) void k_replay_gather(const GatherAr
   }
   __syncthreads();
   const int n_here = min(kSamplesPerWg, G.B - base);
-  for (int idx = tid; idx < n_here * W; idx += kGatherThreads) {
-    const int smp = idx / W, c = idx - smp * W;
-    const long e = s_ep[smp], t = s_t[smp];
-    float v;
-    if (c < 2 * S) v = G.states[(e * (G.L + 1) + t) * S + c];            // s | s' contiguous
-    else if (c < 2 * S + A) v = G.actions[(e * G.L + t) * A + (c - 2 * S)];
-    else if (c == 2 * S + A) v = G.rewards[e * G.L + t];
-    else v = G.dones[e * G.L + t];
-    stage[idx] = v;
+  // Rows -> LDS.  Branch-free source selection and all of a thread's loads issued before its LDS
+  // stores: an if/else per kind (s|s', a, r, d) diverges inside a wave and turns the copy into several
+  // serialised load -> wait -> store round trips (the kernel is pure latency: 8.5 us at B = 256 before).
+  constexpr int kU = 4;
+  for (int i0 = 0; i0 < n_here * W; i0 += kU * kGatherThreads) {
+    float v[kU];
+#pragma unroll
+    for (int j = 0; j < kU; ++j) {
+      const int idx = min(i0 + j * kGatherThreads + tid, n_here * W - 1);
+      const int smp = idx / W, c = idx - smp * W;
+      const long e = s_ep[smp], t = s_t[smp];
+      const float* src = G.states + (e * (G.L + 1) + t) * S + c;                       // s | s' contiguous
+      if (c >= 2 * S) src = G.actions + (e * G.L + t) * A + (c - 2 * S);
+      if (c == 2 * S + A) src = G.rewards + e * G.L + t;
+      if (c == 2 * S + A + 1) src = G.dones + e * G.L + t;
+      v[j] = *src;
+    }
+#pragma unroll
+    for (int j = 0; j < kU; ++j) {
+      const int idx = i0 + j * kGatherThreads + tid;
+      if (idx < n_here * W) stage[idx] = v[j];
+    }
   }
   __syncthreads();
   for (int idx = tid; idx < n_here * S; idx += kGatherThreads) {
