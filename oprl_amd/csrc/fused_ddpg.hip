@@ -104,11 +104,15 @@ __device__ __forceinline__ void load_batch(const BatchSrc& P, int row0, int B, i
       const int row = idx / W, c = idx - row * W;
       if (row0 + row >= B) continue;
       const long e = meta[row], t = meta[kR + row];
-      if (c < S) xa[row * kX0Ld + c] = P.states[(e * (P.L + 1) + t) * S + c];
-      else if (c < 2 * S) xb[row * kX0Ld + (c - S)] = P.states[(e * (P.L + 1) + t) * S + c];
-      else if (c < 2 * S + A) xa[row * kX0Ld + S + (c - 2 * S)] = P.actions[(e * P.L + t) * A + (c - 2 * S)];
-      else if (c == 2 * S + A) rS[row] = P.rewards[e * P.L + t];
-      else dS[row] = P.dones[e * P.L + t];
+      // branch-free: one load and one LDS store per element (an if/else per kind diverges inside
+      // a wave and serialises load -> wait -> store)
+      const float* src = P.states + (e * (P.L + 1) + t) * S + c;          // s | s' contiguous
+      float* dst = xa + row * kX0Ld + c;
+      if (c >= S) dst = xb + row * kX0Ld + (c - S);
+      if (c >= 2 * S) { src = P.actions + (e * P.L + t) * A + (c - 2 * S); dst = xa + row * kX0Ld + S + (c - 2 * S); }
+      if (c == 2 * S + A) { src = P.rewards + e * P.L + t; dst = rS + row; }
+      if (c == 2 * S + A + 1) { src = P.dones + e * P.L + t; dst = dS + row; }
+      *dst = *src;
     }
   } else {
     __syncthreads();
