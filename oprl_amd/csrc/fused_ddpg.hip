@@ -402,11 +402,34 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   lds_zero(xa, 2 * kR * kX0Ld);
   if constexpr (LEAN) lds_zero(auxS, kR * kOutLd);   // the gradient tile's padding columns stay zero
   __syncthreads();
-  load_rows(xa, kX0Ld, 0, A.aX[0], A.aldx0, S, row0, B);
-  load_rows(xa, kX0Ld, S, A.pi, Ad, Ad, row0, B);
-  load_rows(piS, kX0Ld, 0, A.pi, Ad, Ad, row0, B);
-  load_rows4(ha1, WL, A.aX[1], WIDTH, WIDTH, row0, B);
-  load_rows4(ha2, WL, A.aX[2], WIDTH, WIDTH, row0, B);
+  if constexpr (LEAN) {
+    // every thread's loads first (one cold round trip), then its LDS stores: five helper calls in a
+    // row are five load -> wait -> store sequences for the threads that take part in all of them
+    constexpr int K4 = WIDTH / 4;                        // float4 per activation row
+    const int r4 = tid / K4, c4 = (tid - r4 * K4) * 4;    // kR * K4 == kThreads for WIDTH 256
+    const bool ok4 = row0 + r4 < B;
+    f32x4 v1 = f32x4{0.f, 0.f, 0.f, 0.f}, v2 = v1;
+    if (ok4) {
+      v1 = ld4(A.aX[1] + (size_t)(row0 + r4) * WIDTH + c4);
+      v2 = ld4(A.aX[2] + (size_t)(row0 + r4) * WIDTH + c4);
+    }
+    const int rs_ = tid / S, cs_ = tid - rs_ * S;          // state rows: kR * S <= 1024 here
+    const bool oks = tid < kR * S && row0 + rs_ < B;
+    const float vs = oks ? A.aX[0][(size_t)(row0 + rs_) * A.aldx0 + cs_] : 0.f;
+    const int rp_ = tid / Ad, cp_ = tid - rp_ * Ad;
+    const bool okp = tid < kR * Ad && row0 + rp_ < B;
+    const float vp = okp ? A.pi[(size_t)(row0 + rp_) * Ad + cp_] : 0.f;
+    *reinterpret_cast<f32x4*>(ha1 + r4 * WL + c4) = v1;
+    *reinterpret_cast<f32x4*>(ha2 + r4 * WL + c4) = v2;
+    if (tid < kR * S) xa[rs_ * kX0Ld + cs_] = vs;
+    if (tid < kR * Ad) { xa[rp_ * kX0Ld + S + cp_] = vp; piS[rp_ * kX0Ld + cp_] = vp; }
+  } else {
+    load_rows(xa, kX0Ld, 0, A.aX[0], A.aldx0, S, row0, B);
+    load_rows(xa, kX0Ld, S, A.pi, Ad, Ad, row0, B);
+    load_rows(piS, kX0Ld, 0, A.pi, Ad, Ad, row0, B);
+    load_rows4(ha1, WL, A.aX[1], WIDTH, WIDTH, row0, B);
+    load_rows4(ha2, WL, A.aX[2], WIDTH, WIDTH, row0, B);
+  }
   stamp();
   // ---- q = critic(s, pi) with the updated critic, and its backward down to the action
   // columns: da -> auxS[:, 0:A].  The seed -1/B is a constant, so the lean path runs both
