@@ -340,10 +340,16 @@ struct oprl_learner {
   int no_lean = 0;
   unsigned long long* xbuf = nullptr;
   size_t xbuf_granules = 0;
-  // largest cluster whose phase-1 grid (roles A, one B per critic, C) is fully co-resident, one
-  // workgroup per CU
+  // Largest cluster size for which ONE role's clusters (c x slices workgroups, one per CU) fit on the
+  // chip.  Phase 1's grid may then exceed the CU count (B > 256): workgroups are dispatched in block
+  // order — role A's clusters, then B's, then C's — role A waits for nobody, the members of a cluster
+  // are dispatched together, and a B workgroup only ever waits for an A workgroup dispatched before it,
+  // so later roles simply start as earlier workgroups retire.
+  // Measured (profiles/r01g_batch_sweep.txt): worth it for the lean clusters of 4 (B = 512: 76 -> 51 us
+  // per DDPG update); the generic passes on smaller clusters do better fully co-resident.
   int nc_cluster(int B) const {
     const int slices = (B + kR - 1) / kR;
+    if (ncl == 4 && 4 * slices <= n_cus) return 4;
     const int roles = 2 + nc;
     int c = ncl;
     while (c > 1 && roles * c * slices > n_cus) c >>= 1;

@@ -51,13 +51,15 @@ def test_fused_equals_generic(B, cluster, monkeypatch):
         assert abs(sf[k] - sg[k]) <= 1e-5 * max(abs(sg[k]), 1e-12), k
 
 
-@pytest.mark.parametrize("B", [1024, 4096])
+@pytest.mark.parametrize("B", [512, 1024, 4096])
 def test_fused_large_batches(B):
-    """Beyond 3 x 4 x ceil(B/16) <= CUs the clusters shrink (B=1024: 1 CU per slice, 192 workgroups;
-    B=4096 = the default max_batch: 768 workgroups, more than the chip holds at once — role B then
-    only ever waits for a role-A workgroup that was dispatched before it)."""
+    """Clusters of 4 (the lean passes) are kept while ONE role's clusters fit the chip,
+    4 x ceil(B/16) <= CUs: at B=512 / 1024 phase 1 has 384 / 768 workgroups for 256 CUs and the later
+    roles start as earlier workgroups retire (block order = A, B, C; a B workgroup only ever waits for
+    an A workgroup dispatched before it).  B=4096 = the default max_batch: 1 CU per slice, generic
+    passes, 768 workgroups."""
     fused, generic = _ddpg(max_batch=B), _ddpg(max_batch=B, no_fuse=True)
-    for step in range(2):
+    for step in range(3):
         batch = [x.cuda() for x in fx.make_batch(75 + step, B, 24, 6)]
         fused.update(*batch)
         generic.update(*batch)
@@ -106,6 +108,20 @@ def test_fused_td3_equals_generic(inject):
     sf, sg = fused.learner.read_scalars(), generic.learner.read_scalars()
     for k in ("critic_loss", "q_mean", "q_target_mean"):
         assert abs(sf[k] - sg[k]) <= 1e-4 * max(abs(sg[k]), 1e-6), k
+
+
+@pytest.mark.parametrize("B", [512, 1024])
+def test_fused_td3_oversubscribed_grid(B):
+    """TD3 at B=512 / 1024: phase 1 is 4 roles x 4 CUs x 32 / 64 slices = 512 / 1024 workgroups."""
+    fused, generic = _td3(max_batch=B), _td3(max_batch=B, no_fuse=True)
+    for step in range(4):
+        batch = [x.cuda() for x in fx.make_batch(60 + step, B, 17, 6)]
+        fused.update(*batch)
+        generic.update(*batch)
+    t.cuda.synchronize()
+    assert t.isfinite(fused.critic._oprl_arena).all()
+    for m in ("actor", "critic", "actor_target", "critic_target"):
+        assert _close(getattr(fused, m)._oprl_arena, getattr(generic, m)._oprl_arena, 1e-4), m
 
 
 def test_fused_td3_falls_back_without_lean_passes(monkeypatch):
