@@ -34,6 +34,7 @@ class SAC(OffPolicyAlgorithm):
     log_every: int = 5000
     max_batch: int = 4096
     export_grads: bool = False
+    no_fuse: bool = False     # True: the generic per-net launch sequence instead of the fused kernels
 
     actor: PolicyProtocol = field(init=False)
     critic: nn.Module = field(init=False)
@@ -71,7 +72,8 @@ class SAC(OffPolicyAlgorithm):
             critic_group=self.critic, critic_mlps=[self.critic.q1, self.critic.q2],
             critic_target_group=self.critic_target,
             critic_target_mlps=[self.critic_target.q1, self.critic_target.q2],
-            hp=hp, max_batch=self.max_batch, export_grads=self.export_grads, log_alpha=self.log_alpha)
+            hp=hp, max_batch=self.max_batch, export_grads=self.export_grads, log_alpha=self.log_alpha,
+            no_fuse=self.no_fuse)
         self._created = True
         return self
 

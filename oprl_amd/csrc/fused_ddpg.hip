@@ -26,6 +26,12 @@
 //            backward                                  (ddpg.py:103-107)
 //   k_dw_adam(actor)           dW + Adam + Polyak     (ddpg.py:105-107, 79-84)
 //
+// TD3 runs the same two kernels with twin critics (roles A | B1 | B2 | C, target smoothing in A);
+// SAC as well (template flag): both actor passes end in the tanh-Gaussian head, role A uses the
+// online actor and subtracts alpha log pi, phase 2 runs both critics and routes the smaller q's
+// action gradient through the head's backward (sac.py:90-141).  The temperature step stays a
+// separate small launch (k_alpha_step).
+//
 // Arithmetic and summation order are those of the generic kernels (same
 // engine.h routines, same seeds), so the two paths agree bit for bit
 // (tests/test_gpu_fused.py).  The minibatch either comes from caller pointers
@@ -33,6 +39,7 @@
 // draw and index map as k_replay_gather (step_n).
 #include "kernels.h"
 #include "philox.h"
+#include "slice_head.h"
 #include "tp4.h"
 
 namespace oprl {
@@ -62,7 +69,8 @@ struct FusedLds {   // floats
   static constexpr int h = xb + kR * kX0Ld;          // 5 hidden buffers
   static constexpr int out = h + 5 * kR * WL;
   static constexpr int aux = out + kR * kOutLd;
-  static constexpr int scr = aux + kR * kOutLd;
+  static constexpr int aux2 = aux + kR * kOutLd;     // SAC phase 2: the twin critic's action gradient
+  static constexpr int scr = aux2 + kR * kOutLd;
   static constexpr int misc = scr + kWaves * kR * 16;   // r[16] d[16] y[16] ep[16] t[16] + ends
   static constexpr int total = misc + 96 + kMaxEnds;
 };
@@ -124,6 +132,39 @@ __device__ __forceinline__ void load_batch(const BatchSrc& P, int row0, int B, i
       rS[tid] = gr < B ? P.r[gr] : 0.f;
       dS[tid] = gr < B ? P.d[gr] : 0.f;
     }
+  }
+}
+
+// SAC: tanh-Gaussian head over outS = [mean | log_std] (16 lanes per row, the first 256 threads, as
+// slice_head.h does it): the action goes to aS[row * a_ld + col] (LDS) and/or pi_g, the row's log pi
+// to lpS[row] (LDS) and/or logp_g, the raw head output to raw_g.  No barrier inside.
+__device__ __forceinline__ void gauss_head(const float* outS, int row0, int B, int Ad, const float* noise,
+                                           unsigned long long seed, unsigned long long ctr, float* aS, int a_ld,
+                                           float* lpS, float* pi_g, float* raw_g, float* logp_g) {
+  const int tid = threadIdx.x;
+  if (tid >= kR * 16) return;
+  const int row = tid >> 4, sub = tid & 15, gr = row0 + row;
+  float lp = 0.f;
+  if (gr < B) {
+    for (int col = sub; col < Ad; col += 16) {
+      const float mu = outS[row * kOutLd + col];
+      const float lsr = outS[row * kOutLd + Ad + col];
+      const float e = noise != nullptr ? noise[(size_t)gr * Ad + col] : philox_normal(seed, ctr, (unsigned)gr, (unsigned)col);
+      float a;
+      lp += gauss_elem(mu, lsr, e, &a);
+      if (aS != nullptr) aS[row * a_ld + col] = a;
+      if (pi_g != nullptr) pi_g[(size_t)gr * Ad + col] = a;
+      if (raw_g != nullptr) {
+        raw_g[(size_t)gr * 2 * Ad + col] = mu;
+        raw_g[(size_t)gr * 2 * Ad + Ad + col] = lsr;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) lp += __shfl_xor(lp, m);
+  if (sub == 0 && gr < B) {
+    if (lpS != nullptr) lpS[row] = lp;
+    if (logp_g != nullptr) logp_g[gr] = lp;
   }
 }
 
@@ -243,7 +284,7 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
   if constexpr (!LEAN) tp_bwd<WIDTH, LEAN>(critic, auxS, h1, h2, scr, tp, st, row0, B, 0, 0, auxS, stamp);
 }
 
-template <int WIDTH, bool LEAN>
+template <int WIDTH, bool LEAN, bool SAC>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<WIDTH>;
@@ -289,6 +330,15 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
     // ---- role C: actor(s) forward.  Pack rows beyond S are zero, so [s | a] serves as input.
     const Tp3Store st{A.aX[1], A.aX[2], nullptr, nullptr, 0};
     tp_fwd<WIDTH, LEAN>(A.actor, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
+    if constexpr (SAC) {
+      // pi(s) ~ tanh-Gaussian, its log-density (temperature step, actor seed) and the raw head output
+      if (lead) {
+        gauss_head(outS, row0, B, Ad, A.noise_pi, A.rng_seed_pi, A.rng_ctr, nullptr, 0, nullptr, A.pi, A.raw, A.logp);
+        store_rows(xa, kX0Ld, A.aX[0], A.aldx0, S, row0, B);
+      }
+      stamp();
+      return;
+    }
     if (lead) {
       for (int idx = tid; idx < kR * Ad; idx += kThreads) {
         const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
@@ -303,8 +353,11 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   if (role == 0) {
     // ---- role A: a' = tanh(actor_target(s')) (TD3: + clipped noise), q' = critic_target(s', a')
     // (TD3: min over the twin targets), TD target                    (ddpg.py:94-95, td3.py:83-101)
-    tp_fwd<WIDTH, LEAN>(A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
-    for (int idx = tid; idx < kR * Ad; idx += kThreads) {
+    // (SAC: a' ~ pi(s') from the online actor, log pi(a'|s') kept per row     sac.py:90-97)
+    tp_fwd<WIDTH, LEAN>(SAC ? A.actor : A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
+    if constexpr (SAC)
+      gauss_head(outS, row0, B, Ad, A.noise, A.rng_seed, A.rng_ctr, xb + S, kX0Ld, yS, nullptr, nullptr, nullptr);
+    for (int idx = tid; !SAC && idx < kR * Ad; idx += kThreads) {
       const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
       float v = 0.f;
       if (gr < B) {
@@ -324,6 +377,12 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
     if (A.n_critics == 2) {
       tp_fwd<WIDTH, LEAN>(A.critic2_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
       if (tid < kR) qn = fminf(qn, outS[tid * kOutLd]);
+    }
+    if constexpr (SAC) {
+      if (tid < kR) {
+        const float alpha = A.log_alpha != nullptr ? (float)exp(*A.log_alpha) : A.alpha_const;
+        qn -= alpha * yS[tid];
+      }
     }
     if (lead && tid < kR && row0 + tid < B) {
       const float y = rS[tid] + ((1.f - dS[tid]) * A.gamma) * qn;
@@ -346,7 +405,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
 }
 
 // Role B of phase 1 for one online critic (layer inputs X[], pre-activation grads dY[]).
-template <int WIDTH, bool LEAN>
+template <int WIDTH, bool LEAN, bool SAC>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<WIDTH>;
@@ -402,6 +461,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   lds_zero(xa, 2 * kR * kX0Ld);
   if constexpr (LEAN) lds_zero(auxS, kR * kOutLd);   // the gradient tile's padding columns stay zero
   __syncthreads();
+  float g_mu = 0.f, g_ls = 0.f, g_e = 0.f;   // SAC: this thread's (row, action dim) head output and draw
   if constexpr (LEAN) {
     // every thread's loads first (one cold round trip), then its LDS stores: five helper calls in a
     // row are five load -> wait -> store sequences for the threads that take part in all of them
@@ -413,16 +473,31 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
       v1 = ld4(A.aX[1] + (size_t)(row0 + r4) * WIDTH + c4);
       v2 = ld4(A.aX[2] + (size_t)(row0 + r4) * WIDTH + c4);
     }
-    const int rs_ = tid / S, cs_ = tid - rs_ * S;          // state rows: kR * S <= 1024 here
+    const int rs_ = tid / S, cs_ = tid - rs_ * S;          // state rows: kR * S <= 2 * kThreads (S <= 96)
     const bool oks = tid < kR * S && row0 + rs_ < B;
     const float vs = oks ? A.aX[0][(size_t)(row0 + rs_) * A.aldx0 + cs_] : 0.f;
+    const int tid2 = tid + kThreads;                       // elements kThreads .. kR * S of wide states
+    const int rs2_ = tid2 / S, cs2_ = tid2 - rs2_ * S;
+    const bool oks2 = tid2 < kR * S && row0 + rs2_ < B;
+    const float vs2 = oks2 ? A.aX[0][(size_t)(row0 + rs2_) * A.aldx0 + cs2_] : 0.f;
     const int rp_ = tid / Ad, cp_ = tid - rp_ * Ad;
     const bool okp = tid < kR * Ad && row0 + rp_ < B;
     const float vp = okp ? A.pi[(size_t)(row0 + rp_) * Ad + cp_] : 0.f;
+    if constexpr (SAC) {
+      if (okp) {
+        g_mu = A.raw[(size_t)(row0 + rp_) * 2 * Ad + cp_];
+        g_ls = A.raw[(size_t)(row0 + rp_) * 2 * Ad + Ad + cp_];
+        if (A.noise_pi != nullptr) g_e = A.noise_pi[(size_t)(row0 + rp_) * Ad + cp_];
+      }
+    }
     *reinterpret_cast<f32x4*>(ha1 + r4 * WL + c4) = v1;
     *reinterpret_cast<f32x4*>(ha2 + r4 * WL + c4) = v2;
     if (tid < kR * S) xa[rs_ * kX0Ld + cs_] = vs;
+    if (tid2 < kR * S) xa[rs2_ * kX0Ld + cs2_] = vs2;
     if (tid < kR * Ad) { xa[rp_ * kX0Ld + S + cp_] = vp; piS[rp_ * kX0Ld + cp_] = vp; }
+    if constexpr (SAC) {   // the same draw as role C's forward
+      if (okp && A.noise_pi == nullptr) g_e = philox_normal(A.rng_seed_pi, A.rng_ctr, (unsigned)(row0 + rp_), (unsigned)cp_);
+    }
   } else {
     load_rows(xa, kX0Ld, 0, A.aX[0], A.aldx0, S, row0, B);
     load_rows(xa, kX0Ld, S, A.pi, Ad, Ad, row0, B);
@@ -434,6 +509,49 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   // ---- q = critic(s, pi) with the updated critic, and its backward down to the action
   // columns: da -> auxS[:, 0:A].  The seed -1/B is a constant, so the lean path runs both
   // as one pass (tp4_scalar_fb) in which q — only logged — is off the critical path.
+  if constexpr (SAC) {
+    // SAC: both online critics at (s, pi), each forward + unit-seed (-1/B) backward to the action
+    // columns; per row the smaller q routes its gradient (torch.min: ties split), then the
+    // tanh-Gaussian head backward with the entropy term             (sac.py:118-127)
+    float* d2S = smem + LY::aux2;
+    float* q1S = smem + LY::misc;
+    tp4_scalar_fb(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp);
+    if (tid < kR) q1S[tid] = outS[tid * kOutLd];
+    tp4_scalar_fb(A.critic2, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, d2S, stamp);
+    if (A.partials_a != nullptr && lead && tid < 64) {
+      float v = (tid < kR && row0 + tid < B) ? fminf(q1S[tid], outS[tid * kOutLd]) : 0.f;
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m);
+      if (tid == 0) {
+        A.partials_a[slice * 4 + 0] = 0.f;
+        A.partials_a[slice * 4 + 1] = v;
+        A.partials_a[slice * 4 + 2] = 0.f;
+      }
+    }
+    stamp();   // da ready
+    const int r_ = tid / Ad, c_ = tid - r_ * Ad;
+    const bool mine = tid < kR * Ad;
+    float dmu = 0.f, dls = 0.f;
+    if (mine && row0 + r_ < B) {
+      const float q1 = q1S[r_], q2 = outS[r_ * kOutLd];
+      const float w1 = q1 < q2 ? 1.f : (q1 == q2 ? 0.5f : 0.f);
+      const float da = w1 * auxS[r_ * kOutLd + c_] + (1.f - w1) * d2S[r_ * kOutLd + c_];
+      const float alpha = A.log_alpha != nullptr ? (float)exp(*A.log_alpha) : A.alpha_const;
+      gauss_elem_bwd(g_mu, g_ls, g_e, da, alpha * A.inv_B, &dmu, &dls);
+    }
+    if (mine) {   // in place over critic 1's action gradient; the tile's other columns are zero
+      auxS[r_ * kOutLd + c_] = dmu;
+      auxS[r_ * kOutLd + Ad + c_] = dls;
+      if (lead && row0 + r_ < B) {
+        A.adY[2][(size_t)(row0 + r_) * A.alddo + c_] = dmu;
+        A.adY[2][(size_t)(row0 + r_) * A.alddo + Ad + c_] = dls;
+      }
+    }
+    const Tp3Store sta{nullptr, nullptr, A.adY[1], A.adY[0], A.adY0_stride};
+    tp_bwd<WIDTH, LEAN>(A.actor, auxS, ha1, ha2, scr, tp, sta, row0, B, 0, 0, auxS, stamp);
+    stamp();
+    return;
+  }
   if constexpr (LEAN) {
     float* qsum = nullptr;   // mean-q diagnostics: written by the q wave of the lead member
     if (A.partials_a != nullptr && lead) {
@@ -500,10 +618,12 @@ size_t fused_ddpg_lds_bytes() { return sizeof(float) * FusedLds<256>::total; }
 size_t fused_xbuf_granules_per_cluster(int nc) { return (size_t)kTpStages * nc * kTpBlk; }
 
 hipError_t init_fused_attrs() {
-  const void* ks[4] = {reinterpret_cast<const void*>(&k_ddpg_phase1<256, false>),
-                       reinterpret_cast<const void*>(&k_ddpg_phase1<256, true>),
-                       reinterpret_cast<const void*>(&k_ddpg_phase2<256, false>),
-                       reinterpret_cast<const void*>(&k_ddpg_phase2<256, true>)};
+  const void* ks[6] = {reinterpret_cast<const void*>(&k_ddpg_phase1<256, false, false>),
+                       reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, false>),
+                       reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, true>),
+                       reinterpret_cast<const void*>(&k_ddpg_phase2<256, false, false>),
+                       reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false>),
+                       reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, true>)};
   for (const void* k : ks) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -517,25 +637,34 @@ static bool lean_ok(const DdpgArgs& a) { return fused_ddpg_is_lean(a); }
 // (the twin-critic variant, TD3, exists in the lean form only: learner.hip falls back to the
 // generic launch sequence when this returns false)
 bool fused_ddpg_is_lean(const DdpgArgs& a) {
-  return a.nc == 4 && !a.no_lean && tp4_shape_ok(256, a.S + a.A, 1) && tp4_shape_ok(256, a.S, a.A);
+  return a.nc == 4 && !a.no_lean && tp4_shape_ok(256, a.S + a.A, 1) && tp4_shape_ok(256, a.S, a.sac ? 2 * a.A : a.A);
 }
 
 hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
-  if (lean_ok(a))
-    hipLaunchKernelGGL((k_ddpg_phase1<256, true>), dim3(slices, (2 + a.n_critics) * a.nc), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
-  else
-    hipLaunchKernelGGL((k_ddpg_phase1<256, false>), dim3(slices, (2 + a.n_critics) * a.nc), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  const dim3 grid(slices, (2 + a.n_critics) * a.nc);
+  if (a.sac) {
+    if (!lean_ok(a)) return hipErrorInvalidValue;   // SAC is fused in the lean form only (use_fused() checks)
+    hipLaunchKernelGGL((k_ddpg_phase1<256, true, true>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  } else if (lean_ok(a)) {
+    hipLaunchKernelGGL((k_ddpg_phase1<256, true, false>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  } else {
+    hipLaunchKernelGGL((k_ddpg_phase1<256, false, false>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
-  const int rows = a.nc + (a.prefetch_next ? 1 : 0);   // + the next-minibatch gather row
-  if (lean_ok(a))
-    hipLaunchKernelGGL((k_ddpg_phase2<256, true>), dim3(slices, rows), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
-  else
-    hipLaunchKernelGGL((k_ddpg_phase2<256, false>), dim3(slices, rows), dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  const dim3 grid(slices, a.nc + (a.prefetch_next ? 1 : 0));   // + the next-minibatch gather row
+  if (a.sac) {
+    if (!lean_ok(a)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_ddpg_phase2<256, true, true>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  } else if (lean_ok(a)) {
+    hipLaunchKernelGGL((k_ddpg_phase2<256, true, false>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  } else {
+    hipLaunchKernelGGL((k_ddpg_phase2<256, false, false>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  }
   return hipGetLastError();
 }
 

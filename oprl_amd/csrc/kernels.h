@@ -163,6 +163,16 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   unsigned long long rng_seed, rng_ctr;
   float* c2X[kMaxLayers];              // critic 2 layer inputs / pre-activation grads (ld as critic 1)
   float* c2dY[kMaxLayers];
+  // SAC (sac == 1, twin critics, no target actor): both actor passes end in the tanh-Gaussian head.
+  // Role A samples a' ~ pi(s') from the ONLINE actor (draws: noise / stream rng_seed) and subtracts
+  // alpha log pi(a'|s') from the twin-min target (sac.py:90-104); role C samples pi(s) (draws:
+  // noise_pi / stream rng_seed_pi) and leaves the raw head output and log pi for phase 2 and the
+  // temperature step (sac.py:118-141)
+  int sac;
+  const float* noise_pi; unsigned long long rng_seed_pi;
+  const double* log_alpha; float alpha_const;   // alpha = exp(*log_alpha) or the constant
+  float* raw;                          // [B][2A] actor head output (mean | log_std) at s
+  float* logp;                         // [B] log pi(pi(s) | s)
   int B, S, A;
   BatchSrc src;
   // step_n: phase 2 carries one extra row of workgroups that gathers the NEXT update's

@@ -325,7 +325,8 @@ struct oprl_learner {
   hipStream_t side[OPRL_MAX_CRITICS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[OPRL_MAX_CRITICS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool have_side = false;
-  bool fused = false;          // DDPG / TD3 two-kernel path (csrc/fused_ddpg.hip) is built for this learner
+  bool fused = false;          // DDPG / TD3 / SAC two-kernel path (csrc/fused_ddpg.hip) is built for this learner
+  const float* noise1_pending = nullptr;   // update()'s injected actor-phase draws: SAC's role C runs in phase 1
   bool tp_generic_on = false;  // the generic per-net launches may run on clusters of 4 (csrc/slice_tp.hip)
   unsigned tp_tag = 0;         // launch-unique tag source of the cluster exchanges (fused and generic)
   // for_each_net over two nets: their cluster launches are collected and go out as one (k_mlp_slice_tp2)
@@ -603,17 +604,28 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   a.critic_t = net_view(c.critics[0], true);
   a.n_critics = h->nc;
   a.do_actor = 1;
-  if (h->nc == 2) {      // TD3: twin critic, target-policy smoothing (td3.py:83-93)
+  if (h->nc == 2) {      // TD3 / SAC: twin critic
     a.critic2 = net_view(c.critics[1], false);
     a.critic2_t = net_view(c.critics[1], true);
     for (int l = 0; l < kMaxLayers; ++l) { a.c2X[l] = h->ws_critic[1].X[l]; a.c2dY[l] = h->ws_critic[1].dY[l]; }
+    a.rng_seed = 0x0b5e55edULL + 1;                       // the streams seed_rng() gives the generic path
+    a.rng_ctr = (unsigned long long)h->update_count;
+  }
+  if (c.algo == OPRL_TD3) {   // target-policy smoothing (td3.py:83-93), delayed actor steps
     a.smooth = 1;
     a.policy_noise = (float)c.hp.policy_noise;
     a.noise_clip = (float)c.hp.noise_clip;
     a.max_action = (float)c.hp.max_action;
-    a.rng_seed = 0x0b5e55edULL + 1;                       // the streams seed_rng() gives the generic path
-    a.rng_ctr = (unsigned long long)h->update_count;
     a.do_actor = actor_due(h) ? 1 : 0;
+  }
+  if (c.algo == OPRL_SAC) {   // tanh-Gaussian actor, entropy term (sac.py:90-141)
+    a.sac = 1;
+    a.noise_pi = h->noise1_pending;
+    a.rng_seed_pi = 0x0b5e55edULL + 2;
+    a.log_alpha = alpha_ptr(h);
+    a.alpha_const = (float)c.hp.alpha_init;
+    a.raw = h->raw;
+    a.logp = h->logp;
   }
   a.B = B; a.S = h->S; a.A = h->A;
   a.src = h->src;
@@ -642,7 +654,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
 }
 
 // DDPG runs fused for every batch size (generic tp3.h passes when the lean ones do not fit);
-// TD3's fused kernels exist in the lean form only, otherwise the generic launch sequence is used
+// TD3's and SAC's fused kernels exist in the lean form only, otherwise the generic launch sequence is used
 bool use_fused(oprl_learner* h, int B) {
   if (!h->fused) return false;
   if (h->cfg.algo == OPRL_DDPG) return true;
@@ -779,7 +791,15 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     prof_end(st);
     HIPC(e);
     HIPC(chain_after(st));
-    return dw_step(h, false, B, true, st);
+    RC(dw_step(h, false, B, c.actor.theta_target != nullptr, st));
+    if (alpha_ptr(h) != nullptr) {   // SAC temperature (sac.py:129-141), from role C's log pi
+      h->opt_step_alpha += 1;
+      HIPC(launch_alpha_step(c.log_alpha, c.log_alpha_m, c.log_alpha_v, h->logp, B,
+                             (float)c.hp.target_entropy, c.hp.lr_alpha, c.hp.beta1, c.hp.beta2,
+                             c.hp.adam_eps, h->opt_step_alpha,
+                             c.export_grads ? h->alpha_grad : nullptr, nullptr, 1.0f, st));
+    }
+    return OPRL_OK;
   }
   const int S = h->S, A = h->A, nc = h->nc;
   const int algo = c.algo;
@@ -1125,8 +1145,9 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
            hipEventCreateWithFlags(&h->ev_join[j], hipEventDisableTiming) == hipSuccess;
     h->have_side = ok;
   }
-  h->fused = (cfg->algo == OPRL_DDPG || cfg->algo == OPRL_TD3) && !cfg->no_fuse && h->w_actor == 256 &&
-             h->w_critic == 256 && cfg->actor.n_layers == 3 && cfg->critics[0].n_layers == 3;
+  h->fused = (cfg->algo == OPRL_DDPG || cfg->algo == OPRL_TD3 || (cfg->algo == OPRL_SAC && h->nc == 2)) &&
+             !cfg->no_fuse && h->w_actor == 256 && h->w_critic == 256 && cfg->actor.n_layers == 3 &&
+             cfg->critics[0].n_layers == 3;
 
   const int B = h->Bmax, S = h->S, A = h->A, nc = h->nc;
   // scalar critics: q' is read with stride 1 by the TD seed; TQC: [B][ldq] quantile rows
@@ -1272,6 +1293,7 @@ extern "C" int oprl_learner_update_phase(oprl_learner* h, int32_t phase, const f
   h->last_B = B;
   if (phase == 0) h->trace_slot = 0;
   if (!h->src.gather) { h->src.s = s; h->src.a = a; h->src.r = r; h->src.d = d; h->src.s2 = s2; }
+  h->noise1_pending = noise1;
   if (phase == 0) return critic_phase(h, s, a, r, d, s2, B, noise0, st);
   if (phase == 1) {
     h->actor_updated_last = actor_due(h);

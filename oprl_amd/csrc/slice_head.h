@@ -32,6 +32,31 @@ __device__ __forceinline__ float noise_at(const MlpArgs& A, int gr, int col) {
 }
 
 
+// One action dimension of the tanh-Gaussian head (nn_models.py:168-178): reparameterised sample,
+// squash, and this dimension's term of log pi.
+__device__ __forceinline__ float gauss_elem(float mu, float lsr, float e, float* a_out) {
+  const float ls = fminf(fmaxf(lsr, kLogStdMin), kLogStdMax);
+  const float sd = expf(ls);
+  const float u = mu + sd * e;
+  *a_out = tanhf(u);
+  const float diff = u - mu;
+  return -(diff * diff) / (2.f * sd * sd) - logf(sd) - kHalfLog2Pi -
+         (kTwoLog2 + logsigmoidf(2.f * u) + logsigmoidf(-2.f * u));
+}
+
+// ... and its backward: d(loss)/d(mean), d(loss)/d(log_std) from da = dLoss/da (through the critics)
+// and dlp = dLoss/d(log pi) = alpha / B                                        (sac.py:118-127)
+__device__ __forceinline__ void gauss_elem_bwd(float mu, float lsr, float e, float da, float dlp,
+                                               float* dmu, float* dls) {
+  const float ls = fminf(fmaxf(lsr, kLogStdMin), kLogStdMax);
+  const float sd = expf(ls);
+  const float a = tanhf(mu + sd * e);
+  const float du = da * (1.f - a * a) + dlp * (2.f * a);
+  const bool in = (lsr >= kLogStdMin) && (lsr <= kLogStdMax);
+  *dmu = du;
+  *dls = in ? (du * sd * e - dlp) : 0.f;
+}
+
 // Output head: reads outS[kR][kOutLd]; global results only from the lead member.
 __device__ __forceinline__ void slice_head(const MlpArgs& A, const float* outS, int Nout, int row0, bool lead) {
   const int tid = threadIdx.x, B = A.B;
@@ -45,14 +70,8 @@ __device__ __forceinline__ void slice_head(const MlpArgs& A, const float* outS, 
       for (int col = sub; col < Ad; col += 16) {
         const float mu = outS[row * kOutLd + col];
         const float lsr = outS[row * kOutLd + Ad + col];
-        const float ls = fminf(fmaxf(lsr, kLogStdMin), kLogStdMax);
-        const float sd = expf(ls);
-        const float e = noise_at(A, gr, col);
-        const float u = mu + sd * e;
-        const float a = tanhf(u);
-        const float diff = u - mu;
-        lp += -(diff * diff) / (2.f * sd * sd) - logf(sd) - kHalfLog2Pi -
-              (kTwoLog2 + logsigmoidf(2.f * u) + logsigmoidf(-2.f * u));
+        float a;
+        lp += gauss_elem(mu, lsr, noise_at(A, gr, col), &a);
         if (lead && A.out != nullptr) A.out[(size_t)gr * A.ldo + col] = a;
         if (lead && A.raw_out != nullptr) {
           A.raw_out[(size_t)gr * A.ldraw + col] = mu;
@@ -152,16 +171,13 @@ __device__ __forceinline__ void slice_seed(const MlpArgs& A, const float* outS, 
         if (gr >= B) continue;
         const float mu = S.p1[(size_t)gr * Nout + col];
         const float lsr = S.p1[(size_t)gr * Nout + Ad + col];
-        const float ls = fminf(fmaxf(lsr, kLogStdMin), kLogStdMax);
-        const float sd = expf(ls);
         const float e = noise_at(A, gr, col);   // same injected / Philox draw as the forward
-        const float a = tanhf(mu + sd * e);
         float da = 0.f;
         for (int n = 0; n < S.n_da; ++n) da += S.p0[n * S.da_stride + (size_t)gr * S.ld0 + col];
-        const float du = da * (1.f - a * a) + dlp * (2.f * a);
-        const bool in = (lsr >= kLogStdMin) && (lsr <= kLogStdMax);
-        auxS[row * kOutLd + col] = du;
-        auxS[row * kOutLd + Ad + col] = in ? (du * sd * e - dlp) : 0.f;
+        float dmu, dls;
+        gauss_elem_bwd(mu, lsr, e, da, dlp, &dmu, &dls);
+        auxS[row * kOutLd + col] = dmu;
+        auxS[row * kOutLd + Ad + col] = dls;
       }
     } break;
     case SEED_QHUBER: {

@@ -12,11 +12,12 @@ from oracle import fixtures as fx
 pytestmark = pytest.mark.gpu
 
 
-def _ddpg(**kw):
+def _ddpg(state_dim=24, action_dim=6, **kw):
     from oprl_amd.algos.ddpg import DDPG
     from oprl_amd.logging import NullLogger
     t.manual_seed(0)
-    return DDPG(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", **kw).create()
+    return DDPG(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=state_dim, action_dim=action_dim,
+                device="cuda", **kw).create()
 
 
 def _close(a, b, tol=1e-5):
@@ -65,6 +66,23 @@ def test_fused_large_batches(B):
         generic.update(*batch)
     t.cuda.synchronize()
     assert t.isfinite(fused.critic._oprl_arena).all()
+    for m in ("actor", "critic", "actor_target", "critic_target"):
+        assert _close(getattr(fused, m)._oprl_arena, getattr(generic, m)._oprl_arena, 1e-4), m
+
+
+@pytest.mark.parametrize("S,A", [(67, 21), (75, 21), (5, 1)])
+def test_fused_wide_and_narrow_dims(S, A):
+    """Humanoid dims: 16 x 67 state elements per slice are more than one element per thread of the
+    lean phase-2 prologue; S + A = 96 is the widest layer-0 input the lean passes take; pendulum-
+    sized dims at the other end."""
+    B = 256
+    fused, generic = _ddpg(S, A), _ddpg(S, A, no_fuse=True)
+    for step in range(3):
+        batch = [x.cuda() for x in fx.make_batch(40 + step, B, S, A)]
+        fused.update(*batch)
+        generic.update(*batch)
+    t.cuda.synchronize()
+    assert t.isfinite(fused.actor._oprl_arena).all()
     for m in ("actor", "critic", "actor_target", "critic_target"):
         assert _close(getattr(fused, m)._oprl_arena, getattr(generic, m)._oprl_arena, 1e-4), m
 
@@ -216,3 +234,65 @@ def test_fused_runs_are_deterministic(algo):
         assert t.isfinite(a.actor._oprl_arena).all() and t.isfinite(a.critic._oprl_arena).all()
         outs.append((a.actor._oprl_arena.clone(), a.critic._oprl_arena.clone()))
     assert t.equal(outs[0][0], outs[1][0]) and t.equal(outs[0][1], outs[1][1])
+
+
+# ---- SAC: the same two kernels with the tanh-Gaussian head (roles A | B1 | B2 | C) -----------------
+def _sac(state_dim=24, action_dim=6, **kw):
+    from oprl_amd.algos.sac import SAC
+    from oprl_amd.logging import NullLogger
+    t.manual_seed(0)
+    return SAC(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=state_dim, action_dim=action_dim,
+               device="cuda", **kw).create()
+
+
+@pytest.mark.parametrize("tune_alpha", [False, True])
+@pytest.mark.parametrize("inject", [True, False])
+def test_fused_sac_equals_generic(inject, tune_alpha):
+    """Both Normal(0,1) draws injected (as the golden tests do) or drawn on device (same Philox streams
+    in both paths); fixed or learned temperature."""
+    B, S, A = 256, 24, 6
+    fused, generic = _sac(tune_alpha=tune_alpha), _sac(tune_alpha=tune_alpha, no_fuse=True)
+    for step in range(5):
+        batch = [x.cuda() for x in fx.make_batch(300 + step, B, S, A)]
+        noise = (fx.make_noise(400 + step, (B, A)).cuda(), fx.make_noise(500 + step, (B, A)).cuda()) if inject else None
+        fused.update(*batch, noise=noise)
+        generic.update(*batch, noise=noise)
+    t.cuda.synchronize()
+    assert t.isfinite(fused.actor._oprl_arena).all() and t.isfinite(fused.critic._oprl_arena).all()
+    for m in ("actor", "critic", "critic_target"):
+        assert _close(getattr(fused, m)._oprl_arena, getattr(generic, m)._oprl_arena, 1e-4), m
+    q_f, y_f = fused.learner.debug_q_y(B)
+    q_g, y_g = generic.learner.debug_q_y(B)
+    assert _close(q_f, q_g, 2e-5) and _close(y_f, y_g, 2e-5)
+    sf, sg = fused.learner.read_scalars(), generic.learner.read_scalars()
+    for k in ("critic_loss", "q_mean", "q_target_mean", "actor_loss", "alpha"):
+        assert abs(sf[k] - sg[k]) <= 1e-4 * max(abs(sg[k]), 1e-6), k
+    if tune_alpha:
+        assert abs(fused.alpha - generic.alpha) <= 1e-6 * generic.alpha
+
+
+@pytest.mark.parametrize("B,S,A", [(1024, 67, 21), (100, 24, 6), (8, 17, 6)])
+def test_fused_sac_shapes(B, S, A):
+    """Humanoid dims at the reference's batch (over-subscribed grid: 4 roles x 4 x 64 workgroups),
+    ragged and tiny batches."""
+    fused, generic = _sac(S, A, max_batch=B, tune_alpha=True), _sac(S, A, max_batch=B, tune_alpha=True, no_fuse=True)
+    for step in range(3):
+        batch = [x.cuda() for x in fx.make_batch(310 + step, B, S, A)]
+        fused.update(*batch)
+        generic.update(*batch)
+    t.cuda.synchronize()
+    assert t.isfinite(fused.actor._oprl_arena).all() and t.isfinite(fused.critic._oprl_arena).all()
+    for m in ("actor", "critic", "critic_target"):
+        assert _close(getattr(fused, m)._oprl_arena, getattr(generic, m)._oprl_arena, 1e-4), m
+
+
+def test_fused_sac_step_n_equals_generic_step_n():
+    from tests.test_gpu_callers import _filled_buffer
+    fused, generic = _sac(max_batch=64, tune_alpha=True), _sac(max_batch=64, tune_alpha=True, no_fuse=True)
+    buf = _filled_buffer()
+    fused.learner.step_n(buf.handle, 10, 64, seed=11)
+    generic.learner.step_n(buf.handle, 10, 64, seed=11)
+    t.cuda.synchronize()
+    for m in ("actor", "critic", "critic_target"):
+        assert _close(getattr(fused, m)._oprl_arena, getattr(generic, m)._oprl_arena, 1e-4), m
+    assert abs(fused.alpha - generic.alpha) <= 1e-6 * generic.alpha
