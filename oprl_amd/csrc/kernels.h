@@ -77,6 +77,9 @@ struct MlpArgs {
   void* owner;                       // the learner: lets launch() pair two nets of one for_each_net
 };
 
+constexpr int kMaxMulti = 5;           // nets per k_mlp_slice_multi launch (TQC: 5 quantile critics)
+struct MlpMultiArgs { MlpArgs a[kMaxMulti]; };
+
 // ---- dW + Adam + Polyak ------------------------------------------------------
 struct DwItem {      // one Linear layer of one net
   const float* X; int ldx; int K;      // layer input  [B][ldx]

@@ -18,7 +18,7 @@
 namespace oprl {
 
 template <int WIDTH>
-__global__ __launch_bounds__(kThreads) void k_mlp_slice(const MlpArgs A) {
+__device__ __forceinline__ void mlp_slice_body(const MlpArgs& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = SliceLds<WIDTH>;
   constexpr int WL = lds_ld(WIDTH);
@@ -67,8 +67,23 @@ __global__ __launch_bounds__(kThreads) void k_mlp_slice(const MlpArgs A) {
   stamp();  // end
 }
 
+template <int WIDTH>
+__global__ __launch_bounds__(kThreads) void k_mlp_slice(const MlpArgs A) { mlp_slice_body<WIDTH>(A); }
+
+// Up to kMaxMulti independent nets of one learner (TQC's five quantile critics) in ONE launch,
+// grid (slices, nets): side streams gave them only ~1.7x overlap (5 streams share 4 hardware
+// queues, every fork/join is an event round trip).  The argument blocks travel by value; a
+// workgroup addresses its own through the kernarg segment pointer (scalar loads, as k_dw_adam does).
+template <int WIDTH>
+__global__ __launch_bounds__(kThreads) void k_mlp_slice_multi(const MlpMultiArgs M) {
+  const MlpMultiArgs* kp = (const MlpMultiArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  mlp_slice_body<WIDTH>(kp->a[blockIdx.y]);
+}
+
 template __global__ void k_mlp_slice<256>(const MlpArgs);
 template __global__ void k_mlp_slice<512>(const MlpArgs);
+template __global__ void k_mlp_slice_multi<256>(const MlpMultiArgs);
+template __global__ void k_mlp_slice_multi<512>(const MlpMultiArgs);
 
 // ---------------------------------------------------------------------------
 // dW[n,k] = sum_b dY[b,n] X[b,k]  on a 32x32 tile per workgroup; the 4 waves
@@ -486,12 +501,31 @@ hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st) {
   return hipGetLastError();
 }
 
+// n <= kMaxMulti launches of equal width, depth and batch as one
+hipError_t launch_mlp_slice_multi(const MlpArgs* a, int n, int width, hipStream_t st) {
+  if (n < 1 || n > kMaxMulti) return hipErrorInvalidValue;
+  MlpMultiArgs m;
+  for (int j = 0; j < n; ++j) m.a[j] = a[j];
+  for (int j = n; j < kMaxMulti; ++j) m.a[j] = a[0];
+  const dim3 grid((a[0].B + kR - 1) / kR, n);
+  const size_t lds = mlp_slice_lds_bytes(width, a[0].net.n_layers);
+  if (width == 256) {
+    hipLaunchKernelGGL(k_mlp_slice_multi<256>, grid, dim3(kThreads), lds, st, m);
+  } else {
+    hipLaunchKernelGGL(k_mlp_slice_multi<512>, grid, dim3(kThreads), lds, st, m);
+  }
+  return hipGetLastError();
+}
+
 hipError_t init_kernel_attrs() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_slice<256>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_slice<512>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const void* ks[4] = {reinterpret_cast<const void*>(&k_mlp_slice<256>), reinterpret_cast<const void*>(&k_mlp_slice<512>),
+                       reinterpret_cast<const void*>(&k_mlp_slice_multi<256>),
+                       reinterpret_cast<const void*>(&k_mlp_slice_multi<512>)};
+  for (const void* k : ks) {
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 __device__ float g_one = 1.f;

@@ -126,6 +126,7 @@ static hipError_t chain_after(hipStream_t st) {
 
 size_t mlp_slice_lds_bytes(int width, int n_layers);
 hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
+hipError_t launch_mlp_slice_multi(const MlpArgs* a, int n, int width, hipStream_t st);
 hipError_t launch_mlp_slice_tp(const MlpArgs& a, hipStream_t st);
 hipError_t launch_mlp_slice_tp2(const MlpArgs& a0, const MlpArgs& a1, int n_cus, hipStream_t st);
 hipError_t init_slice_tp_attrs();
@@ -333,6 +334,10 @@ struct oprl_learner {
   bool pair_collect = false;
   int pair_n = 0;
   MlpArgs pair_args[2];
+  bool no_multi = false;
+  bool multi_collect = false;  // for_each_net over > 2 single-CU nets: one k_mlp_slice_multi launch
+  int multi_n = 0, multi_width = 0;
+  MlpArgs multi_args[kMaxMulti];
   bool staged_ready = false;   // step_n: the staging batch holds the next update's rows (written by phase 2)
   unsigned long long* y_granules = nullptr;   // [Bmax] TD-target hand-off (fused DDPG)
   unsigned epoch = 0;          // monotonically increasing, never reset
@@ -465,11 +470,11 @@ bool tp_generic(const oprl_learner* h, const oprl_net& n, int B) {
 MlpArgs base_args(oprl_learner* h, const oprl_net& n, bool target, int B) {
   MlpArgs a;
   memset(&a, 0, sizeof a);
+  a.owner = h;
   if (tp_generic(h, n, B)) {
     a.tp_xbuf = h->xbuf;
     a.tp_tag_counter = &h->tp_tag;
     a.tp_xbuf_bytes = h->xbuf_granules * sizeof(unsigned long long);
-    a.owner = h;
   }
   if (h->trace != nullptr && h->trace_slot < OPRL_TRACE_SLOTS)
     a.trace = h->trace + (size_t)(h->trace_slot++) * 64 * kTraceStamps * 2;
@@ -520,6 +525,14 @@ int launch(const MlpArgs& a0, int width, hipStream_t st) {
     return OPRL_OK;
   }
   const MlpArgs& a = a0;
+  {
+    oprl_learner* own = (oprl_learner*)a.owner;
+    if (own != nullptr && own->multi_collect && own->multi_n < kMaxMulti) {
+      own->multi_width = width;
+      own->multi_args[own->multi_n++] = a;
+      return OPRL_OK;
+    }
+  }
   prof_begin(0, st);
   hipError_t e = launch_mlp_slice(a, width, st);
   prof_end(st);
@@ -563,6 +576,34 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
       }
     }
     h->pair_n = 0;
+    return OPRL_OK;
+  }
+  if (n > 2 && n <= kMaxMulti && !h->no_multi) {
+    // equal nets on the same slices (TQC's quantile critics): one launch, grid (slices, nets)
+    h->multi_collect = true;
+    h->multi_n = 0;
+    int rc = OPRL_OK;
+    for (int j = 0; j < n && rc == OPRL_OK; ++j) rc = launch_j(j, st);
+    h->multi_collect = false;
+    RC(rc);
+    bool same = h->multi_n > 0;
+    for (int k = 1; k < h->multi_n; ++k)
+      same = same && h->multi_args[k].B == h->multi_args[0].B &&
+             h->multi_args[k].net.n_layers == h->multi_args[0].net.n_layers;
+    if (same) {
+      prof_begin(0, st);
+      hipError_t e = launch_mlp_slice_multi(h->multi_args, h->multi_n, h->multi_width, st);
+      prof_end(st);
+      HIPC(e);
+    } else {
+      for (int k = 0; k < h->multi_n; ++k) {
+        prof_begin(0, st);
+        hipError_t e = launch_mlp_slice(h->multi_args[k], h->multi_width, st);
+        prof_end(st);
+        HIPC(e);
+      }
+    }
+    h->multi_n = 0;
     return OPRL_OK;
   }
   if (n <= 2 || !h->have_side) {
@@ -1219,6 +1260,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     const char* env = getenv("OPRL_AMD_CLUSTER");
     h->ncl = env ? atoi(env) : kMaxCluster;
     if (h->ncl != 1 && h->ncl != 2 && h->ncl != 4) h->ncl = kMaxCluster;
+    const char* nm = getenv("OPRL_AMD_NO_MULTI");    // tests / A-B: side streams instead of k_mlp_slice_multi
+    h->no_multi = (nm != nullptr && atoi(nm) != 0);
     const char* nl = getenv("OPRL_AMD_NO_LEAN");
     h->no_lean = (nl != nullptr && atoi(nl) != 0) ? 1 : 0;
     // the generic per-net launches on clusters of 4 (slice_tp.hip): any net of the common shape

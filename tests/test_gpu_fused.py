@@ -296,3 +296,27 @@ def test_fused_sac_step_n_equals_generic_step_n():
     for m in ("actor", "critic", "critic_target"):
         assert _close(getattr(fused, m)._oprl_arena, getattr(generic, m)._oprl_arena, 1e-4), m
     assert abs(fused.alpha - generic.alpha) <= 1e-6 * generic.alpha
+
+
+# ---- TQC: the five quantile critics of a phase in one launch ----------------------------------------
+def test_tqc_multi_launch_equals_side_streams(monkeypatch):
+    """k_mlp_slice_multi (grid = slices x nets) runs the same workgroup code as five k_mlp_slice
+    launches on side streams: bit-identical."""
+    from oprl_amd.algos.tqc import TQC
+    from oprl_amd.logging import NullLogger
+
+    def make():
+        t.manual_seed(0)
+        return TQC(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=256).create()
+
+    multi = make()
+    monkeypatch.setenv("OPRL_AMD_NO_MULTI", "1")
+    streams = make()
+    for step in range(3):
+        batch = [x.cuda() for x in fx.make_batch(20 + step, 256, 24, 6)]
+        multi.update(*batch)
+        streams.update(*batch)
+    t.cuda.synchronize()
+    assert t.isfinite(multi.critic._oprl_arena).all()
+    for m in ("actor", "critic", "critic_target"):
+        assert t.equal(getattr(multi, m)._oprl_arena, getattr(streams, m)._oprl_arena), m
