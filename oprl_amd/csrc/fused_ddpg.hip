@@ -421,11 +421,15 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   float* scr = smem + LY::scr;
   float* piS = smem + LY::xb;        // [kR][kX0Ld] tile reused for pi
   const int slice = blockIdx.x, row0 = slice * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
-  Tp tp{(int)blockIdx.y, A.nc, A.xbuf + (size_t)slice * kTpStages * A.nc * kTpBlk, A.cluster_tag, 0};
+  // SAC with p2_pair: two clusters per slice, one per online critic (g = 0 / 1), side by side
+  const int n_clus = SAC ? 1 + A.p2_pair : 1;
+  const int g = (SAC && (int)blockIdx.y < n_clus * A.nc) ? (int)blockIdx.y / A.nc : 0;
+  Tp tp{(int)blockIdx.y - g * A.nc, A.nc,
+        A.xbuf + ((size_t)g * gridDim.x + slice) * kTpStages * A.nc * kTpBlk, A.cluster_tag, 0};
   const bool lead = tp.c == 0;
   int n_stamp = 0;
   auto stamp = [&]() {
-    if (A.trace != nullptr && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
+    if (A.trace != nullptr && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && g == 0 && n_stamp < kTraceStamps) {
       const int slot = tid == 0 ? slice : 16 + (tid >> 6);
       long long* tr = A.trace + ((size_t)slot * kTraceStamps + n_stamp) * 2;
       tr[0] = (long long)__builtin_readcyclecounter();
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
     }
     ++n_stamp;
   };
-  if ((int)blockIdx.y == A.nc) {
+  if ((int)blockIdx.y == n_clus * A.nc) {
     // ---- prefetch row: gather the next update's rows (same draw as load_batch will not have
     // to make) and leave them contiguous for phase 1 of the next step
     float* xb = smem + LY::xb;
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
     // row are five load -> wait -> store sequences for the threads that take part in all of them
     constexpr int K4 = WIDTH / 4;                        // float4 per activation row
     const int r4 = tid / K4, c4 = (tid - r4 * K4) * 4;    // kR * K4 == kThreads for WIDTH 256
-    const bool ok4 = row0 + r4 < B;
+    const bool ok4 = row0 + r4 < B && g == 0;              // (the twin critic's cluster needs only [s | pi])
     f32x4 v1 = f32x4{0.f, 0.f, 0.f, 0.f}, v2 = v1;
     if (ok4) {
       v1 = ld4(A.aX[1] + (size_t)(row0 + r4) * WIDTH + c4);
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
     const bool okp = tid < kR * Ad && row0 + rp_ < B;
     const float vp = okp ? A.pi[(size_t)(row0 + rp_) * Ad + cp_] : 0.f;
     if constexpr (SAC) {
-      if (okp) {
+      if (okp && g == 0) {
         g_mu = A.raw[(size_t)(row0 + rp_) * 2 * Ad + cp_];
         g_ls = A.raw[(size_t)(row0 + rp_) * 2 * Ad + Ad + cp_];
         if (A.noise_pi != nullptr) g_e = A.noise_pi[(size_t)(row0 + rp_) * Ad + cp_];
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
     if (tid2 < kR * S) xa[rs2_ * kX0Ld + cs2_] = vs2;
     if (tid < kR * Ad) { xa[rp_ * kX0Ld + S + cp_] = vp; piS[rp_ * kX0Ld + cp_] = vp; }
     if constexpr (SAC) {   // the same draw as role C's forward
-      if (okp && A.noise_pi == nullptr) g_e = philox_normal(A.rng_seed_pi, A.rng_ctr, (unsigned)(row0 + rp_), (unsigned)cp_);
+      if (okp && g == 0 && A.noise_pi == nullptr) g_e = philox_normal(A.rng_seed_pi, A.rng_ctr, (unsigned)(row0 + rp_), (unsigned)cp_);
     }
   } else {
     load_rows(xa, kX0Ld, 0, A.aX[0], A.aldx0, S, row0, B);
@@ -514,12 +518,48 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
     // columns; per row the smaller q routes its gradient (torch.min: ties split), then the
     // tanh-Gaussian head backward with the entropy term             (sac.py:118-127)
     float* d2S = smem + LY::aux2;
-    float* q1S = smem + LY::misc;
-    tp4_scalar_fb(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp);
-    if (tid < kR) q1S[tid] = outS[tid * kOutLd];
-    tp4_scalar_fb(A.critic2, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, d2S, stamp);
+    float* qxS = smem + LY::misc;      // the q that is not in outS: q1 (back to back) or q2 (side by side)
+    const float* q1p = qxS; int q1s = 1;
+    const float* q2p = outS; int q2s = kOutLd;
+    if (A.p2_pair) {
+      // one granule per (row, action dim | q) from the lead member of cluster 1 to every member of
+      // cluster 0, in the exchange area of the unused role slot 2, tagged with the launch's tag
+      unsigned long long* xq = A.xbuf + ((size_t)2 * gridDim.x + slice) * kTpStages * A.nc * kTpBlk + tid;
+      const unsigned tag = (A.cluster_tag << 6) | 63u;
+      const int xr = tid / (Ad + 1), xc = tid - xr * (Ad + 1);
+      const bool xmine = tid < kR * (Ad + 1);
+      if (g == 1) {
+        tp4_scalar_fb(A.critic2, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp);
+        if (lead && xmine) {
+          const float v = xc < Ad ? auxS[xr * kOutLd + xc] : outS[xr * kOutLd];
+          __hip_atomic_store(xq, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+      }
+      tp4_scalar_fb(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp);
+      if (xmine) {
+        unsigned long long x = 0;
+        bool ok = false;
+        for (int spin = 0; spin < kTpSpin; ++spin) {
+          x = __hip_atomic_load(xq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = (unsigned)(x >> 32) == tag;
+          if (ok) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        const float v = ok ? __uint_as_float((unsigned)x) : __builtin_nanf("");
+        if (xc < Ad) d2S[xr * kOutLd + xc] = v; else qxS[xr] = v;
+      }
+      __syncthreads();
+      q1p = outS; q1s = kOutLd;
+      q2p = qxS; q2s = 1;
+    } else {
+      tp4_scalar_fb(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp);
+      if (tid < kR) qxS[tid] = outS[tid * kOutLd];
+      tp4_scalar_fb(A.critic2, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, d2S, stamp);
+    }
     if (A.partials_a != nullptr && lead && tid < 64) {
-      float v = (tid < kR && row0 + tid < B) ? fminf(q1S[tid], outS[tid * kOutLd]) : 0.f;
+      float v = (tid < kR && row0 + tid < B) ? fminf(q1p[tid * q1s], q2p[tid * q2s]) : 0.f;
 #pragma unroll
       for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m);
       if (tid == 0) {
@@ -533,7 +573,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
     const bool mine = tid < kR * Ad;
     float dmu = 0.f, dls = 0.f;
     if (mine && row0 + r_ < B) {
-      const float q1 = q1S[r_], q2 = outS[r_ * kOutLd];
+      const float q1 = q1p[r_ * q1s], q2 = q2p[r_ * q2s];
       const float w1 = q1 < q2 ? 1.f : (q1 == q2 ? 0.5f : 0.f);
       const float da = w1 * auxS[r_ * kOutLd + c_] + (1.f - w1) * d2S[r_ * kOutLd + c_];
       const float alpha = A.log_alpha != nullptr ? (float)exp(*A.log_alpha) : A.alpha_const;
@@ -656,7 +696,8 @@ hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st) {
 
 hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
-  const dim3 grid(slices, a.nc + (a.prefetch_next ? 1 : 0));   // + the next-minibatch gather row
+  // SAC side by side: one cluster per online critic; + the next-minibatch gather row
+  const dim3 grid(slices, a.nc * ((a.sac && a.p2_pair) ? 2 : 1) + (a.prefetch_next ? 1 : 0));
   if (a.sac) {
     if (!lean_ok(a)) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_ddpg_phase2<256, true, true>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);

@@ -172,6 +172,7 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   // noise_pi / stream rng_seed_pi) and leaves the raw head output and log pi for phase 2 and the
   // temperature step (sac.py:118-141)
   int sac;
+  int p2_pair;                         // phase 2: the twin critics on two clusters per slice, side by side (both fit the chip)
   const float* noise_pi; unsigned long long rng_seed_pi;
   const double* log_alpha; float alpha_const;   // alpha = exp(*log_alpha) or the constant
   float* raw;                          // [B][2A] actor head output (mean | log_std) at s

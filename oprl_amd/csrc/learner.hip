@@ -335,6 +335,7 @@ struct oprl_learner {
   int pair_n = 0;
   MlpArgs pair_args[2];
   bool no_multi = false;
+  bool no_p2_pair = false;     // OPRL_AMD_NO_P2_PAIR: SAC phase 2 runs the twin critics back to back (tests / A-B)
   bool multi_collect = false;  // for_each_net over > 2 single-CU nets: one k_mlp_slice_multi launch
   int multi_n = 0, multi_width = 0;
   MlpArgs multi_args[kMaxMulti];
@@ -667,6 +668,8 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
     a.alpha_const = (float)c.hp.alpha_init;
     a.raw = h->raw;
     a.logp = h->logp;
+    // both phase-2 clusters of a slice must be co-resident: cluster 0 waits for cluster 1's result
+    a.p2_pair = (h->ncl == 4 && 2 * 4 * ((B + kR - 1) / kR) <= h->n_cus && !h->no_p2_pair) ? 1 : 0;
   }
   a.B = B; a.S = h->S; a.A = h->A;
   a.src = h->src;
@@ -1262,6 +1265,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     if (h->ncl != 1 && h->ncl != 2 && h->ncl != 4) h->ncl = kMaxCluster;
     const char* nm = getenv("OPRL_AMD_NO_MULTI");    // tests / A-B: side streams instead of k_mlp_slice_multi
     h->no_multi = (nm != nullptr && atoi(nm) != 0);
+    const char* np2 = getenv("OPRL_AMD_NO_P2_PAIR");
+    h->no_p2_pair = (np2 != nullptr && atoi(np2) != 0);
     const char* nl = getenv("OPRL_AMD_NO_LEAN");
     h->no_lean = (nl != nullptr && atoi(nl) != 0) ? 1 : 0;
     // the generic per-net launches on clusters of 4 (slice_tp.hip): any net of the common shape

@@ -245,11 +245,14 @@ def _sac(state_dim=24, action_dim=6, **kw):
                device="cuda", **kw).create()
 
 
+@pytest.mark.parametrize("pair", [True, False])
 @pytest.mark.parametrize("tune_alpha", [False, True])
 @pytest.mark.parametrize("inject", [True, False])
-def test_fused_sac_equals_generic(inject, tune_alpha):
+def test_fused_sac_equals_generic(inject, tune_alpha, pair, monkeypatch):
     """Both Normal(0,1) draws injected (as the golden tests do) or drawn on device (same Philox streams
-    in both paths); fixed or learned temperature."""
+    in both paths); fixed or learned temperature; phase 2's twin critics on two clusters side by side
+    or back to back on one."""
+    monkeypatch.setenv("OPRL_AMD_NO_P2_PAIR", "0" if pair else "1")
     B, S, A = 256, 24, 6
     fused, generic = _sac(tune_alpha=tune_alpha), _sac(tune_alpha=tune_alpha, no_fuse=True)
     for step in range(5):
