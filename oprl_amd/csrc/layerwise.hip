@@ -1,0 +1,242 @@
+// layerwise.hip — wide nets (TQC's 512-wide, 4-layer quantile critics) layer by layer.
+//
+// k_mlp_slice carries a 16-row slice through a whole MLP on ONE CU.  For a 512x512 layer that is
+// 4096 fp32 MFMAs = 13.7 us at the CU's matrix peak, twice per forward, and five critics x 16
+// slices occupy 80 of the 256 CUs (profiles/r01g_kernel_stats_tqc.csv: 50 / 122 / 97 us per
+// launch).  The activations between layers are [B, 512] rows — 0.5 MB per net — so here the
+// hand-over between layers is a kernel boundary (2.1 us) instead of a cluster exchange: every
+// launch covers ONE layer of all nets with a workgroup per (slice, 128 output columns, net), 320
+// workgroups for TQC at B = 256 — two per CU, all resident at once — each a [16 x K] x [K x 128]
+// product through the same packs and the same gemm_packed() as the slice kernels (two waves per
+// 16-column tile split the contraction).
+// The hidden activations and pre-activation gradients travel through the very buffers k_dw_adam
+// reads afterwards (NetWs::X / dY), so nothing is stored twice.
+//
+//   k_lw_in      [x0 | x1] -> h1 = relu(W0 x + b0)                        slices x W/128 x nets workgroups
+//   k_lw_mid     forward:  h[l+1] = relu(W_l h[l] + b_l)                  (1-D, XCD-aware: lw_who())
+//                backward: dz[l-1] = (dz[l] W_l) * [h[l] > 0]
+//   k_lw_head    out = W_L h + b_L -> head -> loss seed -> dz[L-2]        grid (slices, 1, nets)
+//   k_lw_dact    gradient wrt the action columns of the input             grid (slices, 1, nets)
+//
+// Heads and seeds are those of k_mlp_slice (slice_head.h).  Summation order differs from the
+// single-CU kernel (the contraction is split over two waves), so the two agree to rounding, not
+// bit for bit (tests/test_gpu_fused.py::test_tqc_layerwise_equals_slice_kernel).
+// Reference ops replaced: the addmm / threshold_backward chains of algos/nn_models.py:84-107 under
+// autograd, for tqc.py:128-177.
+#include "kernels.h"
+#include "slice_head.h"
+
+namespace oprl {
+
+constexpr int kLwCols = 128;                 // output columns per workgroup: 8 tiles x 2 waves
+constexpr int kLwTiles = kLwCols / 16;
+
+template <int WIDTH>
+struct LwLds {   // floats
+  static constexpr int WL = lds_ld(WIDTH);
+  static constexpr int x = 0;                              // [kR][WL] input rows of the layer
+  static constexpr int x0 = x + kR * WL;                   // [kR][kX0Ld] net input (k_lw_in)
+  static constexpr int out = x0 + kR * kX0Ld;
+  static constexpr int aux = out + kR * kOutLd;
+  static constexpr int scr = aux + kR * kOutLd;
+  static constexpr int total = scr + kWaves * kR * 16;
+};
+
+// Wide launches are 1-D and XCD-aware.  Every launch starts with cold L2s (eight of them, one per
+// XCD, filled over the fabric), workgroup i runs on XCD i % 8, and the bytes that matter are the
+// 256 KB weight slab of a (net, column group) pair — shared by that pair's slices — and the
+// [16 x K] input rows of a (net, slice).  A UNIT is a pair's slices, or 1/nsplit of them (nsplit is
+// the smallest power of two that makes the unit count a multiple of 8, so the XCDs carry equal
+// loads: TQC has 20 pairs -> 40 half-units, five per XCD); XCD x owns the consecutive units
+// [x * upx, (x + 1) * upx) in net-major order, so a slab crosses the fabric once (twice) and an XCD
+// reads the rows of at most two nets.
+struct LwWho { int slice, cg, net; bool ok; };
+struct LwGrid { int slices, nets, nsplit, spu, upx; };   // spu: slices per unit, upx: units per XCD
+__device__ __forceinline__ LwWho lw_who(const LwGrid& G, int ncg) {
+  const int units = G.nets * ncg * G.nsplit;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int ul = j / G.spu, u = xcd * G.upx + ul;
+  const int p = u / G.nsplit, part = u - p * G.nsplit;
+  LwWho w;
+  w.slice = part * G.spu + (j - ul * G.spu);
+  w.net = p / ncg;
+  w.cg = p - w.net * ncg;
+  w.ok = u < units && w.slice < G.slices;
+  return w;
+}
+inline LwGrid lw_grid(int slices, int ncg, int nets) {
+  LwGrid g;
+  g.slices = slices; g.nets = nets; g.nsplit = 1;
+  while (g.nsplit < 8 && (nets * ncg * g.nsplit) % 8 != 0 && g.nsplit * 2 <= slices) g.nsplit *= 2;
+  g.spu = (slices + g.nsplit - 1) / g.nsplit;
+  g.upx = (nets * ncg * g.nsplit + 7) / 8;
+  return g;
+}
+inline int lw_blocks(const LwGrid& g) { return 8 * g.upx * g.spu; }
+
+__device__ __forceinline__ const MlpArgs& lw_args(int net) {
+  const MlpMultiArgs* kp = (const MlpMultiArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  return kp->a[net];
+}
+
+// this thread's two elements of a [kR x 128] result in gemm_packed()'s split-contraction epilogue:
+// (row, col) and (row, col + 64)
+__device__ __forceinline__ void lw_elem(int* row, int* col) {
+  const int rt = threadIdx.x >> 8, rrem = threadIdx.x & 255;
+  *row = rrem >> 4;
+  *col = 16 * rt + (rrem & 15);
+}
+
+// (launch bounds: 8 waves per SIMD = two workgroups per CU, i.e. at most 64 VGPRs — with one
+// workgroup per CU a TQC layer launch was 2.5 rounds of workgroups, 15.8 us)
+template <int WIDTH>
+__global__ __launch_bounds__(kThreads, 8) void k_lw_in(const MlpMultiArgs M, const LwGrid G) {
+  __shared__ __attribute__((aligned(16))) float smem[kR * kX0Ld + kWaves * kR * 16];
+  const LwWho w = lw_who(G, WIDTH / kLwCols);
+  if (!w.ok) return;
+  const MlpArgs& A = lw_args(w.net);
+  float* x0s = smem;
+  float* scr = smem + kR * kX0Ld;
+  const int row0 = w.slice * kR, cg = w.cg, B = A.B;
+  const int K0 = A.net.dims[0], NS0 = cdiv(K0, 16);
+  lds_zero(x0s, kR * kX0Ld);
+  __syncthreads();
+  load_rows(x0s, kX0Ld, 0, A.x0, A.k0, A.k0, row0, B);
+  if (A.x1 != nullptr) load_rows(x0s, kX0Ld, A.k0, A.x1, A.k1, A.k1, row0, B);
+  float* Y = A.Xg[1];
+  gemm_packed(x0s, kX0Ld, A.net.pf[0] + (size_t)cg * kLwTiles * NS0 * 256, kLwTiles, NS0, scr,
+              A.net.b[0] + cg * kLwCols, kLwCols, [&](int row, int col, float v) {
+                if (row0 + row < B) Y[(size_t)(row0 + row) * WIDTH + cg * kLwCols + col] = fmaxf(v, 0.f);
+              });
+  if (cg == 0 && A.Xg[0] != nullptr) store_rows(x0s, kX0Ld, A.Xg[0], A.ldx0, K0, row0, B);
+}
+
+// forward (BWD = false): Xg[l] -> Xg[l+1];  backward (BWD = true): dYg[l] -> dYg[l-1], masked by Xg[l]
+template <int WIDTH, bool BWD>
+__global__ __launch_bounds__(kThreads, 8) void k_lw_mid(const MlpMultiArgs M, int l, const LwGrid G) {
+  constexpr int WL = lds_ld(WIDTH), NTW = WIDTH / 16;
+  __shared__ __attribute__((aligned(16))) float smem[kR * WL + kWaves * kR * 16];
+  const LwWho w = lw_who(G, WIDTH / kLwCols);
+  if (!w.ok) return;
+  const MlpArgs& A = lw_args(w.net);
+  float* xs = smem;
+  float* scr = smem + kR * WL;
+  const int row0 = w.slice * kR, cg = w.cg, B = A.B;
+  int erow, ecol;
+  lw_elem(&erow, &ecol);
+  const bool eok = row0 + erow < B;
+  const size_t eoff = (size_t)(row0 + erow) * WIDTH + cg * kLwCols + ecol;
+  if constexpr (BWD) {
+    // the ReLU masks of this thread's two elements, requested before anything else
+    const float h0 = eok ? A.Xg[l][eoff] : 0.f, h1 = eok ? A.Xg[l][eoff + 64] : 0.f;
+    load_rows4(xs, WL, A.dYg[l], WIDTH, WIDTH, row0, B);
+    float* dX = A.dYg[l - 1];
+    gemm_packed(xs, WL, A.net.pb[l] + (size_t)cg * kLwTiles * NTW * 256, kLwTiles, NTW, scr, nullptr, 0,
+                [&](int, int col, float v) {
+                  const bool second = col >= 64;
+                  if (eok) dX[eoff + (second ? 64 : 0)] = (second ? h1 : h0) > 0.f ? v : 0.f;
+                });
+  } else {
+    load_rows4(xs, WL, A.Xg[l], WIDTH, WIDTH, row0, B);
+    float* Y = A.Xg[l + 1];
+    gemm_packed(xs, WL, A.net.pf[l] + (size_t)cg * kLwTiles * NTW * 256, kLwTiles, NTW, scr,
+                A.net.b[l] + cg * kLwCols, kLwCols, [&](int, int col, float v) {
+                  if (eok) Y[eoff + (col >= 64 ? 64 : 0)] = fmaxf(v, 0.f);
+                });
+  }
+}
+
+template <int WIDTH>
+__global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M) {
+  __shared__ __attribute__((aligned(16))) float smem[LwLds<WIDTH>::total];
+  using LY = LwLds<WIDTH>;
+  constexpr int WL = LY::WL, NTW = WIDTH / 16;
+  const MlpArgs& A = lw_args(blockIdx.z);
+  float* hb = smem + LY::x;
+  float* outS = smem + LY::out;
+  float* auxS = smem + LY::aux;
+  float* scr = smem + LY::scr;
+  const int slice = blockIdx.x, row0 = slice * kR, B = A.B;
+  const int L = A.net.n_layers, Nout = A.net.dims[L];
+  load_rows4(hb, WL, A.Xg[L - 1], WIDTH, WIDTH, row0, B);
+  if (A.do_fwd) {
+    gemm_packed(hb, WL, A.net.pf[L - 1], cdiv(Nout, 16), NTW, scr, A.net.b[L - 1], Nout,
+                [&](int row, int col, float v) { outS[row * kOutLd + col] = col < Nout ? v : 0.f; });
+    slice_head(A, outS, Nout, row0, true);
+  } else {
+    __syncthreads();
+  }
+  if (!A.do_bwd) return;
+  slice_seed(A, outS, auxS, scr, Nout, L, row0, slice, true);
+  // dz[L-2] = (dout W_{L-1}) * [h > 0], in place over the activations (each element's mask is
+  // read by the lane that overwrites it)
+  gemm_packed(auxS, kOutLd, A.net.pb[L - 1], NTW, cdiv(Nout, 16), scr, nullptr, 0, [&](int row, int col, float v) {
+    float* p = hb + row * WL + col;
+    *p = *p > 0.f ? v : 0.f;
+  });
+  __syncthreads();
+  store_rows4(hb, WL, A.dYg[L - 2], WIDTH, WIDTH, row0, B);
+}
+
+template <int WIDTH>
+__global__ __launch_bounds__(kThreads) void k_lw_dact(const MlpMultiArgs M) {
+  __shared__ __attribute__((aligned(16))) float smem[LwLds<WIDTH>::total];
+  using LY = LwLds<WIDTH>;
+  constexpr int WL = LY::WL, NTW = WIDTH / 16;
+  const MlpArgs& A = lw_args(blockIdx.z);
+  float* xs = smem + LY::x;
+  float* dactS = smem + LY::aux;
+  float* scr = smem + LY::scr;
+  const int row0 = blockIdx.x * kR, B = A.B;
+  const int c0 = A.dact_col0, nc = A.dact_cols;
+  load_rows4(xs, WL, A.dYg[0], WIDTH, WIDTH, row0, B);
+  gemm_packed(xs, WL, A.net.pb[0], cdiv(A.net.dims[0], 16), NTW, scr, nullptr, 0, [&](int row, int col, float v) {
+    const int c = col - c0;
+    if (c >= 0 && c < nc) dactS[row * kOutLd + c] = v;
+  });
+  store_rows(dactS, kOutLd, A.dact, A.lddact, nc, row0, B);
+}
+
+// Can these launches (one for_each_net round) run layer by layer?  Equal shapes and flags, wide
+// hidden layers, every exchange buffer present.
+bool mlp_layerwise_ok(const MlpArgs* a, int n, int width) {
+  if (n < 1 || n > kMaxMulti || width != 512) return false;
+  const MlpArgs& r = a[0];
+  const int L = r.net.n_layers;
+  if (L < 3) return false;
+  for (int j = 0; j < n; ++j) {
+    const MlpArgs& x = a[j];
+    if (x.B != r.B || x.net.n_layers != L || x.do_fwd != r.do_fwd || x.do_bwd != r.do_bwd) return false;
+    if ((x.dact_cols > 0) != (r.dact_cols > 0)) return false;
+    if (x.net.dims[0] > 96 || x.net.dims[L] > kNarrowMax) return false;
+    for (int l = 1; l < L; ++l)
+      if (x.net.dims[l] != width || x.Xg[l] == nullptr) return false;
+    if (x.do_bwd)
+      for (int l = 0; l + 1 < L; ++l)
+        if (x.dYg[l] == nullptr) return false;
+    if (x.dact_cols > 0 && x.dact == nullptr) return false;
+  }
+  return true;
+}
+
+hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, hipStream_t st) {
+  if (!mlp_layerwise_ok(a, n, width)) return hipErrorInvalidValue;
+  MlpMultiArgs m;
+  for (int j = 0; j < n; ++j) m.a[j] = a[j];
+  for (int j = n; j < kMaxMulti; ++j) m.a[j] = a[0];
+  const int slices = (a[0].B + kR - 1) / kR, L = a[0].net.n_layers;
+  const LwGrid g = lw_grid(slices, width / kLwCols, n);
+  const dim3 wide(lw_blocks(g)), narrow(slices, 1, n), blk(kThreads);
+  if (a[0].do_fwd) {
+    hipLaunchKernelGGL(k_lw_in<512>, wide, blk, 0, st, m, g);
+    for (int l = 1; l + 1 < L; ++l) hipLaunchKernelGGL((k_lw_mid<512, false>), wide, blk, 0, st, m, l, g);
+  }
+  hipLaunchKernelGGL(k_lw_head<512>, narrow, blk, 0, st, m);
+  if (a[0].do_bwd) {
+    for (int l = L - 2; l >= 1; --l) hipLaunchKernelGGL((k_lw_mid<512, true>), wide, blk, 0, st, m, l, g);
+    if (a[0].dact_cols > 0) hipLaunchKernelGGL(k_lw_dact<512>, narrow, blk, 0, st, m);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace oprl

@@ -127,6 +127,8 @@ static hipError_t chain_after(hipStream_t st) {
 size_t mlp_slice_lds_bytes(int width, int n_layers);
 hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
 hipError_t launch_mlp_slice_multi(const MlpArgs* a, int n, int width, hipStream_t st);
+bool mlp_layerwise_ok(const MlpArgs* a, int n, int width);
+hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, hipStream_t st);
 hipError_t launch_mlp_slice_tp(const MlpArgs& a, hipStream_t st);
 hipError_t launch_mlp_slice_tp2(const MlpArgs& a0, const MlpArgs& a1, int n_cus, hipStream_t st);
 hipError_t init_slice_tp_attrs();
@@ -335,6 +337,7 @@ struct oprl_learner {
   int pair_n = 0;
   MlpArgs pair_args[2];
   bool no_multi = false;
+  bool no_layerwise = false;   // OPRL_AMD_NO_LAYERWISE: wide nets stay on the single-CU slice kernel (tests / A-B)
   bool no_p2_pair = false;     // OPRL_AMD_NO_P2_PAIR: SAC phase 2 runs the twin critics back to back (tests / A-B)
   bool multi_collect = false;  // for_each_net over > 2 single-CU nets: one k_mlp_slice_multi launch
   int multi_n = 0, multi_width = 0;
@@ -591,7 +594,25 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
     for (int k = 1; k < h->multi_n; ++k)
       same = same && h->multi_args[k].B == h->multi_args[0].B &&
              h->multi_args[k].net.n_layers == h->multi_args[0].net.n_layers;
-    if (same) {
+    // wide nets go layer by layer over the whole chip (csrc/layerwise.hip); launches that keep no
+    // activations (target nets, the actor phase's critics) borrow the nets' dW exchange buffers,
+    // which nobody reads until the next storing launch overwrites them
+    if (same && !h->no_layerwise && h->multi_width == 512 && h->multi_n <= h->nc) {
+      for (int k = 0; k < h->multi_n; ++k) {
+        MlpArgs& a = h->multi_args[k];
+        const NetWs& ws = h->ws_critic[k];
+        for (int l = 1; l < a.net.n_layers; ++l)
+          if (a.Xg[l] == nullptr) a.Xg[l] = ws.X[l];
+        for (int l = 0; l + 1 < a.net.n_layers; ++l)
+          if (a.dYg[l] == nullptr) a.dYg[l] = ws.dY[l];
+      }
+    }
+    if (same && !h->no_layerwise && mlp_layerwise_ok(h->multi_args, h->multi_n, h->multi_width)) {
+      prof_begin(0, st);
+      hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, st);
+      prof_end(st);
+      HIPC(e);
+    } else if (same) {
       prof_begin(0, st);
       hipError_t e = launch_mlp_slice_multi(h->multi_args, h->multi_n, h->multi_width, st);
       prof_end(st);
@@ -1265,6 +1286,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     if (h->ncl != 1 && h->ncl != 2 && h->ncl != 4) h->ncl = kMaxCluster;
     const char* nm = getenv("OPRL_AMD_NO_MULTI");    // tests / A-B: side streams instead of k_mlp_slice_multi
     h->no_multi = (nm != nullptr && atoi(nm) != 0);
+    const char* nlw = getenv("OPRL_AMD_NO_LAYERWISE");
+    h->no_layerwise = (nlw != nullptr && atoi(nlw) != 0);
     const char* np2 = getenv("OPRL_AMD_NO_P2_PAIR");
     h->no_p2_pair = (np2 != nullptr && atoi(np2) != 0);
     const char* nl = getenv("OPRL_AMD_NO_LEAN");

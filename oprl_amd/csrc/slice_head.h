@@ -182,12 +182,23 @@ __device__ __forceinline__ void slice_seed(const MlpArgs& A, const float* outS, 
     } break;
     case SEED_QHUBER: {
       const int Q = S.Q, M = S.M;
+      // the slice's target samples [kR][M] through LDS (scr is free until the diagnostics below):
+      // read from global inside the loop they are M dependent L1 round trips per thread — 20 of the
+      // 29 us of the head launch of TQC's critic step
+      const bool staged = kR * M <= kWaves * kR * 16;
+      if (staged) {
+        for (int idx = tid; idx < kR * M; idx += kThreads) {
+          const int row = idx / M, gr = row0 + row;
+          scr[idx] = gr < B ? S.p0[(size_t)gr * M + (idx - row * M)] : 0.f;
+        }
+        __syncthreads();
+      }
       for (int idx = tid; idx < kR * Q; idx += kThreads) {
         const int row = idx / Q, q = idx - row * Q, gr = row0 + row;
         if (gr >= B) continue;
         const float z = outS[row * kOutLd + q];
         const float tau = ((float)q) / (float)Q + 0.5f / (float)Q;
-        const float* yrow = S.p0 + (size_t)gr * M;
+        const float* yrow = staged ? scr + row * M : S.p0 + (size_t)gr * M;
         float g = 0.f, ls = 0.f;
         for (int s = 0; s < M; ++s) {
           const float dl = yrow[s] - z;

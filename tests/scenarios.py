@@ -221,9 +221,9 @@ class OracleTQC:
     def log_alpha(self): return float(self.o.log_alpha)
 
 
-def tqc_scenario(make, n_steps=2):
+def tqc_scenario(make, n_steps=2, B=256):
     S, A = fx.ENVS["walker"]
-    B, seed = 256, 400
+    seed = 400
     actor = fx.make_net(seed + 1, fx.actor_dims(S, A, gaussian=True))
     critics = [fx.make_net(seed + 2 + n, fx.critic_dims(S, A, out=25, hidden=(512, 512, 512)))
                for n in range(5)]
