@@ -23,8 +23,10 @@
 // bit for bit (tests/test_gpu_fused.py::test_tqc_layerwise_equals_slice_kernel).
 // Reference ops replaced: the addmm / threshold_backward chains of algos/nn_models.py:84-107 under
 // autograd, for tqc.py:128-177.
+#include <cstdlib>
 #include "kernels.h"
 #include "slice_head.h"
+#include "tp4.h"
 
 namespace oprl {
 
@@ -146,6 +148,129 @@ __global__ __launch_bounds__(kThreads, 8) void k_lw_mid(const MlpMultiArgs M, in
   }
 }
 
+// ---- balanced hidden layers -----------------------------------------------------------------------
+// k_lw_mid above deals out equal workgroups, but TQC's 5 nets x 16 slices x 4 column groups = 320 of
+// them land on 256 CUs, a quarter of which then carry two: 6.8 us of MFMA issue where the chip-wide
+// floor is 4.3 us (15.8 us per launch).  Here the 16x16 output tiles of ONE slice across ALL nets
+// (5 x 32 = 160) are cut into G consecutive runs, G x slices = the CU count: 10 tiles per workgroup,
+// one workgroup per CU.  A run may straddle two nets (two input tiles in LDS).  Wave w contracts
+// K-eighth (w & 7) — four macro steps, the same A fragments for all its tiles — of every second tile
+// of the run (parity w >> 3): 20 B fragments per wave, all requested at entry, before the rows.  The
+// eight partial tiles of a tile meet in LDS and are summed in K order.
+constexpr int kLwMaxRun = 10;                   // tiles per workgroup
+struct LwRun { int slices, nets, G, tpg, gpx; };   // runs per slice, tiles per run, runs per XCD
+
+template <bool BWD>
+__global__ __launch_bounds__(kThreads) void k_lw_mid_run(const MlpMultiArgs M, int l, const LwRun R) {
+  constexpr int WIDTH = 512, WL = lds_ld(WIDTH), NTW = WIDTH / 16;
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  float* xs0 = dsm;
+  float* xs1 = dsm + kR * WL;
+  float* scr = dsm + 2 * kR * WL;               // [run tile][K-eighth][64 lanes][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  // XCD x owns the runs [x * gpx, (x + 1) * gpx) of every slice: a run's weights cross the fabric once
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int gl = j / R.slices, g = xcd * R.gpx + gl, slice = j - gl * R.slices;
+  const int total = R.nets * NTW;
+  const int t0 = g * R.tpg, t1 = min(t0 + R.tpg, total);
+  if (gl >= R.gpx || g >= R.G || t0 >= total) return;
+  const int nt = t1 - t0, n0 = t0 / NTW, n1 = (t1 - 1) / NTW;
+  const int row0 = slice * kR;
+  const int B = lw_args(n0).B;
+  const int ke = wave & 7, par = wave >> 3;
+
+  // ---- requests: this wave's B fragments, then the input rows (and, backward, the ReLU masks)
+  f32x4 b[5][4];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int tl = par + 2 * q;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b[q][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tl < nt) {
+      const int t = t0 + tl, net = t / NTW, ntile = t - net * NTW;
+      const MlpArgs& A = lw_args(net);
+      const float* pk = (BWD ? A.net.pb[l] : A.net.pf[l]) + (((size_t)ntile * NTW + 4 * ke) * 64 + lane) * 4;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b[q][s] = ld4(pk + s * 256);
+    }
+  }
+  {
+    const MlpArgs& A0 = lw_args(n0);
+    const MlpArgs& A1 = lw_args(n1);
+    const float* src0 = BWD ? A0.dYg[l] : A0.Xg[l];
+    const float* src1 = BWD ? A1.dYg[l] : A1.Xg[l];
+    f32x4 v[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int idx = tid + h * kThreads;                 // 16 rows x 128 float4
+      const int row = idx >> 7, col = (idx & 127) * 4, gr = row0 + row;
+      v[0][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+      v[1][h] = v[0][h];
+      if (gr < B) {
+        v[0][h] = ld4(src0 + (size_t)gr * WIDTH + col);
+        if (n1 != n0) v[1][h] = ld4(src1 + (size_t)gr * WIDTH + col);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int idx = tid + h * kThreads;
+      const int row = idx >> 7, col = (idx & 127) * 4;
+      *reinterpret_cast<f32x4*>(xs0 + row * WL + col) = v[0][h];
+      if (n1 != n0) *reinterpret_cast<f32x4*>(xs1 + row * WL + col) = v[1][h];
+    }
+  }
+  __syncthreads();
+
+  // ---- partial tiles
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int tl = par + 2 * q;
+    if (tl < nt) {
+      const int net = (t0 + tl) / NTW;
+      const float* xr = (net == n0 ? xs0 : xs1) + i * WL + 64 * ke + 4 * kk;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mac4(ld4(xr + 16 * s), b[q][s], acc);
+      *reinterpret_cast<f32x4*>(scr + ((size_t)(tl * 8 + ke) * 64 + lane) * 4) = acc;
+    }
+  }
+  __syncthreads();
+
+  // ---- K-ordered sum, bias + ReLU (forward) or ReLU mask (backward), rows out
+  for (int e = tid; e < nt * 256; e += kThreads) {
+    const int tl = e >> 8, r = e & 255, row = r >> 4, col = r & 15, gr = row0 + row;
+    if (gr >= B) continue;
+    const int t = t0 + tl, net = t / NTW, ntile = t - net * NTW;
+    const MlpArgs& A = lw_args(net);
+    const size_t off = (size_t)gr * WIDTH + ntile * 16 + col;
+    const float* sp = scr + ((size_t)(tl * 8) * 64 + (row >> 2) * 16 + col) * 4 + (row & 3);
+    float v = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) v += sp[p * 256];
+    if constexpr (BWD) {
+      A.dYg[l - 1][off] = A.Xg[l][off] > 0.f ? v : 0.f;
+    } else {
+      A.Xg[l + 1][off] = fmaxf(v + A.net.b[l][ntile * 16 + col], 0.f);
+    }
+  }
+}
+
+inline LwRun lw_run(int slices, int nets, int n_cus) {
+  LwRun r;
+  r.slices = slices; r.nets = nets;
+  const int total = nets * 32;
+  int G = n_cus / slices;
+  if (G < 1) G = 1;
+  if (G > total) G = total;
+  r.tpg = (total + G - 1) / G;
+  if (r.tpg > kLwMaxRun) r.tpg = kLwMaxRun;
+  r.G = (total + r.tpg - 1) / r.tpg;
+  r.gpx = (r.G + 7) / 8;
+  return r;
+}
+constexpr size_t kLwRunLds = sizeof(float) * (2 * kR * lds_ld(512) + kLwMaxRun * 8 * 256);
+
 template <int WIDTH>
 __global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M) {
   __shared__ __attribute__((aligned(16))) float smem[LwLds<WIDTH>::total];
@@ -219,7 +344,15 @@ bool mlp_layerwise_ok(const MlpArgs* a, int n, int width) {
   return true;
 }
 
-hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, hipStream_t st) {
+hipError_t init_layerwise_attrs() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_mid_run<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLwRunLds);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_mid_run<true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLwRunLds);
+}
+
+hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st) {
   if (!mlp_layerwise_ok(a, n, width)) return hipErrorInvalidValue;
   MlpMultiArgs m;
   for (int j = 0; j < n; ++j) m.a[j] = a[j];
@@ -227,13 +360,24 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, hipStream_t 
   const int slices = (a[0].B + kR - 1) / kR, L = a[0].net.n_layers;
   const LwGrid g = lw_grid(slices, width / kLwCols, n);
   const dim3 wide(lw_blocks(g)), narrow(slices, 1, n), blk(kThreads);
+  // hidden layers: runs of tiles balanced over the CUs (k_lw_mid_run), or — OPRL_AMD_LW_EQUAL=1, A/B
+  // and tests — the equal (slice, 128 columns, net) workgroups of k_lw_mid
+  static const bool equal_wgs = [] { const char* e = getenv("OPRL_AMD_LW_EQUAL"); return e != nullptr && atoi(e) != 0; }();
+  const LwRun r = lw_run(slices, n, n_cus > 0 ? n_cus : 256);
+  const dim3 runs(8 * r.gpx * slices);
   if (a[0].do_fwd) {
     hipLaunchKernelGGL(k_lw_in<512>, wide, blk, 0, st, m, g);
-    for (int l = 1; l + 1 < L; ++l) hipLaunchKernelGGL((k_lw_mid<512, false>), wide, blk, 0, st, m, l, g);
+    for (int l = 1; l + 1 < L; ++l) {
+      if (equal_wgs) hipLaunchKernelGGL((k_lw_mid<512, false>), wide, blk, 0, st, m, l, g);
+      else hipLaunchKernelGGL((k_lw_mid_run<false>), runs, blk, kLwRunLds, st, m, l, r);
+    }
   }
   hipLaunchKernelGGL(k_lw_head<512>, narrow, blk, 0, st, m);
   if (a[0].do_bwd) {
-    for (int l = L - 2; l >= 1; --l) hipLaunchKernelGGL((k_lw_mid<512, true>), wide, blk, 0, st, m, l, g);
+    for (int l = L - 2; l >= 1; --l) {
+      if (equal_wgs) hipLaunchKernelGGL((k_lw_mid<512, true>), wide, blk, 0, st, m, l, g);
+      else hipLaunchKernelGGL((k_lw_mid_run<true>), runs, blk, kLwRunLds, st, m, l, r);
+    }
     if (a[0].dact_cols > 0) hipLaunchKernelGGL(k_lw_dact<512>, narrow, blk, 0, st, m);
   }
   return hipGetLastError();

@@ -128,7 +128,8 @@ size_t mlp_slice_lds_bytes(int width, int n_layers);
 hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
 hipError_t launch_mlp_slice_multi(const MlpArgs* a, int n, int width, hipStream_t st);
 bool mlp_layerwise_ok(const MlpArgs* a, int n, int width);
-hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, hipStream_t st);
+hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st);
+hipError_t init_layerwise_attrs();
 hipError_t launch_mlp_slice_tp(const MlpArgs& a, hipStream_t st);
 hipError_t launch_mlp_slice_tp2(const MlpArgs& a0, const MlpArgs& a1, int n_cus, hipStream_t st);
 hipError_t init_slice_tp_attrs();
@@ -609,7 +610,7 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
     }
     if (same && !h->no_layerwise && mlp_layerwise_ok(h->multi_args, h->multi_n, h->multi_width)) {
       prof_begin(0, st);
-      hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, st);
+      hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, h->n_cus, st);
       prof_end(st);
       HIPC(e);
     } else if (same) {
@@ -1200,6 +1201,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   hipError_t e = init_kernel_attrs();
   if (e == hipSuccess) e = init_fused_attrs();
   if (e == hipSuccess) e = init_slice_tp_attrs();
+  if (e == hipSuccess) e = init_layerwise_attrs();
   if (e != hipSuccess) { set_err("hipFuncSetAttribute: %s", hipGetErrorString(e)); delete h; return OPRL_ERR_HIP; }
   memset(&h->src, 0, sizeof h->src);
   memset(&h->next_src, 0, sizeof h->next_src);
