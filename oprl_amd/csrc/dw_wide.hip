@@ -1,0 +1,209 @@
+// dw_wide.hip — dW + Adam + Polyak for wide layers (TQC's 512x512 quantile-critic layers).
+//
+// k_dw_adam's 16(n) x 32(k) tiles are sized for the 256-wide nets of the headline path, where the
+// launch is a latency chain and more, smaller workgroups win.  On a 512x512 layer every tile
+// re-reads 48 KB of X / dY rows for 512 outputs: 24 MB per layer, 240 MB for TQC's ten wide layers
+// (72 us per critic step, profiles/r01g_kernel_stats_tqc.csv).  Here a workgroup owns a 64 x 64
+// tile (128 KB of rows for 4096 outputs, 8 MB per layer): eight waves, each two 16x16 MFMA tiles
+// sharing the dY operand, the minibatch walked in 64-row chunks through LDS; the epilogue is the
+// same torch-semantics Adam + Polyak as k_dw_adam, eight consecutive k per thread as float4
+// accesses, the three fragment-order packs written block by block from the staged tile.
+// Reference ops replaced: loss.backward()'s addmm-backward + optim.Adam.step + soft_update
+// (tqc.py:150-177, nn_functions.py:5-10).
+#include "kernels.h"
+
+namespace oprl {
+
+constexpr int kWT = 64;                  // tile extent in n and in k
+constexpr int kWLd = kWT + 16;           // staging rows: 80 floats, the four 16-lane groups of a read hit distinct banks
+constexpr int kWChunk = 64;              // minibatch rows per staging round
+constexpr int kWThreads = 512;
+constexpr int kWMaxItems = 10;
+
+struct DwWideArgs {
+  int tile_end[kWMaxItems];
+  DwItem items[kWMaxItems];
+  int n_items, B;
+  AdamScalars ad;
+};
+
+__global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A) {
+  __shared__ __attribute__((aligned(16))) float stA[kWChunk][kWLd];   // dY rows [b][n]; later the new W tile
+  __shared__ __attribute__((aligned(16))) float stX[kWChunk][kWLd];   // X  rows [b][k]; later the new target tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const DwWideArgs* KA = (const DwWideArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  int item = 0;
+  for (int j = 0; j + 1 < A.n_items; ++j) item += (int)blockIdx.x >= KA->tile_end[j] ? 1 : 0;
+  const DwItem I = KA->items[item];
+  const int lt = (int)blockIdx.x - (item > 0 ? KA->tile_end[item - 1] : 0);
+  const int tiles_k = I.K / kWT;
+  const int tn = lt / tiles_k, tk = lt - tn * tiles_k;
+  const int n_base = tn * kWT, k_base = tk * kWT;
+  const int NSk = I.K >> 4, NSn = I.N >> 4;
+  const bool polyak = A.ad.do_polyak && I.w_t != nullptr;
+  const int B = A.B;
+
+  // ---- this thread's 8 epilogue elements: row en, columns ek .. ek+7; Adam state requested now
+  const int el_n = tid >> 3, el_k = (tid & 7) * 8;
+  const size_t eo = (size_t)(n_base + el_n) * I.K + k_base + el_k;
+  f32x4 p_th[2], p_m[2], p_v[2], p_tt[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    p_th[h] = p_m[h] = p_v[h] = p_tt[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (A.ad.do_adam) {
+      p_th[h] = ld4(I.w + eo + 4 * h);
+      p_m[h] = ld4(I.w_m + eo + 4 * h);
+      p_v[h] = ld4(I.w_v + eo + 4 * h);
+      if (polyak) p_tt[h] = ld4(I.w_t + eo + 4 * h);
+    }
+  }
+
+  // ---- dW tile = sum_b dY[b, n]^T X[b, k].  Wave w: n block w >> 1, k blocks 2 (w & 1) + {0, 1}.
+  // MFMA step u of a chunk contracts rows 4u .. 4u+3: lane (c, i) feeds dY[4u + c][n] as A and
+  // X[4u + c][k], X[4u + c][k + 16] as the two B operands.
+  const int i = lane & 15, c = lane >> 4;
+  const int nb = wave >> 1, kb = 2 * (wave & 1);
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  float sA = 0.f;
+  // staging: 64 rows x 16 float4 per matrix = 2 float4 per thread per matrix
+  const int sr = tid >> 4, sc4 = (tid & 15) * 4;
+  f32x4 va[2], vx[2];
+  auto request = [&](int chunk) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int bb = chunk * kWChunk + sr + 32 * h;
+      va[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+      vx[h] = va[h];
+      if (bb < B) {
+        va[h] = ld4(I.dY + (size_t)bb * I.ldy + n_base + sc4);
+        vx[h] = ld4(I.X + (size_t)bb * I.ldx + k_base + sc4);
+      }
+    }
+  };
+  const int n_chunks = (B + kWChunk - 1) / kWChunk;
+  request(0);
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    __syncthreads();                      // the previous chunk's reads are done
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<f32x4*>(&stA[sr + 32 * h][sc4]) = va[h];
+      *reinterpret_cast<f32x4*>(&stX[sr + 32 * h][sc4]) = vx[h];
+    }
+    if (chunk + 1 < n_chunks) request(chunk + 1);   // in flight during this chunk's MFMAs
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kWChunk / 4; ++u) {
+      const float av = stA[4 * u + c][nb * 16 + i];
+      const float x0 = stX[4 * u + c][kb * 16 + i];
+      const float x1 = stX[4 * u + c][kb * 16 + 16 + i];
+      sA += av;
+      acc[0] = mfma4(av, x0, acc[0]);
+      acc[1] = mfma4(av, x1, acc[1]);
+    }
+  }
+  __syncthreads();
+  // gradient tile -> stA[n][k] (acc row = n index 4c + r, column = k index i); db -> stX[0][n]
+#pragma unroll
+  for (int w = 0; w < 2; ++w)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) stA[nb * 16 + c * 4 + r][(kb + w) * 16 + i] = acc[w][r];
+  {
+    float sb = sA;
+    sb += __shfl_xor(sb, 16);
+    sb += __shfl_xor(sb, 32);
+    if ((wave & 1) == 0 && c == 0) stX[0][nb * 16 + i] = sb;
+  }
+  __syncthreads();
+
+  // ---- epilogue
+  const float step_size = A.ad.step_size_host, bc2_sqrt = A.ad.bc2_sqrt_host;
+  f32x4 th_new[2], tt_new[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f32x4 g = ld4(&stA[el_n][el_k + 4 * h]) * A.ad.grad_scale;
+    th_new[h] = p_th[h];
+    tt_new[h] = p_tt[h];
+    if (I.w_g != nullptr) *reinterpret_cast<f32x4*>(I.w_g + eo + 4 * h) = g;
+    if (A.ad.do_adam) {
+      f32x4 mm, vv, th;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        mm[t] = p_m[h][t] + (g[t] - p_m[h][t]) * A.ad.omb1;
+        vv[t] = p_v[h][t] * A.ad.beta2 + A.ad.omb2 * g[t] * g[t];
+        th[t] = p_th[h][t] - step_size * (mm[t] / (sqrtf(vv[t]) / bc2_sqrt + A.ad.eps));
+      }
+      *reinterpret_cast<f32x4*>(I.w_m + eo + 4 * h) = mm;
+      *reinterpret_cast<f32x4*>(I.w_v + eo + 4 * h) = vv;
+      *reinterpret_cast<f32x4*>(I.w + eo + 4 * h) = th;
+      th_new[h] = th;
+      if (polyak) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) tt_new[h][t] = p_tt[h][t] * A.ad.omtau + A.ad.tau * th[t];
+        *reinterpret_cast<f32x4*>(I.w_t + eo + 4 * h) = tt_new[h];
+      }
+    }
+  }
+  // bias (one k tile per n range does it)
+  float gb = 0.f;
+  if (tk == 0 && tid < kWT) gb = stX[0][tid];
+  __syncthreads();                        // gradient tile and db consumed
+  if (tk == 0 && tid < kWT) {
+    const int n = n_base + tid;
+    float t0, t1;
+    (void)adam_polyak_elem(gb, I.b + n, I.b_m ? I.b_m + n : nullptr, I.b_v ? I.b_v + n : nullptr,
+                           I.b_t ? I.b_t + n : nullptr, I.b_g ? I.b_g + n : nullptr, A.ad, step_size, bc2_sqrt,
+                           &t0, &t1);
+  }
+  if (!(A.ad.do_adam && I.pf != nullptr)) return;
+  // ---- packs: the new tile(s) staged as [n][k], then 16 blocks of 16x16 per pack in pack order
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    *reinterpret_cast<f32x4*>(&stA[el_n][el_k + 4 * h]) = th_new[h];
+    *reinterpret_cast<f32x4*>(&stX[el_n][el_k + 4 * h]) = tt_new[h];
+  }
+  __syncthreads();
+  const int l = tid & 63, li = l & 15, lk = l >> 4;
+  for (int job = tid >> 6; job < 48; job += kWThreads / 64) {
+    const int which = job >> 4, blk = job & 15, bn = blk >> 2, bk = blk & 3;   // block (n block, k block)
+    if (which == 1) {            // W^T pack: tiles over k, steps over n
+      if (I.pb == nullptr) continue;
+      f32x4 v;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = stA[bn * 16 + 4 * lk + t][bk * 16 + li];
+      *reinterpret_cast<f32x4*>(I.pb + (((size_t)((k_base >> 4) + bk) * NSn + (n_base >> 4) + bn) * 64 + l) * 4) = v;
+    } else {                     // W pack (online, target): tiles over n, steps over k
+      float* dst = which == 0 ? I.pf : (polyak ? I.tpf : nullptr);
+      if (dst == nullptr) continue;
+      const float (*src)[kWLd] = which == 0 ? stA : stX;
+      *reinterpret_cast<f32x4*>(dst + (((size_t)((n_base >> 4) + bn) * NSk + (k_base >> 4) + bk) * 64 + l) * 4) =
+          *reinterpret_cast<const f32x4*>(&src[bn * 16 + li][bk * 16 + 4 * lk]);
+    }
+  }
+}
+
+// Is this layer one for the wide kernel?  (Full 64 x 64 tiles; no dz1 partial buffers, no per-row seed.)
+bool dw_wide_item_ok(const DwItem& it, const DwArgs& a) {
+  if (a.apply_only || a.B < 1) return false;
+  if (it.N % kWT != 0 || it.K % kWT != 0 || it.N < 512 || it.K < 512) return false;   // (256-wide layers: k_dw_adam, one launch)
+  if (it.dY_part_stride > 0 && a.n_part > 1) return false;
+  if (it.scaled != 0 && a.use_row_scale != 0) return false;
+  if (it.ldx % 4 != 0 || it.ldy % 4 != 0) return false;
+  return true;
+}
+
+hipError_t launch_dw_adam_wide(const DwItem* items, int n_items, int B, const AdamScalars& ad, hipStream_t st) {
+  if (n_items < 1 || n_items > kWMaxItems) return hipErrorInvalidValue;
+  DwWideArgs k;
+  int total = 0;
+  for (int j = 0; j < n_items; ++j) {
+    k.items[j] = items[j];
+    total += (items[j].N / kWT) * (items[j].K / kWT);
+    k.tile_end[j] = total;
+  }
+  for (int j = n_items; j < kWMaxItems; ++j) { k.items[j] = items[0]; k.tile_end[j] = total; }
+  k.n_items = n_items; k.B = B; k.ad = ad;
+  hipLaunchKernelGGL(k_dw_adam_wide, dim3(total), dim3(kWThreads), 0, st, k);
+  return hipGetLastError();
+}
+
+}  // namespace oprl

@@ -113,6 +113,36 @@ struct AdamScalars {
   float grad_scale;
 };
 
+// Per element, torch.optim.Adam single-tensor semantics and the Polyak target update:
+//   m += (g-m)(1-b1);  v = b2 v + (1-b2) g g;  th -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps)
+//   th_t = (1-tau) th_t + tau th                       (nn_functions.py:5-10)
+// returns bit0: theta written (*th_new), bit1: target written (*tt_new)
+__device__ __forceinline__ int adam_polyak_elem(float g, float* th, float* m, float* v, float* tt,
+                                                float* gout, const AdamScalars& ad,
+                                                float step_size, float bc2_sqrt, float* th_new,
+                                                float* tt_new) {
+  g *= ad.grad_scale;
+  if (gout != nullptr) *gout = g;
+  if (!ad.do_adam) return 0;
+  float mm = *m, vv = *v, t = *th;
+  mm = mm + (g - mm) * ad.omb1;
+  vv = vv * ad.beta2 + ad.omb2 * g * g;
+  const float denom = sqrtf(vv) / bc2_sqrt + ad.eps;
+  t = t - step_size * (mm / denom);
+  *m = mm;
+  *v = vv;
+  *th = t;
+  *th_new = t;
+  if (ad.do_polyak && tt != nullptr) {
+    const float u = *tt * ad.omtau + ad.tau * t;
+    *tt = u;
+    *tt_new = u;
+    return 3;
+  }
+  return 1;
+}
+
+
 struct DwArgs {                         // host-side description of one k_dw_adam launch
   const DwItem* items;                 // HOST array
   int n_items; int total_tiles; int B;

@@ -11,6 +11,7 @@
 //
 // Reference op groups replaced: SURVEY.md §2.2 K2-K13.
 #include <cmath>
+#include <cstdlib>
 #include "kernels.h"
 #include "philox.h"
 #include "slice_head.h"
@@ -92,32 +93,6 @@ template __global__ void k_mlp_slice_multi<512>(const MlpMultiArgs);
 //   m += (g-m)(1-b1);  v = b2 v + (1-b2) g g;  th -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps)
 //   th_t = (1-tau) th_t + tau th                       (Polyak, nn_functions.py:5-10)
 // ---------------------------------------------------------------------------
-// returns bit0: theta written (*th_new), bit1: target written (*tt_new)
-__device__ __forceinline__ int adam_polyak_elem(float g, float* th, float* m, float* v, float* tt,
-                                                float* gout, const AdamScalars& ad,
-                                                float step_size, float bc2_sqrt, float* th_new,
-                                                float* tt_new) {
-  g *= ad.grad_scale;
-  if (gout != nullptr) *gout = g;
-  if (!ad.do_adam) return 0;
-  float mm = *m, vv = *v, t = *th;
-  mm = mm + (g - mm) * ad.omb1;
-  vv = vv * ad.beta2 + ad.omb2 * g * g;
-  const float denom = sqrtf(vv) / bc2_sqrt + ad.eps;
-  t = t - step_size * (mm / denom);
-  *m = mm;
-  *v = vv;
-  *th = t;
-  *th_new = t;
-  if (ad.do_polyak && tt != nullptr) {
-    const float u = *tt * ad.omtau + ad.tau * t;
-    *tt = u;
-    *tt_new = u;
-    return 3;
-  }
-  return 1;
-}
-
 __device__ __forceinline__ void adam_bias_corr(const AdamScalars& ad, float* step_size, float* bc2_sqrt) {
   if (ad.step_dev == nullptr) {   // host knows the step: corrections arrive precomputed (double math)
     *step_size = ad.step_size_host;
@@ -530,8 +505,27 @@ hipError_t init_kernel_attrs() {
 
 __device__ float g_one = 1.f;
 
-hipError_t launch_dw_adam(const DwArgs& a, hipStream_t st) {
-  if (a.n_items < 1 || a.n_items > kDwMaxItems) return hipErrorInvalidValue;
+bool dw_wide_item_ok(const DwItem& it, const DwArgs& a);
+hipError_t launch_dw_adam_wide(const DwItem* items, int n_items, int B, const AdamScalars& ad, hipStream_t st);
+
+hipError_t launch_dw_adam(const DwArgs& a0, hipStream_t st) {
+  if (a0.n_items < 1 || a0.n_items > kDwMaxItems) return hipErrorInvalidValue;
+  // wide layers (TQC's 512x512) go to the 64x64-tile kernel (csrc/dw_wide.hip), the rest stay here
+  static const bool no_wide = [] { const char* e = getenv("OPRL_AMD_NO_DW_WIDE"); return e != nullptr && atoi(e) != 0; }();
+  DwItem rest[kDwMaxItems], wide[kDwMaxItems];
+  int n_rest = 0, n_wide = 0;
+  for (int j = 0; j < a0.n_items; ++j) {
+    if (!no_wide && n_wide < 10 && dw_wide_item_ok(a0.items[j], a0)) wide[n_wide++] = a0.items[j];
+    else rest[n_rest++] = a0.items[j];
+  }
+  if (n_wide > 0) {
+    hipError_t e = launch_dw_adam_wide(wide, n_wide, a0.B, a0.ad, st);
+    if (e != hipSuccess) return e;
+    if (n_rest == 0) return hipSuccess;
+  }
+  DwArgs a = a0;
+  a.items = rest;
+  a.n_items = n_rest;
   static const float* one_dev = nullptr;
   if (one_dev == nullptr) {
     void* p = nullptr;

@@ -359,3 +359,45 @@ def test_tqc_layerwise_equals_slice_kernel(B, monkeypatch):
     sl, sr = lw.learner.read_scalars(), ref.learner.read_scalars()
     for k in ("critic_loss", "actor_loss", "alpha"):
         assert abs(sl[k] - sr[k]) <= 1e-4 * max(abs(sr[k]), 1e-6), k
+
+
+def test_tqc_wide_dw_equals_small_tiles(monkeypatch):
+    """csrc/dw_wide.hip (64x64 tiles for the 512x512 layers) against k_dw_adam's 16x32 tiles: same
+    gradient up to the summation order over the minibatch, same Adam / Polyak / pack epilogue."""
+    from oprl_amd.algos.tqc import TQC
+    from oprl_amd.logging import NullLogger
+    import subprocess, sys, os
+    # the switch is read once per process: run the small-tile learner in a child
+    code = (
+        "import torch as t, sys; sys.path.insert(0, %r)\n"
+        "from oracle import fixtures as fx\n"
+        "from oprl_amd.algos.tqc import TQC\n"
+        "from oprl_amd.logging import NullLogger\n"
+        "t.manual_seed(0)\n"
+        "a = TQC(logger=NullLogger('/tmp/oprl_amd_test'), state_dim=24, action_dim=6, device='cuda', max_batch=256).create()\n"
+        "for step in range(3):\n"
+        "    a.update(*[x.cuda() for x in fx.make_batch(25 + step, 256, 24, 6)])\n"
+        "t.cuda.synchronize()\n"
+        "t.save({m: getattr(a, m)._oprl_arena.cpu() for m in ('actor', 'critic', 'critic_target')}, sys.argv[1])\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = "/tmp/oprl_amd_test_dw_small.pt"
+    env = dict(os.environ, OPRL_AMD_NO_DW_WIDE="1")
+    subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=300)
+    ref = t.load(out)
+    t.manual_seed(0)
+    wide = TQC(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=256).create()
+    for step in range(3):
+        wide.update(*[x.cuda() for x in fx.make_batch(25 + step, 256, 24, 6)])
+    t.cuda.synchronize()
+    for m in ("actor", "critic", "critic_target"):
+        a, b = getattr(wide, m)._oprl_arena.cpu(), ref[m]
+        d = (a - b).abs()
+        assert t.isfinite(a).all(), m
+        assert d.max().item() <= 3 * 3 * 3e-4, m
+        assert (d > 1e-5 * b.abs().max().item()).float().mean().item() < 1e-2, m
+    # packs in step with the masters: a forward through the packs the kernel wrote equals one through
+    # packs rebuilt from the master parameters
+    sb, ab = [x.cuda() for x in fx.make_batch(31, 256, 24, 6)[:2]]
+    z0, zt0 = wide.critic(sb, ab).clone(), wide.critic_target(sb, ab).clone()
+    wide.learner.sync_params()
+    assert t.equal(z0, wide.critic(sb, ab)) and t.equal(zt0, wide.critic_target(sb, ab))
