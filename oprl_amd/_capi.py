@@ -146,8 +146,34 @@ def check(rc: int, what: str = "") -> None:
 
 
 def current_stream():
+    """The caller's current HIP stream as a void* (torch.cuda.current_stream() builds a Stream
+    object per call, ~10 us; the raw accessor is what torch's own compiled code uses)."""
     import torch
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        return C.c_void_p(raw(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(dev):
+    """``with on_device(dev):`` — torch.cuda.device(dev) only when dev is not already current
+    (entering the real guard costs several microseconds on the per-env-step path)."""
+    import torch
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if torch.cuda.current_device() == idx:
+        return _NO_GUARD
+    return torch.cuda.device(idx)
 
 
 def ptr(t) -> C.c_void_p:

@@ -30,6 +30,23 @@ class OffPolicyAlgorithm(ABC):
     def get_policy_state_dict(self) -> dict[str, Any]:
         return self.actor.state_dict()
 
+    def _log_update(self, step: int) -> None:
+        """Scalar logging at the algorithm's cadence (the only host sync of an update)."""
+
+    def update_from_buffer(self, replay_buffer, batch_size: int) -> None:
+        """``update(*replay_buffer.sample(batch_size))`` as ONE C call (oprl_learner_step_n with
+        K = 1): the slice kernels gather their own rows from the HBM replay with the sampler's
+        Philox draw, so the per-step host work is one ctypes call instead of a gather launch, five
+        output allocations and the update's argument checks.  A buffer without a device handle
+        (or a gradient-exporting data-parallel learner) takes the two-call path."""
+        handle = getattr(replay_buffer, "handle", None)
+        if handle is None or self.learner.export_grads:
+            self.update(*replay_buffer.sample(batch_size))
+            return
+        step = self.update_step
+        self.learner.step_n(handle, 1, int(batch_size), seed=int(getattr(replay_buffer, "seed", 0)))
+        self._log_update(step)
+
     # full learner state (parameters, targets, optimiser moments, counters): exact resume
     def state_dict(self) -> dict[str, Any]:
         return self.learner.state_dict()
@@ -132,7 +149,7 @@ class HipLearner:
         self._mlps = (actor_mlp, actor_target_mlp, list(critic_mlps), list(critic_target_mlps))
         self._ptrs = self._snapshot_ptrs()
         h = C.c_void_p()
-        with t.cuda.device(device):
+        with _capi.on_device(device):
             _capi.check(self.lib.oprl_learner_create(C.byref(cfg), C.byref(h)), "oprl_learner_create")
         self.handle = h
         self._all_mlps = [m for m in [actor_mlp, actor_target_mlp, *critic_mlps, *critic_target_mlps]
@@ -171,7 +188,7 @@ class HipLearner:
         """Rebuild the fragment-order packs from the master parameters.  Called
         automatically when torch reports an in-place change (load_state_dict,
         ``param.copy_``); call it yourself after writing through ``.data``."""
-        with t.cuda.device(self.device):
+        with _capi.on_device(self.device):
             _capi.check(self.lib.oprl_learner_sync_params(self.handle, _capi.current_stream()),
                         "oprl_learner_sync_params")
         for m in self._all_mlps:
@@ -257,7 +274,7 @@ class HipLearner:
         B, s, a, r, d, s2 = self._prep(state, action, reward, done, next_state)
         n0 = None if noise0 is None else noise0.to(device=self.device, dtype=t.float32).reshape(B, self.A).contiguous()
         n1 = None if noise1 is None else noise1.to(device=self.device, dtype=t.float32).reshape(B, self.A).contiguous()
-        with t.cuda.device(self.device):
+        with _capi.on_device(self.device):
             _capi.check(self.lib.oprl_learner_update(
                 self.handle, _capi.ptr(s), _capi.ptr(a), _capi.ptr(r), _capi.ptr(d), _capi.ptr(s2), B,
                 _capi.ptr(n0), _capi.ptr(n1), _capi.current_stream()), "oprl_learner_update")
@@ -267,25 +284,25 @@ class HipLearner:
         B, s, a, r, d, s2 = self._prep(state, action, reward, done, next_state)
         n0 = None if noise0 is None else noise0.to(device=self.device, dtype=t.float32).reshape(B, self.A).contiguous()
         n1 = None if noise1 is None else noise1.to(device=self.device, dtype=t.float32).reshape(B, self.A).contiguous()
-        with t.cuda.device(self.device):
+        with _capi.on_device(self.device):
             _capi.check(self.lib.oprl_learner_update_phase(
                 self.handle, phase, _capi.ptr(s), _capi.ptr(a), _capi.ptr(r), _capi.ptr(d), _capi.ptr(s2),
                 B, _capi.ptr(n0), _capi.ptr(n1), _capi.current_stream()), "oprl_learner_update_phase")
 
     def apply(self, phase: int, grad_scale: float) -> None:
-        with t.cuda.device(self.device):
+        with _capi.on_device(self.device):
             _capi.check(self.lib.oprl_learner_apply(self.handle, phase, float(grad_scale),
                                                     _capi.current_stream()), "oprl_learner_apply")
 
     def step_n(self, replay_handle, K: int, B: int, seed: int) -> None:
         self.check_bound()
-        with t.cuda.device(self.device):
+        with _capi.on_device(self.device):
             _capi.check(self.lib.oprl_learner_step_n(self.handle, replay_handle, K, B, seed,
                                                      _capi.current_stream()), "oprl_learner_step_n")
 
     def read_scalars(self) -> dict[str, float]:
         buf = (C.c_float * 6)()
-        with t.cuda.device(self.device):
+        with _capi.on_device(self.device):
             _capi.check(self.lib.oprl_learner_read_scalars(self.handle, buf, 6, _capi.current_stream()),
                         "oprl_learner_read_scalars")
         keys = ("critic_loss", "actor_loss", "q_mean", "q_target_mean", "alpha", "update_step")

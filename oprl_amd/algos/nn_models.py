@@ -124,23 +124,33 @@ class MLP(nn.Module):
         self._hip_ok = isinstance(hidden_activation, nn.ReLU) and isinstance(output_activation, nn.Identity)
         self._pack: t.Tensor | None = None   # fragment-order weight packs (device)
         self._pack_key = None
+        self._plist: list[nn.Parameter] | None = None   # the Parameter objects (they outlive .data swaps)
+        self._desc_key = None
+        self._desc = None
+
+    def _params(self) -> list[nn.Parameter]:
+        # walking the module tree costs ~25 us per call; the Parameter OBJECTS of a built MLP never
+        # change (flatten_module_, load_state_dict and .to() swap or fill their .data)
+        if self._plist is None:
+            self._plist = list(self.parameters())
+        return self._plist
 
     # -- HIP path ------------------------------------------------------------
     def theta_ptr(self) -> int:
         """Device pointer of this MLP's W0 (its parameters must be flat; they
         are when the MLP or an ancestor went through flatten_module_)."""
-        ps = list(self.parameters())
+        ps = self._params()
         expect = ps[0].data_ptr()
         for p in ps:
             if p.data_ptr() != expect:
                 flatten_module_(self)
-                return next(self.parameters()).data_ptr()
+                return ps[0].data_ptr()
             expect += p.numel() * 4
         return ps[0].data_ptr()
 
     # -- fragment-order packs ---------------------------------------------------
     def _param_key(self):
-        ps = list(self.parameters())
+        ps = self._params()
         return tuple(p.data_ptr() for p in ps) + tuple(p._version for p in ps)
 
     def mark_dirty(self) -> None:
@@ -154,23 +164,32 @@ class MLP(nn.Module):
 
     def pack_tensor(self) -> t.Tensor:
         """The pack buffer (allocated on first use, on the parameters' device)."""
-        dev = next(self.parameters()).device
+        dev = self._params()[0].device
         if self._pack is None or self._pack.device != dev:
             self._pack = t.zeros(pack_floats(self.dims), dtype=t.float32, device=dev)
             self._pack_key = None
         return self._pack
 
     def ensure_packed(self) -> t.Tensor:
+        return self._packed_desc()[0]
+
+    def _packed_desc(self):
+        """(pack tensor, C descriptor of this net with its packs), the packs rebuilt if the master
+        parameters changed behind them."""
         pk = self.pack_tensor()
         theta = self.theta_ptr()
         key = self._param_key()
         if key != self._pack_key:
             desc = _net_desc(self.dims, theta, pack_ptr=pk.data_ptr())
-            with t.cuda.device(pk.device):
+            with _capi.on_device(pk.device):
                 _capi.check(_capi.load().oprl_net_repack(C.byref(desc), 1, _capi.current_stream()),
                             "oprl_net_repack")
             self._pack_key = self._param_key()
-        return pk
+        dkey = (theta, pk.data_ptr())
+        if dkey != self._desc_key:
+            self._desc = _net_desc(self.dims, theta, pack_ptr=pk.data_ptr())
+            self._desc_key = dkey
+        return pk, self._desc
 
     def hip_forward(self, x0: t.Tensor, x1: t.Tensor | None = None, out_act: int = _capi.ACT_NONE) -> t.Tensor:
         if not self._hip_ok:
@@ -185,9 +204,8 @@ class MLP(nn.Module):
         B = x0.shape[0]
         n_out = self.dims[-1] // 2 if out_act == _capi.ACT_GAUSS_MEAN else self.dims[-1]
         out = t.empty((B, n_out), dtype=t.float32, device=x0.device)
-        pk = self.ensure_packed()
-        desc = _net_desc(self.dims, self.theta_ptr(), pack_ptr=pk.data_ptr())
-        with t.cuda.device(x0.device):
+        _, desc = self._packed_desc()
+        with _capi.on_device(x0.device):
             _capi.check(lib.oprl_mlp_forward(C.byref(desc), 0, _capi.ptr(x0), k0, _capi.ptr(x1), k1,
                                              B, out_act, _capi.ptr(out), _capi.current_stream()),
                         "oprl_mlp_forward")
@@ -327,16 +345,30 @@ class GaussianActor(nn.Module):
         action, pre = dist.rsample(eps)
         return action, dist.log_prob(pre).sum(dim=1, keepdim=True)
 
-    def explore(self, state: npt.NDArray) -> npt.NDArray:
+    def _act(self, state: npt.NDArray, sample: bool) -> npt.NDArray:
+        """One observation -> one action: the MLP on the GPU, the 2A-float head on the host (the
+        log-density the training forward also returns is not needed to act, and a handful of
+        torch ops on a [1, A] device tensor cost more than the network)."""
         s = t.as_tensor(state, dtype=t.float32, device=self.device).unsqueeze(0)
+        if not s.is_cuda:
+            with t.no_grad():
+                was = self.training
+                self.train(sample)
+                try:
+                    return self.forward(s)[0].numpy()[0]
+                finally:
+                    self.train(was)
         with t.no_grad():
-            action, _ = self.forward(s)
-        return action.cpu().numpy()[0]
+            raw = self.net(s).cpu()[0]
+        mean, log_std = raw[:self.action_dim], raw[self.action_dim:]
+        if not sample:
+            return t.tanh(mean).numpy()
+        std = t.exp(log_std.clamp(*LOG_STD_MIN_MAX))
+        return t.tanh(mean + std * t.randn(self.action_dim)).numpy()
+
+    def explore(self, state: npt.NDArray) -> npt.NDArray:
+        # reference semantics (nn_models.py:180-195): a sample in train mode, tanh(mean) in eval mode
+        return self._act(state, sample=self.training)
 
     def exploit(self, state: npt.NDArray) -> npt.NDArray:
-        was_training = self.training
-        self.eval()
-        try:
-            return self.explore(state)
-        finally:
-            self.train(was_training)
+        return self._act(state, sample=False)

@@ -102,6 +102,9 @@ class SAC(OffPolicyAlgorithm):
         n0, n1 = noise if noise is not None else (None, None)
         step = self.update_step
         self.learner.update(state, action, reward, done, next_state, noise0=n0, noise1=n1)
+        self._log_update(step)
+
+    def _log_update(self, step: int) -> None:
         if step % self.log_every == 0:
             sc = self.learner.read_scalars()
             self.logger.log_scalars({

@@ -103,6 +103,9 @@ class TD3(OffPolicyAlgorithm):
         ``randn_like(action)`` (td3.py:98); None draws it on device (Philox)."""
         step = self.update_step
         self.learner.update(state, action, reward, done, next_state, noise0=noise)
+        self._log_update(step)
+
+    def _log_update(self, step: int) -> None:
         if step % self.log_every == 0:
             sc = self.learner.read_scalars()   # the only host sync, every log_every updates
             self.logger.log_scalar("algo/q1", sc["q_mean"], step)

@@ -72,7 +72,7 @@ class EpisodicReplayBuffer(ReplayBufferProtocol):
             self._dev = dev if dev.index is not None else t.device("cuda", t.cuda.current_device())
             lib = _capi.load()
             h = C.c_void_p()
-            with t.cuda.device(self._dev):
+            with _capi.on_device(self._dev):
                 _capi.check(lib.oprl_replay_create(
                     E, L, S, A, _capi.ptr(self._tensors["states"]), _capi.ptr(self._tensors["actions"]),
                     _capi.ptr(self._tensors["rewards"]), _capi.ptr(self._tensors["dones"]), C.byref(h)),
@@ -98,7 +98,7 @@ class EpisodicReplayBuffer(ReplayBufferProtocol):
     # storage views (flush staged rows first so they are observable) -----------
     def _flush(self) -> None:
         if self._handle is not None:
-            with t.cuda.device(self._dev):
+            with _capi.on_device(self._dev):
                 _capi.check(self._lib.oprl_replay_flush(self._handle, _capi.current_stream()),
                             "oprl_replay_flush")
 
@@ -168,9 +168,11 @@ class EpisodicReplayBuffer(ReplayBufferProtocol):
     def _sync_lens(self) -> None:
         if self._lens_dirty:
             n = self.episodes_counter
-            arr = (C.c_int32 * max(n, 1))(*self.ep_lens[:n])
-            with t.cuda.device(self._dev):
-                _capi.check(self._lib.oprl_replay_set_lens(self._handle, arr, n, _capi.current_stream()),
+            # (a ctypes array built from the list costs O(episodes) python work per env step)
+            arr = np.asarray(self.ep_lens[:max(n, 1)], dtype=np.int32)
+            with _capi.on_device(self._dev):
+                _capi.check(self._lib.oprl_replay_set_lens(self._handle, arr.ctypes.data_as(C.POINTER(C.c_int32)), n,
+                                                           _capi.current_stream()),
                             "oprl_replay_set_lens")
             self._lens_dirty = False
 
@@ -211,7 +213,7 @@ class EpisodicReplayBuffer(ReplayBufferProtocol):
         if return_indices:
             ep = t.empty(B, dtype=t.int32, device=dev)
             st = t.empty(B, dtype=t.int32, device=dev)
-        with t.cuda.device(dev):
+        with _capi.on_device(dev):
             _capi.check(self._lib.oprl_replay_sample(
                 self._handle, B, _capi.ptr(idx), self.seed, self._sample_counter, _capi.ptr(out_s),
                 _capi.ptr(out_a), _capi.ptr(out_r), _capi.ptr(out_d), _capi.ptr(out_s2),

@@ -39,6 +39,7 @@ class BaseTrainer(TrainerProtocol):
     save_checkpoint_every: int = 0      # > 0: full learner + replay state every so many env steps (N4)
     estimate_q_every: int = 0
     stdout_log_every: int = int(1e5)
+    fused_sample_update: bool = True    # sample + update as one C call (algo.update_from_buffer); False: the two calls
     device: str = "cuda"
     seed: int = 0
 
@@ -59,9 +60,18 @@ class BaseTrainer(TrainerProtocol):
             state = next_state
             if len(self.replay_buffer) < self.batch_size:
                 continue
-            batch = self.replay_buffer.sample(self.batch_size)
-            self.algo.update(*batch)
-            rewards = batch[2]
+            fused = self.fused_sample_update and hasattr(self.algo, "update_from_buffer")
+            if fused:
+                # reference: sample() then update(*batch) (base_trainer.py:63-70); here the update
+                # gathers its own rows on the device.  The logging below wants a batch of rewards
+                # only at its own cadence.
+                self.algo.update_from_buffer(self.replay_buffer, self.batch_size)
+                need_rewards = (env_step % self.eval_interval == 0) or (env_step % self.stdout_log_every == 0)
+                rewards = self.replay_buffer.sample(self.batch_size)[2] if need_rewards else None
+            else:
+                batch = self.replay_buffer.sample(self.batch_size)
+                self.algo.update(*batch)
+                rewards = batch[2]
             self._log_evaluation(env_step, rewards)
             self._save_policy(env_step)
             if self.save_checkpoint_every > 0 and env_step % self.save_checkpoint_every == 0:

@@ -145,6 +145,22 @@ def test_trainer_end_to_end_on_synthetic_env():
     assert len(buf) == 401 and buf.episodes_counter == 5
 
 
+def test_update_from_buffer_is_step_n_of_one():
+    """The trainer's fused sample+update call = oprl_learner_step_n with K = 1 and the buffer's seed,
+    and = the python loop sample(inds from the same Philox draw) + update (checked by
+    test_step_n_equals_python_loop_bitwise for step_n)."""
+    B = 64
+    a1, a2 = _ddpg(max_batch=B), _ddpg(max_batch=B)
+    b1, b2 = _filled_buffer(), _filled_buffer()
+    for _ in range(5):
+        a1.update_from_buffer(b1, B)
+    a2.learner.step_n(b2.handle, 5, B, seed=b2.seed)
+    t.cuda.synchronize()
+    assert a1.update_step == a2.update_step == 5
+    for m in ("actor", "critic", "actor_target", "critic_target"):
+        assert t.equal(getattr(a1, m)._oprl_arena, getattr(a2, m)._oprl_arena), m
+
+
 def test_distributed_learner_with_in_host_actors():
     """Two CPU actor processes feed the GPU learner through the in-host queues."""
     from oprl_amd.algos.nn_models import DeterministicPolicy
