@@ -176,6 +176,12 @@ int oprl_net_repack(const oprl_net* net, int32_t which, void* stream);
 int oprl_mlp_forward(const oprl_net* net, int32_t use_target, const float* x0, int32_t k0,
                      const float* x1, int32_t k1, int32_t B, int32_t out_act, float* out,
                      void* stream);
+/* The per-environment-step policy call (reference nn_models.py:138-150 explore / exploit and
+ * :180-195: as_tensor(state) -> forward -> .cpu()): ONE observation obs_host[k0] in host memory ->
+ * out_host[n_out] in host memory (n_out = dims[L], or dims[L]/2 with out_act 4 = tanh of the
+ * Gaussian mean).  Synchronous on `stream`. */
+int oprl_mlp_act(const oprl_net* net, const float* obs_host, int32_t k0, int32_t out_act,
+                 float* out_host, int32_t n_out, void* stream);
 /* Gradient of sum(out * dout) wrt every parameter (into net->grad) and, if
  * dx != NULL, wrt the concatenated input [B,dims[0]].  Test/debug entry that
  * exercises the same backward + dW kernels update() uses. */

@@ -86,6 +86,7 @@ SIGNATURES = {
     "oprl_net_repack": (C.c_int, [C.POINTER(OprlNet), _I32, _P]),
     "oprl_learner_sync_params": (C.c_int, [_P, _P]),
     "oprl_mlp_forward": (C.c_int, [C.POINTER(OprlNet), _I32, _P, _I32, _P, _I32, _I32, _I32, _P, _P]),
+    "oprl_mlp_act": (C.c_int, [C.POINTER(OprlNet), _P, _I32, _I32, _P, _I32, _P]),
     "oprl_mlp_backward": (C.c_int, [C.POINTER(OprlNet), _P, _I32, _P, _I32, _I32, _P, _P, _P]),
     "oprl_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _D, _D, _D, _D, _D, _P]),
     "oprl_polyak": (C.c_int, [_P, _P, _I64, _D, _P]),

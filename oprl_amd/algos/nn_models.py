@@ -211,6 +211,24 @@ class MLP(nn.Module):
                         "oprl_mlp_forward")
         return out
 
+    def hip_act(self, obs: npt.NDArray, out_act: int = _capi.ACT_NONE) -> npt.NDArray:
+        """One observation (host) -> one output row (host) through oprl_mlp_act: the per-env-step
+        policy call without torch tensors on the way."""
+        if not self._hip_ok:
+            raise RuntimeError("the HIP MLP kernels implement ReLU hidden / identity output only")
+        x = np.ascontiguousarray(obs, dtype=np.float32).reshape(-1)
+        n_out = self.dims[-1] // 2 if out_act == _capi.ACT_GAUSS_MEAN else self.dims[-1]
+        out = np.empty(n_out, dtype=np.float32)
+        _, desc = self._packed_desc()
+        with _capi.on_device(self._params()[0].device):
+            _capi.check(_capi.load().oprl_mlp_act(C.byref(desc), x.ctypes.data_as(C.c_void_p), x.shape[0], out_act,
+                                                  out.ctypes.data_as(C.c_void_p), n_out, _capi.current_stream()),
+                        "oprl_mlp_act")
+        return out
+
+    def on_gpu(self) -> bool:
+        return self._params()[0].is_cuda
+
     def forward(self, x: t.Tensor) -> t.Tensor:
         if x.is_cuda:
             return self.hip_forward(x)
@@ -285,17 +303,22 @@ class DeterministicPolicy(nn.Module):
         return t.tanh(self.mlp.nn(states))
 
     def exploit(self, state: npt.NDArray) -> npt.NDArray:
+        if self.mlp.on_gpu():
+            return self.mlp.hip_act(state, _capi.ACT_TANH)
         s = t.as_tensor(state, dtype=t.float32, device=self._device).unsqueeze(0)
         with t.no_grad():
             return self.forward(s).cpu().numpy().reshape(-1)
 
     def explore(self, state: npt.NDArray) -> npt.NDArray:
         # reference quirk kept: NO tanh on the exploration path (nn_models.py:144-150)
-        s = t.as_tensor(state, dtype=t.float32, device=self._device).unsqueeze(0)
-        noise = t.randn(self._action_shape) * self._expl_noise
-        with t.no_grad():
-            raw = self.mlp(s).cpu()[0] + noise
-        return np.clip(raw.numpy(), -self._max_action, self._max_action)
+        noise = (t.randn(self._action_shape) * self._expl_noise).numpy()
+        if self.mlp.on_gpu():
+            raw = self.mlp.hip_act(state) + noise
+        else:
+            s = t.as_tensor(state, dtype=t.float32, device=self._device).unsqueeze(0)
+            with t.no_grad():
+                raw = self.mlp(s)[0].numpy() + noise
+        return np.clip(raw, -self._max_action, self._max_action)
 
 
 class TanhNormal:
@@ -349,8 +372,8 @@ class GaussianActor(nn.Module):
         """One observation -> one action: the MLP on the GPU, the 2A-float head on the host (the
         log-density the training forward also returns is not needed to act, and a handful of
         torch ops on a [1, A] device tensor cost more than the network)."""
-        s = t.as_tensor(state, dtype=t.float32, device=self.device).unsqueeze(0)
-        if not s.is_cuda:
+        if not self.net.on_gpu():
+            s = t.as_tensor(state, dtype=t.float32, device=self.device).unsqueeze(0)
             with t.no_grad():
                 was = self.training
                 self.train(sample)
@@ -358,13 +381,12 @@ class GaussianActor(nn.Module):
                     return self.forward(s)[0].numpy()[0]
                 finally:
                     self.train(was)
-        with t.no_grad():
-            raw = self.net(s).cpu()[0]
-        mean, log_std = raw[:self.action_dim], raw[self.action_dim:]
         if not sample:
-            return t.tanh(mean).numpy()
-        std = t.exp(log_std.clamp(*LOG_STD_MIN_MAX))
-        return t.tanh(mean + std * t.randn(self.action_dim)).numpy()
+            return self.net.hip_act(state, _capi.ACT_GAUSS_MEAN)
+        raw = self.net.hip_act(state)
+        mean, log_std = raw[:self.action_dim], raw[self.action_dim:]
+        std = np.exp(np.clip(log_std, *LOG_STD_MIN_MAX))
+        return np.tanh(mean + std * t.randn(self.action_dim).numpy()).astype(np.float32)
 
     def explore(self, state: npt.NDArray) -> npt.NDArray:
         # reference semantics (nn_models.py:180-195): a sample in train mode, tanh(mean) in eval mode

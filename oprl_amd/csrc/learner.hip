@@ -1589,6 +1589,56 @@ extern "C" int oprl_mlp_forward(const oprl_net* net, int32_t use_target, const f
   return launch(a, width, (hipStream_t)stream);
 }
 
+// One observation in HOST memory -> one output row in HOST memory: what a policy's explore() /
+// exploit() does once per environment step (reference nn_models.py:138-150, 180-195: as_tensor ->
+// forward -> .cpu()).  Pinned staging rows on both sides, one H2D copy, one slice launch, one D2H
+// copy and a stream sync — four runtime calls instead of the dozen torch dispatches around
+// oprl_mlp_forward (37 us for as_tensor alone).
+namespace {
+struct ActStage {
+  std::mutex mu;
+  float* host = nullptr;   // pinned: [0, 256) observation, [256, 512) output
+  float* dev = nullptr;    // device: same layout
+};
+ActStage g_act;
+}  // namespace
+
+extern "C" int oprl_mlp_act(const oprl_net* net, const float* obs_host, int32_t k0, int32_t out_act,
+                            float* out_host, int32_t n_out, void* stream) {
+  if (!net || !obs_host || !out_host) { set_err("oprl_mlp_act: invalid argument"); return OPRL_ERR_INVALID; }
+  int width = 0;
+  RC(check_net(*net, "net", &width));
+  const int nout = net->dims[net->n_layers];
+  const int want = (out_act == ACT_GAUSS_MEAN) ? nout / 2 : nout;
+  if (k0 != net->dims[0] || k0 > 256 || n_out != want || want > 256) {
+    set_err("oprl_mlp_act: dims (%d in, %d out) do not match the net (%d in, %d out)", k0, n_out, net->dims[0], want);
+    return OPRL_ERR_INVALID;
+  }
+  if (out_act != ACT_NONE && out_act != ACT_TANH && out_act != ACT_GAUSS_MEAN) { set_err("oprl_mlp_act: out_act %d unsupported here", out_act); return OPRL_ERR_INVALID; }
+  if (!g_attrs_done) { HIPC(init_kernel_attrs()); g_attrs_done = true; }
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(g_act.mu);
+  if (g_act.host == nullptr) {
+    HIPC(hipHostMalloc((void**)&g_act.host, 512 * sizeof(float), hipHostMallocDefault));
+    HIPC(hipMalloc((void**)&g_act.dev, 512 * sizeof(float)));
+  }
+  memcpy(g_act.host, obs_host, sizeof(float) * k0);
+  HIPC(hipMemcpyAsync(g_act.dev, g_act.host, sizeof(float) * k0, hipMemcpyHostToDevice, st));
+  MlpArgs a;
+  memset(&a, 0, sizeof a);
+  a.net = net_view(*net, false);
+  a.B = 1; a.do_fwd = 1;
+  a.x0 = g_act.dev; a.k0 = k0;
+  a.out_act = out_act;
+  a.action_dim = nout / 2;
+  a.out = g_act.dev + 256; a.ldo = want;
+  RC(launch(a, width, st));
+  HIPC(hipMemcpyAsync(g_act.host + 256, g_act.dev + 256, sizeof(float) * want, hipMemcpyDeviceToHost, st));
+  HIPC(hipStreamSynchronize(st));
+  memcpy(out_host, g_act.host + 256, sizeof(float) * want);
+  return OPRL_OK;
+}
+
 extern "C" int oprl_mlp_backward(const oprl_net* net, const float* x0, int32_t k0, const float* x1,
                                  int32_t k1, int32_t B, const float* dout, float* dx, void* stream) {
   if (!net || !x0 || !dout || B < 1 || !net->grad) { set_err("oprl_mlp_backward: invalid argument (grad arena required)"); return OPRL_ERR_INVALID; }

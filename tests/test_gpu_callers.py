@@ -145,6 +145,30 @@ def test_trainer_end_to_end_on_synthetic_env():
     assert len(buf) == 401 and buf.episodes_counter == 5
 
 
+def test_policy_act_equals_batched_forward():
+    """oprl_mlp_act (one observation, host in / host out) runs the same slice kernel as the batched
+    forward: exploit() = row 0 of forward(), for both policy classes."""
+    from oprl_amd.algos.sac import SAC
+    from oprl_amd.logging import NullLogger
+    rs = np.random.RandomState(3)
+    obs = rs.standard_normal(24)            # float64, like a gym observation
+    d = _ddpg()
+    want = d.actor(t.as_tensor(obs, dtype=t.float32, device="cuda").unsqueeze(0)).cpu().numpy()[0]
+    assert np.array_equal(d.actor.exploit(obs), want)
+    a = d.actor.explore(obs)
+    assert a.shape == (6,) and np.all(np.abs(a) <= 1.0)
+    s = SAC(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda").create()
+    s.actor.eval()
+    want, _ = s.actor(t.as_tensor(obs, dtype=t.float32, device="cuda").unsqueeze(0))
+    s.actor.train()
+    assert np.array_equal(s.actor.exploit(obs), want.cpu().numpy()[0])
+    t.manual_seed(5)
+    a1 = s.actor.explore(obs)
+    t.manual_seed(5)
+    a2 = s.actor.explore(obs)
+    assert a1.shape == (6,) and np.array_equal(a1, a2) and not np.array_equal(a1, s.actor.exploit(obs))
+
+
 def test_update_from_buffer_is_step_n_of_one():
     """The trainer's fused sample+update call = oprl_learner_step_n with K = 1 and the buffer's seed,
     and = the python loop sample(inds from the same Philox draw) + update (checked by
