@@ -180,7 +180,26 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid_run(const MlpMultiArgs M, i
   const int B = lw_args(n0).B;
   const int ke = wave & 7, par = wave >> 3;
 
-  // ---- requests: this wave's B fragments, then the input rows (and, backward, the ReLU masks)
+  // ---- requests: the input rows first (every wave waits for them at the barrier; behind 320 KB of
+  // weight fragments per CU they arrived last and the MFMAs started only when everything was in),
+  // then this wave's B fragments, which stream in while the first tiles are contracted
+  const MlpArgs& A0 = lw_args(n0);
+  const MlpArgs& A1 = lw_args(n1);
+  const float* src0 = BWD ? A0.dYg[l] : A0.Xg[l];
+  const float* src1 = BWD ? A1.dYg[l] : A1.Xg[l];
+  f32x4 v[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int idx = tid + h * kThreads;                 // 16 rows x 128 float4
+    const int row = idx >> 7, col = (idx & 127) * 4, gr = row0 + row;
+    v[0][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    v[1][h] = v[0][h];
+    if (gr < B) {
+      v[0][h] = ld4(src0 + (size_t)gr * WIDTH + col);
+      if (n1 != n0) v[1][h] = ld4(src1 + (size_t)gr * WIDTH + col);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
   f32x4 b[5][4];
 #pragma unroll
   for (int q = 0; q < 5; ++q) {
@@ -195,30 +214,33 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid_run(const MlpMultiArgs M, i
       for (int s = 0; s < 4; ++s) b[q][s] = ld4(pk + s * 256);
     }
   }
-  {
-    const MlpArgs& A0 = lw_args(n0);
-    const MlpArgs& A1 = lw_args(n1);
-    const float* src0 = BWD ? A0.dYg[l] : A0.Xg[l];
-    const float* src1 = BWD ? A1.dYg[l] : A1.Xg[l];
-    f32x4 v[2][2];
+  // ... and this thread's (up to three) output elements: where they go, their bias (forward) or
+  // ReLU mask (backward) — requested now, a dependent round trip per element if left to the end
+  size_t e_off[3];
+  float* e_dst[3];
+  float e_x[3];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int idx = tid + h * kThreads;                 // 16 rows x 128 float4
-      const int row = idx >> 7, col = (idx & 127) * 4, gr = row0 + row;
-      v[0][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-      v[1][h] = v[0][h];
-      if (gr < B) {
-        v[0][h] = ld4(src0 + (size_t)gr * WIDTH + col);
-        if (n1 != n0) v[1][h] = ld4(src1 + (size_t)gr * WIDTH + col);
-      }
+  for (int k = 0; k < 3; ++k) {
+    const int e = tid + k * kThreads;
+    const int tl = e >> 8, r = e & 255, row = r >> 4, col = r & 15, gr = row0 + row;
+    e_dst[k] = nullptr;
+    e_off[k] = 0;
+    e_x[k] = 0.f;
+    if (tl < nt && gr < B) {
+      const int t = t0 + tl, net = t / NTW, ntile = t - net * NTW;
+      const MlpArgs& A = lw_args(net);
+      e_off[k] = (size_t)gr * WIDTH + ntile * 16 + col;
+      e_dst[k] = BWD ? A.dYg[l - 1] : A.Xg[l + 1];
+      e_x[k] = BWD ? A.Xg[l][e_off[k]] : A.net.b[l][ntile * 16 + col];
     }
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int idx = tid + h * kThreads;
-      const int row = idx >> 7, col = (idx & 127) * 4;
-      *reinterpret_cast<f32x4*>(xs0 + row * WL + col) = v[0][h];
-      if (n1 != n0) *reinterpret_cast<f32x4*>(xs1 + row * WL + col) = v[1][h];
-    }
+  for (int h = 0; h < 2; ++h) {
+    const int idx = tid + h * kThreads;
+    const int row = idx >> 7, col = (idx & 127) * 4;
+    *reinterpret_cast<f32x4*>(xs0 + row * WL + col) = v[0][h];
+    if (n1 != n0) *reinterpret_cast<f32x4*>(xs1 + row * WL + col) = v[1][h];
   }
   __syncthreads();
 
@@ -238,21 +260,17 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid_run(const MlpMultiArgs M, i
   __syncthreads();
 
   // ---- K-ordered sum, bias + ReLU (forward) or ReLU mask (backward), rows out
-  for (int e = tid; e < nt * 256; e += kThreads) {
-    const int tl = e >> 8, r = e & 255, row = r >> 4, col = r & 15, gr = row0 + row;
-    if (gr >= B) continue;
-    const int t = t0 + tl, net = t / NTW, ntile = t - net * NTW;
-    const MlpArgs& A = lw_args(net);
-    const size_t off = (size_t)gr * WIDTH + ntile * 16 + col;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (e_dst[k] == nullptr) continue;
+    const int e = tid + k * kThreads;
+    const int tl = e >> 8, r = e & 255, row = r >> 4, col = r & 15;
     const float* sp = scr + ((size_t)(tl * 8) * 64 + (row >> 2) * 16 + col) * 4 + (row & 3);
     float v = 0.f;
 #pragma unroll
     for (int p = 0; p < 8; ++p) v += sp[p * 256];
-    if constexpr (BWD) {
-      A.dYg[l - 1][off] = A.Xg[l][off] > 0.f ? v : 0.f;
-    } else {
-      A.Xg[l + 1][off] = fmaxf(v + A.net.b[l][ntile * 16 + col], 0.f);
-    }
+    if constexpr (BWD) e_dst[k][e_off[k]] = e_x[k] > 0.f ? v : 0.f;
+    else e_dst[k][e_off[k]] = fmaxf(v + e_x[k], 0.f);
   }
 }
 
