@@ -135,16 +135,34 @@ __device__ __forceinline__ void load_batch(const BatchSrc& P, int row0, int B, i
   }
 }
 
+// one tagged 8-byte granule: the value is its own flag (as the cluster exchanges of tp3.h / tp4.h)
+__device__ __forceinline__ void granule_put(unsigned long long* g, unsigned tag, float v) {
+  __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float granule_get(const unsigned long long* g, unsigned tag) {
+  for (int spin = 0; spin < kTpSpin; ++spin) {
+    const unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(x >> 32) == tag) return __uint_as_float((unsigned)x);
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return __builtin_nanf("");   // bounded: a lost partner shows up as NaN, not as a hang
+}
+
 // SAC: tanh-Gaussian head over outS = [mean | log_std] (16 lanes per row, the first 256 threads, as
 // slice_head.h does it): the action goes to aS[row * a_ld + col] (LDS) and/or pi_g, the row's log pi
 // to lpS[row] (LDS) and/or logp_g, the raw head output to raw_g.  No barrier inside.
 __device__ __forceinline__ void gauss_head(const float* outS, int row0, int B, int Ad, const float* noise,
                                            unsigned long long seed, unsigned long long ctr, float* aS, int a_ld,
-                                           float* lpS, float* pi_g, float* raw_g, float* logp_g) {
+                                           float* lpS, float* pi_g, float* raw_g, float* logp_g,
+                                           unsigned long long* a_gran = nullptr, unsigned a_tag = 0) {
+  // a_gran (optional): the action also goes out as granules [row][col] (zeros for rows beyond B)
   const int tid = threadIdx.x;
   if (tid >= kR * 16) return;
   const int row = tid >> 4, sub = tid & 15, gr = row0 + row;
   float lp = 0.f;
+  if (gr >= B && a_gran != nullptr)
+    for (int col = sub; col < Ad; col += 16) granule_put(a_gran + row * Ad + col, a_tag, 0.f);
   if (gr < B) {
     for (int col = sub; col < Ad; col += 16) {
       const float mu = outS[row * kOutLd + col];
@@ -152,6 +170,7 @@ __device__ __forceinline__ void gauss_head(const float* outS, int row0, int B, i
       const float e = noise != nullptr ? noise[(size_t)gr * Ad + col] : philox_normal(seed, ctr, (unsigned)gr, (unsigned)col);
       float a;
       lp += gauss_elem(mu, lsr, e, &a);
+      if (a_gran != nullptr) granule_put(a_gran + row * Ad + col, a_tag, a);
       if (aS != nullptr) aS[row * a_ld + col] = a;
       if (pi_g != nullptr) pi_g[(size_t)gr * Ad + col] = a;
       if (raw_g != nullptr) {
@@ -284,6 +303,9 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
   if constexpr (!LEAN) tp_bwd<WIDTH, LEAN>(critic, auxS, h1, h2, scr, tp, st, row0, B, 0, 0, auxS, stamp);
 }
 
+// (A separate template instance for the twin-critic algorithms, so that the single-critic kernel
+// carries none of their code, was measured SLOWER for all three: phase 1 15.0 vs 14.3 us for DDPG,
+// TD3 38.5 vs 36.0 us, SAC 54.5 vs 51.6 us per update — profiles/r01b_experiments.txt #29.)
 template <int WIDTH, bool LEAN, bool SAC>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -324,28 +346,43 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   load_batch(A.src, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
   stamp();   // batch rows requested
   const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
+  // twin_split (TD3 / SAC, all four roles co-resident): role A evaluates target critic 1 only; the
+  // role-C cluster, after its actor pass, receives a' from role A, evaluates target critic 2 and
+  // returns q2' — the two target passes run side by side instead of back to back.  Exchange slots:
+  // the never-used last stage of the receiving role's cluster area.
+  auto x_slot = [&](int to_role) {   // (formed only on the twin_split paths)
+    return A.xbuf + (((size_t)to_role * gridDim.x + slice) * kTpStages + (kTpStages - 1)) * A.nc * kTpBlk;
+  };
+  const unsigned x_tag = (A.cluster_tag << 6) | 62u;
 
   if (role == role_c) {
-    if (!A.do_actor) return;   // TD3: no actor step in this update
-    // ---- role C: actor(s) forward.  Pack rows beyond S are zero, so [s | a] serves as input.
-    const Tp3Store st{A.aX[1], A.aX[2], nullptr, nullptr, 0};
-    tp_fwd<WIDTH, LEAN>(A.actor, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
-    if constexpr (SAC) {
-      // pi(s) ~ tanh-Gaussian, its log-density (temperature step, actor seed) and the raw head output
-      if (lead) {
-        gauss_head(outS, row0, B, Ad, A.noise_pi, A.rng_seed_pi, A.rng_ctr, nullptr, 0, nullptr, A.pi, A.raw, A.logp);
+    if (A.do_actor) {   // (TD3: no actor step in every other update)
+      // ---- role C: actor(s) forward.  Pack rows beyond S are zero, so [s | a] serves as input.
+      const Tp3Store st{A.aX[1], A.aX[2], nullptr, nullptr, 0};
+      tp_fwd<WIDTH, LEAN>(A.actor, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
+      if constexpr (SAC) {
+        // pi(s) ~ tanh-Gaussian, its log-density (temperature step, actor seed) and the raw head output
+        if (lead) {
+          gauss_head(outS, row0, B, Ad, A.noise_pi, A.rng_seed_pi, A.rng_ctr, nullptr, 0, nullptr, A.pi, A.raw, A.logp);
+          store_rows(xa, kX0Ld, A.aX[0], A.aldx0, S, row0, B);
+        }
+      } else if (lead) {
+        for (int idx = tid; idx < kR * Ad; idx += kThreads) {
+          const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
+          if (gr < B) A.pi[(size_t)gr * Ad + col] = tanhf(outS[row * kOutLd + col]);
+        }
         store_rows(xa, kX0Ld, A.aX[0], A.aldx0, S, row0, B);
       }
       stamp();
-      return;
     }
-    if (lead) {
-      for (int idx = tid; idx < kR * Ad; idx += kThreads) {
-        const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
-        if (gr < B) A.pi[(size_t)gr * Ad + col] = tanhf(outS[row * kOutLd + col]);
-      }
-      store_rows(xa, kX0Ld, A.aX[0], A.aldx0, S, row0, B);
+    if (!A.twin_split) return;
+    // ---- ... then target critic 2 on (s', a') with role A's a'
+    if (tid < kR * Ad) {
+      const int row = tid / Ad, col = tid - row * Ad;
+      xb[row * kX0Ld + S + col] = granule_get(x_slot(role_c) + tid, x_tag);
     }
+    tp_fwd<WIDTH, LEAN>(A.critic2_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
+    if (lead && tid < kR) granule_put(x_slot(0) + tid, x_tag, outS[tid * kOutLd]);
     stamp();
     return;
   }
@@ -355,8 +392,11 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
     // (TD3: min over the twin targets), TD target                    (ddpg.py:94-95, td3.py:83-101)
     // (SAC: a' ~ pi(s') from the online actor, log pi(a'|s') kept per row     sac.py:90-97)
     tp_fwd<WIDTH, LEAN>(SAC ? A.actor : A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
+    const bool send_a2 = A.twin_split && lead;
+    unsigned long long* x_a2 = send_a2 ? x_slot(role_c) : nullptr;
     if constexpr (SAC)
-      gauss_head(outS, row0, B, Ad, A.noise, A.rng_seed, A.rng_ctr, xb + S, kX0Ld, yS, nullptr, nullptr, nullptr);
+      gauss_head(outS, row0, B, Ad, A.noise, A.rng_seed, A.rng_ctr, xb + S, kX0Ld, yS, nullptr, nullptr, nullptr,
+                 x_a2, x_tag);
     for (int idx = tid; !SAC && idx < kR * Ad; idx += kThreads) {
       const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
       float v = 0.f;
@@ -369,12 +409,15 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
           v = fminf(fmaxf(v + n, -A.max_action), A.max_action);
         }
       }
+      if (send_a2) granule_put(x_a2 + idx, x_tag, v);
       xb[row * kX0Ld + S + col] = v;
     }
     // (the next GEMM's own barrier publishes xb)
     tp_fwd<WIDTH, LEAN>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
     float qn = (tid < kR) ? outS[tid * kOutLd] : 0.f;
-    if (A.n_critics == 2) {
+    if (A.twin_split) {
+      if (lead && tid < kR) qn = fminf(qn, granule_get(x_slot(0) + tid, x_tag));
+    } else if (A.n_critics == 2) {
       tp_fwd<WIDTH, LEAN>(A.critic2_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
       if (tid < kR) qn = fminf(qn, outS[tid * kOutLd]);
     }
@@ -399,8 +442,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   // ---- role B: q = critic_j(s, a) forward (runs while role A computes the target).  The twin
   // critic gets its own copy of the code (a runtime-selected Net would leave the kernel-argument
   // registers: profiles/r01b_experiments.txt #10).
-  const bool second = role == 2;
-  if (second) { role_b<WIDTH, LEAN>(A, A.critic2, A.c2X, A.c2dY, A.partials_c + (size_t)gridDim.x * 4, false, smem, tp, stamp); return; }
+  if (role == 2) { role_b<WIDTH, LEAN>(A, A.critic2, A.c2X, A.c2dY, A.partials_c + (size_t)gridDim.x * 4, false, smem, tp, stamp); return; }
   role_b<WIDTH, LEAN>(A, A.critic, A.cX, A.cdY, A.partials_c, true, smem, tp, stamp);
 }
 

@@ -190,6 +190,7 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   Net critic2, critic2_t;
   int n_critics;                       // 1 (DDPG) or 2 (TD3)
   int do_actor;                        // 0: role C (actor forward) has nothing to do in this update
+  int twin_split;                      // 1: target critic 2 runs in the role-C cluster, beside role A's target critic 1
   int smooth;                          // 1: a' = clip(tanh(mu) + clip(sigma * N(0,1), +-c), +-max_action)
   float policy_noise, noise_clip, max_action;
   const float* noise;                  // injected N(0,1) draws [B][A], or null: Philox(rng_seed, rng_ctr)

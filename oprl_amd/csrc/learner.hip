@@ -337,6 +337,7 @@ struct oprl_learner {
   bool pair_collect = false;
   int pair_n = 0;
   MlpArgs pair_args[2];
+  bool no_twin_split = false;  // OPRL_AMD_NO_TWIN_SPLIT: role A runs both target critics back to back (tests / A-B)
   bool no_multi = false;
   bool no_layerwise = false;   // OPRL_AMD_NO_LAYERWISE: wide nets stay on the single-CU slice kernel (tests / A-B)
   bool no_p2_pair = false;     // OPRL_AMD_NO_P2_PAIR: SAC phase 2 runs the twin critics back to back (tests / A-B)
@@ -712,6 +713,9 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   a.trace = nullptr;
   a.nc = h->nc_cluster(B);
   a.no_lean = h->no_lean;
+  // role A and the role-C cluster wait for each other: only with all four roles of a slice resident
+  a.twin_split = (h->nc == 2 && a.nc == 4 && !h->no_lean && !h->no_twin_split &&
+                  (2 + h->nc) * 4 * ((B + kR - 1) / kR) <= h->n_cus) ? 1 : 0;
   a.xbuf = h->xbuf;
   a.cdY0_stride = h->ws_critic[0].dY0_stride;
   a.adY0_stride = h->ws_actor.dY0_stride;
@@ -1290,6 +1294,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->no_multi = (nm != nullptr && atoi(nm) != 0);
     const char* nlw = getenv("OPRL_AMD_NO_LAYERWISE");
     h->no_layerwise = (nlw != nullptr && atoi(nlw) != 0);
+    const char* nts = getenv("OPRL_AMD_NO_TWIN_SPLIT");
+    h->no_twin_split = (nts != nullptr && atoi(nts) != 0);
     const char* np2 = getenv("OPRL_AMD_NO_P2_PAIR");
     h->no_p2_pair = (np2 != nullptr && atoi(np2) != 0);
     const char* nl = getenv("OPRL_AMD_NO_LEAN");

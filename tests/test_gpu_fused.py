@@ -106,10 +106,13 @@ def _td3(state_dim=17, **kw):
     return TD3(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=state_dim, action_dim=6, device="cuda", **kw).create()
 
 
+@pytest.mark.parametrize("split", [True, False])
 @pytest.mark.parametrize("inject", [True, False])
-def test_fused_td3_equals_generic(inject):
+def test_fused_td3_equals_generic(inject, split, monkeypatch):
     """6 updates = 3 critic-only + 3 actor steps (policy_freq 2); target-policy smoothing noise
-    injected (as the golden tests do) or drawn on device (same Philox stream in both paths)."""
+    injected (as the golden tests do) or drawn on device (same Philox stream in both paths); the twin
+    target critics side by side (role A and the role-C cluster) or back to back in role A."""
+    monkeypatch.setenv("OPRL_AMD_NO_TWIN_SPLIT", "0" if split else "1")
     fused, generic = _td3(), _td3(no_fuse=True)
     for step in range(6):
         batch = [x.cuda() for x in fx.make_batch(90 + step, 256, 17, 6)]
@@ -253,6 +256,7 @@ def test_fused_sac_equals_generic(inject, tune_alpha, pair, monkeypatch):
     in both paths); fixed or learned temperature; phase 2's twin critics on two clusters side by side
     or back to back on one."""
     monkeypatch.setenv("OPRL_AMD_NO_P2_PAIR", "0" if pair else "1")
+    monkeypatch.setenv("OPRL_AMD_NO_TWIN_SPLIT", "0" if pair else "1")   # (phase 1's twin targets likewise)
     B, S, A = 256, 24, 6
     fused, generic = _sac(tune_alpha=tune_alpha), _sac(tune_alpha=tune_alpha, no_fuse=True)
     for step in range(5):
