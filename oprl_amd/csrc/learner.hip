@@ -769,7 +769,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     DdpgArgs fa = ddpg_args(h, B);
     fa.noise = noise0;
     RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &fa.cluster_tag));
-    if (h->trace != nullptr && c.algo == OPRL_DDPG) fa.trace = h->trace;   // roles use slots 0,1,2
+    if (h->trace != nullptr) fa.trace = h->trace;   // roles use slots 0 .. 1 + n_critics
     HIPC(chain_before(st));
     prof_begin(4, st);
     hipError_t e = launch_ddpg_phase1(fa, st);
