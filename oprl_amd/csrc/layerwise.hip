@@ -160,8 +160,13 @@ __global__ __launch_bounds__(kThreads, 8) void k_lw_mid(const MlpMultiArgs M, in
 constexpr int kLwMaxRun = 10;                   // tiles per workgroup
 struct LwRun { int slices, nets, G, tpg, gpx; };   // runs per slice, tiles per run, runs per XCD
 
-template <bool BWD>
+// MODE 0: forward layer l, 1: backward through layer l, 2: forward layer 1 with the FIRST layer fused in —
+// for a narrow net input (<= 32 columns: two macro steps) every workgroup recomputes the slice's
+// h1 = relu(W0 [x0 | x1] + b0) tile(s) in LDS instead of reading them (8 MFMAs per wave; the run
+// that starts a net also stores h1 and the input rows for k_dw_adam), which saves the k_lw_in launch
+template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_lw_mid_run(const MlpMultiArgs M, int l, const LwRun R) {
+  constexpr bool BWD = MODE == 1, FIN = MODE == 2;
   constexpr int WIDTH = 512, WL = lds_ld(WIDTH), NTW = WIDTH / 16;
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   float* xs0 = dsm;
@@ -188,15 +193,43 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid_run(const MlpMultiArgs M, i
   const float* src0 = BWD ? A0.dYg[l] : A0.Xg[l];
   const float* src1 = BWD ? A1.dYg[l] : A1.Xg[l];
   f32x4 v[2][2];
+  float* xin0 = scr;                          // FIN: the nets' input rows [kR][kX0Ld], in the partial-tile area
+  float* xin1 = scr + kR * kX0Ld;
+  f32x4 w0f[2][2];                            // FIN: [tile wave / wave + 16][macro step] first-layer fragments
+  float b0f[2];
+  const int NS0 = FIN ? cdiv(A0.net.dims[0], 16) : 0;   // <= 2 (host-checked)
+  auto request_l0 = [&](const MlpArgs& An) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int idx = tid + h * kThreads;                 // 16 rows x 128 float4
-    const int row = idx >> 7, col = (idx & 127) * 4, gr = row0 + row;
-    v[0][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    v[1][h] = v[0][h];
-    if (gr < B) {
-      v[0][h] = ld4(src0 + (size_t)gr * WIDTH + col);
-      if (n1 != n0) v[1][h] = ld4(src1 + (size_t)gr * WIDTH + col);
+    for (int q = 0; q < 2; ++q) {
+      const int tile = wave + 16 * q;
+      b0f[q] = An.net.b[0][16 * tile + i];
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+        w0f[q][st] = st < NS0 ? ld4(An.net.pf[0] + (((size_t)tile * NS0 + st) * 64 + lane) * 4)
+                              : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  if constexpr (FIN) {
+    lds_zero(xin0, 2 * kR * kX0Ld);
+    request_l0(A0);
+    __syncthreads();
+    load_rows(xin0, kX0Ld, 0, A0.x0, A0.k0, A0.k0, row0, B);
+    if (A0.x1 != nullptr) load_rows(xin0, kX0Ld, A0.k0, A0.x1, A0.k1, A0.k1, row0, B);
+    if (n1 != n0) {
+      load_rows(xin1, kX0Ld, 0, A1.x0, A1.k0, A1.k0, row0, B);
+      if (A1.x1 != nullptr) load_rows(xin1, kX0Ld, A1.k0, A1.x1, A1.k1, A1.k1, row0, B);
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int idx = tid + h * kThreads;                 // 16 rows x 128 float4
+      const int row = idx >> 7, col = (idx & 127) * 4, gr = row0 + row;
+      v[0][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+      v[1][h] = v[0][h];
+      if (gr < B) {
+        v[0][h] = ld4(src0 + (size_t)gr * WIDTH + col);
+        if (n1 != n0) v[1][h] = ld4(src1 + (size_t)gr * WIDTH + col);
+      }
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -219,30 +252,59 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid_run(const MlpMultiArgs M, i
   size_t e_off[3];
   float* e_dst[3];
   float e_x[3];
+  auto request_out = [&]() {
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int e = tid + k * kThreads;
-    const int tl = e >> 8, r = e & 255, row = r >> 4, col = r & 15, gr = row0 + row;
-    e_dst[k] = nullptr;
-    e_off[k] = 0;
-    e_x[k] = 0.f;
-    if (tl < nt && gr < B) {
-      const int t = t0 + tl, net = t / NTW, ntile = t - net * NTW;
-      const MlpArgs& A = lw_args(net);
-      e_off[k] = (size_t)gr * WIDTH + ntile * 16 + col;
-      e_dst[k] = BWD ? A.dYg[l - 1] : A.Xg[l + 1];
-      e_x[k] = BWD ? A.Xg[l][e_off[k]] : A.net.b[l][ntile * 16 + col];
+    for (int k = 0; k < 3; ++k) {
+      const int e = tid + k * kThreads;
+      const int tl = e >> 8, r = e & 255, row = r >> 4, col = r & 15, gr = row0 + row;
+      e_dst[k] = nullptr;
+      e_off[k] = 0;
+      e_x[k] = 0.f;
+      if (tl < nt && gr < B) {
+        const int t = t0 + tl, net = t / NTW, ntile = t - net * NTW;
+        const MlpArgs& A = lw_args(net);
+        e_off[k] = (size_t)gr * WIDTH + ntile * 16 + col;
+        e_dst[k] = BWD ? A.dYg[l - 1] : A.Xg[l + 1];
+        e_x[k] = BWD ? A.Xg[l][e_off[k]] : A.net.b[l][ntile * 16 + col];
+      }
     }
-  }
+  };
+  if constexpr (!FIN) request_out();          // (FIN: after the first layer, when its fragments' registers are free)
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (FIN) {
+    __syncthreads();                          // input rows visible
+    // the run that starts a net keeps that net's dW inputs: the input rows now, h1 below
+    const bool keep0 = t0 - n0 * NTW == 0, keep1 = n1 != n0;
+    if (keep0 && A0.Xg[0] != nullptr) store_rows(xin0, kX0Ld, A0.Xg[0], A0.ldx0, A0.net.dims[0], row0, B);
+    if (keep1 && A1.Xg[0] != nullptr) store_rows(xin1, kX0Ld, A1.Xg[0], A1.ldx0, A1.net.dims[0], row0, B);
+    for (int nn = 0; nn < (n1 != n0 ? 2 : 1); ++nn) {
+      if (nn == 1) request_l0(A1);            // a straddling run (3 of 16): the second net's fragments, exposed
+      const float* xr = (nn == 0 ? xin0 : xin1) + i * kX0Ld + 4 * kk;
+      float* hs = nn == 0 ? xs0 : xs1;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int idx = tid + h * kThreads;
-    const int row = idx >> 7, col = (idx & 127) * 4;
-    *reinterpret_cast<f32x4*>(xs0 + row * WL + col) = v[0][h];
-    if (n1 != n0) *reinterpret_cast<f32x4*>(xs1 + row * WL + col) = v[1][h];
+      for (int q = 0; q < 2; ++q) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        mac4(ld4(xr), w0f[q][0], acc);
+        mac4(ld4(xr + 16), w0f[q][1], acc);
+        float* o = hs + (kk * 4) * WL + 16 * (wave + 16 * q) + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r * WL] = fmaxf(acc[r] + b0f[q], 0.f);
+      }
+    }
+    request_out();
+    __syncthreads();                          // h1 tiles complete; the input rows are no longer needed
+    if (keep0) store_rows4(xs0, WL, A0.Xg[1], WIDTH, WIDTH, row0, B);
+    if (keep1) store_rows4(xs1, WL, A1.Xg[1], WIDTH, WIDTH, row0, B);
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int idx = tid + h * kThreads;
+      const int row = idx >> 7, col = (idx & 127) * 4;
+      *reinterpret_cast<f32x4*>(xs0 + row * WL + col) = v[0][h];
+      if (n1 != n0) *reinterpret_cast<f32x4*>(xs1 + row * WL + col) = v[1][h];
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   // ---- partial tiles
 #pragma unroll
@@ -363,11 +425,13 @@ bool mlp_layerwise_ok(const MlpArgs* a, int n, int width) {
 }
 
 hipError_t init_layerwise_attrs() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_mid_run<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLwRunLds);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_mid_run<true>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLwRunLds);
+  const void* ks[3] = {reinterpret_cast<const void*>(&k_lw_mid_run<0>), reinterpret_cast<const void*>(&k_lw_mid_run<1>),
+                       reinterpret_cast<const void*>(&k_lw_mid_run<2>)};
+  for (const void* k : ks) {
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLwRunLds);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st) {
@@ -384,17 +448,21 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
   const LwRun r = lw_run(slices, n, n_cus > 0 ? n_cus : 256);
   const dim3 runs(8 * r.gpx * slices);
   if (a[0].do_fwd) {
-    hipLaunchKernelGGL(k_lw_in<512>, wide, blk, 0, st, m, g);
+    // a narrow net input (two macro steps) is folded into the first hidden layer's launch
+    bool fuse_in = !equal_wgs && L >= 3;
+    for (int j = 0; j < n; ++j) fuse_in = fuse_in && a[j].net.dims[0] <= 32;
+    if (!fuse_in) hipLaunchKernelGGL(k_lw_in<512>, wide, blk, 0, st, m, g);
     for (int l = 1; l + 1 < L; ++l) {
       if (equal_wgs) hipLaunchKernelGGL((k_lw_mid<512, false>), wide, blk, 0, st, m, l, g);
-      else hipLaunchKernelGGL((k_lw_mid_run<false>), runs, blk, kLwRunLds, st, m, l, r);
+      else if (l == 1 && fuse_in) hipLaunchKernelGGL((k_lw_mid_run<2>), runs, blk, kLwRunLds, st, m, l, r);
+      else hipLaunchKernelGGL((k_lw_mid_run<0>), runs, blk, kLwRunLds, st, m, l, r);
     }
   }
   hipLaunchKernelGGL(k_lw_head<512>, narrow, blk, 0, st, m);
   if (a[0].do_bwd) {
     for (int l = L - 2; l >= 1; --l) {
       if (equal_wgs) hipLaunchKernelGGL((k_lw_mid<512, true>), wide, blk, 0, st, m, l, g);
-      else hipLaunchKernelGGL((k_lw_mid_run<true>), runs, blk, kLwRunLds, st, m, l, r);
+      else hipLaunchKernelGGL((k_lw_mid_run<1>), runs, blk, kLwRunLds, st, m, l, r);
     }
     if (a[0].dact_cols > 0) hipLaunchKernelGGL(k_lw_dact<512>, narrow, blk, 0, st, m);
   }
