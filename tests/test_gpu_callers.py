@@ -91,6 +91,34 @@ def test_td3_export_grads_split_equals_fused_update():
         assert (a - b).abs().max().item() <= 1e-7 * max(1.0, a.abs().max().item()), m
 
 
+@pytest.mark.parametrize("tune_alpha", [False, True])
+def test_sac_export_grads_split_equals_fused_update(tune_alpha):
+    """SAC through the fused kernels in data-parallel mode (role C's pi(s) sample is taken in phase 0
+    and consumed in phase 1; the temperature gradient is exported and applied like the arenas')."""
+    from oprl_amd.algos.sac import SAC
+    from oprl_amd.logging import NullLogger
+
+    def make(**kw):
+        t.manual_seed(0)
+        return SAC(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=256,
+                   tune_alpha=tune_alpha, **kw).create()
+
+    fused, split = make(), make(export_grads=True)
+    for step in range(4):
+        batch = [x.cuda() for x in fx.make_batch(60 + step, 256, 24, 6)]
+        n0, n1 = fx.make_noise(160 + step, (256, 6)).cuda(), fx.make_noise(260 + step, (256, 6)).cuda()
+        fused.update(*batch, noise=(n0, n1))
+        L = split.learner
+        L.update_phase(0, *batch, noise0=n0, noise1=n1); L.apply(0, 1.0)
+        L.update_phase(1, *batch, noise0=n0, noise1=n1); L.apply(1, 1.0)
+    t.cuda.synchronize()
+    for m in ("actor", "critic", "critic_target"):
+        a, b = getattr(fused, m)._oprl_arena, getattr(split, m)._oprl_arena
+        assert (a - b).abs().max().item() <= 1e-7 * max(1.0, a.abs().max().item()), m
+    if tune_alpha:
+        assert abs(fused.alpha - split.alpha) <= 1e-9 * fused.alpha
+
+
 def test_load_state_dict_is_picked_up_by_the_learner():
     algo = _ddpg()
     other = _ddpg()
