@@ -128,6 +128,15 @@ class MLP(nn.Module):
         self._desc_key = None
         self._desc = None
 
+    def __getstate__(self):
+        # t.save(actor) pickles the whole module (base_trainer.py:113-120): the cached C descriptor
+        # (ctypes, holds raw pointers) and the Parameter list are rebuilt on first use after loading
+        state = self.__dict__.copy()
+        state["_desc"] = None
+        state["_desc_key"] = None
+        state["_plist"] = None
+        return state
+
     def _params(self) -> list[nn.Parameter]:
         # walking the module tree costs ~25 us per call; the Parameter OBJECTS of a built MLP never
         # change (flatten_module_, load_state_dict and .to() swap or fill their .data)

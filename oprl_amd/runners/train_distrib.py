@@ -6,13 +6,14 @@ from __future__ import annotations
 from multiprocessing import get_context
 from typing import Callable
 
-from oprl_amd.distrib.env_worker import run_env_worker
-from oprl_amd.distrib.policy_update_worker import run_policy_update_worker
 from oprl_amd.distrib.queue import QueueHub
 from oprl_amd.runners.config import DistribConfig
 
 
 def run_distrib_training(
+    run_env_worker: Callable | None = None,
+    run_policy_update_worker: Callable | None = None,
+    *,
     make_env: Callable,
     make_algo: Callable,
     make_policy: Callable,
@@ -21,6 +22,13 @@ def run_distrib_training(
     config: DistribConfig,
     max_epochs: int | None = None,
 ) -> None:
+    """The reference's config script passes the two worker entry points explicitly
+    (configs/distrib_ddpg.py:80-90); through the ``oprl`` alias they are this package's
+    (``distrib/env_worker.py``, ``distrib/policy_update_worker.py``), which is also the default."""
+    from oprl_amd.distrib.env_worker import run_env_worker as _env_worker
+    from oprl_amd.distrib.policy_update_worker import run_policy_update_worker as _learner
+    run_env_worker = run_env_worker or _env_worker
+    run_policy_update_worker = run_policy_update_worker or _learner
     ctx = get_context("spawn")
     names = [f"{kind}_{i}" for i in range(config.num_env_workers) for kind in ("env", "policy")]
     hub = QueueHub(names, ctx)

@@ -141,6 +141,7 @@ def test_policy_save_load_interop_with_plain_cpu_module():
     from oprl_amd.algos.nn_models import DeterministicPolicy
     algo = _ddpg()
     algo.update(*[x.cuda() for x in fx.make_batch(1, 128, 24, 6)])
+    algo.actor.explore(np.zeros(24))        # the acting path caches a C descriptor in the module: not pickled
     buf = io.BytesIO()
     t.save(algo.actor, buf)                 # whole-module pickle, like base_trainer.py:113-120
     buf.seek(0)
@@ -195,6 +196,19 @@ def test_policy_act_equals_batched_forward():
     t.manual_seed(5)
     a2 = s.actor.explore(obs)
     assert a1.shape == (6,) and np.array_equal(a1, a2) and not np.array_equal(a1, s.actor.exploit(obs))
+
+
+def test_gaussian_actor_pickles_after_acting():
+    from oprl_amd.algos.sac import SAC
+    from oprl_amd.logging import NullLogger
+    s = SAC(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda").create()
+    obs = np.random.RandomState(1).standard_normal(24)
+    want = s.actor.exploit(obs)
+    buf = io.BytesIO()
+    t.save(s.actor, buf)
+    buf.seek(0)
+    loaded = t.load(buf, weights_only=False)
+    assert np.allclose(loaded.exploit(obs), want, atol=1e-6)
 
 
 def test_update_from_buffer_is_step_n_of_one():

@@ -190,3 +190,38 @@ def test_distributed_learner_loop_counts():
             break
         pushed += 1
     assert pushed == n_epochs + 1          # one state_dict per epoch + the final STOP
+
+
+def test_alias_package_serves_the_reference_config_scripts():
+    """Every name the reference's config scripts import (configs/{ddpg,td3,sac,tqc}.py:1-13,
+    configs/distrib_ddpg.py:1-22) resolves through the ``oprl`` alias package, and
+    ``run_distrib_training`` takes the keyword arguments distrib_ddpg.py:80-90 passes."""
+    import importlib
+    import inspect
+    names = {
+        "oprl.algos.ddpg": ["DDPG"], "oprl.algos.td3": ["TD3"], "oprl.algos.sac": ["SAC"], "oprl.algos.tqc": ["TQC"],
+        "oprl.algos.nn_models": ["DeterministicPolicy", "GaussianActor"],
+        "oprl.algos.protocols": ["AlgorithmProtocol", "PolicyProtocol"],
+        "oprl.buffers.protocols": ["ReplayBufferProtocol"],
+        "oprl.buffers.episodic_buffer": ["EpisodicReplayBuffer"],
+        "oprl.environment": ["make_env"], "oprl.environment.protocols": ["EnvProtocol"],
+        "oprl.logging": ["LoggerProtocol", "FileTxtLogger", "get_logs_path", "make_text_logger_func"],
+        "oprl.parse_args": ["parse_args", "parse_args_distrib"],
+        "oprl.runners.config": ["CommonParameters", "DistribConfig"],
+        "oprl.runners.train": ["run_training"], "oprl.runners.train_distrib": ["run_distrib_training"],
+        "oprl.distrib.env_worker": ["run_env_worker"],
+        "oprl.distrib.policy_update_worker": ["run_policy_update_worker"],
+    }
+    for mod, ns in names.items():
+        m = importlib.import_module(mod)
+        for n in ns:
+            assert hasattr(m, n), f"{mod}.{n}"
+    from oprl.runners.train_distrib import run_distrib_training
+    params = inspect.signature(run_distrib_training).parameters
+    for k in ("run_env_worker", "run_policy_update_worker", "make_env", "make_algo", "make_policy",
+              "make_replay_buffer", "make_logger", "config"):
+        assert k in params, k
+    from oprl.runners.train import run_training
+    params = inspect.signature(run_training).parameters
+    for k in ("make_algo", "make_env", "make_replay_buffer", "make_logger", "config", "seeds", "start_seed"):
+        assert k in params, k
