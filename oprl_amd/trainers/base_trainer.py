@@ -124,6 +124,45 @@ class BaseTrainer(TrainerProtocol):
         self.replay_buffer.load_state_dict(ck["replay"])
         return int(ck["env_step"])
 
+    # Q-value sanity probe (reference base_trainer.py:122-174; defined there but never called from
+    # train(), kept with the same names and semantics): discounted Monte-Carlo return of the greedy
+    # policy against the critic's Q at the first state-action of the same episodes.
+    def _estimate_q(self, env_step: int) -> None:
+        if self.estimate_q_every > 0 and env_step % self.estimate_q_every == 0:
+            q_true = self.estimate_true_q()
+            q_critic = self.estimate_critic_q()
+            self.logger.log_scalar("trainer/Q-estimate", q_true, env_step)
+            self.logger.log_scalar("trainer/Q-critic", q_critic, env_step)
+            self.logger.log_scalar("trainer/Q_asb_diff", q_critic - q_true, env_step)
+
+    def estimate_true_q(self, eval_episodes: int = 10) -> float:
+        qs = []
+        for i_eval in range(eval_episodes):
+            env = self.make_env_test(self.seed * 100 + i_eval)
+            state, _ = env.reset()
+            q, discount, done = 0.0, self.gamma, False
+            while not done:
+                state, r, terminated, truncated, _ = env.step(self.algo.actor.exploit(state))
+                q += r * discount          # (the reference starts the discount at gamma^1)
+                discount *= self.gamma
+                done = terminated or truncated
+            qs.append(q)
+        return float(np.mean(qs))
+
+    def estimate_critic_q(self, num_episodes: int = 10) -> float:
+        qs = []
+        for i_eval in range(num_episodes):
+            env = self.make_env_test(self.seed * 100 + i_eval)
+            state, _ = env.reset()
+            action = self.algo.actor.exploit(state)
+            s = t.as_tensor(np.asarray(state), dtype=t.float32, device=self.device).unsqueeze(0)
+            a = t.as_tensor(np.asarray(action), dtype=t.float32, device=self.device).unsqueeze(0)
+            q = self.algo.critic(s, a)
+            if isinstance(q, tuple):       # twin critics: Q1
+                q = q[0]
+            qs.append(float(q.reshape(-1)[0].item()))   # (quantile critics: first entry, as the reference's .item() would need)
+        return float(np.mean(qs))
+
     def _log_stdout(self, env_step: int, rewards: t.Tensor) -> None:
         if env_step % self.stdout_log_every == 0:
             perc = int(env_step / max(self.num_steps, 1) * 100)

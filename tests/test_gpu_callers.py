@@ -172,6 +172,11 @@ def test_trainer_end_to_end_on_synthetic_env():
     assert algo.update_step == 401 - 31
     assert t.isfinite(algo.actor._oprl_arena).all() and not t.equal(before, algo.actor._oprl_arena)
     assert len(buf) == 401 and buf.episodes_counter == 5
+    tr = BaseTrainer(logger=NullLogger("/tmp/oprl_amd_test"), env=env(0), make_env_test=env, replay_buffer=buf,
+                     algo=algo, num_steps=1, estimate_q_every=1)
+    q_true, q_critic = tr.estimate_true_q(2), tr.estimate_critic_q(2)
+    assert np.isfinite(q_true) and np.isfinite(q_critic)
+    tr._estimate_q(1)
 
 
 def test_policy_act_equals_batched_forward():
