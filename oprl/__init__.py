@@ -10,7 +10,7 @@ _SUBMODULES = [
     "algos", "algos.protocols", "algos.base_algorithm", "algos.nn_models", "algos.nn_functions",
     "algos.ddpg", "algos.td3", "algos.sac", "algos.tqc",
     "buffers", "buffers.protocols", "buffers.episodic_buffer",
-    "environment", "environment.protocols",
+    "environment", "environment.protocols", "environment.make_env",
     "runners", "runners.config", "runners.train", "runners.train_distrib",
     "trainers", "trainers.protocols", "trainers.base_trainer",
     "distrib", "distrib.queue", "distrib.env_worker", "distrib.policy_update_worker",

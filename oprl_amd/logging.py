@@ -93,6 +93,14 @@ class FileTxtLogger(BaseLogger):
             f.write(f"{step} {value}\n")
 
 
+def copy_exp_dir(log_dir: Path) -> None:
+    """Snapshot of the package sources next to the logs (reference logging.py:42-46)."""
+    dest = Path(log_dir) / "src"
+    shutil.copytree(Path(__file__).parent, dest, dirs_exist_ok=True,
+                    ignore=shutil.ignore_patterns("*.so", "__pycache__"))
+    logger.info(f"Source copied into {dest}")
+
+
 def make_text_logger_func(algo: str, env: str) -> Callable[[int], LoggerProtocol]:
     def make_logger(seed: int) -> LoggerProtocol:
         root = os.environ.get("OPRL_LOGS", "logs")
