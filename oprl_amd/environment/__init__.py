@@ -1,11 +1,6 @@
-"""``make_env(name, seed)`` (reference: /root/reference/src/oprl/environment/make_env.py).
-Real simulators are out of scope (CPU physics); see synthetic.py."""
+"""Environment factory (reference: /root/reference/src/oprl/environment/)."""
 from oprl_amd.environment.protocols import EnvProtocol
 from oprl_amd.environment.synthetic import DM_CONTROL_DIMS, SyntheticEnv
-
-
-def make_env(name: str, seed: int = 0) -> EnvProtocol:
-    return SyntheticEnv(name, seed=seed)
-
+from oprl_amd.environment.make_env import make_env   # (rebinds the name from the submodule to the function)
 
 __all__ = ["EnvProtocol", "SyntheticEnv", "make_env", "DM_CONTROL_DIMS"]

@@ -1,5 +1,8 @@
-"""``oprl.environment.make_env`` as a module path (reference: environment/make_env.py): the
-function lives in the package's ``__init__``."""
-from oprl_amd.environment import make_env  # noqa: F401
+"""``make_env(name, seed)`` (reference: /root/reference/src/oprl/environment/make_env.py).
+Real simulators are out of scope (CPU physics); see synthetic.py."""
+from oprl_amd.environment.protocols import EnvProtocol
+from oprl_amd.environment.synthetic import SyntheticEnv
 
-__all__ = ["make_env"]
+
+def make_env(name: str, seed: int = 0) -> EnvProtocol:
+    return SyntheticEnv(name, seed=seed)

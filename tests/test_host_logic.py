@@ -216,6 +216,9 @@ def test_alias_package_serves_the_reference_config_scripts():
         m = importlib.import_module(mod)
         for n in ns:
             assert hasattr(m, n), f"{mod}.{n}"
+    import oprl.environment
+    from oprl.environment.make_env import make_env as by_module
+    assert callable(oprl.environment.make_env) and oprl.environment.make_env is by_module   # not shadowed by the submodule
     from oprl.runners.train_distrib import run_distrib_training
     params = inspect.signature(run_distrib_training).parameters
     for k in ("run_env_worker", "run_policy_update_worker", "make_env", "make_algo", "make_policy",
