@@ -192,6 +192,9 @@ def main():
     ap.add_argument("--learners", type=int, default=8,
                     help="extra measurement: this many independent learners (seeds) on separate "
                          "streams of the same GPU (multi-seed packing, runners/train.py --seeds); 0 = skip")
+    ap.add_argument("--no-p2p", action="store_true",
+                    help="data-parallel path: keep the gradient exchanges on RCCL (default: one-shot peer-window "
+                         "all-reduce when its self-test passes)")
     ap.add_argument("--force-dp", action="store_true",
                     help="use the data-parallel path (RCCL all-reduce) even with one rank")
     args = ap.parse_args()
@@ -216,6 +219,7 @@ def main():
 
     dist = None
     use_dp = world > 1 or args.force_dp
+    use_p2p = False
     if use_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -237,6 +241,15 @@ def main():
         dp = DataParallelLearner(algo, dist.group.WORLD)
         dp.broadcast_parameters()
         dp.init_native_comm()
+        # the two gradient exchanges per update as one-shot all-reduces over peer windows (csrc/p2p.hip)
+        # when every rank's self-test passes; otherwise they stay on the RCCL communicator
+        use_p2p = False
+        if not args.no_p2p:
+            try:
+                use_p2p = dp.init_p2p()
+            except Exception as exc:  # noqa: BLE001
+                if rank == 0:
+                    print(f"bench.py: peer windows unavailable ({exc}); using RCCL", file=sys.stderr)
 
         def run(n):
             dp.step_n(replay.handle, n, B, seed=0)
@@ -258,6 +271,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     value = world * K / dt
+    dp_check = None
+    if use_dp:
+        # replicas must have stayed identical (every rank sums the gradients in the same order) and finite
+        spread = dp.replica_checksum()                       # collective: [max - min] over ranks of two checksums
+        finite = bool(t.isfinite(algo.actor._oprl_arena).all() and t.isfinite(algo.critic._oprl_arena).all())
+        dp_check = {"replicas_identical": bool(float(spread.abs().max()) == 0.0), "finite": finite,
+                    "exchange": "p2p" if use_p2p else "rccl"}
 
     out = None
     if rank == 0:
@@ -325,9 +345,11 @@ def main():
                                    f"{E}x{L} transitions resident in HBM, device-side uniform sampling, "
                                    "exact-fp32 MFMA (parity mode)",
                        "path": "oprl_learner_step_n" if not use_dp else
-                               "oprl_learner_dp_step_n: update_phase/apply + 2 RCCL all-reduces (critic, actor grads) per step, all in C",
+                               ("oprl_learner_dp_step_n: update_phase/apply + 2 gradient all-reduces (critic, actor) per step, all in C; "
+                                + ("one-shot peer-window all-reduce over xGMI (csrc/p2p.hip, self-test passed on every rank)"
+                                   if use_p2p else "RCCL ncclAllReduce")),
                        "parallelism": f"dp{world}", "global_batch": B * world},
-            "roofline": roof, "cpu_baseline": cpu, "multi_learner": multi,
+            "roofline": roof, "cpu_baseline": cpu, "multi_learner": multi, "data_parallel_check": dp_check,
             "flop_per_step": 2.0 * B * (MACS_SLICE + MACS_DW), "state_bytes_per_step": STATE_BYTES,
         }
         print(json.dumps(out), flush=True)

@@ -208,6 +208,19 @@ int oprl_polyak(float* target, const float* source, int64_t n, double tau, void*
 int oprl_comm_unique_id(const char* rccl_path, char id_out[OPRL_COMM_ID_BYTES]);
 int oprl_comm_init(oprl_learner* h, const char* rccl_path, int32_t rank, int32_t world,
                    const char id[OPRL_COMM_ID_BYTES]);
+/* Optional: the two gradient exchanges as ONE-SHOT all-reduces over peer windows (csrc/p2p.hip)
+ * instead of RCCL rings — every rank pushes its arena straight into a slot of every other rank's
+ * window over the xGMI mesh and sums the slots in rank order.  oprl_p2p_create allocates this rank's
+ * window and returns its IPC handle; the host gathers the `world` handles (any side channel) and
+ * passes them, in rank order, to oprl_p2p_connect; oprl_p2p_selftest (all ranks together) exchanges
+ * a known pattern and reports whether this rank's sums were exact; when every rank passed, every
+ * rank calls oprl_p2p_enable(h, 1) and the exchanges of dp_update / dp_step_n use the windows.  Without RCCL
+ * (oprl_comm_init never called) a connected learner runs dp_update / dp_step_n on the windows alone. */
+#define OPRL_P2P_HANDLE_BYTES 64
+int oprl_p2p_create(oprl_learner* h, int32_t rank, int32_t world, char handle_out[OPRL_P2P_HANDLE_BYTES]);
+int oprl_p2p_connect(oprl_learner* h, const char* handles /* world x OPRL_P2P_HANDLE_BYTES */);
+int oprl_p2p_selftest(oprl_learner* h, void* stream);
+int oprl_p2p_enable(oprl_learner* h, int32_t on);
 int oprl_learner_dp_update(oprl_learner* h, const float* s, const float* a, const float* r,
                            const float* d, const float* s2, int32_t B, const float* noise0,
                            const float* noise1, void* stream);

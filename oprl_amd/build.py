@@ -10,7 +10,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "lib" / "liboprl_amd.so"
-SOURCES = ["kernels.hip", "fused_ddpg.hip", "slice_tp.hip", "layerwise.hip", "dw_wide.hip", "replay.hip", "learner.hip"]
+SOURCES = ["kernels.hip", "fused_ddpg.hip", "slice_tp.hip", "layerwise.hip", "dw_wide.hip", "p2p.hip", "replay.hip", "learner.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ldl"]
 
 

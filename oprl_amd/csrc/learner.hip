@@ -20,6 +20,7 @@
 
 #include "../../include/oprl_amd.h"
 #include "kernels.h"
+#include "p2p.h"
 
 namespace oprl {
 
@@ -337,6 +338,8 @@ struct oprl_learner {
   bool pair_collect = false;
   int pair_n = 0;
   MlpArgs pair_args[2];
+  P2pState p2p;                // one-shot all-reduce windows (csrc/p2p.hip); used when p2p_ok
+  bool p2p_ok = false, p2p_tested = false;
   bool no_twin_split = false;  // OPRL_AMD_NO_TWIN_SPLIT: role A runs both target critics back to back (tests / A-B)
   bool no_multi = false;
   bool no_layerwise = false;   // OPRL_AMD_NO_LAYERWISE: wide nets stay on the single-CU slice kernel (tests / A-B)
@@ -1046,11 +1049,9 @@ extern "C" int oprl_comm_unique_id(const char* rccl_path, char id_out[OPRL_COMM_
   return OPRL_OK;
 }
 
-extern "C" int oprl_comm_init(oprl_learner* h, const char* rccl_path, int32_t rank, int32_t world,
-                              const char id[OPRL_COMM_ID_BYTES]) {
-  if (!h || !id || world < 1 || rank < 0 || rank >= world) { set_err("oprl_comm_init: invalid argument"); return OPRL_ERR_INVALID; }
-  if (!h->cfg.export_grads) { set_err("oprl_comm_init: learner was not created with export_grads"); return OPRL_ERR_STATE; }
-  // the gradient arenas must be contiguous per group (critics back to back)
+namespace {
+// the gradient arenas must be contiguous per group (critics back to back)
+int dp_arena_sizes(oprl_learner* h) {
   long off = 0;
   for (int j = 0; j < h->nc; ++j) {
     if (h->cfg.critics[j].grad != h->cfg.critics[0].grad + off) { set_err("critic gradient arenas are not contiguous"); return OPRL_ERR_INVALID; }
@@ -1058,6 +1059,15 @@ extern "C" int oprl_comm_init(oprl_learner* h, const char* rccl_path, int32_t ra
   }
   h->n_critic_params = off;
   h->n_actor_params = net_param_count(h->cfg.actor);
+  return OPRL_OK;
+}
+}  // namespace
+
+extern "C" int oprl_comm_init(oprl_learner* h, const char* rccl_path, int32_t rank, int32_t world,
+                              const char id[OPRL_COMM_ID_BYTES]) {
+  if (!h || !id || world < 1 || rank < 0 || rank >= world) { set_err("oprl_comm_init: invalid argument"); return OPRL_ERR_INVALID; }
+  if (!h->cfg.export_grads) { set_err("oprl_comm_init: learner was not created with export_grads"); return OPRL_ERR_STATE; }
+  RC(dp_arena_sizes(h));
   RC(rccl_bind(h->rccl, rccl_path));
   NcclId nid;
   memcpy(nid.internal, id, OPRL_COMM_ID_BYTES);
@@ -1067,23 +1077,91 @@ extern "C" int oprl_comm_init(oprl_learner* h, const char* rccl_path, int32_t ra
   return OPRL_OK;
 }
 
+// ---- one-shot all-reduce over peer windows (csrc/p2p.hip) -------------------------------------------
+extern "C" int oprl_p2p_create(oprl_learner* h, int32_t rank, int32_t world, char handle_out[OPRL_P2P_HANDLE_BYTES]) {
+  if (!h || !handle_out) { set_err("oprl_p2p_create: invalid argument"); return OPRL_ERR_INVALID; }
+  if (!h->cfg.export_grads) { set_err("oprl_p2p_create: learner was not created with export_grads"); return OPRL_ERR_STATE; }
+  if (h->p2p.window != nullptr) { set_err("oprl_p2p_create: window already exists"); return OPRL_ERR_STATE; }
+  RC(dp_arena_sizes(h));
+  const size_t n = (size_t)std::max(h->n_critic_params, h->n_actor_params);
+  hipError_t e = p2p_create(h->p2p, rank, world, n, handle_out);
+  if (e != hipSuccess) {
+    set_err("oprl_p2p_create: %s", hipGetErrorString(e));
+    (void)hipGetLastError();
+    p2p_destroy(h->p2p);
+    return OPRL_ERR_HIP;
+  }
+  return OPRL_OK;
+}
+
+extern "C" int oprl_p2p_connect(oprl_learner* h, const char* handles) {
+  if (!h || !handles || h->p2p.window == nullptr) { set_err("oprl_p2p_connect: call oprl_p2p_create first"); return OPRL_ERR_STATE; }
+  hipError_t e = p2p_connect(h->p2p, handles);
+  if (e != hipSuccess) { set_err("oprl_p2p_connect: %s", hipGetErrorString(e)); (void)hipGetLastError(); return OPRL_ERR_HIP; }
+  return OPRL_OK;
+}
+
+// Every rank contributes (rank + 1) * (1 + i mod 7) at element i of its critic gradient arena; the
+// windows are kept only if this rank's sum is exact everywhere.  (The ranks decide together: the
+// host reduces the verdicts, oprl_amd/parallel.py.)
+extern "C" int oprl_p2p_selftest(oprl_learner* h, void* stream) {
+  if (!h || !h->p2p.connected) { set_err("oprl_p2p_selftest: windows are not connected"); return OPRL_ERR_STATE; }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = (size_t)h->n_critic_params;
+  float* g = h->cfg.critics[0].grad;
+  std::vector<float> host(n);
+  bool all_ok = true;
+  for (int round = 0; round < 3 && all_ok; ++round) {   // three rounds: both window halves and a reuse
+    for (size_t i = 0; i < n; ++i) host[i] = (float)((h->p2p.rank + 1) * (1 + (int)((i + round) % 7)));
+    HIPC(hipMemcpyAsync(g, host.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPC(p2p_all_reduce(h->p2p, g, n, false, st));
+    HIPC(hipMemcpyAsync(host.data(), g, n * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    const int tri = h->p2p.world * (h->p2p.world + 1) / 2;
+    for (size_t i = 0; i < n && all_ok; ++i) all_ok = host[i] == (float)(tri * (1 + (int)((i + round) % 7)));
+  }
+  HIPC(hipMemsetAsync(g, 0, n * sizeof(float), st));
+  h->p2p_tested = all_ok;
+  if (!all_ok) { set_err("oprl_p2p_selftest: the exchanged sum is wrong; staying on RCCL"); return OPRL_ERR_STATE; }
+  return OPRL_OK;
+}
+
+// The ranks agree on the host (every self-test passed) and then switch together.
+extern "C" int oprl_p2p_enable(oprl_learner* h, int32_t on) {
+  if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
+  if (on && !h->p2p_tested) { set_err("oprl_p2p_enable: the self-test has not passed on this rank"); return OPRL_ERR_STATE; }
+  h->p2p_ok = on != 0;
+  return OPRL_OK;
+}
+
+namespace {
+int dp_world(const oprl_learner* h) { return h->p2p_ok ? h->p2p.world : h->rccl.world; }
+int dp_rank(const oprl_learner* h) { return h->p2p_ok ? h->p2p.rank : h->rccl.rank; }
+// in-place sum over ranks of a float (or one-double) buffer: peer windows when they passed the self-test, else RCCL
+int dp_all_reduce(oprl_learner* h, void* buf, size_t n, bool as_double, hipStream_t st) {
+  if (h->p2p_ok) {
+    HIPC(p2p_all_reduce(h->p2p, buf, n, as_double, st));
+    return OPRL_OK;
+  }
+  NCCLC(h, h->rccl.all_reduce(buf, buf, n, as_double ? kNcclFloat64 : kNcclFloat32, kNcclSum, h->rccl.comm, st));
+  return OPRL_OK;
+}
+}  // namespace
+
 extern "C" int oprl_learner_dp_update(oprl_learner* h, const float* s, const float* a, const float* r,
                                       const float* d, const float* s2, int32_t B, const float* noise0,
                                       const float* noise1, void* stream) {
-  if (!h || !h->rccl.comm) { set_err("oprl_learner_dp_update: call oprl_comm_init first"); return OPRL_ERR_STATE; }
+  if (!h || (!h->rccl.comm && !h->p2p_ok)) { set_err("oprl_learner_dp_update: call oprl_comm_init (or connect the peer windows) first"); return OPRL_ERR_STATE; }
   hipStream_t st = (hipStream_t)stream;
   const oprl_learner_config& c = h->cfg;
-  const double scale = 1.0 / (double)h->rccl.world;
+  const double scale = 1.0 / (double)dp_world(h);
   RC(oprl_learner_update_phase(h, 0, s, a, r, d, s2, B, noise0, noise1, stream));
-  NCCLC(h, h->rccl.all_reduce(c.critics[0].grad, c.critics[0].grad, (size_t)h->n_critic_params,
-                              kNcclFloat32, kNcclSum, h->rccl.comm, st));
+  RC(dp_all_reduce(h, c.critics[0].grad, (size_t)h->n_critic_params, false, st));
   RC(oprl_learner_apply(h, 0, scale, stream));
   RC(oprl_learner_update_phase(h, 1, s, a, r, d, s2, B, noise0, noise1, stream));
   if (h->actor_updated_last) {
-    NCCLC(h, h->rccl.all_reduce(c.actor.grad, c.actor.grad, (size_t)h->n_actor_params, kNcclFloat32,
-                                kNcclSum, h->rccl.comm, st));
-    if (alpha_ptr(h) != nullptr)
-      NCCLC(h, h->rccl.all_reduce(h->alpha_grad, h->alpha_grad, 1, kNcclFloat64, kNcclSum, h->rccl.comm, st));
+    RC(dp_all_reduce(h, c.actor.grad, (size_t)h->n_actor_params, false, st));
+    if (alpha_ptr(h) != nullptr) RC(dp_all_reduce(h, h->alpha_grad, 1, true, st));
     RC(oprl_learner_apply(h, 1, scale, stream));
   }
   return OPRL_OK;
@@ -1092,13 +1170,13 @@ extern "C" int oprl_learner_dp_update(oprl_learner* h, const float* s, const flo
 extern "C" int oprl_learner_dp_step_n(oprl_learner* h, oprl_replay* replay, int32_t K, int32_t B,
                                       uint64_t seed, void* stream) {
   if (!h || !replay) { set_err("oprl_learner_dp_step_n: null handle"); return OPRL_ERR_INVALID; }
-  if (!h->rccl.comm) { set_err("oprl_learner_dp_step_n: call oprl_comm_init first"); return OPRL_ERR_STATE; }
+  if (!h->rccl.comm && !h->p2p_ok) { set_err("oprl_learner_dp_step_n: call oprl_comm_init (or connect the peer windows) first"); return OPRL_ERR_STATE; }
   int S = 0, A = 0;
   replay_dims(replay, &S, &A);
   if (S != h->S || A != h->A) { set_err("replay dims (%d,%d) != learner dims (%d,%d)", S, A, h->S, h->A); return OPRL_ERR_INVALID; }
   if (K < 0 || B < 1 || B > h->Bmax) { set_err("dp_step_n: bad K/B"); return OPRL_ERR_INVALID; }
   // every rank samples its own shard: the Philox key mixes the rank in
-  const uint64_t rseed = seed * 0x9E3779B97F4A7C15ull + (uint64_t)h->rccl.rank;
+  const uint64_t rseed = seed * 0x9E3779B97F4A7C15ull + (uint64_t)dp_rank(h);
   if (use_fused(h, B)) {
     BatchSrc& sc = h->src;
     RC(oprl_replay_flush(replay, stream));
@@ -1353,6 +1431,7 @@ extern "C" int oprl_learner_destroy(oprl_learner* h) {
   if (h->rccl.comm && h->rccl.comm_destroy) (void)h->rccl.comm_destroy(h->rccl.comm);
   if (h->fused) { std::lock_guard<std::mutex> lk(g_chain_mu); if (g_chain.live > 0) g_chain.live -= 1; }
   if (h->xbuf) (void)hipFree(h->xbuf);
+  if (h->p2p.window) p2p_destroy(h->p2p);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   for (int j = 1; j < OPRL_MAX_CRITICS; ++j) {
     if (h->ev_join[j]) (void)hipEventDestroy(h->ev_join[j]);

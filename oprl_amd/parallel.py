@@ -57,6 +57,52 @@ class DataParallelLearner:
                         "oprl_comm_init")
         self._native = True
 
+    def init_p2p(self) -> bool:
+        """Set up the one-shot all-reduce over peer windows (csrc/p2p.hip): every rank allocates its
+        window, the IPC handles travel over torch.distributed, every rank maps the others' windows, then
+        all ranks run the self-test together and keep the path only if EVERY rank's sum was exact
+        (otherwise the RCCL communicator of init_native_comm() keeps doing the exchanges).  Returns
+        whether the windows are in use."""
+        import ctypes as C
+
+        from oprl_amd import _capi
+        lib = _capi.load()
+        e = self.engine
+        ok = True
+        self.p2p_error = ""
+
+        def failed(what: str) -> None:
+            self.p2p_error = f"{what}: {lib.oprl_last_error().decode('utf-8', 'replace')}"
+
+        buf = C.create_string_buffer(64)
+        with t.cuda.device(e.device):
+            ok = lib.oprl_p2p_create(e.handle, self.rank, self.world, buf) == 0
+        if not ok:
+            failed("oprl_p2p_create")
+        handles = [None] * self.world
+        dist.all_gather_object(handles, buf.raw if ok else None, group=self.group)
+        ok = ok and all(h is not None for h in handles)
+        if ok:
+            with t.cuda.device(e.device):
+                ok = lib.oprl_p2p_connect(e.handle, b"".join(handles)) == 0
+            if not ok:
+                failed("oprl_p2p_connect")
+        verdicts = [None] * self.world
+        dist.all_gather_object(verdicts, bool(ok), group=self.group)
+        if not all(verdicts):
+            return False                     # some rank could not map a window: nobody enters the self-test
+        with t.cuda.device(e.device):
+            ok = lib.oprl_p2p_selftest(e.handle, _capi.current_stream()) == 0
+        if not ok:
+            failed("oprl_p2p_selftest")
+        dist.all_gather_object(verdicts, bool(ok), group=self.group)
+        good = all(verdicts)
+        if good:
+            _capi.check(lib.oprl_p2p_enable(e.handle, 1), "oprl_p2p_enable")
+            self._native = True
+        self.p2p = good
+        return good
+
     def step_n(self, replay_handle, K: int, B: int, seed: int = 0) -> None:
         """K synchronous data-parallel sample()+update() iterations in one C call."""
         from oprl_amd import _capi

@@ -1,0 +1,80 @@
+"""The one-shot all-reduce over peer windows (csrc/p2p.hip) with TWO processes: the data-parallel step
+through the windows must leave both replicas bit-identical and equal to a single-process emulation
+that sums the two ranks' gradients in rank order."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch as t
+
+pytestmark = pytest.mark.gpu
+
+
+def make_algo(name, B, **kw):
+    from oprl_amd.algos.ddpg import DDPG
+    from oprl_amd.algos.sac import SAC
+    from oprl_amd.logging import NullLogger
+    t.manual_seed(0)
+    if name == "sac":
+        return SAC(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=B, tune_alpha=True,
+                   log_every=10 ** 9, **kw).create()
+    return DDPG(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=B, **kw).create()
+
+
+def make_shard(rank):
+    from oprl_amd.buffers.episodic_buffer import EpisodicReplayBuffer
+    buf = EpisodicReplayBuffer(buffer_size_transitions=600, state_dim=24, action_dim=6, max_episode_lenth=50,
+                               device="cuda", seed=3).create()
+    rs = np.random.RandomState(100 + rank)
+    for e in range(5):
+        for i in range(50 - e):
+            buf.add_transition(rs.standard_normal(24).astype(np.float32), rs.uniform(-1, 1, 6),
+                               float(rs.uniform()), False, episode_done=(i == 50 - e - 1))
+    return buf
+
+
+@pytest.mark.parametrize("algo_name", ["ddpg", "sac"])
+def test_two_process_p2p_data_parallel_step(algo_name):
+    K, B, world = 6, 64, 2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        rdv, out = os.path.join(td, "rdv"), os.path.join(td, "out")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "p2p_worker.py"), str(r), str(world),
+                                   rdv, out, algo_name, str(K), str(B)], env=env, cwd=root)
+                 for r in range(world)]
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+        res = [t.load(f"{out}.{r}", weights_only=False) for r in range(world)]
+    assert all(r["ok"] for r in res), f"the peer windows are not in use: {[r['why'] for r in res]}"
+    for m in ("actor", "critic"):
+        assert t.equal(res[0]["arenas"][m], res[1]["arenas"][m]), f"replicas diverged: {m}"
+        assert t.isfinite(res[0]["arenas"][m]).all()
+    # single-process emulation: two export_grads learners, gradients summed in rank order
+    L = [make_algo(algo_name, B, export_grads=True) for _ in range(world)]
+    shards = [make_shard(r) for r in range(world)]
+    for r in range(world):
+        shards[r].seed = (5 * 0x9E3779B97F4A7C15 + r) & (2 ** 64 - 1)
+    for k in range(K):
+        batches = []
+        for r in range(world):
+            shards[r]._sample_counter = k
+            batches.append(shards[r].sample(B))
+        for phase, which in ((0, "critic_grad"), (1, "actor_grad")):
+            for r in range(world):
+                L[r].learner.update_phase(phase, *batches[r])
+            total = getattr(L[0].learner, which) + getattr(L[1].learner, which)
+            for r in range(world):
+                getattr(L[r].learner, which).copy_(total)
+            if phase == 1 and L[0].learner.log_alpha_grad is not None:
+                ta = L[0].learner.log_alpha_grad + L[1].learner.log_alpha_grad
+                for r in range(world):
+                    L[r].learner.log_alpha_grad.copy_(ta)
+            for r in range(world):
+                L[r].learner.apply(phase, 1.0 / world)
+    t.cuda.synchronize()
+    for m in ("actor", "critic"):
+        assert t.equal(getattr(L[0], m)._oprl_arena.cpu(), res[0]["arenas"][m]), m
