@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kP2pThreads) void k_p2p_reduce(const P2pReduceArgs 
     const unsigned long long* f = reinterpret_cast<const unsigned long long*>(a.window + p2p_flags_off(a.world, a.slot_floats)) +
                                   ((size_t)a.parity * a.world + threadIdx.x) * kFlagStride;
     bool ok = false;
-    for (int spin = 0; spin < (1 << 24) && !ok; ++spin) {
+    for (int spin = 0; spin < (1 << 22) && !ok; ++spin) {
       ok = __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= a.seq;
       if (!ok) __builtin_amdgcn_s_sleep(8);
     }
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kP2pThreads) void k_p2p_all_reduce(const P2pFusedAr
       const unsigned long long* f = reinterpret_cast<const unsigned long long*>(a.window + foff) +
                                     ((size_t)a.parity * a.world + threadIdx.x) * kFlagStride;
       bool ok = false;
-      for (int spin = 0; spin < (1 << 24) && !ok; ++spin) {
+      for (int spin = 0; spin < (1 << 22) && !ok; ++spin) {
         ok = __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= a.seq;
         if (!ok) __builtin_amdgcn_s_sleep(4);
       }
