@@ -226,33 +226,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
-    t.manual_seed(0)                                   # reference-style init, same on all ranks
-    algo = DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device=f"cuda:{local_rank}",
-                max_batch=B, export_grads=use_dp).create()
     replay = make_replay(dev, seed=rank)               # disjoint shard per rank
-    learner = algo.learner
     K, W = args.steps, args.warmup
-
-    if not use_dp:
-        def run(n):
-            learner.step_n(replay.handle, n, B, seed=0)
-    else:
-        from oprl_amd.parallel import DataParallelLearner
-        dp = DataParallelLearner(algo, dist.group.WORLD)
-        dp.broadcast_parameters()
-        dp.init_native_comm()
-        # the two gradient exchanges per update as one-shot all-reduces over peer windows (csrc/p2p.hip)
-        # when every rank's self-test passes; otherwise they stay on the RCCL communicator
-        use_p2p = False
-        if not args.no_p2p:
-            try:
-                use_p2p = dp.init_p2p()
-            except Exception as exc:  # noqa: BLE001
-                if rank == 0:
-                    print(f"bench.py: peer windows unavailable ({exc}); using RCCL", file=sys.stderr)
-
-        def run(n):
-            dp.step_n(replay.handle, n, B, seed=0)
 
     def barrier():
         t.cuda.synchronize(dev)
@@ -260,7 +235,57 @@ def main():
             dist.barrier()
         t.cuda.synchronize(dev)
 
-    run(W)
+    def make_learner():
+        t.manual_seed(0)                               # reference-style init, same on all ranks
+        return DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device=f"cuda:{local_rank}",
+                    max_batch=B, export_grads=use_dp).create()
+
+    dp = None
+    p2p_level = 0
+    if not use_dp:
+        algo = make_learner()
+        learner = algo.learner
+
+        def run(n):
+            learner.step_n(replay.handle, n, B, seed=0)
+        run(W)
+    else:
+        from oprl_amd.parallel import DataParallelLearner
+        # The two gradient exchanges per update, fastest first: (2) inside the dW + Adam launches over
+        # peer windows (csrc/p2p.hip, k_dw_adam<true>), (1) one window kernel per exchange, (0) RCCL.
+        # A level is kept only if every rank's window self-test passed AND, after the warm-up updates,
+        # every replica is finite and identical — otherwise fresh replicas are built one level down.
+        for level in ((0,) if args.no_p2p else (2, 1, 0)):
+            algo = make_learner()
+            learner = algo.learner
+            dp = DataParallelLearner(algo, dist.group.WORLD)
+            dp.broadcast_parameters()
+            dp.init_native_comm()
+            ok = True
+            if level > 0:
+                try:
+                    ok = dp.init_p2p(level)
+                except Exception as exc:  # noqa: BLE001
+                    ok = False
+                    if rank == 0:
+                        print(f"bench.py: peer windows unavailable ({exc})", file=sys.stderr)
+                if not ok and rank == 0:
+                    print(f"bench.py: peer-window level {level} not available ({dp.p2p_error})", file=sys.stderr)
+            if ok:
+                dp.step_n(replay.handle, max(W, 50), B, seed=0)
+                ok = dp.healthy()
+                if not ok and rank == 0:
+                    print(f"bench.py: replicas unhealthy after warm-up at exchange level {level}; stepping down",
+                          file=sys.stderr)
+            if ok:
+                p2p_level = level
+                break
+            del dp, learner, algo
+        use_p2p = p2p_level > 0
+
+        def run(n):
+            dp.step_n(replay.handle, n, B, seed=0)
+
     barrier()
     t0 = time.perf_counter()
     run(K)
@@ -277,7 +302,7 @@ def main():
         spread = dp.replica_checksum()                       # collective: [max - min] over ranks of two checksums
         finite = bool(t.isfinite(algo.actor._oprl_arena).all() and t.isfinite(algo.critic._oprl_arena).all())
         dp_check = {"replicas_identical": bool(float(spread.abs().max()) == 0.0), "finite": finite,
-                    "exchange": "p2p" if use_p2p else "rccl"}
+                    "exchange": {2: "p2p-inline", 1: "p2p", 0: "rccl"}[p2p_level]}
 
     out = None
     if rank == 0:
@@ -346,8 +371,9 @@ def main():
                                    "exact-fp32 MFMA (parity mode)",
                        "path": "oprl_learner_step_n" if not use_dp else
                                ("oprl_learner_dp_step_n: update_phase/apply + 2 gradient all-reduces (critic, actor) per step, all in C; "
-                                + ("one-shot peer-window all-reduce over xGMI (csrc/p2p.hip, self-test passed on every rank)"
-                                   if use_p2p else "RCCL ncclAllReduce")),
+                                + {2: "all-reduced per tile inside the dW + Adam launches over xGMI peer windows (csrc/p2p.hip, k_dw_adam<true>)",
+                                   1: "one-shot peer-window all-reduce over xGMI, one kernel per exchange (csrc/p2p.hip)",
+                                   0: "RCCL ncclAllReduce"}[p2p_level]),
                        "parallelism": f"dp{world}", "global_batch": B * world},
             "roofline": roof, "cpu_baseline": cpu, "multi_learner": multi, "data_parallel_check": dp_check,
             "flop_per_step": 2.0 * B * (MACS_SLICE + MACS_DW), "state_bytes_per_step": STATE_BYTES,

@@ -214,7 +214,11 @@ int oprl_comm_init(oprl_learner* h, const char* rccl_path, int32_t rank, int32_t
  * window and returns its IPC handle; the host gathers the `world` handles (any side channel) and
  * passes them, in rank order, to oprl_p2p_connect; oprl_p2p_selftest (all ranks together) exchanges
  * a known pattern and reports whether this rank's sums were exact; when every rank passed, every
- * rank calls oprl_p2p_enable(h, 1) and the exchanges of dp_update / dp_step_n use the windows.  Without RCCL
+ * rank calls oprl_p2p_enable(h, level): 1 = the two exchanges of dp_update / dp_step_n run as one
+ * window kernel each; 2 = in addition the fused learners (DDPG / TD3 / SAC) all-reduce every gradient
+ * tile INSIDE their dW + Adam launches (no separate exchange or apply launches at all; the caller should
+ * check after a few updates that parameters are finite and replicas identical, and step down to 1
+ * otherwise — bench.py does); 0 = back to RCCL.  Without RCCL
  * (oprl_comm_init never called) a connected learner runs dp_update / dp_step_n on the windows alone. */
 #define OPRL_P2P_HANDLE_BYTES 64
 int oprl_p2p_create(oprl_learner* h, int32_t rank, int32_t world, char handle_out[OPRL_P2P_HANDLE_BYTES]);

@@ -143,6 +143,22 @@ __device__ __forceinline__ int adam_polyak_elem(float g, float* th, float* m, fl
 }
 
 
+// Data-parallel learner, peer windows (csrc/p2p.hip): k_dw_adam<true> exchanges each 16x32 gradient tile
+// (+ 16 bias sums) with the same tile of the other ranks between its GEMM and its Adam epilogue — the
+// separate all-reduce and apply launches of the RCCL path disappear.  Tile region of a window:
+// [parity][source rank][tile][kDwXchgTile] 8-byte {sequence, value} granules.
+constexpr int kDwXchgTile = 512 + 16;
+constexpr int kDwXchgMaxWorld = 8;
+struct DwXchg {
+  char* peer[kDwXchgMaxWorld];         // every rank's tile region as mapped here
+  char* window;                        // this rank's tile region
+  int world, rank, parity, max_tiles;
+  unsigned long long seq;
+};
+__host__ __device__ inline size_t dw_xchg_bytes(int world, int max_tiles) {
+  return (size_t)2 * world * max_tiles * kDwXchgTile * sizeof(unsigned long long);
+}
+
 struct DwArgs {                         // host-side description of one k_dw_adam launch
   const DwItem* items;                 // HOST array
   int n_items; int total_tiles; int B;
@@ -151,7 +167,10 @@ struct DwArgs {                         // host-side description of one k_dw_ada
   long long* trace;                    // debug stamps (tools/trace_slice.py) or null
   int use_row_scale;                   // 1: the slice kernels left unit-seed dz rows (lean fused path)
   int apply_only;                      // 1: no GEMM — the gradient is read from w_g / b_g (data-parallel apply after the all-reduce)
+  const DwXchg* xchg = nullptr;       // data-parallel: all-reduce every gradient tile over the peer windows inside this launch
 };
+
+
 
 // What the kernel receives: the layer table travels BY VALUE in the kernel arguments (read
 // with scalar loads through the kernarg segment pointer), so a workgroup's first global
@@ -169,6 +188,7 @@ struct DwKArgs {
   int use_row_scale;
   const float* one;                    // device word holding 1.0f (row scale of unscaled layers)
   int apply_only;
+  DwXchg xchg;                         // k_dw_adam<true> only
 };
 
 struct BatchSrc {

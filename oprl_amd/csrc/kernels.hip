@@ -12,6 +12,7 @@
 // Reference op groups replaced: SURVEY.md §2.2 K2-K13.
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include "kernels.h"
 #include "philox.h"
 #include "slice_head.h"
@@ -106,6 +107,11 @@ __device__ __forceinline__ void adam_bias_corr(const AdamScalars& ad, float* ste
   *bc2_sqrt = (float)sqrt(bc2);
 }
 
+// XCHG (data-parallel learner on peer windows, csrc/p2p.hip): between the GEMM and the epilogue every
+// workgroup all-reduces its gradient tile with the same tile of the other ranks — tagged granules into
+// the peers' windows, a bounded per-element wait for the peers' granules, sum in rank order.  A separate template instance: the single-rank kernel is untouched.  All workgroups of the
+// launch must be resident (they wait for their counterparts on the other GPUs): at most a few hundred.
+template <bool XCHG>
 __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
   constexpr int TN = kDwTileN, TK = kDwTile, LD = TK + 4;
   __shared__ __attribute__((aligned(16))) float part[kDwWaves][TN][LD];
@@ -248,6 +254,49 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
   float g = 0.f;
 #pragma unroll
   for (int w = 0; w < kDwWaves; ++w) g += part[w][nl][kl];
+  float gb_x = 0.f;
+  if constexpr (XCHG) {
+    const DwXchg& X = A.xchg;
+    float gbw = 0.f;
+    if (tid < TN) {
+#pragma unroll
+      for (int w = 0; w < kDwWaves; ++w) gbw += bpart[w][tid];
+    }
+    // 8-byte {sequence, value} granules written through at system scope: the value is its own flag, no
+    // fences (two system fences per workgroup cost 50 us per launch), the wait is per element
+    const unsigned tag = (unsigned)X.seq;
+    const size_t tile_off = (((size_t)X.parity * X.world + X.rank) * X.max_tiles + blockIdx.x) * kDwXchgTile;
+    for (int p = 0; p < X.world; ++p) {
+      if (p == X.rank) continue;
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(X.peer[p]) + tile_off;
+      __hip_atomic_store(dst + tid, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(g),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (tid < TN)
+        __hip_atomic_store(dst + 512 + tid, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(gbw),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    float gs = 0.f, gbs = 0.f;
+    bool all_ok = true;
+    for (int r = 0; r < X.world; ++r) {      // rank order on every rank: identical replicas
+      if (r == X.rank) { gs += g; gbs += gbw; continue; }
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(X.window) +
+                                      (((size_t)X.parity * X.world + r) * X.max_tiles + blockIdx.x) * kDwXchgTile;
+      unsigned long long x = 0, xb = 0;
+      bool ok = false;
+      for (int spin = 0; spin < (1 << 22) && !ok; ++spin) {
+        x = __hip_atomic_load(src + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        xb = tid < TN ? __hip_atomic_load(src + 512 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : x;
+        ok = (unsigned)(x >> 32) == tag && (unsigned)(xb >> 32) == tag;
+        if (!ok) __builtin_amdgcn_s_sleep(2);
+      }
+      all_ok = all_ok && ok;
+      gs += __uint_as_float((unsigned)x);
+      if (tid < TN) gbs += __uint_as_float((unsigned)xb);
+    }
+    if (!all_ok) { gs = __builtin_nanf(""); gbs = gs; }   // bounded wait: a lost rank poisons the tile instead of hanging
+    g = gs;
+    gb_x = gbs;
+  }
   if (A.apply_only) g = e_ok ? I.w_g[eo] : 0.f;   // the (all-reduced) gradient instead of this rank's GEMM
   g *= A.ad.grad_scale;
   float th_new = 0.f, tt_new = 0.f;
@@ -307,6 +356,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
       float gb = 0.f;
 #pragma unroll
       for (int w = 0; w < kDwWaves; ++w) gb += bpart[w][tid];
+      if constexpr (XCHG) gb = gb_x;
       if (A.apply_only) gb = I.b_g[n];
       float t0, t1;
       (void)adam_polyak_elem(gb, I.b + n, I.b_m ? I.b_m + n : nullptr, I.b_v ? I.b_v + n : nullptr,
@@ -544,7 +594,14 @@ hipError_t launch_dw_adam(const DwArgs& a0, hipStream_t st) {
   k.n_items = a.n_items; k.B = a.B; k.n_part = a.n_part; k.ad = a.ad; k.trace = a.trace;
   k.use_row_scale = a.use_row_scale; k.one = one_dev;
   k.apply_only = a.apply_only;
-  hipLaunchKernelGGL(k_dw_adam, dim3(total), dim3(kDwThreads), 0, st, k);
+  memset(&k.xchg, 0, sizeof k.xchg);
+  if (a.xchg != nullptr) {
+    if (a.apply_only || n_wide > 0 || total > a.xchg->max_tiles) return hipErrorInvalidValue;
+    k.xchg = *a.xchg;
+    hipLaunchKernelGGL(k_dw_adam<true>, dim3(total), dim3(kDwThreads), 0, st, k);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(k_dw_adam<false>, dim3(total), dim3(kDwThreads), 0, st, k);
   return hipGetLastError();
 }
 

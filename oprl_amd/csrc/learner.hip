@@ -339,7 +339,11 @@ struct oprl_learner {
   int pair_n = 0;
   MlpArgs pair_args[2];
   P2pState p2p;                // one-shot all-reduce windows (csrc/p2p.hip); used when p2p_ok
-  bool p2p_ok = false, p2p_tested = false;
+  bool p2p_ok = false, p2p_tested = false, p2p_inline = false;
+  int p2p_max_tiles = 0;
+  bool dp_inline = false;      // this data-parallel update exchanges inside the dW launches (k_dw_adam<true>)
+  DwXchg dw_xchg;
+  bool no_dp_inline = false;   // OPRL_AMD_NO_DP_INLINE: peer-window exchanges as separate launches (tests / A-B)
   bool no_twin_split = false;  // OPRL_AMD_NO_TWIN_SPLIT: role A runs both target critics back to back (tests / A-B)
   bool no_multi = false;
   bool no_layerwise = false;   // OPRL_AMD_NO_LAYERWISE: wide nets stay on the single-CU slice kernel (tests / A-B)
@@ -755,6 +759,19 @@ int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st) {
   // the lean phase 1 leaves unit-seed dz rows (tp4_scalar_fb): each critic's TD-error seed, dY of
   // its output layer, is applied per row (DwItem::rs)
   dw.use_row_scale = (critic && fused && fused_ddpg_is_lean(ddpg_args(h, B))) ? 1 : 0;
+  if (h->dp_inline) {
+    // data-parallel on peer windows: this launch all-reduces its tiles itself and runs Adam on the mean
+    P2pState& P = h->p2p;
+    P.tile_seq += 1;
+    DwXchg& X = h->dw_xchg;
+    for (int r = 0; r < kDwXchgMaxWorld; ++r) X.peer[r] = r < P.world ? P.peer[r] + P.tile_off : nullptr;
+    X.window = P.window + P.tile_off;
+    X.world = P.world; X.rank = P.rank; X.parity = (int)(P.tile_seq & 1); X.max_tiles = h->p2p_max_tiles;
+    X.seq = P.tile_seq;
+    dw.xchg = &X;
+    dw.ad.do_adam = 1;
+    dw.ad.grad_scale = 1.0f / (float)P.world;
+  }
   HIPC(launch_dw_prof(dw, st));
   return OPRL_OK;
 }
@@ -1084,7 +1101,11 @@ extern "C" int oprl_p2p_create(oprl_learner* h, int32_t rank, int32_t world, cha
   if (h->p2p.window != nullptr) { set_err("oprl_p2p_create: window already exists"); return OPRL_ERR_STATE; }
   RC(dp_arena_sizes(h));
   const size_t n = (size_t)std::max(h->n_critic_params, h->n_actor_params);
-  hipError_t e = p2p_create(h->p2p, rank, world, n, handle_out);
+  // second region: the per-tile exchange of k_dw_adam<true> (fused learners; a few MB)
+  h->p2p_max_tiles = std::max(h->tiles_critic, h->tiles_actor);
+  size_t tile_bytes = h->fused ? dw_xchg_bytes(world, h->p2p_max_tiles) : 0;
+  if (tile_bytes > ((size_t)256 << 20)) tile_bytes = 0;
+  hipError_t e = p2p_create(h->p2p, rank, world, n, tile_bytes, handle_out);
   if (e != hipSuccess) {
     set_err("oprl_p2p_create: %s", hipGetErrorString(e));
     (void)hipGetLastError();
@@ -1130,7 +1151,9 @@ extern "C" int oprl_p2p_selftest(oprl_learner* h, void* stream) {
 extern "C" int oprl_p2p_enable(oprl_learner* h, int32_t on) {
   if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
   if (on && !h->p2p_tested) { set_err("oprl_p2p_enable: the self-test has not passed on this rank"); return OPRL_ERR_STATE; }
+  if (on < 0 || on > 2) { set_err("oprl_p2p_enable: level must be 0, 1 or 2"); return OPRL_ERR_INVALID; }
   h->p2p_ok = on != 0;
+  h->p2p_inline = on == 2;     // 2: fused learners also exchange inside their dW launches (k_dw_adam<true>)
   return OPRL_OK;
 }
 
@@ -1155,6 +1178,22 @@ extern "C" int oprl_learner_dp_update(oprl_learner* h, const float* s, const flo
   hipStream_t st = (hipStream_t)stream;
   const oprl_learner_config& c = h->cfg;
   const double scale = 1.0 / (double)dp_world(h);
+  // Fused learners on peer windows: the two dW launches exchange their own tiles (k_dw_adam<true>) and
+  // run Adam on the mean — no separate all-reduce or apply launches.
+  if (h->p2p_ok && h->p2p_inline && !h->no_dp_inline && h->p2p.tile_bytes > 0 && use_fused(h, B)) {
+    h->dp_inline = true;
+    int rc = oprl_learner_update_phase(h, 0, s, a, r, d, s2, B, noise0, noise1, stream);
+    if (rc == OPRL_OK) rc = oprl_learner_update_phase(h, 1, s, a, r, d, s2, B, noise0, noise1, stream);
+    h->dp_inline = false;
+    RC(rc);
+    if (h->actor_updated_last && alpha_ptr(h) != nullptr) {   // the temperature: one double, exchanged on its own
+      RC(dp_all_reduce(h, h->alpha_grad, 1, true, st));
+      HIPC(launch_alpha_step(c.log_alpha, c.log_alpha_m, c.log_alpha_v, nullptr, 1, (float)c.hp.target_entropy,
+                             c.hp.lr_alpha, c.hp.beta1, c.hp.beta2, c.hp.adam_eps, h->opt_step_alpha,
+                             nullptr, h->alpha_grad, (float)scale, st));
+    }
+    return OPRL_OK;
+  }
   RC(oprl_learner_update_phase(h, 0, s, a, r, d, s2, B, noise0, noise1, stream));
   RC(dp_all_reduce(h, c.critics[0].grad, (size_t)h->n_critic_params, false, st));
   RC(oprl_learner_apply(h, 0, scale, stream));
@@ -1372,6 +1411,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->no_multi = (nm != nullptr && atoi(nm) != 0);
     const char* nlw = getenv("OPRL_AMD_NO_LAYERWISE");
     h->no_layerwise = (nlw != nullptr && atoi(nlw) != 0);
+    const char* ndi = getenv("OPRL_AMD_NO_DP_INLINE");
+    h->no_dp_inline = (ndi != nullptr && atoi(ndi) != 0);
     const char* nts = getenv("OPRL_AMD_NO_TWIN_SPLIT");
     h->no_twin_split = (nts != nullptr && atoi(nts) != 0);
     const char* np2 = getenv("OPRL_AMD_NO_P2_PAIR");

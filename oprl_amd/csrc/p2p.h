@@ -18,9 +18,11 @@ struct P2pState {
   char* peer[kP2pMaxWorld] = {nullptr};      // every rank's window as mapped here (peer[rank] == window)
   unsigned* done = nullptr;                  // device counter of finished push workgroups
   unsigned long long seq = 0;                // exchanges so far
+  size_t tile_off = 0, tile_bytes = 0;       // second region of the window: k_dw_adam<true>'s per-tile exchange
+  unsigned long long tile_seq = 0;
 };
 
-hipError_t p2p_create(P2pState& s, int rank, int world, size_t max_floats, void* handle_out);
+hipError_t p2p_create(P2pState& s, int rank, int world, size_t max_floats, size_t tile_region_bytes, void* handle_out);
 hipError_t p2p_connect(P2pState& s, const void* handles);
 void p2p_destroy(P2pState& s);
 hipError_t p2p_all_reduce(P2pState& s, void* buf, size_t n, bool as_double, hipStream_t st);

@@ -221,11 +221,13 @@ __global__ __launch_bounds__(kP2pThreads) void k_p2p_all_reduce(const P2pFusedAr
 }
 
 // ---- host -------------------------------------------------------------------------------------------
-hipError_t p2p_create(P2pState& s, int rank, int world, size_t max_floats, void* handle_out) {
+hipError_t p2p_create(P2pState& s, int rank, int world, size_t max_floats, size_t tile_region_bytes, void* handle_out) {
   if (world < 1 || world > kP2pMaxWorld || rank < 0 || rank >= world) return hipErrorInvalidValue;
   s.world = world; s.rank = rank;
   s.slot_floats = (max_floats + 1023) / 1024 * 1024;
-  s.window_bytes = p2p_window_bytes(world, s.slot_floats);
+  s.tile_off = (p2p_window_bytes(world, s.slot_floats) + 255) / 256 * 256;
+  s.tile_bytes = tile_region_bytes;
+  s.window_bytes = s.tile_off + tile_region_bytes;
   hipError_t e = hipExtMallocWithFlags((void**)&s.window, s.window_bytes, hipDeviceMallocFinegrained);
   if (e != hipSuccess) return e;
   e = hipMemset(s.window, 0, s.window_bytes);

@@ -57,8 +57,9 @@ class DataParallelLearner:
                         "oprl_comm_init")
         self._native = True
 
-    def init_p2p(self) -> bool:
-        """Set up the one-shot all-reduce over peer windows (csrc/p2p.hip): every rank allocates its
+    def init_p2p(self, level: int = 2) -> bool:
+        """``level``: see set_p2p_level (2 = also inside the dW launches of fused learners).
+        Set up the one-shot all-reduce over peer windows (csrc/p2p.hip): every rank allocates its
         window, the IPC handles travel over torch.distributed, every rank maps the others' windows, then
         all ranks run the self-test together and keep the path only if EVERY rank's sum was exact
         (otherwise the RCCL communicator of init_native_comm() keeps doing the exchanges).  Returns
@@ -98,10 +99,28 @@ class DataParallelLearner:
         dist.all_gather_object(verdicts, bool(ok), group=self.group)
         good = all(verdicts)
         if good:
-            _capi.check(lib.oprl_p2p_enable(e.handle, 1), "oprl_p2p_enable")
+            _capi.check(lib.oprl_p2p_enable(e.handle, int(level)), "oprl_p2p_enable")
             self._native = True
         self.p2p = good
+        self.p2p_level = int(level) if good else 0
         return good
+
+    def set_p2p_level(self, level: int) -> None:
+        """0: RCCL; 1: one window kernel per exchange; 2: fused learners exchange inside their dW launches
+        (all ranks must switch together)."""
+        from oprl_amd import _capi
+        _capi.check(_capi.load().oprl_p2p_enable(self.engine.handle, int(level)), "oprl_p2p_enable")
+        self.p2p_level = int(level)
+
+    def healthy(self) -> bool:
+        """Collective: parameters finite on this rank and replica checksums identical across ranks."""
+        e = self.engine
+        finite = bool(t.isfinite(e.actor_arena).all() and t.isfinite(e.critic_arena).all())
+        flags = [None] * self.world
+        dist.all_gather_object(flags, finite, group=self.group)
+        if not all(flags):
+            return False
+        return float(self.replica_checksum().abs().max()) == 0.0
 
     def step_n(self, replay_handle, K: int, B: int, seed: int = 0) -> None:
         """K synchronous data-parallel sample()+update() iterations in one C call."""

@@ -12,8 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main() -> None:
-    rank, world, rdv, out, algo_name, K, B = (int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4],
-                                               sys.argv[5], int(sys.argv[6]), int(sys.argv[7]))
+    rank, world, rdv, out, algo_name, K, B, level = (int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4],
+                                                      sys.argv[5], int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8]))
     dist.init_process_group("gloo", init_method=f"file://{rdv}", rank=rank, world_size=world)
     from oprl_amd.logging import NullLogger
     from oprl_amd.parallel import DataParallelLearner
@@ -21,7 +21,7 @@ def main() -> None:
     algo = make_algo(algo_name, B, export_grads=True)
     buf = make_shard(rank)
     dp = DataParallelLearner(algo, dist.group.WORLD)
-    ok = dp.init_p2p()
+    ok = dp.init_p2p(level)
     if ok:
         dp.step_n(buf.handle, K, B, seed=5)
         t.cuda.synchronize()

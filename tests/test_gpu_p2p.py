@@ -36,22 +36,27 @@ def make_shard(rank):
     return buf
 
 
-@pytest.mark.parametrize("algo_name", ["ddpg", "sac"])
-def test_two_process_p2p_data_parallel_step(algo_name):
-    K, B, world = 6, 64, 2
+# level 1: one window kernel per exchange; level 2: the exchange inside the dW + Adam launches.  Two ranks
+# share this GPU, so a rank's waiting dW workgroups (level 2) and the other rank's one-workgroup-per-CU
+# phase kernels compete for the same CUs: DDPG at a small batch leaves room for both, SAC's twice as many
+# dW tiles do not — SAC is exercised at level 1 (which also covers the 64-bit temperature exchange).
+@pytest.mark.parametrize("algo_name,level", [("ddpg", 2), ("ddpg", 1), ("sac", 1)])
+def test_two_process_p2p_data_parallel_step(algo_name, level):
+    K, B, world = 6, 32, 2
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as td:
         rdv, out = os.path.join(td, "rdv"), os.path.join(td, "out")
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "p2p_worker.py"), str(r), str(world),
-                                   rdv, out, algo_name, str(K), str(B)], env=env, cwd=root)
+                                   rdv, out, algo_name, str(K), str(B), str(level)], env=env, cwd=root)
                  for r in range(world)]
         for p in procs:
             assert p.wait(timeout=300) == 0
         res = [t.load(f"{out}.{r}", weights_only=False) for r in range(world)]
     assert all(r["ok"] for r in res), f"the peer windows are not in use: {[r['why'] for r in res]}"
-    for m in ("actor", "critic"):
-        assert t.equal(res[0]["arenas"][m], res[1]["arenas"][m]), f"replicas diverged: {m}"
+    for m in ("critic", "actor"):
+        d = (res[0]["arenas"][m] - res[1]["arenas"][m]).abs().max().item()
+        assert t.equal(res[0]["arenas"][m], res[1]["arenas"][m]), f"replicas diverged: {m} (max |d| = {d:.3e})"
         assert t.isfinite(res[0]["arenas"][m]).all()
     # single-process emulation: two export_grads learners, gradients summed in rank order
     L = [make_algo(algo_name, B, export_grads=True) for _ in range(world)]
@@ -76,5 +81,9 @@ def test_two_process_p2p_data_parallel_step(algo_name):
             for r in range(world):
                 L[r].learner.apply(phase, 1.0 / world)
     t.cuda.synchronize()
-    for m in ("actor", "critic"):
-        assert t.equal(getattr(L[0], m)._oprl_arena.cpu(), res[0]["arenas"][m]), m
+    for m in ("critic", "actor"):
+        d = (getattr(L[0], m)._oprl_arena.cpu() - res[0]["arenas"][m]).abs().max().item()
+        if level == 1:     # same kernels as the emulation: bit for bit
+            assert t.equal(getattr(L[0], m)._oprl_arena.cpu(), res[0]["arenas"][m]), f"{m}: max |d| vs emulation = {d:.3e}"
+        else:              # k_dw_adam<true> is another instance of the kernel (its own FMA contraction): 1-ulp level
+            assert d <= 1e-6, f"{m}: max |d| vs emulation = {d:.3e}"
