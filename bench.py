@@ -272,6 +272,9 @@ def main():
                 if not ok and rank == 0:
                     print(f"bench.py: peer-window level {level} not available ({dp.p2p_error})", file=sys.stderr)
             if ok:
+                dp.step_n(replay.handle, 2, B, seed=0)          # (a broken exchange shows at once: bounded waits, NaN)
+                ok = dp.healthy()
+            if ok:
                 dp.step_n(replay.handle, max(W, 50), B, seed=0)
                 ok = dp.healthy()
                 if not ok and rank == 0:

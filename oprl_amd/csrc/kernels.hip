@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
                                       (((size_t)X.parity * X.world + r) * X.max_tiles + blockIdx.x) * kDwXchgTile;
       unsigned long long x = 0, xb = 0;
       bool ok = false;
-      for (int spin = 0; spin < (1 << 22) && !ok; ++spin) {
+      for (int spin = 0; spin < (1 << 20) && !ok; ++spin) {
         x = __hip_atomic_load(src + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         xb = tid < TN ? __hip_atomic_load(src + 512 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : x;
         ok = (unsigned)(x >> 32) == tag && (unsigned)(xb >> 32) == tag;
