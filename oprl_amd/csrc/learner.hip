@@ -1142,6 +1142,9 @@ extern "C" int oprl_p2p_selftest(oprl_learner* h, void* stream) {
     for (size_t i = 0; i < n && all_ok; ++i) all_ok = host[i] == (float)(tri * (1 + (int)((i + round) % 7)));
   }
   HIPC(hipMemsetAsync(g, 0, n * sizeof(float), st));
+  if (const char* f = getenv("OPRL_AMD_P2P_SELFTEST_FAIL")) {   // tests: exercise the fall-back to RCCL
+    if (atoi(f) != 0) all_ok = false;
+  }
   h->p2p_tested = all_ok;
   if (!all_ok) { set_err("oprl_p2p_selftest: the exchanged sum is wrong; staying on RCCL"); return OPRL_ERR_STATE; }
   return OPRL_OK;

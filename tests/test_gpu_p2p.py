@@ -87,3 +87,21 @@ def test_two_process_p2p_data_parallel_step(algo_name, level):
             assert t.equal(getattr(L[0], m)._oprl_arena.cpu(), res[0]["arenas"][m]), f"{m}: max |d| vs emulation = {d:.3e}"
         else:              # k_dw_adam<true> is another instance of the kernel (its own FMA contraction): 1-ulp level
             assert d <= 1e-6, f"{m}: max |d| vs emulation = {d:.3e}"
+
+
+@pytest.mark.parametrize("fail,expect", [("0", "p2p-inline"), ("1", "rccl")])
+def test_bench_picks_the_exchange_and_falls_back(fail, expect):
+    """bench.py --force-dp (one rank): the fastest exchange whose self-test and replica health check pass;
+    with the self-test forced to fail it must rebuild the replicas on RCCL and still report healthy ones."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OPRL_AMD_P2P_SELFTEST_FAIL=fail, MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dp", "--no-cpu-baseline",
+                          "--learners", "0", "--steps", "300", "--warmup", "30"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [x for x in out.stdout.splitlines() if x.startswith("{")][-1]
+    d = json.loads(line)
+    chk = d["data_parallel_check"]
+    assert chk["exchange"] == expect and chk["finite"] and chk["replicas_identical"], chk
+    assert d["n_gpus"] == 1 and d["value"] > 1000
