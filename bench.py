@@ -251,39 +251,59 @@ def main():
         run(W)
     else:
         from oprl_amd.parallel import DataParallelLearner
-        # The two gradient exchanges per update, fastest first: (2) inside the dW + Adam launches over
-        # peer windows (csrc/p2p.hip, k_dw_adam<true>), (1) one window kernel per exchange, (0) RCCL.
-        # A level is kept only if every rank's window self-test passed AND, after the warm-up updates,
-        # every replica is finite and identical — otherwise fresh replicas are built one level down.
-        for level in ((0,) if args.no_p2p else (2, 1, 0)):
-            algo = make_learner()
-            learner = algo.learner
-            dp = DataParallelLearner(algo, dist.group.WORLD)
-            dp.broadcast_parameters()
-            dp.init_native_comm()
-            ok = True
+        # The two gradient exchanges per update can run (2) inside the dW + Adam launches over peer
+        # windows (csrc/p2p.hip, k_dw_adam<true>), (1) as one window kernel per exchange, or (0) on RCCL.
+        # A level is usable only if every rank's window self-test passed AND, after some updates, every
+        # replica is finite and identical.  Which usable level is fastest depends on the node (xGMI
+        # store granularity against RCCL's ring latency), so each one is PROBED on fresh replicas and the
+        # fastest is rebuilt for the measurement.
+        def build(level):
+            algo_ = make_learner()
+            dp_ = DataParallelLearner(algo_, dist.group.WORLD)
+            dp_.broadcast_parameters()
+            dp_.init_native_comm()
+            ok_ = True
             if level > 0:
                 try:
-                    ok = dp.init_p2p(level)
+                    ok_ = dp_.init_p2p(level)
                 except Exception as exc:  # noqa: BLE001
-                    ok = False
+                    ok_ = False
                     if rank == 0:
                         print(f"bench.py: peer windows unavailable ({exc})", file=sys.stderr)
-                if not ok and rank == 0:
-                    print(f"bench.py: peer-window level {level} not available ({dp.p2p_error})", file=sys.stderr)
+                if not ok_ and rank == 0:
+                    print(f"bench.py: peer-window level {level} not available ({dp_.p2p_error})", file=sys.stderr)
+            if ok_:
+                dp_.step_n(replay.handle, 2, B, seed=0)          # (a broken exchange shows at once: bounded waits, NaN)
+                ok_ = dp_.healthy()
+            return algo_, dp_, ok_
+
+        probes = {}
+        for level in ((0,) if args.no_p2p else (2, 1, 0)):
+            algo, dp, ok = build(level)
             if ok:
-                dp.step_n(replay.handle, 2, B, seed=0)          # (a broken exchange shows at once: bounded waits, NaN)
+                dp.step_n(replay.handle, 300, B, seed=0)
+                best = 1e30
+                for _rep in range(2):                     # best of two 1000-update probes
+                    barrier()
+                    tp0 = time.perf_counter()
+                    dp.step_n(replay.handle, 1000, B, seed=0)
+                    barrier()
+                    tp = t.tensor([time.perf_counter() - tp0], dtype=t.float64, device=dev)
+                    dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+                    best = min(best, float(tp.item()))
                 ok = dp.healthy()
-            if ok:
-                dp.step_n(replay.handle, max(W, 50), B, seed=0)
-                ok = dp.healthy()
-                if not ok and rank == 0:
-                    print(f"bench.py: replicas unhealthy after warm-up at exchange level {level}; stepping down",
-                          file=sys.stderr)
-            if ok:
-                p2p_level = level
-                break
-            del dp, learner, algo
+                if ok:
+                    probes[level] = best / 1000 * 1e6
+            if not ok and rank == 0:
+                print(f"bench.py: exchange level {level} unusable on this node", file=sys.stderr)
+            del dp, algo
+        if not probes:
+            raise SystemExit("bench.py: no usable gradient exchange")
+        p2p_level = min(probes, key=probes.get)
+        algo, dp, ok = build(p2p_level)
+        assert ok, "the probed exchange level failed on rebuild"
+        learner = algo.learner
+        dp.step_n(replay.handle, W, B, seed=0)
         use_p2p = p2p_level > 0
 
         def run(n):
@@ -305,7 +325,8 @@ def main():
         spread = dp.replica_checksum()                       # collective: [max - min] over ranks of two checksums
         finite = bool(t.isfinite(algo.actor._oprl_arena).all() and t.isfinite(algo.critic._oprl_arena).all())
         dp_check = {"replicas_identical": bool(float(spread.abs().max()) == 0.0), "finite": finite,
-                    "exchange": {2: "p2p-inline", 1: "p2p", 0: "rccl"}[p2p_level]}
+                    "exchange": {2: "p2p-inline", 1: "p2p", 0: "rccl"}[p2p_level],
+                    "probe_us_per_step": {({2: "p2p-inline", 1: "p2p", 0: "rccl"}[k]): round(v, 2) for k, v in probes.items()}}
 
     out = None
     if rank == 0:
