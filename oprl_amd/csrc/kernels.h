@@ -146,7 +146,8 @@ __device__ __forceinline__ int adam_polyak_elem(float g, float* th, float* m, fl
 // Data-parallel learner, peer windows (csrc/p2p.hip): k_dw_adam<true> exchanges each 16x32 gradient tile
 // (+ 16 bias sums) with the same tile of the other ranks between its GEMM and its Adam epilogue — the
 // separate all-reduce and apply launches of the RCCL path disappear.  Tile region of a window:
-// [parity][source rank][tile][kDwXchgTile] 8-byte {sequence, value} granules.
+// [parity][source rank, or `world` = the owner's summed tile][tile][kDwXchgTile] 8-byte {sequence, value}
+// granules.
 constexpr int kDwXchgTile = 512 + 16;
 constexpr int kDwXchgMaxWorld = 8;
 struct DwXchg {
@@ -156,7 +157,7 @@ struct DwXchg {
   unsigned long long seq;
 };
 __host__ __device__ inline size_t dw_xchg_bytes(int world, int max_tiles) {
-  return (size_t)2 * world * max_tiles * kDwXchgTile * sizeof(unsigned long long);
+  return (size_t)2 * (world + 1) * max_tiles * kDwXchgTile * sizeof(unsigned long long);
 }
 
 struct DwArgs {                         // host-side description of one k_dw_adam launch

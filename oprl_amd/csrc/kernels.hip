@@ -263,24 +263,24 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
       for (int w = 0; w < kDwWaves; ++w) gbw += bpart[w][tid];
     }
     // 8-byte {sequence, value} granules written through at system scope: the value is its own flag, no
-    // fences (two system fences per workgroup cost 50 us per launch), the wait is per element
+    // fences (two system fences per workgroup cost 50 us per launch), the wait is per element.
+    // Two hops per tile instead of an all-to-all: the tile's OWNER (tile % world) collects the other
+    // ranks' partial tiles, sums them in rank order and sends the sum back — 2 x (world - 1) / world of
+    // the arena leaves every GPU instead of (world - 1) x, and all replicas apply the very same sum.
     const unsigned tag = (unsigned)X.seq;
-    const size_t tile_off = (((size_t)X.parity * X.world + X.rank) * X.max_tiles + blockIdx.x) * kDwXchgTile;
-    for (int p = 0; p < X.world; ++p) {
-      if (p == X.rank) continue;
-      unsigned long long* dst = reinterpret_cast<unsigned long long*>(X.peer[p]) + tile_off;
-      __hip_atomic_store(dst + tid, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(g),
+    const int owner = (int)(blockIdx.x % (unsigned)X.world);
+    auto slot = [&](char* base, int src_slot) {
+      return reinterpret_cast<unsigned long long*>(base) +
+             (((size_t)X.parity * (X.world + 1) + src_slot) * X.max_tiles + blockIdx.x) * kDwXchgTile;
+    };
+    auto put = [&](unsigned long long* dst, float v, float vb) {
+      __hip_atomic_store(dst + tid, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if (tid < TN)
-        __hip_atomic_store(dst + 512 + tid, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(gbw),
+        __hip_atomic_store(dst + 512 + tid, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(vb),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    float gs = 0.f, gbs = 0.f;
-    bool all_ok = true;
-    for (int r = 0; r < X.world; ++r) {      // rank order on every rank: identical replicas
-      if (r == X.rank) { gs += g; gbs += gbw; continue; }
-      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(X.window) +
-                                      (((size_t)X.parity * X.world + r) * X.max_tiles + blockIdx.x) * kDwXchgTile;
+    };
+    auto get = [&](const unsigned long long* src, float* v, float* vb) {
       unsigned long long x = 0, xb = 0;
       bool ok = false;
       for (int spin = 0; spin < (1 << 20) && !ok; ++spin) {
@@ -289,9 +289,25 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
         ok = (unsigned)(x >> 32) == tag && (unsigned)(xb >> 32) == tag;
         if (!ok) __builtin_amdgcn_s_sleep(2);
       }
-      all_ok = all_ok && ok;
-      gs += __uint_as_float((unsigned)x);
-      if (tid < TN) gbs += __uint_as_float((unsigned)xb);
+      *v = __uint_as_float((unsigned)x);
+      *vb = __uint_as_float((unsigned)xb);
+      return ok;
+    };
+    float gs = 0.f, gbs = 0.f;
+    bool all_ok = true;
+    if (X.rank == owner) {
+      for (int r = 0; r < X.world; ++r) {    // rank order
+        float v = g, vb = gbw;
+        if (r != X.rank) all_ok = get(slot(X.window, r), &v, &vb) && all_ok;
+        gs += v;
+        if (tid < TN) gbs += vb;
+      }
+      if (!all_ok) { gs = __builtin_nanf(""); gbs = gs; }   // (the poison travels to every replica)
+      for (int p = 0; p < X.world; ++p)
+        if (p != X.rank) put(slot(X.peer[p], X.world), gs, gbs);
+    } else {
+      put(slot(X.peer[owner], X.rank), g, gbw);
+      all_ok = get(slot(X.window, X.world), &gs, &gbs);
     }
     if (!all_ok) { gs = __builtin_nanf(""); gbs = gs; }   // bounded wait: a lost rank poisons the tile instead of hanging
     g = gs;
