@@ -361,7 +361,7 @@ def main():
             ach = flop_per_launch / (kern[dom]["us_per_launch"] * 1e-6) / 1e12
             traffic = None
             try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-                pmc = json.load(open(ROOT / "profiles" / "r01f_pmc_traffic.json"))
+                pmc = json.load(open(ROOT / "profiles" / "r01h_pmc_traffic.json"))
                 traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:  # noqa: BLE001
                 pass
@@ -374,10 +374,10 @@ def main():
                              f"(serialised pass of {P} steps) minus event_overhead_us, the per-launch "
                              "excess of that pass over the un-instrumented timed loop (where the same "
                              "launches run back to back, so a step is the sum of their durations); they "
-                             "agree with rocprofv3 --kernel-trace --stats (profiles/r01f_kernel_stats.csv: "
-                             "14.0 / 12.3 / 7.6 us); sum of kernel time per step = "
+                             "agree with rocprofv3 --kernel-trace --stats (profiles/r01h_kernel_stats.csv: "
+                             "14.2 / 12.3 / 7.5 us); sum of kernel time per step = "
                              f"{sum(k['us_per_step'] for k in kern.values()):.1f} us; traffic = "
-                             "(2*FETCH_SIZE + WRITE_SIZE) KB from profiles/r01f_pmc_traffic.json; the "
+                             "(2*FETCH_SIZE + WRITE_SIZE) KB from profiles/r01h_pmc_traffic.json; the "
                              "launch is 192 workgroups (3 roles x 16 slices x 4-CU clusters), one per CU, "
                              "and the step is a chain of 4 dependent launches bound by latency, not by "
                              "the matrix cores (DESIGN.md section 6)")
