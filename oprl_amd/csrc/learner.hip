@@ -1165,7 +1165,11 @@ int dp_world(const oprl_learner* h) { return h->p2p_ok ? h->p2p.world : h->rccl.
 int dp_rank(const oprl_learner* h) { return h->p2p_ok ? h->p2p.rank : h->rccl.rank; }
 // in-place sum over ranks of a float (or one-double) buffer: peer windows when they passed the self-test, else RCCL
 int dp_all_reduce(oprl_learner* h, void* buf, size_t n, bool as_double, hipStream_t st) {
-  if (h->p2p_ok) {
+  // The one-shot exchange sends the whole arena to every peer: right for the latency-bound ~300 KB
+  // arenas of the 256-wide nets, wrong for TQC's 11 MB critic arena, where a ring moves 2 x 7/8 of the
+  // bytes instead of 7 x — those stay on RCCL when a communicator exists.
+  const bool small = n * (as_double ? 8 : 4) <= ((size_t)1 << 20);
+  if (h->p2p_ok && (small || !h->rccl.comm)) {
     HIPC(p2p_all_reduce(h->p2p, buf, n, as_double, st));
     return OPRL_OK;
   }
