@@ -220,6 +220,51 @@ __global__ __launch_bounds__(kP2pThreads) void k_p2p_all_reduce(const P2pFusedAr
   }
 }
 
+// A handful of doubles (SAC's temperature gradient): two tagged 8-byte granules per value straight into
+// the peers' slots, no fences, one workgroup.
+struct P2pF64Args {
+  char* peer[kP2pMaxWorld];
+  const char* window;
+  int world, rank, parity, n;
+  size_t slot_floats;
+  double* buf;
+  unsigned long long seq;
+};
+
+__global__ __launch_bounds__(kP2pThreads) void k_p2p_all_reduce_f64(const P2pF64Args a) {
+  const int i = threadIdx.x;
+  if (i >= a.n) return;
+  const unsigned tag = (unsigned)a.seq;
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(a.buf[i]);
+  // the granules live in the spare words of the (parity, source) flag line: never shared with arena data
+  const size_t foff = p2p_flags_off(a.world, a.slot_floats);
+  for (int p = 0; p < a.world; ++p) {
+    if (p == a.rank) continue;
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.peer[p] + foff) +
+                              ((size_t)a.parity * a.world + a.rank) * kFlagStride + 2 + 2 * i;
+    __hip_atomic_store(dst, ((unsigned long long)tag << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dst + 1, ((unsigned long long)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  double s = 0.0;
+  bool all_ok = true;
+  for (int r = 0; r < a.world; ++r) {        // rank order
+    if (r == a.rank) { s += a.buf[i]; continue; }
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.window + foff) +
+                                    ((size_t)a.parity * a.world + r) * kFlagStride + 2 + 2 * i;
+    unsigned long long lo = 0, hi = 0;
+    bool ok = false;
+    for (int spin = 0; spin < (1 << 22) && !ok; ++spin) {
+      lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      ok = (unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag;
+      if (!ok) __builtin_amdgcn_s_sleep(2);
+    }
+    all_ok = all_ok && ok;
+    s += __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
+  }
+  a.buf[i] = all_ok ? s : __builtin_nan("");
+}
+
 // ---- host -------------------------------------------------------------------------------------------
 hipError_t p2p_create(P2pState& s, int rank, int world, size_t max_floats, size_t tile_region_bytes, void* handle_out) {
   if (world < 1 || world > kP2pMaxWorld || rank < 0 || rank >= world) return hipErrorInvalidValue;
@@ -279,6 +324,14 @@ hipError_t p2p_all_reduce(P2pState& s, void* buf, size_t n, bool as_double, hipS
     const size_t want = ((n >> 2) + kP2pThreads - 1) / kP2pThreads;
     const int blocks = (int)(want < 1 ? 1 : (want < (size_t)kP2pBlocks ? want : (size_t)kP2pBlocks));
     hipLaunchKernelGGL(k_p2p_all_reduce, dim3(blocks), dim3(kP2pThreads), 0, st, fa);
+    return hipGetLastError();
+  }
+  if (as_double && 2 + 2 * n <= kFlagStride) {
+    P2pF64Args da;
+    for (int r = 0; r < kP2pMaxWorld; ++r) da.peer[r] = r < s.world ? s.peer[r] : nullptr;
+    da.window = s.window; da.world = s.world; da.rank = s.rank; da.parity = (int)(s.seq & 1); da.n = (int)n;
+    da.slot_floats = s.slot_floats; da.buf = (double*)buf; da.seq = s.seq;
+    hipLaunchKernelGGL(k_p2p_all_reduce_f64, dim3(1), dim3(kP2pThreads), 0, st, da);
     return hipGetLastError();
   }
   P2pPushArgs pa;
