@@ -94,9 +94,9 @@ class OracleDDPG:
         self._g = (self.o.last["g_critic"], self.o.last["g_actor"])
 
 
-def ddpg_scenario(make):
+def ddpg_scenario(make, B=256):
     S, A = fx.ENVS["walker"]
-    B, seed = 256, 100
+    seed = 100
     actor = fx.make_net(seed + 1, fx.actor_dims(S, A))
     critic = fx.make_net(seed + 2, fx.critic_dims(S, A))
     algo = make(S, A, actor, critic)
@@ -139,9 +139,9 @@ class OracleTD3:
     def params(self, which): return getattr(self.o, which)
 
 
-def td3_scenario(make):
+def td3_scenario(make, B=256):
     S, A = fx.ENVS["cheetah"]
-    B, seed = 256, 200
+    seed = 200
     actor = fx.make_net(seed + 1, fx.actor_dims(S, A))
     c1 = fx.make_net(seed + 2, fx.critic_dims(S, A))
     c2 = fx.make_net(seed + 3, fx.critic_dims(S, A))

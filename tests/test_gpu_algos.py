@@ -49,6 +49,21 @@ def test_tqc_walker_b256():
     _both(got, "tqc_walker_b256", sc.tqc_scenario(sc.OracleTQC), skip=("qh.",))
 
 
+@pytest.mark.parametrize("B", [100, 8, 1])
+def test_all_algos_against_the_oracle_at_ragged_batches(B):
+    """Batches that are not a multiple of the 16-row slice (and a single row): every algorithm through its
+    default (fused / layer-wise) path against the oracle computed on the spot — the oracle itself is pinned
+    by the golden vectors at the reference's batch sizes (tests/test_oracle_golden.py)."""
+    cases = [("ddpg", sc.ddpg_scenario(ha.HipDDPG, B=B), sc.ddpg_scenario(sc.OracleDDPG, B=B), ()),
+             ("td3", sc.td3_scenario(ha.HipTD3, B=B), sc.td3_scenario(sc.OracleTD3, B=B), ()),
+             ("sac", sc.sac_scenario(ha.HipSAC, "walker", B, 350, True, 3),
+              sc.sac_scenario(sc.OracleSAC, "walker", B, 350, True, 3), ()),
+             ("tqc", sc.tqc_scenario(ha.HipTQC, B=B), sc.tqc_scenario(sc.OracleTQC, B=B), ("qh.",))]
+    for name, got, want, skip in cases:
+        worst = sc.compare(got, {k: v for k, v in want.items()}, TOL, skip=skip, param_tol=sc.PARAM_TOL)
+        print(f"{name} B={B}: worst vs oracle {worst}")
+
+
 def test_reference_style_smoke_all_algos():
     """What the reference's own test does (tests/functional/test_rl_algos.py:17-31):
     batch of 8, int64 dones, next_state aliasing state, no injected noise."""
