@@ -21,6 +21,10 @@ def make_algo(name, B, **kw):
     if name == "sac":
         return SAC(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=B, tune_alpha=True,
                    log_every=10 ** 9, **kw).create()
+    if name == "td3":
+        from oprl_amd.algos.td3 import TD3
+        return TD3(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=B, log_every=10 ** 9,
+                   **kw).create()
     return DDPG(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=B, **kw).create()
 
 
@@ -40,7 +44,7 @@ def make_shard(rank):
 # share this GPU, so a rank's waiting dW workgroups (level 2) and the other rank's one-workgroup-per-CU
 # phase kernels compete for the same CUs: DDPG at a small batch leaves room for both, SAC's twice as many
 # dW tiles do not — SAC is exercised at level 1 (which also covers the 64-bit temperature exchange).
-@pytest.mark.parametrize("algo_name,level", [("ddpg", 2), ("ddpg", 1), ("sac", 1)])
+@pytest.mark.parametrize("algo_name,level", [("ddpg", 2), ("ddpg", 1), ("sac", 1), ("td3", 1)])
 def test_two_process_p2p_data_parallel_step(algo_name, level):
     K, B, world = 6, 32, 2
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
