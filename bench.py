@@ -332,10 +332,24 @@ def main():
     if rank == 0:
         # ---- instrumented pass: per-kernel durations from HIP events on the stream
         roof = None
-        if not use_dp:
+        if True:
             P = max(1, min(args.profile_steps, K))
+            prof_learner, us_per_step_plain = learner, 1e6 * dt / K
+            if use_dp:
+                # the kernels of a data-parallel rank are those of the single-GPU learner (plus the exchange
+                # inside / after the dW launches): the roofline pass runs on a plain replica on rank 0
+                t.manual_seed(0)
+                plain = DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device=f"cuda:{local_rank}",
+                             max_batch=B).create()
+                prof_learner = plain.learner
+                prof_learner.step_n(replay.handle, 300, B, seed=1)
+                t.cuda.synchronize(dev)
+                tq0 = time.perf_counter()
+                prof_learner.step_n(replay.handle, P, B, seed=1)
+                t.cuda.synchronize(dev)
+                us_per_step_plain = 1e6 * (time.perf_counter() - tq0) / P
             lib.oprl_profile_enable(1)
-            learner.step_n(replay.handle, P, B, seed=1)
+            prof_learner.step_n(replay.handle, P, B, seed=1)
             NK = 6
             cnt = (C.c_int64 * NK)()
             ms = (C.c_double * NK)()
@@ -348,7 +362,7 @@ def main():
             # overhead (~2.4 us), and is subtracted.
             raw_us_per_step = sum(ms[i] for i in range(NK)) * 1e3 / P
             launches_per_step = sum(cnt[i] for i in range(NK)) / P
-            ev_us = max(raw_us_per_step - 1e6 * dt / K, 0.0) / max(launches_per_step, 1.0)
+            ev_us = max(raw_us_per_step - us_per_step_plain, 0.0) / max(launches_per_step, 1.0)
             kern = {names[i]: dict(launches_per_step=cnt[i] / P,
                                    us_per_launch=max(ms[i] * 1e3 / cnt[i] - ev_us, 0.0),
                                    us_per_launch_raw=ms[i] * 1e3 / cnt[i],
@@ -370,6 +384,9 @@ def main():
                         frac=round(ach / PEAK_F32_MATRIX_TFLOPS, 5), traffic=traffic,
                         flop_per_launch=flop_per_launch, kernels=kern,
                         event_overhead_us=round(ev_us, 3),
+                        measured_on=("the timed learner" if not use_dp else
+                                     "a single-GPU replica of the same kernels on rank 0 "
+                                     f"({us_per_step_plain:.1f} us per update without the exchange)"),
                         note="durations from hipEvent pairs around each launch on the launch stream "
                              f"(serialised pass of {P} steps) minus event_overhead_us, the per-launch "
                              "excess of that pass over the un-instrumented timed loop (where the same "
@@ -384,7 +401,7 @@ def main():
         multi = None
         if not use_dp and args.learners > 1:
             multi = multi_learner(args.learners, dev, local_rank, steps=max(200, min(K, 2000)))
-        cpu = None if args.no_cpu_baseline else cpu_baseline()
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()   # rank 0 at N = 1 only
         out = {
             "metric": "learner gradient steps/sec, DDPG batch=256 walker-walk",
             "value": round(value, 1), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
