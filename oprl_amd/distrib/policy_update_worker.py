@@ -1,16 +1,12 @@
-"""Learner process of the distributed setup (reference:
-/root/reference/src/oprl/distrib/policy_update_worker.py:22-119).
-
-Per epoch: one episode from every actor -> ``buffer.add_episode``; after
-``warmup_epochs`` run ``episode_length * num_env_workers`` back-to-back
-sample()+update() iterations; push the actor's state_dict to every actor.  The
-update loop is one C call (``oprl_learner_step_n``: device-side sampling, no
-host sync) instead of 4000 python iterations."""
+"""Learner side of the distributed setup (what the reference's distrib/policy_update_worker.py:22-119
+does): per epoch it takes one episode from every actor into the HBM replay, — after the warm-up epochs —
+trains ``episode_length x num_env_workers`` updates, and answers every actor with the new policy weights.
+The training block is ONE C call (``oprl_learner_step_n``: the update kernels gather their own rows on the
+device) instead of thousands of python sample()/update() iterations."""
 from __future__ import annotations
 
 import pickle
 import time
-from itertools import count
 from pathlib import Path
 from typing import Callable
 
@@ -26,6 +22,47 @@ from oprl_amd.logging import LoggerProtocol, create_stdout_logger
 from oprl_amd.runners.config import DistribConfig
 
 logger = create_stdout_logger()
+STOP = b"STOP"
+EVAL_EVERY_EPOCHS = 10
+
+
+class EpochLearner:
+    def __init__(self, algo: AlgorithmProtocol, buffer: ReplayBufferProtocol, config: DistribConfig, hub: QueueHub) -> None:
+        self.algo, self.buffer, self.config = algo, buffer, config
+        n = config.num_env_workers
+        self.inboxes = [Queue(f"env_{i}", hub) for i in range(n)]
+        self.outboxes = [Queue(f"policy_{i}", hub) for i in range(n)]
+
+    def gather_episodes(self) -> bool:
+        """One episode from every actor into the replay; False if the actors stay silent for
+        ``learner_num_waits`` seconds in total."""
+        deadline = time.monotonic() + float(self.config.learner_num_waits)
+        for inbox in self.inboxes:
+            data = None
+            while not data:
+                left = deadline - time.monotonic()
+                if left <= 0.0:
+                    return False
+                data = inbox.pop_wait(min(left, 1.0))
+            self.buffer.add_episode(pickle.loads(data))
+        return True
+
+    def train(self, i_epoch: int) -> None:
+        n_updates = self.config.episode_length * self.config.num_env_workers
+        fused = getattr(getattr(self.algo, "learner", None), "step_n", None)
+        if fused is not None and hasattr(self.buffer, "handle"):
+            fused(self.buffer.handle, n_updates, self.config.batch_size, seed=i_epoch)
+            return
+        for _ in range(n_updates):
+            self.algo.update(*self.buffer.sample(self.config.batch_size))
+
+    def tell_actors(self, message: bytes) -> None:
+        for box in self.outboxes:
+            box.push(message)
+
+    def policy_message(self) -> bytes:
+        weights = {name: w.detach().cpu() for name, w in self.algo.get_policy_state_dict().items()}
+        return pickle.dumps(weights)
 
 
 def run_policy_update_worker(
@@ -39,50 +76,23 @@ def run_policy_update_worker(
     wait_s: float = 0.05,
     on_epoch: Callable[[int, AlgorithmProtocol], None] | None = None,
 ) -> AlgorithmProtocol:
-    scalar_logger = make_logger()
-    algo = make_algo(scalar_logger)
-    buffer = make_buffer()
-    q_envs = [Queue(f"env_{i}", hub) for i in range(config.num_env_workers)]
-    q_policies = [Queue(f"policy_{i}", hub) for i in range(config.num_env_workers)]
-
-    for i_epoch in count(0):
-        if max_epochs is not None and i_epoch >= max_epochs:
+    algo = make_algo(make_logger())
+    learner = EpochLearner(algo, make_buffer(), config, hub)
+    i_epoch = 0
+    while max_epochs is None or i_epoch < max_epochs:
+        if not learner.gather_episodes():
+            logger.info("Learner is not receiving data, exiting...")
             break
-        n_waits = 0
-        for i_env in range(config.num_env_workers):
-            while True:
-                data = q_envs[i_env].pop()
-                if data:
-                    buffer.add_episode(pickle.loads(data))
-                    break
-                time.sleep(wait_s)
-                n_waits += 1
-                if n_waits >= config.learner_num_waits / wait_s:
-                    logger.info("Learner is not receiving data, exiting...")
-                    for q in q_policies:
-                        q.push(b"STOP")
-                    return algo
-
         if i_epoch > config.warmup_epochs:
-            n_updates = config.episode_length * config.num_env_workers
-            step_n = getattr(getattr(algo, "learner", None), "step_n", None)
-            if step_n is not None and hasattr(buffer, "handle"):
-                step_n(buffer.handle, n_updates, config.batch_size, seed=i_epoch)
-            else:
-                for _ in range(n_updates):
-                    algo.update(*buffer.sample(config.batch_size))
-
-        payload = pickle.dumps({k: v.detach().cpu() for k, v in algo.get_policy_state_dict().items()})
-        for q in q_policies:
-            q.push(payload)
+            learner.train(i_epoch)
+        learner.tell_actors(learner.policy_message())
         if on_epoch is not None:
             on_epoch(i_epoch, algo)
-        if i_epoch > 0 and i_epoch % 10 == 0:
-            mean_reward = evaluate(algo, make_env_test)
-            algo.logger.log_scalar("trainer/ep_reward", mean_reward, i_epoch)
+        if i_epoch > 0 and i_epoch % EVAL_EVERY_EPOCHS == 0:
+            algo.logger.log_scalar("trainer/ep_reward", evaluate(algo, make_env_test), i_epoch)
             save_policy(algo.actor, algo.logger.log_dir / "weights" / f"epoch_{i_epoch}.w")
-    for q in q_policies:
-        q.push(b"STOP")
+        i_epoch += 1
+    learner.tell_actors(STOP)
     return algo
 
 
@@ -93,14 +103,15 @@ def save_policy(policy: nn.Module, save_path: Path) -> None:
 
 def evaluate(algo: AlgorithmProtocol, make_env_test: Callable[[int], EnvProtocol],
              num_eval_episodes: int = 5, seed: int = 0) -> float:
-    returns = []
-    for i_ep in range(num_eval_episodes):
-        env_test = make_env_test(seed * 100 + i_ep)
-        state, _ = env_test.reset()
-        total, done = 0.0, False
-        while not done:
-            state, reward, terminated, truncated, _ = env_test.step(algo.actor.exploit(state))
-            total += reward
-            done = terminated or truncated
-        returns.append(total)
-    return float(np.mean(returns))
+    """Mean undiscounted return of the greedy policy over a few fresh environments."""
+    totals = []
+    for k in range(num_eval_episodes):
+        env = make_env_test(seed * 100 + k)
+        obs, _ = env.reset()
+        ret, over = 0.0, False
+        while not over:
+            obs, reward, terminated, truncated, _ = env.step(algo.actor.exploit(obs))
+            ret += reward
+            over = bool(terminated or truncated)
+        totals.append(ret)
+    return float(np.mean(totals))

@@ -33,3 +33,11 @@ class Queue:
             return self._q.get_nowait()
         except _queue.Empty:
             return None
+
+    def pop_wait(self, timeout_s: float) -> bytes | None:
+        """Blocking pop: the next message, or None after ``timeout_s`` seconds without one (the reference
+        polls its broker and sleeps; a process queue can simply block)."""
+        try:
+            return self._q.get(timeout=max(timeout_s, 0.0))
+        except _queue.Empty:
+            return None

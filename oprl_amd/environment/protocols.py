@@ -1,5 +1,5 @@
-"""Environment interface used by the trainers (reference:
-/root/reference/src/oprl/environment/protocols.py:6-34)."""
+"""What the trainers and the actor processes need from an environment (the gymnasium-style step /
+reset pair the reference wraps its simulators into, src/oprl/environment/protocols.py:6-34)."""
 from __future__ import annotations
 
 from typing import Any, Protocol
@@ -8,16 +8,27 @@ import numpy.typing as npt
 
 
 class EnvProtocol(Protocol):
-    env_family: str
+    env_family: str            # "dm_control" / "gymnasium": the runners refuse anything else
 
-    def step(self, action: npt.NDArray) -> tuple[npt.NDArray, float, bool, bool, dict[str, Any]]: ...
+    def reset(self) -> tuple[npt.NDArray, dict[str, Any]]:
+        """Starts an episode: ``(observation [state_dim], info)``."""
+        ...
 
-    def reset(self) -> tuple[npt.NDArray, dict[str, Any]]: ...
+    def step(self, action: npt.NDArray) -> tuple[npt.NDArray, float, bool, bool, dict[str, Any]]:
+        """``(next_observation, reward, terminated, truncated, info)``; the trainer stores ``terminated`` as
+        the transition's ``done`` and closes the replay episode on either flag."""
+        ...
 
-    def sample_action(self) -> npt.NDArray: ...
+    def sample_action(self) -> npt.NDArray:
+        """A uniform action in the action range (the warm-up policy)."""
+        ...
 
     @property
-    def observation_space(self): ...
+    def observation_space(self):
+        """Object with a ``.shape`` (``(state_dim,)``)."""
+        ...
 
     @property
-    def action_space(self): ...
+    def action_space(self):
+        """Object with a ``.shape`` (``(action_dim,)``)."""
+        ...

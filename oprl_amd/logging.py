@@ -101,11 +101,21 @@ def copy_exp_dir(log_dir: Path) -> None:
     logger.info(f"Source copied into {dest}")
 
 
-def make_text_logger_func(algo: str, env: str) -> Callable[[int], LoggerProtocol]:
-    def make_logger(seed: int) -> LoggerProtocol:
+class TextLoggerFactory:
+    """``factory(seed) -> FileTxtLogger`` under ``$OPRL_LOGS/<algo>/<env>/...``.  A class, not a closure:
+    the multi-seed runner hands its factories to spawned processes, so they have to pickle."""
+
+    def __init__(self, algo: str, env: str) -> None:
+        self.algo, self.env = algo, env
+
+    def __call__(self, seed: int) -> LoggerProtocol:
         root = os.environ.get("OPRL_LOGS", "logs")
-        lg = FileTxtLogger(get_logs_path(logdir=root, algo=algo, env=env, seed=seed))
+        lg = FileTxtLogger(get_logs_path(logdir=root, algo=self.algo, env=self.env, seed=seed))
         lg.log_dir.mkdir(parents=True, exist_ok=True)
         lg.copy_source_code()
         return lg
-    return make_logger
+
+
+def make_text_logger_func(algo: str, env: str) -> Callable[[int], LoggerProtocol]:
+    """The reference's factory-of-a-factory (logging.py:49-56)."""
+    return TextLoggerFactory(algo, env)

@@ -228,3 +228,23 @@ def test_alias_package_serves_the_reference_config_scripts():
     params = inspect.signature(run_training).parameters
     for k in ("make_algo", "make_env", "make_replay_buffer", "make_logger", "config", "seeds", "start_seed"):
         assert k in params, k
+
+
+def test_config_script_factories_pickle_for_the_multi_seed_runner(monkeypatch):
+    """``--seeds N`` spawns one process per seed and passes the script's factories: all of them must
+    pickle (a closure-returning logger factory did not)."""
+    import importlib
+    import pickle
+    import sys
+    from pathlib import Path
+    monkeypatch.setattr(sys, "argv", ["sac.py", "--env", "walker-walk", "--device", "cuda"])
+    monkeypatch.syspath_prepend(str(Path(__file__).resolve().parents[1] / "configs"))
+    sys.modules.pop("_common", None)
+    mod = importlib.import_module("sac")
+    try:
+        for name in ("make_env", "make_algo", "make_replay_buffer", "make_logger", "config"):
+            pickle.loads(pickle.dumps(getattr(mod, name)))
+        assert mod.config.state_dim == 24 and mod.config.action_dim == 6
+    finally:
+        sys.modules.pop("sac", None)
+        sys.modules.pop("_common", None)
