@@ -1,29 +1,37 @@
-"""Command-line flags of the config scripts (reference:
-/root/reference/src/oprl/parse_args.py).  Same flag names and defaults, except
-that ``--device`` defaults to ``cuda``: this learner has no CPU path."""
+"""Command line of the config scripts.  The flags and their defaults are the reference's
+(src/oprl/parse_args.py) — scripts written against it parse the same way — except ``--device``, which
+defaults to the only kind of device this learner runs on."""
 from __future__ import annotations
 
 import argparse
 
+# (flag, type, default, help) — shared by both entry points
+_SHARED = (
+    ("--config", str, None, "path of a config file (accepted for compatibility; the scripts are the config)"),
+    ("--env", str, "cartpole-balance", "environment name, e.g. walker-walk"),
+    ("--device", str, "cuda", "device of the learner (a ROCm GPU; there is no CPU path)"),
+)
+_SINGLE = (
+    ("--seeds", int, 1, "how many seeds to train, one process each"),
+    ("--start_seed", int, 0, "first seed; the others count up from it"),
+)
+_DISTRIB = (
+    ("--seed", int, 0, "random seed of the run"),
+)
 
-def _common(description: str) -> argparse.ArgumentParser:
-    p = argparse.ArgumentParser(description=description)
-    p.add_argument("--config", type=str, help="Path to the config file.")
-    p.add_argument("--env", type=str, default="cartpole-balance", help="Name of the environment.")
-    p.add_argument("--device", type=str, default="cuda", help="Device to perform training on.")
-    return p
+
+def _parser(title: str, extra) -> argparse.ArgumentParser:
+    parser = argparse.ArgumentParser(description=title)
+    for flag, kind, default, text in (*_SHARED, *extra):
+        parser.add_argument(flag, type=kind, default=default, help=text)
+    return parser
 
 
 def parse_args() -> argparse.Namespace:
-    p = _common("Run training")
-    p.add_argument("--seeds", type=int, default=1,
-                   help="Number of parallel processes launched with different random seeds.")
-    p.add_argument("--start_seed", type=int, default=0,
-                   help="Number of the first seed. Following seeds will be incremented from it.")
-    return p.parse_args()
+    """Flags of the single-process scripts (configs/ddpg.py ...)."""
+    return _parser("Run training", _SINGLE).parse_args()
 
 
 def parse_args_distrib() -> argparse.Namespace:
-    p = _common("Run distrib training")
-    p.add_argument("--seed", type=int, default=0, help="Random seed")
-    return p.parse_args()
+    """Flags of configs/distrib_ddpg.py."""
+    return _parser("Run distrib training", _DISTRIB).parse_args()

@@ -43,70 +43,82 @@ class BaseTrainer(TrainerProtocol):
     device: str = "cuda"
     seed: int = 0
 
+    # ---- the loop ----------------------------------------------------------------------------------
+    # Call order per environment step, as in the reference (base_trainer.py:38-74): choose an action
+    # (uniform during the first ``start_steps``, then ``actor.explore``), step, store the transition,
+    # and — once the buffer holds a batch — one update, then the periodic work.
     def train(self) -> None:
         self.algo.check_created()
         self.replay_buffer.check_created()
-        state, _ = self.env.reset()
-        for env_step in range(self.num_steps + 1):
-            if env_step <= self.start_steps:
-                action = self.env.sample_action()
-            else:
-                action = self.algo.actor.explore(state)
-            next_state, reward, terminated, truncated, _ = self.env.step(action)
-            self.replay_buffer.add_transition(state, action, reward, terminated,
-                                              episode_done=terminated or truncated)
-            if terminated or truncated:
-                next_state, _ = self.env.reset()
-            state = next_state
+        obs, _ = self.env.reset()
+        for step in range(self.num_steps + 1):
+            obs = self._collect(step, obs)
             if len(self.replay_buffer) < self.batch_size:
                 continue
-            fused = self.fused_sample_update and hasattr(self.algo, "update_from_buffer")
-            if fused:
-                # reference: sample() then update(*batch) (base_trainer.py:63-70); here the update
-                # gathers its own rows on the device.  The logging below wants a batch of rewards
-                # only at its own cadence.
-                self.algo.update_from_buffer(self.replay_buffer, self.batch_size)
-                need_rewards = (env_step % self.eval_interval == 0) or (env_step % self.stdout_log_every == 0)
-                rewards = self.replay_buffer.sample(self.batch_size)[2] if need_rewards else None
-            else:
-                batch = self.replay_buffer.sample(self.batch_size)
-                self.algo.update(*batch)
-                rewards = batch[2]
-            self._log_evaluation(env_step, rewards)
-            self._save_policy(env_step)
-            if self.save_checkpoint_every > 0 and env_step % self.save_checkpoint_every == 0:
-                self.save_checkpoint(self.logger.log_dir / "checkpoints" / f"{env_step}.ckpt", env_step)
-            self._log_stdout(env_step, rewards)
+            rewards = self._learn(step)
+            self._periodic(step, rewards)
+
+    def _collect(self, step: int, obs):
+        """One environment step into the replay; returns the observation the next step starts from."""
+        warm_up = step <= self.start_steps
+        action = self.env.sample_action() if warm_up else self.algo.actor.explore(obs)
+        nxt, reward, terminated, truncated, _ = self.env.step(action)
+        over = bool(terminated or truncated)
+        self.replay_buffer.add_transition(obs, action, reward, terminated, episode_done=over)
+        if over:
+            nxt, _ = self.env.reset()
+        return nxt
+
+    def _learn(self, step: int):
+        """One update.  Fused (default): ``algo.update_from_buffer`` — the kernels gather their own rows on
+        the device, one C call; a batch of rewards is sampled only when the logging below will print it.
+        Otherwise the reference's two calls, ``sample()`` then ``update(*batch)``."""
+        if self.fused_sample_update and hasattr(self.algo, "update_from_buffer"):
+            self.algo.update_from_buffer(self.replay_buffer, self.batch_size)
+            wanted = step % self.eval_interval == 0 or step % self.stdout_log_every == 0
+            return self.replay_buffer.sample(self.batch_size)[2] if wanted else None
+        batch = self.replay_buffer.sample(self.batch_size)
+        self.algo.update(*batch)
+        return batch[2]
+
+    def _periodic(self, step: int, rewards) -> None:
+        self._log_evaluation(step, rewards)
+        self._save_policy(step)
+        if self.save_checkpoint_every > 0 and step % self.save_checkpoint_every == 0:
+            self.save_checkpoint(self.logger.log_dir / "checkpoints" / f"{step}.ckpt", step)
+        self._log_stdout(step, rewards)
 
     def _log_evaluation(self, env_step: int, rewards: t.Tensor) -> None:
         if env_step % self.eval_interval != 0:
             return
-        metrics = self.evaluate()
-        rb = self.replay_buffer
-        self.logger.log_scalar("trainer/ep_reward", metrics["return"], env_step)
-        self.logger.log_scalar("trainer/avg_reward", rewards.mean().item(), env_step)
-        self.logger.log_scalar("trainer/buffer_transitions", len(rb), env_step)
-        self.logger.log_scalar("trainer/buffer_episodes", rb.episodes_counter, env_step)
-        self.logger.log_scalar("trainer/buffer_last_ep_len", rb.last_episode_length, env_step)
+        buf, log = self.replay_buffer, self.logger.log_scalar
+        log("trainer/ep_reward", self.evaluate()["return"], env_step)
+        log("trainer/avg_reward", rewards.mean().item(), env_step)
+        log("trainer/buffer_transitions", len(buf), env_step)
+        log("trainer/buffer_episodes", buf.episodes_counter, env_step)
+        log("trainer/buffer_last_ep_len", buf.last_episode_length, env_step)
 
     def evaluate(self) -> dict[str, float]:
-        returns = []
-        for i_ep in range(self.num_eval_episodes):
-            env_test = self.make_env_test(self.seed + i_ep)
-            state, _ = env_test.reset()
-            total, done = 0.0, False
-            while not done:
-                state, reward, terminated, truncated, _ = env_test.step(self.algo.actor.exploit(state))
-                total += reward
-                done = terminated or truncated
-            returns.append(total)
-        return {"return": float(np.mean(returns))}
+        """Mean undiscounted return of the greedy policy over ``num_eval_episodes`` fresh environments."""
+        totals = []
+        for k in range(self.num_eval_episodes):
+            env = self.make_env_test(self.seed + k)
+            obs, _ = env.reset()
+            ret, over = 0.0, False
+            while not over:
+                obs, reward, terminated, truncated, _ = env.step(self.algo.actor.exploit(obs))
+                ret += reward
+                over = bool(terminated or truncated)
+            totals.append(ret)
+        return {"return": float(np.mean(totals))}
 
     def _save_policy(self, env_step: int) -> None:
-        if self.save_policy_every > 0 and env_step % self.save_policy_every == 0:
-            path = self.logger.log_dir / "weights" / f"{env_step}.w"
-            path.parent.mkdir(parents=True, exist_ok=True)
-            t.save(self.algo.actor, path)
+        """Whole-module pickle of the actor, as the reference does (base_trainer.py:113-120)."""
+        if self.save_policy_every <= 0 or env_step % self.save_policy_every != 0:
+            return
+        target = self.logger.log_dir / "weights" / f"{env_step}.w"
+        target.parent.mkdir(parents=True, exist_ok=True)
+        t.save(self.algo.actor, target)
 
     # Full-state checkpoint (the reference only pickles the policy, base_trainer.py:113-120):
     # learner arenas + Adam moments + counters and the replay with its write / sample positions;
@@ -135,33 +147,39 @@ class BaseTrainer(TrainerProtocol):
             self.logger.log_scalar("trainer/Q-critic", q_critic, env_step)
             self.logger.log_scalar("trainer/Q_asb_diff", q_critic - q_true, env_step)
 
+    def _probe_envs(self, n: int):
+        """The probe's environments: seeds ``seed * 100 + k``, each reset, as (env, first observation)."""
+        for k in range(n):
+            env = self.make_env_test(self.seed * 100 + k)
+            first, _ = env.reset()
+            yield env, first
+
     def estimate_true_q(self, eval_episodes: int = 10) -> float:
-        qs = []
-        for i_eval in range(eval_episodes):
-            env = self.make_env_test(self.seed * 100 + i_eval)
-            state, _ = env.reset()
-            q, discount, done = 0.0, self.gamma, False
-            while not done:
-                state, r, terminated, truncated, _ = env.step(self.algo.actor.exploit(state))
-                q += r * discount          # (the reference starts the discount at gamma^1)
-                discount *= self.gamma
-                done = terminated or truncated
-            qs.append(q)
-        return float(np.mean(qs))
+        """Discounted Monte-Carlo return of the greedy policy (the first reward already carries one factor
+        of gamma, as in the reference)."""
+        returns = []
+        for env, obs in self._probe_envs(eval_episodes):
+            total, weight, over = 0.0, self.gamma, False
+            while not over:
+                obs, reward, terminated, truncated, _ = env.step(self.algo.actor.exploit(obs))
+                total += weight * reward
+                weight *= self.gamma
+                over = bool(terminated or truncated)
+            returns.append(total)
+        return float(np.mean(returns))
 
     def estimate_critic_q(self, num_episodes: int = 10) -> float:
-        qs = []
-        for i_eval in range(num_episodes):
-            env = self.make_env_test(self.seed * 100 + i_eval)
-            state, _ = env.reset()
-            action = self.algo.actor.exploit(state)
-            s = t.as_tensor(np.asarray(state), dtype=t.float32, device=self.device).unsqueeze(0)
-            a = t.as_tensor(np.asarray(action), dtype=t.float32, device=self.device).unsqueeze(0)
+        """The critic's value of the greedy action at the first state of the same episodes (twin critics:
+        Q1; quantile critics: the first entry)."""
+        values = []
+        for _env, obs in self._probe_envs(num_episodes):
+            act = self.algo.actor.exploit(obs)
+            s = t.as_tensor(np.asarray(obs), dtype=t.float32, device=self.device).unsqueeze(0)
+            a = t.as_tensor(np.asarray(act), dtype=t.float32, device=self.device).unsqueeze(0)
             q = self.algo.critic(s, a)
-            if isinstance(q, tuple):       # twin critics: Q1
-                q = q[0]
-            qs.append(float(q.reshape(-1)[0].item()))   # (quantile critics: first entry, as the reference's .item() would need)
-        return float(np.mean(qs))
+            q = q[0] if isinstance(q, tuple) else q
+            values.append(float(q.reshape(-1)[0].item()))
+        return float(np.mean(values))
 
     def _log_stdout(self, env_step: int, rewards: t.Tensor) -> None:
         if env_step % self.stdout_log_every == 0:
