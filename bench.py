@@ -182,6 +182,27 @@ def multi_learner(n, dev, local_rank, steps):
                 verified=dict(all_finite=finite, learner0_equals_solo_run=same))
 
 
+def self_launch(n_gpus: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: start the N ranks here (one process per GPU,
+    ``torch.distributed.run`` on 127.0.0.1) and hand their output through; rank 0 prints the JSON line.
+    With fewer than N GPUs on the node nothing can be measured: one JSON line saying so, exit code 0."""
+    import socket
+    import subprocess
+    have = t.cuda.device_count() if t.cuda.is_available() else 0
+    if have < n_gpus:
+        why = f"--gpus {n_gpus} needs {n_gpus} GPUs on this node, found {have}: nothing measured"
+        print(f"bench.py: {why}", file=sys.stderr)
+        print(json.dumps({"metric": "learner gradient steps/sec, DDPG batch=256 walker-walk", "value": None,
+                          "unit": "steps/s", "n_gpus": n_gpus, "skipped": why}), flush=True)
+        return 0
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.run(cmd).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,15 +220,13 @@ def main():
                     help="use the data-parallel path (RCCL all-reduce) even with one rank")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: measuring WORLD_SIZE ranks", file=sys.stderr)
     assert t.cuda.is_available(), "bench.py needs an MI355X"
     t.cuda.set_device(local_rank)
     dev = t.device("cuda", local_rank)

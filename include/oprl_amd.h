@@ -161,6 +161,12 @@ int oprl_learner_set_update_count(oprl_learner* h, int64_t count);
 #define OPRL_N_COUNTERS 4
 int oprl_learner_get_counters(oprl_learner* h, int64_t out_host[OPRL_N_COUNTERS]);
 int oprl_learner_set_counters(oprl_learner* h, const int64_t in_host[OPRL_N_COUNTERS]);
+/* Key of the learner's device-side noise streams (TD3 target smoothing, the SAC / TQC
+ * reparameterisation draws, drawn with Philox when update() gets no injected noise): `seed` is the
+ * run seed (the reference seeds torch's generator in runners/train.py:14-21), `rank` the
+ * data-parallel rank (oprl_comm_init / oprl_p2p_create set it too) so that every seed and every
+ * rank draws its own eps.  Seed 0 on rank 0 is the default. */
+int oprl_learner_set_seed(oprl_learner* h, uint64_t seed, int32_t rank);
 /* device pointer to the per-row Q / TD-target of the last critic step ([B] each,
  * critic 0), for parity tests. */
 int oprl_learner_debug_ptrs(oprl_learner* h, const float** q, const float** y);

@@ -47,6 +47,10 @@ class OffPolicyAlgorithm(ABC):
         self.learner.step_n(handle, 1, int(batch_size), seed=int(getattr(replay_buffer, "seed", 0)))
         self._log_update(step)
 
+    def set_seed(self, seed: int, rank: int = 0) -> None:
+        """Key the learner's device-side noise streams with the run seed (and data-parallel rank)."""
+        self.learner.set_seed(seed, rank)
+
     # full learner state (parameters, targets, optimiser moments, counters): exact resume
     def state_dict(self) -> dict[str, Any]:
         return self.learner.state_dict()
@@ -299,6 +303,11 @@ class HipLearner:
         with _capi.on_device(self.device):
             _capi.check(self.lib.oprl_learner_step_n(self.handle, replay_handle, K, B, seed,
                                                      _capi.current_stream()), "oprl_learner_step_n")
+
+    def set_seed(self, seed: int, rank: int = 0) -> None:
+        self.seed = int(seed)
+        _capi.check(self.lib.oprl_learner_set_seed(self.handle, int(seed) & (2 ** 64 - 1), int(rank)),
+                    "oprl_learner_set_seed")
 
     def read_scalars(self) -> dict[str, float]:
         buf = (C.c_float * 6)()

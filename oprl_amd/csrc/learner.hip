@@ -377,6 +377,10 @@ struct oprl_learner {
   BatchSrc src;                // where the current update's minibatch comes from
   BatchSrc next_src;           // step_n: what phase 2 should gather for the next update
   int prefetch_next = 0;
+  // key of the in-update noise streams (TD3 smoothing, SAC / TQC reparameterisation draws): the run
+  // seed and, in a data-parallel job, the rank — every seed and every rank draws its own eps
+  uint64_t noise_seed = 0;
+  int noise_rank = 0;
   // prebuilt device repack tables: [0] critics online, [1] critics online+target, [2] actor (+target)
   RepackItem* rp_dev[3] = {nullptr, nullptr, nullptr};
   int rp_n[3] = {0, 0, 0}, rp_blocks[3] = {0, 0, 0};
@@ -657,9 +661,22 @@ const double* alpha_ptr(const oprl_learner* h) {
   return learned ? h->cfg.log_alpha : nullptr;
 }
 
+// Philox key of noise stream `stream_id` (1: next-state draw / TD3 smoothing, 2: actor-step draw).
+// Seed 0 on rank 0 is the bare stream constant; anything else is mixed in (splitmix64 finaliser).
+unsigned long long noise_key(const oprl_learner* h, uint64_t stream_id) {
+  uint64_t x = h->noise_seed ^ ((uint64_t)h->noise_rank * 0x9E3779B97F4A7C15ULL);
+  if (x != 0) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+  }
+  return 0x0b5e55edULL + stream_id + x;
+}
+
 void seed_rng(MlpArgs& a, const oprl_learner* h, const float* noise, uint64_t stream_id) {
   a.noise = noise;
-  a.rng_seed = 0x0b5e55edULL + stream_id;
+  a.rng_seed = noise_key(h, stream_id);
   a.rng_ctr = (unsigned long long)h->update_count;
 }
 
@@ -680,7 +697,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
     a.critic2 = net_view(c.critics[1], false);
     a.critic2_t = net_view(c.critics[1], true);
     for (int l = 0; l < kMaxLayers; ++l) { a.c2X[l] = h->ws_critic[1].X[l]; a.c2dY[l] = h->ws_critic[1].dY[l]; }
-    a.rng_seed = 0x0b5e55edULL + 1;                       // the streams seed_rng() gives the generic path
+    a.rng_seed = noise_key(h, 1);                         // the streams seed_rng() gives the generic path
     a.rng_ctr = (unsigned long long)h->update_count;
   }
   if (c.algo == OPRL_TD3) {   // target-policy smoothing (td3.py:83-93), delayed actor steps
@@ -693,7 +710,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   if (c.algo == OPRL_SAC) {   // tanh-Gaussian actor, entropy term (sac.py:90-141)
     a.sac = 1;
     a.noise_pi = h->noise1_pending;
-    a.rng_seed_pi = 0x0b5e55edULL + 2;
+    a.rng_seed_pi = noise_key(h, 2);
     a.log_alpha = alpha_ptr(h);
     a.alpha_const = (float)c.hp.alpha_init;
     a.raw = h->raw;
@@ -1091,6 +1108,7 @@ extern "C" int oprl_comm_init(oprl_learner* h, const char* rccl_path, int32_t ra
   NCCLC(h, h->rccl.comm_init_rank(&h->rccl.comm, world, nid, rank));
   h->rccl.rank = rank;
   h->rccl.world = world;
+  h->noise_rank = rank;          // every rank draws its own in-update noise
   return OPRL_OK;
 }
 
@@ -1105,6 +1123,7 @@ extern "C" int oprl_p2p_create(oprl_learner* h, int32_t rank, int32_t world, cha
   h->p2p_max_tiles = std::max(h->tiles_critic, h->tiles_actor);
   size_t tile_bytes = h->fused ? dw_xchg_bytes(world, h->p2p_max_tiles) : 0;
   if (tile_bytes > ((size_t)256 << 20)) tile_bytes = 0;
+  h->noise_rank = rank;
   hipError_t e = p2p_create(h->p2p, rank, world, n, tile_bytes, handle_out);
   if (e != hipSuccess) {
     set_err("oprl_p2p_create: %s", hipGetErrorString(e));
@@ -1652,6 +1671,13 @@ extern "C" int oprl_learner_update_count(oprl_learner* h, int64_t* out_host) {
 extern "C" int oprl_learner_set_update_count(oprl_learner* h, int64_t count) {
   if (!h || count < 0) { set_err("invalid argument"); return OPRL_ERR_INVALID; }
   h->update_count = count;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_learner_set_seed(oprl_learner* h, uint64_t seed, int32_t rank) {
+  if (!h || rank < 0) { set_err("oprl_learner_set_seed: invalid argument"); return OPRL_ERR_INVALID; }
+  h->noise_seed = seed;
+  h->noise_rank = rank;
   return OPRL_OK;
 }
 

@@ -8,7 +8,7 @@ import numpy.typing as npt
 
 
 class EnvProtocol(Protocol):
-    env_family: str            # "dm_control" / "gymnasium": the runners refuse anything else
+    env_family: str            # "dm_control" / "gymnasium" / "synthetic" (this build's stand-in): the runners refuse anything else
 
     def reset(self) -> tuple[npt.NDArray, dict[str, Any]]:
         """Starts an episode: ``(observation [state_dim], info)``."""

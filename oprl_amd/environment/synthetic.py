@@ -11,6 +11,7 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 from typing import Any
+import zlib
 
 import numpy as np
 import numpy.typing as npt
@@ -34,7 +35,7 @@ class _Box:
 
 
 class SyntheticEnv:
-    env_family = "dm_control"
+    env_family = "synthetic"      # never passes for a simulator: runners and logs can tell
 
     def __init__(self, name: str, seed: int = 0, episode_length: int = 1000):
         if name not in DM_CONTROL_DIMS:
@@ -43,7 +44,9 @@ class SyntheticEnv:
         self.S, self.A = DM_CONTROL_DIMS[name]
         self.episode_length = episode_length
         self._rng = np.random.RandomState(seed)
-        dyn = np.random.RandomState(hash(name) % (2 ** 31))
+        # (crc32, not hash(): str hashes are salted per interpreter, and actors, learner and the
+        # children of --seeds N must all build the SAME dynamics for a task name)
+        dyn = np.random.RandomState(zlib.crc32(name.encode()) % (2 ** 31))
         self._F = (0.95 * np.eye(self.S) + 0.02 * dyn.standard_normal((self.S, self.S))).astype(np.float32)
         self._G = (0.3 * dyn.standard_normal((self.S, self.A))).astype(np.float32)
         self._goal = dyn.standard_normal(self.S).astype(np.float32)

@@ -31,6 +31,8 @@ class DataParallelLearner:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        if hasattr(self.engine, "set_seed"):       # every rank draws its own in-update noise
+            self.engine.set_seed(getattr(self.engine, "seed", 0), self.rank)
 
     # ---- native (C) data-parallel loop -------------------------------------------
     def init_native_comm(self, rccl_path: str | None = None) -> None:

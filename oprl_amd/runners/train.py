@@ -32,7 +32,14 @@ def _run_training_func(make_algo, make_env, make_replay_buffer, make_logger,
     replay_buffer = make_replay_buffer()
     logger = make_logger(seed)
     algo = make_algo(logger)
-    if env.env_family not in ("dm_control", "gymnasium"):
+    # the run seed reaches the DEVICE-side generators too (the reference draws minibatch indices from
+    # np.random and the in-update noise from torch after set_seed(seed), runners/train.py:14-21): the
+    # replay's Philox sampler key and the learner's noise key
+    if hasattr(replay_buffer, "seed"):
+        replay_buffer.seed = seed
+    if hasattr(algo, "set_seed"):
+        algo.set_seed(seed)
+    if env.env_family not in ("dm_control", "gymnasium", "synthetic"):
         raise ValueError(f"Unsupported env family: {env.env_family}")
     BaseTrainer(env=env, make_env_test=make_env, algo=algo, replay_buffer=replay_buffer,
                 num_steps=config.num_steps, eval_interval=config.eval_every, device=config.device,

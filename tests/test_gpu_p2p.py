@@ -64,6 +64,8 @@ def test_two_process_p2p_data_parallel_step(algo_name, level):
         assert t.isfinite(res[0]["arenas"][m]).all()
     # single-process emulation: two export_grads learners, gradients summed in rank order
     L = [make_algo(algo_name, B, export_grads=True) for _ in range(world)]
+    for r in range(world):
+        L[r].learner.set_seed(0, r)      # as the ranks of the job: every rank draws its own noise
     shards = [make_shard(r) for r in range(world)]
     for r in range(world):
         shards[r].seed = (5 * 0x9E3779B97F4A7C15 + r) & (2 ** 64 - 1)

@@ -248,3 +248,25 @@ def test_config_script_factories_pickle_for_the_multi_seed_runner(monkeypatch):
     finally:
         sys.modules.pop("sac", None)
         sys.modules.pop("_common", None)
+
+
+def test_synthetic_env_dynamics_do_not_depend_on_the_interpreter_hash_seed():
+    """Actors, learner and --seeds children are separate processes: the stand-in's dynamics must be the
+    same in all of them (str hashes are salted per interpreter; the task name is hashed with crc32)."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("from oprl_amd.environment import make_env; import zlib; "
+            "e = make_env('synthetic:walker-walk', 3); print(zlib.crc32(e._F.tobytes() + e._G.tobytes() + e._goal.tobytes()))")
+    outs = []
+    for hs in ("1", "2"):
+        env = dict(os.environ, PYTHONHASHSEED=hs)
+        outs.append(subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True,
+                                   text=True, check=True).stdout.strip())
+    assert outs[0] == outs[1]
+    from oprl_amd.environment import make_env
+    e = make_env("walker-walk", 0)          # bare name: accepted (reference command lines), but labelled
+    assert e.env_family == "synthetic"
+    with pytest.raises(ValueError):
+        make_env("Ant-v4", 0)
