@@ -44,9 +44,20 @@ typedef enum oprl_status {
 
 typedef enum oprl_algo { OPRL_DDPG = 0, OPRL_TD3 = 1, OPRL_SAC = 2, OPRL_TQC = 3 } oprl_algo;
 
-/* Arithmetic mode of the MLP GEMMs.  F32 = exact-fp32 MFMA
- * (v_mfma_f32_16x16x4_f32), the parity mode.  */
-typedef enum oprl_precision { OPRL_PREC_F32 = 0 } oprl_precision;
+/* Arithmetic mode of the MLP GEMMs.
+ *   F32  = exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), the parity mode: Q-values and gradients within
+ *          1e-4 of the reference (measured <= 2e-6).
+ *   BF16 = v_mfma_f32_16x16x32_bf16 with fp32 accumulation (16x the matrix rate, half the weight
+ *          bytes): both GEMM operands of the forward and backward passes of the fused update kernels
+ *          (DDPG / TD3 / SAC phase kernels, TQC's layer-wise critic kernels) are rounded to bf16 on the
+ *          way into the matrix cores — the weights once per Adam step, into bf16 fragment packs the
+ *          library owns.  Master weights, Adam moments, Polyak targets, activations in LDS / HBM, the
+ *          heads, losses and the dW GEMM stay fp32.  Outside the fused kernels (oprl_mlp_forward / act /
+ *          backward, generic fall-back launches for shapes the fused kernels do not cover) a BF16
+ *          learner computes in fp32 from the fp32 packs.  Deviation from the reference: ~1e-3..1e-2
+ *          relative on Q (bf16 inputs cannot meet the 1e-4 gate; tests/test_gpu_bf16.py states and
+ *          measures the tolerance). */
+typedef enum oprl_precision { OPRL_PREC_F32 = 0, OPRL_PREC_BF16 = 1 } oprl_precision;
 
 /* One MLP (ReLU hidden layers, identity output), parameters laid out exactly
  * like the reference module's state_dict: W0[out0,in0] row-major, b0, W1, b1...

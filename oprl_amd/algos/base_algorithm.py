@@ -82,7 +82,7 @@ class HipLearner:
                  critic_target_group: nn.Module, critic_target_mlps: Sequence[MLP],
                  hp: dict, max_batch: int, export_grads: bool = False,
                  log_alpha: t.Tensor | None = None, actor_target_group: nn.Module | None = None,
-                 no_fuse: bool = False):
+                 no_fuse: bool = False, precision: str = "f32"):
         self.lib = _capi.load()
         self.device = device
         self.S, self.A = state_dim, action_dim
@@ -112,7 +112,10 @@ class HipLearner:
         cfg = _capi.OprlLearnerConfig()
         cfg.abi_version = _capi.OPRL_ABI_VERSION
         cfg.algo = _capi.ALGO[algo]
-        cfg.precision = 0
+        if precision not in _capi.PRECISION:
+            raise ValueError(f"precision={precision!r}: expected one of {sorted(_capi.PRECISION)}")
+        cfg.precision = _capi.PRECISION[precision]
+        self.precision = precision
         cfg.state_dim, cfg.action_dim = state_dim, action_dim
         cfg.max_batch = self.max_batch
         cfg.n_critics = len(critic_mlps)

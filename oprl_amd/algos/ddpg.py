@@ -34,6 +34,7 @@ class DDPG(OffPolicyAlgorithm):
     max_batch: int = 4096          # rows the HIP workspace is sized for
     export_grads: bool = False     # data-parallel learner: reduce grads between phases
     no_fuse: bool = False          # force the generic per-net launch sequence (tests / A-B)
+    precision: str = "f32"        # "f32": exact-fp32 MFMA (parity mode); "bf16": bf16 MFMA inputs, fp32 accumulate / master / Adam (include/oprl_amd.h)
 
     actor: PolicyProtocol = field(init=False)
     actor_target: PolicyProtocol = field(init=False)
@@ -75,7 +76,7 @@ class DDPG(OffPolicyAlgorithm):
             actor_target_group=self.actor_target,
             critic_group=self.critic, critic_mlps=[self.critic.q1],
             critic_target_group=self.critic_target, critic_target_mlps=[self.critic_target.q1],
-            hp=hp, max_batch=self.max_batch, export_grads=self.export_grads, no_fuse=self.no_fuse)
+            hp=hp, max_batch=self.max_batch, export_grads=self.export_grads, no_fuse=self.no_fuse, precision=self.precision)
         self._created = True
         return self
 

@@ -35,6 +35,7 @@ class SAC(OffPolicyAlgorithm):
     max_batch: int = 4096
     export_grads: bool = False
     no_fuse: bool = False     # True: the generic per-net launch sequence instead of the fused kernels
+    precision: str = "f32"        # "f32": exact-fp32 MFMA (parity mode); "bf16": bf16 MFMA inputs, fp32 accumulate / master / Adam (include/oprl_amd.h)
 
     actor: PolicyProtocol = field(init=False)
     critic: nn.Module = field(init=False)
@@ -73,7 +74,7 @@ class SAC(OffPolicyAlgorithm):
             critic_target_group=self.critic_target,
             critic_target_mlps=[self.critic_target.q1, self.critic_target.q2],
             hp=hp, max_batch=self.max_batch, export_grads=self.export_grads, log_alpha=self.log_alpha,
-            no_fuse=self.no_fuse)
+            no_fuse=self.no_fuse, precision=self.precision)
         self._created = True
         return self
 

@@ -36,6 +36,7 @@ class TD3(OffPolicyAlgorithm):
     max_batch: int = 4096
     export_grads: bool = False
     no_fuse: bool = False     # True: the generic per-net launch sequence instead of the fused kernels
+    precision: str = "f32"        # "f32": exact-fp32 MFMA (parity mode); "bf16": bf16 MFMA inputs, fp32 accumulate / master / Adam (include/oprl_amd.h)
 
     actor: PolicyProtocol = field(init=False)
     actor_target: PolicyProtocol = field(init=False)
@@ -81,7 +82,7 @@ class TD3(OffPolicyAlgorithm):
             critic_group=self.critic, critic_mlps=[self.critic.q1, self.critic.q2],
             critic_target_group=self.critic_target,
             critic_target_mlps=[self.critic_target.q1, self.critic_target.q2],
-            hp=hp, max_batch=self.max_batch, export_grads=self.export_grads, no_fuse=self.no_fuse)
+            hp=hp, max_batch=self.max_batch, export_grads=self.export_grads, no_fuse=self.no_fuse, precision=self.precision)
         self._created = True
         return self
 

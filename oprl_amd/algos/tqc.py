@@ -60,6 +60,7 @@ class TQC(OffPolicyAlgorithm):
     device: str = "cuda"
     max_batch: int = 4096
     export_grads: bool = False
+    precision: str = "f32"         # "f32": exact-fp32 MFMA (parity mode); "bf16": bf16 MFMA inputs, fp32 accumulate / master / Adam
 
     actor: PolicyProtocol = field(init=False)
     critic: QuantileQritic = field(init=False)
@@ -96,7 +97,8 @@ class TQC(OffPolicyAlgorithm):
             actor_group=self.actor, actor_mlp=self.actor.net, actor_target_mlp=None,
             critic_group=self.critic, critic_mlps=self.critic.nets,
             critic_target_group=self.critic_target, critic_target_mlps=self.critic_target.nets,
-            hp=hp, max_batch=self.max_batch, export_grads=self.export_grads, log_alpha=self.log_alpha)
+            hp=hp, max_batch=self.max_batch, export_grads=self.export_grads, log_alpha=self.log_alpha,
+            precision=self.precision)
         self._created = True
         return self
 

@@ -179,6 +179,30 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A) 
           *reinterpret_cast<const f32x4*>(&src[bn * 16 + li][bk * 16 + 4 * lk]);
     }
   }
+  if (I.pf16 == nullptr) return;
+  // ---- bf16 packs (PrecBF16, engine.h): 8 blocks of 16 x 32 per pack, a block = fp32 blocks 2b, 2b + 1 side by side
+  const int NSk2 = I.K >> 5, NSn2 = I.N >> 5;
+  for (int job = tid >> 6; job < 24; job += kWThreads / 64) {
+    const int which = job >> 3, blk = job & 7, b16 = blk >> 1, b32 = blk & 1;   // (16-row block, 32-column step)
+    if (which == 1) {            // W^T: rows = k (16-row tile b16), steps = n (32 wide, b32)
+      if (I.pb16 == nullptr) continue;
+      f32x4 lo, hi;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        lo[t] = stA[b32 * 32 + 4 * lk + t][b16 * 16 + li];
+        hi[t] = stA[b32 * 32 + 16 + 4 * lk + t][b16 * 16 + li];
+      }
+      *reinterpret_cast<bf16x8*>(I.pb16 + (((size_t)((k_base >> 4) + b16) * NSn2 + (n_base >> 5) + b32) * 64 + l) * 4) =
+          cvt_bf16x8(lo, hi);
+    } else {
+      float* dst = which == 0 ? I.pf16 : (polyak ? I.tpf16 : nullptr);
+      if (dst == nullptr) continue;
+      const float (*src)[kWLd] = which == 0 ? stA : stX;
+      *reinterpret_cast<bf16x8*>(dst + (((size_t)((n_base >> 4) + b16) * NSk2 + (k_base >> 5) + b32) * 64 + l) * 4) =
+          cvt_bf16x8(*reinterpret_cast<const f32x4*>(&src[b16 * 16 + li][b32 * 32 + 4 * lk]),
+                     *reinterpret_cast<const f32x4*>(&src[b16 * 16 + li][b32 * 32 + 16 + 4 * lk]));
+    }
+  }
 }
 
 // Is this layer one for the wide kernel?  (Full 64 x 64 tiles; no dz1 partial buffers, no per-row seed.)

@@ -74,6 +74,78 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// ---------------------------------------------------------------------------
+// Precision policies of the lean passes (tp4.h), the layer-wise kernels and the dW GEMMs.
+//
+// A MACRO STEP is one 16-byte B fragment per lane (1 KB per wave, contiguous in the pack):
+//   PrecF32   16 contraction indices: four v_mfma_f32_16x16x4_f32 (exact fp32, the parity mode)
+//   PrecBF16  32 contraction indices: ONE v_mfma_f32_16x16x32_bf16 (fp32 accumulate), 16x the
+//             matrix rate and half the weight bytes.  Its fragment is two consecutive fp32 macro
+//             steps side by side, rounded to bf16 (RNE, v_cvt_pk_bf16_f32): lane (kk, i) holds
+//                 M[16 tile + i][32 s + 4 kk + t]        t = 0..3   (fp32 step 2s)
+//                 M[16 tile + i][32 s + 16 + 4 kk + t]   t = 0..3   (fp32 step 2s + 1)
+//             so the A operand is the SAME two conflict-free ds_read_b128 of the fp32 LDS
+//             activation tile the fp32 mode issues for steps 2s and 2s + 1, converted on the way
+//             in (activations stay fp32 in LDS and HBM; master weights, Adam and Polyak stay fp32;
+//             the bf16 packs are derived state written by the dW + Adam epilogue).  The MFMA pairs
+//             element t of A's lane group with element t of B's: any k-order inside a step is
+//             as good as any other as long as both operands use it.
+// xr in mac(): X + (lane & 15) * ld + 4 * (lane >> 4), X a row-major fp32 LDS tile.
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 cvt_bf16x8(const f32x4 lo, const f32x4 hi) {
+  const f32x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_convertvector(v, bf16x8);
+}
+
+struct PrecF32 {
+  static constexpr int KS = 16;
+  static constexpr bool kBf16 = false;
+  __device__ static __forceinline__ void mac(const float* xr, int s, const f32x4 b, f32x4& acc) {
+    const f32x4 a = ld4(xr + 16 * s);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = mfma4(a[t], b[t], acc);
+  }
+  // k16 = valid fp32-size steps of the contraction: nothing to guard here
+  __device__ static __forceinline__ void mac_tail(const float* xr, int s, const f32x4 b, f32x4& acc, int) {
+    mac(xr, s, b, acc);
+  }
+  // the first matrix element of a fragment
+  __device__ static __forceinline__ float first(const float* frag) { return frag[0]; }
+};
+
+struct PrecBF16 {
+  static constexpr int KS = 32;
+  static constexpr bool kBf16 = true;
+  __device__ static __forceinline__ void mac(const float* xr, int s, const f32x4 b, f32x4& acc) {
+    const bf16x8 a = cvt_bf16x8(ld4(xr + 32 * s), ld4(xr + 32 * s + 16));
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  }
+  // the upper half of the last step may lie beyond the LDS tile's row (narrow [kR][kOutLd] tiles):
+  // it is read only when fp32-size step 2s + 1 exists
+  __device__ static __forceinline__ void mac_tail(const float* xr, int s, const f32x4 b, f32x4& acc, int k16) {
+    const f32x4 lo = ld4(xr + 32 * s);
+    const f32x4 hi = (2 * s + 1 < k16) ? ld4(xr + 32 * s + 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cvt_bf16x8(lo, hi), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  }
+  __device__ static __forceinline__ float first(const float* frag) {
+    return __uint_as_float((*reinterpret_cast<const unsigned*>(frag) & 0xffffu) << 16);
+  }
+};
+
+// position (in bf16 elements) of M[r][c] inside its bf16 pack (NS = cdiv(cols, 32))
+__host__ __device__ inline long pack16_index(int r, int c, int NS) {
+  const int tile = r >> 4, i = r & 15, s = c >> 5, c5 = c & 31;
+  const int half = c5 >> 4, kk = (c5 & 15) >> 2, t = (c5 & 3) + 4 * half;
+  return (((long)tile * NS + s) * 64 + (kk * 16 + i)) * 8 + t;
+}
+// 16-byte units ("float4 slots") of one bf16 pack of an [rows x cols] matrix, in floats
+__host__ __device__ constexpr long pack16_floats(int rows, int cols) {
+  return (long)cdiv(rows, 16) * cdiv(cols, 32) * 256;
+}
+
 // Compile-time-indexed select from a small array that lives in kernel-argument
 // memory: a runtime subscript would make hipcc copy the whole by-value argument
 // block to scratch (observed: 440 B/lane).

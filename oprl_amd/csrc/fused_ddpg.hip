@@ -47,17 +47,17 @@ namespace oprl {
 constexpr int kMaxEnds = 2048;
 
 // one MLP pass of a cluster: the lean tp4 routines or the generic tp3 ones
-template <int WIDTH, bool LEAN, class ST>
+template <int WIDTH, bool LEAN, class P, class ST>
 __device__ __forceinline__ void tp_fwd(const Net& net, const float* x0s, float* h1, float* h2, float* outS,
                                        float* scr, Tp& tp, const Tp3Store& st, int row0, int B, ST sf) {
-  if constexpr (LEAN) tp4_forward(net, x0s, h1, h2, outS, tp, st, row0, B, sf);
+  if constexpr (LEAN) tp4_forward<P>(net, x0s, h1, h2, outS, tp, st, row0, B, sf);
   else tp3_forward<WIDTH>(net, x0s, h1, h2, outS, scr, tp, st, row0, B, sf);
 }
-template <int WIDTH, bool LEAN, class ST>
+template <int WIDTH, bool LEAN, class P, class ST>
 __device__ __forceinline__ void tp_bwd(const Net& net, const float* doutS, float* h1, float* h2, float* scr,
                                        Tp& tp, const Tp3Store& st, int row0, int B, int dact_col0,
                                        int dact_cols, float* dactS, ST sf) {
-  if constexpr (LEAN) tp4_backward(net, doutS, h1, h2, scr, tp, st, row0, B, dact_col0, dact_cols, dactS, sf);
+  if constexpr (LEAN) tp4_backward<P>(net, doutS, h1, h2, scr, tp, st, row0, B, dact_col0, dact_cols, dactS, sf);
   else tp3_backward<WIDTH>(net, doutS, h1, h2, scr, tp, st, row0, B, dact_col0, dact_cols, dactS, sf);
 }
 
@@ -187,7 +187,7 @@ __device__ __forceinline__ void gauss_head(const float* outS, int row0, int B, i
   }
 }
 
-template <int WIDTH, bool LEAN, class ST>
+template <int WIDTH, bool LEAN, class P, class ST>
 __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, float* const* cX, float* const* cdY,
                                        float* partials, bool diag, float* smem, Tp& tp, ST& stamp) {
   using LY = FusedLds<WIDTH>;
@@ -207,9 +207,9 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
     // ... and, the critic being scalar-output, its whole backward with unit seed as well:
     // k_dw_adam applies 2(q - y)/B per row (tp4_scalar_fb), so after y arrives only that
     // vector is left to publish
-    tp4_scalar_fb(critic, xa, h1, h2, h1 + 2 * HB, outS, scr, tp, st, row0, B, 1.f, 0, 0, nullptr, stamp);
+    tp4_scalar_fb<P>(critic, xa, h1, h2, h1 + 2 * HB, outS, scr, tp, st, row0, B, 1.f, 0, 0, nullptr, stamp);
   } else {
-    tp_fwd<WIDTH, LEAN>(critic, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
+    tp_fwd<WIDTH, LEAN, P>(critic, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
   }
   if (lead) store_rows(xa, kX0Ld, cX[0], A.cldx0, S + Ad, row0, B);
   if constexpr (LEAN) {
@@ -300,13 +300,13 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
   __syncthreads();
   if (lead) store_rows(auxS, kOutLd, cdY[2], A.clddo, 1, row0, B);
   stamp();
-  if constexpr (!LEAN) tp_bwd<WIDTH, LEAN>(critic, auxS, h1, h2, scr, tp, st, row0, B, 0, 0, auxS, stamp);
+  if constexpr (!LEAN) tp_bwd<WIDTH, LEAN, P>(critic, auxS, h1, h2, scr, tp, st, row0, B, 0, 0, auxS, stamp);
 }
 
 // (A separate template instance for the twin-critic algorithms, so that the single-critic kernel
 // carries none of their code, was measured SLOWER for all three: phase 1 15.0 vs 14.3 us for DDPG,
 // TD3 38.5 vs 36.0 us, SAC 54.5 vs 51.6 us per update — profiles/r01b_experiments.txt #29.)
-template <int WIDTH, bool LEAN, bool SAC>
+template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<WIDTH>;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
     if (A.do_actor) {   // (TD3: no actor step in every other update)
       // ---- role C: actor(s) forward.  Pack rows beyond S are zero, so [s | a] serves as input.
       const Tp3Store st{A.aX[1], A.aX[2], nullptr, nullptr, 0};
-      tp_fwd<WIDTH, LEAN>(A.actor, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
+      tp_fwd<WIDTH, LEAN, P>(A.actor, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
       if constexpr (SAC) {
         // pi(s) ~ tanh-Gaussian, its log-density (temperature step, actor seed) and the raw head output
         if (lead) {
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
       const int row = tid / Ad, col = tid - row * Ad;
       xb[row * kX0Ld + S + col] = granule_get(x_slot(role_c) + tid, x_tag);
     }
-    tp_fwd<WIDTH, LEAN>(A.critic2_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
+    tp_fwd<WIDTH, LEAN, P>(A.critic2_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
     if (lead && tid < kR) granule_put(x_slot(0) + tid, x_tag, outS[tid * kOutLd]);
     stamp();
     return;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
     // ---- role A: a' = tanh(actor_target(s')) (TD3: + clipped noise), q' = critic_target(s', a')
     // (TD3: min over the twin targets), TD target                    (ddpg.py:94-95, td3.py:83-101)
     // (SAC: a' ~ pi(s') from the online actor, log pi(a'|s') kept per row     sac.py:90-97)
-    tp_fwd<WIDTH, LEAN>(SAC ? A.actor : A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
+    tp_fwd<WIDTH, LEAN, P>(SAC ? A.actor : A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
     const bool send_a2 = A.twin_split && lead;
     unsigned long long* x_a2 = send_a2 ? x_slot(role_c) : nullptr;
     if constexpr (SAC)
@@ -413,12 +413,12 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
       xb[row * kX0Ld + S + col] = v;
     }
     // (the next GEMM's own barrier publishes xb)
-    tp_fwd<WIDTH, LEAN>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
+    tp_fwd<WIDTH, LEAN, P>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
     float qn = (tid < kR) ? outS[tid * kOutLd] : 0.f;
     if (A.twin_split) {
       if (lead && tid < kR) qn = fminf(qn, granule_get(x_slot(0) + tid, x_tag));
     } else if (A.n_critics == 2) {
-      tp_fwd<WIDTH, LEAN>(A.critic2_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
+      tp_fwd<WIDTH, LEAN, P>(A.critic2_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
       if (tid < kR) qn = fminf(qn, outS[tid * kOutLd]);
     }
     if constexpr (SAC) {
@@ -442,12 +442,12 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   // ---- role B: q = critic_j(s, a) forward (runs while role A computes the target).  The twin
   // critic gets its own copy of the code (a runtime-selected Net would leave the kernel-argument
   // registers: profiles/r01b_experiments.txt #10).
-  if (role == 2) { role_b<WIDTH, LEAN>(A, A.critic2, A.c2X, A.c2dY, A.partials_c + (size_t)gridDim.x * 4, false, smem, tp, stamp); return; }
-  role_b<WIDTH, LEAN>(A, A.critic, A.cX, A.cdY, A.partials_c, true, smem, tp, stamp);
+  if (role == 2) { role_b<WIDTH, LEAN, P>(A, A.critic2, A.c2X, A.c2dY, A.partials_c + (size_t)gridDim.x * 4, false, smem, tp, stamp); return; }
+  role_b<WIDTH, LEAN, P>(A, A.critic, A.cX, A.cdY, A.partials_c, true, smem, tp, stamp);
 }
 
 // Role B of phase 1 for one online critic (layer inputs X[], pre-activation grads dY[]).
-template <int WIDTH, bool LEAN, bool SAC>
+template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<WIDTH>;
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
       const int xr = tid / (Ad + 1), xc = tid - xr * (Ad + 1);
       const bool xmine = tid < kR * (Ad + 1);
       if (g == 1) {
-        tp4_scalar_fb(A.critic2, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp);
+        tp4_scalar_fb<P>(A.critic2, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp);
         if (lead && xmine) {
           const float v = xc < Ad ? auxS[xr * kOutLd + xc] : outS[xr * kOutLd];
           __hip_atomic_store(xq, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v),
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
         }
         return;
       }
-      tp4_scalar_fb(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp);
+      tp4_scalar_fb<P>(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp);
       if (xmine) {
         unsigned long long x = 0;
         bool ok = false;
@@ -596,9 +596,9 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
       q1p = outS; q1s = kOutLd;
       q2p = qxS; q2s = 1;
     } else {
-      tp4_scalar_fb(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp);
+      tp4_scalar_fb<P>(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp);
       if (tid < kR) qxS[tid] = outS[tid * kOutLd];
-      tp4_scalar_fb(A.critic2, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, d2S, stamp);
+      tp4_scalar_fb<P>(A.critic2, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, d2S, stamp);
     }
     if (A.partials_a != nullptr && lead && tid < 64) {
       float v = (tid < kR && row0 + tid < B) ? fminf(q1p[tid * q1s], q2p[tid * q2s]) : 0.f;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
       }
     }
     const Tp3Store sta{nullptr, nullptr, A.adY[1], A.adY[0], A.adY0_stride};
-    tp_bwd<WIDTH, LEAN>(A.actor, auxS, ha1, ha2, scr, tp, sta, row0, B, 0, 0, auxS, stamp);
+    tp_bwd<WIDTH, LEAN, P>(A.actor, auxS, ha1, ha2, scr, tp, sta, row0, B, 0, 0, auxS, stamp);
     stamp();
     return;
   }
@@ -640,9 +640,9 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
       qsum = A.partials_a + slice * 4 + 1;
       if (tid == 0) { A.partials_a[slice * 4 + 0] = 0.f; A.partials_a[slice * 4 + 2] = 0.f; }
     }
-    tp4_scalar_fb(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum);
+    tp4_scalar_fb<P>(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum);
   } else {
-    tp_fwd<WIDTH, LEAN>(A.critic, xa, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
+    tp_fwd<WIDTH, LEAN, P>(A.critic, xa, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
     stamp();
     lds_zero(auxS, kR * kOutLd);
     __syncthreads();
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
     }
   }
   if constexpr (!LEAN)
-    tp_bwd<WIDTH, LEAN>(A.critic, auxS, h1, h2, scr, tp, nostore, row0, B, S, Ad, auxS, stamp);
+    tp_bwd<WIDTH, LEAN, P>(A.critic, auxS, h1, h2, scr, tp, nostore, row0, B, S, Ad, auxS, stamp);
   stamp();   // da ready
   // ---- du = da (1 - pi^2), zero padded
   float du = 0.f;
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   }
   // ---- actor backward over its stored activations
   const Tp3Store sta{nullptr, nullptr, A.adY[1], A.adY[0], A.adY0_stride};
-  tp_bwd<WIDTH, LEAN>(A.actor, auxS, ha1, ha2, scr, tp, sta, row0, B, 0, 0, auxS, stamp);
+  tp_bwd<WIDTH, LEAN, P>(A.actor, auxS, ha1, ha2, scr, tp, sta, row0, B, 0, 0, auxS, stamp);
   stamp();
 }
 
@@ -700,12 +700,16 @@ size_t fused_ddpg_lds_bytes() { return sizeof(float) * FusedLds<256>::total; }
 size_t fused_xbuf_granules_per_cluster(int nc) { return (size_t)kTpStages * nc * kTpBlk; }
 
 hipError_t init_fused_attrs() {
-  const void* ks[6] = {reinterpret_cast<const void*>(&k_ddpg_phase1<256, false, false>),
-                       reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, false>),
-                       reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, true>),
-                       reinterpret_cast<const void*>(&k_ddpg_phase2<256, false, false>),
-                       reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false>),
-                       reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, true>)};
+  const void* ks[10] = {reinterpret_cast<const void*>(&k_ddpg_phase1<256, false, false>),
+                        reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, false>),
+                        reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, true>),
+                        reinterpret_cast<const void*>(&k_ddpg_phase2<256, false, false>),
+                        reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false>),
+                        reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, true>),
+                        reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, false, PrecBF16>),
+                        reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, true, PrecBF16>),
+                        reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false, PrecBF16>),
+                        reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, true, PrecBF16>)};
   for (const void* k : ks) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -725,7 +729,12 @@ bool fused_ddpg_is_lean(const DdpgArgs& a) {
 hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
   const dim3 grid(slices, (2 + a.n_critics) * a.nc);
-  if (a.sac) {
+  if (a.bf16) {
+    // the bf16 MFMA mode exists for the lean passes only; the nets' pf / pb point at bf16 packs
+    if (!lean_ok(a)) return hipErrorInvalidValue;
+    if (a.sac) hipLaunchKernelGGL((k_ddpg_phase1<256, true, true, PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+    else hipLaunchKernelGGL((k_ddpg_phase1<256, true, false, PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  } else if (a.sac) {
     if (!lean_ok(a)) return hipErrorInvalidValue;   // SAC is fused in the lean form only (use_fused() checks)
     hipLaunchKernelGGL((k_ddpg_phase1<256, true, true>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
   } else if (lean_ok(a)) {
@@ -740,7 +749,11 @@ hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
   // SAC side by side: one cluster per online critic; + the next-minibatch gather row
   const dim3 grid(slices, a.nc * ((a.sac && a.p2_pair) ? 2 : 1) + (a.prefetch_next ? 1 : 0));
-  if (a.sac) {
+  if (a.bf16) {
+    if (!lean_ok(a)) return hipErrorInvalidValue;
+    if (a.sac) hipLaunchKernelGGL((k_ddpg_phase2<256, true, true, PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+    else hipLaunchKernelGGL((k_ddpg_phase2<256, true, false, PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+  } else if (a.sac) {
     if (!lean_ok(a)) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_ddpg_phase2<256, true, true>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
   } else if (lean_ok(a)) {

@@ -87,6 +87,7 @@ struct DwItem {      // one Linear layer of one net
   float *w, *w_t, *w_m, *w_v, *w_g;    // [N][K] views into theta / theta_target / m / v / grad
   float *b, *b_t, *b_m, *b_v, *b_g;    // [N]
   float *pf, *pb, *tpf;                // fragment-order packs: W (fwd), W^T (bwd), target W (fwd)
+  float *pf16, *pb16, *tpf16;          // the same three as bf16 packs (PrecBF16, engine.h), or null: fp32-only learner
   int tiles_k, tile_begin, tile_end;
   int tile_n;                          // n rows per tile: kDwTileN, or 8 for a layer that sums dz1 partials
   long dY_part_stride;                 // > 0: dY is the sum of DwArgs::n_part buffers this many floats apart
@@ -97,6 +98,7 @@ struct DwItem {      // one Linear layer of one net
 struct RepackItem {  // one Linear layer: master -> packs
   const float* w; int N, K;
   float *pf, *pb;    // pb may be null (target nets are never differentiated)
+  float *pf16, *pb16; // bf16 packs (bf16 learners), or null
   int blk_begin, blk_end;   // 256-element blocks of the N*K index space
 };
 
@@ -245,6 +247,7 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   float *y_out, *q_out;                // [B] diagnostics / parity
   unsigned long long* y_granules;      // [B] {epoch<<32 | float bits}: TD target hand-off between roles
   unsigned epoch;                      // monotonically increasing per update, never 0
+  int bf16;                            // 1: the nets' pf / pb are bf16 packs and the lean passes run PrecBF16 (engine.h)
   int nc;                              // CUs per slice cluster (tensor-parallel, csrc/tp3.h): 1, 2 or 4
   int no_lean;                         // 1: never use the tp4.h specialisation (OPRL_AMD_NO_LEAN, tests)
   unsigned long long* xbuf;            // cluster exchange areas: [role][slice][kTpStages][nc][kTpBlk] granules

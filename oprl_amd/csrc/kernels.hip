@@ -366,6 +366,36 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
       }
     }
   }
+  if (A.ad.do_adam && I.pf16 != nullptr) {
+    // ... and the bf16 packs (PrecBF16, engine.h): a bf16 macro step = fp32 steps 2s, 2s + 1 side by
+    // side, so this 16 x 32 tile is ONE forward fragment block (64 lanes x 16 B, online and target) and,
+    // for W^T, one HALF (8 B per lane) of a block for each of its two 16-row k tiles — the other half
+    // belongs to the neighbouring n tile.  Same staged tiles, no further barrier.
+    const float (*tileW)[LD] = part[0];
+    const float (*tileT)[LD] = part[1];
+    const int NSk2 = cdiv(I.K, 32), NSn2 = cdiv(I.N, 32);
+    if (tid < 128) {             // W packs: which = online / target
+      const int which = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
+      float* dst = which == 0 ? I.pf16 : (polyak ? I.tpf16 : nullptr);
+      if (dst != nullptr && li >= n_off && li < n_off + TNi) {
+        const float (*src)[LD] = which == 0 ? tileW : tileT;
+        const bf16x8 v = cvt_bf16x8(*reinterpret_cast<const f32x4*>(&src[li][4 * lk]),
+                                    *reinterpret_cast<const f32x4*>(&src[li][16 + 4 * lk]));
+        *reinterpret_cast<bf16x8*>(dst + (((size_t)ptile * NSk2 + tk) * 64 + l) * 4) = v;
+      }
+    } else if (tid < 256 && I.pb16 != nullptr) {   // W^T pack: k tile 2 tk + blk, n step n_base / 32, half (n_base / 16) & 1
+      const int q = tid - 128, blk = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
+      const int ktile = 2 * tk + blk;
+      if (16 * ktile < I.K && 4 * lk >= n_off && 4 * lk < n_off + TNi) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        f32x4 v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = tileW[4 * lk + t][16 * blk + li];
+        const bf16x4 h = __builtin_convertvector(v, bf16x4);
+        *reinterpret_cast<bf16x4*>(I.pb16 + (((size_t)ktile * NSn2 + (n_base >> 5)) * 64 + l) * 4 + 2 * ((n_base >> 4) & 1)) = h;
+      }
+    }
+  }
   if (tk == 0 && tid < TNi) {
     const int n = n_base + tid;
     if (n < I.N) {
@@ -521,6 +551,8 @@ __global__ void k_repack(const RepackItem* items, int n_items) {
   const float w = I.w[e];
   if (I.pf != nullptr) I.pf[pack_index(n, k, cdiv(I.K, 16))] = w;
   if (I.pb != nullptr) I.pb[pack_index(k, n, cdiv(I.N, 16))] = w;
+  if (I.pf16 != nullptr) reinterpret_cast<__bf16*>(I.pf16)[pack16_index(n, k, cdiv(I.K, 32))] = (__bf16)w;
+  if (I.pb16 != nullptr) reinterpret_cast<__bf16*>(I.pb16)[pack16_index(k, n, cdiv(I.N, 32))] = (__bf16)w;
 }
 
 // ---------------------------------------------------------------------------

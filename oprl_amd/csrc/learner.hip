@@ -262,6 +262,15 @@ long pack_off_fwd(const oprl_net& n, int l) {
 long pack_off_bwd(const oprl_net& n, int l) { return pack_off_fwd(n, l) + pack_floats(n.dims[l + 1], n.dims[l]); }
 long net_pack_floats(const oprl_net& n) { return pack_off_fwd(n, n.n_layers); }
 
+// the same for the bf16 packs (library-owned, oprl_learner::pack16 / pack16_t), in floats (16-byte fragments)
+long pack16_off_fwd(const oprl_net& n, int l) {
+  long c = 0;
+  for (int j = 0; j < l; ++j) c += pack16_floats(n.dims[j + 1], n.dims[j]) + pack16_floats(n.dims[j], n.dims[j + 1]);
+  return c;
+}
+long pack16_off_bwd(const oprl_net& n, int l) { return pack16_off_fwd(n, l) + pack16_floats(n.dims[l + 1], n.dims[l]); }
+long net_pack16_floats(const oprl_net& n) { return pack16_off_fwd(n, n.n_layers); }
+
 Net net_view(const oprl_net& n, bool target) {
   Net v;
   memset(&v, 0, sizeof v);
@@ -279,6 +288,16 @@ Net net_view(const oprl_net& n, bool target) {
 
 // per-net activation / gradient exchange buffers (HBM, sized for max_batch rows)
 constexpr int kMaxCluster = 4;   // CUs per tensor-parallel slice cluster (csrc/tp3.h)
+
+// a Net whose pf / pb point at the bf16 packs (for the PrecBF16 kernels only)
+Net net_view16(const oprl_net& n, bool target, const float* pk16) {
+  Net v = net_view(n, target);
+  for (int l = 0; l < n.n_layers; ++l) {
+    v.pf[l] = pk16 + pack16_off_fwd(n, l);
+    v.pb[l] = pk16 + pack16_off_bwd(n, l);
+  }
+  return v;
+}
 
 struct NetWs {
   float* X[kMaxLayers] = {nullptr, nullptr, nullptr, nullptr};
@@ -381,6 +400,12 @@ struct oprl_learner {
   // seed and, in a data-parallel job, the rank — every seed and every rank draws its own eps
   uint64_t noise_seed = 0;
   int noise_rank = 0;
+  // OPRL_PREC_BF16: bf16 fragment packs of every net (online: forward + backward, target: forward),
+  // derived state owned by the library and written by the dW + Adam epilogues / k_repack; index 0 = actor,
+  // 1 + j = critic j
+  bool bf16 = false;
+  float* pack16[OPRL_MAX_CRITICS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* pack16_t[OPRL_MAX_CRITICS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // prebuilt device repack tables: [0] critics online, [1] critics online+target, [2] actor (+target)
   RepackItem* rp_dev[3] = {nullptr, nullptr, nullptr};
   int rp_n[3] = {0, 0, 0}, rp_blocks[3] = {0, 0, 0};
@@ -388,7 +413,8 @@ struct oprl_learner {
 
 namespace {
 
-void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int* tiles, bool small_partial_tiles = false) {
+void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int* tiles, bool small_partial_tiles = false,
+                float* pk16 = nullptr, float* pk16_t = nullptr) {
   for (int l = 0; l < n.n_layers; ++l) {
     DwItem it;
     memset(&it, 0, sizeof it);
@@ -408,6 +434,9 @@ void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int*
     it.pf = n.pack + pack_off_fwd(n, l);
     it.pb = n.pack + pack_off_bwd(n, l);
     it.tpf = n.pack_target ? n.pack_target + pack_off_fwd(n, l) : nullptr;
+    it.pf16 = pk16 ? pk16 + pack16_off_fwd(n, l) : nullptr;
+    it.pb16 = pk16 ? pk16 + pack16_off_bwd(n, l) : nullptr;
+    it.tpf16 = (pk16_t && n.theta_target) ? pk16_t + pack16_off_fwd(n, l) : nullptr;
     it.dY_part_stride = (l == 0 && n.n_layers > 1) ? ws.dY0_stride : 0;
     it.scaled = (l < n.n_layers - 1) ? 1 : 0;
     it.rs = ws.dY[n.n_layers - 1];
@@ -744,6 +773,17 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   a.cdY0_stride = h->ws_critic[0].dY0_stride;
   a.adY0_stride = h->ws_actor.dY0_stride;
   a.partials_c = h->part_c; a.partials_a = h->part_a;
+  if (h->bf16 && fused_ddpg_is_lean(a)) {   // the PrecBF16 instances of the (lean) phase kernels: every net through its bf16 packs
+    a.bf16 = 1;
+    a.actor = net_view16(c.actor, false, h->pack16[0]);
+    if (c.actor.theta_target) a.actor_t = net_view16(c.actor, true, h->pack16_t[0]);
+    a.critic = net_view16(c.critics[0], false, h->pack16[1]);
+    a.critic_t = net_view16(c.critics[0], true, h->pack16_t[1]);
+    if (h->nc == 2) {
+      a.critic2 = net_view16(c.critics[1], false, h->pack16[2]);
+      a.critic2_t = net_view16(c.critics[1], true, h->pack16_t[2]);
+    }
+  }
   return a;
 }
 
@@ -1006,7 +1046,8 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
 // master -> packs for a list of nets (which: bit0 online, bit1 target).  The item
 // table goes through a small device scratch; synchronous on `st` only.
 void build_repack_items(const oprl_net* const* nets, int n_nets, int which,
-                        std::vector<RepackItem>& items, int* blocks_out) {
+                        std::vector<RepackItem>& items, int* blocks_out,
+                        float* const* pk16 = nullptr, float* const* pk16_t = nullptr) {
   int blocks = 0;
   for (int i = 0; i < n_nets; ++i) {
     const oprl_net& n = *nets[i];
@@ -1021,6 +1062,9 @@ void build_repack_items(const oprl_net* const* nets, int n_nets, int which,
         it.N = n.dims[l + 1]; it.K = n.dims[l];
         it.pf = pk + pack_off_fwd(n, l);
         it.pb = pass == 0 ? pk + pack_off_bwd(n, l) : nullptr;
+        float* p16 = pass == 0 ? (pk16 ? pk16[i] : nullptr) : (pk16_t ? pk16_t[i] : nullptr);
+        it.pf16 = p16 ? p16 + pack16_off_fwd(n, l) : nullptr;
+        it.pb16 = (p16 && pass == 0) ? p16 + pack16_off_bwd(n, l) : nullptr;
         it.blk_begin = blocks;
         blocks += (int)(((long)it.N * it.K + 255) / 256);
         it.blk_end = blocks;
@@ -1031,10 +1075,11 @@ void build_repack_items(const oprl_net* const* nets, int n_nets, int which,
   *blocks_out = blocks;
 }
 
-int repack_nets(const oprl_net* const* nets, int n_nets, int which, hipStream_t st) {
+int repack_nets(const oprl_net* const* nets, int n_nets, int which, hipStream_t st,
+                float* const* pk16 = nullptr, float* const* pk16_t = nullptr) {
   std::vector<RepackItem> items;
   int blocks = 0;
-  build_repack_items(nets, n_nets, which, items, &blocks);
+  build_repack_items(nets, n_nets, which, items, &blocks, pk16, pk16_t);
   if (items.empty()) return OPRL_OK;
   RepackItem* dev = nullptr;
   HIPC(hipMalloc(&dev, sizeof(RepackItem) * items.size()));
@@ -1299,7 +1344,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   if (!cfg || !out) { set_err("oprl_learner_create: null argument"); return OPRL_ERR_INVALID; }
   if (cfg->abi_version != OPRL_ABI_VERSION) { set_err("ABI version mismatch: caller %d, library %d", cfg->abi_version, OPRL_ABI_VERSION); return OPRL_ERR_INVALID; }
   if (cfg->algo < OPRL_DDPG || cfg->algo > OPRL_TQC) { set_err("unknown algo %d", cfg->algo); return OPRL_ERR_INVALID; }
-  if (cfg->precision != OPRL_PREC_F32) { set_err("precision %d not built", cfg->precision); return OPRL_ERR_INVALID; }
+  if (cfg->precision != OPRL_PREC_F32 && cfg->precision != OPRL_PREC_BF16) { set_err("precision %d unknown", cfg->precision); return OPRL_ERR_INVALID; }
   const int nc_expect = cfg->algo == OPRL_DDPG ? 1 : (cfg->algo == OPRL_TQC ? cfg->n_critics : 2);
   if (cfg->n_critics != nc_expect || cfg->n_critics < 1 || cfg->n_critics > OPRL_MAX_CRITICS) {
     set_err("n_critics=%d invalid for algo %d", cfg->n_critics, cfg->algo);
@@ -1309,6 +1354,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   auto* h = new oprl_learner();
   h->cfg = *cfg;
   h->S = cfg->state_dim; h->A = cfg->action_dim; h->Bmax = cfg->max_batch; h->nc = cfg->n_critics;
+  h->bf16 = cfg->precision == OPRL_PREC_BF16;
   int rc = check_net(cfg->actor, "actor", &h->w_actor);
   for (int j = 0; rc == OPRL_OK && j < h->nc; ++j) {
     int w = 0;
@@ -1374,6 +1420,10 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   floats += (size_t)(nc + 1) * n_slices * 4 + 16;
   floats += (size_t)B * (2 * S + A + 2);
   floats += 64 * 32 + 2 * (size_t)B;
+  if (h->bf16) {
+    floats += 2 * ((size_t)net_pack16_floats(cfg->actor) + 64);
+    for (int j = 0; j < nc; ++j) floats += 2 * ((size_t)net_pack16_floats(cfg->critics[j]) + 64);
+  }
   const size_t bytes = floats * sizeof(float) + 8192 + sizeof(DwItem) * (size_t)(nc + 1) * kMaxLayers +
                        sizeof(RepackItem) * (size_t)(4 * nc + 4) * kMaxLayers;
   if (hipMalloc(&h->pool.base, bytes) != hipSuccess) { set_err("hipMalloc(%zu) failed", bytes); delete h; return OPRL_ERR_NOMEM; }
@@ -1403,10 +1453,19 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   h->br = p.take<float>(B);
   h->bd = p.take<float>(B);
   h->bs2 = p.take<float>((size_t)B * S);
+  if (h->bf16) {   // (the pool is zeroed: pad positions of the packs stay zero for good)
+    h->pack16[0] = p.take<float>((size_t)net_pack16_floats(cfg->actor));
+    h->pack16_t[0] = p.take<float>((size_t)net_pack16_floats(cfg->actor));
+    for (int j = 0; j < nc; ++j) {
+      h->pack16[1 + j] = p.take<float>((size_t)net_pack16_floats(cfg->critics[j]));
+      h->pack16_t[1 + j] = p.take<float>((size_t)net_pack16_floats(cfg->critics[j]));
+    }
+  }
   std::vector<DwItem> items;
-  for (int j = 0; j < nc; ++j) fill_items(cfg->critics[j], h->ws_critic[j], items, &h->tiles_critic, h->fused);
+  for (int j = 0; j < nc; ++j)
+    fill_items(cfg->critics[j], h->ws_critic[j], items, &h->tiles_critic, h->fused, h->pack16[1 + j], h->pack16_t[1 + j]);
   h->n_items_critic = (int)items.size();
-  fill_items(cfg->actor, h->ws_actor, items, &h->tiles_actor, h->fused);
+  fill_items(cfg->actor, h->ws_actor, items, &h->tiles_actor, h->fused, h->pack16[0], h->pack16_t[0]);
   h->n_items_actor = (int)items.size() - h->n_items_critic;
   h->items_host = items;
   std::vector<RepackItem> rp[3];
@@ -1464,7 +1523,10 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     const oprl_net* nets[OPRL_MAX_CRITICS + 1];
     for (int j = 0; j < nc; ++j) nets[j] = &h->cfg.critics[j];
     nets[nc] = &h->cfg.actor;
-    int prc = repack_nets(nets, nc + 1, 3, nullptr);
+    float *p16[OPRL_MAX_CRITICS + 1], *p16t[OPRL_MAX_CRITICS + 1];
+    for (int j = 0; j < nc; ++j) { p16[j] = h->pack16[1 + j]; p16t[j] = h->pack16_t[1 + j]; }
+    p16[nc] = h->pack16[0]; p16t[nc] = h->pack16_t[0];
+    int prc = repack_nets(nets, nc + 1, 3, nullptr, h->bf16 ? p16 : nullptr, h->bf16 ? p16t : nullptr);
     if (prc != OPRL_OK) { (void)hipFree(p.base); delete h; return prc; }
   }
   *out = h;
@@ -1476,7 +1538,10 @@ extern "C" int oprl_learner_sync_params(oprl_learner* h, void* stream) {
   const oprl_net* nets[OPRL_MAX_CRITICS + 1];
   for (int j = 0; j < h->nc; ++j) nets[j] = &h->cfg.critics[j];
   nets[h->nc] = &h->cfg.actor;
-  return repack_nets(nets, h->nc + 1, 3, (hipStream_t)stream);
+  float *p16[OPRL_MAX_CRITICS + 1], *p16t[OPRL_MAX_CRITICS + 1];
+  for (int j = 0; j < h->nc; ++j) { p16[j] = h->pack16[1 + j]; p16t[j] = h->pack16_t[1 + j]; }
+  p16[h->nc] = h->pack16[0]; p16t[h->nc] = h->pack16_t[0];
+  return repack_nets(nets, h->nc + 1, 3, (hipStream_t)stream, h->bf16 ? p16 : nullptr, h->bf16 ? p16t : nullptr);
 }
 
 extern "C" int64_t oprl_net_pack_floats(const oprl_net* net) {

@@ -30,9 +30,20 @@ namespace oprl {
 
 constexpr int kW4 = 256;
 constexpr int kWL4 = lds_ld(kW4);
-constexpr int kTpc4 = 4;                      // tiles (= macro steps) per member
+constexpr int kTpc4 = 4;                      // 16-column tiles per member
 constexpr int kCols4 = kTpc4 * 16;            // hidden columns per member
-constexpr int kMaxS0 = 6;                     // layer-0 macro steps: fan-in <= 96 (humanoid S + A = 88)
+constexpr int kMaxS0 = 6;                     // layer-0 fp32 macro steps: fan-in <= 96 (humanoid S + A = 88)
+
+// Every pass is a template over the precision policy P (engine.h): the stage structure, barriers,
+// exchanges and epilogues are the same, only the macro step changes — 16 contraction indices and
+// four fp32 MFMAs (PrecF32, the parity mode) or 32 indices and one bf16 MFMA (PrecBF16).  Step
+// counts of the fixed shapes:
+template <class P> struct Tp4Steps {
+  static constexpr int W = kW4 / P::KS;       // the whole 256-deep contraction: 16 / 8
+  static constexpr int M = kCols4 / P::KS;    // a member's 64 columns: 4 / 2
+  static constexpr int S0 = 16 * kMaxS0 / P::KS;   // widest layer-0 input: 6 / 3
+  static constexpr int O = (kNarrowMax + P::KS - 1) / P::KS;   // widest output: 3 / 2
+};
 
 __host__ __device__ inline bool tp4_shape_ok(int width, int fan_in, int n_out) {
   return width == kW4 && fan_in <= 16 * kMaxS0 && n_out <= kNarrowMax;
@@ -93,39 +104,40 @@ __device__ __forceinline__ f32x4 tp4_allreduce_regs(const f32x4 mine, int col, b
   return sum;
 }
 
-template <class ST = NoStamp>
+template <class P = PrecF32, class ST = NoStamp>
 __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, float* h1, float* h2,
                                             float* outS, Tp& tp, const Tp3Store& st, int row0, int B,
                                             ST sf = ST()) {
+  using NS = Tp4Steps<P>;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
   const int c = tp.c, c0 = c * kCols4;
   const int N = net.dims[3];
-  const int NS0 = (net.dims[0] + 15) >> 4, NTo = (N + 15) >> 4;
+  const int NS0 = (net.dims[0] + P::KS - 1) / P::KS, NTo = (N + 15) >> 4;
   const int t2 = wave - 4;                    // output tile of waves 4..4+NTo-1
   const bool l2_wave = t2 >= 0 && t2 < NTo;
 
   // ---- requests for the whole pass
-  f32x4 w0[kMaxS0], wq[16];
+  f32x4 w0[NS::S0], wq[NS::W];
   {
     const float* p0 = net.pf[0] + ((size_t)wave * NS0 * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < kMaxS0; ++s) w0[s] = s < NS0 ? ld4(p0 + s * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < NS::S0; ++s) w0[s] = s < NS0 ? ld4(p0 + s * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float bias0 = net.b[0][16 * wave + i];
   float bias12 = 0.f;
 #pragma unroll
-  for (int s = 0; s < 16; ++s) wq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < NS::W; ++s) wq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (wave < kTpc4) {
-    const float* p1 = net.pf[1] + ((size_t)(c * kTpc4 + wave) * 16 * 64 + lane) * 4;
+    const float* p1 = net.pf[1] + ((size_t)(c * kTpc4 + wave) * NS::W * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) wq[s] = ld4(p1 + s * 256);
+    for (int s = 0; s < NS::W; ++s) wq[s] = ld4(p1 + s * 256);
     bias12 = net.b[1][c0 + 16 * wave + i];
   } else if (l2_wave) {
-    const float* p2 = net.pf[2] + (((size_t)t2 * 16 + c * kTpc4) * 64 + lane) * 4;
+    const float* p2 = net.pf[2] + (((size_t)t2 * NS::W + c * NS::M) * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < kTpc4; ++s) wq[s] = ld4(p2 + s * 256);
+    for (int s = 0; s < NS::M; ++s) wq[s] = ld4(p2 + s * 256);
     if (16 * t2 + i < N) bias12 = net.b[2][16 * t2 + i];
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -136,8 +148,8 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* xr = x0s + i * kX0Ld + 4 * kk;
 #pragma unroll
-    for (int s = 0; s < kMaxS0; ++s)
-      if (s < NS0) mac4(ld4(xr + 16 * s), w0[s], acc);
+    for (int s = 0; s < NS::S0; ++s)
+      if (s < NS0) P::mac(xr, s, w0[s], acc);
     float* o = h1 + (kk * 4) * kWL4 + 16 * wave + i;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r * kWL4] = fmaxf(acc[r] + bias0, 0.f);
@@ -150,9 +162,9 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
     f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
     const float* hr = h1 + i * kWL4 + 4 * kk;
 #pragma unroll
-    for (int s = 0; s < 16; s += 2) {
-      mac4(ld4(hr + 16 * s), wq[s], a0);
-      mac4(ld4(hr + 16 * s + 16), wq[s + 1], a1);
+    for (int s = 0; s < NS::W; s += 2) {
+      P::mac(hr, s, wq[s], a0);
+      P::mac(hr, s + 1, wq[s + 1], a1);
     }
     float* o = h2 + (kk * 4) * kWL4 + c0 + 16 * wave + i;
 #pragma unroll
@@ -170,10 +182,11 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
   if (l2_wave) {
     f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
     const float* hr = h2 + i * kWL4 + c0 + 4 * kk;
-    mac4(ld4(hr), wq[0], a0);
-    mac4(ld4(hr + 16), wq[1], a1);
-    mac4(ld4(hr + 32), wq[2], a0);
-    mac4(ld4(hr + 48), wq[3], a1);
+#pragma unroll
+    for (int s = 0; s < NS::M; s += 2) {
+      P::mac(hr, s, wq[s], a0);
+      P::mac(hr, s + 1, wq[s + 1], a1);
+    }
     const int col = 16 * t2 + i;
     const bool valid = col < N;
     const f32x4 sum = tp4_allreduce_regs(a0 + a1, col, valid, tp);
@@ -191,15 +204,17 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
   sf();
 }
 
-template <class ST = NoStamp>
+template <class P = PrecF32, class ST = NoStamp>
 __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS, float* h1, float* h2,
                                              float* scr, Tp& tp, const Tp3Store& st, int row0, int B,
                                              int dact_col0, int dact_cols, float* dactS, ST sf = ST()) {
+  using NS = Tp4Steps<P>;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
   const int c = tp.c, c0 = c * kCols4;
-  const int NSo = (net.dims[3] + 15) >> 4;
+  const int No16 = (net.dims[3] + 15) >> 4;                  // valid 16-column groups of dout
+  const int NSo = (net.dims[3] + P::KS - 1) / P::KS;
   const bool dact = dact_cols > 0;
   // input-column gradient: only the 16-column tiles that overlap [dact_col0, +dact_cols)
   // (at most 4: one wave per tile and contraction quarter)
@@ -208,26 +223,26 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
   const bool dact_wave = dact && dt < dnt;
 
   // ---- requests
-  f32x4 wo[3], wz[4], wd[4];
+  f32x4 wo[NS::O], wz[NS::M], wd[NS::M];
 #pragma unroll
-  for (int s = 0; s < 3; ++s) wo[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < NS::O; ++s) wo[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (wave < kTpc4) {
     const float* q2 = net.pb[2] + ((size_t)(c * kTpc4 + wave) * NSo * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < NS::O; ++s)
       if (s < NSo) wo[s] = ld4(q2 + s * 256);
   }
   {
-    const float* q1 = net.pb[1] + (((size_t)wave * 16 + c * kTpc4) * 64 + lane) * 4;
+    const float* q1 = net.pb[1] + (((size_t)wave * NS::W + c * NS::M) * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wz[s] = ld4(q1 + s * 256);
+    for (int s = 0; s < NS::M; ++s) wz[s] = ld4(q1 + s * 256);
   }
 #pragma unroll
-  for (int s = 0; s < 4; ++s) wd[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < NS::M; ++s) wd[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (dact_wave) {
-    const float* q0 = net.pb[0] + (((size_t)(dt0 + dt) * 16 + dpart * 4) * 64 + lane) * 4;
+    const float* q0 = net.pb[0] + (((size_t)(dt0 + dt) * NS::W + dpart * NS::M) * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wd[s] = ld4(q0 + s * 256);
+    for (int s = 0; s < NS::M; ++s) wd[s] = ld4(q0 + s * 256);
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();   // dout visible
@@ -237,8 +252,8 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* dr = doutS + i * kOutLd + 4 * kk;
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
-      if (s < NSo) mac4(ld4(dr + 16 * s), wo[s], acc);
+    for (int s = 0; s < NS::O; ++s)
+      if (s < NSo) P::mac_tail(dr, s, wo[s], acc, No16);
     float* p = h2 + (kk * 4) * kWL4 + c0 + 16 * wave + i;
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[r * kWL4] = p[r * kWL4] > 0.f ? acc[r] : 0.f;
@@ -250,10 +265,11 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
   {
     f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
     const float* hr = h2 + i * kWL4 + c0 + 4 * kk;
-    mac4(ld4(hr), wz[0], a0);
-    mac4(ld4(hr + 16), wz[1], a1);
-    mac4(ld4(hr + 32), wz[2], a0);
-    mac4(ld4(hr + 48), wz[3], a1);
+#pragma unroll
+    for (int s = 0; s < NS::M; s += 2) {
+      P::mac(hr, s, wz[s], a0);
+      P::mac(hr, s + 1, wz[s + 1], a1);
+    }
     float* p = h1 + (kk * 4) * kWL4 + 16 * wave + i;
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[r * kWL4] = p[r * kWL4] > 0.f ? a0[r] + a1[r] : 0.f;
@@ -278,10 +294,11 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
     if (dact_wave) {
       f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
       const float* hr = h1 + i * kWL4 + 64 * dpart + 4 * kk;
-      mac4(ld4(hr), wd[0], a0);
-      mac4(ld4(hr + 16), wd[1], a1);
-      mac4(ld4(hr + 32), wd[2], a0);
-      mac4(ld4(hr + 48), wd[3], a1);
+#pragma unroll
+      for (int s = 0; s < NS::M; s += 2) {
+        P::mac(hr, s, wd[s], a0);
+        P::mac(hr, s + 1, wd[s + 1], a1);
+      }
       *reinterpret_cast<f32x4*>(scr + wave * 256 + lane * 4) = a0 + a1;
     }
     sf();
@@ -325,7 +342,7 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
 //         [quarters] gather + all-reduce -> dactS            (if wanted)
 // g2: one more [kR][kWL4] LDS buffer.  tp.stage advances by 1 (2 with dact).
 // ---------------------------------------------------------------------------------------
-template <class ST = NoStamp>
+template <class P = PrecF32, class ST = NoStamp>
 __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, float* h1, float* h2,
                                               float* g2, float* outS, float* scr, Tp& tp,
                                               const Tp3Store& st, int row0, int B, float seed,
@@ -337,7 +354,8 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
   const int c = tp.c, c0 = c * kCols4;
-  const int NS0 = (net.dims[0] + 15) >> 4;          // layer-0 steps
+  using NS = Tp4Steps<P>;
+  const int NS0 = (net.dims[0] + P::KS - 1) / P::KS;   // layer-0 steps
   const bool dact = dact_cols > 0;
   const int dt0 = dact_col0 >> 4, dnt = dact ? ((dact_col0 + dact_cols - 1) >> 4) - dt0 + 1 : 0;
   const int dt = wave >> 2, dpart = wave & 3;
@@ -345,26 +363,26 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   constexpr int kOutWave = 12;
 
   // ---- requests
-  f32x4 w0[kMaxS0], wq[16], wz[4], wd[4];
+  f32x4 w0[NS::S0], wq[NS::W], wz[NS::M], wd[NS::M];
   {
     const float* p0 = net.pf[0] + ((size_t)wave * NS0 * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < kMaxS0; ++s) w0[s] = s < NS0 ? ld4(p0 + s * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < NS::S0; ++s) w0[s] = s < NS0 ? ld4(p0 + s * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float bias0 = net.b[0][16 * wave + i];
   float bias12 = 0.f, w3 = 0.f;
 #pragma unroll
-  for (int s = 0; s < 16; ++s) wq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < NS::W; ++s) wq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (wave < kTpc4) {
-    const float* p1 = net.pf[1] + ((size_t)(c * kTpc4 + wave) * 16 * 64 + lane) * 4;
+    const float* p1 = net.pf[1] + ((size_t)(c * kTpc4 + wave) * NS::W * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) wq[s] = ld4(p1 + s * 256);
+    for (int s = 0; s < NS::W; ++s) wq[s] = ld4(p1 + s * 256);
     bias12 = net.b[1][c0 + 16 * wave + i];
-    w3 = net.pb[2][((size_t)(c * kTpc4 + wave) * 64 + i) * 4];   // W3[c0 + 16 wave + i]  (NSo = 1)
+    w3 = P::first(net.pb[2] + ((size_t)(c * kTpc4 + wave) * 64 + i) * 4);   // W3[c0 + 16 wave + i]  (one step)
   } else if (wave == kOutWave) {
-    const float* p2 = net.pf[2] + (((size_t)c * kTpc4) * 64 + lane) * 4;
+    const float* p2 = net.pf[2] + (((size_t)c * NS::M) * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < kTpc4; ++s) wq[s] = ld4(p2 + s * 256);
+    for (int s = 0; s < NS::M; ++s) wq[s] = ld4(p2 + s * 256);
     if (i == 0) bias12 = net.b[2][0];
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -375,16 +393,16 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* xr = x0s + i * kX0Ld + 4 * kk;
 #pragma unroll
-    for (int s = 0; s < kMaxS0; ++s)
-      if (s < NS0) mac4(ld4(xr + 16 * s), w0[s], acc);
+    for (int s = 0; s < NS::S0; ++s)
+      if (s < NS0) P::mac(xr, s, w0[s], acc);
     float* o = h1 + (kk * 4) * kWL4 + 16 * wave + i;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r * kWL4] = fmaxf(acc[r] + bias0, 0.f);
   }
   {
-    const float* q1 = net.pb[1] + (((size_t)wave * 16 + c * kTpc4) * 64 + lane) * 4;
+    const float* q1 = net.pb[1] + (((size_t)wave * NS::W + c * NS::M) * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wz[s] = ld4(q1 + s * 256);
+    for (int s = 0; s < NS::M; ++s) wz[s] = ld4(q1 + s * 256);
   }
   sf();
   __syncthreads();   // h1 visible
@@ -394,9 +412,9 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
     f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
     const float* hr = h1 + i * kWL4 + 4 * kk;
 #pragma unroll
-    for (int s = 0; s < 16; s += 2) {
-      mac4(ld4(hr + 16 * s), wq[s], a0);
-      mac4(ld4(hr + 16 * s + 16), wq[s + 1], a1);
+    for (int s = 0; s < NS::W; s += 2) {
+      P::mac(hr, s, wq[s], a0);
+      P::mac(hr, s + 1, wq[s + 1], a1);
     }
     const int off = (kk * 4) * kWL4 + c0 + 16 * wave + i;
     const float gz = seed * w3;
@@ -413,11 +431,11 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
     }
   }
 #pragma unroll
-  for (int s = 0; s < 4; ++s) wd[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < NS::M; ++s) wd[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (dact_wave) {
-    const float* q0 = net.pb[0] + (((size_t)(dt0 + dt) * 16 + dpart * 4) * 64 + lane) * 4;
+    const float* q0 = net.pb[0] + (((size_t)(dt0 + dt) * NS::W + dpart * NS::M) * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wd[s] = ld4(q0 + s * 256);
+    for (int s = 0; s < NS::M; ++s) wd[s] = ld4(q0 + s * 256);
   }
   sf();
   __syncthreads();   // h2, g2 (the member's columns) visible
@@ -426,10 +444,11 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   {
     f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
     const float* gr_ = g2 + i * kWL4 + c0 + 4 * kk;
-    mac4(ld4(gr_), wz[0], a0);
-    mac4(ld4(gr_ + 16), wz[1], a1);
-    mac4(ld4(gr_ + 32), wz[2], a0);
-    mac4(ld4(gr_ + 48), wz[3], a1);
+#pragma unroll
+    for (int s = 0; s < NS::M; s += 2) {
+      P::mac(gr_, s, wz[s], a0);
+      P::mac(gr_, s + 1, wz[s + 1], a1);
+    }
     float* p = h1 + (kk * 4) * kWL4 + 16 * wave + i;
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[r * kWL4] = p[r * kWL4] > 0.f ? a0[r] + a1[r] : 0.f;
@@ -456,10 +475,11 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   if (dact_wave) {
     f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
     const float* hr = h1 + i * kWL4 + 64 * dpart + 4 * kk;
-    mac4(ld4(hr), wd[0], a0);
-    mac4(ld4(hr + 16), wd[1], a1);
-    mac4(ld4(hr + 32), wd[2], a0);
-    mac4(ld4(hr + 48), wd[3], a1);
+#pragma unroll
+    for (int s = 0; s < NS::M; s += 2) {
+      P::mac(hr, s, wd[s], a0);
+      P::mac(hr, s + 1, wd[s + 1], a1);
+    }
     *reinterpret_cast<f32x4*>(scr + wave * 256 + lane * 4) = a0 + a1;
   }
   if (dact) {
@@ -471,10 +491,11 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   if (wave == kOutWave) {
     f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
     const float* hr = h2 + i * kWL4 + c0 + 4 * kk;
-    mac4(ld4(hr), wq[0], a0);
-    mac4(ld4(hr + 16), wq[1], a1);
-    mac4(ld4(hr + 32), wq[2], a0);
-    mac4(ld4(hr + 48), wq[3], a1);
+#pragma unroll
+    for (int s = 0; s < NS::M; s += 2) {
+      P::mac(hr, s, wq[s], a0);
+      P::mac(hr, s + 1, wq[s + 1], a1);
+    }
     const bool valid = i == 0;
     const f32x4 sum = tp4_allreduce_regs(a0 + a1, i, valid, tp);
     float* o = outS + (kk * 4) * kOutLd + i;

@@ -63,12 +63,42 @@ def clone_params(p: list[t.Tensor]) -> list[t.Tensor]:
 # --------------------------------------------------------------------------- #
 # MLP forward / backward (nn_models.py:84-107; ReLU hidden, identity output)  #
 # --------------------------------------------------------------------------- #
+# Emulation of the HIP library's OPRL_PREC_BF16 mode (include/oprl_amd.h): both operands of every
+# forward / backward GEMM are rounded to bf16 (round-to-nearest-even, what v_cvt_pk_bf16_f32 does) and
+# multiplied / accumulated in fp32; master weights, biases, activations, dW, Adam and Polyak stay fp32.
+# Not part of the reference (which is fp32 throughout): it pins what the bf16 kernels claim to compute,
+# the fp32 oracle measures how far that is from the reference.
+GEMM_BF16 = False
+
+
+class bf16_gemm:
+    """``with bf16_gemm(): ...`` — run the oracle with bf16-rounded GEMM operands."""
+
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        global GEMM_BF16
+        self.saved = GEMM_BF16
+        GEMM_BF16 = self.on
+        return self
+
+    def __exit__(self, *exc):
+        global GEMM_BF16
+        GEMM_BF16 = self.saved
+        return False
+
+
+def _q(x: t.Tensor) -> t.Tensor:
+    return x.to(t.bfloat16).to(F32) if GEMM_BF16 else x
+
+
 def mlp_forward(p: list[t.Tensor], x: t.Tensor) -> list[t.Tensor]:
     """Returns [x0, x1, ..., x_{L-1}, out]; x_l is the *input* of layer l."""
     acts = [x]
     n_layers = len(p) // 2
     for l in range(n_layers):
-        z = t.addmm(p[2 * l + 1], acts[-1], p[2 * l].t())
+        z = t.addmm(p[2 * l + 1], _q(acts[-1]), _q(p[2 * l]).t())
         if l < n_layers - 1:
             z = t.relu(z)
         acts.append(z)
@@ -82,14 +112,42 @@ def mlp_backward(p: list[t.Tensor], acts: list[t.Tensor], dout: t.Tensor,
     grads: list[Optional[t.Tensor]] = [None] * (2 * n_layers)
     dz = dout
     dx = None
+    # bf16 emulation of a scalar-output net (a critic): the kernels run its backward with a UNIT seed
+    # (the backward is linear in the per-row seed) and apply the seed per row afterwards in fp32
+    # (csrc/tp4.h tp4_scalar_fb), so the seed itself is never rounded to bf16
+    row_scale = None
+    parts = None
+    if GEMM_BF16 and dout.shape[1] == 1 and n_layers > 1:
+        row_scale = dout
+        dz = t.ones_like(dout)
     for l in range(n_layers - 1, -1, -1):
+        dz_s = dz if row_scale is None else dz * row_scale
         if need_dw:
-            grads[2 * l] = dz.t() @ acts[l]
-            grads[2 * l + 1] = dz.sum(0)
+            grads[2 * l] = dz_s.t() @ acts[l]
+            grads[2 * l + 1] = dz_s.sum(0)
         if l > 0 or need_dx:
-            dx = dz @ p[2 * l]
+            if row_scale is not None and l == n_layers - 1:
+                dx = dz * _q(p[2 * l])          # [B,1] x [1,W]: an elementwise product, no GEMM
+            elif row_scale is not None and l == 0 and parts is not None:
+                # the input gradient of a scalar net on a 4-CU cluster: every member rounds ITS partial
+                # dz (contraction over its quarter of the hidden columns) to bf16 for the next GEMM and
+                # the members' products are summed in fp32 (csrc/tp4.h: dact quarters + all-reduce)
+                dx = sum(_q(pm) @ _q(p[0]) for pm in parts)
+            else:
+                dx = _q(dz) @ _q(p[2 * l])
         if l > 0:
-            dz = dx * (acts[l] > 0).to(F32)  # threshold_backward on the ReLU output
+            mask = (acts[l] > 0).to(F32)     # threshold_backward on the ReLU output
+            parts = None
+            if row_scale is not None and n_layers == 3 and l == 1 and dz.shape[1] % 4 == 0:
+                w4 = dz.shape[1] // 4
+                parts = [(_q(dz[:, m * w4:(m + 1) * w4]) @ _q(p[2 * l][m * w4:(m + 1) * w4, :])) * mask
+                         for m in range(4)]
+                dx = parts[0] + parts[1] + parts[2] + parts[3]     # member order, as k_dw_adam sums them
+                dz = dx
+            else:
+                dz = dx * mask
+    if row_scale is not None and dx is not None:
+        dx = dx * row_scale
     return grads, (dx if need_dx else None)
 
 

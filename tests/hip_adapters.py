@@ -41,6 +41,7 @@ def g(x):
 class HipDDPG:
     def __init__(self, S, A, actor, critic, **kw):
         self.args = (S, A, actor, critic)
+        self.kw = kw
         self.algo = DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device=DEV, **kw).create()
         for m, p in ((self.algo.actor, actor), (self.algo.actor_target, actor),
                      (self.algo.critic, critic), (self.algo.critic_target, critic)):
@@ -66,7 +67,7 @@ class HipDDPG:
         """Gradients of update #1 via the export_grads (data-parallel) split of the
         same update: phase 0 -> critic grads -> apply -> phase 1 -> actor grads."""
         S, A, actor, critic = self.args
-        tw = HipDDPG(S, A, actor, critic, export_grads=True)
+        tw = HipDDPG(S, A, actor, critic, **{**self.kw, "export_grads": True})
         s, a, r, d, s2 = (g(x) for x in self._first)
         L = tw.algo.learner
         L.update_phase(0, s, a, r, d, s2)
@@ -82,8 +83,8 @@ class HipDDPG:
 
 
 class HipTD3:
-    def __init__(self, S, A, actor, c1, c2):
-        self.algo = TD3(logger=NullLogger(), state_dim=S, action_dim=A, device=DEV, log_every=10 ** 9).create()
+    def __init__(self, S, A, actor, c1, c2, **kw):
+        self.algo = TD3(logger=NullLogger(), state_dim=S, action_dim=A, device=DEV, log_every=10 ** 9, **kw).create()
         load_params(self.algo.actor, actor); load_params(self.algo.actor_target, actor)
         load_params(self.algo.critic, c1 + c2); load_params(self.algo.critic_target, c1 + c2)
 
@@ -101,9 +102,9 @@ class HipTD3:
 
 
 class HipSAC:
-    def __init__(self, S, A, actor, c1, c2, tune_alpha):
+    def __init__(self, S, A, actor, c1, c2, tune_alpha, **kw):
         self.algo = SAC(logger=NullLogger(), state_dim=S, action_dim=A, device=DEV,
-                        tune_alpha=tune_alpha, log_every=10 ** 9).create()
+                        tune_alpha=tune_alpha, log_every=10 ** 9, **kw).create()
         load_params(self.algo.actor, actor)
         load_params(self.algo.critic, c1 + c2); load_params(self.algo.critic_target, c1 + c2)
 
@@ -125,8 +126,8 @@ class HipSAC:
 
 
 class HipTQC:
-    def __init__(self, S, A, actor, critics):
-        self.algo = TQC(logger=NullLogger(), state_dim=S, action_dim=A, device=DEV, log_every=10 ** 9).create()
+    def __init__(self, S, A, actor, critics, **kw):
+        self.algo = TQC(logger=NullLogger(), state_dim=S, action_dim=A, device=DEV, log_every=10 ** 9, **kw).create()
         load_params(self.algo.actor, actor)
         flat = [x for c in critics for x in c]
         load_params(self.algo.critic, flat); load_params(self.algo.critic_target, flat)
