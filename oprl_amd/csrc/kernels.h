@@ -75,6 +75,9 @@ struct MlpArgs {
   // area's size for the wrap-around reset
   unsigned* tp_tag_counter; size_t tp_xbuf_bytes;
   void* owner;                       // the learner: lets launch() pair two nets of one for_each_net
+  // host-side only: this net's bf16 fragment packs per layer (bf16 learners; null otherwise) — a launcher
+  // whose kernels run PrecBF16 moves them into net.pf / net.pb
+  const float* pf16[kMaxLayers]; const float* pb16[kMaxLayers];
 };
 
 constexpr int kMaxMulti = 5;           // nets per k_mlp_slice_multi launch (TQC: 5 quantile critics)

@@ -164,9 +164,14 @@ struct LwRun { int slices, nets, G, tpg, gpx; };   // runs per slice, tiles per 
 // for a narrow net input (<= 32 columns: two macro steps) every workgroup recomputes the slice's
 // h1 = relu(W0 [x0 | x1] + b0) tile(s) in LDS instead of reading them (8 MFMAs per wave; the run
 // that starts a net also stores h1 and the input rows for k_dw_adam), which saves the k_lw_in launch
-template <int MODE>
+// P (engine.h): the precision of the hidden-layer GEMM — PrecBF16 reads layer l's pack as bf16 fragments
+// (the launch's nets carry bf16 pointers for their hidden layers then; the folded first layer, the heads
+// and k_lw_dact stay fp32: together 3 % of a TQC critic's FLOPs).
+template <int MODE, class P = PrecF32>
 __global__ __launch_bounds__(kThreads) void k_lw_mid_run(const MlpMultiArgs M, int l, const LwRun R) {
   constexpr bool BWD = MODE == 1, FIN = MODE == 2;
+  constexpr int NSE = 64 / P::KS;               // macro steps of a K-eighth (64 columns): 4 / 2
+  constexpr int NSW = 512 / P::KS;              // of the whole contraction: 32 / 16
   constexpr int WIDTH = 512, WL = lds_ld(WIDTH), NTW = WIDTH / 16;
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   float* xs0 = dsm;
@@ -233,18 +238,18 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid_run(const MlpMultiArgs M, i
     }
   }
   __builtin_amdgcn_sched_barrier(0);
-  f32x4 b[5][4];
+  f32x4 b[5][NSE];
 #pragma unroll
   for (int q = 0; q < 5; ++q) {
     const int tl = par + 2 * q;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) b[q][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < NSE; ++s) b[q][s] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tl < nt) {
       const int t = t0 + tl, net = t / NTW, ntile = t - net * NTW;
       const MlpArgs& A = lw_args(net);
-      const float* pk = (BWD ? A.net.pb[l] : A.net.pf[l]) + (((size_t)ntile * NTW + 4 * ke) * 64 + lane) * 4;
+      const float* pk = (BWD ? A.net.pb[l] : A.net.pf[l]) + (((size_t)ntile * NSW + NSE * ke) * 64 + lane) * 4;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) b[q][s] = ld4(pk + s * 256);
+      for (int s = 0; s < NSE; ++s) b[q][s] = ld4(pk + s * 256);
     }
   }
   // ... and this thread's (up to three) output elements: where they go, their bias (forward) or
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid_run(const MlpMultiArgs M, i
       const float* xr = (net == n0 ? xs0 : xs1) + i * WL + 64 * ke + 4 * kk;
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 4; ++s) mac4(ld4(xr + 16 * s), b[q][s], acc);
+      for (int s = 0; s < NSE; ++s) P::mac(xr, s, b[q][s], acc);
       *reinterpret_cast<f32x4*>(scr + ((size_t)(tl * 8 + ke) * 64 + lane) * 4) = acc;
     }
   }
@@ -425,8 +430,11 @@ bool mlp_layerwise_ok(const MlpArgs* a, int n, int width) {
 }
 
 hipError_t init_layerwise_attrs() {
-  const void* ks[3] = {reinterpret_cast<const void*>(&k_lw_mid_run<0>), reinterpret_cast<const void*>(&k_lw_mid_run<1>),
-                       reinterpret_cast<const void*>(&k_lw_mid_run<2>)};
+  const void* ks[6] = {reinterpret_cast<const void*>(&k_lw_mid_run<0>), reinterpret_cast<const void*>(&k_lw_mid_run<1>),
+                       reinterpret_cast<const void*>(&k_lw_mid_run<2>),
+                       reinterpret_cast<const void*>(&k_lw_mid_run<0, PrecBF16>),
+                       reinterpret_cast<const void*>(&k_lw_mid_run<1, PrecBF16>),
+                       reinterpret_cast<const void*>(&k_lw_mid_run<2, PrecBF16>)};
   for (const void* k : ks) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLwRunLds);
     if (e != hipSuccess) return e;
@@ -434,7 +442,9 @@ hipError_t init_layerwise_attrs() {
   return hipSuccess;
 }
 
-hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st) {
+// bf16: the nets' pf / pb of the HIDDEN layers (1 .. L-2) point at bf16 packs (MlpArgs::pf16 / pb16 moved in
+// by the caller) and the hidden-layer launches run PrecBF16; needs the balanced-run kernels.
+hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, bool bf16) {
   if (!mlp_layerwise_ok(a, n, width)) return hipErrorInvalidValue;
   MlpMultiArgs m;
   for (int j = 0; j < n; ++j) m.a[j] = a[j];
@@ -444,7 +454,8 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
   const dim3 wide(lw_blocks(g)), narrow(slices, 1, n), blk(kThreads);
   // hidden layers: runs of tiles balanced over the CUs (k_lw_mid_run), or — OPRL_AMD_LW_EQUAL=1, A/B
   // and tests — the equal (slice, 128 columns, net) workgroups of k_lw_mid
-  static const bool equal_wgs = [] { const char* e = getenv("OPRL_AMD_LW_EQUAL"); return e != nullptr && atoi(e) != 0; }();
+  static const bool equal_env = [] { const char* e = getenv("OPRL_AMD_LW_EQUAL"); return e != nullptr && atoi(e) != 0; }();
+  const bool equal_wgs = equal_env && !bf16;
   const LwRun r = lw_run(slices, n, n_cus > 0 ? n_cus : 256);
   const dim3 runs(8 * r.gpx * slices);
   if (a[0].do_fwd) {
@@ -454,14 +465,20 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
     if (!fuse_in) hipLaunchKernelGGL(k_lw_in<512>, wide, blk, 0, st, m, g);
     for (int l = 1; l + 1 < L; ++l) {
       if (equal_wgs) hipLaunchKernelGGL((k_lw_mid<512, false>), wide, blk, 0, st, m, l, g);
-      else if (l == 1 && fuse_in) hipLaunchKernelGGL((k_lw_mid_run<2>), runs, blk, kLwRunLds, st, m, l, r);
-      else hipLaunchKernelGGL((k_lw_mid_run<0>), runs, blk, kLwRunLds, st, m, l, r);
+      else if (l == 1 && fuse_in) {
+        if (bf16) hipLaunchKernelGGL((k_lw_mid_run<2, PrecBF16>), runs, blk, kLwRunLds, st, m, l, r);
+        else hipLaunchKernelGGL((k_lw_mid_run<2>), runs, blk, kLwRunLds, st, m, l, r);
+      } else {
+        if (bf16) hipLaunchKernelGGL((k_lw_mid_run<0, PrecBF16>), runs, blk, kLwRunLds, st, m, l, r);
+        else hipLaunchKernelGGL((k_lw_mid_run<0>), runs, blk, kLwRunLds, st, m, l, r);
+      }
     }
   }
   hipLaunchKernelGGL(k_lw_head<512>, narrow, blk, 0, st, m);
   if (a[0].do_bwd) {
     for (int l = L - 2; l >= 1; --l) {
       if (equal_wgs) hipLaunchKernelGGL((k_lw_mid<512, true>), wide, blk, 0, st, m, l, g);
+      else if (bf16) hipLaunchKernelGGL((k_lw_mid_run<1, PrecBF16>), runs, blk, kLwRunLds, st, m, l, r);
       else hipLaunchKernelGGL((k_lw_mid_run<1>), runs, blk, kLwRunLds, st, m, l, r);
     }
     if (a[0].dact_cols > 0) hipLaunchKernelGGL(k_lw_dact<512>, narrow, blk, 0, st, m);

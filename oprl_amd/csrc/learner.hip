@@ -129,7 +129,7 @@ size_t mlp_slice_lds_bytes(int width, int n_layers);
 hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
 hipError_t launch_mlp_slice_multi(const MlpArgs* a, int n, int width, hipStream_t st);
 bool mlp_layerwise_ok(const MlpArgs* a, int n, int width);
-hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st);
+hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, bool bf16);
 hipError_t init_layerwise_attrs();
 hipError_t launch_mlp_slice_tp(const MlpArgs& a, hipStream_t st);
 hipError_t launch_mlp_slice_tp2(const MlpArgs& a0, const MlpArgs& a1, int n_cus, hipStream_t st);
@@ -525,6 +525,16 @@ MlpArgs base_args(oprl_learner* h, const oprl_net& n, bool target, int B) {
   if (h->trace != nullptr && h->trace_slot < OPRL_TRACE_SLOTS)
     a.trace = h->trace + (size_t)(h->trace_slot++) * 64 * kTraceStamps * 2;
   a.net = net_view(n, target);
+  if (h->bf16) {
+    int idx = -1;                                      // 0 = actor, 1 + j = critic j
+    if (&n == &h->cfg.actor) idx = 0;
+    for (int j = 0; j < h->nc; ++j) if (&n == &h->cfg.critics[j]) idx = 1 + j;
+    const float* pk16 = idx < 0 ? nullptr : (target ? h->pack16_t[idx] : h->pack16[idx]);
+    for (int l = 0; pk16 != nullptr && l < n.n_layers; ++l) {
+      a.pf16[l] = pk16 + pack16_off_fwd(n, l);
+      a.pb16[l] = target ? nullptr : pk16 + pack16_off_bwd(n, l);
+    }
+  }
   a.B = B;
   a.action_dim = h->A;
   a.policy_noise = (float)h->cfg.hp.policy_noise;
@@ -650,8 +660,20 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
       }
     }
     if (same && !h->no_layerwise && mlp_layerwise_ok(h->multi_args, h->multi_n, h->multi_width)) {
+      // bf16 learners: the hidden layers (all but the first and the last) through their bf16 packs
+      bool lw16 = h->bf16;
+      for (int k = 0; k < h->multi_n; ++k) {
+        const MlpArgs& a = h->multi_args[k];
+        for (int l = 1; l + 1 < a.net.n_layers; ++l)
+          lw16 = lw16 && a.pf16[l] != nullptr && (!a.do_bwd || a.pb16[l] != nullptr);
+      }
+      if (lw16)
+        for (int k = 0; k < h->multi_n; ++k) {
+          MlpArgs& a = h->multi_args[k];
+          for (int l = 1; l + 1 < a.net.n_layers; ++l) { a.net.pf[l] = a.pf16[l]; if (a.pb16[l]) a.net.pb[l] = a.pb16[l]; }
+        }
       prof_begin(0, st);
-      hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, h->n_cus, st);
+      hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, h->n_cus, st, lw16);
       prof_end(st);
       HIPC(e);
     } else if (same) {

@@ -69,28 +69,34 @@ def clone_params(p: list[t.Tensor]) -> list[t.Tensor]:
 # Not part of the reference (which is fp32 throughout): it pins what the bf16 kernels claim to compute,
 # the fp32 oracle measures how far that is from the reference.
 GEMM_BF16 = False
+GEMM_BF16_MIN_DIM = 0     # only layers whose fan-in AND fan-out reach this are rounded
 
 
 class bf16_gemm:
-    """``with bf16_gemm(): ...`` — run the oracle with bf16-rounded GEMM operands."""
+    """``with bf16_gemm(): ...`` — run the oracle with bf16-rounded GEMM operands.  ``min_dim=512``:
+    only the 512 x 512 layers (what a bf16 TQC learner does: its layer-wise critic kernels run the hidden
+    layers in bf16; the first layer, the heads and the 256-wide actor stay fp32)."""
 
-    def __init__(self, on: bool = True):
-        self.on = on
+    def __init__(self, on: bool = True, min_dim: int = 0):
+        self.on, self.min_dim = on, min_dim
 
     def __enter__(self):
-        global GEMM_BF16
-        self.saved = GEMM_BF16
-        GEMM_BF16 = self.on
+        global GEMM_BF16, GEMM_BF16_MIN_DIM
+        self.saved = (GEMM_BF16, GEMM_BF16_MIN_DIM)
+        GEMM_BF16, GEMM_BF16_MIN_DIM = self.on, self.min_dim
         return self
 
     def __exit__(self, *exc):
-        global GEMM_BF16
-        GEMM_BF16 = self.saved
+        global GEMM_BF16, GEMM_BF16_MIN_DIM
+        GEMM_BF16, GEMM_BF16_MIN_DIM = self.saved
         return False
 
 
-def _q(x: t.Tensor) -> t.Tensor:
-    return x.to(t.bfloat16).to(F32) if GEMM_BF16 else x
+def _q(x: t.Tensor, w: Optional[t.Tensor] = None) -> t.Tensor:
+    """x rounded to bf16 if the emulation is on (and the layer with weight ``w`` is wide enough)."""
+    if not GEMM_BF16 or (w is not None and min(w.shape) < GEMM_BF16_MIN_DIM):
+        return x
+    return x.to(t.bfloat16).to(F32)
 
 
 def mlp_forward(p: list[t.Tensor], x: t.Tensor) -> list[t.Tensor]:
@@ -98,7 +104,7 @@ def mlp_forward(p: list[t.Tensor], x: t.Tensor) -> list[t.Tensor]:
     acts = [x]
     n_layers = len(p) // 2
     for l in range(n_layers):
-        z = t.addmm(p[2 * l + 1], _q(acts[-1]), _q(p[2 * l]).t())
+        z = t.addmm(p[2 * l + 1], _q(acts[-1], p[2 * l]), _q(p[2 * l], p[2 * l]).t())
         if l < n_layers - 1:
             z = t.relu(z)
         acts.append(z)
@@ -117,7 +123,7 @@ def mlp_backward(p: list[t.Tensor], acts: list[t.Tensor], dout: t.Tensor,
     # (csrc/tp4.h tp4_scalar_fb), so the seed itself is never rounded to bf16
     row_scale = None
     parts = None
-    if GEMM_BF16 and dout.shape[1] == 1 and n_layers > 1:
+    if GEMM_BF16 and GEMM_BF16_MIN_DIM == 0 and dout.shape[1] == 1 and n_layers > 1:
         row_scale = dout
         dz = t.ones_like(dout)
     for l in range(n_layers - 1, -1, -1):
@@ -134,7 +140,7 @@ def mlp_backward(p: list[t.Tensor], acts: list[t.Tensor], dout: t.Tensor,
                 # the members' products are summed in fp32 (csrc/tp4.h: dact quarters + all-reduce)
                 dx = sum(_q(pm) @ _q(p[0]) for pm in parts)
             else:
-                dx = _q(dz) @ _q(p[2 * l])
+                dx = _q(dz, p[2 * l]) @ _q(p[2 * l], p[2 * l])
         if l > 0:
             mask = (acts[l] > 0).to(F32)     # threshold_backward on the ReLU output
             parts = None

@@ -21,7 +21,8 @@ CASES = [("DDPG walker B=256", DDPG, 24, 6, 256, {}),
          ("TQC walker B=256", TQC, 24, 6, 256, dict(log_every=10 ** 9))]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 only = sys.argv[2] if len(sys.argv) > 2 else ""     # substring filter on the case name
-for name, cls, S, A, B, kw in CASES:
+precs = sys.argv[3].split(",") if len(sys.argv) > 3 else ["f32"]   # e.g. f32,bf16
+for name, cls, S, A, B, kw in [(f"{c[0]} [{p}]", *c[1:5], dict(c[5], precision=p)) for c in CASES for p in precs]:
     if only and only not in name:
         continue
     t.manual_seed(0)
@@ -60,5 +61,5 @@ for name, cls, S, A, B, kw in CASES:
         L.step_n(buf.handle, n, B, seed=2)
         t.cuda.synchronize()
         dt2 = min(dt2, time.perf_counter() - t0)
-    print(f"{name:26s} update(): {n / dt:9.1f}/s {dt / n * 1e6:7.1f} us   step_n: {n / dt2:9.1f}/s {dt2 / n * 1e6:7.1f} us", flush=True)
+    print(f"{name:32s} update(): {n / dt:9.1f}/s {dt / n * 1e6:7.1f} us   step_n: {n / dt2:9.1f}/s {dt2 / n * 1e6:7.1f} us", flush=True)
     del buf

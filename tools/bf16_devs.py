@@ -20,6 +20,10 @@ elif which == "td3":
     got = sc.td3_scenario(lambda *a: ha.HipTD3(*a, precision="bf16"))
     emu = sc.td3_scenario(_bf16_updates(sc.OracleTD3))
     gold = sc.load_golden("td3_cheetah_b256")
+elif which == "tqc":
+    got = sc.tqc_scenario(lambda *a: ha.HipTQC(*a, precision="bf16"))
+    emu = sc.tqc_scenario(_bf16_updates(sc.OracleTQC, min_dim=512))
+    gold = sc.load_golden("tqc_walker_b256")
 else:
     got = sc.sac_scenario(lambda *a: ha.HipSAC(*a, precision="bf16"), "walker", 256, 350, True, 3)
     emu = sc.sac_scenario(_bf16_updates(sc.OracleSAC), "walker", 256, 350, True, 3)
