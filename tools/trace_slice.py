@@ -13,7 +13,7 @@ from oprl_amd.logging import NullLogger
 S, A, B = 24, 6, 256
 t.manual_seed(0)
 algo = DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device="cuda", max_batch=B,
-            no_fuse="--generic" in sys.argv).create()
+            no_fuse="--generic" in sys.argv, precision="bf16" if "--bf16" in sys.argv else "f32").create()
 L = algo.learner
 NS, NST = 24, 24
 buf = t.zeros((NS, 64, NST, 2), dtype=t.int64, device="cuda")
@@ -30,7 +30,7 @@ if "--step-n" in sys.argv:     # the benchmarked mode: in-kernel replay gather
 for _ in range(3):
     buf.zero_()
     if replay is not None:
-        L.step_n(replay.handle, 1, B, seed=5)
+        L.step_n(replay.handle, 4, B, seed=5)     # the stamps left are the LAST update's: rows staged by its predecessor's phase 2
     else:
         algo.update(*batch)
 t.cuda.synchronize()
