@@ -172,6 +172,19 @@ int oprl_learner_set_update_count(oprl_learner* h, int64_t count);
 #define OPRL_N_COUNTERS 4
 int oprl_learner_get_counters(oprl_learner* h, int64_t out_host[OPRL_N_COUNTERS]);
 int oprl_learner_set_counters(oprl_learner* h, const int64_t in_host[OPRL_N_COUNTERS]);
+/* Device-side failures.  The fused update kernels and the data-parallel exchanges contain BOUNDED waits
+ * between workgroups (4-CU slice clusters, the TD-target hand-off between roles, gradient tiles between
+ * ranks).  An expired wait poisons its result with NaN — it cannot hang the GPU — and is REPORTED: the
+ * kernel stores (kernel << 8 | wait site) into a host-visible error word of the learner.  The word is
+ * checked, without any synchronisation, at the start of every oprl_learner_update / update_phase / apply /
+ * step_n / dp_* call and after the synchronisation inside oprl_learner_read_scalars; once set those calls
+ * return OPRL_ERR_STATE with the kernel and wait site in oprl_last_error() until it is cleared.
+ * oprl_learner_check polls it explicitly (synchronise the stream first for a definitive answer);
+ * oprl_learner_debug_expire (tests) makes one wait site (2 = TD-target hand-off, 1 = cluster all-reduce;
+ * 0 = off) give up immediately in subsequent launches. */
+int oprl_learner_check(oprl_learner* h);
+int oprl_learner_clear_error(oprl_learner* h);
+int oprl_learner_debug_expire(oprl_learner* h, int32_t site);
 /* Key of the learner's device-side noise streams (TD3 target smoothing, the SAC / TQC
  * reparameterisation draws, drawn with Philox when update() gets no injected noise): `seed` is the
  * run seed (the reference seeds torch's generator in runners/train.py:14-21), `rank` the

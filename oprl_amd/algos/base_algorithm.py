@@ -307,6 +307,14 @@ class HipLearner:
             _capi.check(self.lib.oprl_learner_step_n(self.handle, replay_handle, K, B, seed,
                                                      _capi.current_stream()), "oprl_learner_step_n")
 
+    def check(self) -> None:
+        """Raise if a kernel of this learner reported an expired cross-workgroup wait (include/oprl_amd.h,
+        "Device-side failures").  Every update / step_n / read_scalars call checks too."""
+        _capi.check(self.lib.oprl_learner_check(self.handle), "oprl_learner_check")
+
+    def clear_error(self) -> None:
+        _capi.check(self.lib.oprl_learner_clear_error(self.handle), "oprl_learner_clear_error")
+
     def set_seed(self, seed: int, rank: int = 0) -> None:
         self.seed = int(seed)
         _capi.check(self.lib.oprl_learner_set_seed(self.handle, int(seed) & (2 ** 64 - 1), int(rank)),

@@ -140,13 +140,15 @@ __device__ __forceinline__ void granule_put(unsigned long long* g, unsigned tag,
   __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float granule_get(const unsigned long long* g, unsigned tag) {
+__device__ __forceinline__ float granule_get(const unsigned long long* g, unsigned tag, unsigned* err = nullptr,
+                                             unsigned code = 0) {
   for (int spin = 0; spin < kTpSpin; ++spin) {
     const unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((unsigned)(x >> 32) == tag) return __uint_as_float((unsigned)x);
     __builtin_amdgcn_s_sleep(1);
   }
-  return __builtin_nanf("");   // bounded: a lost partner shows up as NaN, not as a hang
+  report_expired(err, code);   // bounded: a lost partner is reported to the host and shows up as NaN, not as a hang
+  return __builtin_nanf("");
 }
 
 // SAC: tanh-Gaussian head over outS = [mean | log_std] (16 lanes per row, the first 256 threads, as
@@ -221,12 +223,14 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
     if (row_ok) {
       unsigned long long g = 0;
       bool ok = false;
-      for (int spin = 0; spin < (1 << 20); ++spin) {
+      const int lim = A.debug_expire == (int)SITE_TD_TARGET ? 0 : (1 << 20);
+      for (int spin = 0; spin < lim; ++spin) {
         g = __hip_atomic_load(A.y_granules + gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = (unsigned)(g >> 32) == A.epoch;
         if (ok) break;
         __builtin_amdgcn_s_sleep(8);
       }
+      if (!ok) report_expired(A.err, (KERN_PHASE1 << 8) | SITE_TD_TARGET);
       y = ok ? __uint_as_float((unsigned)g) : __builtin_nanf("");
       q = outS[tid * kOutLd];
       cdY[2][(size_t)gr * A.clddo] = 2.f * (q - y) * A.inv_B;
@@ -254,12 +258,14 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
     if (tid < kR && row0 + tid < B) {
       unsigned long long g = 0;
       bool ok = false;
-      for (int spin = 0; spin < (1 << 20); ++spin) {
+      const int lim = A.debug_expire == (int)SITE_TD_TARGET ? 0 : (1 << 20);
+      for (int spin = 0; spin < lim; ++spin) {
         g = __hip_atomic_load(A.y_granules + row0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = (unsigned)(g >> 32) == A.epoch;
         if (ok) break;
         __builtin_amdgcn_s_sleep(8);
       }
+      if (!ok) report_expired(A.err, (KERN_PHASE1 << 8) | SITE_TD_TARGET);
       y = ok ? __uint_as_float((unsigned)g) : __builtin_nanf("");
     }
     if (tid < kR) yS[tid] = y;
@@ -329,7 +335,8 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   const int role = blockIdx.y / A.nc;
   const int role_c = 1 + A.n_critics;
   Tp tp{(int)blockIdx.y % A.nc, A.nc,
-        A.xbuf + ((size_t)role * gridDim.x + slice) * kTpStages * A.nc * kTpBlk, A.cluster_tag, 0};
+        A.xbuf + ((size_t)role * gridDim.x + slice) * kTpStages * A.nc * kTpBlk, A.cluster_tag, 0,
+        A.err, KERN_PHASE1 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
   const bool lead = tp.c == 0;                 // member 0 does the un-sliced global stores
   int n_stamp = 0;
   auto stamp = [&]() {
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
     // ---- ... then target critic 2 on (s', a') with role A's a'
     if (tid < kR * Ad) {
       const int row = tid / Ad, col = tid - row * Ad;
-      xb[row * kX0Ld + S + col] = granule_get(x_slot(role_c) + tid, x_tag);
+      xb[row * kX0Ld + S + col] = granule_get(x_slot(role_c) + tid, x_tag, A.err, (KERN_PHASE1 << 8) | SITE_TWIN_SPLIT);
     }
     tp_fwd<WIDTH, LEAN, P>(A.critic2_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
     if (lead && tid < kR) granule_put(x_slot(0) + tid, x_tag, outS[tid * kOutLd]);
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
     tp_fwd<WIDTH, LEAN, P>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
     float qn = (tid < kR) ? outS[tid * kOutLd] : 0.f;
     if (A.twin_split) {
-      if (lead && tid < kR) qn = fminf(qn, granule_get(x_slot(0) + tid, x_tag));
+      if (lead && tid < kR) qn = fminf(qn, granule_get(x_slot(0) + tid, x_tag, A.err, (KERN_PHASE1 << 8) | SITE_TWIN_SPLIT));
     } else if (A.n_critics == 2) {
       tp_fwd<WIDTH, LEAN, P>(A.critic2_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
       if (tid < kR) qn = fminf(qn, outS[tid * kOutLd]);
@@ -467,7 +474,8 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   const int n_clus = SAC ? 1 + A.p2_pair : 1;
   const int g = (SAC && (int)blockIdx.y < n_clus * A.nc) ? (int)blockIdx.y / A.nc : 0;
   Tp tp{(int)blockIdx.y - g * A.nc, A.nc,
-        A.xbuf + ((size_t)g * gridDim.x + slice) * kTpStages * A.nc * kTpBlk, A.cluster_tag, 0};
+        A.xbuf + ((size_t)g * gridDim.x + slice) * kTpStages * A.nc * kTpBlk, A.cluster_tag, 0,
+        A.err, KERN_PHASE2 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
   const bool lead = tp.c == 0;
   int n_stamp = 0;
   auto stamp = [&]() {
@@ -589,6 +597,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
           if (ok) break;
           __builtin_amdgcn_s_sleep(1);
         }
+        if (!ok) report_expired(A.err, (KERN_PHASE2 << 8) | SITE_P2_PAIR);
         const float v = ok ? __uint_as_float((unsigned)x) : __builtin_nanf("");
         if (xc < Ad) d2S[xr * kOutLd + xc] = v; else qxS[xr] = v;
       }

@@ -71,6 +71,7 @@ struct MlpArgs {
   // tensor-parallel launch (csrc/slice_tp.hip): cluster exchange area and launch-unique tag, and
   // the distance between the members' dz1 partial buffers (dYg[0] + member * dY0_stride)
   unsigned long long* tp_xbuf; unsigned tp_tag; long dY0_stride;
+  unsigned* err;                     // the learner's host-visible error word (expired waits), or null
   // host-side only (ignored by the kernels): where launch() draws the tag from, the exchange
   // area's size for the wrap-around reset
   unsigned* tp_tag_counter; size_t tp_xbuf_bytes;
@@ -160,6 +161,7 @@ struct DwXchg {
   char* window;                        // this rank's tile region
   int world, rank, parity, max_tiles;
   unsigned long long seq;
+  unsigned* err;                       // host-visible error word (expired tile wait), or null
 };
 __host__ __device__ inline size_t dw_xchg_bytes(int world, int max_tiles) {
   return (size_t)2 * (world + 1) * max_tiles * kDwXchgTile * sizeof(unsigned long long);
@@ -258,6 +260,8 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   long cdY0_stride, adY0_stride;       // floats between the members' dz1 partial buffers
   float *partials_c, *partials_a;      // [slices][4]
   long long* trace;
+  unsigned* err;                       // host-visible error word: an expired bounded wait stores (kernel << 8 | site) there
+  int debug_expire;                    // test hook: this wait site (WaitSite, tp3.h) gives up at once
 };
 
 constexpr int kDwTile = 32;      // k (fan-in) extent of a dW tile

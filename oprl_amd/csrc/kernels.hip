@@ -16,6 +16,7 @@
 #include "kernels.h"
 #include "philox.h"
 #include "slice_head.h"
+#include "tp3.h"
 
 namespace oprl {
 
@@ -309,7 +310,10 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
       put(slot(X.peer[owner], X.rank), g, gbw);
       all_ok = get(slot(X.window, X.world), &gs, &gbs);
     }
-    if (!all_ok) { gs = __builtin_nanf(""); gbs = gs; }   // bounded wait: a lost rank poisons the tile instead of hanging
+    if (!all_ok) {   // bounded wait: a lost rank is reported and poisons the tile instead of hanging
+      report_expired(X.err, (KERN_DW_XCHG << 8) | SITE_DW_TILE);
+      gs = __builtin_nanf(""); gbs = gs;
+    }
     g = gs;
     gb_x = gbs;
   }

@@ -403,6 +403,13 @@ struct oprl_learner {
   // OPRL_PREC_BF16: bf16 fragment packs of every net (online: forward + backward, target: forward),
   // derived state owned by the library and written by the dW + Adam epilogues / k_repack; index 0 = actor,
   // 1 + j = critic j
+  // Bounded cross-workgroup waits (cluster all-reduce, TD-target hand-off, twin exchanges, gradient tile /
+  // window exchanges) REPORT an expiry here besides poisoning their result with NaN: one word of
+  // host-mapped memory, written by the device only on that error path (tp3.h report_expired), read by
+  // the host at the start of every update / step_n / apply / read_scalars call — no copy, no sync.
+  unsigned* err_host = nullptr;
+  unsigned* err_dev = nullptr;
+  int debug_expire = 0;        // test hook (oprl_learner_debug_expire): this wait site gives up at once
   bool bf16 = false;
   float* pack16[OPRL_MAX_CRITICS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   float* pack16_t[OPRL_MAX_CRITICS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -525,6 +532,7 @@ MlpArgs base_args(oprl_learner* h, const oprl_net& n, bool target, int B) {
   if (h->trace != nullptr && h->trace_slot < OPRL_TRACE_SLOTS)
     a.trace = h->trace + (size_t)(h->trace_slot++) * 64 * kTraceStamps * 2;
   a.net = net_view(n, target);
+  a.err = h->err_dev;
   if (h->bf16) {
     int idx = -1;                                      // 0 = actor, 1 + j = critic j
     if (&n == &h->cfg.actor) idx = 0;
@@ -795,6 +803,8 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   a.cdY0_stride = h->ws_critic[0].dY0_stride;
   a.adY0_stride = h->ws_actor.dY0_stride;
   a.partials_c = h->part_c; a.partials_a = h->part_a;
+  a.err = h->err_dev;
+  a.debug_expire = h->debug_expire;
   if (h->bf16 && fused_ddpg_is_lean(a)) {   // the PrecBF16 instances of the (lean) phase kernels: every net through its bf16 packs
     a.bf16 = 1;
     a.actor = net_view16(c.actor, false, h->pack16[0]);
@@ -847,6 +857,7 @@ int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st) {
     X.window = P.window + P.tile_off;
     X.world = P.world; X.rank = P.rank; X.parity = (int)(P.tile_seq & 1); X.max_tiles = h->p2p_max_tiles;
     X.seq = P.tile_seq;
+    X.err = h->err_dev;
     dw.xchg = &X;
     dw.ad.do_adam = 1;
     dw.ad.grad_scale = 1.0f / (float)P.world;
@@ -1125,10 +1136,48 @@ int check_batch(const oprl_learner* h, const void* s, const void* a, const void*
   return OPRL_OK;
 }
 
+// Has a kernel of this learner reported an expired wait?  (Sticky until oprl_learner_clear_error.)
+int check_device_error(const oprl_learner* h) {
+  if (h == nullptr || h->err_host == nullptr) return OPRL_OK;
+  const unsigned code = *(volatile const unsigned*)h->err_host;
+  if (code == 0) return OPRL_OK;
+  static const char* kern[] = {"?", "k_ddpg_phase1", "k_ddpg_phase2", "k_mlp_slice_tp", "k_dw_adam<exchange>", "peer-window all-reduce"};
+  static const char* site[] = {"?", "cluster all-reduce (a member of a 4-CU slice cluster never published its partial)",
+                               "TD-target hand-off (role B never received y from role A)",
+                               "twin-target exchange between role A and the role-C cluster",
+                               "SAC phase 2 pair exchange (critic 2's cluster never delivered)",
+                               "gradient tile exchange with another rank", "peer-window flag of another rank"};
+  const unsigned k = (code >> 8) & 0xff, w = code & 0xff;
+  set_err("device error 0x%x: a bounded cross-workgroup wait expired in %s at the %s; the results of that "
+          "update (and everything after it) are poisoned with NaN.  Typical causes: the launch's workgroups were "
+          "not co-resident (another process or learner held the GPU's compute units for longer than the wait bound), "
+          "or a data-parallel peer died.  Restore a checkpoint, then oprl_learner_clear_error().",
+          code, k < 6 ? kern[k] : "?", w < 7 ? site[w] : "?");
+  return OPRL_ERR_STATE;
+}
+
 }  // namespace
 
 // =========================================================================== C-ABI
 extern "C" const char* oprl_last_error(void) { return g_err.c_str(); }
+
+extern "C" int oprl_learner_check(oprl_learner* h) {
+  if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
+  return check_device_error(h);
+}
+
+extern "C" int oprl_learner_clear_error(oprl_learner* h) {
+  if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
+  if (h->err_host) *(volatile unsigned*)h->err_host = 0;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_learner_debug_expire(oprl_learner* h, int32_t site) {
+  if (!h || site < 0 || site > 6) { set_err("oprl_learner_debug_expire: invalid argument"); return OPRL_ERR_INVALID; }
+  h->debug_expire = site;
+  return OPRL_OK;
+}
+
 
 #define NCCLC(h, x)                                                                   \
   do {                                                                                 \
@@ -1191,6 +1240,7 @@ extern "C" int oprl_p2p_create(oprl_learner* h, int32_t rank, int32_t world, cha
   size_t tile_bytes = h->fused ? dw_xchg_bytes(world, h->p2p_max_tiles) : 0;
   if (tile_bytes > ((size_t)256 << 20)) tile_bytes = 0;
   h->noise_rank = rank;
+  h->p2p.err = h->err_dev;
   hipError_t e = p2p_create(h->p2p, rank, world, n, tile_bytes, handle_out);
   if (e != hipSuccess) {
     set_err("oprl_p2p_create: %s", hipGetErrorString(e));
@@ -1451,6 +1501,19 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   if (hipMalloc(&h->pool.base, bytes) != hipSuccess) { set_err("hipMalloc(%zu) failed", bytes); delete h; return OPRL_ERR_NOMEM; }
   h->pool.cap = bytes;
   (void)hipMemset(h->pool.base, 0, bytes);
+  {
+    // the error word: host memory the device can write (only ever on the error path)
+    void* eh = nullptr; void* ed = nullptr;
+    if (hipHostMalloc(&eh, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&ed, eh, 0) != hipSuccess) {
+      set_err("hipHostMalloc(error word) failed");
+      if (eh) (void)hipHostFree(eh);
+      (void)hipFree(h->pool.base); delete h; return OPRL_ERR_NOMEM;
+    }
+    memset(eh, 0, 64);
+    h->err_host = (unsigned*)eh;
+    h->err_dev = (unsigned*)ed;
+  }
   Pool& p = h->pool;
   alloc_net_ws(p, cfg->actor, B, &h->ws_actor);
   for (int j = 0; j < nc; ++j) alloc_net_ws(p, cfg->critics[j], B, &h->ws_critic[j]);
@@ -1585,6 +1648,7 @@ extern "C" int oprl_learner_destroy(oprl_learner* h) {
   if (h->rccl.comm && h->rccl.comm_destroy) (void)h->rccl.comm_destroy(h->rccl.comm);
   if (h->fused) { std::lock_guard<std::mutex> lk(g_chain_mu); if (g_chain.live > 0) g_chain.live -= 1; }
   if (h->xbuf) (void)hipFree(h->xbuf);
+  if (h->err_host) (void)hipHostFree(h->err_host);
   if (h->p2p.window) p2p_destroy(h->p2p);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   for (int j = 1; j < OPRL_MAX_CRITICS; ++j) {
@@ -1601,6 +1665,7 @@ extern "C" int oprl_learner_update_phase(oprl_learner* h, int32_t phase, const f
                                          const float* s2, int32_t B, const float* noise0,
                                          const float* noise1, void* stream) {
   RC(check_batch(h, s, a, r, d, s2, B));
+  RC(check_device_error(h));      // an expired wait of an earlier launch (asynchronous: whatever has run by now)
   hipStream_t st = (hipStream_t)stream;
   h->last_B = B;
   if (phase == 0) h->trace_slot = 0;
@@ -1628,6 +1693,7 @@ extern "C" int oprl_learner_update(oprl_learner* h, const float* s, const float*
 extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, double grad_scale, void* stream) {
   if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
   if (!h->cfg.export_grads) { set_err("oprl_learner_apply: learner was not created with export_grads"); return OPRL_ERR_STATE; }
+  RC(check_device_error(h));
   hipStream_t st = (hipStream_t)stream;
   const oprl_learner_config& c = h->cfg;
   if (phase == 0) {
@@ -1732,6 +1798,7 @@ extern "C" int oprl_learner_read_scalars(oprl_learner* h, float* out_host, int32
   const double* lap = alpha_ptr(h);
   if (lap) HIPC(hipMemcpyAsync(&la, lap, sizeof(double), hipMemcpyDeviceToHost, st));
   HIPC(hipStreamSynchronize(st));
+  RC(check_device_error(h));      // after the synchronisation: definitive for everything launched so far
   float res[6];
   res[0] = host[0];                 // critic loss
   res[1] = host[5];                 // actor loss (-mean q part)

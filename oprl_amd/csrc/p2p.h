@@ -20,6 +20,7 @@ struct P2pState {
   unsigned long long seq = 0;                // exchanges so far
   size_t tile_off = 0, tile_bytes = 0;       // second region of the window: k_dw_adam<true>'s per-tile exchange
   unsigned long long tile_seq = 0;
+  unsigned* err = nullptr;                   // the learner's host-visible error word (an expired flag wait is reported there)
 };
 
 hipError_t p2p_create(P2pState& s, int rank, int world, size_t max_floats, size_t tile_region_bytes, void* handle_out);

@@ -23,6 +23,7 @@
 
 #include "../../include/oprl_amd.h"
 #include "p2p.h"
+#include "tp3.h"
 
 namespace oprl {
 
@@ -81,6 +82,7 @@ struct P2pReduceArgs {
   size_t slot_floats, n;                     // n: elements (floats, or doubles with as_double)
   void* dst;
   unsigned long long seq;
+  unsigned* err;
 };
 
 __global__ __launch_bounds__(kP2pThreads) void k_p2p_reduce(const P2pReduceArgs a) {
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(kP2pThreads) void k_p2p_reduce(const P2pReduceArgs 
       ok = __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= a.seq;
       if (!ok) __builtin_amdgcn_s_sleep(8);
     }
-    if (!ok) s_ok = 0;                       // bounded: a missing peer poisons the result instead of hanging
+    if (!ok) { s_ok = 0; report_expired(a.err, (KERN_P2P << 8) | SITE_WINDOW); }   // bounded: a missing peer is reported and poisons the result instead of hanging
   }
   __syncthreads();
   __threadfence_system();
@@ -152,6 +154,7 @@ struct P2pFusedArgs {
   float* buf;
   unsigned* done;
   unsigned long long seq;
+  unsigned* err;
 };
 
 __global__ __launch_bounds__(kP2pThreads) void k_p2p_all_reduce(const P2pFusedArgs a) {
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(kP2pThreads) void k_p2p_all_reduce(const P2pFusedAr
         ok = __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= a.seq;
         if (!ok) __builtin_amdgcn_s_sleep(4);
       }
-      if (!ok) s_ok = 0;
+      if (!ok) { s_ok = 0; report_expired(a.err, (KERN_P2P << 8) | SITE_WINDOW); }
     }
     __syncthreads();
     __threadfence_system();
@@ -229,6 +232,7 @@ struct P2pF64Args {
   size_t slot_floats;
   double* buf;
   unsigned long long seq;
+  unsigned* err;
 };
 
 __global__ __launch_bounds__(kP2pThreads) void k_p2p_all_reduce_f64(const P2pF64Args a) {
@@ -262,6 +266,7 @@ __global__ __launch_bounds__(kP2pThreads) void k_p2p_all_reduce_f64(const P2pF64
     all_ok = all_ok && ok;
     s += __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
   }
+  if (!all_ok) report_expired(a.err, (KERN_P2P << 8) | SITE_WINDOW);
   a.buf[i] = all_ok ? s : __builtin_nan("");
 }
 
@@ -320,7 +325,7 @@ hipError_t p2p_all_reduce(P2pState& s, void* buf, size_t n, bool as_double, hipS
     P2pFusedArgs fa;
     for (int r = 0; r < kP2pMaxWorld; ++r) fa.peer[r] = r < s.world ? s.peer[r] : nullptr;
     fa.window = s.window; fa.world = s.world; fa.rank = s.rank; fa.parity = (int)(s.seq & 1);
-    fa.slot_floats = s.slot_floats; fa.n = n; fa.buf = (float*)buf; fa.done = s.done; fa.seq = s.seq;
+    fa.slot_floats = s.slot_floats; fa.n = n; fa.buf = (float*)buf; fa.done = s.done; fa.seq = s.seq; fa.err = s.err;
     const size_t want = ((n >> 2) + kP2pThreads - 1) / kP2pThreads;
     const int blocks = (int)(want < 1 ? 1 : (want < (size_t)kP2pBlocks ? want : (size_t)kP2pBlocks));
     hipLaunchKernelGGL(k_p2p_all_reduce, dim3(blocks), dim3(kP2pThreads), 0, st, fa);
@@ -330,7 +335,7 @@ hipError_t p2p_all_reduce(P2pState& s, void* buf, size_t n, bool as_double, hipS
     P2pF64Args da;
     for (int r = 0; r < kP2pMaxWorld; ++r) da.peer[r] = r < s.world ? s.peer[r] : nullptr;
     da.window = s.window; da.world = s.world; da.rank = s.rank; da.parity = (int)(s.seq & 1); da.n = (int)n;
-    da.slot_floats = s.slot_floats; da.buf = (double*)buf; da.seq = s.seq;
+    da.slot_floats = s.slot_floats; da.buf = (double*)buf; da.seq = s.seq; da.err = s.err;
     hipLaunchKernelGGL(k_p2p_all_reduce_f64, dim3(1), dim3(kP2pThreads), 0, st, da);
     return hipGetLastError();
   }
@@ -342,7 +347,7 @@ hipError_t p2p_all_reduce(P2pState& s, void* buf, size_t n, bool as_double, hipS
   hipLaunchKernelGGL(k_p2p_push, dim3(blocks), dim3(kP2pThreads), 0, st, pa);
   P2pReduceArgs ra;
   ra.window = s.window; ra.world = s.world; ra.parity = pa.parity; ra.as_double = as_double ? 1 : 0;
-  ra.slot_floats = s.slot_floats; ra.n = n; ra.dst = buf; ra.seq = s.seq;
+  ra.slot_floats = s.slot_floats; ra.n = n; ra.dst = buf; ra.seq = s.seq; ra.err = s.err;
   const int rblocks = (int)((n + kP2pThreads - 1) / kP2pThreads < kP2pBlocks ? (n + kP2pThreads - 1) / kP2pThreads : kP2pBlocks);
   hipLaunchKernelGGL(k_p2p_reduce, dim3(rblocks), dim3(kP2pThreads), 0, st, ra);
   return hipGetLastError();

@@ -26,7 +26,7 @@ __device__ __forceinline__ void slice_tp_body(const MlpArgs& A) {
   float* auxS = smem + LY::aux_off(2);
   float* scr = smem + LY::scr_off(2);
   const int slice = blockIdx.x, row0 = slice * kR, B = A.B;
-  Tp tp{(int)blockIdx.y, 4, A.tp_xbuf + (size_t)slice * kTpStages * 4 * kTpBlk, A.tp_tag, 0};
+  Tp tp{(int)blockIdx.y, 4, A.tp_xbuf + (size_t)slice * kTpStages * 4 * kTpBlk, A.tp_tag, 0, A.err, KERN_SLICE_TP << 8, kTpSpin};
   const bool lead = tp.c == 0;
   const int Nout = A.net.dims[3];
 

@@ -36,7 +36,21 @@ struct Tp {
   unsigned long long* xbuf;     // this cluster's area: [kTpStages][nc][kTpBlk] granules
   unsigned tag;                 // launch-unique (26 bits used)
   int stage;
+  // an expired wait is REPORTED (and the value poisoned with NaN): err = the learner's host-visible error
+  // word (or null), err_code = kernel id << 8; spin = the wait bound (kTpSpin; 0 from the test hook)
+  unsigned* err = nullptr;
+  unsigned err_code = 0;
+  int spin = kTpSpin;
 };
+
+// Wait sites (low byte of the error word) and kernels (second byte): oprl_learner_check() decodes them.
+enum WaitSite : unsigned { SITE_CLUSTER = 1, SITE_TD_TARGET = 2, SITE_TWIN_SPLIT = 3, SITE_P2_PAIR = 4, SITE_DW_TILE = 5, SITE_WINDOW = 6 };
+enum WaitKernel : unsigned { KERN_PHASE1 = 1, KERN_PHASE2 = 2, KERN_SLICE_TP = 3, KERN_DW_XCHG = 4, KERN_P2P = 5 };
+// First report wins (the word is host-mapped memory: one system-scope store, only ever on the error path).
+__device__ __forceinline__ void report_expired(unsigned* err, unsigned code) {
+  if (err != nullptr && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u)
+    __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // P[kR][ncols] (LDS, leading dim kOutLd) holds this member's partial, complete and
 // visible.  OUT[row][col] = sum over members (in member order) + bias[col].  OUT may be P.
@@ -67,12 +81,13 @@ __device__ __forceinline__ void tp_allreduce(float* P, int ncols, const float* _
         const unsigned long long* g = slot + (size_t)m * kTpBlk + e;
         unsigned long long x = 0;
         bool ok = false;
-        for (int spin = 0; spin < kTpSpin; ++spin) {
+        for (int spin = 0; spin < tp.spin; ++spin) {
           x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ok = (unsigned)(x >> 32) == tag;
           if (ok) break;
           __builtin_amdgcn_s_sleep(1);
         }
+        if (!ok) report_expired(tp.err, tp.err_code | SITE_CLUSTER);
         v = ok ? __uint_as_float((unsigned)x) : __builtin_nanf("");
       }
       sum += v;

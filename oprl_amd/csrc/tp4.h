@@ -73,7 +73,7 @@ __device__ __forceinline__ f32x4 tp4_allreduce_regs(const f32x4 mine, int col, b
                          ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(mine[r]),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool ok = false;
-    for (int spin = 0; spin < kTpSpin && !ok; ++spin) {
+    for (int spin = 0; spin < tp.spin && !ok; ++spin) {
       unsigned long long x[4][4];
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -94,6 +94,7 @@ __device__ __forceinline__ f32x4 tp4_allreduce_regs(const f32x4 mine, int col, b
       if (!ok) __builtin_amdgcn_s_sleep(1);
     }
     if (!ok) {
+      report_expired(tp.err, tp.err_code | SITE_CLUSTER);
       const float nan = __builtin_nanf("");
       v[0] = f32x4{nan, nan, nan, nan};
     }

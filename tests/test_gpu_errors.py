@@ -1,0 +1,75 @@
+"""Device-side failures are visible to the host (include/oprl_amd.h, "Device-side failures"): a bounded
+cross-workgroup wait that expires poisons its result with NaN AND stores (kernel, wait site) into the
+learner's host-mapped error word; the next update / step_n / read_scalars call returns OPRL_ERR_STATE with
+the text.  The expiry is forced through the test hook oprl_learner_debug_expire."""
+import pytest
+import torch as t
+
+from oracle import fixtures as fx
+from oprl_amd.algos.ddpg import DDPG
+from oprl_amd.logging import NullLogger
+
+pytestmark = pytest.mark.gpu
+S, A, B = 24, 6, 256
+
+
+def _algo(**kw):
+    t.manual_seed(0)
+    return DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device="cuda", max_batch=B, **kw).create()
+
+
+@pytest.mark.parametrize("site,text", [(2, "TD-target hand-off"), (1, "cluster all-reduce")])
+def test_expired_wait_is_reported_not_silent(site, text):
+    algo = _algo()
+    L = algo.learner
+    batch = [x.cuda() for x in fx.make_batch(3, B, S, A)]
+    for _ in range(3):
+        algo.update(*batch)
+    t.cuda.synchronize()
+    L.check()                                   # clean so far
+    good = L.state_dict()
+    assert L.lib.oprl_learner_debug_expire(L.handle, site) == 0
+    algo.update(*batch)                         # its kernels give up their wait at once
+    t.cuda.synchronize()
+    with pytest.raises(RuntimeError, match=text):
+        algo.update(*batch)                     # reported at the next call, with kernel and site
+    with pytest.raises(RuntimeError, match="expired"):
+        L.read_scalars()
+    with pytest.raises(RuntimeError, match="expired"):
+        L.check()
+    assert not bool(t.isfinite(algo.critic._oprl_arena).all())      # (and poisoned, as before)
+    # recovery: hook off, error cleared, state restored from the checkpoint taken before
+    assert L.lib.oprl_learner_debug_expire(L.handle, 0) == 0
+    L.clear_error()
+    L.load_state_dict(good)
+    for _ in range(3):
+        algo.update(*batch)
+    t.cuda.synchronize()
+    L.check()
+    assert bool(t.isfinite(algo.critic._oprl_arena).all()) and bool(t.isfinite(algo.actor._oprl_arena).all())
+
+
+def test_packed_learners_and_long_runs_stay_clean():
+    """Two learners driven from two host threads on two streams (the default multi-seed layout), 2000
+    updates each: no wait expires, every parameter stays finite."""
+    import threading
+    import bench
+    replay = bench.make_replay(t.device("cuda", 0), seed=3)
+    handle = replay.handle
+    algos = [_algo() for _ in range(2)]
+    streams = [t.cuda.Stream() for _ in range(2)]
+
+    def run(i):
+        with t.cuda.stream(streams[i]):
+            for _ in range(20):
+                algos[i].learner.step_n(handle, 100, B, seed=10 + i)
+
+    ths = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    t.cuda.synchronize()
+    for a in algos:
+        a.learner.check()
+        assert bool(t.isfinite(a.critic._oprl_arena).all()) and bool(t.isfinite(a.actor._oprl_arena).all())
