@@ -191,6 +191,12 @@ int oprl_learner_debug_expire(oprl_learner* h, int32_t site);
  * data-parallel rank (oprl_comm_init / oprl_p2p_create set it too) so that every seed and every
  * rank draws its own eps.  Seed 0 on rank 0 is the default. */
 int oprl_learner_set_seed(oprl_learner* h, uint64_t seed, int32_t rank);
+/* Test / audit export of the device-side noise: out_dev[rows][cols] = the N(0,1) draws (Philox4x32-10 +
+ * Box-Muller, csrc/philox.h) the update kernels of this learner take for noise stream `stream_id` (1: next-state
+ * draw / TD3 target smoothing, 2: actor-step draw) at update counter `counter`, element (row, col) = (minibatch
+ * row, action dimension), under the learner's current seed and rank (oprl_learner_set_seed). */
+int oprl_debug_noise(oprl_learner* h, int32_t stream_id, uint64_t counter, int32_t rows, int32_t cols,
+                     float* out_dev, void* stream);
 /* device pointer to the per-row Q / TD-target of the last critic step ([B] each,
  * critic 0), for parity tests. */
 int oprl_learner_debug_ptrs(oprl_learner* h, const float** q, const float** y);

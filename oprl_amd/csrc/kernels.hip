@@ -542,6 +542,21 @@ __global__ __launch_bounds__(64 * kTqcWaves) void k_tqc_target(const float* z, l
   }
 }
 
+// the device N(0,1) stream exactly as the update kernels draw it: out[row][col] = philox_normal(seed, ctr, row, col)
+__global__ void k_debug_normal(unsigned long long seed, unsigned long long ctr, int rows, int cols, float* out) {
+  const long n = (long)rows * cols;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+    out[e] = philox_normal(seed, ctr, (unsigned)(e / cols), (unsigned)(e % cols));
+}
+
+hipError_t launch_debug_normal(unsigned long long seed, unsigned long long ctr, int rows, int cols, float* out,
+                               hipStream_t st) {
+  const long n = (long)rows * cols;
+  const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(k_debug_normal, dim3(grid < 1 ? 1 : grid), dim3(256), 0, st, seed, ctr, rows, cols, out);
+  return hipGetLastError();
+}
+
 // master (row-major [N][K]) -> fragment-order packs; one 256-thread block per 256
 // consecutive elements of a layer.  Pad positions are never written (the pack
 // buffers are zeroed once at allocation).

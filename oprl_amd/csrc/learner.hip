@@ -155,6 +155,8 @@ int replay_dims(const oprl_replay* h, int* S, int* A);
 int replay_view(const oprl_replay* h, const float** states, const float** actions,
                 const float** rewards, const float** dones, const int** ends, int* n_eps, int* L,
                 long* n_transitions);
+hipError_t launch_debug_normal(unsigned long long seed, unsigned long long ctr, int rows, int cols, float* out,
+                               hipStream_t st);
 hipError_t init_fused_attrs();
 size_t fused_xbuf_granules_per_cluster(int nc);
 hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st);
@@ -1169,6 +1171,13 @@ extern "C" int oprl_learner_check(oprl_learner* h) {
 extern "C" int oprl_learner_clear_error(oprl_learner* h) {
   if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
   if (h->err_host) *(volatile unsigned*)h->err_host = 0;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_debug_noise(oprl_learner* h, int32_t stream_id, uint64_t counter, int32_t rows, int32_t cols,
+                                float* out_dev, void* stream) {
+  if (!h || stream_id < 1 || stream_id > 2 || rows < 1 || cols < 1 || !out_dev) { set_err("oprl_debug_noise: invalid argument"); return OPRL_ERR_INVALID; }
+  HIPC(launch_debug_normal(noise_key(h, (uint64_t)stream_id), counter, rows, cols, out_dev, (hipStream_t)stream));
   return OPRL_OK;
 }
 

@@ -354,3 +354,79 @@ def test_checkpoint_resume_is_bit_exact(algo, tmp_path):
     s1, s2 = b1.sample(8), b2.sample(8)
     for x, y in zip(s1, s2):
         assert t.equal(x, y)
+
+
+def test_policy_io_matches_the_reference_vectors_on_the_hip_path(monkeypatch):
+    """G6 (tests/golden/policy_io.npz, generated by running the reference's DeterministicPolicy /
+    GaussianActor): exploit / explore of both policy classes through oprl_mlp_act, with the reference's
+    noise draws injected — including the reference's quirk that DeterministicPolicy.explore applies NO
+    tanh (nn_models.py:144-150) and GaussianActor.explore samples in train mode and returns tanh(mean)
+    in eval mode (:180-195)."""
+    from oracle import fixtures as fx
+    from tests import hip_adapters as ha
+    from tests import scenarios as sc
+    from oprl_amd.algos.sac import SAC
+    from oprl_amd.logging import NullLogger
+    gold = sc.load_golden("policy_io")
+    S, A, seed = (int(x) for x in gold["meta"])
+    obs = np.random.RandomState(seed + 3).standard_normal(S).astype(np.float32)
+    d = _ddpg()
+    ha.load_params(d.actor, fx.make_net(seed + 1, fx.actor_dims(S, A)))
+    assert sc.rel_dev(d.actor.exploit(obs), gold["det.exploit"]) < 2e-6
+    real_randn = t.randn
+    monkeypatch.setattr(t, "randn", lambda *a, **k: fx.make_noise(seed + 4, (A,)))
+    raw_explore = d.actor.explore(obs)
+    monkeypatch.setattr(t, "randn", real_randn)
+    assert sc.rel_dev(raw_explore, gold["det.explore"]) < 2e-6
+    # the quirk is observable in the vector: tanh would have changed it
+    assert sc.rel_dev(np.tanh(raw_explore), gold["det.explore"]) > 1e-3
+    s = SAC(logger=NullLogger(), state_dim=S, action_dim=A, device="cuda").create()
+    ha.load_params(s.actor, fx.make_net(seed + 2, fx.actor_dims(S, A, gaussian=True)))
+    assert sc.rel_dev(s.actor.exploit(obs), gold["ga.exploit"]) < 2e-6
+    s.actor.train()
+    monkeypatch.setattr(t, "randn", lambda *a, **k: fx.make_noise(seed + 5, (1, A))[0])
+    sampled = s.actor.explore(obs)
+    monkeypatch.setattr(t, "randn", real_randn)
+    assert sc.rel_dev(sampled, gold["ga.explore"]) < 2e-6
+    s.actor.eval()
+    assert sc.rel_dev(s.actor.explore(obs), gold["ga.exploit"]) < 2e-6      # eval mode: tanh(mean)
+    s.actor.train()
+    assert list(d.actor.state_dict().keys()) == list(gold["det.keys"])
+    assert list(s.actor.state_dict().keys()) == list(gold["ga.keys"])
+
+
+def test_device_noise_stream_is_standard_normal_and_keyed_by_seed_rank_counter():
+    """The N(0,1) draws the TD3 / SAC / TQC kernels take on device when no noise is injected (Philox4x32-10 +
+    Box-Muller, csrc/philox.h), exported through oprl_debug_noise: moments, a Kolmogorov-Smirnov test against
+    the normal CDF, no correlation between neighbouring rows / columns / counters, and distinct streams for
+    distinct (seed, rank, stream, counter)."""
+    from scipy import stats
+    from oprl_amd import _capi
+    d = _ddpg()
+    L = d.learner
+    rows, cols = 4096, 64
+
+    def draw(stream_id, counter):
+        out = t.empty((rows, cols), dtype=t.float32, device="cuda")
+        _capi.check(L.lib.oprl_debug_noise(L.handle, stream_id, counter, rows, cols, _capi.ptr(out), _capi.current_stream()))
+        t.cuda.synchronize()
+        return out.cpu().numpy().astype(np.float64)
+
+    x = draw(1, 0)
+    n = x.size
+    assert abs(x.mean()) < 4 / np.sqrt(n) and abs(x.var() - 1) < 4 * np.sqrt(2 / n)
+    assert abs(stats.skew(x.ravel())) < 4 * np.sqrt(6 / n) and abs(stats.kurtosis(x.ravel())) < 4 * np.sqrt(24 / n)
+    ks = stats.kstest(x.ravel(), "norm")
+    assert ks.pvalue > 1e-3, ks
+    assert abs(np.abs(x).max() - 5.2) < 1.0          # 24-bit uniforms: the tail reaches ~5.6 sigma, no infinities
+    for a, b in ((x[:-1], x[1:]), (x[:, :-1], x[:, 1:]), (x, draw(1, 1)), (x, draw(2, 0))):
+        r = np.corrcoef(a.ravel(), b.ravel())[0, 1]
+        assert abs(r) < 4 / np.sqrt(a.size), r
+    assert np.array_equal(x, draw(1, 0))              # a pure function of (key, counter, row, col)
+    L.set_seed(7, 0)
+    y = draw(1, 0)
+    L.set_seed(7, 3)
+    z = draw(1, 0)
+    assert not np.array_equal(x, y) and not np.array_equal(y, z)
+    assert abs(np.corrcoef(x.ravel(), y.ravel())[0, 1]) < 4 / np.sqrt(n)
+    assert abs(np.corrcoef(y.ravel(), z.ravel())[0, 1]) < 4 / np.sqrt(n)
