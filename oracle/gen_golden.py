@@ -45,6 +45,14 @@ def _install_stubs():
     sys.modules["torch.utils.tensorboard.writer"] = wr
     if REF_SRC not in sys.path:
         sys.path.insert(0, REF_SRC)
+    # ``oprl`` must be the REFERENCE here: it has no __init__.py (a namespace package), so this repo's
+    # ``oprl/`` alias package (a regular package on sys.path[0] when run from the repo root) would win the
+    # import — pin the name to the reference's directory explicitly
+    for name in [m for m in sys.modules if m == "oprl" or m.startswith("oprl.")]:
+        del sys.modules[name]
+    pkg = types.ModuleType("oprl")
+    pkg.__path__ = [os.path.join(REF_SRC, "oprl")]
+    sys.modules["oprl"] = pkg
 
 
 class NullLogger:
@@ -380,6 +388,96 @@ def gen_policy_io():
     save("policy_io", **out)
 
 
+# --------------------------------------------------------------------------------------------------
+# G7: the CALLERS of the hot path — the reference's BaseTrainer.train,
+# run_policy_update_worker and run_env_worker driven with recording fakes (tests/caller_fakes.py); the
+# stored traces are what this repo's loop counterparts must reproduce (tests/test_callers_golden.py).
+# --------------------------------------------------------------------------------------------------
+TRAINER_KW = dict(num_steps=60, start_steps=12, batch_size=8, eval_interval=20, num_eval_episodes=2,
+                  save_policy_every=30, stdout_log_every=25, seed=3)
+WORKER_CFG = dict(batch_size=4, num_env_workers=3, episodes_per_worker=5, warmup_epochs=1, episode_length=6,
+                  learner_num_waits=2, warmup_env_steps=8)
+
+
+LEARNER_EPOCHS_FED = 12      # epochs 0..11: training from epoch 2 on, evaluation + policy save at epoch 10
+
+
+def _install_caller_stubs():
+    """Import-time dependencies of the reference's trainer / workers that are absent here (simulators, the
+    broker client, pydantic-settings): empty modules — the fakes replace everything they would do."""
+    import pydantic
+    for name, attrs in (("dm_control", {"suite": types.SimpleNamespace()}), ("gymnasium", {}), ("pika", {}),
+                        ("pydantic_settings", {"BaseSettings": pydantic.BaseModel})):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for k, v in attrs.items():
+                setattr(m, k, v)
+            sys.modules[name] = m
+
+
+def gen_callers():
+    import tempfile
+    import time
+    from tests import caller_fakes as cf
+    _install_caller_stubs()
+    from oprl.trainers.base_trainer import BaseTrainer
+    import oprl.distrib.policy_update_worker as puw
+    import oprl.distrib.env_worker as ew
+    out = {}
+    # ---- BaseTrainer.train (base_trainer.py:38-74)
+    with tempfile.TemporaryDirectory() as td:
+        tr = cf.Trace()
+        env = cf.FakeEnv(tr, "env", length=9, terminate_at=31)
+        BaseTrainer(logger=cf.FakeLogger(tr, Path(td)), env=env,
+                    make_env_test=lambda seed: (tr(f"make_env_test {seed}"), cf.FakeEnv(tr, "test_env", length=4))[1],
+                    replay_buffer=cf.FakeBuffer(tr), algo=cf.FakeAlgo(tr), **TRAINER_KW).train()
+        out["trainer"] = np.array(cf.compress(tr.events))
+        out["trainer_files"] = np.array(sorted(str(f.relative_to(td)) for f in Path(td).rglob("*") if f.is_file()))
+    # ---- run_policy_update_worker (policy_update_worker.py:22-92): three actors' queues pre-filled with twelve
+    # epochs of episodes; the learner then finds them empty and gives up after learner_num_waits polls
+    cfg = types.SimpleNamespace(**WORKER_CFG)
+    names = [f"{k}_{i}" for i in range(cfg.num_env_workers) for k in ("env", "policy")]
+    with tempfile.TemporaryDirectory() as td:
+        tr = cf.Trace()
+        reg = cf.Registry(tr, names)
+        import pickle
+        for epoch in range(LEARNER_EPOCHS_FED):
+            for i in range(cfg.num_env_workers):
+                ep = [[np.zeros(cf.S, np.float32), np.zeros(cf.A, np.float32), 0.0, False, np.zeros(cf.S, np.float32)]
+                      for _ in range(cfg.episode_length - (i == 1))]
+                reg.fifo[f"env_{i}"].append(pickle.dumps(ep))
+        saved_q, saved_sleep = puw.Queue, time.sleep
+        puw.Queue = reg.reference_queue_class()
+        time.sleep = lambda s: tr("sleep")
+        try:
+            puw.run_policy_update_worker(
+                make_algo=lambda lg: cf.FakeAlgo(tr, lg),
+                make_env_test=lambda seed: (tr(f"make_env_test {seed}"), cf.FakeEnv(tr, "test_env", length=4))[1],
+                make_buffer=lambda: cf.FakeBuffer(tr), make_logger=lambda: cf.FakeLogger(tr, Path(td)), config=cfg)
+        finally:
+            puw.Queue, time.sleep = saved_q, saved_sleep
+        out["learner"] = np.array(cf.compress([e for e in tr.events if e != "sleep"]))
+        out["learner_files"] = np.array(sorted(str(f.relative_to(td)) for f in Path(td).rglob("*") if f.is_file()))
+    # ---- run_env_worker (env_worker.py:15-64): the policy queue answers every episode at once
+    tr = cf.Trace()
+    reg = cf.Registry(tr, names)
+    for _ in range(cfg.episodes_per_worker):
+        reg.fifo["policy_1"].append(pickle.dumps({"w": t.zeros(1)}))
+    saved_q, saved_sleep = ew.Queue, time.sleep
+    ew.Queue = reg.reference_queue_class()
+    time.sleep = lambda s: tr("sleep")
+    import builtins
+    saved_print = builtins.print
+    builtins.print = lambda *a, **k: None
+    try:
+        ew.run_env_worker(make_env=lambda seed: cf.FakeEnv(tr, "env", length=cfg.episode_length, terminate_at=20),
+                          make_policy=lambda: cf.FakeActor(tr), config=cfg, id_worker=1)
+    finally:
+        ew.Queue, time.sleep, builtins.print = saved_q, saved_sleep, saved_print
+    out["actor"] = np.array(cf.compress([e for e in tr.events if e != "sleep"]))
+    save("callers", **out)
+
+
 def main():
     assert os.path.isdir(REF_SRC), "run in the build container (needs /root/reference)"
     t.set_num_threads(1)
@@ -391,6 +489,7 @@ def main():
     gen_tqc()
     gen_replay()
     gen_policy_io()
+    gen_callers()
 
 
 if __name__ == "__main__":
