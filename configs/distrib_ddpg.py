@@ -1,10 +1,16 @@
 """Distributed DDPG, the counterpart of the reference's configs/distrib_ddpg.py: a pool of CPU actor
-processes steps environments with a policy snapshot and feeds whole episodes to ONE learner process,
-which owns the GPU, keeps the replay in HBM and trains with the fused HIP update.  The processes talk
-over in-host queues (``oprl_amd/distrib/queue.py``); the reference used RabbitMQ for the same hand-off.
-The reference's own script also runs against this repo unchanged (same module paths, same keywords).
+processes steps environments with a policy snapshot and feeds the learner(s), which own the GPU(s), keep
+the replay in HBM and train with the fused HIP update.
 
-    python configs/distrib_ddpg.py --env walker-walk --device cuda
+    python configs/distrib_ddpg.py --env walker-walk --device cuda                 # one learner, in-host queues
+    python configs/distrib_ddpg.py --env walker-walk --learners 8 --actors 32      # BASELINE.json config 5
+
+With ``--learners 1`` the layout is the reference's: whole episodes to ONE learner, actors and learner taking
+turns, over in-host queues (``oprl_amd/distrib/queue.py``; the reference used RabbitMQ).  With ``--learners N``
+the run is N data-parallel learner processes, one per MI355X, gradients all-reduced over RCCL / xGMI, actor i
+writing into the HBM replay shard of rank i % N through a shared-memory ring, the policy published by rank 0 on
+a shared-memory board — actors and learners overlap (``oprl_amd/distrib/dp_learner.py``).  The reference's own
+script also runs against this repo unchanged (same module paths, same keywords).
 """
 import os
 import sys
@@ -27,9 +33,10 @@ cli = parse_args_distrib()
 HIDDEN = (256, 256)
 REPLAY_TRANSITIONS = 1_000_000
 
-# four actors x 100 episodes of 1000 steps per epoch; the learner starts after 16 warm-up epochs
-settings = DistribConfig(num_env_workers=4, episodes_per_worker=100, episode_length=1000, warmup_epochs=16,
-                         batch_size=128, learner_num_waits=10)
+# 32 actors (BASELINE.json config 5; the reference's script starts 4) x 100 episodes of 1000 steps; the
+# learner(s) start after 16 warm-up epochs
+settings = DistribConfig(num_env_workers=cli.actors or 32, episodes_per_worker=100, episode_length=1000,
+                         warmup_epochs=16, batch_size=128, learner_num_waits=10)
 
 
 def make_env(seed: int):
@@ -48,13 +55,15 @@ def make_policy():
                                device="cpu")
 
 
-def make_algo(logger):
-    return DDPG(logger=logger, state_dim=OBS_DIM, action_dim=ACT_DIM, device=cli.device).create()
+def make_algo(logger, **overrides):
+    """``overrides``: what a data-parallel rank needs on top (device=cuda:<rank>, export_grads=True)."""
+    return DDPG(logger=logger, state_dim=OBS_DIM, action_dim=ACT_DIM, **{"device": cli.device, **overrides}).create()
 
 
-def make_replay_buffer():
+def make_replay_buffer(**overrides):
+    """``overrides``: a data-parallel rank's device and sampler seed (its own HBM shard)."""
     return EpisodicReplayBuffer(buffer_size_transitions=REPLAY_TRANSITIONS, state_dim=OBS_DIM, action_dim=ACT_DIM,
-                                device=cli.device).create()
+                                **{"device": cli.device, **overrides}).create()
 
 
 def make_logger():
@@ -66,4 +75,5 @@ if __name__ == "__main__":
     run_distrib_training(config=settings, make_env=make_env, make_policy=make_policy, make_algo=make_algo,
                          make_replay_buffer=make_replay_buffer, make_logger=make_logger,
                          run_env_worker=env_worker.run_env_worker,
-                         run_policy_update_worker=policy_update_worker.run_policy_update_worker)
+                         run_policy_update_worker=policy_update_worker.run_policy_update_worker,
+                         learners=cli.learners)

@@ -298,6 +298,11 @@ int oprl_replay_destroy(oprl_replay* h);
  * flush/sample.  Index bookkeeping stays with the caller (it is host logic). */
 int oprl_replay_write(oprl_replay* h, int32_t ep, int32_t t, const float* state_host,
                       const float* action_host, float reward, float done);
+/* The same for n consecutive steps [t0, t0+n) of one episode from host records
+ * [state (S) | action (A) | reward | done | ...], row_stride floats apart: add_episode / a drained actor
+ * ring segment in one call.  Staging that fills up is flushed on `stream`. */
+int oprl_replay_write_block(oprl_replay* h, int32_t ep, int32_t t0, int32_t n, const float* rows_host,
+                            int32_t row_stride, void* stream);
 int oprl_replay_flush(oprl_replay* h, void* stream);
 /* Upload ep_lens[0:episodes_counter] (episodic_buffer.py:114-116); the device
  * keeps the cumulative ends for the flat-index -> (episode, step) map. */

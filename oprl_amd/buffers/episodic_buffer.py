@@ -138,9 +138,11 @@ class EpisodicReplayBuffer(ReplayBufferProtocol):
         s = np.ascontiguousarray(state, dtype=np.float32).reshape(self.state_dim)
         a = np.ascontiguousarray(action, dtype=np.float32).reshape(self.action_dim)  # f64 actions are cast
         if self._handle is not None:
-            _capi.check(self._lib.oprl_replay_write(
-                self._handle, e, l, s.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p),
-                float(reward), float(done)), "oprl_replay_write")
+            # (staging that fills up is flushed by the library: this buffer's device must be current then)
+            with _capi.on_device(self._dev):
+                _capi.check(self._lib.oprl_replay_write(
+                    self._handle, e, l, s.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p),
+                    float(reward), float(done)), "oprl_replay_write")
         else:  # host container only (no GPU): plain row stores
             self._tensors["states"][e, l] = t.from_numpy(s)
             self._tensors["actions"][e, l] = t.from_numpy(a)
@@ -152,7 +154,42 @@ class EpisodicReplayBuffer(ReplayBufferProtocol):
         if episode_done:
             self._inc_episode()
 
+    def add_transitions(self, rows: npt.NDArray, episode_done: bool = False) -> None:
+        """``len(rows)`` consecutive transitions of the episode being written, as float32 records
+        ``[state (S) | action (A) | reward | done | ...]`` (extra columns ignored) — the bookkeeping of that many
+        ``add_transition`` calls and ONE library call for the data (oprl_replay_write_block); with
+        ``episode_done`` the episode is closed after the last one.  What the learner ranks of the distributed
+        setup use to take in a whole actor episode (extension; the reference adds transitions one by one)."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        n, S, A = len(rows), self.state_dim, self.action_dim
+        if rows.ndim != 2 or rows.shape[1] < S + A + 2:
+            raise ValueError(f"rows must be [n, >= {S + A + 2}] float32 records")
+        e, l = self._ep_pointer, self.ep_lens[self._ep_pointer]
+        if l + n > self.max_episode_lenth:
+            raise IndexError(f"episode slot {e} would overflow ({l} + {n} steps, max_episode_lenth={self.max_episode_lenth})")
+        if n:
+            if self._handle is not None:
+                with _capi.on_device(self._dev):
+                    _capi.check(self._lib.oprl_replay_write_block(
+                        self._handle, e, l, n, rows.ctypes.data_as(C.c_void_p), rows.shape[1],
+                        _capi.current_stream()), "oprl_replay_write_block")
+            else:
+                self._tensors["states"][e, l:l + n] = t.from_numpy(rows[:, :S])
+                self._tensors["actions"][e, l:l + n] = t.from_numpy(rows[:, S:S + A])
+                self._tensors["rewards"][e, l:l + n, 0] = t.from_numpy(rows[:, S + A])
+                self._tensors["dones"][e, l:l + n, 0] = t.from_numpy(rows[:, S + A + 1])
+            self.ep_lens[e] += n
+            self._number_transitions = min(self._number_transitions + n, self.buffer_size_transitions)
+            self._lens_dirty = True
+        if episode_done:
+            self._inc_episode()
+
     def _inc_episode(self) -> None:
+        nxt = (self._ep_pointer + 1) % self._max_episodes
+        if self.ep_lens[nxt] > 0:
+            # the ring wraps onto a slot that holds data: rows staged for that slot and rows about to be
+            # staged for it must not meet in one scatter launch (its blocks run in no particular order)
+            self._flush()
         self._ep_pointer = (self._ep_pointer + 1) % self._max_episodes
         self.episodes_counter = min(self.episodes_counter + 1, self._max_episodes)
         self._number_transitions -= self.ep_lens[self._ep_pointer]

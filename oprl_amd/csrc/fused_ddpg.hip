@@ -39,6 +39,7 @@
 // draw and index map as k_replay_gather (step_n).
 #include "kernels.h"
 #include "philox.h"
+#include "replay_index.h"
 #include "slice_head.h"
 #include "tp4.h"
 
@@ -82,11 +83,8 @@ __device__ __forceinline__ void load_batch(const BatchSrc& P, int row0, int B, i
   const int tid = threadIdx.x;
   lds_zero(xa, 2 * kR * kX0Ld);   // xa and xb are adjacent
   if (P.gather) {
-    const bool in_lds = P.n_eps <= kMaxEnds;
-    if (in_lds)
-      for (int e = tid; e < P.n_eps; e += kThreads) endsS[e] = P.ends[e];
+    const EndsLds ET = stage_ends(P.ends, P.n_eps, endsS, kMaxEnds, tid, kThreads);
     __syncthreads();
-    const int* ends = in_lds ? endsS : P.ends;
     if (tid < kR) {
       const int i = row0 + tid;
       int e = 0, t = 0;
@@ -95,13 +93,9 @@ __device__ __forceinline__ void load_batch(const BatchSrc& P, int row0, int B, i
             u32x4{(uint32_t)P.counter, (uint32_t)(P.counter >> 32), (uint32_t)i, 0x5a17u},
             (uint32_t)P.seed, (uint32_t)(P.seed >> 32));
         const long ind = (long)bounded_u32(rnd.x, (uint32_t)P.n_transitions);
-        int lo = 0, hi = P.n_eps;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if ((long)ends[mid] > ind) hi = mid; else lo = mid + 1;
-        }
-        e = lo < P.n_eps ? lo : 0;
-        t = (int)(ind - (e > 0 ? (long)ends[e - 1] : 0));
+        long start = 0;
+        e = find_episode(P.ends, P.n_eps, ET, ind, &start);
+        t = (int)(ind - start);
       }
       meta[tid] = e;
       meta[kR + tid] = t;

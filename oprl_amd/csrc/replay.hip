@@ -19,6 +19,7 @@
 
 #include "../../include/oprl_amd.h"
 #include "philox.h"
+#include "replay_index.h"
 
 namespace oprl {
 void set_err(const char* fmt, ...);
@@ -59,14 +60,10 @@ __global__ __launch_bounds__(kGatherThreads) void k_replay_gather(const GatherAr
   __shared__ int s_ep[kSamplesPerWg], s_t[kSamplesPerWg];
   __shared__ int s_ends[kMaxEndsLds];
   const int tid = threadIdx.x;
-  // the episode table (<= 4 KB at the reference's 1000 episodes) goes to LDS in
-  // one coalesced pass; a binary search over global memory is 10 dependent
-  // round trips to L2/HBM (measured 7.4 us for this kernel before)
-  const bool ends_in_lds = G.n_eps <= kMaxEndsLds;
-  if (ends_in_lds)
-    for (int e = tid; e < G.n_eps; e += kGatherThreads) s_ends[e] = G.ends[e];
+  // the episode table goes to LDS in one coalesced pass (whole, or every stride-th end: replay_index.h); a
+  // binary search over global memory is 10+ dependent round trips to L2/HBM (measured 7.4 us for this kernel)
+  const oprl::EndsLds ET = oprl::stage_ends(G.ends, G.n_eps, s_ends, kMaxEndsLds, tid, kGatherThreads);
   __syncthreads();
-  const int* ends = ends_in_lds ? s_ends : G.ends;
   const int base = blockIdx.x * kSamplesPerWg;
   const int S = G.S, A = G.A, W = 2 * S + A + 2;
   if (tid < kSamplesPerWg) {
@@ -83,13 +80,8 @@ __global__ __launch_bounds__(kGatherThreads) void k_replay_gather(const GatherAr
         ind = (long)oprl::bounded_u32(r.x, (uint32_t)G.n_transitions);
       }
       // first episode with ends[e] > ind  (np.argmin over the >= mask; all-True -> 0)
-      int lo = 0, hi = G.n_eps;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if ((long)ends[mid] > ind) hi = mid; else lo = mid + 1;
-      }
-      e = lo < G.n_eps ? lo : 0;
-      const long start = e > 0 ? (long)ends[e - 1] : 0;
+      long start = 0;
+      e = oprl::find_episode(G.ends, G.n_eps, ET, ind, &start);
       t = (int)(ind - start);
       if (G.out_ep != nullptr) G.out_ep[i] = e;
       if (G.out_step != nullptr) G.out_step[i] = t;
@@ -253,6 +245,33 @@ extern "C" int oprl_replay_write(oprl_replay* h, int32_t ep, int32_t t, const fl
   row[2 + h->S + h->A] = reward;
   row[3 + h->S + h->A] = done;
   ++h->n_staged;
+  return OPRL_OK;
+}
+
+// n consecutive steps [t0, t0 + n) of episode `ep` from host records [s (S) | a (A) | r | d | ...] that are
+// `row_stride` floats apart — a whole episode (or a drained ring segment) in ONE call instead of n
+// oprl_replay_write calls (the learner ranks of the distributed setup take in tens of thousands of
+// transitions per second).  Staging that fills up is flushed on `stream`.
+extern "C" int oprl_replay_write_block(oprl_replay* h, int32_t ep, int32_t t0, int32_t n, const float* rows_host,
+                                       int32_t row_stride, void* stream) {
+  if (!h || !rows_host || n < 0) { set_err("oprl_replay_write_block: invalid argument"); return OPRL_ERR_INVALID; }
+  if (ep < 0 || ep >= h->E || t0 < 0 || t0 + n > h->L || row_stride < h->S + h->A + 2) {
+    set_err("oprl_replay_write_block: steps [%d,%d) of episode %d outside [%d,%d) x [0,%d) or stride %d too small",
+            t0, t0 + n, ep, 0, h->E, h->L, row_stride);
+    return OPRL_ERR_INVALID;
+  }
+  for (int i = 0; i < n; ++i) {
+    if (h->n_staged == kStageRows) {
+      int rc = oprl_replay_flush(h, stream);
+      if (rc != OPRL_OK) return rc;
+    }
+    float* row = h->stage_host[h->cur] + (size_t)h->n_staged * h->rowlen;
+    const int t = t0 + i;
+    memcpy(row, &ep, 4);
+    memcpy(row + 1, &t, 4);
+    memcpy(row + 2, rows_host + (size_t)i * row_stride, sizeof(float) * (h->S + h->A + 2));
+    ++h->n_staged;
+  }
   return OPRL_OK;
 }
 

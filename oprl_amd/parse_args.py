@@ -17,6 +17,10 @@ _SINGLE = (
 )
 _DISTRIB = (
     ("--seed", int, 0, "random seed of the run"),
+    # extension (BASELINE.json config 5): > 1 = that many data-parallel learner processes, one per GPU,
+    # fed over shared-memory rings (runners/train_distrib.py::run_dp_training); 1 = the reference's layout
+    ("--learners", int, 1, "data-parallel learner processes (one per GPU)"),
+    ("--actors", int, 0, "CPU actor processes (0: the script's default)"),
 )
 
 

@@ -83,3 +83,59 @@ def test_empty_and_ragged():
     with pytest.raises(IndexError):
         for _ in range(11):
             buf.add_transition(np.ones(3, np.float32), np.ones(2), 1.0, False)
+
+
+def test_block_write_equals_transition_writes_on_device():
+    """oprl_replay_write_block (whole actor episodes, staging overflow included) against oprl_replay_write:
+    identical HBM storage and identical gathers, across ring wrap-around."""
+    import numpy as np
+    import torch as t
+    from oprl_amd.buffers.episodic_buffer import EpisodicReplayBuffer
+
+    def mk():
+        return EpisodicReplayBuffer(buffer_size_transitions=6000, state_dim=7, action_dim=3, max_episode_lenth=500,
+                                    device="cuda", seed=5).create()
+    a, b = mk(), mk()
+    rs = np.random.RandomState(1)
+    for _ep in range(30):                      # 12 slots of 500: wraps; 30 x ~400 rows overflow the 4096-row staging
+        n = int(rs.randint(300, 501))
+        rows = rs.standard_normal((n, 7 + 3 + 3)).astype(np.float32)
+        rows[:, 11] = rs.rand(n) < 0.01
+        for k, r in enumerate(rows):
+            a.add_transition(r[:7], r[7:10], float(r[10]), bool(r[11]), episode_done=(k == n - 1))
+        b.add_transitions(rows, episode_done=True)
+    assert a.ep_lens == b.ep_lens and len(a) == len(b)
+    for k in ("states", "actions", "rewards", "dones"):
+        assert t.equal(getattr(a, k), getattr(b, k)), k
+    inds = np.random.RandomState(2).randint(0, len(a), 512)
+    for x, y in zip(a.sample(512, inds=inds), b.sample(512, inds=inds)):
+        assert t.equal(x, y)
+
+
+def test_index_map_with_more_episodes_than_the_lds_table_holds():
+    """5000 short episodes (> the 2048-entry LDS table: coarse table + global finish, csrc/replay_index.h), ragged
+    lengths: injected flat indices must map to the (episode, step) numpy's cumulative-ends rule gives — the gather
+    kernel and the fused update kernels' own sampler (step_n) share the routine."""
+    import numpy as np
+    import torch as t
+    from oprl_amd.buffers.episodic_buffer import EpisodicReplayBuffer
+    E, L, S, A = 5000, 40, 4, 2
+    buf = EpisodicReplayBuffer(buffer_size_transitions=E * L, state_dim=S, action_dim=A, max_episode_lenth=L,
+                               device="cuda").create()
+    rs = np.random.RandomState(0)
+    lens = rs.randint(1, L + 1, size=E)
+    buf._tensors["states"].copy_(t.arange(E * (L + 1) * S, dtype=t.float32, device="cuda").view(E, L + 1, S))
+    buf.ep_lens = [int(x) for x in lens]
+    buf.episodes_counter = E
+    buf._number_transitions = int(lens.sum())
+    buf._lens_dirty = True
+    ends = np.cumsum(lens)
+    inds = np.concatenate([rs.randint(0, ends[-1], 2000), [0, ends[-1] - 1], ends[:50] - 1, ends[:50]])
+    inds = inds[inds < ends[-1]]
+    (s, _a, _r, _d, s2), (ep, st) = buf.sample(len(inds), inds=inds, return_indices=True)
+    want_ep = np.searchsorted(ends, inds, side="right")
+    want_st = inds - np.where(want_ep > 0, ends[np.maximum(want_ep - 1, 0)], 0)
+    assert np.array_equal(ep.cpu().numpy(), want_ep) and np.array_equal(st.cpu().numpy(), want_st)
+    base = (want_ep * (L + 1) + want_st) * S
+    assert np.array_equal(s[:, 0].cpu().numpy(), base.astype(np.float32))
+    assert np.array_equal(s2[:, 0].cpu().numpy(), (base + S).astype(np.float32))

@@ -270,3 +270,27 @@ def test_synthetic_env_dynamics_do_not_depend_on_the_interpreter_hash_seed():
     assert e.env_family == "synthetic"
     with pytest.raises(ValueError):
         make_env("Ant-v4", 0)
+
+
+def test_add_transitions_block_equals_transition_by_transition():
+    """The block write the distributed learner ranks use (one library call per actor episode) leaves the
+    replay exactly as the same transitions added one by one: storage, lengths, pointer, eviction."""
+    from oprl_amd.buffers.episodic_buffer import EpisodicReplayBuffer
+
+    def mk():
+        return EpisodicReplayBuffer(buffer_size_transitions=40, state_dim=3, action_dim=2, max_episode_lenth=10,
+                                    device="cpu").create()
+    a, b = mk(), mk()
+    rs = np.random.RandomState(0)
+    for _ep in range(9):                       # 4 slots: wraps and evicts
+        n = int(rs.randint(1, 11))
+        rows = rs.standard_normal((n, 3 + 2 + 3)).astype(np.float32)
+        rows[:, 6] = rs.rand(n) < 0.1
+        for k, r in enumerate(rows):
+            a.add_transition(r[:3], r[3:5], float(r[5]), bool(r[6]), episode_done=(k == n - 1))
+        b.add_transitions(rows, episode_done=True)
+        assert (a.ep_lens, len(a), a.episodes_counter, a._ep_pointer) == (b.ep_lens, len(b), b.episodes_counter, b._ep_pointer)
+    for k in ("states", "actions", "rewards", "dones"):
+        assert t.equal(a._tensors[k], b._tensors[k]), k
+    with pytest.raises(IndexError):
+        b.add_transitions(np.zeros((11, 8), np.float32))
