@@ -59,7 +59,7 @@ assert MACS_P1 + MACS_P2 == MACS_SLICE
 STATE_BYTES = 32 * (F_ACTOR + HID * 2 + A + F_CRITIC + HID * 2 + 1)  # 32 B per trainable param
 
 
-def make_replay(device, seed):
+def make_replay(device, seed, S=S, A=A):
     from oprl_amd.buffers.episodic_buffer import EpisodicReplayBuffer
     buf = EpisodicReplayBuffer(buffer_size_transitions=E * L, state_dim=S, action_dim=A,
                                device=str(device), seed=seed).create()
@@ -121,6 +121,91 @@ def cpu_baseline(budget_s: float = 14.0):
                 sample=f"DDPG sample+update (B={B}, walker dims) with the torch-CPU oracle, "
                        f"{budget_s / 2:.0f} s per setting: {detail}; host has {os.cpu_count()} cores, "
                        f"torch {t.__version__}")
+
+
+# ---- the other BASELINE.json configurations, the bf16 mode and the through-the-API rate --------
+PEAK_BF16_MATRIX_TFLOPS = 2500.0       # dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_TBS = 8.0
+# name -> (class name, S, A, B, constructor extras, algorithmic GFLOP / update, state MB / update): BASELINE.md section 4
+BASELINE_CONFIGS = {
+    "DDPG walker-walk B=256": ("DDPG", 24, 6, 256, {}, 0.365, 4.73),
+    "TD3 cheetah-run B=256": ("TD3", 17, 6, 256, {"log_every": 10 ** 9}, 0.413, 5.19),
+    "SAC humanoid-walk B=1024": ("SAC", 67, 21, 1024, {"log_every": 10 ** 9}, 2.74, 7.94),
+    "TQC walker-walk B=256 5x25": ("TQC", 24, 6, 256, {"log_every": 10 ** 9}, 8.57, 90.4),
+}
+
+
+def _make_algo(cls_name, S_, A_, B_, extras, dev, precision="f32", seed=0):
+    import importlib
+    from oprl_amd.logging import NullLogger
+    cls = getattr(importlib.import_module(f"oprl_amd.algos.{cls_name.lower()}"), cls_name)
+    t.manual_seed(seed)
+    return cls(logger=NullLogger(), state_dim=S_, action_dim=A_, device=str(dev), max_batch=B_,
+               precision=precision, **extras).create()
+
+
+def _time_step_n(algo, replay, B_, n, dev):
+    L_ = algo.learner
+    L_.step_n(replay.handle, max(n // 10, 50), B_, seed=1)
+    best = 1e30
+    for _rep in range(2):
+        t.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        L_.step_n(replay.handle, n, B_, seed=2)
+        t.cuda.synchronize(dev)
+        best = min(best, time.perf_counter() - t0)
+    return best / n
+
+
+def config_table(dev, replays, n_steps=2000):
+    """Every BASELINE.json single-GPU configuration through the fused step_n path, fp32 (the parity mode)
+    and bf16: updates/s, us/update and the fraction of the binding roof for the WHOLE update — the larger
+    of (algorithmic FLOP / matrix peak of the mode) and (state bytes / HBM peak) over the measured time."""
+    rows = []
+    for name, (cls_name, S_, A_, B_, extras, gflop, mbytes) in BASELINE_CONFIGS.items():
+        replay = replays(S_, A_)
+        for prec, peak in (("f32", PEAK_F32_MATRIX_TFLOPS), ("bf16", PEAK_BF16_MATRIX_TFLOPS)):
+            algo = _make_algo(cls_name, S_, A_, B_, extras, dev, prec)
+            n = n_steps if cls_name != "TQC" else max(n_steps // 4, 200)
+            sec = _time_step_n(algo, replay, B_, n, dev)
+            t_mfma, t_hbm = gflop * 1e9 / (peak * 1e12), mbytes * 1e6 / (PEAK_HBM_TBS * 1e12)
+            rows.append(dict(name=name, dtype=prec, steps_per_s=round(1.0 / sec, 1), us_per_step=round(sec * 1e6, 2),
+                             roof="mfma" if t_mfma >= t_hbm else "hbm",
+                             roofline_frac=round(max(t_mfma, t_hbm) / sec, 5), path="oprl_learner_step_n",
+                             steps=n))
+            algo.learner.check()
+            del algo
+    return rows
+
+
+def bf16_q_deviation(dev, replay, updates=10):
+    """Q(s, a) of an fp32 and a bf16 DDPG learner after the same `updates` updates (same initial weights,
+    same minibatches): max-norm relative deviation on a fixed probe batch — the accuracy price of the mode."""
+    a32 = _make_algo("DDPG", S, A, B, {}, dev, "f32")
+    a16 = _make_algo("DDPG", S, A, B, {}, dev, "bf16")
+    g = t.Generator(device=dev).manual_seed(7)
+    ps = t.randn((B, S), device=dev, generator=g)
+    pa = t.rand((B, A), device=dev, generator=g) * 2 - 1
+    for a in (a32, a16):
+        a.learner.step_n(replay.handle, updates, B, seed=11)
+    q32, q16 = a32.critic(ps, pa), a16.critic(ps, pa)
+    return float((q16 - q32).abs().max() / q32.abs().max())
+
+
+def api_rate(dev, replay, n=3000):
+    """The reference's call pattern from Python, one call pair per step: replay_buffer.sample(B) then
+    algo.update(*batch) (trainers/base_trainer.py:63-70)."""
+    algo = _make_algo("DDPG", S, A, B, {}, dev)
+    for _ in range(200):
+        algo.update(*replay.sample(B))
+    t.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        algo.update(*replay.sample(B))
+    t.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return dict(value=round(n / dt, 1), unit="steps/s", us_per_step=round(dt / n * 1e6, 2), steps=n,
+                path="EpisodicReplayBuffer.sample() + DDPG.update() from Python (two C calls: gather kernel, 4 update launches)")
 
 
 def multi_learner(n, dev, local_rank, steps):
@@ -213,6 +298,13 @@ def main():
     ap.add_argument("--learners", type=int, default=8,
                     help="extra measurement: this many independent learners (seeds) on separate "
                          "streams of the same GPU (multi-seed packing, runners/train.py --seeds); 0 = skip")
+    ap.add_argument("--pre-warm", type=int, default=3000,
+                    help="untimed updates BEFORE the --warmup ones (GPU clock ramp, first touches): the driver's short "
+                         "runs (--steps 20 --warmup 5) otherwise time the learner at ramping clocks, 5 %% low")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the extra blocks: the other BASELINE.json configs (TD3 / SAC / TQC, fp32 and bf16), the "
+                         "bf16 DDPG line and the through-the-API rate")
+    ap.add_argument("--config-steps", type=int, default=2000)
     ap.add_argument("--no-p2p", action="store_true",
                     help="data-parallel path: keep the gradient exchanges on RCCL (default: one-shot peer-window "
                          "all-reduce when its self-test passes)")
@@ -267,6 +359,7 @@ def main():
 
         def run(n):
             learner.step_n(replay.handle, n, B, seed=0)
+        run(args.pre_warm)          # clock ramp / first-touch, before the W warm-up steps of the contract
         run(W)
     else:
         from oprl_amd.parallel import DataParallelLearner
@@ -279,8 +372,8 @@ def main():
         def build(level):
             algo_ = make_learner()
             dp_ = DataParallelLearner(algo_, dist.group.WORLD)
-            dp_.broadcast_parameters()
             dp_.init_native_comm()
+            dp_.broadcast_parameters()             # (oprl_comm_broadcast_params: ncclBroadcast from rank 0 in C)
             ok_ = True
             if level > 0:
                 try:
@@ -322,6 +415,7 @@ def main():
         algo, dp, ok = build(p2p_level)
         assert ok, "the probed exchange level failed on rebuild"
         learner = algo.learner
+        dp.step_n(replay.handle, args.pre_warm, B, seed=0)
         dp.step_n(replay.handle, W, B, seed=0)
         use_p2p = p2p_level > 0
 
@@ -391,6 +485,8 @@ def main():
             dom = "k_ddpg_phase1" if "k_ddpg_phase1" in kern else "k_mlp_slice"
             macs = MACS_P1 if dom == "k_ddpg_phase1" else MACS_SLICE / kern[dom]["launches_per_step"]
             flop_per_launch = 2.0 * B * macs
+            if kern[dom]["us_per_launch"] <= 0.0:          # (a very short run: the overhead estimate swallowed the reading)
+                kern[dom]["us_per_launch"] = kern[dom]["us_per_launch_raw"]
             ach = flop_per_launch / (kern[dom]["us_per_launch"] * 1e-6) / 1e12
             traffic = None
             try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
@@ -420,12 +516,31 @@ def main():
         multi = None
         if not use_dp and args.learners > 1:
             multi = multi_learner(args.learners, dev, local_rank, steps=max(200, min(K, 2000)))
+        configs = bf16 = api = None
+        if not use_dp and not args.no_configs:
+            cache = {(S, A): replay}
+
+            def replays(S_, A_):
+                # (one extra replay resident at a time: the humanoid one is 0.5 GB)
+                for k in [k for k in cache if k != (S, A) and k != (S_, A_)]:
+                    del cache[k]
+                if (S_, A_) not in cache:
+                    cache[(S_, A_)] = make_replay(dev, seed=rank, S=S_, A=A_)
+                return cache[(S_, A_)]
+            configs = config_table(dev, replays, n_steps=args.config_steps)
+            d16 = next(r for r in configs if r["name"].startswith("DDPG") and r["dtype"] == "bf16")
+            bf16 = dict(value=d16["steps_per_s"], unit="steps/s", us_per_step=d16["us_per_step"],
+                        roofline_frac=d16["roofline_frac"], roof=d16["roof"], peak_tflops=PEAK_BF16_MATRIX_TFLOPS,
+                        q_rel_dev_vs_f32_after_10_updates=round(bf16_q_deviation(dev, replay), 6),
+                        note="OPRL_PREC_BF16: v_mfma_f32_16x16x32_bf16, fp32 accumulate / master / Adam; the "
+                             "headline `value` above stays the fp32 parity mode")
+            api = api_rate(dev, replay)
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()   # rank 0 at N = 1 only
         out = {
             "metric": "learner gradient steps/sec, DDPG batch=256 walker-walk",
             "value": round(value, 1), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "pre_warm_steps": args.pre_warm,
             "config": {"workload": f"DDPG walker-walk dims S={S} A={A} B={B}, hidden (256,256), replay "
                                    f"{E}x{L} transitions resident in HBM, device-side uniform sampling, "
                                    "exact-fp32 MFMA (parity mode)",
@@ -435,7 +550,8 @@ def main():
                                    1: "one-shot peer-window all-reduce over xGMI, one kernel per exchange (csrc/p2p.hip)",
                                    0: "RCCL ncclAllReduce"}[p2p_level]),
                        "parallelism": f"dp{world}", "global_batch": B * world},
-            "roofline": roof, "cpu_baseline": cpu, "multi_learner": multi, "data_parallel_check": dp_check,
+            "roofline": roof, "cpu_baseline": cpu, "configs": configs, "bf16": bf16, "api_rate": api,
+            "multi_learner": multi, "data_parallel_check": dp_check,
             "flop_per_step": 2.0 * B * (MACS_SLICE + MACS_DW), "state_bytes_per_step": STATE_BYTES,
         }
         print(json.dumps(out), flush=True)

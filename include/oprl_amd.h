@@ -244,6 +244,9 @@ int oprl_polyak(float* target, const float* source, int64_t n, double tau, void*
 int oprl_comm_unique_id(const char* rccl_path, char id_out[OPRL_COMM_ID_BYTES]);
 int oprl_comm_init(oprl_learner* h, const char* rccl_path, int32_t rank, int32_t world,
                    const char id[OPRL_COMM_ID_BYTES]);
+/* Make every replica identical to rank `root` (ncclBroadcast of every net's theta / theta_target / Adam
+ * moments and of the temperature with its moments; the packs are rebuilt).  Once, after oprl_comm_init. */
+int oprl_comm_broadcast_params(oprl_learner* h, int32_t root, void* stream);
 /* Optional: the two gradient exchanges as ONE-SHOT all-reduces over peer windows (csrc/p2p.hip)
  * instead of RCCL rings — every rank pushes its arena straight into a slot of every other rank's
  * window over the xGMI mesh and sums the slots in rank order.  oprl_p2p_create allocates this rank's

@@ -99,6 +99,7 @@ SIGNATURES = {
     "oprl_learner_set_trace": (C.c_int, [_P, _P]),
     "oprl_comm_unique_id": (C.c_int, [C.c_char_p, C.c_char_p]),
     "oprl_comm_init": (C.c_int, [_P, C.c_char_p, _I32, _I32, C.c_char_p]),
+    "oprl_comm_broadcast_params": (C.c_int, [_P, _I32, _P]),
     "oprl_p2p_create": (C.c_int, [_P, _I32, _I32, _P]),
     "oprl_p2p_connect": (C.c_int, [_P, _P]),
     "oprl_p2p_selftest": (C.c_int, [_P, _P]),

@@ -173,6 +173,7 @@ struct NcclId { char internal[OPRL_COMM_ID_BYTES]; };
 typedef int (*fn_get_unique_id)(NcclId*);
 typedef int (*fn_comm_init_rank)(void**, int, NcclId, int);
 typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_comm_destroy)(void*);
 typedef const char* (*fn_get_error_string)(int);
 constexpr int kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0;
@@ -182,6 +183,7 @@ struct Rccl {
   fn_get_unique_id get_unique_id = nullptr;
   fn_comm_init_rank comm_init_rank = nullptr;
   fn_all_reduce all_reduce = nullptr;
+  fn_broadcast broadcast = nullptr;
   fn_comm_destroy comm_destroy = nullptr;
   fn_get_error_string err_str = nullptr;
   void* comm = nullptr;
@@ -195,6 +197,7 @@ int rccl_bind(Rccl& r, const char* path) {
   r.get_unique_id = (fn_get_unique_id)dlsym(r.lib, "ncclGetUniqueId");
   r.comm_init_rank = (fn_comm_init_rank)dlsym(r.lib, "ncclCommInitRank");
   r.all_reduce = (fn_all_reduce)dlsym(r.lib, "ncclAllReduce");
+  r.broadcast = (fn_broadcast)dlsym(r.lib, "ncclBroadcast");
   r.comm_destroy = (fn_comm_destroy)dlsym(r.lib, "ncclCommDestroy");
   r.err_str = (fn_get_error_string)dlsym(r.lib, "ncclGetErrorString");
   if (!r.get_unique_id || !r.comm_init_rank || !r.all_reduce) {
@@ -1235,6 +1238,30 @@ extern "C" int oprl_comm_init(oprl_learner* h, const char* rccl_path, int32_t ra
   h->rccl.world = world;
   h->noise_rank = rank;          // every rank draws its own in-update noise
   return OPRL_OK;
+}
+
+// Every replica identical to rank `root`: parameters, targets, Adam moments (and the temperature with its
+// moments) of all nets by ncclBroadcast, then the derived packs rebuilt.  Done once after oprl_comm_init
+// ("parameters, targets and Adam state replicated, broadcast from rank 0 once").
+extern "C" int oprl_comm_broadcast_params(oprl_learner* h, int32_t root, void* stream) {
+  if (!h || !h->rccl.comm) { set_err("oprl_comm_broadcast_params: call oprl_comm_init first"); return OPRL_ERR_STATE; }
+  if (!h->rccl.broadcast) { set_err("the RCCL library does not export ncclBroadcast"); return OPRL_ERR_INVALID; }
+  if (root < 0 || root >= h->rccl.world) { set_err("oprl_comm_broadcast_params: bad root %d", root); return OPRL_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  const oprl_learner_config& c = h->cfg;
+  auto bc_net = [&](const oprl_net& n) -> int {
+    const size_t cnt = (size_t)net_param_count(n);
+    float* arenas[4] = {n.theta, n.theta_target, n.adam_m, n.adam_v};
+    for (float* a : arenas)
+      if (a != nullptr) NCCLC(h, h->rccl.broadcast(a, a, cnt, kNcclFloat32, root, h->rccl.comm, st));
+    return OPRL_OK;
+  };
+  RC(bc_net(c.actor));
+  for (int j = 0; j < h->nc; ++j) RC(bc_net(c.critics[j]));
+  double* scalars[3] = {c.log_alpha, c.log_alpha_m, c.log_alpha_v};
+  for (double* p : scalars)
+    if (p != nullptr) NCCLC(h, h->rccl.broadcast(p, p, 1, kNcclFloat64, root, h->rccl.comm, st));
+  return oprl_learner_sync_params(h, stream);
 }
 
 // ---- one-shot all-reduce over peer windows (csrc/p2p.hip) -------------------------------------------

@@ -128,9 +128,9 @@ def learner_rank_loop(rank: int, world: int, algo, buffer, rings: list[Transitio
     dp = None
     if not solo:
         dp = DataParallelLearner(algo, group, engine=eng)
-        dp.broadcast_parameters(src=0)
         if native:
             dp.init_native_comm()
+        dp.broadcast_parameters(src=0)
     if rank == 0:
         board.publish(flatten_state_dict(algo.get_policy_state_dict()))
     dev = getattr(eng, "device", None) or t.device("cpu")

@@ -146,9 +146,22 @@ class DataParallelLearner:
         return out
 
     def broadcast_parameters(self, src: int = 0) -> None:
-        """Make every replica bit-identical to rank ``src`` (done once)."""
+        """Make every replica bit-identical to rank ``src`` (done once).  With the library's own RCCL
+        communicator (init_native_comm) this is one C call, oprl_comm_broadcast_params; otherwise
+        torch.distributed broadcasts of the same arenas (any backend; the gloo tests)."""
+        if getattr(self, "_native", False) and getattr(self.engine, "handle", None) is not None \
+                and not getattr(self, "p2p", False):
+            from oprl_amd import _capi
+            with t.cuda.device(self.engine.device):
+                _capi.check(self.engine.lib.oprl_comm_broadcast_params(self.engine.handle, int(src),
+                                                                       _capi.current_stream()),
+                            "oprl_comm_broadcast_params")
+            self.engine.sync_params()
+            return
         for x in self._state_tensors():
             dist.broadcast(x, src=src, group=self.group)
+        if hasattr(self.engine, "sync_params"):
+            self.engine.sync_params()      # the fragment packs are derived from the arenas just overwritten
 
     def replica_checksum(self) -> t.Tensor:
         """[max - min] over ranks of a parameter checksum: 0 iff replicas agree."""

@@ -293,8 +293,13 @@ def test_native_dp_single_rank_equals_export_split():
         a1, a2 = _ddpg(max_batch=B, export_grads=True), _ddpg(max_batch=B, export_grads=True)
         buf = _filled_buffer()
         dp = DataParallelLearner(a1)
-        dp.broadcast_parameters()
         dp.init_native_comm()
+        # the library's own broadcast (oprl_comm_broadcast_params: ncclBroadcast of every arena, packs rebuilt);
+        # with one rank it must leave the replica exactly as it is
+        before = [x.clone() for x in dp._state_tensors()]
+        dp.broadcast_parameters(src=0)
+        t.cuda.synchronize()
+        assert all(t.equal(a, b) for a, b in zip(before, dp._state_tensors()))
         dp.step_n(buf.handle, K, B, seed=5)
         # python-driven reference: same shard key as the C loop derives for rank 0
         buf.seed = (5 * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
