@@ -156,8 +156,10 @@ int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t K, int32_t
                         uint64_t seed, void* stream);
 
 /* Diagnostics of the most recent update, read without forcing a sync inside
- * update(): out_host[0]=critic_loss, [1]=actor_loss, [2]=mean q, [3]=mean
- * target, [4]=alpha, [5]=update_step.  Synchronises `stream`. */
+ * update(): out_host[0]=critic_loss, [1]=-mean q(s, pi) (DDPG / TD3 actor loss; min over twins for SAC),
+ * [2]=mean q over all critics, [3]=mean target, [4]=alpha, [5]=update_step, and (n up to 10) [6]=mean q of
+ * critic 0 (the reference's "q1"), [7]=mean log pi of the actor step, [8]=SAC / TQC actor loss
+ * alpha * mean(log pi) - mean(min q), [9]=temperature loss.  Synchronises `stream`. */
 int oprl_learner_read_scalars(oprl_learner* h, float* out_host, int32_t n, void* stream);
 /* Rebuild every pack of the learner's nets from their masters (after the caller
  * changed parameters from outside, e.g. load_state_dict). */

@@ -321,11 +321,12 @@ class HipLearner:
                     "oprl_learner_set_seed")
 
     def read_scalars(self) -> dict[str, float]:
-        buf = (C.c_float * 6)()
+        buf = (C.c_float * 10)()
         with _capi.on_device(self.device):
-            _capi.check(self.lib.oprl_learner_read_scalars(self.handle, buf, 6, _capi.current_stream()),
+            _capi.check(self.lib.oprl_learner_read_scalars(self.handle, buf, 10, _capi.current_stream()),
                         "oprl_learner_read_scalars")
-        keys = ("critic_loss", "actor_loss", "q_mean", "q_target_mean", "alpha", "update_step")
+        keys = ("critic_loss", "actor_loss", "q_mean", "q_target_mean", "alpha", "update_step",
+                "q1_mean", "log_pi_mean", "gauss_actor_loss", "alpha_loss")
         return dict(zip(keys, (float(x) for x in buf)))
 
     @property

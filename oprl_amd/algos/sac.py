@@ -107,8 +107,16 @@ class SAC(OffPolicyAlgorithm):
 
     def _log_update(self, step: int) -> None:
         if step % self.log_every == 0:
+            # the reference's tag set (sac.py:108-155), read from the kernels' partial sums in one host sync
             sc = self.learner.read_scalars()
             self.logger.log_scalars({
-                "algo/q1": sc["q_mean"], "algo/q_target": sc["q_target_mean"],
-                "algo/critic_loss": sc["critic_loss"], "algo/alpha": sc["alpha"],
+                "algo/q1": sc["q1_mean"], "algo/q_target": sc["q_target_mean"],
+                "algo/abs_q_err": sc["q1_mean"] - sc["q_target_mean"],
+                "algo/critic_loss": sc["critic_loss"],
+            }, step)
+            if self.tune_alpha:
+                self.logger.log_scalar("algo/loss_alpha", sc["alpha_loss"], step)
+            self.logger.log_scalars({
+                "algo/loss_actor": sc["gauss_actor_loss"], "algo/alpha": sc["alpha"],
+                "algo/log_pi": sc["log_pi_mean"],
             }, step)

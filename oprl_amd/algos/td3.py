@@ -109,9 +109,9 @@ class TD3(OffPolicyAlgorithm):
     def _log_update(self, step: int) -> None:
         if step % self.log_every == 0:
             sc = self.learner.read_scalars()   # the only host sync, every log_every updates
-            self.logger.log_scalar("algo/q1", sc["q_mean"], step)
+            self.logger.log_scalar("algo/q1", sc["q1_mean"], step)
             self.logger.log_scalar("algo/q_target", sc["q_target_mean"], step)
-            self.logger.log_scalar("algo/abs_q_err", sc["q_mean"] - sc["q_target_mean"], step)
+            self.logger.log_scalar("algo/abs_q_err", sc["q1_mean"] - sc["q_target_mean"], step)
             self.logger.log_scalar("algo/critic_loss", sc["critic_loss"], step)
             if step % self.policy_freq == 0:
                 self.logger.log_scalar("algo/loss_actor", sc["actor_loss"], step)

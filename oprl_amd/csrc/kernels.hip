@@ -493,6 +493,23 @@ __global__ void k_reduce_partials(const float* partials, int n_slices, float* ou
   }
 }
 
+// out[out_off] = scale * sum of x[0..n)  (one workgroup; diagnostics only)
+__global__ void k_sum(const float* x, int n, float* out, int out_off, float scale) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[out_off] = scale * (((red[0] + red[1]) + red[2]) + red[3]);
+}
+
+hipError_t launch_sum(const float* x, int n, float* out, int out_off, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, st, x, n, out, out_off, scale);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // TQC target (tqc.py:129-145): per row gather n_nets*Q quantiles of the target
 // critics, ascending bitonic sort in LDS (one wave per row, 128-slot network),

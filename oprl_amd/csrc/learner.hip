@@ -147,6 +147,7 @@ hipError_t launch_alpha_step(double* log_alpha, double* m, double* v, const floa
                              hipStream_t st);
 hipError_t launch_reduce_partials(const float* partials, int n_slices, float* out, int out_off,
                                   float scale_loss, float scale_mean, hipStream_t st);
+hipError_t launch_sum(const float* x, int n, float* out, int out_off, float scale, hipStream_t st);
 hipError_t launch_tqc_target(const float* z, long net_stride, int ldz, int n_nets, int Q, int drop,
                              const float* r, const float* d, const float* logp,
                              const double* log_alpha, float gamma, int B, float* target,
@@ -1828,8 +1829,12 @@ extern "C" int oprl_learner_read_scalars(oprl_learner* h, float* out_host, int32
   HIPC(launch_reduce_partials(h->part_c, n_slices * h->nc, h->scalars, 0, loss_scale,
                               1.0f / ((float)B * (float)h->nc), st));
   HIPC(launch_reduce_partials(h->part_a, n_slices, h->scalars, 4, 0.f, -1.0f / (float)B, st));
-  float host[8] = {0};
-  HIPC(hipMemcpyAsync(host, h->scalars, sizeof(float) * 8, hipMemcpyDeviceToHost, st));
+  // critic 0 alone (the reference logs q1, not the twin mean) and the mean log-density of the actor step
+  HIPC(launch_reduce_partials(h->part_c, n_slices, h->scalars, 8, loss_scale, 1.0f / (float)B, st));
+  const bool gauss = c.algo == OPRL_SAC || c.algo == OPRL_TQC;
+  if (gauss) HIPC(launch_sum(h->logp, B, h->scalars, 12, 1.0f / (float)B, st));
+  float host[16] = {0};
+  HIPC(hipMemcpyAsync(host, h->scalars, sizeof(float) * 13, hipMemcpyDeviceToHost, st));
   double la = 0.0;
   const double* lap = alpha_ptr(h);
   if (lap) HIPC(hipMemcpyAsync(&la, lap, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1842,7 +1847,15 @@ extern "C" int oprl_learner_read_scalars(oprl_learner* h, float* out_host, int32
   res[3] = host[2];                 // mean TD target
   res[4] = lap ? (float)exp(la) : (float)c.hp.alpha_init;
   res[5] = (float)h->update_count;
+  float res2[4];
+  res2[0] = host[9];                                  // mean q of critic 0 (the reference's "q1")
+  res2[1] = gauss ? host[12] : 0.f;                   // mean log pi(a|s) of the last actor step
+  // SAC / TQC actor loss as the reference forms it: alpha * mean(log pi) - mean(min q)   (sac.py:124-126)
+  res2[2] = gauss ? res[4] * res2[1] + res[1] : res[1];
+  // temperature loss -log_alpha * (target_entropy + mean log pi)   (sac.py:133-135; with the CURRENT log_alpha)
+  res2[3] = lap ? (float)(-la * (c.hp.target_entropy + (double)res2[1])) : 0.f;
   for (int i = 0; i < n && i < 6; ++i) out_host[i] = res[i];
+  for (int i = 6; i < n && i < 10; ++i) out_host[i] = res2[i - 6];
   return OPRL_OK;
 }
 

@@ -109,3 +109,41 @@ def test_ddpg_q_and_target_rows_match_oracle():
     s = hip.algo.learner.read_scalars()
     assert abs(s["critic_loss"] - float(ora.o.last["critic_loss"])) < 1e-4 * abs(float(ora.o.last["critic_loss"])) + 1e-7
     assert abs(s["actor_loss"] - float(ora.o.last["actor_loss"])) < 1e-4 * abs(float(ora.o.last["actor_loss"])) + 1e-7
+
+
+def test_sac_logged_scalars_are_the_reference_tags():
+    """What sac.py:108-155 logs — q1 (critic 0 alone, not the twin mean), q_target, abs_q_err, critic_loss,
+    loss_actor = alpha * mean(log pi) - mean(min q), log_pi, loss_alpha — from the kernels' partial sums,
+    against the oracle's values of the same update."""
+    from oracle import fixtures as fx
+    S, A = fx.ENVS["walker"]
+    B, seed = 256, 350
+    actor = fx.make_net(seed + 1, fx.actor_dims(S, A, gaussian=True))
+    c1, c2 = fx.make_net(seed + 2, fx.critic_dims(S, A)), fx.make_net(seed + 3, fx.critic_dims(S, A))
+    hip, ora = ha.HipSAC(S, A, actor, c1, c2, True), sc.OracleSAC(S, A, actor, c1, c2, True)
+    logged = {}
+    hip.algo.logger.log_scalars = lambda vals, step: logged.update(vals)
+    hip.algo.logger.log_scalar = lambda tag, v, step: logged.__setitem__(tag, v)
+    hip.algo.log_every = 1
+    log_alpha_before = float(ora.o.log_alpha)
+    args = (*fx.make_batch(seed + 10, B, S, A), fx.make_noise(seed + 50, (B, A)), fx.make_noise(seed + 70, (B, A)))
+    hip.update(*args)
+    ora.update(*args)
+    L = ora.o.last
+    want = {"algo/q1": float(L["q1"].mean()), "algo/q_target": float(L["y"].mean()),
+            "algo/abs_q_err": float((L["q1"] - L["y"]).mean()), "algo/critic_loss": float(L["critic_loss"]),
+            "algo/log_pi": float(L["logp"].mean())}
+    # loss_actor = alpha * mean(log pi) - mean(min q): logged with the temperature AFTER its step of this update
+    # (one host read at the end of the update); the reference forms it with the temperature before that step
+    import math
+    lp_mean = float(L["logp"].mean())
+    min_q_mean = math.exp(log_alpha_before) * lp_mean - float(L["actor_loss"])
+    want["algo/loss_actor"] = math.exp(float(ora.o.log_alpha)) * lp_mean - min_q_mean
+    assert abs(want["algo/loss_actor"] - float(L["actor_loss"])) < 2e-3
+    assert set(logged) == set(want) | {"algo/alpha", "algo/loss_alpha"}
+    for k, v in want.items():
+        assert abs(float(logged[k]) - v) <= 2e-5 * max(abs(v), 1.0), (k, logged[k], v)
+    # (the temperature loss is logged with the log_alpha AFTER its step; the reference reads it before)
+    lp = float(L["logp"].mean())
+    assert abs(float(logged["algo/loss_alpha"]) - (-float(ora.o.log_alpha) * (-A + lp))) < 1e-4
+    assert abs(-log_alpha_before * (-A + lp) - float(logged["algo/loss_alpha"])) < 2e-2
