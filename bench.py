@@ -288,6 +288,47 @@ def self_launch(n_gpus: int) -> int:
     return subprocess.run(cmd).returncode
 
 
+def packed_group(n, dev, local_rank, steps):
+    """N3 as a batched step: n independent DDPG learners in a LearnerGroup (oprl_group_step_n: four launches per
+    update for ALL members, grid.z = learner, single-CU slices).  Verified: every member finite, member 0
+    bit-identical to the same learner stepped alone at cluster size 1."""
+    from oprl_amd.algos.ddpg import DDPG
+    from oprl_amd.group import LearnerGroup
+    from oprl_amd.logging import NullLogger
+
+    def member(i):
+        t.manual_seed(100 + i)
+        return DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device=f"cuda:{local_rank}", max_batch=B).create()
+    algos = [member(i) for i in range(n)]
+    shared = make_replay(dev, seed=7)
+    handle = shared.handle
+    seeds = [1000 + i for i in range(n)]
+    g = LearnerGroup(algos)
+    warm = 100
+    g.step_n(handle, warm, B, seeds)
+    t.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    g.step_n(handle, steps, B, seeds)
+    t.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    finite = all(bool(t.isfinite(a.actor._oprl_arena).all()) and bool(t.isfinite(a.critic._oprl_arena).all()) for a in algos)
+    solo = member(0)
+    _capi_check = __import__("oprl_amd._capi", fromlist=["check"]).check
+    _capi_check(solo.learner.lib.oprl_learner_set_cluster(solo.learner.handle, 1))
+    solo.learner.step_n(handle, warm, B, seed=seeds[0])
+    solo.learner.step_n(handle, steps, B, seed=seeds[0])
+    t.cuda.synchronize(dev)
+    same = bool(t.equal(solo.actor._oprl_arena, algos[0].actor._oprl_arena)) and \
+        bool(t.equal(solo.critic._oprl_arena, algos[0].critic._oprl_arena))
+    for a in algos:
+        a.learner.check()
+    g.close()
+    return dict(learners=n, value=round(n * steps / dt, 1), unit="steps/s (aggregate)",
+                us_per_group_update=round(dt / steps * 1e6, 1), steps_each=steps,
+                path="oprl_group_step_n: 4 launches per update for the whole group (grid.z = learner), fp32, cluster size 1",
+                verified=dict(all_finite=finite, member0_equals_solo_run_at_cluster_1=same))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -298,6 +339,8 @@ def main():
     ap.add_argument("--learners", type=int, default=8,
                     help="extra measurement: this many independent learners (seeds) on separate "
                          "streams of the same GPU (multi-seed packing, runners/train.py --seeds); 0 = skip")
+    ap.add_argument("--group", type=int, default=32,
+                    help="extra measurement: a LearnerGroup of this many learners stepped by one launch sequence")
     ap.add_argument("--pre-warm", type=int, default=3000,
                     help="untimed updates BEFORE the --warmup ones (GPU clock ramp, first touches): the driver's short "
                          "runs (--steps 20 --warmup 5) otherwise time the learner at ramping clocks, 5 %% low")
@@ -514,8 +557,10 @@ def main():
                              "and the step is a chain of 4 dependent launches bound by latency, not by "
                              "the matrix cores (DESIGN.md section 6)")
         multi = None
+        group = None
         if not use_dp and args.learners > 1:
             multi = multi_learner(args.learners, dev, local_rank, steps=max(200, min(K, 2000)))
+            group = packed_group(args.group, dev, local_rank, steps=max(200, min(K, 1000)))
         configs = bf16 = api = None
         if not use_dp and not args.no_configs:
             cache = {(S, A): replay}
@@ -551,7 +596,7 @@ def main():
                                    0: "RCCL ncclAllReduce"}[p2p_level]),
                        "parallelism": f"dp{world}", "global_batch": B * world},
             "roofline": roof, "cpu_baseline": cpu, "configs": configs, "bf16": bf16, "api_rate": api,
-            "multi_learner": multi, "data_parallel_check": dp_check,
+            "multi_learner": multi, "packed_group": group, "data_parallel_check": dp_check,
             "flop_per_step": 2.0 * B * (MACS_SLICE + MACS_DW), "state_bytes_per_step": STATE_BYTES,
         }
         print(json.dumps(out), flush=True)

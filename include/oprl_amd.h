@@ -155,6 +155,20 @@ int oprl_learner_update_phase(oprl_learner* h, int32_t phase, const float* s, co
 int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t K, int32_t B,
                         uint64_t seed, void* stream);
 
+/* ---- packed learners: the reference's --seeds fan-out (runners/train.py:24-50) on ONE GPU ----------------
+ * A group steps N independent fused fp32 DDPG learners of one shape (own weights, own sampler keys
+ * seeds[i], one shared HBM replay) with FOUR launches per update for all of them (grid.z = learner; the
+ * argument blocks travel to device memory once per update).  Members run on single-CU slices
+ * (oprl_learner_set_cluster(h, 1) is applied to them): a member's result is bit-identical to the same learner
+ * stepped alone with cluster size 1, whoever else is in the group.  The members stay ordinary learners
+ * (update / step_n / checkpoints) between group calls. */
+typedef struct oprl_group oprl_group;
+int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group** out);
+int oprl_group_destroy(oprl_group* g);
+int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, int32_t B, const uint64_t* seeds, void* stream);
+/* CUs per 16-row slice in the fused kernels: 4 (default: tensor-parallel clusters, lowest latency), 2 or 1
+ * (least CU time per update: what packed learners use). */
+int oprl_learner_set_cluster(oprl_learner* h, int32_t nc);
 /* Diagnostics of the most recent update, read without forcing a sync inside
  * update(): out_host[0]=critic_loss, [1]=-mean q(s, pi) (DDPG / TD3 actor loss; min over twins for SAC),
  * [2]=mean q over all critics, [3]=mean target, [4]=alpha, [5]=update_step, and (n up to 10) [6]=mean q of

@@ -79,6 +79,10 @@ SIGNATURES = {
     "oprl_learner_apply": (C.c_int, [_P, _I32, _D, _P]),
     "oprl_learner_update_phase": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _P]),
     "oprl_learner_step_n": (C.c_int, [_P, _P, _I32, _I32, _U64, _P]),
+    "oprl_group_create": (C.c_int, [C.POINTER(_P), _I32, C.POINTER(_P)]),
+    "oprl_group_destroy": (C.c_int, [_P]),
+    "oprl_group_step_n": (C.c_int, [_P, _P, _I32, _I32, C.POINTER(_U64), _P]),
+    "oprl_learner_set_cluster": (C.c_int, [_P, _I32]),
     "oprl_learner_read_scalars": (C.c_int, [_P, C.POINTER(C.c_float), _I32, _P]),
     "oprl_learner_update_count": (C.c_int, [_P, C.POINTER(_I64)]),
     "oprl_learner_set_update_count": (C.c_int, [_P, _I64]),

@@ -306,8 +306,8 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
 // (A separate template instance for the twin-critic algorithms, so that the single-critic kernel
 // carries none of their code, was measured SLOWER for all three: phase 1 15.0 vs 14.3 us for DDPG,
 // TD3 38.5 vs 36.0 us, SAC 54.5 vs 51.6 us per update — profiles/r01b_experiments.txt #29.)
-template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32>
-__global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
+template <int WIDTH, bool LEAN, bool SAC, class P>
+__device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<WIDTH>;
   constexpr int WL = lds_ld(WIDTH);
@@ -447,9 +447,18 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) {
   role_b<WIDTH, LEAN, P>(A, A.critic, A.cX, A.cdY, A.partials_c, true, smem, tp, stamp);
 }
 
-// Role B of phase 1 for one online critic (layer inputs X[], pre-activation grads dY[]).
 template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32>
-__global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
+__global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) { ddpg_phase1_body<WIDTH, LEAN, SAC, P>(A); }
+
+// N independent learners in ONE launch (grid.z = learner): the argument blocks live in device memory (N x 1.7 KB
+// does not fit the kernel-argument segment), every field read is a scalar load through one uniform pointer.
+template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32>
+__global__ __launch_bounds__(kThreads) void k_ddpg_phase1_group(const DdpgArgs* __restrict__ batch) {
+  ddpg_phase1_body<WIDTH, LEAN, SAC, P>(batch[blockIdx.z]);
+}
+
+template <int WIDTH, bool LEAN, bool SAC, class P>
+__device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<WIDTH>;
   constexpr int WL = lds_ld(WIDTH);
@@ -699,6 +708,14 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) {
   stamp();
 }
 
+template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32>
+__global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) { ddpg_phase2_body<WIDTH, LEAN, SAC, P>(A); }
+
+template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32>
+__global__ __launch_bounds__(kThreads) void k_ddpg_phase2_group(const DdpgArgs* __restrict__ batch) {
+  ddpg_phase2_body<WIDTH, LEAN, SAC, P>(batch[blockIdx.z]);
+}
+
 size_t fused_ddpg_lds_bytes() { return sizeof(float) * FusedLds<256>::total; }
 size_t fused_xbuf_granules_per_cluster(int nc) { return (size_t)kTpStages * nc * kTpBlk; }
 
@@ -717,7 +734,29 @@ hipError_t init_fused_attrs() {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
   }
+  const void* kg[2] = {reinterpret_cast<const void*>(&k_ddpg_phase1_group<256, false, false>),
+                       reinterpret_cast<const void*>(&k_ddpg_phase2_group<256, false, false>)};
+  for (const void* k : kg) {
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+  }
   return hipSuccess;
+}
+
+// Group launches (N3: packed learners): the generic single-CU-per-slice passes (nc = 1 — a workgroup never
+// waits for a later one of its launch, so any number of learners may be queued behind each other), fp32.
+// `a0` = learner 0's arguments (for the grid), `batch_dev` = all of them in device memory.
+hipError_t launch_ddpg_phase1_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st) {
+  if (a0.nc != 1 || a0.sac || a0.bf16 || a0.n_critics != 1) return hipErrorInvalidValue;
+  const dim3 grid((a0.B + kR - 1) / kR, 3, n);
+  hipLaunchKernelGGL((k_ddpg_phase1_group<256, false, false>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, batch_dev);
+  return hipGetLastError();
+}
+hipError_t launch_ddpg_phase2_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st) {
+  if (a0.nc != 1 || a0.sac || a0.bf16 || a0.n_critics != 1) return hipErrorInvalidValue;
+  const dim3 grid((a0.B + kR - 1) / kR, 1 + (a0.prefetch_next ? 1 : 0), n);
+  hipLaunchKernelGGL((k_ddpg_phase2_group<256, false, false>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, batch_dev);
+  return hipGetLastError();
 }
 
 // the lean tp4 passes serve clusters of 4 whose four nets fit tp4_shape_ok

@@ -113,7 +113,7 @@ __device__ __forceinline__ void adam_bias_corr(const AdamScalars& ad, float* ste
 // the peers' windows, a bounded per-element wait for the peers' granules, sum in rank order.  A separate template instance: the single-rank kernel is untouched.  All workgroups of the
 // launch must be resident (they wait for their counterparts on the other GPUs): at most a few hundred.
 template <bool XCHG>
-__global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
+__device__ __forceinline__ void dw_adam_body(const DwKArgs& A) {
   constexpr int TN = kDwTileN, TK = kDwTile, LD = TK + 4;
   __shared__ __attribute__((aligned(16))) float part[kDwWaves][TN][LD];
   __shared__ float bpart[kDwWaves][TN];
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // this workgroup's layer, straight from the kernel-argument segment (dynamic index into a
   // by-value array: through the segment pointer it is a scalar load, not a scratch copy)
-  const DwKArgs* KA = (const DwKArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  const DwKArgs* KA = &A;
   int item = 0;
   for (int j = 0; j + 1 < A.n_items; ++j) item += (int)blockIdx.x >= KA->tile_end[j] ? 1 : 0;
   const DwItem I = KA->items[item];
@@ -417,6 +417,19 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
   stamp();   // stores issued
 }
 
+template <bool XCHG>
+__global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
+  // (through the kernel-argument segment pointer: a dynamic index into the by-value table is then a scalar load)
+  dw_adam_body<XCHG>(*(const DwKArgs*)__builtin_amdgcn_kernarg_segment_ptr());
+}
+
+// N learners' dW + Adam launches as one (grid.z = learner; argument blocks in device memory)
+__global__ __launch_bounds__(kDwThreads) void k_dw_adam_group(const DwKArgs* __restrict__ batch) {
+  const DwKArgs& A = batch[blockIdx.z];
+  if ((int)blockIdx.x >= A.tile_end[A.n_items - 1]) return;
+  dw_adam_body<false>(A);
+}
+
 // flat Adam over an arena (data-parallel apply after the all-reduce; alpha-free)
 __global__ void k_adam_flat(float* th, float* m, float* v, float* tt, const float* g, long n,
                             const AdamScalars ad) {
@@ -641,6 +654,38 @@ __device__ float g_one = 1.f;
 
 bool dw_wide_item_ok(const DwItem& it, const DwArgs& a);
 hipError_t launch_dw_adam_wide(const DwItem* items, int n_items, int B, const AdamScalars& ad, hipStream_t st);
+
+static const float* dw_one_dev() {
+  static const float* one_dev = nullptr;
+  if (one_dev == nullptr) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_one)) != hipSuccess) return nullptr;
+    one_dev = (const float*)p;
+  }
+  return one_dev;
+}
+
+// the kernel-side argument block of a (non-wide, single-rank) launch; returns the tile count or -1
+int fill_dw_kargs(const DwArgs& a, DwKArgs* k) {
+  if (a.n_items < 1 || a.n_items > kDwMaxItems || a.xchg != nullptr) return -1;
+  int total = 0;
+  for (int j = 0; j < a.n_items; ++j) {
+    k->items[j] = a.items[j];
+    total += a.items[j].tile_end - a.items[j].tile_begin;
+    k->tile_end[j] = total;
+  }
+  for (int j = a.n_items; j < kDwMaxItems; ++j) { k->items[j] = a.items[0]; k->tile_end[j] = total; }
+  k->n_items = a.n_items; k->B = a.B; k->n_part = a.n_part; k->ad = a.ad; k->trace = a.trace;
+  k->use_row_scale = a.use_row_scale; k->one = dw_one_dev();
+  k->apply_only = a.apply_only;
+  memset(&k->xchg, 0, sizeof k->xchg);
+  return k->one != nullptr ? total : -1;
+}
+
+hipError_t launch_dw_adam_group(const DwKArgs* batch_dev, int n, int tiles, hipStream_t st) {
+  hipLaunchKernelGGL(k_dw_adam_group, dim3(tiles, 1, n), dim3(kDwThreads), 0, st, batch_dev);
+  return hipGetLastError();
+}
 
 hipError_t launch_dw_adam(const DwArgs& a0, hipStream_t st) {
   if (a0.n_items < 1 || a0.n_items > kDwMaxItems) return hipErrorInvalidValue;

@@ -163,6 +163,10 @@ size_t fused_xbuf_granules_per_cluster(int nc);
 hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st);
 bool fused_ddpg_is_lean(const DdpgArgs& a);
 hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st);
+hipError_t launch_ddpg_phase1_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
+hipError_t launch_ddpg_phase2_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
+int fill_dw_kargs(const DwArgs& a, DwKArgs* k);
+hipError_t launch_dw_adam_group(const DwKArgs* batch_dev, int n, int tiles, hipStream_t st);
 
 }  // namespace oprl
 
@@ -1811,6 +1815,147 @@ extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t
                           h->bd, h->bs2, nullptr, nullptr, stream));
     RC(oprl_learner_update(h, h->bs, h->ba, h->br, h->bd, h->bs2, B, nullptr, nullptr, stream));
   }
+  return OPRL_OK;
+}
+
+// ===================================================================== packed learners
+// The reference trains several seeds as several processes (runners/train.py:36-50).  One DDPG learner at B = 256
+// is a chain of four latency-bound launches that keeps a fraction of the chip busy; a GROUP steps N independent
+// learners (own weights, own replay keys) with FOUR launches per update for all of them: grid.z = learner, the
+// argument blocks in device memory.  Group members run the single-CU-per-slice passes (cluster size 1): no
+// workgroup of such a launch waits for a later one, so the N x 48 phase-1 workgroups may simply queue behind
+// each other on the 256 CUs, and a learner's result does not depend on who else is in the launch.
+struct oprl_group {
+  std::vector<oprl_learner*> L;
+  DdpgArgs* p_dev[2] = {nullptr, nullptr};     // phase 1 / phase 2 argument blocks [N]
+  DwKArgs* dw_dev[2] = {nullptr, nullptr};     // critic / actor dW + Adam argument blocks [N]
+  char* stage[2] = {nullptr, nullptr};         // pinned host staging (double buffered)
+  hipEvent_t stage_ev[2] = {nullptr, nullptr};
+  bool stage_busy[2] = {false, false};
+  int cur = 0;
+  size_t bytes = 0;
+};
+
+extern "C" int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group** out) {
+  if (!learners || !out || n < 1 || n > 64) { set_err("oprl_group_create: invalid argument"); return OPRL_ERR_INVALID; }
+  for (int i = 0; i < n; ++i) {
+    oprl_learner* h = learners[i];
+    if (!h || h->cfg.algo != OPRL_DDPG || !h->fused || h->cfg.export_grads || h->bf16 || h->S != learners[0]->S ||
+        h->A != learners[0]->A || h->Bmax != learners[0]->Bmax) {
+      set_err("oprl_group_create: member %d is not a fused fp32 DDPG learner of the group's shape", i);
+      return OPRL_ERR_INVALID;
+    }
+  }
+  auto* g = new oprl_group();
+  g->L.assign(learners, learners + n);
+  for (oprl_learner* h : g->L) h->ncl = 1;       // single-CU slices (see above); a solo run for comparison sets the same
+  g->bytes = (size_t)n * (2 * sizeof(DdpgArgs) + 2 * sizeof(DwKArgs));
+  bool ok = true;
+  for (int i = 0; i < 2 && ok; ++i) {
+    ok = hipMalloc(&g->p_dev[i], sizeof(DdpgArgs) * n) == hipSuccess && hipMalloc(&g->dw_dev[i], sizeof(DwKArgs) * n) == hipSuccess &&
+         hipHostMalloc((void**)&g->stage[i], g->bytes) == hipSuccess &&
+         hipEventCreateWithFlags(&g->stage_ev[i], hipEventDisableTiming) == hipSuccess;
+  }
+  if (!ok) { set_err("oprl_group_create: allocation failed"); return OPRL_ERR_NOMEM; }
+  *out = g;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_group_destroy(oprl_group* g) {
+  if (!g) return OPRL_OK;
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < 2; ++i) {
+    if (g->p_dev[i]) (void)hipFree(g->p_dev[i]);
+    if (g->dw_dev[i]) (void)hipFree(g->dw_dev[i]);
+    if (g->stage[i]) (void)hipHostFree(g->stage[i]);
+    if (g->stage_ev[i]) (void)hipEventDestroy(g->stage_ev[i]);
+  }
+  delete g;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_learner_set_cluster(oprl_learner* h, int32_t nc) {
+  if (!h || (nc != 1 && nc != 2 && nc != 4)) { set_err("oprl_learner_set_cluster: cluster size must be 1, 2 or 4"); return OPRL_ERR_INVALID; }
+  h->ncl = nc;
+  return OPRL_OK;
+}
+
+// K updates of every member: per update one H2D copy of the N x 4 argument blocks and four launches.
+extern "C" int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, int32_t B, const uint64_t* seeds,
+                                 void* stream) {
+  if (!g || !replay || !seeds || K < 0) { set_err("oprl_group_step_n: invalid argument"); return OPRL_ERR_INVALID; }
+  const int n = (int)g->L.size();
+  oprl_learner* h0 = g->L[0];
+  if (B < 1 || B > h0->Bmax) { set_err("oprl_group_step_n: bad batch %d", B); return OPRL_ERR_INVALID; }
+  int S = 0, A = 0;
+  replay_dims(replay, &S, &A);
+  if (S != h0->S || A != h0->A) { set_err("replay dims (%d,%d) != group dims (%d,%d)", S, A, h0->S, h0->A); return OPRL_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  RC(oprl_replay_flush(replay, stream));
+  for (int l = 0; l < n; ++l) {
+    oprl_learner* h = g->L[l];
+    RC(check_device_error(h));
+    BatchSrc& sc = h->src;
+    long n_tr = 0;
+    replay_view(replay, &sc.states, &sc.actions, &sc.rewards, &sc.dones, &sc.ends, &sc.n_eps, &sc.L, &n_tr);
+    if (n_tr <= 0 || sc.n_eps <= 0) { set_err("oprl_group_step_n: replay buffer is empty"); return OPRL_ERR_STATE; }
+    sc.n_transitions = n_tr;
+    sc.seed = seeds[l];
+    sc.gather = 1;
+    sc.s = h->bs; sc.a = h->ba; sc.r = h->br; sc.d = h->bd; sc.s2 = h->bs2;
+    h->next_src = sc;
+    h->staged_ready = false;
+    h->last_B = B;
+  }
+  for (int k = 0; k < K; ++k) {
+    const int c = g->cur;
+    if (g->stage_busy[c]) { HIPC(hipEventSynchronize(g->stage_ev[c])); g->stage_busy[c] = false; }
+    DdpgArgs* p1 = reinterpret_cast<DdpgArgs*>(g->stage[c]);
+    DdpgArgs* p2 = p1 + n;
+    DwKArgs* dc = reinterpret_cast<DwKArgs*>(p2 + n);
+    DwKArgs* da = dc + n;
+    int tiles_c = 0, tiles_a = 0;
+    for (int l = 0; l < n; ++l) {
+      oprl_learner* h = g->L[l];
+      const oprl_learner_config& cf = h->cfg;
+      h->src.counter = (unsigned long long)h->update_count;
+      h->next_src.counter = h->src.counter + 1;
+      h->src.gather = h->staged_ready ? 0 : 1;
+      const int prefetch = (k + 1 < K) ? 1 : 0;
+      h->epoch += 1;
+      if (h->epoch == 0) { h->epoch = 1; HIPC(hipMemsetAsync(h->y_granules, 0, (size_t)h->Bmax * sizeof(unsigned long long), st)); }
+      p1[l] = ddpg_args(h, B);
+      RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &p1[l].cluster_tag));
+      p2[l] = ddpg_args(h, B);
+      p2[l].cluster_tag = p1[l].cluster_tag;
+      p2[l].prefetch_next = prefetch;
+      h->staged_ready = prefetch != 0;
+      h->opt_step_critic += 1;
+      h->opt_step_actor += 1;
+      DwArgs dw;
+      dw.items = h->items_host.data(); dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
+      dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.use_row_scale = 0; dw.apply_only = 0;
+      dw.ad = adam_scalars(h, cf.hp.lr_critic, h->opt_step_critic, true, 1.0f);
+      tiles_c = fill_dw_kargs(dw, &dc[l]);
+      dw.items = h->items_host.data() + h->n_items_critic; dw.n_items = h->n_items_actor; dw.total_tiles = h->tiles_actor;
+      dw.ad = adam_scalars(h, cf.hp.lr_actor, h->opt_step_actor, cf.actor.theta_target != nullptr, 1.0f);
+      tiles_a = fill_dw_kargs(dw, &da[l]);
+      if (tiles_c < 0 || tiles_a < 0 || p1[l].nc != 1) { set_err("oprl_group_step_n: internal: bad launch arguments"); return OPRL_ERR_INVALID; }
+      h->update_count += 1;
+    }
+    HIPC(hipMemcpyAsync(g->p_dev[0], p1, sizeof(DdpgArgs) * n, hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(g->p_dev[1], p2, sizeof(DdpgArgs) * n, hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(g->dw_dev[0], dc, sizeof(DwKArgs) * n, hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(g->dw_dev[1], da, sizeof(DwKArgs) * n, hipMemcpyHostToDevice, st));
+    HIPC(hipEventRecord(g->stage_ev[c], st));
+    g->stage_busy[c] = true;
+    g->cur ^= 1;
+    HIPC(launch_ddpg_phase1_group(p1[0], g->p_dev[0], n, st));
+    HIPC(launch_dw_adam_group(g->dw_dev[0], n, tiles_c, st));
+    HIPC(launch_ddpg_phase2_group(p2[0], g->p_dev[1], n, st));
+    HIPC(launch_dw_adam_group(g->dw_dev[1], n, tiles_a, st));
+  }
+  for (oprl_learner* h : g->L) { h->src.gather = 0; h->prefetch_next = 0; h->staged_ready = false; }
   return OPRL_OK;
 }
 

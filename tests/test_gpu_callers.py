@@ -435,3 +435,40 @@ def test_device_noise_stream_is_standard_normal_and_keyed_by_seed_rank_counter()
     assert not np.array_equal(x, y) and not np.array_equal(y, z)
     assert abs(np.corrcoef(x.ravel(), y.ravel())[0, 1]) < 4 / np.sqrt(n)
     assert abs(np.corrcoef(y.ravel(), z.ravel())[0, 1]) < 4 / np.sqrt(n)
+
+
+def test_packed_learner_group_equals_solo_learners():
+    """N3: three independent DDPG learners stepped as a group (four launches per update for all of them) end
+    with exactly the parameters, targets and Adam moments each of them reaches alone at cluster size 1 — and
+    remain ordinary learners afterwards."""
+    from oprl_amd.group import LearnerGroup
+    B, K = 64, 7
+    buf = _filled_buffer()
+
+    def member(i):
+        t.manual_seed(40 + i)
+        from oprl_amd.algos.ddpg import DDPG
+        from oprl_amd.logging import NullLogger
+        return DDPG(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=B).create()
+    group_members, solo = [member(i) for i in range(3)], [member(i) for i in range(3)]
+    seeds = [11, 12, 13]
+    g = LearnerGroup(group_members)
+    g.step_n(buf.handle, K, B, seeds)
+    g.step_n(buf.handle, 2, B, seeds)             # a second call continues the streams
+    for a, s in zip(solo, seeds):
+        assert a.learner.lib.oprl_learner_set_cluster(a.learner.handle, 1) == 0
+        a.learner.step_n(buf.handle, K, B, seed=s)
+        a.learner.step_n(buf.handle, 2, B, seed=s)
+    t.cuda.synchronize()
+    for a, b in zip(group_members, solo):
+        for m in ("actor", "critic", "actor_target", "critic_target"):
+            assert t.equal(getattr(a, m)._oprl_arena, getattr(b, m)._oprl_arena), m
+        assert t.equal(a.learner.critic_m, b.learner.critic_m) and t.equal(a.learner.actor_v, b.learner.actor_v)
+        assert a.update_step == b.update_step == K + 2
+        a.learner.check()
+    # members are still ordinary learners
+    batch = buf.sample(B)
+    group_members[0].update(*batch)
+    solo[0].update(*batch)
+    t.cuda.synchronize()
+    assert t.equal(group_members[0].critic._oprl_arena, solo[0].critic._oprl_arena)

@@ -1,0 +1,31 @@
+"""Aggregate steps/s of a LearnerGroup (N packed DDPG learners, four launches per update for all) for a few N."""
+import sys
+import time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch as t
+import bench
+from oprl_amd.algos.ddpg import DDPG
+from oprl_amd.group import LearnerGroup
+from oprl_amd.logging import NullLogger
+
+dev = t.device("cuda", 0)
+replay = bench.make_replay(dev, seed=7)
+for n in [int(x) for x in sys.argv[1].split(",")]:
+    algos = []
+    for i in range(n):
+        t.manual_seed(100 + i)
+        algos.append(DDPG(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda:0", max_batch=256).create())
+    g = LearnerGroup(algos)
+    seeds = [1000 + i for i in range(n)]
+    g.step_n(replay.handle, 200, 256, seeds)
+    t.cuda.synchronize()
+    K = 1000
+    t0 = time.perf_counter()
+    g.step_n(replay.handle, K, 256, seeds)
+    t.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    finite = all(bool(t.isfinite(a.critic._oprl_arena).all()) for a in algos)
+    print(f"group of {n}: {n * K / dt:.0f} steps/s aggregate ({K / dt:.0f} group updates/s, {dt / K * 1e6:.1f} us per group update), finite={finite}", flush=True)
+    g.close()
+    del algos, g
