@@ -163,6 +163,10 @@ struct oprl_replay {
   hipEvent_t stage_ev[2], ends_ev[2];
   bool stage_busy[2] = {false, false}, ends_busy[2] = {false, false};
   int cur = 0, ends_cur = 0, n_staged = 0;
+  // the stream of the caller's most recent flush / sample / block write / table upload: where a staging buffer
+  // that fills up inside oprl_replay_write (which takes no stream) is flushed, so that the scatter stays ordered
+  // with the caller's later gathers
+  hipStream_t stream_hint = nullptr;
 };
 
 extern "C" int oprl_replay_create(int32_t n_episodes, int32_t max_ep_len, int32_t state_dim,
@@ -206,6 +210,7 @@ extern "C" int oprl_replay_destroy(oprl_replay* h) {
 
 extern "C" int oprl_replay_flush(oprl_replay* h, void* stream) {
   if (!h) { set_err("null replay handle"); return OPRL_ERR_INVALID; }
+  h->stream_hint = (hipStream_t)stream;
   if (h->n_staged == 0) return OPRL_OK;
   hipStream_t st = (hipStream_t)stream;
   const int c = h->cur, n = h->n_staged;
@@ -234,7 +239,7 @@ extern "C" int oprl_replay_write(oprl_replay* h, int32_t ep, int32_t t, const fl
     return OPRL_ERR_INVALID;
   }
   if (h->n_staged == kStageRows) {
-    int rc = oprl_replay_flush(h, nullptr);
+    int rc = oprl_replay_flush(h, h->stream_hint);
     if (rc != OPRL_OK) return rc;
   }
   float* row = h->stage_host[h->cur] + (size_t)h->n_staged * h->rowlen;
