@@ -51,7 +51,7 @@ constexpr int kMaxEnds = 2048;
 template <int WIDTH, bool LEAN, class P, class ST>
 __device__ __forceinline__ void tp_fwd(const Net& net, const float* x0s, float* h1, float* h2, float* outS,
                                        float* scr, Tp& tp, const Tp3Store& st, int row0, int B, ST sf) {
-  if constexpr (LEAN) tp4_forward<P>(net, x0s, h1, h2, outS, tp, st, row0, B, sf);
+  if constexpr (LEAN) tp4_forward<P>(net, x0s, h1, h2, outS, scr, tp, st, row0, B, sf);
   else tp3_forward<WIDTH>(net, x0s, h1, h2, outS, scr, tp, st, row0, B, sf);
 }
 template <int WIDTH, bool LEAN, class P, class ST>

@@ -36,7 +36,7 @@ __device__ __forceinline__ void slice_tp_body(const MlpArgs& A) {
     load_rows(x0s, kX0Ld, 0, A.x0, A.k0, A.k0, row0, B);
     if (A.x1 != nullptr) load_rows(x0s, kX0Ld, A.k0, A.x1, A.k1, A.k1, row0, B);
     const Tp3Store st{A.Xg[1], A.Xg[2], nullptr, nullptr, 0};
-    tp4_forward(A.net, x0s, h1, h2, outS, tp, st, row0, B);
+    tp4_forward(A.net, x0s, h1, h2, outS, scr, tp, st, row0, B);
     if (lead && A.Xg[0] != nullptr) store_rows(x0s, kX0Ld, A.Xg[0], A.ldx0, A.net.dims[0], row0, B);
     slice_head(A, outS, Nout, row0, lead);
   } else if (A.do_bwd) {

@@ -105,9 +105,16 @@ __device__ __forceinline__ f32x4 tp4_allreduce_regs(const f32x4 mine, int col, b
   return sum;
 }
 
+// Layer 1 (the member's 256 x 64 shard) is contracted by ALL 16 waves: wave w = output tile (w & 3), quarter
+// (w >> 2) of the contraction, the four partial tiles meeting in `scr` ([kWaves][256] floats) and summed in
+// quarter order by one thread per element.  An earlier version gave whole tiles to waves 0..3: 16 fragments
+// (64 VGPRs) per lane in four waves while twelve waves idled, and — the fragment requests sitting under a
+// wave-id branch — hipcc's wait-count pass could not tell how many younger loads follow the layer-0
+// fragments, so layer 0 waited for ALL of the pass's fragments (s_waitcnt vmcnt(1)).  With uniform,
+// unconditional requests layer 0 starts as soon as ITS fragments are in.
 template <class P = PrecF32, class ST = NoStamp>
 __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, float* h1, float* h2,
-                                            float* outS, Tp& tp, const Tp3Store& st, int row0, int B,
+                                            float* outS, float* scr, Tp& tp, const Tp3Store& st, int row0, int B,
                                             ST sf = ST()) {
   using NS = Tp4Steps<P>;
   const int lane = threadIdx.x & 63;
@@ -119,27 +126,33 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
   const int t2 = wave - 4;                    // output tile of waves 4..4+NTo-1
   const bool l2_wave = t2 >= 0 && t2 < NTo;
 
-  // ---- requests for the whole pass
-  f32x4 w0[NS::S0], wq[NS::W];
+  constexpr int NQ = NS::W / 4;               // macro steps of one quarter of layer 1's contraction
+  const int t1 = wave & 3, kq = wave >> 2;    // layer 1: this wave's tile of the member and contraction quarter
+  // the layer-1 element this thread finishes: tile rt, accumulator slot (rl, rr) = row 4 (rl >> 4) + rr, column rl & 15
+  const int rt = (int)threadIdx.x >> 8, rl = ((int)threadIdx.x & 255) >> 2, rr = (int)threadIdx.x & 3;
+
+  // ---- requests for the whole pass (uniform over the waves but for the few output-layer fragments)
+  f32x4 w0[NS::S0], w1[NQ], w2[NS::M];
   {
     const float* p0 = net.pf[0] + ((size_t)wave * NS0 * 64 + lane) * 4;
 #pragma unroll
     for (int s = 0; s < NS::S0; ++s) w0[s] = s < NS0 ? ld4(p0 + s * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float bias0 = net.b[0][16 * wave + i];
-  float bias12 = 0.f;
+  {
+    const float* p1 = net.pf[1] + (((size_t)(c * kTpc4 + t1) * NS::W + kq * NQ) * 64 + lane) * 4;
 #pragma unroll
-  for (int s = 0; s < NS::W; ++s) wq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (wave < kTpc4) {
-    const float* p1 = net.pf[1] + ((size_t)(c * kTpc4 + wave) * NS::W * 64 + lane) * 4;
+    for (int s = 0; s < NQ; ++s) w1[s] = ld4(p1 + s * 256);
+  }
+  const float bias1 = net.b[1][c0 + 16 * rt + (rl & 15)];
+  float bias2 = 0.f;
 #pragma unroll
-    for (int s = 0; s < NS::W; ++s) wq[s] = ld4(p1 + s * 256);
-    bias12 = net.b[1][c0 + 16 * wave + i];
-  } else if (l2_wave) {
+  for (int s = 0; s < NS::M; ++s) w2[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (l2_wave) {
     const float* p2 = net.pf[2] + (((size_t)t2 * NS::W + c * NS::M) * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < NS::M; ++s) wq[s] = ld4(p2 + s * 256);
-    if (16 * t2 + i < N) bias12 = net.b[2][16 * t2 + i];
+    for (int s = 0; s < NS::M; ++s) w2[s] = ld4(p2 + s * 256);
+    if (16 * t2 + i < N) bias2 = net.b[2][16 * t2 + i];
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();   // x0 visible
@@ -158,25 +171,28 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
   sf();
   __syncthreads();   // h1 visible
 
-  // ---- L1 on waves 0..3; the others store h1 (member 0) for the dW kernel
-  if (wave < kTpc4) {
+  // ---- L1: every wave a quarter of one tile's contraction -> scr; member 0's threads store h1 for the dW kernel
+  {
     f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
-    const float* hr = h1 + i * kWL4 + 4 * kk;
+    const float* hr = h1 + i * kWL4 + 64 * kq + 4 * kk;
 #pragma unroll
-    for (int s = 0; s < NS::W; s += 2) {
-      P::mac(hr, s, wq[s], a0);
-      P::mac(hr, s + 1, wq[s + 1], a1);
+    for (int s = 0; s < NQ; s += 2) {
+      P::mac(hr, s, w1[s], a0);
+      P::mac(hr, s + 1, w1[s + 1], a1);
     }
-    float* o = h2 + (kk * 4) * kWL4 + c0 + 16 * wave + i;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r * kWL4] = fmaxf((a0[r] + a1[r]) + bias12, 0.f);
-  } else if (st.X1 != nullptr && c == 0) {
-    for (int idx = (int)threadIdx.x - 64 * kTpc4; idx < kR * (kW4 / 4); idx += kThreads - 64 * kTpc4) {
-      const int row = idx >> 6, col = (idx & 63) * 4, gr = row0 + row;
-      if (gr < B) *reinterpret_cast<f32x4*>(st.X1 + (size_t)gr * kW4 + col) = ld4(h1 + row * kWL4 + col);
-    }
+    *reinterpret_cast<f32x4*>(scr + ((size_t)wave * 64 + lane) * 4) = a0 + a1;
+  }
+  if (st.X1 != nullptr && c == 0) {
+    const int row = (int)threadIdx.x >> 6, col = ((int)threadIdx.x & 63) * 4, gr = row0 + row;     // 16 rows x 64 float4
+    if (gr < B) *reinterpret_cast<f32x4*>(st.X1 + (size_t)gr * kW4 + col) = ld4(h1 + row * kWL4 + col);
   }
   sf();
+  __syncthreads();   // partial tiles visible
+  {
+    const float* sp = scr + ((size_t)rt * 64 + rl) * 4 + rr;      // wave (quarter q, tile rt) = 4 q + rt
+    const float v = ((sp[0] + sp[4 * 256]) + sp[8 * 256]) + sp[12 * 256];
+    h2[(4 * (rl >> 4) + rr) * kWL4 + c0 + 16 * rt + (rl & 15)] = fmaxf(v + bias1, 0.f);
+  }
   __syncthreads();   // the member's h2 columns visible
 
   // ---- L2 partial + all-reduce from registers on waves 4..; waves 8..11 store the h2 columns
@@ -185,15 +201,15 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
     const float* hr = h2 + i * kWL4 + c0 + 4 * kk;
 #pragma unroll
     for (int s = 0; s < NS::M; s += 2) {
-      P::mac(hr, s, wq[s], a0);
-      P::mac(hr, s + 1, wq[s + 1], a1);
+      P::mac(hr, s, w2[s], a0);
+      P::mac(hr, s + 1, w2[s + 1], a1);
     }
     const int col = 16 * t2 + i;
     const bool valid = col < N;
     const f32x4 sum = tp4_allreduce_regs(a0 + a1, col, valid, tp);
     float* o = outS + (kk * 4) * kOutLd + col;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r * kOutLd] = valid ? sum[r] + bias12 : 0.f;
+    for (int r = 0; r < 4; ++r) o[r * kOutLd] = valid ? sum[r] + bias2 : 0.f;
   } else if (st.X2 != nullptr && wave >= 8 && wave < 12) {
     const int idx = (int)threadIdx.x - 512;          // 16 rows x 16 float4
     const int row = idx >> 4, col = c0 + (idx & 15) * 4, gr = row0 + row;
@@ -363,28 +379,33 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   const bool dact_wave = dact && dt < dnt;
   constexpr int kOutWave = 12;
 
+  constexpr int NQ = NS::W / 4;               // layer 1 as in tp4_forward: wave = (tile, contraction quarter)
+  const int t1 = wave & 3, kq = wave >> 2;
+  const int rt = (int)threadIdx.x >> 8, rl = ((int)threadIdx.x & 255) >> 2, rr = (int)threadIdx.x & 3;
+
   // ---- requests
-  f32x4 w0[NS::S0], wq[NS::W], wz[NS::M], wd[NS::M];
+  f32x4 w0[NS::S0], w1[NQ], w2[NS::M], wz[NS::M], wd[NS::M];
   {
     const float* p0 = net.pf[0] + ((size_t)wave * NS0 * 64 + lane) * 4;
 #pragma unroll
     for (int s = 0; s < NS::S0; ++s) w0[s] = s < NS0 ? ld4(p0 + s * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float bias0 = net.b[0][16 * wave + i];
-  float bias12 = 0.f, w3 = 0.f;
+  {
+    const float* p1 = net.pf[1] + (((size_t)(c * kTpc4 + t1) * NS::W + kq * NQ) * 64 + lane) * 4;
 #pragma unroll
-  for (int s = 0; s < NS::W; ++s) wq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (wave < kTpc4) {
-    const float* p1 = net.pf[1] + ((size_t)(c * kTpc4 + wave) * NS::W * 64 + lane) * 4;
+    for (int s = 0; s < NQ; ++s) w1[s] = ld4(p1 + s * 256);
+  }
+  const float bias1 = net.b[1][c0 + 16 * rt + (rl & 15)];
+  const float w3 = P::first(net.pb[2] + ((size_t)(c * kTpc4 + rt) * 64 + (rl & 15)) * 4);   // W3[c0 + 16 rt + col]  (one step)
+  float bias2 = 0.f;
 #pragma unroll
-    for (int s = 0; s < NS::W; ++s) wq[s] = ld4(p1 + s * 256);
-    bias12 = net.b[1][c0 + 16 * wave + i];
-    w3 = P::first(net.pb[2] + ((size_t)(c * kTpc4 + wave) * 64 + i) * 4);   // W3[c0 + 16 wave + i]  (one step)
-  } else if (wave == kOutWave) {
+  for (int s = 0; s < NS::M; ++s) w2[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (wave == kOutWave) {
     const float* p2 = net.pf[2] + (((size_t)c * NS::M) * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < NS::M; ++s) wq[s] = ld4(p2 + s * 256);
-    if (i == 0) bias12 = net.b[2][0];
+    for (int s = 0; s < NS::M; ++s) w2[s] = ld4(p2 + s * 256);
+    if (i == 0) bias2 = net.b[2][0];
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();   // x0 visible
@@ -408,28 +429,29 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   sf();
   __syncthreads();   // h1 visible
 
-  // ---- L1 and the unit-seed dz2 on waves 0..3; the others store h1
-  if (wave < kTpc4) {
+  // ---- L1 (every wave a quarter of one tile's contraction -> scr); member 0's threads store h1
+  {
     f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
-    const float* hr = h1 + i * kWL4 + 4 * kk;
+    const float* hr = h1 + i * kWL4 + 64 * kq + 4 * kk;
 #pragma unroll
-    for (int s = 0; s < NS::W; s += 2) {
-      P::mac(hr, s, wq[s], a0);
-      P::mac(hr, s + 1, wq[s + 1], a1);
+    for (int s = 0; s < NQ; s += 2) {
+      P::mac(hr, s, w1[s], a0);
+      P::mac(hr, s + 1, w1[s + 1], a1);
     }
-    const int off = (kk * 4) * kWL4 + c0 + 16 * wave + i;
-    const float gz = seed * w3;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = fmaxf((a0[r] + a1[r]) + bias12, 0.f);
-      h2[off + r * kWL4] = v;
-      g2[off + r * kWL4] = v > 0.f ? gz : 0.f;
-    }
-  } else if (st.X1 != nullptr && c == 0) {
-    for (int idx = (int)threadIdx.x - 64 * kTpc4; idx < kR * (kW4 / 4); idx += kThreads - 64 * kTpc4) {
-      const int row = idx >> 6, col = (idx & 63) * 4, gr = row0 + row;
-      if (gr < B) *reinterpret_cast<f32x4*>(st.X1 + (size_t)gr * kW4 + col) = ld4(h1 + row * kWL4 + col);
-    }
+    *reinterpret_cast<f32x4*>(scr + ((size_t)wave * 64 + lane) * 4) = a0 + a1;
+  }
+  if (st.X1 != nullptr && c == 0) {
+    const int row = (int)threadIdx.x >> 6, col = ((int)threadIdx.x & 63) * 4, gr = row0 + row;
+    if (gr < B) *reinterpret_cast<f32x4*>(st.X1 + (size_t)gr * kW4 + col) = ld4(h1 + row * kWL4 + col);
+  }
+  sf();
+  __syncthreads();   // partial tiles visible
+  {   // ... summed in quarter order, bias + ReLU, and the unit-seed dz2 of the same element
+    const float* sp = scr + ((size_t)rt * 64 + rl) * 4 + rr;
+    const float v = fmaxf((((sp[0] + sp[4 * 256]) + sp[8 * 256]) + sp[12 * 256]) + bias1, 0.f);
+    const int off = (4 * (rl >> 4) + rr) * kWL4 + c0 + 16 * rt + (rl & 15);
+    h2[off] = v;
+    g2[off] = v > 0.f ? seed * w3 : 0.f;
   }
 #pragma unroll
   for (int s = 0; s < NS::M; ++s) wd[s] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -494,18 +516,18 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
     const float* hr = h2 + i * kWL4 + c0 + 4 * kk;
 #pragma unroll
     for (int s = 0; s < NS::M; s += 2) {
-      P::mac(hr, s, wq[s], a0);
-      P::mac(hr, s + 1, wq[s + 1], a1);
+      P::mac(hr, s, w2[s], a0);
+      P::mac(hr, s + 1, w2[s + 1], a1);
     }
     const bool valid = i == 0;
     const f32x4 sum = tp4_allreduce_regs(a0 + a1, i, valid, tp);
     float* o = outS + (kk * 4) * kOutLd + i;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r * kOutLd] = valid ? sum[r] + bias12 : 0.f;
+    for (int r = 0; r < 4; ++r) o[r * kOutLd] = valid ? sum[r] + bias2 : 0.f;
     if (q_sum_out != nullptr) {
       float qs = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) qs += (valid && row0 + kk * 4 + r < B) ? sum[r] + bias12 : 0.f;
+      for (int r = 0; r < 4; ++r) qs += (valid && row0 + kk * 4 + r < B) ? sum[r] + bias2 : 0.f;
       qs += __shfl_xor(qs, 16);
       qs += __shfl_xor(qs, 32);
       if (lane == 0) *q_sum_out = qs;
