@@ -125,6 +125,7 @@ def cpu_baseline(budget_s: float = 14.0):
 
 # ---- the other BASELINE.json configurations, the bf16 mode and the through-the-API rate --------
 PEAK_BF16_MATRIX_TFLOPS = 2500.0       # dense bf16 MFMA (MI355X_MICROARCH.md)
+PMC_FILE = {"f32": "r02f_pmc_traffic.json", "bf16": "r02f_pmc_traffic_bf16.json"}
 PEAK_HBM_TBS = 8.0
 # name -> (class name, S, A, B, constructor extras, algorithmic GFLOP / update, state MB / update): BASELINE.md section 4
 BASELINE_CONFIGS = {
@@ -339,6 +340,9 @@ def main():
     ap.add_argument("--learners", type=int, default=8,
                     help="extra measurement: this many independent learners (seeds) on separate "
                          "streams of the same GPU (multi-seed packing, runners/train.py --seeds); 0 = skip")
+    ap.add_argument("--precision", choices=("f32", "bf16"), default="f32",
+                    help="arithmetic mode of the TIMED learner: f32 = exact-fp32 MFMA, the parity mode and the headline; "
+                         "bf16 = the bf16 MFMA mode (profiling that path; the default run reports it in its `bf16` block)")
     ap.add_argument("--group", type=int, default=32,
                     help="extra measurement: a LearnerGroup of this many learners stepped by one launch sequence")
     ap.add_argument("--pre-warm", type=int, default=3000,
@@ -392,7 +396,7 @@ def main():
     def make_learner():
         t.manual_seed(0)                               # reference-style init, same on all ranks
         return DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device=f"cuda:{local_rank}",
-                    max_batch=B, export_grads=use_dp).create()
+                    max_batch=B, export_grads=use_dp, precision=args.precision).create()
 
     dp = None
     p2p_level = 0
@@ -531,15 +535,18 @@ def main():
             if kern[dom]["us_per_launch"] <= 0.0:          # (a very short run: the overhead estimate swallowed the reading)
                 kern[dom]["us_per_launch"] = kern[dom]["us_per_launch_raw"]
             ach = flop_per_launch / (kern[dom]["us_per_launch"] * 1e-6) / 1e12
-            traffic = None
-            try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-                pmc = json.load(open(ROOT / "profiles" / "r01h_pmc_traffic.json"))
+            traffic = mfma_util = None
+            try:   # HBM bytes per launch and matrix-core utilisation from the committed rocprofv3 PMC passes of this same command
+                pmc = json.load(open(ROOT / "profiles" / PMC_FILE[args.precision]))
                 traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
+                mfma_util = pmc.get(dom, {}).get("mfma_util")
             except Exception:  # noqa: BLE001
                 pass
-            roof = dict(bound="mfma", kernel=f"{dom}<256> (exact-fp32 v_mfma_f32_16x16x4_f32)",
-                        achieved=round(ach, 3), peak=PEAK_F32_MATRIX_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_F32_MATRIX_TFLOPS, 5), traffic=traffic,
+            peak = PEAK_F32_MATRIX_TFLOPS if args.precision == "f32" else PEAK_BF16_MATRIX_TFLOPS
+            roof = dict(bound="mfma", kernel=f"{dom}<256> (" + ("exact-fp32 v_mfma_f32_16x16x4_f32" if args.precision == "f32"
+                                                               else "v_mfma_f32_16x16x32_bf16, fp32 accumulate") + ")",
+                        achieved=round(ach, 3), peak=peak, unit="TFLOP/s",
+                        frac=round(ach / peak, 5), traffic=traffic, mfma_util=mfma_util,
                         flop_per_launch=flop_per_launch, kernels=kern,
                         event_overhead_us=round(ev_us, 3),
                         measured_on=("the timed learner" if not use_dp else
@@ -549,10 +556,11 @@ def main():
                              f"(serialised pass of {P} steps) minus event_overhead_us, the per-launch "
                              "excess of that pass over the un-instrumented timed loop (where the same "
                              "launches run back to back, so a step is the sum of their durations); they "
-                             "agree with rocprofv3 --kernel-trace --stats (profiles/r01h_kernel_stats.csv: "
-                             "14.2 / 12.3 / 7.5 us); sum of kernel time per step = "
+                             "agree with rocprofv3 --kernel-trace --stats (profiles/r02f_kernel_stats.csv); "
+                             "sum of kernel time per step = "
                              f"{sum(k['us_per_step'] for k in kern.values()):.1f} us; traffic = "
-                             "(2*FETCH_SIZE + WRITE_SIZE) KB from profiles/r01h_pmc_traffic.json; the "
+                             f"(2*FETCH_SIZE + WRITE_SIZE) KB and mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024) "
+                             f"from profiles/{PMC_FILE[args.precision]} (separate --pmc passes, tools/profile_round.sh); the "
                              "launch is 192 workgroups (3 roles x 16 slices x 4-CU clusters), one per CU, "
                              "and the step is a chain of 4 dependent launches bound by latency, not by "
                              "the matrix cores (DESIGN.md section 6)")
@@ -585,10 +593,11 @@ def main():
             "metric": "learner gradient steps/sec, DDPG batch=256 walker-walk",
             "value": round(value, 1), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "pre_warm_steps": args.pre_warm,
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic", "pre_warm_steps": args.pre_warm,
             "config": {"workload": f"DDPG walker-walk dims S={S} A={A} B={B}, hidden (256,256), replay "
                                    f"{E}x{L} transitions resident in HBM, device-side uniform sampling, "
-                                   "exact-fp32 MFMA (parity mode)",
+                                   + ("exact-fp32 MFMA (parity mode)" if args.precision == "f32" else
+                                      "bf16 MFMA inputs, fp32 accumulate / master / Adam (OPRL_PREC_BF16)"),
                        "path": "oprl_learner_step_n" if not use_dp else
                                ("oprl_learner_dp_step_n: update_phase/apply + 2 gradient all-reduces (critic, actor) per step, all in C; "
                                 + {2: "all-reduced per tile inside the dW + Adam launches over xGMI peer windows (csrc/p2p.hip, k_dw_adam<true>)",
