@@ -95,6 +95,17 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
+// Sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), returned in every lane of the row: four
+// data-parallel-primitive adds (quad xor 1, quad xor 2, half mirror, row mirror) — VALU operand modifiers,
+// a few cycles each — where __shfl_xor costs a ds_bpermute round trip (~100 cycles) per step.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
 __device__ __forceinline__ bf16x8 cvt_bf16x8(const f32x4 lo, const f32x4 hi) {
   const f32x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_convertvector(v, bf16x8);

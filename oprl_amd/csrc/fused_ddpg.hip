@@ -175,8 +175,7 @@ __device__ __forceinline__ void gauss_head(const float* outS, int row0, int B, i
       }
     }
   }
-#pragma unroll
-  for (int m = 1; m < 16; m <<= 1) lp += __shfl_xor(lp, m);
+  lp = row16_sum(lp);
   if (sub == 0 && gr < B) {
     if (lpS != nullptr) lpS[row] = lp;
     if (logp_g != nullptr) logp_g[gr] = lp;
@@ -185,7 +184,7 @@ __device__ __forceinline__ void gauss_head(const float* outS, int row0, int B, i
 
 template <int WIDTH, bool LEAN, class P, class ST>
 __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, float* const* cX, float* const* cdY,
-                                       float* partials, bool diag, float* smem, Tp& tp, ST& stamp) {
+                                       float* partials, bool diag, int j, float* smem, Tp& tp, ST& stamp) {
   using LY = FusedLds<WIDTH>;
   constexpr int WL = lds_ld(WIDTH);
   constexpr int HB = kR * WL;
@@ -198,7 +197,7 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
   float* yS = smem + LY::misc + 2 * kR;
   const int slice = blockIdx.x, row0 = slice * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
   const bool lead = tp.c == 0;
-  const Tp3Store st{cX[1], cX[2], cdY[1], cdY[0], A.cdY0_stride};
+  const Tp3Store st{cX[1], cX[2], cdY[1], cdY[0], A.cdY0_stride, LEAN ? B : 0};   // lean: tile-major dz1 partials
   if constexpr (LEAN) {
     // ... and, the critic being scalar-output, its whole backward with unit seed as well:
     // k_dw_adam applies 2(q - y)/B per row (tp4_scalar_fb), so after y arrives only that
@@ -209,39 +208,16 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
   }
   if (lead) store_rows(xa, kX0Ld, cX[0], A.cldx0, S + Ad, row0, B);
   if constexpr (LEAN) {
-    // only the seed vector and the diagnostics are left: one wave of the lead member, no LDS
+    // q goes to role A of this slice as granules — A, the last to finish, turns it into the per-row seed
+    // 2 (q - y) / B and the diagnostics itself; this role is done (it used to wait here for y: one more hop
+    // and a wake-up on the launch's critical path)
     if (!lead || tid >= 64) return;
-    float y = 0.f, q = 0.f;
     const int gr = row0 + tid;
-    const bool row_ok = tid < kR && gr < B;
-    if (row_ok) {
-      unsigned long long g = 0;
-      bool ok = false;
-      const int lim = A.debug_expire == (int)SITE_TD_TARGET ? 0 : (1 << 20);
-      for (int spin = 0; spin < lim; ++spin) {
-        g = __hip_atomic_load(A.y_granules + gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = (unsigned)(g >> 32) == A.epoch;
-        if (ok) break;
-        __builtin_amdgcn_s_sleep(8);
-      }
-      if (!ok) report_expired(A.err, (KERN_PHASE1 << 8) | SITE_TD_TARGET);
-      y = ok ? __uint_as_float((unsigned)g) : __builtin_nanf("");
-      q = outS[tid * kOutLd];
-      cdY[2][(size_t)gr * A.clddo] = 2.f * (q - y) * A.inv_B;
-      if (diag && A.y_out != nullptr) A.y_out[gr] = y;
-      if (diag && A.q_out != nullptr) A.q_out[gr] = q;
-    }
-    stamp();   // TD target received, seed published
-    if (partials != nullptr) {
-      float v[3] = {row_ok ? (q - y) * (q - y) : 0.f, row_ok ? q : 0.f, row_ok ? y : 0.f};
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) v[k] += __shfl_xor(v[k], m);
-        if (tid == 0) partials[slice * 4 + k] = v[k];
-      }
-    }
-    stamp();
+    if (tid < kR && gr < B)
+      __hip_atomic_store(A.y_granules + (size_t)(1 + j) * A.gran_stride + gr,
+                         ((unsigned long long)A.epoch << 32) | (unsigned long long)__float_as_uint(outS[tid * kOutLd]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stamp();   // q published
     return;
   }
   // wait for this slice's TD targets: lanes 0..15 of wave 0 poll their granule (relaxed,
@@ -325,9 +301,13 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A) {
   int* meta = reinterpret_cast<int*>(yS + kR);
   int* endsS = reinterpret_cast<int*>(smem + LY::misc + 96);
   const int slice = blockIdx.x, row0 = slice * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
-  // roles: 0 = A target chain, 1 .. n_critics = B (one per online critic), last = C actor forward
-  const int role = blockIdx.y / A.nc;
+  // roles: 0 = A target chain, 1 .. n_critics = B (one per online critic), last = C actor forward.
+  // Order in the grid (= dispatch order when the grid over-subscribes the chip): whoever is waited for comes
+  // first — generic passes A | B.. | C (the B roles wait for A's TD target), lean passes B.. | A | C (role A
+  // waits for the B roles' q; twin_split's mutual A <-> C exchange needs co-residency either way)
+  const int ry = blockIdx.y / A.nc;
   const int role_c = 1 + A.n_critics;
+  const int role = !LEAN ? ry : (ry < A.n_critics ? 1 + ry : (ry == A.n_critics ? 0 : ry));
   Tp tp{(int)blockIdx.y % A.nc, A.nc,
         A.xbuf + ((size_t)role * gridDim.x + slice) * kTpStages * A.nc * kTpBlk, A.cluster_tag, 0,
         A.err, KERN_PHASE1 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
@@ -414,7 +394,21 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A) {
       xb[row * kX0Ld + S + col] = v;
     }
     // (the next GEMM's own barrier publishes xb)
-    tp_fwd<WIDTH, LEAN, P>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
+    // lean: the B roles' q granules (long published by then) are requested from inside this pass — after its
+    // layer-1 stage — so that the seed stage below does not start with a cold round trip
+    unsigned long long gq[2] = {0ull, 0ull};
+    int hook_n = 0;
+    const unsigned long long* gq_src = A.y_granules + A.gran_stride + min(row0 + (tid & (kR - 1)), B - 1);
+    auto hook = [&]() {
+      stamp();
+      if constexpr (LEAN) {
+        if (++hook_n == 2) {
+          gq[0] = __hip_atomic_load(gq_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (A.n_critics == 2) gq[1] = __hip_atomic_load(gq_src + A.gran_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    };
+    tp_fwd<WIDTH, LEAN, P>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, hook);
     float qn = (tid < kR) ? outS[tid * kOutLd] : 0.f;
     if (A.twin_split) {
       if (lead && tid < kR) qn = fminf(qn, granule_get(x_slot(0) + tid, x_tag, A.err, (KERN_PHASE1 << 8) | SITE_TWIN_SPLIT));
@@ -428,13 +422,52 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A) {
         qn -= alpha * yS[tid];
       }
     }
-    if (lead && tid < kR && row0 + tid < B) {
-      const float y = rS[tid] + ((1.f - dS[tid]) * A.gamma) * qn;
-      // hand-off to the B roles of this slice: ONE aligned 8-byte {epoch, value} granule per
-      // row, written through (agent-scope relaxed atomic = sc1 store); the tag makes the
-      // data its own flag, no fence needed (cdna guide, G16 R2).
-      const unsigned long long g = ((unsigned long long)A.epoch << 32) | (unsigned long long)__float_as_uint(y);
-      __hip_atomic_store(A.y_granules + row0 + tid, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (!LEAN) {
+      if (lead && tid < kR && row0 + tid < B) {
+        const float y = rS[tid] + ((1.f - dS[tid]) * A.gamma) * qn;
+        // hand-off to the B roles of this slice: ONE aligned 8-byte {epoch, value} granule per
+        // row, written through (agent-scope relaxed atomic = sc1 store); the tag makes the
+        // data its own flag, no fence needed (cdna guide, G16 R2).
+        const unsigned long long g = ((unsigned long long)A.epoch << 32) | (unsigned long long)__float_as_uint(y);
+        __hip_atomic_store(A.y_granules + row0 + tid, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else if (lead && tid < 64) {
+      // lean passes: the B roles ran the critics' whole backward with unit seed and sent their q long ago;
+      // the seed vectors 2 (q_j - y) / B (k_dw_adam's per-row scale) and the diagnostics are written HERE,
+      // by the role that finishes last — nobody waits for this role any more
+      const int gr = row0 + tid;
+      const bool row_ok = tid < kR && gr < B;
+      const float y = row_ok ? rS[tid] + ((1.f - dS[tid]) * A.gamma) * qn : 0.f;
+      const int lim = A.debug_expire == (int)SITE_TD_TARGET ? 0 : (1 << 20);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j < A.n_critics) {
+          float q = 0.f;
+          if (row_ok) {
+            unsigned long long g = gq[j];                  // requested during the pass above
+            bool ok = lim > 0 && (unsigned)(g >> 32) == A.epoch;
+            for (int spin = 0; spin < lim && !ok; ++spin) {
+              g = __hip_atomic_load(A.y_granules + (size_t)(1 + j) * A.gran_stride + gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ok = (unsigned)(g >> 32) == A.epoch;
+              if (!ok) __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok) report_expired(A.err, (KERN_PHASE1 << 8) | SITE_TD_TARGET);
+            q = ok ? __uint_as_float((unsigned)g) : __builtin_nanf("");
+            float* const* dYj = j == 0 ? A.cdY : A.c2dY;
+            dYj[2][(size_t)gr * A.clddo] = 2.f * (q - y) * A.inv_B;
+            if (j == 0 && A.y_out != nullptr) A.y_out[gr] = y;
+            if (j == 0 && A.q_out != nullptr) A.q_out[gr] = q;
+          }
+          if (A.partials_c != nullptr) {
+            float v[3] = {row_ok ? (q - y) * (q - y) : 0.f, row_ok ? q : 0.f, row_ok ? y : 0.f};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const float sum = row16_sum(v[k]);             // the slice's 16 rows sit in lanes 0..15
+              if (tid == 0) A.partials_c[((size_t)j * gridDim.x + slice) * 4 + k] = sum;
+            }
+          }
+        }
+      }
     }
     stamp();
     return;
@@ -443,8 +476,8 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A) {
   // ---- role B: q = critic_j(s, a) forward (runs while role A computes the target).  The twin
   // critic gets its own copy of the code (a runtime-selected Net would leave the kernel-argument
   // registers: profiles/r01b_experiments.txt #10).
-  if (role == 2) { role_b<WIDTH, LEAN, P>(A, A.critic2, A.c2X, A.c2dY, A.partials_c + (size_t)gridDim.x * 4, false, smem, tp, stamp); return; }
-  role_b<WIDTH, LEAN, P>(A, A.critic, A.cX, A.cdY, A.partials_c, true, smem, tp, stamp);
+  if (role == 2) { role_b<WIDTH, LEAN, P>(A, A.critic2, A.c2X, A.c2dY, A.partials_c + (size_t)gridDim.x * 4, false, 1, smem, tp, stamp); return; }
+  role_b<WIDTH, LEAN, P>(A, A.critic, A.cX, A.cdY, A.partials_c, true, 0, smem, tp, stamp);
 }
 
 template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32>
@@ -614,8 +647,7 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A) {
     }
     if (A.partials_a != nullptr && lead && tid < 64) {
       float v = (tid < kR && row0 + tid < B) ? fminf(q1p[tid * q1s], q2p[tid * q2s]) : 0.f;
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m);
+      v = row16_sum(v);
       if (tid == 0) {
         A.partials_a[slice * 4 + 0] = 0.f;
         A.partials_a[slice * 4 + 1] = v;
@@ -641,7 +673,7 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A) {
         A.adY[2][(size_t)(row0 + r_) * A.alddo + Ad + c_] = dls;
       }
     }
-    const Tp3Store sta{nullptr, nullptr, A.adY[1], A.adY[0], A.adY0_stride};
+    const Tp3Store sta{nullptr, nullptr, A.adY[1], A.adY[0], A.adY0_stride, LEAN ? B : 0};
     tp_bwd<WIDTH, LEAN, P>(A.actor, auxS, ha1, ha2, scr, tp, sta, row0, B, 0, 0, auxS, stamp);
     stamp();
     return;
@@ -703,7 +735,7 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A) {
     if (lead) store_rows(auxS, kOutLd, A.adY[2], A.alddo, Ad, row0, B);
   }
   // ---- actor backward over its stored activations
-  const Tp3Store sta{nullptr, nullptr, A.adY[1], A.adY[0], A.adY0_stride};
+  const Tp3Store sta{nullptr, nullptr, A.adY[1], A.adY[0], A.adY0_stride, LEAN ? B : 0};
   tp_bwd<WIDTH, LEAN, P>(A.actor, auxS, ha1, ha2, scr, tp, sta, row0, B, 0, 0, auxS, stamp);
   stamp();
 }

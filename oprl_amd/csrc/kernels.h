@@ -171,6 +171,7 @@ struct DwArgs {                         // host-side description of one k_dw_ada
   const DwItem* items;                 // HOST array
   int n_items; int total_tiles; int B;
   int n_part;                          // members of the tensor-parallel cluster that wrote dz1 partials
+  int dy_tiled = 0;                    // 1: those partial buffers are tile-major (written by the tp4 passes, Tp3Store::dY0_tile_rows = B)
   AdamScalars ad;
   long long* trace;                    // debug stamps (tools/trace_slice.py) or null
   int use_row_scale;                   // 1: the slice kernels left unit-seed dz rows (lean fused path)
@@ -190,7 +191,7 @@ constexpr int kDwMaxItems = 20;        // 5 critics x 4 layers (TQC)
 struct DwKArgs {
   int tile_end[kDwMaxItems];           // exclusive prefix ends, relative to this launch
   DwItem items[kDwMaxItems];
-  int n_items, B, n_part;
+  int n_items, B, n_part, dy_tiled;
   AdamScalars ad;
   long long* trace;
   int use_row_scale;
@@ -250,7 +251,9 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   float* adY[kMaxLayers]; int alddo;
   float* pi;                           // [B][A]
   float *y_out, *q_out;                // [B] diagnostics / parity
-  unsigned long long* y_granules;      // [B] {epoch<<32 | float bits}: TD target hand-off between roles
+  unsigned long long* y_granules;      // [3][gran_stride] {epoch<<32 | float bits}: [0] TD target, role A -> B roles (generic passes);
+                                       // [1 + j] q of online critic j, role B_j -> role A (lean passes: A publishes the seeds itself)
+  int gran_stride;
   unsigned epoch;                      // monotonically increasing per update, never 0
   int bf16;                            // 1: the nets' pf / pb are bf16 packs and the lean passes run PrecBF16 (engine.h)
   int nc;                              // CUs per slice cluster (tensor-parallel, csrc/tp3.h): 1, 2 or 4

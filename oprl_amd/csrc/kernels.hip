@@ -145,6 +145,7 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A) {
   const int i = lane & 15, c = lane >> 4;
   const int NSk = cdiv(I.K, 16), NSn = cdiv(I.N, 16);
   const int npart = I.dY_part_stride > 0 ? A.n_part : 1;
+  const bool tiled = I.dY_part_stride > 0 && A.dy_tiled != 0;   // tile-major partial buffers (tp4_store_dz1)
   const bool polyak = A.ad.do_polyak && I.w_t != nullptr;
 
   // this thread's element of the epilogue; its Adam state is requested NOW so the round
@@ -159,6 +160,19 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A) {
     p_m = I.w_m[eo];
     p_v = I.w_v[eo];
     if (polyak) p_tt = I.w_t[eo];
+  }
+  // ... and the bias element of the tiles that own one (tk == 0, thread = column): requested here as
+  // well — fetched in the epilogue it was a cold round trip (0.6 us) at the very end of the layer-0
+  // tiles, the ones every launch waits for
+  const bool b_own = tk == 0 && tid < TNi && n_base + tid < I.N;
+  const bool b_pol = A.ad.do_polyak && I.b_t != nullptr;
+  float q_th = 0.f, q_m = 0.f, q_v = 0.f, q_tt = 0.f;
+  if (b_own && A.ad.do_adam) {
+    const int n = n_base + tid;
+    q_th = I.b[n];
+    q_m = I.b_m[n];
+    q_v = I.b_v[n];
+    if (b_pol) q_tt = I.b_t[n];
   }
 
   // ---- dW tile = sum_b dY[b, n]^T X[b, k].  Each wave owns 32 consecutive minibatch rows per
@@ -192,7 +206,8 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) va[h][m] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (bb < A.B && an_ok) {
-        const float* src = I.dY + (size_t)bb * I.ldy + n_base + an;
+        const float* src = tiled ? I.dY + ((size_t)((n_base + an) >> 4) * A.B + bb) * 16 + ((n_base + an) & 15)
+                                 : I.dY + (size_t)bb * I.ldy + n_base + an;
         va[h][0] = ld4(src);
         // tensor-parallel slices leave the first layer's dz as n_part (<= 4) partial buffers
         // (csrc/tp3.h): all requested up front, summed below in member order
@@ -400,18 +415,25 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A) {
       }
     }
   }
-  if (tk == 0 && tid < TNi) {
+  if (b_own) {
     const int n = n_base + tid;
-    if (n < I.N) {
-      float gb = 0.f;
+    float gb = 0.f;
 #pragma unroll
-      for (int w = 0; w < kDwWaves; ++w) gb += bpart[w][tid];
-      if constexpr (XCHG) gb = gb_x;
-      if (A.apply_only) gb = I.b_g[n];
-      float t0, t1;
-      (void)adam_polyak_elem(gb, I.b + n, I.b_m ? I.b_m + n : nullptr, I.b_v ? I.b_v + n : nullptr,
-                             I.b_t ? I.b_t + n : nullptr, (I.b_g && !A.apply_only) ? I.b_g + n : nullptr,
-                             A.ad, step_size, bc2_sqrt, &t0, &t1);
+    for (int w = 0; w < kDwWaves; ++w) gb += bpart[w][tid];
+    if constexpr (XCHG) gb = gb_x;
+    if (A.apply_only) gb = I.b_g[n];
+    gb *= A.ad.grad_scale;                 // (the arithmetic of adam_polyak_elem, on the prefetched state)
+    if (I.b_g != nullptr && !A.apply_only) I.b_g[n] = gb;
+    if (A.ad.do_adam) {
+      float mm = q_m, vv = q_v, th = q_th;
+      mm = mm + (gb - mm) * A.ad.omb1;
+      vv = vv * A.ad.beta2 + A.ad.omb2 * gb * gb;
+      const float denom = sqrtf(vv) / bc2_sqrt + A.ad.eps;
+      th = th - step_size * (mm / denom);
+      I.b_m[n] = mm;
+      I.b_v[n] = vv;
+      I.b[n] = th;
+      if (b_pol) I.b_t[n] = q_tt * A.ad.omtau + A.ad.tau * th;
     }
   }
   stamp();   // stores issued
@@ -675,7 +697,7 @@ int fill_dw_kargs(const DwArgs& a, DwKArgs* k) {
     k->tile_end[j] = total;
   }
   for (int j = a.n_items; j < kDwMaxItems; ++j) { k->items[j] = a.items[0]; k->tile_end[j] = total; }
-  k->n_items = a.n_items; k->B = a.B; k->n_part = a.n_part; k->ad = a.ad; k->trace = a.trace;
+  k->n_items = a.n_items; k->B = a.B; k->n_part = a.n_part; k->dy_tiled = a.dy_tiled; k->ad = a.ad; k->trace = a.trace;
   k->use_row_scale = a.use_row_scale; k->one = dw_one_dev();
   k->apply_only = a.apply_only;
   memset(&k->xchg, 0, sizeof k->xchg);
@@ -720,7 +742,7 @@ hipError_t launch_dw_adam(const DwArgs& a0, hipStream_t st) {
     k.tile_end[j] = total;
   }
   for (int j = a.n_items; j < kDwMaxItems; ++j) { k.items[j] = a.items[0]; k.tile_end[j] = total; }
-  k.n_items = a.n_items; k.B = a.B; k.n_part = a.n_part; k.ad = a.ad; k.trace = a.trace;
+  k.n_items = a.n_items; k.B = a.B; k.n_part = a.n_part; k.dy_tiled = a.dy_tiled; k.ad = a.ad; k.trace = a.trace;
   k.use_row_scale = a.use_row_scale; k.one = one_dev;
   k.apply_only = a.apply_only;
   memset(&k.xchg, 0, sizeof k.xchg);

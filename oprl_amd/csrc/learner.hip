@@ -801,7 +801,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   a.aldx0 = h->ws_actor.ldx0;     a.alddo = h->ws_actor.lddo;
   a.pi = h->pi;
   a.y_out = h->ydbg; a.q_out = h->qdbg;
-  a.y_granules = h->y_granules;
+  a.y_granules = h->y_granules; a.gran_stride = h->Bmax;
   a.epoch = h->epoch;
   a.trace = nullptr;
   a.nc = h->nc_cluster(B);
@@ -857,7 +857,9 @@ int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st) {
   dw.apply_only = 0;
   // the lean phase 1 leaves unit-seed dz rows (tp4_scalar_fb): each critic's TD-error seed, dY of
   // its output layer, is applied per row (DwItem::rs)
-  dw.use_row_scale = (critic && fused && fused_ddpg_is_lean(ddpg_args(h, B))) ? 1 : 0;
+  const bool lean = fused && fused_ddpg_is_lean(ddpg_args(h, B));
+  dw.use_row_scale = (critic && lean) ? 1 : 0;
+  dw.dy_tiled = (lean && dw.n_part > 1) ? 1 : 0;      // the lean passes leave tile-major dz1 partials
   if (h->dp_inline) {
     // data-parallel on peer windows: this launch all-reduces its tiles itself and runs Adam on the mean
     P2pState& P = h->p2p;
@@ -884,7 +886,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     h->epoch += 1;
     if (h->epoch == 0) {   // the TD-target tag wrapped: retire every stale granule
       h->epoch = 1;
-      HIPC(hipMemsetAsync(h->y_granules, 0, (size_t)h->Bmax * sizeof(unsigned long long), st));
+      HIPC(hipMemsetAsync(h->y_granules, 0, (size_t)3 * h->Bmax * sizeof(unsigned long long), st));
     }
     DdpgArgs fa = ddpg_args(h, B);
     fa.noise = noise0;
@@ -959,6 +961,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     DwArgs dw;
     dw.items = h->items_host.data(); dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
     dw.B = B; dw.n_part = tp_generic(h, c.critics[0], B) ? 4 : 1; dw.use_row_scale = 0; dw.apply_only = 0;
+    dw.dy_tiled = dw.n_part > 1 ? 1 : 0;               // k_mlp_slice_tp runs the tp4 passes
     dw.trace = h->trace != nullptr ? h->trace + (size_t)4 * 64 * kTraceStamps * 2 : nullptr;   // slot 4
     dw.ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, 1.0f);
     HIPC(launch_dw_prof(dw, st));
@@ -1070,6 +1073,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     DwArgs dw;
     dw.items = h->items_host.data() + h->n_items_critic; dw.n_items = h->n_items_actor;
     dw.total_tiles = h->tiles_actor; dw.B = B; dw.n_part = tp_generic(h, c.actor, B) ? 4 : 1; dw.use_row_scale = 0; dw.apply_only = 0;
+    dw.dy_tiled = dw.n_part > 1 ? 1 : 0;
     dw.trace = h->trace != nullptr ? h->trace + (size_t)5 * 64 * kTraceStamps * 2 : nullptr;   // slot 5
     dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, c.actor.theta_target != nullptr, 1.0f);
     HIPC(launch_dw_prof(dw, st));
@@ -1532,7 +1536,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
             (size_t)nc * B * A + (size_t)nc * B + (size_t)B * 128 + 2 * (size_t)B;
   floats += (size_t)(nc + 1) * n_slices * 4 + 16;
   floats += (size_t)B * (2 * S + A + 2);
-  floats += 64 * 32 + 2 * (size_t)B;
+  floats += 64 * 32 + 6 * (size_t)B;      // (granule arrays: y, q1, q2)
   if (h->bf16) {
     floats += 2 * ((size_t)net_pack16_floats(cfg->actor) + 64);
     for (int j = 0; j < nc; ++j) floats += 2 * ((size_t)net_pack16_floats(cfg->critics[j]) + 64);
@@ -1573,7 +1577,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   h->part_a = p.take<float>((size_t)n_slices * 4);
   h->scalars = p.take<float>(16);
   h->alpha_grad = cfg->log_alpha_grad ? cfg->log_alpha_grad : p.take<double>(2);
-  h->y_granules = p.take<unsigned long long>((size_t)B);
+  h->y_granules = p.take<unsigned long long>((size_t)3 * B);
   h->bs = p.take<float>((size_t)B * S);
   h->ba = p.take<float>((size_t)B * A);
   h->br = p.take<float>(B);
@@ -1923,7 +1927,7 @@ extern "C" int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, 
       h->src.gather = h->staged_ready ? 0 : 1;
       const int prefetch = (k + 1 < K) ? 1 : 0;
       h->epoch += 1;
-      if (h->epoch == 0) { h->epoch = 1; HIPC(hipMemsetAsync(h->y_granules, 0, (size_t)h->Bmax * sizeof(unsigned long long), st)); }
+      if (h->epoch == 0) { h->epoch = 1; HIPC(hipMemsetAsync(h->y_granules, 0, (size_t)3 * h->Bmax * sizeof(unsigned long long), st)); }
       p1[l] = ddpg_args(h, B);
       RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &p1[l].cluster_tag));
       p2[l] = ddpg_args(h, B);

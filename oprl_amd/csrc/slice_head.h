@@ -79,8 +79,7 @@ __device__ __forceinline__ void slice_head(const MlpArgs& A, const float* outS, 
         }
       }
     }
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) lp += __shfl_xor(lp, m);
+    lp = row16_sum(lp);
     if (lead && mine && sub == 0 && gr < B && A.logp != nullptr) A.logp[gr] = lp;
   } else if (lead && A.out != nullptr) {
     const int ncol = (A.out_act == ACT_GAUSS_MEAN) ? A.action_dim : Nout;

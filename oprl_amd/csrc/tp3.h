@@ -118,6 +118,10 @@ struct Tp3Store {
   float* dY1;       // [B][W]   dz2 (each member its columns)
   float* dY0;       // [nc][B][W] dz1 partials (member c writes buffer c)
   long dY0_stride;  // floats between two members' partial buffers
+  // > 0 (tp4 passes only): the partial buffers are TILE-MAJOR, [16-column tile][dY0_tile_rows rows][16] —
+  // what a layer-0 tile of k_dw_adam reads from a member's buffer is then one contiguous run of full
+  // cache lines instead of 64-byte pieces of 1 KB rows (DwArgs::dy_tiled).  0: row-major [B][W].
+  int dY0_tile_rows = 0;
 };
 
 // Forward.  x0s: [kR][kX0Ld] input tile (zero padded; no barrier needed).  On return h1

@@ -105,6 +105,23 @@ __device__ __forceinline__ f32x4 tp4_allreduce_regs(const f32x4 mine, int col, b
   return sum;
 }
 
+// This member's dz1 partial (the whole [16 x 256] tile in h1) -> its partial buffer, for k_dw_adam.
+// Tile-major when st.dY0_tile_rows > 0: a wave writes one 16-column tile of the slice, 16 rows x 64 B = one
+// contiguous KB.
+__device__ __forceinline__ void tp4_store_dz1(const Tp3Store& st, int c, const float* h1, int row0, int B) {
+  if (st.dY0 == nullptr) return;
+  float* dst = st.dY0 + (size_t)c * st.dY0_stride;
+  const int idx = threadIdx.x;                       // 16 rows x 64 float4
+  if (st.dY0_tile_rows > 0) {
+    const int t = idx >> 6, row = (idx >> 2) & 15, c4 = (idx & 3) * 4, gr = row0 + row;
+    if (gr < B)
+      *reinterpret_cast<f32x4*>(dst + ((size_t)t * st.dY0_tile_rows + gr) * 16 + c4) = ld4(h1 + row * kWL4 + 16 * t + c4);
+  } else {
+    const int row = idx >> 6, col = (idx & 63) * 4, gr = row0 + row;
+    if (gr < B) *reinterpret_cast<f32x4*>(dst + (size_t)gr * kW4 + col) = ld4(h1 + row * kWL4 + col);
+  }
+}
+
 // Layer 1 (the member's 256 x 64 shard) is contracted by ALL 16 waves: wave w = output tile (w & 3), quarter
 // (w >> 2) of the contraction, the four partial tiles meeting in `scr` ([kWaves][256] floats) and summed in
 // quarter order by one thread per element.  An earlier version gave whole tiles to waves 0..3: 16 fragments
@@ -299,13 +316,7 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
   sf();
   __syncthreads();   // dz1 partial visible
 
-  if (st.dY0 != nullptr) {
-    const int idx = threadIdx.x;                     // 16 rows x 64 float4
-    const int row = idx >> 6, col = (idx & 63) * 4, gr = row0 + row;
-    if (gr < B)
-      *reinterpret_cast<f32x4*>(st.dY0 + (size_t)c * st.dY0_stride + (size_t)gr * kW4 + col) =
-          ld4(h1 + row * kWL4 + col);
-  }
+  tp4_store_dz1(st, c, h1, row0, B);
   if (dact) {
     // partial gradient wrt the input columns: tile dt, contraction quarter dpart
     if (dact_wave) {
@@ -488,13 +499,7 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   sf();
   __syncthreads();   // dz1 partial visible
 
-  if (st.dY0 != nullptr) {
-    const int idx = threadIdx.x;
-    const int row = idx >> 6, col = (idx & 63) * 4, gr = row0 + row;
-    if (gr < B)
-      *reinterpret_cast<f32x4*>(st.dY0 + (size_t)c * st.dY0_stride + (size_t)gr * kW4 + col) =
-          ld4(h1 + row * kWL4 + col);
-  }
+  tp4_store_dz1(st, c, h1, row0, B);
   if (dact_wave) {
     f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
     const float* hr = h1 + i * kWL4 + 64 * dpart + 4 * kk;

@@ -54,6 +54,16 @@ for slot in range(len(names)):
           f"max-wg={tot_us.max():.2f}us  cyc/us~{clk.mean():.2f} GHz  start spread={(rt[:,0].max()-rt[:,0].min())/100:.2f}us")
     if "--cycles" in sys.argv:
         print(f"{'':22s} wg0 phases(cycles)={d_cyc[0].astype(int).tolist()}")
+    if slot >= 4 and fused and "--dw-tiles" in sys.argv:
+        # the traced workgroups of a dW launch are the first 16 tiles of each layer (slot index = 16 * layer + tile)
+        for layer in range(3):
+            y = tr[slot, 16 * layer:16 * layer + 16]
+            y = y[y[:, 0, 1] != 0]
+            if len(y) == 0:
+                continue
+            ph = np.diff(y[:, :n, 1].astype(np.float64), axis=1) / 100.0
+            print(f"{'':10s} layer {layer}: {len(y)} tiles traced, phases mean(us)={np.round(ph.mean(0), 2).tolist()} "
+                  f"max(us)={np.round(ph.max(0), 2).tolist()} total mean={ph.sum(1).mean():.2f} max={ph.sum(1).max():.2f}")
 
 # absolute timeline on the shared 100 MHz clock: first/last stamp over all traced workgroups
 if fused:
