@@ -167,6 +167,17 @@ __host__ __device__ inline size_t dw_xchg_bytes(int world, int max_tiles) {
   return (size_t)2 * (world + 1) * max_tiles * kDwXchgTile * sizeof(unsigned long long);
 }
 
+// The temperature's Adam step (float64, k_alpha_step) as ONE EXTRA workgroup of a k_dw_adam launch: SAC's and
+// TQC's updates end with it, and as a launch of its own it cost a kernel boundary for 3 us of work.
+struct AlphaJob {
+  double* log_alpha = nullptr;         // null: no job
+  double *m = nullptr, *v = nullptr;
+  const float* logp = nullptr;         // [B] log pi of this update's actor sample
+  int B = 0;
+  float target_entropy = 0.f;
+  double lr = 0, beta1 = 0, beta2 = 0, eps = 0, bc1 = 1, bc2_sqrt = 1;
+};
+
 struct DwArgs {                         // host-side description of one k_dw_adam launch
   const DwItem* items;                 // HOST array
   int n_items; int total_tiles; int B;
@@ -177,6 +188,7 @@ struct DwArgs {                         // host-side description of one k_dw_ada
   int use_row_scale;                   // 1: the slice kernels left unit-seed dz rows (lean fused path)
   int apply_only;                      // 1: no GEMM — the gradient is read from w_g / b_g (data-parallel apply after the all-reduce)
   const DwXchg* xchg = nullptr;       // data-parallel: all-reduce every gradient tile over the peer windows inside this launch
+  AlphaJob alpha;                      // optional: the temperature step rides on this launch (one more workgroup)
 };
 
 
@@ -198,6 +210,7 @@ struct DwKArgs {
   const float* one;                    // device word holding 1.0f (row scale of unscaled layers)
   int apply_only;
   DwXchg xchg;                         // k_dw_adam<true> only
+  AlphaJob alpha;                      // workgroup `tile_end[n_items - 1]` (one past the tiles) runs it
 };
 
 struct BatchSrc {

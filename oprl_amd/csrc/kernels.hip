@@ -112,6 +112,11 @@ __device__ __forceinline__ void adam_bias_corr(const AdamScalars& ad, float* ste
 // workgroup all-reduces its gradient tile with the same tile of the other ranks — tagged granules into
 // the peers' windows, a bounded per-element wait for the peers' granules, sum in rank order.  A separate template instance: the single-rank kernel is untouched.  All workgroups of the
 // launch must be resident (they wait for their counterparts on the other GPUs): at most a few hundred.
+__device__ __forceinline__ void alpha_step_block(double* log_alpha, double* m, double* v, const float* logp, int B,
+                                                 float target_entropy, double lr, double beta1, double beta2, double eps,
+                                                 double bc1, double bc2_sqrt, double* grad_out, const double* grad_in,
+                                                 float grad_scale);
+
 template <bool XCHG>
 __device__ __forceinline__ void dw_adam_body(const DwKArgs& A) {
   constexpr int TN = kDwTileN, TK = kDwTile, LD = TK + 4;
@@ -122,6 +127,13 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A) {
   // this workgroup's layer, straight from the kernel-argument segment (dynamic index into a
   // by-value array: through the segment pointer it is a scalar load, not a scratch copy)
   const DwKArgs* KA = &A;
+  if ((int)blockIdx.x >= KA->tile_end[A.n_items - 1]) {
+    // one workgroup past the tiles: the temperature's Adam step rides on this launch (AlphaJob)
+    const AlphaJob& J = A.alpha;
+    alpha_step_block(J.log_alpha, J.m, J.v, J.logp, J.B, J.target_entropy, J.lr, J.beta1, J.beta2, J.eps, J.bc1,
+                     J.bc2_sqrt, nullptr, nullptr, 1.f);
+    return;
+  }
   int item = 0;
   for (int j = 0; j + 1 < A.n_items; ++j) item += (int)blockIdx.x >= KA->tile_end[j] ? 1 : 0;
   const DwItem I = KA->items[item];
@@ -486,17 +498,21 @@ __device__ __forceinline__ double shfl_xor_f64(double x, int m) {
 
 // bc1 = 1 - beta1^step and bc2_sqrt = sqrt(1 - beta2^step) arrive from the host (it knows the
 // step; a device-side double pow() alone cost several microseconds of this scalar update).
-__global__ void k_alpha_step(double* log_alpha, double* m, double* v, const float* logp, int B,
-                             float target_entropy, double lr, double beta1, double beta2, double eps,
-                             double bc1, double bc2_sqrt, double* grad_out, const double* grad_in,
-                             float grad_scale) {
+// (the first 256 threads of the block sum logp — the same partition and order whether the block is the
+// 256-thread k_alpha_step or the extra 512-thread workgroup of a k_dw_adam launch)
+__device__ __forceinline__ void alpha_step_block(double* log_alpha, double* m, double* v, const float* logp, int B,
+                                                 float target_entropy, double lr, double beta1, double beta2, double eps,
+                                                 double bc1, double bc2_sqrt, double* grad_out, const double* grad_in,
+                                                 float grad_scale) {
   __shared__ double red[4];
   double s = 0.0;
   if (grad_in == nullptr) {
-    for (int idx = threadIdx.x; idx < B; idx += blockDim.x) s += (double)logp[idx];
+    if (threadIdx.x < 256) {
+      for (int idx = threadIdx.x; idx < B; idx += 256) s += (double)logp[idx];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) s += shfl_xor_f64(s, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+      for (int o = 1; o < 64; o <<= 1) s += shfl_xor_f64(s, o);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    }
     __syncthreads();
   }
   if (threadIdx.x != 0) return;
@@ -516,6 +532,14 @@ __global__ void k_alpha_step(double* log_alpha, double* m, double* v, const floa
   *log_alpha = *log_alpha - (lr / bc1) * (mm / denom);
   *m = mm;
   *v = vv;
+}
+
+__global__ void k_alpha_step(double* log_alpha, double* m, double* v, const float* logp, int B,
+                             float target_entropy, double lr, double beta1, double beta2, double eps,
+                             double bc1, double bc2_sqrt, double* grad_out, const double* grad_in,
+                             float grad_scale) {
+  alpha_step_block(log_alpha, m, v, logp, B, target_entropy, lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_out, grad_in,
+                   grad_scale);
 }
 
 // out[0..3] = sum over slices of partials[.][0..3]  (then scaled by the caller)
@@ -700,6 +724,7 @@ int fill_dw_kargs(const DwArgs& a, DwKArgs* k) {
   k->n_items = a.n_items; k->B = a.B; k->n_part = a.n_part; k->dy_tiled = a.dy_tiled; k->ad = a.ad; k->trace = a.trace;
   k->use_row_scale = a.use_row_scale; k->one = dw_one_dev();
   k->apply_only = a.apply_only;
+  k->alpha = AlphaJob{};
   memset(&k->xchg, 0, sizeof k->xchg);
   return k->one != nullptr ? total : -1;
 }
@@ -722,7 +747,7 @@ hipError_t launch_dw_adam(const DwArgs& a0, hipStream_t st) {
   if (n_wide > 0) {
     hipError_t e = launch_dw_adam_wide(wide, n_wide, a0.B, a0.ad, st);
     if (e != hipSuccess) return e;
-    if (n_rest == 0) return hipSuccess;
+    if (n_rest == 0) return a0.alpha.log_alpha != nullptr ? hipErrorInvalidValue : hipSuccess;   // (a job needs a tile launch to ride on)
   }
   DwArgs a = a0;
   a.items = rest;
@@ -745,14 +770,15 @@ hipError_t launch_dw_adam(const DwArgs& a0, hipStream_t st) {
   k.n_items = a.n_items; k.B = a.B; k.n_part = a.n_part; k.dy_tiled = a.dy_tiled; k.ad = a.ad; k.trace = a.trace;
   k.use_row_scale = a.use_row_scale; k.one = one_dev;
   k.apply_only = a.apply_only;
+  k.alpha = a.alpha;
   memset(&k.xchg, 0, sizeof k.xchg);
   if (a.xchg != nullptr) {
-    if (a.apply_only || n_wide > 0 || total > a.xchg->max_tiles) return hipErrorInvalidValue;
+    if (a.apply_only || n_wide > 0 || total > a.xchg->max_tiles || a.alpha.log_alpha != nullptr) return hipErrorInvalidValue;
     k.xchg = *a.xchg;
     hipLaunchKernelGGL(k_dw_adam<true>, dim3(total), dim3(kDwThreads), 0, st, k);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(k_dw_adam<false>, dim3(total), dim3(kDwThreads), 0, st, k);
+  hipLaunchKernelGGL(k_dw_adam<false>, dim3(total + (a.alpha.log_alpha != nullptr ? 1 : 0)), dim3(kDwThreads), 0, st, k);
   return hipGetLastError();
 }
 

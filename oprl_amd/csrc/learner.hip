@@ -837,9 +837,28 @@ bool use_fused(oprl_learner* h, int B) {
   return fused_ddpg_is_lean(ddpg_args(h, B));
 }
 
-int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st) {
+// The temperature step of this update as a job for the actor's dW launch (one more workgroup), when nothing
+// but this rank's own Adam step is wanted of it; otherwise (gradient export, exchange inside the dW launch)
+// the caller launches k_alpha_step itself.
+bool alpha_rides(const oprl_learner* h) {
+  return alpha_ptr(h) != nullptr && !h->cfg.export_grads && !h->dp_inline;
+}
+AlphaJob alpha_job(oprl_learner* h, int B) {
+  const oprl_learner_config& c = h->cfg;
+  h->opt_step_alpha += 1;
+  AlphaJob j;
+  j.log_alpha = c.log_alpha; j.m = c.log_alpha_m; j.v = c.log_alpha_v; j.logp = h->logp; j.B = B;
+  j.target_entropy = (float)c.hp.target_entropy;
+  j.lr = c.hp.lr_alpha; j.beta1 = c.hp.beta1; j.beta2 = c.hp.beta2; j.eps = c.hp.adam_eps;
+  j.bc1 = 1.0 - std::pow(c.hp.beta1, (double)h->opt_step_alpha);
+  j.bc2_sqrt = std::sqrt(1.0 - std::pow(c.hp.beta2, (double)h->opt_step_alpha));
+  return j;
+}
+
+int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st, bool with_alpha = false) {
   const oprl_learner_config& c = h->cfg;
   DwArgs dw;
+  if (with_alpha) dw.alpha = alpha_job(h, B);
   if (critic) {
     h->opt_step_critic += 1;
     dw.items = h->items_host.data(); dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
@@ -984,8 +1003,9 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     prof_end(st);
     HIPC(e);
     HIPC(chain_after(st));
-    RC(dw_step(h, false, B, c.actor.theta_target != nullptr, st));
-    if (alpha_ptr(h) != nullptr) {   // SAC temperature (sac.py:129-141), from role C's log pi
+    const bool rides = alpha_rides(h);      // SAC temperature (sac.py:129-141), from role C's log pi
+    RC(dw_step(h, false, B, c.actor.theta_target != nullptr, st, rides));
+    if (alpha_ptr(h) != nullptr && !rides) {
       h->opt_step_alpha += 1;
       HIPC(launch_alpha_step(c.log_alpha, c.log_alpha_m, c.log_alpha_v, h->logp, B,
                              (float)c.hp.target_entropy, c.hp.lr_alpha, c.hp.beta1, c.hp.beta2,
@@ -1076,10 +1096,11 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     dw.dy_tiled = dw.n_part > 1 ? 1 : 0;
     dw.trace = h->trace != nullptr ? h->trace + (size_t)5 * 64 * kTraceStamps * 2 : nullptr;   // slot 5
     dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, c.actor.theta_target != nullptr, 1.0f);
+    if (alpha_rides(h)) dw.alpha = alpha_job(h, B);
     HIPC(launch_dw_prof(dw, st));
   }
-  // 10. temperature
-  if (alpha_ptr(h) != nullptr) {
+  // 10. temperature (when it did not ride on the actor's dW launch)
+  if (alpha_ptr(h) != nullptr && !alpha_rides(h)) {
     h->opt_step_alpha += 1;
     HIPC(launch_alpha_step(c.log_alpha, c.log_alpha_m, c.log_alpha_v, h->logp, B,
                            (float)c.hp.target_entropy, c.hp.lr_alpha, c.hp.beta1, c.hp.beta2,
