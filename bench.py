@@ -224,6 +224,7 @@ def multi_learner(n, dev, local_rank, steps):
         t.manual_seed(100 + i)
         algos.append(DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device=f"cuda:{local_rank}",
                           max_batch=B).create())
+        algos[-1].learner.set_cluster(4)       # learners that share the chip: clusters of four only (include/oprl_amd.h)
         streams.append(t.cuda.Stream(device=dev))
     shared = make_replay(dev, seed=7)          # one HBM replay, n sampler keys
     chunk = 50
@@ -257,6 +258,7 @@ def multi_learner(n, dev, local_rank, steps):
     # the same update stream, alone on the GPU
     t.manual_seed(100)
     solo = DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device=f"cuda:{local_rank}", max_batch=B).create()
+    solo.learner.set_cluster(4)
     total = chunk * 2 + (steps // chunk) * chunk
     for _ in range(total // chunk):
         solo.learner.step_n(handle, chunk, B, seed=1000)

@@ -166,8 +166,13 @@ typedef struct oprl_group oprl_group;
 int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group** out);
 int oprl_group_destroy(oprl_group* g);
 int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, int32_t B, const uint64_t* seeds, void* stream);
-/* CUs per 16-row slice in the fused kernels: 4 (default: tensor-parallel clusters, lowest latency), 2 or 1
- * (least CU time per update: what packed learners use). */
+/* CUs per 16-row slice in the fused kernels.  8 (the default): tensor-parallel clusters of four, and of EIGHT
+ * for the forward-only chains where that still fits the chip (DDPG's target chain, DDPG / TD3's critic pass of
+ * the actor step; exact-fp32 mode, action_dim <= 8) — lowest latency for a learner that has the GPU (nearly) to
+ * itself; such launches want every CU, so learners that share a GPU with more than two others (seeds packed on
+ * streams, one process per seed on one GPU) use 4: clusters of four only (also OPRL_AMD_NO_WIDE=1).  2 or 1:
+ * least CU time per update (what oprl_group uses).  Results differ in the last bits between settings (order of
+ * the exchange sums); a setting is part of a run's configuration like the seed. */
 int oprl_learner_set_cluster(oprl_learner* h, int32_t nc);
 /* Diagnostics of the most recent update, read without forcing a sync inside
  * update(): out_host[0]=critic_loss, [1]=-mean q(s, pi) (DDPG / TD3 actor loss; min over twins for SAC),

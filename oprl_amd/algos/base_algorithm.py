@@ -315,6 +315,12 @@ class HipLearner:
     def clear_error(self) -> None:
         _capi.check(self.lib.oprl_learner_clear_error(self.handle), "oprl_learner_clear_error")
 
+    def set_cluster(self, nc: int) -> None:
+        """CUs per 16-row slice in the fused kernels (include/oprl_amd.h): 8 = the default (clusters of four, of
+        eight where the kernels have them: a learner that has the GPU to itself), 4 = clusters of four only
+        (learners that share a GPU with more than two others), 2 / 1 = least CU time per update."""
+        _capi.check(self.lib.oprl_learner_set_cluster(self.handle, int(nc)), "oprl_learner_set_cluster")
+
     def set_seed(self, seed: int, rank: int = 0) -> None:
         self.seed = int(seed)
         _capi.check(self.lib.oprl_learner_set_seed(self.handle, int(seed) & (2 ** 64 - 1), int(rank)),

@@ -48,10 +48,10 @@ namespace oprl {
 constexpr int kMaxEnds = 2048;
 
 // one MLP pass of a cluster: the lean tp4 routines or the generic tp3 ones
-template <int WIDTH, bool LEAN, class P, class ST>
+template <int WIDTH, bool LEAN, class P, int NM = 4, class ST>
 __device__ __forceinline__ void tp_fwd(const Net& net, const float* x0s, float* h1, float* h2, float* outS,
                                        float* scr, Tp& tp, const Tp3Store& st, int row0, int B, ST sf) {
-  if constexpr (LEAN) tp4_forward<P>(net, x0s, h1, h2, outS, scr, tp, st, row0, B, sf);
+  if constexpr (LEAN) tp4_forward<P, NM>(net, x0s, h1, h2, outS, scr, tp, st, row0, B, sf);
   else tp3_forward<WIDTH>(net, x0s, h1, h2, outS, scr, tp, st, row0, B, sf);
 }
 template <int WIDTH, bool LEAN, class P, class ST>
@@ -282,7 +282,10 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
 // (A separate template instance for the twin-critic algorithms, so that the single-critic kernel
 // carries none of their code, was measured SLOWER for all three: phase 1 15.0 vs 14.3 us for DDPG,
 // TD3 38.5 vs 36.0 us, SAC 54.5 vs 51.6 us per update — profiles/r01b_experiments.txt #29.)
-template <int WIDTH, bool LEAN, bool SAC, class P>
+// WIDE (DDPG, fp32 lean passes, a grid that still fits the chip): role A — two forward passes, the launch's
+// critical chain — runs on clusters of EIGHT CUs (tp4_forward<P, 8>): half the 256 x 256 layer's bytes and
+// MFMAs per member; roles B and C keep four.
+template <int WIDTH, bool LEAN, bool SAC, class P, bool WIDE = false>
 __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<WIDTH>;
@@ -300,16 +303,34 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A) {
   float* yS = dS + kR;
   int* meta = reinterpret_cast<int*>(yS + kR);
   int* endsS = reinterpret_cast<int*>(smem + LY::misc + 96);
-  const int slice = blockIdx.x, row0 = slice * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
+  const int B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
+  int slice = blockIdx.x;
   // roles: 0 = A target chain, 1 .. n_critics = B (one per online critic), last = C actor forward.
   // Order in the grid (= dispatch order when the grid over-subscribes the chip): whoever is waited for comes
   // first — generic passes A | B.. | C (the B roles wait for A's TD target), lean passes B.. | A | C (role A
   // waits for the B roles' q; twin_split's mutual A <-> C exchange needs co-residency either way)
-  const int ry = blockIdx.y / A.nc;
+  constexpr int NMA = (LEAN && WIDE) ? 8 : 4;          // members of role A's clusters (lean passes)
   const int role_c = 1 + A.n_critics;
-  const int role = !LEAN ? ry : (ry < A.n_critics ? 1 + ry : (ry == A.n_critics ? 0 : ry));
-  Tp tp{(int)blockIdx.y % A.nc, A.nc,
-        A.xbuf + ((size_t)role * gridDim.x + slice) * kTpStages * A.nc * kTpBlk, A.cluster_tag, 0,
+  const int nA = (LEAN && WIDE) ? 8 : A.nc;
+  int role, member;
+  if constexpr (!LEAN) {
+    role = (int)blockIdx.y / A.nc;
+    member = (int)blockIdx.y % A.nc;
+  } else {
+    const int y = (int)blockIdx.y, yb = A.n_critics * A.nc;
+    if (y < yb) { role = 1 + y / A.nc; member = y % A.nc; }
+    else if (y < yb + nA) {
+      // (wide: slice-major like every role — all members of a slice on one XCD; member-major ids, eight
+      // consecutive workgroups per cluster, measured 1.6 us slower per update.  The price: a launch cut in the
+      // middle of this role leaves every slice with half its members resident and spinning, so wide clusters
+      // are for learners that do not share the chip with several others — learner.hip's rule)
+      role = 0; member = y - yb;
+    }
+    else { role = role_c; member = y - yb - nA; }
+  }
+  const int row0 = slice * kR;
+  Tp tp{member, role == 0 ? nA : A.nc,
+        A.xbuf + ((size_t)role * gridDim.x + slice) * kTpStages * A.xnc * kTpBlk, A.cluster_tag, 0,
         A.err, KERN_PHASE1 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
   const bool lead = tp.c == 0;                 // member 0 does the un-sliced global stores
   int n_stamp = 0;
@@ -332,7 +353,7 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A) {
   // returns q2' — the two target passes run side by side instead of back to back.  Exchange slots:
   // the never-used last stage of the receiving role's cluster area.
   auto x_slot = [&](int to_role) {   // (formed only on the twin_split paths)
-    return A.xbuf + (((size_t)to_role * gridDim.x + slice) * kTpStages + (kTpStages - 1)) * A.nc * kTpBlk;
+    return A.xbuf + (((size_t)to_role * gridDim.x + slice) * kTpStages + (kTpStages - 1)) * A.xnc * kTpBlk;
   };
   const unsigned x_tag = (A.cluster_tag << 6) | 62u;
 
@@ -372,7 +393,7 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A) {
     // ---- role A: a' = tanh(actor_target(s')) (TD3: + clipped noise), q' = critic_target(s', a')
     // (TD3: min over the twin targets), TD target                    (ddpg.py:94-95, td3.py:83-101)
     // (SAC: a' ~ pi(s') from the online actor, log pi(a'|s') kept per row     sac.py:90-97)
-    tp_fwd<WIDTH, LEAN, P>(SAC ? A.actor : A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
+    tp_fwd<WIDTH, LEAN, P, NMA>(SAC ? A.actor : A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
     const bool send_a2 = A.twin_split && lead;
     unsigned long long* x_a2 = send_a2 ? x_slot(role_c) : nullptr;
     if constexpr (SAC)
@@ -408,12 +429,12 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A) {
         }
       }
     };
-    tp_fwd<WIDTH, LEAN, P>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, hook);
+    tp_fwd<WIDTH, LEAN, P, NMA>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, hook);
     float qn = (tid < kR) ? outS[tid * kOutLd] : 0.f;
     if (A.twin_split) {
       if (lead && tid < kR) qn = fminf(qn, granule_get(x_slot(0) + tid, x_tag, A.err, (KERN_PHASE1 << 8) | SITE_TWIN_SPLIT));
     } else if (A.n_critics == 2) {
-      tp_fwd<WIDTH, LEAN, P>(A.critic2_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
+      tp_fwd<WIDTH, LEAN, P, NMA>(A.critic2_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
       if (tid < kR) qn = fminf(qn, outS[tid * kOutLd]);
     }
     if constexpr (SAC) {
@@ -480,8 +501,8 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A) {
   role_b<WIDTH, LEAN, P>(A, A.critic, A.cX, A.cdY, A.partials_c, true, 0, smem, tp, stamp);
 }
 
-template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32>
-__global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) { ddpg_phase1_body<WIDTH, LEAN, SAC, P>(A); }
+template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32, bool WIDE = false>
+__global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) { ddpg_phase1_body<WIDTH, LEAN, SAC, P, WIDE>(A); }
 
 // N independent learners in ONE launch (grid.z = learner): the argument blocks live in device memory (N x 1.7 KB
 // does not fit the kernel-argument segment), every field read is a scalar load through one uniform pointer.
@@ -490,7 +511,11 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1_group(const DdpgArgs* 
   ddpg_phase1_body<WIDTH, LEAN, SAC, P>(batch[blockIdx.z]);
 }
 
-template <int WIDTH, bool LEAN, bool SAC, class P>
+// WIDE (DDPG / TD3, fp32 lean passes): the critic's forward + backward pass — two thirds of this kernel, on a
+// launch that leaves most of the chip idle — runs on clusters of EIGHT CUs (tp4_scalar_fb<P, 8>: no dz1
+// partials leave it); members 4..7 are done after it, members 0..3 go on to the actor's backward (clusters of 4,
+// no exchange), so the actor's dW launch still sums four partial buffers.
+template <int WIDTH, bool LEAN, bool SAC, class P, bool WIDE = false>
 __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<WIDTH>;
@@ -505,12 +530,17 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A) {
   float* auxS = smem + LY::aux;
   float* scr = smem + LY::scr;
   float* piS = smem + LY::xb;        // [kR][kX0Ld] tile reused for pi
-  const int slice = blockIdx.x, row0 = slice * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
+  const int B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
+  const int slice = blockIdx.x;
+  const int row0 = slice * kR;
   // SAC with p2_pair: two clusters per slice, one per online critic (g = 0 / 1), side by side
+  static_assert(!(WIDE && SAC), "SAC's phase 2 runs its twin critics on two clusters of 4");
+  constexpr int NMC = (LEAN && WIDE) ? 8 : 4;          // members of the critic pass's clusters (lean passes)
+  const int ncl = (LEAN && WIDE) ? 8 : A.nc;           // rows of the grid per cluster
   const int n_clus = SAC ? 1 + A.p2_pair : 1;
-  const int g = (SAC && (int)blockIdx.y < n_clus * A.nc) ? (int)blockIdx.y / A.nc : 0;
-  Tp tp{(int)blockIdx.y - g * A.nc, A.nc,
-        A.xbuf + ((size_t)g * gridDim.x + slice) * kTpStages * A.nc * kTpBlk, A.cluster_tag, 0,
+  const int g = (SAC && (int)blockIdx.y < n_clus * ncl) ? (int)blockIdx.y / ncl : 0;
+  Tp tp{(int)blockIdx.y - g * ncl, ncl,
+        A.xbuf + ((size_t)g * gridDim.x + slice) * kTpStages * A.xnc * kTpBlk, A.cluster_tag, 0,
         A.err, KERN_PHASE2 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
   const bool lead = tp.c == 0;
   int n_stamp = 0;
@@ -523,7 +553,7 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A) {
     }
     ++n_stamp;
   };
-  if ((int)blockIdx.y == n_clus * A.nc) {
+  if ((int)blockIdx.y == n_clus * ncl) {
     // ---- prefetch row: gather the next update's rows (same draw as load_batch will not have
     // to make) and leave them contiguous for phase 1 of the next step
     float* xb = smem + LY::xb;
@@ -557,7 +587,7 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A) {
     // row are five load -> wait -> store sequences for the threads that take part in all of them
     constexpr int K4 = WIDTH / 4;                        // float4 per activation row
     const int r4 = tid / K4, c4 = (tid - r4 * K4) * 4;    // kR * K4 == kThreads for WIDTH 256
-    const bool ok4 = row0 + r4 < B && g == 0;              // (the twin critic's cluster needs only [s | pi])
+    const bool ok4 = row0 + r4 < B && g == 0 && tp.c < 4;  // (the twin critic's cluster, and members 4..7 of a wide one, need only [s | pi])
     f32x4 v1 = f32x4{0.f, 0.f, 0.f, 0.f}, v2 = v1;
     if (ok4) {
       v1 = ld4(A.aX[1] + (size_t)(row0 + r4) * WIDTH + c4);
@@ -610,7 +640,7 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A) {
     if (A.p2_pair) {
       // one granule per (row, action dim | q) from the lead member of cluster 1 to every member of
       // cluster 0, in the exchange area of the unused role slot 2, tagged with the launch's tag
-      unsigned long long* xq = A.xbuf + ((size_t)2 * gridDim.x + slice) * kTpStages * A.nc * kTpBlk + tid;
+      unsigned long long* xq = A.xbuf + ((size_t)2 * gridDim.x + slice) * kTpStages * A.xnc * kTpBlk + tid;
       const unsigned tag = (A.cluster_tag << 6) | 63u;
       const int xr = tid / (Ad + 1), xc = tid - xr * (Ad + 1);
       const bool xmine = tid < kR * (Ad + 1);
@@ -684,7 +714,11 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A) {
       qsum = A.partials_a + slice * 4 + 1;
       if (tid == 0) { A.partials_a[slice * 4 + 0] = 0.f; A.partials_a[slice * 4 + 2] = 0.f; }
     }
-    tp4_scalar_fb<P>(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum);
+    tp4_scalar_fb<P, NMC>(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum);
+    if constexpr (WIDE) {
+      if (tp.c >= 4) return;        // the actor's backward is a cluster of four
+      tp.nc = 4;
+    }
   } else {
     tp_fwd<WIDTH, LEAN, P>(A.critic, xa, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
     stamp();
@@ -740,8 +774,8 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A) {
   stamp();
 }
 
-template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32>
-__global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) { ddpg_phase2_body<WIDTH, LEAN, SAC, P>(A); }
+template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32, bool WIDE = false>
+__global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) { ddpg_phase2_body<WIDTH, LEAN, SAC, P, WIDE>(A); }
 
 template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase2_group(const DdpgArgs* __restrict__ batch) {
@@ -766,8 +800,10 @@ hipError_t init_fused_attrs() {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
   }
-  const void* kg[2] = {reinterpret_cast<const void*>(&k_ddpg_phase1_group<256, false, false>),
-                       reinterpret_cast<const void*>(&k_ddpg_phase2_group<256, false, false>)};
+  const void* kg[4] = {reinterpret_cast<const void*>(&k_ddpg_phase1_group<256, false, false>),
+                       reinterpret_cast<const void*>(&k_ddpg_phase2_group<256, false, false>),
+                       reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, false, PrecF32, true>),
+                       reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false, PrecF32, true>)};
   for (const void* k : kg) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -802,6 +838,12 @@ bool fused_ddpg_is_lean(const DdpgArgs& a) {
 
 hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
+  if ((a.wide & 1) != 0) {      // role A on clusters of 8 (DDPG, fp32 lean passes; learner.hip decides)
+    if (!lean_ok(a) || a.sac || a.bf16 || a.n_critics != 1 || a.xnc < 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_ddpg_phase1<256, true, false, PrecF32, true>), dim3(slices, a.nc + 8 + a.nc), dim3(kThreads),
+                       fused_ddpg_lds_bytes(), st, a);
+    return hipGetLastError();
+  }
   const dim3 grid(slices, (2 + a.n_critics) * a.nc);
   if (a.bf16) {
     // the bf16 MFMA mode exists for the lean passes only; the nets' pf / pb point at bf16 packs
@@ -822,6 +864,12 @@ hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st) {
 hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
   // SAC side by side: one cluster per online critic; + the next-minibatch gather row
+  if ((a.wide & 2) != 0) {      // the critic pass on clusters of 8 (DDPG / TD3, fp32 lean passes)
+    if (!lean_ok(a) || a.sac || a.bf16 || a.xnc < 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_ddpg_phase2<256, true, false, PrecF32, true>), dim3(slices, 8 + (a.prefetch_next ? 1 : 0)),
+                       dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+    return hipGetLastError();
+  }
   const dim3 grid(slices, a.nc * ((a.sac && a.p2_pair) ? 2 : 1) + (a.prefetch_next ? 1 : 0));
   if (a.bf16) {
     if (!lean_ok(a)) return hipErrorInvalidValue;

@@ -270,6 +270,8 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   unsigned epoch;                      // monotonically increasing per update, never 0
   int bf16;                            // 1: the nets' pf / pb are bf16 packs and the lean passes run PrecBF16 (engine.h)
   int nc;                              // CUs per slice cluster (tensor-parallel, csrc/tp3.h): 1, 2 or 4
+  int xnc;                             // members an exchange area of `xbuf` is laid out for (>= nc; 8 when wide clusters may run)
+  int wide;                            // bit 0: phase 1's role A, bit 1: phase 2's critic pass on clusters of EIGHT (fp32 lean passes)
   int no_lean;                         // 1: never use the tp4.h specialisation (OPRL_AMD_NO_LEAN, tests)
   unsigned long long* xbuf;            // cluster exchange areas: [role][slice][kTpStages][nc][kTpBlk] granules
   unsigned cluster_tag;                // launch-unique

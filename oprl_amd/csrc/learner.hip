@@ -386,6 +386,8 @@ struct oprl_learner {
   int ncl = 1;                 // CUs per slice cluster in the fused path (csrc/tp3.h)
   int n_cus = 256;
   int no_lean = 0;
+  int no_wide = 0;             // OPRL_AMD_NO_WIDE: never run role A / phase 2's critic pass on clusters of eight
+  int xnc = kMaxCluster;       // members an exchange area of xbuf is laid out for
   unsigned long long* xbuf = nullptr;
   size_t xbuf_granules = 0;
   // Largest cluster size for which ONE role's clusters (c x slices workgroups, one per CU) fit on the
@@ -825,6 +827,22 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
       a.critic2 = net_view16(c.critics[1], false, h->pack16[2]);
       a.critic2_t = net_view16(c.critics[1], true, h->pack16_t[2]);
     }
+  }
+  // clusters of EIGHT for role A (DDPG: the roles then fill the chip exactly at B = 256) and for phase 2's
+  // critic pass (DDPG / TD3), while the launch still fits the chip; exact-fp32 lean passes only
+  // A property of the LEARNER (oprl_learner_set_cluster(h, 8) = the default / (h, 4) = never), not of the
+  // moment: results differ in the last bits between cluster sizes (summation order of the exchanges).  A wide
+  // launch wants the whole chip; FOUR such launches each cut in the middle of role A (64 members resident, 64
+  // waiting for a CU) fill it with workgroups that spin for each other — measured with eight learners on eight
+  // streams: every wait ran into its bound and was reported.  Learners that share a GPU with more than two
+  // others (packed seeds on streams, one process per seed on one GPU) turn it off: set_cluster(h, 4) or
+  // OPRL_AMD_NO_WIDE=1; up to three cannot dead-lock (the B roles always finish and free their CUs).
+  a.xnc = h->xnc;
+  a.wide = 0;
+  if (h->xnc >= 8 && !h->no_wide && !a.sac && !a.bf16 && a.A <= 8 && fused_ddpg_is_lean(a)) {   // (narrow exchanges: <= 8 action columns)
+    const int slices = (B + kR - 1) / kR;
+    if (h->nc == 1 && (a.nc + 8 + a.nc) * slices <= h->n_cus) a.wide |= 1;
+    if ((8 + 1) * slices <= h->n_cus) a.wide |= 2;
   }
   return a;
 }
@@ -1655,6 +1673,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->no_p2_pair = (np2 != nullptr && atoi(np2) != 0);
     const char* nl = getenv("OPRL_AMD_NO_LEAN");
     h->no_lean = (nl != nullptr && atoi(nl) != 0) ? 1 : 0;
+    const char* nw = getenv("OPRL_AMD_NO_WIDE");
+    h->no_wide = (nw != nullptr && atoi(nw) != 0) ? 1 : 0;
     // the generic per-net launches on clusters of 4 (slice_tp.hip): any net of the common shape
     const char* ng = getenv("OPRL_AMD_NO_TP_GENERIC");
     // (decided per net by tp_generic(): TQC's 512-wide critics stay on k_mlp_slice, its actor moves)
@@ -1662,7 +1682,10 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   }
   if (h->fused || h->tp_generic_on) {
     const size_t slices = (size_t)(h->Bmax + kR - 1) / kR;
-    h->xbuf_granules = (size_t)(2 + nc) * slices * fused_xbuf_granules_per_cluster(kMaxCluster);
+    // (areas laid out for clusters of eight where wide clusters may run: DDPG / TD3, fp32, lean passes)
+    h->xnc = (h->fused && !h->bf16 && !h->no_lean && !h->no_wide && h->ncl == 4 &&
+              (cfg->algo == OPRL_DDPG || cfg->algo == OPRL_TD3)) ? 8 : kMaxCluster;
+    h->xbuf_granules = (size_t)(2 + nc) * slices * fused_xbuf_granules_per_cluster(h->xnc);
     if (hipMalloc(&h->xbuf, h->xbuf_granules * sizeof(unsigned long long)) != hipSuccess) {
       set_err("hipMalloc(cluster exchange area, %zu MB) failed", (h->xbuf_granules * 8) >> 20);
       (void)hipFree(p.base); delete h; return OPRL_ERR_NOMEM;
@@ -1900,8 +1923,11 @@ extern "C" int oprl_group_destroy(oprl_group* g) {
 }
 
 extern "C" int oprl_learner_set_cluster(oprl_learner* h, int32_t nc) {
-  if (!h || (nc != 1 && nc != 2 && nc != 4)) { set_err("oprl_learner_set_cluster: cluster size must be 1, 2 or 4"); return OPRL_ERR_INVALID; }
-  h->ncl = nc;
+  if (!h || (nc != 1 && nc != 2 && nc != 4 && nc != 8)) { set_err("oprl_learner_set_cluster: cluster size must be 1, 2, 4 or 8"); return OPRL_ERR_INVALID; }
+  // 8 = clusters of four, and of eight where the fused kernels have them (the default); 4 = never eight
+  h->ncl = nc == 8 ? 4 : nc;
+  static const bool env_off = [] { const char* e = getenv("OPRL_AMD_NO_WIDE"); return e != nullptr && atoi(e) != 0; }();
+  h->no_wide = (nc == 8 && !env_off) ? 0 : 1;
   return OPRL_OK;
 }
 

@@ -45,6 +45,33 @@ template <class P> struct Tp4Steps {
   static constexpr int O = (kNarrowMax + P::KS - 1) / P::KS;   // widest output: 3 / 2
 };
 
+// The cluster size NM (members per slice) is a template parameter of the forward passes: 4 (the default; the
+// backward and every dz1-partial producer) or 8 (forward / scalar-critic passes of workgroups that would
+// otherwise idle: DDPG's role A and phase 2).  A member then owns TPM 16-column tiles of the hidden layer and
+// takes in (and multiplies) 1 / NM of the 256 x 256 layer; layer 0 stays replicated.
+template <class P, int NM> struct Tp4Shape {
+  static_assert(NM == 4 || NM == 8, "cluster sizes of the lean passes");
+  static constexpr int TPM = 16 / NM;                    // 16-column tiles per member: 4 / 2
+  static constexpr int COLS = 16 * TPM;                  // hidden columns per member: 64 / 32
+  static constexpr int KP = 16 / TPM;                    // layer 1: waves (contraction parts) per tile: 4 / 8
+  static constexpr int NQ = Tp4Steps<P>::W / KP;         // macro steps of one part
+  static constexpr int KW = kW4 / KP;                    // floats of one part: 64 / 32
+  static constexpr int M = COLS / P::KS;                 // macro steps over the member's columns
+  static_assert(NQ >= 1 && M >= 1, "bf16 macro steps are 32 wide: clusters of 8 need the fp32 policy");
+};
+
+// sum over N macro steps, even steps on one accumulator and odd ones on another (two independent MFMA chains)
+template <class P, int N>
+__device__ __forceinline__ f32x4 tp4_mac_steps(const float* xr, const f32x4 (&w)[N]) {
+  f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+  for (int s = 0; s < N; ++s) {
+    if (s & 1) P::mac(xr, s, w[s], a1);
+    else P::mac(xr, s, w[s], a0);
+  }
+  return a0 + a1;
+}
+
 __host__ __device__ inline bool tp4_shape_ok(int width, int fan_in, int n_out) {
   return width == kW4 && fan_in <= 16 * kMaxS0 && n_out <= kNarrowMax;
 }
@@ -55,54 +82,125 @@ __device__ __forceinline__ void mac4(const f32x4 a, const f32x4 b, f32x4& acc) {
 }
 
 // All-reduce of one 16x16 tile held in MFMA accumulator layout (lane (kk,i): rows 4kk..4kk+3,
-// column i) over the 4 members; `valid` lanes take part, `col` (< kNarrowMax, distinct per
+// column i) over the NM members; `valid` lanes take part, `col` (< kNarrowMax, distinct per
 // valid (tile, i)) names the lane's column.  Returns sum over members in member order.
 // Granule slot of (row = 4kk + r, col): ((r*4 + kk) * kNarrowMax + col)  (< kTpBlk).
+template <int NM = 4>
 __device__ __forceinline__ f32x4 tp4_allreduce_regs(const f32x4 mine, int col, bool valid, const Tp& tp) {
   const int kk = (threadIdx.x & 63) >> 4;
   constexpr int kRs = 4 * kNarrowMax;   // granules between two r
   const unsigned tag = (tp.tag << 6) | (unsigned)(tp.stage & 63);
-  unsigned long long* slot = tp.xbuf + (size_t)tp.stage * 4 * kTpBlk + (valid ? kk * kNarrowMax + col : 0);
-  f32x4 v[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) v[m] = mine;
+  unsigned long long* slot = tp.xbuf + (size_t)tp.stage * NM * kTpBlk + (valid ? kk * kNarrowMax + col : 0);
+  f32x4 sum = mine;
   if (valid) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       __hip_atomic_store(slot + (size_t)tp.c * kTpBlk + r * kRs,
                          ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(mine[r]),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // all peers' granules are requested together (one round trip per poll), then checked; the values are
+    // summed straight from the granules in member order (this member's own term from its registers)
     bool ok = false;
+    unsigned long long x[NM][4];
     for (int spin = 0; spin < tp.spin && !ok; ++spin) {
-      unsigned long long x[4][4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < NM; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          x[m][r] = (m == tp.c) ? 0ull
+          x[m][r] = (m == tp.c) ? ((unsigned long long)tag << 32)
                                 : __hip_atomic_load(slot + (size_t)m * kTpBlk + r * kRs, __ATOMIC_RELAXED,
                                                     __HIP_MEMORY_SCOPE_AGENT);
       ok = true;
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < NM; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (m != tp.c) {
-            ok = ok && (unsigned)(x[m][r] >> 32) == tag;
-            v[m][r] = __uint_as_float((unsigned)x[m][r]);
-          }
+        for (int r = 0; r < 4; ++r) ok = ok && (unsigned)(x[m][r] >> 32) == tag;
       if (!ok) __builtin_amdgcn_s_sleep(1);
     }
-    if (!ok) {
+    if (ok) {
+      sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] += (m == tp.c) ? mine[r] : __uint_as_float((unsigned)x[m][r]);
+    } else {
       report_expired(tp.err, tp.err_code | SITE_CLUSTER);
       const float nan = __builtin_nanf("");
-      v[0] = f32x4{nan, nan, nan, nan};
+      sum = f32x4{nan, nan, nan, nan};
     }
   }
-  f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int m = 0; m < 4; ++m) sum += v[m];
   return sum;
+}
+
+// The same all-reduce for NARROW tiles (<= 8 valid columns: a critic's q, an action-sized output or input
+// gradient) with one ELEMENT per lane slot instead of four rows per lane: the tile goes through 1 KB of
+// wave-private LDS, lane L takes elements L and L + 64 of the 16 x ncols valid block — at most two granules per
+// peer and lane, so that a cluster of eight needs no more registers than a cluster of four does above.  Valid
+// columns = lanes i in [i_first, i_first + ncols); they are exchanged as columns cc_first .. of the granule block
+// and written to out[row * kOutLd + cc_first + k] (+ bias[k], nullable).  Same slots as tp4_allreduce_regs.
+// (tp4_narrow_elem: the k-th valid column of lane slot j — what the caller needs to fetch a per-column bias EARLY.)
+__device__ __forceinline__ int tp4_narrow_elem(int j, int ncols) {
+  const int e = (int)(threadIdx.x & 63) + 64 * j;
+  return e < 16 * ncols ? e % ncols : -1;
+}
+template <int NM>
+__device__ __forceinline__ void tp4_allreduce_narrow(const f32x4 mine, int i_first, int ncols, int cc_first,
+                                                     float* wscr, float b0, float b1, float* out, const Tp& tp) {
+  const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
+  constexpr int kRs = 4 * kNarrowMax;
+  const unsigned tag = (tp.tag << 6) | (unsigned)(tp.stage & 63);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) wscr[(4 * kk + r) * 16 + i] = mine[r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int n = 16 * ncols;                     // <= 128
+  unsigned long long* base = tp.xbuf + (size_t)tp.stage * NM * kTpBlk;
+  float val[2];
+  const float bv[2] = {b0, b1};
+  int off[2], oidx[2];
+  bool have[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = lane + 64 * j;
+    have[j] = e < n;
+    const int row = have[j] ? e / ncols : 0, k = have[j] ? e - row * ncols : 0;
+    val[j] = wscr[row * 16 + i_first + k];
+    off[j] = ((row & 3) * 4 + (row >> 2)) * kNarrowMax + cc_first + k;     // (r * 4 + kk) * kNarrowMax + col
+    oidx[j] = row * kOutLd + cc_first + k;
+    if (have[j])
+      __hip_atomic_store(base + (size_t)tp.c * kTpBlk + off[j],
+                         ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(val[j]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  (void)kRs;
+  if (have[0]) {
+    bool ok = false;
+    unsigned long long x[NM][2];
+    for (int spin = 0; spin < tp.spin && !ok; ++spin) {
+#pragma unroll
+      for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          x[m][j] = (m == tp.c || !have[j]) ? ((unsigned long long)tag << 32)
+                                            : __hip_atomic_load(base + (size_t)m * kTpBlk + off[j], __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+      ok = true;
+#pragma unroll
+      for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ok = ok && (unsigned)(x[m][j] >> 32) == tag;
+      if (!ok) __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) report_expired(tp.err, tp.err_code | SITE_CLUSTER);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float sum = 0.f;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) sum += (m == tp.c) ? val[j] : __uint_as_float((unsigned)x[m][j]);
+      if (have[j]) out[oidx[j]] = ok ? sum + bv[j] : __builtin_nanf("");
+    }
+  }
 }
 
 // This member's dz1 partial (the whole [16 x 256] tile in h1) -> its partial buffer, for k_dw_adam.
@@ -129,27 +227,29 @@ __device__ __forceinline__ void tp4_store_dz1(const Tp3Store& st, int c, const f
 // wave-id branch — hipcc's wait-count pass could not tell how many younger loads follow the layer-0
 // fragments, so layer 0 waited for ALL of the pass's fragments (s_waitcnt vmcnt(1)).  With uniform,
 // unconditional requests layer 0 starts as soon as ITS fragments are in.
-template <class P = PrecF32, class ST = NoStamp>
+template <class P = PrecF32, int NM = 4, class ST = NoStamp>
 __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, float* h1, float* h2,
                                             float* outS, float* scr, Tp& tp, const Tp3Store& st, int row0, int B,
                                             ST sf = ST()) {
   using NS = Tp4Steps<P>;
+  using SH = Tp4Shape<P, NM>;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
-  const int c = tp.c, c0 = c * kCols4;
+  const int c = tp.c, c0 = c * SH::COLS;
   const int N = net.dims[3];
   const int NS0 = (net.dims[0] + P::KS - 1) / P::KS, NTo = (N + 15) >> 4;
   const int t2 = wave - 4;                    // output tile of waves 4..4+NTo-1
   const bool l2_wave = t2 >= 0 && t2 < NTo;
 
-  constexpr int NQ = NS::W / 4;               // macro steps of one quarter of layer 1's contraction
-  const int t1 = wave & 3, kq = wave >> 2;    // layer 1: this wave's tile of the member and contraction quarter
-  // the layer-1 element this thread finishes: tile rt, accumulator slot (rl, rr) = row 4 (rl >> 4) + rr, column rl & 15
+  constexpr int NQ = SH::NQ;                  // macro steps of one part of layer 1's contraction
+  const int t1 = wave % SH::TPM, kq = wave / SH::TPM;   // layer 1: this wave's tile of the member and contraction part
+  // the layer-1 element this thread finishes (threads < 256 TPM): tile rt, accumulator slot (rl, rr) = row 4 (rl >> 4) + rr, column rl & 15
   const int rt = (int)threadIdx.x >> 8, rl = ((int)threadIdx.x & 255) >> 2, rr = (int)threadIdx.x & 3;
+  const bool r_mine = rt < SH::TPM;
 
   // ---- requests for the whole pass (uniform over the waves but for the few output-layer fragments)
-  f32x4 w0[NS::S0], w1[NQ], w2[NS::M];
+  f32x4 w0[NS::S0], w1[NQ], w2[SH::M];
   {
     const float* p0 = net.pf[0] + ((size_t)wave * NS0 * 64 + lane) * 4;
 #pragma unroll
@@ -157,19 +257,26 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
   }
   const float bias0 = net.b[0][16 * wave + i];
   {
-    const float* p1 = net.pf[1] + (((size_t)(c * kTpc4 + t1) * NS::W + kq * NQ) * 64 + lane) * 4;
+    const float* p1 = net.pf[1] + (((size_t)(c * SH::TPM + t1) * NS::W + kq * NQ) * 64 + lane) * 4;
 #pragma unroll
     for (int s = 0; s < NQ; ++s) w1[s] = ld4(p1 + s * 256);
   }
-  const float bias1 = net.b[1][c0 + 16 * rt + (rl & 15)];
-  float bias2 = 0.f;
+  const float bias1 = net.b[1][c0 + 16 * (r_mine ? rt : 0) + (rl & 15)];
+  float bias2 = 0.f, bias2e[2] = {0.f, 0.f};   // output bias: of this lane's column / of its narrow-exchange elements
 #pragma unroll
-  for (int s = 0; s < NS::M; ++s) w2[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < SH::M; ++s) w2[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (l2_wave) {
-    const float* p2 = net.pf[2] + (((size_t)t2 * NS::W + c * NS::M) * 64 + lane) * 4;
+    const float* p2 = net.pf[2] + (((size_t)t2 * NS::W + c * SH::M) * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < NS::M; ++s) w2[s] = ld4(p2 + s * 256);
+    for (int s = 0; s < SH::M; ++s) w2[s] = ld4(p2 + s * 256);
     if (16 * t2 + i < N) bias2 = net.b[2][16 * t2 + i];
+    if constexpr (NM == 8) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int k = tp4_narrow_elem(j, N);
+        if (k >= 0) bias2e[j] = net.b[2][k];
+      }
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();   // x0 visible
@@ -188,48 +295,47 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
   sf();
   __syncthreads();   // h1 visible
 
-  // ---- L1: every wave a quarter of one tile's contraction -> scr; member 0's threads store h1 for the dW kernel
-  {
-    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
-    const float* hr = h1 + i * kWL4 + 64 * kq + 4 * kk;
-#pragma unroll
-    for (int s = 0; s < NQ; s += 2) {
-      P::mac(hr, s, w1[s], a0);
-      P::mac(hr, s + 1, w1[s + 1], a1);
-    }
-    *reinterpret_cast<f32x4*>(scr + ((size_t)wave * 64 + lane) * 4) = a0 + a1;
-  }
+  // ---- L1: every wave one part of one tile's contraction -> scr; member 0's threads store h1 for the dW kernel
+  *reinterpret_cast<f32x4*>(scr + ((size_t)wave * 64 + lane) * 4) =
+      tp4_mac_steps<P, NQ>(h1 + i * kWL4 + SH::KW * kq + 4 * kk, w1);
   if (st.X1 != nullptr && c == 0) {
     const int row = (int)threadIdx.x >> 6, col = ((int)threadIdx.x & 63) * 4, gr = row0 + row;     // 16 rows x 64 float4
     if (gr < B) *reinterpret_cast<f32x4*>(st.X1 + (size_t)gr * kW4 + col) = ld4(h1 + row * kWL4 + col);
   }
   sf();
   __syncthreads();   // partial tiles visible
-  {
-    const float* sp = scr + ((size_t)rt * 64 + rl) * 4 + rr;      // wave (quarter q, tile rt) = 4 q + rt
-    const float v = ((sp[0] + sp[4 * 256]) + sp[8 * 256]) + sp[12 * 256];
+  if (r_mine) {
+    const float* sp = scr + ((size_t)rt * 64 + rl) * 4 + rr;      // wave (part q, tile rt) = TPM q + rt
+    float v = sp[0];
+#pragma unroll
+    for (int q = 1; q < SH::KP; ++q) v += sp[q * SH::TPM * 256];
     h2[(4 * (rl >> 4) + rr) * kWL4 + c0 + 16 * rt + (rl & 15)] = fmaxf(v + bias1, 0.f);
   }
   __syncthreads();   // the member's h2 columns visible
 
-  // ---- L2 partial + all-reduce from registers on waves 4..; waves 8..11 store the h2 columns
+  // ---- L2 partial + all-reduce from registers on waves 4..; waves 8.. store the h2 columns
   if (l2_wave) {
-    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
-    const float* hr = h2 + i * kWL4 + c0 + 4 * kk;
-#pragma unroll
-    for (int s = 0; s < NS::M; s += 2) {
-      P::mac(hr, s, w2[s], a0);
-      P::mac(hr, s + 1, w2[s + 1], a1);
-    }
+    const f32x4 part = tp4_mac_steps<P, SH::M>(h2 + i * kWL4 + c0 + 4 * kk, w2);
     const int col = 16 * t2 + i;
     const bool valid = col < N;
-    const f32x4 sum = tp4_allreduce_regs(a0 + a1, col, valid, tp);
     float* o = outS + (kk * 4) * kOutLd + col;
+    if constexpr (NM == 8) {
+      // clusters of eight serve outputs of at most 8 columns (one tile, this wave): padding columns zeroed
+      // here, the valid ones written by the narrow exchange
+      if (!valid) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r * kOutLd] = valid ? sum[r] + bias2 : 0.f;
-  } else if (st.X2 != nullptr && wave >= 8 && wave < 12) {
-    const int idx = (int)threadIdx.x - 512;          // 16 rows x 16 float4
-    const int row = idx >> 4, col = c0 + (idx & 15) * 4, gr = row0 + row;
+        for (int r = 0; r < 4; ++r) o[r * kOutLd] = 0.f;
+      }
+      tp4_allreduce_narrow<NM>(part, 0, N, 0, scr + wave * 256, bias2e[0], bias2e[1], outS, tp);
+    } else {
+      const f32x4 sum = tp4_allreduce_regs<NM>(part, col, valid, tp);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r * kOutLd] = valid ? sum[r] + bias2 : 0.f;
+    }
+  } else if (st.X2 != nullptr && wave >= 8 && wave < 8 + SH::TPM) {
+    constexpr int C4 = SH::COLS / 4;                 // float4 per row of the member's columns
+    const int idx = (int)threadIdx.x - 512;          // 16 rows x C4 float4
+    const int row = idx / C4, col = c0 + (idx - row * C4) * 4, gr = row0 + row;
     if (gr < B) *reinterpret_cast<f32x4*>(st.X2 + (size_t)gr * kW4 + col) = ld4(h2 + row * kWL4 + col);
   }
   tp.stage += 1;
@@ -370,7 +476,7 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
 //         [quarters] gather + all-reduce -> dactS            (if wanted)
 // g2: one more [kR][kWL4] LDS buffer.  tp.stage advances by 1 (2 with dact).
 // ---------------------------------------------------------------------------------------
-template <class P = PrecF32, class ST = NoStamp>
+template <class P = PrecF32, int NM = 4, class ST = NoStamp>
 __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, float* h1, float* h2,
                                               float* g2, float* outS, float* scr, Tp& tp,
                                               const Tp3Store& st, int row0, int B, float seed,
@@ -381,8 +487,9 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
-  const int c = tp.c, c0 = c * kCols4;
   using NS = Tp4Steps<P>;
+  using SH = Tp4Shape<P, NM>;
+  const int c = tp.c, c0 = c * SH::COLS;
   const int NS0 = (net.dims[0] + P::KS - 1) / P::KS;   // layer-0 steps
   const bool dact = dact_cols > 0;
   const int dt0 = dact_col0 >> 4, dnt = dact ? ((dact_col0 + dact_cols - 1) >> 4) - dt0 + 1 : 0;
@@ -390,12 +497,14 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   const bool dact_wave = dact && dt < dnt;
   constexpr int kOutWave = 12;
 
-  constexpr int NQ = NS::W / 4;               // layer 1 as in tp4_forward: wave = (tile, contraction quarter)
-  const int t1 = wave & 3, kq = wave >> 2;
+  constexpr int NQ = SH::NQ;                  // layer 1 as in tp4_forward: wave = (tile, contraction part)
+  constexpr int Q4 = NS::W / 4;               // macro steps of a QUARTER of a 256-deep contraction (the input-column gradient)
+  const int t1 = wave % SH::TPM, kq = wave / SH::TPM;
   const int rt = (int)threadIdx.x >> 8, rl = ((int)threadIdx.x & 255) >> 2, rr = (int)threadIdx.x & 3;
+  const bool r_mine = rt < SH::TPM;
 
   // ---- requests
-  f32x4 w0[NS::S0], w1[NQ], w2[NS::M], wz[NS::M], wd[NS::M];
+  f32x4 w0[NS::S0], w1[NQ], w2[SH::M], wz[SH::M], wd[Q4];
   {
     const float* p0 = net.pf[0] + ((size_t)wave * NS0 * 64 + lane) * 4;
 #pragma unroll
@@ -403,20 +512,20 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   }
   const float bias0 = net.b[0][16 * wave + i];
   {
-    const float* p1 = net.pf[1] + (((size_t)(c * kTpc4 + t1) * NS::W + kq * NQ) * 64 + lane) * 4;
+    const float* p1 = net.pf[1] + (((size_t)(c * SH::TPM + t1) * NS::W + kq * NQ) * 64 + lane) * 4;
 #pragma unroll
     for (int s = 0; s < NQ; ++s) w1[s] = ld4(p1 + s * 256);
   }
-  const float bias1 = net.b[1][c0 + 16 * rt + (rl & 15)];
-  const float w3 = P::first(net.pb[2] + ((size_t)(c * kTpc4 + rt) * 64 + (rl & 15)) * 4);   // W3[c0 + 16 rt + col]  (one step)
+  const float bias1 = net.b[1][c0 + 16 * (r_mine ? rt : 0) + (rl & 15)];
+  const float w3 = P::first(net.pb[2] + ((size_t)(c * SH::TPM + (r_mine ? rt : 0)) * 64 + (rl & 15)) * 4);   // W3[c0 + 16 rt + col]  (one step)
   float bias2 = 0.f;
 #pragma unroll
-  for (int s = 0; s < NS::M; ++s) w2[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < SH::M; ++s) w2[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (wave == kOutWave) {
-    const float* p2 = net.pf[2] + (((size_t)c * NS::M) * 64 + lane) * 4;
+    const float* p2 = net.pf[2] + (((size_t)c * SH::M) * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < NS::M; ++s) w2[s] = ld4(p2 + s * 256);
-    if (i == 0) bias2 = net.b[2][0];
+    for (int s = 0; s < SH::M; ++s) w2[s] = ld4(p2 + s * 256);
+    if (i == 0 || NM == 8) bias2 = net.b[2][0];
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();   // x0 visible
@@ -433,66 +542,56 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
     for (int r = 0; r < 4; ++r) o[r * kWL4] = fmaxf(acc[r] + bias0, 0.f);
   }
   {
-    const float* q1 = net.pb[1] + (((size_t)wave * NS::W + c * NS::M) * 64 + lane) * 4;
+    const float* q1 = net.pb[1] + (((size_t)wave * NS::W + c * SH::M) * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < NS::M; ++s) wz[s] = ld4(q1 + s * 256);
+    for (int s = 0; s < SH::M; ++s) wz[s] = ld4(q1 + s * 256);
   }
   sf();
   __syncthreads();   // h1 visible
 
   // ---- L1 (every wave a quarter of one tile's contraction -> scr); member 0's threads store h1
-  {
-    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
-    const float* hr = h1 + i * kWL4 + 64 * kq + 4 * kk;
-#pragma unroll
-    for (int s = 0; s < NQ; s += 2) {
-      P::mac(hr, s, w1[s], a0);
-      P::mac(hr, s + 1, w1[s + 1], a1);
-    }
-    *reinterpret_cast<f32x4*>(scr + ((size_t)wave * 64 + lane) * 4) = a0 + a1;
-  }
+  *reinterpret_cast<f32x4*>(scr + ((size_t)wave * 64 + lane) * 4) =
+      tp4_mac_steps<P, NQ>(h1 + i * kWL4 + SH::KW * kq + 4 * kk, w1);
   if (st.X1 != nullptr && c == 0) {
     const int row = (int)threadIdx.x >> 6, col = ((int)threadIdx.x & 63) * 4, gr = row0 + row;
     if (gr < B) *reinterpret_cast<f32x4*>(st.X1 + (size_t)gr * kW4 + col) = ld4(h1 + row * kWL4 + col);
   }
   sf();
   __syncthreads();   // partial tiles visible
-  {   // ... summed in quarter order, bias + ReLU, and the unit-seed dz2 of the same element
+  if (r_mine) {   // ... summed in part order, bias + ReLU, and the unit-seed dz2 of the same element
     const float* sp = scr + ((size_t)rt * 64 + rl) * 4 + rr;
-    const float v = fmaxf((((sp[0] + sp[4 * 256]) + sp[8 * 256]) + sp[12 * 256]) + bias1, 0.f);
+    float sum = sp[0];
+#pragma unroll
+    for (int q = 1; q < SH::KP; ++q) sum += sp[q * SH::TPM * 256];
+    const float v = fmaxf(sum + bias1, 0.f);
     const int off = (4 * (rl >> 4) + rr) * kWL4 + c0 + 16 * rt + (rl & 15);
     h2[off] = v;
     g2[off] = v > 0.f ? seed * w3 : 0.f;
   }
 #pragma unroll
-  for (int s = 0; s < NS::M; ++s) wd[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < Q4; ++s) wd[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (dact_wave) {
-    const float* q0 = net.pb[0] + (((size_t)(dt0 + dt) * NS::W + dpart * NS::M) * 64 + lane) * 4;
+    const float* q0 = net.pb[0] + (((size_t)(dt0 + dt) * NS::W + dpart * Q4) * 64 + lane) * 4;
 #pragma unroll
-    for (int s = 0; s < NS::M; ++s) wd[s] = ld4(q0 + s * 256);
+    for (int s = 0; s < Q4; ++s) wd[s] = ld4(q0 + s * 256);
   }
   sf();
   __syncthreads();   // h2, g2 (the member's columns) visible
 
   // ---- dz1 partial (unit seed), mask in place over h1; then the h2 / g2 column stores
   {
-    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
-    const float* gr_ = g2 + i * kWL4 + c0 + 4 * kk;
-#pragma unroll
-    for (int s = 0; s < NS::M; s += 2) {
-      P::mac(gr_, s, wz[s], a0);
-      P::mac(gr_, s + 1, wz[s + 1], a1);
-    }
+    const f32x4 a = tp4_mac_steps<P, SH::M>(g2 + i * kWL4 + c0 + 4 * kk, wz);
     float* p = h1 + (kk * 4) * kWL4 + 16 * wave + i;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) p[r * kWL4] = p[r * kWL4] > 0.f ? a0[r] + a1[r] : 0.f;
+    for (int r = 0; r < 4; ++r) p[r * kWL4] = p[r * kWL4] > 0.f ? a[r] : 0.f;
   }
-  if (wave >= 4 && wave < 12) {
+  if ((wave >= 4 && wave < 4 + SH::TPM) || (wave >= 8 && wave < 8 + SH::TPM)) {
     float* dstg = wave < 8 ? st.X2 : st.dY1;
     if (dstg != nullptr) {
+      constexpr int C4 = SH::COLS / 4;                               // float4 per row of the member's columns
       const float* src = wave < 8 ? h2 : g2;
-      const int idx = (int)threadIdx.x - (wave < 8 ? 256 : 512);   // 16 rows x 16 float4
-      const int row = idx >> 4, col = c0 + (idx & 15) * 4, gr = row0 + row;
+      const int idx = (int)threadIdx.x - (wave < 8 ? 256 : 512);   // 16 rows x C4 float4
+      const int row = idx / C4, col = c0 + (idx - row * C4) * 4, gr = row0 + row;
       if (gr < B) *reinterpret_cast<f32x4*>(dstg + (size_t)gr * kW4 + col) = ld4(src + row * kWL4 + col);
     }
   }
@@ -500,16 +599,8 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   __syncthreads();   // dz1 partial visible
 
   tp4_store_dz1(st, c, h1, row0, B);
-  if (dact_wave) {
-    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
-    const float* hr = h1 + i * kWL4 + 64 * dpart + 4 * kk;
-#pragma unroll
-    for (int s = 0; s < NS::M; s += 2) {
-      P::mac(hr, s, wd[s], a0);
-      P::mac(hr, s + 1, wd[s + 1], a1);
-    }
-    *reinterpret_cast<f32x4*>(scr + wave * 256 + lane * 4) = a0 + a1;
-  }
+  if (dact_wave)
+    *reinterpret_cast<f32x4*>(scr + wave * 256 + lane * 4) = tp4_mac_steps<P, Q4>(h1 + i * kWL4 + 64 * dpart + 4 * kk, wd);
   if (dact) {
     sf();
     __syncthreads();   // quarters visible
@@ -517,16 +608,25 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   // q (wave 12) and the input-column gradient (waves < dnt) finish side by side: both are one
   // hop of the cluster exchange, neither waits for the other
   if (wave == kOutWave) {
-    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
-    const float* hr = h2 + i * kWL4 + c0 + 4 * kk;
-#pragma unroll
-    for (int s = 0; s < NS::M; s += 2) {
-      P::mac(hr, s, w2[s], a0);
-      P::mac(hr, s + 1, w2[s + 1], a1);
-    }
+    const f32x4 qpart = tp4_mac_steps<P, SH::M>(h2 + i * kWL4 + c0 + 4 * kk, w2);
     const bool valid = i == 0;
-    const f32x4 sum = tp4_allreduce_regs(a0 + a1, i, valid, tp);
     float* o = outS + (kk * 4) * kOutLd + i;
+    if constexpr (NM == 8) {
+      if (!valid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r * kOutLd] = 0.f;
+      }
+      tp4_allreduce_narrow<NM>(qpart, 0, 1, 0, scr + wave * 256, bias2, 0.f, outS, tp);   // lanes 0..15: one row each
+      if (q_sum_out != nullptr) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float qv = (lane < kR && row0 + lane < B) ? outS[lane * kOutLd] : 0.f;
+        const float qs = row16_sum(qv);
+        if (lane == 0) *q_sum_out = qs;
+      }
+    } else {
+    const f32x4 sum = tp4_allreduce_regs<NM>(qpart, i, valid, tp);
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r * kOutLd] = valid ? sum[r] + bias2 : 0.f;
     if (q_sum_out != nullptr) {
@@ -536,6 +636,7 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
       qs += __shfl_xor(qs, 16);
       qs += __shfl_xor(qs, 32);
       if (lane == 0) *q_sum_out = qs;
+    }
     }
   }
   if (dact) {
@@ -547,11 +648,20 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
       for (int q = 0; q < 4; ++q) part += ld4(scr + (wave * 4 + q) * 256 + lane * 4);
       const int cc = 16 * (dt0 + wave) + i - dact_col0;
       const bool valid = cc >= 0 && cc < dact_cols;
-      const f32x4 sum = tp4_allreduce_regs(part, cc, valid, tp2);
+      if constexpr (NM == 8) {
+        // this tile's share of the (at most 8) wanted columns: lanes [i_first, i_first + ncols)
+        const int t0 = 16 * (dt0 + wave);
+        const int i_first = dact_col0 > t0 ? dact_col0 - t0 : 0;
+        const int cc_first = t0 + i_first - dact_col0;
+        const int ncols = min(16 - i_first, dact_cols - cc_first);
+        tp4_allreduce_narrow<NM>(part, i_first, ncols, cc_first, scr + (size_t)wave * 4 * 256, 0.f, 0.f, dactS, tp2);
+      } else {
+      const f32x4 sum = tp4_allreduce_regs<NM>(part, cc, valid, tp2);
       if (valid) {
         float* o = dactS + (kk * 4) * kOutLd + cc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r * kOutLd] = sum[r];
+      }
       }
     }
     tp.stage += 1;

@@ -4,6 +4,7 @@ the trainer; ``seeds > 1`` fans out one process per seed."""
 from __future__ import annotations
 
 import logging
+import os
 import random
 from multiprocessing import get_context
 from typing import Callable
@@ -60,6 +61,10 @@ def run_training(
     if seeds == 1:
         _run_training_func(make_algo, make_env, make_replay_buffer, make_logger, config, 0, **trainer_kwargs)
         return
+    if seeds > 3:
+        # the seeds share ONE GPU: learners that want every CU for a launch (clusters of eight, include/oprl_amd.h)
+        # would spin for each other — the children inherit clusters of four
+        os.environ.setdefault("OPRL_AMD_NO_WIDE", "1")
     ctx = get_context("spawn")   # a forked child cannot re-initialise the GPU runtime
     procs = [ctx.Process(target=_run_training_func,
                          args=(make_algo, make_env, make_replay_buffer, make_logger, config, seed),

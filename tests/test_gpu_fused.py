@@ -24,12 +24,15 @@ def _close(a, b, tol=1e-5):
     return (a - b).abs().max().item() <= tol * max(b.abs().max().item(), 1e-12)
 
 
-# cluster "4g": clusters of 4 through the generic tp3.h passes instead of the lean tp4.h ones
-@pytest.mark.parametrize("cluster", [4, "4g", 2, 1])
+# cluster 8: the default — clusters of 4, of EIGHT for role A and phase 2's critic pass (tp4_forward /
+# tp4_scalar_fb <P, 8>, narrow exchanges); 4: clusters of four only; "4g": clusters of 4 through the generic
+# tp3.h passes instead of the lean tp4.h ones
+@pytest.mark.parametrize("cluster", [8, 4, "4g", 2, 1])
 @pytest.mark.parametrize("B", [256, 8, 100])
 def test_fused_equals_generic(B, cluster, monkeypatch):
     monkeypatch.setenv("OPRL_AMD_NO_LEAN", "1" if cluster == "4g" else "0")
-    cluster = 4 if cluster == "4g" else cluster
+    monkeypatch.setenv("OPRL_AMD_NO_WIDE", "0" if cluster == 8 else "1")
+    cluster = 4 if cluster in ("4g", 8) else cluster
     monkeypatch.setenv("OPRL_AMD_CLUSTER", str(cluster))
     fused, generic = _ddpg(), _ddpg(no_fuse=True)
     for step in range(4):
