@@ -125,7 +125,7 @@ def cpu_baseline(budget_s: float = 14.0):
 
 # ---- the other BASELINE.json configurations, the bf16 mode and the through-the-API rate --------
 PEAK_BF16_MATRIX_TFLOPS = 2500.0       # dense bf16 MFMA (MI355X_MICROARCH.md)
-PMC_FILE = {"f32": "r02g_pmc_traffic.json", "bf16": "r02g_pmc_traffic_bf16.json"}
+PMC_FILE = {"f32": "r02h_pmc_traffic.json", "bf16": "r02h_pmc_traffic_bf16.json"}
 PEAK_HBM_TBS = 8.0
 # name -> (class name, S, A, B, constructor extras, algorithmic GFLOP / update, state MB / update): BASELINE.md section 4
 BASELINE_CONFIGS = {
@@ -558,12 +558,13 @@ def main():
                              f"(serialised pass of {P} steps) minus event_overhead_us, the per-launch "
                              "excess of that pass over the un-instrumented timed loop (where the same "
                              "launches run back to back, so a step is the sum of their durations); they "
-                             "agree with rocprofv3 --kernel-trace --stats (profiles/r02g_kernel_stats.csv); "
+                             "agree with rocprofv3 --kernel-trace --stats (profiles/r02h_kernel_stats.csv); "
                              "sum of kernel time per step = "
                              f"{sum(k['us_per_step'] for k in kern.values()):.1f} us; traffic = "
-                             f"(2*FETCH_SIZE + WRITE_SIZE) KB and mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024) "
+                             f"(2*FETCH_SIZE + WRITE_SIZE) KB and mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (average launch duration x 2.4 GHz x 1024 SIMDs) "
                              f"from profiles/{PMC_FILE[args.precision]} (separate --pmc passes, tools/profile_round.sh); the "
-                             "launch is 192 workgroups (3 roles x 16 slices x 4-CU clusters), one per CU, "
+                             "launch is one workgroup per CU: 16 slices x (4 + 8 + 4) cluster members in the fp32 mode "
+                             "(role A on clusters of eight CUs: 256 workgroups), 16 x 3 x 4 = 192 in the bf16 mode, "
                              "and the step is a chain of 4 dependent launches bound by latency, not by "
                              "the matrix cores (DESIGN.md section 6)")
         multi = None
