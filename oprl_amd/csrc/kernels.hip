@@ -127,38 +127,56 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A) {
   // this workgroup's layer, straight from the kernel-argument segment (dynamic index into a
   // by-value array: through the segment pointer it is a scalar load, not a scratch copy)
   const DwKArgs* KA = &A;
-  if ((int)blockIdx.x >= KA->tile_end[A.n_items - 1]) {
-    // one workgroup past the tiles: the temperature's Adam step rides on this launch (AlphaJob)
-    const AlphaJob& J = A.alpha;
-    alpha_step_block(J.log_alpha, J.m, J.v, J.logp, J.B, J.target_entropy, J.lr, J.beta1, J.beta2, J.eps, J.bc1,
-                     J.bc2_sqrt, nullptr, nullptr, 1.f);
-    return;
+  // this workgroup's layer: the first four prefix ends in ONE scalar load (a loop with a load and a wait per
+  // item cost two dependent round trips before the first row request); entries past the last item hold the
+  // launch's total (fill_dw_kargs), so launches of up to four layers never look further, and the workgroup one
+  // past the tiles — the temperature's Adam step riding on this launch (AlphaJob) — is found on the rare path
+  const int bx = (int)blockIdx.x;
+  const int te0 = KA->tile_end[0], te1 = KA->tile_end[1], te2 = KA->tile_end[2], te3 = KA->tile_end[3];
+  // ... and the launch's scalar header with them, pinned into SGPRs here: left to the compiler every field is
+  // fetched where it is first used — a scalar load and a wait each, four of them in a row before the first row
+  // request and more in the epilogue
+  const int hB = A.B, h_n_part = A.n_part, h_tiled = A.dy_tiled, h_row_scale = A.use_row_scale, h_apply = A.apply_only;
+  long long* const h_trace = A.trace;
+  const float* const h_one = A.one;
+  const AdamScalars ad = A.ad;
+  asm volatile("" :: "s"(hB), "s"(h_n_part), "s"(h_tiled), "s"(h_row_scale), "s"(h_apply), "s"(h_trace), "s"(h_one),
+               "s"(ad.step_dev), "s"(ad.do_adam), "s"(ad.do_polyak), "s"(ad.omb1), "s"(ad.beta2), "s"(ad.omb2), "s"(ad.eps),
+               "s"(ad.omtau), "s"(ad.tau), "s"(ad.grad_scale), "s"(ad.step_size_host), "s"(ad.bc2_sqrt_host));
+  int item = (bx >= te0 ? 1 : 0) + (bx >= te1 ? 1 : 0) + (bx >= te2 ? 1 : 0) + (bx >= te3 ? 1 : 0);
+  if (bx >= te3) {
+    if (bx >= KA->tile_end[kDwMaxItems - 1]) {
+      const AlphaJob& J = A.alpha;
+      alpha_step_block(J.log_alpha, J.m, J.v, J.logp, J.B, J.target_entropy, J.lr, J.beta1, J.beta2, J.eps, J.bc1,
+                       J.bc2_sqrt, nullptr, nullptr, 1.f);
+      return;
+    }
+#pragma unroll
+    for (int j = 4; j + 1 < kDwMaxItems; ++j) item += bx >= KA->tile_end[j] ? 1 : 0;   // more than four layers (TQC)
   }
-  int item = 0;
-  for (int j = 0; j + 1 < A.n_items; ++j) item += (int)blockIdx.x >= KA->tile_end[j] ? 1 : 0;
   const DwItem I = KA->items[item];
   const int lt = (int)blockIdx.x - (item > 0 ? KA->tile_end[item - 1] : 0);
   int n_stamp = 0;
   auto stamp = [&]() {
     const int wg = item * 16 + lt;   // the first 16 tiles of each item
-    if (A.trace != nullptr && tid == 0 && lt < 16 && wg < 64 && n_stamp < kTraceStamps) {
-      long long* tr = A.trace + ((size_t)wg * kTraceStamps + n_stamp) * 2;
+    if (h_trace != nullptr && tid == 0 && lt < 16 && wg < 64 && n_stamp < kTraceStamps) {
+      long long* tr = h_trace + ((size_t)wg * kTraceStamps + n_stamp) * 2;
       tr[0] = (long long)__builtin_readcyclecounter();
       tr[1] = (long long)wall_clock64();
     }
     ++n_stamp;
   };
   stamp();
-  if (tid == 64) adam_bias_corr(A.ad, &sc[0], &sc[1]);
+  if (tid == 64) adam_bias_corr(ad, &sc[0], &sc[1]);
   const int tn = lt / I.tiles_k, tk = lt - tn * I.tiles_k;
   const int TNi = I.tile_n;                               // 16, or 8 (partial-sum layers)
   const int n_base = tn * TNi, k_base = tk * TK;
   const int ptile = n_base >> 4, n_off = n_base & 15;     // 16-row pack tile and our offset in it
   const int i = lane & 15, c = lane >> 4;
   const int NSk = cdiv(I.K, 16), NSn = cdiv(I.N, 16);
-  const int npart = I.dY_part_stride > 0 ? A.n_part : 1;
-  const bool tiled = I.dY_part_stride > 0 && A.dy_tiled != 0;   // tile-major partial buffers (tp4_store_dz1)
-  const bool polyak = A.ad.do_polyak && I.w_t != nullptr;
+  const int npart = I.dY_part_stride > 0 ? h_n_part : 1;
+  const bool tiled = I.dY_part_stride > 0 && h_tiled != 0;   // tile-major partial buffers (tp4_store_dz1)
+  const bool polyak = ad.do_polyak && I.w_t != nullptr;
 
   // this thread's element of the epilogue; its Adam state is requested NOW so the round
   // trip overlaps the GEMM
@@ -167,7 +185,7 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A) {
   const bool e_ok = nl < TNi && en < I.N && ek < I.K;
   const size_t eo = (size_t)en * I.K + ek;
   float p_th = 0.f, p_m = 0.f, p_v = 0.f, p_tt = 0.f;
-  if (e_ok && A.ad.do_adam) {
+  if (e_ok && ad.do_adam) {
     p_th = I.w[eo];
     p_m = I.w_m[eo];
     p_v = I.w_v[eo];
@@ -177,9 +195,9 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A) {
   // well — fetched in the epilogue it was a cold round trip (0.6 us) at the very end of the layer-0
   // tiles, the ones every launch waits for
   const bool b_own = tk == 0 && tid < TNi && n_base + tid < I.N;
-  const bool b_pol = A.ad.do_polyak && I.b_t != nullptr;
+  const bool b_pol = ad.do_polyak && I.b_t != nullptr;
   float q_th = 0.f, q_m = 0.f, q_v = 0.f, q_tt = 0.f;
-  if (b_own && A.ad.do_adam) {
+  if (b_own && ad.do_adam) {
     const int n = n_base + tid;
     q_th = I.b[n];
     q_m = I.b_m[n];
@@ -200,25 +218,25 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A) {
   float sA = 0.f;
   // per-row seed of unit-seed layers, or the constant 1 (stride 0): always a load, no branch
   // between the row requests
-  const bool scaled = I.scaled != 0 && A.use_row_scale != 0;
-  const float* rsp = scaled ? I.rs : A.one;
+  const bool scaled = I.scaled != 0 && h_row_scale != 0;
+  const float* rsp = scaled ? I.rs : h_one;
   const size_t rs_ld = scaled ? (size_t)I.rs_ld : 0;
   const int ar = lane >> 2, an = (lane & 3) * 4;      // dY: 16 rows x 4 lanes x float4
   const int xr = lane >> 3, xk = (lane & 7) * 4;      // X :  8 rows x 8 lanes x float4
   const bool an_ok = an < TNi && n_base + an < I.ldy;  // ldy, ldx are multiples of 4
   const bool xk_ok = k_base + xk < I.ldx;
-  for (int chunk = 0; chunk * 256 < (A.apply_only ? 0 : A.B); ++chunk) {
+  for (int chunk = 0; chunk * 256 < (h_apply ? 0 : hB); ++chunk) {
     const int base = chunk * 256 + 32 * wave;
     f32x4 va[2][4], vx[4];
     float rs[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int bb = base + ar + 16 * h;
-      rs[h] = rsp[(size_t)(bb < A.B ? bb : 0) * rs_ld];
+      rs[h] = rsp[(size_t)(bb < hB ? bb : 0) * rs_ld];
 #pragma unroll
       for (int m = 0; m < 4; ++m) va[h][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (bb < A.B && an_ok) {
-        const float* src = tiled ? I.dY + ((size_t)((n_base + an) >> 4) * A.B + bb) * 16 + ((n_base + an) & 15)
+      if (bb < hB && an_ok) {
+        const float* src = tiled ? I.dY + ((size_t)((n_base + an) >> 4) * hB + bb) * 16 + ((n_base + an) & 15)
                                  : I.dY + (size_t)bb * I.ldy + n_base + an;
         va[h][0] = ld4(src);
         // tensor-parallel slices leave the first layer's dz as n_part (<= 4) partial buffers
@@ -232,7 +250,7 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A) {
     for (int j = 0; j < 4; ++j) {
       const int bb = base + xr + 8 * j;
       vx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (bb < A.B && xk_ok) vx[j] = ld4(I.X + (size_t)bb * I.ldx + k_base + xk);
+      if (bb < hB && xk_ok) vx[j] = ld4(I.X + (size_t)bb * I.ldx + k_base + xk);
     }
     stamp();   // rows requested
 #pragma unroll
@@ -344,27 +362,27 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A) {
     g = gs;
     gb_x = gbs;
   }
-  if (A.apply_only) g = e_ok ? I.w_g[eo] : 0.f;   // the (all-reduced) gradient instead of this rank's GEMM
-  g *= A.ad.grad_scale;
+  if (h_apply) g = e_ok ? I.w_g[eo] : 0.f;   // the (all-reduced) gradient instead of this rank's GEMM
+  g *= ad.grad_scale;
   float th_new = 0.f, tt_new = 0.f;
   if (e_ok) {
-    if (I.w_g != nullptr && !A.apply_only) I.w_g[eo] = g;
-    if (A.ad.do_adam) {
+    if (I.w_g != nullptr && !h_apply) I.w_g[eo] = g;
+    if (ad.do_adam) {
       float mm = p_m, vv = p_v, th = p_th;
-      mm = mm + (g - mm) * A.ad.omb1;
-      vv = vv * A.ad.beta2 + A.ad.omb2 * g * g;
-      th = th - step_size * (mm / (sqrtf(vv) / bc2_sqrt + A.ad.eps));
+      mm = mm + (g - mm) * ad.omb1;
+      vv = vv * ad.beta2 + ad.omb2 * g * g;
+      th = th - step_size * (mm / (sqrtf(vv) / bc2_sqrt + ad.eps));
       I.w_m[eo] = mm;
       I.w_v[eo] = vv;
       I.w[eo] = th;
       th_new = th;
       if (polyak) {
-        tt_new = p_tt * A.ad.omtau + A.ad.tau * th;
+        tt_new = p_tt * ad.omtau + ad.tau * th;
         I.w_t[eo] = tt_new;
       }
     }
   }
-  if (A.ad.do_adam && I.pf != nullptr) {
+  if (ad.do_adam && I.pf != nullptr) {
     // keep the fragment-order packs in step with the master: stage the new 16x32 tile(s)
     // (zero outside the matrix, like the packs' padding), then 3 x 128 float4 jobs
     float (*tileW)[LD] = part[0];
@@ -397,7 +415,7 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A) {
       }
     }
   }
-  if (A.ad.do_adam && I.pf16 != nullptr) {
+  if (ad.do_adam && I.pf16 != nullptr) {
     // ... and the bf16 packs (PrecBF16, engine.h): a bf16 macro step = fp32 steps 2s, 2s + 1 side by
     // side, so this 16 x 32 tile is ONE forward fragment block (64 lanes x 16 B, online and target) and,
     // for W^T, one HALF (8 B per lane) of a block for each of its two 16-row k tiles — the other half
@@ -433,19 +451,19 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A) {
 #pragma unroll
     for (int w = 0; w < kDwWaves; ++w) gb += bpart[w][tid];
     if constexpr (XCHG) gb = gb_x;
-    if (A.apply_only) gb = I.b_g[n];
-    gb *= A.ad.grad_scale;                 // (the arithmetic of adam_polyak_elem, on the prefetched state)
-    if (I.b_g != nullptr && !A.apply_only) I.b_g[n] = gb;
-    if (A.ad.do_adam) {
+    if (h_apply) gb = I.b_g[n];
+    gb *= ad.grad_scale;                 // (the arithmetic of adam_polyak_elem, on the prefetched state)
+    if (I.b_g != nullptr && !h_apply) I.b_g[n] = gb;
+    if (ad.do_adam) {
       float mm = q_m, vv = q_v, th = q_th;
-      mm = mm + (gb - mm) * A.ad.omb1;
-      vv = vv * A.ad.beta2 + A.ad.omb2 * gb * gb;
-      const float denom = sqrtf(vv) / bc2_sqrt + A.ad.eps;
+      mm = mm + (gb - mm) * ad.omb1;
+      vv = vv * ad.beta2 + ad.omb2 * gb * gb;
+      const float denom = sqrtf(vv) / bc2_sqrt + ad.eps;
       th = th - step_size * (mm / denom);
       I.b_m[n] = mm;
       I.b_v[n] = vv;
       I.b[n] = th;
-      if (b_pol) I.b_t[n] = q_tt * A.ad.omtau + A.ad.tau * th;
+      if (b_pol) I.b_t[n] = q_tt * ad.omtau + ad.tau * th;
     }
   }
   stamp();   // stores issued
@@ -460,7 +478,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
 // N learners' dW + Adam launches as one (grid.z = learner; argument blocks in device memory)
 __global__ __launch_bounds__(kDwThreads) void k_dw_adam_group(const DwKArgs* __restrict__ batch) {
   const DwKArgs& A = batch[blockIdx.z];
-  if ((int)blockIdx.x >= A.tile_end[A.n_items - 1]) return;
+  if ((int)blockIdx.x >= A.tile_end[kDwMaxItems - 1]) return;   // (entries past the last item hold the total)
   dw_adam_body<false>(A);
 }
 
