@@ -577,6 +577,13 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A) {
   }
   stamp();
   const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
+  if constexpr (LEAN) {
+    // the prologue's pointers, fetched together HERE (one scalar wait, under the LDS zeroing): left to the
+    // compiler each is loaded where it is first used — a scalar load and a wait between every two row requests
+    const float* p0 = A.aX[0]; const float* p1 = A.aX[1]; const float* p2 = A.aX[2]; const float* p3 = A.pi;
+    const int ld0 = A.aldx0;
+    asm volatile("" :: "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(ld0));
+  }
   // [s | pi] and the actor's forward activations (for its ReLU masks)
   lds_zero(xa, 2 * kR * kX0Ld);
   if constexpr (LEAN) lds_zero(auxS, kR * kOutLd);   // the gradient tile's padding columns stay zero

@@ -233,6 +233,10 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
                                             ST sf = ST()) {
   using NS = Tp4Steps<P>;
   using SH = Tp4Shape<P, NM>;
+  // the net's pointers and dims, fetched from the kernel arguments TOGETHER (one scalar wait): left to the
+  // compiler they come in where first used, a scalar load and a wait in front of every group of fragment requests
+  asm volatile("" :: "s"(net.pf[0]), "s"(net.pf[1]), "s"(net.pf[2]), "s"(net.b[0]), "s"(net.b[1]), "s"(net.b[2]),
+               "s"(net.dims[0]), "s"(net.dims[3]));
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
@@ -349,6 +353,7 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
                                              float* scr, Tp& tp, const Tp3Store& st, int row0, int B,
                                              int dact_col0, int dact_cols, float* dactS, ST sf = ST()) {
   using NS = Tp4Steps<P>;
+  asm volatile("" :: "s"(net.pb[0]), "s"(net.pb[1]), "s"(net.pb[2]), "s"(net.dims[3]));   // (as in tp4_forward)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
@@ -489,6 +494,8 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   const int i = lane & 15, kk = lane >> 4;
   using NS = Tp4Steps<P>;
   using SH = Tp4Shape<P, NM>;
+  asm volatile("" :: "s"(net.pf[0]), "s"(net.pf[1]), "s"(net.pf[2]), "s"(net.pb[0]), "s"(net.pb[1]), "s"(net.pb[2]),
+               "s"(net.b[0]), "s"(net.b[1]), "s"(net.b[2]), "s"(net.dims[0]));   // (as in tp4_forward)
   const int c = tp.c, c0 = c * SH::COLS;
   const int NS0 = (net.dims[0] + P::KS - 1) / P::KS;   // layer-0 steps
   const bool dact = dact_cols > 0;
