@@ -37,7 +37,7 @@ t.cuda.synchronize()
 tr = buf.cpu().numpy()
 fused = "--generic" not in sys.argv
 names = (["P1 role A target chain", "P1 role B critic f+b", "P1 role C actor fwd", "P2 critic f+b, actor bwd",
-          "dW critic (wg0 = layer 0 tile 0)", "dW actor"]
+          "dW critic (wg0 = hidden-layer tile 0)", "dW actor"]
          if fused else ["actor_t fwd", "critic_t fwd", "critic fwd+bwd", "actor fwd", "critic(s,pi) fwd+bwd", "actor bwd"])
 for slot in range(len(names)):
     x = tr[slot, :16]                       # 16 workgroups
