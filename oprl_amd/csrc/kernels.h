@@ -199,6 +199,15 @@ struct DwArgs {                         // host-side description of one k_dw_ada
 // started with two dependent misses (probe, then the item) — 9.3 us per launch for ~3 MB
 // of traffic.  grid = total tiles exactly (dispatch costs ~13 ns per workgroup, even one
 // that exits at once); a workgroup finds its layer by a scalar scan of tile_end[].
+// GATED tile workgroups (merged phase launches): flag granules {tag, *} they wait for (csrc/dw_body.h)
+struct DwGate {
+  const unsigned long long* rows = nullptr; int n_rows = 0;   // every producer of X / dY rows has finished
+  const unsigned long long* seed = nullptr; int n_seed = 0;   // the per-row seeds (and `late_dY`) are out
+  const float* late_dY = nullptr;      // dY buffer that is written with the seeds (the scalar critic's output layer)
+  unsigned tag = 0; int spin = 0;
+  unsigned* err = nullptr; unsigned err_code = 0;
+};
+
 constexpr int kDwMaxItems = 20;        // 5 critics x 4 layers (TQC)
 struct DwKArgs {
   int tile_end[kDwMaxItems];           // exclusive prefix ends, relative to this launch
@@ -211,6 +220,7 @@ struct DwKArgs {
   int apply_only;
   DwXchg xchg;                         // k_dw_adam<true> only
   AlphaJob alpha;                      // workgroup `tile_end[n_items - 1]` (one past the tiles) runs it
+  DwGate gate;                         // dw_adam_body<*, GATED> only
 };
 
 struct BatchSrc {
