@@ -121,7 +121,7 @@ __device__ __forceinline__ float ld1_sc1(const float* p) {
 // `gate_seed` (the per-row seeds, and the output layer's dY) before those; rows and seeds are read with sc1 loads
 // (the producers write them through: no kernel boundary lies in between).
 template <bool XCHG, bool GATED = false>
-__device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds) {
+__device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int bx) {   // bx: the tile (bx of a stand-alone launch)
   constexpr int TN = kDwTileN, TK = kDwTile, LD = TK + 4;
   float (*part)[TN][LD] = reinterpret_cast<float (*)[TN][LD]>(lds + kDwLdsPart);
   float (*bpart)[TN] = reinterpret_cast<float (*)[TN]>(lds + kDwLdsBpart);
@@ -134,7 +134,6 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds) {
   // item cost two dependent round trips before the first row request); entries past the last item hold the
   // launch's total (fill_dw_kargs), so launches of up to four layers never look further, and the workgroup one
   // past the tiles — the temperature's Adam step riding on this launch (AlphaJob) — is found on the rare path
-  const int bx = (int)blockIdx.x;
   const int te0 = KA->tile_end[0], te1 = KA->tile_end[1], te2 = KA->tile_end[2], te3 = KA->tile_end[3];
   // ... and the launch's scalar header with them, pinned into SGPRs here: left to the compiler every field is
   // fetched where it is first used — a scalar load and a wait each, four of them in a row before the first row
@@ -158,7 +157,7 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds) {
     for (int j = 4; j + 1 < kDwMaxItems; ++j) item += bx >= KA->tile_end[j] ? 1 : 0;   // more than four layers (TQC)
   }
   const DwItem I = KA->items[item];
-  const int lt = (int)blockIdx.x - (item > 0 ? KA->tile_end[item - 1] : 0);
+  const int lt = bx - (item > 0 ? KA->tile_end[item - 1] : 0);
   int n_stamp = 0;
   auto stamp = [&]() {
     const int wg = item * 16 + lt;   // the first 16 tiles of each item
@@ -240,6 +239,7 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds) {
     const int base = chunk * 256 + 32 * wave;
     f32x4 va[2][4], vx[4];
     float rs[2];
+
     auto load_dy = [&](int h) {
       const int bb = base + ar + 16 * h;
 #pragma unroll
@@ -275,15 +275,34 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds) {
       }
     }
     if constexpr (GATED) {
-      // everything that does not depend on the seeds is under way; now the seeds' gate
-      const bool ok = dw_gate_wait(A.gate.seed, A.gate.n_seed, A.gate.tag, A.gate.spin);
-      if (!ok) report_expired(A.gate.err, A.gate.err_code);
-      __syncthreads();
+      // everything that does not depend on the seeds is under way; the seeds themselves arrive as {tag, value}
+      // granules, one per minibatch row (the value is its own flag: the producer neither waits nor flags): every
+      // lane polls the granules of its two rows.  They are the row scale of the unit-seed layers and the dY rows
+      // of the output layer (`late_dY`, one column).
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        load_rs(h);
-        if (dy_late) load_dy(h);
+        const int bb = base + ar + 16 * h;
+        float sd = 1.f;
+        if (bb < hB && A.gate.n_seed > 0) {
+          unsigned long long g = 0;
+          bool ok = false;
+          for (int spin = 0; spin < A.gate.spin && !ok; ++spin) {
+            g = __hip_atomic_load(A.gate.seed + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = (unsigned)(g >> 32) == A.gate.tag;
+            if (!ok) __builtin_amdgcn_s_sleep(1);
+          }
+          if (!ok) report_expired(A.gate.err, A.gate.err_code);
+          sd = ok ? __uint_as_float((unsigned)g) : __builtin_nanf("");
+        }
+        rs[h] = scaled ? sd : 1.f;
+        if (dy_late) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) va[h][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (n_base + an == 0 && bb < hB) va[h][0][0] = sd;   // (rows past the minibatch stay zero)
+        }
       }
+      // the sc1 row loads are inline asm: hipcc does not count them — wait for them here, before the rows are staged
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     stamp();   // rows requested
 #pragma unroll
@@ -347,10 +366,10 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds) {
     // ranks' partial tiles, sums them in rank order and sends the sum back — 2 x (world - 1) / world of
     // the arena leaves every GPU instead of (world - 1) x, and all replicas apply the very same sum.
     const unsigned tag = (unsigned)X.seq;
-    const int owner = (int)(blockIdx.x % (unsigned)X.world);
+    const int owner = (int)(bx % (unsigned)X.world);
     auto slot = [&](char* base, int src_slot) {
       return reinterpret_cast<unsigned long long*>(base) +
-             (((size_t)X.parity * (X.world + 1) + src_slot) * X.max_tiles + blockIdx.x) * kDwXchgTile;
+             (((size_t)X.parity * (X.world + 1) + src_slot) * X.max_tiles + bx) * kDwXchgTile;
     };
     auto put = [&](unsigned long long* dst, float v, float vb) {
       __hip_atomic_store(dst + tid, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v),

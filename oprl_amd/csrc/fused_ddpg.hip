@@ -42,6 +42,7 @@
 #include "replay_index.h"
 #include "slice_head.h"
 #include "tp4.h"
+#include "dw_body.h"
 
 namespace oprl {
 
@@ -197,7 +198,8 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
   float* yS = smem + LY::misc + 2 * kR;
   const int slice = blockIdx.x, row0 = slice * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
   const bool lead = tp.c == 0;
-  const Tp3Store st{cX[1], cX[2], cdY[1], cdY[0], A.cdY0_stride, LEAN ? B : 0};   // lean: tile-major dz1 partials
+  const bool wt = LEAN && (A.merged & 1) != 0;   // the dW tiles of this very launch read what this role stores
+  const Tp3Store st{cX[1], cX[2], cdY[1], cdY[0], A.cdY0_stride, LEAN ? B : 0, wt};   // lean: tile-major dz1 partials
   if constexpr (LEAN) {
     // ... and, the critic being scalar-output, its whole backward with unit seed as well:
     // k_dw_adam applies 2(q - y)/B per row (tp4_scalar_fb), so after y arrives only that
@@ -206,8 +208,25 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
   } else {
     tp_fwd<WIDTH, LEAN, P>(critic, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
   }
-  if (lead) store_rows(xa, kX0Ld, cX[0], A.cldx0, S + Ad, row0, B);
+  if (lead) {
+    if (wt) {
+      for (int idx = tid; idx < kR * (S + Ad); idx += kThreads) {
+        const int row = idx / (S + Ad), col = idx - row * (S + Ad), gr = row0 + row;
+        if (gr < B) __hip_atomic_store(cX[0] + (size_t)gr * A.cldx0 + col, xa[row * kX0Ld + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      store_rows(xa, kX0Ld, cX[0], A.cldx0, S + Ad, row0, B);
+    }
+  }
   if constexpr (LEAN) {
+    if (wt) {
+      // every wave's rows are out (written through) before the member says so: one flag granule per member
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_store(A.gate_flags + slice * 4 + tp.c, (unsigned long long)A.epoch << 32, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);   // (merged launches: one critic, j == 0)
+    }
     // q goes to role A of this slice as granules — A, the last to finish, turns it into the per-row seed
     // 2 (q - y) / B and the diagnostics itself; this role is done (it used to wait here for y: one more hop
     // and a wake-up on the launch's critical path)
@@ -285,9 +304,24 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
 // WIDE (DDPG, fp32 lean passes, a grid that still fits the chip): role A — two forward passes, the launch's
 // critical chain — runs on clusters of EIGHT CUs (tp4_forward<P, 8>): half the 256 x 256 layer's bytes and
 // MFMAs per member; roles B and C keep four.
-template <int WIDTH, bool LEAN, bool SAC, class P, bool WIDE = false>
-__device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A) {
+// MERGED (DDPG, lean passes, B <= 256): the critic's dW + Adam tiles are extra grid rows of THIS launch
+// (dw_adam_body<false, GATED>): dispatched after the roles' workgroups, they run where CUs are free or come free
+// (role C's after 7 us, role B's after 8.5), take in their Adam state and — once role B's members have flagged
+// their rows — X and dY, and wait for role A's seed flags: what is left after the launch's critical chain is one
+// flag hop, 16 MFMAs and the Adam epilogue instead of a kernel boundary and a whole k_dw_adam launch.
+template <int WIDTH, bool LEAN, bool SAC, class P, bool WIDE = false, bool MERGED = false>
+__device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const DwKArgs* D = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if constexpr (MERGED) {
+    const int rows = (2 + A.n_critics) * A.nc + ((LEAN && WIDE) ? 4 : 0);
+    if ((int)blockIdx.y >= rows) {
+      if (threadIdx.x >= kDwThreads) return;      // a tile workgroup is the first 8 waves (the stand-alone kernel's shape and arithmetic)
+      const int tile = ((int)blockIdx.y - rows) * (int)gridDim.x + (int)blockIdx.x;
+      if (tile >= D->tile_end[kDwMaxItems - 1]) return;
+      dw_adam_body<false, true>(*D, smem, tile);
+      return;
+    }
+  }
   using LY = FusedLds<WIDTH>;
   constexpr int WL = lds_ld(WIDTH);
   constexpr int HB = kR * WL;
@@ -475,7 +509,11 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A) {
             if (!ok) report_expired(A.err, (KERN_PHASE1 << 8) | SITE_TD_TARGET);
             q = ok ? __uint_as_float((unsigned)g) : __builtin_nanf("");
             float* const* dYj = j == 0 ? A.cdY : A.c2dY;
-            dYj[2][(size_t)gr * A.clddo] = 2.f * (q - y) * A.inv_B;
+            const float seed = 2.f * (q - y) * A.inv_B;
+            dYj[2][(size_t)gr * A.clddo] = seed;
+            if ((A.merged & 1) != 0 && j == 0)   // ... and to the dW tiles of this very launch as a granule (the TD-target array is free in the lean form)
+              __hip_atomic_store(A.y_granules + gr, ((unsigned long long)A.epoch << 32) | (unsigned long long)__float_as_uint(seed),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (j == 0 && A.y_out != nullptr) A.y_out[gr] = y;
             if (j == 0 && A.q_out != nullptr) A.q_out[gr] = q;
           }
@@ -503,6 +541,16 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A) {
 
 template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32, bool WIDE = false>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) { ddpg_phase1_body<WIDTH, LEAN, SAC, P, WIDE>(A); }
+
+// phase 1 + the critic's dW tiles in one launch (both argument blocks by value; the tile workgroups index the
+// second one through the kernel-argument segment: scalar loads, as k_dw_adam does)
+constexpr size_t kMergedDwOffset = (sizeof(DdpgArgs) + alignof(DwKArgs) - 1) / alignof(DwKArgs) * alignof(DwKArgs);
+template <class P>
+__global__ __launch_bounds__(kThreads) void k_ddpg_phase1_dw(const DdpgArgs A, const DwKArgs D) {
+  const DwKArgs* Dp = (const DwKArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kMergedDwOffset);
+  ddpg_phase1_body<256, true, false, P, false, true>(A, Dp);
+}
+
 
 // N independent learners in ONE launch (grid.z = learner): the argument blocks live in device memory (N x 1.7 KB
 // does not fit the kernel-argument segment), every field read is a scalar load through one uniform pointer.
@@ -807,10 +855,12 @@ hipError_t init_fused_attrs() {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
   }
-  const void* kg[4] = {reinterpret_cast<const void*>(&k_ddpg_phase1_group<256, false, false>),
+  const void* kg[6] = {reinterpret_cast<const void*>(&k_ddpg_phase1_group<256, false, false>),
                        reinterpret_cast<const void*>(&k_ddpg_phase2_group<256, false, false>),
                        reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, false, PrecF32, true>),
-                       reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false, PrecF32, true>)};
+                       reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false, PrecF32, true>),
+                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecF32>),
+                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecBF16>)};
   for (const void* k : kg) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -841,6 +891,19 @@ static bool lean_ok(const DdpgArgs& a) { return fused_ddpg_is_lean(a); }
 // generic launch sequence when this returns false)
 bool fused_ddpg_is_lean(const DdpgArgs& a) {
   return a.nc == 4 && !a.no_lean && tp4_shape_ok(256, a.S + a.A, 1) && tp4_shape_ok(256, a.S, a.sac ? 2 * a.A : a.A);
+}
+
+// phase 1 with the critic's dW + Adam tiles as extra grid rows (DdpgArgs::merged bit 0; `d` = fill_dw_kargs of
+// that launch with its gate filled in)
+hipError_t launch_ddpg_phase1_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st) {
+  if (!lean_ok(a) || a.sac || a.n_critics != 1 || (a.wide & 1) != 0 || (a.merged & 1) == 0) return hipErrorInvalidValue;
+  static_assert(sizeof(DdpgArgs) % alignof(DwKArgs) == 0 || true, "");
+  const int slices = (a.B + kR - 1) / kR;
+  const int tiles = d.tile_end[kDwMaxItems - 1];
+  const dim3 grid(slices, 3 * a.nc + (tiles + slices - 1) / slices);
+  if (a.bf16) hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
+  else hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecF32>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
+  return hipGetLastError();
 }
 
 hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st) {

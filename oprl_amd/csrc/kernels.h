@@ -282,6 +282,12 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   int nc;                              // CUs per slice cluster (tensor-parallel, csrc/tp3.h): 1, 2 or 4
   int xnc;                             // members an exchange area of `xbuf` is laid out for (>= nc; 8 when wide clusters may run)
   int wide;                            // bit 0: phase 1's role A, bit 1: phase 2's critic pass on clusters of EIGHT (fp32 lean passes)
+  // merged launches: the critic's dW + Adam tiles ride on phase 1's launch as extra workgroups (bit 0) — they
+  // start while the roles run, take their Adam state in, and wait for flag granules: gate_flags[0 .. 4 slices)
+  // = role B's members have written their X / dY rows through, gate_flags[64 + slice] = role A has written the
+  // slice's seeds through; tagged with `epoch`
+  int merged;
+  unsigned long long* gate_flags;
   int no_lean;                         // 1: never use the tp4.h specialisation (OPRL_AMD_NO_LEAN, tests)
   unsigned long long* xbuf;            // cluster exchange areas: [role][slice][kTpStages][nc][kTpBlk] granules
   unsigned cluster_tag;                // launch-unique

@@ -93,7 +93,7 @@ template <bool XCHG>
 __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
   // (through the kernel-argument segment pointer: a dynamic index into the by-value table is then a scalar load)
   __shared__ __attribute__((aligned(16))) float dw_lds[kDwLdsFloats];
-  dw_adam_body<XCHG>(*(const DwKArgs*)__builtin_amdgcn_kernarg_segment_ptr(), dw_lds);
+  dw_adam_body<XCHG>(*(const DwKArgs*)__builtin_amdgcn_kernarg_segment_ptr(), dw_lds, (int)blockIdx.x);
 }
 
 // N learners' dW + Adam launches as one (grid.z = learner; argument blocks in device memory)
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam_group(const DwKArgs* __r
   const DwKArgs& A = batch[blockIdx.z];
   if ((int)blockIdx.x >= A.tile_end[kDwMaxItems - 1]) return;   // (entries past the last item hold the total)
   __shared__ __attribute__((aligned(16))) float dw_lds[kDwLdsFloats];
-  dw_adam_body<false>(A, dw_lds);
+  dw_adam_body<false>(A, dw_lds, (int)blockIdx.x);
 }
 
 // flat Adam over an arena (data-parallel apply after the all-reduce; alpha-free)

@@ -161,6 +161,7 @@ hipError_t launch_debug_normal(unsigned long long seed, unsigned long long ctr, 
 hipError_t init_fused_attrs();
 size_t fused_xbuf_granules_per_cluster(int nc);
 hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st);
+hipError_t launch_ddpg_phase1_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st);
 bool fused_ddpg_is_lean(const DdpgArgs& a);
 hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st);
 hipError_t launch_ddpg_phase1_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
@@ -386,6 +387,7 @@ struct oprl_learner {
   int ncl = 1;                 // CUs per slice cluster in the fused path (csrc/tp3.h)
   int n_cus = 256;
   int no_lean = 0;
+  int no_merge = 0;            // OPRL_AMD_NO_MERGE: dW launches of their own
   int no_wide = 0;             // OPRL_AMD_NO_WIDE: never run role A / phase 2's critic pass on clusters of eight
   int xnc = kMaxCluster;       // members an exchange area of xbuf is laid out for
   unsigned long long* xbuf = nullptr;
@@ -804,6 +806,8 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   a.pi = h->pi;
   a.y_out = h->ydbg; a.q_out = h->qdbg;
   a.y_granules = h->y_granules; a.gran_stride = h->Bmax;
+  a.gate_flags = h->y_granules + (size_t)3 * h->Bmax;   // 256 flag granules behind the TD / q granules
+  a.merged = 0;
   a.epoch = h->epoch;
   a.trace = nullptr;
   a.nc = h->nc_cluster(B);
@@ -844,6 +848,12 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
     if (h->nc == 1 && (a.nc + 8 + a.nc) * slices <= h->n_cus) a.wide |= 1;
     if ((8 + 1) * slices <= h->n_cus) a.wide |= 2;
   }
+  // merged launches (DDPG, lean passes, one 256-row chunk, this rank's own Adam step): the critic's dW tiles ride
+  // on phase 1 — whose role A then stays on a cluster of four: 64 CUs must be free for tile workgroups from the start
+  if (!h->no_merge && h->nc == 1 && !a.sac && B <= 256 && !h->cfg.export_grads && !h->dp_inline && fused_ddpg_is_lean(a)) {
+    a.merged |= 1;
+    a.wide &= ~1;
+  }
   return a;
 }
 
@@ -873,7 +883,8 @@ AlphaJob alpha_job(oprl_learner* h, int B) {
   return j;
 }
 
-int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st, bool with_alpha = false) {
+// (dw_build advances the optimiser's step count: call it once per launch, merged or not)
+DwArgs dw_build(oprl_learner* h, bool critic, int B, bool polyak, bool with_alpha) {
   const oprl_learner_config& c = h->cfg;
   DwArgs dw;
   if (with_alpha) dw.alpha = alpha_job(h, B);
@@ -897,6 +908,11 @@ int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st, bo
   const bool lean = fused && fused_ddpg_is_lean(ddpg_args(h, B));
   dw.use_row_scale = (critic && lean) ? 1 : 0;
   dw.dy_tiled = (lean && dw.n_part > 1) ? 1 : 0;      // the lean passes leave tile-major dz1 partials
+  return dw;
+}
+
+int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st, bool with_alpha = false) {
+  DwArgs dw = dw_build(h, critic, B, polyak, with_alpha);
   if (h->dp_inline) {
     // data-parallel on peer windows: this launch all-reduces its tiles itself and runs Adam on the mean
     P2pState& P = h->p2p;
@@ -923,13 +939,31 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     h->epoch += 1;
     if (h->epoch == 0) {   // the TD-target tag wrapped: retire every stale granule
       h->epoch = 1;
-      HIPC(hipMemsetAsync(h->y_granules, 0, (size_t)3 * h->Bmax * sizeof(unsigned long long), st));
+      HIPC(hipMemsetAsync(h->y_granules, 0, ((size_t)3 * h->Bmax + 256) * sizeof(unsigned long long), st));
     }
     DdpgArgs fa = ddpg_args(h, B);
     fa.noise = noise0;
     RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &fa.cluster_tag));
     if (h->trace != nullptr) fa.trace = h->trace;   // roles use slots 0 .. 1 + n_critics
     HIPC(chain_before(st));
+    if ((fa.merged & 1) != 0) {
+      // phase 1 and the critic's dW + Adam tiles as ONE launch: the tiles wait for the roles' flag granules
+      DwArgs dw = dw_build(h, true, B, true, false);
+      DwKArgs kd;
+      if (fill_dw_kargs(dw, &kd) < 0) { set_err("merged phase 1: bad dW table"); return OPRL_ERR_INVALID; }
+      const int slices = (B + kR - 1) / kR;
+      kd.gate.rows = fa.gate_flags; kd.gate.n_rows = 4 * slices;
+      kd.gate.seed = fa.y_granules; kd.gate.n_seed = B;      // the seeds come as granules, one per row
+      kd.gate.late_dY = h->ws_critic[0].dY[c.critics[0].n_layers - 1];
+      kd.gate.tag = h->epoch; kd.gate.spin = h->debug_expire == 7 ? 0 : (1 << 20);
+      kd.gate.err = h->err_dev; kd.gate.err_code = (1u << 8) | 7u;      // KERN_PHASE1, SITE_DW_GATE (csrc/tp3.h)
+      prof_begin(4, st);
+      hipError_t e = launch_ddpg_phase1_dw(fa, kd, st);
+      prof_end(st);
+      HIPC(e);
+      HIPC(chain_after(st));
+      return OPRL_OK;
+    }
     prof_begin(4, st);
     hipError_t e = launch_ddpg_phase1(fa, st);
     prof_end(st);
@@ -1199,13 +1233,14 @@ int check_device_error(const oprl_learner* h) {
                                "TD-target hand-off (role B never received y from role A)",
                                "twin-target exchange between role A and the role-C cluster",
                                "SAC phase 2 pair exchange (critic 2's cluster never delivered)",
-                               "gradient tile exchange with another rank", "peer-window flag of another rank"};
+                               "gradient tile exchange with another rank", "peer-window flag of another rank",
+                               "gate of the dW tiles riding on a phase launch (a role never flagged its rows / seeds)"};
   const unsigned k = (code >> 8) & 0xff, w = code & 0xff;
   set_err("device error 0x%x: a bounded cross-workgroup wait expired in %s at the %s; the results of that "
           "update (and everything after it) are poisoned with NaN.  Typical causes: the launch's workgroups were "
           "not co-resident (another process or learner held the GPU's compute units for longer than the wait bound), "
           "or a data-parallel peer died.  Restore a checkpoint, then oprl_learner_clear_error().",
-          code, k < 6 ? kern[k] : "?", w < 7 ? site[w] : "?");
+          code, k < 6 ? kern[k] : "?", w < 8 ? site[w] : "?");
   return OPRL_ERR_STATE;
 }
 
@@ -1233,7 +1268,7 @@ extern "C" int oprl_debug_noise(oprl_learner* h, int32_t stream_id, uint64_t cou
 }
 
 extern "C" int oprl_learner_debug_expire(oprl_learner* h, int32_t site) {
-  if (!h || site < 0 || site > 6) { set_err("oprl_learner_debug_expire: invalid argument"); return OPRL_ERR_INVALID; }
+  if (!h || site < 0 || site > 7) { set_err("oprl_learner_debug_expire: invalid argument"); return OPRL_ERR_INVALID; }
   h->debug_expire = site;
   return OPRL_OK;
 }
@@ -1575,7 +1610,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
             (size_t)nc * B * A + (size_t)nc * B + (size_t)B * 128 + 2 * (size_t)B;
   floats += (size_t)(nc + 1) * n_slices * 4 + 16;
   floats += (size_t)B * (2 * S + A + 2);
-  floats += 64 * 32 + 6 * (size_t)B;      // (granule arrays: y, q1, q2)
+  floats += 64 * 32 + 6 * (size_t)B + 512;      // (granule arrays: y, q1, q2; 256 gate flags)
   if (h->bf16) {
     floats += 2 * ((size_t)net_pack16_floats(cfg->actor) + 64);
     for (int j = 0; j < nc; ++j) floats += 2 * ((size_t)net_pack16_floats(cfg->critics[j]) + 64);
@@ -1616,7 +1651,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   h->part_a = p.take<float>((size_t)n_slices * 4);
   h->scalars = p.take<float>(16);
   h->alpha_grad = cfg->log_alpha_grad ? cfg->log_alpha_grad : p.take<double>(2);
-  h->y_granules = p.take<unsigned long long>((size_t)3 * B);
+  h->y_granules = p.take<unsigned long long>((size_t)3 * B + 256);
   h->bs = p.take<float>((size_t)B * S);
   h->ba = p.take<float>((size_t)B * A);
   h->br = p.take<float>(B);
@@ -1673,6 +1708,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->no_p2_pair = (np2 != nullptr && atoi(np2) != 0);
     const char* nl = getenv("OPRL_AMD_NO_LEAN");
     h->no_lean = (nl != nullptr && atoi(nl) != 0) ? 1 : 0;
+    const char* nmg = getenv("OPRL_AMD_NO_MERGE");
+    h->no_merge = (nmg != nullptr && atoi(nmg) != 0) ? 1 : 0;
     const char* nw = getenv("OPRL_AMD_NO_WIDE");
     h->no_wide = (nw != nullptr && atoi(nw) != 0) ? 1 : 0;
     // the generic per-net launches on clusters of 4 (slice_tp.hip): any net of the common shape
@@ -1974,7 +2011,7 @@ extern "C" int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, 
       h->src.gather = h->staged_ready ? 0 : 1;
       const int prefetch = (k + 1 < K) ? 1 : 0;
       h->epoch += 1;
-      if (h->epoch == 0) { h->epoch = 1; HIPC(hipMemsetAsync(h->y_granules, 0, (size_t)3 * h->Bmax * sizeof(unsigned long long), st)); }
+      if (h->epoch == 0) { h->epoch = 1; HIPC(hipMemsetAsync(h->y_granules, 0, ((size_t)3 * h->Bmax + 256) * sizeof(unsigned long long), st)); }
       p1[l] = ddpg_args(h, B);
       RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &p1[l].cluster_tag));
       p2[l] = ddpg_args(h, B);

@@ -44,7 +44,7 @@ struct Tp {
 };
 
 // Wait sites (low byte of the error word) and kernels (second byte): oprl_learner_check() decodes them.
-enum WaitSite : unsigned { SITE_CLUSTER = 1, SITE_TD_TARGET = 2, SITE_TWIN_SPLIT = 3, SITE_P2_PAIR = 4, SITE_DW_TILE = 5, SITE_WINDOW = 6 };
+enum WaitSite : unsigned { SITE_CLUSTER = 1, SITE_TD_TARGET = 2, SITE_TWIN_SPLIT = 3, SITE_P2_PAIR = 4, SITE_DW_TILE = 5, SITE_WINDOW = 6, SITE_DW_GATE = 7 };
 enum WaitKernel : unsigned { KERN_PHASE1 = 1, KERN_PHASE2 = 2, KERN_SLICE_TP = 3, KERN_DW_XCHG = 4, KERN_P2P = 5 };
 // First report wins (the word is host-mapped memory: one system-scope store, only ever on the error path).
 __device__ __forceinline__ void report_expired(unsigned* err, unsigned code) {
@@ -122,6 +122,10 @@ struct Tp3Store {
   // what a layer-0 tile of k_dw_adam reads from a member's buffer is then one contiguous run of full
   // cache lines instead of 64-byte pieces of 1 KB rows (DwArgs::dy_tiled).  0: row-major [B][W].
   int dY0_tile_rows = 0;
+  // tp4 passes only: X / dY rows leave with write-through stores (sc1) — their consumer is a tile workgroup of
+  // the SAME launch (merged phase kernels, csrc/fused_ddpg.hip), possibly on another XCD, with no kernel
+  // boundary in between
+  bool wt = false;
 };
 
 // Forward.  x0s: [kR][kX0Ld] input tile (zero padded; no barrier needed).  On return h1

@@ -18,7 +18,8 @@ def _algo(**kw):
     return DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device="cuda", max_batch=B, **kw).create()
 
 
-@pytest.mark.parametrize("site,text", [(2, "TD-target hand-off"), (1, "cluster all-reduce")])
+@pytest.mark.parametrize("site,text", [(2, "TD-target hand-off"), (1, "cluster all-reduce"),
+                                       (7, "gate of the dW tiles")])   # 7: the tiles riding on phase 1's launch
 def test_expired_wait_is_reported_not_silent(site, text):
     algo = _algo()
     L = algo.learner
