@@ -125,7 +125,7 @@ def cpu_baseline(budget_s: float = 14.0):
 
 # ---- the other BASELINE.json configurations, the bf16 mode and the through-the-API rate --------
 PEAK_BF16_MATRIX_TFLOPS = 2500.0       # dense bf16 MFMA (MI355X_MICROARCH.md)
-PMC_FILE = {"f32": "r02h_pmc_traffic.json", "bf16": "r02h_pmc_traffic_bf16.json"}
+PMC_FILE = {"f32": "r02i_pmc_traffic.json", "bf16": "r02i_pmc_traffic_bf16.json"}
 PEAK_HBM_TBS = 8.0
 # name -> (class name, S, A, B, constructor extras, algorithmic GFLOP / update, state MB / update): BASELINE.md section 4
 BASELINE_CONFIGS = {
@@ -532,7 +532,10 @@ def main():
                     for i in range(NK) if cnt[i]}
             # dominant kernel: phase 1 of the fused path (falls back to the generic slice kernel)
             dom = "k_ddpg_phase1" if "k_ddpg_phase1" in kern else "k_mlp_slice"
-            macs = MACS_P1 if dom == "k_ddpg_phase1" else MACS_SLICE / kern[dom]["launches_per_step"]
+            # merged launches (DDPG): the critic's dW + Adam tiles ride on phase 1's launch — one k_dw_adam launch per
+            # step is left, and the dominant launch's work includes the critic's dW GEMMs
+            merged = dom == "k_ddpg_phase1" and kern.get("k_dw_adam", {}).get("launches_per_step", 2.0) < 1.5
+            macs = (MACS_P1 + (F_CRITIC if merged else 0)) if dom == "k_ddpg_phase1" else MACS_SLICE / kern[dom]["launches_per_step"]
             flop_per_launch = 2.0 * B * macs
             if kern[dom]["us_per_launch"] <= 0.0:          # (a very short run: the overhead estimate swallowed the reading)
                 kern[dom]["us_per_launch"] = kern[dom]["us_per_launch_raw"]
@@ -540,12 +543,13 @@ def main():
             traffic = mfma_util = None
             try:   # HBM bytes per launch and matrix-core utilisation from the committed rocprofv3 PMC passes of this same command
                 pmc = json.load(open(ROOT / "profiles" / PMC_FILE[args.precision]))
-                traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
-                mfma_util = pmc.get(dom, {}).get("mfma_util")
+                pk = "k_ddpg_phase1_dw" if merged and "k_ddpg_phase1_dw" in pmc else dom
+                traffic = pmc.get(pk, {}).get("hbm_bytes_per_launch")
+                mfma_util = pmc.get(pk, {}).get("mfma_util")
             except Exception:  # noqa: BLE001
                 pass
             peak = PEAK_F32_MATRIX_TFLOPS if args.precision == "f32" else PEAK_BF16_MATRIX_TFLOPS
-            roof = dict(bound="mfma", kernel=f"{dom}<256> (" + ("exact-fp32 v_mfma_f32_16x16x4_f32" if args.precision == "f32"
+            roof = dict(bound="mfma", kernel=(f"{dom}_dw (phase 1 + the critic's dW / Adam tiles in one launch; " if merged else f"{dom}<256> (") + ("exact-fp32 v_mfma_f32_16x16x4_f32" if args.precision == "f32"
                                                                else "v_mfma_f32_16x16x32_bf16, fp32 accumulate") + ")",
                         achieved=round(ach, 3), peak=peak, unit="TFLOP/s",
                         frac=round(ach / peak, 5), traffic=traffic, mfma_util=mfma_util,
@@ -558,13 +562,13 @@ def main():
                              f"(serialised pass of {P} steps) minus event_overhead_us, the per-launch "
                              "excess of that pass over the un-instrumented timed loop (where the same "
                              "launches run back to back, so a step is the sum of their durations); they "
-                             "agree with rocprofv3 --kernel-trace --stats (profiles/r02h_kernel_stats.csv); "
+                             "agree with rocprofv3 --kernel-trace --stats (profiles/r02i_kernel_stats.csv); "
                              "sum of kernel time per step = "
                              f"{sum(k['us_per_step'] for k in kern.values()):.1f} us; traffic = "
                              f"(2*FETCH_SIZE + WRITE_SIZE) KB and mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (average launch duration x 2.4 GHz x 1024 SIMDs) "
                              f"from profiles/{PMC_FILE[args.precision]} (separate --pmc passes, tools/profile_round.sh); the "
-                             "launch is one workgroup per CU: 16 slices x (4 + 8 + 4) cluster members in the fp32 mode "
-                             "(role A on clusters of eight CUs: 256 workgroups), 16 x 3 x 4 = 192 in the bf16 mode, "
+                             "launch is 16 slices x 3 roles x 4 cluster members = 192 workgroups plus the critic's 152 dW / Adam tile "
+                             "workgroups, which start where CUs are free and wait for the roles' flag granules (DESIGN.md 4.4), "
                              "and the step is a chain of 4 dependent launches bound by latency, not by "
                              "the matrix cores (DESIGN.md section 6)")
         multi = None
