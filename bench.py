@@ -206,7 +206,7 @@ def api_rate(dev, replay, n=3000):
     t.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     return dict(value=round(n / dt, 1), unit="steps/s", us_per_step=round(dt / n * 1e6, 2), steps=n,
-                path="EpisodicReplayBuffer.sample() + DDPG.update() from Python (two C calls: gather kernel, 4 update launches)")
+                path="EpisodicReplayBuffer.sample() + DDPG.update() from Python (two C calls: gather kernel, 3 update launches)")
 
 
 def multi_learner(n, dev, local_rank, steps):

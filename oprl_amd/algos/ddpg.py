@@ -2,7 +2,7 @@
 
 Same dataclass fields, ``create()`` / ``update()`` contract and attributes as
 the reference (/root/reference/src/oprl/algos/ddpg.py:16-107); ``update()`` is
-one call into liboprl_amd.so (4 kernel launches on the fused path, no host sync) instead of
+one call into liboprl_amd.so (3 kernel launches on the fused path — phase 1 with the critic's dW + Adam tiles riding on it, phase 2, the actor's dW + Adam — no host sync) instead of
 autograd + two torch Adam steps + 12 Polyak tensor ops."""
 from __future__ import annotations
 
