@@ -150,7 +150,7 @@ class EpisodicReplayBuffer(ReplayBufferProtocol):
             self._tensors["dones"][e, l] = float(done)
         self.ep_lens[e] += 1
         self._number_transitions = min(self._number_transitions + 1, self.buffer_size_transitions)
-        self._lens_dirty = True
+        self._touch_len(e)
         if episode_done:
             self._inc_episode()
 
@@ -180,7 +180,7 @@ class EpisodicReplayBuffer(ReplayBufferProtocol):
                 self._tensors["dones"][e, l:l + n, 0] = t.from_numpy(rows[:, S + A + 1])
             self.ep_lens[e] += n
             self._number_transitions = min(self._number_transitions + n, self.buffer_size_transitions)
-            self._lens_dirty = True
+            self._touch_len(e)
         if episode_done:
             self._inc_episode()
 
@@ -194,7 +194,7 @@ class EpisodicReplayBuffer(ReplayBufferProtocol):
         self.episodes_counter = min(self.episodes_counter + 1, self._max_episodes)
         self._number_transitions -= self.ep_lens[self._ep_pointer]
         self.ep_lens[self._ep_pointer] = 0
-        self._lens_dirty = True
+        self._touch_len(self._ep_pointer)
 
     def add_episode(self, episode: list[Transition]) -> None:
         for s, a, r, d, _ in episode:
@@ -202,16 +202,28 @@ class EpisodicReplayBuffer(ReplayBufferProtocol):
         self._inc_episode()
 
     # read path ------------------------------------------------------------------
+    def _touch_len(self, e: int) -> None:
+        """ep_lens[e] changed through this class: keep the int32 mirror the library reads in step (one element — a
+        mirror rebuilt from the list costs O(episodes) of python per env step, 20 us at a thousand episodes)."""
+        mirror = getattr(self, "_lens_np", None)
+        if mirror is None or len(mirror) != len(self.ep_lens):
+            self._lens_dirty = True            # no mirror yet (or ep_lens was replaced): rebuild at the next sync
+        else:
+            mirror[e] = self.ep_lens[e]
+            self._lens_touched = True
+
     def _sync_lens(self) -> None:
-        if self._lens_dirty:
+        if self._lens_dirty:                   # set by create / load_state_dict / whoever assigns ep_lens directly
+            self._lens_np = np.asarray(self.ep_lens, dtype=np.int32).copy()
+            self._lens_dirty = False
+            self._lens_touched = True
+        if getattr(self, "_lens_touched", False):
             n = self.episodes_counter
-            # (a ctypes array built from the list costs O(episodes) python work per env step)
-            arr = np.asarray(self.ep_lens[:max(n, 1)], dtype=np.int32)
             with _capi.on_device(self._dev):
-                _capi.check(self._lib.oprl_replay_set_lens(self._handle, arr.ctypes.data_as(C.POINTER(C.c_int32)), n,
+                _capi.check(self._lib.oprl_replay_set_lens(self._handle, self._lens_np.ctypes.data_as(C.POINTER(C.c_int32)), n,
                                                            _capi.current_stream()),
                             "oprl_replay_set_lens")
-            self._lens_dirty = False
+            self._lens_touched = False
 
     @property
     def handle(self):
