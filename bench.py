@@ -568,7 +568,9 @@ def main():
                              f"(2*FETCH_SIZE + WRITE_SIZE) KB and mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (average launch duration x 2.4 GHz x 1024 SIMDs) "
                              f"from profiles/{PMC_FILE[args.precision]} (separate --pmc passes, tools/profile_round.sh); the "
                              "launch is 16 slices x 3 roles x 4 cluster members = 192 workgroups plus the critic's 152 dW / Adam tile "
-                             "workgroups, which start where CUs are free and wait for the roles' flag granules (DESIGN.md 4.4), "
+                             "workgroups, which start where CUs are free and wait for the roles' flag granules (DESIGN.md 4.4; the "
+                             "launch spans the roles' chain AND the tiles' tail: the same phase-1 work as a launch of its own, "
+                             "OPRL_AMD_NO_MERGE=1, reads frac 0.094 at 1.8 us more per update), "
                              "and the step is a chain of 4 dependent launches bound by latency, not by "
                              "the matrix cores (DESIGN.md section 6)")
         multi = None
