@@ -571,7 +571,7 @@ def main():
                              "workgroups, which start where CUs are free and wait for the roles' flag granules (DESIGN.md 4.4; the "
                              "launch spans the roles' chain AND the tiles' tail: the same phase-1 work as a launch of its own, "
                              "OPRL_AMD_NO_MERGE=1, reads frac 0.094 at 1.8 us more per update), "
-                             "and the step is a chain of 4 dependent launches bound by latency, not by "
+                             "and the step is a chain of dependent launches (three with the merged launch, four without) bound by latency, not by "
                              "the matrix cores (DESIGN.md section 6)")
         multi = None
         group = None
