@@ -201,7 +201,7 @@ int oprl_learner_set_counters(oprl_learner* h, const int64_t in_host[OPRL_N_COUN
  * step_n / dp_* call and after the synchronisation inside oprl_learner_read_scalars; once set those calls
  * return OPRL_ERR_STATE with the kernel and wait site in oprl_last_error() until it is cleared.
  * oprl_learner_check polls it explicitly (synchronise the stream first for a definitive answer);
- * oprl_learner_debug_expire (tests) makes one wait site (2 = TD-target hand-off, 1 = cluster all-reduce;
+ * oprl_learner_debug_expire (tests) makes one wait site (2 = TD-target hand-off, 1 = cluster all-reduce, 7 = gate of the dW tiles riding on phase 1's launch;
  * 0 = off) give up immediately in subsequent launches. */
 int oprl_learner_check(oprl_learner* h);
 int oprl_learner_clear_error(oprl_learner* h);
