@@ -356,6 +356,197 @@ inline LwRun lw_run(int slices, int nets, int n_cus) {
 }
 constexpr size_t kLwRunLds = sizeof(float) * (2 * kR * lds_ld(512) + kLwMaxRun * 8 * 256);
 
+// ---- 32-row runs -------------------------------------------------------------------------------------
+// A CU takes data in at ≈45 KB/us whatever the request order, and k_lw_mid_run's 16 rows x 10
+// tiles are 32 KB of rows + 320 KB of weight fragments per workgroup: 8 us before the last MFMA can issue.
+// The same ten 16x16 output tiles cut as 32 rows x 5 column tiles are 64 + 160 KB.  Here a workgroup owns
+// 32 rows x a run of 5 or 6 column tiles of ONE net (32 tiles = 4 runs of 5 + 2 of 6: no run straddles two
+// nets, 5 nets x 6 runs x 8 row slices = 240 workgroups for TQC at B = 256).  Wave w contracts K-eighth
+// (w & 7) of every second tile of the run (parity w >> 3) for BOTH row tiles with the same B fragments
+// (a fragment is requested by exactly one wave); the partial tiles meet in LDS — over the input rows, which
+// are dead by then — and are summed in K order.
+constexpr int kLw2Rows = 32;
+constexpr int kLw2MaxRun = 6;
+struct LwRun2 { int slices, nets, rpn, base, rem, ppx; };   // runs per net; tiles per run = base (+1 for the first rem runs); pairs per XCD
+
+template <int MODE, class P = PrecF32>
+__global__ __launch_bounds__(kThreads) void k_lw_mid_run2(const MlpMultiArgs M, int l, const LwRun2 R) {
+  constexpr bool BWD = MODE == 1, FIN = MODE == 2;
+  constexpr int NSE = 64 / P::KS;               // macro steps of a K-eighth (64 columns): 4 / 2
+  constexpr int NSW = 512 / P::KS;
+  constexpr int WIDTH = 512, WL = lds_ld(WIDTH), NTW = WIDTH / 16;
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  float* xs = dsm;                              // [32][WL] input rows of the layer
+  float* xin = dsm + kLw2Rows * WL;             // FIN: [32][kX0Ld] net input rows
+  float* scr = dsm;                             // after the MFMAs: [row tile][run tile][K-eighth][64 lanes][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  // XCD x owns the (net, run) pairs [x * ppx, (x + 1) * ppx) with all their row slices: a run's weights
+  // cross the fabric once and an XCD reads the rows of at most two nets
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int pl = j / R.slices, pair = xcd * R.ppx + pl, slice = j - pl * R.slices;
+  if (pair >= R.nets * R.rpn) return;
+  const int net = pair / R.rpn, run = pair - net * R.rpn;
+  const int t0 = run * R.base + min(run, R.rem), nt = R.base + (run < R.rem ? 1 : 0);
+  const MlpArgs& A = lw_args(net);
+  const int row0 = slice * kLw2Rows, B = A.B;
+  const int ke = wave & 7, par = wave >> 3;
+
+  // ---- requests, in the order of use: rows, (first-layer fragments,) B fragments, bias / masks
+  f32x4 v[4];
+  float x0v = 0.f;
+  f32x4 w0f[2][2];
+  float b0f[2];
+  const int K0 = FIN ? A.net.dims[0] : 0, NS0 = FIN ? cdiv(K0, 16) : 0;   // <= 2 (host-checked)
+  if constexpr (FIN) {
+    const int row = tid >> 5, col = tid & 31, gr = row0 + row;   // one element of the [32 x 32] input tile each
+    if (gr < B && col < K0)
+      x0v = col < A.k0 ? A.x0[(size_t)gr * A.k0 + col] : A.x1[(size_t)gr * A.k1 + col - A.k0];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int tile = wave + 16 * q;
+      b0f[q] = A.net.b[0][16 * tile + i];
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+        w0f[q][st] = st < NS0 ? ld4(A.net.pf[0] + (((size_t)tile * NS0 + st) * 64 + lane) * 4)
+                              : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  } else {
+    const float* src = BWD ? A.dYg[l] : A.Xg[l];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int idx = tid + h * kThreads;                 // 32 rows x 128 float4
+      const int row = idx >> 7, col = (idx & 127) * 4, gr = row0 + row;
+      v[h] = gr < B ? ld4(src + (size_t)gr * WIDTH + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 b[3][NSE];
+  {
+    const float* pk0 = (BWD ? A.net.pb[l] : A.net.pf[l]) + ((size_t)NSE * ke * 64 + lane) * 4;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int tl = par + 2 * q;
+#pragma unroll
+      for (int s = 0; s < NSE; ++s) b[q][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (tl < nt) {
+        const float* pk = pk0 + (size_t)(t0 + tl) * NSW * 256;
+#pragma unroll
+        for (int s = 0; s < NSE; ++s) b[q][s] = ld4(pk + s * 256);
+      }
+    }
+  }
+  // this thread's (up to three) output elements: out tile ot = row tile * kLw2MaxRun + run tile
+  size_t e_off[3];
+  float e_x[3];
+  bool e_ok[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int e = tid + k * kThreads;
+    const int ot = e >> 8, r = e & 255, rt = ot / kLw2MaxRun, tl = ot - rt * kLw2MaxRun;
+    const int gr = row0 + rt * 16 + (r >> 4), col = (t0 + tl) * 16 + (r & 15);
+    e_ok[k] = tl < nt && gr < B;
+    e_off[k] = e_ok[k] ? (size_t)gr * WIDTH + col : 0;
+    e_x[k] = 0.f;
+    if (e_ok[k]) e_x[k] = BWD ? A.Xg[l][e_off[k]] : A.net.b[l][col];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  if constexpr (FIN) {
+    xin[(tid >> 5) * kX0Ld + (tid & 31)] = x0v;
+    __syncthreads();
+    // dW's copies: the net's input rows (the run that starts a net stores them, from the registers) and,
+    // below, h1 — every run its own columns (one run storing all 64 KB was 1.5 us of the launch)
+    if (run == 0 && A.Xg[0] != nullptr) {
+      const int row = tid >> 5, col = tid & 31;
+      if (row0 + row < B && col < K0) A.Xg[0][(size_t)(row0 + row) * A.ldx0 + col] = x0v;
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const float* xr = xin + (rt * 16 + i) * kX0Ld + 4 * kk;
+      const f32x4 a0 = ld4(xr), a1 = ld4(xr + 16);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        mac4(a0, w0f[q][0], acc);
+        mac4(a1, w0f[q][1], acc);
+        float* o = xs + (rt * 16 + kk * 4) * WL + 16 * (wave + 16 * q) + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r * WL] = fmaxf(acc[r] + b0f[q], 0.f);
+      }
+    }
+    __syncthreads();                          // h1 rows complete
+    {
+      const int c4n = nt * 4, row = tid / c4n, col = t0 * 16 + (tid - row * c4n) * 4;
+      if (row < kLw2Rows && row0 + row < B)
+        *reinterpret_cast<f32x4*>(A.Xg[1] + (size_t)(row0 + row) * WIDTH + col) = ld4(xs + row * WL + col);
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int idx = tid + h * kThreads;
+      *reinterpret_cast<f32x4*>(xs + (idx >> 7) * WL + (idx & 127) * 4) = v[h];
+    }
+    __syncthreads();
+  }
+
+  // ---- partial tiles: the wave's K-eighth of its tiles, both row tiles against the same B fragments
+  f32x4 acc[3][2];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      acc[q][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (par + 2 * q < nt) {
+        const float* xr = xs + (rt * 16 + i) * WL + 64 * ke + 4 * kk;
+#pragma unroll
+        for (int s = 0; s < NSE; ++s) P::mac(xr, s, b[q][s], acc[q][rt]);
+      }
+    }
+  __syncthreads();                            // every wave is done with the rows: the partial tiles go over them
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int tl = par + 2 * q;
+    if (tl < nt)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+        *reinterpret_cast<f32x4*>(scr + ((size_t)((rt * kLw2MaxRun + tl) * 8 + ke) * 64 + lane) * 4) = acc[q][rt];
+  }
+  __syncthreads();
+
+  // ---- K-ordered sum, bias + ReLU (forward) or ReLU mask (backward), rows out
+  float* dst = BWD ? A.dYg[l - 1] : A.Xg[l + 1];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (!e_ok[k]) continue;
+    const int e = tid + k * kThreads;
+    const int ot = e >> 8, r = e & 255, row = r >> 4, col = r & 15;
+    const float* sp = scr + ((size_t)(ot * 8) * 64 + (row >> 2) * 16 + col) * 4 + (row & 3);
+    float vs = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) vs += sp[p * 256];
+    if constexpr (BWD) dst[e_off[k]] = e_x[k] > 0.f ? vs : 0.f;
+    else dst[e_off[k]] = fmaxf(vs + e_x[k], 0.f);
+  }
+}
+
+inline LwRun2 lw_run2(int B, int nets, int n_cus) {
+  LwRun2 r;
+  r.slices = (B + kLw2Rows - 1) / kLw2Rows;
+  r.nets = nets;
+  int rpn = n_cus / (nets * r.slices);
+  const int min_rpn = (32 + kLw2MaxRun - 1) / kLw2MaxRun;
+  if (rpn < min_rpn) rpn = min_rpn;
+  if (rpn > 32) rpn = 32;
+  r.rpn = rpn;
+  r.base = 32 / rpn;
+  r.rem = 32 % rpn;
+  r.ppx = (nets * rpn + 7) / 8;
+  return r;
+}
+constexpr size_t kLwRun2Lds = sizeof(float) * (2 * kLw2MaxRun * 8 * 256);   // partial tiles 96 KB >= rows 65 KB + net input 13 KB
+static_assert(kLwRun2Lds >= sizeof(float) * (kLw2Rows * lds_ld(512) + kLw2Rows * kX0Ld), "rows + net input fit under the partial tiles");
+
 template <int WIDTH>
 __global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M) {
   __shared__ __attribute__((aligned(16))) float smem[LwLds<WIDTH>::total];
@@ -439,6 +630,15 @@ hipError_t init_layerwise_attrs() {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLwRunLds);
     if (e != hipSuccess) return e;
   }
+  const void* k2[6] = {reinterpret_cast<const void*>(&k_lw_mid_run2<0>), reinterpret_cast<const void*>(&k_lw_mid_run2<1>),
+                       reinterpret_cast<const void*>(&k_lw_mid_run2<2>),
+                       reinterpret_cast<const void*>(&k_lw_mid_run2<0, PrecBF16>),
+                       reinterpret_cast<const void*>(&k_lw_mid_run2<1, PrecBF16>),
+                       reinterpret_cast<const void*>(&k_lw_mid_run2<2, PrecBF16>)};
+  for (const void* k : k2) {
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLwRun2Lds);
+    if (e != hipSuccess) return e;
+  }
   return hipSuccess;
 }
 
@@ -458,6 +658,21 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
   const bool equal_wgs = equal_env && !bf16;
   const LwRun r = lw_run(slices, n, n_cus > 0 ? n_cus : 256);
   const dim3 runs(8 * r.gpx * slices);
+  // 32-row runs (k_lw_mid_run2) unless OPRL_AMD_LW_RUN16=1 (A/B and tests: the 16-row runs of k_lw_mid_run)
+  static const bool run16_env = [] { const char* e = getenv("OPRL_AMD_LW_RUN16"); return e != nullptr && atoi(e) != 0; }();
+  const LwRun2 r2 = lw_run2(a[0].B, n, n_cus > 0 ? n_cus : 256);
+  const dim3 runs2(8 * r2.ppx * r2.slices);
+  auto mid = [&](int mode, int l) {
+    if (run16_env) {
+      if (mode == 0) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run<0, PrecBF16>), runs, blk, kLwRunLds, st, m, l, r); else hipLaunchKernelGGL((k_lw_mid_run<0>), runs, blk, kLwRunLds, st, m, l, r); }
+      if (mode == 1) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run<1, PrecBF16>), runs, blk, kLwRunLds, st, m, l, r); else hipLaunchKernelGGL((k_lw_mid_run<1>), runs, blk, kLwRunLds, st, m, l, r); }
+      if (mode == 2) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run<2, PrecBF16>), runs, blk, kLwRunLds, st, m, l, r); else hipLaunchKernelGGL((k_lw_mid_run<2>), runs, blk, kLwRunLds, st, m, l, r); }
+    } else {
+      if (mode == 0) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<0, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2); else hipLaunchKernelGGL((k_lw_mid_run2<0>), runs2, blk, kLwRun2Lds, st, m, l, r2); }
+      if (mode == 1) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<1, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2); else hipLaunchKernelGGL((k_lw_mid_run2<1>), runs2, blk, kLwRun2Lds, st, m, l, r2); }
+      if (mode == 2) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<2, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2); else hipLaunchKernelGGL((k_lw_mid_run2<2>), runs2, blk, kLwRun2Lds, st, m, l, r2); }
+    }
+  };
   if (a[0].do_fwd) {
     // a narrow net input (two macro steps) is folded into the first hidden layer's launch
     bool fuse_in = !equal_wgs && L >= 3;
@@ -465,21 +680,14 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
     if (!fuse_in) hipLaunchKernelGGL(k_lw_in<512>, wide, blk, 0, st, m, g);
     for (int l = 1; l + 1 < L; ++l) {
       if (equal_wgs) hipLaunchKernelGGL((k_lw_mid<512, false>), wide, blk, 0, st, m, l, g);
-      else if (l == 1 && fuse_in) {
-        if (bf16) hipLaunchKernelGGL((k_lw_mid_run<2, PrecBF16>), runs, blk, kLwRunLds, st, m, l, r);
-        else hipLaunchKernelGGL((k_lw_mid_run<2>), runs, blk, kLwRunLds, st, m, l, r);
-      } else {
-        if (bf16) hipLaunchKernelGGL((k_lw_mid_run<0, PrecBF16>), runs, blk, kLwRunLds, st, m, l, r);
-        else hipLaunchKernelGGL((k_lw_mid_run<0>), runs, blk, kLwRunLds, st, m, l, r);
-      }
+      else mid(l == 1 && fuse_in ? 2 : 0, l);
     }
   }
   hipLaunchKernelGGL(k_lw_head<512>, narrow, blk, 0, st, m);
   if (a[0].do_bwd) {
     for (int l = L - 2; l >= 1; --l) {
       if (equal_wgs) hipLaunchKernelGGL((k_lw_mid<512, true>), wide, blk, 0, st, m, l, g);
-      else if (bf16) hipLaunchKernelGGL((k_lw_mid_run<1, PrecBF16>), runs, blk, kLwRunLds, st, m, l, r);
-      else hipLaunchKernelGGL((k_lw_mid_run<1>), runs, blk, kLwRunLds, st, m, l, r);
+      else mid(1, l);
     }
     if (a[0].dact_cols > 0) hipLaunchKernelGGL(k_lw_dact<512>, narrow, blk, 0, st, m);
   }
