@@ -10,7 +10,9 @@
 // accesses, the three fragment-order packs written block by block from the staged tile.
 // Reference ops replaced: loss.backward()'s addmm-backward + optim.Adam.step + soft_update
 // (tqc.py:150-177, nn_functions.py:5-10).
+#include <cstring>
 #include "kernels.h"
+#include "dw_body.h"
 
 namespace oprl {
 
@@ -24,12 +26,26 @@ struct DwWideArgs {
   int tile_end[kWMaxItems];
   DwItem items[kWMaxItems];
   int n_items, B;
+  int total;                             // 64 x 64 tiles = workgroups of this kernel's own work
   AdamScalars ad;
 };
+static_assert(kWThreads == kDwThreads, "the riding k_dw_adam tiles run in this kernel's workgroups");
+constexpr int kWLdsFloats = 2 * kWChunk * kWLd > kDwLdsFloats ? 2 * kWChunk * kWLd : kDwLdsFloats;
 
-__global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A) {
-  __shared__ __attribute__((aligned(16))) float stA[kWChunk][kWLd];   // dY rows [b][n]; later the new W tile
-  __shared__ __attribute__((aligned(16))) float stX[kWChunk][kWLd];   // X  rows [b][k]; later the new target tile
+// `N`: the SAME update's narrow layers (TQC's critics: the 30 x 512 input layers and the 512 x 25 heads), whose
+// 16 x 32 tiles of k_dw_adam (dw_body.h) ride as the workgroups past `total` — dispatched last, they fill the
+// CUs the 640 wide tiles' second round leaves idle, instead of a launch of their own (9 us).  N.n_items == 0:
+// nothing rides.
+__global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, const DwKArgs N) {
+  __shared__ __attribute__((aligned(16))) float lds[kWLdsFloats];
+  if ((int)blockIdx.x >= A.total) {
+    const char* kp = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    dw_adam_body<false>(*(const DwKArgs*)(kp + ((sizeof(DwWideArgs) + alignof(DwKArgs) - 1) / alignof(DwKArgs)) * alignof(DwKArgs)),
+                        lds, (int)blockIdx.x - A.total);
+    return;
+  }
+  float (*stA)[kWLd] = reinterpret_cast<float (*)[kWLd]>(lds);                      // dY rows [b][n]; later the new W tile
+  float (*stX)[kWLd] = reinterpret_cast<float (*)[kWLd]>(lds + kWChunk * kWLd);     // X  rows [b][k]; later the new target tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const DwWideArgs* KA = (const DwWideArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   int item = 0;
@@ -174,7 +190,7 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A) 
     } else {                     // W pack (online, target): tiles over n, steps over k
       float* dst = which == 0 ? I.pf : (polyak ? I.tpf : nullptr);
       if (dst == nullptr) continue;
-      const float (*src)[kWLd] = which == 0 ? stA : stX;
+      float (*src)[kWLd] = which == 0 ? stA : stX;
       *reinterpret_cast<f32x4*>(dst + (((size_t)((n_base >> 4) + bn) * NSk + (k_base >> 4) + bk) * 64 + l) * 4) =
           *reinterpret_cast<const f32x4*>(&src[bn * 16 + li][bk * 16 + 4 * lk]);
     }
@@ -197,7 +213,7 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A) 
     } else {
       float* dst = which == 0 ? I.pf16 : (polyak ? I.tpf16 : nullptr);
       if (dst == nullptr) continue;
-      const float (*src)[kWLd] = which == 0 ? stA : stX;
+      float (*src)[kWLd] = which == 0 ? stA : stX;
       *reinterpret_cast<bf16x8*>(dst + (((size_t)((n_base >> 4) + b16) * NSk2 + (k_base >> 5) + b32) * 64 + l) * 4) =
           cvt_bf16x8(*reinterpret_cast<const f32x4*>(&src[b16 * 16 + li][b32 * 32 + 4 * lk]),
                      *reinterpret_cast<const f32x4*>(&src[b16 * 16 + li][b32 * 32 + 16 + 4 * lk]));
@@ -215,7 +231,9 @@ bool dw_wide_item_ok(const DwItem& it, const DwArgs& a) {
   return true;
 }
 
-hipError_t launch_dw_adam_wide(const DwItem* items, int n_items, int B, const AdamScalars& ad, hipStream_t st) {
+// ride / ride_blocks: a filled k_dw_adam argument block and its grid (tiles, + 1 with a temperature job), or null / 0
+hipError_t launch_dw_adam_wide(const DwItem* items, int n_items, int B, const AdamScalars& ad, hipStream_t st,
+                               const DwKArgs* ride, int ride_blocks) {
   if (n_items < 1 || n_items > kWMaxItems) return hipErrorInvalidValue;
   DwWideArgs k;
   int total = 0;
@@ -225,8 +243,10 @@ hipError_t launch_dw_adam_wide(const DwItem* items, int n_items, int B, const Ad
     k.tile_end[j] = total;
   }
   for (int j = n_items; j < kWMaxItems; ++j) { k.items[j] = items[0]; k.tile_end[j] = total; }
-  k.n_items = n_items; k.B = B; k.ad = ad;
-  hipLaunchKernelGGL(k_dw_adam_wide, dim3(total), dim3(kWThreads), 0, st, k);
+  k.n_items = n_items; k.B = B; k.ad = ad; k.total = total;
+  static const DwKArgs none = [] { DwKArgs z; std::memset((void*)&z, 0, sizeof z); return z; }();
+  if (ride == nullptr) ride_blocks = 0;
+  hipLaunchKernelGGL(k_dw_adam_wide, dim3(total + ride_blocks), dim3(kWThreads), 0, st, k, ride != nullptr ? *ride : none);
   return hipGetLastError();
 }
 

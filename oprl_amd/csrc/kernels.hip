@@ -291,7 +291,8 @@ hipError_t init_kernel_attrs() {
 __device__ float g_one = 1.f;
 
 bool dw_wide_item_ok(const DwItem& it, const DwArgs& a);
-hipError_t launch_dw_adam_wide(const DwItem* items, int n_items, int B, const AdamScalars& ad, hipStream_t st);
+hipError_t launch_dw_adam_wide(const DwItem* items, int n_items, int B, const AdamScalars& ad, hipStream_t st,
+                               const DwKArgs* ride, int ride_blocks);
 
 static const float* dw_one_dev() {
   static const float* one_dev = nullptr;
@@ -337,8 +338,11 @@ hipError_t launch_dw_adam(const DwArgs& a0, hipStream_t st) {
     if (!no_wide && n_wide < 10 && dw_wide_item_ok(a0.items[j], a0)) wide[n_wide++] = a0.items[j];
     else rest[n_rest++] = a0.items[j];
   }
-  if (n_wide > 0) {
-    hipError_t e = launch_dw_adam_wide(wide, n_wide, a0.B, a0.ad, st);
+  // the narrow layers of the same update ride on the wide launch (OPRL_AMD_NO_DW_RIDE=1: a launch of their own)
+  static const bool no_ride = [] { const char* e = getenv("OPRL_AMD_NO_DW_RIDE"); return e != nullptr && atoi(e) != 0; }();
+  const bool ride = n_wide > 0 && n_rest > 0 && !no_ride && a0.xchg == nullptr;
+  if (n_wide > 0 && !ride) {
+    hipError_t e = launch_dw_adam_wide(wide, n_wide, a0.B, a0.ad, st, nullptr, 0);
     if (e != hipSuccess) return e;
     if (n_rest == 0) return a0.alpha.log_alpha != nullptr ? hipErrorInvalidValue : hipSuccess;   // (a job needs a tile launch to ride on)
   }
@@ -372,7 +376,9 @@ hipError_t launch_dw_adam(const DwArgs& a0, hipStream_t st) {
     hipLaunchKernelGGL(k_dw_adam<true>, dim3(total), dim3(kDwThreads), 0, st, k);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(k_dw_adam<false>, dim3(total + (a.alpha.log_alpha != nullptr ? 1 : 0)), dim3(kDwThreads), 0, st, k);
+  const int blocks = total + (a.alpha.log_alpha != nullptr ? 1 : 0);
+  if (ride) return launch_dw_adam_wide(wide, n_wide, a0.B, a0.ad, st, &k, blocks);
+  hipLaunchKernelGGL(k_dw_adam<false>, dim3(blocks), dim3(kDwThreads), 0, st, k);
   return hipGetLastError();
 }
 

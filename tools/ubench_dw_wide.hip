@@ -39,10 +39,10 @@ int main() {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   auto run = [&](const char* name, DwItem* items, int b, AdamScalars a) {
-    for (int w = 0; w < 20; ++w) launch_dw_adam_wide(items, L, b, a, st);
+    for (int w = 0; w < 20; ++w) launch_dw_adam_wide(items, L, b, a, st, nullptr, 0);
     hipEventRecord(e0, st);
     const int n = 200;
-    for (int w = 0; w < n; ++w) launch_dw_adam_wide(items, L, b, a, st);
+    for (int w = 0; w < n; ++w) launch_dw_adam_wide(items, L, b, a, st, nullptr, 0);
     hipEventRecord(e1, st);
     hipStreamSynchronize(st);
     float ms;
