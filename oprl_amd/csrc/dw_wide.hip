@@ -26,7 +26,8 @@ struct DwWideArgs {
   int tile_end[kWMaxItems];
   DwItem items[kWMaxItems];
   int n_items, B;
-  int total;                             // 64 x 64 tiles = workgroups of this kernel's own work
+  int total;                             // 64 x 64 tiles of this kernel's own work
+  int grid_own;                          // 8 * ceil(total / 8) workgroups carry them (riding workgroups come after)
   AdamScalars ad;
 };
 static_assert(kWThreads == kDwThreads, "the riding k_dw_adam tiles run in this kernel's workgroups");
@@ -36,24 +37,50 @@ constexpr int kWLdsFloats = 2 * kWChunk * kWLd > kDwLdsFloats ? 2 * kWChunk * kW
 // 16 x 32 tiles of k_dw_adam (dw_body.h) ride as the workgroups past `total` — dispatched last, they fill the
 // CUs the 640 wide tiles' second round leaves idle, instead of a launch of their own (9 us).  N.n_items == 0:
 // nothing rides.
+#ifdef DWW_TRACE
+__device__ unsigned long long g_dww_trace[1024 * 8];
+#endif
 __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, const DwKArgs N) {
   __shared__ __attribute__((aligned(16))) float lds[kWLdsFloats];
-  if ((int)blockIdx.x >= A.total) {
+  if ((int)blockIdx.x >= A.grid_own) {
     const char* kp = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
     dw_adam_body<false>(*(const DwKArgs*)(kp + ((sizeof(DwWideArgs) + alignof(DwKArgs) - 1) / alignof(DwKArgs)) * alignof(DwKArgs)),
-                        lds, (int)blockIdx.x - A.total);
+                        lds, (int)blockIdx.x - A.grid_own);
     return;
   }
   float (*stA)[kWLd] = reinterpret_cast<float (*)[kWLd]>(lds);                      // dY rows [b][n]; later the new W tile
   float (*stX)[kWLd] = reinterpret_cast<float (*)[kWLd]>(lds + kWChunk * kWLd);     // X  rows [b][k]; later the new target tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const DwWideArgs* KA = (const DwWideArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+#ifdef DWW_TRACE
+#define DWW_STAMP(k) do { if (tid == 0) g_dww_trace[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DWW_STAMP(k) do { } while (0)
+#endif
+  DWW_STAMP(0);
+  // Which tile: workgroup b runs on XCD b % 8, and a tile streams 64 KB of dY rows and 64 KB of X rows that its
+  // row / column neighbours share.  With tiles dealt out in launch order every XCD read ALL of dY (5.2 MB for TQC's
+  // ten layers, more than its 4 MB L2): 80+ MB of rows over the fabric per launch, as much as the Adam state and
+  // the packs together, and the launch is bound by exactly that sum.  Here the tile list (layer-major, 4 x 4
+  // super-blocks inside a layer) is cut into eight consecutive pieces, one per XCD: a piece is a whole layer plus
+  // a super-block or two — 1.5 MB of rows, read once.
+  const int per = (A.total + 7) >> 3;
+  const int pos = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (pos >= A.total) return;
   int item = 0;
-  for (int j = 0; j + 1 < A.n_items; ++j) item += (int)blockIdx.x >= KA->tile_end[j] ? 1 : 0;
+  for (int j = 0; j + 1 < A.n_items; ++j) item += pos >= KA->tile_end[j] ? 1 : 0;
   const DwItem I = KA->items[item];
-  const int lt = (int)blockIdx.x - (item > 0 ? KA->tile_end[item - 1] : 0);
-  const int tiles_k = I.K / kWT;
-  const int tn = lt / tiles_k, tk = lt - tn * tiles_k;
+  const int lt = pos - (item > 0 ? KA->tile_end[item - 1] : 0);
+  const int tiles_k = I.K / kWT, tiles_n = I.N / kWT;
+  int tn, tk;
+  if (((tiles_k | tiles_n) & 3) == 0) {
+    const int sb = lt >> 4, r = lt & 15, sbk = tiles_k >> 2, sbn = sb / sbk;
+    tn = sbn * 4 + (r >> 2);
+    tk = (sb - sbn * sbk) * 4 + (r & 3);
+  } else {
+    tn = lt / tiles_k;
+    tk = lt - tn * tiles_k;
+  }
   const int n_base = tn * kWT, k_base = tk * kWT;
   const int NSk = I.K >> 4, NSn = I.N >> 4;
   const bool polyak = A.ad.do_polyak && I.w_t != nullptr;
@@ -64,15 +91,20 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, 
   const size_t eo = (size_t)(n_base + el_n) * I.K + k_base + el_k;
   f32x4 p_th[2], p_m[2], p_v[2], p_tt[2];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    p_th[h] = p_m[h] = p_v[h] = p_tt[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (A.ad.do_adam) {
-      p_th[h] = ld4(I.w + eo + 4 * h);
-      p_m[h] = ld4(I.w_m + eo + 4 * h);
-      p_v[h] = ld4(I.w_v + eo + 4 * h);
-      if (polyak) p_tt[h] = ld4(I.w_t + eo + 4 * h);
-    }
-  }
+  for (int h = 0; h < 2; ++h) p_th[h] = p_m[h] = p_v[h] = p_tt[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // requested behind the LAST chunk's rows (below): ahead of the first rows — loads return in order — the 64 KB
+  // of state per workgroup, 42 MB from HBM over the chip, stood between the launch and its first MFMA; there
+  // they arrive under the last chunks' MFMAs, when the memory pipe has nothing else to do
+  auto request_state = [&]() {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (A.ad.do_adam) {
+        p_th[h] = ld4(I.w + eo + 4 * h);
+        p_m[h] = ld4(I.w_m + eo + 4 * h);
+        p_v[h] = ld4(I.w_v + eo + 4 * h);
+        if (polyak) p_tt[h] = ld4(I.w_t + eo + 4 * h);
+      }
+  };
 
   // ---- dW tile = sum_b dY[b, n]^T X[b, k].  Wave w: n block w >> 1, k blocks 2 (w & 1) + {0, 1}.
   // MFMA step u of a chunk contracts rows 4u .. 4u+3: lane (c, i) feeds dY[4u + c][n] as A and
@@ -98,6 +130,7 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, 
   };
   const int n_chunks = (B + kWChunk - 1) / kWChunk;
   request(0);
+  if (n_chunks <= 1) request_state();
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     __syncthreads();                      // the previous chunk's reads are done
 #pragma unroll
@@ -105,8 +138,12 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, 
       *reinterpret_cast<f32x4*>(&stA[sr + 32 * h][sc4]) = va[h];
       *reinterpret_cast<f32x4*>(&stX[sr + 32 * h][sc4]) = vx[h];
     }
-    if (chunk + 1 < n_chunks) request(chunk + 1);   // in flight during this chunk's MFMAs
+    if (chunk + 1 < n_chunks) {
+      request(chunk + 1);                           // in flight during this chunk's MFMAs
+      if (chunk + 2 == n_chunks) request_state();
+    }
     __syncthreads();
+    if (chunk == 0) DWW_STAMP(1);
 #pragma unroll
     for (int u = 0; u < kWChunk / 4; ++u) {
       const float av = stA[4 * u + c][nb * 16 + i];
@@ -118,6 +155,7 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, 
     }
   }
   __syncthreads();
+  DWW_STAMP(2);
   // gradient tile -> stA[n][k] (acc row = n index 4c + r, column = k index i); db -> stX[0][n]
 #pragma unroll
   for (int w = 0; w < 2; ++w)
@@ -159,6 +197,7 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, 
       }
     }
   }
+  DWW_STAMP(3);
   // bias (one k tile per n range does it)
   float gb = 0.f;
   if (tk == 0 && tid < kWT) gb = stX[0][tid];
@@ -195,6 +234,7 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, 
           *reinterpret_cast<const f32x4*>(&src[bn * 16 + li][bk * 16 + 4 * lk]);
     }
   }
+  DWW_STAMP(4);
   if (I.pf16 == nullptr) return;
   // ---- bf16 packs (PrecBF16, engine.h): 8 blocks of 16 x 32 per pack, a block = fp32 blocks 2b, 2b + 1 side by side
   const int NSk2 = I.K >> 5, NSn2 = I.N >> 5;
@@ -244,9 +284,10 @@ hipError_t launch_dw_adam_wide(const DwItem* items, int n_items, int B, const Ad
   }
   for (int j = n_items; j < kWMaxItems; ++j) { k.items[j] = items[0]; k.tile_end[j] = total; }
   k.n_items = n_items; k.B = B; k.ad = ad; k.total = total;
+  k.grid_own = 8 * ((total + 7) / 8);
   static const DwKArgs none = [] { DwKArgs z; std::memset((void*)&z, 0, sizeof z); return z; }();
   if (ride == nullptr) ride_blocks = 0;
-  hipLaunchKernelGGL(k_dw_adam_wide, dim3(total + ride_blocks), dim3(kWThreads), 0, st, k, ride != nullptr ? *ride : none);
+  hipLaunchKernelGGL(k_dw_adam_wide, dim3(k.grid_own + ride_blocks), dim3(kWThreads), 0, st, k, ride != nullptr ? *ride : none);
   return hipGetLastError();
 }
 

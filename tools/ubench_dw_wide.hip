@@ -60,6 +60,32 @@ int main() {
   { DwItem v[L]; for (int j = 0; j < L; ++j) { v[j] = it[j]; v[j].pf = v[j].pb = v[j].tpf = nullptr; }
     run("no GEMM, no packs", v, 0, ad); }
   { AdamScalars a = ad; a.do_adam = 0; run("nothing (B = 0, no Adam): launch + lookup", it, 0, a); }
+  auto dump = [&]() {
+#ifdef DWW_TRACE
+  {
+    std::vector<unsigned long long> t(1024 * 8);
+    hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_dww_trace), t.size() * 8);
+    unsigned long long t0 = ~0ull;
+    for (int w = 0; w < 640; ++w) t0 = t[w * 8] < t0 ? t[w * 8] : t0;
+    const char* names[5] = {"entry", "first rows in", "GEMM done", "Adam stores issued", "fp32 packs issued"};
+    for (int k = 0; k < 5; ++k) {
+      double mn = 1e9, mx = 0, av = 0;
+      for (int w = 0; w < 640; ++w) { const double d = (double)(t[w * 8 + k] - t0) / 100.0; mn = d < mn ? d : mn; mx = d > mx ? d : mx; av += d / 640; }
+      printf("  %-22s min %6.2f avg %6.2f max %6.2f us\n", names[k], mn, av, mx);
+    }
+    int late = 0;
+    for (int w = 0; w < 640; ++w) late += (double)(t[w * 8] - t0) / 100.0 > 3.0 ? 1 : 0;
+    printf("  workgroups entering after 3 us: %d\n", late);
+    // per-workgroup durations
+    double d01 = 0, d12 = 0, d23 = 0, d34 = 0;
+    for (int w = 0; w < 640; ++w) { d01 += (t[w*8+1]-t[w*8]) / 64000.0; d12 += (t[w*8+2]-t[w*8+1]) / 64000.0; d23 += (t[w*8+3]-t[w*8+2]) / 64000.0; d34 += (t[w*8+4]-t[w*8+3]) / 64000.0; }
+    printf("  per workgroup avg: entry->rows %.2f  rows->GEMM done %.2f  ->Adam stores %.2f  ->packs %.2f us\n", d01, d12, d23, d34);
+  }
+#endif
+  };
   run("whole again", it, B, ad);
+  dump();
+  { AdamScalars a = ad; a.do_adam = 0; run("GEMM only again", it, B, a); }
+  dump();
   return 0;
 }
