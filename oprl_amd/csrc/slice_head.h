@@ -192,22 +192,35 @@ __device__ __forceinline__ void slice_seed(const MlpArgs& A, const float* outS, 
         }
         __syncthreads();
       }
-      for (int idx = tid; idx < kR * Q; idx += kThreads) {
-        const int row = idx / Q, q = idx - row * Q, gr = row0 + row;
-        if (gr >= B) continue;
-        const float z = outS[row * kOutLd + q];
+      // kR * Q elements (400 for TQC) x M samples each (115): one thread per element kept 7 of the 16 waves busy for
+      // M iterations — 5 us of the critic step's head launch.  Four lanes per element, a quarter of the samples each,
+      // summed over the quad in a fixed order: every wave carries the same work.
+      const int n_el = kR * Q, m4 = (M + 3) >> 2;
+      for (int it = 0; it * kThreads < 4 * n_el; ++it) {   // (uniform trip count: the quad shuffles below need whole quads)
+        const int idx = tid + it * kThreads, el = idx >> 2, part = idx & 3;
+        const int row = el / Q, q = el - row * Q, gr = row0 + row;
+        const bool ok = el < n_el && gr < B;
+        const float z = ok ? outS[row * kOutLd + q] : 0.f;
         const float tau = ((float)q) / (float)Q + 0.5f / (float)Q;
+        const float w_pos = fabsf(tau), w_neg = fabsf(tau - 1.f);
         const float* yrow = staged ? scr + row * M : S.p0 + (size_t)gr * M;
         float g = 0.f, ls = 0.f;
-        for (int s = 0; s < M; ++s) {
+        const int s0 = part * m4, s1 = ok ? min(M, s0 + m4) : s0;
+        for (int s = s0; s < s1; ++s) {
           const float dl = yrow[s] - z;
           const float ad = fabsf(dl);
-          const float w = fabsf(tau - (dl < 0.f ? 1.f : 0.f));
-          g += w * (ad > 1.f ? (dl > 0.f ? 1.f : -1.f) : dl);
+          const float w = dl < 0.f ? w_neg : w_pos;
+          g += w * fminf(fmaxf(dl, -1.f), 1.f);
           ls += w * (ad > 1.f ? ad - 0.5f : dl * dl * 0.5f);
         }
-        auxS[row * kOutLd + q] = -g * S.cval;
-        p_loss += ls;
+        g += __shfl_xor(g, 1);
+        ls += __shfl_xor(ls, 1);
+        g += __shfl_xor(g, 2);
+        ls += __shfl_xor(ls, 2);
+        if (ok && part == 0) {
+          auxS[row * kOutLd + q] = -g * S.cval;
+          p_loss += ls;
+        }
       }
     } break;
     default: break;
