@@ -178,6 +178,21 @@ struct AlphaJob {
   double lr = 0, beta1 = 0, beta2 = 0, eps = 0, bc1 = 1, bc2_sqrt = 1;
 };
 
+// TQC's TD target (sort the target critics' n_nets * Q quantiles of a row, drop the top ones, TD backup:
+// k_tqc_target) as the tail of the target critics' head launch (k_lw_head): the head workgroup that arrives LAST
+// at its 16-row slice — a per-slice arrival counter, never reset: every launch adds n_nets to it — does the slice's
+// rows, one wave per row.  The heads' outputs travel as agent-scope stores / loads (write-through: the nets'
+// workgroups sit on different XCDs); as a launch of its own the target cost a kernel boundary for 2 us of work.
+struct TqcJob {
+  unsigned long long* counter = nullptr;   // [slices]; null: no job
+  float* z = nullptr; long net_stride = 0; int ldz = 0;   // the heads' outputs [n_nets][B][ldz] (= their MlpArgs::out)
+  int n_nets = 0, Q = 0, drop = 0;
+  const float *r = nullptr, *d = nullptr, *logp = nullptr;
+  const double* log_alpha = nullptr;
+  float gamma = 0.f;
+  float* target = nullptr;                 // [B][n_nets * Q - drop]
+};
+
 struct DwArgs {                         // host-side description of one k_dw_adam launch
   const DwItem* items;                 // HOST array
   int n_items; int total_tiles; int B;

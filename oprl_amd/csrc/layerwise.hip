@@ -547,8 +547,61 @@ inline LwRun2 lw_run2(int B, int nets, int n_cus) {
 constexpr size_t kLwRun2Lds = sizeof(float) * (2 * kLw2MaxRun * 8 * 256);   // partial tiles 96 KB >= rows 65 KB + net input 13 KB
 static_assert(kLwRun2Lds >= sizeof(float) * (kLw2Rows * lds_ld(512) + kLw2Rows * kX0Ld), "rows + net input fit under the partial tiles");
 
+// TqcJob (kernels.h): the slice's TD targets by the last of the nets' head workgroups to arrive.  Called by all
+// threads of a forward-only head workgroup after slice_head(); scr: 16 waves x 128 floats.
+__device__ __forceinline__ void lw_tqc_target(const TqcJob& J, const MlpArgs& A, const float* outS, float* scr,
+                                              int Nout, int row0, int slice) {
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, B = A.B;
+  for (int idx = tid; idx < kR * Nout; idx += kThreads) {
+    const int row = idx / Nout, col = idx - row * Nout;
+    if (row0 + row < B)
+      __hip_atomic_store(A.out + (size_t)(row0 + row) * A.ldo + col, outS[row * kOutLd + col], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // written through before this workgroup counts as arrived
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned long long old = __hip_atomic_fetch_add(J.counter + slice, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ((old + 1ull) % (unsigned long long)J.n_nets) == 0ull ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_last == 0) return;
+  const int row = row0 + wave;                          // one wave per row, 128-slot bitonic network in the wave's LDS
+  if (row >= B) return;
+  const int total = J.n_nets * J.Q, Mt = total - J.drop;
+  float* sb = scr + wave * 128;
+  for (int e = lane; e < 128; e += 64) {
+    float v = __builtin_huge_valf();
+    if (e < total) {
+      const int n = e / J.Q, q = e - n * J.Q;
+      v = __hip_atomic_load(J.z + n * J.net_stride + (size_t)row * J.ldz + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    sb[e] = v;
+  }
+  for (int k = 2; k <= 128; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int e = ((lane & ~(j - 1)) << 1) | (lane & (j - 1));  // lower index of the pair
+      const int p = e | j;
+      const bool up = (e & k) == 0;
+      const float a = sb[e], b = sb[p];
+      if ((a > b) == up) { sb[e] = b; sb[p] = a; }
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float alpha = (float)exp(*J.log_alpha);
+  const float al = alpha * J.logp[row];
+  const float coef = (1.f - J.d[row]) * J.gamma;
+  const float rr = J.r[row];
+  for (int s = lane; s < Mt; s += 64) J.target[(size_t)row * Mt + s] = rr + coef * (sb[s] - al);
+}
+
 template <int WIDTH>
-__global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M) {
+__global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M, const TqcJob J) {
   __shared__ __attribute__((aligned(16))) float smem[LwLds<WIDTH>::total];
   using LY = LwLds<WIDTH>;
   constexpr int WL = LY::WL, NTW = WIDTH / 16;
@@ -567,7 +620,13 @@ __global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M) {
   } else {
     __syncthreads();
   }
-  if (!A.do_bwd) return;
+  if (!A.do_bwd) {
+    if (J.counter != nullptr) {
+      __syncthreads();                                  // slice_head is done with outS / scr
+      lw_tqc_target(J, A, outS, scr, Nout, row0, slice);
+    }
+    return;
+  }
   slice_seed(A, outS, auxS, scr, Nout, L, row0, slice, true);
   // dz[L-2] = (dout W_{L-1}) * [h > 0], in place over the activations (each element's mask is
   // read by the lane that overwrites it)
@@ -644,8 +703,11 @@ hipError_t init_layerwise_attrs() {
 
 // bf16: the nets' pf / pb of the HIDDEN layers (1 .. L-2) point at bf16 packs (MlpArgs::pf16 / pb16 moved in
 // by the caller) and the hidden-layer launches run PrecBF16; needs the balanced-run kernels.
-hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, bool bf16) {
+// job: a TD-target job for the heads of a forward-only launch of all its nets (TqcJob, kernels.h), or null
+hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, bool bf16, const TqcJob* job) {
   if (!mlp_layerwise_ok(a, n, width)) return hipErrorInvalidValue;
+  if (job != nullptr && (a[0].do_bwd || !a[0].do_fwd || job->n_nets != n || job->n_nets * job->Q > 128 || job->counter == nullptr))
+    return hipErrorInvalidValue;
   MlpMultiArgs m;
   for (int j = 0; j < n; ++j) m.a[j] = a[j];
   for (int j = n; j < kMaxMulti; ++j) m.a[j] = a[0];
@@ -683,7 +745,7 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
       else mid(l == 1 && fuse_in ? 2 : 0, l);
     }
   }
-  hipLaunchKernelGGL(k_lw_head<512>, narrow, blk, 0, st, m);
+  hipLaunchKernelGGL(k_lw_head<512>, narrow, blk, 0, st, m, job != nullptr ? *job : TqcJob{});
   if (a[0].do_bwd) {
     for (int l = L - 2; l >= 1; --l) {
       if (equal_wgs) hipLaunchKernelGGL((k_lw_mid<512, true>), wide, blk, 0, st, m, l, g);

@@ -129,7 +129,7 @@ size_t mlp_slice_lds_bytes(int width, int n_layers);
 hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
 hipError_t launch_mlp_slice_multi(const MlpArgs* a, int n, int width, hipStream_t st);
 bool mlp_layerwise_ok(const MlpArgs* a, int n, int width);
-hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, bool bf16);
+hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, bool bf16, const TqcJob* job);
 hipError_t init_layerwise_attrs();
 hipError_t launch_mlp_slice_tp(const MlpArgs& a, hipStream_t st);
 hipError_t launch_mlp_slice_tp2(const MlpArgs& a0, const MlpArgs& a1, int n_cus, hipStream_t st);
@@ -376,6 +376,10 @@ struct oprl_learner {
   bool no_dp_inline = false;   // OPRL_AMD_NO_DP_INLINE: peer-window exchanges as separate launches (tests / A-B)
   bool no_twin_split = false;  // OPRL_AMD_NO_TWIN_SPLIT: role A runs both target critics back to back (tests / A-B)
   bool no_multi = false;
+  TqcJob tqc_job;              // TQC: the TD target as the tail of the target critics' head launch (kernels.h) ...
+  bool tqc_job_pending = false; // ... offered to the next for_each_net; still set afterwards: k_tqc_target as a launch of its own
+  bool no_tqc_ride = false;    // OPRL_AMD_NO_TQC_RIDE: always that launch (tests / A-B)
+  unsigned long long* tqc_counter = nullptr;   // [slices at Bmax] arrival counters, zeroed once
   bool no_layerwise = false;   // OPRL_AMD_NO_LAYERWISE: wide nets stay on the single-CU slice kernel (tests / A-B)
   bool no_p2_pair = false;     // OPRL_AMD_NO_P2_PAIR: SAC phase 2 runs the twin critics back to back (tests / A-B)
   bool multi_collect = false;  // for_each_net over > 2 single-CU nets: one k_mlp_slice_multi launch
@@ -695,7 +699,14 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
           for (int l = 1; l + 1 < a.net.n_layers; ++l) { a.net.pf[l] = a.pf16[l]; if (a.pb16[l]) a.net.pb[l] = a.pb16[l]; }
         }
       prof_begin(0, st);
-      hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, h->n_cus, st, lw16);
+      // a pending TD-target job (critic_phase) rides on this launch's heads when it is the target critics' forward
+      const TqcJob* job = nullptr;
+      if (h->tqc_job_pending && !h->multi_args[0].do_bwd && h->multi_args[0].do_fwd && h->multi_n == h->tqc_job.n_nets &&
+          h->multi_args[0].out == h->tqc_job.z) {
+        job = &h->tqc_job;
+        h->tqc_job_pending = false;
+      }
+      hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, h->n_cus, st, lw16, job);
       prof_end(st);
       HIPC(e);
     } else if (same) {
@@ -988,6 +999,15 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     RC(launch(f, h->w_actor, st));
   }
   // 2. target critics on (s', a')   (independent: one stream each)
+  if (algo == OPRL_TQC && h->tqc_counter != nullptr && !h->no_tqc_ride) {
+    TqcJob& J = h->tqc_job;
+    J.counter = h->tqc_counter;
+    J.z = h->qn; J.net_stride = (long)h->Bmax * h->ldq; J.ldz = h->ldq;
+    J.n_nets = nc; J.Q = c.hp.n_quantiles; J.drop = c.hp.top_quantiles_to_drop;
+    J.r = r; J.d = d; J.logp = h->logp2; J.log_alpha = c.log_alpha; J.gamma = (float)c.hp.gamma;
+    J.target = h->target;
+    h->tqc_job_pending = true;
+  }
   RC(for_each_net(h, nc, st, [&](int j, hipStream_t sj) {
     MlpArgs f = base_args(h, c.critics[j], true, B);
     f.do_fwd = 1;
@@ -995,7 +1015,12 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     f.out = h->qn + (size_t)j * h->Bmax * h->ldq; f.ldo = h->ldq;
     return launch(f, h->w_critic, sj);
   }));
-  if (algo == OPRL_TQC) {
+  if (algo == OPRL_TQC && h->tqc_job_pending) {     // (the job did not ride: not the layer-by-layer path)
+    h->tqc_job_pending = false;
+    const int Q = c.hp.n_quantiles, drop = c.hp.top_quantiles_to_drop;
+    HIPC(launch_tqc_target(h->qn, (long)h->Bmax * h->ldq, h->ldq, nc, Q, drop, r, d, h->logp2,
+                           c.log_alpha, (float)c.hp.gamma, B, h->target, st));
+  } else if (algo == OPRL_TQC && (h->tqc_counter == nullptr || h->no_tqc_ride)) {
     const int Q = c.hp.n_quantiles, drop = c.hp.top_quantiles_to_drop;
     HIPC(launch_tqc_target(h->qn, (long)h->Bmax * h->ldq, h->ldq, nc, Q, drop, r, d, h->logp2,
                            c.log_alpha, (float)c.hp.gamma, B, h->target, st));
@@ -1700,6 +1725,13 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->no_multi = (nm != nullptr && atoi(nm) != 0);
     const char* nlw = getenv("OPRL_AMD_NO_LAYERWISE");
     h->no_layerwise = (nlw != nullptr && atoi(nlw) != 0);
+    const char* ntr = getenv("OPRL_AMD_NO_TQC_RIDE");
+    h->no_tqc_ride = (ntr != nullptr && atoi(ntr) != 0);
+    if (cfg->algo == OPRL_TQC && nc * cfg->hp.n_quantiles <= 128) {
+      const size_t slices = (size_t)(h->Bmax + kR - 1) / kR;
+      if (hipMalloc(&h->tqc_counter, slices * sizeof(unsigned long long)) != hipSuccess) h->tqc_counter = nullptr;   // (then: the stand-alone launch)
+      else (void)hipMemset(h->tqc_counter, 0, slices * sizeof(unsigned long long));
+    }
     const char* ndi = getenv("OPRL_AMD_NO_DP_INLINE");
     h->no_dp_inline = (ndi != nullptr && atoi(ndi) != 0);
     const char* nts = getenv("OPRL_AMD_NO_TWIN_SPLIT");
@@ -1774,6 +1806,7 @@ extern "C" int oprl_learner_destroy(oprl_learner* h) {
   if (h->rccl.comm && h->rccl.comm_destroy) (void)h->rccl.comm_destroy(h->rccl.comm);
   if (h->fused) { std::lock_guard<std::mutex> lk(g_chain_mu); if (g_chain.live > 0) g_chain.live -= 1; }
   if (h->xbuf) (void)hipFree(h->xbuf);
+  if (h->tqc_counter) (void)hipFree(h->tqc_counter);
   if (h->err_host) (void)hipHostFree(h->err_host);
   if (h->p2p.window) p2p_destroy(h->p2p);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);

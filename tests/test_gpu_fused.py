@@ -372,6 +372,31 @@ def test_tqc_layerwise_equals_slice_kernel(B, monkeypatch):
         assert abs(sl[k] - sr[k]) <= 1e-4 * max(abs(sr[k]), 1e-6), k
 
 
+@pytest.mark.parametrize("B", [256, 100])
+def test_tqc_target_on_head_launch_equals_target_launch(B, monkeypatch):
+    """The TD target as the tail of the target critics' head launch (the last head workgroup of a slice to arrive
+    sorts the slice's rows; csrc/layerwise.hip lw_tqc_target) against k_tqc_target as a launch of its own: the same
+    sorting network on the same values — bit-identical, at a full and a ragged batch."""
+    from oprl_amd.algos.tqc import TQC
+    from oprl_amd.logging import NullLogger
+
+    def make():
+        t.manual_seed(0)
+        return TQC(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=256).create()
+
+    ride = make()
+    monkeypatch.setenv("OPRL_AMD_NO_TQC_RIDE", "1")      # (read when the learner is created)
+    ref = make()
+    for step in range(4):
+        batch = [x.cuda() for x in fx.make_batch(40 + step, B, 24, 6)]
+        ride.update(*batch)
+        ref.update(*batch)
+    t.cuda.synchronize()
+    assert t.isfinite(ride.critic._oprl_arena).all()
+    for m in ("actor", "critic", "critic_target"):
+        assert t.equal(getattr(ride, m)._oprl_arena, getattr(ref, m)._oprl_arena), m
+
+
 def test_tqc_wide_dw_equals_small_tiles(monkeypatch):
     """csrc/dw_wide.hip (64x64 tiles for the 512x512 layers) against k_dw_adam's 16x32 tiles: same
     gradient up to the summation order over the minibatch, same Adam / Polyak / pack epilogue."""
