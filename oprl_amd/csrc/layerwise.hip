@@ -27,6 +27,7 @@
 #include "kernels.h"
 #include "slice_head.h"
 #include "tp4.h"
+#include "slice_tp_body.h"
 
 namespace oprl {
 
@@ -600,9 +601,18 @@ __device__ __forceinline__ void lw_tqc_target(const TqcJob& J, const MlpArgs& A,
   for (int s = lane; s < Mt; s += 64) J.target[(size_t)row * Mt + s] = rr + coef * (sb[s] - al);
 }
 
+// R (n_ride = 4): ANOTHER net's k_mlp_slice_tp launch on the same slices — its clusters of four ride as the
+// workgroups blockIdx.z >= nets (slice_tp_body.h).  The heads are (slices x nets) workgroups, 80 of TQC's 256 CUs:
+// the actor's forward on s, which the actor step needs only after the critic step, runs beside the critic step's
+// heads instead of as a launch of its own (8.5 us).  The host checks that all workgroups are resident at once
+// (the riders' cluster exchanges wait for each other).
 template <int WIDTH>
-__global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M, const TqcJob J) {
-  __shared__ __attribute__((aligned(16))) float smem[LwLds<WIDTH>::total];
+__global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M, const TqcJob J, const MlpArgs R, int nets) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];        // max(LwLds<WIDTH>::total, SliceLds<256>::total(2)) floats
+  if ((int)blockIdx.z >= nets) {
+    slice_tp_body(R, (int)blockIdx.x, (int)blockIdx.z - nets);
+    return;
+  }
   using LY = LwLds<WIDTH>;
   constexpr int WL = LY::WL, NTW = WIDTH / 16;
   const MlpArgs& A = lw_args(blockIdx.z);
@@ -689,6 +699,13 @@ hipError_t init_layerwise_attrs() {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLwRunLds);
     if (e != hipSuccess) return e;
   }
+  {
+    constexpr size_t head_f = LwLds<512>::total, ride_f = SliceLds<256>::total(2);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_head<512>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(float) * (ride_f > head_f ? ride_f : head_f)));
+    if (e != hipSuccess) return e;
+  }
   const void* k2[6] = {reinterpret_cast<const void*>(&k_lw_mid_run2<0>), reinterpret_cast<const void*>(&k_lw_mid_run2<1>),
                        reinterpret_cast<const void*>(&k_lw_mid_run2<2>),
                        reinterpret_cast<const void*>(&k_lw_mid_run2<0, PrecBF16>),
@@ -703,9 +720,21 @@ hipError_t init_layerwise_attrs() {
 
 // bf16: the nets' pf / pb of the HIDDEN layers (1 .. L-2) point at bf16 packs (MlpArgs::pf16 / pb16 moved in
 // by the caller) and the hidden-layer launches run PrecBF16; needs the balanced-run kernels.
+bool mlp_slice_tp_shape_ok(const MlpArgs& a, int width);
+
+// Can `rider` (a prepared k_mlp_slice_tp launch: tag drawn, exchange area set) ride on the head launch of these nets?
+bool mlp_layerwise_rider_ok(const MlpArgs* a, int n, const MlpArgs& rider, int n_cus) {
+  const int slices = (a[0].B + kR - 1) / kR;
+  return rider.B == a[0].B && rider.tp_xbuf != nullptr && mlp_slice_tp_shape_ok(rider, 256) &&
+         slices * (n + 4) <= (n_cus > 0 ? n_cus : 256);
+}
+
 // job: a TD-target job for the heads of a forward-only launch of all its nets (TqcJob, kernels.h), or null
-hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, bool bf16, const TqcJob* job) {
+// rider: see k_lw_head; or null
+hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, bool bf16, const TqcJob* job,
+                                const MlpArgs* rider) {
   if (!mlp_layerwise_ok(a, n, width)) return hipErrorInvalidValue;
+  if (rider != nullptr && !mlp_layerwise_rider_ok(a, n, *rider, n_cus)) return hipErrorInvalidValue;
   if (job != nullptr && (a[0].do_bwd || !a[0].do_fwd || job->n_nets != n || job->n_nets * job->Q > 128 || job->counter == nullptr))
     return hipErrorInvalidValue;
   MlpMultiArgs m;
@@ -745,7 +774,13 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
       else mid(l == 1 && fuse_in ? 2 : 0, l);
     }
   }
-  hipLaunchKernelGGL(k_lw_head<512>, narrow, blk, 0, st, m, job != nullptr ? *job : TqcJob{});
+  {
+    constexpr size_t head_f = LwLds<512>::total, ride_f = SliceLds<256>::total(2);
+    const size_t lds = sizeof(float) * (rider != nullptr && ride_f > head_f ? ride_f : head_f);
+    const dim3 heads(slices, 1, n + (rider != nullptr ? 4 : 0));
+    hipLaunchKernelGGL(k_lw_head<512>, heads, blk, lds, st, m, job != nullptr ? *job : TqcJob{},
+                       rider != nullptr ? *rider : a[0], n);
+  }
   if (a[0].do_bwd) {
     for (int l = L - 2; l >= 1; --l) {
       if (equal_wgs) hipLaunchKernelGGL((k_lw_mid<512, true>), wide, blk, 0, st, m, l, g);

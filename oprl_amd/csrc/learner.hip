@@ -129,7 +129,9 @@ size_t mlp_slice_lds_bytes(int width, int n_layers);
 hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
 hipError_t launch_mlp_slice_multi(const MlpArgs* a, int n, int width, hipStream_t st);
 bool mlp_layerwise_ok(const MlpArgs* a, int n, int width);
-hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, bool bf16, const TqcJob* job);
+hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, bool bf16, const TqcJob* job,
+                                const MlpArgs* rider);
+bool mlp_layerwise_rider_ok(const MlpArgs* a, int n, const MlpArgs& rider, int n_cus);
 hipError_t init_layerwise_attrs();
 hipError_t launch_mlp_slice_tp(const MlpArgs& a, hipStream_t st);
 hipError_t launch_mlp_slice_tp2(const MlpArgs& a0, const MlpArgs& a1, int n_cus, hipStream_t st);
@@ -376,6 +378,10 @@ struct oprl_learner {
   bool no_dp_inline = false;   // OPRL_AMD_NO_DP_INLINE: peer-window exchanges as separate launches (tests / A-B)
   bool no_twin_split = false;  // OPRL_AMD_NO_TWIN_SPLIT: role A runs both target critics back to back (tests / A-B)
   bool no_multi = false;
+  MlpArgs rider;               // TQC: the actor's forward on s, prepared in critic_phase to ride on the critic step's head launch ...
+  bool rider_pending = false;  // ... offered to the next for_each_net; taken: rider_done, and actor_phase skips its step 5
+  bool rider_done = false;
+  bool no_af_ride = false;     // OPRL_AMD_NO_AF_RIDE: the forward stays a launch of actor_phase (tests / A-B)
   TqcJob tqc_job;              // TQC: the TD target as the tail of the target critics' head launch (kernels.h) ...
   bool tqc_job_pending = false; // ... offered to the next for_each_net; still set afterwards: k_tqc_target as a launch of its own
   bool no_tqc_ride = false;    // OPRL_AMD_NO_TQC_RIDE: always that launch (tests / A-B)
@@ -706,7 +712,15 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
         job = &h->tqc_job;
         h->tqc_job_pending = false;
       }
-      hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, h->n_cus, st, lw16, job);
+      // a pending rider (critic_phase: the actor's forward on s) goes with the storing launch's heads
+      const MlpArgs* rider = nullptr;
+      if (h->rider_pending && h->multi_args[0].do_bwd && h->multi_args[0].do_fwd &&
+          mlp_layerwise_rider_ok(h->multi_args, h->multi_n, h->rider, h->n_cus)) {
+        rider = &h->rider;
+        h->rider_pending = false;
+        h->rider_done = true;
+      }
+      hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, h->n_cus, st, lw16, job, rider);
       prof_end(st);
       HIPC(e);
     } else if (same) {
@@ -942,6 +956,24 @@ int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st, bo
   return OPRL_OK;
 }
 
+// the actor's forward on s with the activations kept for its backward (actor_phase step 5)
+MlpArgs actor_forward_args(oprl_learner* h, const float* s, int B, const float* noise1) {
+  const oprl_learner_config& c = h->cfg;
+  const bool gauss = (c.algo == OPRL_SAC || c.algo == OPRL_TQC);
+  MlpArgs f = base_args(h, c.actor, false, B);
+  f.do_fwd = 1;
+  f.x0 = s; f.k0 = h->S;
+  with_store(f, h->ws_actor, true, false);
+  f.out = h->pi; f.ldo = h->A;
+  if (gauss) {
+    f.out_act = ACT_GAUSS; f.raw_out = h->raw; f.ldraw = 2 * h->A; f.logp = h->logp;
+    seed_rng(f, h, noise1, 2);
+  } else {
+    f.out_act = ACT_TANH;
+  }
+  return f;
+}
+
 // ------------------------------------------------------------ critic phase
 int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r, const float* d,
                  const float* s2, int B, const float* noise0, hipStream_t st) {
@@ -1026,6 +1058,18 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
                            c.log_alpha, (float)c.hp.gamma, B, h->target, st));
   }
   // 3. online critics: forward + loss seed + backward   (independent: one stream each)
+  // TQC: the actor step's forward on s depends on nothing of the critic step: offered as a rider of this launch's
+  // heads (k_lw_head: 80 workgroups on 256 CUs), with the noise and the counter actor_phase would give it
+  h->rider_pending = false;
+  h->rider_done = false;
+  if (algo == OPRL_TQC && !h->no_af_ride && !c.export_grads && actor_due(h)) {
+    MlpArgs f = actor_forward_args(h, s, B, h->noise1_pending);
+    if (f.tp_xbuf != nullptr) {
+      RC(next_tp_tag(f.tp_tag_counter, f.tp_xbuf, f.tp_xbuf_bytes, st, &f.tp_tag));
+      h->rider = f;
+      h->rider_pending = true;
+    }
+  }
   RC(for_each_net(h, nc, st, [&](int j, hipStream_t sj) {
     MlpArgs f = base_args(h, c.critics[j], false, B);
     f.do_fwd = 1; f.do_bwd = 1;
@@ -1050,6 +1094,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     }
     return launch(f, h->w_critic, sj);
   }));
+  h->rider_pending = false;          // (not taken: actor_phase launches the forward itself)
   // 4. dW + Adam (+ Polyak where the reference does it every step)
   {
     const bool polyak = (algo == OPRL_TD3) ? (h->update_count % c.hp.policy_freq == 0) : true;
@@ -1095,19 +1140,11 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
   const int algo = c.algo;
   const bool gauss = (algo == OPRL_SAC || algo == OPRL_TQC);
   const int n_slices = (B + kR - 1) / kR;
-  // 5. actor forward (activations kept for its backward)
-  {
-    MlpArgs f = base_args(h, c.actor, false, B);
-    f.do_fwd = 1;
-    f.x0 = s; f.k0 = S;
-    with_store(f, h->ws_actor, true, false);
-    f.out = h->pi; f.ldo = A;
-    if (gauss) {
-      f.out_act = ACT_GAUSS; f.raw_out = h->raw; f.ldraw = 2 * A; f.logp = h->logp;
-      seed_rng(f, h, noise1, 2);
-    } else {
-      f.out_act = ACT_TANH;
-    }
+  // 5. actor forward (activations kept for its backward) — unless it rode on the critic step's heads (critic_phase)
+  if (h->rider_done) {
+    h->rider_done = false;
+  } else {
+    const MlpArgs f = actor_forward_args(h, s, B, noise1);
     RC(launch(f, h->w_actor, st));
   }
   // 6./7. critics on (s, pi): gradient wrt the action columns
@@ -1725,6 +1762,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->no_multi = (nm != nullptr && atoi(nm) != 0);
     const char* nlw = getenv("OPRL_AMD_NO_LAYERWISE");
     h->no_layerwise = (nlw != nullptr && atoi(nlw) != 0);
+    const char* nar = getenv("OPRL_AMD_NO_AF_RIDE");
+    h->no_af_ride = (nar != nullptr && atoi(nar) != 0);
     const char* ntr = getenv("OPRL_AMD_NO_TQC_RIDE");
     h->no_tqc_ride = (ntr != nullptr && atoi(ntr) != 0);
     if (cfg->algo == OPRL_TQC && nc * cfg->hp.n_quantiles <= 128) {

@@ -9,66 +9,27 @@
 // of tp4.h; inputs, head, loss-gradient seed and outputs are those of k_mlp_slice (slice_head.h),
 // computed identically by every member, written by member 0.  The first layer's dz goes out as
 // four partial buffers, summed by k_dw_adam on load (DwArgs::n_part = 4).
-#include "slice_head.h"
-#include "tp4.h"
+#include "slice_tp_body.h"
 
 namespace oprl {
 
-__device__ __forceinline__ void slice_tp_body(const MlpArgs& A) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  using LY = SliceLds<256>;
-  constexpr int WL = lds_ld(256);
-  constexpr int L = 3;
-  float* x0s = smem;
-  float* h1 = smem + LY::h_off;
-  float* h2 = h1 + LY::hbuf;
-  float* outS = smem + LY::out_off(2);
-  float* auxS = smem + LY::aux_off(2);
-  float* scr = smem + LY::scr_off(2);
-  const int slice = blockIdx.x, row0 = slice * kR, B = A.B;
-  Tp tp{(int)blockIdx.y, 4, A.tp_xbuf + (size_t)slice * kTpStages * 4 * kTpBlk, A.tp_tag, 0, A.err, KERN_SLICE_TP << 8, kTpSpin};
-  const bool lead = tp.c == 0;
-  const int Nout = A.net.dims[3];
-
-  if (A.do_fwd) {
-    lds_zero(x0s, kR * kX0Ld);
-    __syncthreads();
-    load_rows(x0s, kX0Ld, 0, A.x0, A.k0, A.k0, row0, B);
-    if (A.x1 != nullptr) load_rows(x0s, kX0Ld, A.k0, A.x1, A.k1, A.k1, row0, B);
-    const Tp3Store st{A.Xg[1], A.Xg[2], nullptr, nullptr, 0};
-    tp4_forward(A.net, x0s, h1, h2, outS, scr, tp, st, row0, B);
-    if (lead && A.Xg[0] != nullptr) store_rows(x0s, kX0Ld, A.Xg[0], A.ldx0, A.net.dims[0], row0, B);
-    slice_head(A, outS, Nout, row0, lead);
-  } else if (A.do_bwd) {
-    load_rows4(h1, WL, A.Xg[1], 256, 256, row0, B);
-    load_rows4(h2, WL, A.Xg[2], 256, 256, row0, B);
-  }
-  if (!A.do_bwd) return;
-
-  slice_seed(A, outS, auxS, scr, Nout, L, row0, slice, lead);
-  const Tp3Store sb{nullptr, nullptr, A.dYg[1], A.dYg[0], A.dY0_stride, B};   // tile-major dz1 partials (DwArgs::dy_tiled)
-  tp4_backward(A.net, auxS, h1, h2, scr, tp, sb, row0, B, A.dact_col0, A.dact_cols, auxS);
-  if (lead && A.dact_cols > 0 && A.dact != nullptr)
-    store_rows(auxS, kOutLd, A.dact, A.lddact, A.dact_cols, row0, B);
-}
-
-__global__ __launch_bounds__(kThreads) void k_mlp_slice_tp(const MlpArgs A) { slice_tp_body(A); }
+__global__ __launch_bounds__(kThreads) void k_mlp_slice_tp(const MlpArgs A) { slice_tp_body(A, blockIdx.x, blockIdx.y); }
 
 // Two nets on the same slices in one launch (twin critics: target pair forward, online pair
 // forward + backward): one boundary and one start-up instead of two.  Two by-value argument
 // structs and two copies of the body — a runtime-selected struct would leave the kernel-argument
 // registers.
 __global__ __launch_bounds__(kThreads) void k_mlp_slice_tp2(const MlpArgs A0, const MlpArgs A1) {
-  slice_tp_body(A0);
+  slice_tp_body(A0, blockIdx.x, blockIdx.y);
   __syncthreads();
-  slice_tp_body(A1);
+  slice_tp_body(A1, blockIdx.x, blockIdx.y);
 }
 
 // The same pair side by side (grid.z = net) when both fit on the chip at once: 2 x slices x 4
 // workgroups <= CUs (B <= 512 on MI355X).  Each net has its own exchange area.
 __global__ __launch_bounds__(kThreads) void k_mlp_slice_tp2z(const MlpArgs A0, const MlpArgs A1) {
-  if (blockIdx.z == 0) slice_tp_body(A0);
-  else slice_tp_body(A1);
+  if (blockIdx.z == 0) slice_tp_body(A0, blockIdx.x, blockIdx.y);
+  else slice_tp_body(A1, blockIdx.x, blockIdx.y);
 }
 
 bool mlp_slice_tp_shape_ok(const MlpArgs& a, int width) {

@@ -397,6 +397,39 @@ def test_tqc_target_on_head_launch_equals_target_launch(B, monkeypatch):
         assert t.equal(getattr(ride, m)._oprl_arena, getattr(ref, m)._oprl_arena), m
 
 
+@pytest.mark.parametrize("B", [256, 100])
+def test_tqc_actor_forward_riding_on_heads_equals_own_launch(B, monkeypatch):
+    """TQC's actor forward on s as riding workgroups of the critic step's head launch (k_lw_head's `R`; the same
+    slice_tp_body on the same inputs, counter and noise) against the forward as a launch of the actor phase:
+    bit-identical, through update() and through step_n."""
+    from oprl_amd.algos.tqc import TQC
+    from oprl_amd.logging import NullLogger
+    from tests.test_gpu_callers import _filled_buffer
+
+    def make():
+        t.manual_seed(0)
+        return TQC(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=256).create()
+
+    ride = make()
+    monkeypatch.setenv("OPRL_AMD_NO_AF_RIDE", "1")       # (read when the learner is created)
+    own = make()
+    for step in range(3):
+        batch = [x.cuda() for x in fx.make_batch(60 + step, B, 24, 6)]
+        ride.update(*batch)
+        own.update(*batch)
+    buf = _filled_buffer()
+    ride.learner.step_n(buf.handle, 12, 64, seed=5)
+    own.learner.step_n(buf.handle, 12, 64, seed=5)
+    t.cuda.synchronize()
+    ride.learner.check()
+    assert t.isfinite(ride.critic._oprl_arena).all()
+    for m in ("actor", "critic", "critic_target"):
+        assert t.equal(getattr(ride, m)._oprl_arena, getattr(own, m)._oprl_arena), m
+    sr, so = ride.learner.read_scalars(), own.learner.read_scalars()
+    for k in ("critic_loss", "actor_loss", "alpha"):
+        assert sr[k] == so[k], k
+
+
 def test_tqc_wide_dw_equals_small_tiles(monkeypatch):
     """csrc/dw_wide.hip (64x64 tiles for the 512x512 layers) against k_dw_adam's 16x32 tiles: same
     gradient up to the summation order over the minibatch, same Adam / Polyak / pack epilogue."""
