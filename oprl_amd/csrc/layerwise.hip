@@ -549,9 +549,9 @@ constexpr size_t kLwRun2Lds = sizeof(float) * (2 * kLw2MaxRun * 8 * 256);   // p
 static_assert(kLwRun2Lds >= sizeof(float) * (kLw2Rows * lds_ld(512) + kLw2Rows * kX0Ld), "rows + net input fit under the partial tiles");
 
 // TqcJob (kernels.h): the slice's TD targets by the last of the nets' head workgroups to arrive.  Called by all
-// threads of a forward-only head workgroup after slice_head(); scr: 16 waves x 128 floats.
-__device__ __forceinline__ void lw_tqc_target(const TqcJob& J, const MlpArgs& A, const float* outS, float* scr,
-                                              int Nout, int row0, int slice) {
+// threads of a forward-only head workgroup after slice_head().
+__device__ __forceinline__ void lw_tqc_target(const TqcJob& J, const MlpArgs& A, const float* outS, int Nout, int row0,
+                                              int slice) {
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, B = A.B;
   for (int idx = tid; idx < kR * Nout; idx += kThreads) {
@@ -568,37 +568,43 @@ __device__ __forceinline__ void lw_tqc_target(const TqcJob& J, const MlpArgs& A,
   }
   __syncthreads();
   if (s_last == 0) return;
-  const int row = row0 + wave;                          // one wave per row, 128-slot bitonic network in the wave's LDS
+  const int row = row0 + wave;                          // one wave per row
   if (row >= B) return;
+  // 128-slot ascending bitonic network in REGISTERS: lane l holds slots l and l + 64; a stage's partner is the other
+  // register (j = 64) or lane l ^ j (a cross-lane move) — the same compare-exchange network as k_tqc_target's LDS
+  // version, hence the same sorted row, in ~1/10 of its time (28 stages of LDS round trips were 6 us of this launch)
   const int total = J.n_nets * J.Q, Mt = total - J.drop;
-  float* sb = scr + wave * 128;
-  for (int e = lane; e < 128; e += 64) {
+  auto fetch = [&](int e) {
     float v = __builtin_huge_valf();
     if (e < total) {
       const int n = e / J.Q, q = e - n * J.Q;
       v = __hip_atomic_load(J.z + n * J.net_stride + (size_t)row * J.ldz + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    sb[e] = v;
-  }
-  for (int k = 2; k <= 128; k <<= 1)
+    return v;
+  };
+  float v0 = fetch(lane), v1 = fetch(lane + 64);
+#pragma unroll
+  for (int k = 2; k <= 128; k <<= 1) {
+#pragma unroll
     for (int j = k >> 1; j > 0; j >>= 1) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int e = ((lane & ~(j - 1)) << 1) | (lane & (j - 1));  // lower index of the pair
-      const int p = e | j;
-      const bool up = (e & k) == 0;
-      const float a = sb[e], b = sb[p];
-      if ((a > b) == up) { sb[e] = b; sb[p] = a; }
+      if (j == 64) {                                    // (k = 128: ascending everywhere)
+        const float lo = fminf(v0, v1), hi = fmaxf(v0, v1);
+        v0 = lo; v1 = hi;
+      } else {
+        const float p0 = __shfl_xor(v0, j), p1 = __shfl_xor(v1, j);
+        const bool low = (lane & j) == 0;               // this slot is the lower index of its pair
+        const bool up0 = (lane & k) == 0, up1 = ((lane + 64) & k) == 0;
+        v0 = (low == up0) ? fminf(v0, p0) : fmaxf(v0, p0);
+        v1 = (low == up1) ? fminf(v1, p1) : fmaxf(v1, p1);
+      }
     }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
   const float alpha = (float)exp(*J.log_alpha);
   const float al = alpha * J.logp[row];
   const float coef = (1.f - J.d[row]) * J.gamma;
   const float rr = J.r[row];
-  for (int s = lane; s < Mt; s += 64) J.target[(size_t)row * Mt + s] = rr + coef * (sb[s] - al);
+  if (lane < Mt) J.target[(size_t)row * Mt + lane] = rr + coef * (v0 - al);
+  if (lane + 64 < Mt) J.target[(size_t)row * Mt + lane + 64] = rr + coef * (v1 - al);
 }
 
 // R (n_ride = 4): ANOTHER net's k_mlp_slice_tp launch on the same slices — its clusters of four ride as the
@@ -633,7 +639,7 @@ __global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M, cons
   if (!A.do_bwd) {
     if (J.counter != nullptr) {
       __syncthreads();                                  // slice_head is done with outS / scr
-      lw_tqc_target(J, A, outS, scr, Nout, row0, slice);
+      lw_tqc_target(J, A, outS, Nout, row0, slice);
     }
     return;
   }

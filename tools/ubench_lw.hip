@@ -6,6 +6,7 @@
 #include <vector>
 #include "../oprl_amd/csrc/layerwise.hip"
 
+namespace oprl { bool mlp_slice_tp_shape_ok(const MlpArgs&, int) { return true; } }   // (slice_tp.hip is not part of this build)
 using namespace oprl;
 
 static float* dalloc(size_t n, float v) {
