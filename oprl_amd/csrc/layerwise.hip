@@ -24,6 +24,7 @@
 // Reference ops replaced: the addmm / threshold_backward chains of algos/nn_models.py:84-107 under
 // autograd, for tqc.py:128-177.
 #include <cstdlib>
+#include <cstring>
 #include "kernels.h"
 #include "slice_head.h"
 #include "tp4.h"
@@ -370,8 +371,10 @@ constexpr int kLw2Rows = 32;
 constexpr int kLw2MaxRun = 6;
 struct LwRun2 { int slices, nets, rpn, base, rem, ppx; };   // runs per net; tiles per run = base (+1 for the first rem runs); pairs per XCD
 
-template <int MODE, class P = PrecF32>
-__global__ __launch_bounds__(kThreads) void k_lw_mid_run2(const MlpMultiArgs M, int l, const LwRun2 R) {
+// (the body as a function of the workgroup index bx: the launch below, and the riding form k_slice_tp_fin)
+// KM: the nets' arguments in the kernel-argument segment; net0: R's nets are KM->a[net0 ..]
+template <int MODE, class P>
+__device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, const LwRun2& R, int bx, int net0) {
   constexpr bool BWD = MODE == 1, FIN = MODE == 2;
   constexpr int NSE = 64 / P::KS;               // macro steps of a K-eighth (64 columns): 4 / 2
   constexpr int NSW = 512 / P::KS;
@@ -384,12 +387,12 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid_run2(const MlpMultiArgs M, 
   const int i = lane & 15, kk = lane >> 4;
   // XCD x owns the (net, run) pairs [x * ppx, (x + 1) * ppx) with all their row slices: a run's weights
   // cross the fabric once and an XCD reads the rows of at most two nets
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int xcd = bx & 7, j = bx >> 3;
   const int pl = j / R.slices, pair = xcd * R.ppx + pl, slice = j - pl * R.slices;
-  if (pair >= R.nets * R.rpn) return;
+  if (pl >= R.ppx || pair >= R.nets * R.rpn) return;      // (pl >= ppx: a riding grid rounded up past the runs)
   const int net = pair / R.rpn, run = pair - net * R.rpn;
   const int t0 = run * R.base + min(run, R.rem), nt = R.base + (run < R.rem ? 1 : 0);
-  const MlpArgs& A = lw_args(net);
+  const MlpArgs& A = KM->a[net0 + net];
   const int row0 = slice * kLw2Rows, B = A.B;
   const int ke = wave & 7, par = wave >> 3;
 
@@ -531,6 +534,35 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid_run2(const MlpMultiArgs M, 
   }
 }
 
+template <int MODE, class P = PrecF32>
+__global__ __launch_bounds__(kThreads) void k_lw_mid_run2(const MlpMultiArgs M, int l, const LwRun2 R, int net0) {
+  lw_mid_run2_body<MODE, P>((const MlpMultiArgs*)__builtin_amdgcn_kernarg_segment_ptr(), l, R, (int)blockIdx.x, net0);
+}
+
+// A k_mlp_slice_tp launch (`A`: slices x 4 workgroups, blocks [0, host)) carrying, as riding workgroups behind its
+// own, the first hidden launch (first layer folded in, MODE 2) of the nets `M` — which must not depend on it.
+// TQC's critic step opens with the actor's forward on s' on 64 of 256 CUs; the online critics' first two layers on
+// (s, a) need nothing of it, and as a launch of their own they are the next 10-16 us of the chain.
+// `host` is a multiple of 8, so a rider's bx & 7 is still its XCD.
+template <class P>
+__global__ __launch_bounds__(kThreads) void k_slice_tp_fin(const MlpMultiArgs M, const MlpArgs A, const LwRun2 R, int host,
+                                                           int slices) {
+  const int b = (int)blockIdx.x;
+  if (b < host) {
+    if (b < slices * 4) slice_tp_body(A, b % slices, b / slices);
+    return;
+  }
+  lw_mid_run2_body<2, P>((const MlpMultiArgs*)__builtin_amdgcn_kernarg_segment_ptr(), 1, R, b - host, 0);
+}
+
+// The rest of such a first launch — the nets that did not fit beside k_slice_tp_fin's host — as riders of a head
+// launch (k_lw_head, blockIdx.z >= z0): their own argument block, R.nets nets from net0 on.
+struct LwFinTail {
+  MlpMultiArgs M;
+  LwRun2 R;
+  int net0, z0, bf16;     // z0 < 0: nothing rides
+};
+
 inline LwRun2 lw_run2(int B, int nets, int n_cus) {
   LwRun2 r;
   r.slices = (B + kLw2Rows - 1) / kLw2Rows;
@@ -612,9 +644,21 @@ __device__ __forceinline__ void lw_tqc_target(const TqcJob& J, const MlpArgs& A,
 // the actor's forward on s, which the actor step needs only after the critic step, runs beside the critic step's
 // heads instead of as a launch of its own (8.5 us).  The host checks that all workgroups are resident at once
 // (the riders' cluster exchanges wait for each other).
+__host__ __device__ constexpr size_t lw_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+constexpr size_t kLwHeadTailOffset =       // LwFinTail's place in k_lw_head's kernel-argument segment
+    lw_align_up(lw_align_up(lw_align_up(lw_align_up(sizeof(MlpMultiArgs), alignof(TqcJob)) + sizeof(TqcJob), alignof(MlpArgs)) +
+                                sizeof(MlpArgs), alignof(int)) + sizeof(int), alignof(LwFinTail));
 template <int WIDTH>
-__global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M, const TqcJob J, const MlpArgs R, int nets) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];        // max(LwLds<WIDTH>::total, SliceLds<256>::total(2)) floats
+__global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M, const TqcJob J, const MlpArgs R, int nets,
+                                                       const LwFinTail F) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];        // max(LwLds<WIDTH>::total, SliceLds<256>::total(2)[, kLwRun2Lds]) floats
+  if (F.z0 >= 0 && (int)blockIdx.z >= F.z0) {
+    const LwFinTail* KF = (const LwFinTail*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kLwHeadTailOffset);
+    const int bx = ((int)blockIdx.z - F.z0) * (int)gridDim.x + (int)blockIdx.x;
+    if (F.bf16) lw_mid_run2_body<2, PrecBF16>(&KF->M, 1, KF->R, bx, F.net0);
+    else lw_mid_run2_body<2, PrecF32>(&KF->M, 1, KF->R, bx, F.net0);
+    return;
+  }
   if ((int)blockIdx.z >= nets) {
     slice_tp_body(R, (int)blockIdx.x, (int)blockIdx.z - nets);
     return;
@@ -707,9 +751,16 @@ hipError_t init_layerwise_attrs() {
   }
   {
     constexpr size_t head_f = LwLds<512>::total, ride_f = SliceLds<256>::total(2);
+    size_t lds = sizeof(float) * (ride_f > head_f ? ride_f : head_f);
+    if (kLwRun2Lds > lds) lds = kLwRun2Lds;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_head<512>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(sizeof(float) * (ride_f > head_f ? ride_f : head_f)));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  for (const void* k : {reinterpret_cast<const void*>(&k_slice_tp_fin<PrecF32>), reinterpret_cast<const void*>(&k_slice_tp_fin<PrecBF16>)}) {
+    constexpr size_t ride_f = SliceLds<256>::total(2);
+    const size_t lds = sizeof(float) * ride_f > kLwRun2Lds ? sizeof(float) * ride_f : kLwRun2Lds;
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   const void* k2[6] = {reinterpret_cast<const void*>(&k_lw_mid_run2<0>), reinterpret_cast<const void*>(&k_lw_mid_run2<1>),
@@ -737,9 +788,74 @@ bool mlp_layerwise_rider_ok(const MlpArgs* a, int n, const MlpArgs& rider, int n
 
 // job: a TD-target job for the heads of a forward-only launch of all its nets (TqcJob, kernels.h), or null
 // rider: see k_lw_head; or null
+static bool lw_env(const char* name) { const char* e = getenv(name); return e != nullptr && atoi(e) != 0; }
+
+// Can the first hidden launch (first layer folded in) of these nets ride on another launch (k_slice_tp_fin)?
+bool mlp_layerwise_fin_ok(const MlpArgs* a, int n, int width) {
+  if (!mlp_layerwise_ok(a, n, width) || !a[0].do_fwd || a[0].net.n_layers < 3) return false;
+  if (lw_env("OPRL_AMD_LW_RUN16") || lw_env("OPRL_AMD_LW_EQUAL")) return false;
+  for (int j = 0; j < n; ++j)
+    if (a[j].net.dims[0] > 32) return false;
+  return true;
+}
+
+// How many of these n nets' first-launch workgroups fit beside `host_wgs` workgroups of a host launch, all resident at once
+int mlp_layerwise_fin_fit(const MlpArgs* a, int n, int host_wgs, int n_cus) {
+  const int cus = n_cus > 0 ? n_cus : 256;
+  const LwRun2 r = lw_run2(a[0].B, n, cus);          // (the run shape of the launch of all n nets: kept for every subset)
+  const int per_net = r.rpn * r.slices;
+  int fit = per_net > 0 ? (cus - host_wgs) / per_net : 0;
+  return fit < 0 ? 0 : (fit > n ? n : fit);
+}
+
+// the run shape of `n_all` nets' launch, applied to `n_sub` of them
+static LwRun2 lw_run2_subset(int B, int n_all, int n_sub, int n_cus) {
+  LwRun2 r = lw_run2(B, n_all, n_cus);
+  r.nets = n_sub;
+  r.ppx = (n_sub * r.rpn + 7) / 8;
+  return r;
+}
+
+// `host`: a prepared k_mlp_slice_tp launch (tag drawn); the first hidden launch of nets a[0 .. n_ride) of the n rides behind it
+hipError_t launch_slice_tp_with_fin(const MlpArgs& host, const MlpArgs* a, int n, int n_ride, int width, int n_cus, hipStream_t st,
+                                    bool bf16) {
+  if (!mlp_layerwise_fin_ok(a, n, width) || host.tp_xbuf == nullptr || !mlp_slice_tp_shape_ok(host, 256) || n_ride < 1 || n_ride > n)
+    return hipErrorInvalidValue;
+  MlpMultiArgs m;
+  for (int j = 0; j < n; ++j) m.a[j] = a[j];
+  for (int j = n; j < kMaxMulti; ++j) m.a[j] = a[0];
+  const LwRun2 r2 = lw_run2_subset(a[0].B, n, n_ride, n_cus > 0 ? n_cus : 256);
+  const int slices = (host.B + kR - 1) / kR, hostb = (slices * 4 + 7) / 8 * 8;
+  constexpr size_t ride_f = SliceLds<256>::total(2);
+  const size_t lds = sizeof(float) * ride_f > kLwRun2Lds ? sizeof(float) * ride_f : kLwRun2Lds;
+  const dim3 grid(hostb + 8 * r2.ppx * r2.slices), blk(kThreads);
+  if (bf16) hipLaunchKernelGGL((k_slice_tp_fin<PrecBF16>), grid, blk, lds, st, m, host, r2, hostb, slices);
+  else hipLaunchKernelGGL((k_slice_tp_fin<PrecF32>), grid, blk, lds, st, m, host, r2, hostb, slices);
+  return hipGetLastError();
+}
+
+// The first hidden launch of nets t[t0 .. t_n) (of t_n nets that pass mlp_layerwise_fin_ok) as a launch of its own
+hipError_t launch_mlp_layerwise_first(const MlpArgs* t, int t_n, int t0, int width, int n_cus, hipStream_t st, bool bf16) {
+  if (!mlp_layerwise_fin_ok(t, t_n, width) || t0 < 0 || t0 >= t_n) return hipErrorInvalidValue;
+  MlpMultiArgs m;
+  for (int j = 0; j < t_n; ++j) m.a[j] = t[j];
+  for (int j = t_n; j < kMaxMulti; ++j) m.a[j] = t[0];
+  const LwRun2 r = lw_run2_subset(t[0].B, t_n, t_n - t0, n_cus > 0 ? n_cus : 256);
+  const dim3 grid(8 * r.ppx * r.slices), blk(kThreads);
+  if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<2, PrecBF16>), grid, blk, kLwRun2Lds, st, m, 1, r, t0);
+  else hipLaunchKernelGGL((k_lw_mid_run2<2>), grid, blk, kLwRun2Lds, st, m, 1, r, t0);
+  return hipGetLastError();
+}
+
+// first_done: the first hidden launch of this forward already ran (launch_slice_tp_with_fin [+ a tail])
+// tail / tail_n / tail0 / tail16: ANOTHER forward's nets tail[0 .. tail_n), of which the first hidden launch of
+//   tail[tail0 ..] rides on this launch's heads (LwFinTail); null: nothing
 hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, bool bf16, const TqcJob* job,
-                                const MlpArgs* rider) {
+                                const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, bool tail16) {
   if (!mlp_layerwise_ok(a, n, width)) return hipErrorInvalidValue;
+  if (first_done && !mlp_layerwise_fin_ok(a, n, width)) return hipErrorInvalidValue;
+  if (tail != nullptr && (!mlp_layerwise_fin_ok(tail, tail_n, width) || tail0 < 0 || tail0 >= tail_n || tail[0].B != a[0].B))
+    return hipErrorInvalidValue;
   if (rider != nullptr && !mlp_layerwise_rider_ok(a, n, *rider, n_cus)) return hipErrorInvalidValue;
   if (job != nullptr && (a[0].do_bwd || !a[0].do_fwd || job->n_nets != n || job->n_nets * job->Q > 128 || job->counter == nullptr))
     return hipErrorInvalidValue;
@@ -765,9 +881,9 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
       if (mode == 1) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run<1, PrecBF16>), runs, blk, kLwRunLds, st, m, l, r); else hipLaunchKernelGGL((k_lw_mid_run<1>), runs, blk, kLwRunLds, st, m, l, r); }
       if (mode == 2) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run<2, PrecBF16>), runs, blk, kLwRunLds, st, m, l, r); else hipLaunchKernelGGL((k_lw_mid_run<2>), runs, blk, kLwRunLds, st, m, l, r); }
     } else {
-      if (mode == 0) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<0, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2); else hipLaunchKernelGGL((k_lw_mid_run2<0>), runs2, blk, kLwRun2Lds, st, m, l, r2); }
-      if (mode == 1) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<1, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2); else hipLaunchKernelGGL((k_lw_mid_run2<1>), runs2, blk, kLwRun2Lds, st, m, l, r2); }
-      if (mode == 2) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<2, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2); else hipLaunchKernelGGL((k_lw_mid_run2<2>), runs2, blk, kLwRun2Lds, st, m, l, r2); }
+      if (mode == 0) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<0, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); else hipLaunchKernelGGL((k_lw_mid_run2<0>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); }
+      if (mode == 1) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<1, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); else hipLaunchKernelGGL((k_lw_mid_run2<1>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); }
+      if (mode == 2) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<2, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); else hipLaunchKernelGGL((k_lw_mid_run2<2>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); }
     }
   };
   if (a[0].do_fwd) {
@@ -776,16 +892,30 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
     for (int j = 0; j < n; ++j) fuse_in = fuse_in && a[j].net.dims[0] <= 32;
     if (!fuse_in) hipLaunchKernelGGL(k_lw_in<512>, wide, blk, 0, st, m, g);
     for (int l = 1; l + 1 < L; ++l) {
+      if (l == 1 && first_done) continue;
       if (equal_wgs) hipLaunchKernelGGL((k_lw_mid<512, false>), wide, blk, 0, st, m, l, g);
       else mid(l == 1 && fuse_in ? 2 : 0, l);
     }
   }
   {
     constexpr size_t head_f = LwLds<512>::total, ride_f = SliceLds<256>::total(2);
-    const size_t lds = sizeof(float) * (rider != nullptr && ride_f > head_f ? ride_f : head_f);
-    const dim3 heads(slices, 1, n + (rider != nullptr ? 4 : 0));
+    size_t lds = sizeof(float) * (rider != nullptr && ride_f > head_f ? ride_f : head_f);
+    int z = n + (rider != nullptr ? 4 : 0);
+    static const LwFinTail none = [] { LwFinTail f; memset((void*)&f, 0, sizeof f); f.z0 = -1; return f; }();
+    LwFinTail ft_local;
+    const LwFinTail* ft = &none;
+    if (tail != nullptr) {
+      for (int j = 0; j < tail_n; ++j) ft_local.M.a[j] = tail[j];
+      for (int j = tail_n; j < kMaxMulti; ++j) ft_local.M.a[j] = tail[0];
+      ft_local.R = lw_run2_subset(tail[0].B, tail_n, tail_n - tail0, n_cus > 0 ? n_cus : 256);
+      ft_local.net0 = tail0; ft_local.z0 = z; ft_local.bf16 = tail16 ? 1 : 0;
+      z += (8 * ft_local.R.ppx * ft_local.R.slices + slices - 1) / slices;
+      if (kLwRun2Lds > lds) lds = kLwRun2Lds;
+      ft = &ft_local;
+    }
+    const dim3 heads(slices, 1, z);
     hipLaunchKernelGGL(k_lw_head<512>, heads, blk, lds, st, m, job != nullptr ? *job : TqcJob{},
-                       rider != nullptr ? *rider : a[0], n);
+                       rider != nullptr ? *rider : a[0], n, *ft);
   }
   if (a[0].do_bwd) {
     for (int l = L - 2; l >= 1; --l) {

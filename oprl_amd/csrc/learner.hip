@@ -130,7 +130,12 @@ hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
 hipError_t launch_mlp_slice_multi(const MlpArgs* a, int n, int width, hipStream_t st);
 bool mlp_layerwise_ok(const MlpArgs* a, int n, int width);
 hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, bool bf16, const TqcJob* job,
-                                const MlpArgs* rider);
+                                const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, bool tail16);
+bool mlp_layerwise_fin_ok(const MlpArgs* a, int n, int width);
+int mlp_layerwise_fin_fit(const MlpArgs* a, int n, int host_wgs, int n_cus);
+hipError_t launch_slice_tp_with_fin(const MlpArgs& host, const MlpArgs* a, int n, int n_ride, int width, int n_cus, hipStream_t st,
+                                    bool bf16);
+hipError_t launch_mlp_layerwise_first(const MlpArgs* t, int t_n, int t0, int width, int n_cus, hipStream_t st, bool bf16);
 bool mlp_layerwise_rider_ok(const MlpArgs* a, int n, const MlpArgs& rider, int n_cus);
 hipError_t init_layerwise_attrs();
 hipError_t launch_mlp_slice_tp(const MlpArgs& a, hipStream_t st);
@@ -378,6 +383,12 @@ struct oprl_learner {
   bool no_dp_inline = false;   // OPRL_AMD_NO_DP_INLINE: peer-window exchanges as separate launches (tests / A-B)
   bool no_twin_split = false;  // OPRL_AMD_NO_TWIN_SPLIT: role A runs both target critics back to back (tests / A-B)
   bool no_multi = false;
+  MlpArgs fin_args[OPRL_MAX_CRITICS];   // TQC: the online critics' first-launch arguments of this update (critic_phase step 1) ...
+  int fin_tail0 = -1;          // ... of which [fin_tail0, nc) did not fit beside the actor's forward: offered to the target pass's head launch (-1: none pending)
+  bool fin16 = false;
+  bool fin_done = false;       // TQC: the online critics' first hidden launch rode on the actor's forward on s' (critic_phase step 1); step 3 skips it
+  bool no_fin_ride = false;    // OPRL_AMD_NO_FIN_RIDE: it stays the first launch of step 3 (tests / A-B)
+  float* lw_scratch = nullptr; // [critics][layers 1 .. L-1][Bmax x 512]: activations of forward-only layer-by-layer launches (the target pass) — not the nets' dW exchange buffers, which the early first launch has already filled
   MlpArgs rider;               // TQC: the actor's forward on s, prepared in critic_phase to ride on the critic step's head launch ...
   bool rider_pending = false;  // ... offered to the next for_each_net; taken: rider_done, and actor_phase skips its step 5
   bool rider_done = false;
@@ -686,7 +697,10 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
         MlpArgs& a = h->multi_args[k];
         const NetWs& ws = h->ws_critic[k];
         for (int l = 1; l < a.net.n_layers; ++l)
-          if (a.Xg[l] == nullptr) a.Xg[l] = ws.X[l];
+          if (a.Xg[l] == nullptr)
+            a.Xg[l] = (!a.do_bwd && h->lw_scratch != nullptr)
+                          ? h->lw_scratch + ((size_t)k * (kMaxLayers - 1) + (l - 1)) * (size_t)h->Bmax * 512
+                          : ws.X[l];
         for (int l = 0; l + 1 < a.net.n_layers; ++l)
           if (a.dYg[l] == nullptr) a.dYg[l] = ws.dY[l];
       }
@@ -720,7 +734,22 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
         h->rider_pending = false;
         h->rider_done = true;
       }
-      hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, h->n_cus, st, lw16, job, rider);
+      const bool first_done = h->fin_done && h->multi_args[0].do_bwd && h->multi_args[0].do_fwd && h->multi_args[0].Xg[0] != nullptr;
+      if (first_done) h->fin_done = false;
+      // the part of the online critics' early first launch that did not fit beside the actor's forward rides on the
+      // target pass's heads (forward-only launch, 80 workgroups)
+      const MlpArgs* tail = nullptr;
+      int tail0 = 0;
+      if (h->fin_tail0 >= 0 && !h->multi_args[0].do_bwd && h->multi_args[0].do_fwd) {
+        const int slices = (h->multi_args[0].B + kR - 1) / kR;
+        const int rest = h->nc - h->fin_tail0;
+        if (mlp_layerwise_fin_fit(h->fin_args, h->nc, slices * h->multi_n, h->n_cus) >= rest) {   // all resident at once
+          tail = h->fin_args; tail0 = h->fin_tail0;
+          h->fin_tail0 = -1;
+        }
+      }
+      hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, h->n_cus, st, lw16, job, rider, first_done,
+                                          tail, h->nc, tail0, h->fin16);
       prof_end(st);
       HIPC(e);
     } else if (same) {
@@ -1028,7 +1057,43 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     if (algo == OPRL_DDPG) f.out_act = ACT_TANH;
     else if (algo == OPRL_TD3) { f.out_act = ACT_TANH_SMOOTH; seed_rng(f, h, noise0, 1); }
     else { f.out_act = ACT_GAUSS; f.logp = h->logp2; seed_rng(f, h, noise0, 1); }
-    RC(launch(f, h->w_actor, st));
+    // TQC: this launch is 64 workgroups on 256 CUs, and the online critics' first two layers on (s, a) — the
+    // first launch of step 3 — depend on nothing of it: they ride behind it (k_slice_tp_fin, layerwise.hip)
+    bool fin_ride = false, fin16 = false;
+    MlpArgs* fin_args = h->fin_args;
+    h->fin_done = false;
+    h->fin_tail0 = -1;
+    if (algo == OPRL_TQC && !h->no_fin_ride && !h->no_layerwise && !h->no_multi && nc > 2 && nc <= kMaxMulti &&
+        h->lw_scratch != nullptr && h->w_critic == 512 && f.tp_xbuf != nullptr) {
+      fin16 = h->bf16;
+      for (int j = 0; j < nc; ++j) {
+        MlpArgs g = base_args(h, c.critics[j], false, B);
+        g.do_fwd = 1; g.do_bwd = 1;
+        g.x0 = s; g.k0 = S; g.x1 = a; g.k1 = A;
+        with_store(g, h->ws_critic[j], true, true);
+        for (int l = 1; l + 1 < g.net.n_layers; ++l) fin16 = fin16 && g.pf16[l] != nullptr && g.pb16[l] != nullptr;
+        fin_args[j] = g;
+      }
+      if (fin16)
+        for (int j = 0; j < nc; ++j)
+          for (int l = 1; l + 1 < fin_args[j].net.n_layers; ++l) fin_args[j].net.pf[l] = fin_args[j].pf16[l];
+      fin_ride = mlp_layerwise_fin_ok(fin_args, nc, h->w_critic);
+    }
+    // as many nets as fit beside the forward's 4 x slices workgroups with everything resident at once (4 of TQC's 5)
+    const int n_ride = fin_ride ? mlp_layerwise_fin_fit(fin_args, nc, 4 * n_slices, h->n_cus) : 0;
+    if (fin_ride && n_ride >= 1) {
+      MlpArgs ff = f;
+      RC(next_tp_tag(ff.tp_tag_counter, ff.tp_xbuf, ff.tp_xbuf_bytes, st, &ff.tp_tag));
+      prof_begin(0, st);
+      hipError_t e = launch_slice_tp_with_fin(ff, fin_args, nc, n_ride, h->w_critic, h->n_cus, st, fin16);
+      prof_end(st);
+      HIPC(e);
+      h->fin_done = true;
+      h->fin16 = fin16;
+      if (n_ride < nc) h->fin_tail0 = n_ride;
+    } else {
+      RC(launch(f, h->w_actor, st));
+    }
   }
   // 2. target critics on (s', a')   (independent: one stream each)
   if (algo == OPRL_TQC && h->tqc_counter != nullptr && !h->no_tqc_ride) {
@@ -1047,6 +1112,13 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     f.out = h->qn + (size_t)j * h->Bmax * h->ldq; f.ldo = h->ldq;
     return launch(f, h->w_critic, sj);
   }));
+  if (h->fin_tail0 >= 0) {                           // (the rest of the early first launch found no head launch to ride on)
+    prof_begin(0, st);
+    hipError_t e = launch_mlp_layerwise_first(h->fin_args, nc, h->fin_tail0, h->w_critic, h->n_cus, st, h->fin16);
+    prof_end(st);
+    HIPC(e);
+    h->fin_tail0 = -1;
+  }
   if (algo == OPRL_TQC && h->tqc_job_pending) {     // (the job did not ride: not the layer-by-layer path)
     h->tqc_job_pending = false;
     const int Q = c.hp.n_quantiles, drop = c.hp.top_quantiles_to_drop;
@@ -1095,6 +1167,11 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     return launch(f, h->w_critic, sj);
   }));
   h->rider_pending = false;          // (not taken: actor_phase launches the forward itself)
+  if (h->fin_done) {                 // the early first launch was not picked up: step 3 did not run layer by layer
+    h->fin_done = false;
+    set_err("TQC critic step: the online critics' early first launch has no layer-by-layer continuation");
+    return OPRL_ERR_STATE;
+  }
   // 4. dW + Adam (+ Polyak where the reference does it every step)
   {
     const bool polyak = (algo == OPRL_TD3) ? (h->update_count % c.hp.policy_freq == 0) : true;
@@ -1762,6 +1839,12 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->no_multi = (nm != nullptr && atoi(nm) != 0);
     const char* nlw = getenv("OPRL_AMD_NO_LAYERWISE");
     h->no_layerwise = (nlw != nullptr && atoi(nlw) != 0);
+    const char* nfr = getenv("OPRL_AMD_NO_FIN_RIDE");
+    h->no_fin_ride = (nfr != nullptr && atoi(nfr) != 0);
+    if (cfg->algo == OPRL_TQC && h->w_critic == 512) {
+      const size_t n = (size_t)nc * (kMaxLayers - 1) * (size_t)h->Bmax * 512;
+      if (hipMalloc(&h->lw_scratch, n * sizeof(float)) != hipSuccess) h->lw_scratch = nullptr;   // (then: the nets' own buffers, no early launch)
+    }
     const char* nar = getenv("OPRL_AMD_NO_AF_RIDE");
     h->no_af_ride = (nar != nullptr && atoi(nar) != 0);
     const char* ntr = getenv("OPRL_AMD_NO_TQC_RIDE");
@@ -1846,6 +1929,7 @@ extern "C" int oprl_learner_destroy(oprl_learner* h) {
   if (h->fused) { std::lock_guard<std::mutex> lk(g_chain_mu); if (g_chain.live > 0) g_chain.live -= 1; }
   if (h->xbuf) (void)hipFree(h->xbuf);
   if (h->tqc_counter) (void)hipFree(h->tqc_counter);
+  if (h->lw_scratch) (void)hipFree(h->lw_scratch);
   if (h->err_host) (void)hipHostFree(h->err_host);
   if (h->p2p.window) p2p_destroy(h->p2p);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);

@@ -430,6 +430,40 @@ def test_tqc_actor_forward_riding_on_heads_equals_own_launch(B, monkeypatch):
         assert sr[k] == so[k], k
 
 
+@pytest.mark.parametrize("B,prec", [(256, "f32"), (100, "f32"), (256, "bf16")])
+def test_tqc_early_first_launch_equals_in_place(B, prec, monkeypatch):
+    """TQC's online critics' first hidden launch riding behind the actor's forward on s' (k_slice_tp_fin) against the
+    same launch in its place at the head of step 3: the same workgroup code on the same inputs, the target pass on
+    scratch activations instead of the nets' dW buffers — bit-identical, through update() and through step_n."""
+    from oprl_amd.algos.tqc import TQC
+    from oprl_amd.logging import NullLogger
+    from tests.test_gpu_callers import _filled_buffer
+
+    def make():
+        t.manual_seed(0)
+        return TQC(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=256,
+                   precision=prec).create()
+
+    early = make()
+    monkeypatch.setenv("OPRL_AMD_NO_FIN_RIDE", "1")      # (read when the learner is created)
+    inplace = make()
+    for step in range(3):
+        batch = [x.cuda() for x in fx.make_batch(90 + step, B, 24, 6)]
+        early.update(*batch)
+        inplace.update(*batch)
+    buf = _filled_buffer()
+    early.learner.step_n(buf.handle, 12, 64, seed=9)
+    inplace.learner.step_n(buf.handle, 12, 64, seed=9)
+    t.cuda.synchronize()
+    early.learner.check()
+    assert t.isfinite(early.critic._oprl_arena).all()
+    for m in ("actor", "critic", "critic_target"):
+        assert t.equal(getattr(early, m)._oprl_arena, getattr(inplace, m)._oprl_arena), m
+    se, si = early.learner.read_scalars(), inplace.learner.read_scalars()
+    for k in ("critic_loss", "actor_loss", "alpha"):
+        assert se[k] == si[k], k
+
+
 def test_tqc_wide_dw_equals_small_tiles(monkeypatch):
     """csrc/dw_wide.hip (64x64 tiles for the 512x512 layers) against k_dw_adam's 16x32 tiles: same
     gradient up to the summation order over the minibatch, same Adam / Polyak / pack epilogue."""

@@ -57,13 +57,13 @@ int main() {
     printf("%-40s %7.2f us per launch\n", name, ms * 1e3 / n);
   };
   time_it("run16 fwd f32", [&] { hipLaunchKernelGGL((k_lw_mid_run<0>), runs, blk, kLwRunLds, st, m, 2, r); });
-  time_it("run32 fwd f32", [&] { hipLaunchKernelGGL((k_lw_mid_run2<0>), runs2, blk, kLwRun2Lds, st, m, 2, r2); });
+  time_it("run32 fwd f32", [&] { hipLaunchKernelGGL((k_lw_mid_run2<0>), runs2, blk, kLwRun2Lds, st, m, 2, r2, 0); });
   time_it("run16 bwd f32", [&] { hipLaunchKernelGGL((k_lw_mid_run<1>), runs, blk, kLwRunLds, st, m, 2, r); });
-  time_it("run32 bwd f32", [&] { hipLaunchKernelGGL((k_lw_mid_run2<1>), runs2, blk, kLwRun2Lds, st, m, 2, r2); });
+  time_it("run32 bwd f32", [&] { hipLaunchKernelGGL((k_lw_mid_run2<1>), runs2, blk, kLwRun2Lds, st, m, 2, r2, 0); });
   time_it("run16 fwd+first f32", [&] { hipLaunchKernelGGL((k_lw_mid_run<2>), runs, blk, kLwRunLds, st, m, 1, r); });
-  time_it("run32 fwd+first f32", [&] { hipLaunchKernelGGL((k_lw_mid_run2<2>), runs2, blk, kLwRun2Lds, st, m, 1, r2); });
+  time_it("run32 fwd+first f32", [&] { hipLaunchKernelGGL((k_lw_mid_run2<2>), runs2, blk, kLwRun2Lds, st, m, 1, r2, 0); });
   time_it("run16 fwd bf16", [&] { hipLaunchKernelGGL((k_lw_mid_run<0, PrecBF16>), runs, blk, kLwRunLds, st, m, 2, r); });
-  time_it("run32 fwd bf16", [&] { hipLaunchKernelGGL((k_lw_mid_run2<0, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, 2, r2); });
-  time_it("run32 fwd+first bf16", [&] { hipLaunchKernelGGL((k_lw_mid_run2<2, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, 1, r2); });
+  time_it("run32 fwd bf16", [&] { hipLaunchKernelGGL((k_lw_mid_run2<0, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, 2, r2, 0); });
+  time_it("run32 fwd+first bf16", [&] { hipLaunchKernelGGL((k_lw_mid_run2<2, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, 1, r2, 0); });
   return 0;
 }
