@@ -1,0 +1,91 @@
+// batch_rows.h — a 16-row slice of the minibatch into LDS, from caller-supplied rows or gathered from the replay
+// with the draw of k_replay_gather (replay.hip), and the same slice written back out as plain rows: what the fused
+// phase kernels start with (fused_ddpg.hip), their phase 2's prefetch row, and the riding workgroups that gather
+// the NEXT update's rows during a layer-by-layer launch (layerwise.hip, PrefetchJob).
+#pragma once
+#include "kernels.h"
+#include "philox.h"
+#include "replay_index.h"
+
+namespace oprl {
+
+constexpr int kMaxEnds = 2048;
+
+// rows [row0, row0+kR) of the minibatch -> xa = [s | a | 0], xb = [s' | 0], r, d (LDS)
+__device__ __forceinline__ void load_batch(const BatchSrc& P, int row0, int B, int S, int A,
+                                           float* xa, float* xb, float* rS, float* dS, int* meta,
+                                           int* endsS) {
+  const int tid = threadIdx.x;
+  lds_zero(xa, 2 * kR * kX0Ld);   // xa and xb are adjacent
+  if (P.gather) {
+    const EndsLds ET = stage_ends(P.ends, P.n_eps, endsS, kMaxEnds, tid, kThreads);
+    __syncthreads();
+    if (tid < kR) {
+      const int i = row0 + tid;
+      int e = 0, t = 0;
+      if (i < B) {
+        const u32x4 rnd = philox4x32_10(
+            u32x4{(uint32_t)P.counter, (uint32_t)(P.counter >> 32), (uint32_t)i, 0x5a17u},
+            (uint32_t)P.seed, (uint32_t)(P.seed >> 32));
+        const long ind = (long)bounded_u32(rnd.x, (uint32_t)P.n_transitions);
+        long start = 0;
+        e = find_episode(P.ends, P.n_eps, ET, ind, &start);
+        t = (int)(ind - start);
+      }
+      meta[tid] = e;
+      meta[kR + tid] = t;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < kR * (2 * S + A + 2); idx += kThreads) {
+      const int W = 2 * S + A + 2;
+      const int row = idx / W, c = idx - row * W;
+      if (row0 + row >= B) continue;
+      const long e = meta[row], t = meta[kR + row];
+      // branch-free: one load and one LDS store per element (an if/else per kind diverges inside
+      // a wave and serialises load -> wait -> store)
+      const float* src = P.states + (e * (P.L + 1) + t) * S + c;          // s | s' contiguous
+      float* dst = xa + row * kX0Ld + c;
+      if (c >= S) dst = xb + row * kX0Ld + (c - S);
+      if (c >= 2 * S) { src = P.actions + (e * P.L + t) * A + (c - 2 * S); dst = xa + row * kX0Ld + S + (c - 2 * S); }
+      if (c == 2 * S + A) { src = P.rewards + e * P.L + t; dst = rS + row; }
+      if (c == 2 * S + A + 1) { src = P.dones + e * P.L + t; dst = dS + row; }
+      *dst = *src;
+    }
+  } else {
+    __syncthreads();
+    load_rows(xa, kX0Ld, 0, P.s, S, S, row0, B);
+    load_rows(xa, kX0Ld, S, P.a, A, A, row0, B);
+    load_rows(xb, kX0Ld, 0, P.s2, S, S, row0, B);
+    if (tid < kR) {
+      const int gr = row0 + tid;
+      rS[tid] = gr < B ? P.r[gr] : 0.f;
+      dS[tid] = gr < B ? P.d[gr] : 0.f;
+    }
+  }
+}
+
+// The next update's rows, gathered by one workgroup per 16-row slice and left as plain rows in N.s / a / r / d / s2.
+// smem: 2 * kR * kX0Ld + 96 + kMaxEnds floats.  (PrefetchJob: kernels.h)
+__device__ __forceinline__ void prefetch_rows_body(const PrefetchJob& J, int slice, float* smem) {
+  const int tid = threadIdx.x, row0 = slice * kR, S = J.S, Ad = J.A, B = J.B;
+  float* xa = smem;
+  float* xb = xa + kR * kX0Ld;
+  float* rS = xb + kR * kX0Ld;
+  float* dS = rS + kR;
+  int* meta = reinterpret_cast<int*>(dS + 2 * kR);
+  int* endsS = reinterpret_cast<int*>(rS + 96);
+  load_batch(J.next, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
+  __syncthreads();
+  store_rows(xa, kX0Ld, const_cast<float*>(J.next.s), S, S, row0, B);
+  store_rows(xb, kX0Ld, const_cast<float*>(J.next.s2), S, S, row0, B);
+  for (int idx = tid; idx < kR * Ad; idx += kThreads) {
+    const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
+    if (gr < B) const_cast<float*>(J.next.a)[(size_t)gr * Ad + col] = xa[row * kX0Ld + S + col];
+  }
+  if (tid < kR && row0 + tid < B) {
+    const_cast<float*>(J.next.r)[row0 + tid] = rS[tid];
+    const_cast<float*>(J.next.d)[row0 + tid] = dS[tid];
+  }
+}
+
+}  // namespace oprl

@@ -40,13 +40,14 @@
 #include "kernels.h"
 #include "philox.h"
 #include "replay_index.h"
+#include "batch_rows.h"
 #include "slice_head.h"
 #include "tp4.h"
 #include "dw_body.h"
 
 namespace oprl {
 
-constexpr int kMaxEnds = 2048;
+// (kMaxEnds: batch_rows.h)
 
 // one MLP pass of a cluster: the lean tp4 routines or the generic tp3 ones
 template <int WIDTH, bool LEAN, class P, int NM = 4, class ST>
@@ -76,59 +77,6 @@ struct FusedLds {   // floats
   static constexpr int misc = scr + kWaves * kR * 16;   // r[16] d[16] y[16] ep[16] t[16] + ends
   static constexpr int total = misc + 96 + kMaxEnds;
 };
-
-// rows [row0, row0+kR) of the minibatch -> xa = [s | a | 0], xb = [s' | 0], r, d (LDS)
-__device__ __forceinline__ void load_batch(const BatchSrc& P, int row0, int B, int S, int A,
-                                           float* xa, float* xb, float* rS, float* dS, int* meta,
-                                           int* endsS) {
-  const int tid = threadIdx.x;
-  lds_zero(xa, 2 * kR * kX0Ld);   // xa and xb are adjacent
-  if (P.gather) {
-    const EndsLds ET = stage_ends(P.ends, P.n_eps, endsS, kMaxEnds, tid, kThreads);
-    __syncthreads();
-    if (tid < kR) {
-      const int i = row0 + tid;
-      int e = 0, t = 0;
-      if (i < B) {
-        const u32x4 rnd = philox4x32_10(
-            u32x4{(uint32_t)P.counter, (uint32_t)(P.counter >> 32), (uint32_t)i, 0x5a17u},
-            (uint32_t)P.seed, (uint32_t)(P.seed >> 32));
-        const long ind = (long)bounded_u32(rnd.x, (uint32_t)P.n_transitions);
-        long start = 0;
-        e = find_episode(P.ends, P.n_eps, ET, ind, &start);
-        t = (int)(ind - start);
-      }
-      meta[tid] = e;
-      meta[kR + tid] = t;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < kR * (2 * S + A + 2); idx += kThreads) {
-      const int W = 2 * S + A + 2;
-      const int row = idx / W, c = idx - row * W;
-      if (row0 + row >= B) continue;
-      const long e = meta[row], t = meta[kR + row];
-      // branch-free: one load and one LDS store per element (an if/else per kind diverges inside
-      // a wave and serialises load -> wait -> store)
-      const float* src = P.states + (e * (P.L + 1) + t) * S + c;          // s | s' contiguous
-      float* dst = xa + row * kX0Ld + c;
-      if (c >= S) dst = xb + row * kX0Ld + (c - S);
-      if (c >= 2 * S) { src = P.actions + (e * P.L + t) * A + (c - 2 * S); dst = xa + row * kX0Ld + S + (c - 2 * S); }
-      if (c == 2 * S + A) { src = P.rewards + e * P.L + t; dst = rS + row; }
-      if (c == 2 * S + A + 1) { src = P.dones + e * P.L + t; dst = dS + row; }
-      *dst = *src;
-    }
-  } else {
-    __syncthreads();
-    load_rows(xa, kX0Ld, 0, P.s, S, S, row0, B);
-    load_rows(xa, kX0Ld, S, P.a, A, A, row0, B);
-    load_rows(xb, kX0Ld, 0, P.s2, S, S, row0, B);
-    if (tid < kR) {
-      const int gr = row0 + tid;
-      rS[tid] = gr < B ? P.r[gr] : 0.f;
-      dS[tid] = gr < B ? P.d[gr] : 0.f;
-    }
-  }
-}
 
 // one tagged 8-byte granule: the value is its own flag (as the cluster exchanges of tp3.h / tp4.h)
 __device__ __forceinline__ void granule_put(unsigned long long* g, unsigned tag, float v) {

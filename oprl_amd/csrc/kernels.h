@@ -250,6 +250,14 @@ struct BatchSrc {
   unsigned long long seed, counter;
 };
 
+// The next update's minibatch rows gathered by riding workgroups of a layer-by-layer launch (batch_rows.h
+// prefetch_rows_body, layerwise.hip k_lw_dact): one workgroup per 16-row slice
+struct PrefetchJob {
+  BatchSrc next;       // gather = 1; s .. s2: where the rows go
+  int S, A, B;
+  int z0;              // the riders are blockIdx.z == z0 of their host launch (< 0: no job)
+};
+
 struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   Net actor, actor_t, critic, critic_t;
   // TD3 (n_critics == 2): the twin critic, its exchange buffers, target-policy smoothing

@@ -29,6 +29,7 @@
 #include "slice_head.h"
 #include "tp4.h"
 #include "slice_tp_body.h"
+#include "batch_rows.h"
 
 namespace oprl {
 
@@ -77,6 +78,8 @@ inline LwGrid lw_grid(int slices, int ncg, int nets) {
   return g;
 }
 inline int lw_blocks(const LwGrid& g) { return 8 * g.upx * g.spu; }
+
+__host__ __device__ constexpr size_t lw_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 __device__ __forceinline__ const MlpArgs& lw_args(int net) {
   const MlpMultiArgs* kp = (const MlpMultiArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -644,7 +647,6 @@ __device__ __forceinline__ void lw_tqc_target(const TqcJob& J, const MlpArgs& A,
 // the actor's forward on s, which the actor step needs only after the critic step, runs beside the critic step's
 // heads instead of as a launch of its own (8.5 us).  The host checks that all workgroups are resident at once
 // (the riders' cluster exchanges wait for each other).
-__host__ __device__ constexpr size_t lw_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 constexpr size_t kLwHeadTailOffset =       // LwFinTail's place in k_lw_head's kernel-argument segment
     lw_align_up(lw_align_up(lw_align_up(lw_align_up(sizeof(MlpMultiArgs), alignof(TqcJob)) + sizeof(TqcJob), alignof(MlpArgs)) +
                                 sizeof(MlpArgs), alignof(int)) + sizeof(int), alignof(LwFinTail));
@@ -698,9 +700,18 @@ __global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M, cons
   store_rows4(hb, WL, A.dYg[L - 2], WIDTH, WIDTH, row0, B);
 }
 
+// Pj (blockIdx.z == Pj.z0): one more row of workgroups gathers the NEXT update's minibatch rows from the replay
+// (step_n: a k_replay_gather launch per update, 5.6 us + gap, as riders of a launch that fills a third of the chip)
+constexpr size_t kLwDactPjOffset = lw_align_up(sizeof(MlpMultiArgs), alignof(PrefetchJob));
+static_assert(LwLds<512>::total >= 2 * kR * kX0Ld + 96 + kMaxEnds, "the prefetch riders' LDS fits in the launch's");
 template <int WIDTH>
-__global__ __launch_bounds__(kThreads) void k_lw_dact(const MlpMultiArgs M) {
+__global__ __launch_bounds__(kThreads) void k_lw_dact(const MlpMultiArgs M, const PrefetchJob Pj) {
   __shared__ __attribute__((aligned(16))) float smem[LwLds<WIDTH>::total];
+  if (Pj.z0 >= 0 && (int)blockIdx.z >= Pj.z0) {
+    prefetch_rows_body(*(const PrefetchJob*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kLwDactPjOffset),
+                       (int)blockIdx.x, smem);
+    return;
+  }
   using LY = LwLds<WIDTH>;
   constexpr int WL = LY::WL, NTW = WIDTH / 16;
   const MlpArgs& A = lw_args(blockIdx.z);
@@ -847,11 +858,13 @@ hipError_t launch_mlp_layerwise_first(const MlpArgs* t, int t_n, int t0, int wid
   return hipGetLastError();
 }
 
+// prefetch: a PrefetchJob (batch_rows.h) for a launch with a k_lw_dact stage: the next update's rows, or null
 // first_done: the first hidden launch of this forward already ran (launch_slice_tp_with_fin [+ a tail])
 // tail / tail_n / tail0 / tail16: ANOTHER forward's nets tail[0 .. tail_n), of which the first hidden launch of
 //   tail[tail0 ..] rides on this launch's heads (LwFinTail); null: nothing
 hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, bool bf16, const TqcJob* job,
-                                const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, bool tail16) {
+                                const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, bool tail16,
+                                const PrefetchJob* prefetch) {
   if (!mlp_layerwise_ok(a, n, width)) return hipErrorInvalidValue;
   if (first_done && !mlp_layerwise_fin_ok(a, n, width)) return hipErrorInvalidValue;
   if (tail != nullptr && (!mlp_layerwise_fin_ok(tail, tail_n, width) || tail0 < 0 || tail0 >= tail_n || tail[0].B != a[0].B))
@@ -922,7 +935,14 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
       if (equal_wgs) hipLaunchKernelGGL((k_lw_mid<512, true>), wide, blk, 0, st, m, l, g);
       else mid(1, l);
     }
-    if (a[0].dact_cols > 0) hipLaunchKernelGGL(k_lw_dact<512>, narrow, blk, 0, st, m);
+    if (a[0].dact_cols > 0) {
+      static const PrefetchJob no_job = [] { PrefetchJob j; memset((void*)&j, 0, sizeof j); j.z0 = -1; return j; }();
+      PrefetchJob pj = no_job;
+      if (prefetch != nullptr && prefetch->B == a[0].B) { pj = *prefetch; pj.z0 = n; }
+      hipLaunchKernelGGL(k_lw_dact<512>, dim3(slices, 1, n + (pj.z0 >= 0 ? 1 : 0)), blk, 0, st, m, pj);
+    } else if (prefetch != nullptr) {
+      return hipErrorInvalidValue;
+    }
   }
   return hipGetLastError();
 }

@@ -130,7 +130,8 @@ hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
 hipError_t launch_mlp_slice_multi(const MlpArgs* a, int n, int width, hipStream_t st);
 bool mlp_layerwise_ok(const MlpArgs* a, int n, int width);
 hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, bool bf16, const TqcJob* job,
-                                const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, bool tail16);
+                                const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, bool tail16,
+                                const PrefetchJob* prefetch);
 bool mlp_layerwise_fin_ok(const MlpArgs* a, int n, int width);
 int mlp_layerwise_fin_fit(const MlpArgs* a, int n, int host_wgs, int n_cus);
 hipError_t launch_slice_tp_with_fin(const MlpArgs& host, const MlpArgs* a, int n, int n_ride, int width, int n_cus, hipStream_t st,
@@ -383,6 +384,10 @@ struct oprl_learner {
   bool no_dp_inline = false;   // OPRL_AMD_NO_DP_INLINE: peer-window exchanges as separate launches (tests / A-B)
   bool no_twin_split = false;  // OPRL_AMD_NO_TWIN_SPLIT: role A runs both target critics back to back (tests / A-B)
   bool no_multi = false;
+  PrefetchJob prefetch;        // step_n on the generic path (TQC): the next update's rows as riders of this update's k_lw_dact launch
+  bool prefetch_pending = false, prefetch_done = false;
+  bool no_gather_ride = false; // OPRL_AMD_NO_GATHER_RIDE: a k_replay_gather launch per update (tests / A-B)
+  float* batch_alt = nullptr;  // the second set of batch rows [Bmax x (2 S + A + 2)] the riders fill while an update reads the first
   MlpArgs fin_args[OPRL_MAX_CRITICS];   // TQC: the online critics' first-launch arguments of this update (critic_phase step 1) ...
   int fin_tail0 = -1;          // ... of which [fin_tail0, nc) did not fit beside the actor's forward: offered to the target pass's head launch (-1: none pending)
   bool fin16 = false;
@@ -748,8 +753,15 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
           h->fin_tail0 = -1;
         }
       }
+      // step_n: the next update's rows ride on the launch sequence that ends in k_lw_dact (the actor step's critics)
+      const PrefetchJob* pf = nullptr;
+      if (h->prefetch_pending && h->multi_args[0].do_bwd && h->multi_args[0].dact_cols > 0 && h->prefetch.B == h->multi_args[0].B) {
+        pf = &h->prefetch;
+        h->prefetch_pending = false;
+        h->prefetch_done = true;
+      }
       hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, h->n_cus, st, lw16, job, rider, first_done,
-                                          tail, h->nc, tail0, h->fin16);
+                                          tail, h->nc, tail0, h->fin16, pf);
       prof_end(st);
       HIPC(e);
     } else if (same) {
@@ -1839,6 +1851,12 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->no_multi = (nm != nullptr && atoi(nm) != 0);
     const char* nlw = getenv("OPRL_AMD_NO_LAYERWISE");
     h->no_layerwise = (nlw != nullptr && atoi(nlw) != 0);
+    const char* ngr = getenv("OPRL_AMD_NO_GATHER_RIDE");
+    h->no_gather_ride = (ngr != nullptr && atoi(ngr) != 0);
+    if (cfg->algo == OPRL_TQC) {
+      const size_t n = (size_t)h->Bmax * (2 * (size_t)h->S + h->A + 2);
+      if (hipMalloc(&h->batch_alt, n * sizeof(float)) != hipSuccess) h->batch_alt = nullptr;   // (then: a gather launch per update)
+    }
     const char* nfr = getenv("OPRL_AMD_NO_FIN_RIDE");
     h->no_fin_ride = (nfr != nullptr && atoi(nfr) != 0);
     if (cfg->algo == OPRL_TQC && h->w_critic == 512) {
@@ -1930,6 +1948,7 @@ extern "C" int oprl_learner_destroy(oprl_learner* h) {
   if (h->xbuf) (void)hipFree(h->xbuf);
   if (h->tqc_counter) (void)hipFree(h->tqc_counter);
   if (h->lw_scratch) (void)hipFree(h->lw_scratch);
+  if (h->batch_alt) (void)hipFree(h->batch_alt);
   if (h->err_host) (void)hipHostFree(h->err_host);
   if (h->p2p.window) p2p_destroy(h->p2p);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -2049,6 +2068,50 @@ extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t
     sc.gather = 0;
     h->prefetch_next = 0;
     h->staged_ready = false;
+    return rc;
+  }
+  if (h->cfg.algo == OPRL_TQC && h->batch_alt != nullptr && !h->no_gather_ride && K > 1) {
+    // the rows of update k + 1 are gathered by riders of update k's k_lw_dact launch (same draw as k_replay_gather)
+    // into the other of two sets of batch rows; only the first update's rows are a launch
+    PrefetchJob base;
+    memset((void*)&base, 0, sizeof base);
+    RC(oprl_replay_flush(replay, stream));
+    long n_tr = 0;
+    replay_view(replay, &base.next.states, &base.next.actions, &base.next.rewards, &base.next.dones, &base.next.ends,
+                &base.next.n_eps, &base.next.L, &n_tr);
+    if (n_tr <= 0 || base.next.n_eps <= 0) { set_err("step_n: replay buffer is empty"); return OPRL_ERR_STATE; }
+    base.next.n_transitions = n_tr;
+    base.next.seed = seed;
+    base.next.gather = 1;
+    base.S = h->S; base.A = h->A; base.B = B; base.z0 = -1;
+    const size_t Bm = (size_t)h->Bmax;
+    float* alt = h->batch_alt;
+    float* set[2][5] = {{h->bs, h->ba, h->br, h->bd, h->bs2},
+                        {alt, alt + Bm * h->S, alt + Bm * (h->S + h->A), alt + Bm * (h->S + h->A + 1), alt + Bm * (h->S + h->A + 2)}};
+    int cur = 0;
+    bool staged = false;
+    int rc = OPRL_OK;
+    for (int k = 0; k < K && rc == OPRL_OK; ++k) {
+      float** b = set[cur];
+      if (!staged)
+        rc = oprl_replay_sample(replay, B, nullptr, seed, (uint64_t)h->update_count, b[0], b[1], b[2], b[3], b[4], nullptr, nullptr, stream);
+      staged = false;
+      h->prefetch_done = false;
+      h->prefetch_pending = false;
+      if (rc == OPRL_OK && k + 1 < K) {
+        float** nb = set[cur ^ 1];
+        h->prefetch = base;
+        h->prefetch.next.counter = (unsigned long long)h->update_count + 1;
+        h->prefetch.next.s = nb[0]; h->prefetch.next.a = nb[1]; h->prefetch.next.r = nb[2]; h->prefetch.next.d = nb[3];
+        h->prefetch.next.s2 = nb[4];
+        h->prefetch_pending = true;
+      }
+      if (rc == OPRL_OK) rc = oprl_learner_update(h, b[0], b[1], b[2], b[3], b[4], B, nullptr, nullptr, stream);
+      h->prefetch_pending = false;
+      staged = h->prefetch_done;
+      h->prefetch_done = false;
+      cur ^= 1;
+    }
     return rc;
   }
   for (int k = 0; k < K; ++k) {

@@ -208,10 +208,12 @@ __device__ __forceinline__ void slice_seed(const MlpArgs& A, const float* outS, 
         const int s0 = part * m4, s1 = ok ? min(M, s0 + m4) : s0;
         for (int s = s0; s < s1; ++s) {
           const float dl = yrow[s] - z;
-          const float ad = fabsf(dl);
           const float w = dl < 0.f ? w_neg : w_pos;
-          g += w * fminf(fmaxf(dl, -1.f), 1.f);
-          ls += w * (ad > 1.f ? ad - 0.5f : dl * dl * 0.5f);
+          const float hub = fminf(fmaxf(dl, -1.f), 1.f);     // Huber's derivative: clamp(dl, -1, 1)
+          g += w * hub;
+          // Huber itself as hub * (dl - hub / 2): dl^2 / 2 inside, |dl| - 1/2 outside — the same values, bit for bit,
+          // as the two-branch form (the halvings are exact), in three operations instead of seven
+          ls += w * (hub * (dl - 0.5f * hub));
         }
         g += __shfl_xor(g, 1);
         ls += __shfl_xor(ls, 1);

@@ -464,6 +464,34 @@ def test_tqc_early_first_launch_equals_in_place(B, prec, monkeypatch):
         assert se[k] == si[k], k
 
 
+@pytest.mark.parametrize("B", [64, 100])
+def test_tqc_step_n_rows_gathered_by_riders_equal_gather_launches(B, monkeypatch):
+    """TQC's step_n: the next update's minibatch rows gathered by riding workgroups of the k_lw_dact launch (same
+    Philox draw and index map as k_replay_gather, into the other of two row sets) against a gather launch per
+    update, and against the Python loop sample() + update(): bit-identical."""
+    from oprl_amd.algos.tqc import TQC
+    from oprl_amd.logging import NullLogger
+    from tests.test_gpu_callers import _filled_buffer
+
+    def make():
+        t.manual_seed(0)
+        return TQC(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=256).create()
+
+    riders = make()
+    monkeypatch.setenv("OPRL_AMD_NO_GATHER_RIDE", "1")   # (read when the learner is created)
+    launches = make()
+    buf = _filled_buffer()
+    riders.learner.step_n(buf.handle, 9, B, seed=4)
+    riders.learner.step_n(buf.handle, 1, B, seed=4)       # (K = 1: nothing to prefetch)
+    riders.learner.step_n(buf.handle, 6, B, seed=4)
+    launches.learner.step_n(buf.handle, 16, B, seed=4)
+    t.cuda.synchronize()
+    riders.learner.check()
+    assert t.isfinite(riders.critic._oprl_arena).all()
+    for m in ("actor", "critic", "critic_target"):
+        assert t.equal(getattr(riders, m)._oprl_arena, getattr(launches, m)._oprl_arena), m
+
+
 def test_tqc_wide_dw_equals_small_tiles(monkeypatch):
     """csrc/dw_wide.hip (64x64 tiles for the 512x512 layers) against k_dw_adam's 16x32 tiles: same
     gradient up to the summation order over the minibatch, same Adam / Polyak / pack epilogue."""
