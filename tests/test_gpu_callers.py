@@ -47,6 +47,31 @@ def test_step_n_equals_python_loop_bitwise():
     assert a1.update_step == a2.update_step == K
 
 
+def test_tqc_step_n_equals_python_loop_bitwise():
+    """TQC's step_n — rows of update k + 1 gathered by riding workgroups of update k's launches (csrc/batch_rows.h),
+    every other rider of DESIGN.md 4.5 active — against the reference's call pattern sample() + update() per step:
+    the same rows (same Philox draw and index map), the same kernels: bit-identical."""
+    from oprl_amd.algos.tqc import TQC
+    from oprl_amd.logging import NullLogger
+
+    def make():
+        t.manual_seed(0)
+        return TQC(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=64).create()
+
+    K, B = 10, 64
+    a1, a2 = make(), make()
+    buf = _filled_buffer()
+    a1.learner.step_n(buf.handle, K, B, seed=7)
+    buf.seed = 7
+    for k in range(K):
+        buf._sample_counter = k
+        a2.update(*buf.sample(B))
+    t.cuda.synchronize()
+    a1.learner.check()
+    for m in ("actor", "critic", "critic_target"):
+        assert t.equal(getattr(a1, m)._oprl_arena, getattr(a2, m)._oprl_arena), m
+
+
 def test_export_grads_split_equals_fused_update():
     fused, split = _ddpg(), _ddpg(export_grads=True)
     for step in range(3):
