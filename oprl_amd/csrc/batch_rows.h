@@ -88,4 +88,44 @@ __device__ __forceinline__ void prefetch_rows_body(const PrefetchJob& J, int sli
   }
 }
 
+// The same rows without the LDS tile, for a workgroup of `nt` threads (a rider of the 512-thread dW launch): element
+// by element from the replay to N.s / a / r / d / s2 — the copies load_batch + the stores above make, so the same rows
+// bit for bit.  lds_i: kMaxEnds + 2 * kR ints.
+__device__ __forceinline__ void prefetch_rows_direct(const PrefetchJob& J, int slice, int* lds_i, int nt) {
+  const int tid = threadIdx.x, row0 = slice * kR, S = J.S, Ad = J.A, B = J.B;
+  const BatchSrc& P = J.next;
+  int* endsS = lds_i;
+  int* meta = lds_i + kMaxEnds;
+  const EndsLds ET = stage_ends(P.ends, P.n_eps, endsS, kMaxEnds, tid, nt);
+  __syncthreads();
+  if (tid < kR) {
+    const int i = row0 + tid;
+    int e = 0, t = 0;
+    if (i < B) {
+      const u32x4 rnd = philox4x32_10(u32x4{(uint32_t)P.counter, (uint32_t)(P.counter >> 32), (uint32_t)i, 0x5a17u},
+                                      (uint32_t)P.seed, (uint32_t)(P.seed >> 32));
+      const long ind = (long)bounded_u32(rnd.x, (uint32_t)P.n_transitions);
+      long start = 0;
+      e = find_episode(P.ends, P.n_eps, ET, ind, &start);
+      t = (int)(ind - start);
+    }
+    meta[tid] = e;
+    meta[kR + tid] = t;
+  }
+  __syncthreads();
+  const int W = 2 * S + Ad + 2;
+  for (int idx = tid; idx < kR * W; idx += nt) {
+    const int row = idx / W, c = idx - row * W, gr = row0 + row;
+    if (gr >= B) continue;
+    const long e = meta[row], t = meta[kR + row];
+    const float* src = P.states + (e * (P.L + 1) + t) * S + c;          // s | s' contiguous
+    float* dst = const_cast<float*>(P.s) + (size_t)gr * S + c;
+    if (c >= S) dst = const_cast<float*>(P.s2) + (size_t)gr * S + (c - S);
+    if (c >= 2 * S) { src = P.actions + (e * P.L + t) * Ad + (c - 2 * S); dst = const_cast<float*>(P.a) + (size_t)gr * Ad + (c - 2 * S); }
+    if (c == 2 * S + Ad) { src = P.rewards + e * P.L + t; dst = const_cast<float*>(P.r) + gr; }
+    if (c == 2 * S + Ad + 1) { src = P.dones + e * P.L + t; dst = const_cast<float*>(P.d) + gr; }
+    *dst = *src;
+  }
+}
+
 }  // namespace oprl

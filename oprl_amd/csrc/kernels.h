@@ -193,6 +193,7 @@ struct TqcJob {
   float* target = nullptr;                 // [B][n_nets * Q - drop]
 };
 
+struct PrefetchJob;
 struct DwArgs {                         // host-side description of one k_dw_adam launch
   const DwItem* items;                 // HOST array
   int n_items; int total_tiles; int B;
@@ -204,6 +205,7 @@ struct DwArgs {                         // host-side description of one k_dw_ada
   int apply_only;                      // 1: no GEMM — the gradient is read from w_g / b_g (data-parallel apply after the all-reduce)
   const DwXchg* xchg = nullptr;       // data-parallel: all-reduce every gradient tile over the peer windows inside this launch
   AlphaJob alpha;                      // optional: the temperature step rides on this launch (one more workgroup)
+  const PrefetchJob* prefetch = nullptr;   // optional: the next update's minibatch rows as riders of this launch (batch_rows.h prefetch_rows_direct)
 };
 
 

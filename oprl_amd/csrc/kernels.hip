@@ -18,6 +18,7 @@
 #include "slice_head.h"
 #include "tp3.h"
 #include "dw_body.h"
+#include "batch_rows.h"
 
 namespace oprl {
 
@@ -89,10 +90,19 @@ template __global__ void k_mlp_slice<512>(const MlpArgs);
 template __global__ void k_mlp_slice_multi<256>(const MlpMultiArgs);
 template __global__ void k_mlp_slice_multi<512>(const MlpMultiArgs);
 
+// Pj (blocks Pj.z0 ..): the next update's minibatch rows gathered from the replay by riding workgroups, one per 16-row
+// slice (batch_rows.h) — where the phase-2 launch that otherwise carries them over-subscribes the chip (B = 1024)
+constexpr size_t kDwPjOffset = (sizeof(DwKArgs) + alignof(PrefetchJob) - 1) / alignof(PrefetchJob) * alignof(PrefetchJob);
+static_assert(kDwLdsFloats >= kMaxEnds + 2 * kR, "the riders' LDS fits in the launch's");
 template <bool XCHG>
-__global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A) {
+__global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A, const PrefetchJob Pj) {
   // (through the kernel-argument segment pointer: a dynamic index into the by-value table is then a scalar load)
   __shared__ __attribute__((aligned(16))) float dw_lds[kDwLdsFloats];
+  if (Pj.z0 >= 0 && (int)blockIdx.x >= Pj.z0) {
+    prefetch_rows_direct(*(const PrefetchJob*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kDwPjOffset),
+                         (int)blockIdx.x - Pj.z0, reinterpret_cast<int*>(dw_lds), kDwThreads);
+    return;
+  }
   dw_adam_body<XCHG>(*(const DwKArgs*)__builtin_amdgcn_kernarg_segment_ptr(), dw_lds, (int)blockIdx.x);
 }
 
@@ -330,6 +340,7 @@ hipError_t launch_dw_adam_group(const DwKArgs* batch_dev, int n, int tiles, hipS
 
 hipError_t launch_dw_adam(const DwArgs& a0, hipStream_t st) {
   if (a0.n_items < 1 || a0.n_items > kDwMaxItems) return hipErrorInvalidValue;
+  static const PrefetchJob no_prefetch = [] { PrefetchJob j; memset((void*)&j, 0, sizeof j); j.z0 = -1; return j; }();
   // wide layers (TQC's 512x512) go to the 64x64-tile kernel (csrc/dw_wide.hip), the rest stay here
   static const bool no_wide = [] { const char* e = getenv("OPRL_AMD_NO_DW_WIDE"); return e != nullptr && atoi(e) != 0; }();
   DwItem rest[kDwMaxItems], wide[kDwMaxItems];
@@ -373,12 +384,20 @@ hipError_t launch_dw_adam(const DwArgs& a0, hipStream_t st) {
   if (a.xchg != nullptr) {
     if (a.apply_only || n_wide > 0 || total > a.xchg->max_tiles || a.alpha.log_alpha != nullptr) return hipErrorInvalidValue;
     k.xchg = *a.xchg;
-    hipLaunchKernelGGL(k_dw_adam<true>, dim3(total), dim3(kDwThreads), 0, st, k);
+    if (a.prefetch != nullptr) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_dw_adam<true>, dim3(total), dim3(kDwThreads), 0, st, k, no_prefetch);
     return hipGetLastError();
   }
   const int blocks = total + (a.alpha.log_alpha != nullptr ? 1 : 0);
-  if (ride) return launch_dw_adam_wide(wide, n_wide, a0.B, a0.ad, st, &k, blocks);
-  hipLaunchKernelGGL(k_dw_adam<false>, dim3(blocks), dim3(kDwThreads), 0, st, k);
+  if (ride) return a.prefetch != nullptr ? hipErrorInvalidValue : launch_dw_adam_wide(wide, n_wide, a0.B, a0.ad, st, &k, blocks);
+  PrefetchJob pj = no_prefetch;
+  int pf_blocks = 0;
+  if (a.prefetch != nullptr) {
+    pj = *a.prefetch;
+    pj.z0 = blocks;
+    pf_blocks = (pj.B + kR - 1) / kR;
+  }
+  hipLaunchKernelGGL(k_dw_adam<false>, dim3(blocks + pf_blocks), dim3(kDwThreads), 0, st, k, pj);
   return hipGetLastError();
 }
 

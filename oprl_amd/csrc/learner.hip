@@ -977,8 +977,10 @@ DwArgs dw_build(oprl_learner* h, bool critic, int B, bool polyak, bool with_alph
   return dw;
 }
 
-int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st, bool with_alpha = false) {
+int dw_step(oprl_learner* h, bool critic, int B, bool polyak, hipStream_t st, bool with_alpha = false,
+            const PrefetchJob* prefetch = nullptr) {
   DwArgs dw = dw_build(h, critic, B, polyak, with_alpha);
+  dw.prefetch = prefetch;
   if (h->dp_inline) {
     // data-parallel on peer windows: this launch all-reduces its tiles itself and runs Adam on the mean
     P2pState& P = h->p2p;
@@ -1207,6 +1209,22 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &fa.cluster_tag));
     if (h->trace != nullptr && c.algo == OPRL_DDPG) fa.trace = h->trace + (size_t)3 * 64 * kTraceStamps * 2;   // slot 3
     fa.prefetch_next = h->prefetch_next;
+    // Where phase 2's own workgroups already fill the chip (SAC at B = 1024: 4 x 64), its prefetch row is a round of
+    // its own; the actor's dW launch, which follows and leaves 40 % of the chip idle, carries the row instead
+    // (prefetch_rows_direct, the same rows).  OPRL_AMD_PREFETCH_P2=1: always phase 2.
+    bool pf_on_dw = false;
+    PrefetchJob pj;
+    {
+      const int slices = (B + kR - 1) / kR;
+      const int rows = (fa.wide & 2) != 0 ? 8 : fa.nc * ((fa.sac && fa.p2_pair) ? 2 : 1);
+      static const bool p2_only = [] { const char* e = getenv("OPRL_AMD_PREFETCH_P2"); return e != nullptr && atoi(e) != 0; }();
+      if (fa.prefetch_next && (rows + 1) * slices > h->n_cus && !h->dp_inline && !p2_only) {
+        pf_on_dw = true;
+        fa.prefetch_next = 0;
+        memset((void*)&pj, 0, sizeof pj);
+        pj.next = fa.next; pj.S = h->S; pj.A = h->A; pj.B = B; pj.z0 = -1;
+      }
+    }
     if (h->prefetch_next) h->staged_ready = true;
     HIPC(chain_before(st));
     prof_begin(5, st);
@@ -1215,7 +1233,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     HIPC(e);
     HIPC(chain_after(st));
     const bool rides = alpha_rides(h);      // SAC temperature (sac.py:129-141), from role C's log pi
-    RC(dw_step(h, false, B, c.actor.theta_target != nullptr, st, rides));
+    RC(dw_step(h, false, B, c.actor.theta_target != nullptr, st, rides, pf_on_dw ? &pj : nullptr));
     if (alpha_ptr(h) != nullptr && !rides) {
       h->opt_step_alpha += 1;
       HIPC(launch_alpha_step(c.log_alpha, c.log_alpha_m, c.log_alpha_v, h->logp, B,

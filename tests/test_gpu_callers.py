@@ -72,6 +72,33 @@ def test_tqc_step_n_equals_python_loop_bitwise():
         assert t.equal(getattr(a1, m)._oprl_arena, getattr(a2, m)._oprl_arena), m
 
 
+def test_sac_b1024_step_n_equals_python_loop_bitwise():
+    """SAC at B = 1024: phase 2's grid fills the chip, so step_n's rows for the next update are gathered by riding
+    workgroups of the actor's dW launch (batch_rows.h prefetch_rows_direct) instead of phase 2's prefetch row —
+    against sample() + update() per step (k_replay_gather launches): the same rows, bit-identical."""
+    from oprl_amd.algos.sac import SAC
+    from oprl_amd.logging import NullLogger
+
+    def make():
+        t.manual_seed(0)
+        return SAC(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=1024,
+                   tune_alpha=True).create()
+
+    K, B = 8, 1024
+    a1, a2 = make(), make()
+    buf = _filled_buffer()
+    a1.learner.step_n(buf.handle, K, B, seed=7)
+    buf.seed = 7
+    for k in range(K):
+        buf._sample_counter = k
+        a2.update(*buf.sample(B))
+    t.cuda.synchronize()
+    a1.learner.check()
+    for m in ("actor", "critic", "critic_target"):
+        assert t.equal(getattr(a1, m)._oprl_arena, getattr(a2, m)._oprl_arena), m
+    assert a1.alpha == a2.alpha
+
+
 def test_export_grads_split_equals_fused_update():
     fused, split = _ddpg(), _ddpg(export_grads=True)
     for step in range(3):
