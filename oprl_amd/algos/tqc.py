@@ -1,7 +1,14 @@
 """TQC on the MI355X-native learner (reference:
 /root/reference/src/oprl/algos/tqc.py): 5 quantile critics (30->512->512->512->25),
 row-wise sort + truncation of the 125 target quantiles, fused quantile-Huber
-forward/backward, learned temperature."""
+forward/backward, learned temperature.
+
+One update is 17 launches (csrc/learner.hip critic_phase / actor_phase, csrc/layerwise.hip): the five critics run
+layer by layer over the whole chip; the launches that leave CUs idle carry independent work as riding workgroups
+(the online critics' first layers behind the actor's forward on s', the TD-target sort on the target pass's heads,
+the actor step's forward on the critic step's heads, the narrow layers' dW tiles behind the wide dW launch, the
+temperature step on the actor's dW launch, and — in step_n — the next update's minibatch rows on the
+action-gradient launch).  DESIGN.md section 4.5."""
 from __future__ import annotations
 
 import math
