@@ -83,12 +83,17 @@ __device__ __forceinline__ void adam_bias_corr(const AdamScalars& ad, float* ste
 // launch must be resident (they wait for their counterparts on the other GPUs): at most a few hundred.
 
 // LDS of one tile workgroup (floats): the partial tiles, the wave-private row staging, the bias partials, two scalars
-constexpr int kDwLdsPart = 0;
-constexpr int kDwLdsStA = kDwLdsPart + kDwWaves * kDwTileN * (kDwTile + 4);
-constexpr int kDwLdsStX = kDwLdsStA + kDwWaves * 32 * kDwTileN;
-constexpr int kDwLdsBpart = kDwLdsStX + kDwWaves * 32 * (kDwTile + 4);
-constexpr int kDwLdsSc = kDwLdsBpart + kDwWaves * kDwTileN;
-constexpr int kDwLdsFloats = kDwLdsSc + 4;                       // 72.2 KB
+// (NW waves split the 256-row chunk: 8 waves x 32 rows in the stand-alone kernel, 16 x 16 in the actor's tiles on phase 2)
+template <int NW> struct DwLds {
+  static constexpr int RW = 256 / NW;                        // minibatch rows per wave and chunk
+  static constexpr int part = 0;
+  static constexpr int stA = part + NW * kDwTileN * (kDwTile + 4);
+  static constexpr int stX = stA + NW * RW * kDwTileN;
+  static constexpr int bpart = stX + NW * RW * (kDwTile + 4);
+  static constexpr int sc = bpart + NW * kDwTileN;
+  static constexpr int floats = sc + 4;
+};
+constexpr int kDwLdsFloats = DwLds<kDwWaves>::floats;            // 72.2 KB
 
 // one bounded wait of a GATED tile workgroup for `n` flag granules {tag, *} (lanes of wave w poll, everybody is
 // released by the barrier that follows in the caller)
@@ -120,12 +125,18 @@ __device__ __forceinline__ float ld1_sc1(const float* p) {
 // before it touches what they write: `gate_rows` (every producer of X / dY rows) before the row requests,
 // `gate_seed` (the per-row seeds, and the output layer's dY) before those; rows and seeds are read with sc1 loads
 // (the producers write them through: no kernel boundary lies in between).
-template <bool XCHG, bool GATED = false>
+// GATE: 0 = a launch of its own, 1 = the critic's tiles on phase 1's launch (above), 2 = the ACTOR's tiles on phase
+// 2's launch: X rows are the previous launch's, dY is formed here from the du granules (DwGate, kernels.h).
+template <bool XCHG, int GATE = 0, int NW = kDwWaves>
 __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int bx) {   // bx: the tile (bx of a stand-alone launch)
+  constexpr bool GATED = GATE == 1;
   constexpr int TN = kDwTileN, TK = kDwTile, LD = TK + 4;
-  float (*part)[TN][LD] = reinterpret_cast<float (*)[TN][LD]>(lds + kDwLdsPart);
-  float (*bpart)[TN] = reinterpret_cast<float (*)[TN]>(lds + kDwLdsBpart);
-  float* sc = lds + kDwLdsSc;
+  using DL = DwLds<NW>;
+  constexpr int RW = DL::RW;
+  static_assert(GATE == 2 || NW == kDwWaves, "the chunk loop of the stand-alone kernel is written for 8 waves x 32 rows");
+  float (*part)[TN][LD] = reinterpret_cast<float (*)[TN][LD]>(lds + DL::part);
+  float (*bpart)[TN] = reinterpret_cast<float (*)[TN]>(lds + DL::bpart);
+  float* sc = lds + DL::sc;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // this workgroup's layer, straight from the kernel-argument segment (dynamic index into a
   // by-value array: through the segment pointer it is a scalar load, not a scratch copy)
@@ -214,8 +225,8 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int b
   // per-row seed applied in registers, then the wave stages its rows in wave-private LDS and
   // reads them back in MFMA layout: lane (c, i) feeds dY[row 4u + c][n_base + i] as the A
   // operand and X[row 4u + c][k_base + 2i + {0,1}] as two B operands.
-  float (*stA)[32][TN] = reinterpret_cast<float (*)[32][TN]>(lds + kDwLdsStA);
-  float (*stX)[32][LD] = reinterpret_cast<float (*)[32][LD]>(lds + kDwLdsStX);
+  float (*stA)[RW][TN] = reinterpret_cast<float (*)[RW][TN]>(lds + DL::stA);
+  float (*stX)[RW][LD] = reinterpret_cast<float (*)[RW][LD]>(lds + DL::stX);
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   float sA = 0.f;
   // per-row seed of unit-seed layers, or the constant 1 (stride 0): always a load, no branch
@@ -235,7 +246,113 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int b
     if (!ok) report_expired(A.gate.err, A.gate.err_code);
     __syncthreads();
   }
-  for (int chunk = 0; chunk * 256 < (h_apply ? 0 : hB); ++chunk) {
+  if constexpr (GATE == 2) {
+    // ---- the actor's tiles on phase 2's launch (one 256-row chunk, NW = 16 waves x 16 rows: lane (ar, an) owns dY
+    // row ar, columns an .. an + 3): X first — it is the previous launch's — then whatever of dY does not depend on
+    // du, then the du granules
+    static_assert(RW == 16, "one dY row group per wave");
+    const DwGate& G = KA->gate;
+    const int kind = item == 0 ? G.kind[0] : (item == 1 ? G.kind[1] : (item == 2 ? G.kind[2] : G.kind[3]));
+    const int Ad = G.n_act;
+    const int bb = RW * wave + ar;                     // this lane's dY row
+    const int ncol = n_base + an;                      // ... and its first dY column
+    f32x4 vx[2], va[kDuLd];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int bx_ = RW * wave + xr + 8 * j;
+      vx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (bx_ < hB && xk_ok) vx[j] = ld4(I.X + (size_t)bx_ * I.ldx + k_base + xk);
+    }
+#pragma unroll
+    for (int j = 0; j < kDuLd; ++j) va[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 hmask = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (kind == 1 && an_ok) {
+      // the second hidden layer's activations (ReLU mask) and the output layer's rows W3[j][ncol .. ncol + 3]
+      if (bb < hB) hmask = ld4(G.h2 + (size_t)bb * I.ldy + ncol);
+#pragma unroll
+      for (int j = 0; j < kDuLd; ++j)
+        if (j < Ad) va[j] = ld4(G.w3 + ((size_t)(ncol >> 4) * 64 + ((ncol & 15) >> 2) * 16 + j) * 4);
+    }
+    // role U's rows (first hidden layer); and — for every tile — role U must have READ the packs this tile's
+    // epilogue rewrites: its flags are waited for before anything is stored
+    if (kind == 2) {
+      const bool ok = dw_gate_wait(G.rows, G.n_rows, G.tag, G.spin);
+      if (!ok) report_expired(G.err, G.err_code);
+      __syncthreads();
+      if (an_ok && bb < hB) {
+        const float* src = G.U + (((size_t)(ncol >> 4) * Ad) * hB + bb) * 16 + (ncol & 15);
+#pragma unroll
+        for (int j = 0; j < kDuLd; ++j)
+          if (j < Ad) va[j] = ld4_sc1(src + (size_t)j * hB * 16);
+      }
+    }
+    float du[kDuLd];
+    {
+      unsigned long long g[kDuLd];
+      bool ok = false;
+      for (int spin = 0; spin < G.spin && !ok && bb < hB; ++spin) {
+#pragma unroll
+        for (int j = 0; j < kDuLd; ++j)
+          g[j] = j < Ad ? __hip_atomic_load(G.seed + (size_t)bb * kDuLd + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                        : ((unsigned long long)G.tag << 32);
+        ok = true;
+#pragma unroll
+        for (int j = 0; j < kDuLd; ++j) ok = ok && (unsigned)(g[j] >> 32) == G.tag;
+        if (!ok) __builtin_amdgcn_s_sleep(1);
+      }
+      if (!ok && bb < hB) report_expired(G.err, G.err_code);
+#pragma unroll
+      for (int j = 0; j < kDuLd; ++j)
+        du[j] = (bb < hB && j < Ad) ? (ok ? __uint_as_float((unsigned)g[j]) : __builtin_nanf("")) : 0.f;
+    }
+    if (kind != 2) {
+      const bool ok = dw_gate_wait(G.rows, G.n_rows, G.tag, G.spin);
+      if (!ok) report_expired(G.err, G.err_code);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the sc1 row loads are inline asm: hipcc does not count them)
+    stamp();   // rows and seeds in
+    {
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kind != 0) {
+#pragma unroll
+        for (int j = 0; j < kDuLd; ++j) v += va[j] * du[j];
+        if (kind == 1) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = hmask[t] > 0.f ? v[t] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float x = 0.f;
+#pragma unroll
+          for (int j = 0; j < kDuLd; ++j) x = (ncol + t == j) ? du[j] : x;
+          v[t] = x;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = (ncol + t < I.N && an < TNi) ? v[t] : 0.f;
+      *reinterpret_cast<f32x4*>(&stA[wave][ar][an]) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x4 v = vx[j];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = (k_base + xk + t < I.K) ? v[t] : 0.f;
+      *reinterpret_cast<f32x4*>(&stX[wave][xr + 8 * j][xk]) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int u = 0; u < RW / 4; ++u) {
+      const float av = stA[wave][4 * u + c][i];
+      const f32x2 xv = *reinterpret_cast<const f32x2*>(&stX[wave][4 * u + c][2 * i]);
+      sA += av;
+      acc[0] = mfma4(av, xv[0], acc[0]);
+      acc[1] = mfma4(av, xv[1], acc[1]);
+    }
+  }
+  for (int chunk = 0; GATE != 2 && chunk * 256 < (h_apply ? 0 : hB); ++chunk) {
     const int base = chunk * 256 + 32 * wave;
     f32x4 va[2][4], vx[4];
     float rs[2];
@@ -351,14 +468,14 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int b
   // packs are written IN PACK ORDER as 16-byte stores
   float g = 0.f;
 #pragma unroll
-  for (int w = 0; w < kDwWaves; ++w) g += part[w][nl][kl];
+  for (int w = 0; w < NW; ++w) g += part[w][nl][kl];
   float gb_x = 0.f;
   if constexpr (XCHG) {
     const DwXchg& X = A.xchg;
     float gbw = 0.f;
     if (tid < TN) {
 #pragma unroll
-      for (int w = 0; w < kDwWaves; ++w) gbw += bpart[w][tid];
+      for (int w = 0; w < NW; ++w) gbw += bpart[w][tid];
     }
     // 8-byte {sequence, value} granules written through at system scope: the value is its own flag, no
     // fences (two system fences per workgroup cost 50 us per launch), the wait is per element.
@@ -501,7 +618,7 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int b
     const int n = n_base + tid;
     float gb = 0.f;
 #pragma unroll
-    for (int w = 0; w < kDwWaves; ++w) gb += bpart[w][tid];
+    for (int w = 0; w < NW; ++w) gb += bpart[w][tid];
     if constexpr (XCHG) gb = gb_x;
     if (h_apply) gb = I.b_g[n];
     gb *= ad.grad_scale;                 // (the arithmetic of adam_polyak_elem, on the prefetched state)

@@ -266,7 +266,7 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const DwKArg
       if (threadIdx.x >= kDwThreads) return;      // a tile workgroup is the first 8 waves (the stand-alone kernel's shape and arithmetic)
       const int tile = ((int)blockIdx.y - rows) * (int)gridDim.x + (int)blockIdx.x;
       if (tile >= D->tile_end[kDwMaxItems - 1]) return;
-      dw_adam_body<false, true>(*D, smem, tile);
+      dw_adam_body<false, 1>(*D, smem, tile);
       return;
     }
   }
@@ -356,6 +356,11 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const DwKArg
           if (gr < B) A.pi[(size_t)gr * Ad + col] = tanhf(outS[row * kOutLd + col]);
         }
         store_rows(xa, kX0Ld, A.aX[0], A.aldx0, S, row0, B);
+        // merged phase 2: its tiles rewrite the actor's output layer while other tiles still want the OLD one
+        // (dz2 = du W3): one copy of the layer's forward pack (16 KB) for them, taken here
+        if ((A.merged & 2) != 0 && slice == 0)
+          for (int idx = tid * 4; idx < 16 * 256; idx += kThreads * 4)
+            *reinterpret_cast<f32x4*>(A.w3_snap + idx) = ld4(A.actor.pf[2] + idx);
       }
       stamp();
     }
@@ -785,6 +790,207 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2_group(const DdpgArgs* 
   ddpg_phase2_body<WIDTH, LEAN, SAC, P>(batch[blockIdx.z]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Phase 2 with the ACTOR's dW + Adam tiles on the same launch (DdpgArgs::merged bit 1; DDPG / TD3, fp32 lean passes,
+// action_dim <= kDuLd, B <= 256).
+//
+// The actor's backward is linear in its output seed du = da (1 - pi^2) [B x A], and everything else it needs — the
+// actor's weights and its forward activations (role C of phase 1) — exists when this launch starts.  So it leaves
+// the update's critical chain: ROLE U (four workgroups per slice, beside the critic pass) runs it with A unit seeds
+//     U_j[b, k] = (h1[b, k] > 0) sum_n (h2[b, n] > 0) W3[j, n] W2[n, k]          (member c: columns 64 c .. 64 c + 63)
+// and writes the rows through; the critic pass (forward + constant-seed backward to the action columns, unchanged)
+// ends by publishing du as {epoch, value} granules; the actor's dW tiles (dw_adam_body<false, 2>), riding behind the
+// roles like the critic's tiles ride on phase 1, have taken in their Adam state and X rows by then and form their dY
+// from du:  output layer du itself, second hidden layer (h2 > 0) (du W3), first hidden layer sum_j du_j U_j.  What
+// used to follow the critic pass — the actor's backward (a whole pass), a kernel boundary and a k_dw_adam launch — is
+// one granule hop, a few FMAs per element, 16 MFMAs and the Adam epilogue.
+// Grid rows: [0, NMC) critic pass | [NMC, NMC + 4) role U | prefetch row (step_n) | tiles.
+// ---------------------------------------------------------------------------------------------------------------
+struct RoleULds {   // floats
+  static constexpr int w = 0;                               // the member's W2^T shard: [4 tiles][16 steps][256]
+  static constexpr int h2 = w + 4 * 16 * 256;               // [kR][kWL4]
+  static constexpr int w3 = h2 + kR * kWL4;                 // [kDuLd][256] rows of the output layer (zero beyond A)
+  static constexpr int total = w3 + kDuLd * 256;
+};
+
+__device__ __forceinline__ void role_u(const DdpgArgs& A, float* smem, int slice, int c) {
+  float* Wl = smem + RoleULds::w;
+  float* h2s = smem + RoleULds::h2;
+  float* w3s = smem + RoleULds::w3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
+  const int row0 = slice * kR, B = A.B, Ad = A.A;
+  // ---- requests: the shard (64 KB, four b128 per thread), the slice's h2 rows, the output layer's snapshot, and
+  // this lane's h1 elements (the mask of what it will store)
+  const float* wsrc = A.actor.pb[1] + (size_t)c * 4 * 16 * 256;
+  f32x4 wv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wv[q] = ld4(wsrc + ((size_t)q * kThreads + tid) * 4);
+  const int hr = tid >> 6, hc = (tid & 63) * 4;
+  f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (row0 + hr < B) hv = ld4(A.aX[2] + (size_t)(row0 + hr) * kW4 + hc);
+  const f32x4 w3q = ld4(A.w3_snap + (size_t)tid * 4);     // pack element (s = tid >> 6, lane = tid & 63): W3[lane & 15][16 s + 4 (lane >> 4) + t]
+  const int t1 = wave & 3, g = wave >> 2;                  // this wave: tile t1 of the member, unit seeds 2 g, 2 g + 1
+  float m1[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gr = row0 + 4 * kk + r;
+    m1[r] = gr < B ? A.aX[1][(size_t)gr * kW4 + 64 * c + 16 * t1 + i] : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(Wl + ((size_t)q * kThreads + tid) * 4) = wv[q];
+  *reinterpret_cast<f32x4*>(h2s + hr * kWL4 + hc) = hv;
+  {
+    const int j = lane & 15;
+    if (j < kDuLd)
+      *reinterpret_cast<f32x4*>(w3s + j * 256 + 16 * (tid >> 6) + 4 * (lane >> 4)) = j < Ad ? w3q : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  const int j0 = 2 * g, j1 = 2 * g + 1;
+  if (j0 < Ad) {
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    const float* hrow = h2s + i * kWL4 + 4 * kk;
+    const float* w0 = w3s + j0 * 256 + 4 * kk;
+    const float* w1 = w3s + (j1 < kDuLd ? j1 : j0) * 256 + 4 * kk;
+    const float* bw = Wl + ((size_t)t1 * 16 * 64 + lane) * 4;
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const f32x4 b = ld4(bw + s * 256);
+      const f32x4 h = ld4(hrow + 16 * s);
+      const f32x4 x0 = ld4(w0 + 16 * s), x1 = ld4(w1 + 16 * s);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a0 = mfma4(h[t] > 0.f ? x0[t] : 0.f, b[t], a0);
+        a1 = mfma4(h[t] > 0.f ? x1[t] : 0.f, b[t], a1);
+      }
+    }
+    // lane (kk, i): rows 4 kk + r, column 64 c + 16 t1 + i of unit seeds j0 / j1 -> U[tile][j][row][16], written through
+    const int tile = 4 * c + t1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gr = row0 + 4 * kk + r;
+      if (gr < B) {
+        float* d0 = A.U + (((size_t)tile * Ad + j0) * B + gr) * 16 + i;
+        __hip_atomic_store(d0, m1[r] > 0.f ? a0[r] : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (j1 < Ad)
+          __hip_atomic_store(d0 + (size_t)B * 16, m1[r] > 0.f ? a1[r] : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0)
+    __hip_atomic_store(A.u_flags + slice * 4 + c, (unsigned long long)A.epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <class P, bool WIDE>
+__device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const DwKArgs* D) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using LY = FusedLds<256>;
+  constexpr int HB = kR * kWL4;
+  constexpr int NMC = WIDE ? 8 : 4;
+  const int B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
+  const int slice = blockIdx.x, row0 = slice * kR;
+  const int y = (int)blockIdx.y;
+  const int yP = NMC + 4, yT = yP + (A.prefetch_next ? 1 : 0);
+  if (y >= yT) {   // a tile workgroup: all 16 waves (16 minibatch rows each)
+    const int tile = (y - yT) * (int)gridDim.x + slice;
+    if (tile >= D->tile_end[kDwMaxItems - 1]) return;
+    dw_adam_body<false, 2, 16>(*D, smem, tile);
+    return;
+  }
+  if (y >= NMC && y < yP) { role_u(A, smem, slice, y - NMC); return; }
+  float* xa = smem + LY::xa;
+  if (y == yP) {
+    // ---- prefetch row: the next update's rows (as in ddpg_phase2_body)
+    float* xb = smem + LY::xb;
+    float* rS = smem + LY::misc;
+    float* dS = rS + kR;
+    int* meta = reinterpret_cast<int*>(dS + 2 * kR);
+    int* endsS = reinterpret_cast<int*>(smem + LY::misc + 96);
+    load_batch(A.next, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
+    __syncthreads();
+    store_rows(xa, kX0Ld, const_cast<float*>(A.next.s), S, S, row0, B);
+    store_rows(xb, kX0Ld, const_cast<float*>(A.next.s2), S, S, row0, B);
+    for (int idx = tid; idx < kR * Ad; idx += kThreads) {
+      const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
+      if (gr < B) const_cast<float*>(A.next.a)[(size_t)gr * Ad + col] = xa[row * kX0Ld + S + col];
+    }
+    if (tid < kR && row0 + tid < B) {
+      const_cast<float*>(A.next.r)[row0 + tid] = rS[tid];
+      const_cast<float*>(A.next.d)[row0 + tid] = dS[tid];
+    }
+    return;
+  }
+  // ---- the critic pass: q = critic(s, pi) forward + constant-seed backward to the action columns -> du -> granules
+  float* h1 = smem + LY::h;
+  float* h2 = h1 + HB;
+  float* g2 = h2 + HB;
+  float* outS = smem + LY::out;
+  float* auxS = smem + LY::aux;
+  float* scr = smem + LY::scr;
+  Tp tp{y, NMC, A.xbuf + (size_t)slice * kTpStages * A.xnc * kTpBlk, A.cluster_tag, 0,
+        A.err, KERN_PHASE2 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
+  const bool lead = tp.c == 0;
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if (A.trace != nullptr && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
+      const int slot = tid == 0 ? slice : 16 + (tid >> 6);
+      long long* tr = A.trace + ((size_t)slot * kTraceStamps + n_stamp) * 2;
+      tr[0] = (long long)__builtin_readcyclecounter();
+      tr[1] = (long long)wall_clock64();
+    }
+    ++n_stamp;
+  };
+  stamp();
+  const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
+  {
+    const float* p0 = A.aX[0]; const float* p3 = A.pi; const int ld0 = A.aldx0;
+    asm volatile("" :: "s"(p0), "s"(p3), "s"(ld0));
+  }
+  // [s | pi]: loads first, then the zero fill and the stores
+  const int rs_ = tid / S, cs_ = tid - rs_ * S;
+  const bool oks = tid < kR * S && row0 + rs_ < B;
+  const float vs = oks ? A.aX[0][(size_t)(row0 + rs_) * A.aldx0 + cs_] : 0.f;
+  const int tid2 = tid + kThreads;
+  const int rs2_ = tid2 / S, cs2_ = tid2 - rs2_ * S;
+  const bool oks2 = tid2 < kR * S && row0 + rs2_ < B;
+  const float vs2 = oks2 ? A.aX[0][(size_t)(row0 + rs2_) * A.aldx0 + cs2_] : 0.f;
+  const int rp_ = tid / Ad, cp_ = tid - rp_ * Ad;
+  const bool okp = tid < kR * Ad && row0 + rp_ < B;
+  const float vp = okp ? A.pi[(size_t)(row0 + rp_) * Ad + cp_] : 0.f;
+  lds_zero(xa, kR * kX0Ld);
+  lds_zero(auxS, kR * kOutLd);
+  __syncthreads();
+  if (tid < kR * S) xa[rs_ * kX0Ld + cs_] = vs;
+  if (tid2 < kR * S) xa[rs2_ * kX0Ld + cs2_] = vs2;
+  if (tid < kR * Ad) xa[rp_ * kX0Ld + S + cp_] = vp;
+  stamp();
+  float* qsum = nullptr;
+  if (A.partials_a != nullptr && lead) {
+    qsum = A.partials_a + slice * 4 + 1;
+    if (tid == 0) { A.partials_a[slice * 4 + 0] = 0.f; A.partials_a[slice * 4 + 2] = 0.f; }
+  }
+  tp4_scalar_fb<P, NMC>(A.critic, xa, h1, h2, g2, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum);
+  stamp();   // da ready
+  // du = da (1 - pi^2): every member holds the same da; the lead member publishes (rows beyond B are never polled)
+  if (lead && okp) {
+    const float du = auxS[rp_ * kOutLd + cp_] * (1.f - vp * vp);
+    granule_put(A.du_granules + (size_t)(row0 + rp_) * kDuLd + cp_, A.epoch, du);
+    A.adY[2][(size_t)(row0 + rp_) * A.alddo + cp_] = du;
+  }
+  stamp();
+}
+
+template <class P, bool WIDE>
+__global__ __launch_bounds__(kThreads) void k_ddpg_phase2_dw(const DdpgArgs A, const DwKArgs D) {
+  const DwKArgs* Dp = (const DwKArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kMergedDwOffset);
+  ddpg_phase2m_body<P, WIDE>(A, Dp);
+}
+
+static_assert(FusedLds<256>::total >= RoleULds::total, "role U fits the phase kernels' LDS");
+static_assert(FusedLds<256>::total >= kDwLdsFloats && FusedLds<256>::total >= DwLds<16>::floats, "a tile workgroup fits the phase kernels' LDS");
+
 size_t fused_ddpg_lds_bytes() { return sizeof(float) * FusedLds<256>::total; }
 size_t fused_xbuf_granules_per_cluster(int nc) { return (size_t)kTpStages * nc * kTpBlk; }
 
@@ -809,6 +1015,12 @@ hipError_t init_fused_attrs() {
                        reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false, PrecF32, true>),
                        reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecF32>),
                        reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecBF16>)};
+  const void* km[2] = {reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecF32, true>),
+                       reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecF32, false>)};
+  for (const void* k : km) {
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+  }
   for (const void* k : kg) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -851,6 +1063,20 @@ hipError_t launch_ddpg_phase1_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_
   const dim3 grid(slices, 3 * a.nc + (tiles + slices - 1) / slices);
   if (a.bf16) hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
   else hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecF32>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
+  return hipGetLastError();
+}
+
+// phase 2 with the actor's dW + Adam tiles as extra grid rows (DdpgArgs::merged bit 1; `d` = fill_dw_kargs of the
+// actor's launch with the phase-2 gate filled in)
+hipError_t launch_ddpg_phase2_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st) {
+  if (!lean_ok(a) || a.sac || a.bf16 || (a.merged & 2) == 0 || a.A > kDuLd || a.B > 256) return hipErrorInvalidValue;
+  const int slices = (a.B + kR - 1) / kR;
+  const int tiles = d.tile_end[kDwMaxItems - 1];
+  const bool wide = (a.wide & 2) != 0;
+  if (wide && a.xnc < 8) return hipErrorInvalidValue;
+  const dim3 grid(slices, (wide ? 8 : 4) + 4 + (a.prefetch_next ? 1 : 0) + (tiles + slices - 1) / slices);
+  if (wide) hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecF32, true>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
+  else hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecF32, false>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
   return hipGetLastError();
 }
 

@@ -223,7 +223,21 @@ struct DwGate {
   const float* late_dY = nullptr;      // dY buffer that is written with the seeds (the scalar critic's output layer)
   unsigned tag = 0; int spin = 0;
   unsigned* err = nullptr; unsigned err_code = 0;
+  // GATE == 2 (the ACTOR's tiles on phase 2's launch, csrc/fused_ddpg.hip): no dY rows exist when the tiles start —
+  // the actor's backward is linear in the output seed du = dLoss/d(pre-tanh) [B x A], so its layers' dY are formed
+  // in the tile from du (granules `seed`, kDuLd per row, published by the critic pass at its very end) and from what
+  // does not depend on du:
+  //   kind 0  output layer:  dY = du
+  //   kind 1  second hidden: dY[b, n] = (h2[b, n] > 0) * sum_j du[b, j] W3[j, n]      (h2 rows, W3 snapshot `w3`)
+  //   kind 2  first hidden:  dY[b, n] = sum_j du[b, j] U_j[b, n]                      (role U's unit backward rows)
+  // U: [16-column tile][n_act][B][16] floats, written through by role U of the same launch (flags `rows`).
+  int kind[4] = {0, 0, 0, 0};          // per item of the launch
+  const float* h2 = nullptr;           // [B][256] the actor's second hidden activations (written by the launch before)
+  const float* w3 = nullptr;           // the output layer's forward pack as it was BEFORE this launch (16 steps x 256 floats)
+  const float* U = nullptr;
+  int n_act = 0;
 };
+constexpr int kDuLd = 8;               // du granules per minibatch row (action_dim <= 8)
 
 constexpr int kDwMaxItems = 20;        // 5 critics x 4 layers (TQC)
 struct DwKArgs {
@@ -311,8 +325,15 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   // start while the roles run, take their Adam state in, and wait for flag granules: gate_flags[0 .. 4 slices)
   // = role B's members have written their X / dY rows through, gate_flags[64 + slice] = role A has written the
   // slice's seeds through; tagged with `epoch`
+  // bit 1: the ACTOR's dW + Adam tiles ride on phase 2's launch: the actor's backward leaves the critical chain — role U
+  // (4 workgroups per slice, beside the critic pass) runs it with unit seeds, one per action dimension, the critic
+  // pass publishes du = da (1 - pi^2) as granules and the tiles combine (DwGate, GATE == 2)
   int merged;
   unsigned long long* gate_flags;
+  unsigned long long* du_granules;     // [B][kDuLd] {epoch, du}
+  unsigned long long* u_flags;         // [slices][4] role U's members have written their rows through
+  float* U;                            // [16][A][B][16] unit-seed dz1 of the actor (role U -> first-layer tiles)
+  float* w3_snap;                      // the actor's output-layer forward pack, copied by phase 1's role C (slice 0)
   int no_lean;                         // 1: never use the tp4.h specialisation (OPRL_AMD_NO_LEAN, tests)
   unsigned long long* xbuf;            // cluster exchange areas: [role][slice][kTpStages][nc][kTpBlk] granules
   unsigned cluster_tag;                // launch-unique

@@ -172,6 +172,7 @@ hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st);
 hipError_t launch_ddpg_phase1_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st);
 bool fused_ddpg_is_lean(const DdpgArgs& a);
 hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st);
+hipError_t launch_ddpg_phase2_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st);
 hipError_t launch_ddpg_phase1_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
 hipError_t launch_ddpg_phase2_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
 int fill_dw_kargs(const DwArgs& a, DwKArgs* k);
@@ -414,6 +415,13 @@ struct oprl_learner {
   int n_cus = 256;
   int no_lean = 0;
   int no_merge = 0;            // OPRL_AMD_NO_MERGE: dW launches of their own
+  int no_merge2 = 0;           // OPRL_AMD_NO_MERGE2: phase 2 runs the actor's backward itself, the actor's dW is a launch of its own
+  // merged phase 2 (DdpgArgs::merged bit 1): du granules [Bm][kDuLd], role U's flags [slices][4], its unit-seed rows
+  // [16][A][Bm][16] and the snapshot of the actor's output-layer pack (Bm = min(max_batch, 256))
+  unsigned long long* du_granules = nullptr;
+  unsigned long long* u_flags = nullptr;
+  float* U = nullptr;
+  float* w3_snap = nullptr;
   int no_wide = 0;             // OPRL_AMD_NO_WIDE: never run role A / phase 2's critic pass on clusters of eight
   int xnc = kMaxCluster;       // members an exchange area of xbuf is laid out for
   unsigned long long* xbuf = nullptr;
@@ -920,6 +928,20 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
     a.merged |= 1;
     a.wide &= ~1;
   }
+  // ... and the ACTOR's tiles on phase 2 (DDPG / TD3: the tanh head, action_dim <= kDuLd): the actor's backward runs
+  // beside the critic pass with unit seeds (role U), the tiles combine with du (csrc/fused_ddpg.hip)
+  if (!h->no_merge2 && h->du_granules != nullptr && !a.sac && !a.bf16 && B <= 256 && !h->cfg.export_grads && !h->dp_inline &&
+      fused_ddpg_is_lean(a) && c.actor.theta_target != nullptr) {
+    const int slices = (B + kR - 1) / kR;
+    const int rows = ((a.wide & 2) != 0 ? 8 : 4) + 4 + 1;
+    if (rows * slices <= h->n_cus) {
+      a.merged |= 2;
+      a.du_granules = h->du_granules;
+      a.u_flags = h->u_flags;
+      a.U = h->U;
+      a.w3_snap = h->w3_snap;
+    }
+  }
   return a;
 }
 
@@ -1026,6 +1048,10 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     if (h->epoch == 0) {   // the TD-target tag wrapped: retire every stale granule
       h->epoch = 1;
       HIPC(hipMemsetAsync(h->y_granules, 0, ((size_t)3 * h->Bmax + 256) * sizeof(unsigned long long), st));
+      if (h->du_granules != nullptr) {
+        HIPC(hipMemsetAsync(h->du_granules, 0, (size_t)(h->Bmax < 256 ? h->Bmax : 256) * kDuLd * sizeof(unsigned long long), st));
+        HIPC(hipMemsetAsync(h->u_flags, 0, 64 * sizeof(unsigned long long), st));
+      }
     }
     DdpgArgs fa = ddpg_args(h, B);
     fa.noise = noise0;
@@ -1227,6 +1253,29 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     }
     if (h->prefetch_next) h->staged_ready = true;
     HIPC(chain_before(st));
+    if ((fa.merged & 2) != 0 && !pf_on_dw) {
+      // phase 2 and the actor's dW + Adam tiles as ONE launch: role U's unit-seed backward beside the critic pass,
+      // the tiles wait for the du granules
+      DwArgs dw = dw_build(h, false, B, true, false);
+      DwKArgs kd;
+      if (fill_dw_kargs(dw, &kd) < 0 || dw.n_items != 3) { set_err("merged phase 2: bad dW table"); return OPRL_ERR_INVALID; }
+      const int slices = (B + kR - 1) / kR;
+      kd.gate.rows = fa.u_flags; kd.gate.n_rows = 4 * slices;
+      kd.gate.seed = fa.du_granules; kd.gate.n_seed = B;
+      kd.gate.tag = h->epoch; kd.gate.spin = h->debug_expire == 7 ? 0 : (1 << 20);
+      kd.gate.err = h->err_dev; kd.gate.err_code = (2u << 8) | 7u;      // KERN_PHASE2, SITE_DW_GATE (csrc/tp3.h)
+      kd.gate.kind[0] = 2; kd.gate.kind[1] = 1; kd.gate.kind[2] = 0; kd.gate.kind[3] = 0;   // items = the actor's layers 0, 1, 2
+      kd.gate.h2 = h->ws_actor.X[2];
+      kd.gate.w3 = fa.w3_snap;
+      kd.gate.U = fa.U;
+      kd.gate.n_act = h->A;
+      prof_begin(5, st);
+      hipError_t e = launch_ddpg_phase2_dw(fa, kd, st);
+      prof_end(st);
+      HIPC(e);
+      HIPC(chain_after(st));
+      return OPRL_OK;
+    }
     prof_begin(5, st);
     hipError_t e = launch_ddpg_phase2(fa, st);
     prof_end(st);
@@ -1780,6 +1829,9 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   floats += (size_t)(nc + 1) * n_slices * 4 + 16;
   floats += (size_t)B * (2 * S + A + 2);
   floats += 64 * 32 + 6 * (size_t)B + 512;      // (granule arrays: y, q1, q2; 256 gate flags)
+  const int Bm = B < 256 ? B : 256;             // merged phase 2 serves one 256-row chunk
+  const bool merge2_bufs = h->fused && cfg->algo != OPRL_SAC && A <= kDuLd;
+  if (merge2_bufs) floats += 2 * ((size_t)Bm * kDuLd + 64) + 256 + (size_t)16 * A * Bm * 16 + 16 * 256 + 4 * 64;
   if (h->bf16) {
     floats += 2 * ((size_t)net_pack16_floats(cfg->actor) + 64);
     for (int j = 0; j < nc; ++j) floats += 2 * ((size_t)net_pack16_floats(cfg->critics[j]) + 64);
@@ -1821,6 +1873,12 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   h->scalars = p.take<float>(16);
   h->alpha_grad = cfg->log_alpha_grad ? cfg->log_alpha_grad : p.take<double>(2);
   h->y_granules = p.take<unsigned long long>((size_t)3 * B + 256);
+  if (merge2_bufs) {
+    h->du_granules = p.take<unsigned long long>((size_t)Bm * kDuLd);
+    h->u_flags = p.take<unsigned long long>(64);
+    h->U = p.take<float>((size_t)16 * A * Bm * 16);
+    h->w3_snap = p.take<float>(16 * 256);
+  }
   h->bs = p.take<float>((size_t)B * S);
   h->ba = p.take<float>((size_t)B * A);
   h->br = p.take<float>(B);
@@ -1900,6 +1958,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->no_lean = (nl != nullptr && atoi(nl) != 0) ? 1 : 0;
     const char* nmg = getenv("OPRL_AMD_NO_MERGE");
     h->no_merge = (nmg != nullptr && atoi(nmg) != 0) ? 1 : 0;
+    const char* nm2 = getenv("OPRL_AMD_NO_MERGE2");
+    h->no_merge2 = (nm2 != nullptr && atoi(nm2) != 0) ? 1 : 0;
     const char* nw = getenv("OPRL_AMD_NO_WIDE");
     h->no_wide = (nw != nullptr && atoi(nw) != 0) ? 1 : 0;
     // the generic per-net launches on clusters of 4 (slice_tp.hip): any net of the common shape

@@ -29,13 +29,16 @@ def _close(a, b, tol=1e-5):
 # tp3.h passes instead of the lean tp4.h ones
 # (8 and 4 run the critic's dW + Adam tiles inside phase 1's launch, csrc/dw_body.h GATED; "8s": role A on eight CUs and the
 # dW launches on their own, OPRL_AMD_NO_MERGE)
-@pytest.mark.parametrize("cluster", [8, "8s", 4, "4g", 2, 1])
+# 8 and 4 also run the ACTOR's dW + Adam tiles inside phase 2's launch, its backward as role U with unit seeds (GATE == 2);
+# "8p": phase 2 runs the actor's backward itself and the actor's dW is a launch of its own, OPRL_AMD_NO_MERGE2)
+@pytest.mark.parametrize("cluster", [8, "8s", "8p", 4, "4g", 2, 1])
 @pytest.mark.parametrize("B", [256, 8, 100])
 def test_fused_equals_generic(B, cluster, monkeypatch):
     monkeypatch.setenv("OPRL_AMD_NO_LEAN", "1" if cluster == "4g" else "0")
-    monkeypatch.setenv("OPRL_AMD_NO_WIDE", "0" if cluster in (8, "8s") else "1")
+    monkeypatch.setenv("OPRL_AMD_NO_WIDE", "0" if cluster in (8, "8s", "8p") else "1")
     monkeypatch.setenv("OPRL_AMD_NO_MERGE", "1" if cluster == "8s" else "0")
-    cluster = 4 if cluster in ("4g", 8, "8s") else cluster
+    monkeypatch.setenv("OPRL_AMD_NO_MERGE2", "1" if cluster in ("8s", "8p") else "0")
+    cluster = 4 if cluster in ("4g", 8, "8s", "8p") else cluster
     monkeypatch.setenv("OPRL_AMD_CLUSTER", str(cluster))
     fused, generic = _ddpg(), _ddpg(no_fuse=True)
     for step in range(4):
