@@ -273,12 +273,29 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int b
       for (int j = 0; j < kDuLd; ++j)
         if (j < Ad) va[j] = ld4(G.w3 + ((size_t)(ncol >> 4) * 64 + ((ncol & 15) >> 2) * 16 + j) * 4);
     }
-    // role U's rows (first hidden layer); and — for every tile — role U must have READ the packs this tile's
-    // epilogue rewrites: its flags are waited for before anything is stored
-    if (kind == 2) {
-      const bool ok = dw_gate_wait(G.rows, G.n_rows, G.tag, G.spin);
+    // First attempts at everything this tile waits for are REQUESTED TOGETHER with the rows above (a tile that starts
+    // after the roles have retired finds it all there: one round trip, not one per kind of flag): the row's du
+    // granules, and this thread's flag of role U — its members have written their rows through (first hidden layer,
+    // `rows`) or at least READ the packs this tile's epilogue rewrites (`read`: every other tile, before it stores).
+    unsigned long long g[kDuLd];
+#pragma unroll
+    for (int j = 0; j < kDuLd; ++j)
+      g[j] = (j < Ad && bb < hB) ? __hip_atomic_load(G.seed + (size_t)bb * kDuLd + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                 : ((unsigned long long)G.tag << 32);
+    const unsigned long long* fl = kind == 2 ? G.rows : G.read;
+    const int nfl = kind == 2 ? G.n_rows : G.n_read;
+    const unsigned long long* myf = fl + (tid < nfl ? tid : 0);       // (n flags <= 128 < threads: every flag has a poller)
+    unsigned long long f0 = __hip_atomic_load(myf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+      bool ok = (unsigned)(f0 >> 32) == G.tag;
+      for (int spin = 0; spin < G.spin && !ok; ++spin) {
+        __builtin_amdgcn_s_sleep(2);
+        ok = (unsigned)(__hip_atomic_load(myf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == G.tag;
+      }
       if (!ok) report_expired(G.err, G.err_code);
-      __syncthreads();
+    }
+    if (kind == 2) {
+      __syncthreads();     // every member of role U has flagged its rows
       if (an_ok && bb < hB) {
         const float* src = G.U + (((size_t)(ncol >> 4) * Ad) * hB + bb) * 16 + (ncol & 15);
 #pragma unroll
@@ -288,26 +305,22 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int b
     }
     float du[kDuLd];
     {
-      unsigned long long g[kDuLd];
-      bool ok = false;
-      for (int spin = 0; spin < G.spin && !ok && bb < hB; ++spin) {
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < kDuLd; ++j) ok = ok && (unsigned)(g[j] >> 32) == G.tag;
+      for (int spin = 0; spin < G.spin && !ok; ++spin) {
+        __builtin_amdgcn_s_sleep(1);
 #pragma unroll
         for (int j = 0; j < kDuLd; ++j)
-          g[j] = j < Ad ? __hip_atomic_load(G.seed + (size_t)bb * kDuLd + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                        : ((unsigned long long)G.tag << 32);
+          if (j < Ad) g[j] = __hip_atomic_load(G.seed + (size_t)bb * kDuLd + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = true;
 #pragma unroll
         for (int j = 0; j < kDuLd; ++j) ok = ok && (unsigned)(g[j] >> 32) == G.tag;
-        if (!ok) __builtin_amdgcn_s_sleep(1);
       }
-      if (!ok && bb < hB) report_expired(G.err, G.err_code);
+      if (!ok) report_expired(G.err, G.err_code);
 #pragma unroll
       for (int j = 0; j < kDuLd; ++j)
         du[j] = (bb < hB && j < Ad) ? (ok ? __uint_as_float((unsigned)g[j]) : __builtin_nanf("")) : 0.f;
-    }
-    if (kind != 2) {
-      const bool ok = dw_gate_wait(G.rows, G.n_rows, G.tag, G.spin);
-      if (!ok) report_expired(G.err, G.err_code);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the sc1 row loads are inline asm: hipcc does not count them)
     stamp();   // rows and seeds in

@@ -260,6 +260,13 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
 template <int WIDTH, bool LEAN, bool SAC, class P, bool WIDE = false, bool MERGED = false>
 __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const DwKArgs* D = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (A.prefetch_p1 && blockIdx.y == gridDim.y - 1) {
+    // the next update's rows (dispatched last: these workgroups start as roles retire), into the other staging set
+    PrefetchJob J;
+    J.next = A.next; J.S = A.S; J.A = A.A; J.B = A.B; J.z0 = 0;
+    prefetch_rows_body(J, (int)blockIdx.x, smem);
+    return;
+  }
   if constexpr (MERGED) {
     const int rows = (2 + A.n_critics) * A.nc + ((LEAN && WIDE) ? 4 : 0);
     if ((int)blockIdx.y >= rows) {
@@ -797,90 +804,105 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2_group(const DdpgArgs* 
 //
 // The actor's backward is linear in its output seed du = da (1 - pi^2) [B x A], and everything else it needs — the
 // actor's weights and its forward activations (role C of phase 1) — exists when this launch starts.  So it leaves
-// the update's critical chain: ROLE U (four workgroups per slice, beside the critic pass) runs it with A unit seeds
-//     U_j[b, k] = (h1[b, k] > 0) sum_n (h2[b, n] > 0) W3[j, n] W2[n, k]          (member c: columns 64 c .. 64 c + 63)
+// the update's critical chain: ROLE U (eight workgroups per slice, beside the critic pass) runs it with A unit seeds
+//     U_j[b, k] = (h1[b, k] > 0) sum_n (h2[b, n] > 0) W3[j, n] W2[n, k]          (member c: columns 32 c .. 32 c + 31; wave = tile x seed)
 // and writes the rows through; the critic pass (forward + constant-seed backward to the action columns, unchanged)
 // ends by publishing du as {epoch, value} granules; the actor's dW tiles (dw_adam_body<false, 2>), riding behind the
 // roles like the critic's tiles ride on phase 1, have taken in their Adam state and X rows by then and form their dY
 // from du:  output layer du itself, second hidden layer (h2 > 0) (du W3), first hidden layer sum_j du_j U_j.  What
 // used to follow the critic pass — the actor's backward (a whole pass), a kernel boundary and a k_dw_adam launch — is
 // one granule hop, a few FMAs per element, 16 MFMAs and the Adam epilogue.
-// Grid rows: [0, NMC) critic pass | [NMC, NMC + 4) role U | prefetch row (step_n) | tiles.
+// Grid rows: [0, NMC) critic pass | [NMC, NMC + 8) role U | prefetch row (step_n) | tiles.
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int kUMembers = 8;    // role U's workgroups per slice: member c owns columns 32 c .. 32 c + 31 of the first hidden layer
 struct RoleULds {   // floats
-  static constexpr int w = 0;                               // the member's W2^T shard: [4 tiles][16 steps][256]
-  static constexpr int h2 = w + 4 * 16 * 256;               // [kR][kWL4]
+  static constexpr int w = 0;                               // the member's W2^T shard: [2 tiles][16 steps][256]
+  static constexpr int h2 = w + 2 * 16 * 256;               // [kR][kWL4]
   static constexpr int w3 = h2 + kR * kWL4;                 // [kDuLd][256] rows of the output layer (zero beyond A)
-  static constexpr int total = w3 + kDuLd * 256;
+  static constexpr int out = w3 + kDuLd * 256;              // [kWaves][16][16] finished tiles, for 16-byte stores
+  static constexpr int total = out + kWaves * 256;
 };
 
 __device__ __forceinline__ void role_u(const DdpgArgs& A, float* smem, int slice, int c) {
   float* Wl = smem + RoleULds::w;
   float* h2s = smem + RoleULds::h2;
   float* w3s = smem + RoleULds::w3;
+  float* outs = smem + RoleULds::out;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
   const int row0 = slice * kR, B = A.B, Ad = A.A;
-  // ---- requests: the shard (64 KB, four b128 per thread), the slice's h2 rows, the output layer's snapshot, and
-  // this lane's h1 elements (the mask of what it will store)
-  const float* wsrc = A.actor.pb[1] + (size_t)c * 4 * 16 * 256;
-  f32x4 wv[4];
+  int n_stamp = 0;
+  auto stamp = [&]() {   // trace slot 6 (phase 2's own is slot 3): workgroup = slice, member 0
+    if (A.trace != nullptr && tid == 0 && c == 0 && n_stamp < kTraceStamps) {
+      long long* tr = A.trace + (((size_t)3 * 64 + slice) * kTraceStamps + n_stamp) * 2;
+      tr[0] = (long long)__builtin_readcyclecounter();
+      tr[1] = (long long)wall_clock64();
+    }
+    ++n_stamp;
+  };
+  stamp();
+  // ---- requests: the shard (32 KB, two b128 per thread), the slice's h2 rows, the output layer's snapshot, and
+  // this lane's h1 elements (the mask of what it will finish)
+  const float* wsrc = A.actor.pb[1] + (size_t)c * 2 * 16 * 256;
+  f32x4 wv[2];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) wv[q] = ld4(wsrc + ((size_t)q * kThreads + tid) * 4);
+  for (int q = 0; q < 2; ++q) wv[q] = ld4(wsrc + ((size_t)q * kThreads + tid) * 4);
   const int hr = tid >> 6, hc = (tid & 63) * 4;
   f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};
   if (row0 + hr < B) hv = ld4(A.aX[2] + (size_t)(row0 + hr) * kW4 + hc);
   const f32x4 w3q = ld4(A.w3_snap + (size_t)tid * 4);     // pack element (s = tid >> 6, lane = tid & 63): W3[lane & 15][16 s + 4 (lane >> 4) + t]
-  const int t1 = wave & 3, g = wave >> 2;                  // this wave: tile t1 of the member, unit seeds 2 g, 2 g + 1
+  const int t1 = wave & 1, j = wave >> 1;                  // this wave: tile t1 of the member, unit seed j
   float m1[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int gr = row0 + 4 * kk + r;
-    m1[r] = gr < B ? A.aX[1][(size_t)gr * kW4 + 64 * c + 16 * t1 + i] : 0.f;
+    m1[r] = gr < B ? A.aX[1][(size_t)gr * kW4 + 32 * c + 16 * t1 + i] : 0.f;
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(Wl + ((size_t)q * kThreads + tid) * 4) = wv[q];
+  for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(Wl + ((size_t)q * kThreads + tid) * 4) = wv[q];
   *reinterpret_cast<f32x4*>(h2s + hr * kWL4 + hc) = hv;
   {
-    const int j = lane & 15;
-    if (j < kDuLd)
-      *reinterpret_cast<f32x4*>(w3s + j * 256 + 16 * (tid >> 6) + 4 * (lane >> 4)) = j < Ad ? w3q : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int jj = lane & 15;
+    if (jj < kDuLd)
+      *reinterpret_cast<f32x4*>(w3s + jj * 256 + 16 * (tid >> 6) + 4 * (lane >> 4)) = jj < Ad ? w3q : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
-  const int j0 = 2 * g, j1 = 2 * g + 1;
-  if (j0 < Ad) {
-    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+  // everything this role reads of the actor is in LDS: the tiles of this launch may rewrite the actor's packs
+  if (tid == 0)
+    __hip_atomic_store(A.u_flags + 128 + slice * kUMembers + c, (unsigned long long)A.epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  stamp();   // shard, rows and the output layer in LDS
+  if (j < Ad) {
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;   // even / odd steps: two MFMA chains
     const float* hrow = h2s + i * kWL4 + 4 * kk;
-    const float* w0 = w3s + j0 * 256 + 4 * kk;
-    const float* w1 = w3s + (j1 < kDuLd ? j1 : j0) * 256 + 4 * kk;
+    const float* w0 = w3s + j * 256 + 4 * kk;
     const float* bw = Wl + ((size_t)t1 * 16 * 64 + lane) * 4;
-#pragma unroll 4
-    for (int s = 0; s < 16; ++s) {
-      const f32x4 b = ld4(bw + s * 256);
-      const f32x4 h = ld4(hrow + 16 * s);
-      const f32x4 x0 = ld4(w0 + 16 * s), x1 = ld4(w1 + 16 * s);
+#pragma unroll
+    for (int s = 0; s < 16; s += 2) {
+      const f32x4 b0 = ld4(bw + s * 256), b1 = ld4(bw + (s + 1) * 256);
+      const f32x4 h0 = ld4(hrow + 16 * s), h1v = ld4(hrow + 16 * (s + 1));
+      const f32x4 x0 = ld4(w0 + 16 * s), x1 = ld4(w0 + 16 * (s + 1));
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        a0 = mfma4(h[t] > 0.f ? x0[t] : 0.f, b[t], a0);
-        a1 = mfma4(h[t] > 0.f ? x1[t] : 0.f, b[t], a1);
+        a0 = mfma4(h0[t] > 0.f ? x0[t] : 0.f, b0[t], a0);
+        a1 = mfma4(h1v[t] > 0.f ? x1[t] : 0.f, b1[t], a1);
       }
     }
-    // lane (kk, i): rows 4 kk + r, column 64 c + 16 t1 + i of unit seeds j0 / j1 -> U[tile][j][row][16], written through
-    const int tile = 4 * c + t1;
+    // lane (kk, i): rows 4 kk + r, column 32 c + 16 t1 + i of unit seed j -> through wave-private LDS -> U[tile][j][row][16]
+    // as one contiguous KB per wave, written through
+    float* o = outs + wave * 256;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int gr = row0 + 4 * kk + r;
-      if (gr < B) {
-        float* d0 = A.U + (((size_t)tile * Ad + j0) * B + gr) * 16 + i;
-        __hip_atomic_store(d0, m1[r] > 0.f ? a0[r] : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (j1 < Ad)
-          __hip_atomic_store(d0 + (size_t)B * 16, m1[r] > 0.f ? a1[r] : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+    for (int r = 0; r < 4; ++r) o[(4 * kk + r) * 16 + i] = m1[r] > 0.f ? a0[r] + a1[r] : 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int tile = 2 * c + t1, row = lane >> 2, gr = row0 + row;
+    if (gr < B) tp4_st4(A.U + (((size_t)tile * Ad + j) * B + gr) * 16 + (lane & 3) * 4, ld4(o + row * 16 + (lane & 3) * 4), true);
   }
+  stamp();   // MFMAs done, stores issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  stamp();   // written through
   if (tid == 0)
-    __hip_atomic_store(A.u_flags + slice * 4 + c, (unsigned long long)A.epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(A.u_flags + slice * kUMembers + c, (unsigned long long)A.epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <class P, bool WIDE>
@@ -892,7 +914,7 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const DwKAr
   const int B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
   const int slice = blockIdx.x, row0 = slice * kR;
   const int y = (int)blockIdx.y;
-  const int yP = NMC + 4, yT = yP + (A.prefetch_next ? 1 : 0);
+  const int yP = NMC + kUMembers, yT = yP + (A.prefetch_next ? 1 : 0);
   if (y >= yT) {   // a tile workgroup: all 16 waves (16 minibatch rows each)
     const int tile = (y - yT) * (int)gridDim.x + slice;
     if (tile >= D->tile_end[kDwMaxItems - 1]) return;
@@ -1060,7 +1082,7 @@ hipError_t launch_ddpg_phase1_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_
   static_assert(sizeof(DdpgArgs) % alignof(DwKArgs) == 0 || true, "");
   const int slices = (a.B + kR - 1) / kR;
   const int tiles = d.tile_end[kDwMaxItems - 1];
-  const dim3 grid(slices, 3 * a.nc + (tiles + slices - 1) / slices);
+  const dim3 grid(slices, 3 * a.nc + (tiles + slices - 1) / slices + (a.prefetch_p1 ? 1 : 0));
   if (a.bf16) hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
   else hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecF32>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
   return hipGetLastError();
@@ -1074,7 +1096,7 @@ hipError_t launch_ddpg_phase2_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_
   const int tiles = d.tile_end[kDwMaxItems - 1];
   const bool wide = (a.wide & 2) != 0;
   if (wide && a.xnc < 8) return hipErrorInvalidValue;
-  const dim3 grid(slices, (wide ? 8 : 4) + 4 + (a.prefetch_next ? 1 : 0) + (tiles + slices - 1) / slices);
+  const dim3 grid(slices, (wide ? 8 : 4) + kUMembers + (a.prefetch_next ? 1 : 0) + (tiles + slices - 1) / slices);
   if (wide) hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecF32, true>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
   else hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecF32, false>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
   return hipGetLastError();
@@ -1084,11 +1106,11 @@ hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
   if ((a.wide & 1) != 0) {      // role A on clusters of 8 (DDPG, fp32 lean passes; learner.hip decides)
     if (!lean_ok(a) || a.sac || a.bf16 || a.n_critics != 1 || a.xnc < 8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_ddpg_phase1<256, true, false, PrecF32, true>), dim3(slices, a.nc + 8 + a.nc), dim3(kThreads),
+    hipLaunchKernelGGL((k_ddpg_phase1<256, true, false, PrecF32, true>), dim3(slices, a.nc + 8 + a.nc + (a.prefetch_p1 ? 1 : 0)), dim3(kThreads),
                        fused_ddpg_lds_bytes(), st, a);
     return hipGetLastError();
   }
-  const dim3 grid(slices, (2 + a.n_critics) * a.nc);
+  const dim3 grid(slices, (2 + a.n_critics) * a.nc + (a.prefetch_p1 ? 1 : 0));
   if (a.bf16) {
     // the bf16 MFMA mode exists for the lean passes only; the nets' pf / pb point at bf16 packs
     if (!lean_ok(a)) return hipErrorInvalidValue;

@@ -232,6 +232,7 @@ struct DwGate {
   //   kind 2  first hidden:  dY[b, n] = sum_j du[b, j] U_j[b, n]                      (role U's unit backward rows)
   // U: [16-column tile][n_act][B][16] floats, written through by role U of the same launch (flags `rows`).
   int kind[4] = {0, 0, 0, 0};          // per item of the launch
+  const unsigned long long* read = nullptr; int n_read = 0;   // role U has taken in what it reads of the actor's packs: only then may a tile's epilogue rewrite them
   const float* h2 = nullptr;           // [B][256] the actor's second hidden activations (written by the launch before)
   const float* w3 = nullptr;           // the output layer's forward pack as it was BEFORE this launch (16 steps x 256 floats)
   const float* U = nullptr;
@@ -306,6 +307,9 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   // here), so the ends-table -> search -> random-row chain leaves phase 1's critical path
   BatchSrc next;
   int prefetch_next;
+  // ... or PHASE 1 carries that row, as the last row of its grid, into the OTHER of two staging sets (step_n with the
+  // merged phase 2, whose role U and critic pass fill the chip: DdpgArgs::merged bit 1)
+  int prefetch_p1;
   float gamma, inv_B;
   float* cX[kMaxLayers]; int cldx0;    // critic layer inputs ([s|a], h1, h2) for dW
   float* cdY[kMaxLayers]; int clddo;   // critic pre-activation grads
@@ -331,7 +335,7 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   int merged;
   unsigned long long* gate_flags;
   unsigned long long* du_granules;     // [B][kDuLd] {epoch, du}
-  unsigned long long* u_flags;         // [slices][4] role U's members have written their rows through
+  unsigned long long* u_flags;         // [0, 128): role U's members have written their rows through; [128, 256): ... have read the actor's packs
   float* U;                            // [16][A][B][16] unit-seed dz1 of the actor (role U -> first-layer tiles)
   float* w3_snap;                      // the actor's output-layer forward pack, copied by phase 1's role C (slice 0)
   int no_lean;                         // 1: never use the tp4.h specialisation (OPRL_AMD_NO_LEAN, tests)

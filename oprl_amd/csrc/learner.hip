@@ -444,6 +444,7 @@ struct oprl_learner {
   BatchSrc src;                // where the current update's minibatch comes from
   BatchSrc next_src;           // step_n: what phase 2 should gather for the next update
   int prefetch_next = 0;
+  bool prefetch_p1 = false;    // step_n: phase 1 carries the next update's rows (two staging sets), not phase 2
   // key of the in-update noise streams (TD3 smoothing, SAC / TQC reparameterisation draws): the run
   // seed and, in a data-parallel job, the rank — every seed and every rank draws its own eps
   uint64_t noise_seed = 0;
@@ -932,9 +933,15 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   // beside the critic pass with unit seeds (role U), the tiles combine with du (csrc/fused_ddpg.hip)
   if (!h->no_merge2 && h->du_granules != nullptr && !a.sac && !a.bf16 && B <= 256 && !h->cfg.export_grads && !h->dp_inline &&
       fused_ddpg_is_lean(a) && c.actor.theta_target != nullptr) {
+    // (role U takes eight workgroups per slice; where those, the critic pass on eight and the prefetch row do not fit the
+    // chip together — B = 256 — the critic pass stays on a cluster of four)
     const int slices = (B + kR - 1) / kR;
-    const int rows = ((a.wide & 2) != 0 ? 8 : 4) + 4 + 1;
-    if (rows * slices <= h->n_cus) {
+    // (step_n's prefetch row rides on phase 1 then — two staging sets — unless the second set could not be allocated)
+    const int pf_rows = h->batch_alt == nullptr ? 1 : 0;
+    int nmc = (a.wide & 2) != 0 ? 8 : 4;
+    if ((nmc + 8 + pf_rows) * slices > h->n_cus) nmc = 4;
+    if ((nmc + 8 + pf_rows) * slices <= h->n_cus) {
+      if (nmc == 4) a.wide &= ~2;
       a.merged |= 2;
       a.du_granules = h->du_granules;
       a.u_flags = h->u_flags;
@@ -1050,11 +1057,15 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
       HIPC(hipMemsetAsync(h->y_granules, 0, ((size_t)3 * h->Bmax + 256) * sizeof(unsigned long long), st));
       if (h->du_granules != nullptr) {
         HIPC(hipMemsetAsync(h->du_granules, 0, (size_t)(h->Bmax < 256 ? h->Bmax : 256) * kDuLd * sizeof(unsigned long long), st));
-        HIPC(hipMemsetAsync(h->u_flags, 0, 64 * sizeof(unsigned long long), st));
+        HIPC(hipMemsetAsync(h->u_flags, 0, 256 * sizeof(unsigned long long), st));
       }
     }
     DdpgArgs fa = ddpg_args(h, B);
     fa.noise = noise0;
+    if (h->prefetch_p1 && h->prefetch_next) {
+      fa.prefetch_p1 = 1;
+      h->staged_ready = true;
+    }
     RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &fa.cluster_tag));
     if (h->trace != nullptr) fa.trace = h->trace;   // roles use slots 0 .. 1 + n_critics
     HIPC(chain_before(st));
@@ -1234,7 +1245,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     DdpgArgs fa = ddpg_args(h, B);
     RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &fa.cluster_tag));
     if (h->trace != nullptr && c.algo == OPRL_DDPG) fa.trace = h->trace + (size_t)3 * 64 * kTraceStamps * 2;   // slot 3
-    fa.prefetch_next = h->prefetch_next;
+    fa.prefetch_next = h->prefetch_p1 ? 0 : h->prefetch_next;
     // Where phase 2's own workgroups already fill the chip (SAC at B = 1024: 4 x 64), its prefetch row is a round of
     // its own; the actor's dW launch, which follows and leaves 40 % of the chip idle, carries the row instead
     // (prefetch_rows_direct, the same rows).  OPRL_AMD_PREFETCH_P2=1: always phase 2.
@@ -1251,7 +1262,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
         pj.next = fa.next; pj.S = h->S; pj.A = h->A; pj.B = B; pj.z0 = -1;
       }
     }
-    if (h->prefetch_next) h->staged_ready = true;
+    if (h->prefetch_next && !h->prefetch_p1) h->staged_ready = true;
     HIPC(chain_before(st));
     if ((fa.merged & 2) != 0 && !pf_on_dw) {
       // phase 2 and the actor's dW + Adam tiles as ONE launch: role U's unit-seed backward beside the critic pass,
@@ -1260,7 +1271,8 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
       DwKArgs kd;
       if (fill_dw_kargs(dw, &kd) < 0 || dw.n_items != 3) { set_err("merged phase 2: bad dW table"); return OPRL_ERR_INVALID; }
       const int slices = (B + kR - 1) / kR;
-      kd.gate.rows = fa.u_flags; kd.gate.n_rows = 4 * slices;
+      kd.gate.rows = fa.u_flags; kd.gate.n_rows = 8 * slices;
+      kd.gate.read = fa.u_flags + 128; kd.gate.n_read = 8 * slices;
       kd.gate.seed = fa.du_granules; kd.gate.n_seed = B;
       kd.gate.tag = h->epoch; kd.gate.spin = h->debug_expire == 7 ? 0 : (1 << 20);
       kd.gate.err = h->err_dev; kd.gate.err_code = (2u << 8) | 7u;      // KERN_PHASE2, SITE_DW_GATE (csrc/tp3.h)
@@ -1831,7 +1843,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   floats += 64 * 32 + 6 * (size_t)B + 512;      // (granule arrays: y, q1, q2; 256 gate flags)
   const int Bm = B < 256 ? B : 256;             // merged phase 2 serves one 256-row chunk
   const bool merge2_bufs = h->fused && cfg->algo != OPRL_SAC && A <= kDuLd;
-  if (merge2_bufs) floats += 2 * ((size_t)Bm * kDuLd + 64) + 256 + (size_t)16 * A * Bm * 16 + 16 * 256 + 4 * 64;
+  if (merge2_bufs) floats += 2 * ((size_t)Bm * kDuLd + 64) + 2 * 256 + 128 + (size_t)16 * A * Bm * 16 + 16 * 256 + 4 * 64;
   if (h->bf16) {
     floats += 2 * ((size_t)net_pack16_floats(cfg->actor) + 64);
     for (int j = 0; j < nc; ++j) floats += 2 * ((size_t)net_pack16_floats(cfg->critics[j]) + 64);
@@ -1875,7 +1887,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   h->y_granules = p.take<unsigned long long>((size_t)3 * B + 256);
   if (merge2_bufs) {
     h->du_granules = p.take<unsigned long long>((size_t)Bm * kDuLd);
-    h->u_flags = p.take<unsigned long long>(64);
+    h->u_flags = p.take<unsigned long long>(256);
     h->U = p.take<float>((size_t)16 * A * Bm * 16);
     h->w3_snap = p.take<float>(16 * 256);
   }
@@ -1929,7 +1941,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->no_layerwise = (nlw != nullptr && atoi(nlw) != 0);
     const char* ngr = getenv("OPRL_AMD_NO_GATHER_RIDE");
     h->no_gather_ride = (ngr != nullptr && atoi(ngr) != 0);
-    if (cfg->algo == OPRL_TQC) {
+    if (cfg->algo == OPRL_TQC || h->du_granules != nullptr) {
       const size_t n = (size_t)h->Bmax * (2 * (size_t)h->S + h->A + 2);
       if (hipMalloc(&h->batch_alt, n * sizeof(float)) != hipSuccess) h->batch_alt = nullptr;   // (then: a gather launch per update)
     }
@@ -2129,22 +2141,33 @@ extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t
     // The first update gathers in-kernel; every update's phase 2 also gathers the NEXT
     // update's rows into the staging batch (h->bs ..), which phase 1 then reads as plain rows.
     h->next_src = sc;
-    h->next_src.s = h->bs; h->next_src.a = h->ba; h->next_src.r = h->br; h->next_src.d = h->bd;
-    h->next_src.s2 = h->bs2;
+    // With the merged phase 2 (whose roles fill the chip) PHASE 1 carries the next update's rows — every update, TD3's
+    // critic-only ones included — into the other of two staging sets, since its own roles are still reading theirs
+    const size_t Bm = (size_t)h->Bmax;
+    float* alt = h->batch_alt;
+    float* set[2][5] = {{h->bs, h->ba, h->br, h->bd, h->bs2},
+                        {alt, alt + Bm * h->S, alt + Bm * (h->S + h->A), alt + Bm * (h->S + h->A + 1), alt + Bm * (h->S + h->A + 2)}};
+    h->prefetch_p1 = alt != nullptr && (ddpg_args(h, B).merged & 2) != 0;
+    int cur = 0;
     int rc = OPRL_OK;
     h->staged_ready = false;
     for (int k = 0; k < K && rc == OPRL_OK; ++k) {
+      float** b = set[cur];
+      float** nb = set[h->prefetch_p1 ? cur ^ 1 : cur];
+      h->next_src.s = nb[0]; h->next_src.a = nb[1]; h->next_src.r = nb[2]; h->next_src.d = nb[3]; h->next_src.s2 = nb[4];
       sc.counter = (unsigned long long)h->update_count;
       h->next_src.counter = sc.counter + 1;
       h->prefetch_next = (k + 1 < K) ? 1 : 0;
-      // rows staged by the previous update's phase 2 (it does not run on TD3's critic-only
-      // steps), else the slice kernels gather their own
+      // rows staged by the previous update (phase 2 does not run on TD3's critic-only steps), else the slice kernels
+      // gather their own
       sc.gather = h->staged_ready ? 0 : 1;
       h->staged_ready = false;
-      rc = oprl_learner_update(h, h->bs, h->ba, h->br, h->bd, h->bs2, B, nullptr, nullptr, stream);
+      rc = oprl_learner_update(h, b[0], b[1], b[2], b[3], b[4], B, nullptr, nullptr, stream);
+      if (h->prefetch_p1) cur ^= 1;
     }
     sc.gather = 0;
     h->prefetch_next = 0;
+    h->prefetch_p1 = false;
     h->staged_ready = false;
     return rc;
   }

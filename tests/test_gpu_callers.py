@@ -99,7 +99,10 @@ def test_sac_b1024_step_n_equals_python_loop_bitwise():
     assert a1.alpha == a2.alpha
 
 
-def test_export_grads_split_equals_fused_update():
+def test_export_grads_split_equals_fused_update(monkeypatch):
+    # (the one-call update with the actor's backward in phase 2 itself, as the split path runs it: the merged phase 2
+    # — role U's unit seeds — sums in another order and is held to the generic path by tests/test_gpu_fused.py)
+    monkeypatch.setenv("OPRL_AMD_NO_MERGE2", "1")
     fused, split = _ddpg(), _ddpg(export_grads=True)
     for step in range(3):
         batch = [x.cuda() for x in fx.make_batch(50 + step, 256, 24, 6)]
@@ -118,7 +121,7 @@ def test_export_grads_split_equals_fused_update():
     assert t.equal(q_split, split.critic(s, a))
 
 
-def test_td3_export_grads_split_equals_fused_update():
+def test_td3_export_grads_split_equals_fused_update(monkeypatch):
     """TD3 through the fused twin-critic kernels in data-parallel mode: update_phase / apply (the
     k_dw_adam apply_only launch over both critics' layer tables) against the one-call update, over
     critic-only and actor steps."""
@@ -129,6 +132,7 @@ def test_td3_export_grads_split_equals_fused_update():
         t.manual_seed(0)
         return TD3(logger=NullLogger(), state_dim=17, action_dim=6, device="cuda", max_batch=256, **kw).create()
 
+    monkeypatch.setenv("OPRL_AMD_NO_MERGE2", "1")     # (as in the DDPG test above)
     fused, split = make(), make(export_grads=True)
     for step in range(4):
         batch = [x.cuda() for x in fx.make_batch(60 + step, 256, 17, 6)]

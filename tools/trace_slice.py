@@ -37,13 +37,15 @@ t.cuda.synchronize()
 tr = buf.cpu().numpy()
 fused = "--generic" not in sys.argv
 names = (["P1 role A target chain", "P1 role B critic f+b", "P1 role C actor fwd", "P2 critic f+b, actor bwd",
-          "dW critic (wg0 = hidden-layer tile 0)", "dW actor"]
+          "dW critic (wg0 = hidden-layer tile 0)", "dW actor", "P2 role U (actor unit backward)"]
          if fused else ["actor_t fwd", "critic_t fwd", "critic fwd+bwd", "actor fwd", "critic(s,pi) fwd+bwd", "actor bwd"])
 for slot in range(len(names)):
     x = tr[slot, :16]                       # 16 workgroups
-    if slot >= 4 and fused:
+    if slot in (4, 5) and fused:
         x = tr[slot, 16:32]                 # dW: the hidden layer's first 16 tiles
     n = int((x[0, :, 0] != 0).sum())
+    if n < 2:
+        continue
     cyc = x[:, :n, 0].astype(np.float64)
     rt = x[:, :n, 1].astype(np.float64)     # 100 MHz ticks
     d_cyc = np.diff(cyc, axis=1)
@@ -54,7 +56,7 @@ for slot in range(len(names)):
           f"max-wg={tot_us.max():.2f}us  cyc/us~{clk.mean():.2f} GHz  start spread={(rt[:,0].max()-rt[:,0].min())/100:.2f}us")
     if "--cycles" in sys.argv:
         print(f"{'':22s} wg0 phases(cycles)={d_cyc[0].astype(int).tolist()}")
-    if slot >= 4 and fused and "--dw-tiles" in sys.argv:
+    if slot in (4, 5) and fused and "--dw-tiles" in sys.argv:
         # the traced workgroups of a dW launch are the first 16 tiles of each layer (slot index = 16 * layer + tile)
         for layer in range(3):
             y = tr[slot, 16 * layer:16 * layer + 16]
