@@ -125,7 +125,7 @@ def cpu_baseline(budget_s: float = 14.0):
 
 # ---- the other BASELINE.json configurations, the bf16 mode and the through-the-API rate --------
 PEAK_BF16_MATRIX_TFLOPS = 2500.0       # dense bf16 MFMA (MI355X_MICROARCH.md)
-PMC_FILE = {"f32": "r02i_pmc_traffic.json", "bf16": "r02i_pmc_traffic_bf16.json"}
+PMC_FILE = {"f32": "r02i_pmc_traffic.json", "bf16": "r02i_pmc_traffic_bf16.json", "x2": "r02i_pmc_traffic.json"}
 PEAK_HBM_TBS = 8.0
 # name -> (class name, S, A, B, constructor extras, algorithmic GFLOP / update, state MB / update): BASELINE.md section 4
 BASELINE_CONFIGS = {
@@ -342,7 +342,7 @@ def main():
     ap.add_argument("--learners", type=int, default=8,
                     help="extra measurement: this many independent learners (seeds) on separate "
                          "streams of the same GPU (multi-seed packing, runners/train.py --seeds); 0 = skip")
-    ap.add_argument("--precision", choices=("f32", "bf16"), default="f32",
+    ap.add_argument("--precision", choices=("f32", "bf16", "x2"), default="f32",
                     help="arithmetic mode of the TIMED learner: f32 = exact-fp32 MFMA, the parity mode and the headline; "
                          "bf16 = the bf16 MFMA mode (profiling that path; the default run reports it in its `bf16` block)")
     ap.add_argument("--group", type=int, default=32,

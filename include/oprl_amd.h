@@ -57,7 +57,7 @@ typedef enum oprl_algo { OPRL_DDPG = 0, OPRL_TD3 = 1, OPRL_SAC = 2, OPRL_TQC = 3
  *          learner computes in fp32 from the fp32 packs.  Deviation from the reference: ~1e-3..1e-2
  *          relative on Q (bf16 inputs cannot meet the 1e-4 gate; tests/test_gpu_bf16.py states and
  *          measures the tolerance). */
-typedef enum oprl_precision { OPRL_PREC_F32 = 0, OPRL_PREC_BF16 = 1 } oprl_precision;
+typedef enum oprl_precision { OPRL_PREC_F32 = 0, OPRL_PREC_BF16 = 1, OPRL_PREC_X2 = 2 } oprl_precision;
 
 /* One MLP (ReLU hidden layers, identity output), parameters laid out exactly
  * like the reference module's state_dict: W0[out0,in0] row-major, b0, W1, b1...

@@ -14,7 +14,7 @@ OPRL_ABI_VERSION = 1
 OPRL_MAX_LAYERS = 4
 OPRL_MAX_CRITICS = 5
 ALGO = {"ddpg": 0, "td3": 1, "sac": 2, "tqc": 3}
-PRECISION = {"f32": 0, "bf16": 1}
+PRECISION = {"f32": 0, "bf16": 1, "x2": 2}
 ACT_NONE, ACT_TANH, ACT_GAUSS_MEAN = 0, 1, 4
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liboprl_amd.so"

@@ -66,25 +66,29 @@ __device__ __forceinline__ void load_batch(const BatchSrc& P, int row0, int B, i
 
 // The next update's rows, gathered by one workgroup per 16-row slice and left as plain rows in N.s / a / r / d / s2.
 // smem: 2 * kR * kX0Ld + 96 + kMaxEnds floats.  (PrefetchJob: kernels.h)
+__device__ __forceinline__ void prefetch_rows_src(const BatchSrc& N, int S, int Ad, int B, int slice, float* smem);
 __device__ __forceinline__ void prefetch_rows_body(const PrefetchJob& J, int slice, float* smem) {
-  const int tid = threadIdx.x, row0 = slice * kR, S = J.S, Ad = J.A, B = J.B;
+  prefetch_rows_src(J.next, J.S, J.A, J.B, slice, smem);
+}
+__device__ __forceinline__ void prefetch_rows_src(const BatchSrc& N, int S, int Ad, int B, int slice, float* smem) {
+  const int tid = threadIdx.x, row0 = slice * kR;
   float* xa = smem;
   float* xb = xa + kR * kX0Ld;
   float* rS = xb + kR * kX0Ld;
   float* dS = rS + kR;
   int* meta = reinterpret_cast<int*>(dS + 2 * kR);
   int* endsS = reinterpret_cast<int*>(rS + 96);
-  load_batch(J.next, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
+  load_batch(N, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
   __syncthreads();
-  store_rows(xa, kX0Ld, const_cast<float*>(J.next.s), S, S, row0, B);
-  store_rows(xb, kX0Ld, const_cast<float*>(J.next.s2), S, S, row0, B);
+  store_rows(xa, kX0Ld, const_cast<float*>(N.s), S, S, row0, B);
+  store_rows(xb, kX0Ld, const_cast<float*>(N.s2), S, S, row0, B);
   for (int idx = tid; idx < kR * Ad; idx += kThreads) {
     const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
-    if (gr < B) const_cast<float*>(J.next.a)[(size_t)gr * Ad + col] = xa[row * kX0Ld + S + col];
+    if (gr < B) const_cast<float*>(N.a)[(size_t)gr * Ad + col] = xa[row * kX0Ld + S + col];
   }
   if (tid < kR && row0 + tid < B) {
-    const_cast<float*>(J.next.r)[row0 + tid] = rS[tid];
-    const_cast<float*>(J.next.d)[row0 + tid] = dS[tid];
+    const_cast<float*>(N.r)[row0 + tid] = rS[tid];
+    const_cast<float*>(N.d)[row0 + tid] = dS[tid];
   }
 }
 

@@ -271,7 +271,7 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int b
       if (bb < hB) hmask = ld4(G.h2 + (size_t)bb * I.ldy + ncol);
 #pragma unroll
       for (int j = 0; j < kDuLd; ++j)
-        if (j < Ad) va[j] = ld4(G.w3 + ((size_t)(ncol >> 4) * 64 + ((ncol & 15) >> 2) * 16 + j) * 4);
+        if (j < Ad) va[j] = ld4(G.w3 + (size_t)j * I.ldy + ncol);
     }
     // First attempts at everything this tile waits for are REQUESTED TOGETHER with the rows above (a tile that starts
     // after the roles have retired finds it all there: one round trip, not one per kind of flag): the row's du
@@ -564,9 +564,11 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int b
       }
     }
   }
-  if (ad.do_adam && I.pf != nullptr) {
+  if (ad.do_adam && (I.pf != nullptr || I.pf16 != nullptr)) {
     // keep the fragment-order packs in step with the master: stage the new 16x32 tile(s)
     // (zero outside the matrix, like the packs' padding), then 3 x 128 float4 jobs
+    // (I.pf == nullptr: a PrecX2 learner's fused update — its kernels read the two-plane fp16 packs only, the fp32
+    // packs are rebuilt from the master when somebody asks for them, learner.hip fresh32)
     float (*tileW)[LD] = part[0];
     float (*tileT)[LD] = part[1];
     __syncthreads();               // every thread has read its partial sums
@@ -575,7 +577,7 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int b
       tileT[n_off + nl][kl] = tt_new;
     }
     __syncthreads();
-    if (tid < 384) {
+    if (tid < 384 && I.pf != nullptr) {
       const int which = tid >> 7, q = tid & 127;
       const int blk = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
       if (which == 1) {            // W^T pack: tiles over k, steps over n; we own n in [n_off, n_off + TNi)
@@ -602,17 +604,29 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int b
     // side, so this 16 x 32 tile is ONE forward fragment block (64 lanes x 16 B, online and target) and,
     // for W^T, one HALF (8 B per lane) of a block for each of its two 16-row k tiles — the other half
     // belongs to the neighbouring n tile.  Same staged tiles, no further barrier.
+    // PrecX2 learners (A.x2): the same positions in blocks of TWO fp16 planes — hi = fp16(2^8 w), lo = fp16(2^8 w - hi),
+    // the lo plane 256 floats behind the hi plane.
     const float (*tileW)[LD] = part[0];
     const float (*tileT)[LD] = part[1];
     const int NSk2 = cdiv(I.K, 32), NSn2 = cdiv(I.N, 32);
+    const bool x2 = I.x2 != 0;
+    const size_t BK16 = x2 ? 512 : 256;
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     if (tid < 128) {             // W packs: which = online / target
       const int which = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
       float* dst = which == 0 ? I.pf16 : (polyak ? I.tpf16 : nullptr);
       if (dst != nullptr && li >= n_off && li < n_off + TNi) {
         const float (*src)[LD] = which == 0 ? tileW : tileT;
-        const bf16x8 v = cvt_bf16x8(*reinterpret_cast<const f32x4*>(&src[li][4 * lk]),
-                                    *reinterpret_cast<const f32x4*>(&src[li][16 + 4 * lk]));
-        *reinterpret_cast<bf16x8*>(dst + (((size_t)ptile * NSk2 + tk) * 64 + l) * 4) = v;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(&src[li][4 * lk]), v1 = *reinterpret_cast<const f32x4*>(&src[li][16 + 4 * lk]);
+        float* d = dst + ((size_t)ptile * NSk2 + tk) * BK16 + (size_t)l * 4;
+        if (x2) {
+          f16x8 hi, lo;
+          x2_split8(v0 * PrecX2::kWScale, v1 * PrecX2::kWScale, hi, lo);
+          *reinterpret_cast<f16x8*>(d) = hi;
+          *reinterpret_cast<f16x8*>(d + 256) = lo;
+        } else {
+          *reinterpret_cast<bf16x8*>(d) = cvt_bf16x8(v0, v1);
+        }
       }
     } else if (tid < 256 && I.pb16 != nullptr) {   // W^T pack: k tile 2 tk + blk, n step n_base / 32, half (n_base / 16) & 1
       const int q = tid - 128, blk = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
@@ -622,8 +636,16 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int b
         f32x4 v;
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[t] = tileW[4 * lk + t][16 * blk + li];
-        const bf16x4 h = __builtin_convertvector(v, bf16x4);
-        *reinterpret_cast<bf16x4*>(I.pb16 + (((size_t)ktile * NSn2 + (n_base >> 5)) * 64 + l) * 4 + 2 * ((n_base >> 4) & 1)) = h;
+        float* d = I.pb16 + ((size_t)ktile * NSn2 + (n_base >> 5)) * BK16 + (size_t)l * 4 + 2 * ((n_base >> 4) & 1);
+        if (x2) {
+          const f32x4 vs = v * PrecX2::kWScale;
+          const f16x4 hi = __builtin_convertvector(vs, f16x4);
+          const f32x4 r = vs - __builtin_convertvector(hi, f32x4);
+          *reinterpret_cast<f16x4*>(d) = hi;
+          *reinterpret_cast<f16x4*>(d + 256) = __builtin_convertvector(r, f16x4);
+        } else {
+          *reinterpret_cast<bf16x4*>(d) = __builtin_convertvector(v, bf16x4);
+        }
       }
     }
   }

@@ -114,6 +114,18 @@ __device__ __forceinline__ bf16x8 cvt_bf16x8(const f32x4 lo, const f32x4 hi) {
 struct PrecF32 {
   static constexpr int KS = 16;
   static constexpr bool kBf16 = false;
+  static constexpr bool kX2 = false;
+  // the policy-independent part of the interface (PrecX2 below is where it matters): a macro step's B fragment, the
+  // floats between two (tile, step) blocks of a pack, the factor every accumulator is multiplied by
+  typedef f32x4 Frag;
+  static constexpr int kBlk = 256;
+  static constexpr float kOut = 1.f;
+  static constexpr float kFwdA = 1.f;
+  __device__ static __forceinline__ Frag ldf(const float* p) { return ld4(p); }
+  __device__ static __forceinline__ Frag zf() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __device__ static __forceinline__ void mac_s(const float* xr, int s, const Frag b, f32x4& acc, float) { mac(xr, s, b, acc); }
+  __device__ static __forceinline__ void mac_tail_s(const float* xr, int s, const Frag b, f32x4& acc, int k16, float) { mac_tail(xr, s, b, acc, k16); }
+  __device__ static __forceinline__ float a_scale(float) { return 1.f; }     // scale of the A operand for a tile whose largest |element| is given
   __device__ static __forceinline__ void mac(const float* xr, int s, const f32x4 b, f32x4& acc) {
     const f32x4 a = ld4(xr + 16 * s);
 #pragma unroll
@@ -130,6 +142,16 @@ struct PrecF32 {
 struct PrecBF16 {
   static constexpr int KS = 32;
   static constexpr bool kBf16 = true;
+  static constexpr bool kX2 = false;
+  typedef f32x4 Frag;
+  static constexpr int kBlk = 256;
+  static constexpr float kOut = 1.f;
+  static constexpr float kFwdA = 1.f;
+  __device__ static __forceinline__ Frag ldf(const float* p) { return ld4(p); }
+  __device__ static __forceinline__ Frag zf() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __device__ static __forceinline__ void mac_s(const float* xr, int s, const Frag b, f32x4& acc, float) { mac(xr, s, b, acc); }
+  __device__ static __forceinline__ void mac_tail_s(const float* xr, int s, const Frag b, f32x4& acc, int k16, float) { mac_tail(xr, s, b, acc, k16); }
+  __device__ static __forceinline__ float a_scale(float) { return 1.f; }
   __device__ static __forceinline__ void mac(const float* xr, int s, const f32x4 b, f32x4& acc) {
     const bf16x8 a = cvt_bf16x8(ld4(xr + 32 * s), ld4(xr + 32 * s + 16));
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
@@ -143,6 +165,99 @@ struct PrecBF16 {
   }
   __device__ static __forceinline__ float first(const float* frag) {
     return __uint_as_float((*reinterpret_cast<const unsigned*>(frag) & 0xffffu) << 16);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// PrecX2 — fp32-class arithmetic at the fp16 matrix rate ("split" mode, the parity mode of round 3).
+// Every operand is the sum of two fp16 numbers, x = hi + lo with hi = fp16(x) and lo = fp16(x - hi) (round to nearest:
+// 22 significant bits), and a product is three MFMAs v_mfma_f32_16x16x32_f16 with fp32 accumulation,
+//     lo_a hi_b  +  hi_a lo_b  +  hi_a hi_b            (the dropped lo lo term is 2^-22 of the product)
+// — 48 cycles per 32 contraction indices where the exact-fp32 instruction takes 256, for a per-product error of
+// ~2^-21 against fp32's 2^-24 (summation-order noise of the 256-deep contractions is of the same size).
+//   B operand: fragment packs with TWO fp16 planes per (tile, macro step) block — [hi: 64 lanes x 8 halfs | lo: the
+//     same] = 2 KB, the bytes of the fp32 pack — in the k-order of the bf16 packs (pack16_index), holding 2^8 w (the
+//     weights sit around 2^-4: scaled, their lo parts are normal fp16 numbers); written by the dW + Adam epilogues
+//     and k_repack from the fp32 master (RNE).
+//   A operand: the SAME two ds_read_b128 of the fp32 LDS activation tile as the other modes, split on the way in:
+//     4 v_cvt_pk_f16_f32 (hi), 8 v_fma_mix_f32 (x - hi, the fp16 operand converted by the instruction), 4 v_cvt_pk
+//     (lo): 16 VALU operations per macro step.  Gradient tiles are scaled by a power of two first (mac_s): their
+//     elements sit far below fp16's normal range (2^-14).  a_scale(m) = 2^(10 - exponent of m), m the largest
+//     magnitude the tile can hold; below 2^-25 of that an element contributes its hi part only (fixed point).
+//   Accumulators come out as 2^8 a_scale times the product: every epilogue multiplies by kOut / a_scale (exact).
+// Range: forward activations go in unscaled, |x| < 65504 (fp16's largest number; beyond that the split is inf - inf
+// = NaN and the poison reaches every output: loud, not silent).
+// ---------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned x2u4 __attribute__((ext_vector_type(4)));
+struct FragX2 { f32x4 hi, lo; };
+
+// x - (float)half of a packed pair, the conversion folded into the FMA (v_fma_mix_f32: operand 0 read as fp16)
+__device__ __forceinline__ float x2_res_lo(float x, unsigned hp) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float x2_res_hi(float x, unsigned hp) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(x));
+  return r;
+}
+__device__ __forceinline__ void x2_split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
+  const f32x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  hi = __builtin_convertvector(v, f16x8);
+  const x2u4 hp = __builtin_bit_cast(x2u4, hi);
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r[2 * i] = x2_res_lo(v[2 * i], hp[i]);
+    r[2 * i + 1] = x2_res_hi(v[2 * i + 1], hp[i]);
+  }
+  lo = __builtin_convertvector(r, f16x8);
+}
+
+struct PrecX2 {
+  static constexpr int KS = 32;
+  static constexpr bool kBf16 = false;
+  static constexpr bool kX2 = true;
+  typedef FragX2 Frag;
+  static constexpr int kBlk = 512;
+  static constexpr float kWScale = 256.f;            // the packs hold 2^8 w
+  static constexpr float kOut = 1.f / 256.f;
+  // forward activations are scaled by 2^4 on the way in: full 22 bits for |x| >= 2^-7, an absolute floor of 2^-29
+  // below, |x| < 4094
+  static constexpr float kFwdA = 16.f;
+  __device__ static __forceinline__ Frag ldf(const float* p) { return FragX2{ld4(p), ld4(p + 256)}; }
+  __device__ static __forceinline__ Frag zf() { return FragX2{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}; }
+  __device__ static __forceinline__ void mma3(const f32x4 x0, const f32x4 x1, const Frag& b, f32x4& acc) {
+    f16x8 ah, al;
+    x2_split8(x0, x1, ah, al);
+    const f16x8 bh = __builtin_bit_cast(f16x8, b.hi), bl = __builtin_bit_cast(f16x8, b.lo);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+  }
+  __device__ static __forceinline__ void mac(const float* xr, int s, const Frag& b, f32x4& acc) {
+    mma3(ld4(xr + 32 * s), ld4(xr + 32 * s + 16), b, acc);
+  }
+  __device__ static __forceinline__ void mac_s(const float* xr, int s, const Frag& b, f32x4& acc, float sc) {
+    mma3(ld4(xr + 32 * s) * sc, ld4(xr + 32 * s + 16) * sc, b, acc);
+  }
+  // (the upper half of the last step may lie beyond the LDS tile's row: read only when fp32-size step 2s + 1 exists)
+  __device__ static __forceinline__ void mac_tail_s(const float* xr, int s, const Frag& b, f32x4& acc, int k16, float sc) {
+    const f32x4 lo = ld4(xr + 32 * s);
+    const f32x4 hi = (2 * s + 1 < k16) ? ld4(xr + 32 * s + 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    mma3(lo * sc, hi * sc, b, acc);
+  }
+  // 2^(10 - e) for m in [2^e, 2^(e+1)); 1 for m = 0 (an all-zero tile)
+  __device__ static __forceinline__ float a_scale(float m) {
+    const unsigned e = (__float_as_uint(m) >> 23) & 0xffu;
+    return e == 0u ? 1.f : __uint_as_float((unsigned)(127 + 10 + 127 - (int)e) << 23);
+  }
+  // the first matrix element of a fragment block (pointer at the lane's hi quad)
+  __device__ static __forceinline__ float first(const float* frag) {
+    const unsigned h = *reinterpret_cast<const unsigned*>(frag) & 0xffffu, l = *reinterpret_cast<const unsigned*>(frag + 256) & 0xffffu;
+    return ((float)__builtin_bit_cast(_Float16, (unsigned short)h) + (float)__builtin_bit_cast(_Float16, (unsigned short)l)) * kOut;
   }
 };
 

@@ -37,6 +37,7 @@
 // (tests/test_gpu_fused.py).  The minibatch either comes from caller pointers
 // (update()) or is gathered in-kernel from the HBM replay with the same Philox
 // draw and index map as k_replay_gather (step_n).
+#include <cstddef>
 #include "kernels.h"
 #include "philox.h"
 #include "replay_index.h"
@@ -260,16 +261,12 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
 template <int WIDTH, bool LEAN, bool SAC, class P, bool WIDE = false, bool MERGED = false>
 __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const DwKArgs* D = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (A.prefetch_p1 && blockIdx.y == gridDim.y - 1) {
-    // the next update's rows (dispatched last: these workgroups start as roles retire), into the other staging set
-    PrefetchJob J;
-    J.next = A.next; J.S = A.S; J.A = A.A; J.B = A.B; J.z0 = 0;
-    prefetch_rows_body(J, (int)blockIdx.x, smem);
-    return;
-  }
+  // the last grid row of a step_n launch may be the PREFETCH row: the next update's rows (dispatched last: these
+  // workgroups start as roles retire) into the other staging set — the same load_batch call as the roles', from A.next
+  const bool pf_row = A.prefetch_p1 && blockIdx.y == gridDim.y - 1;
   if constexpr (MERGED) {
     const int rows = (2 + A.n_critics) * A.nc + ((LEAN && WIDE) ? 4 : 0);
-    if ((int)blockIdx.y >= rows) {
+    if ((int)blockIdx.y >= rows && !pf_row) {
       if (threadIdx.x >= kDwThreads) return;      // a tile workgroup is the first 8 waves (the stand-alone kernel's shape and arithmetic)
       const int tile = ((int)blockIdx.y - rows) * (int)gridDim.x + (int)blockIdx.x;
       if (tile >= D->tile_end[kDwMaxItems - 1]) return;
@@ -334,7 +331,26 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const DwKArg
     ++n_stamp;
   };
   stamp();   // entry
-  load_batch(A.src, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
+  // (both sources live in the kernel-argument segment, this block at its start: addressed through the segment pointer
+  // they are read with scalar loads — `pf_row ? &A.next : &A.src` makes hipcc copy the block to scratch; the group
+  // kernels, whose blocks sit in device memory, never carry a prefetch row)
+  const BatchSrc* srcp = &A.src;
+  if (pf_row) srcp = (const BatchSrc*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(DdpgArgs, next));
+  load_batch(*srcp, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
+  if (pf_row) {
+    __syncthreads();
+    store_rows(xa, kX0Ld, const_cast<float*>(A.next.s), S, S, row0, B);
+    store_rows(xb, kX0Ld, const_cast<float*>(A.next.s2), S, S, row0, B);
+    for (int idx = tid; idx < kR * Ad; idx += kThreads) {
+      const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
+      if (gr < B) const_cast<float*>(A.next.a)[(size_t)gr * Ad + col] = xa[row * kX0Ld + S + col];
+    }
+    if (tid < kR && row0 + tid < B) {
+      const_cast<float*>(A.next.r)[row0 + tid] = rS[tid];
+      const_cast<float*>(A.next.d)[row0 + tid] = dS[tid];
+    }
+    return;
+  }
   stamp();   // batch rows requested
   const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
   // twin_split (TD3 / SAC, all four roles co-resident): role A evaluates target critic 1 only; the
@@ -364,10 +380,10 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const DwKArg
         }
         store_rows(xa, kX0Ld, A.aX[0], A.aldx0, S, row0, B);
         // merged phase 2: its tiles rewrite the actor's output layer while other tiles still want the OLD one
-        // (dz2 = du W3): one copy of the layer's forward pack (16 KB) for them, taken here
+        // (dz2 = du W3): one copy of the layer (A x 256 floats of the row-major master) for them, taken here
         if ((A.merged & 2) != 0 && slice == 0)
-          for (int idx = tid * 4; idx < 16 * 256; idx += kThreads * 4)
-            *reinterpret_cast<f32x4*>(A.w3_snap + idx) = ld4(A.actor.pf[2] + idx);
+          for (int idx = tid * 4; idx < Ad * kW4; idx += kThreads * 4)
+            *reinterpret_cast<f32x4*>(A.w3_snap + idx) = ld4(A.w3_src + idx);
       }
       stamp();
     }
@@ -823,6 +839,7 @@ struct RoleULds {   // floats
   static constexpr int total = out + kWaves * 256;
 };
 
+template <class P>
 __device__ __forceinline__ void role_u(const DdpgArgs& A, float* smem, int slice, int c) {
   float* Wl = smem + RoleULds::w;
   float* h2s = smem + RoleULds::h2;
@@ -849,7 +866,8 @@ __device__ __forceinline__ void role_u(const DdpgArgs& A, float* smem, int slice
   const int hr = tid >> 6, hc = (tid & 63) * 4;
   f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};
   if (row0 + hr < B) hv = ld4(A.aX[2] + (size_t)(row0 + hr) * kW4 + hc);
-  const f32x4 w3q = ld4(A.w3_snap + (size_t)tid * 4);     // pack element (s = tid >> 6, lane = tid & 63): W3[lane & 15][16 s + 4 (lane >> 4) + t]
+  f32x4 w3q = f32x4{0.f, 0.f, 0.f, 0.f};                  // W3[tid >> 6][4 (tid & 63) ..]: rows beyond A stay zero
+  if ((tid >> 6) < Ad) w3q = ld4(A.w3_snap + (size_t)tid * 4);
   const int t1 = wave & 1, j = wave >> 1;                  // this wave: tile t1 of the member, unit seed j
   float m1[4];
 #pragma unroll
@@ -860,11 +878,7 @@ __device__ __forceinline__ void role_u(const DdpgArgs& A, float* smem, int slice
 #pragma unroll
   for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(Wl + ((size_t)q * kThreads + tid) * 4) = wv[q];
   *reinterpret_cast<f32x4*>(h2s + hr * kWL4 + hc) = hv;
-  {
-    const int jj = lane & 15;
-    if (jj < kDuLd)
-      *reinterpret_cast<f32x4*>(w3s + jj * 256 + 16 * (tid >> 6) + 4 * (lane >> 4)) = jj < Ad ? w3q : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+  if (tid < kDuLd * 64) *reinterpret_cast<f32x4*>(w3s + (size_t)tid * 4) = w3q;
   __syncthreads();
   // everything this role reads of the actor is in LDS: the tiles of this launch may rewrite the actor's packs
   if (tid == 0)
@@ -874,16 +888,38 @@ __device__ __forceinline__ void role_u(const DdpgArgs& A, float* smem, int slice
     f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;   // even / odd steps: two MFMA chains
     const float* hrow = h2s + i * kWL4 + 4 * kk;
     const float* w0 = w3s + j * 256 + 4 * kk;
-    const float* bw = Wl + ((size_t)t1 * 16 * 64 + lane) * 4;
+    if constexpr (P::kX2) {
+      // the shard is [2 tiles][8 macro steps][hi 256 | lo 256 floats]; the masked output-layer row goes in scaled by
+      // 2^12 (|w3| < 16), as the unit-seed tiles of tp4_scalar_fb do
+      constexpr float sb = 4096.f;
+      const float* bw = Wl + (size_t)t1 * 8 * 512 + lane * 4;
 #pragma unroll
-    for (int s = 0; s < 16; s += 2) {
-      const f32x4 b0 = ld4(bw + s * 256), b1 = ld4(bw + (s + 1) * 256);
-      const f32x4 h0 = ld4(hrow + 16 * s), h1v = ld4(hrow + 16 * (s + 1));
-      const f32x4 x0 = ld4(w0 + 16 * s), x1 = ld4(w0 + 16 * (s + 1));
+      for (int s = 0; s < 8; ++s) {
+        const FragX2 b{ld4(bw + s * 512), ld4(bw + s * 512 + 256)};
+        const f32x4 h0 = ld4(hrow + 32 * s), h1v = ld4(hrow + 32 * s + 16);
+        f32x4 x0 = ld4(w0 + 32 * s) * sb, x1 = ld4(w0 + 32 * s + 16) * sb;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        a0 = mfma4(h0[t] > 0.f ? x0[t] : 0.f, b0[t], a0);
-        a1 = mfma4(h1v[t] > 0.f ? x1[t] : 0.f, b1[t], a1);
+        for (int t = 0; t < 4; ++t) {
+          x0[t] = h0[t] > 0.f ? x0[t] : 0.f;
+          x1[t] = h1v[t] > 0.f ? x1[t] : 0.f;
+        }
+        if (s & 1) PrecX2::mma3(x0, x1, b, a1);
+        else PrecX2::mma3(x0, x1, b, a0);
+      }
+      a0 = (a0 + a1) * (PrecX2::kOut / sb);
+      a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      const float* bw = Wl + ((size_t)t1 * 16 * 64 + lane) * 4;
+#pragma unroll
+      for (int s = 0; s < 16; s += 2) {
+        const f32x4 b0 = ld4(bw + s * 256), b1 = ld4(bw + (s + 1) * 256);
+        const f32x4 h0 = ld4(hrow + 16 * s), h1v = ld4(hrow + 16 * (s + 1));
+        const f32x4 x0 = ld4(w0 + 16 * s), x1 = ld4(w0 + 16 * (s + 1));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          a0 = mfma4(h0[t] > 0.f ? x0[t] : 0.f, b0[t], a0);
+          a1 = mfma4(h1v[t] > 0.f ? x1[t] : 0.f, b1[t], a1);
+        }
       }
     }
     // lane (kk, i): rows 4 kk + r, column 32 c + 16 t1 + i of unit seed j -> through wave-private LDS -> U[tile][j][row][16]
@@ -921,7 +957,7 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const DwKAr
     dw_adam_body<false, 2, 16>(*D, smem, tile);
     return;
   }
-  if (y >= NMC && y < yP) { role_u(A, smem, slice, y - NMC); return; }
+  if (y >= NMC && y < yP) { role_u<P>(A, smem, slice, y - NMC); return; }
   float* xa = smem + LY::xa;
   if (y == yP) {
     // ---- prefetch row: the next update's rows (as in ddpg_phase2_body)
@@ -1017,33 +1053,34 @@ size_t fused_ddpg_lds_bytes() { return sizeof(float) * FusedLds<256>::total; }
 size_t fused_xbuf_granules_per_cluster(int nc) { return (size_t)kTpStages * nc * kTpBlk; }
 
 hipError_t init_fused_attrs() {
-  const void* ks[10] = {reinterpret_cast<const void*>(&k_ddpg_phase1<256, false, false>),
-                        reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, false>),
-                        reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, true>),
-                        reinterpret_cast<const void*>(&k_ddpg_phase2<256, false, false>),
-                        reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false>),
-                        reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, true>),
-                        reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, false, PrecBF16>),
-                        reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, true, PrecBF16>),
-                        reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false, PrecBF16>),
-                        reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, true, PrecBF16>)};
+  const void* ks[] = {reinterpret_cast<const void*>(&k_ddpg_phase1<256, false, false>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, false>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, true>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2<256, false, false>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, true>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, false, PrecBF16>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, true, PrecBF16>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false, PrecBF16>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, true, PrecBF16>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, false, PrecX2>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, true, PrecX2>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false, PrecX2>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, true, PrecX2>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_group<256, false, false>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2_group<256, false, false>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, false, PrecF32, true>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false, PrecF32, true>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, false, PrecX2, true>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false, PrecX2, true>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecF32>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecBF16>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecX2>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecF32, true>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecF32, false>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecX2, true>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecX2, false>)};
   for (const void* k : ks) {
-    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-  }
-  const void* kg[6] = {reinterpret_cast<const void*>(&k_ddpg_phase1_group<256, false, false>),
-                       reinterpret_cast<const void*>(&k_ddpg_phase2_group<256, false, false>),
-                       reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, false, PrecF32, true>),
-                       reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false, PrecF32, true>),
-                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecF32>),
-                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecBF16>)};
-  const void* km[2] = {reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecF32, true>),
-                       reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecF32, false>)};
-  for (const void* k : km) {
-    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-  }
-  for (const void* k : kg) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
   }
@@ -1079,11 +1116,11 @@ bool fused_ddpg_is_lean(const DdpgArgs& a) {
 // that launch with its gate filled in)
 hipError_t launch_ddpg_phase1_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st) {
   if (!lean_ok(a) || a.sac || a.n_critics != 1 || (a.wide & 1) != 0 || (a.merged & 1) == 0) return hipErrorInvalidValue;
-  static_assert(sizeof(DdpgArgs) % alignof(DwKArgs) == 0 || true, "");
   const int slices = (a.B + kR - 1) / kR;
   const int tiles = d.tile_end[kDwMaxItems - 1];
   const dim3 grid(slices, 3 * a.nc + (tiles + slices - 1) / slices + (a.prefetch_p1 ? 1 : 0));
-  if (a.bf16) hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
+  if (a.x2) hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
+  else if (a.bf16) hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
   else hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecF32>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
   return hipGetLastError();
 }
@@ -1097,57 +1134,75 @@ hipError_t launch_ddpg_phase2_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_
   const bool wide = (a.wide & 2) != 0;
   if (wide && a.xnc < 8) return hipErrorInvalidValue;
   const dim3 grid(slices, (wide ? 8 : 4) + kUMembers + (a.prefetch_next ? 1 : 0) + (tiles + slices - 1) / slices);
-  if (wide) hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecF32, true>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
-  else hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecF32, false>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
+  const dim3 blk(kThreads);
+  const size_t lds = fused_ddpg_lds_bytes();
+  if (a.x2) {
+    if (wide) hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecX2, true>), grid, blk, lds, st, a, d);
+    else hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecX2, false>), grid, blk, lds, st, a, d);
+  } else {
+    if (wide) hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecF32, true>), grid, blk, lds, st, a, d);
+    else hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecF32, false>), grid, blk, lds, st, a, d);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
-  if ((a.wide & 1) != 0) {      // role A on clusters of 8 (DDPG, fp32 lean passes; learner.hip decides)
+  const dim3 blk(kThreads);
+  const size_t lds = fused_ddpg_lds_bytes();
+  const int pf = a.prefetch_p1 ? 1 : 0;
+  if ((a.wide & 1) != 0) {      // role A on clusters of 8 (DDPG, lean passes; learner.hip decides)
     if (!lean_ok(a) || a.sac || a.bf16 || a.n_critics != 1 || a.xnc < 8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_ddpg_phase1<256, true, false, PrecF32, true>), dim3(slices, a.nc + 8 + a.nc + (a.prefetch_p1 ? 1 : 0)), dim3(kThreads),
-                       fused_ddpg_lds_bytes(), st, a);
+    const dim3 grid(slices, a.nc + 8 + a.nc + pf);
+    if (a.x2) hipLaunchKernelGGL((k_ddpg_phase1<256, true, false, PrecX2, true>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((k_ddpg_phase1<256, true, false, PrecF32, true>), grid, blk, lds, st, a);
     return hipGetLastError();
   }
-  const dim3 grid(slices, (2 + a.n_critics) * a.nc + (a.prefetch_p1 ? 1 : 0));
-  if (a.bf16) {
-    // the bf16 MFMA mode exists for the lean passes only; the nets' pf / pb point at bf16 packs
+  const dim3 grid(slices, (2 + a.n_critics) * a.nc + pf);
+  if (a.bf16 || a.x2) {
+    // the 16-bit MFMA modes exist for the lean passes only; the nets' pf / pb point at bf16 / two-plane fp16 packs
     if (!lean_ok(a)) return hipErrorInvalidValue;
-    if (a.sac) hipLaunchKernelGGL((k_ddpg_phase1<256, true, true, PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
-    else hipLaunchKernelGGL((k_ddpg_phase1<256, true, false, PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+    if (a.x2 && a.sac) hipLaunchKernelGGL((k_ddpg_phase1<256, true, true, PrecX2>), grid, blk, lds, st, a);
+    else if (a.x2) hipLaunchKernelGGL((k_ddpg_phase1<256, true, false, PrecX2>), grid, blk, lds, st, a);
+    else if (a.sac) hipLaunchKernelGGL((k_ddpg_phase1<256, true, true, PrecBF16>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((k_ddpg_phase1<256, true, false, PrecBF16>), grid, blk, lds, st, a);
   } else if (a.sac) {
     if (!lean_ok(a)) return hipErrorInvalidValue;   // SAC is fused in the lean form only (use_fused() checks)
-    hipLaunchKernelGGL((k_ddpg_phase1<256, true, true>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+    hipLaunchKernelGGL((k_ddpg_phase1<256, true, true>), grid, blk, lds, st, a);
   } else if (lean_ok(a)) {
-    hipLaunchKernelGGL((k_ddpg_phase1<256, true, false>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+    hipLaunchKernelGGL((k_ddpg_phase1<256, true, false>), grid, blk, lds, st, a);
   } else {
-    hipLaunchKernelGGL((k_ddpg_phase1<256, false, false>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+    hipLaunchKernelGGL((k_ddpg_phase1<256, false, false>), grid, blk, lds, st, a);
   }
   return hipGetLastError();
 }
 
 hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st) {
   const int slices = (a.B + kR - 1) / kR;
+  const dim3 blk(kThreads);
+  const size_t lds = fused_ddpg_lds_bytes();
   // SAC side by side: one cluster per online critic; + the next-minibatch gather row
-  if ((a.wide & 2) != 0) {      // the critic pass on clusters of 8 (DDPG / TD3, fp32 lean passes)
+  if ((a.wide & 2) != 0) {      // the critic pass on clusters of 8 (DDPG / TD3, lean passes)
     if (!lean_ok(a) || a.sac || a.bf16 || a.xnc < 8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_ddpg_phase2<256, true, false, PrecF32, true>), dim3(slices, 8 + (a.prefetch_next ? 1 : 0)),
-                       dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+    const dim3 grid(slices, 8 + (a.prefetch_next ? 1 : 0));
+    if (a.x2) hipLaunchKernelGGL((k_ddpg_phase2<256, true, false, PrecX2, true>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((k_ddpg_phase2<256, true, false, PrecF32, true>), grid, blk, lds, st, a);
     return hipGetLastError();
   }
   const dim3 grid(slices, a.nc * ((a.sac && a.p2_pair) ? 2 : 1) + (a.prefetch_next ? 1 : 0));
-  if (a.bf16) {
+  if (a.bf16 || a.x2) {
     if (!lean_ok(a)) return hipErrorInvalidValue;
-    if (a.sac) hipLaunchKernelGGL((k_ddpg_phase2<256, true, true, PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
-    else hipLaunchKernelGGL((k_ddpg_phase2<256, true, false, PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+    if (a.x2 && a.sac) hipLaunchKernelGGL((k_ddpg_phase2<256, true, true, PrecX2>), grid, blk, lds, st, a);
+    else if (a.x2) hipLaunchKernelGGL((k_ddpg_phase2<256, true, false, PrecX2>), grid, blk, lds, st, a);
+    else if (a.sac) hipLaunchKernelGGL((k_ddpg_phase2<256, true, true, PrecBF16>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((k_ddpg_phase2<256, true, false, PrecBF16>), grid, blk, lds, st, a);
   } else if (a.sac) {
     if (!lean_ok(a)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_ddpg_phase2<256, true, true>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+    hipLaunchKernelGGL((k_ddpg_phase2<256, true, true>), grid, blk, lds, st, a);
   } else if (lean_ok(a)) {
-    hipLaunchKernelGGL((k_ddpg_phase2<256, true, false>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+    hipLaunchKernelGGL((k_ddpg_phase2<256, true, false>), grid, blk, lds, st, a);
   } else {
-    hipLaunchKernelGGL((k_ddpg_phase2<256, false, false>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a);
+    hipLaunchKernelGGL((k_ddpg_phase2<256, false, false>), grid, blk, lds, st, a);
   }
   return hipGetLastError();
 }

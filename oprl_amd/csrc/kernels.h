@@ -92,6 +92,7 @@ struct DwItem {      // one Linear layer of one net
   float *b, *b_t, *b_m, *b_v, *b_g;    // [N]
   float *pf, *pb, *tpf;                // fragment-order packs: W (fwd), W^T (bwd), target W (fwd)
   float *pf16, *pb16, *tpf16;          // the same three as bf16 packs (PrecBF16, engine.h), or null: fp32-only learner
+  int x2;                              // 1: those three are PrecX2 packs (blocks of two fp16 planes, 2^8 w)
   int tiles_k, tile_begin, tile_end;
   int tile_n;                          // n rows per tile: kDwTileN, or 8 for a layer that sums dz1 partials
   long dY_part_stride;                 // > 0: dY is the sum of DwArgs::n_part buffers this many floats apart
@@ -103,6 +104,7 @@ struct RepackItem {  // one Linear layer: master -> packs
   const float* w; int N, K;
   float *pf, *pb;    // pb may be null (target nets are never differentiated)
   float *pf16, *pb16; // bf16 packs (bf16 learners), or null
+  int x2;             // 1: those are PrecX2 packs (two fp16 planes per block, 2^8 w)
   int blk_begin, blk_end;   // 256-element blocks of the N*K index space
 };
 
@@ -202,6 +204,7 @@ struct DwArgs {                         // host-side description of one k_dw_ada
   AdamScalars ad;
   long long* trace;                    // debug stamps (tools/trace_slice.py) or null
   int use_row_scale;                   // 1: the slice kernels left unit-seed dz rows (lean fused path)
+  int skip32 = 0;                      // 1: do not write the fp32 packs (pf / pb / tpf): a PrecX2 learner's fused update, whose kernels read the fp16 packs only
   int apply_only;                      // 1: no GEMM — the gradient is read from w_g / b_g (data-parallel apply after the all-reduce)
   const DwXchg* xchg = nullptr;       // data-parallel: all-reduce every gradient tile over the peer windows inside this launch
   AlphaJob alpha;                      // optional: the temperature step rides on this launch (one more workgroup)
@@ -234,7 +237,7 @@ struct DwGate {
   int kind[4] = {0, 0, 0, 0};          // per item of the launch
   const unsigned long long* read = nullptr; int n_read = 0;   // role U has taken in what it reads of the actor's packs: only then may a tile's epilogue rewrite them
   const float* h2 = nullptr;           // [B][256] the actor's second hidden activations (written by the launch before)
-  const float* w3 = nullptr;           // the output layer's forward pack as it was BEFORE this launch (16 steps x 256 floats)
+  const float* w3 = nullptr;           // the output layer [A][256] (row-major) as it was BEFORE this launch
   const float* U = nullptr;
   int n_act = 0;
 };
@@ -322,6 +325,7 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   int gran_stride;
   unsigned epoch;                      // monotonically increasing per update, never 0
   int bf16;                            // 1: the nets' pf / pb are bf16 packs and the lean passes run PrecBF16 (engine.h)
+  int x2;                              // 1: ... are PrecX2 packs (two fp16 planes) and the lean passes run PrecX2
   int nc;                              // CUs per slice cluster (tensor-parallel, csrc/tp3.h): 1, 2 or 4
   int xnc;                             // members an exchange area of `xbuf` is laid out for (>= nc; 8 when wide clusters may run)
   int wide;                            // bit 0: phase 1's role A, bit 1: phase 2's critic pass on clusters of EIGHT (fp32 lean passes)
@@ -337,7 +341,8 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   unsigned long long* du_granules;     // [B][kDuLd] {epoch, du}
   unsigned long long* u_flags;         // [0, 128): role U's members have written their rows through; [128, 256): ... have read the actor's packs
   float* U;                            // [16][A][B][16] unit-seed dz1 of the actor (role U -> first-layer tiles)
-  float* w3_snap;                      // the actor's output-layer forward pack, copied by phase 1's role C (slice 0)
+  float* w3_snap;                      // the actor's output layer [A][256] as it is before phase 2, copied by phase 1's role C (slice 0)
+  const float* w3_src;                 // ... from here (the row-major master)
   int no_lean;                         // 1: never use the tp4.h specialisation (OPRL_AMD_NO_LEAN, tests)
   unsigned long long* xbuf;            // cluster exchange areas: [role][slice][kTpStages][nc][kTpBlk] granules
   unsigned cluster_tag;                // launch-unique

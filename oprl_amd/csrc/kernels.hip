@@ -248,6 +248,21 @@ __global__ void k_repack(const RepackItem* items, int n_items) {
   const float w = I.w[e];
   if (I.pf != nullptr) I.pf[pack_index(n, k, cdiv(I.K, 16))] = w;
   if (I.pb != nullptr) I.pb[pack_index(k, n, cdiv(I.N, 16))] = w;
+  if (I.x2) {   // PrecX2 packs: blocks of two fp16 planes (hi | lo), 2^8 w
+    const float ws = w * PrecX2::kWScale;
+    const _Float16 hi = (_Float16)ws, lo = (_Float16)(ws - (float)hi);
+    if (I.pf16 != nullptr) {
+      const long e16 = pack16_index(n, k, cdiv(I.K, 32));
+      _Float16* d = reinterpret_cast<_Float16*>(I.pf16) + (e16 >> 9) * 1024 + (e16 & 511);
+      d[0] = hi; d[512] = lo;
+    }
+    if (I.pb16 != nullptr) {
+      const long e16 = pack16_index(k, n, cdiv(I.N, 32));
+      _Float16* d = reinterpret_cast<_Float16*>(I.pb16) + (e16 >> 9) * 1024 + (e16 & 511);
+      d[0] = hi; d[512] = lo;
+    }
+    return;
+  }
   if (I.pf16 != nullptr) reinterpret_cast<__bf16*>(I.pf16)[pack16_index(n, k, cdiv(I.K, 32))] = (__bf16)w;
   if (I.pb16 != nullptr) reinterpret_cast<__bf16*>(I.pb16)[pack16_index(k, n, cdiv(I.N, 32))] = (__bf16)w;
 }
@@ -324,6 +339,8 @@ int fill_dw_kargs(const DwArgs& a, DwKArgs* k) {
     k->tile_end[j] = total;
   }
   for (int j = a.n_items; j < kDwMaxItems; ++j) { k->items[j] = a.items[0]; k->tile_end[j] = total; }
+  if (a.skip32)
+    for (int j = 0; j < kDwMaxItems; ++j) { k->items[j].pf = nullptr; k->items[j].pb = nullptr; k->items[j].tpf = nullptr; }
   k->n_items = a.n_items; k->B = a.B; k->n_part = a.n_part; k->dy_tiled = a.dy_tiled; k->ad = a.ad; k->trace = a.trace;
   k->use_row_scale = a.use_row_scale; k->one = dw_one_dev();
   k->apply_only = a.apply_only;
@@ -375,6 +392,8 @@ hipError_t launch_dw_adam(const DwArgs& a0, hipStream_t st) {
     k.tile_end[j] = total;
   }
   for (int j = a.n_items; j < kDwMaxItems; ++j) { k.items[j] = a.items[0]; k.tile_end[j] = total; }
+  if (a.skip32)
+    for (int j = 0; j < kDwMaxItems; ++j) { k.items[j].pf = nullptr; k.items[j].pb = nullptr; k.items[j].tpf = nullptr; }
   k.n_items = a.n_items; k.B = a.B; k.n_part = a.n_part; k.dy_tiled = a.dy_tiled; k.ad = a.ad; k.trace = a.trace;
   k.use_row_scale = a.use_row_scale; k.one = one_dev;
   k.apply_only = a.apply_only;

@@ -6,6 +6,7 @@
 // loss sees the post-Adam critic, Polyak sees both updated nets):
 //   DDPG  algos/ddpg.py:61-107      TD3  algos/td3.py:71-146
 //   SAC   algos/sac.py:75-155       TQC  algos/tqc.py:116-189
+#include <algorithm>
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -283,13 +284,14 @@ long pack_off_bwd(const oprl_net& n, int l) { return pack_off_fwd(n, l) + pack_f
 long net_pack_floats(const oprl_net& n) { return pack_off_fwd(n, n.n_layers); }
 
 // the same for the bf16 packs (library-owned, oprl_learner::pack16 / pack16_t), in floats (16-byte fragments)
-long pack16_off_fwd(const oprl_net& n, int l) {
+// (pl = fp16 / bf16 planes per block: 1 for the bf16 packs, 2 for the PrecX2 packs — hi | lo)
+long pack16_off_fwd(const oprl_net& n, int l, int pl = 1) {
   long c = 0;
-  for (int j = 0; j < l; ++j) c += pack16_floats(n.dims[j + 1], n.dims[j]) + pack16_floats(n.dims[j], n.dims[j + 1]);
+  for (int j = 0; j < l; ++j) c += pl * (pack16_floats(n.dims[j + 1], n.dims[j]) + pack16_floats(n.dims[j], n.dims[j + 1]));
   return c;
 }
-long pack16_off_bwd(const oprl_net& n, int l) { return pack16_off_fwd(n, l) + pack16_floats(n.dims[l + 1], n.dims[l]); }
-long net_pack16_floats(const oprl_net& n) { return pack16_off_fwd(n, n.n_layers); }
+long pack16_off_bwd(const oprl_net& n, int l, int pl = 1) { return pack16_off_fwd(n, l, pl) + pl * pack16_floats(n.dims[l + 1], n.dims[l]); }
+long net_pack16_floats(const oprl_net& n, int pl = 1) { return pack16_off_fwd(n, n.n_layers, pl); }
 
 Net net_view(const oprl_net& n, bool target) {
   Net v;
@@ -310,11 +312,11 @@ Net net_view(const oprl_net& n, bool target) {
 constexpr int kMaxCluster = 4;   // CUs per tensor-parallel slice cluster (csrc/tp3.h)
 
 // a Net whose pf / pb point at the bf16 packs (for the PrecBF16 kernels only)
-Net net_view16(const oprl_net& n, bool target, const float* pk16) {
+Net net_view16(const oprl_net& n, bool target, const float* pk16, int pl = 1) {
   Net v = net_view(n, target);
   for (int l = 0; l < n.n_layers; ++l) {
-    v.pf[l] = pk16 + pack16_off_fwd(n, l);
-    v.pb[l] = pk16 + pack16_off_bwd(n, l);
+    v.pf[l] = pk16 + pack16_off_fwd(n, l, pl);
+    v.pb[l] = pk16 + pack16_off_bwd(n, l, pl);
   }
   return v;
 }
@@ -460,6 +462,12 @@ struct oprl_learner {
   unsigned* err_dev = nullptr;
   int debug_expire = 0;        // test hook (oprl_learner_debug_expire): this wait site gives up at once
   bool bf16 = false;
+  bool x2 = false;             // OPRL_PREC_X2: the lean fused kernels run PrecX2 (engine.h) from packs of two fp16 planes, kept in pack16 / pack16_t
+  int planes = 1;              // fp16 / bf16 planes per block of those packs
+  // PrecX2 learners: the fused updates do not write the fp32 packs (nothing of theirs reads them); whoever does —
+  // the nets' own forward (oprl_mlp_forward / act / backward), a generic launch sequence — gets them rebuilt from the
+  // master first (fresh32): [0] the critics' (online + target), [1] the actor's
+  bool stale32[2] = {false, false};
   float* pack16[OPRL_MAX_CRITICS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   float* pack16_t[OPRL_MAX_CRITICS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // prebuilt device repack tables: [0] critics online, [1] critics online+target, [2] actor (+target)
@@ -469,8 +477,40 @@ struct oprl_learner {
 
 namespace {
 
+// learners with lazily maintained fp32 packs, by pack pointer (oprl_mlp_* know a net, not its learner)
+std::mutex g_lazy_mu;
+std::vector<oprl_learner*> g_lazy;
+
+int fresh32_tables(oprl_learner* h, int which /* bit 0 critics, bit 1 actor */, hipStream_t st) {
+  if ((which & 1) && h->stale32[0]) {
+    HIPC(launch_repack(h->rp_dev[1], h->rp_n[1], h->rp_blocks[1], st));
+    h->stale32[0] = false;
+  }
+  if ((which & 2) && h->stale32[1]) {
+    HIPC(launch_repack(h->rp_dev[2], h->rp_n[2], h->rp_blocks[2], st));
+    h->stale32[1] = false;
+  }
+  return OPRL_OK;
+}
+
+// before a launch that reads `net`'s fp32 packs outside its learner's fused kernels
+int fresh32(const oprl_net* net, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_lazy_mu);
+  for (oprl_learner* h : g_lazy) {
+    if (!h->stale32[0] && !h->stale32[1]) continue;
+    // (a target module of the Python host is a net of its own whose pack IS the learner's target pack)
+    auto same = [&](const oprl_net& n) {
+      return net->pack == n.pack || (n.pack_target != nullptr && (net->pack == n.pack_target || net->pack_target == n.pack_target));
+    };
+    if (same(h->cfg.actor)) return fresh32_tables(h, 2, st);
+    for (int j = 0; j < h->nc; ++j)
+      if (same(h->cfg.critics[j])) return fresh32_tables(h, 1, st);
+  }
+  return OPRL_OK;
+}
+
 void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int* tiles, bool small_partial_tiles = false,
-                float* pk16 = nullptr, float* pk16_t = nullptr) {
+                float* pk16 = nullptr, float* pk16_t = nullptr, int pl = 1) {
   for (int l = 0; l < n.n_layers; ++l) {
     DwItem it;
     memset(&it, 0, sizeof it);
@@ -490,9 +530,10 @@ void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int*
     it.pf = n.pack + pack_off_fwd(n, l);
     it.pb = n.pack + pack_off_bwd(n, l);
     it.tpf = n.pack_target ? n.pack_target + pack_off_fwd(n, l) : nullptr;
-    it.pf16 = pk16 ? pk16 + pack16_off_fwd(n, l) : nullptr;
-    it.pb16 = pk16 ? pk16 + pack16_off_bwd(n, l) : nullptr;
-    it.tpf16 = (pk16_t && n.theta_target) ? pk16_t + pack16_off_fwd(n, l) : nullptr;
+    it.pf16 = pk16 ? pk16 + pack16_off_fwd(n, l, pl) : nullptr;
+    it.pb16 = pk16 ? pk16 + pack16_off_bwd(n, l, pl) : nullptr;
+    it.tpf16 = (pk16_t && n.theta_target) ? pk16_t + pack16_off_fwd(n, l, pl) : nullptr;
+    it.x2 = pl == 2 ? 1 : 0;
     it.dY_part_stride = (l == 0 && n.n_layers > 1) ? ws.dY0_stride : 0;
     it.scaled = (l < n.n_layers - 1) ? 1 : 0;
     it.rs = ws.dY[n.n_layers - 1];
@@ -896,6 +937,18 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   a.partials_c = h->part_c; a.partials_a = h->part_a;
   a.err = h->err_dev;
   a.debug_expire = h->debug_expire;
+  a.w3_src = c.actor.theta + w_off(c.actor, c.actor.n_layers - 1);
+  if (h->x2 && fused_ddpg_is_lean(a)) {     // the PrecX2 instances: every net through its packs of two fp16 planes
+    a.x2 = 1;
+    a.actor = net_view16(c.actor, false, h->pack16[0], 2);
+    if (c.actor.theta_target) a.actor_t = net_view16(c.actor, true, h->pack16_t[0], 2);
+    a.critic = net_view16(c.critics[0], false, h->pack16[1], 2);
+    a.critic_t = net_view16(c.critics[0], true, h->pack16_t[1], 2);
+    if (h->nc == 2) {
+      a.critic2 = net_view16(c.critics[1], false, h->pack16[2], 2);
+      a.critic2_t = net_view16(c.critics[1], true, h->pack16_t[2], 2);
+    }
+  }
   if (h->bf16 && fused_ddpg_is_lean(a)) {   // the PrecBF16 instances of the (lean) phase kernels: every net through its bf16 packs
     a.bf16 = 1;
     a.actor = net_view16(c.actor, false, h->pack16[0]);
@@ -1003,6 +1056,10 @@ DwArgs dw_build(oprl_learner* h, bool critic, int B, bool polyak, bool with_alph
   const bool lean = fused && fused_ddpg_is_lean(ddpg_args(h, B));
   dw.use_row_scale = (critic && lean) ? 1 : 0;
   dw.dy_tiled = (lean && dw.n_part > 1) ? 1 : 0;      // the lean passes leave tile-major dz1 partials
+  if (h->x2 && lean && !c.export_grads) {             // the PrecX2 kernels read the fp16 packs only (fresh32)
+    dw.skip32 = 1;
+    h->stale32[critic ? 0 : 1] = true;
+  }
   return dw;
 }
 
@@ -1061,6 +1118,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
       }
     }
     DdpgArgs fa = ddpg_args(h, B);
+    if (h->x2 && !fa.x2) RC(fresh32_tables(h, 3, st));     // (a batch the lean kernels do not take: fp32 packs)
     fa.noise = noise0;
     if (h->prefetch_p1 && h->prefetch_next) {
       fa.prefetch_p1 = 1;
@@ -1095,6 +1153,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     // TD3 moves its targets only on actor steps (td3.py:135-146)
     return dw_step(h, true, B, c.algo == OPRL_TD3 ? actor_due(h) : true, st);
   }
+  RC(fresh32_tables(h, 3, st));      // (a PrecX2 learner's generic launches read the fp32 packs)
   const int S = h->S, A = h->A, nc = h->nc;
   const int algo = c.algo;
   const int n_slices = (B + kR - 1) / kR;
@@ -1243,6 +1302,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
   const oprl_learner_config& c = h->cfg;
   if (use_fused(h, B)) {
     DdpgArgs fa = ddpg_args(h, B);
+    if (h->x2 && !fa.x2) RC(fresh32_tables(h, 3, st));
     RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &fa.cluster_tag));
     if (h->trace != nullptr && c.algo == OPRL_DDPG) fa.trace = h->trace + (size_t)3 * 64 * kTraceStamps * 2;   // slot 3
     fa.prefetch_next = h->prefetch_p1 ? 0 : h->prefetch_next;
@@ -1304,6 +1364,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     }
     return OPRL_OK;
   }
+  RC(fresh32_tables(h, 3, st));
   const int S = h->S, A = h->A, nc = h->nc;
   const int algo = c.algo;
   const bool gauss = (algo == OPRL_SAC || algo == OPRL_TQC);
@@ -1397,7 +1458,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
 // table goes through a small device scratch; synchronous on `st` only.
 void build_repack_items(const oprl_net* const* nets, int n_nets, int which,
                         std::vector<RepackItem>& items, int* blocks_out,
-                        float* const* pk16 = nullptr, float* const* pk16_t = nullptr) {
+                        float* const* pk16 = nullptr, float* const* pk16_t = nullptr, int pl = 1) {
   int blocks = 0;
   for (int i = 0; i < n_nets; ++i) {
     const oprl_net& n = *nets[i];
@@ -1413,8 +1474,9 @@ void build_repack_items(const oprl_net* const* nets, int n_nets, int which,
         it.pf = pk + pack_off_fwd(n, l);
         it.pb = pass == 0 ? pk + pack_off_bwd(n, l) : nullptr;
         float* p16 = pass == 0 ? (pk16 ? pk16[i] : nullptr) : (pk16_t ? pk16_t[i] : nullptr);
-        it.pf16 = p16 ? p16 + pack16_off_fwd(n, l) : nullptr;
-        it.pb16 = (p16 && pass == 0) ? p16 + pack16_off_bwd(n, l) : nullptr;
+        it.pf16 = p16 ? p16 + pack16_off_fwd(n, l, pl) : nullptr;
+        it.pb16 = (p16 && pass == 0) ? p16 + pack16_off_bwd(n, l, pl) : nullptr;
+        it.x2 = pl == 2 ? 1 : 0;
         it.blk_begin = blocks;
         blocks += (int)(((long)it.N * it.K + 255) / 256);
         it.blk_end = blocks;
@@ -1426,10 +1488,10 @@ void build_repack_items(const oprl_net* const* nets, int n_nets, int which,
 }
 
 int repack_nets(const oprl_net* const* nets, int n_nets, int which, hipStream_t st,
-                float* const* pk16 = nullptr, float* const* pk16_t = nullptr) {
+                float* const* pk16 = nullptr, float* const* pk16_t = nullptr, int pl = 1) {
   std::vector<RepackItem> items;
   int blocks = 0;
-  build_repack_items(nets, n_nets, which, items, &blocks, pk16, pk16_t);
+  build_repack_items(nets, n_nets, which, items, &blocks, pk16, pk16_t, pl);
   if (items.empty()) return OPRL_OK;
   RepackItem* dev = nullptr;
   HIPC(hipMalloc(&dev, sizeof(RepackItem) * items.size()));
@@ -1765,7 +1827,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   if (!cfg || !out) { set_err("oprl_learner_create: null argument"); return OPRL_ERR_INVALID; }
   if (cfg->abi_version != OPRL_ABI_VERSION) { set_err("ABI version mismatch: caller %d, library %d", cfg->abi_version, OPRL_ABI_VERSION); return OPRL_ERR_INVALID; }
   if (cfg->algo < OPRL_DDPG || cfg->algo > OPRL_TQC) { set_err("unknown algo %d", cfg->algo); return OPRL_ERR_INVALID; }
-  if (cfg->precision != OPRL_PREC_F32 && cfg->precision != OPRL_PREC_BF16) { set_err("precision %d unknown", cfg->precision); return OPRL_ERR_INVALID; }
+  if (cfg->precision != OPRL_PREC_F32 && cfg->precision != OPRL_PREC_BF16 && cfg->precision != OPRL_PREC_X2) { set_err("precision %d unknown", cfg->precision); return OPRL_ERR_INVALID; }
   const int nc_expect = cfg->algo == OPRL_DDPG ? 1 : (cfg->algo == OPRL_TQC ? cfg->n_critics : 2);
   if (cfg->n_critics != nc_expect || cfg->n_critics < 1 || cfg->n_critics > OPRL_MAX_CRITICS) {
     set_err("n_critics=%d invalid for algo %d", cfg->n_critics, cfg->algo);
@@ -1776,6 +1838,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   h->cfg = *cfg;
   h->S = cfg->state_dim; h->A = cfg->action_dim; h->Bmax = cfg->max_batch; h->nc = cfg->n_critics;
   h->bf16 = cfg->precision == OPRL_PREC_BF16;
+  h->x2 = cfg->precision == OPRL_PREC_X2;
+  h->planes = h->x2 ? 2 : 1;
   int rc = check_net(cfg->actor, "actor", &h->w_actor);
   for (int j = 0; rc == OPRL_OK && j < h->nc; ++j) {
     int w = 0;
@@ -1844,9 +1908,9 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   const int Bm = B < 256 ? B : 256;             // merged phase 2 serves one 256-row chunk
   const bool merge2_bufs = h->fused && cfg->algo != OPRL_SAC && A <= kDuLd;
   if (merge2_bufs) floats += 2 * ((size_t)Bm * kDuLd + 64) + 2 * 256 + 128 + (size_t)16 * A * Bm * 16 + 16 * 256 + 4 * 64;
-  if (h->bf16) {
-    floats += 2 * ((size_t)net_pack16_floats(cfg->actor) + 64);
-    for (int j = 0; j < nc; ++j) floats += 2 * ((size_t)net_pack16_floats(cfg->critics[j]) + 64);
+  if (h->bf16 || h->x2) {
+    floats += 2 * ((size_t)net_pack16_floats(cfg->actor, h->planes) + 64);
+    for (int j = 0; j < nc; ++j) floats += 2 * ((size_t)net_pack16_floats(cfg->critics[j], h->planes) + 64);
   }
   const size_t bytes = floats * sizeof(float) + 8192 + sizeof(DwItem) * (size_t)(nc + 1) * kMaxLayers +
                        sizeof(RepackItem) * (size_t)(4 * nc + 4) * kMaxLayers;
@@ -1896,19 +1960,19 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   h->br = p.take<float>(B);
   h->bd = p.take<float>(B);
   h->bs2 = p.take<float>((size_t)B * S);
-  if (h->bf16) {   // (the pool is zeroed: pad positions of the packs stay zero for good)
-    h->pack16[0] = p.take<float>((size_t)net_pack16_floats(cfg->actor));
-    h->pack16_t[0] = p.take<float>((size_t)net_pack16_floats(cfg->actor));
+  if (h->bf16 || h->x2) {   // (the pool is zeroed: pad positions of the packs stay zero for good)
+    h->pack16[0] = p.take<float>((size_t)net_pack16_floats(cfg->actor, h->planes));
+    h->pack16_t[0] = p.take<float>((size_t)net_pack16_floats(cfg->actor, h->planes));
     for (int j = 0; j < nc; ++j) {
-      h->pack16[1 + j] = p.take<float>((size_t)net_pack16_floats(cfg->critics[j]));
-      h->pack16_t[1 + j] = p.take<float>((size_t)net_pack16_floats(cfg->critics[j]));
+      h->pack16[1 + j] = p.take<float>((size_t)net_pack16_floats(cfg->critics[j], h->planes));
+      h->pack16_t[1 + j] = p.take<float>((size_t)net_pack16_floats(cfg->critics[j], h->planes));
     }
   }
   std::vector<DwItem> items;
   for (int j = 0; j < nc; ++j)
-    fill_items(cfg->critics[j], h->ws_critic[j], items, &h->tiles_critic, h->fused, h->pack16[1 + j], h->pack16_t[1 + j]);
+    fill_items(cfg->critics[j], h->ws_critic[j], items, &h->tiles_critic, h->fused, h->pack16[1 + j], h->pack16_t[1 + j], h->planes);
   h->n_items_critic = (int)items.size();
-  fill_items(cfg->actor, h->ws_actor, items, &h->tiles_actor, h->fused, h->pack16[0], h->pack16_t[0]);
+  fill_items(cfg->actor, h->ws_actor, items, &h->tiles_actor, h->fused, h->pack16[0], h->pack16_t[0], h->planes);
   h->n_items_actor = (int)items.size() - h->n_items_critic;
   h->items_host = items;
   std::vector<RepackItem> rp[3];
@@ -1999,9 +2063,10 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     float *p16[OPRL_MAX_CRITICS + 1], *p16t[OPRL_MAX_CRITICS + 1];
     for (int j = 0; j < nc; ++j) { p16[j] = h->pack16[1 + j]; p16t[j] = h->pack16_t[1 + j]; }
     p16[nc] = h->pack16[0]; p16t[nc] = h->pack16_t[0];
-    int prc = repack_nets(nets, nc + 1, 3, nullptr, h->bf16 ? p16 : nullptr, h->bf16 ? p16t : nullptr);
+    int prc = repack_nets(nets, nc + 1, 3, nullptr, (h->bf16 || h->x2) ? p16 : nullptr, (h->bf16 || h->x2) ? p16t : nullptr, h->planes);
     if (prc != OPRL_OK) { (void)hipFree(p.base); delete h; return prc; }
   }
+  if (h->x2) { std::lock_guard<std::mutex> lk(g_lazy_mu); g_lazy.push_back(h); }
   *out = h;
   return OPRL_OK;
 }
@@ -2014,7 +2079,8 @@ extern "C" int oprl_learner_sync_params(oprl_learner* h, void* stream) {
   float *p16[OPRL_MAX_CRITICS + 1], *p16t[OPRL_MAX_CRITICS + 1];
   for (int j = 0; j < h->nc; ++j) { p16[j] = h->pack16[1 + j]; p16t[j] = h->pack16_t[1 + j]; }
   p16[h->nc] = h->pack16[0]; p16t[h->nc] = h->pack16_t[0];
-  return repack_nets(nets, h->nc + 1, 3, (hipStream_t)stream, h->bf16 ? p16 : nullptr, h->bf16 ? p16t : nullptr);
+  h->stale32[0] = h->stale32[1] = false;     // (every pack is rebuilt from the master here)
+  return repack_nets(nets, h->nc + 1, 3, (hipStream_t)stream, (h->bf16 || h->x2) ? p16 : nullptr, (h->bf16 || h->x2) ? p16t : nullptr, h->planes);
 }
 
 extern "C" int64_t oprl_net_pack_floats(const oprl_net* net) {
@@ -2032,6 +2098,10 @@ extern "C" int oprl_net_repack(const oprl_net* net, int32_t which, void* stream)
 
 extern "C" int oprl_learner_destroy(oprl_learner* h) {
   if (!h) return OPRL_OK;
+  {
+    std::lock_guard<std::mutex> lk(g_lazy_mu);
+    g_lazy.erase(std::remove(g_lazy.begin(), g_lazy.end(), h), g_lazy.end());
+  }
   (void)hipDeviceSynchronize();
   if (h->rccl.comm && h->rccl.comm_destroy) (void)h->rccl.comm_destroy(h->rccl.comm);
   if (h->fused) { std::lock_guard<std::mutex> lk(g_chain_mu); if (g_chain.live > 0) g_chain.live -= 1; }
@@ -2245,7 +2315,7 @@ extern "C" int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group*
   if (!learners || !out || n < 1 || n > 64) { set_err("oprl_group_create: invalid argument"); return OPRL_ERR_INVALID; }
   for (int i = 0; i < n; ++i) {
     oprl_learner* h = learners[i];
-    if (!h || h->cfg.algo != OPRL_DDPG || !h->fused || h->cfg.export_grads || h->bf16 || h->S != learners[0]->S ||
+    if (!h || h->cfg.algo != OPRL_DDPG || !h->fused || h->cfg.export_grads || h->bf16 || h->x2 || h->S != learners[0]->S ||
         h->A != learners[0]->A || h->Bmax != learners[0]->Bmax) {
       set_err("oprl_group_create: member %d is not a fused fp32 DDPG learner of the group's shape", i);
       return OPRL_ERR_INVALID;
@@ -2492,6 +2562,7 @@ extern "C" int oprl_mlp_forward(const oprl_net* net, int32_t use_target, const f
   if (k0 + (x1 ? k1 : 0) != net->dims[0]) { set_err("oprl_mlp_forward: k0+k1=%d != input dim %d", k0 + (x1 ? k1 : 0), net->dims[0]); return OPRL_ERR_INVALID; }
   if (out_act != ACT_NONE && out_act != ACT_TANH && out_act != ACT_GAUSS_MEAN) { set_err("oprl_mlp_forward: out_act %d unsupported here", out_act); return OPRL_ERR_INVALID; }
   if (!g_attrs_done) { HIPC(init_kernel_attrs()); g_attrs_done = true; }
+  RC(fresh32(net, (hipStream_t)stream));
   MlpArgs a;
   memset(&a, 0, sizeof a);
   a.net = net_view(*net, use_target != 0);
@@ -2532,6 +2603,7 @@ extern "C" int oprl_mlp_act(const oprl_net* net, const float* obs_host, int32_t 
   if (out_act != ACT_NONE && out_act != ACT_TANH && out_act != ACT_GAUSS_MEAN) { set_err("oprl_mlp_act: out_act %d unsupported here", out_act); return OPRL_ERR_INVALID; }
   if (!g_attrs_done) { HIPC(init_kernel_attrs()); g_attrs_done = true; }
   hipStream_t st = (hipStream_t)stream;
+  RC(fresh32(net, st));
   std::lock_guard<std::mutex> lk(g_act.mu);
   if (g_act.host == nullptr) {
     HIPC(hipHostMalloc((void**)&g_act.host, 512 * sizeof(float), hipHostMallocDefault));
@@ -2562,6 +2634,7 @@ extern "C" int oprl_mlp_backward(const oprl_net* net, const float* x0, int32_t k
   if (k0 + (x1 ? k1 : 0) != net->dims[0]) { set_err("oprl_mlp_backward: input dims mismatch"); return OPRL_ERR_INVALID; }
   if (!g_attrs_done) { HIPC(init_kernel_attrs()); g_attrs_done = true; }
   hipStream_t st = (hipStream_t)stream;
+  RC(fresh32(net, st));
   NetWs ws;
   float* base = g_tmp.get(net_ws_floats(*net, B) + sizeof(DwItem) * kMaxLayers / sizeof(float) + 2048);
   if (!base) { set_err("oprl_mlp_backward: scratch allocation failed"); return OPRL_ERR_NOMEM; }

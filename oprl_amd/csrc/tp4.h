@@ -61,15 +61,29 @@ template <class P, int NM> struct Tp4Shape {
 };
 
 // sum over N macro steps, even steps on one accumulator and odd ones on another (two independent MFMA chains)
+// (`sc`: the power of two the A operand is multiplied by on its way in — PrecX2; the other policies ignore it)
 template <class P, int N>
-__device__ __forceinline__ f32x4 tp4_mac_steps(const float* xr, const f32x4 (&w)[N]) {
+__device__ __forceinline__ f32x4 tp4_mac_steps(const float* xr, const typename P::Frag (&w)[N], float sc = P::kFwdA) {
   f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
 #pragma unroll
   for (int s = 0; s < N; ++s) {
-    if (s & 1) P::mac(xr, s, w[s], a1);
-    else P::mac(xr, s, w[s], a0);
+    if (s & 1) P::mac_s(xr, s, w[s], a1, sc);
+    else P::mac_s(xr, s, w[s], a0, sc);
   }
   return a0 + a1;
+}
+// the largest magnitude of the [kR][ncols16 * 16] block of an LDS tile (leading dim kOutLd), in every lane of the wave
+__device__ __forceinline__ float tp4_tile_amax(const float* T, int ncols16) {
+  const int lane = threadIdx.x & 63;
+  float m = 0.f;
+  for (int e = lane; e < kR * 4 * ncols16; e += 64) {        // float4 units: 4 per 16 columns
+    const int row = e / (4 * ncols16), q = e - row * (4 * ncols16);
+    const f32x4 v = ld4(T + row * kOutLd + 4 * q);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+  return m;
 }
 
 __host__ __device__ inline bool tp4_shape_ok(int width, int fan_in, int n_out) {
@@ -258,26 +272,29 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
   const bool r_mine = rt < SH::TPM;
 
   // ---- requests for the whole pass (uniform over the waves but for the few output-layer fragments)
-  f32x4 w0[NS::S0], w1[NQ], w2[SH::M];
+  using F = typename P::Frag;
+  constexpr int BK = P::kBlk;                 // floats between two (tile, step) blocks of a pack
+  constexpr float kO = P::kOut / P::kFwdA;    // accumulator -> product (1 but for PrecX2)
+  F w0[NS::S0], w1[NQ], w2[SH::M];
   {
-    const float* p0 = net.pf[0] + ((size_t)wave * NS0 * 64 + lane) * 4;
+    const float* p0 = net.pf[0] + (size_t)wave * NS0 * BK + lane * 4;
 #pragma unroll
-    for (int s = 0; s < NS::S0; ++s) w0[s] = s < NS0 ? ld4(p0 + s * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < NS::S0; ++s) w0[s] = s < NS0 ? P::ldf(p0 + s * BK) : P::zf();
   }
   const float bias0 = net.b[0][16 * wave + i];
   {
-    const float* p1 = net.pf[1] + (((size_t)(c * SH::TPM + t1) * NS::W + kq * NQ) * 64 + lane) * 4;
+    const float* p1 = net.pf[1] + ((size_t)(c * SH::TPM + t1) * NS::W + kq * NQ) * BK + lane * 4;
 #pragma unroll
-    for (int s = 0; s < NQ; ++s) w1[s] = ld4(p1 + s * 256);
+    for (int s = 0; s < NQ; ++s) w1[s] = P::ldf(p1 + s * BK);
   }
   const float bias1 = net.b[1][c0 + 16 * (r_mine ? rt : 0) + (rl & 15)];
   float bias2 = 0.f, bias2e[2] = {0.f, 0.f};   // output bias: of this lane's column / of its narrow-exchange elements
 #pragma unroll
-  for (int s = 0; s < SH::M; ++s) w2[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < SH::M; ++s) w2[s] = P::zf();
   if (l2_wave) {
-    const float* p2 = net.pf[2] + (((size_t)t2 * NS::W + c * SH::M) * 64 + lane) * 4;
+    const float* p2 = net.pf[2] + ((size_t)t2 * NS::W + c * SH::M) * BK + lane * 4;
 #pragma unroll
-    for (int s = 0; s < SH::M; ++s) w2[s] = ld4(p2 + s * 256);
+    for (int s = 0; s < SH::M; ++s) w2[s] = P::ldf(p2 + s * BK);
     if (16 * t2 + i < N) bias2 = net.b[2][16 * t2 + i];
     if constexpr (NM == 8) {
 #pragma unroll
@@ -296,10 +313,10 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
     const float* xr = x0s + i * kX0Ld + 4 * kk;
 #pragma unroll
     for (int s = 0; s < NS::S0; ++s)
-      if (s < NS0) P::mac(xr, s, w0[s], acc);
+      if (s < NS0) P::mac_s(xr, s, w0[s], acc, P::kFwdA);
     float* o = h1 + (kk * 4) * kWL4 + 16 * wave + i;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r * kWL4] = fmaxf(acc[r] + bias0, 0.f);
+    for (int r = 0; r < 4; ++r) o[r * kWL4] = fmaxf(acc[r] * kO + bias0, 0.f);
   }
   sf();
   __syncthreads();   // h1 visible
@@ -318,13 +335,13 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
     float v = sp[0];
 #pragma unroll
     for (int q = 1; q < SH::KP; ++q) v += sp[q * SH::TPM * 256];
-    h2[(4 * (rl >> 4) + rr) * kWL4 + c0 + 16 * rt + (rl & 15)] = fmaxf(v + bias1, 0.f);
+    h2[(4 * (rl >> 4) + rr) * kWL4 + c0 + 16 * rt + (rl & 15)] = fmaxf(v * kO + bias1, 0.f);
   }
   __syncthreads();   // the member's h2 columns visible
 
   // ---- L2 partial + all-reduce from registers on waves 4..; waves 8.. store the h2 columns
   if (l2_wave) {
-    const f32x4 part = tp4_mac_steps<P, SH::M>(h2 + i * kWL4 + c0 + 4 * kk, w2);
+    const f32x4 part = tp4_mac_steps<P, SH::M>(h2 + i * kWL4 + c0 + 4 * kk, w2) * kO;
     const int col = 16 * t2 + i;
     const bool valid = col < N;
     float* o = outS + (kk * 4) * kOutLd + col;
@@ -373,29 +390,41 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
   const bool dact_wave = dact && dt < dnt;
 
   // ---- requests
-  f32x4 wo[NS::O], wz[NS::M], wd[NS::M];
+  using F = typename P::Frag;
+  constexpr int BK = P::kBlk;
+  F wo[NS::O], wz[NS::M], wd[NS::M];
 #pragma unroll
-  for (int s = 0; s < NS::O; ++s) wo[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < NS::O; ++s) wo[s] = P::zf();
   if (wave < kTpc4) {
-    const float* q2 = net.pb[2] + ((size_t)(c * kTpc4 + wave) * NSo * 64 + lane) * 4;
+    const float* q2 = net.pb[2] + (size_t)(c * kTpc4 + wave) * NSo * BK + lane * 4;
 #pragma unroll
     for (int s = 0; s < NS::O; ++s)
-      if (s < NSo) wo[s] = ld4(q2 + s * 256);
+      if (s < NSo) wo[s] = P::ldf(q2 + s * BK);
   }
   {
-    const float* q1 = net.pb[1] + (((size_t)wave * NS::W + c * NS::M) * 64 + lane) * 4;
+    const float* q1 = net.pb[1] + ((size_t)wave * NS::W + c * NS::M) * BK + lane * 4;
 #pragma unroll
-    for (int s = 0; s < NS::M; ++s) wz[s] = ld4(q1 + s * 256);
+    for (int s = 0; s < NS::M; ++s) wz[s] = P::ldf(q1 + s * BK);
   }
 #pragma unroll
-  for (int s = 0; s < NS::M; ++s) wd[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < NS::M; ++s) wd[s] = P::zf();
   if (dact_wave) {
-    const float* q0 = net.pb[0] + (((size_t)(dt0 + dt) * NS::W + dpart * NS::M) * 64 + lane) * 4;
+    const float* q0 = net.pb[0] + ((size_t)(dt0 + dt) * NS::W + dpart * NS::M) * BK + lane * 4;
 #pragma unroll
-    for (int s = 0; s < NS::M; ++s) wd[s] = ld4(q0 + s * 256);
+    for (int s = 0; s < NS::M; ++s) wd[s] = P::ldf(q0 + s * BK);
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();   // dout visible
+  // PrecX2: the gradient tiles go into the MFMAs scaled by a power of two fixed by the largest seed of the slice
+  // (every wave looks for itself: twelve of the sixteen idle through the first stage anyway; all members and waves
+  // find the same value).  dz2 = dout W3^T stays below |dout| sum|W3| and dz1 below 256 max|dz2| max|W2|: the later
+  // stages get 2^-2 of the headroom back.
+  float s1 = 1.f, s2 = 1.f;
+  if constexpr (P::kX2) {
+    s1 = P::a_scale(tp4_tile_amax(doutS, No16));
+    s2 = 0.25f * s1;
+  }
+  const float o1 = P::kOut / s1, o2 = P::kOut / s2;
 
   // ---- dz2[:, mine] = (dout · W3^T)[:, mine] ⊙ (h2 > 0), in place (waves 0..3)
   if (wave < kTpc4) {
@@ -403,10 +432,10 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
     const float* dr = doutS + i * kOutLd + 4 * kk;
 #pragma unroll
     for (int s = 0; s < NS::O; ++s)
-      if (s < NSo) P::mac_tail(dr, s, wo[s], acc, No16);
+      if (s < NSo) P::mac_tail_s(dr, s, wo[s], acc, No16, s1);
     float* p = h2 + (kk * 4) * kWL4 + c0 + 16 * wave + i;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) p[r * kWL4] = p[r * kWL4] > 0.f ? acc[r] : 0.f;
+    for (int r = 0; r < 4; ++r) p[r * kWL4] = p[r * kWL4] > 0.f ? acc[r] * o1 : 0.f;
   }
   sf();
   __syncthreads();   // dz2 visible
@@ -417,12 +446,12 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
     const float* hr = h2 + i * kWL4 + c0 + 4 * kk;
 #pragma unroll
     for (int s = 0; s < NS::M; s += 2) {
-      P::mac(hr, s, wz[s], a0);
-      P::mac(hr, s + 1, wz[s + 1], a1);
+      P::mac_s(hr, s, wz[s], a0, s1);
+      P::mac_s(hr, s + 1, wz[s + 1], a1, s1);
     }
     float* p = h1 + (kk * 4) * kWL4 + 16 * wave + i;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) p[r * kWL4] = p[r * kWL4] > 0.f ? a0[r] + a1[r] : 0.f;
+    for (int r = 0; r < 4; ++r) p[r * kWL4] = p[r * kWL4] > 0.f ? (a0[r] + a1[r]) * o1 : 0.f;
   }
   if (st.dY1 != nullptr && wave >= 12) {
     const int idx = (int)threadIdx.x - 768;          // 16 rows x 16 float4 of dz2
@@ -440,10 +469,10 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
       const float* hr = h1 + i * kWL4 + 64 * dpart + 4 * kk;
 #pragma unroll
       for (int s = 0; s < NS::M; s += 2) {
-        P::mac(hr, s, wd[s], a0);
-        P::mac(hr, s + 1, wd[s + 1], a1);
+        P::mac_s(hr, s, wd[s], a0, s2);
+        P::mac_s(hr, s + 1, wd[s + 1], a1, s2);
       }
-      *reinterpret_cast<f32x4*>(scr + wave * 256 + lane * 4) = a0 + a1;
+      *reinterpret_cast<f32x4*>(scr + wave * 256 + lane * 4) = (a0 + a1) * o2;
     }
     sf();
     __syncthreads();
@@ -516,27 +545,35 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   const bool r_mine = rt < SH::TPM;
 
   // ---- requests
-  f32x4 w0[NS::S0], w1[NQ], w2[SH::M], wz[SH::M], wd[Q4];
+  using F = typename P::Frag;
+  constexpr int BK = P::kBlk;
+  constexpr float kO = P::kOut / P::kFwdA;    // accumulator -> product, forward stages (1 but for PrecX2)
+  // PrecX2: the unit-seed gradient tiles g2 = seed w3 (h2 > 0) and dz1 = g2 W2 go in scaled by 2^12 / |seed| (a
+  // power of two): |w3| < 16, |dz1| <= |seed| max|w3| sum|W2 column| < 16 |seed| stay inside fp16's range
+  float sb = 1.f;
+  if constexpr (P::kX2) sb = 4.f * P::a_scale(fabsf(seed));
+  const float ob = P::kOut / sb;
+  F w0[NS::S0], w1[NQ], w2[SH::M], wz[SH::M], wd[Q4];
   {
-    const float* p0 = net.pf[0] + ((size_t)wave * NS0 * 64 + lane) * 4;
+    const float* p0 = net.pf[0] + (size_t)wave * NS0 * BK + lane * 4;
 #pragma unroll
-    for (int s = 0; s < NS::S0; ++s) w0[s] = s < NS0 ? ld4(p0 + s * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < NS::S0; ++s) w0[s] = s < NS0 ? P::ldf(p0 + s * BK) : P::zf();
   }
   const float bias0 = net.b[0][16 * wave + i];
   {
-    const float* p1 = net.pf[1] + (((size_t)(c * SH::TPM + t1) * NS::W + kq * NQ) * 64 + lane) * 4;
+    const float* p1 = net.pf[1] + ((size_t)(c * SH::TPM + t1) * NS::W + kq * NQ) * BK + lane * 4;
 #pragma unroll
-    for (int s = 0; s < NQ; ++s) w1[s] = ld4(p1 + s * 256);
+    for (int s = 0; s < NQ; ++s) w1[s] = P::ldf(p1 + s * BK);
   }
   const float bias1 = net.b[1][c0 + 16 * (r_mine ? rt : 0) + (rl & 15)];
-  const float w3 = P::first(net.pb[2] + ((size_t)(c * SH::TPM + (r_mine ? rt : 0)) * 64 + (rl & 15)) * 4);   // W3[c0 + 16 rt + col]  (one step)
+  const float w3 = P::first(net.pb[2] + (size_t)(c * SH::TPM + (r_mine ? rt : 0)) * BK + (rl & 15) * 4);   // W3[c0 + 16 rt + col]  (one step)
   float bias2 = 0.f;
 #pragma unroll
-  for (int s = 0; s < SH::M; ++s) w2[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < SH::M; ++s) w2[s] = P::zf();
   if (wave == kOutWave) {
-    const float* p2 = net.pf[2] + (((size_t)c * SH::M) * 64 + lane) * 4;
+    const float* p2 = net.pf[2] + ((size_t)c * SH::M) * BK + lane * 4;
 #pragma unroll
-    for (int s = 0; s < SH::M; ++s) w2[s] = ld4(p2 + s * 256);
+    for (int s = 0; s < SH::M; ++s) w2[s] = P::ldf(p2 + s * BK);
     if (i == 0 || NM == 8) bias2 = net.b[2][0];
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -548,15 +585,15 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
     const float* xr = x0s + i * kX0Ld + 4 * kk;
 #pragma unroll
     for (int s = 0; s < NS::S0; ++s)
-      if (s < NS0) P::mac(xr, s, w0[s], acc);
+      if (s < NS0) P::mac_s(xr, s, w0[s], acc, P::kFwdA);
     float* o = h1 + (kk * 4) * kWL4 + 16 * wave + i;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r * kWL4] = fmaxf(acc[r] + bias0, 0.f);
+    for (int r = 0; r < 4; ++r) o[r * kWL4] = fmaxf(acc[r] * kO + bias0, 0.f);
   }
   {
-    const float* q1 = net.pb[1] + (((size_t)wave * NS::W + c * SH::M) * 64 + lane) * 4;
+    const float* q1 = net.pb[1] + ((size_t)wave * NS::W + c * SH::M) * BK + lane * 4;
 #pragma unroll
-    for (int s = 0; s < SH::M; ++s) wz[s] = ld4(q1 + s * 256);
+    for (int s = 0; s < SH::M; ++s) wz[s] = P::ldf(q1 + s * BK);
   }
   sf();
   __syncthreads();   // h1 visible
@@ -575,24 +612,24 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
     float sum = sp[0];
 #pragma unroll
     for (int q = 1; q < SH::KP; ++q) sum += sp[q * SH::TPM * 256];
-    const float v = fmaxf(sum + bias1, 0.f);
+    const float v = fmaxf(sum * kO + bias1, 0.f);
     const int off = (4 * (rl >> 4) + rr) * kWL4 + c0 + 16 * rt + (rl & 15);
     h2[off] = v;
     g2[off] = v > 0.f ? seed * w3 : 0.f;
   }
 #pragma unroll
-  for (int s = 0; s < Q4; ++s) wd[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < Q4; ++s) wd[s] = P::zf();
   if (dact_wave) {
-    const float* q0 = net.pb[0] + (((size_t)(dt0 + dt) * NS::W + dpart * Q4) * 64 + lane) * 4;
+    const float* q0 = net.pb[0] + ((size_t)(dt0 + dt) * NS::W + dpart * Q4) * BK + lane * 4;
 #pragma unroll
-    for (int s = 0; s < Q4; ++s) wd[s] = ld4(q0 + s * 256);
+    for (int s = 0; s < Q4; ++s) wd[s] = P::ldf(q0 + s * BK);
   }
   sf();
   __syncthreads();   // h2, g2 (the member's columns) visible
 
   // ---- dz1 partial (unit seed), mask in place over h1; then the h2 / g2 column stores
   {
-    const f32x4 a = tp4_mac_steps<P, SH::M>(g2 + i * kWL4 + c0 + 4 * kk, wz);
+    const f32x4 a = tp4_mac_steps<P, SH::M>(g2 + i * kWL4 + c0 + 4 * kk, wz, sb) * ob;
     float* p = h1 + (kk * 4) * kWL4 + 16 * wave + i;
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[r * kWL4] = p[r * kWL4] > 0.f ? a[r] : 0.f;
@@ -612,7 +649,7 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
 
   tp4_store_dz1(st, c, h1, row0, B);
   if (dact_wave)
-    *reinterpret_cast<f32x4*>(scr + wave * 256 + lane * 4) = tp4_mac_steps<P, Q4>(h1 + i * kWL4 + 64 * dpart + 4 * kk, wd);
+    *reinterpret_cast<f32x4*>(scr + wave * 256 + lane * 4) = tp4_mac_steps<P, Q4>(h1 + i * kWL4 + 64 * dpart + 4 * kk, wd, sb) * ob;
   if (dact) {
     sf();
     __syncthreads();   // quarters visible
@@ -620,7 +657,7 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   // q (wave 12) and the input-column gradient (waves < dnt) finish side by side: both are one
   // hop of the cluster exchange, neither waits for the other
   if (wave == kOutWave) {
-    const f32x4 qpart = tp4_mac_steps<P, SH::M>(h2 + i * kWL4 + c0 + 4 * kk, w2);
+    const f32x4 qpart = tp4_mac_steps<P, SH::M>(h2 + i * kWL4 + c0 + 4 * kk, w2) * kO;
     const bool valid = i == 0;
     float* o = outS + (kk * 4) * kOutLd + i;
     if constexpr (NM == 8) {

@@ -46,14 +46,25 @@ def _is_param_key(k: str) -> bool:
                                        "m_critic", "v_critic"))
 
 
-def compare(got: dict, want: dict, tol: float, skip=(), param_tol: float | None = None):
+def _is_moment_key(k: str) -> bool:
+    return ".m_critic." in k or ".v_critic." in k
+
+
+def compare(got: dict, want: dict, tol: float, skip=(), param_tol: float | None = None, moment_tol: float | None = None):
     """max-norm relative deviation per key; returns worst (key, dev).
 
     ``param_tol`` (GPU runs) applies to parameter / Adam-state digests: an
     element whose minibatch gradient cancels to ~1e-3 of its terms has its
     summation-order noise amplified by Adam's m/sqrt(v) (measured: one W3
     element of the SAC actor, step-1 gradient 2.7e-6 vs median 2.3e-3, moves by
-    1.3% of one step = 6e-5 of max|W|).  Network outputs keep ``tol``."""
+    1.3% of one step = 6e-5 of max|W|).  Network outputs keep ``tol``.
+
+    ``moment_tol`` (x2 runs) applies to the Adam-moment digests only: ONE ReLU unit whose pre-activation lies within
+    rounding noise of zero for ONE minibatch row is masked on one side and not on the other (measured, update 10 of
+    the DDPG scenario, tools/x2_probe.py: every moment agrees to 2e-7 through nine updates, then h1 unit 97 / h2 unit
+    30 flip for one row and that unit's gradient differs by that row's term, 1.6e-3 of the largest moment; the
+    parameters still agree to 1e-7).  Any two fp32 implementations with different summation orders do this to each
+    other; the exact-fp32 mode happens not to on these seeds."""
     worst = ("", 0.0)
     for k, w in want.items():
         if k == "meta" or any(k.startswith(s) for s in skip):
@@ -68,6 +79,8 @@ def compare(got: dict, want: dict, tol: float, skip=(), param_tol: float | None 
         if dev > worst[1]:
             worst = (k, dev)
         lim = param_tol if (param_tol is not None and _is_param_key(k)) else tol
+        if moment_tol is not None and _is_moment_key(k):
+            lim = moment_tol
         assert dev <= lim, f"{k}: rel dev {dev:.3e} > {lim:.1e}"
     return worst
 

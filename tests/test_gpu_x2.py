@@ -1,0 +1,103 @@
+"""The split-precision mode (OPRL_PREC_X2, csrc/engine.h PrecX2: every operand as the sum of two fp16 numbers, three
+v_mfma_f32_16x16x32_f16 per product with fp32 accumulation) against the SAME golden vectors — produced by running the
+reference — and the same CPU oracle as the exact-fp32 mode, at the SAME gates (tests/test_gpu_algos.py: outputs 2e-5,
+parameter digests 1e-4 = north_star's gate): it is a parity mode, not a reduced-precision one.  The reference has no
+such arithmetic; what pins it is that nothing here is compared with anything but the reference's own numbers."""
+import functools
+
+import numpy as np
+import pytest
+import torch as t
+
+from tests import scenarios as sc
+from tests import hip_adapters as ha
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+MOMENT_TOL = 5e-3      # Adam-moment digests: one ReLU mask flip of one row (tests/scenarios.py::compare)
+
+
+def _x2(cls):
+    return functools.partial(cls, precision="x2")
+
+
+def _both(got, name, oracle_out, skip=()):
+    gold = sc.load_golden(name)
+    w1 = sc.compare(got, gold, TOL, skip=skip, param_tol=sc.PARAM_TOL, moment_tol=MOMENT_TOL)
+    w2 = sc.compare(got, {k: v for k, v in oracle_out.items()}, TOL, skip=skip, param_tol=sc.PARAM_TOL, moment_tol=MOMENT_TOL)
+    print(f"{name} [x2]: worst vs golden {w1}, vs oracle {w2}")
+
+
+def test_x2_learner_actually_runs_the_split_kernels():
+    """The mode is not a label: a learner created with precision='x2' owns two-plane fp16 packs that follow the
+    master weights through the updates (the fused kernels read nothing else)."""
+    from oprl_amd.algos.ddpg import DDPG
+    from oprl_amd.logging import NullLogger
+    t.manual_seed(0)
+    a = DDPG(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", precision="x2").create()
+    b = DDPG(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", precision="f32").create()
+    b.actor.load_state_dict(a.actor.state_dict()); b.critic.load_state_dict(a.critic.state_dict())
+    b.actor_target.load_state_dict(a.actor_target.state_dict()); b.critic_target.load_state_dict(a.critic_target.state_dict())
+    from oracle import fixtures as fx
+    for step in range(3):
+        batch = [x.cuda() for x in fx.make_batch(900 + step, 256, 24, 6)]
+        a.update(*batch); b.update(*batch)
+    t.cuda.synchronize()
+    pa, pb = a.critic._oprl_arena, b.critic._oprl_arena
+    dev = (pa - pb).abs().max().item() / pb.abs().max().item()
+    assert t.isfinite(pa).all()
+    assert 0.0 < dev < 1e-4, dev          # another arithmetic (not bit-identical), the same numbers
+
+
+def test_x2_ddpg_walker_b256():
+    got = sc.ddpg_scenario(_x2(ha.HipDDPG))
+    _both(got, "ddpg_walker_b256", sc.ddpg_scenario(sc.OracleDDPG))
+
+
+def test_x2_td3_cheetah_b256():
+    got = sc.td3_scenario(_x2(ha.HipTD3))
+    _both(got, "td3_cheetah_b256", sc.td3_scenario(sc.OracleTD3))
+
+
+def test_x2_sac_humanoid_b1024():
+    got = sc.sac_scenario(_x2(ha.HipSAC), "humanoid", 1024, 300, False, 2)
+    _both(got, "sac_humanoid_b1024", sc.sac_scenario(sc.OracleSAC, "humanoid", 1024, 300, False, 2))
+
+
+def test_x2_sac_walker_tuned_alpha():
+    got = sc.sac_scenario(_x2(ha.HipSAC), "walker", 256, 350, True, 3)
+    _both(got, "sac_walker_tune_b256", sc.sac_scenario(sc.OracleSAC, "walker", 256, 350, True, 3))
+
+
+@pytest.mark.parametrize("B", [100, 8, 1])
+def test_x2_ragged_batches_against_the_oracle(B):
+    cases = [("ddpg", sc.ddpg_scenario(_x2(ha.HipDDPG), B=B), sc.ddpg_scenario(sc.OracleDDPG, B=B)),
+             ("td3", sc.td3_scenario(_x2(ha.HipTD3), B=B), sc.td3_scenario(sc.OracleTD3, B=B)),
+             ("sac", sc.sac_scenario(_x2(ha.HipSAC), "walker", B, 350, True, 3),
+              sc.sac_scenario(sc.OracleSAC, "walker", B, 350, True, 3))]
+    for name, got, want in cases:
+        worst = sc.compare(got, {k: v for k, v in want.items()}, TOL, param_tol=sc.PARAM_TOL, moment_tol=MOMENT_TOL)
+        print(f"{name} B={B} [x2]: worst vs oracle {worst}")
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 300.0])
+def test_x2_holds_its_accuracy_over_input_magnitudes(scale):
+    """States three orders of magnitude smaller / larger than the fixtures' N(0, 1) (the A operand goes into the MFMAs
+    through fp16: a static 2^4 scale on forward activations, a seed-normalised one on gradient tiles): Q of the x2
+    learner against the exact-fp32 learner after 5 updates from the same state."""
+    from oprl_amd.algos.ddpg import DDPG
+    from oprl_amd.logging import NullLogger
+    from oracle import fixtures as fx
+    t.manual_seed(0)
+    a = DDPG(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", precision="x2").create()
+    b = DDPG(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", precision="f32").create()
+    for m in ("actor", "critic", "actor_target", "critic_target"):
+        getattr(b, m).load_state_dict(getattr(a, m).state_dict())
+    for step in range(5):
+        s, ac, r, d, s2 = [x.cuda() for x in fx.make_batch(700 + step, 256, 24, 6)]
+        a.update(s * scale, ac, r, d, s2 * scale); b.update(s * scale, ac, r, d, s2 * scale)
+    s, ac, *_ = [x.cuda() for x in fx.make_batch(799, 256, 24, 6)]
+    qa, qb = a.critic(s * scale, ac), b.critic(s * scale, ac)
+    dev = (qa - qb).abs().max().item() / qb.abs().max().item()
+    print(f"scale {scale}: x2 vs f32 Q deviation {dev:.2e}")
+    assert np.isfinite(dev) and dev < 2e-5, dev

@@ -13,7 +13,7 @@ from oprl_amd.logging import NullLogger
 S, A, B = 24, 6, 256
 t.manual_seed(0)
 algo = DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device="cuda", max_batch=B,
-            no_fuse="--generic" in sys.argv, precision="bf16" if "--bf16" in sys.argv else "f32").create()
+            no_fuse="--generic" in sys.argv, precision="bf16" if "--bf16" in sys.argv else ("x2" if "--x2" in sys.argv else "f32")).create()
 L = algo.learner
 NS, NST = 24, 24
 buf = t.zeros((NS, 64, NST, 2), dtype=t.int64, device="cuda")
