@@ -125,6 +125,83 @@ __device__ __forceinline__ float ld1_sc1(const float* p) {
 // before it touches what they write: `gate_rows` (every producer of X / dY rows) before the row requests,
 // `gate_seed` (the per-row seeds, and the output layer's dY) before those; rows and seeds are read with sc1 loads
 // (the producers write them through: no kernel boundary lies in between).
+// The updated 16 x 32 tile (tileW: online, tileT: target; staged in LDS, zero outside the matrix) into the fragment
+// packs, in pack order as 16-byte stores: the fp32 packs (pf / pb / tpf, unless null: a PrecX2 learner's fused update)
+// and the 16-bit packs (pf16 / pb16 / tpf16: bf16, or — I.x2 — blocks of two fp16 planes holding 2^8 w).
+__device__ __forceinline__ void dw_write_packs(const DwItem& I, const float (*tileW)[kDwTile + 4], const float (*tileT)[kDwTile + 4],
+                                               int tid, int tk, int n_base, int n_off, int ptile, int TNi, int NSk, int NSn,
+                                               bool polyak) {
+  if (tid < 384 && I.pf != nullptr) {
+    const int which = tid >> 7, q = tid & 127;
+    const int blk = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
+    if (which == 1) {            // W^T pack: tiles over k, steps over n; we own n in [n_off, n_off + TNi)
+      const int ktile = 2 * tk + blk;
+      if (I.pb != nullptr && ktile < NSk && 4 * lk >= n_off && 4 * lk < n_off + TNi) {
+        f32x4 v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = tileW[4 * lk + t][16 * blk + li];
+        *reinterpret_cast<f32x4*>(I.pb + (((size_t)ktile * NSn + ptile) * 64 + l) * 4) = v;
+      }
+    } else {                     // W pack (online, target): tiles over n, steps over k
+      const int kstep = 2 * tk + blk;
+      float* dst = which == 0 ? I.pf : (polyak ? I.tpf : nullptr);
+      if (dst != nullptr && kstep < NSk && li >= n_off && li < n_off + TNi) {
+        const float (*src)[kDwTile + 4] = which == 0 ? tileW : tileT;
+        *reinterpret_cast<f32x4*>(dst + (((size_t)ptile * NSk + kstep) * 64 + l) * 4) =
+            *reinterpret_cast<const f32x4*>(&src[li][16 * blk + 4 * lk]);
+      }
+    }
+  }
+  if (I.pf16 != nullptr) {
+    // the 16-bit packs: a macro step = fp32 steps 2s, 2s + 1 side by side, so this 16 x 32 tile is ONE forward
+    // fragment block (64 lanes x 16 B, online and target) and, for W^T, one HALF (8 B per lane) of a block for each
+    // of its two 16-row k tiles — the other half belongs to the neighbouring n tile.
+    // PrecX2 packs (I.x2): the same positions in blocks of TWO fp16 planes — hi = fp16(2^8 w), lo = fp16(2^8 w - hi),
+    // the lo plane 256 floats behind the hi plane.
+    const int NSk2 = cdiv(I.K, 32), NSn2 = cdiv(I.N, 32);
+    const bool x2 = I.x2 != 0;
+    const size_t BK16 = x2 ? 512 : 256;
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    if (tid < 128) {             // W packs: which = online / target
+      const int which = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
+      float* dst = which == 0 ? I.pf16 : (polyak ? I.tpf16 : nullptr);
+      if (dst != nullptr && li >= n_off && li < n_off + TNi) {
+        const float (*src)[kDwTile + 4] = which == 0 ? tileW : tileT;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(&src[li][4 * lk]), v1 = *reinterpret_cast<const f32x4*>(&src[li][16 + 4 * lk]);
+        float* d = dst + ((size_t)ptile * NSk2 + tk) * BK16 + (size_t)l * 4;
+        if (x2) {
+          f16x8 hi, lo;
+          x2_split8(v0 * PrecX2::kWScale, v1 * PrecX2::kWScale, hi, lo);
+          *reinterpret_cast<f16x8*>(d) = hi;
+          *reinterpret_cast<f16x8*>(d + 256) = lo;
+        } else {
+          *reinterpret_cast<bf16x8*>(d) = cvt_bf16x8(v0, v1);
+        }
+      }
+    } else if (tid < 256 && I.pb16 != nullptr) {   // W^T pack: k tile 2 tk + blk, n step n_base / 32, half (n_base / 16) & 1
+      const int q = tid - 128, blk = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
+      const int ktile = 2 * tk + blk;
+      if (16 * ktile < I.K && 4 * lk >= n_off && 4 * lk < n_off + TNi) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        f32x4 v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = tileW[4 * lk + t][16 * blk + li];
+        float* d = I.pb16 + ((size_t)ktile * NSn2 + (n_base >> 5)) * BK16 + (size_t)l * 4 + 2 * ((n_base >> 4) & 1);
+        if (x2) {
+          const f32x4 vs = v * PrecX2::kWScale;
+          const f16x4 hi = __builtin_convertvector(vs, f16x4);
+          const f32x4 r = vs - __builtin_convertvector(hi, f32x4);
+          *reinterpret_cast<f16x4*>(d) = hi;
+          *reinterpret_cast<f16x4*>(d + 256) = __builtin_convertvector(r, f16x4);
+        } else {
+          *reinterpret_cast<bf16x4*>(d) = __builtin_convertvector(v, bf16x4);
+        }
+      }
+    }
+  }
+}
+
+
 // GATE: 0 = a launch of its own, 1 = the critic's tiles on phase 1's launch (above), 2 = the ACTOR's tiles on phase
 // 2's launch: X rows are the previous launch's, dY is formed here from the du granules (DwGate, kernels.h).
 template <bool XCHG, int GATE = 0, int NW = kDwWaves>
@@ -577,77 +654,7 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int b
       tileT[n_off + nl][kl] = tt_new;
     }
     __syncthreads();
-    if (tid < 384 && I.pf != nullptr) {
-      const int which = tid >> 7, q = tid & 127;
-      const int blk = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
-      if (which == 1) {            // W^T pack: tiles over k, steps over n; we own n in [n_off, n_off + TNi)
-        const int ktile = 2 * tk + blk;
-        if (I.pb != nullptr && ktile < NSk && 4 * lk >= n_off && 4 * lk < n_off + TNi) {
-          f32x4 v;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) v[t] = tileW[4 * lk + t][16 * blk + li];
-          *reinterpret_cast<f32x4*>(I.pb + (((size_t)ktile * NSn + ptile) * 64 + l) * 4) = v;
-        }
-      } else {                     // W pack (online, target): tiles over n, steps over k
-        const int kstep = 2 * tk + blk;
-        float* dst = which == 0 ? I.pf : (polyak ? I.tpf : nullptr);
-        if (dst != nullptr && kstep < NSk && li >= n_off && li < n_off + TNi) {
-          const float (*src)[LD] = which == 0 ? tileW : tileT;
-          *reinterpret_cast<f32x4*>(dst + (((size_t)ptile * NSk + kstep) * 64 + l) * 4) =
-              *reinterpret_cast<const f32x4*>(&src[li][16 * blk + 4 * lk]);
-        }
-      }
-    }
-  }
-  if (ad.do_adam && I.pf16 != nullptr) {
-    // ... and the bf16 packs (PrecBF16, engine.h): a bf16 macro step = fp32 steps 2s, 2s + 1 side by
-    // side, so this 16 x 32 tile is ONE forward fragment block (64 lanes x 16 B, online and target) and,
-    // for W^T, one HALF (8 B per lane) of a block for each of its two 16-row k tiles — the other half
-    // belongs to the neighbouring n tile.  Same staged tiles, no further barrier.
-    // PrecX2 learners (A.x2): the same positions in blocks of TWO fp16 planes — hi = fp16(2^8 w), lo = fp16(2^8 w - hi),
-    // the lo plane 256 floats behind the hi plane.
-    const float (*tileW)[LD] = part[0];
-    const float (*tileT)[LD] = part[1];
-    const int NSk2 = cdiv(I.K, 32), NSn2 = cdiv(I.N, 32);
-    const bool x2 = I.x2 != 0;
-    const size_t BK16 = x2 ? 512 : 256;
-    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-    if (tid < 128) {             // W packs: which = online / target
-      const int which = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
-      float* dst = which == 0 ? I.pf16 : (polyak ? I.tpf16 : nullptr);
-      if (dst != nullptr && li >= n_off && li < n_off + TNi) {
-        const float (*src)[LD] = which == 0 ? tileW : tileT;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(&src[li][4 * lk]), v1 = *reinterpret_cast<const f32x4*>(&src[li][16 + 4 * lk]);
-        float* d = dst + ((size_t)ptile * NSk2 + tk) * BK16 + (size_t)l * 4;
-        if (x2) {
-          f16x8 hi, lo;
-          x2_split8(v0 * PrecX2::kWScale, v1 * PrecX2::kWScale, hi, lo);
-          *reinterpret_cast<f16x8*>(d) = hi;
-          *reinterpret_cast<f16x8*>(d + 256) = lo;
-        } else {
-          *reinterpret_cast<bf16x8*>(d) = cvt_bf16x8(v0, v1);
-        }
-      }
-    } else if (tid < 256 && I.pb16 != nullptr) {   // W^T pack: k tile 2 tk + blk, n step n_base / 32, half (n_base / 16) & 1
-      const int q = tid - 128, blk = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
-      const int ktile = 2 * tk + blk;
-      if (16 * ktile < I.K && 4 * lk >= n_off && 4 * lk < n_off + TNi) {
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        f32x4 v;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = tileW[4 * lk + t][16 * blk + li];
-        float* d = I.pb16 + ((size_t)ktile * NSn2 + (n_base >> 5)) * BK16 + (size_t)l * 4 + 2 * ((n_base >> 4) & 1);
-        if (x2) {
-          const f32x4 vs = v * PrecX2::kWScale;
-          const f16x4 hi = __builtin_convertvector(vs, f16x4);
-          const f32x4 r = vs - __builtin_convertvector(hi, f32x4);
-          *reinterpret_cast<f16x4*>(d) = hi;
-          *reinterpret_cast<f16x4*>(d + 256) = __builtin_convertvector(r, f16x4);
-        } else {
-          *reinterpret_cast<bf16x4*>(d) = __builtin_convertvector(v, bf16x4);
-        }
-      }
-    }
+    dw_write_packs(I, tileW, tileT, tid, tk, n_base, n_off, ptile, TNi, NSk, NSn, polyak);
   }
   if (b_own) {
     const int n = n_base + tid;

@@ -45,6 +45,9 @@
 #include "slice_head.h"
 #include "tp4.h"
 #include "dw_body.h"
+#include "dw_tile_x2.h"
+
+namespace oprl { constexpr bool kDwTileX2 = false; }   // the two-compute-wave tile of dw_tile_x2.h: measured slower (r03 log), off
 
 namespace oprl {
 
@@ -267,10 +270,14 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const DwKArg
   if constexpr (MERGED) {
     const int rows = (2 + A.n_critics) * A.nc + ((LEAN && WIDE) ? 4 : 0);
     if ((int)blockIdx.y >= rows && !pf_row) {
-      if (threadIdx.x >= kDwThreads) return;      // a tile workgroup is the first 8 waves (the stand-alone kernel's shape and arithmetic)
       const int tile = ((int)blockIdx.y - rows) * (int)gridDim.x + (int)blockIdx.x;
       if (tile >= D->tile_end[kDwMaxItems - 1]) return;
-      dw_adam_body<false, 1>(*D, smem, tile);
+      if constexpr (P::kX2 && kDwTileX2) {
+        dw_tile_x2<1>(*D, smem, tile);            // all 16 waves load, two compute (dw_tile_x2.h)
+      } else {
+        if (threadIdx.x >= kDwThreads) return;    // a tile workgroup is the first 8 waves (the stand-alone kernel's shape and arithmetic)
+        dw_adam_body<false, 1>(*D, smem, tile);
+      }
       return;
     }
   }
@@ -954,7 +961,8 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const DwKAr
   if (y >= yT) {   // a tile workgroup: all 16 waves (16 minibatch rows each)
     const int tile = (y - yT) * (int)gridDim.x + slice;
     if (tile >= D->tile_end[kDwMaxItems - 1]) return;
-    dw_adam_body<false, 2, 16>(*D, smem, tile);
+    if constexpr (P::kX2 && kDwTileX2) dw_tile_x2<2>(*D, smem, tile);
+    else dw_adam_body<false, 2, 16>(*D, smem, tile);
     return;
   }
   if (y >= NMC && y < yP) { role_u<P>(A, smem, slice, y - NMC); return; }
@@ -1047,7 +1055,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2_dw(const DdpgArgs A, c
 }
 
 static_assert(FusedLds<256>::total >= RoleULds::total, "role U fits the phase kernels' LDS");
-static_assert(FusedLds<256>::total >= kDwLdsFloats && FusedLds<256>::total >= DwLds<16>::floats, "a tile workgroup fits the phase kernels' LDS");
+static_assert(FusedLds<256>::total >= kDwLdsFloats && FusedLds<256>::total >= DwLds<16>::floats && FusedLds<256>::total >= DwX2Lds::floats, "a tile workgroup fits the phase kernels' LDS");
 
 size_t fused_ddpg_lds_bytes() { return sizeof(float) * FusedLds<256>::total; }
 size_t fused_xbuf_granules_per_cluster(int nc) { return (size_t)kTpStages * nc * kTpBlk; }
