@@ -115,6 +115,9 @@ __device__ __forceinline__ f32x4 ld4_sc1(const float* p) {
   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
+// after an explicit s_waitcnt for such loads: redefine the loaded register, so that nothing computed from it can be
+// scheduled above the wait (volatile asms keep their order; plain arithmetic on an asm's output does not)
+__device__ __forceinline__ void sc1_arrived(f32x4& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ float ld1_sc1(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

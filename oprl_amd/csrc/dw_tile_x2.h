@@ -1,143 +1,184 @@
-// dw_tile_x2.h — the dW + Adam tile of a PrecX2 learner's MERGED phase launches (fused_ddpg.hip), rebuilt around what
-// such a tile waits for.
+// dw_tile_x2.h — the dW + Adam tile of a PrecX2 learner's MERGED phase launches (fused_ddpg.hip): 16 (n) x 64 (k)
+// outputs per workgroup of 1024 threads, the 256-row contraction on the fp16 matrix rate with the split product of
+// engine.h (PrecX2), built around what such a tile waits for.
 //
-// A gated tile (dw_body.h, GATE 1 / 2) has everything early but a few numbers per minibatch row — the critic's TD-error
-// seed, the actor's du — and what followed their arrival WAS the update's tail twice over: staging rows through
-// wave-private LDS, 16 MFMAs per wave on partial tiles, a barrier that waited for the slowest of 8 / 16 waves, a
-// 16-way partial-sum reduction, Adam, two more barriers around the pack staging: 2.9 us (phase 1) and 4.4 us (phase
-// 2) of a 32 us update.  Here the 16 waves are LOADERS — they put the tile's operands into LDS TRANSPOSED (minibatch
-// index contiguous), X already split into its two fp16 planes — and TWO waves compute: one 16 x 16 output tile each
-// over the whole 256-row contraction with the split product of engine.h (8 macro steps of 32 rows, three
-// v_mfma_f32_16x16x32_f16 each), the result in their registers: no partial tiles, no reduction, Adam straight from
-// the accumulators with state those lanes requested at entry.  After the seeds: poll, 8 steps, Adam, stores, one
-// barrier, packs.
+// A gated tile (dw_body.h, GATE 1 / 2) has everything early but a few numbers per minibatch row — the critic's
+// TD-error seed, the actor's du.  X therefore goes into LDS at once, transposed (minibatch index contiguous) and
+// already split into its two fp16 planes; what follows the late numbers is short:
+//     form dY (4 elements per lane) -> LDS, transposed          [barrier]
+//     wave = (32-row group g, half of the k columns): A = its group's dY rows, scaled by a power of two fixed by the
+//       GROUP's largest magnitude and split; two 16 x 16 output tiles x 3 MFMAs; partial tiles -> LDS   [barrier]
+//     thread = element: 8 partials, Adam (state requested at entry), Polyak, stores; the new tile -> LDS  [barrier]
+//     fp16 packs in pack order
+// Twice the tile of dw_body.h (84 tiles per net instead of 152: every tile of a merged launch is resident long before
+// its seeds arrive) at a quarter of its matrix time (the exact-fp32 MFMAs of a 16 x 32 tile are 0.43 us per CU).
 //   GATE 1 (the critic's tiles on phase 1): dY = U[b, n] * seed[b], U = the unit-seed rows role B wrote (summed over
-//       the cluster's partial buffers where there are any) or e_0 for the output layer; the compute waves poll the
-//       256 seed granules themselves and scale their A operand on the way in.
-//   GATE 2 (the actor's tiles on phase 2): dY is formed by the loaders from du (dw_body.h's three kinds), written
-//       transposed, one more barrier.
-// Scales: X goes in as 2^4 x (forward activations, PrecX2::kFwdA); the dY tile as s dY with s = a_scale of its
-// largest magnitude (GATE 1: max|U| max|seed|; GATE 2: the loaders' max) — the accumulators come out as 16 s dW.
-// One 256-row chunk (B <= 256), 16-row n tiles.
+//       the cluster's partial buffers where there are any), or e_0 for the output layer.
+//   GATE 2 (the actor's tiles on phase 2): dY from du, dw_body.h's three kinds.
+// Scales: X goes in as 2^4 x (PrecX2::kFwdA); a group's dY as s dY, s = a_scale(its largest |dY|).
+// One 256-row chunk (B <= 256); fp32 packs are not written (PrecX2 learners keep them lazily: learner.hip fresh32).
+// (A first form of this file — all 16 waves as loaders, TWO waves computing a 16 x 32 tile over the whole contraction,
+// Adam from their accumulators — was slower than dw_body.h's: one wave's 8 dependent steps of LDS reads, a 16-
+// instruction split and three MFMAs are a 2.5 us latency chain with nothing to hide it behind.  r03 experiment log.)
 #pragma once
 #include "dw_body.h"
 
 namespace oprl {
 
-struct DwX2Lds {   // floats
-  // minibatch extent of a transposed row: 256 + padding such that the compute lanes' b128 reads (16 rows i, 16 bytes
-  // each) fall into 16 different groups of four banks — fp32 rows 260 dwords apart, fp16 rows 264 halfs = 132 dwords
-  static constexpr int LDF = 260, LDH = 264;
-  static constexpr int dyt = 0;                          // [16 n][LDF] fp32
-  static constexpr int xh = dyt + 16 * LDF;              // [32 k][LDH] fp16: hi plane of 2^4 X
-  static constexpr int xl = xh + 32 * LDH / 2;           // ... lo plane
-  static constexpr int seed = xl + 32 * LDH / 2;         // [2][256] the compute waves' seeds (GATE 1)
-  static constexpr int tw = seed + 512;                  // [16][36] updated tile, online
-  static constexpr int tt = tw + 16 * (kDwTile + 4);     // ... target
-  static constexpr int misc = tt + 16 * (kDwTile + 4);   // [16] the loader waves' max|dY|
-  static constexpr int floats = misc + 16;
-};
+constexpr int kDwX2TileK = 64;
 
+// max over the 64 lanes, in every lane: four DPP steps inside the rows of 16 (engine.h row16_sum's), then the four
+// rows through scalar registers — six ds_bpermute round trips (~100 cycles each, serial) as __shfl_xor steps
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+struct DwX2Lds {   // floats
+  // minibatch extent of a transposed row, padded such that the compute lanes' b128 reads (16 rows i, 16 bytes each)
+  // fall into 16 different groups of four banks — fp32 rows 260 dwords apart, fp16 rows 264 halfs = 132 dwords
+  static constexpr int LDF = 260, LDH = 264, LDT = kDwX2TileK + 4;
+  static constexpr int dyt = 0;                          // [16 n][LDF] fp32; later the updated tile: online [16][LDT] | target
+  static constexpr int xh = dyt + 16 * LDF;              // [64 k][LDH] fp16: hi plane of 2^4 X
+  static constexpr int xl = xh + 64 * LDH / 2;           // ... lo plane
+  static constexpr int part = xl + 64 * LDH / 2;         // [8 groups][16][LDT] partial tiles
+  static constexpr int bpart = part + 8 * 16 * LDT;      // [8 groups x 4 row quarters][16] partial column sums of dY
+  static constexpr int floats = bpart + 512;
+};
+static_assert(2 * 16 * DwX2Lds::LDT <= 16 * DwX2Lds::LDF, "the staged tiles fit the dY area");
+
+// begin(): the tile's header, its Adam state and (GATE 2) every row that does not depend on this launch; finish(): the
+// rest.  Two calls, so that a workgroup that has something else to do first (role U of phase 2, which goes on as a tile
+// workgroup) can have its rows in flight meanwhile.
 template <int GATE>
-__device__ __forceinline__ void dw_tile_x2(const DwKArgs& A, float* lds, int bx) {
+struct DwX2Tile {
   static_assert(GATE == 1 || GATE == 2, "the gated tiles of the merged phase launches");
-  constexpr int TK = kDwTile, LD = TK + 4, LDF = DwX2Lds::LDF, LDH = DwX2Lds::LDH;
-  float* dyt = lds + DwX2Lds::dyt;
-  _Float16* xh = reinterpret_cast<_Float16*>(lds + DwX2Lds::xh);
-  _Float16* xl = reinterpret_cast<_Float16*>(lds + DwX2Lds::xl);
-  float (*tileW)[LD] = reinterpret_cast<float (*)[LD]>(lds + DwX2Lds::tw);
-  float (*tileT)[LD] = reinterpret_cast<float (*)[LD]>(lds + DwX2Lds::tt);
-  float* amaxw = lds + DwX2Lds::misc;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const DwKArgs* KA = &A;
-  const int te0 = KA->tile_end[0], te1 = KA->tile_end[1], te2 = KA->tile_end[2], te3 = KA->tile_end[3];
-  const int hB = A.B, h_n_part = A.n_part, h_tiled = A.dy_tiled;
-  long long* const h_trace = A.trace;
-  const AdamScalars ad = A.ad;
-  asm volatile("" :: "s"(hB), "s"(h_n_part), "s"(h_tiled), "s"(h_trace), "s"(ad.do_polyak), "s"(ad.omb1), "s"(ad.beta2),
-               "s"(ad.omb2), "s"(ad.eps), "s"(ad.omtau), "s"(ad.tau), "s"(ad.grad_scale), "s"(ad.step_size_host),
-               "s"(ad.bc2_sqrt_host));
-  const int item = (bx >= te0 ? 1 : 0) + (bx >= te1 ? 1 : 0) + (bx >= te2 ? 1 : 0) + (bx >= te3 ? 1 : 0);   // (<= 4 layers)
-  const DwItem I = KA->items[item];
-  const DwGate& G = KA->gate;
-  const int lt = bx - (item > 0 ? KA->tile_end[item - 1] : 0);
-  int n_stamp = 0;
-  auto stamp = [&]() {
+  static constexpr int TK = kDwX2TileK, LDF = DwX2Lds::LDF, LDH = DwX2Lds::LDH, LDT = DwX2Lds::LDT;
+  // (only what must survive between begin() and finish(): the layer's table entry, the tile's coordinates and flags are
+  // formed again in finish() — scalar work — instead of being carried through whatever runs in between)
+  const DwKArgs* KA;
+  float* lds;
+  int item, lt, n_stamp;
+  float p_th, p_m, p_v, p_tt, q_th, q_m, q_v, q_tt;
+  f32x4 vx[2][2], hmask;
+
+  __device__ __forceinline__ void stamp() {
+    long long* const h_trace = KA->trace;
     const int wg = item * 16 + lt;
-    if (h_trace != nullptr && tid == 0 && lt < 16 && wg < 64 && n_stamp < kTraceStamps) {
+    if (h_trace != nullptr && threadIdx.x == 0 && lt < 16 && wg < 64 && n_stamp < kTraceStamps) {
       long long* tr = h_trace + ((size_t)wg * kTraceStamps + n_stamp) * 2;
       tr[0] = (long long)__builtin_readcyclecounter();
       tr[1] = (long long)wall_clock64();
     }
     ++n_stamp;
-  };
-  stamp();
-#if defined(DW_X2_DEBUG) && DW_X2_DEBUG == 1
-  if (GATE == 1) return;
-#endif
-  const int tn = lt / I.tiles_k, tk = lt - tn * I.tiles_k;
-  const int n_base = tn * kDwTileN, k_base = tk * TK;
-  const int ptile = n_base >> 4;
-  const int i = lane & 15, kk = lane >> 4;
-  const int NSk = cdiv(I.K, 16), NSn = cdiv(I.N, 16);
-  const bool polyak = ad.do_polyak && I.w_t != nullptr;
-  const float step_size = ad.step_size_host, bc2_sqrt = ad.bc2_sqrt_host;   // (the host knows the step in the merged launches)
-
-  // ---- the two compute waves: lane (kk, i) of wave w owns dW[n_base + 4 kk + r][k_base + 16 w + i], r = 0..3; their
-  // Adam state is requested once the loaders' own rows have left the registers (below: `request_state`)
-  const bool cw = wave < 2;
-  const int ek = k_base + 16 * wave + i;
-  float p_th[4], p_m[4], p_v[4], p_tt[4];
-  bool e_ok[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    e_ok[r] = cw && n_base + 4 * kk + r < I.N && ek < I.K;
-    p_th[r] = p_m[r] = p_v[r] = p_tt[r] = 0.f;
   }
-  // the bias element: wave 0, lanes kk == 0 (column n = i), of the tiles that own one
-  const bool b_own = tk == 0 && wave == 0 && kk == 0 && n_base + i < I.N;
-  const bool b_pol = ad.do_polyak && I.b_t != nullptr;
-  float q_th = 0.f, q_m = 0.f, q_v = 0.f, q_tt = 0.f;
-  auto request_state = [&]() {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (e_ok[r]) {
-        const size_t eo = (size_t)(n_base + 4 * kk + r) * I.K + ek;
-        p_th[r] = I.w[eo]; p_m[r] = I.w_m[eo]; p_v[r] = I.w_v[eo];
-        if (polyak) p_tt[r] = I.w_t[eo];
-      }
+
+  __device__ __forceinline__ void begin(const DwKArgs& A, float* lds_, int bx) {
+    KA = &A;
+    lds = lds_;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int te0 = KA->tile_end[0], te1 = KA->tile_end[1], te2 = KA->tile_end[2], te3 = KA->tile_end[3];
+    const int hB = A.B;
+    const AdamScalars& ad = A.ad;
+    item = (bx >= te0 ? 1 : 0) + (bx >= te1 ? 1 : 0) + (bx >= te2 ? 1 : 0) + (bx >= te3 ? 1 : 0);   // (<= 4 layers)
+    const DwItem I = KA->items[item];
+    const DwGate& G = KA->gate;
+    lt = bx - (item > 0 ? KA->tile_end[item - 1] : 0);
+    n_stamp = 0;
+    stamp();
+    const int tiles_k = cdiv(I.K, TK);
+    const int tn = lt / tiles_k, tk = lt - tn * tiles_k;
+    const int n_base = tn * kDwTileN, k_base = tk * TK;
+    const bool polyak = ad.do_polyak && I.w_t != nullptr;
+    // ---- this thread's element (nl, kl) of the epilogue and its Adam state, requested now
+    const int nl = tid >> 6, kl = tid & 63;
+    const int en = n_base + nl, ek = k_base + kl;
+    const bool e_ok = en < I.N && ek < I.K;
+    const size_t eo = (size_t)en * I.K + ek;
+    p_th = p_m = p_v = p_tt = 0.f;
+    if (e_ok) {
+      p_th = I.w[eo]; p_m = I.w_m[eo]; p_v = I.w_v[eo];
+      if (polyak) p_tt = I.w_t[eo];
     }
+    const bool b_own = tk == 0 && tid < kDwTileN && n_base + tid < I.N;
+    const bool b_pol = ad.do_polyak && I.b_t != nullptr;
+    q_th = q_m = q_v = q_tt = 0.f;
     if (b_own) {
-      const int n = n_base + i;
+      const int n = n_base + tid;
       q_th = I.b[n]; q_m = I.b_m[n]; q_v = I.b_v[n];
       if (b_pol) q_tt = I.b_t[n];
     }
-  };
+    // ---- loaders (wave w: minibatch rows 16 w .. 16 w + 15).  X: lane = (row pair p = lane >> 3, quad q = lane & 7) x
+    // two column halves — two ADJACENT rows per lane, so that a transposed fp16 pair is one dword
+    const int xq = (lane & 7) * 4, xb0 = 16 * wave + 2 * (lane >> 3);
+    const int an = (lane & 3) * 4, bb = 16 * wave + (lane >> 2), ncol = n_base + an;
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) vx[h][0] = vx[h][1] = z4;
+    hmask = z4;
+    if constexpr (GATE == 2) {
+      const int kind = item == 0 ? G.kind[0] : (item == 1 ? G.kind[1] : (item == 2 ? G.kind[2] : G.kind[3]));
+      // X is the launch before's: at once
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int xc = k_base + 32 * h + xq;
+        if (xc < I.ldx) {
+          if (xb0 < hB) vx[h][0] = ld4(I.X + (size_t)xb0 * I.ldx + xc);
+          if (xb0 + 1 < hB) vx[h][1] = ld4(I.X + (size_t)(xb0 + 1) * I.ldx + xc);
+        }
+      }
+      if (kind == 1 && ncol < I.ldy && bb < hB) hmask = ld4(G.h2 + (size_t)bb * I.ldy + ncol);
+    }
+  }
 
-  // ---- loaders.  X: lane = (row pair p = lane >> 3, quad q = lane & 7) of the wave's 16 rows — two ADJACENT rows, so
-  // that a transposed fp16 pair is one dword
+  __device__ __forceinline__ void finish() {
+  const DwKArgs& A = *KA;
+  float* dyt = lds + DwX2Lds::dyt;
+  _Float16* xh = reinterpret_cast<_Float16*>(lds + DwX2Lds::xh);
+  _Float16* xl = reinterpret_cast<_Float16*>(lds + DwX2Lds::xl);
+  float* part = lds + DwX2Lds::part;
+  float* bpart = lds + DwX2Lds::bpart;
+  float* tileW = lds + DwX2Lds::dyt;
+  float* tileT = tileW + 16 * LDT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hB = A.B, h_n_part = A.n_part, h_tiled = A.dy_tiled;
+  const AdamScalars ad = A.ad;
+  const DwGate& G = KA->gate;
+  const DwItem I = KA->items[item];
+  const int tiles_k = cdiv(I.K, TK);
+  const int tn = lt / tiles_k, tk = lt - tn * tiles_k;
+  const int n_base = tn * kDwTileN, k_base = tk * TK;
+  const bool polyak = ad.do_polyak && I.w_t != nullptr;
+  const bool e_ok = n_base + (tid >> 6) < I.N && k_base + (tid & 63) < I.K;
+  const size_t eo = (size_t)(n_base + (tid >> 6)) * I.K + k_base + (tid & 63);
+  const bool b_own = tk == 0 && tid < kDwTileN && n_base + tid < I.N;
+  const bool b_pol = ad.do_polyak && I.b_t != nullptr;
+  int kind = 0;
+  if constexpr (GATE == 2) kind = item == 0 ? G.kind[0] : (item == 1 ? G.kind[1] : (item == 2 ? G.kind[2] : G.kind[3]));
+  const int ptile = n_base >> 4;
+  const int i = lane & 15, kk = lane >> 4;
+  const float step_size = ad.step_size_host, bc2_sqrt = ad.bc2_sqrt_host;   // (the host knows the step in the merged launches)
+  const int nl = tid >> 6, kl = tid & 63;
   const int xp = lane >> 3, xq = (lane & 7) * 4;
   const int xb0 = 16 * wave + 2 * xp;
-  const bool xk_ok = k_base + xq < I.ldx;
-  f32x4 vx0 = f32x4{0.f, 0.f, 0.f, 0.f}, vx1 = vx0;
-  // dY ingredients: lane = (row ar = lane >> 2, column quad an = 4 (lane & 3))
+  // dY: lane = (row ar = lane >> 2, column quad an = 4 (lane & 3))
   const int ar = lane >> 2, an = (lane & 3) * 4;
   const int bb = 16 * wave + ar, ncol = n_base + an;
   const bool an_ok = ncol < I.ldy;
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 va[kDuLd];
 #pragma unroll
-  for (int j = 0; j < kDuLd; ++j) va[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 hmask = f32x4{0.f, 0.f, 0.f, 0.f};
-  int kind = 0;
+  for (int j = 0; j < kDuLd; ++j) va[j] = z4;
   if constexpr (GATE == 2) {
-    kind = item == 0 ? G.kind[0] : (item == 1 ? G.kind[1] : (item == 2 ? G.kind[2] : G.kind[3]));
-    // X is the launch before's: at once
-    if (xk_ok) {
-      if (xb0 < hB) vx0 = ld4(I.X + (size_t)xb0 * I.ldx + k_base + xq);
-      if (xb0 + 1 < hB) vx1 = ld4(I.X + (size_t)(xb0 + 1) * I.ldx + k_base + xq);
-    }
+    // the output layer's rows W3[j][ncol .. ncol + 3] (a few hundred bytes, shared by every tile of the layer: not
+    // worth eight registers per lane through role U)
     if (kind == 1 && an_ok) {
-      if (bb < hB) hmask = ld4(G.h2 + (size_t)bb * I.ldy + ncol);
 #pragma unroll
       for (int j = 0; j < kDuLd; ++j)
         if (j < G.n_act) va[j] = ld4(G.w3 + (size_t)j * I.ldy + ncol);
@@ -162,7 +203,7 @@ __device__ __forceinline__ void dw_tile_x2(const DwKArgs& A, float* lds, int bx)
     }
     if (!ok) report_expired(G.err, G.err_code);
   }
-  float umax = 0.f;
+  f32x4 u = z4;          // GATE 1: the unit-seed dY of this lane
   if constexpr (GATE == 1) {
     __syncthreads();     // role B's members have flagged their rows (written through): X and the unit-seed dY
     // The write-through rows are read with inline-asm sc1 loads, which hipcc neither counts nor orders: they are
@@ -172,29 +213,29 @@ __device__ __forceinline__ void dw_tile_x2(const DwKArgs& A, float* lds, int bx)
     const int npart = I.dY_part_stride > 0 ? h_n_part : 1;
     const bool tiled = I.dY_part_stride > 0 && h_tiled != 0;
     const int xr0 = xb0 < hB ? xb0 : hB - 1, xr1 = xb0 + 1 < hB ? xb0 + 1 : hB - 1;
-    const int xc = xk_ok ? k_base + xq : 0;
+    const bool c0 = k_base + xq < I.ldx, c1 = k_base + 32 + xq < I.ldx;
+    const int xc0 = c0 ? k_base + xq : 0, xc1 = c1 ? k_base + 32 + xq : 0;
     const int ub = bb < hB ? bb : hB - 1, uc = (an_ok && !late) ? ncol : 0;
     const float* usrc = tiled ? I.dY + ((size_t)(uc >> 4) * hB + ub) * 16 + (uc & 15) : I.dY + (size_t)ub * I.ldy + uc;
     const size_t ps = (size_t)I.dY_part_stride;
-    const f32x4 rx0 = ld4_sc1(I.X + (size_t)xr0 * I.ldx + xc), rx1 = ld4_sc1(I.X + (size_t)xr1 * I.ldx + xc);
-    const f32x4 pa0 = ld4_sc1(usrc), pa1 = ld4_sc1(usrc + (npart > 1 ? ps : 0)), pa2 = ld4_sc1(usrc + (npart > 2 ? 2 * ps : 0)),
-                pa3 = ld4_sc1(usrc + (npart > 3 ? 3 * ps : 0));
+    f32x4 r00 = ld4_sc1(I.X + (size_t)xr0 * I.ldx + xc0), r01 = ld4_sc1(I.X + (size_t)xr1 * I.ldx + xc0);
+    f32x4 r10 = ld4_sc1(I.X + (size_t)xr0 * I.ldx + xc1), r11 = ld4_sc1(I.X + (size_t)xr1 * I.ldx + xc1);
+    f32x4 pa0 = ld4_sc1(usrc), pa1 = ld4_sc1(usrc + (npart > 1 ? ps : 0)), pa2 = ld4_sc1(usrc + (npart > 2 ? 2 * ps : 0)),
+          pa3 = ld4_sc1(usrc + (npart > 3 ? 3 * ps : 0));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    vx0 = (xk_ok && xb0 < hB) ? rx0 : z4;
-    vx1 = (xk_ok && xb0 + 1 < hB) ? rx1 : z4;
-    f32x4 u = ((pa0 + (npart > 1 ? pa1 : z4)) + (npart > 2 ? pa2 : z4)) + (npart > 3 ? pa3 : z4);   // member order, as k_dw_adam sums them
+    // (... and every loaded register is REDEFINED by an asm placed after the wait: arithmetic on an asm's output has
+    // no dependence on a later asm, and hipcc had hoisted the 2^4 scaling of the X rows above the wait)
+    sc1_arrived(r00); sc1_arrived(r01); sc1_arrived(r10); sc1_arrived(r11);
+    sc1_arrived(pa0); sc1_arrived(pa1); sc1_arrived(pa2); sc1_arrived(pa3);
+    vx[0][0] = (c0 && xb0 < hB) ? r00 : z4;
+    vx[0][1] = (c0 && xb0 + 1 < hB) ? r01 : z4;
+    vx[1][0] = (c1 && xb0 < hB) ? r10 : z4;
+    vx[1][1] = (c1 && xb0 + 1 < hB) ? r11 : z4;
+    u = ((pa0 + (npart > 1 ? pa1 : z4)) + (npart > 2 ? pa2 : z4)) + (npart > 3 ? pa3 : z4);   // member order, as k_dw_adam sums them
     if (late) u = f32x4{ncol == 0 ? 1.f : 0.f, 0.f, 0.f, 0.f};
     if (!(bb < hB && (an_ok || late))) u = z4;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      u[t] = (ncol + t < I.N) ? u[t] : 0.f;
-      dyt[(an + t) * LDF + bb] = u[t];
-      umax = fmaxf(umax, fabsf(u[t]));
-    }
   } else if (kind == 2) {
     __syncthreads();     // every member of role U has flagged its rows
-    // (unconditional sc1 loads from clamped addresses, then the wait: see GATE 1)
     const bool ok_u = an_ok && bb < hB;
     const int ub = bb < hB ? bb : hB - 1, uc = an_ok ? ncol : 0;
     const float* src = G.U + (((size_t)(uc >> 4) * G.n_act) * hB + ub) * 16 + (uc & 15);
@@ -203,15 +244,17 @@ __device__ __forceinline__ void dw_tile_x2(const DwKArgs& A, float* lds, int bx)
     for (int j = 0; j < kDuLd; ++j) ru[j] = ld4_sc1(src + (size_t)(j < G.n_act ? j : 0) * hB * 16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < kDuLd; ++j) va[j] = (ok_u && j < G.n_act) ? ru[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < kDuLd; ++j) sc1_arrived(ru[j]);
+#pragma unroll
+    for (int j = 0; j < kDuLd; ++j) va[j] = (ok_u && j < G.n_act) ? ru[j] : z4;
   }
   // X -> 2^4 X -> two fp16 planes, transposed: plane[k][b], the two rows of this lane side by side
-  {
-    if constexpr (GATE == 2) { /* plain loads: hipcc counts them */ }
-    f32x4 a = vx0 * PrecX2::kFwdA, b = vx1 * PrecX2::kFwdA;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f32x4 a = vx[h][0] * PrecX2::kFwdA, b = vx[h][1] * PrecX2::kFwdA;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const bool k_in = k_base + xq + t < I.K;
+      const bool k_in = k_base + 32 * h + xq + t < I.K;
       a[t] = k_in ? a[t] : 0.f;
       b[t] = k_in ? b[t] : 0.f;
     }
@@ -220,13 +263,28 @@ __device__ __forceinline__ void dw_tile_x2(const DwKArgs& A, float* lds, int bx)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-      *reinterpret_cast<f16x2*>(xh + (size_t)(xq + t) * LDH + xb0) = f16x2{hi[t], hi[4 + t]};
-      *reinterpret_cast<f16x2*>(xl + (size_t)(xq + t) * LDH + xb0) = f16x2{lo[t], lo[4 + t]};
+      *reinterpret_cast<f16x2*>(xh + (size_t)(32 * h + xq + t) * LDH + xb0) = f16x2{hi[t], hi[4 + t]};
+      *reinterpret_cast<f16x2*>(xl + (size_t)(32 * h + xq + t) * LDH + xb0) = f16x2{lo[t], lo[4 + t]};
     }
   }
-  request_state();
-  if constexpr (GATE == 2) {
-    // ---- du (granules), the combination, the transposed dY tile
+  // ---- the late numbers: per-row seeds (GATE 1) / du (GATE 2), then this lane's four dY elements
+  f32x4 v = z4;
+  if constexpr (GATE == 1) {
+    float sd = 0.f;
+    if (bb < hB && G.n_seed > 0) {
+      unsigned long long x = 0;
+      bool ok = false;
+      for (int spin = 0; spin < G.spin && !ok; ++spin) {
+        x = __hip_atomic_load(G.seed + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = (unsigned)(x >> 32) == G.tag;
+        if (!ok) __builtin_amdgcn_s_sleep(1);
+      }
+      if (!ok) report_expired(G.err, G.err_code);
+      sd = ok ? __uint_as_float((unsigned)x) : __builtin_nanf("");
+    }
+    stamp();   // seeds in
+    v = u * sd;
+  } else {
     float du[kDuLd];
     bool ok = true;
 #pragma unroll
@@ -244,9 +302,7 @@ __device__ __forceinline__ void dw_tile_x2(const DwKArgs& A, float* lds, int bx)
 #pragma unroll
     for (int j = 0; j < kDuLd; ++j)
       du[j] = (bb < hB && j < G.n_act) ? (ok ? __uint_as_float((unsigned)g[j]) : __builtin_nanf("")) : 0.f;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (role U's rows: inline-asm loads)
     stamp();   // rows and seeds in
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (kind != 0) {
 #pragma unroll
       for (int j = 0; j < kDuLd; ++j) v += va[j] * du[j];
@@ -263,127 +319,71 @@ __device__ __forceinline__ void dw_tile_x2(const DwKArgs& A, float* lds, int bx)
         v[t] = x;
       }
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      v[t] = (ncol + t < I.N) ? v[t] : 0.f;
-      dyt[(an + t) * LDF + bb] = v[t];
-      umax = fmaxf(umax, fabsf(v[t]));
-    }
   }
-  // the tile's largest |dY| (|U| for GATE 1): every loader wave leaves its own
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) umax = fmaxf(umax, __shfl_xor(umax, o));
-  if (lane == 0) amaxw[wave] = umax;
-  __syncthreads();       // the operands are in LDS
-  if constexpr (GATE == 1) stamp();   // operands staged (the seeds are still out)
-#if defined(DW_X2_DEBUG) && DW_X2_DEBUG == 2
-  if (GATE == 1) return;
-#endif
-  if (!cw) {
-    __syncthreads();     // (the pack staging's barrier below)
-    dw_write_packs(I, tileW, tileT, tid, tk, n_base, 0, ptile, kDwTileN, NSk, NSn, polyak);
-    return;
-  }
+  for (int t = 0; t < 4; ++t) dyt[(an + t) * LDF + bb] = (ncol + t < I.N) ? v[t] : 0.f;
+  __syncthreads();       // dY and both planes of X are in LDS
 
-  // ---- the two compute waves
-  float dscale = 1.f;      // seeds' share of the A operand's magnitude (GATE 1)
-  float* sd = lds + DwX2Lds::seed + 256 * wave;
-  if constexpr (GATE == 1) {
-    // the per-row seeds, {tag, value} granules straight from role A: every compute wave polls all 256 (4 per lane)
-    float smax = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int b = 64 * q + lane;
-      float sv = 0.f;
-      if (b < hB && G.n_seed > 0) {
-        unsigned long long x = 0;
-        bool ok = false;
-        for (int spin = 0; spin < G.spin && !ok; ++spin) {
-          x = __hip_atomic_load(G.seed + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = (unsigned)(x >> 32) == G.tag;
-          if (!ok) __builtin_amdgcn_s_sleep(1);
-        }
-        if (!ok) report_expired(G.err, G.err_code);
-        sv = ok ? __uint_as_float((unsigned)x) : __builtin_nanf("");
-      }
-      sd[b] = sv;
-      smax = fmaxf(smax, fabsf(sv));
-    }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) smax = fmaxf(smax, __shfl_xor(smax, o));
-    dscale = smax;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    stamp();   // seeds in
-  }
-  float tmax = amaxw[lane & 15];
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
-  tmax *= (GATE == 1 ? dscale : 1.f);
-  const float sa = PrecX2::a_scale(tmax);
-  f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-  float bsum = 0.f;
+  // ---- wave = (32-row group g, half of the k columns): two output tiles over the group's rows
   {
-    const float* arow = dyt + (size_t)i * LDF + 8 * kk;
-    const _Float16* bh = xh + (size_t)(16 * wave + i) * LDH + 8 * kk;
-    const _Float16* bl = xl + (size_t)(16 * wave + i) * LDH + 8 * kk;
-    auto step = [&](int s, f32x4& acc) {
-      f32x4 a0 = ld4(arow + 32 * s), a1 = ld4(arow + 32 * s + 4);
-      if constexpr (GATE == 1) {
-        a0 *= ld4(sd + 32 * s + 8 * kk);
-        a1 *= ld4(sd + 32 * s + 8 * kk + 4);
-      }
-      bsum += ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a1[0] + a1[1]) + (a1[2] + a1[3]));
-      f16x8 ah, al;
-      x2_split8(a0 * sa, a1 * sa, ah, al);
-      const f16x8 xhi = *reinterpret_cast<const f16x8*>(bh + 32 * s), xlo = *reinterpret_cast<const f16x8*>(bl + 32 * s);
+    const int grp = wave >> 1, half = wave & 1;
+    const float* arow = dyt + (size_t)i * LDF + 32 * grp + 8 * kk;
+    const f32x4 a0 = ld4(arow), a1 = ld4(arow + 4);
+    // the group's largest |dY| fixes its scale (both waves of the group find the same value)
+    float m = fmaxf(fmaxf(fmaxf(fabsf(a0[0]), fabsf(a0[1])), fmaxf(fabsf(a0[2]), fabsf(a0[3]))),
+                    fmaxf(fmaxf(fabsf(a1[0]), fabsf(a1[1])), fmaxf(fabsf(a1[2]), fabsf(a1[3]))));
+    m = wave_max(m);
+    const float sa = PrecX2::a_scale(m);
+    // column n = i over this lane's eight rows; the four row quarters kk are summed by the bias's thread below
+    if (half == 0) bpart[(grp * 4 + kk) * 16 + i] = ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a1[0] + a1[1]) + (a1[2] + a1[3]));
+    f16x8 ah, al;
+    x2_split8(a0 * sa, a1 * sa, ah, al);
+    const float un = 1.f / (sa * PrecX2::kFwdA);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const size_t brow = (size_t)(32 * half + 16 * t + i) * LDH + 32 * grp + 8 * kk;
+      const f16x8 xhi = *reinterpret_cast<const f16x8*>(xh + brow), xlo = *reinterpret_cast<const f16x8*>(xl + brow);
+      f32x4 acc = z4;
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xhi, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xlo, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xhi, acc, 0, 0, 0);
-    };
-    // (two steps per trip, not eight unrolled: hipcc hoists every LDS read of an unrolled loop to its top and the
-    // kernel — 128 VGPRs per lane at 1024 threads — spills)
-#pragma unroll 1
-    for (int s = 0; s < 8; s += 2) {
-      step(s, acc0);
-      step(s + 1, acc1);
-    }
-  }
-  stamp();   // MFMAs done
-#if defined(DW_X2_DEBUG) && DW_X2_DEBUG == 3
-  if (GATE == 1) return;
-#endif
-  const float unscale = ad.grad_scale / (sa * PrecX2::kFwdA);
-  // ---- Adam (torch.optim.Adam single-tensor semantics) and Polyak on the accumulators, as dw_adam_body's epilogue
+      float* o = part + ((size_t)grp * 16 + 4 * kk) * LDT + 32 * half + 16 * t + i;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float gr = (acc0[r] + acc1[r]) * unscale;
-    float th_new = 0.f, tt_new = 0.f;
-    if (e_ok[r]) {
-      const size_t eo = (size_t)(n_base + 4 * kk + r) * I.K + ek;
-      float mm = p_m[r], vv = p_v[r], th = p_th[r];
-      mm = mm + (gr - mm) * ad.omb1;
-      vv = vv * ad.beta2 + ad.omb2 * gr * gr;
-      th = th - step_size * (mm / (sqrtf(vv) / bc2_sqrt + ad.eps));
-      I.w_m[eo] = mm;
-      I.w_v[eo] = vv;
-      I.w[eo] = th;
-      th_new = th;
-      if (polyak) {
-        tt_new = p_tt[r] * ad.omtau + ad.tau * th;
-        I.w_t[eo] = tt_new;
-      }
+      for (int r = 0; r < 4; ++r) o[r * LDT] = acc[r] * un;
     }
-    tileW[4 * kk + r][16 * wave + i] = th_new;
-    tileT[4 * kk + r][16 * wave + i] = tt_new;
   }
-  // the bias gradient: column sums of dY — this lane's 64 rows, then over the four row groups kk
-  bsum += __shfl_xor(bsum, 16);
-  bsum += __shfl_xor(bsum, 32);
+  stamp();   // MFMAs done, partial tiles in LDS
+  __syncthreads();
+
+  // ---- thread = element: the eight groups' partials in group order, Adam (torch.optim.Adam single-tensor semantics)
+  // and Polyak as dw_adam_body's epilogue; the updated tile goes through LDS for the packs
+  float gsum = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) gsum += part[((size_t)q * 16 + nl) * LDT + kl];
+  gsum *= ad.grad_scale;
+  float th_new = 0.f, tt_new = 0.f;
+  if (e_ok) {
+    float mm = p_m, vv = p_v, th = p_th;
+    mm = mm + (gsum - mm) * ad.omb1;
+    vv = vv * ad.beta2 + ad.omb2 * gsum * gsum;
+    th = th - step_size * (mm / (sqrtf(vv) / bc2_sqrt + ad.eps));
+    I.w_m[eo] = mm;
+    I.w_v[eo] = vv;
+    I.w[eo] = th;
+    th_new = th;
+    if (polyak) {
+      tt_new = p_tt * ad.omtau + ad.tau * th;
+      I.w_t[eo] = tt_new;
+    }
+  }
+  tileW[nl * LDT + kl] = th_new;      // (the dY area: every wave is past its MFMAs)
+  tileT[nl * LDT + kl] = tt_new;
   if (b_own) {
-    const int n = n_base + i;
-    const float gb = bsum * ad.grad_scale;
+    const int n = n_base + tid;
+    float gb = 0.f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) gb += bpart[q * 16 + tid];
+    gb *= ad.grad_scale;
     float mm = q_m, vv = q_v, th = q_th;
     mm = mm + (gb - mm) * ad.omb1;
     vv = vv * ad.beta2 + ad.omb2 * gb * gb;
@@ -394,8 +394,49 @@ __device__ __forceinline__ void dw_tile_x2(const DwKArgs& A, float* lds, int bx)
     if (b_pol) I.b_t[n] = q_tt * ad.omtau + ad.tau * th;
   }
   __syncthreads();       // the updated tile is staged
-  dw_write_packs(I, tileW, tileT, tid, tk, n_base, 0, ptile, kDwTileN, NSk, NSn, polyak);
+
+  // ---- the two-plane fp16 packs (hi = fp16(2^8 w), lo = fp16(2^8 w - hi); the lo plane 256 floats behind the hi
+  // plane of a block), in pack order: threads 0..255 the forward packs (online | target) x two 32-column macro
+  // steps, threads 256..511 the W^T pack's four 16-row k tiles (this tile's n columns are one HALF of their block)
+  if (I.pf16 != nullptr) {
+    const int NSk2 = cdiv(I.K, 32), NSn2 = cdiv(I.N, 32);
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    if (tid < 256) {
+      const int which = tid >> 7, hb = (tid >> 6) & 1, l = tid & 63, li = l & 15, lk = l >> 4;
+      float* dst = which == 0 ? I.pf16 : (polyak ? I.tpf16 : nullptr);
+      if (dst != nullptr && 2 * tk + hb < NSk2) {
+        const float* src = (which == 0 ? tileW : tileT) + li * LDT + 32 * hb;
+        f16x8 hi, lo;
+        x2_split8(ld4(src + 4 * lk) * PrecX2::kWScale, ld4(src + 16 + 4 * lk) * PrecX2::kWScale, hi, lo);
+        float* d = dst + ((size_t)ptile * NSk2 + 2 * tk + hb) * 512 + (size_t)l * 4;
+        *reinterpret_cast<f16x8*>(d) = hi;
+        *reinterpret_cast<f16x8*>(d + 256) = lo;
+      }
+    } else if (tid < 512 && I.pb16 != nullptr) {
+      const int q = tid - 256, blk = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
+      const int ktile = 4 * tk + blk;
+      if (16 * ktile < I.K) {
+        f32x4 w4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w4[t] = tileW[(4 * lk + t) * LDT + 16 * blk + li];
+        const f32x4 vs = w4 * PrecX2::kWScale;
+        const f16x4 hi = __builtin_convertvector(vs, f16x4);
+        const f32x4 r = vs - __builtin_convertvector(hi, f32x4);
+        float* d = I.pb16 + ((size_t)ktile * NSn2 + (n_base >> 5)) * 512 + (size_t)l * 4 + 2 * ((n_base >> 4) & 1);
+        *reinterpret_cast<f16x4*>(d) = hi;
+        *reinterpret_cast<f16x4*>(d + 256) = __builtin_convertvector(r, f16x4);
+      }
+    }
+  }
   stamp();   // stores issued
+  }
+};
+
+template <int GATE>
+__device__ __forceinline__ void dw_tile_x2(const DwKArgs& A, float* lds, int bx) {
+  DwX2Tile<GATE> T;
+  T.begin(A, lds, bx);
+  T.finish();
 }
 
 }  // namespace oprl

@@ -47,7 +47,7 @@
 #include "dw_body.h"
 #include "dw_tile_x2.h"
 
-namespace oprl { constexpr bool kDwTileX2 = false; }   // the two-compute-wave tile of dw_tile_x2.h: measured slower (r03 log), off
+namespace oprl { constexpr bool kDwTileX2 = true; }    // PrecX2 learners: the 16 x 64 split-product tile of dw_tile_x2.h in the merged launches
 
 namespace oprl {
 
@@ -528,10 +528,12 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) { dd
 // phase 1 + the critic's dW tiles in one launch (both argument blocks by value; the tile workgroups index the
 // second one through the kernel-argument segment: scalar loads, as k_dw_adam does)
 constexpr size_t kMergedDwOffset = (sizeof(DdpgArgs) + alignof(DwKArgs) - 1) / alignof(DwKArgs) * alignof(DwKArgs);
-template <class P>
+// (WIDE: role A on clusters of eight — with the 84 16 x 64 tiles of a PrecX2 learner, which all find a compute unit when
+// roles C and B retire, long before the seeds; the 152 tiles of dw_body.h needed 64 free from the start)
+template <class P, bool WIDE = false>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase1_dw(const DdpgArgs A, const DwKArgs D) {
   const DwKArgs* Dp = (const DwKArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kMergedDwOffset);
-  ddpg_phase1_body<256, true, false, P, false, true>(A, Dp);
+  ddpg_phase1_body<256, true, false, P, WIDE, true>(A, Dp);
 }
 
 
@@ -846,8 +848,10 @@ struct RoleULds {   // floats
   static constexpr int total = out + kWaves * 256;
 };
 
-template <class P>
-__device__ __forceinline__ void role_u(const DdpgArgs& A, float* smem, int slice, int c) {
+// (T, D, tile: the tile this workgroup goes on with — PrecX2 — requests its rows once this role's own loads are in flight)
+struct NoTile { __device__ __forceinline__ void begin(const DwKArgs&, float*, int) {} };
+template <class P, class TileT>
+__device__ __forceinline__ void role_u(const DdpgArgs& A, float* smem, int slice, int c, TileT& T, const DwKArgs* D, int tile) {
   float* Wl = smem + RoleULds::w;
   float* h2s = smem + RoleULds::h2;
   float* w3s = smem + RoleULds::w3;
@@ -882,6 +886,7 @@ __device__ __forceinline__ void role_u(const DdpgArgs& A, float* smem, int slice
     const int gr = row0 + 4 * kk + r;
     m1[r] = gr < B ? A.aX[1][(size_t)gr * kW4 + 32 * c + 16 * t1 + i] : 0.f;
   }
+  if (tile >= 0) T.begin(*D, smem, tile);
 #pragma unroll
   for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(Wl + ((size_t)q * kThreads + tid) * 4) = wv[q];
   *reinterpret_cast<f32x4*>(h2s + hr * kWL4 + hc) = hv;
@@ -900,8 +905,7 @@ __device__ __forceinline__ void role_u(const DdpgArgs& A, float* smem, int slice
       // 2^12 (|w3| < 16), as the unit-seed tiles of tp4_scalar_fb do
       constexpr float sb = 4096.f;
       const float* bw = Wl + (size_t)t1 * 8 * 512 + lane * 4;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
+      auto step = [&](int s, f32x4& acc) {
         const FragX2 b{ld4(bw + s * 512), ld4(bw + s * 512 + 256)};
         const f32x4 h0 = ld4(hrow + 32 * s), h1v = ld4(hrow + 32 * s + 16);
         f32x4 x0 = ld4(w0 + 32 * s) * sb, x1 = ld4(w0 + 32 * s + 16) * sb;
@@ -910,8 +914,14 @@ __device__ __forceinline__ void role_u(const DdpgArgs& A, float* smem, int slice
           x0[t] = h0[t] > 0.f ? x0[t] : 0.f;
           x1[t] = h1v[t] > 0.f ? x1[t] : 0.f;
         }
-        if (s & 1) PrecX2::mma3(x0, x1, b, a1);
-        else PrecX2::mma3(x0, x1, b, a0);
+        PrecX2::mma3(x0, x1, b, acc);
+      };
+      // (two steps per trip: unrolled eight times hipcc hoists every LDS read to the top of the loop, and this role
+      // carries its tile's rows through it — 128 VGPRs per lane at 1024 threads)
+#pragma unroll 1
+      for (int s = 0; s < 8; s += 2) {
+        step(s, a0);
+        step(s + 1, a1);
       }
       a0 = (a0 + a1) * (PrecX2::kOut / sb);
       a1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -958,14 +968,31 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const DwKAr
   const int slice = blockIdx.x, row0 = slice * kR;
   const int y = (int)blockIdx.y;
   const int yP = NMC + kUMembers, yT = yP + (A.prefetch_next ? 1 : 0);
+  constexpr bool CONT = P::kX2 && kDwTileX2;     // role U's workgroups go on as tile workgroups (below)
   if (y >= yT) {   // a tile workgroup: all 16 waves (16 minibatch rows each)
-    const int tile = (y - yT) * (int)gridDim.x + slice;
+    const int tile = (CONT ? kUMembers * (int)gridDim.x : 0) + (y - yT) * (int)gridDim.x + slice;
     if (tile >= D->tile_end[kDwMaxItems - 1]) return;
-    if constexpr (P::kX2 && kDwTileX2) dw_tile_x2<2>(*D, smem, tile);
+    if constexpr (CONT) dw_tile_x2<2>(*D, smem, tile);
     else dw_adam_body<false, 2, 16>(*D, smem, tile);
     return;
   }
-  if (y >= NMC && y < yP) { role_u<P>(A, smem, slice, y - NMC); return; }
+  if (y >= NMC && y < yP) {
+    if constexpr (CONT) {
+      // role U's workgroup goes on as the tile workgroup of tile (slice, member): resident since the launch began — a
+      // workgroup dispatched when this one retires starts 1.2 us later with its whole input phase still in front of
+      // it — and its tile's rows and Adam state are requested from inside role U, behind that role's own requests:
+      // they have arrived when it is done, two microseconds before the critic pass publishes du
+      const int tile = slice * kUMembers + (y - NMC);
+      const bool has = tile < D->tile_end[kDwMaxItems - 1];
+      DwX2Tile<2> T;
+      role_u<P>(A, smem, slice, y - NMC, T, D, has ? tile : -1);
+      if (has) T.finish();
+    } else {
+      NoTile T;
+      role_u<P>(A, smem, slice, y - NMC, T, D, -1);
+    }
+    return;
+  }
   float* xa = smem + LY::xa;
   if (y == yP) {
     // ---- prefetch row: the next update's rows (as in ddpg_phase2_body)
@@ -1056,6 +1083,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2_dw(const DdpgArgs A, c
 
 static_assert(FusedLds<256>::total >= RoleULds::total, "role U fits the phase kernels' LDS");
 static_assert(FusedLds<256>::total >= kDwLdsFloats && FusedLds<256>::total >= DwLds<16>::floats && FusedLds<256>::total >= DwX2Lds::floats, "a tile workgroup fits the phase kernels' LDS");
+bool fused_x2_tiles() { return kDwTileX2; }
 
 size_t fused_ddpg_lds_bytes() { return sizeof(float) * FusedLds<256>::total; }
 size_t fused_xbuf_granules_per_cluster(int nc) { return (size_t)kTpStages * nc * kTpBlk; }
@@ -1084,6 +1112,7 @@ hipError_t init_fused_attrs() {
                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecF32>),
                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecBF16>),
                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecX2>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecX2, true>),
                       reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecF32, true>),
                       reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecF32, false>),
                       reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecX2, true>),
@@ -1123,11 +1152,13 @@ bool fused_ddpg_is_lean(const DdpgArgs& a) {
 // phase 1 with the critic's dW + Adam tiles as extra grid rows (DdpgArgs::merged bit 0; `d` = fill_dw_kargs of
 // that launch with its gate filled in)
 hipError_t launch_ddpg_phase1_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st) {
-  if (!lean_ok(a) || a.sac || a.n_critics != 1 || (a.wide & 1) != 0 || (a.merged & 1) == 0) return hipErrorInvalidValue;
+  const bool wide = (a.wide & 1) != 0;
+  if (!lean_ok(a) || a.sac || a.n_critics != 1 || (a.merged & 1) == 0 || (wide && (!a.x2 || a.xnc < 8))) return hipErrorInvalidValue;
   const int slices = (a.B + kR - 1) / kR;
   const int tiles = d.tile_end[kDwMaxItems - 1];
-  const dim3 grid(slices, 3 * a.nc + (tiles + slices - 1) / slices + (a.prefetch_p1 ? 1 : 0));
-  if (a.x2) hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
+  const dim3 grid(slices, 3 * a.nc + (wide ? 4 : 0) + (tiles + slices - 1) / slices + (a.prefetch_p1 ? 1 : 0));
+  if (a.x2 && wide) hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecX2, true>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
+  else if (a.x2) hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
   else if (a.bf16) hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
   else hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecF32>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
   return hipGetLastError();
@@ -1141,7 +1172,9 @@ hipError_t launch_ddpg_phase2_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_
   const int tiles = d.tile_end[kDwMaxItems - 1];
   const bool wide = (a.wide & 2) != 0;
   if (wide && a.xnc < 8) return hipErrorInvalidValue;
-  const dim3 grid(slices, (wide ? 8 : 4) + kUMembers + (a.prefetch_next ? 1 : 0) + (tiles + slices - 1) / slices);
+  // (PrecX2: role U's 8 x slices workgroups take the first tiles themselves, only the rest are rows of their own)
+  const int own = (a.x2 && kDwTileX2) ? (tiles > kUMembers * slices ? tiles - kUMembers * slices : 0) : tiles;
+  const dim3 grid(slices, (wide ? 8 : 4) + kUMembers + (a.prefetch_next ? 1 : 0) + (own + slices - 1) / slices);
   const dim3 blk(kThreads);
   const size_t lds = fused_ddpg_lds_bytes();
   if (a.x2) {

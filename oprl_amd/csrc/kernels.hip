@@ -330,12 +330,21 @@ static const float* dw_one_dev() {
 }
 
 // the kernel-side argument block of a (non-wide, single-rank) launch; returns the tile count or -1
-int fill_dw_kargs(const DwArgs& a, DwKArgs* k) {
+// tile_k: the k extent of a tile — kDwTile (k_dw_adam and the tiles of dw_body.h), or 64 (dw_tile_x2.h: the table is
+// recomputed for 16 x 64 tiles)
+int fill_dw_kargs(const DwArgs& a, DwKArgs* k, int tile_k) {
   if (a.n_items < 1 || a.n_items > kDwMaxItems || a.xchg != nullptr) return -1;
   int total = 0;
   for (int j = 0; j < a.n_items; ++j) {
     k->items[j] = a.items[j];
-    total += a.items[j].tile_end - a.items[j].tile_begin;
+    if (tile_k == kDwTile) {
+      total += a.items[j].tile_end - a.items[j].tile_begin;
+    } else {
+      k->items[j].tiles_k = (a.items[j].K + tile_k - 1) / tile_k;
+      k->items[j].tile_begin = total;
+      total += ((a.items[j].N + kDwTileN - 1) / kDwTileN) * k->items[j].tiles_k;
+      k->items[j].tile_end = total;
+    }
     k->tile_end[j] = total;
   }
   for (int j = a.n_items; j < kDwMaxItems; ++j) { k->items[j] = a.items[0]; k->tile_end[j] = total; }

@@ -176,7 +176,8 @@ hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st);
 hipError_t launch_ddpg_phase2_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st);
 hipError_t launch_ddpg_phase1_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
 hipError_t launch_ddpg_phase2_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
-int fill_dw_kargs(const DwArgs& a, DwKArgs* k);
+int fill_dw_kargs(const DwArgs& a, DwKArgs* k, int tile_k = 32);
+bool fused_x2_tiles();
 hipError_t launch_dw_adam_group(const DwKArgs* batch_dev, int n, int tiles, hipStream_t st);
 
 }  // namespace oprl
@@ -980,7 +981,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   // on phase 1 — whose role A then stays on a cluster of four: 64 CUs must be free for tile workgroups from the start
   if (!h->no_merge && h->nc == 1 && !a.sac && B <= 256 && !h->cfg.export_grads && !h->dp_inline && fused_ddpg_is_lean(a)) {
     a.merged |= 1;
-    a.wide &= ~1;
+    if (!(a.x2 && fused_x2_tiles())) a.wide &= ~1;     // (the 84 16 x 64 tiles of a PrecX2 learner get along with role A on eight)
   }
   // ... and the ACTOR's tiles on phase 2 (DDPG / TD3: the tanh head, action_dim <= kDuLd): the actor's backward runs
   // beside the critic pass with unit seeds (role U), the tiles combine with du (csrc/fused_ddpg.hip)
@@ -1131,7 +1132,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
       // phase 1 and the critic's dW + Adam tiles as ONE launch: the tiles wait for the roles' flag granules
       DwArgs dw = dw_build(h, true, B, true, false);
       DwKArgs kd;
-      if (fill_dw_kargs(dw, &kd) < 0) { set_err("merged phase 1: bad dW table"); return OPRL_ERR_INVALID; }
+      if (fill_dw_kargs(dw, &kd, (fa.x2 && fused_x2_tiles()) ? 64 : 32) < 0) { set_err("merged phase 1: bad dW table"); return OPRL_ERR_INVALID; }
       const int slices = (B + kR - 1) / kR;
       kd.gate.rows = fa.gate_flags; kd.gate.n_rows = 4 * slices;
       kd.gate.seed = fa.y_granules; kd.gate.n_seed = B;      // the seeds come as granules, one per row
@@ -1329,7 +1330,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
       // the tiles wait for the du granules
       DwArgs dw = dw_build(h, false, B, true, false);
       DwKArgs kd;
-      if (fill_dw_kargs(dw, &kd) < 0 || dw.n_items != 3) { set_err("merged phase 2: bad dW table"); return OPRL_ERR_INVALID; }
+      if (fill_dw_kargs(dw, &kd, (fa.x2 && fused_x2_tiles()) ? 64 : 32) < 0 || dw.n_items != 3) { set_err("merged phase 2: bad dW table"); return OPRL_ERR_INVALID; }
       const int slices = (B + kR - 1) / kR;
       kd.gate.rows = fa.u_flags; kd.gate.n_rows = 8 * slices;
       kd.gate.read = fa.u_flags + 128; kd.gate.n_read = 8 * slices;

@@ -37,7 +37,8 @@ class LearnerPlan:
     warmup_transitions: int = 1000       # per rank, before the first update
     updates_per_transition: float = 1.0  # optimiser steps per environment transition received (all ranks together)
     seed: int = 0
-    idle_timeout_s: float = 60.0         # give up when nothing arrives for this long before training could start
+    idle_timeout_s: float = 60.0         # nothing arrives for this long: before training could start an error, after it the end of the run
+    wall_timeout_s: float | None = None  # bound on the whole run (run_dp_training terminates the ranks beyond it)
 
 
 def run_ring_actor(make_env: Callable, make_policy: Callable, config, id_worker: int, ring_name: str,
@@ -139,30 +140,45 @@ def learner_rank_loop(rank: int, world: int, algo, buffer, rings: list[Transitio
     drain = RingDrainer(rings, buffer)
     t_begin = time.monotonic()
     t_parts = [0.0, 0.0, 0.0]          # enqueue the chunk / drain the rings / publish (= wait for the GPU)
+    stopped_early = None
+    sample_seed = getattr(buffer, "seed", None)      # the buffer's own (per-rank) sampler seed
+    if sample_seed is None:
+        sample_seed = plan.seed
     while done < plan.total_updates:
         ready = received >= plan.warmup_transitions and len(buffer) >= plan.batch_size
-        starved = (not ready) and (drain.exhausted() or time.monotonic() - t_last_data > plan.idle_timeout_s)
-        # one small all-reduce decides for everybody: [all ready?, anybody starved?, transitions received]
+        dry = drain.exhausted() or time.monotonic() - t_last_data > plan.idle_timeout_s   # nothing more is coming
+        starved = (not ready) and dry
+        # one small all-reduce decides for everybody: [all ready?, anybody starved?, every rank dry?, transitions received]
         k = 0
         if world > 1:
-            v = t.tensor([1.0 if ready else 0.0, 0.0 if starved else 1.0, float(received)], dtype=t.float64, device=dev)
+            v = t.tensor([1.0 if ready else 0.0, 0.0 if starved else 1.0, 1.0 if dry else 0.0, float(received)],
+                         dtype=t.float64, device=dev)
             lo = v.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
             tot = v.clone()
             dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
-            all_ready, any_starved, total_received = lo[0].item() == 1.0, lo[1].item() == 0.0, tot[2].item()
+            all_ready, any_starved, all_dry, total_received = (lo[0].item() == 1.0, lo[1].item() == 0.0,
+                                                               lo[2].item() == 1.0, tot[3].item())
         else:
-            all_ready, any_starved, total_received = ready, starved, float(received)
+            all_ready, any_starved, all_dry, total_received = ready, starved, dry, float(received)
         if any_starved:
             raise RuntimeError("a learner rank ran out of actor data before training could start")
         if all_ready:
             k = min(plan.chunk, plan.total_updates - done, int(plan.updates_per_transition * total_received) - done)
+            if k <= 0 and all_dry:
+                # the update quota of everything the actors ever delivered is used up and no ring will deliver more
+                # (actors finished, died, or their episodes ended early): the reference's learner gives up after
+                # learner_num_waits empty polls (distrib/policy_update_worker.py:55-63); this one returns what it has
+                # done instead of spinning on empty rings for ever
+                stopped_early = (f"actors delivered {int(total_received)} transitions = a quota of "
+                                 f"{int(plan.updates_per_transition * total_received)} updates of {plan.total_updates}")
+                break
         t0 = time.monotonic()
         if k > 0:      # enqueue the chunk (asynchronous on the GPU path) ...
             if solo:
-                eng.step_n(buffer.handle, k, plan.batch_size, seed=plan.seed)
+                eng.step_n(buffer.handle, k, plan.batch_size, seed=sample_seed)
             elif native:
-                dp.step_n(buffer.handle, k, plan.batch_size, seed=plan.seed)
+                dp.step_n(buffer.handle, k, plan.batch_size, seed=sample_seed)
             else:
                 for _ in range(k):
                     dp.update(*buffer.sample(plan.batch_size))
@@ -195,4 +211,4 @@ def learner_rank_loop(rank: int, world: int, algo, buffer, rings: list[Transitio
         board.stop()
     return dict(rank=rank, updates=done, received=received, chunks=chunks, train_s=t_train,
                 wall_s=time.monotonic() - t_begin, enqueue_s=t_parts[0], drain_s=t_parts[1], publish_wait_s=t_parts[2],
-                replica_spread=spread, policy_version=board.version)
+                replica_spread=spread, policy_version=board.version, stopped_early=stopped_early)

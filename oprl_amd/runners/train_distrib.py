@@ -85,6 +85,8 @@ def _dp_learner_main(rank: int, world: int, init_file: str, make_algo, make_repl
     dist.init_process_group(backend, init_method=f"file://{init_file}", rank=rank, world_size=world, **kw)
     t.manual_seed(plan.seed)                        # every replica starts from the same parameters
     algo = _call_with_overrides(make_algo, "make_algo", make_logger(), device=device, export_grads=world > 1)
+    if hasattr(algo, "set_seed"):
+        algo.set_seed(plan.seed, rank)              # the run seed reaches the device-side noise keys, per rank
     buffer = _call_with_overrides(make_replay_buffer, "make_replay_buffer", device=device, seed=plan.seed * 1000 + rank)
     rings = [TransitionRing(n) for n in ring_names]
     board = PolicyBoard(board_name)
@@ -148,8 +150,20 @@ def run_dp_training(*, make_env, make_algo, make_policy, make_replay_buffer, mak
                     os.environ[k] = v
         for p in ranks:
             p.start()
-        for p in ranks:
-            p.join()
+        # poll instead of a blind join: a rank that died takes the others down with it (they would wait in a
+        # collective for ever), and the whole run has a wall-clock bound
+        import time
+        t_end = None if getattr(plan, "wall_timeout_s", None) is None else time.monotonic() + plan.wall_timeout_s
+        while any(p.is_alive() for p in ranks):
+            dead = [p.exitcode for p in ranks if p.exitcode not in (None, 0)]
+            if dead or (t_end is not None and time.monotonic() > t_end):
+                for p in ranks:
+                    if p.is_alive():
+                        p.terminate()
+                board.stop()
+                raise RuntimeError(f"learner rank(s) failed with exit codes {dead}" if dead else
+                                   f"data-parallel training exceeded its wall-clock bound of {plan.wall_timeout_s} s")
+            time.sleep(0.2)
         board.stop()
         for p in actors:
             p.join(timeout=30)

@@ -194,3 +194,36 @@ def test_two_learner_ranks_fed_by_ring_actors_gloo():
         assert s["replica_spread"] == 0.0 and all(c == 0.0 for c in s["checks"])      # bit-identical replicas
     assert st[0]["actor_sum"] == st[1]["actor_sum"]
     assert st[0]["policy_version"] >= 4            # the initial policy + one publication per chunk
+
+
+def test_learner_loop_ends_when_the_actors_stop_short_of_the_update_quota():
+    """The round-2 advisor's livelock: every rank `ready`, the rings closed and drained, the update quota of what
+    arrived (updates_per_transition x received) below total_updates — the loop slept 2 ms for ever.  It must return
+    what it has done, and say so (the reference's learner gives up after learner_num_waits empty polls,
+    distrib/policy_update_worker.py:55-63)."""
+    from oracle import fixtures as fx
+    from oprl_amd.distrib.dp_learner import LearnerPlan, learner_rank_loop
+    from tests.oracle_engine import OracleDDPGEngine
+    import torch.distributed as dist
+    ring = TransitionRing(None, capacity=512, state_dim=WS, action_dim=WA, create=True)
+    board = PolicyBoard(None, n_floats=sum(x.numel() for x in fx.make_net(1, fx.actor_dims(WS, WA))), create=True)
+    td = tempfile.mkdtemp()
+    dist.init_process_group("gloo", init_method=f"file://{os.path.join(td, 'rdv')}", rank=0, world_size=1)
+    try:
+        rs = np.random.RandomState(0)
+        for k in range(200):                      # four whole episodes of 50, then the actor is gone
+            ring.push(rs.standard_normal(WS).astype(np.float32), rs.uniform(-1, 1, WA).astype(np.float32), 0.5, False,
+                      k % 50 == 49)
+        ring.close_writer()
+        eng = OracleDDPGEngine(WS, WA, fx.make_net(1, fx.actor_dims(WS, WA)), fx.make_net(2, fx.critic_dims(WS, WA)))
+        plan = LearnerPlan(total_updates=1000, batch_size=WB, chunk=8, warmup_transitions=100, seed=3,
+                           updates_per_transition=0.1)
+        t0 = time.monotonic()
+        stats = learner_rank_loop(0, 1, _Algo(eng), _CpuReplay(10), [ring], board, plan, native=False)
+        assert time.monotonic() - t0 < 60
+        assert stats["received"] == 200 and stats["updates"] == 20        # the quota of 200 transitions, not 1000
+        assert stats["stopped_early"] and "quota" in stats["stopped_early"]
+    finally:
+        dist.destroy_process_group()
+        ring.detach()
+        board.detach()

@@ -1,0 +1,35 @@
+"""x2 learner with the merged phase-1 tiles against an x2 learner with the critic's dW as a launch of its own: where do
+the critic's Adam moments differ after ONE update? (debug tool)"""
+import os, sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import numpy as np, torch as t
+from oprl_amd.algos.ddpg import DDPG
+from oprl_amd.logging import NullLogger
+from oracle import fixtures as fx
+
+def make(env):
+    for k, v in env.items(): os.environ[k] = v
+    t.manual_seed(0)
+    a = DDPG(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", precision="x2").create()
+    for k in env: os.environ[k] = "0"
+    return a
+a = make({"OPRL_AMD_NO_MERGE2": "1"})
+b = make({"OPRL_AMD_NO_MERGE2": "1", "OPRL_AMD_NO_MERGE": "1"})
+batch = [x.cuda() for x in fx.make_batch(110, 256, 24, 6)]
+a.update(*batch); b.update(*batch)
+t.cuda.synchronize()
+ma, mb = a.learner.critic_m.cpu().numpy(), b.learner.critic_m.cpu().numpy()
+dims = [(256, 30), (256,), (256, 256), (256,), (1, 256), (1,)]
+off = 0
+for i, d in enumerate(dims):
+    n = int(np.prod(d))
+    xa, xb = ma[off:off + n].reshape(d), mb[off:off + n].reshape(d)
+    off += n
+    nan = int(np.isnan(xa).sum())
+    diff = np.abs(np.nan_to_num(xa) - xb)
+    idx = np.unravel_index(diff.argmax(), diff.shape)
+    print(f"layer item {i} {d}: NaNs {nan}/{n}, max diff {diff.max():.3e} (ref max {np.abs(xb).max():.3e}) at {idx}; ratio sample {xa.flat[0] / (xb.flat[0] + 1e-30):.4f}")
+    if xa.ndim == 2 and nan:
+        rows = np.isnan(xa).any(1).nonzero()[0]; cols = np.isnan(xa).any(0).nonzero()[0]
+        print("   NaN rows", rows[:20], "cols", cols[:40])
