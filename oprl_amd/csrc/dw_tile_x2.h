@@ -56,13 +56,13 @@ static_assert(2 * 16 * DwX2Lds::LDT <= 16 * DwX2Lds::LDF, "the staged tiles fit 
 // begin(): the tile's header, its Adam state and (GATE 2) every row that does not depend on this launch; finish(): the
 // rest.  Two calls, so that a workgroup that has something else to do first (role U of phase 2, which goes on as a tile
 // workgroup) can have its rows in flight meanwhile.
-template <int GATE>
+template <int GATE, class KArgs = DwKArgs>
 struct DwX2Tile {
   static_assert(GATE == 1 || GATE == 2, "the gated tiles of the merged phase launches");
   static constexpr int TK = kDwX2TileK, LDF = DwX2Lds::LDF, LDH = DwX2Lds::LDH, LDT = DwX2Lds::LDT;
   // (only what must survive between begin() and finish(): the layer's table entry, the tile's coordinates and flags are
   // formed again in finish() — scalar work — instead of being carried through whatever runs in between)
-  const DwKArgs* KA;
+  const KArgs* KA;
   float* lds;
   int item, lt, n_stamp;
   float p_th, p_m, p_v, p_tt, q_th, q_m, q_v, q_tt;
@@ -79,7 +79,7 @@ struct DwX2Tile {
     ++n_stamp;
   }
 
-  __device__ __forceinline__ void begin(const DwKArgs& A, float* lds_, int bx) {
+  __device__ __forceinline__ void begin(const KArgs& A, float* lds_, int bx) {
     KA = &A;
     lds = lds_;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -138,7 +138,7 @@ struct DwX2Tile {
   }
 
   __device__ __forceinline__ void finish() {
-  const DwKArgs& A = *KA;
+  const KArgs& A = *KA;
   float* dyt = lds + DwX2Lds::dyt;
   _Float16* xh = reinterpret_cast<_Float16*>(lds + DwX2Lds::xh);
   _Float16* xl = reinterpret_cast<_Float16*>(lds + DwX2Lds::xl);
@@ -357,6 +357,12 @@ struct DwX2Tile {
 
   // ---- thread = element: the eight groups' partials in group order, Adam (torch.optim.Adam single-tensor semantics)
   // and Polyak as dw_adam_body's epilogue; the updated tile goes through LDS for the packs
+  // (a tile with a completion flag — k_ddpg_update's critic tiles, which the critic pass of the same launch waits for —
+  // writes what that pass reads FIRST: the online packs and the bias copy, then the flag, then the masters, the moments
+  // and the target's packs)
+  const bool flagged = G.done != nullptr;
+  const int bx_ = (item > 0 ? KA->tile_end[item - 1] : 0) + lt;
+  float e_m = 0.f, e_v = 0.f;
   float gsum = 0.f;
 #pragma unroll
   for (int q = 0; q < 8; ++q) gsum += part[((size_t)q * 16 + nl) * LDT + kl];
@@ -367,13 +373,14 @@ struct DwX2Tile {
     mm = mm + (gsum - mm) * ad.omb1;
     vv = vv * ad.beta2 + ad.omb2 * gsum * gsum;
     th = th - step_size * (mm / (sqrtf(vv) / bc2_sqrt + ad.eps));
-    I.w_m[eo] = mm;
-    I.w_v[eo] = vv;
-    I.w[eo] = th;
     th_new = th;
-    if (polyak) {
-      tt_new = p_tt * ad.omtau + ad.tau * th;
-      I.w_t[eo] = tt_new;
+    if (polyak) tt_new = p_tt * ad.omtau + ad.tau * th;
+    e_m = mm; e_v = vv;
+    if (!flagged) {
+      I.w_m[eo] = mm;
+      I.w_v[eo] = vv;
+      I.w[eo] = th;
+      if (polyak) I.w_t[eo] = tt_new;
     }
   }
   tileW[nl * LDT + kl] = th_new;      // (the dY area: every wave is past its MFMAs)
@@ -388,6 +395,7 @@ struct DwX2Tile {
     mm = mm + (gb - mm) * ad.omb1;
     vv = vv * ad.beta2 + ad.omb2 * gb * gb;
     th = th - step_size * (mm / (sqrtf(vv) / bc2_sqrt + ad.eps));
+    if (I.b16 != nullptr) I.b16[n] = th;      // (uncached copy for readers inside the same launch)
     I.b_m[n] = mm;
     I.b_v[n] = vv;
     I.b[n] = th;
@@ -404,7 +412,7 @@ struct DwX2Tile {
     if (tid < 256) {
       const int which = tid >> 7, hb = (tid >> 6) & 1, l = tid & 63, li = l & 15, lk = l >> 4;
       float* dst = which == 0 ? I.pf16 : (polyak ? I.tpf16 : nullptr);
-      if (dst != nullptr && 2 * tk + hb < NSk2) {
+      if (dst != nullptr && 2 * tk + hb < NSk2 && !(flagged && which == 1)) {
         const float* src = (which == 0 ? tileW : tileT) + li * LDT + 32 * hb;
         f16x8 hi, lo;
         x2_split8(ld4(src + 4 * lk) * PrecX2::kWScale, ld4(src + 16 + 4 * lk) * PrecX2::kWScale, hi, lo);
@@ -428,13 +436,37 @@ struct DwX2Tile {
       }
     }
   }
+  if (flagged) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_store(G.done + bx_, (unsigned long long)G.tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (e_ok) {
+      I.w_m[eo] = e_m;
+      I.w_v[eo] = e_v;
+      I.w[eo] = th_new;
+      if (polyak) I.w_t[eo] = tt_new;
+    }
+    if (I.pf16 != nullptr && polyak && I.tpf16 != nullptr && tid >= 128 && tid < 256) {
+      const int NSk2 = cdiv(I.K, 32);
+      const int hb = (tid >> 6) & 1, l = tid & 63, li = l & 15, lk = l >> 4;
+      if (2 * tk + hb < NSk2) {
+        const float* src = tileT + li * LDT + 32 * hb;
+        f16x8 hi, lo;
+        x2_split8(ld4(src + 4 * lk) * PrecX2::kWScale, ld4(src + 16 + 4 * lk) * PrecX2::kWScale, hi, lo);
+        float* d = I.tpf16 + ((size_t)ptile * NSk2 + 2 * tk + hb) * 512 + (size_t)l * 4;
+        *reinterpret_cast<f16x8*>(d) = hi;
+        *reinterpret_cast<f16x8*>(d + 256) = lo;
+      }
+    }
+  }
   stamp();   // stores issued
   }
 };
 
-template <int GATE>
-__device__ __forceinline__ void dw_tile_x2(const DwKArgs& A, float* lds, int bx) {
-  DwX2Tile<GATE> T;
+template <int GATE, class KArgs = DwKArgs>
+__device__ __forceinline__ void dw_tile_x2(const KArgs& A, float* lds, int bx) {
+  DwX2Tile<GATE, KArgs> T;
   T.begin(A, lds, bx);
   T.finish();
 }

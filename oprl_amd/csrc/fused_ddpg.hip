@@ -38,6 +38,7 @@
 // (update()) or is gathered in-kernel from the HBM replay with the same Philox
 // draw and index map as k_replay_gather (step_n).
 #include <cstddef>
+#include <type_traits>
 #include "kernels.h"
 #include "philox.h"
 #include "replay_index.h"
@@ -261,20 +262,27 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
 // (role C's after 7 us, role B's after 8.5), take in their Adam state and — once role B's members have flagged
 // their rows — X and dY, and wait for role A's seed flags: what is left after the launch's critical chain is one
 // flag hop, 16 MFMAs and the Adam epilogue instead of a kernel boundary and a whole k_dw_adam launch.
-template <int WIDTH, bool LEAN, bool SAC, class P, bool WIDE = false, bool MERGED = false>
-__device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const DwKArgs* D = nullptr) {
+__device__ __forceinline__ int dw_total(const DwKArgs& d) { return d.tile_end[kDwMaxItems - 1]; }
+__device__ __forceinline__ int dw_total(const DwKArgs4& d) { return d.tile_end[kDwFusedItems - 1]; }
+
+// (`by`: this workgroup's row of the roles' / tiles' block — blockIdx.y unless the caller runs the body inside a larger
+// grid: k_ddpg_update)
+template <int WIDTH, bool LEAN, bool SAC, class P, bool WIDE = false, bool MERGED = false, class KA = DwKArgs>
+__device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const KA* D = nullptr, int by_in = -1) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int by = by_in < 0 ? (int)blockIdx.y : by_in;
   // the last grid row of a step_n launch may be the PREFETCH row: the next update's rows (dispatched last: these
   // workgroups start as roles retire) into the other staging set — the same load_batch call as the roles', from A.next
   const bool pf_row = A.prefetch_p1 && blockIdx.y == gridDim.y - 1;
   if constexpr (MERGED) {
     const int rows = (2 + A.n_critics) * A.nc + ((LEAN && WIDE) ? 4 : 0);
-    if ((int)blockIdx.y >= rows && !pf_row) {
-      const int tile = ((int)blockIdx.y - rows) * (int)gridDim.x + (int)blockIdx.x;
-      if (tile >= D->tile_end[kDwMaxItems - 1]) return;
+    if (by >= rows && !pf_row) {
+      // (whole-update launch: roles B and C go on as the first 8 x slices tiles themselves, below)
+      const int tile = (A.whole ? 8 * (int)gridDim.x : 0) + (by - rows) * (int)gridDim.x + (int)blockIdx.x;
+      if (tile >= dw_total(*D)) return;
       if constexpr (P::kX2 && kDwTileX2) {
-        dw_tile_x2<1>(*D, smem, tile);            // all 16 waves load, two compute (dw_tile_x2.h)
-      } else {
+        dw_tile_x2<1, KA>(*D, smem, tile);        // the 16 x 64 split-product tile (dw_tile_x2.h), all 16 waves
+      } else if constexpr (std::is_same<KA, DwKArgs>::value) {
         if (threadIdx.x >= kDwThreads) return;    // a tile workgroup is the first 8 waves (the stand-alone kernel's shape and arithmetic)
         dw_adam_body<false, 1>(*D, smem, tile);
       }
@@ -307,10 +315,10 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const DwKArg
   const int nA = (LEAN && WIDE) ? 8 : A.nc;
   int role, member;
   if constexpr (!LEAN) {
-    role = (int)blockIdx.y / A.nc;
-    member = (int)blockIdx.y % A.nc;
+    role = by / A.nc;
+    member = by % A.nc;
   } else {
-    const int y = (int)blockIdx.y, yb = A.n_critics * A.nc;
+    const int y = by, yb = A.n_critics * A.nc;
     if (y < yb) { role = 1 + y / A.nc; member = y % A.nc; }
     else if (y < yb + nA) {
       // (wide: slice-major like every role — all members of a slice on one XCD; member-major ids, eight
@@ -393,6 +401,25 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const DwKArg
             *reinterpret_cast<f32x4*>(A.w3_snap + idx) = ld4(A.w3_src + idx);
       }
       stamp();
+      if (A.whole) {
+        // role U and the critic pass of this very launch read what this member has stored (uncached memory): the flag
+        // follows the acknowledgement of every wave's stores
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+          __hip_atomic_store(A.w_flags + slice * 4 + tp.c, (unsigned long long)A.epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if constexpr (MERGED && P::kX2 && kDwTileX2) {
+      if (A.whole) {
+        // ... and goes on as one of the critic's tile workgroups (k_ddpg_update): no compute unit has to come free
+        // for those, so the critic pass — dispatched behind them — is resident, all eight members per slice, when role
+        // A retires, long before the tiles' flags
+        __syncthreads();
+        const int tile = 4 * (int)gridDim.x + slice * 4 + tp.c;
+        if (tile < dw_total(*D)) dw_tile_x2<1, KA>(*D, smem, tile);
+        return;
+      }
     }
     if (!A.twin_split) return;
     // ---- ... then target critic 2 on (s', a') with role A's a'
@@ -520,6 +547,13 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const DwKArg
   // registers: profiles/r01b_experiments.txt #10).
   if (role == 2) { role_b<WIDTH, LEAN, P>(A, A.critic2, A.c2X, A.c2dY, A.partials_c + (size_t)gridDim.x * 4, false, 1, smem, tp, stamp); return; }
   role_b<WIDTH, LEAN, P>(A, A.critic, A.cX, A.cdY, A.partials_c, true, 0, smem, tp, stamp);
+  if constexpr (MERGED && P::kX2 && kDwTileX2) {
+    if (A.whole) {       // (as role C above: this workgroup goes on as critic tile (slice, member))
+      __syncthreads();
+      const int tile = slice * 4 + tp.c;
+      if (tile < dw_total(*D)) dw_tile_x2<1, KA>(*D, smem, tile);
+    }
+  }
 }
 
 template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32, bool WIDE = false>
@@ -849,9 +883,21 @@ struct RoleULds {   // floats
 };
 
 // (T, D, tile: the tile this workgroup goes on with — PrecX2 — requests its rows once this role's own loads are in flight)
-struct NoTile { __device__ __forceinline__ void begin(const DwKArgs&, float*, int) {} };
-template <class P, class TileT>
-__device__ __forceinline__ void role_u(const DdpgArgs& A, float* smem, int slice, int c, TileT& T, const DwKArgs* D, int tile) {
+struct NoTile { template <class KA> __device__ __forceinline__ void begin(const KA&, float*, int) {} };
+// one bounded wait for n flag granules {tag, *}: thread k polls flag k (n <= threads); the caller's barrier releases everybody
+__device__ __forceinline__ void wait_flags(const unsigned long long* flags, int n, unsigned tag, unsigned* err, unsigned code) {
+  const int k = (int)threadIdx.x;
+  if (k < n) {
+    bool ok = false;
+    for (int spin = 0; spin < kTpSpin && !ok; ++spin) {
+      ok = (unsigned)(__hip_atomic_load(flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == tag;
+      if (!ok) __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ok) report_expired(err, code);
+  }
+}
+template <class P, class TileT, class KA>
+__device__ __forceinline__ void role_u(const DdpgArgs& A, float* smem, int slice, int c, TileT& T, const KA* D, int tile) {
   float* Wl = smem + RoleULds::w;
   float* h2s = smem + RoleULds::h2;
   float* w3s = smem + RoleULds::w3;
@@ -868,6 +914,13 @@ __device__ __forceinline__ void role_u(const DdpgArgs& A, float* smem, int slice
     ++n_stamp;
   };
   stamp();
+  if (A.whole) {
+    // (k_ddpg_update) role C of this very launch writes what this role reads — uncached memory: its members' flags,
+    // then an invalidate of this CU's L1, which an earlier workgroup may have left lines of those buffers in
+    wait_flags(A.w_flags, 4 * (int)gridDim.x, A.epoch, A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
+    __syncthreads();
+    asm volatile("buffer_inv sc0" ::: "memory");
+  }
   // ---- requests: the shard (32 KB, two b128 per thread), the slice's h2 rows, the output layer's snapshot, and
   // this lane's h1 elements (the mask of what it will finish)
   const float* wsrc = A.actor.pb[1] + (size_t)c * 2 * 16 * 256;
@@ -958,22 +1011,27 @@ __device__ __forceinline__ void role_u(const DdpgArgs& A, float* smem, int slice
     __hip_atomic_store(A.u_flags + slice * kUMembers + c, (unsigned long long)A.epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <class P, bool WIDE>
-__device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const DwKArgs* D) {
+template <class P, bool WIDE, class KA = DwKArgs>
+__device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const KA* D, int by_in = -1) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<256>;
   constexpr int HB = kR * kWL4;
   constexpr int NMC = WIDE ? 8 : 4;
   const int B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
   const int slice = blockIdx.x, row0 = slice * kR;
-  const int y = (int)blockIdx.y;
+  const int y = by_in < 0 ? (int)blockIdx.y : by_in;
   const int yP = NMC + kUMembers, yT = yP + (A.prefetch_next ? 1 : 0);
   constexpr bool CONT = P::kX2 && kDwTileX2;     // role U's workgroups go on as tile workgroups (below)
   if (y >= yT) {   // a tile workgroup: all 16 waves (16 minibatch rows each)
     const int tile = (CONT ? kUMembers * (int)gridDim.x : 0) + (y - yT) * (int)gridDim.x + slice;
-    if (tile >= D->tile_end[kDwMaxItems - 1]) return;
-    if constexpr (CONT) dw_tile_x2<2>(*D, smem, tile);
-    else dw_adam_body<false, 2, 16>(*D, smem, tile);
+    if (tile >= dw_total(*D)) return;
+    if (A.whole) {      // (k_ddpg_update: the rows this tile reads are role C's of this very launch, as role U's are)
+      wait_flags(A.w_flags, 4 * (int)gridDim.x, A.epoch, A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
+      __syncthreads();
+      asm volatile("buffer_inv sc0" ::: "memory");
+    }
+    if constexpr (CONT) dw_tile_x2<2, KA>(*D, smem, tile);
+    else if constexpr (std::is_same<KA, DwKArgs>::value) dw_adam_body<false, 2, 16>(*D, smem, tile);
     return;
   }
   if (y >= NMC && y < yP) {
@@ -983,8 +1041,8 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const DwKAr
       // it — and its tile's rows and Adam state are requested from inside role U, behind that role's own requests:
       // they have arrived when it is done, two microseconds before the critic pass publishes du
       const int tile = slice * kUMembers + (y - NMC);
-      const bool has = tile < D->tile_end[kDwMaxItems - 1];
-      DwX2Tile<2> T;
+      const bool has = tile < dw_total(*D);
+      DwX2Tile<2, KA> T;
       role_u<P>(A, smem, slice, y - NMC, T, D, has ? tile : -1);
       if (has) T.finish();
     } else {
@@ -1022,14 +1080,15 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const DwKAr
   float* outS = smem + LY::out;
   float* auxS = smem + LY::aux;
   float* scr = smem + LY::scr;
-  Tp tp{y, NMC, A.xbuf + (size_t)slice * kTpStages * A.xnc * kTpBlk, A.cluster_tag, 0,
+  Tp tp{y, NMC, A.xbuf + (size_t)slice * kTpStages * A.xnc * kTpBlk, A.whole ? A.cluster_tag2 : A.cluster_tag, 0,
         A.err, KERN_PHASE2 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
   const bool lead = tp.c == 0;
+  long long* const trace = A.whole ? A.trace2 : A.trace;
   int n_stamp = 0;
   auto stamp = [&]() {
-    if (A.trace != nullptr && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
+    if (trace != nullptr && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
       const int slot = tid == 0 ? slice : 16 + (tid >> 6);
-      long long* tr = A.trace + ((size_t)slot * kTraceStamps + n_stamp) * 2;
+      long long* tr = trace + ((size_t)slot * kTraceStamps + n_stamp) * 2;
       tr[0] = (long long)__builtin_readcyclecounter();
       tr[1] = (long long)wall_clock64();
     }
@@ -1037,6 +1096,14 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const DwKAr
   };
   stamp();
   const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
+  Net critic = A.critic;
+  if (A.whole) {
+    // (k_ddpg_update) role C of this launch wrote s and pi — uncached memory: its members' flags, then an invalidate of
+    // this CU's L1; the critic's packs and biases follow below, behind the rows
+    wait_flags(A.w_flags, 4 * (int)gridDim.x, A.epoch, A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
+    __syncthreads();
+    asm volatile("buffer_inv sc0" ::: "memory");
+  }
   {
     const float* p0 = A.aX[0]; const float* p3 = A.pi; const int ld0 = A.aldx0;
     asm volatile("" :: "s"(p0), "s"(p3), "s"(ld0));
@@ -1058,13 +1125,29 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const DwKAr
   if (tid < kR * S) xa[rs_ * kX0Ld + cs_] = vs;
   if (tid2 < kR * S) xa[rs2_ * kX0Ld + cs2_] = vs2;
   if (tid < kR * Ad) xa[rp_ * kX0Ld + S + cp_] = vp;
+  if (A.whole) {
+    // ... the critic's TILES of this launch wrote the critic's fp16 packs and biases (uncached memory): their flags
+    // (one poller each), the invalidate; the biases come from the tiles' uncached copies (the masters sit dirty in
+    // another XCD's L2)
+    if (tid < A.n_ct) {
+      bool ok = false;
+      for (int spin = 0; spin < kTpSpin && !ok; ++spin) {
+        ok = (unsigned)(__hip_atomic_load(A.ct_done + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == A.epoch;
+        if (!ok) __builtin_amdgcn_s_sleep(1);
+      }
+      if (!ok) report_expired(A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
+    }
+    __syncthreads();
+    asm volatile("buffer_inv sc0" ::: "memory");
+    critic.b[0] = A.critic_b16[0]; critic.b[1] = A.critic_b16[1]; critic.b[2] = A.critic_b16[2];
+  }
   stamp();
   float* qsum = nullptr;
   if (A.partials_a != nullptr && lead) {
     qsum = A.partials_a + slice * 4 + 1;
     if (tid == 0) { A.partials_a[slice * 4 + 0] = 0.f; A.partials_a[slice * 4 + 2] = 0.f; }
   }
-  tp4_scalar_fb<P, NMC>(A.critic, xa, h1, h2, g2, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum);
+  tp4_scalar_fb<P, NMC>(critic, xa, h1, h2, g2, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum);
   stamp();   // da ready
   // du = da (1 - pi^2): every member holds the same da; the lead member publishes (rows beyond B are never polled)
   if (lead && okp) {
@@ -1079,6 +1162,37 @@ template <class P, bool WIDE>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase2_dw(const DdpgArgs A, const DwKArgs D) {
   const DwKArgs* Dp = (const DwKArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kMergedDwOffset);
   ddpg_phase2m_body<P, WIDE>(A, Dp);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The WHOLE update as one launch (PrecX2 learners, DDPG, B <= 256): the rows of the merged phase 1 — roles B | A (on
+// eight) | C, the critic's tiles — followed by the rows of the merged phase 2 — role U (going on as the actor's tiles),
+// the critic pass — and the prefetch row.  Workgroups are dispatched in this order and only ever wait for workgroups
+// dispatched before them: role U for role C, the critic pass for role C and the critic's tiles, every tile for its
+// seeds.  By the time the critic pass has all its eight members per slice resident (the critic's tiles have retired)
+// its inputs exist.  What used to cross the kernel boundary between the two launches — the critic's new packs and
+// biases, pi, the actor's activations — lives in uncached memory and travels behind flags (DdpgArgs::whole).
+// One launch gap (~3 us of an update) less.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr size_t kWholeDcOffset = (sizeof(DdpgArgs) + alignof(DwKArgs4) - 1) / alignof(DwKArgs4) * alignof(DwKArgs4);
+constexpr size_t kWholeDaOffset = (kWholeDcOffset + sizeof(DwKArgs4) + alignof(DwKArgs4) - 1) / alignof(DwKArgs4) * alignof(DwKArgs4);
+template <class P>
+__global__ __launch_bounds__(kThreads) void k_ddpg_update(const DdpgArgs A, const DwKArgs4 Dc, const DwKArgs4 Da) {
+  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  const DwKArgs4* Dcp = (const DwKArgs4*)(ka + kWholeDcOffset);
+  const DwKArgs4* Dap = (const DwKArgs4*)(ka + kWholeDaOffset);
+  const int slices = (int)gridDim.x;
+  // roles (B 4 | A 8 | C 4) + those of the critic's tiles that roles B and C do not go on with themselves
+  const int tc = Dcp->tile_end[kDwFusedItems - 1];
+  const int rows1 = 3 * 4 + 4 + ((tc > 8 * slices ? tc - 8 * slices : 0) + slices - 1) / slices;
+  const int y = (int)blockIdx.y;
+  if (y < rows1 || (A.prefetch_p1 && y == (int)gridDim.y - 1)) ddpg_phase1_body<256, true, false, P, true, true, DwKArgs4>(A, Dcp, y);
+  else {
+    // (ddpg_phase2m_body's rows are [0, 8) the critic pass | [8, 16) role U | tiles: here role U is dispatched first —
+    // measured: the critic pass first leaves role U without compute units until the critic's tiles retire, 2 us worse)
+    const int y2 = y - rows1;
+    ddpg_phase2m_body<P, true, DwKArgs4>(A, Dap, y2 < 8 ? y2 + 8 : (y2 < 16 ? y2 - 8 : y2));
+  }
 }
 
 static_assert(FusedLds<256>::total >= RoleULds::total, "role U fits the phase kernels' LDS");
@@ -1116,7 +1230,8 @@ hipError_t init_fused_attrs() {
                       reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecF32, true>),
                       reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecF32, false>),
                       reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecX2, true>),
-                      reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecX2, false>)};
+                      reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecX2, false>),
+                      reinterpret_cast<const void*>(&k_ddpg_update<PrecX2>)};
   for (const void* k : ks) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -1184,6 +1299,20 @@ hipError_t launch_ddpg_phase2_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_
     if (wide) hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecF32, true>), grid, blk, lds, st, a, d);
     else hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecF32, false>), grid, blk, lds, st, a, d);
   }
+  return hipGetLastError();
+}
+
+// the whole update as one launch (DdpgArgs::whole; `dc` / `da`: the critic's and the actor's tile tables with their gates)
+hipError_t launch_ddpg_update(const DdpgArgs& a, const DwKArgs4& dc, const DwKArgs4& da, hipStream_t st) {
+  if (!lean_ok(a) || a.sac || !a.x2 || !kDwTileX2 || a.n_critics != 1 || !a.whole || (a.merged & 3) != 3 || (a.wide & 3) != 3 ||
+      a.xnc < 8 || a.A > kDuLd || a.B > 256 || a.prefetch_next)
+    return hipErrorInvalidValue;
+  const int slices = (a.B + kR - 1) / kR;
+  const int tc = dc.tile_end[kDwFusedItems - 1], ta = da.tile_end[kDwFusedItems - 1];
+  const int own = ta > kUMembers * slices ? ta - kUMembers * slices : 0;
+  const int ownc = tc > 8 * slices ? tc - 8 * slices : 0;
+  const dim3 grid(slices, 16 + (ownc + slices - 1) / slices + kUMembers + 8 + (own + slices - 1) / slices + (a.prefetch_p1 ? 1 : 0));
+  hipLaunchKernelGGL((k_ddpg_update<PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, dc, da);
   return hipGetLastError();
 }
 

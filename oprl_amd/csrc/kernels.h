@@ -93,6 +93,7 @@ struct DwItem {      // one Linear layer of one net
   float *pf, *pb, *tpf;                // fragment-order packs: W (fwd), W^T (bwd), target W (fwd)
   float *pf16, *pb16, *tpf16;          // the same three as bf16 packs (PrecBF16, engine.h), or null: fp32-only learner
   int x2;                              // 1: those three are PrecX2 packs (blocks of two fp16 planes, 2^8 w)
+  float* b16;                          // copy of the bias in UNCACHED memory (or null): what a workgroup of the same launch reads (k_ddpg_update's critic pass)
   int tiles_k, tile_begin, tile_end;
   int tile_n;                          // n rows per tile: kDwTileN, or 8 for a layer that sums dz1 partials
   long dY_part_stride;                 // > 0: dY is the sum of DwArgs::n_part buffers this many floats apart
@@ -234,6 +235,9 @@ struct DwGate {
   //   kind 1  second hidden: dY[b, n] = (h2[b, n] > 0) * sum_j du[b, j] W3[j, n]      (h2 rows, W3 snapshot `w3`)
   //   kind 2  first hidden:  dY[b, n] = sum_j du[b, j] U_j[b, n]                      (role U's unit backward rows)
   // U: [16-column tile][n_act][B][16] floats, written through by role U of the same launch (flags `rows`).
+  // k_ddpg_update (the whole update as one launch): a tile raises done[tile] = {tag, *} when its stores have been
+  // acknowledged (the critic's tiles: the critic pass of the same launch waits for them); null: no flag
+  unsigned long long* done = nullptr;
   int kind[4] = {0, 0, 0, 0};          // per item of the launch
   const unsigned long long* read = nullptr; int n_read = 0;   // role U has taken in what it reads of the actor's packs: only then may a tile's epilogue rewrite them
   const float* h2 = nullptr;           // [B][256] the actor's second hidden activations (written by the launch before)
@@ -256,6 +260,18 @@ struct DwKArgs {
   DwXchg xchg;                         // k_dw_adam<true> only
   AlphaJob alpha;                      // workgroup `tile_end[n_items - 1]` (one past the tiles) runs it
   DwGate gate;                         // dw_adam_body<*, GATED> only
+};
+
+// the same for the tiles of dw_tile_x2.h (PrecX2 learners: at most four layers per net), a quarter of the bytes: the
+// whole-update launch carries two of them beside its DdpgArgs
+constexpr int kDwFusedItems = 4;
+struct DwKArgs4 {
+  int tile_end[kDwFusedItems];
+  DwItem items[kDwFusedItems];
+  int n_items, B, n_part, dy_tiled;
+  AdamScalars ad;
+  long long* trace;
+  DwGate gate;
 };
 
 struct BatchSrc {
@@ -341,6 +357,16 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   unsigned long long* du_granules;     // [B][kDuLd] {epoch, du}
   unsigned long long* u_flags;         // [0, 128): role U's members have written their rows through; [128, 256): ... have read the actor's packs
   float* U;                            // [16][A][B][16] unit-seed dz1 of the actor (role U -> first-layer tiles)
+  // k_ddpg_update: phase 1's roles, the critic's tiles, role U (+ the actor's tiles) and phase 2's critic pass in ONE
+  // launch.  What a role hands to a later one crosses no kernel boundary: it lives in uncached memory (the learner's
+  // workspace and fp16 packs), is written before a flag {epoch, *} — w_flags[0, 64): role C's members, the critic's tiles
+  // raise DwGate::done — and read after the flag and an L1 invalidate.
+  int whole;
+  unsigned cluster_tag2;               // the critic pass's exchange tag (phase 2's cluster_tag in the two-launch form)
+  long long* trace2;                   // ... and its trace slot
+  unsigned long long* w_flags;
+  unsigned long long* ct_done; int n_ct;   // the critic's tiles' completion flags
+  const float* critic_b16[kMaxLayers]; // the critic's biases as its tiles of this launch leave them (uncached copies)
   float* w3_snap;                      // the actor's output layer [A][256] as it is before phase 2, copied by phase 1's role C (slice 0)
   const float* w3_src;                 // ... from here (the row-major master)
   int no_lean;                         // 1: never use the tp4.h specialisation (OPRL_AMD_NO_LEAN, tests)

@@ -174,6 +174,7 @@ hipError_t launch_ddpg_phase1_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_
 bool fused_ddpg_is_lean(const DdpgArgs& a);
 hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st);
 hipError_t launch_ddpg_phase2_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st);
+hipError_t launch_ddpg_update(const DdpgArgs& a, const DwKArgs4& dc, const DwKArgs4& da, hipStream_t st);
 hipError_t launch_ddpg_phase1_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
 hipError_t launch_ddpg_phase2_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
 int fill_dw_kargs(const DwArgs& a, DwKArgs* k, int tile_k = 32);
@@ -469,6 +470,13 @@ struct oprl_learner {
   // the nets' own forward (oprl_mlp_forward / act / backward), a generic launch sequence — gets them rebuilt from the
   // master first (fresh32): [0] the critics' (online + target), [1] the actor's
   bool stale32[2] = {false, false};
+  float* uc_base = nullptr;    // the fp16 packs' uncached allocation (PrecX2 learners)
+  bool uc_pool = false;        // the workspace pool is uncached memory as well
+  // k_ddpg_update (the whole update as one launch): role C's / the critic tiles' flags, the critic's uncached bias copies
+  unsigned long long* w_flags = nullptr;
+  float* critic_b16 = nullptr;
+  int no_whole = 0;            // OPRL_AMD_NO_WHOLE: two launches per update (merged phase 1, merged phase 2)
+  bool whole_done = false;     // this update's actor phase was part of the critic phase's launch
   float* pack16[OPRL_MAX_CRITICS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   float* pack16_t[OPRL_MAX_CRITICS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // prebuilt device repack tables: [0] critics online, [1] critics online+target, [2] actor (+target)
@@ -1003,6 +1011,15 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
       a.w3_snap = h->w3_snap;
     }
   }
+  // the whole update as ONE launch (k_ddpg_update): both merged forms, role A and the critic pass on eight, the 16 x 64
+  // tiles, and everything the roles hand to each other in uncached memory
+  if (!h->no_whole && a.x2 && fused_x2_tiles() && h->nc == 1 && (a.merged & 3) == 3 && (a.wide & 3) == 3 && h->uc_pool &&
+      h->uc_base != nullptr && h->w_flags != nullptr) {
+    a.whole = 1;
+    a.w_flags = h->w_flags;
+    a.ct_done = h->w_flags + 64;
+    for (int l = 0; l < c.critics[0].n_layers; ++l) a.critic_b16[l] = h->critic_b16 + 256 * l;
+  }
   return a;
 }
 
@@ -1116,6 +1133,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
       if (h->du_granules != nullptr) {
         HIPC(hipMemsetAsync(h->du_granules, 0, (size_t)(h->Bmax < 256 ? h->Bmax : 256) * kDuLd * sizeof(unsigned long long), st));
         HIPC(hipMemsetAsync(h->u_flags, 0, 256 * sizeof(unsigned long long), st));
+        HIPC(hipMemsetAsync(h->w_flags, 0, 256 * sizeof(unsigned long long), st));
       }
     }
     DdpgArgs fa = ddpg_args(h, B);
@@ -1128,6 +1146,57 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &fa.cluster_tag));
     if (h->trace != nullptr) fa.trace = h->trace;   // roles use slots 0 .. 1 + n_critics
     HIPC(chain_before(st));
+    h->whole_done = false;
+    if (fa.whole && B <= 256) {
+      // the whole update as ONE launch (k_ddpg_update): phase 1's roles, the critic's tiles, role U + the actor's
+      // tiles, the critic pass
+      RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &fa.cluster_tag2));
+      if (h->trace != nullptr && c.algo == OPRL_DDPG) fa.trace2 = h->trace + (size_t)3 * 64 * kTraceStamps * 2;   // slot 3
+      fa.prefetch_next = 0;
+      const int slices = (B + kR - 1) / kR;
+      DwKArgs kd;
+      DwKArgs4 kc, ka;
+      auto compact = [&](const DwKArgs& k, DwKArgs4* o) {
+        for (int j = 0; j < kDwFusedItems; ++j) { o->tile_end[j] = k.tile_end[j]; o->items[j] = k.items[j]; }
+        o->n_items = k.n_items; o->B = k.B; o->n_part = k.n_part; o->dy_tiled = k.dy_tiled; o->ad = k.ad; o->trace = k.trace;
+        o->gate = k.gate;
+      };
+      {
+        DwArgs dw = dw_build(h, true, B, true, false);
+        if (fill_dw_kargs(dw, &kd, 64) < 0 || dw.n_items > kDwFusedItems) { set_err("whole update: bad critic dW table"); return OPRL_ERR_INVALID; }
+        kd.gate.rows = fa.gate_flags; kd.gate.n_rows = 4 * slices;
+        kd.gate.seed = fa.y_granules; kd.gate.n_seed = B;
+        kd.gate.late_dY = h->ws_critic[0].dY[c.critics[0].n_layers - 1];
+        kd.gate.tag = h->epoch; kd.gate.spin = h->debug_expire == 7 ? 0 : (1 << 20);
+        kd.gate.err = h->err_dev; kd.gate.err_code = (1u << 8) | 7u;
+        kd.gate.done = fa.ct_done;
+        fa.n_ct = kd.tile_end[kDwMaxItems - 1];
+        if (fa.n_ct > 192 - 64) { set_err("whole update: too many critic tiles"); return OPRL_ERR_INVALID; }
+        compact(kd, &kc);
+      }
+      {
+        DwArgs dw = dw_build(h, false, B, true, false);
+        if (fill_dw_kargs(dw, &kd, 64) < 0 || dw.n_items != 3) { set_err("whole update: bad actor dW table"); return OPRL_ERR_INVALID; }
+        kd.gate.rows = fa.u_flags; kd.gate.n_rows = 8 * slices;
+        kd.gate.read = fa.u_flags + 128; kd.gate.n_read = 8 * slices;
+        kd.gate.seed = fa.du_granules; kd.gate.n_seed = B;
+        kd.gate.tag = h->epoch; kd.gate.spin = h->debug_expire == 7 ? 0 : (1 << 20);
+        kd.gate.err = h->err_dev; kd.gate.err_code = (2u << 8) | 7u;
+        kd.gate.kind[0] = 2; kd.gate.kind[1] = 1; kd.gate.kind[2] = 0; kd.gate.kind[3] = 0;
+        kd.gate.h2 = h->ws_actor.X[2];
+        kd.gate.w3 = fa.w3_snap;
+        kd.gate.U = fa.U;
+        kd.gate.n_act = h->A;
+        compact(kd, &ka);
+      }
+      prof_begin(4, st);
+      hipError_t e = launch_ddpg_update(fa, kc, ka, st);
+      prof_end(st);
+      HIPC(e);
+      HIPC(chain_after(st));
+      h->whole_done = true;
+      return OPRL_OK;
+    }
     if ((fa.merged & 1) != 0) {
       // phase 1 and the critic's dW + Adam tiles as ONE launch: the tiles wait for the roles' flag granules
       DwArgs dw = dw_build(h, true, B, true, false);
@@ -1301,6 +1370,10 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
 // ------------------------------------------------------------- actor phase
 int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hipStream_t st) {
   const oprl_learner_config& c = h->cfg;
+  if (h->whole_done) {          // (this update's actor step ran inside the critic phase's launch: k_ddpg_update)
+    h->whole_done = false;
+    return OPRL_OK;
+  }
   if (use_fused(h, B)) {
     DdpgArgs fa = ddpg_args(h, B);
     if (h->x2 && !fa.x2) RC(fresh32_tables(h, 3, st));
@@ -1908,14 +1981,20 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   floats += 64 * 32 + 6 * (size_t)B + 512;      // (granule arrays: y, q1, q2; 256 gate flags)
   const int Bm = B < 256 ? B : 256;             // merged phase 2 serves one 256-row chunk
   const bool merge2_bufs = h->fused && cfg->algo != OPRL_SAC && A <= kDuLd;
-  if (merge2_bufs) floats += 2 * ((size_t)Bm * kDuLd + 64) + 2 * 256 + 128 + (size_t)16 * A * Bm * 16 + 16 * 256 + 4 * 64;
+  if (merge2_bufs) floats += 2 * ((size_t)Bm * kDuLd + 64) + 2 * 256 + 128 + (size_t)16 * A * Bm * 16 + 16 * 256 + 4 * 64 + 2 * 256 + 64 + kMaxLayers * 256 + 64;
   if (h->bf16 || h->x2) {
     floats += 2 * ((size_t)net_pack16_floats(cfg->actor, h->planes) + 64);
     for (int j = 0; j < nc; ++j) floats += 2 * ((size_t)net_pack16_floats(cfg->critics[j], h->planes) + 64);
   }
   const size_t bytes = floats * sizeof(float) + 8192 + sizeof(DwItem) * (size_t)(nc + 1) * kMaxLayers +
                        sizeof(RepackItem) * (size_t)(4 * nc + 4) * kMaxLayers;
-  if (hipMalloc(&h->pool.base, bytes) != hipSuccess) { set_err("hipMalloc(%zu) failed", bytes); delete h; return OPRL_ERR_NOMEM; }
+  // PrecX2 learners: the workspace — activation exchange buffers, granules, staged rows — in UNCACHED device memory
+  // (measured: no slower than cached, r03 log), so that a role of the whole-update launch reads what an earlier role
+  // of the same launch wrote
+  static const int uc_pool_env = [] { const char* e = getenv("OPRL_AMD_UC_POOL"); return e != nullptr ? atoi(e) : 1; }();
+  const int uc_pool = (h->x2 && uc_pool_env) ? 1 : 0;
+  h->uc_pool = uc_pool != 0;
+  if ((uc_pool ? hipExtMallocWithFlags((void**)&h->pool.base, bytes, hipDeviceMallocUncached) : hipMalloc(&h->pool.base, bytes)) != hipSuccess) { set_err("hipMalloc(%zu) failed", bytes); delete h; return OPRL_ERR_NOMEM; }
   h->pool.cap = bytes;
   (void)hipMemset(h->pool.base, 0, bytes);
   {
@@ -1955,12 +2034,36 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->u_flags = p.take<unsigned long long>(256);
     h->U = p.take<float>((size_t)16 * A * Bm * 16);
     h->w3_snap = p.take<float>(16 * 256);
+    h->w_flags = p.take<unsigned long long>(256);
+    h->critic_b16 = p.take<float>(kMaxLayers * 256);
   }
   h->bs = p.take<float>((size_t)B * S);
   h->ba = p.take<float>((size_t)B * A);
   h->br = p.take<float>(B);
   h->bd = p.take<float>(B);
   h->bs2 = p.take<float>((size_t)B * S);
+  // the two-plane packs of a PrecX2 learner in UNCACHED device memory — every load and store goes to the fabric, so
+  // that a workgroup reads what a workgroup on another XCD has just written without a kernel boundary in between
+  // (measured: no slower than cached, r03 log)
+  // (OPRL_AMD_UC_PACKS=0 / OPRL_AMD_UC_POOL=0: ordinary device memory — then no whole-update launch)
+  static const int uc_packs = [] { const char* e = getenv("OPRL_AMD_UC_PACKS"); return e != nullptr ? atoi(e) : 1; }();
+  if (h->x2 && uc_packs) {
+    size_t fl = 2 * ((size_t)net_pack16_floats(cfg->actor, 2) + 64);
+    for (int j = 0; j < nc; ++j) fl += 2 * ((size_t)net_pack16_floats(cfg->critics[j], 2) + 64);
+    float* base = nullptr;
+    if (hipExtMallocWithFlags((void**)&base, fl * sizeof(float), uc_packs == 2 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached) != hipSuccess) {
+      set_err("hipExtMallocWithFlags(uncached packs) failed"); (void)hipFree(p.base); delete h; return OPRL_ERR_NOMEM;
+    }
+    (void)hipMemset(base, 0, fl * sizeof(float));
+    h->uc_base = base;
+    auto take = [&](size_t n) { float* q = base; base += (n + 63) & ~(size_t)63; return q; };
+    h->pack16[0] = take((size_t)net_pack16_floats(cfg->actor, 2));
+    h->pack16_t[0] = take((size_t)net_pack16_floats(cfg->actor, 2));
+    for (int j = 0; j < nc; ++j) {
+      h->pack16[1 + j] = take((size_t)net_pack16_floats(cfg->critics[j], 2));
+      h->pack16_t[1 + j] = take((size_t)net_pack16_floats(cfg->critics[j], 2));
+    }
+  } else
   if (h->bf16 || h->x2) {   // (the pool is zeroed: pad positions of the packs stay zero for good)
     h->pack16[0] = p.take<float>((size_t)net_pack16_floats(cfg->actor, h->planes));
     h->pack16_t[0] = p.take<float>((size_t)net_pack16_floats(cfg->actor, h->planes));
@@ -1973,6 +2076,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   for (int j = 0; j < nc; ++j)
     fill_items(cfg->critics[j], h->ws_critic[j], items, &h->tiles_critic, h->fused, h->pack16[1 + j], h->pack16_t[1 + j], h->planes);
   h->n_items_critic = (int)items.size();
+  if (h->critic_b16 != nullptr && nc == 1)
+    for (int l = 0; l < h->n_items_critic; ++l) items[l].b16 = h->critic_b16 + 256 * l;
   fill_items(cfg->actor, h->ws_actor, items, &h->tiles_actor, h->fused, h->pack16[0], h->pack16_t[0], h->planes);
   h->n_items_actor = (int)items.size() - h->n_items_critic;
   h->items_host = items;
@@ -2037,6 +2142,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->no_merge = (nmg != nullptr && atoi(nmg) != 0) ? 1 : 0;
     const char* nm2 = getenv("OPRL_AMD_NO_MERGE2");
     h->no_merge2 = (nm2 != nullptr && atoi(nm2) != 0) ? 1 : 0;
+    const char* nwh = getenv("OPRL_AMD_NO_WHOLE");
+    h->no_whole = (nwh != nullptr && atoi(nwh) != 0) ? 1 : 0;
     const char* nw = getenv("OPRL_AMD_NO_WIDE");
     h->no_wide = (nw != nullptr && atoi(nw) != 0) ? 1 : 0;
     // the generic per-net launches on clusters of 4 (slice_tp.hip): any net of the common shape
@@ -2110,6 +2217,7 @@ extern "C" int oprl_learner_destroy(oprl_learner* h) {
   if (h->tqc_counter) (void)hipFree(h->tqc_counter);
   if (h->lw_scratch) (void)hipFree(h->lw_scratch);
   if (h->batch_alt) (void)hipFree(h->batch_alt);
+  if (h->uc_base) (void)hipFree(h->uc_base);
   if (h->err_host) (void)hipHostFree(h->err_host);
   if (h->p2p.window) p2p_destroy(h->p2p);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
