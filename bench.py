@@ -11,14 +11,23 @@ timed region.
     python bench.py --gpus 1 --steps 20000 --warmup 1000
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+The timed learner runs the parity mode `x2` (OPRL_PREC_X2: every fp32 operand as the
+sum of two fp16 numbers, three v_mfma_f32_16x16x32_f16 per product, fp32 accumulate /
+master weights / Adam — at the same gates against the reference's golden vectors as the
+exact-fp32 MFMA mode, tests/test_gpu_x2.py); `--precision f32` times the exact-fp32
+MFMA mode, `--precision bf16` the reduced-precision one.  The default run reports all
+three (blocks `exact_f32`, `bf16`).
+
 Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline     dominant kernel (k_mlp_slice, exact-fp32 MFMA): algorithmic FLOP
-               per launch / its average duration (HIP events on the launch
-               stream, measured live in a separate instrumented pass) vs the
-               157.3 TFLOP/s fp32-matrix peak
+  roofline     dominant kernel (x2: k_ddpg_update, the whole update as one launch):
+               algorithmic bytes / FLOP per launch over its average duration (HIP
+               events on the launch stream, measured live in a separate instrumented
+               pass) against the binding peak
   cpu_baseline the CPU oracle (port of the reference's torch-CPU update path)
                timed on this box's host cores on a bounded sample of the same
                workload.
+Whatever goes wrong after start-up, rank 0 still prints one JSON line (`value` null and
+an `error` field): a watchdog bounds every phase of the run.
 """
 from __future__ import annotations
 
@@ -125,7 +134,11 @@ def cpu_baseline(budget_s: float = 14.0):
 
 # ---- the other BASELINE.json configurations, the bf16 mode and the through-the-API rate --------
 PEAK_BF16_MATRIX_TFLOPS = 2500.0       # dense bf16 MFMA (MI355X_MICROARCH.md)
-PMC_FILE = {"f32": "r02i_pmc_traffic.json", "bf16": "r02i_pmc_traffic_bf16.json", "x2": "r02i_pmc_traffic.json"}
+PEAK_F16_MATRIX_TFLOPS = 2500.0        # dense fp16 MFMA; the x2 mode spends three products per algorithmic one
+PMC_FILE = {"f32": "r03_pmc_traffic_f32.json", "bf16": "r03_pmc_traffic_bf16.json", "x2": "r03_pmc_traffic_x2.json"}
+PEAK_OF = {"f32": PEAK_F32_MATRIX_TFLOPS, "bf16": PEAK_BF16_MATRIX_TFLOPS, "x2": PEAK_F16_MATRIX_TFLOPS / 3.0}
+DTYPE_OF = {"f32": "f32 (exact-fp32 MFMA)", "bf16": "bf16 (fp32 accumulate / master / Adam)",
+            "x2": "f32 as split fp16x2 (hi + lo, 3 fp16 MFMAs per product, fp32 accumulate / master / Adam)"}
 PEAK_HBM_TBS = 8.0
 # name -> (class name, S, A, B, constructor extras, algorithmic GFLOP / update, state MB / update): BASELINE.md section 4
 BASELINE_CONFIGS = {
@@ -159,14 +172,23 @@ def _time_step_n(algo, replay, B_, n, dev):
 
 
 def config_table(dev, replays, n_steps=2000):
-    """Every BASELINE.json single-GPU configuration through the fused step_n path, fp32 (the parity mode)
-    and bf16: updates/s, us/update and the fraction of the binding roof for the WHOLE update — the larger
+    """Every BASELINE.json single-GPU configuration through the fused step_n path, the two parity modes (x2,
+    exact fp32) and bf16: updates/s, us/update and the fraction of the binding roof for the WHOLE update — the larger
     of (algorithmic FLOP / matrix peak of the mode) and (state bytes / HBM peak) over the measured time."""
     rows = []
     for name, (cls_name, S_, A_, B_, extras, gflop, mbytes) in BASELINE_CONFIGS.items():
         replay = replays(S_, A_)
-        for prec, peak in (("f32", PEAK_F32_MATRIX_TFLOPS), ("bf16", PEAK_BF16_MATRIX_TFLOPS)):
-            algo = _make_algo(cls_name, S_, A_, B_, extras, dev, prec)
+        for prec in ("x2", "f32", "bf16"):
+            peak = PEAK_OF[prec]
+            if prec == "x2" and cls_name == "TQC":
+                rows.append(dict(name=name, dtype=prec, steps_per_s=None,
+                                 unsupported="no split-fp16 kernels for the TQC path yet: its parity mode is f32"))
+                continue
+            try:
+                algo = _make_algo(cls_name, S_, A_, B_, extras, dev, prec)
+            except Exception as exc:  # noqa: BLE001  (a mode an algorithm does not have: said, not hidden)
+                rows.append(dict(name=name, dtype=prec, steps_per_s=None, unsupported=str(exc)[:120]))
+                continue
             n = n_steps if cls_name != "TQC" else max(n_steps // 4, 200)
             sec = _time_step_n(algo, replay, B_, n, dev)
             t_mfma, t_hbm = gflop * 1e9 / (peak * 1e12), mbytes * 1e6 / (PEAK_HBM_TBS * 1e12)
@@ -193,10 +215,10 @@ def bf16_q_deviation(dev, replay, updates=10):
     return float((q16 - q32).abs().max() / q32.abs().max())
 
 
-def api_rate(dev, replay, n=3000):
+def api_rate(dev, replay, precision="x2", n=3000):
     """The reference's call pattern from Python, one call pair per step: replay_buffer.sample(B) then
     algo.update(*batch) (trainers/base_trainer.py:63-70)."""
-    algo = _make_algo("DDPG", S, A, B, {}, dev)
+    algo = _make_algo("DDPG", S, A, B, {}, dev, precision)
     for _ in range(200):
         algo.update(*replay.sample(B))
     t.cuda.synchronize(dev)
@@ -206,7 +228,8 @@ def api_rate(dev, replay, n=3000):
     t.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     return dict(value=round(n / dt, 1), unit="steps/s", us_per_step=round(dt / n * 1e6, 2), steps=n,
-                path="EpisodicReplayBuffer.sample() + DDPG.update() from Python (two C calls: gather kernel, 3 update launches)")
+                dtype=precision,
+                path="EpisodicReplayBuffer.sample() + DDPG.update() from Python (two C calls: the gather kernel, the update's launch(es))")
 
 
 def multi_learner(n, dev, local_rank, steps):
@@ -280,8 +303,7 @@ def self_launch(n_gpus: int) -> int:
     if have < n_gpus:
         why = f"--gpus {n_gpus} needs {n_gpus} GPUs on this node, found {have}: nothing measured"
         print(f"bench.py: {why}", file=sys.stderr)
-        print(json.dumps({"metric": "learner gradient steps/sec, DDPG batch=256 walker-walk", "value": None,
-                          "unit": "steps/s", "n_gpus": n_gpus, "skipped": why}), flush=True)
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "steps/s", "n_gpus": n_gpus, "skipped": why}), flush=True)
         return 0
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -332,6 +354,89 @@ def packed_group(n, dev, local_rank, steps):
                 verified=dict(all_finite=finite, member0_equals_solo_run_at_cluster_1=same))
 
 
+def dp_single_rank(dev, local_rank, replay, precision, steps):
+    """The data-parallel step (oprl_learner_dp_step_n: update_phase / apply with the two gradient all-reduces on RCCL,
+    all in C) with ONE rank — what the N > 1 runs execute per rank, minus the wire: its rate against the headline's is
+    the fixed price of the exchange structure (un-merged launches + two ncclAllReduce calls per update)."""
+    import socket
+    import torch.distributed as dist
+    from oprl_amd.algos.ddpg import DDPG
+    from oprl_amd.logging import NullLogger
+    from oprl_amd.parallel import DataParallelLearner
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        t.manual_seed(0)
+        algo = DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device=f"cuda:{local_rank}", max_batch=B,
+                    export_grads=True, precision=precision).create()
+        dp = DataParallelLearner(algo, dist.group.WORLD)
+        dp.init_native_comm()
+        dp.broadcast_parameters()
+        dp.step_n(replay.handle, 300, B, seed=0)
+        t.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        dp.step_n(replay.handle, steps, B, seed=0)
+        t.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        ok = dp.healthy()
+        finite = bool(t.isfinite(algo.actor._oprl_arena).all() and t.isfinite(algo.critic._oprl_arena).all())
+        return dict(value=round(steps / dt, 1), unit="steps/s", us_per_step=round(dt / steps * 1e6, 2), steps=steps,
+                    dtype=precision, exchange="rccl", healthy=bool(ok), finite=finite,
+                    path="oprl_learner_dp_step_n at world size 1 (the --gpus N path per rank, RCCL all-reduce of one rank)")
+    finally:
+        dist.destroy_process_group()
+
+
+METRIC = "learner gradient steps/sec, DDPG batch=256 walker-walk"
+
+
+def failure_line(args, world, why):
+    """The one JSON line of a run that could not measure: same keys, value null, the reason."""
+    return json.dumps({"metric": METRIC, "value": None, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+                       "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                       "vs_baseline": None, "dtype": DTYPE_OF[args.precision], "data": "synthetic",
+                       "config": {"workload": f"DDPG walker-walk dims S={S} A={A} B={B}", "parallelism": f"dp{world}"},
+                       "roofline": None, "cpu_baseline": None, "data_parallel_check": None, "error": why})
+
+
+class Watchdog:
+    """A hung collective (or a kernel that never returns) must not leave the driver without a line: every phase of the
+    run re-arms this timer; when a phase outlives it, rank 0 prints the failure line and every rank leaves through
+    os._exit (ctypes and torch drop the GIL inside their C calls, so this thread runs while the main one is stuck)."""
+
+    def __init__(self, seconds, args, world, rank):
+        import threading
+        self.seconds, self.args, self.world, self.rank = seconds, args, world, rank
+        self.phase, self.deadline, self.done = "start-up", time.monotonic() + seconds, False
+        self.lock = threading.Lock()
+        threading.Thread(target=self._watch, daemon=True).start()
+
+    def kick(self, phase):
+        with self.lock:
+            self.phase, self.deadline = phase, time.monotonic() + self.seconds
+
+    def finish(self):
+        with self.lock:
+            self.done = True
+
+    def _watch(self):
+        while True:
+            time.sleep(1.0)
+            with self.lock:
+                if self.done:
+                    return
+                late = time.monotonic() > self.deadline
+                phase = self.phase
+            if late:
+                why = f"watchdog: phase '{phase}' exceeded {self.seconds:.0f} s on rank {self.rank}"
+                print(f"bench.py: {why}", file=sys.stderr, flush=True)
+                if self.rank == 0:
+                    print(failure_line(self.args, self.world, why), flush=True)
+                os._exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,9 +447,11 @@ def main():
     ap.add_argument("--learners", type=int, default=8,
                     help="extra measurement: this many independent learners (seeds) on separate "
                          "streams of the same GPU (multi-seed packing, runners/train.py --seeds); 0 = skip")
-    ap.add_argument("--precision", choices=("f32", "bf16", "x2"), default="f32",
-                    help="arithmetic mode of the TIMED learner: f32 = exact-fp32 MFMA, the parity mode and the headline; "
-                         "bf16 = the bf16 MFMA mode (profiling that path; the default run reports it in its `bf16` block)")
+    ap.add_argument("--precision", choices=("f32", "bf16", "x2"), default="x2",
+                    help="arithmetic mode of the TIMED learner: x2 = fp32 operands as fp16 hi + lo, three fp16 MFMAs per "
+                         "product (a parity mode: same gates against the reference's vectors as f32) and the headline; "
+                         "f32 = exact-fp32 MFMA; bf16 = the reduced-precision mode (the default run reports both in "
+                         "its `exact_f32` / `bf16` blocks)")
     ap.add_argument("--group", type=int, default=32,
                     help="extra measurement: a LearnerGroup of this many learners stepped by one launch sequence")
     ap.add_argument("--pre-warm", type=int, default=3000,
@@ -354,15 +461,38 @@ def main():
                     help="skip the extra blocks: the other BASELINE.json configs (TD3 / SAC / TQC, fp32 and bf16), the "
                          "bf16 DDPG line and the through-the-API rate")
     ap.add_argument("--config-steps", type=int, default=2000)
-    ap.add_argument("--no-p2p", action="store_true",
-                    help="data-parallel path: keep the gradient exchanges on RCCL (default: one-shot peer-window "
-                         "all-reduce when its self-test passes)")
+    ap.add_argument("--p2p", action="store_true",
+                    help="data-parallel path: ALSO probe the peer-window exchanges (csrc/p2p.hip) and use the fastest "
+                         "healthy one.  Default: RCCL only — the windows have never run on a multi-GPU node")
+    ap.add_argument("--no-p2p", action="store_true", help="(accepted for compatibility: RCCL only is the default)")
+    ap.add_argument("--watchdog", type=float, default=900.0,
+                    help="seconds any one phase of the run may take before rank 0 prints a JSON line with value null "
+                         "and the process exits (a hung collective must not leave the driver without a line)")
     ap.add_argument("--force-dp", action="store_true",
                     help="use the data-parallel path (RCCL all-reduce) even with one rank")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    wd = Watchdog(args.watchdog, args, world, rank)
+    try:
+        measure(args, wd)
+        wd.finish()
+    except BaseException as exc:  # noqa: BLE001  (whatever it was: the line is printed, then the error is shown)
+        if isinstance(exc, SystemExit) and exc.code in (0, None):
+            raise
+        wd.finish()
+        import traceback
+        traceback.print_exc()
+        if rank == 0:
+            print(failure_line(args, world, f"{type(exc).__name__}: {exc}"[:400]), flush=True)
+        sys.stdout.flush()
+        os._exit(1)       # (not sys.exit: a peer stuck in a collective would keep this rank's teardown waiting)
+
+
+def measure(args, wd):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -384,7 +514,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        import datetime
+        wd.kick("RCCL rendezvous")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev,
+                                timeout=datetime.timedelta(seconds=max(60.0, args.watchdog)))
 
     replay = make_replay(dev, seed=rank)               # disjoint shard per rank
     K, W = args.steps, args.warmup
@@ -439,8 +572,18 @@ def main():
             return algo_, dp_, ok_
 
         probes = {}
-        for level in ((0,) if args.no_p2p else (2, 1, 0)):
-            algo, dp, ok = build(level)
+        # RCCL first, always: it is the exchange that is known to work; the peer-window levels (never yet run on a
+        # multi-GPU node) are probed only on request, AFTER RCCL has produced its number, each under the watchdog
+        for level in ((0, 1, 2) if (args.p2p and not args.no_p2p) else (0,)):
+            wd.kick(f"data-parallel probe, exchange level {level}")
+            try:
+                algo, dp, ok = build(level)
+            except Exception as exc:  # noqa: BLE001
+                if level == 0:
+                    raise
+                if rank == 0:
+                    print(f"bench.py: exchange level {level} failed to build ({exc})", file=sys.stderr)
+                continue
             if ok:
                 dp.step_n(replay.handle, 300, B, seed=0)
                 best = 1e30
@@ -461,6 +604,7 @@ def main():
         if not probes:
             raise SystemExit("bench.py: no usable gradient exchange")
         p2p_level = min(probes, key=probes.get)
+        wd.kick("data-parallel rebuild + warm-up")
         algo, dp, ok = build(p2p_level)
         assert ok, "the probed exchange level failed on rebuild"
         learner = algo.learner
@@ -471,11 +615,13 @@ def main():
         def run(n):
             dp.step_n(replay.handle, n, B, seed=0)
 
+    wd.kick("timed region")
     barrier()
     t0 = time.perf_counter()
     run(K)
     barrier()
     dt = time.perf_counter() - t0
+    wd.kick("checks + instrumented pass")
     if dist is not None:
         tt = t.tensor([dt], dtype=t.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -502,7 +648,7 @@ def main():
                 # inside / after the dW launches): the roofline pass runs on a plain replica on rank 0
                 t.manual_seed(0)
                 plain = DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device=f"cuda:{local_rank}",
-                             max_batch=B).create()
+                             max_batch=B, precision=args.precision).create()
                 prof_learner = plain.learner
                 prof_learner.step_n(replay.handle, 300, B, seed=1)
                 t.cuda.synchronize(dev)
@@ -530,31 +676,59 @@ def main():
                                    us_per_launch_raw=ms[i] * 1e3 / cnt[i],
                                    us_per_step=max(ms[i] * 1e3 / cnt[i] - ev_us, 0.0) * cnt[i] / P)
                     for i in range(NK) if cnt[i]}
-            # dominant kernel: phase 1 of the fused path (falls back to the generic slice kernel)
-            dom = "k_ddpg_phase1" if "k_ddpg_phase1" in kern else "k_mlp_slice"
-            # merged launches (DDPG): the critic's dW + Adam tiles ride on phase 1's launch — one k_dw_adam launch per
-            # step is left, and the dominant launch's work includes the critic's dW GEMMs
+            # which launch structure ran (csrc/learner.hip): the whole update as ONE launch (x2: k_ddpg_update — it
+            # is counted in phase 1's slot), the merged launches (phase 1 + the critic's tiles | phase 2 [+ the actor's
+            # tiles]), or the plain sequence
+            whole = "k_ddpg_phase1" in kern and "k_ddpg_phase2" not in kern and "k_dw_adam" not in kern
+            if whole:
+                kern["k_ddpg_update"] = kern.pop("k_ddpg_phase1")
+            dom = "k_ddpg_update" if whole else ("k_ddpg_phase1" if "k_ddpg_phase1" in kern else "k_mlp_slice")
             merged = dom == "k_ddpg_phase1" and kern.get("k_dw_adam", {}).get("launches_per_step", 2.0) < 1.5
-            macs = (MACS_P1 + (F_CRITIC if merged else 0)) if dom == "k_ddpg_phase1" else MACS_SLICE / kern[dom]["launches_per_step"]
+            if whole:
+                macs = MACS_SLICE + MACS_DW
+                nbytes = STATE_BYTES + 4 * B * (2 * S + A + 2)
+            elif dom == "k_ddpg_phase1":
+                macs = MACS_P1 + (F_CRITIC if merged else 0)
+                nbytes = (32 * (F_CRITIC + HID * 2 + 1) if merged else 0) + 4 * B * (2 * S + A + 2)
+            else:
+                macs = MACS_SLICE / kern[dom]["launches_per_step"]
+                nbytes = 0
             flop_per_launch = 2.0 * B * macs
             if kern[dom]["us_per_launch"] <= 0.0:          # (a very short run: the overhead estimate swallowed the reading)
                 kern[dom]["us_per_launch"] = kern[dom]["us_per_launch_raw"]
-            ach = flop_per_launch / (kern[dom]["us_per_launch"] * 1e-6) / 1e12
+            dur = kern[dom]["us_per_launch"] * 1e-6
+            peak = PEAK_OF[args.precision]
+            ach_flops, ach_bytes = flop_per_launch / dur / 1e12, nbytes / dur / 1e9
+            # the binding roof is the one whose ideal time for this launch is longer
+            t_mfma, t_hbm = flop_per_launch / (peak * 1e12), nbytes / (PEAK_HBM_TBS * 1e12)
+            hbm_bound = t_hbm > t_mfma
             traffic = mfma_util = None
             try:   # HBM bytes per launch and matrix-core utilisation from the committed rocprofv3 PMC passes of this same command
                 pmc = json.load(open(ROOT / "profiles" / PMC_FILE[args.precision]))
-                pk = "k_ddpg_phase1_dw" if merged and "k_ddpg_phase1_dw" in pmc else dom
+                pk = next((k for k in (dom, dom + "_dw") if k in pmc), dom)
                 traffic = pmc.get(pk, {}).get("hbm_bytes_per_launch")
                 mfma_util = pmc.get(pk, {}).get("mfma_util")
             except Exception:  # noqa: BLE001
                 pass
-            peak = PEAK_F32_MATRIX_TFLOPS if args.precision == "f32" else PEAK_BF16_MATRIX_TFLOPS
-            roof = dict(bound="mfma", kernel=(f"{dom}_dw (phase 1 + the critic's dW / Adam tiles in one launch; " if merged else f"{dom}<256> (") + ("exact-fp32 v_mfma_f32_16x16x4_f32" if args.precision == "f32"
-                                                               else "v_mfma_f32_16x16x32_bf16, fp32 accumulate") + ")",
-                        achieved=round(ach, 3), peak=peak, unit="TFLOP/s",
-                        frac=round(ach / peak, 5), traffic=traffic, mfma_util=mfma_util,
-                        flop_per_launch=flop_per_launch, kernels=kern,
-                        event_overhead_us=round(ev_us, 3),
+            arith = {"f32": "exact-fp32 v_mfma_f32_16x16x4_f32", "bf16": "v_mfma_f32_16x16x32_bf16, fp32 accumulate",
+                     "x2": "v_mfma_f32_16x16x32_f16 x 3 per product (fp16 hi + lo operands), fp32 accumulate"}[args.precision]
+            what = {"k_ddpg_update": "k_ddpg_update (the WHOLE update as one launch: target chain, critic forward / backward, "
+                                     "the critic's dW + Adam + Polyak tiles, critic pass for the actor loss, the actor's "
+                                     "backward and dW + Adam + Polyak tiles, next batch's gather; ",
+                    "k_ddpg_phase1": ("k_ddpg_phase1_dw (phase 1 + the critic's dW / Adam tiles in one launch; " if merged
+                                      else "k_ddpg_phase1<256> ("),
+                    "k_mlp_slice": "k_mlp_slice ("}[dom]
+            roof = dict(bound="hbm" if hbm_bound else "mfma", kernel=what + arith + ")",
+                        achieved=round(ach_bytes if hbm_bound else ach_flops, 3),
+                        peak=PEAK_HBM_TBS * 1e3 if hbm_bound else round(peak, 1), unit="GB/s" if hbm_bound else "TFLOP/s",
+                        frac=round((t_hbm if hbm_bound else t_mfma) / dur, 5), traffic=traffic, mfma_util=mfma_util,
+                        flop_per_launch=flop_per_launch, bytes_per_launch=nbytes,
+                        other_roof=dict(bound="mfma" if hbm_bound else "hbm",
+                                        achieved=round(ach_flops if hbm_bound else ach_bytes, 3),
+                                        peak=round(peak, 1) if hbm_bound else PEAK_HBM_TBS * 1e3,
+                                        unit="TFLOP/s" if hbm_bound else "GB/s",
+                                        frac=round((t_mfma if hbm_bound else t_hbm) / dur, 5)),
+                        kernels=kern, event_overhead_us=round(ev_us, 3),
                         measured_on=("the timed learner" if not use_dp else
                                      "a single-GPU replica of the same kernels on rank 0 "
                                      f"({us_per_step_plain:.1f} us per update without the exchange)"),
@@ -562,23 +736,26 @@ def main():
                              f"(serialised pass of {P} steps) minus event_overhead_us, the per-launch "
                              "excess of that pass over the un-instrumented timed loop (where the same "
                              "launches run back to back, so a step is the sum of their durations); they "
-                             "agree with rocprofv3 --kernel-trace --stats (profiles/r02i_kernel_stats.csv); "
+                             "agree with rocprofv3 --kernel-trace --stats (profiles/r03_kernel_stats_*.csv); "
                              "sum of kernel time per step = "
-                             f"{sum(k['us_per_step'] for k in kern.values()):.1f} us; traffic = "
-                             f"(2*FETCH_SIZE + WRITE_SIZE) KB and mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (average launch duration x 2.4 GHz x 1024 SIMDs) "
-                             f"from profiles/{PMC_FILE[args.precision]} (separate --pmc passes, tools/profile_round.sh); the "
-                             "launch is 16 slices x 3 roles x 4 cluster members = 192 workgroups plus the critic's 152 dW / Adam tile "
-                             "workgroups, which start where CUs are free and wait for the roles' flag granules (DESIGN.md 4.4; the "
-                             "launch spans the roles' chain AND the tiles' tail: the same phase-1 work as a launch of its own, "
-                             "OPRL_AMD_NO_MERGE=1, reads frac 0.094 at 1.8 us more per update), "
-                             "and the step is a chain of dependent launches (three with the merged launch, four without) bound by latency, not by "
-                             "the matrix cores (DESIGN.md section 6)")
+                             f"{sum(k['us_per_step'] for k in kern.values()):.1f} us; bytes_per_launch = 32 B per trained "
+                             "parameter (theta, m, v, theta_target read + written) + the gathered minibatch rows; "
+                             "flop_per_launch = 2 x B x the algorithmic MACs of the launch (SURVEY.md 8d); the x2 peak is "
+                             "the dense fp16 MFMA peak / 3 (three hardware products per algorithmic one); traffic = "
+                             "(2*FETCH_SIZE + WRITE_SIZE) KB and mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (average launch "
+                             f"duration x 2.4 GHz x 1024 SIMDs) from profiles/{PMC_FILE[args.precision]} (separate --pmc "
+                             "passes, tools/profile_round.sh).  Neither roof binds: an update is a CHAIN of dependent "
+                             "16-row-slice stages (target chain -> TD seeds -> critic tiles -> critic pass -> du -> actor "
+                             "tiles) whose length is set by cross-workgroup flag hops, cold weight-shard loads and "
+                             "workgroup dispatch, not by bandwidth or the matrix cores (DESIGN.md section 6; timeline in "
+                             "profiles/r03_stage_stamps.txt)")
         multi = None
         group = None
         if not use_dp and args.learners > 1:
+            wd.kick("multi-learner + packed group")
             multi = multi_learner(args.learners, dev, local_rank, steps=max(200, min(K, 2000)))
             group = packed_group(args.group, dev, local_rank, steps=max(200, min(K, 1000)))
-        configs = bf16 = api = None
+        configs = bf16 = api = exact = dp1 = None
         if not use_dp and not args.no_configs:
             cache = {(S, A): replay}
 
@@ -589,34 +766,54 @@ def main():
                 if (S_, A_) not in cache:
                     cache[(S_, A_)] = make_replay(dev, seed=rank, S=S_, A=A_)
                 return cache[(S_, A_)]
+            wd.kick("config table")
             configs = config_table(dev, replays, n_steps=args.config_steps)
             d16 = next(r for r in configs if r["name"].startswith("DDPG") and r["dtype"] == "bf16")
             bf16 = dict(value=d16["steps_per_s"], unit="steps/s", us_per_step=d16["us_per_step"],
                         roofline_frac=d16["roofline_frac"], roof=d16["roof"], peak_tflops=PEAK_BF16_MATRIX_TFLOPS,
                         q_rel_dev_vs_f32_after_10_updates=round(bf16_q_deviation(dev, replay), 6),
                         note="OPRL_PREC_BF16: v_mfma_f32_16x16x32_bf16, fp32 accumulate / master / Adam; the "
-                             "headline `value` above stays the fp32 parity mode")
-            api = api_rate(dev, replay)
+                             "headline `value` above is a parity mode")
+            api = api_rate(dev, replay, args.precision)
+            d32 = next(r for r in configs if r["name"].startswith("DDPG") and r["dtype"] == "f32")
+            exact = dict(value=d32["steps_per_s"], unit="steps/s", us_per_step=d32["us_per_step"],
+                         note="OPRL_PREC_F32: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), the other parity mode")
+            wd.kick("single-rank data-parallel rate")
+            try:
+                dp1 = dp_single_rank(dev, local_rank, replay, args.precision, max(200, min(K, 3000)))
+            except Exception as exc:  # noqa: BLE001
+                dp1 = dict(value=None, error=f"{type(exc).__name__}: {exc}"[:300])
+        wd.kick("cpu baseline")
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()   # rank 0 at N = 1 only
         out = {
-            "metric": "learner gradient steps/sec, DDPG batch=256 walker-walk",
+            "metric": METRIC,
             "value": round(value, 1), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic", "pre_warm_steps": args.pre_warm,
+            "vs_baseline": None, "dtype": DTYPE_OF[args.precision], "precision_mode": args.precision, "data": "synthetic", "pre_warm_steps": args.pre_warm,
             "config": {"workload": f"DDPG walker-walk dims S={S} A={A} B={B}, hidden (256,256), replay "
                                    f"{E}x{L} transitions resident in HBM, device-side uniform sampling, "
-                                   + ("exact-fp32 MFMA (parity mode)" if args.precision == "f32" else
-                                      "bf16 MFMA inputs, fp32 accumulate / master / Adam (OPRL_PREC_BF16)"),
+                                   + {"f32": "exact-fp32 MFMA (OPRL_PREC_F32, a parity mode)",
+                                      "x2": "fp32 operands as fp16 hi + lo, three fp16 MFMAs per product, fp32 accumulate / "
+                                            "master / Adam (OPRL_PREC_X2, a parity mode: same gates against the reference's "
+                                            "golden vectors as the exact-fp32 mode, tests/test_gpu_x2.py)",
+                                      "bf16": "bf16 MFMA inputs, fp32 accumulate / master / Adam (OPRL_PREC_BF16, NOT a "
+                                              "parity mode)"}[args.precision],
                        "path": "oprl_learner_step_n" if not use_dp else
                                ("oprl_learner_dp_step_n: update_phase/apply + 2 gradient all-reduces (critic, actor) per step, all in C; "
                                 + {2: "all-reduced per tile inside the dW + Adam launches over xGMI peer windows (csrc/p2p.hip, k_dw_adam<true>)",
                                    1: "one-shot peer-window all-reduce over xGMI, one kernel per exchange (csrc/p2p.hip)",
                                    0: "RCCL ncclAllReduce"}[p2p_level]),
                        "parallelism": f"dp{world}", "global_batch": B * world},
-            "roofline": roof, "cpu_baseline": cpu, "configs": configs, "bf16": bf16, "api_rate": api,
+            "roofline": roof, "cpu_baseline": cpu, "configs": configs, "exact_f32": exact, "bf16": bf16, "api_rate": api,
+            "dp_single_rank": dp1,
             "multi_learner": multi, "packed_group": group, "data_parallel_check": dp_check,
             "flop_per_step": 2.0 * B * (MACS_SLICE + MACS_DW), "state_bytes_per_step": STATE_BYTES,
         }
+        sys.stderr.flush()
+        try:        # (RCCL prints its version banner through C stdio: out before the line, so that the line is the last one)
+            C.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

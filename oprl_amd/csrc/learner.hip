@@ -993,7 +993,9 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   }
   // ... and the ACTOR's tiles on phase 2 (DDPG / TD3: the tanh head, action_dim <= kDuLd): the actor's backward runs
   // beside the critic pass with unit seeds (role U), the tiles combine with du (csrc/fused_ddpg.hip)
-  if (!h->no_merge2 && h->du_granules != nullptr && !a.sac && !a.bf16 && B <= 256 && !h->cfg.export_grads && !h->dp_inline &&
+  // PrecX2 learners only: with the exact-fp32 tiles the merged form measured no faster than the two launches (34.9 vs
+  // 34.7 us) and its TD3 variant tripped a bounded wait under step_n — it is not offered
+  if (!h->no_merge2 && a.x2 && fused_x2_tiles() && h->du_granules != nullptr && !a.sac && B <= 256 && !h->cfg.export_grads && !h->dp_inline &&
       fused_ddpg_is_lean(a) && c.actor.theta_target != nullptr) {
     // (role U takes eight workgroups per slice; where those, the critic pass on eight and the prefetch row do not fit the
     // chip together — B = 256 — the critic pass stays on a cluster of four)
@@ -2418,7 +2420,18 @@ struct oprl_group {
   bool stage_busy[2] = {false, false};
   int cur = 0;
   size_t bytes = 0;
+  int device = 0;                              // the device the group's buffers (and its members) live on
 };
+
+static void group_free(oprl_group* g) {
+  for (int i = 0; i < 2; ++i) {
+    if (g->p_dev[i]) (void)hipFree(g->p_dev[i]);
+    if (g->dw_dev[i]) (void)hipFree(g->dw_dev[i]);
+    if (g->stage[i]) (void)hipHostFree(g->stage[i]);
+    if (g->stage_ev[i]) (void)hipEventDestroy(g->stage_ev[i]);
+  }
+  delete g;
+}
 
 extern "C" int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group** out) {
   if (!learners || !out || n < 1 || n > 64) { set_err("oprl_group_create: invalid argument"); return OPRL_ERR_INVALID; }
@@ -2432,7 +2445,7 @@ extern "C" int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group*
   }
   auto* g = new oprl_group();
   g->L.assign(learners, learners + n);
-  for (oprl_learner* h : g->L) h->ncl = 1;       // single-CU slices (see above); a solo run for comparison sets the same
+  (void)hipGetDevice(&g->device);
   g->bytes = (size_t)n * (2 * sizeof(DdpgArgs) + 2 * sizeof(DwKArgs));
   bool ok = true;
   for (int i = 0; i < 2 && ok; ++i) {
@@ -2440,21 +2453,26 @@ extern "C" int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group*
          hipHostMalloc((void**)&g->stage[i], g->bytes) == hipSuccess &&
          hipEventCreateWithFlags(&g->stage_ev[i], hipEventDisableTiming) == hipSuccess;
   }
-  if (!ok) { set_err("oprl_group_create: allocation failed"); return OPRL_ERR_NOMEM; }
+  if (!ok) {      // (nothing is kept of a failed create: the partial allocations go, the members stay as they were)
+    group_free(g);
+    set_err("oprl_group_create: allocation failed");
+    return OPRL_ERR_NOMEM;
+  }
+  for (oprl_learner* h : g->L) h->ncl = 1;       // single-CU slices (see above); a solo run for comparison sets the same
   *out = g;
   return OPRL_OK;
 }
 
 extern "C" int oprl_group_destroy(oprl_group* g) {
   if (!g) return OPRL_OK;
+  // the group's OWN device, whatever the caller's current one is: launches that read the argument blocks may be in flight
+  int cur = 0;
+  const int dev = g->device;
+  (void)hipGetDevice(&cur);
+  if (cur != dev) (void)hipSetDevice(dev);
   (void)hipDeviceSynchronize();
-  for (int i = 0; i < 2; ++i) {
-    if (g->p_dev[i]) (void)hipFree(g->p_dev[i]);
-    if (g->dw_dev[i]) (void)hipFree(g->dw_dev[i]);
-    if (g->stage[i]) (void)hipHostFree(g->stage[i]);
-    if (g->stage_ev[i]) (void)hipEventDestroy(g->stage_ev[i]);
-  }
-  delete g;
+  group_free(g);
+  if (cur != dev) (void)hipSetDevice(cur);
   return OPRL_OK;
 }
 

@@ -166,7 +166,6 @@ struct oprl_replay {
   // the stream of the caller's most recent flush / sample / block write / table upload: where a staging buffer
   // that fills up inside oprl_replay_write (which takes no stream) is flushed, so that the scatter stays ordered
   // with the caller's later gathers
-  hipStream_t stream_hint = nullptr;
 };
 
 extern "C" int oprl_replay_create(int32_t n_episodes, int32_t max_ep_len, int32_t state_dim,
@@ -210,7 +209,6 @@ extern "C" int oprl_replay_destroy(oprl_replay* h) {
 
 extern "C" int oprl_replay_flush(oprl_replay* h, void* stream) {
   if (!h) { set_err("null replay handle"); return OPRL_ERR_INVALID; }
-  h->stream_hint = (hipStream_t)stream;
   if (h->n_staged == 0) return OPRL_OK;
   hipStream_t st = (hipStream_t)stream;
   const int c = h->cur, n = h->n_staged;
@@ -239,8 +237,12 @@ extern "C" int oprl_replay_write(oprl_replay* h, int32_t ep, int32_t t, const fl
     return OPRL_ERR_INVALID;
   }
   if (h->n_staged == kStageRows) {
-    int rc = oprl_replay_flush(h, h->stream_hint);
+    // staging is full and this entry point has no stream argument: the scatter goes on the null stream and is
+    // WAITED for — no stream handle of an earlier call is kept (it may have been destroyed, or not be the stream of the
+    // next sample), and whatever stream that sample runs on finds the rows in HBM.  Once per kStageRows writes.
+    int rc = oprl_replay_flush(h, nullptr);
     if (rc != OPRL_OK) return rc;
+    HIPC(hipStreamSynchronize(nullptr));
   }
   float* row = h->stage_host[h->cur] + (size_t)h->n_staged * h->rowlen;
   memcpy(row, &ep, 4);

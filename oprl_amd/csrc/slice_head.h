@@ -192,7 +192,7 @@ __device__ __forceinline__ void slice_seed(const MlpArgs& A, const float* outS, 
         }
         __syncthreads();
       }
-      // kR * Q elements (400 for TQC) x M samples each (115): one thread per element kept 7 of the 16 waves busy for
+      // kR * Q elements (400 for TQC) x M samples each (123 at the defaults: 5 x 25 quantiles less top_quantiles_to_drop = 2): one thread per element kept 7 of the 16 waves busy for
       // M iterations — 5 us of the critic step's head launch.  Four lanes per element, a quarter of the samples each,
       // summed over the quad in a fixed order: every wave carries the same work.
       const int n_el = kR * Q, m4 = (M + 3) >> 2;

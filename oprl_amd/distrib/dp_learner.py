@@ -39,6 +39,7 @@ class LearnerPlan:
     seed: int = 0
     idle_timeout_s: float = 60.0         # nothing arrives for this long: before training could start an error, after it the end of the run
     wall_timeout_s: float | None = None  # bound on the whole run (run_dp_training terminates the ranks beyond it)
+    force_exchange: bool = False         # one rank: still the data-parallel step (phase / RCCL all-reduce / apply), not the fused one
 
 
 def run_ring_actor(make_env: Callable, make_policy: Callable, config, id_worker: int, ring_name: str,

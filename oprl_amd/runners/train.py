@@ -61,10 +61,12 @@ def run_training(
     if seeds == 1:
         _run_training_func(make_algo, make_env, make_replay_buffer, make_logger, config, 0, **trainer_kwargs)
         return
-    if seeds > 3:
-        # the seeds share ONE GPU: learners that want every CU for a launch (clusters of eight, include/oprl_amd.h)
-        # would spin for each other — the children inherit clusters of four
-        os.environ.setdefault("OPRL_AMD_NO_WIDE", "1")
+    # the seeds share ONE GPU: launches whose workgroups wait for each other inside the launch (clusters of eight, the
+    # merged phase + tile launches, the whole-update launch: include/oprl_amd.h) need their workgroups co-resident, and a
+    # sibling process holding the compute units turns a bounded wait into a poisoned update — not into a slowdown.
+    # From two seeds on the children inherit the forms that only ever wait within a cluster of four
+    for var in ("OPRL_AMD_NO_WIDE", "OPRL_AMD_NO_MERGE", "OPRL_AMD_NO_MERGE2", "OPRL_AMD_NO_WHOLE"):
+        os.environ.setdefault(var, "1")
     ctx = get_context("spawn")   # a forked child cannot re-initialise the GPU runtime
     procs = [ctx.Process(target=_run_training_func,
                          args=(make_algo, make_env, make_replay_buffer, make_logger, config, seed),

@@ -84,7 +84,8 @@ def _dp_learner_main(rank: int, world: int, init_file: str, make_algo, make_repl
         kw["device_id"] = t.device(device)
     dist.init_process_group(backend, init_method=f"file://{init_file}", rank=rank, world_size=world, **kw)
     t.manual_seed(plan.seed)                        # every replica starts from the same parameters
-    algo = _call_with_overrides(make_algo, "make_algo", make_logger(), device=device, export_grads=world > 1)
+    algo = _call_with_overrides(make_algo, "make_algo", make_logger(), device=device,
+                                export_grads=world > 1 or bool(getattr(plan, "force_exchange", False)))
     if hasattr(algo, "set_seed"):
         algo.set_seed(plan.seed, rank)              # the run seed reaches the device-side noise keys, per rank
     buffer = _call_with_overrides(make_replay_buffer, "make_replay_buffer", device=device, seed=plan.seed * 1000 + rank)

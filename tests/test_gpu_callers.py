@@ -304,6 +304,40 @@ def test_distributed_learner_with_in_host_actors():
                          max_epochs=4)
 
 
+def test_data_parallel_training_with_ring_actors_on_one_rank_over_rccl():
+    """BASELINE.json config 5 end to end on this GPU (runners/train_distrib.py::run_dp_training, the --gpus N layout
+    with N = 1): two CPU actor processes feed shared-memory rings, the learner rank runs the DATA-PARALLEL step —
+    update_phase / ncclAllReduce / apply on a world-size-1 RCCL communicator (LearnerPlan.force_exchange), not the
+    fused single-GPU update — drains the rings between chunks, publishes the policy, and stops the actors."""
+    from oprl_amd.distrib.dp_learner import LearnerPlan
+    from oprl_amd.runners.config import DistribConfig
+    from oprl_amd.runners.train_distrib import run_dp_training
+    from tests import test_gpu_callers as me
+    cfg = DistribConfig(batch_size=64, num_env_workers=2, episodes_per_worker=10 ** 6, warmup_epochs=0,
+                        episode_length=40, warmup_env_steps=40)
+    plan = LearnerPlan(total_updates=600, batch_size=64, chunk=100, warmup_transitions=128,
+                       updates_per_transition=4.0, force_exchange=True, wall_timeout_s=240.0, idle_timeout_s=30.0)
+    stats = run_dp_training(make_env=me._mk_env, make_algo=me._mk_algo_kw, make_policy=me._mk_policy,
+                            make_replay_buffer=me._mk_buffer_kw, make_logger=me._mk_logger, config=cfg,
+                            learners=1, plan=plan, backend="nccl")
+    assert len(stats) == 1
+    s0 = stats[0]
+    assert s0["updates"] == 600 and s0["stopped_early"] is None, s0
+    assert s0["received"] >= 150 and s0["chunks"] >= 6, s0
+    assert s0["replica_spread"] == 0.0 and s0["policy_version"] >= 6, s0
+
+
+def _mk_algo_kw(logger, **kw):
+    from oprl_amd.algos.ddpg import DDPG
+    return DDPG(logger=logger, state_dim=24, action_dim=6, max_batch=64, **{"device": "cuda", **kw}).create()
+
+
+def _mk_buffer_kw(**kw):
+    from oprl_amd.buffers.episodic_buffer import EpisodicReplayBuffer
+    return EpisodicReplayBuffer(buffer_size_transitions=40000, state_dim=24, action_dim=6,
+                                max_episode_lenth=40, **{"device": "cuda", **kw}).create()
+
+
 def _mk_env(seed=0):
     from oprl_amd.environment.synthetic import SyntheticEnv
     return SyntheticEnv("walker-walk", seed=seed, episode_length=40)
@@ -374,23 +408,23 @@ def test_native_dp_single_rank_equals_export_split():
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("algo", ["ddpg", "td3", "sac"])
-def test_checkpoint_resume_is_bit_exact(algo, tmp_path):
+@pytest.mark.parametrize("algo,precision", [("ddpg", "f32"), ("td3", "f32"), ("sac", "f32"), ("tqc", "f32"),
+                                            ("ddpg", "bf16"), ("tqc", "bf16"), ("sac", "bf16"),
+                                            ("ddpg", "x2"), ("td3", "x2"), ("sac", "x2")])
+def test_checkpoint_resume_is_bit_exact(algo, precision, tmp_path):
     """learner state (theta, targets, Adam moments, temperature, counters) + replay
     (storage, write position, sample counter) saved mid-run; a fresh process-like restore must
-    continue bit for bit like the uninterrupted run."""
+    continue bit for bit like the uninterrupted run — in every arithmetic mode (the bf16 / split-fp16 weight packs
+    are not part of a checkpoint: they are rebuilt from the restored masters and must come out the same)."""
     from oprl_amd.logging import NullLogger
 
     def make():
+        import importlib
         t.manual_seed(0)
-        if algo == "ddpg":
-            return _ddpg(max_batch=64)
-        if algo == "td3":
-            from oprl_amd.algos.td3 import TD3
-            return TD3(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=64).create()
-        from oprl_amd.algos.sac import SAC
-        return SAC(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=64,
-                   tune_alpha=True).create()
+        cls = getattr(importlib.import_module(f"oprl_amd.algos.{algo}"), algo.upper())
+        extra = {"tune_alpha": True} if algo == "sac" else {}
+        return cls(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=64, precision=precision,
+                   **extra).create()
 
     K, B = 7, 64
     a1, b1 = make(), _filled_buffer()
@@ -409,7 +443,7 @@ def test_checkpoint_resume_is_bit_exact(algo, tmp_path):
     for m in ("actor", "critic", "critic_target"):
         assert t.equal(getattr(a1, m)._oprl_arena, getattr(a2, m)._oprl_arena), m
     assert t.equal(a1.learner.actor_m, a2.learner.actor_m) and t.equal(a1.learner.critic_v, a2.learner.critic_v)
-    if algo == "sac":
+    if algo in ("sac", "tqc") and a1.learner.log_alpha is not None:
         assert t.equal(a1.learner.log_alpha, a2.learner.log_alpha)
     # and the replay's next sample is the same draw
     s1, s2 = b1.sample(8), b2.sample(8)
@@ -491,6 +525,48 @@ def test_device_noise_stream_is_standard_normal_and_keyed_by_seed_rank_counter()
     assert not np.array_equal(x, y) and not np.array_equal(y, z)
     assert abs(np.corrcoef(x.ravel(), y.ravel())[0, 1]) < 4 / np.sqrt(n)
     assert abs(np.corrcoef(y.ravel(), z.ravel())[0, 1]) < 4 / np.sqrt(n)
+
+
+def test_packed_learner_group_members_against_the_cpu_oracle():
+    """N3 against the ORACLE (not only against the same kernels run solo): three members with the oracle's
+    fixture weights, stepped as a group over the replay; the oracle's DDPG (oracle/oprl_oracle.py, pinned to the
+    reference by tests/test_oracle_golden.py) is fed the same rows — the buffer's own Philox draw for each member's
+    seed — and every member must end within the parity gate of its oracle twin."""
+    from oracle import fixtures as fx
+    from oracle import oprl_oracle as orc
+    from oprl_amd.algos.ddpg import DDPG
+    from oprl_amd.group import LearnerGroup
+    from oprl_amd.logging import NullLogger
+    from tests import hip_adapters as ha
+    from tests import scenarios as sc
+    S, A, B, K = 24, 6, 64, 6
+    buf = _filled_buffer()
+    seeds = [21, 22, 23]
+    nets = [(fx.make_net(300 + 2 * i, fx.actor_dims(S, A)), fx.make_net(301 + 2 * i, fx.critic_dims(S, A))) for i in range(3)]
+    members = []
+    for actor, critic in nets:
+        m = DDPG(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=S, action_dim=A, device="cuda", max_batch=B).create()
+        for mod, p in ((m.actor, actor), (m.actor_target, actor), (m.critic, critic), (m.critic_target, critic)):
+            ha.load_params(mod, p)
+        members.append(m)
+    g = LearnerGroup(members)
+    g.step_n(buf.handle, K, B, seeds)
+    t.cuda.synchronize()
+    worst = 0.0
+    for (actor, critic), m, seed in zip(nets, members, seeds):
+        o = orc.DDPGOracle(S, A, actor, critic)
+        buf.seed = seed
+        for k in range(K):
+            buf._sample_counter = k
+            o.update(*[x.cpu() for x in buf.sample(B)])
+        for name in ("actor", "critic", "actor_target", "critic_target"):
+            for got, want in zip(ha.cpu_params(getattr(m, name)), getattr(o, name)):
+                dev = sc.rel_dev(got, want)
+                worst = max(worst, dev)
+                assert dev < sc.PARAM_TOL, (name, dev)     # (north_star's parameter gate, per tensor in max-norm)
+        m.learner.check()
+    print(f"group members vs oracle after {K} updates: worst relative deviation {worst:.2e}")
+    g.close()
 
 
 def test_packed_learner_group_equals_solo_learners():

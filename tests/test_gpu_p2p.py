@@ -95,19 +95,44 @@ def test_two_process_p2p_data_parallel_step(algo_name, level):
             assert d <= 1e-6, f"{m}: max |d| vs emulation = {d:.3e}"
 
 
-@pytest.mark.parametrize("fail,expect", [("0", "p2p-inline"), ("1", "rccl")])
-def test_bench_picks_the_exchange_and_falls_back(fail, expect):
-    """bench.py --force-dp (one rank): the fastest exchange whose self-test and replica health check pass;
-    with the self-test forced to fail it must rebuild the replicas on RCCL and still report healthy ones."""
+@pytest.mark.parametrize("extra,fail,expect", [
+    ([], "0", "rccl"),                                        # the default: RCCL only, the windows are not even probed
+    (["--p2p", "--precision", "f32"], "0", "p2p-inline"),    # on request: the fastest healthy exchange
+    (["--p2p", "--precision", "f32"], "1", "rccl"),          # ... and back to RCCL when the windows' self-test fails
+    (["--p2p"], "0", None),                                   # the x2 learner: whichever is picked must be healthy
+])
+def test_bench_picks_the_exchange_and_falls_back(extra, fail, expect):
+    """bench.py --force-dp (one rank): RCCL unless --p2p asks for the peer-window exchanges to be probed as well —
+    then the fastest exchange whose self-test and replica health check pass; with the self-test forced to fail it
+    must stay on RCCL and still report healthy replicas.  The JSON line is the LAST line of stdout."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, OPRL_AMD_P2P_SELFTEST_FAIL=fail, MASTER_PORT="29533")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dp", "--no-cpu-baseline",
-                          "--learners", "0", "--steps", "300", "--warmup", "30"], env=env, cwd=root,
+                          "--learners", "0", "--steps", "300", "--warmup", "30", *extra], env=env, cwd=root,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = [x for x in out.stdout.splitlines() if x.startswith("{")][-1]
+    line = [x for x in out.stdout.splitlines() if x.strip()][-1]
+    assert line.startswith("{"), out.stdout[-500:]
     d = json.loads(line)
     chk = d["data_parallel_check"]
-    assert chk["exchange"] == expect and chk["finite"] and chk["replicas_identical"], chk
+    assert chk["finite"] and chk["replicas_identical"], chk
+    if expect is not None:
+        assert chk["exchange"] == expect, chk
+    if not extra:
+        assert list(chk["probe_us_per_step"]) == ["rccl"], chk
     assert d["n_gpus"] == 1 and d["value"] > 1000
+
+
+def test_bench_prints_its_line_when_the_run_fails():
+    """Whatever goes wrong after start-up — here: a watchdog of a fraction of a second — rank 0 still prints ONE
+    JSON line (value null, the reason in `error`) and the exit code says so."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--learners", "0",
+                          "--no-configs", "--steps", "200000", "--warmup", "30", "--watchdog", "0.5"], cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    line = [x for x in out.stdout.splitlines() if x.strip()][-1]
+    d = json.loads(line)
+    assert d["value"] is None and "watchdog" in d["error"] and d["n_gpus"] == 1, d
