@@ -13,7 +13,10 @@ import sys
 
 
 def per_kernel(d, counter):
-    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    if not fs:
+        return {}
+    f = fs[0]
     tot, n = collections.defaultdict(float), collections.defaultdict(int)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
@@ -47,6 +50,7 @@ def stats_ns(path):
 CLOCK_GHZ = 2.4      # MI355X_MICROARCH.md max clock; in-kernel stamps read 2.31-2.40 GHz for these kernels
 if len(sys.argv) > 4:
     c = {n: per_kernel(sys.argv[4], n) for n in ("SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_MOPS_BF16",
+                                                 "SQ_INSTS_VALU_MFMA_MOPS_F16",
                                                  "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE")}
     for k in out:
         if k not in c["GRBM_GUI_ACTIVE"]:
@@ -57,6 +61,7 @@ if len(sys.argv) > 4:
         out[k].update({
             "mfma_flops_f32_per_launch": int(512 * c["SQ_INSTS_VALU_MFMA_MOPS_F32"].get(k, (0.0, 0))[0]),
             "mfma_flops_bf16_per_launch": int(512 * c["SQ_INSTS_VALU_MFMA_MOPS_BF16"].get(k, (0.0, 0))[0]),
+            "mfma_flops_f16_per_launch": int(512 * c["SQ_INSTS_VALU_MFMA_MOPS_F16"].get(k, (0.0, 0))[0]),
             "mfma_busy_cycles_per_launch": round(busy, 1), "gui_active_cycles_per_launch": round(gui, 1),
             "sq_busy_cycles_per_launch": round(c["SQ_BUSY_CYCLES"].get(k, (0.0, 0))[0], 1),
             "avg_duration_ns_unprofiled": ns,

@@ -2,7 +2,7 @@
 # Round profile of the headline command (run on the GPU box through gpurun; writes under gpurun_out/prof_$TAG):
 #   kernel stats (rocprofv3 --kernel-trace --stats) and three separate --pmc passes (FETCH_SIZE / WRITE_SIZE / MFMA
 #   counters), as MI355X_MICROARCH.md prescribes (counters never combined with trace domains beyond --kernel-trace).
-# usage: tools/profile_round.sh TAG [extra bench.py args, e.g. --precision bf16]
+# usage: tools/profile_round.sh TAG [extra bench.py args, e.g. --precision bf16]   (default mode: x2)
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $BENC
 BENCH="python bench.py --steps 600 --warmup 100 --no-cpu-baseline --learners 0 --no-configs --profile-steps 1 --pre-warm 200 $*"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- $BENCH > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- $BENCH > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -o m -- $BENCH > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -o m -- $BENCH > /dev/null 2>&1
 head -1 $OUT/stats/*kernel_stats.csv > $OUT/kernel_stats.csv
 grep -E "oprl|k_replay" $OUT/stats/*kernel_stats.csv >> $OUT/kernel_stats.csv
 python tools/pmc_summary.py $OUT/fetch $OUT/write $OUT/pmc_traffic.json $OUT/mfma $OUT/kernel_stats.csv > /dev/null
