@@ -205,15 +205,16 @@ __device__ __forceinline__ void dw_write_packs(const DwItem& I, const float (*ti
 }
 
 
-// GATE: 0 = a launch of its own, 1 = the critic's tiles on phase 1's launch (above), 2 = the ACTOR's tiles on phase
-// 2's launch: X rows are the previous launch's, dY is formed here from the du granules (DwGate, kernels.h).
+// GATE: 0 = a launch of its own, 1 = the critic's tiles on phase 1's launch (above).  (The actor's tiles on phase 2's
+// launch — GATE 2 of DwGate — exist as PrecX2 tiles only: csrc/dw_tile_x2.h.)
 template <bool XCHG, int GATE = 0, int NW = kDwWaves>
 __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int bx) {   // bx: the tile (bx of a stand-alone launch)
   constexpr bool GATED = GATE == 1;
   constexpr int TN = kDwTileN, TK = kDwTile, LD = TK + 4;
   using DL = DwLds<NW>;
   constexpr int RW = DL::RW;
-  static_assert(GATE == 2 || NW == kDwWaves, "the chunk loop of the stand-alone kernel is written for 8 waves x 32 rows");
+  static_assert(GATE == 0 || GATE == 1, "see above");
+  static_assert(NW == kDwWaves, "the chunk loop is written for 8 waves x 32 rows");
   float (*part)[TN][LD] = reinterpret_cast<float (*)[TN][LD]>(lds + DL::part);
   float (*bpart)[TN] = reinterpret_cast<float (*)[TN]>(lds + DL::bpart);
   float* sc = lds + DL::sc;
@@ -326,126 +327,7 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int b
     if (!ok) report_expired(A.gate.err, A.gate.err_code);
     __syncthreads();
   }
-  if constexpr (GATE == 2) {
-    // ---- the actor's tiles on phase 2's launch (one 256-row chunk, NW = 16 waves x 16 rows: lane (ar, an) owns dY
-    // row ar, columns an .. an + 3): X first — it is the previous launch's — then whatever of dY does not depend on
-    // du, then the du granules
-    static_assert(RW == 16, "one dY row group per wave");
-    const DwGate& G = KA->gate;
-    const int kind = item == 0 ? G.kind[0] : (item == 1 ? G.kind[1] : (item == 2 ? G.kind[2] : G.kind[3]));
-    const int Ad = G.n_act;
-    const int bb = RW * wave + ar;                     // this lane's dY row
-    const int ncol = n_base + an;                      // ... and its first dY column
-    f32x4 vx[2], va[kDuLd];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int bx_ = RW * wave + xr + 8 * j;
-      vx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (bx_ < hB && xk_ok) vx[j] = ld4(I.X + (size_t)bx_ * I.ldx + k_base + xk);
-    }
-#pragma unroll
-    for (int j = 0; j < kDuLd; ++j) va[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 hmask = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (kind == 1 && an_ok) {
-      // the second hidden layer's activations (ReLU mask) and the output layer's rows W3[j][ncol .. ncol + 3]
-      if (bb < hB) hmask = ld4(G.h2 + (size_t)bb * I.ldy + ncol);
-#pragma unroll
-      for (int j = 0; j < kDuLd; ++j)
-        if (j < Ad) va[j] = ld4(G.w3 + (size_t)j * I.ldy + ncol);
-    }
-    // First attempts at everything this tile waits for are REQUESTED TOGETHER with the rows above (a tile that starts
-    // after the roles have retired finds it all there: one round trip, not one per kind of flag): the row's du
-    // granules, and this thread's flag of role U — its members have written their rows through (first hidden layer,
-    // `rows`) or at least READ the packs this tile's epilogue rewrites (`read`: every other tile, before it stores).
-    unsigned long long g[kDuLd];
-#pragma unroll
-    for (int j = 0; j < kDuLd; ++j)
-      g[j] = (j < Ad && bb < hB) ? __hip_atomic_load(G.seed + (size_t)bb * kDuLd + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                 : ((unsigned long long)G.tag << 32);
-    const unsigned long long* fl = kind == 2 ? G.rows : G.read;
-    const int nfl = kind == 2 ? G.n_rows : G.n_read;
-    const unsigned long long* myf = fl + (tid < nfl ? tid : 0);       // (n flags <= 128 < threads: every flag has a poller)
-    unsigned long long f0 = __hip_atomic_load(myf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    {
-      bool ok = (unsigned)(f0 >> 32) == G.tag;
-      for (int spin = 0; spin < G.spin && !ok; ++spin) {
-        __builtin_amdgcn_s_sleep(2);
-        ok = (unsigned)(__hip_atomic_load(myf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == G.tag;
-      }
-      if (!ok) report_expired(G.err, G.err_code);
-    }
-    if (kind == 2) {
-      __syncthreads();     // every member of role U has flagged its rows
-      if (an_ok && bb < hB) {
-        const float* src = G.U + (((size_t)(ncol >> 4) * Ad) * hB + bb) * 16 + (ncol & 15);
-#pragma unroll
-        for (int j = 0; j < kDuLd; ++j)
-          if (j < Ad) va[j] = ld4_sc1(src + (size_t)j * hB * 16);
-      }
-    }
-    float du[kDuLd];
-    {
-      bool ok = true;
-#pragma unroll
-      for (int j = 0; j < kDuLd; ++j) ok = ok && (unsigned)(g[j] >> 32) == G.tag;
-      for (int spin = 0; spin < G.spin && !ok; ++spin) {
-        __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-        for (int j = 0; j < kDuLd; ++j)
-          if (j < Ad) g[j] = __hip_atomic_load(G.seed + (size_t)bb * kDuLd + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = true;
-#pragma unroll
-        for (int j = 0; j < kDuLd; ++j) ok = ok && (unsigned)(g[j] >> 32) == G.tag;
-      }
-      if (!ok) report_expired(G.err, G.err_code);
-#pragma unroll
-      for (int j = 0; j < kDuLd; ++j)
-        du[j] = (bb < hB && j < Ad) ? (ok ? __uint_as_float((unsigned)g[j]) : __builtin_nanf("")) : 0.f;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the sc1 row loads are inline asm: hipcc does not count them)
-    stamp();   // rows and seeds in
-    {
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (kind != 0) {
-#pragma unroll
-        for (int j = 0; j < kDuLd; ++j) v += va[j] * du[j];
-        if (kind == 1) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) v[t] = hmask[t] > 0.f ? v[t] : 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          float x = 0.f;
-#pragma unroll
-          for (int j = 0; j < kDuLd; ++j) x = (ncol + t == j) ? du[j] : x;
-          v[t] = x;
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) v[t] = (ncol + t < I.N && an < TNi) ? v[t] : 0.f;
-      *reinterpret_cast<f32x4*>(&stA[wave][ar][an]) = v;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      f32x4 v = vx[j];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) v[t] = (k_base + xk + t < I.K) ? v[t] : 0.f;
-      *reinterpret_cast<f32x4*>(&stX[wave][xr + 8 * j][xk]) = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int u = 0; u < RW / 4; ++u) {
-      const float av = stA[wave][4 * u + c][i];
-      const f32x2 xv = *reinterpret_cast<const f32x2*>(&stX[wave][4 * u + c][2 * i]);
-      sA += av;
-      acc[0] = mfma4(av, xv[0], acc[0]);
-      acc[1] = mfma4(av, xv[1], acc[1]);
-    }
-  }
-  for (int chunk = 0; GATE != 2 && chunk * 256 < (h_apply ? 0 : hB); ++chunk) {
+  for (int chunk = 0; chunk * 256 < (h_apply ? 0 : hB); ++chunk) {
     const int base = chunk * 256 + 32 * wave;
     f32x4 va[2][4], vx[4];
     float rs[2];

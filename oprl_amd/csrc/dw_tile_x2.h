@@ -185,17 +185,27 @@ struct DwX2Tile {
     }
   }
   // first attempts at what the tile waits for, requested with the rows
+  // (kind 2: the lane's four dz1 granules of the critic pass's backward step, in g[0 .. 3])
   unsigned long long g[kDuLd];
+  const unsigned long long* gsrc = nullptr;
+  int n_g = 0;
   if constexpr (GATE == 2) {
+    const bool row_in = bb < hB;
+    if (kind == 2) {
+      gsrc = G.g1 + ((size_t)(ncol >> 4) * hB + (row_in ? bb : 0)) * 16 + (ncol & 15);
+      n_g = (row_in && an_ok) ? 4 : 0;
+    } else {
+      gsrc = G.seed + (size_t)(row_in ? bb : 0) * kDuLd;
+      n_g = row_in ? G.n_act : 0;
+    }
 #pragma unroll
     for (int j = 0; j < kDuLd; ++j)
-      g[j] = (j < G.n_act && bb < hB) ? __hip_atomic_load(G.seed + (size_t)bb * kDuLd + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                      : ((unsigned long long)G.tag << 32);
+      g[j] = j < n_g ? __hip_atomic_load(gsrc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)G.tag << 32);
   }
-  {
-    const unsigned long long* fl = (GATE == 2 && kind != 2) ? G.read : G.rows;
-    const int nfl = (GATE == 2 && kind != 2) ? G.n_read : G.n_rows;
-    const unsigned long long* myf = fl + (tid < nfl ? tid : 0);
+  // (GATE 2 waits for granules only: what the critic pass reads of the actor's packs it has taken in BEFORE it publishes
+  // du, and no tile stores before it has du)
+  if constexpr (GATE == 1) {
+    const unsigned long long* myf = G.rows + (tid < G.n_rows ? tid : 0);
     bool ok = (unsigned)(__hip_atomic_load(myf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == G.tag;
     for (int spin = 0; spin < G.spin && !ok; ++spin) {
       __builtin_amdgcn_s_sleep(2);
@@ -234,19 +244,6 @@ struct DwX2Tile {
     u = ((pa0 + (npart > 1 ? pa1 : z4)) + (npart > 2 ? pa2 : z4)) + (npart > 3 ? pa3 : z4);   // member order, as k_dw_adam sums them
     if (late) u = f32x4{ncol == 0 ? 1.f : 0.f, 0.f, 0.f, 0.f};
     if (!(bb < hB && (an_ok || late))) u = z4;
-  } else if (kind == 2) {
-    __syncthreads();     // every member of role U has flagged its rows
-    const bool ok_u = an_ok && bb < hB;
-    const int ub = bb < hB ? bb : hB - 1, uc = an_ok ? ncol : 0;
-    const float* src = G.U + (((size_t)(uc >> 4) * G.n_act) * hB + ub) * 16 + (uc & 15);
-    f32x4 ru[kDuLd];
-#pragma unroll
-    for (int j = 0; j < kDuLd; ++j) ru[j] = ld4_sc1(src + (size_t)(j < G.n_act ? j : 0) * hB * 16);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < kDuLd; ++j) sc1_arrived(ru[j]);
-#pragma unroll
-    for (int j = 0; j < kDuLd; ++j) va[j] = (ok_u && j < G.n_act) ? ru[j] : z4;
   }
   // X -> 2^4 X -> two fp16 planes, transposed: plane[k][b], the two rows of this lane side by side
 #pragma unroll
@@ -293,7 +290,7 @@ struct DwX2Tile {
       __builtin_amdgcn_s_sleep(1);
 #pragma unroll
       for (int j = 0; j < kDuLd; ++j)
-        if (j < G.n_act) g[j] = __hip_atomic_load(G.seed + (size_t)bb * kDuLd + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (j < n_g) g[j] = __hip_atomic_load(gsrc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ok = true;
 #pragma unroll
       for (int j = 0; j < kDuLd; ++j) ok = ok && (unsigned)(g[j] >> 32) == G.tag;
@@ -301,15 +298,15 @@ struct DwX2Tile {
     if (!ok) report_expired(G.err, G.err_code);
 #pragma unroll
     for (int j = 0; j < kDuLd; ++j)
-      du[j] = (bb < hB && j < G.n_act) ? (ok ? __uint_as_float((unsigned)g[j]) : __builtin_nanf("")) : 0.f;
+      du[j] = j < n_g ? (ok ? __uint_as_float((unsigned)g[j]) : __builtin_nanf("")) : 0.f;
     stamp();   // rows and seeds in
-    if (kind != 0) {
+    if (kind == 2) {
+      v = f32x4{du[0], du[1], du[2], du[3]};
+    } else if (kind == 1) {
 #pragma unroll
       for (int j = 0; j < kDuLd; ++j) v += va[j] * du[j];
-      if (kind == 1) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = hmask[t] > 0.f ? v[t] : 0.f;
-      }
+      for (int t = 0; t < 4; ++t) v[t] = hmask[t] > 0.f ? v[t] : 0.f;
     } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {

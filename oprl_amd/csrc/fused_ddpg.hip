@@ -858,32 +858,25 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2_group(const DdpgArgs* 
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Phase 2 with the ACTOR's dW + Adam tiles on the same launch (DdpgArgs::merged bit 1; DDPG / TD3, fp32 lean passes,
-// action_dim <= kDuLd, B <= 256).
+// Phase 2 with the ACTOR's dW + Adam tiles on the same launch (DdpgArgs::merged bit 1; PrecX2 learners, DDPG / TD3,
+// lean passes on clusters of eight, action_dim <= kDuLd, B <= 256).
 //
 // The actor's backward is linear in its output seed du = da (1 - pi^2) [B x A], and everything else it needs — the
-// actor's weights and its forward activations (role C of phase 1) — exists when this launch starts.  So it leaves
-// the update's critical chain: ROLE U (eight workgroups per slice, beside the critic pass) runs it with A unit seeds
-//     U_j[b, k] = (h1[b, k] > 0) sum_n (h2[b, n] > 0) W3[j, n] W2[n, k]          (member c: columns 32 c .. 32 c + 31; wave = tile x seed)
-// and writes the rows through; the critic pass (forward + constant-seed backward to the action columns, unchanged)
-// ends by publishing du as {epoch, value} granules; the actor's dW tiles (dw_adam_body<false, 2>), riding behind the
-// roles like the critic's tiles ride on phase 1, have taken in their Adam state and X rows by then and form their dY
-// from du:  output layer du itself, second hidden layer (h2 > 0) (du W3), first hidden layer sum_j du_j U_j.  What
-// used to follow the critic pass — the actor's backward (a whole pass), a kernel boundary and a k_dw_adam launch — is
-// one granule hop, a few FMAs per element, 16 MFMAs and the Adam epilogue.
-// Grid rows: [0, NMC) critic pass | [NMC, NMC + 8) role U | prefetch row (step_n) | tiles.
+// actor's weights and its forward activations (role C of phase 1) — exists when this launch starts.  The critic pass
+// (forward + constant-seed backward to the action columns, unchanged) ends by publishing du as {epoch, value}
+// granules; the actor's dW tiles (dw_tile_x2.h, GATE 2), riding behind the pass like the critic's tiles ride on phase
+// 1, have taken in their Adam state and X rows by then and form their dY from du: the output layer's is du itself, the
+// second hidden layer's (h2 > 0) (du W3) — 84 of the 100 tiles' worth of dW.  The first hidden layer's dY is one more
+// backward step,   g1[b, k] = (h1[b, k] > 0) sum_n g2[b, n] W2[n, k],   g2 = (h2 > 0) (du W3):
+// the pass's eight members per slice go on with it (member c: columns 32 c .. 32 c + 31; its W2^T shard, the h2 / h1
+// masks and W3 were taken in at the START of the pass — nothing it reads can be rewritten by a tile, which stores only
+// after du), 3 MFMAs per wave, and publish g1 element by element as granules for the 16 first-layer tiles.  What used
+// to follow the critic pass — the actor's backward (a whole pass), a kernel boundary and a k_dw_adam launch — is one
+// granule hop, a few FMAs per element, the tile's MFMAs and the Adam epilogue.
+// (An earlier form ran the du-independent part of that step with unit seeds on eight more workgroups per slice: 128
+// compute units for 6 us per update that the whole-update launch needs for the pass itself — profiles/r03_experiments.txt.)
+// Grid rows: [0, 8) critic pass | prefetch row (step_n, two-launch form) | tiles.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kUMembers = 8;    // role U's workgroups per slice: member c owns columns 32 c .. 32 c + 31 of the first hidden layer
-struct RoleULds {   // floats
-  static constexpr int w = 0;                               // the member's W2^T shard: [2 tiles][16 steps][256]
-  static constexpr int h2 = w + 2 * 16 * 256;               // [kR][kWL4]
-  static constexpr int w3 = h2 + kR * kWL4;                 // [kDuLd][256] rows of the output layer (zero beyond A)
-  static constexpr int out = w3 + kDuLd * 256;              // [kWaves][16][16] finished tiles, for 16-byte stores
-  static constexpr int total = out + kWaves * 256;
-};
-
-// (T, D, tile: the tile this workgroup goes on with — PrecX2 — requests its rows once this role's own loads are in flight)
-struct NoTile { template <class KA> __device__ __forceinline__ void begin(const KA&, float*, int) {} };
 // one bounded wait for n flag granules {tag, *}: thread k polls flag k (n <= threads); the caller's barrier releases everybody
 __device__ __forceinline__ void wait_flags(const unsigned long long* flags, int n, unsigned tag, unsigned* err, unsigned code) {
   const int k = (int)threadIdx.x;
@@ -896,159 +889,27 @@ __device__ __forceinline__ void wait_flags(const unsigned long long* flags, int 
     if (!ok) report_expired(err, code);
   }
 }
-template <class P, class TileT, class KA>
-__device__ __forceinline__ void role_u(const DdpgArgs& A, float* smem, int slice, int c, TileT& T, const KA* D, int tile) {
-  float* Wl = smem + RoleULds::w;
-  float* h2s = smem + RoleULds::h2;
-  float* w3s = smem + RoleULds::w3;
-  float* outs = smem + RoleULds::out;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
-  const int row0 = slice * kR, B = A.B, Ad = A.A;
-  int n_stamp = 0;
-  auto stamp = [&]() {   // trace slot 6 (phase 2's own is slot 3): workgroup = slice, member 0
-    if (A.trace != nullptr && tid == 0 && c == 0 && n_stamp < kTraceStamps) {
-      long long* tr = A.trace + (((size_t)3 * 64 + slice) * kTraceStamps + n_stamp) * 2;
-      tr[0] = (long long)__builtin_readcyclecounter();
-      tr[1] = (long long)wall_clock64();
-    }
-    ++n_stamp;
-  };
-  stamp();
-  if (A.whole) {
-    // (k_ddpg_update) role C of this very launch writes what this role reads — uncached memory: its members' flags,
-    // then an invalidate of this CU's L1, which an earlier workgroup may have left lines of those buffers in
-    wait_flags(A.w_flags, 4 * (int)gridDim.x, A.epoch, A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
-    __syncthreads();
-    asm volatile("buffer_inv sc0" ::: "memory");
-  }
-  // ---- requests: the shard (32 KB, two b128 per thread), the slice's h2 rows, the output layer's snapshot, and
-  // this lane's h1 elements (the mask of what it will finish)
-  const float* wsrc = A.actor.pb[1] + (size_t)c * 2 * 16 * 256;
-  f32x4 wv[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) wv[q] = ld4(wsrc + ((size_t)q * kThreads + tid) * 4);
-  const int hr = tid >> 6, hc = (tid & 63) * 4;
-  f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (row0 + hr < B) hv = ld4(A.aX[2] + (size_t)(row0 + hr) * kW4 + hc);
-  f32x4 w3q = f32x4{0.f, 0.f, 0.f, 0.f};                  // W3[tid >> 6][4 (tid & 63) ..]: rows beyond A stay zero
-  if ((tid >> 6) < Ad) w3q = ld4(A.w3_snap + (size_t)tid * 4);
-  const int t1 = wave & 1, j = wave >> 1;                  // this wave: tile t1 of the member, unit seed j
-  float m1[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int gr = row0 + 4 * kk + r;
-    m1[r] = gr < B ? A.aX[1][(size_t)gr * kW4 + 32 * c + 16 * t1 + i] : 0.f;
-  }
-  if (tile >= 0) T.begin(*D, smem, tile);
-#pragma unroll
-  for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(Wl + ((size_t)q * kThreads + tid) * 4) = wv[q];
-  *reinterpret_cast<f32x4*>(h2s + hr * kWL4 + hc) = hv;
-  if (tid < kDuLd * 64) *reinterpret_cast<f32x4*>(w3s + (size_t)tid * 4) = w3q;
-  __syncthreads();
-  // everything this role reads of the actor is in LDS: the tiles of this launch may rewrite the actor's packs
-  if (tid == 0)
-    __hip_atomic_store(A.u_flags + 128 + slice * kUMembers + c, (unsigned long long)A.epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  stamp();   // shard, rows and the output layer in LDS
-  if (j < Ad) {
-    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;   // even / odd steps: two MFMA chains
-    const float* hrow = h2s + i * kWL4 + 4 * kk;
-    const float* w0 = w3s + j * 256 + 4 * kk;
-    if constexpr (P::kX2) {
-      // the shard is [2 tiles][8 macro steps][hi 256 | lo 256 floats]; the masked output-layer row goes in scaled by
-      // 2^12 (|w3| < 16), as the unit-seed tiles of tp4_scalar_fb do
-      constexpr float sb = 4096.f;
-      const float* bw = Wl + (size_t)t1 * 8 * 512 + lane * 4;
-      auto step = [&](int s, f32x4& acc) {
-        const FragX2 b{ld4(bw + s * 512), ld4(bw + s * 512 + 256)};
-        const f32x4 h0 = ld4(hrow + 32 * s), h1v = ld4(hrow + 32 * s + 16);
-        f32x4 x0 = ld4(w0 + 32 * s) * sb, x1 = ld4(w0 + 32 * s + 16) * sb;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          x0[t] = h0[t] > 0.f ? x0[t] : 0.f;
-          x1[t] = h1v[t] > 0.f ? x1[t] : 0.f;
-        }
-        PrecX2::mma3(x0, x1, b, acc);
-      };
-      // (two steps per trip: unrolled eight times hipcc hoists every LDS read to the top of the loop, and this role
-      // carries its tile's rows through it — 128 VGPRs per lane at 1024 threads)
-#pragma unroll 1
-      for (int s = 0; s < 8; s += 2) {
-        step(s, a0);
-        step(s + 1, a1);
-      }
-      a0 = (a0 + a1) * (PrecX2::kOut / sb);
-      a1 = f32x4{0.f, 0.f, 0.f, 0.f};
-    } else {
-      const float* bw = Wl + ((size_t)t1 * 16 * 64 + lane) * 4;
-#pragma unroll
-      for (int s = 0; s < 16; s += 2) {
-        const f32x4 b0 = ld4(bw + s * 256), b1 = ld4(bw + (s + 1) * 256);
-        const f32x4 h0 = ld4(hrow + 16 * s), h1v = ld4(hrow + 16 * (s + 1));
-        const f32x4 x0 = ld4(w0 + 16 * s), x1 = ld4(w0 + 16 * (s + 1));
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          a0 = mfma4(h0[t] > 0.f ? x0[t] : 0.f, b0[t], a0);
-          a1 = mfma4(h1v[t] > 0.f ? x1[t] : 0.f, b1[t], a1);
-        }
-      }
-    }
-    // lane (kk, i): rows 4 kk + r, column 32 c + 16 t1 + i of unit seed j -> through wave-private LDS -> U[tile][j][row][16]
-    // as one contiguous KB per wave, written through
-    float* o = outs + wave * 256;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[(4 * kk + r) * 16 + i] = m1[r] > 0.f ? a0[r] + a1[r] : 0.f;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int tile = 2 * c + t1, row = lane >> 2, gr = row0 + row;
-    if (gr < B) tp4_st4(A.U + (((size_t)tile * Ad + j) * B + gr) * 16 + (lane & 3) * 4, ld4(o + row * 16 + (lane & 3) * 4), true);
-  }
-  stamp();   // MFMAs done, stores issued
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  stamp();   // written through
-  if (tid == 0)
-    __hip_atomic_store(A.u_flags + slice * kUMembers + c, (unsigned long long)A.epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
-template <class P, bool WIDE, class KA = DwKArgs>
+template <class P, class KA = DwKArgs>
 __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const KA* D, int by_in = -1) {
+  static_assert(P::kX2 && kDwTileX2, "the merged phase 2 exists for PrecX2 learners");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<256>;
   constexpr int HB = kR * kWL4;
-  constexpr int NMC = WIDE ? 8 : 4;
+  constexpr int NMC = 8;
   const int B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
   const int slice = blockIdx.x, row0 = slice * kR;
   const int y = by_in < 0 ? (int)blockIdx.y : by_in;
-  const int yP = NMC + kUMembers, yT = yP + (A.prefetch_next ? 1 : 0);
-  constexpr bool CONT = P::kX2 && kDwTileX2;     // role U's workgroups go on as tile workgroups (below)
+  const int yP = NMC, yT = yP + (A.prefetch_next ? 1 : 0);
   if (y >= yT) {   // a tile workgroup: all 16 waves (16 minibatch rows each)
-    const int tile = (CONT ? kUMembers * (int)gridDim.x : 0) + (y - yT) * (int)gridDim.x + slice;
+    const int tile = (y - yT) * (int)gridDim.x + slice;
     if (tile >= dw_total(*D)) return;
-    if (A.whole) {      // (k_ddpg_update: the rows this tile reads are role C's of this very launch, as role U's are)
+    if (A.whole) {      // (k_ddpg_update: the rows this tile reads are role C's of this very launch)
       wait_flags(A.w_flags, 4 * (int)gridDim.x, A.epoch, A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
       __syncthreads();
       asm volatile("buffer_inv sc0" ::: "memory");
     }
-    if constexpr (CONT) dw_tile_x2<2, KA>(*D, smem, tile);
-    else if constexpr (std::is_same<KA, DwKArgs>::value) dw_adam_body<false, 2, 16>(*D, smem, tile);
-    return;
-  }
-  if (y >= NMC && y < yP) {
-    if constexpr (CONT) {
-      // role U's workgroup goes on as the tile workgroup of tile (slice, member): resident since the launch began — a
-      // workgroup dispatched when this one retires starts 1.2 us later with its whole input phase still in front of
-      // it — and its tile's rows and Adam state are requested from inside role U, behind that role's own requests:
-      // they have arrived when it is done, two microseconds before the critic pass publishes du
-      const int tile = slice * kUMembers + (y - NMC);
-      const bool has = tile < dw_total(*D);
-      DwX2Tile<2, KA> T;
-      role_u<P>(A, smem, slice, y - NMC, T, D, has ? tile : -1);
-      if (has) T.finish();
-    } else {
-      NoTile T;
-      role_u<P>(A, smem, slice, y - NMC, T, D, -1);
-    }
+    dw_tile_x2<2, KA>(*D, smem, tile);
     return;
   }
   float* xa = smem + LY::xa;
@@ -1077,12 +938,19 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const KA* D
   float* h1 = smem + LY::h;
   float* h2 = h1 + HB;
   float* g2 = h2 + HB;
+  float* Wl = g2 + HB;                             // two spare hidden buffers: the member's W2^T shard [2 tiles][8 steps][hi 256 | lo 256]
   float* outS = smem + LY::out;
   float* auxS = smem + LY::aux;
+  float* duS = smem + LY::aux2;                    // [kR][kDuLd] du of the slice, + 16 wave maxima
   float* scr = smem + LY::scr;
+  float* w3s = smem + LY::misc + 96;               // [kDuLd][256] the output layer's rows (the prefetch rows' ends table is not in use here)
+  static_assert(2 * HB >= 2 * 8 * 512, "the shard fits the two spare hidden buffers");
+  static_assert(kMaxEnds >= kDuLd * 256 && kR * kOutLd >= kR * kDuLd + kWaves, "W3 and du fit their areas");
   Tp tp{y, NMC, A.xbuf + (size_t)slice * kTpStages * A.xnc * kTpBlk, A.whole ? A.cluster_tag2 : A.cluster_tag, 0,
         A.err, KERN_PHASE2 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
   const bool lead = tp.c == 0;
+  const int c = tp.c;
+  const int lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
   long long* const trace = A.whole ? A.trace2 : A.trace;
   int n_stamp = 0;
   auto stamp = [&]() {
@@ -1098,8 +966,8 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const KA* D
   const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
   Net critic = A.critic;
   if (A.whole) {
-    // (k_ddpg_update) role C of this launch wrote s and pi — uncached memory: its members' flags, then an invalidate of
-    // this CU's L1; the critic's packs and biases follow below, behind the rows
+    // (k_ddpg_update) role C of this launch wrote s, pi and the actor's activations — uncached memory: its members'
+    // flags, then an invalidate of this CU's L1; the critic's packs and biases follow below, behind the rows
     wait_flags(A.w_flags, 4 * (int)gridDim.x, A.epoch, A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
     __syncthreads();
     asm volatile("buffer_inv sc0" ::: "memory");
@@ -1108,6 +976,20 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const KA* D
     const float* p0 = A.aX[0]; const float* p3 = A.pi; const int ld0 = A.aldx0;
     asm volatile("" :: "s"(p0), "s"(p3), "s"(ld0));
   }
+  // ---- requests.  For the backward step at the end: the member's W2^T shard (32 KB, two b128 per thread), the
+  // output layer's rows, this thread's four h2 elements and (threads < 512) its h1 element — the ReLU masks
+  const float* wsrc = A.actor.pb[1] + (size_t)c * 2 * 16 * 256;
+  f32x4 wv[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) wv[q] = ld4(wsrc + ((size_t)q * kThreads + tid) * 4);
+  const int hr = tid >> 6, hc = (tid & 63) * 4;                  // g2 element quad: row hr, columns hc .. hc + 3
+  f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (row0 + hr < B) hv = ld4(A.aX[2] + (size_t)(row0 + hr) * kW4 + hc);
+  f32x4 w3q = f32x4{0.f, 0.f, 0.f, 0.f};                         // W3[tid >> 6][4 (tid & 63) ..]: rows beyond A stay zero
+  if ((tid >> 6) < Ad) w3q = ld4(A.w3_snap + (size_t)tid * 4);
+  const int et = (tid >> 8) & 1, er = (tid >> 4) & 15, ec = tid & 15;   // g1 element (threads < 512): tile et, row er, column ec
+  float m1 = 0.f;
+  if (tid < 512 && row0 + er < B) m1 = A.aX[1][(size_t)(row0 + er) * kW4 + 32 * c + 16 * et + ec];
   // [s | pi]: loads first, then the zero fill and the stores
   const int rs_ = tid / S, cs_ = tid - rs_ * S;
   const bool oks = tid < kR * S && row0 + rs_ < B;
@@ -1125,6 +1007,12 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const KA* D
   if (tid < kR * S) xa[rs_ * kX0Ld + cs_] = vs;
   if (tid2 < kR * S) xa[rs2_ * kX0Ld + cs2_] = vs2;
   if (tid < kR * Ad) xa[rp_ * kX0Ld + S + cp_] = vp;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(Wl + ((size_t)q * kThreads + tid) * 4) = wv[q];
+  if (tid < kDuLd * 64) *reinterpret_cast<f32x4*>(w3s + (size_t)tid * 4) = w3q;
+  // (the masks stay in one register through the pass: bits 0..3 the h2 quad, bit 4 the h1 element)
+  const unsigned mbits = (hv[0] > 0.f ? 1u : 0u) | (hv[1] > 0.f ? 2u : 0u) | (hv[2] > 0.f ? 4u : 0u) | (hv[3] > 0.f ? 8u : 0u) |
+                         (m1 > 0.f ? 16u : 0u);
   if (A.whole) {
     // ... the critic's TILES of this launch wrote the critic's fp16 packs and biases (uncached memory): their flags
     // (one poller each), the invalidate; the biases come from the tiles' uncached copies (the masters sit dirty in
@@ -1155,24 +1043,79 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const KA* D
     granule_put(A.du_granules + (size_t)(row0 + rp_) * kDuLd + cp_, A.epoch, du);
     A.adY[2][(size_t)(row0 + rp_) * A.alddo + cp_] = du;
   }
+  // ---- the backward step through the second hidden layer, this member's 32 columns of the first one's dY
+  if (tid < kR * kDuLd) {      // du of the slice [kR][kDuLd], zero beyond A and B
+    const int r = tid >> 3, j = tid & 7;
+    float v = 0.f;
+    if (j < Ad && row0 + r < B) {
+      const float pv = xa[r * kX0Ld + S + j];
+      v = auxS[r * kOutLd + j] * (1.f - pv * pv);
+    }
+    duS[tid] = v;
+  }
+  __syncthreads();
+  {
+    // g2[hr][hc ..] = (h2 > 0) sum_j du[hr][j] W3[j][hc ..]  ->  h1 (the critic's buffers are free), unscaled; the
+    // tile's largest magnitude fixes the scale of the fp16 split (as tp4_backward does it)
+    const f32x4 d0 = ld4(duS + hr * kDuLd), d1 = ld4(duS + hr * kDuLd + 4);
+    f32x4 gq = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gq += ld4(w3s + j * 256 + hc) * d0[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gq += ld4(w3s + (4 + j) * 256 + hc) * d1[j];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) gq[t] = ((mbits >> t) & 1u) != 0u ? gq[t] : 0.f;
+    *reinterpret_cast<f32x4*>(h1 + hr * kWL4 + hc) = gq;
+    float m = fmaxf(fmaxf(fabsf(gq[0]), fabsf(gq[1])), fmaxf(fabsf(gq[2]), fabsf(gq[3])));
+    m = wave_max(m);
+    if (lane == 0) duS[kR * kDuLd + wave] = m;
+  }
+  __syncthreads();
+  {
+    float m = duS[kR * kDuLd + (lane & 15)];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float s1 = P::a_scale(m);
+    // wave = (tile t1 of the member's two, macro step ws of eight): one split product, partial tile -> scr
+    const int t1 = wave & 1, ws = wave >> 1;
+    const float* hrow = h1 + i * kWL4 + 4 * kk;
+    const float* bw = Wl + ((size_t)t1 * 8 + ws) * 512 + lane * 4;
+    const FragX2 bf{ld4(bw), ld4(bw + 256)};
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    PrecX2::mma3(ld4(hrow + 32 * ws) * s1, ld4(hrow + 32 * ws + 16) * s1, bf, acc);
+    float* o = scr + wave * 256;
+    const float un = PrecX2::kOut / s1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[(4 * kk + r) * 16 + i] = acc[r] * un;
+  }
+  __syncthreads();
+  if (tid < 512 && row0 + er < B) {
+    float v = 0.f;
+#pragma unroll
+    for (int ws = 0; ws < 8; ++ws) v += scr[(2 * ws + et) * 256 + er * 16 + ec];
+    v = (mbits & 16u) != 0u ? v : 0.f;
+    granule_put(const_cast<unsigned long long*>(A.g1_granules) + ((size_t)(2 * c + et) * B + row0 + er) * 16 + ec, A.epoch, v);
+  }
   stamp();
 }
 
-template <class P, bool WIDE>
+template <class P>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase2_dw(const DdpgArgs A, const DwKArgs D) {
   const DwKArgs* Dp = (const DwKArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kMergedDwOffset);
-  ddpg_phase2m_body<P, WIDE>(A, Dp);
+  ddpg_phase2m_body<P>(A, Dp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // The WHOLE update as one launch (PrecX2 learners, DDPG, B <= 256): the rows of the merged phase 1 — roles B | A (on
-// eight) | C, the critic's tiles — followed by the rows of the merged phase 2 — role U (going on as the actor's tiles),
-// the critic pass — and the prefetch row.  Workgroups are dispatched in this order and only ever wait for workgroups
-// dispatched before them: role U for role C, the critic pass for role C and the critic's tiles, every tile for its
-// seeds.  By the time the critic pass has all its eight members per slice resident (the critic's tiles have retired)
-// its inputs exist.  What used to cross the kernel boundary between the two launches — the critic's new packs and
-// biases, pi, the actor's activations — lives in uncached memory and travels behind flags (DdpgArgs::whole).
-// One launch gap (~3 us of an update) less.
+// eight) | C; roles B and C go on as the critic's tile workgroups — followed by the rows of the merged phase 2 — the
+// critic pass, the actor's tiles — and the prefetch row.  Workgroups are dispatched in this order and only ever wait
+// for workgroups dispatched before them: the critic pass for role C and the critic's tiles, every tile for its seeds.
+// Compute units: the roles fill the chip; role C's workgroups without a tile retire first (44 at B = 256) and role A's
+// 128 next — the critic pass's 128 workgroups are all resident when the critic's tiles raise their flags (a member that
+// starts late is what the other seven wait for in every all-reduce), the actor's tiles take what is left and what the
+// critic's tiles free, with their rows in long before du.  What used to cross the kernel boundary between the two
+// launches — the critic's new packs and biases, pi, the actor's activations — lives in uncached memory and travels
+// behind flags (DdpgArgs::whole).  One launch gap (~3 us of an update) less.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr size_t kWholeDcOffset = (sizeof(DdpgArgs) + alignof(DwKArgs4) - 1) / alignof(DwKArgs4) * alignof(DwKArgs4);
 constexpr size_t kWholeDaOffset = (kWholeDcOffset + sizeof(DwKArgs4) + alignof(DwKArgs4) - 1) / alignof(DwKArgs4) * alignof(DwKArgs4);
@@ -1187,15 +1130,9 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_update(const DdpgArgs A, cons
   const int rows1 = 3 * 4 + 4 + ((tc > 8 * slices ? tc - 8 * slices : 0) + slices - 1) / slices;
   const int y = (int)blockIdx.y;
   if (y < rows1 || (A.prefetch_p1 && y == (int)gridDim.y - 1)) ddpg_phase1_body<256, true, false, P, true, true, DwKArgs4>(A, Dcp, y);
-  else {
-    // (ddpg_phase2m_body's rows are [0, 8) the critic pass | [8, 16) role U | tiles: here role U is dispatched first —
-    // measured: the critic pass first leaves role U without compute units until the critic's tiles retire, 2 us worse)
-    const int y2 = y - rows1;
-    ddpg_phase2m_body<P, true, DwKArgs4>(A, Dap, y2 < 8 ? y2 + 8 : (y2 < 16 ? y2 - 8 : y2));
-  }
+  else ddpg_phase2m_body<P, DwKArgs4>(A, Dap, y - rows1);
 }
 
-static_assert(FusedLds<256>::total >= RoleULds::total, "role U fits the phase kernels' LDS");
 static_assert(FusedLds<256>::total >= kDwLdsFloats && FusedLds<256>::total >= DwLds<16>::floats && FusedLds<256>::total >= DwX2Lds::floats, "a tile workgroup fits the phase kernels' LDS");
 bool fused_x2_tiles() { return kDwTileX2; }
 
@@ -1227,10 +1164,7 @@ hipError_t init_fused_attrs() {
                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecBF16>),
                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecX2>),
                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecX2, true>),
-                      reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecF32, true>),
-                      reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecF32, false>),
-                      reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecX2, true>),
-                      reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecX2, false>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecX2>),
                       reinterpret_cast<const void*>(&k_ddpg_update<PrecX2>)};
   for (const void* k : ks) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1282,23 +1216,12 @@ hipError_t launch_ddpg_phase1_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_
 // phase 2 with the actor's dW + Adam tiles as extra grid rows (DdpgArgs::merged bit 1; `d` = fill_dw_kargs of the
 // actor's launch with the phase-2 gate filled in)
 hipError_t launch_ddpg_phase2_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st) {
-  if (!lean_ok(a) || a.sac || a.bf16 || (a.merged & 2) == 0 || a.A > kDuLd || a.B > 256) return hipErrorInvalidValue;
+  if (!lean_ok(a) || a.sac || !a.x2 || !kDwTileX2 || (a.merged & 2) == 0 || (a.wide & 2) == 0 || a.xnc < 8 || a.A > kDuLd || a.B > 256)
+    return hipErrorInvalidValue;
   const int slices = (a.B + kR - 1) / kR;
   const int tiles = d.tile_end[kDwMaxItems - 1];
-  const bool wide = (a.wide & 2) != 0;
-  if (wide && a.xnc < 8) return hipErrorInvalidValue;
-  // (PrecX2: role U's 8 x slices workgroups take the first tiles themselves, only the rest are rows of their own)
-  const int own = (a.x2 && kDwTileX2) ? (tiles > kUMembers * slices ? tiles - kUMembers * slices : 0) : tiles;
-  const dim3 grid(slices, (wide ? 8 : 4) + kUMembers + (a.prefetch_next ? 1 : 0) + (own + slices - 1) / slices);
-  const dim3 blk(kThreads);
-  const size_t lds = fused_ddpg_lds_bytes();
-  if (a.x2) {
-    if (wide) hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecX2, true>), grid, blk, lds, st, a, d);
-    else hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecX2, false>), grid, blk, lds, st, a, d);
-  } else {
-    if (wide) hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecF32, true>), grid, blk, lds, st, a, d);
-    else hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecF32, false>), grid, blk, lds, st, a, d);
-  }
+  const dim3 grid(slices, 8 + (a.prefetch_next ? 1 : 0) + (tiles + slices - 1) / slices);
+  hipLaunchKernelGGL((k_ddpg_phase2_dw<PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
   return hipGetLastError();
 }
 
@@ -1309,9 +1232,8 @@ hipError_t launch_ddpg_update(const DdpgArgs& a, const DwKArgs4& dc, const DwKAr
     return hipErrorInvalidValue;
   const int slices = (a.B + kR - 1) / kR;
   const int tc = dc.tile_end[kDwFusedItems - 1], ta = da.tile_end[kDwFusedItems - 1];
-  const int own = ta > kUMembers * slices ? ta - kUMembers * slices : 0;
   const int ownc = tc > 8 * slices ? tc - 8 * slices : 0;
-  const dim3 grid(slices, 16 + (ownc + slices - 1) / slices + kUMembers + 8 + (own + slices - 1) / slices + (a.prefetch_p1 ? 1 : 0));
+  const dim3 grid(slices, 16 + (ownc + slices - 1) / slices + 8 + (ta + slices - 1) / slices + (a.prefetch_p1 ? 1 : 0));
   hipLaunchKernelGGL((k_ddpg_update<PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, dc, da);
   return hipGetLastError();
 }

@@ -228,21 +228,21 @@ struct DwGate {
   unsigned tag = 0; int spin = 0;
   unsigned* err = nullptr; unsigned err_code = 0;
   // GATE == 2 (the ACTOR's tiles on phase 2's launch, csrc/fused_ddpg.hip): no dY rows exist when the tiles start —
-  // the actor's backward is linear in the output seed du = dLoss/d(pre-tanh) [B x A], so its layers' dY are formed
-  // in the tile from du (granules `seed`, kDuLd per row, published by the critic pass at its very end) and from what
-  // does not depend on du:
+  // the actor's backward is linear in the output seed du = dLoss/d(pre-tanh) [B x A], and the two big layers' dY are
+  // formed in the tile from du (granules `seed`, kDuLd per row, published by the critic pass at its very end) and from
+  // what does not depend on du:
   //   kind 0  output layer:  dY = du
   //   kind 1  second hidden: dY[b, n] = (h2[b, n] > 0) * sum_j du[b, j] W3[j, n]      (h2 rows, W3 snapshot `w3`)
-  //   kind 2  first hidden:  dY[b, n] = sum_j du[b, j] U_j[b, n]                      (role U's unit backward rows)
-  // U: [16-column tile][n_act][B][16] floats, written through by role U of the same launch (flags `rows`).
+  //   kind 2  first hidden:  dY[b, n] = g1[b, n], granules [16-column tile][B][16] {tag, value} — the critic pass's
+  //           members go on, after du, with one tp4-style backward step through the second hidden layer (each member
+  //           32 columns, its W2^T shard taken in BEFORE du) and publish the result element by element
   // k_ddpg_update (the whole update as one launch): a tile raises done[tile] = {tag, *} when its stores have been
   // acknowledged (the critic's tiles: the critic pass of the same launch waits for them); null: no flag
   unsigned long long* done = nullptr;
   int kind[4] = {0, 0, 0, 0};          // per item of the launch
-  const unsigned long long* read = nullptr; int n_read = 0;   // role U has taken in what it reads of the actor's packs: only then may a tile's epilogue rewrite them
   const float* h2 = nullptr;           // [B][256] the actor's second hidden activations (written by the launch before)
   const float* w3 = nullptr;           // the output layer [A][256] (row-major) as it was BEFORE this launch
-  const float* U = nullptr;
+  const unsigned long long* g1 = nullptr;
   int n_act = 0;
 };
 constexpr int kDuLd = 8;               // du granules per minibatch row (action_dim <= 8)
@@ -327,7 +327,7 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   BatchSrc next;
   int prefetch_next;
   // ... or PHASE 1 carries that row, as the last row of its grid, into the OTHER of two staging sets (step_n with the
-  // merged phase 2, whose role U and critic pass fill the chip: DdpgArgs::merged bit 1)
+  // merged phase 2: DdpgArgs::merged bit 1)
   int prefetch_p1;
   float gamma, inv_B;
   float* cX[kMaxLayers]; int cldx0;    // critic layer inputs ([s|a], h1, h2) for dW
@@ -349,15 +349,14 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   // start while the roles run, take their Adam state in, and wait for flag granules: gate_flags[0 .. 4 slices)
   // = role B's members have written their X / dY rows through, gate_flags[64 + slice] = role A has written the
   // slice's seeds through; tagged with `epoch`
-  // bit 1: the ACTOR's dW + Adam tiles ride on phase 2's launch: the actor's backward leaves the critical chain — role U
-  // (4 workgroups per slice, beside the critic pass) runs it with unit seeds, one per action dimension, the critic
-  // pass publishes du = da (1 - pi^2) as granules and the tiles combine (DwGate, GATE == 2)
+  // bit 1 (PrecX2 learners): the ACTOR's dW + Adam tiles ride on phase 2's launch: the critic pass publishes
+  // du = da (1 - pi^2) as granules and the tiles of the two big layers form their dY from it (DwGate, GATE == 2); the
+  // first layer's come from the pass's own backward step, granules `g1_granules`
   int merged;
   unsigned long long* gate_flags;
   unsigned long long* du_granules;     // [B][kDuLd] {epoch, du}
-  unsigned long long* u_flags;         // [0, 128): role U's members have written their rows through; [128, 256): ... have read the actor's packs
-  float* U;                            // [16][A][B][16] unit-seed dz1 of the actor (role U -> first-layer tiles)
-  // k_ddpg_update: phase 1's roles, the critic's tiles, role U (+ the actor's tiles) and phase 2's critic pass in ONE
+  unsigned long long* g1_granules;     // [16 tiles][B][16] {epoch, dz1 of the actor}
+  // k_ddpg_update: phase 1's roles, the critic's tiles, phase 2's critic pass and the actor's tiles in ONE
   // launch.  What a role hands to a later one crosses no kernel boundary: it lives in uncached memory (the learner's
   // workspace and fp16 packs), is written before a flag {epoch, *} — w_flags[0, 64): role C's members, the critic's tiles
   // raise DwGate::done — and read after the flag and an L1 invalidate.

@@ -420,11 +420,10 @@ struct oprl_learner {
   int no_lean = 0;
   int no_merge = 0;            // OPRL_AMD_NO_MERGE: dW launches of their own
   int no_merge2 = 0;           // OPRL_AMD_NO_MERGE2: phase 2 runs the actor's backward itself, the actor's dW is a launch of its own
-  // merged phase 2 (DdpgArgs::merged bit 1): du granules [Bm][kDuLd], role U's flags [slices][4], its unit-seed rows
-  // [16][A][Bm][16] and the snapshot of the actor's output-layer pack (Bm = min(max_batch, 256))
+  // merged phase 2 (DdpgArgs::merged bit 1): du granules [Bm][kDuLd], the first layer's dz1 granules [16][Bm][16] and the
+  // snapshot of the actor's output layer (Bm = min(max_batch, 256))
   unsigned long long* du_granules = nullptr;
-  unsigned long long* u_flags = nullptr;
-  float* U = nullptr;
+  unsigned long long* g1_granules = nullptr;
   float* w3_snap = nullptr;
   int no_wide = 0;             // OPRL_AMD_NO_WIDE: never run role A / phase 2's critic pass on clusters of eight
   int xnc = kMaxCluster;       // members an exchange area of xbuf is laid out for
@@ -991,27 +990,16 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
     a.merged |= 1;
     if (!(a.x2 && fused_x2_tiles())) a.wide &= ~1;     // (the 84 16 x 64 tiles of a PrecX2 learner get along with role A on eight)
   }
-  // ... and the ACTOR's tiles on phase 2 (DDPG / TD3: the tanh head, action_dim <= kDuLd): the actor's backward runs
-  // beside the critic pass with unit seeds (role U), the tiles combine with du (csrc/fused_ddpg.hip)
-  // PrecX2 learners only: with the exact-fp32 tiles the merged form measured no faster than the two launches (34.9 vs
-  // 34.7 us) and its TD3 variant tripped a bounded wait under step_n — it is not offered
+  // ... and the ACTOR's tiles on phase 2 (DDPG / TD3: the tanh head, action_dim <= kDuLd): the tiles form their dY from
+  // du, the first layer's comes from one more backward step of the critic pass's members (csrc/fused_ddpg.hip).
+  // PrecX2 learners only, the pass on clusters of eight: with the exact-fp32 tiles the merged form measured no faster
+  // than the two launches (34.9 vs 34.7 us)
   if (!h->no_merge2 && a.x2 && fused_x2_tiles() && h->du_granules != nullptr && !a.sac && B <= 256 && !h->cfg.export_grads && !h->dp_inline &&
-      fused_ddpg_is_lean(a) && c.actor.theta_target != nullptr) {
-    // (role U takes eight workgroups per slice; where those, the critic pass on eight and the prefetch row do not fit the
-    // chip together — B = 256 — the critic pass stays on a cluster of four)
-    const int slices = (B + kR - 1) / kR;
-    // (step_n's prefetch row rides on phase 1 then — two staging sets — unless the second set could not be allocated)
-    const int pf_rows = h->batch_alt == nullptr ? 1 : 0;
-    int nmc = (a.wide & 2) != 0 ? 8 : 4;
-    if ((nmc + 8 + pf_rows) * slices > h->n_cus) nmc = 4;
-    if ((nmc + 8 + pf_rows) * slices <= h->n_cus) {
-      if (nmc == 4) a.wide &= ~2;
-      a.merged |= 2;
-      a.du_granules = h->du_granules;
-      a.u_flags = h->u_flags;
-      a.U = h->U;
-      a.w3_snap = h->w3_snap;
-    }
+      fused_ddpg_is_lean(a) && c.actor.theta_target != nullptr && (a.wide & 2) != 0) {
+    a.merged |= 2;
+    a.du_granules = h->du_granules;
+    a.g1_granules = h->g1_granules;
+    a.w3_snap = h->w3_snap;
   }
   // the whole update as ONE launch (k_ddpg_update): both merged forms, role A and the critic pass on eight, the 16 x 64
   // tiles, and everything the roles hand to each other in uncached memory
@@ -1134,7 +1122,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
       HIPC(hipMemsetAsync(h->y_granules, 0, ((size_t)3 * h->Bmax + 256) * sizeof(unsigned long long), st));
       if (h->du_granules != nullptr) {
         HIPC(hipMemsetAsync(h->du_granules, 0, (size_t)(h->Bmax < 256 ? h->Bmax : 256) * kDuLd * sizeof(unsigned long long), st));
-        HIPC(hipMemsetAsync(h->u_flags, 0, 256 * sizeof(unsigned long long), st));
+        HIPC(hipMemsetAsync(h->g1_granules, 0, (size_t)16 * (h->Bmax < 256 ? h->Bmax : 256) * 16 * sizeof(unsigned long long), st));
         HIPC(hipMemsetAsync(h->w_flags, 0, 256 * sizeof(unsigned long long), st));
       }
     }
@@ -1179,15 +1167,13 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
       {
         DwArgs dw = dw_build(h, false, B, true, false);
         if (fill_dw_kargs(dw, &kd, 64) < 0 || dw.n_items != 3) { set_err("whole update: bad actor dW table"); return OPRL_ERR_INVALID; }
-        kd.gate.rows = fa.u_flags; kd.gate.n_rows = 8 * slices;
-        kd.gate.read = fa.u_flags + 128; kd.gate.n_read = 8 * slices;
         kd.gate.seed = fa.du_granules; kd.gate.n_seed = B;
         kd.gate.tag = h->epoch; kd.gate.spin = h->debug_expire == 7 ? 0 : (1 << 20);
         kd.gate.err = h->err_dev; kd.gate.err_code = (2u << 8) | 7u;
         kd.gate.kind[0] = 2; kd.gate.kind[1] = 1; kd.gate.kind[2] = 0; kd.gate.kind[3] = 0;
         kd.gate.h2 = h->ws_actor.X[2];
         kd.gate.w3 = fa.w3_snap;
-        kd.gate.U = fa.U;
+        kd.gate.g1 = fa.g1_granules;
         kd.gate.n_act = h->A;
         compact(kd, &ka);
       }
@@ -1401,21 +1387,17 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     if (h->prefetch_next && !h->prefetch_p1) h->staged_ready = true;
     HIPC(chain_before(st));
     if ((fa.merged & 2) != 0 && !pf_on_dw) {
-      // phase 2 and the actor's dW + Adam tiles as ONE launch: role U's unit-seed backward beside the critic pass,
-      // the tiles wait for the du granules
+      // phase 2 and the actor's dW + Adam tiles as ONE launch: the tiles wait for the du (first layer: dz1) granules
       DwArgs dw = dw_build(h, false, B, true, false);
       DwKArgs kd;
       if (fill_dw_kargs(dw, &kd, (fa.x2 && fused_x2_tiles()) ? 64 : 32) < 0 || dw.n_items != 3) { set_err("merged phase 2: bad dW table"); return OPRL_ERR_INVALID; }
-      const int slices = (B + kR - 1) / kR;
-      kd.gate.rows = fa.u_flags; kd.gate.n_rows = 8 * slices;
-      kd.gate.read = fa.u_flags + 128; kd.gate.n_read = 8 * slices;
       kd.gate.seed = fa.du_granules; kd.gate.n_seed = B;
       kd.gate.tag = h->epoch; kd.gate.spin = h->debug_expire == 7 ? 0 : (1 << 20);
       kd.gate.err = h->err_dev; kd.gate.err_code = (2u << 8) | 7u;      // KERN_PHASE2, SITE_DW_GATE (csrc/tp3.h)
       kd.gate.kind[0] = 2; kd.gate.kind[1] = 1; kd.gate.kind[2] = 0; kd.gate.kind[3] = 0;   // items = the actor's layers 0, 1, 2
       kd.gate.h2 = h->ws_actor.X[2];
       kd.gate.w3 = fa.w3_snap;
-      kd.gate.U = fa.U;
+      kd.gate.g1 = fa.g1_granules;
       kd.gate.n_act = h->A;
       prof_begin(5, st);
       hipError_t e = launch_ddpg_phase2_dw(fa, kd, st);
@@ -1983,7 +1965,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   floats += 64 * 32 + 6 * (size_t)B + 512;      // (granule arrays: y, q1, q2; 256 gate flags)
   const int Bm = B < 256 ? B : 256;             // merged phase 2 serves one 256-row chunk
   const bool merge2_bufs = h->fused && cfg->algo != OPRL_SAC && A <= kDuLd;
-  if (merge2_bufs) floats += 2 * ((size_t)Bm * kDuLd + 64) + 2 * 256 + 128 + (size_t)16 * A * Bm * 16 + 16 * 256 + 4 * 64 + 2 * 256 + 64 + kMaxLayers * 256 + 64;
+  if (merge2_bufs) floats += 2 * ((size_t)Bm * kDuLd + 64) + 2 * 256 + 128 + 2 * (size_t)16 * Bm * 16 + 64 + 16 * 256 + 4 * 64 + 2 * 256 + 64 + kMaxLayers * 256 + 64;
   if (h->bf16 || h->x2) {
     floats += 2 * ((size_t)net_pack16_floats(cfg->actor, h->planes) + 64);
     for (int j = 0; j < nc; ++j) floats += 2 * ((size_t)net_pack16_floats(cfg->critics[j], h->planes) + 64);
@@ -2033,8 +2015,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   h->y_granules = p.take<unsigned long long>((size_t)3 * B + 256);
   if (merge2_bufs) {
     h->du_granules = p.take<unsigned long long>((size_t)Bm * kDuLd);
-    h->u_flags = p.take<unsigned long long>(256);
-    h->U = p.take<float>((size_t)16 * A * Bm * 16);
+    h->g1_granules = p.take<unsigned long long>((size_t)16 * Bm * 16);
     h->w3_snap = p.take<float>(16 * 256);
     h->w_flags = p.take<unsigned long long>(256);
     h->critic_b16 = p.take<float>(kMaxLayers * 256);
