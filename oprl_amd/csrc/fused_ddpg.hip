@@ -941,11 +941,11 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const KA* D
   float* Wl = g2 + HB;                             // two spare hidden buffers: the member's W2^T shard [2 tiles][8 steps][hi 256 | lo 256]
   float* outS = smem + LY::out;
   float* auxS = smem + LY::aux;
-  float* duS = smem + LY::aux2;                    // [kR][kDuLd] du of the slice, + 16 wave maxima
+  float* duS = smem + LY::aux2;                    // [kR] the rows' un-scaling factors of the backward step
   float* scr = smem + LY::scr;
   float* w3s = smem + LY::misc + 96;               // [kDuLd][256] the output layer's rows (the prefetch rows' ends table is not in use here)
   static_assert(2 * HB >= 2 * 8 * 512, "the shard fits the two spare hidden buffers");
-  static_assert(kMaxEnds >= kDuLd * 256 && kR * kOutLd >= kR * kDuLd + kWaves, "W3 and du fit their areas");
+  static_assert(kMaxEnds >= kDuLd * 256, "W3 fits the ends table's area");
   Tp tp{y, NMC, A.xbuf + (size_t)slice * kTpStages * A.xnc * kTpBlk, A.whole ? A.cluster_tag2 : A.cluster_tag, 0,
         A.err, KERN_PHASE2 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
   const bool lead = tp.c == 0;
@@ -1044,49 +1044,42 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const KA* D
     A.adY[2][(size_t)(row0 + rp_) * A.alddo + cp_] = du;
   }
   // ---- the backward step through the second hidden layer, this member's 32 columns of the first one's dY
-  if (tid < kR * kDuLd) {      // du of the slice [kR][kDuLd], zero beyond A and B
-    const int r = tid >> 3, j = tid & 7;
-    float v = 0.f;
-    if (j < Ad && row0 + r < B) {
-      const float pv = xa[r * kX0Ld + S + j];
-      v = auxS[r * kOutLd + j] * (1.f - pv * pv);
-    }
-    duS[tid] = v;
-  }
-  __syncthreads();
   {
-    // g2[hr][hc ..] = (h2 > 0) sum_j du[hr][j] W3[j][hc ..]  ->  h1 (the critic's buffers are free), unscaled; the
-    // tile's largest magnitude fixes the scale of the fp16 split (as tp4_backward does it)
-    const f32x4 d0 = ld4(duS + hr * kDuLd), d1 = ld4(duS + hr * kDuLd + 4);
+    // g2[hr][hc ..] = (h2 > 0) sum_j du[hr][j] W3[j][hc ..] (wave = minibatch row hr; du once more from da and pi, both
+    // in LDS since the pass: no exchange) -> h1 (the critic's buffers are free), each ROW scaled by the power of two
+    // that brings its largest magnitude to [2^10, 2^11) — the fp16 split's range, as tp4_backward scales its tiles
     f32x4 gq = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool row_in = row0 + hr < B;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) gq += ld4(w3s + j * 256 + hc) * d0[j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) gq += ld4(w3s + (4 + j) * 256 + hc) * d1[j];
+    for (int j = 0; j < kDuLd; ++j) {
+      float d = 0.f;
+      if (j < Ad && row_in) {
+        const float pv = xa[hr * kX0Ld + S + j];
+        d = auxS[hr * kOutLd + j] * (1.f - pv * pv);
+      }
+      gq += ld4(w3s + j * 256 + hc) * d;
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) gq[t] = ((mbits >> t) & 1u) != 0u ? gq[t] : 0.f;
-    *reinterpret_cast<f32x4*>(h1 + hr * kWL4 + hc) = gq;
     float m = fmaxf(fmaxf(fabsf(gq[0]), fabsf(gq[1])), fmaxf(fabsf(gq[2]), fabsf(gq[3])));
     m = wave_max(m);
-    if (lane == 0) duS[kR * kDuLd + wave] = m;
+    const float sr = P::a_scale(m);
+    *reinterpret_cast<f32x4*>(h1 + hr * kWL4 + hc) = gq * sr;
+    if (lane == 0) duS[hr] = PrecX2::kOut / sr;
   }
   __syncthreads();
   {
-    float m = duS[kR * kDuLd + (lane & 15)];
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
-    const float s1 = P::a_scale(m);
     // wave = (tile t1 of the member's two, macro step ws of eight): one split product, partial tile -> scr
     const int t1 = wave & 1, ws = wave >> 1;
     const float* hrow = h1 + i * kWL4 + 4 * kk;
     const float* bw = Wl + ((size_t)t1 * 8 + ws) * 512 + lane * 4;
     const FragX2 bf{ld4(bw), ld4(bw + 256)};
+    const f32x4 un = ld4(duS + 4 * kk);                 // the un-scaling of this lane's four rows
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    PrecX2::mma3(ld4(hrow + 32 * ws) * s1, ld4(hrow + 32 * ws + 16) * s1, bf, acc);
+    PrecX2::mma3(ld4(hrow + 32 * ws), ld4(hrow + 32 * ws + 16), bf, acc);
     float* o = scr + wave * 256;
-    const float un = PrecX2::kOut / s1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[(4 * kk + r) * 16 + i] = acc[r] * un;
+    for (int r = 0; r < 4; ++r) o[(4 * kk + r) * 16 + i] = acc[r] * un[r];
   }
   __syncthreads();
   if (tid < 512 && row0 + er < B) {
