@@ -155,6 +155,16 @@ int oprl_learner_update_phase(oprl_learner* h, int32_t phase, const float* s, co
 int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t K, int32_t B,
                         uint64_t seed, void* stream);
 
+/* The trainer loop's step (trainers/base_trainer.py:38-74: one update, then actor.explore(next_state) opens the next
+ * environment step): oprl_learner_step_n with K = 1 and, enqueued behind it in the same call, the ACTOR's forward
+ * of one observation obs_host[0 .. state_dim) with the weights that update leaves (a 1-row GEMV over the master
+ * weights, csrc/policy_act.hip).  Nothing is waited for: the raw output row of the actor's last layer (no tanh, no
+ * Gaussian head — what oprl_mlp_act returns with out_act = none) is collected with oprl_learner_act_wait, which
+ * spins on a ticket in host-mapped memory (bounded: OPRL_ERR_STATE after `timeout_us`).  One pending row per learner. */
+int oprl_learner_step_act(oprl_learner* h, oprl_replay* replay, int32_t B, uint64_t seed,
+                          const float* obs_host, void* stream);
+int oprl_learner_act_wait(oprl_learner* h, float* out_host, int32_t n_out, int64_t timeout_us);
+
 /* ---- packed learners: the reference's --seeds fan-out (runners/train.py:24-50) on ONE GPU ----------------
  * A group steps N independent fused fp32 DDPG learners of one shape (own weights, own sampler keys
  * seeds[i], one shared HBM replay) with FOUR launches per update for all of them (grid.z = learner; the

@@ -79,6 +79,8 @@ SIGNATURES = {
     "oprl_learner_apply": (C.c_int, [_P, _I32, _D, _P]),
     "oprl_learner_update_phase": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _P]),
     "oprl_learner_step_n": (C.c_int, [_P, _P, _I32, _I32, _U64, _P]),
+    "oprl_learner_step_act": (C.c_int, [_P, _P, _I32, _U64, _P, _P]),
+    "oprl_learner_act_wait": (C.c_int, [_P, _P, _I32, C.c_int64]),
     "oprl_group_create": (C.c_int, [C.POINTER(_P), _I32, C.POINTER(_P)]),
     "oprl_group_destroy": (C.c_int, [_P]),
     "oprl_group_step_n": (C.c_int, [_P, _P, _I32, _I32, C.POINTER(_U64), _P]),

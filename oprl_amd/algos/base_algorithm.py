@@ -11,6 +11,7 @@ import ctypes as C
 from abc import ABC
 from typing import Any, Sequence
 
+import numpy as np
 import torch as t
 import torch.nn as nn
 
@@ -33,19 +34,36 @@ class OffPolicyAlgorithm(ABC):
     def _log_update(self, step: int) -> None:
         """Scalar logging at the algorithm's cadence (the only host sync of an update)."""
 
-    def update_from_buffer(self, replay_buffer, batch_size: int) -> None:
+    def update_from_buffer(self, replay_buffer, batch_size: int, act_next=None) -> None:
         """``update(*replay_buffer.sample(batch_size))`` as ONE C call (oprl_learner_step_n with
         K = 1): the slice kernels gather their own rows from the HBM replay with the sampler's
         Philox draw, so the per-step host work is one ctypes call instead of a gather launch, five
         output allocations and the update's argument checks.  A buffer without a device handle
-        (or a gradient-exporting data-parallel learner) takes the two-call path."""
+        (or a gradient-exporting data-parallel learner) takes the two-call path.
+
+        ``act_next``: the observation the NEXT environment step starts from (the trainer has it before the update,
+        base_trainer.py:38-74).  The actor's forward for it rides behind the update in the same call
+        (oprl_learner_step_act) and the next ``actor.explore(act_next)`` — with this very array — only collects the
+        row: one host wait per environment step instead of update-sync, act-launch, act-sync."""
         handle = getattr(replay_buffer, "handle", None)
         if handle is None or self.learner.export_grads:
             self.update(*replay_buffer.sample(batch_size))
             return
         step = self.update_step
-        self.learner.step_n(handle, 1, int(batch_size), seed=int(getattr(replay_buffer, "seed", 0)))
+        seed = int(getattr(replay_buffer, "seed", 0))
+        mlp = self._actor_mlp() if act_next is not None else None
+        if mlp is not None:
+            self.learner.step_act(handle, int(batch_size), seed, act_next)
+            mlp.set_pending(act_next, self.learner)
+        else:
+            self.learner.step_n(handle, 1, int(batch_size), seed=seed)
         self._log_update(step)
+
+    def _actor_mlp(self):
+        """The actor's MLP when it is one the learner's policy kernel can run (the policy classes of nn_models.py)."""
+        actor = getattr(self, "actor", None)
+        mlp = getattr(actor, "mlp", None) or getattr(actor, "net", None)
+        return mlp if (mlp is not None and hasattr(mlp, "set_pending") and mlp.on_gpu()) else None
 
     def set_seed(self, seed: int, rank: int = 0) -> None:
         """Key the learner's device-side noise streams with the run seed (and data-parallel rank)."""
@@ -306,6 +324,21 @@ class HipLearner:
         with _capi.on_device(self.device):
             _capi.check(self.lib.oprl_learner_step_n(self.handle, replay_handle, K, B, seed,
                                                      _capi.current_stream()), "oprl_learner_step_n")
+
+    def step_act(self, replay_handle, B: int, seed: int, obs) -> None:
+        """One sample()+update() and, enqueued behind it, the actor's forward of ``obs`` with the updated weights
+        (oprl_learner_step_act): nothing is waited for; ``act_wait`` collects the row."""
+        self.check_bound()
+        x = np.ascontiguousarray(obs, dtype=np.float32).reshape(-1)
+        with _capi.on_device(self.device):
+            _capi.check(self.lib.oprl_learner_step_act(self.handle, replay_handle, B, seed, x.ctypes.data_as(C.c_void_p),
+                                                       _capi.current_stream()), "oprl_learner_step_act")
+
+    def act_wait(self, n_out: int, timeout_us: int = 5_000_000):
+        out = np.empty(n_out, dtype=np.float32)
+        _capi.check(self.lib.oprl_learner_act_wait(self.handle, out.ctypes.data_as(C.c_void_p), n_out, timeout_us),
+                    "oprl_learner_act_wait")
+        return out
 
     def check(self) -> None:
         """Raise if a kernel of this learner reported an expired cross-workgroup wait (include/oprl_amd.h,

@@ -225,6 +225,13 @@ class MLP(nn.Module):
         policy call without torch tensors on the way."""
         if not self._hip_ok:
             raise RuntimeError("the HIP MLP kernels implement ReLU hidden / identity output only")
+        pending, self._pending = getattr(self, "_pending", None), None
+        if pending is not None:
+            # the row for exactly this observation was requested with the last update (set_pending): collect it
+            p_obs, learner = pending
+            raw = learner.act_wait(self.dims[-1])
+            if p_obs is obs and out_act == _capi.ACT_NONE:
+                return raw
         x = np.ascontiguousarray(obs, dtype=np.float32).reshape(-1)
         n_out = self.dims[-1] // 2 if out_act == _capi.ACT_GAUSS_MEAN else self.dims[-1]
         out = np.empty(n_out, dtype=np.float32)
@@ -237,6 +244,11 @@ class MLP(nn.Module):
 
     def on_gpu(self) -> bool:
         return self._params()[0].is_cuda
+
+    def set_pending(self, obs, learner) -> None:
+        """The learner has this net's forward of ``obs`` in flight behind its last update (oprl_learner_step_act):
+        the next ``hip_act`` with the same array collects it instead of launching."""
+        self._pending = (obs, learner)
 
     def forward(self, x: t.Tensor) -> t.Tensor:
         if x.is_cuda:

@@ -16,7 +16,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "lib" / "liboprl_amd.so"
 OBJ = HERE / "lib" / "obj"
-SOURCES = ["kernels.hip", "fused_ddpg.hip", "slice_tp.hip", "layerwise.hip", "dw_wide.hip", "p2p.hip", "replay.hip", "learner.hip"]
+SOURCES = ["kernels.hip", "fused_ddpg.hip", "slice_tp.hip", "layerwise.hip", "dw_wide.hip", "p2p.hip", "replay.hip", "policy_act.hip", "learner.hip"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-ldl"]
 

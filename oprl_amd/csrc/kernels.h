@@ -384,4 +384,17 @@ constexpr int kDwThreads = 512;
 constexpr int kDwWaves = 8;
 constexpr int kTraceStamps = 24;
 
+// csrc/policy_act.hip: one observation through a net's row-major master weights; obs / out / ticket are host-mapped
+constexpr int kPolicyActMaxWidth = 512;
+struct PolicyActArgs {
+  int n_layers;
+  int dims[kMaxLayers + 1];
+  const float* w[kMaxLayers];
+  const float* b[kMaxLayers];
+  const float* obs;
+  unsigned long long* out;             // [n_out] {ticket, value}
+  unsigned ticket_value;
+};
+hipError_t launch_policy_act(const PolicyActArgs& a, hipStream_t st);
+
 }  // namespace oprl

@@ -7,6 +7,7 @@
 //   DDPG  algos/ddpg.py:61-107      TD3  algos/td3.py:71-146
 //   SAC   algos/sac.py:75-155       TQC  algos/tqc.py:116-189
 #include <algorithm>
+#include <chrono>
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -422,6 +423,11 @@ struct oprl_learner {
   int no_merge2 = 0;           // OPRL_AMD_NO_MERGE2: phase 2 runs the actor's backward itself, the actor's dW is a launch of its own
   // merged phase 2 (DdpgArgs::merged bit 1): du granules [Bm][kDuLd], the first layer's dz1 granules [16][Bm][16] and the
   // snapshot of the actor's output layer (Bm = min(max_batch, 256))
+  // oprl_learner_step_act: host-mapped pinned block [obs 512 floats | out 512 granules {ticket, value}] and the ticket of the pending row
+  float* act_pin = nullptr;
+  float* act_map = nullptr;
+  unsigned act_ticket = 0;
+  bool act_pending = false;
   unsigned long long* du_granules = nullptr;
   unsigned long long* g1_granules = nullptr;
   float* w3_snap = nullptr;
@@ -488,6 +494,35 @@ namespace {
 // learners with lazily maintained fp32 packs, by pack pointer (oprl_mlp_* know a net, not its learner)
 std::mutex g_lazy_mu;
 std::vector<oprl_learner*> g_lazy;
+
+// Uncached device memory (hipDeviceMallocUncached) is never handed back to the runtime: a block a destroyed learner
+// owned waits here for the next PrecX2 learner.  Measured (tools/sac_probe2.py, r03 log): after hipFree of such a block,
+// later ordinary allocations of the same process — another learner's workspace — lost flag granules in the fused
+// kernels (bounded waits expired) until the process ended; with the blocks kept, 0 failures in the same churn.
+struct UcBlock { void* p; size_t bytes; bool used; };
+std::mutex g_uc_mu;
+std::vector<UcBlock> g_uc;
+hipError_t uc_alloc(void** out, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_uc_mu);
+  for (UcBlock& b : g_uc)
+    if (!b.used && b.bytes >= bytes && b.bytes <= 2 * bytes + (1u << 20)) { b.used = true; *out = b.p; return hipSuccess; }
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) return e;
+  g_uc.push_back(UcBlock{p, bytes, true});
+  *out = p;
+  return hipSuccess;
+}
+void dev_free(void* p);
+bool uc_release(void* p) {       // true: the block was one of these (and is NOT freed)
+  std::lock_guard<std::mutex> lk(g_uc_mu);
+  for (UcBlock& b : g_uc)
+    if (b.p == p) { b.used = false; return true; }
+  return false;
+}
+void dev_free(void* p) {
+  if (p != nullptr && !uc_release(p)) (void)hipFree(p);
+}
 
 int fresh32_tables(oprl_learner* h, int which /* bit 0 critics, bit 1 actor */, hipStream_t st) {
   if ((which & 1) && h->stale32[0]) {
@@ -1978,7 +2013,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   static const int uc_pool_env = [] { const char* e = getenv("OPRL_AMD_UC_POOL"); return e != nullptr ? atoi(e) : 1; }();
   const int uc_pool = (h->x2 && uc_pool_env) ? 1 : 0;
   h->uc_pool = uc_pool != 0;
-  if ((uc_pool ? hipExtMallocWithFlags((void**)&h->pool.base, bytes, hipDeviceMallocUncached) : hipMalloc(&h->pool.base, bytes)) != hipSuccess) { set_err("hipMalloc(%zu) failed", bytes); delete h; return OPRL_ERR_NOMEM; }
+  if ((uc_pool ? uc_alloc((void**)&h->pool.base, bytes) : hipMalloc(&h->pool.base, bytes)) != hipSuccess) { set_err("hipMalloc(%zu) failed", bytes); delete h; return OPRL_ERR_NOMEM; }
   h->pool.cap = bytes;
   (void)hipMemset(h->pool.base, 0, bytes);
   {
@@ -1988,7 +2023,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
         hipHostGetDevicePointer(&ed, eh, 0) != hipSuccess) {
       set_err("hipHostMalloc(error word) failed");
       if (eh) (void)hipHostFree(eh);
-      (void)hipFree(h->pool.base); delete h; return OPRL_ERR_NOMEM;
+      dev_free(h->pool.base); delete h; return OPRL_ERR_NOMEM;
     }
     memset(eh, 0, 64);
     h->err_host = (unsigned*)eh;
@@ -2034,8 +2069,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     size_t fl = 2 * ((size_t)net_pack16_floats(cfg->actor, 2) + 64);
     for (int j = 0; j < nc; ++j) fl += 2 * ((size_t)net_pack16_floats(cfg->critics[j], 2) + 64);
     float* base = nullptr;
-    if (hipExtMallocWithFlags((void**)&base, fl * sizeof(float), uc_packs == 2 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached) != hipSuccess) {
-      set_err("hipExtMallocWithFlags(uncached packs) failed"); (void)hipFree(p.base); delete h; return OPRL_ERR_NOMEM;
+    if (uc_alloc((void**)&base, fl * sizeof(float)) != hipSuccess) {
+      set_err("hipExtMallocWithFlags(uncached packs) failed"); dev_free(p.base); delete h; return OPRL_ERR_NOMEM;
     }
     (void)hipMemset(base, 0, fl * sizeof(float));
     h->uc_base = base;
@@ -2077,7 +2112,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
       h->rp_dev[k] = p.take<RepackItem>(rp[k].size());
     }
   }
-  if (p.used > p.cap) { set_err("internal: workspace pool overflow (%zu > %zu)", p.used, p.cap); (void)hipFree(p.base); delete h; return OPRL_ERR_NOMEM; }
+  if (p.used > p.cap) { set_err("internal: workspace pool overflow (%zu > %zu)", p.used, p.cap); dev_free(p.base); delete h; return OPRL_ERR_NOMEM; }
   for (int k = 0; k < 3; ++k)
     if (!rp[k].empty()) (void)hipMemcpy(h->rp_dev[k], rp[k].data(), sizeof(RepackItem) * rp[k].size(), hipMemcpyHostToDevice);
   {
@@ -2142,7 +2177,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->xbuf_granules = (size_t)(2 + nc) * slices * fused_xbuf_granules_per_cluster(h->xnc);
     if (hipMalloc(&h->xbuf, h->xbuf_granules * sizeof(unsigned long long)) != hipSuccess) {
       set_err("hipMalloc(cluster exchange area, %zu MB) failed", (h->xbuf_granules * 8) >> 20);
-      (void)hipFree(p.base); delete h; return OPRL_ERR_NOMEM;
+      dev_free(p.base); delete h; return OPRL_ERR_NOMEM;
     }
     (void)hipMemset(h->xbuf, 0, h->xbuf_granules * sizeof(unsigned long long));
     if (h->fused) { std::lock_guard<std::mutex> lk(g_chain_mu); g_chain.live += 1; }
@@ -2155,7 +2190,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     for (int j = 0; j < nc; ++j) { p16[j] = h->pack16[1 + j]; p16t[j] = h->pack16_t[1 + j]; }
     p16[nc] = h->pack16[0]; p16t[nc] = h->pack16_t[0];
     int prc = repack_nets(nets, nc + 1, 3, nullptr, (h->bf16 || h->x2) ? p16 : nullptr, (h->bf16 || h->x2) ? p16t : nullptr, h->planes);
-    if (prc != OPRL_OK) { (void)hipFree(p.base); delete h; return prc; }
+    if (prc != OPRL_OK) { dev_free(p.base); delete h; return prc; }
   }
   if (h->x2) { std::lock_guard<std::mutex> lk(g_lazy_mu); g_lazy.push_back(h); }
   *out = h;
@@ -2200,15 +2235,16 @@ extern "C" int oprl_learner_destroy(oprl_learner* h) {
   if (h->tqc_counter) (void)hipFree(h->tqc_counter);
   if (h->lw_scratch) (void)hipFree(h->lw_scratch);
   if (h->batch_alt) (void)hipFree(h->batch_alt);
-  if (h->uc_base) (void)hipFree(h->uc_base);
+  dev_free(h->uc_base);
   if (h->err_host) (void)hipHostFree(h->err_host);
+  if (h->act_pin) (void)hipHostFree(h->act_pin);
   if (h->p2p.window) p2p_destroy(h->p2p);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   for (int j = 1; j < OPRL_MAX_CRITICS; ++j) {
     if (h->ev_join[j]) (void)hipEventDestroy(h->ev_join[j]);
     if (h->side[j]) (void)hipStreamDestroy(h->side[j]);
   }
-  (void)hipFree(h->pool.base);
+  dev_free(h->pool.base);
   delete h;
   return OPRL_OK;
 }
@@ -2382,6 +2418,61 @@ extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t
                           h->bd, h->bs2, nullptr, nullptr, stream));
     RC(oprl_learner_update(h, h->bs, h->ba, h->br, h->bd, h->bs2, B, nullptr, nullptr, stream));
   }
+  return OPRL_OK;
+}
+
+// ===================================================================== the trainer loop's step
+extern "C" int oprl_learner_step_act(oprl_learner* h, oprl_replay* replay, int32_t B, uint64_t seed,
+                                     const float* obs_host, void* stream) {
+  if (!h || !replay || !obs_host) { set_err("oprl_learner_step_act: null argument"); return OPRL_ERR_INVALID; }
+  const oprl_net& n = h->cfg.actor;
+  if (n.n_layers < 1 || n.n_layers > kMaxLayers) { set_err("oprl_learner_step_act: bad actor"); return OPRL_ERR_INVALID; }
+  for (int l = 0; l <= n.n_layers; ++l)
+    if (n.dims[l] > kPolicyActMaxWidth) { set_err("oprl_learner_step_act: layer width %d > %d", n.dims[l], kPolicyActMaxWidth); return OPRL_ERR_INVALID; }
+  if (h->act_pin == nullptr) {
+    HIPC(hipHostMalloc((void**)&h->act_pin, (3 * kPolicyActMaxWidth + 16) * sizeof(float), hipHostMallocMapped));
+    HIPC(hipHostGetDevicePointer((void**)&h->act_map, h->act_pin, 0));
+    memset(h->act_pin, 0, (3 * kPolicyActMaxWidth + 16) * sizeof(float));
+  }
+  RC(oprl_learner_step_n(h, replay, 1, B, seed, stream));
+  memcpy(h->act_pin, obs_host, sizeof(float) * n.dims[0]);
+  PolicyActArgs a;
+  memset(&a, 0, sizeof a);
+  a.n_layers = n.n_layers;
+  for (int l = 0; l <= n.n_layers; ++l) a.dims[l] = n.dims[l];
+  for (int l = 0; l < n.n_layers; ++l) { a.w[l] = n.theta + w_off(n, l); a.b[l] = n.theta + b_off(n, l); }
+  a.obs = h->act_map;
+  a.out = reinterpret_cast<unsigned long long*>(h->act_map + kPolicyActMaxWidth);
+  h->act_ticket += 1;
+  if (h->act_ticket == 0) h->act_ticket = 1;
+  a.ticket_value = h->act_ticket;
+  HIPC(launch_policy_act(a, (hipStream_t)stream));
+  h->act_pending = true;
+  return OPRL_OK;
+}
+
+extern "C" int oprl_learner_act_wait(oprl_learner* h, float* out_host, int32_t n_out, int64_t timeout_us) {
+  if (!h || !out_host) { set_err("oprl_learner_act_wait: null argument"); return OPRL_ERR_INVALID; }
+  if (!h->act_pending) { set_err("oprl_learner_act_wait: no row is pending (oprl_learner_step_act first)"); return OPRL_ERR_STATE; }
+  const oprl_net& n = h->cfg.actor;
+  if (n_out != n.dims[n.n_layers]) { set_err("oprl_learner_act_wait: n_out %d != the actor's %d outputs", n_out, n.dims[n.n_layers]); return OPRL_ERR_INVALID; }
+  const unsigned long long* g = reinterpret_cast<const unsigned long long*>(h->act_pin + kPolicyActMaxWidth);
+  const auto t0 = std::chrono::steady_clock::now();
+  long spins = 0;
+  for (int i = 0; i < n_out; ++i) {
+    unsigned long long x;
+    while ((unsigned)((x = __atomic_load_n(g + i, __ATOMIC_ACQUIRE)) >> 32) != h->act_ticket) {
+      if ((++spins & 1023) == 0 &&
+          std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_us) {
+        set_err("oprl_learner_act_wait: the policy row did not arrive within %lld us", (long long)timeout_us);
+        return OPRL_ERR_STATE;
+      }
+      __builtin_ia32_pause();
+    }
+    const unsigned bits = (unsigned)x;
+    memcpy(out_host + i, &bits, 4);
+  }
+  h->act_pending = false;
   return OPRL_OK;
 }
 

@@ -147,6 +147,29 @@ __global__ void k_replay_scatter(const float* rows, int n, int rowlen, float* st
   }
 }
 
+// The per-env-step form of the same (the trainer loop adds ONE transition between two updates): rows AND the changed
+// tail of the episode-ends table straight from the pinned staging buffers (host-mapped: a few hundred bytes over the
+// link inside the kernel) — one launch instead of two H2D copies and a scatter launch.
+__global__ void k_replay_ingest(const float* rows, int n, int rowlen, float* states, float* actions, float* rewards,
+                                float* dones, int L, int S, int A, const int* ends_src, int* ends_dst, int ends_first,
+                                int ends_n) {
+  for (int rix = blockIdx.x; rix < n; rix += gridDim.x) {
+    const float* row = rows + (size_t)rix * rowlen;
+    const long e = __float_as_int(row[0]), t = __float_as_int(row[1]);
+    for (int c = threadIdx.x; c < S + A + 2; c += blockDim.x) {
+      const float v = row[2 + c];
+      if (c < S) states[(e * (L + 1) + t) * S + c] = v;
+      else if (c < S + A) actions[(e * L + t) * A + (c - S)] = v;
+      else if (c == S + A) rewards[e * L + t] = v;
+      else dones[e * L + t] = v;
+    }
+  }
+  for (int i = ends_first + (int)(blockIdx.x * blockDim.x + threadIdx.x); i < ends_n; i += (int)(gridDim.x * blockDim.x))
+    ends_dst[i] = ends_src[i];
+}
+constexpr int kDirectRows = 16;       // staged rows / changed table entries up to which the ingest kernel reads the pinned buffers itself
+constexpr int kDirectEnds = 2048;
+
 }  // namespace
 
 struct oprl_replay {
@@ -163,6 +186,13 @@ struct oprl_replay {
   hipEvent_t stage_ev[2], ends_ev[2];
   bool stage_busy[2] = {false, false}, ends_busy[2] = {false, false};
   int cur = 0, ends_cur = 0, n_staged = 0;
+  // the device copies of the pinned buffers' addresses, and the ends-table upload oprl_replay_set_lens left for the
+  // next flush: entries [first, n) of ends_host[ends_cur] differ from what the device holds (ends_last = its mirror)
+  float* stage_map[2] = {nullptr, nullptr};
+  int* ends_map[2] = {nullptr, nullptr};
+  std::vector<int> ends_last;
+  bool ends_pending = false;
+  int ends_first = 0, ends_n = 0;
   // the stream of the caller's most recent flush / sample / block write / table upload: where a staging buffer
   // that fills up inside oprl_replay_write (which takes no stream) is flushed, so that the scatter stays ordered
   // with the caller's later gathers
@@ -187,7 +217,10 @@ extern "C" int oprl_replay_create(int32_t n_episodes, int32_t max_ep_len, int32_
     HIPC(hipHostMalloc(&h->ends_host[i], sizeof(int) * n_episodes));
     HIPC(hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ends_ev[i], hipEventDisableTiming));
+    if (hipHostGetDevicePointer((void**)&h->stage_map[i], h->stage_host[i], 0) != hipSuccess) h->stage_map[i] = nullptr;
+    if (hipHostGetDevicePointer((void**)&h->ends_map[i], h->ends_host[i], 0) != hipSuccess) h->ends_map[i] = nullptr;
   }
+  (void)hipGetLastError();
   *out = h;
   return OPRL_OK;
 }
@@ -209,22 +242,43 @@ extern "C" int oprl_replay_destroy(oprl_replay* h) {
 
 extern "C" int oprl_replay_flush(oprl_replay* h, void* stream) {
   if (!h) { set_err("null replay handle"); return OPRL_ERR_INVALID; }
-  if (h->n_staged == 0) return OPRL_OK;
+  if (h->n_staged == 0 && !h->ends_pending) return OPRL_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int c = h->cur, n = h->n_staged;
-  HIPC(hipMemcpyAsync(h->stage_dev[c], h->stage_host[c], sizeof(float) * h->rowlen * n,
-                      hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_replay_scatter, dim3(n < 1024 ? n : 1024), dim3(64), 0, st,
-                     h->stage_dev[c], n, h->rowlen, h->states, h->actions, h->rewards, h->dones,
-                     h->L, h->S, h->A);
-  HIPC(hipGetLastError());
-  HIPC(hipEventRecord(h->stage_ev[c], st));
-  h->stage_busy[c] = true;
-  h->cur ^= 1;
-  h->n_staged = 0;
-  if (h->stage_busy[h->cur]) {  // the other buffer must have drained before we refill it
-    HIPC(hipEventSynchronize(h->stage_ev[h->cur]));
-    h->stage_busy[h->cur] = false;
+  const int c = h->cur, n = h->n_staged, ec = h->ends_cur;
+  const int e_first = h->ends_pending ? h->ends_first : 0, e_n = h->ends_pending ? h->ends_n : 0;
+  const bool direct = n <= kDirectRows && e_n - e_first <= kDirectEnds && h->stage_map[c] != nullptr && h->ends_map[ec] != nullptr;
+  if (direct) {
+    const int wgs = n > 0 ? n : 1;
+    hipLaunchKernelGGL(k_replay_ingest, dim3(wgs), dim3(64), 0, st, h->stage_map[c], n, h->rowlen, h->states, h->actions,
+                       h->rewards, h->dones, h->L, h->S, h->A, h->ends_map[ec], h->ends_dev, e_first, e_n);
+    HIPC(hipGetLastError());
+  } else {
+    if (n > 0) {
+      HIPC(hipMemcpyAsync(h->stage_dev[c], h->stage_host[c], sizeof(float) * h->rowlen * n, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_replay_scatter, dim3(n < 1024 ? n : 1024), dim3(64), 0, st,
+                         h->stage_dev[c], n, h->rowlen, h->states, h->actions, h->rewards, h->dones,
+                         h->L, h->S, h->A);
+      HIPC(hipGetLastError());
+    }
+    if (e_n > e_first)
+      HIPC(hipMemcpyAsync(h->ends_dev + e_first, h->ends_host[ec] + e_first, sizeof(int) * (e_n - e_first),
+                          hipMemcpyHostToDevice, st));
+  }
+  if (n > 0) {
+    HIPC(hipEventRecord(h->stage_ev[c], st));
+    h->stage_busy[c] = true;
+    h->cur ^= 1;
+    h->n_staged = 0;
+    if (h->stage_busy[h->cur]) {  // the other buffer must have drained before we refill it
+      HIPC(hipEventSynchronize(h->stage_ev[h->cur]));
+      h->stage_busy[h->cur] = false;
+    }
+  }
+  if (h->ends_pending) {
+    HIPC(hipEventRecord(h->ends_ev[ec], st));
+    h->ends_busy[ec] = true;
+    h->ends_cur ^= 1;
+    h->ends_pending = false;
   }
   return OPRL_OK;
 }
@@ -288,21 +342,26 @@ extern "C" int oprl_replay_set_lens(oprl_replay* h, const int32_t* ep_lens_host,
     set_err("oprl_replay_set_lens: invalid argument");
     return OPRL_ERR_INVALID;
   }
-  hipStream_t st = (hipStream_t)stream;
+  (void)stream;      // (the table goes up with the next flush — every reader flushes first — on ITS stream)
   const int c = h->ends_cur;
-  if (h->ends_busy[c]) { HIPC(hipEventSynchronize(h->ends_ev[c])); h->ends_busy[c] = false; }
+  if (!h->ends_pending && h->ends_busy[c]) { HIPC(hipEventSynchronize(h->ends_ev[c])); h->ends_busy[c] = false; }
   long acc = 0;
+  int first = -1;
+  if ((int)h->ends_last.size() < episodes_counter) h->ends_last.resize(episodes_counter, -1);
   for (int i = 0; i < episodes_counter; ++i) {
     if (ep_lens_host[i] < 0 || ep_lens_host[i] > h->L) { set_err("ep_lens[%d]=%d out of range", i, ep_lens_host[i]); return OPRL_ERR_INVALID; }
     acc += ep_lens_host[i];
     h->ends_host[c][i] = (int)acc;
+    if (h->ends_last[i] != (int)acc) {
+      if (first < 0) first = i;
+      h->ends_last[i] = (int)acc;
+    }
   }
-  if (episodes_counter > 0)
-    HIPC(hipMemcpyAsync(h->ends_dev, h->ends_host[c], sizeof(int) * episodes_counter,
-                        hipMemcpyHostToDevice, st));
-  HIPC(hipEventRecord(h->ends_ev[c], st));
-  h->ends_busy[c] = true;
-  h->ends_cur ^= 1;
+  if (first >= 0) {
+    h->ends_first = h->ends_pending ? (first < h->ends_first ? first : h->ends_first) : first;
+    h->ends_n = h->ends_pending ? (episodes_counter > h->ends_n ? episodes_counter : h->ends_n) : episodes_counter;
+    h->ends_pending = true;
+  }
   h->n_eps = episodes_counter;
   h->n_transitions = acc;
   return OPRL_OK;

@@ -55,7 +55,7 @@ class BaseTrainer(TrainerProtocol):
             obs = self._collect(step, obs)
             if len(self.replay_buffer) < self.batch_size:
                 continue
-            rewards = self._learn(step)
+            rewards = self._learn(step, obs)
             self._periodic(step, rewards)
 
     def _collect(self, step: int, obs):
@@ -69,17 +69,31 @@ class BaseTrainer(TrainerProtocol):
             nxt, _ = self.env.reset()
         return nxt
 
-    def _learn(self, step: int):
+    def _learn(self, step: int, next_obs=None):
         """One update.  Fused (default): ``algo.update_from_buffer`` — the kernels gather their own rows on
         the device, one C call; a batch of rewards is sampled only when the logging below will print it.
-        Otherwise the reference's two calls, ``sample()`` then ``update(*batch)``."""
+        Otherwise the reference's two calls, ``sample()`` then ``update(*batch)``.
+        ``next_obs``: what the next step's ``actor.explore`` will be called with — its forward rides behind the update
+        (when the next step explores at all: not during the uniform warm-up, not before an evaluation / checkpoint
+        touches the actor in between)."""
         if self.fused_sample_update and hasattr(self.algo, "update_from_buffer"):
-            self.algo.update_from_buffer(self.replay_buffer, self.batch_size)
+            ride = next_obs is not None and hasattr(self.algo, "_actor_mlp") and step + 1 > self.start_steps and step + 1 <= self.num_steps and self._quiet(step)
+            if ride:
+                self.algo.update_from_buffer(self.replay_buffer, self.batch_size, act_next=next_obs)
+            else:
+                self.algo.update_from_buffer(self.replay_buffer, self.batch_size)
             wanted = step % self.eval_interval == 0 or step % self.stdout_log_every == 0
             return self.replay_buffer.sample(self.batch_size)[2] if wanted else None
         batch = self.replay_buffer.sample(self.batch_size)
         self.algo.update(*batch)
         return batch[2]
+
+    def _quiet(self, step: int) -> bool:
+        """No periodic work of this step uses the actor between the update and the next ``explore``."""
+        def due(every):
+            return every > 0 and step % every == 0
+        return not (due(self.eval_interval) or due(self.save_policy_every) or due(self.save_checkpoint_every)
+                    or due(self.estimate_q_every))
 
     def _periodic(self, step: int, rewards) -> None:
         self._log_evaluation(step, rewards)

@@ -288,6 +288,85 @@ def test_update_from_buffer_is_step_n_of_one():
         assert t.equal(getattr(a1, m)._oprl_arena, getattr(a2, m)._oprl_arena), m
 
 
+@pytest.mark.parametrize("algo_name,precision", [("ddpg", "f32"), ("ddpg", "x2"), ("sac", "f32"), ("td3", "x2")])
+def test_step_act_is_update_then_policy_call(algo_name, precision):
+    """oprl_learner_step_act (the trainer's step: one update and, behind it in the same call, the actor's forward of the
+    next observation; the row collected from host-mapped memory) against the two calls it replaces:
+    update_from_buffer, then actor.explore's oprl_mlp_act — same parameters afterwards, the same raw output row."""
+    import importlib
+    from oprl_amd.logging import NullLogger
+
+    def make():
+        t.manual_seed(0)
+        cls = getattr(importlib.import_module(f"oprl_amd.algos.{algo_name}"), algo_name.upper())
+        return cls(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=64, precision=precision).create()
+
+    a1, a2 = make(), make()
+    b1, b2 = _filled_buffer(), _filled_buffer()
+    rs = np.random.RandomState(4)
+    for k in range(5):
+        obs = rs.standard_normal(24).astype(np.float32)
+        a1.update_from_buffer(b1, 64, act_next=obs)
+        mlp1 = a1._actor_mlp()
+        got = mlp1.hip_act(obs)                       # collects the pending row
+        assert mlp1._pending is None
+        a2.update_from_buffer(b2, 64)
+        want = a2._actor_mlp().hip_act(obs)           # oprl_mlp_act: the MFMA kernels over the fp32 packs
+        assert got.shape == want.shape
+        assert sc_rel(got, want) < 2e-6, (k, sc_rel(got, want))
+    t.cuda.synchronize()
+    for m in ("actor", "critic"):
+        assert t.equal(getattr(a1, m)._oprl_arena, getattr(a2, m)._oprl_arena), m
+    # a pending row for another observation is dropped, not returned
+    obs, other = rs.standard_normal(24).astype(np.float32), rs.standard_normal(24).astype(np.float32)
+    a1.update_from_buffer(b1, 64, act_next=obs)
+    a2.update_from_buffer(b2, 64)
+    assert sc_rel(a1._actor_mlp().hip_act(other), a2._actor_mlp().hip_act(other)) < 2e-6
+
+
+def sc_rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(np.abs(b).max(), 1e-30))
+
+
+def test_trainer_with_the_policy_call_riding_on_the_update_equals_the_plain_loop():
+    """BaseTrainer: the actions taken, the transitions stored and the parameters reached are the same whether the next
+    step's explore() collects the row that rode on the update or makes its own call (exploration noise drawn from the
+    same torch generator state in both runs)."""
+    from oprl_amd.algos.ddpg import DDPG
+    from oprl_amd.buffers.episodic_buffer import EpisodicReplayBuffer
+    from oprl_amd.environment.synthetic import SyntheticEnv
+    from oprl_amd.logging import NullLogger
+    from oprl_amd.trainers.base_trainer import BaseTrainer
+
+    def run(ride):
+        t.manual_seed(0)
+        algo = DDPG(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=32).create()
+        if not ride:
+            algo._actor_mlp = lambda: None
+        buf = EpisodicReplayBuffer(buffer_size_transitions=4000, state_dim=24, action_dim=6, max_episode_lenth=40,
+                                   device="cuda", seed=1).create()
+        env = SyntheticEnv("walker-walk", seed=0, episode_length=40)
+        tr = BaseTrainer(logger=NullLogger("/tmp/oprl_amd_test"), env=env,
+                         make_env_test=lambda s: SyntheticEnv("walker-walk", seed=s, episode_length=40),
+                         replay_buffer=buf, algo=algo, num_steps=200, start_steps=60, batch_size=32,
+                         eval_interval=10 ** 9, save_policy_every=0, stdout_log_every=10 ** 9)
+        np.random.seed(0)
+        t.manual_seed(1)
+        tr.train()
+        t.cuda.synchronize()
+        return algo, buf
+
+    a1, b1 = run(True)
+    a2, b2 = run(False)
+    assert a1.update_step == a2.update_step > 100
+    for name in ("states", "actions", "rewards"):
+        x, y = b1._tensors[name], b2._tensors[name]
+        assert float((x - y).abs().max()) < 1e-5, name
+    for m in ("actor", "critic"):
+        d = float((getattr(a1, m)._oprl_arena - getattr(a2, m)._oprl_arena).abs().max())
+        assert d < 1e-4, (m, d)
+
+
 def test_distributed_learner_with_in_host_actors():
     """Two CPU actor processes feed the GPU learner through the in-host queues."""
     from oprl_amd.algos.nn_models import DeterministicPolicy
