@@ -332,6 +332,12 @@ int oprl_replay_destroy(oprl_replay* h);
  * flush/sample.  Index bookkeeping stays with the caller (it is host logic). */
 int oprl_replay_write(oprl_replay* h, int32_t ep, int32_t t, const float* state_host,
                       const float* action_host, float reward, float done);
+/* oprl_replay_write, oprl_replay_set_lens and oprl_replay_flush as one call (the per-env-step caller:
+ * trainers/base_trainer.py adds one transition between two updates; the row and the changed tail of the episode
+ * table travel in one small launch that runs while the host goes on to the update call). */
+int oprl_replay_write_flush(oprl_replay* h, int32_t ep, int32_t t, const float* state_host,
+                            const float* action_host, float reward, float done, const int32_t* ep_lens_host,
+                            int32_t episodes_counter, void* stream);
 /* The same for n consecutive steps [t0, t0+n) of one episode from host records
  * [state (S) | action (A) | reward | done | ...], row_stride floats apart: add_episode / a drained actor
  * ring segment in one call.  Staging that fills up is flushed on `stream`. */

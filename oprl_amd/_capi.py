@@ -121,6 +121,7 @@ SIGNATURES = {
     "oprl_replay_write": (C.c_int, [_P, _I32, _I32, _P, _P, _F, _F]),
     "oprl_replay_write_block": (C.c_int, [_P, _I32, _I32, _I32, _P, _I32, _P]),
     "oprl_replay_flush": (C.c_int, [_P, _P]),
+    "oprl_replay_write_flush": (C.c_int, [_P, _I32, _I32, _P, _P, _F, _F, C.POINTER(C.c_int32), _I32, _P]),
     "oprl_replay_set_lens": (C.c_int, [_P, C.POINTER(C.c_int32), _I32, _P]),
     "oprl_replay_sample": (C.c_int, [_P, _I32, _P, _U64, _U64, _P, _P, _P, _P, _P, _P, _P, _P]),
 }

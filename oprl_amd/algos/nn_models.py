@@ -225,8 +225,9 @@ class MLP(nn.Module):
         policy call without torch tensors on the way."""
         if not self._hip_ok:
             raise RuntimeError("the HIP MLP kernels implement ReLU hidden / identity output only")
-        pending, self._pending = getattr(self, "_pending", None), None
+        pending = self.__dict__.get("_pending")
         if pending is not None:
+            self.__dict__["_pending"] = None
             # the row for exactly this observation was requested with the last update (set_pending): collect it
             p_obs, learner = pending
             raw = learner.act_wait(self.dims[-1])
@@ -248,7 +249,7 @@ class MLP(nn.Module):
     def set_pending(self, obs, learner) -> None:
         """The learner has this net's forward of ``obs`` in flight behind its last update (oprl_learner_step_act):
         the next ``hip_act`` with the same array collects it instead of launching."""
-        self._pending = (obs, learner)
+        self.__dict__["_pending"] = (obs, learner)        # (not nn.Module.__setattr__: microseconds per env step)
 
     def forward(self, x: t.Tensor) -> t.Tensor:
         if x.is_cuda:

@@ -137,7 +137,10 @@ class EpisodicReplayBuffer(ReplayBufferProtocol):
             raise IndexError(f"episode slot {e} is full ({l} steps, max_episode_lenth={self.max_episode_lenth})")
         s = np.ascontiguousarray(state, dtype=np.float32).reshape(self.state_dim)
         a = np.ascontiguousarray(action, dtype=np.float32).reshape(self.action_dim)  # f64 actions are cast
-        if self._handle is not None:
+        eager = self._handle is not None and getattr(self, "eager_flush", False)
+        if eager:
+            pass        # (one library call below, once the episode table has this step in it)
+        elif self._handle is not None:
             # (staging that fills up is flushed by the library: this buffer's device must be current then)
             with _capi.on_device(self._dev):
                 _capi.check(self._lib.oprl_replay_write(
@@ -153,6 +156,18 @@ class EpisodicReplayBuffer(ReplayBufferProtocol):
         self._touch_len(e)
         if episode_done:
             self._inc_episode()
+        if eager:
+            # the per-env-step caller (trainers/base_trainer.py): the row and the episode table go to HBM NOW — one
+            # library call, one small launch that runs while the host walks on to the update call
+            if self._lens_dirty or getattr(self, "_lens_np", None) is None:
+                self._lens_np = np.asarray(self.ep_lens, dtype=np.int32).copy()
+                self._lens_dirty = False
+            with _capi.on_device(self._dev):
+                _capi.check(self._lib.oprl_replay_write_flush(
+                    self._handle, e, l, s.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), float(reward),
+                    float(done), self._lens_np.ctypes.data_as(C.POINTER(C.c_int32)), self.episodes_counter,
+                    _capi.current_stream()), "oprl_replay_write_flush")
+            self._lens_touched = False
 
     def add_transitions(self, rows: npt.NDArray, episode_done: bool = False) -> None:
         """``len(rows)`` consecutive transitions of the episode being written, as float32 records

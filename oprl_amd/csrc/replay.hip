@@ -309,6 +309,18 @@ extern "C" int oprl_replay_write(oprl_replay* h, int32_t ep, int32_t t, const fl
   return OPRL_OK;
 }
 
+// The trainer loop's add_transition as ONE call: stage the row, take the episode table, and put both on their way
+// (oprl_replay_write + oprl_replay_set_lens + oprl_replay_flush).
+extern "C" int oprl_replay_write_flush(oprl_replay* h, int32_t ep, int32_t t, const float* state_host,
+                                       const float* action_host, float reward, float done, const int32_t* ep_lens_host,
+                                       int32_t episodes_counter, void* stream) {
+  int rc = oprl_replay_write(h, ep, t, state_host, action_host, reward, done);
+  if (rc != OPRL_OK) return rc;
+  rc = oprl_replay_set_lens(h, ep_lens_host, episodes_counter, stream);
+  if (rc != OPRL_OK) return rc;
+  return oprl_replay_flush(h, stream);
+}
+
 // n consecutive steps [t0, t0 + n) of episode `ep` from host records [s (S) | a (A) | r | d | ...] that are
 // `row_stride` floats apart — a whole episode (or a drained ring segment) in ONE call instead of n
 // oprl_replay_write calls (the learner ranks of the distributed setup take in tens of thousands of

@@ -50,6 +50,8 @@ class BaseTrainer(TrainerProtocol):
     def train(self) -> None:
         self.algo.check_created()
         self.replay_buffer.check_created()
+        if self.fused_sample_update and hasattr(self.replay_buffer, "handle"):
+            self.replay_buffer.eager_flush = True        # (buffers/episodic_buffer.py::add_transition)
         obs, _ = self.env.reset()
         for step in range(self.num_steps + 1):
             obs = self._collect(step, obs)
