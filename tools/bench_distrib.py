@@ -18,6 +18,7 @@ ap.add_argument("--updates", type=int, default=20000)
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--utd", type=float, default=1.0, help="optimiser steps per transition received")
 ap.add_argument("--episode-length", type=int, default=200)
+ap.add_argument("--precision", default="x2")
 args = ap.parse_args()
 
 S, A = 24, 6
@@ -47,7 +48,8 @@ def make_policy():
 
 def make_algo(logger, **kw):
     from oprl_amd.algos.ddpg import DDPG
-    return DDPG(logger=logger, state_dim=S, action_dim=A, max_batch=args.batch, **{"device": "cuda", **kw}).create()
+    return DDPG(logger=logger, state_dim=S, action_dim=A, max_batch=args.batch, precision=args.precision,
+                **{"device": "cuda", **kw}).create()
 
 
 def make_replay_buffer(**kw):
