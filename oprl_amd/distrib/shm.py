@@ -159,8 +159,21 @@ class PolicyBoard:
 
 
 def flatten_state_dict(sd) -> np.ndarray:
+    """One flat float32 vector, state_dict order.  Device tensors are concatenated ON the device and come over in one
+    copy: a ``torch.cat`` of CPU tensors wakes torch's intra-op thread pool (one thread per host core), whose workers
+    then spin for milliseconds — beside a learner's launch loop that halved the update rate (measured 29 -> 75 us per
+    update in 500-update chunks, tools/probe_gap.py: the spinning workers exhaust the container's CPU quota)."""
     import torch as t
-    return t.cat([v.detach().reshape(-1).to(device="cpu", dtype=t.float32) for v in sd.values()]).numpy()
+    vals = [v.detach().reshape(-1).to(dtype=t.float32) for v in sd.values()]
+    if vals and all(v.is_cuda for v in vals):
+        return t.cat(vals).cpu().numpy()
+    out = np.empty(sum(v.numel() for v in vals), dtype=np.float32)
+    off = 0
+    for v in vals:
+        n = v.numel()
+        out[off:off + n] = v.cpu().numpy()
+        off += n
+    return out
 
 
 def unflatten_into(policy, flat: np.ndarray) -> None:

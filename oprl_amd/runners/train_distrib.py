@@ -76,6 +76,7 @@ def _dp_learner_main(rank: int, world: int, init_file: str, make_algo, make_repl
     from oprl_amd.distrib.dp_learner import learner_rank_loop
     from oprl_amd.distrib.shm import PolicyBoard, TransitionRing
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t.set_num_threads(1)      # a learner rank does no CPU math: no intra-op pool whose idle workers spin beside the launch loop
     device = "cpu"
     kw = {}
     if backend == "nccl":
