@@ -375,9 +375,8 @@ hipError_t launch_dw_adam(const DwArgs& a0, hipStream_t st) {
     if (!no_wide && n_wide < 10 && dw_wide_item_ok(a0.items[j], a0)) wide[n_wide++] = a0.items[j];
     else rest[n_rest++] = a0.items[j];
   }
-  // the narrow layers of the same update ride on the wide launch (OPRL_AMD_NO_DW_RIDE=1: a launch of their own)
-  static const bool no_ride = [] { const char* e = getenv("OPRL_AMD_NO_DW_RIDE"); return e != nullptr && atoi(e) != 0; }();
-  const bool ride = n_wide > 0 && n_rest > 0 && !no_ride && a0.xchg == nullptr;
+  // the narrow layers of the same update ride on the wide launch
+  const bool ride = n_wide > 0 && n_rest > 0 && a0.xchg == nullptr;
   if (n_wide > 0 && !ride) {
     hipError_t e = launch_dw_adam_wide(wide, n_wide, a0.B, a0.ad, st, nullptr, 0);
     if (e != hipSuccess) return e;

@@ -118,53 +118,9 @@ __global__ __launch_bounds__(kThreads, 8) void k_lw_in(const MlpMultiArgs M, con
   if (cg == 0 && A.Xg[0] != nullptr) store_rows(x0s, kX0Ld, A.Xg[0], A.ldx0, K0, row0, B);
 }
 
-// forward (BWD = false): Xg[l] -> Xg[l+1];  backward (BWD = true): dYg[l] -> dYg[l-1], masked by Xg[l]
-template <int WIDTH, bool BWD>
-__global__ __launch_bounds__(kThreads, 8) void k_lw_mid(const MlpMultiArgs M, int l, const LwGrid G) {
-  constexpr int WL = lds_ld(WIDTH), NTW = WIDTH / 16;
-  __shared__ __attribute__((aligned(16))) float smem[kR * WL + kWaves * kR * 16];
-  const LwWho w = lw_who(G, WIDTH / kLwCols);
-  if (!w.ok) return;
-  const MlpArgs& A = lw_args(w.net);
-  float* xs = smem;
-  float* scr = smem + kR * WL;
-  const int row0 = w.slice * kR, cg = w.cg, B = A.B;
-  int erow, ecol;
-  lw_elem(&erow, &ecol);
-  const bool eok = row0 + erow < B;
-  const size_t eoff = (size_t)(row0 + erow) * WIDTH + cg * kLwCols + ecol;
-  if constexpr (BWD) {
-    // the ReLU masks of this thread's two elements, requested before anything else
-    const float h0 = eok ? A.Xg[l][eoff] : 0.f, h1 = eok ? A.Xg[l][eoff + 64] : 0.f;
-    load_rows4(xs, WL, A.dYg[l], WIDTH, WIDTH, row0, B);
-    float* dX = A.dYg[l - 1];
-    gemm_packed(xs, WL, A.net.pb[l] + (size_t)cg * kLwTiles * NTW * 256, kLwTiles, NTW, scr, nullptr, 0,
-                [&](int, int col, float v) {
-                  const bool second = col >= 64;
-                  if (eok) dX[eoff + (second ? 64 : 0)] = (second ? h1 : h0) > 0.f ? v : 0.f;
-                });
-  } else {
-    load_rows4(xs, WL, A.Xg[l], WIDTH, WIDTH, row0, B);
-    float* Y = A.Xg[l + 1];
-    gemm_packed(xs, WL, A.net.pf[l] + (size_t)cg * kLwTiles * NTW * 256, kLwTiles, NTW, scr,
-                A.net.b[l] + cg * kLwCols, kLwCols, [&](int, int col, float v) {
-                  if (eok) Y[eoff + (col >= 64 ? 64 : 0)] = fmaxf(v, 0.f);
-                });
-  }
-}
-
-// ---- balanced hidden layers -----------------------------------------------------------------------
-// k_lw_mid above deals out equal workgroups, but TQC's 5 nets x 16 slices x 4 column groups = 320 of
-// them land on 256 CUs, a quarter of which then carry two: 6.8 us of MFMA issue where the chip-wide
-// floor is 4.3 us (15.8 us per launch).  Here the 16x16 output tiles of ONE slice across ALL nets
-// (5 x 32 = 160) are cut into G consecutive runs, G x slices = the CU count: 10 tiles per workgroup,
-// one workgroup per CU.  A run may straddle two nets (two input tiles in LDS).  Wave w contracts
-// K-eighth (w & 7) — four macro steps, the same A fragments for all its tiles — of every second tile
-// of the run (parity w >> 3): 20 B fragments per wave, all requested at entry, before the rows.  The
-// eight partial tiles of a tile meet in LDS and are summed in K order.
-constexpr int kLwMaxRun = 10;                   // tiles per workgroup
-struct LwRun { int slices, nets, G, tpg, gpx; };   // runs per slice, tiles per run, runs per XCD
-
+// ---- hidden layers ------------------------------------------------------------------------------------
+// (Two earlier cuts of this work — equal (slice, 128-column, net) workgroups, and 16-row runs of ten tiles across nets —
+// were retired in round 3: profiles/r01*, r02_experiments.txt hold their measurements.)
 // MODE 0: forward layer l, 1: backward through layer l, 2: forward layer 1 with the FIRST layer fused in —
 // for a narrow net input (<= 32 columns: two macro steps) every workgroup recomputes the slice's
 // h1 = relu(W0 [x0 | x1] + b0) tile(s) in LDS instead of reading them (8 MFMAs per wave; the run
@@ -172,194 +128,6 @@ struct LwRun { int slices, nets, G, tpg, gpx; };   // runs per slice, tiles per 
 // P (engine.h): the precision of the hidden-layer GEMM — PrecBF16 reads layer l's pack as bf16 fragments
 // (the launch's nets carry bf16 pointers for their hidden layers then; the folded first layer, the heads
 // and k_lw_dact stay fp32: together 3 % of a TQC critic's FLOPs).
-template <int MODE, class P = PrecF32>
-__global__ __launch_bounds__(kThreads) void k_lw_mid_run(const MlpMultiArgs M, int l, const LwRun R) {
-  constexpr bool BWD = MODE == 1, FIN = MODE == 2;
-  constexpr int NSE = 64 / P::KS;               // macro steps of a K-eighth (64 columns): 4 / 2
-  constexpr int NSW = 512 / P::KS;              // of the whole contraction: 32 / 16
-  constexpr int WIDTH = 512, WL = lds_ld(WIDTH), NTW = WIDTH / 16;
-  extern __shared__ __attribute__((aligned(16))) float dsm[];
-  float* xs0 = dsm;
-  float* xs1 = dsm + kR * WL;
-  float* scr = dsm + 2 * kR * WL;               // [run tile][K-eighth][64 lanes][4]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i = lane & 15, kk = lane >> 4;
-  // XCD x owns the runs [x * gpx, (x + 1) * gpx) of every slice: a run's weights cross the fabric once
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int gl = j / R.slices, g = xcd * R.gpx + gl, slice = j - gl * R.slices;
-  const int total = R.nets * NTW;
-  const int t0 = g * R.tpg, t1 = min(t0 + R.tpg, total);
-  if (gl >= R.gpx || g >= R.G || t0 >= total) return;
-  const int nt = t1 - t0, n0 = t0 / NTW, n1 = (t1 - 1) / NTW;
-  const int row0 = slice * kR;
-  const int B = lw_args(n0).B;
-  const int ke = wave & 7, par = wave >> 3;
-
-  // ---- requests: the input rows first (every wave waits for them at the barrier; behind 320 KB of
-  // weight fragments per CU they arrived last and the MFMAs started only when everything was in),
-  // then this wave's B fragments, which stream in while the first tiles are contracted
-  const MlpArgs& A0 = lw_args(n0);
-  const MlpArgs& A1 = lw_args(n1);
-  const float* src0 = BWD ? A0.dYg[l] : A0.Xg[l];
-  const float* src1 = BWD ? A1.dYg[l] : A1.Xg[l];
-  f32x4 v[2][2];
-  float* xin0 = scr;                          // FIN: the nets' input rows [kR][kX0Ld], in the partial-tile area
-  float* xin1 = scr + kR * kX0Ld;
-  f32x4 w0f[2][2];                            // FIN: [tile wave / wave + 16][macro step] first-layer fragments
-  float b0f[2];
-  const int NS0 = FIN ? cdiv(A0.net.dims[0], 16) : 0;   // <= 2 (host-checked)
-  auto request_l0 = [&](const MlpArgs& An) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int tile = wave + 16 * q;
-      b0f[q] = An.net.b[0][16 * tile + i];
-#pragma unroll
-      for (int st = 0; st < 2; ++st)
-        w0f[q][st] = st < NS0 ? ld4(An.net.pf[0] + (((size_t)tile * NS0 + st) * 64 + lane) * 4)
-                              : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  };
-  if constexpr (FIN) {
-    lds_zero(xin0, 2 * kR * kX0Ld);
-    request_l0(A0);
-    __syncthreads();
-    load_rows(xin0, kX0Ld, 0, A0.x0, A0.k0, A0.k0, row0, B);
-    if (A0.x1 != nullptr) load_rows(xin0, kX0Ld, A0.k0, A0.x1, A0.k1, A0.k1, row0, B);
-    if (n1 != n0) {
-      load_rows(xin1, kX0Ld, 0, A1.x0, A1.k0, A1.k0, row0, B);
-      if (A1.x1 != nullptr) load_rows(xin1, kX0Ld, A1.k0, A1.x1, A1.k1, A1.k1, row0, B);
-    }
-  } else {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int idx = tid + h * kThreads;                 // 16 rows x 128 float4
-      const int row = idx >> 7, col = (idx & 127) * 4, gr = row0 + row;
-      v[0][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-      v[1][h] = v[0][h];
-      if (gr < B) {
-        v[0][h] = ld4(src0 + (size_t)gr * WIDTH + col);
-        if (n1 != n0) v[1][h] = ld4(src1 + (size_t)gr * WIDTH + col);
-      }
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  f32x4 b[5][NSE];
-#pragma unroll
-  for (int q = 0; q < 5; ++q) {
-    const int tl = par + 2 * q;
-#pragma unroll
-    for (int s = 0; s < NSE; ++s) b[q][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tl < nt) {
-      const int t = t0 + tl, net = t / NTW, ntile = t - net * NTW;
-      const MlpArgs& A = lw_args(net);
-      const float* pk = (BWD ? A.net.pb[l] : A.net.pf[l]) + (((size_t)ntile * NSW + NSE * ke) * 64 + lane) * 4;
-#pragma unroll
-      for (int s = 0; s < NSE; ++s) b[q][s] = ld4(pk + s * 256);
-    }
-  }
-  // ... and this thread's (up to three) output elements: where they go, their bias (forward) or
-  // ReLU mask (backward) — requested now, a dependent round trip per element if left to the end
-  size_t e_off[3];
-  float* e_dst[3];
-  float e_x[3];
-  auto request_out = [&]() {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int e = tid + k * kThreads;
-      const int tl = e >> 8, r = e & 255, row = r >> 4, col = r & 15, gr = row0 + row;
-      e_dst[k] = nullptr;
-      e_off[k] = 0;
-      e_x[k] = 0.f;
-      if (tl < nt && gr < B) {
-        const int t = t0 + tl, net = t / NTW, ntile = t - net * NTW;
-        const MlpArgs& A = lw_args(net);
-        e_off[k] = (size_t)gr * WIDTH + ntile * 16 + col;
-        e_dst[k] = BWD ? A.dYg[l - 1] : A.Xg[l + 1];
-        e_x[k] = BWD ? A.Xg[l][e_off[k]] : A.net.b[l][ntile * 16 + col];
-      }
-    }
-  };
-  if constexpr (!FIN) request_out();          // (FIN: after the first layer, when its fragments' registers are free)
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (FIN) {
-    __syncthreads();                          // input rows visible
-    // the run that starts a net keeps that net's dW inputs: the input rows now, h1 below
-    const bool keep0 = t0 - n0 * NTW == 0, keep1 = n1 != n0;
-    if (keep0 && A0.Xg[0] != nullptr) store_rows(xin0, kX0Ld, A0.Xg[0], A0.ldx0, A0.net.dims[0], row0, B);
-    if (keep1 && A1.Xg[0] != nullptr) store_rows(xin1, kX0Ld, A1.Xg[0], A1.ldx0, A1.net.dims[0], row0, B);
-    for (int nn = 0; nn < (n1 != n0 ? 2 : 1); ++nn) {
-      if (nn == 1) request_l0(A1);            // a straddling run (3 of 16): the second net's fragments, exposed
-      const float* xr = (nn == 0 ? xin0 : xin1) + i * kX0Ld + 4 * kk;
-      float* hs = nn == 0 ? xs0 : xs1;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        mac4(ld4(xr), w0f[q][0], acc);
-        mac4(ld4(xr + 16), w0f[q][1], acc);
-        float* o = hs + (kk * 4) * WL + 16 * (wave + 16 * q) + i;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r * WL] = fmaxf(acc[r] + b0f[q], 0.f);
-      }
-    }
-    request_out();
-    __syncthreads();                          // h1 tiles complete; the input rows are no longer needed
-    if (keep0) store_rows4(xs0, WL, A0.Xg[1], WIDTH, WIDTH, row0, B);
-    if (keep1) store_rows4(xs1, WL, A1.Xg[1], WIDTH, WIDTH, row0, B);
-  } else {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int idx = tid + h * kThreads;
-      const int row = idx >> 7, col = (idx & 127) * 4;
-      *reinterpret_cast<f32x4*>(xs0 + row * WL + col) = v[0][h];
-      if (n1 != n0) *reinterpret_cast<f32x4*>(xs1 + row * WL + col) = v[1][h];
-    }
-    __syncthreads();
-  }
-
-  // ---- partial tiles
-#pragma unroll
-  for (int q = 0; q < 5; ++q) {
-    const int tl = par + 2 * q;
-    if (tl < nt) {
-      const int net = (t0 + tl) / NTW;
-      const float* xr = (net == n0 ? xs0 : xs1) + i * WL + 64 * ke + 4 * kk;
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < NSE; ++s) P::mac(xr, s, b[q][s], acc);
-      *reinterpret_cast<f32x4*>(scr + ((size_t)(tl * 8 + ke) * 64 + lane) * 4) = acc;
-    }
-  }
-  __syncthreads();
-
-  // ---- K-ordered sum, bias + ReLU (forward) or ReLU mask (backward), rows out
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    if (e_dst[k] == nullptr) continue;
-    const int e = tid + k * kThreads;
-    const int tl = e >> 8, r = e & 255, row = r >> 4, col = r & 15;
-    const float* sp = scr + ((size_t)(tl * 8) * 64 + (row >> 2) * 16 + col) * 4 + (row & 3);
-    float v = 0.f;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) v += sp[p * 256];
-    if constexpr (BWD) e_dst[k][e_off[k]] = e_x[k] > 0.f ? v : 0.f;
-    else e_dst[k][e_off[k]] = fmaxf(v + e_x[k], 0.f);
-  }
-}
-
-inline LwRun lw_run(int slices, int nets, int n_cus) {
-  LwRun r;
-  r.slices = slices; r.nets = nets;
-  const int total = nets * 32;
-  int G = n_cus / slices;
-  if (G < 1) G = 1;
-  if (G > total) G = total;
-  r.tpg = (total + G - 1) / G;
-  if (r.tpg > kLwMaxRun) r.tpg = kLwMaxRun;
-  r.G = (total + r.tpg - 1) / r.tpg;
-  r.gpx = (r.G + 7) / 8;
-  return r;
-}
-constexpr size_t kLwRunLds = sizeof(float) * (2 * kR * lds_ld(512) + kLwMaxRun * 8 * 256);
 
 // ---- 32-row runs -------------------------------------------------------------------------------------
 // A CU takes data in at ≈45 KB/us whatever the request order, and k_lw_mid_run's 16 rows x 10
@@ -751,15 +519,6 @@ bool mlp_layerwise_ok(const MlpArgs* a, int n, int width) {
 }
 
 hipError_t init_layerwise_attrs() {
-  const void* ks[6] = {reinterpret_cast<const void*>(&k_lw_mid_run<0>), reinterpret_cast<const void*>(&k_lw_mid_run<1>),
-                       reinterpret_cast<const void*>(&k_lw_mid_run<2>),
-                       reinterpret_cast<const void*>(&k_lw_mid_run<0, PrecBF16>),
-                       reinterpret_cast<const void*>(&k_lw_mid_run<1, PrecBF16>),
-                       reinterpret_cast<const void*>(&k_lw_mid_run<2, PrecBF16>)};
-  for (const void* k : ks) {
-    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLwRunLds);
-    if (e != hipSuccess) return e;
-  }
   {
     constexpr size_t head_f = LwLds<512>::total, ride_f = SliceLds<256>::total(2);
     size_t lds = sizeof(float) * (ride_f > head_f ? ride_f : head_f);
@@ -799,12 +558,10 @@ bool mlp_layerwise_rider_ok(const MlpArgs* a, int n, const MlpArgs& rider, int n
 
 // job: a TD-target job for the heads of a forward-only launch of all its nets (TqcJob, kernels.h), or null
 // rider: see k_lw_head; or null
-static bool lw_env(const char* name) { const char* e = getenv(name); return e != nullptr && atoi(e) != 0; }
 
 // Can the first hidden launch (first layer folded in) of these nets ride on another launch (k_slice_tp_fin)?
 bool mlp_layerwise_fin_ok(const MlpArgs* a, int n, int width) {
   if (!mlp_layerwise_ok(a, n, width) || !a[0].do_fwd || a[0].net.n_layers < 3) return false;
-  if (lw_env("OPRL_AMD_LW_RUN16") || lw_env("OPRL_AMD_LW_EQUAL")) return false;
   for (int j = 0; j < n; ++j)
     if (a[j].net.dims[0] > 32) return false;
   return true;
@@ -878,36 +635,22 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
   const int slices = (a[0].B + kR - 1) / kR, L = a[0].net.n_layers;
   const LwGrid g = lw_grid(slices, width / kLwCols, n);
   const dim3 wide(lw_blocks(g)), narrow(slices, 1, n), blk(kThreads);
-  // hidden layers: runs of tiles balanced over the CUs (k_lw_mid_run), or — OPRL_AMD_LW_EQUAL=1, A/B
-  // and tests — the equal (slice, 128 columns, net) workgroups of k_lw_mid
-  static const bool equal_env = [] { const char* e = getenv("OPRL_AMD_LW_EQUAL"); return e != nullptr && atoi(e) != 0; }();
-  const bool equal_wgs = equal_env && !bf16;
-  const LwRun r = lw_run(slices, n, n_cus > 0 ? n_cus : 256);
-  const dim3 runs(8 * r.gpx * slices);
-  // 32-row runs (k_lw_mid_run2) unless OPRL_AMD_LW_RUN16=1 (A/B and tests: the 16-row runs of k_lw_mid_run)
-  static const bool run16_env = [] { const char* e = getenv("OPRL_AMD_LW_RUN16"); return e != nullptr && atoi(e) != 0; }();
+  // hidden layers: 32-row runs of column tiles balanced over the CUs (k_lw_mid_run2)
   const LwRun2 r2 = lw_run2(a[0].B, n, n_cus > 0 ? n_cus : 256);
   const dim3 runs2(8 * r2.ppx * r2.slices);
   auto mid = [&](int mode, int l) {
-    if (run16_env) {
-      if (mode == 0) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run<0, PrecBF16>), runs, blk, kLwRunLds, st, m, l, r); else hipLaunchKernelGGL((k_lw_mid_run<0>), runs, blk, kLwRunLds, st, m, l, r); }
-      if (mode == 1) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run<1, PrecBF16>), runs, blk, kLwRunLds, st, m, l, r); else hipLaunchKernelGGL((k_lw_mid_run<1>), runs, blk, kLwRunLds, st, m, l, r); }
-      if (mode == 2) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run<2, PrecBF16>), runs, blk, kLwRunLds, st, m, l, r); else hipLaunchKernelGGL((k_lw_mid_run<2>), runs, blk, kLwRunLds, st, m, l, r); }
-    } else {
-      if (mode == 0) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<0, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); else hipLaunchKernelGGL((k_lw_mid_run2<0>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); }
-      if (mode == 1) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<1, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); else hipLaunchKernelGGL((k_lw_mid_run2<1>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); }
-      if (mode == 2) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<2, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); else hipLaunchKernelGGL((k_lw_mid_run2<2>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); }
-    }
+    if (mode == 0) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<0, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); else hipLaunchKernelGGL((k_lw_mid_run2<0>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); }
+    if (mode == 1) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<1, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); else hipLaunchKernelGGL((k_lw_mid_run2<1>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); }
+    if (mode == 2) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<2, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); else hipLaunchKernelGGL((k_lw_mid_run2<2>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); }
   };
   if (a[0].do_fwd) {
     // a narrow net input (two macro steps) is folded into the first hidden layer's launch
-    bool fuse_in = !equal_wgs && L >= 3;
+    bool fuse_in = L >= 3;
     for (int j = 0; j < n; ++j) fuse_in = fuse_in && a[j].net.dims[0] <= 32;
     if (!fuse_in) hipLaunchKernelGGL(k_lw_in<512>, wide, blk, 0, st, m, g);
     for (int l = 1; l + 1 < L; ++l) {
       if (l == 1 && first_done) continue;
-      if (equal_wgs) hipLaunchKernelGGL((k_lw_mid<512, false>), wide, blk, 0, st, m, l, g);
-      else mid(l == 1 && fuse_in ? 2 : 0, l);
+      mid(l == 1 && fuse_in ? 2 : 0, l);
     }
   }
   {
@@ -932,8 +675,7 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
   }
   if (a[0].do_bwd) {
     for (int l = L - 2; l >= 1; --l) {
-      if (equal_wgs) hipLaunchKernelGGL((k_lw_mid<512, true>), wide, blk, 0, st, m, l, g);
-      else mid(1, l);
+      mid(1, l);
     }
     if (a[0].dact_cols > 0) {
       static const PrefetchJob no_job = [] { PrefetchJob j; memset((void*)&j, 0, sizeof j); j.z0 = -1; return j; }();

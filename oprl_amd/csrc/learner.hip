@@ -79,54 +79,10 @@ void prof_end(hipStream_t st) {
   (void)hipEventRecord(g_prof.ev.back(), st);
 }
 
-// ---- cross-learner ordering of the fused phase kernels --------------------------------
-// k_ddpg_phase1/2 contain bounded cross-workgroup waits (cluster all-reduce, TD-target hand-off)
-// that rely on a launch's workgroups becoming resident together.  One launch has the GPU to
-// itself; two learners launching such kernels from different streams could each get only part
-// of their grid resident and wait on each other until the spin bound poisons the results with
-// NaN.  OPRL_AMD_SERIALIZE_FUSED=1 makes every phase launch wait for the previous phase launch
-// of ANY learner of the process (event chain; dW / small kernels still overlap).  It is OFF by
-// default: measured on MI355X the chain costs more than it protects (8 packed learners 45k ->
-// 17.7k steps/s aggregate), and in practice the dispatcher places a launch's workgroups in
-// order, clusters first — bench.py's multi_learner run checks every packed learner's
-// parameters for NaN and learner 0 against a solo run, bit for bit.
-struct FusedChain {
-  int live = 0;                  // fused learners alive in this process
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  int cur = 0;
-  bool have = false;
-  hipStream_t last_stream = nullptr;
-};
-static FusedChain g_chain;
-static std::mutex g_chain_mu;   // learners may be driven from different host threads
-
-static bool chain_on() {
-  static const bool on = [] { const char* e = getenv("OPRL_AMD_SERIALIZE_FUSED"); return e != nullptr && e[0] == '1'; }();
-  return on;
-}
-static hipError_t chain_before(hipStream_t st) {
-  if (!chain_on()) return hipSuccess;
-  std::lock_guard<std::mutex> lk(g_chain_mu);
-  if (g_chain.live < 2 || !g_chain.have || g_chain.last_stream == st) return hipSuccess;
-  return hipStreamWaitEvent(st, g_chain.ev[g_chain.cur], 0);
-}
-static hipError_t chain_after(hipStream_t st) {
-  if (!chain_on()) return hipSuccess;
-  std::lock_guard<std::mutex> lk(g_chain_mu);
-  if (g_chain.live < 2) return hipSuccess;
-  const int nxt = g_chain.cur ^ 1;
-  if (g_chain.ev[nxt] == nullptr) {
-    hipError_t e = hipEventCreateWithFlags(&g_chain.ev[nxt], hipEventDisableTiming);
-    if (e != hipSuccess) return e;
-  }
-  hipError_t e = hipEventRecord(g_chain.ev[nxt], st);
-  if (e != hipSuccess) return e;
-  g_chain.cur = nxt;
-  g_chain.have = true;
-  g_chain.last_stream = st;
-  return hipSuccess;
-}
-
+// (Learners that share a GPU: the fused phase kernels contain bounded cross-workgroup waits that rely on a launch's
+// workgroups becoming resident together.  An event chain that serialised the phase launches of all learners of a process
+// was measured in round 1 — 8 packed learners 45k -> 17.7k steps/s — and removed in round 3; what protects such runs is
+// the clusters-of-four setting (oprl_learner_set_cluster, runners/train.py) and bench.py's verified multi_learner run.)
 size_t mlp_slice_lds_bytes(int width, int n_layers);
 hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
 hipError_t launch_mlp_slice_multi(const MlpArgs* a, int n, int width, hipStream_t st);
@@ -1170,7 +1126,6 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     }
     RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &fa.cluster_tag));
     if (h->trace != nullptr) fa.trace = h->trace;   // roles use slots 0 .. 1 + n_critics
-    HIPC(chain_before(st));
     h->whole_done = false;
     if (fa.whole && B <= 256) {
       // the whole update as ONE launch (k_ddpg_update): phase 1's roles, the critic's tiles, role U + the actor's
@@ -1216,7 +1171,6 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
       hipError_t e = launch_ddpg_update(fa, kc, ka, st);
       prof_end(st);
       HIPC(e);
-      HIPC(chain_after(st));
       h->whole_done = true;
       return OPRL_OK;
     }
@@ -1235,14 +1189,12 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
       hipError_t e = launch_ddpg_phase1_dw(fa, kd, st);
       prof_end(st);
       HIPC(e);
-      HIPC(chain_after(st));
       return OPRL_OK;
     }
     prof_begin(4, st);
     hipError_t e = launch_ddpg_phase1(fa, st);
     prof_end(st);
     HIPC(e);
-    HIPC(chain_after(st));
     // TD3 moves its targets only on actor steps (td3.py:135-146)
     return dw_step(h, true, B, c.algo == OPRL_TD3 ? actor_due(h) : true, st);
   }
@@ -1405,14 +1357,13 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     fa.prefetch_next = h->prefetch_p1 ? 0 : h->prefetch_next;
     // Where phase 2's own workgroups already fill the chip (SAC at B = 1024: 4 x 64), its prefetch row is a round of
     // its own; the actor's dW launch, which follows and leaves 40 % of the chip idle, carries the row instead
-    // (prefetch_rows_direct, the same rows).  OPRL_AMD_PREFETCH_P2=1: always phase 2.
+    // (prefetch_rows_direct, the same rows).
     bool pf_on_dw = false;
     PrefetchJob pj;
     {
       const int slices = (B + kR - 1) / kR;
       const int rows = (fa.wide & 2) != 0 ? 8 : fa.nc * ((fa.sac && fa.p2_pair) ? 2 : 1);
-      static const bool p2_only = [] { const char* e = getenv("OPRL_AMD_PREFETCH_P2"); return e != nullptr && atoi(e) != 0; }();
-      if (fa.prefetch_next && (rows + 1) * slices > h->n_cus && !h->dp_inline && !p2_only) {
+      if (fa.prefetch_next && (rows + 1) * slices > h->n_cus && !h->dp_inline) {
         pf_on_dw = true;
         fa.prefetch_next = 0;
         memset((void*)&pj, 0, sizeof pj);
@@ -1420,7 +1371,6 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
       }
     }
     if (h->prefetch_next && !h->prefetch_p1) h->staged_ready = true;
-    HIPC(chain_before(st));
     if ((fa.merged & 2) != 0 && !pf_on_dw) {
       // phase 2 and the actor's dW + Adam tiles as ONE launch: the tiles wait for the du (first layer: dz1) granules
       DwArgs dw = dw_build(h, false, B, true, false);
@@ -1438,14 +1388,12 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
       hipError_t e = launch_ddpg_phase2_dw(fa, kd, st);
       prof_end(st);
       HIPC(e);
-      HIPC(chain_after(st));
       return OPRL_OK;
     }
     prof_begin(5, st);
     hipError_t e = launch_ddpg_phase2(fa, st);
     prof_end(st);
     HIPC(e);
-    HIPC(chain_after(st));
     const bool rides = alpha_rides(h);      // SAC temperature (sac.py:129-141), from role C's log pi
     RC(dw_step(h, false, B, c.actor.theta_target != nullptr, st, rides, pf_on_dw ? &pj : nullptr));
     if (alpha_ptr(h) != nullptr && !rides) {
@@ -2180,7 +2128,6 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
       dev_free(p.base); delete h; return OPRL_ERR_NOMEM;
     }
     (void)hipMemset(h->xbuf, 0, h->xbuf_granules * sizeof(unsigned long long));
-    if (h->fused) { std::lock_guard<std::mutex> lk(g_chain_mu); g_chain.live += 1; }
   }
   {
     const oprl_net* nets[OPRL_MAX_CRITICS + 1];
@@ -2230,7 +2177,6 @@ extern "C" int oprl_learner_destroy(oprl_learner* h) {
   }
   (void)hipDeviceSynchronize();
   if (h->rccl.comm && h->rccl.comm_destroy) (void)h->rccl.comm_destroy(h->rccl.comm);
-  if (h->fused) { std::lock_guard<std::mutex> lk(g_chain_mu); if (g_chain.live > 0) g_chain.live -= 1; }
   if (h->xbuf) (void)hipFree(h->xbuf);
   if (h->tqc_counter) (void)hipFree(h->tqc_counter);
   if (h->lw_scratch) (void)hipFree(h->lw_scratch);

@@ -101,3 +101,38 @@ def test_x2_holds_its_accuracy_over_input_magnitudes(scale):
     dev = (qa - qb).abs().max().item() / qb.abs().max().item()
     print(f"scale {scale}: x2 vs f32 Q deviation {dev:.2e}")
     assert np.isfinite(dev) and dev < 2e-5, dev
+
+
+@pytest.mark.parametrize("algo_name", ["ddpg", "td3"])
+def test_x2_launch_forms_agree(algo_name, monkeypatch):
+    """The three launch structures of a PrecX2 learner — the whole update as ONE launch (k_ddpg_update; DDPG), the two
+    merged launches (phase 1 + the critic's tiles | phase 2 + the actor's tiles), and the plain sequence with dW launches
+    of their own — are the same arithmetic cut differently (the merged forms' 16 x 64 split-product tiles against the
+    16 x 32 tiles' sums: last-bits differences): parameters after 20 step_n updates within 2e-6 of each other."""
+    import importlib
+    from oprl_amd.logging import NullLogger
+    from tests.test_gpu_callers import _filled_buffer
+
+    def run(env):
+        for k in ("OPRL_AMD_NO_WHOLE", "OPRL_AMD_NO_MERGE2", "OPRL_AMD_NO_MERGE"):
+            monkeypatch.delenv(k, raising=False)
+        for k in env:
+            monkeypatch.setenv(k, "1")
+        t.manual_seed(0)
+        cls = getattr(importlib.import_module(f"oprl_amd.algos.{algo_name}"), algo_name.upper())
+        a = cls(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=256, precision="x2").create()
+        buf = _filled_buffer(n_eps=8, L=120)
+        a.learner.step_n(buf.handle, 20, 256, seed=3)
+        t.cuda.synchronize()
+        a.learner.check()
+        return {m: getattr(a, m)._oprl_arena.clone() for m in ("actor", "critic", "actor_target", "critic_target")}
+
+    whole = run(())
+    two = run(("OPRL_AMD_NO_WHOLE",))
+    plain = run(("OPRL_AMD_NO_WHOLE", "OPRL_AMD_NO_MERGE2", "OPRL_AMD_NO_MERGE"))
+    for m in whole:
+        scale = float(plain[m].abs().max())
+        d1 = float((whole[m] - two[m]).abs().max()) / scale
+        d2 = float((two[m] - plain[m]).abs().max()) / scale
+        print(f"{algo_name} {m}: whole vs two launches {d1:.2e}, two launches vs plain {d2:.2e}")
+        assert d1 < 2e-6 and d2 < 2e-6, (m, d1, d2)
