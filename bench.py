@@ -180,10 +180,6 @@ def config_table(dev, replays, n_steps=2000):
         replay = replays(S_, A_)
         for prec in ("x2", "f32", "bf16"):
             peak = PEAK_OF[prec]
-            if prec == "x2" and cls_name == "TQC":
-                rows.append(dict(name=name, dtype=prec, steps_per_s=None,
-                                 unsupported="no split-fp16 kernels for the TQC path yet: its parity mode is f32"))
-                continue
             try:
                 algo = _make_algo(cls_name, S_, A_, B_, extras, dev, prec)
             except Exception as exc:  # noqa: BLE001  (a mode an algorithm does not have: said, not hidden)

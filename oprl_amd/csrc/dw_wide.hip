@@ -236,8 +236,38 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, 
   }
   DWW_STAMP(4);
   if (I.pf16 == nullptr) return;
-  // ---- bf16 packs (PrecBF16, engine.h): 8 blocks of 16 x 32 per pack, a block = fp32 blocks 2b, 2b + 1 side by side
   const int NSk2 = I.K >> 5, NSn2 = I.N >> 5;
+  if (I.x2) {
+    // ---- split-fp16 packs (PrecX2, engine.h): the bf16 packs' blocks and element order, every block two planes of
+    // 64 lanes x 8 fp16 — hi = fp16(2^8 w), lo = fp16(2^8 w - hi), the lo plane 256 floats behind the hi plane
+    for (int job = tid >> 6; job < 24; job += kWThreads / 64) {
+      const int which = job >> 3, blk = job & 7, b16 = blk >> 1, b32 = blk & 1;   // (16-row block, 32-column step)
+      f32x4 lo4, hi4;
+      float* d;
+      if (which == 1) {            // W^T: rows = k (16-row tile b16), steps = n (32 wide, b32)
+        if (I.pb16 == nullptr) continue;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          lo4[t] = stA[b32 * 32 + 4 * lk + t][b16 * 16 + li];
+          hi4[t] = stA[b32 * 32 + 16 + 4 * lk + t][b16 * 16 + li];
+        }
+        d = I.pb16 + ((size_t)((k_base >> 4) + b16) * NSn2 + (n_base >> 5) + b32) * 512 + (size_t)l * 4;
+      } else {
+        float* dst = which == 0 ? I.pf16 : (polyak ? I.tpf16 : nullptr);
+        if (dst == nullptr) continue;
+        float (*src)[kWLd] = which == 0 ? stA : stX;
+        lo4 = *reinterpret_cast<const f32x4*>(&src[b16 * 16 + li][b32 * 32 + 4 * lk]);
+        hi4 = *reinterpret_cast<const f32x4*>(&src[b16 * 16 + li][b32 * 32 + 16 + 4 * lk]);
+        d = dst + ((size_t)((n_base >> 4) + b16) * NSk2 + (k_base >> 5) + b32) * 512 + (size_t)l * 4;
+      }
+      f16x8 ph, pl;
+      x2_split8(lo4 * PrecX2::kWScale, hi4 * PrecX2::kWScale, ph, pl);
+      *reinterpret_cast<f16x8*>(d) = ph;
+      *reinterpret_cast<f16x8*>(d + 256) = pl;
+    }
+    return;
+  }
+  // ---- bf16 packs (PrecBF16, engine.h): 8 blocks of 16 x 32 per pack, a block = fp32 blocks 2b, 2b + 1 side by side
   for (int job = tid >> 6; job < 24; job += kWThreads / 64) {
     const int which = job >> 3, blk = job & 7, b16 = blk >> 1, b32 = blk & 1;   // (16-row block, 32-column step)
     if (which == 1) {            // W^T: rows = k (16-row tile b16), steps = n (32 wide, b32)

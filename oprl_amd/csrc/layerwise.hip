@@ -196,18 +196,18 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
     }
   }
   __builtin_amdgcn_sched_barrier(0);
-  f32x4 b[3][NSE];
+  typename P::Frag b[3][NSE];
   {
-    const float* pk0 = (BWD ? A.net.pb[l] : A.net.pf[l]) + ((size_t)NSE * ke * 64 + lane) * 4;
+    const float* pk0 = (BWD ? A.net.pb[l] : A.net.pf[l]) + (size_t)NSE * ke * P::kBlk + lane * 4;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const int tl = par + 2 * q;
 #pragma unroll
-      for (int s = 0; s < NSE; ++s) b[q][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < NSE; ++s) b[q][s] = P::zf();
       if (tl < nt) {
-        const float* pk = pk0 + (size_t)(t0 + tl) * NSW * 256;
+        const float* pk = pk0 + (size_t)(t0 + tl) * NSW * P::kBlk;
 #pragma unroll
-        for (int s = 0; s < NSE; ++s) b[q][s] = ld4(pk + s * 256);
+        for (int s = 0; s < NSE; ++s) b[q][s] = P::ldf(pk + s * P::kBlk);
       }
     }
   }
@@ -267,17 +267,52 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
 
   // ---- partial tiles: the wave's K-eighth of its tiles, both row tiles against the same B fragments
   f32x4 acc[3][2];
-#pragma unroll
-  for (int q = 0; q < 3; ++q)
+  if constexpr (P::kX2) {
+    // PrecX2: the A operand goes through fp16 (hi + lo).  The wave's [32 rows x 64 columns] block of the input is
+    // scaled by the power of two that brings ITS largest magnitude to [2^10, 2^11) — no exchange between waves: a
+    // partial tile is un-scaled before it meets the others in LDS (forward activations and backward gradients alike)
+    f32x4 xa[2][NSE][2];
+    float m = 0.f;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-      acc[q][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (par + 2 * q < nt) {
-        const float* xr = xs + (rt * 16 + i) * WL + 64 * ke + 4 * kk;
+      const float* xr = xs + (rt * 16 + i) * WL + 64 * ke + 4 * kk;
 #pragma unroll
-        for (int s = 0; s < NSE; ++s) P::mac(xr, s, b[q][s], acc[q][rt]);
+      for (int s = 0; s < NSE; ++s) {
+        xa[rt][s][0] = ld4(xr + 32 * s);
+        xa[rt][s][1] = ld4(xr + 32 * s + 16);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) m = fmaxf(m, fabsf(xa[rt][s][h][t]));
       }
     }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float s1 = P::a_scale(m), un = P::kOut / s1;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        acc[q][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (par + 2 * q < nt) {
+#pragma unroll
+          for (int s = 0; s < NSE; ++s) P::mma3(xa[rt][s][0] * s1, xa[rt][s][1] * s1, b[q][s], acc[q][rt]);
+          acc[q][rt] *= un;
+        }
+      }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        acc[q][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (par + 2 * q < nt) {
+          const float* xr = xs + (rt * 16 + i) * WL + 64 * ke + 4 * kk;
+#pragma unroll
+          for (int s = 0; s < NSE; ++s) P::mac(xr, s, b[q][s], acc[q][rt]);
+        }
+      }
+  }
   __syncthreads();                            // every wave is done with the rows: the partial tiles go over them
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
@@ -331,7 +366,7 @@ __global__ __launch_bounds__(kThreads) void k_slice_tp_fin(const MlpMultiArgs M,
 struct LwFinTail {
   MlpMultiArgs M;
   LwRun2 R;
-  int net0, z0, bf16;     // z0 < 0: nothing rides
+  int net0, z0, prec;     // z0 < 0: nothing rides; prec: 0 fp32, 1 bf16, 2 split fp16 (the hidden layer's packs)
 };
 
 inline LwRun2 lw_run2(int B, int nets, int n_cus) {
@@ -425,7 +460,8 @@ __global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M, cons
   if (F.z0 >= 0 && (int)blockIdx.z >= F.z0) {
     const LwFinTail* KF = (const LwFinTail*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kLwHeadTailOffset);
     const int bx = ((int)blockIdx.z - F.z0) * (int)gridDim.x + (int)blockIdx.x;
-    if (F.bf16) lw_mid_run2_body<2, PrecBF16>(&KF->M, 1, KF->R, bx, F.net0);
+    if (F.prec == 2) lw_mid_run2_body<2, PrecX2>(&KF->M, 1, KF->R, bx, F.net0);
+    else if (F.prec == 1) lw_mid_run2_body<2, PrecBF16>(&KF->M, 1, KF->R, bx, F.net0);
     else lw_mid_run2_body<2, PrecF32>(&KF->M, 1, KF->R, bx, F.net0);
     return;
   }
@@ -527,17 +563,21 @@ hipError_t init_layerwise_attrs() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  for (const void* k : {reinterpret_cast<const void*>(&k_slice_tp_fin<PrecF32>), reinterpret_cast<const void*>(&k_slice_tp_fin<PrecBF16>)}) {
+  for (const void* k : {reinterpret_cast<const void*>(&k_slice_tp_fin<PrecF32>), reinterpret_cast<const void*>(&k_slice_tp_fin<PrecBF16>),
+                        reinterpret_cast<const void*>(&k_slice_tp_fin<PrecX2>)}) {
     constexpr size_t ride_f = SliceLds<256>::total(2);
     const size_t lds = sizeof(float) * ride_f > kLwRun2Lds ? sizeof(float) * ride_f : kLwRun2Lds;
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  const void* k2[6] = {reinterpret_cast<const void*>(&k_lw_mid_run2<0>), reinterpret_cast<const void*>(&k_lw_mid_run2<1>),
+  const void* k2[9] = {reinterpret_cast<const void*>(&k_lw_mid_run2<0>), reinterpret_cast<const void*>(&k_lw_mid_run2<1>),
                        reinterpret_cast<const void*>(&k_lw_mid_run2<2>),
                        reinterpret_cast<const void*>(&k_lw_mid_run2<0, PrecBF16>),
                        reinterpret_cast<const void*>(&k_lw_mid_run2<1, PrecBF16>),
-                       reinterpret_cast<const void*>(&k_lw_mid_run2<2, PrecBF16>)};
+                       reinterpret_cast<const void*>(&k_lw_mid_run2<2, PrecBF16>),
+                       reinterpret_cast<const void*>(&k_lw_mid_run2<0, PrecX2>),
+                       reinterpret_cast<const void*>(&k_lw_mid_run2<1, PrecX2>),
+                       reinterpret_cast<const void*>(&k_lw_mid_run2<2, PrecX2>)};
   for (const void* k : k2) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLwRun2Lds);
     if (e != hipSuccess) return e;
@@ -545,7 +585,7 @@ hipError_t init_layerwise_attrs() {
   return hipSuccess;
 }
 
-// bf16: the nets' pf / pb of the HIDDEN layers (1 .. L-2) point at bf16 packs (MlpArgs::pf16 / pb16 moved in
+// prec 1 / 2: the nets' pf / pb of the HIDDEN layers (1 .. L-2) point at bf16 / split-fp16 packs (MlpArgs::pf16 / pb16 moved in
 // by the caller) and the hidden-layer launches run PrecBF16; needs the balanced-run kernels.
 bool mlp_slice_tp_shape_ok(const MlpArgs& a, int width);
 
@@ -586,7 +626,7 @@ static LwRun2 lw_run2_subset(int B, int n_all, int n_sub, int n_cus) {
 
 // `host`: a prepared k_mlp_slice_tp launch (tag drawn); the first hidden launch of nets a[0 .. n_ride) of the n rides behind it
 hipError_t launch_slice_tp_with_fin(const MlpArgs& host, const MlpArgs* a, int n, int n_ride, int width, int n_cus, hipStream_t st,
-                                    bool bf16) {
+                                    int prec) {
   if (!mlp_layerwise_fin_ok(a, n, width) || host.tp_xbuf == nullptr || !mlp_slice_tp_shape_ok(host, 256) || n_ride < 1 || n_ride > n)
     return hipErrorInvalidValue;
   MlpMultiArgs m;
@@ -597,20 +637,22 @@ hipError_t launch_slice_tp_with_fin(const MlpArgs& host, const MlpArgs* a, int n
   constexpr size_t ride_f = SliceLds<256>::total(2);
   const size_t lds = sizeof(float) * ride_f > kLwRun2Lds ? sizeof(float) * ride_f : kLwRun2Lds;
   const dim3 grid(hostb + 8 * r2.ppx * r2.slices), blk(kThreads);
-  if (bf16) hipLaunchKernelGGL((k_slice_tp_fin<PrecBF16>), grid, blk, lds, st, m, host, r2, hostb, slices);
+  if (prec == 2) hipLaunchKernelGGL((k_slice_tp_fin<PrecX2>), grid, blk, lds, st, m, host, r2, hostb, slices);
+  else if (prec == 1) hipLaunchKernelGGL((k_slice_tp_fin<PrecBF16>), grid, blk, lds, st, m, host, r2, hostb, slices);
   else hipLaunchKernelGGL((k_slice_tp_fin<PrecF32>), grid, blk, lds, st, m, host, r2, hostb, slices);
   return hipGetLastError();
 }
 
 // The first hidden launch of nets t[t0 .. t_n) (of t_n nets that pass mlp_layerwise_fin_ok) as a launch of its own
-hipError_t launch_mlp_layerwise_first(const MlpArgs* t, int t_n, int t0, int width, int n_cus, hipStream_t st, bool bf16) {
+hipError_t launch_mlp_layerwise_first(const MlpArgs* t, int t_n, int t0, int width, int n_cus, hipStream_t st, int prec) {
   if (!mlp_layerwise_fin_ok(t, t_n, width) || t0 < 0 || t0 >= t_n) return hipErrorInvalidValue;
   MlpMultiArgs m;
   for (int j = 0; j < t_n; ++j) m.a[j] = t[j];
   for (int j = t_n; j < kMaxMulti; ++j) m.a[j] = t[0];
   const LwRun2 r = lw_run2_subset(t[0].B, t_n, t_n - t0, n_cus > 0 ? n_cus : 256);
   const dim3 grid(8 * r.ppx * r.slices), blk(kThreads);
-  if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<2, PrecBF16>), grid, blk, kLwRun2Lds, st, m, 1, r, t0);
+  if (prec == 2) hipLaunchKernelGGL((k_lw_mid_run2<2, PrecX2>), grid, blk, kLwRun2Lds, st, m, 1, r, t0);
+  else if (prec == 1) hipLaunchKernelGGL((k_lw_mid_run2<2, PrecBF16>), grid, blk, kLwRun2Lds, st, m, 1, r, t0);
   else hipLaunchKernelGGL((k_lw_mid_run2<2>), grid, blk, kLwRun2Lds, st, m, 1, r, t0);
   return hipGetLastError();
 }
@@ -619,8 +661,8 @@ hipError_t launch_mlp_layerwise_first(const MlpArgs* t, int t_n, int t0, int wid
 // first_done: the first hidden launch of this forward already ran (launch_slice_tp_with_fin [+ a tail])
 // tail / tail_n / tail0 / tail16: ANOTHER forward's nets tail[0 .. tail_n), of which the first hidden launch of
 //   tail[tail0 ..] rides on this launch's heads (LwFinTail); null: nothing
-hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, bool bf16, const TqcJob* job,
-                                const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, bool tail16,
+hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, int prec, const TqcJob* job,
+                                const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, int tail_prec,
                                 const PrefetchJob* prefetch) {
   if (!mlp_layerwise_ok(a, n, width)) return hipErrorInvalidValue;
   if (first_done && !mlp_layerwise_fin_ok(a, n, width)) return hipErrorInvalidValue;
@@ -639,9 +681,21 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
   const LwRun2 r2 = lw_run2(a[0].B, n, n_cus > 0 ? n_cus : 256);
   const dim3 runs2(8 * r2.ppx * r2.slices);
   auto mid = [&](int mode, int l) {
-    if (mode == 0) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<0, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); else hipLaunchKernelGGL((k_lw_mid_run2<0>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); }
-    if (mode == 1) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<1, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); else hipLaunchKernelGGL((k_lw_mid_run2<1>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); }
-    if (mode == 2) { if (bf16) hipLaunchKernelGGL((k_lw_mid_run2<2, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); else hipLaunchKernelGGL((k_lw_mid_run2<2>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0); }
+    if (mode == 0) {
+      if (prec == 2) hipLaunchKernelGGL((k_lw_mid_run2<0, PrecX2>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0);
+      else if (prec == 1) hipLaunchKernelGGL((k_lw_mid_run2<0, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0);
+      else hipLaunchKernelGGL((k_lw_mid_run2<0>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0);
+    }
+    if (mode == 1) {
+      if (prec == 2) hipLaunchKernelGGL((k_lw_mid_run2<1, PrecX2>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0);
+      else if (prec == 1) hipLaunchKernelGGL((k_lw_mid_run2<1, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0);
+      else hipLaunchKernelGGL((k_lw_mid_run2<1>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0);
+    }
+    if (mode == 2) {
+      if (prec == 2) hipLaunchKernelGGL((k_lw_mid_run2<2, PrecX2>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0);
+      else if (prec == 1) hipLaunchKernelGGL((k_lw_mid_run2<2, PrecBF16>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0);
+      else hipLaunchKernelGGL((k_lw_mid_run2<2>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0);
+    }
   };
   if (a[0].do_fwd) {
     // a narrow net input (two macro steps) is folded into the first hidden layer's launch
@@ -664,7 +718,7 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
       for (int j = 0; j < tail_n; ++j) ft_local.M.a[j] = tail[j];
       for (int j = tail_n; j < kMaxMulti; ++j) ft_local.M.a[j] = tail[0];
       ft_local.R = lw_run2_subset(tail[0].B, tail_n, tail_n - tail0, n_cus > 0 ? n_cus : 256);
-      ft_local.net0 = tail0; ft_local.z0 = z; ft_local.bf16 = tail16 ? 1 : 0;
+      ft_local.net0 = tail0; ft_local.z0 = z; ft_local.prec = tail_prec;
       z += (8 * ft_local.R.ppx * ft_local.R.slices + slices - 1) / slices;
       if (kLwRun2Lds > lds) lds = kLwRun2Lds;
       ft = &ft_local;

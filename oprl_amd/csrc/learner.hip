@@ -87,14 +87,14 @@ size_t mlp_slice_lds_bytes(int width, int n_layers);
 hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
 hipError_t launch_mlp_slice_multi(const MlpArgs* a, int n, int width, hipStream_t st);
 bool mlp_layerwise_ok(const MlpArgs* a, int n, int width);
-hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, bool bf16, const TqcJob* job,
-                                const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, bool tail16,
+hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, int prec, const TqcJob* job,
+                                const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, int tail_prec,
                                 const PrefetchJob* prefetch);
 bool mlp_layerwise_fin_ok(const MlpArgs* a, int n, int width);
 int mlp_layerwise_fin_fit(const MlpArgs* a, int n, int host_wgs, int n_cus);
 hipError_t launch_slice_tp_with_fin(const MlpArgs& host, const MlpArgs* a, int n, int n_ride, int width, int n_cus, hipStream_t st,
-                                    bool bf16);
-hipError_t launch_mlp_layerwise_first(const MlpArgs* t, int t_n, int t0, int width, int n_cus, hipStream_t st, bool bf16);
+                                    int prec);
+hipError_t launch_mlp_layerwise_first(const MlpArgs* t, int t_n, int t0, int width, int n_cus, hipStream_t st, int prec);
 bool mlp_layerwise_rider_ok(const MlpArgs* a, int n, const MlpArgs& rider, int n_cus);
 hipError_t init_layerwise_attrs();
 hipError_t launch_mlp_slice_tp(const MlpArgs& a, hipStream_t st);
@@ -622,14 +622,14 @@ MlpArgs base_args(oprl_learner* h, const oprl_net& n, bool target, int B) {
     a.trace = h->trace + (size_t)(h->trace_slot++) * 64 * kTraceStamps * 2;
   a.net = net_view(n, target);
   a.err = h->err_dev;
-  if (h->bf16) {
+  if (h->bf16 || h->x2) {     // (the 16-bit packs of the net's layers: bf16, or two fp16 planes per block)
     int idx = -1;                                      // 0 = actor, 1 + j = critic j
     if (&n == &h->cfg.actor) idx = 0;
     for (int j = 0; j < h->nc; ++j) if (&n == &h->cfg.critics[j]) idx = 1 + j;
     const float* pk16 = idx < 0 ? nullptr : (target ? h->pack16_t[idx] : h->pack16[idx]);
     for (int l = 0; pk16 != nullptr && l < n.n_layers; ++l) {
-      a.pf16[l] = pk16 + pack16_off_fwd(n, l);
-      a.pb16[l] = target ? nullptr : pk16 + pack16_off_bwd(n, l);
+      a.pf16[l] = pk16 + pack16_off_fwd(n, l, h->planes);
+      a.pb16[l] = target ? nullptr : pk16 + pack16_off_bwd(n, l, h->planes);
     }
   }
   a.B = B;
@@ -761,7 +761,7 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
     }
     if (same && !h->no_layerwise && mlp_layerwise_ok(h->multi_args, h->multi_n, h->multi_width)) {
       // bf16 learners: the hidden layers (all but the first and the last) through their bf16 packs
-      bool lw16 = h->bf16;
+      bool lw16 = h->bf16 || h->x2;
       for (int k = 0; k < h->multi_n; ++k) {
         const MlpArgs& a = h->multi_args[k];
         for (int l = 1; l + 1 < a.net.n_layers; ++l)
@@ -809,8 +809,8 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
         h->prefetch_pending = false;
         h->prefetch_done = true;
       }
-      hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, h->n_cus, st, lw16, job, rider, first_done,
-                                          tail, h->nc, tail0, h->fin16, pf);
+      hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, h->n_cus, st, lw16 ? (h->x2 ? 2 : 1) : 0, job, rider, first_done,
+                                          tail, h->nc, tail0, h->fin16 ? (h->x2 ? 2 : 1) : 0, pf);
       prof_end(st);
       HIPC(e);
     } else if (same) {
@@ -1220,7 +1220,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     h->fin_tail0 = -1;
     if (algo == OPRL_TQC && !h->no_fin_ride && !h->no_layerwise && !h->no_multi && nc > 2 && nc <= kMaxMulti &&
         h->lw_scratch != nullptr && h->w_critic == 512 && f.tp_xbuf != nullptr) {
-      fin16 = h->bf16;
+      fin16 = h->bf16 || h->x2;
       for (int j = 0; j < nc; ++j) {
         MlpArgs g = base_args(h, c.critics[j], false, B);
         g.do_fwd = 1; g.do_bwd = 1;
@@ -1240,7 +1240,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
       MlpArgs ff = f;
       RC(next_tp_tag(ff.tp_tag_counter, ff.tp_xbuf, ff.tp_xbuf_bytes, st, &ff.tp_tag));
       prof_begin(0, st);
-      hipError_t e = launch_slice_tp_with_fin(ff, fin_args, nc, n_ride, h->w_critic, h->n_cus, st, fin16);
+      hipError_t e = launch_slice_tp_with_fin(ff, fin_args, nc, n_ride, h->w_critic, h->n_cus, st, fin16 ? (h->x2 ? 2 : 1) : 0);
       prof_end(st);
       HIPC(e);
       h->fin_done = true;
@@ -1269,7 +1269,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
   }));
   if (h->fin_tail0 >= 0) {                           // (the rest of the early first launch found no head launch to ride on)
     prof_begin(0, st);
-    hipError_t e = launch_mlp_layerwise_first(h->fin_args, nc, h->fin_tail0, h->w_critic, h->n_cus, st, h->fin16);
+    hipError_t e = launch_mlp_layerwise_first(h->fin_args, nc, h->fin_tail0, h->w_critic, h->n_cus, st, h->fin16 ? (h->x2 ? 2 : 1) : 0);
     prof_end(st);
     HIPC(e);
     h->fin_tail0 = -1;

@@ -489,7 +489,7 @@ def test_native_dp_single_rank_equals_export_split():
 
 @pytest.mark.parametrize("algo,precision", [("ddpg", "f32"), ("td3", "f32"), ("sac", "f32"), ("tqc", "f32"),
                                             ("ddpg", "bf16"), ("tqc", "bf16"), ("sac", "bf16"),
-                                            ("ddpg", "x2"), ("td3", "x2"), ("sac", "x2")])
+                                            ("ddpg", "x2"), ("td3", "x2"), ("sac", "x2"), ("tqc", "x2")])
 def test_checkpoint_resume_is_bit_exact(algo, precision, tmp_path):
     """learner state (theta, targets, Adam moments, temperature, counters) + replay
     (storage, write position, sample counter) saved mid-run; a fresh process-like restore must

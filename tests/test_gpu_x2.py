@@ -69,14 +69,24 @@ def test_x2_sac_walker_tuned_alpha():
     _both(got, "sac_walker_tune_b256", sc.sac_scenario(sc.OracleSAC, "walker", 256, 350, True, 3))
 
 
+def test_x2_tqc_walker_b256():
+    """TQC: the 512-wide critics' hidden layers — 97 % of a critic's FLOPs — through the split-fp16 packs
+    (k_lw_mid_run2<*, PrecX2>, the A operand scaled per wave); the folded first layer, the heads and the 256-wide actor
+    stay exact fp32.  Same golden vectors, same gates as the exact-fp32 learner (tests/test_gpu_algos.py)."""
+    got = sc.tqc_scenario(_x2(ha.HipTQC))
+    _both(got, "tqc_walker_b256", sc.tqc_scenario(sc.OracleTQC), skip=("qh.",))
+
+
 @pytest.mark.parametrize("B", [100, 8, 1])
 def test_x2_ragged_batches_against_the_oracle(B):
     cases = [("ddpg", sc.ddpg_scenario(_x2(ha.HipDDPG), B=B), sc.ddpg_scenario(sc.OracleDDPG, B=B)),
              ("td3", sc.td3_scenario(_x2(ha.HipTD3), B=B), sc.td3_scenario(sc.OracleTD3, B=B)),
              ("sac", sc.sac_scenario(_x2(ha.HipSAC), "walker", B, 350, True, 3),
-              sc.sac_scenario(sc.OracleSAC, "walker", B, 350, True, 3))]
+              sc.sac_scenario(sc.OracleSAC, "walker", B, 350, True, 3)),
+             ("tqc", sc.tqc_scenario(_x2(ha.HipTQC), B=B), sc.tqc_scenario(sc.OracleTQC, B=B))]
     for name, got, want in cases:
-        worst = sc.compare(got, {k: v for k, v in want.items()}, TOL, param_tol=sc.PARAM_TOL, moment_tol=MOMENT_TOL)
+        worst = sc.compare(got, {k: v for k, v in want.items()}, TOL, skip=("qh.",) if name == "tqc" else (),
+                           param_tol=sc.PARAM_TOL, moment_tol=MOMENT_TOL)
         print(f"{name} B={B} [x2]: worst vs oracle {worst}")
 
 

@@ -12,8 +12,6 @@ for name, (cls_name, S_, A_, B_, extras, gflop, mbytes) in bench.BASELINE_CONFIG
         continue
     replay = bench.make_replay(dev, seed=0, S=S_, A=A_)
     for prec in ("x2", "f32", "bf16"):
-        if prec == "x2" and cls_name == "TQC":
-            continue
         try:
             algo = bench._make_algo(cls_name, S_, A_, B_, extras, dev, prec)
             for n in (50, 200, 2000 if cls_name != "TQC" else 300):
