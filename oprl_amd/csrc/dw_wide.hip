@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, 
                            I.b_t ? I.b_t + n : nullptr, I.b_g ? I.b_g + n : nullptr, A.ad, step_size, bc2_sqrt,
                            &t0, &t1);
   }
-  if (!(A.ad.do_adam && I.pf != nullptr)) return;
+  if (!(A.ad.do_adam && (I.pf != nullptr || I.pf16 != nullptr))) return;
   // ---- packs: the new tile(s) staged as [n][k], then 16 blocks of 16x16 per pack in pack order
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, 
   }
   __syncthreads();
   const int l = tid & 63, li = l & 15, lk = l >> 4;
-  for (int job = tid >> 6; job < 48; job += kWThreads / 64) {
+  for (int job = tid >> 6; I.pf != nullptr && job < 48; job += kWThreads / 64) {      // (pf null: the fp32 packs are not kept current)
     const int which = job >> 4, blk = job & 15, bn = blk >> 2, bk = blk & 3;   // block (n block, k block)
     if (which == 1) {            // W^T pack: tiles over k, steps over n
       if (I.pb == nullptr) continue;

@@ -206,6 +206,7 @@ struct DwArgs {                         // host-side description of one k_dw_ada
   long long* trace;                    // debug stamps (tools/trace_slice.py) or null
   int use_row_scale;                   // 1: the slice kernels left unit-seed dz rows (lean fused path)
   int skip32 = 0;                      // 1: do not write the fp32 packs (pf / pb / tpf): a PrecX2 learner's fused update, whose kernels read the fp16 packs only
+  int skip32_wide = 0;                 // 1: ... of the WIDE layers only (TQC's 512 x 512 layers in a 16-bit mode: the hidden-layer launches read the 16-bit packs)
   int apply_only;                      // 1: no GEMM — the gradient is read from w_g / b_g (data-parallel apply after the all-reduce)
   const DwXchg* xchg = nullptr;       // data-parallel: all-reduce every gradient tile over the peer windows inside this launch
   AlphaJob alpha;                      // optional: the temperature step rides on this launch (one more workgroup)

@@ -372,8 +372,15 @@ hipError_t launch_dw_adam(const DwArgs& a0, hipStream_t st) {
   DwItem rest[kDwMaxItems], wide[kDwMaxItems];
   int n_rest = 0, n_wide = 0;
   for (int j = 0; j < a0.n_items; ++j) {
-    if (!no_wide && n_wide < 10 && dw_wide_item_ok(a0.items[j], a0)) wide[n_wide++] = a0.items[j];
-    else rest[n_rest++] = a0.items[j];
+    if (!no_wide && n_wide < 10 && dw_wide_item_ok(a0.items[j], a0)) {
+      wide[n_wide] = a0.items[j];
+      // (16-bit learners: nothing of the update reads these layers' fp32 packs — a third of the launch's stores;
+      // whoever does read them later rebuilds them first: fresh32, learner.hip)
+      if (a0.skip32_wide && wide[n_wide].pf16 != nullptr) { wide[n_wide].pf = nullptr; wide[n_wide].pb = nullptr; wide[n_wide].tpf = nullptr; }
+      ++n_wide;
+    } else {
+      rest[n_rest++] = a0.items[j];
+    }
   }
   // the narrow layers of the same update ride on the wide launch
   const bool ride = n_wide > 0 && n_rest > 0 && a0.xchg == nullptr;

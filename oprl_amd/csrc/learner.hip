@@ -431,6 +431,8 @@ struct oprl_learner {
   // the nets' own forward (oprl_mlp_forward / act / backward), a generic launch sequence — gets them rebuilt from the
   // master first (fresh32): [0] the critics' (online + target), [1] the actor's
   bool stale32[2] = {false, false};
+  bool lazy_wide = false;      // this learner is in g_lazy and its wide layers' fp32 packs may be left stale (16-bit TQC)
+  bool stale_wide = false;     // ... and are: only the critics' 512 x 512 layers' fp32 packs (the narrow layers' are current)
   float* uc_base = nullptr;    // the fp16 packs' uncached allocation (PrecX2 learners)
   bool uc_pool = false;        // the workspace pool is uncached memory as well
   // k_ddpg_update (the whole update as one launch): role C's / the critic tiles' flags, the critic's uncached bias copies
@@ -480,10 +482,12 @@ void dev_free(void* p) {
   if (p != nullptr && !uc_release(p)) (void)hipFree(p);
 }
 
-int fresh32_tables(oprl_learner* h, int which /* bit 0 critics, bit 1 actor */, hipStream_t st) {
-  if ((which & 1) && h->stale32[0]) {
+// (wide_too: also when only the wide layers' packs are stale — the launch about to run reads THOSE)
+int fresh32_tables(oprl_learner* h, int which /* bit 0 critics, bit 1 actor */, hipStream_t st, bool wide_too = false) {
+  if ((which & 1) && (h->stale32[0] || (wide_too && h->stale_wide))) {
     HIPC(launch_repack(h->rp_dev[1], h->rp_n[1], h->rp_blocks[1], st));
     h->stale32[0] = false;
+    h->stale_wide = false;
   }
   if ((which & 2) && h->stale32[1]) {
     HIPC(launch_repack(h->rp_dev[2], h->rp_n[2], h->rp_blocks[2], st));
@@ -496,14 +500,14 @@ int fresh32_tables(oprl_learner* h, int which /* bit 0 critics, bit 1 actor */, 
 int fresh32(const oprl_net* net, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_lazy_mu);
   for (oprl_learner* h : g_lazy) {
-    if (!h->stale32[0] && !h->stale32[1]) continue;
+    if (!h->stale32[0] && !h->stale32[1] && !h->stale_wide) continue;
     // (a target module of the Python host is a net of its own whose pack IS the learner's target pack)
     auto same = [&](const oprl_net& n) {
       return net->pack == n.pack || (n.pack_target != nullptr && (net->pack == n.pack_target || net->pack_target == n.pack_target));
     };
     if (same(h->cfg.actor)) return fresh32_tables(h, 2, st);
     for (int j = 0; j < h->nc; ++j)
-      if (same(h->cfg.critics[j])) return fresh32_tables(h, 1, st);
+      if (same(h->cfg.critics[j])) return fresh32_tables(h, 1, st, true);
   }
   return OPRL_OK;
 }
@@ -814,11 +818,14 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
       prof_end(st);
       HIPC(e);
     } else if (same) {
+      // (these kernels read the fp32 packs: a 16-bit TQC learner's wide critics leave theirs stale)
+      if (h->stale_wide && h->multi_width == h->w_critic) RC(fresh32_tables(h, 1, st, true));
       prof_begin(0, st);
       hipError_t e = launch_mlp_slice_multi(h->multi_args, h->multi_n, h->multi_width, st);
       prof_end(st);
       HIPC(e);
     } else {
+      if (h->stale_wide && h->multi_width == h->w_critic) RC(fresh32_tables(h, 1, st, true));
       for (int k = 0; k < h->multi_n; ++k) {
         prof_begin(0, st);
         hipError_t e = launch_mlp_slice(h->multi_args[k], h->multi_width, st);
@@ -1337,6 +1344,12 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     dw.dy_tiled = dw.n_part > 1 ? 1 : 0;               // k_mlp_slice_tp runs the tp4 passes
     dw.trace = h->trace != nullptr ? h->trace + (size_t)4 * 64 * kTraceStamps * 2 : nullptr;   // slot 4
     dw.ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, 1.0f);
+    // TQC in a 16-bit mode: the critics' 512 x 512 layers run through the 16-bit packs (layerwise.hip); their fp32
+    // packs — a third of the wide dW launch's stores — are left stale and rebuilt by whoever reads them (fresh32)
+    if (algo == OPRL_TQC && (h->x2 || h->bf16) && h->lazy_wide && !c.export_grads && !h->no_layerwise) {
+      dw.skip32_wide = 1;
+      h->stale_wide = true;
+    }
     HIPC(launch_dw_prof(dw, st));
   }
   return OPRL_OK;
@@ -2139,7 +2152,11 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     int prc = repack_nets(nets, nc + 1, 3, nullptr, (h->bf16 || h->x2) ? p16 : nullptr, (h->bf16 || h->x2) ? p16t : nullptr, h->planes);
     if (prc != OPRL_OK) { dev_free(p.base); delete h; return prc; }
   }
-  if (h->x2) { std::lock_guard<std::mutex> lk(g_lazy_mu); g_lazy.push_back(h); }
+  if (h->x2 || (h->bf16 && cfg->algo == OPRL_TQC)) {
+    std::lock_guard<std::mutex> lk(g_lazy_mu);
+    g_lazy.push_back(h);
+    h->lazy_wide = cfg->algo == OPRL_TQC && getenv("OPRL_AMD_KEEP_WIDE32") == nullptr;
+  }
   *out = h;
   return OPRL_OK;
 }
@@ -2153,6 +2170,7 @@ extern "C" int oprl_learner_sync_params(oprl_learner* h, void* stream) {
   for (int j = 0; j < h->nc; ++j) { p16[j] = h->pack16[1 + j]; p16t[j] = h->pack16_t[1 + j]; }
   p16[h->nc] = h->pack16[0]; p16t[h->nc] = h->pack16_t[0];
   h->stale32[0] = h->stale32[1] = false;     // (every pack is rebuilt from the master here)
+  h->stale_wide = false;
   return repack_nets(nets, h->nc + 1, 3, (hipStream_t)stream, (h->bf16 || h->x2) ? p16 : nullptr, (h->bf16 || h->x2) ? p16t : nullptr, h->planes);
 }
 

@@ -14,6 +14,7 @@ from oprl_amd.algos.tqc import TQC
 from oprl_amd.logging import NullLogger
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+prec = sys.argv[2] if len(sys.argv) > 2 else "x2"      # the arithmetic mode of every learner of the run
 CASES = [("DDPG B=256", DDPG, 256, 300_000, {}), ("DDPG B=512 (over-subscribed grid)", DDPG, 512, 100_000, {}),
          ("TD3 B=256", TD3, 256, 300_000, dict(log_every=10 ** 9)),
          ("SAC B=256 tuned alpha", SAC, 256, 300_000, dict(log_every=10 ** 9, tune_alpha=True)),
@@ -27,7 +28,7 @@ for name, cls, B, n, kw in CASES:
     t0 = time.perf_counter()
     for rep in range(2):
         t.manual_seed(0)
-        algo = cls(logger=NullLogger(), state_dim=bench.S, action_dim=bench.A, device="cuda", max_batch=B, **kw).create()
+        algo = cls(logger=NullLogger(), state_dim=bench.S, action_dim=bench.A, device="cuda", max_batch=B, precision=prec, **kw).create()
         done = 0
         while done < n:
             k = min(20_000, n - done)
@@ -41,7 +42,7 @@ for name, cls, B, n, kw in CASES:
     same = all(t.equal(a, b) for a, b in zip(sums[0][1], sums[1][1]))
     good = sums[0][0] and sums[1][0] and same
     ok = ok and good
-    print(f"{name:36s} {n:7d} updates x2  finite={sums[0][0] and sums[1][0]}  runs identical={same}  "
+    print(f"[{prec}] {name:36s} {n:7d} updates x2  finite={sums[0][0] and sums[1][0]}  runs identical={same}  "
           f"({time.perf_counter() - t0:.1f} s)", flush=True)
 print("SOAK_OK" if ok else "SOAK_FAILED")
 sys.exit(0 if ok else 1)
