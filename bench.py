@@ -417,6 +417,12 @@ class Watchdog:
         with self.lock:
             self.done = True
 
+    def teardown(self, seconds=60.0):
+        """The line is out (or this rank has nothing to print): whatever is left — the closing barrier, the process
+        group's destruction — may take this long, then the process leaves quietly with what it has."""
+        with self.lock:
+            self.quiet, self.phase, self.deadline = True, "teardown", time.monotonic() + seconds
+
     def _watch(self):
         while True:
             time.sleep(1.0)
@@ -425,6 +431,8 @@ class Watchdog:
                     return
                 late = time.monotonic() > self.deadline
                 phase = self.phase
+            if late and getattr(self, "quiet", False):
+                os._exit(0)
             if late:
                 why = f"watchdog: phase '{phase}' exceeded {self.seconds:.0f} s on rank {self.rank}"
                 print(f"bench.py: {why}", file=sys.stderr, flush=True)
@@ -811,6 +819,7 @@ def measure(args, wd):
         except Exception:  # noqa: BLE001
             pass
         print(json.dumps(out), flush=True)
+    wd.teardown(60.0 if rank == 0 else 600.0)      # (the other ranks wait at the barrier while rank 0 runs its extra passes)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
