@@ -324,6 +324,33 @@ def test_step_act_is_update_then_policy_call(algo_name, precision):
     assert sc_rel(a1._actor_mlp().hip_act(other), a2._actor_mlp().hip_act(other)) < 2e-6
 
 
+@pytest.mark.parametrize("algo_name,S,A", [("sac", 67, 21), ("ddpg", 67, 21), ("tqc", 24, 6)])
+def test_step_act_other_shapes(algo_name, S, A):
+    """The policy kernel's other forms: a net input wider than 64 (two register chunks per row), an output row wider
+    than 16 (humanoid's Gaussian head, 42: the layer-by-layer kernel), TQC's actor behind the generic update sequence."""
+    import importlib
+    from oprl_amd.buffers.episodic_buffer import EpisodicReplayBuffer
+    from oprl_amd.logging import NullLogger
+    t.manual_seed(0)
+    cls = getattr(importlib.import_module(f"oprl_amd.algos.{algo_name}"), algo_name.upper())
+    a1 = cls(logger=NullLogger(), state_dim=S, action_dim=A, device="cuda", max_batch=64).create()
+    buf = EpisodicReplayBuffer(buffer_size_transitions=600, state_dim=S, action_dim=A, max_episode_lenth=50,
+                               device="cuda", seed=3).create()
+    rs = np.random.RandomState(0)
+    for e in range(5):
+        for i in range(50):
+            buf.add_transition(rs.standard_normal(S).astype(np.float32), rs.uniform(-1, 1, A), float(rs.uniform()), False,
+                               episode_done=(i == 49))
+    for k in range(3):
+        obs = rs.standard_normal(S).astype(np.float32)
+        a1.update_from_buffer(buf, 64, act_next=obs)
+        mlp = a1._actor_mlp()
+        got = mlp.hip_act(obs)
+        want = mlp.hip_act(obs)               # nothing pending now: oprl_mlp_act on the same weights
+        assert got.shape == want.shape == (mlp.dims[-1],)
+        assert sc_rel(got, want) < 2e-6, (k, sc_rel(got, want))
+
+
 def sc_rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(np.abs(b).max(), 1e-30))
 
