@@ -2313,6 +2313,12 @@ extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t
     int cur = 0;
     int rc = OPRL_OK;
     h->staged_ready = false;
+    // OPRL_AMD_GRAPH_PROBE=1 (measurement only, profiles/r03_experiments.txt): the K updates' launches are captured into a
+    // hipGraph — every node with its own argument block: epoch, counters and staging set are baked in at capture — and
+    // replayed once; the call returns when the graph has run.  Does the boundary between two launches move?
+    static const bool graph_probe = [] { const char* e = getenv("OPRL_AMD_GRAPH_PROBE"); return e != nullptr && atoi(e) != 0; }();
+    const bool in_graph = graph_probe && K > 1 && stream != nullptr;
+    if (in_graph) HIPC(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
     for (int k = 0; k < K && rc == OPRL_OK; ++k) {
       float** b = set[cur];
       float** nb = set[h->prefetch_p1 ? cur ^ 1 : cur];
@@ -2326,6 +2332,19 @@ extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t
       h->staged_ready = false;
       rc = oprl_learner_update(h, b[0], b[1], b[2], b[3], b[4], B, nullptr, nullptr, stream);
       if (h->prefetch_p1) cur ^= 1;
+    }
+    if (in_graph) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      HIPC(hipStreamEndCapture((hipStream_t)stream, &graph));
+      HIPC(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      const auto t0 = std::chrono::steady_clock::now();
+      HIPC(hipGraphLaunch(exec, (hipStream_t)stream));
+      HIPC(hipStreamSynchronize((hipStream_t)stream));
+      const double us = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() * 1e-3;
+      fprintf(stderr, "[oprl_amd graph probe] %d updates as one hipGraph: %.2f us per update (launch to drained)\n", K, us / K);
+      (void)hipGraphExecDestroy(exec);
+      (void)hipGraphDestroy(graph);
     }
     sc.gather = 0;
     h->prefetch_next = 0;
