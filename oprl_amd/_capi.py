@@ -130,6 +130,10 @@ _lib = None
 
 
 def lib_path() -> Path:
+    """liboprl_amd.so; with OPRL_AMD_TRACE=1 the build with the in-kernel stage stamps compiled in
+    (liboprl_amd_trace.so, `python -m oprl_amd.build --trace`: tools/trace_slice.py)."""
+    if os.environ.get("OPRL_AMD_TRACE", "0") not in ("", "0") and "OPRL_AMD_LIB" not in os.environ:
+        return LIB_PATH.with_name("liboprl_amd_trace.so")
     return Path(os.environ.get("OPRL_AMD_LIB", str(LIB_PATH)))
 
 

@@ -253,7 +253,7 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int b
   int n_stamp = 0;
   auto stamp = [&]() {
     const int wg = item * 16 + lt;   // the first 16 tiles of each item
-    if (h_trace != nullptr && tid == 0 && lt < 16 && wg < 64 && n_stamp < kTraceStamps) {
+    if (kTraceOn && h_trace != nullptr && tid == 0 && lt < 16 && wg < 64 && n_stamp < kTraceStamps) {
       long long* tr = h_trace + ((size_t)wg * kTraceStamps + n_stamp) * 2;
       tr[0] = (long long)__builtin_readcyclecounter();
       tr[1] = (long long)wall_clock64();

@@ -71,7 +71,7 @@ struct DwX2Tile {
   __device__ __forceinline__ void stamp() {
     long long* const h_trace = KA->trace;
     const int wg = item * 16 + lt;
-    if (h_trace != nullptr && threadIdx.x == 0 && lt < 16 && wg < 64 && n_stamp < kTraceStamps) {
+    if (kTraceOn && h_trace != nullptr && threadIdx.x == 0 && lt < 16 && wg < 64 && n_stamp < kTraceStamps) {
       long long* tr = h_trace + ((size_t)wg * kTraceStamps + n_stamp) * 2;
       tr[0] = (long long)__builtin_readcyclecounter();
       tr[1] = (long long)wall_clock64();

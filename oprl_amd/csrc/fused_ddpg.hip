@@ -337,7 +337,7 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const KA* D 
   int n_stamp = 0;
   auto stamp = [&]() {
     // wave 0 of every slice -> slot `slice`; the other 15 waves of slice 0 -> slots 16 + wave
-    if (A.trace != nullptr && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
+    if (kTraceOn && A.trace != nullptr && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
       const int slot = tid == 0 ? slice : 16 + (tid >> 6);
       long long* tr = A.trace + (((size_t)role * 64 + slot) * kTraceStamps + n_stamp) * 2;
       tr[0] = (long long)__builtin_readcyclecounter();
@@ -612,7 +612,7 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A) {
   const bool lead = tp.c == 0;
   int n_stamp = 0;
   auto stamp = [&]() {
-    if (A.trace != nullptr && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && g == 0 && n_stamp < kTraceStamps) {
+    if (kTraceOn && A.trace != nullptr && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && g == 0 && n_stamp < kTraceStamps) {
       const int slot = tid == 0 ? slice : 16 + (tid >> 6);
       long long* tr = A.trace + ((size_t)slot * kTraceStamps + n_stamp) * 2;
       tr[0] = (long long)__builtin_readcyclecounter();
@@ -954,7 +954,7 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const KA* D
   long long* const trace = A.whole ? A.trace2 : A.trace;
   int n_stamp = 0;
   auto stamp = [&]() {
-    if (trace != nullptr && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
+    if (kTraceOn && trace != nullptr && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
       const int slot = tid == 0 ? slice : 16 + (tid >> 6);
       long long* tr = trace + ((size_t)slot * kTraceStamps + n_stamp) * 2;
       tr[0] = (long long)__builtin_readcyclecounter();

@@ -384,6 +384,13 @@ constexpr int kDwTileN = 16;     // n (fan-out) extent: 16 rows keep a workgroup
 constexpr int kDwThreads = 512;
 constexpr int kDwWaves = 8;
 constexpr int kTraceStamps = 24;
+// in-kernel stage stamps (tools/trace_slice.py): compiled into liboprl_amd_trace.so only (-DOPRL_TRACE) — in the production
+// library the stamp sites vanish (5 KB of cold code inside the hot paths of a 113 KB kernel)
+#ifdef OPRL_TRACE
+constexpr bool kTraceOn = true;
+#else
+constexpr bool kTraceOn = false;
+#endif
 
 // csrc/policy_act.hip: one observation through a net's row-major master weights; obs / out / ticket are host-mapped
 constexpr int kPolicyActMaxWidth = 512;

@@ -39,7 +39,7 @@ __device__ __forceinline__ void mlp_slice_body(const MlpArgs& A) {
   const int tid = threadIdx.x;
   int n_stamp = 0;
   auto stamp = [&]() {
-    if (A.trace != nullptr && tid == 0 && n_stamp < kTraceStamps) {
+    if (kTraceOn && A.trace != nullptr && tid == 0 && n_stamp < kTraceStamps) {
       long long* t = A.trace + ((size_t)blockIdx.x * kTraceStamps + n_stamp) * 2;
       t[0] = (long long)__builtin_readcyclecounter();
       t[1] = (long long)wall_clock64();

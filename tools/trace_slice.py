@@ -1,8 +1,10 @@
 """Debug tool: per-phase timestamps inside k_mlp_slice for one DDPG update
 (needs a GPU).  Prints, per launch, the phase durations of workgroup 0 and the
 spread over workgroups, in shader cycles and in microseconds."""
+import os
 import sys
 from pathlib import Path
+os.environ.setdefault("OPRL_AMD_TRACE", "1")      # the library build with the stamps compiled in (python -m oprl_amd.build --trace)
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np
 import torch as t
