@@ -267,8 +267,12 @@ __device__ __forceinline__ int dw_total(const DwKArgs4& d) { return d.tile_end[k
 
 // (`by`: this workgroup's row of the roles' / tiles' block — blockIdx.y unless the caller runs the body inside a larger
 // grid: k_ddpg_update)
+// Returns the critic tile this workgroup goes on with (merged launches; -1: none): the caller runs it — ONE inlined copy
+// of the tile code per kernel instead of one per place a workgroup may turn into a tile (instruction cache, r03-14 / -25).
+// MERGED kernels are single-critic, non-SAC by their launchers' rules: the twin paths are compiled out of them.
 template <int WIDTH, bool LEAN, bool SAC, class P, bool WIDE = false, bool MERGED = false, class KA = DwKArgs>
-__device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const KA* D = nullptr, int by_in = -1) {
+__device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D = nullptr, int by_in = -1) {
+  constexpr bool TWIN = !MERGED;            // twin critics / twin_split can occur at all
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int by = by_in < 0 ? (int)blockIdx.y : by_in;
   // the last grid row of a step_n launch may be the PREFETCH row: the next update's rows (dispatched last: these
@@ -279,14 +283,7 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const KA* D 
     if (by >= rows && !pf_row) {
       // (whole-update launch: roles B and C go on as the first 8 x slices tiles themselves, below)
       const int tile = (A.whole ? 8 * (int)gridDim.x : 0) + (by - rows) * (int)gridDim.x + (int)blockIdx.x;
-      if (tile >= dw_total(*D)) return;
-      if constexpr (P::kX2 && kDwTileX2) {
-        dw_tile_x2<1, KA>(*D, smem, tile);        // the 16 x 64 split-product tile (dw_tile_x2.h), all 16 waves
-      } else if constexpr (std::is_same<KA, DwKArgs>::value) {
-        if (threadIdx.x >= kDwThreads) return;    // a tile workgroup is the first 8 waves (the stand-alone kernel's shape and arithmetic)
-        dw_adam_body<false, 1>(*D, smem, tile);
-      }
-      return;
+      return tile < dw_total(*D) ? tile : -1;
     }
   }
   using LY = FusedLds<WIDTH>;
@@ -364,7 +361,7 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const KA* D 
       const_cast<float*>(A.next.r)[row0 + tid] = rS[tid];
       const_cast<float*>(A.next.d)[row0 + tid] = dS[tid];
     }
-    return;
+    return -1;
   }
   stamp();   // batch rows requested
   const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
@@ -417,11 +414,10 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const KA* D 
         // A retires, long before the tiles' flags
         __syncthreads();
         const int tile = 4 * (int)gridDim.x + slice * 4 + tp.c;
-        if (tile < dw_total(*D)) dw_tile_x2<1, KA>(*D, smem, tile);
-        return;
+        return tile < dw_total(*D) ? tile : -1;
       }
     }
-    if (!A.twin_split) return;
+    if (!TWIN || !A.twin_split) return -1;
     // ---- ... then target critic 2 on (s', a') with role A's a'
     if (tid < kR * Ad) {
       const int row = tid / Ad, col = tid - row * Ad;
@@ -430,7 +426,7 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const KA* D 
     tp_fwd<WIDTH, LEAN, P>(A.critic2_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
     if (lead && tid < kR) granule_put(x_slot(0) + tid, x_tag, outS[tid * kOutLd]);
     stamp();
-    return;
+    return -1;
   }
 
   if (role == 0) {
@@ -438,7 +434,7 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const KA* D 
     // (TD3: min over the twin targets), TD target                    (ddpg.py:94-95, td3.py:83-101)
     // (SAC: a' ~ pi(s') from the online actor, log pi(a'|s') kept per row     sac.py:90-97)
     tp_fwd<WIDTH, LEAN, P, NMA>(SAC ? A.actor : A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
-    const bool send_a2 = A.twin_split && lead;
+    const bool send_a2 = TWIN && A.twin_split && lead;
     unsigned long long* x_a2 = send_a2 ? x_slot(role_c) : nullptr;
     if constexpr (SAC)
       gauss_head(outS, row0, B, Ad, A.noise, A.rng_seed, A.rng_ctr, xb + S, kX0Ld, yS, nullptr, nullptr, nullptr,
@@ -469,15 +465,15 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const KA* D 
       if constexpr (LEAN) {
         if (++hook_n == 2) {
           gq[0] = __hip_atomic_load(gq_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (A.n_critics == 2) gq[1] = __hip_atomic_load(gq_src + A.gran_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (TWIN && A.n_critics == 2) gq[1] = __hip_atomic_load(gq_src + A.gran_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     };
     tp_fwd<WIDTH, LEAN, P, NMA>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, hook);
     float qn = (tid < kR) ? outS[tid * kOutLd] : 0.f;
-    if (A.twin_split) {
+    if (TWIN && A.twin_split) {
       if (lead && tid < kR) qn = fminf(qn, granule_get(x_slot(0) + tid, x_tag, A.err, (KERN_PHASE1 << 8) | SITE_TWIN_SPLIT));
-    } else if (A.n_critics == 2) {
+    } else if (TWIN && A.n_critics == 2) {
       tp_fwd<WIDTH, LEAN, P, NMA>(A.critic2_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
       if (tid < kR) qn = fminf(qn, outS[tid * kOutLd]);
     }
@@ -506,7 +502,7 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const KA* D 
       const int lim = A.debug_expire == (int)SITE_TD_TARGET ? 0 : (1 << 20);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        if (j < A.n_critics) {
+        if (j < (TWIN ? A.n_critics : 1)) {
           float q = 0.f;
           if (row_ok) {
             unsigned long long g = gq[j];                  // requested during the pass above
@@ -539,25 +535,43 @@ __device__ __forceinline__ void ddpg_phase1_body(const DdpgArgs& A, const KA* D 
       }
     }
     stamp();
-    return;
+    return -1;
   }
 
   // ---- role B: q = critic_j(s, a) forward (runs while role A computes the target).  The twin
   // critic gets its own copy of the code (a runtime-selected Net would leave the kernel-argument
   // registers: profiles/r01b_experiments.txt #10).
-  if (role == 2) { role_b<WIDTH, LEAN, P>(A, A.critic2, A.c2X, A.c2dY, A.partials_c + (size_t)gridDim.x * 4, false, 1, smem, tp, stamp); return; }
+  if constexpr (TWIN)
+    if (role == 2) { role_b<WIDTH, LEAN, P>(A, A.critic2, A.c2X, A.c2dY, A.partials_c + (size_t)gridDim.x * 4, false, 1, smem, tp, stamp); return -1; }
   role_b<WIDTH, LEAN, P>(A, A.critic, A.cX, A.cdY, A.partials_c, true, 0, smem, tp, stamp);
   if constexpr (MERGED && P::kX2 && kDwTileX2) {
     if (A.whole) {       // (as role C above: this workgroup goes on as critic tile (slice, member))
       __syncthreads();
       const int tile = slice * 4 + tp.c;
-      if (tile < dw_total(*D)) dw_tile_x2<1, KA>(*D, smem, tile);
+      return tile < dw_total(*D) ? tile : -1;
     }
+  }
+  return -1;
+}
+
+// the tile a workgroup of a merged phase-1 launch ended up with (the one inlined copy of the tile code per kernel)
+template <class P, class KA>
+__device__ __forceinline__ void ddpg_phase1_tile(const KA* D, int tile) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (tile < 0) return;
+  if constexpr (P::kX2 && kDwTileX2) {
+    dw_tile_x2<1, KA>(*D, smem, tile);        // the 16 x 64 split-product tile (dw_tile_x2.h), all 16 waves
+  } else if constexpr (std::is_same<KA, DwKArgs>::value) {
+    if (threadIdx.x >= kDwThreads) return;    // a tile workgroup is the first 8 waves (the stand-alone kernel's shape and arithmetic)
+    // (said again where the compiler sees it: without it the body's "one past the tiles" path — the temperature's Adam
+    // step, with its 32 bytes of static LDS — stays in a kernel that asks for the whole LDS dynamically)
+    if (tile >= dw_total(*D)) return;
+    dw_adam_body<false, 1>(*D, smem, tile);
   }
 }
 
 template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32, bool WIDE = false>
-__global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) { ddpg_phase1_body<WIDTH, LEAN, SAC, P, WIDE>(A); }
+__global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) { (void)ddpg_phase1_body<WIDTH, LEAN, SAC, P, WIDE>(A); }
 
 // phase 1 + the critic's dW tiles in one launch (both argument blocks by value; the tile workgroups index the
 // second one through the kernel-argument segment: scalar loads, as k_dw_adam does)
@@ -567,7 +581,7 @@ constexpr size_t kMergedDwOffset = (sizeof(DdpgArgs) + alignof(DwKArgs) - 1) / a
 template <class P, bool WIDE = false>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase1_dw(const DdpgArgs A, const DwKArgs D) {
   const DwKArgs* Dp = (const DwKArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kMergedDwOffset);
-  ddpg_phase1_body<256, true, false, P, WIDE, true>(A, Dp);
+  ddpg_phase1_tile<P, DwKArgs>(Dp, ddpg_phase1_body<256, true, false, P, WIDE, true>(A, Dp));
 }
 
 
@@ -575,7 +589,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1_dw(const DdpgArgs A, c
 // does not fit the kernel-argument segment), every field read is a scalar load through one uniform pointer.
 template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase1_group(const DdpgArgs* __restrict__ batch) {
-  ddpg_phase1_body<WIDTH, LEAN, SAC, P>(batch[blockIdx.z]);
+  (void)ddpg_phase1_body<WIDTH, LEAN, SAC, P>(batch[blockIdx.z]);
 }
 
 // WIDE (DDPG / TD3, fp32 lean passes): the critic's forward + backward pass — two thirds of this kernel, on a
@@ -1122,7 +1136,8 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_update(const DdpgArgs A, cons
   const int tc = Dcp->tile_end[kDwFusedItems - 1];
   const int rows1 = 3 * 4 + 4 + ((tc > 8 * slices ? tc - 8 * slices : 0) + slices - 1) / slices;
   const int y = (int)blockIdx.y;
-  if (y < rows1 || (A.prefetch_p1 && y == (int)gridDim.y - 1)) ddpg_phase1_body<256, true, false, P, true, true, DwKArgs4>(A, Dcp, y);
+  if (y < rows1 || (A.prefetch_p1 && y == (int)gridDim.y - 1))
+    ddpg_phase1_tile<P, DwKArgs4>(Dcp, ddpg_phase1_body<256, true, false, P, true, true, DwKArgs4>(A, Dcp, y));
   else ddpg_phase2m_body<P, DwKArgs4>(A, Dap, y - rows1);
 }
 
