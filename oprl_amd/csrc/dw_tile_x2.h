@@ -56,15 +56,17 @@ static_assert(2 * 16 * DwX2Lds::LDT <= 16 * DwX2Lds::LDF, "the staged tiles fit 
 // begin(): the tile's header, its Adam state and (GATE 2) every row that does not depend on this launch; finish(): the
 // rest.  Two calls, so that a workgroup that has something else to do first (role U of phase 2, which goes on as a tile
 // workgroup) can have its rows in flight meanwhile.
-template <int GATE, class KArgs = DwKArgs>
+// (`gate` — 1: the critic's tiles, 2: the actor's — is a RUN-TIME member: k_ddpg_update runs both kinds and carries ONE copy
+// of this code for them, 10 KB less in a kernel whose speed follows its instruction-cache footprint (r03-25 / -26); in
+// the two-launch kernels the value is a constant at the only call site and the other kind's branches fold away)
+template <class KArgs = DwKArgs>
 struct DwX2Tile {
-  static_assert(GATE == 1 || GATE == 2, "the gated tiles of the merged phase launches");
   static constexpr int TK = kDwX2TileK, LDF = DwX2Lds::LDF, LDH = DwX2Lds::LDH, LDT = DwX2Lds::LDT;
   // (only what must survive between begin() and finish(): the layer's table entry, the tile's coordinates and flags are
   // formed again in finish() — scalar work — instead of being carried through whatever runs in between)
   const KArgs* KA;
   float* lds;
-  int item, lt, n_stamp;
+  int item, lt, n_stamp, gate;
   float p_th, p_m, p_v, p_tt, q_th, q_m, q_v, q_tt;
   f32x4 vx[2][2], hmask;
 
@@ -79,7 +81,8 @@ struct DwX2Tile {
     ++n_stamp;
   }
 
-  __device__ __forceinline__ void begin(const KArgs& A, float* lds_, int bx) {
+  __device__ __forceinline__ void begin(const KArgs& A, float* lds_, int bx, int gate_) {
+    gate = gate_;
     KA = &A;
     lds = lds_;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -122,7 +125,7 @@ struct DwX2Tile {
 #pragma unroll
     for (int h = 0; h < 2; ++h) vx[h][0] = vx[h][1] = z4;
     hmask = z4;
-    if constexpr (GATE == 2) {
+    if (gate == 2) {
       const int kind = item == 0 ? G.kind[0] : (item == 1 ? G.kind[1] : (item == 2 ? G.kind[2] : G.kind[3]));
       // X is the launch before's: at once
 #pragma unroll
@@ -160,7 +163,7 @@ struct DwX2Tile {
   const bool b_own = tk == 0 && tid < kDwTileN && n_base + tid < I.N;
   const bool b_pol = ad.do_polyak && I.b_t != nullptr;
   int kind = 0;
-  if constexpr (GATE == 2) kind = item == 0 ? G.kind[0] : (item == 1 ? G.kind[1] : (item == 2 ? G.kind[2] : G.kind[3]));
+  if (gate == 2) kind = item == 0 ? G.kind[0] : (item == 1 ? G.kind[1] : (item == 2 ? G.kind[2] : G.kind[3]));
   const int ptile = n_base >> 4;
   const int i = lane & 15, kk = lane >> 4;
   const float step_size = ad.step_size_host, bc2_sqrt = ad.bc2_sqrt_host;   // (the host knows the step in the merged launches)
@@ -175,7 +178,7 @@ struct DwX2Tile {
   f32x4 va[kDuLd];
 #pragma unroll
   for (int j = 0; j < kDuLd; ++j) va[j] = z4;
-  if constexpr (GATE == 2) {
+  if (gate == 2) {
     // the output layer's rows W3[j][ncol .. ncol + 3] (a few hundred bytes, shared by every tile of the layer: not
     // worth eight registers per lane through role U)
     if (kind == 1 && an_ok) {
@@ -189,7 +192,7 @@ struct DwX2Tile {
   unsigned long long g[kDuLd];
   const unsigned long long* gsrc = nullptr;
   int n_g = 0;
-  if constexpr (GATE == 2) {
+  if (gate == 2) {
     const bool row_in = bb < hB;
     if (kind == 2) {
       gsrc = G.g1 + ((size_t)(ncol >> 4) * hB + (row_in ? bb : 0)) * 16 + (ncol & 15);
@@ -204,7 +207,7 @@ struct DwX2Tile {
   }
   // (GATE 2 waits for granules only: what the critic pass reads of the actor's packs it has taken in BEFORE it publishes
   // du, and no tile stores before it has du)
-  if constexpr (GATE == 1) {
+  if (gate == 1) {
     const unsigned long long* myf = G.rows + (tid < G.n_rows ? tid : 0);
     bool ok = (unsigned)(__hip_atomic_load(myf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == G.tag;
     for (int spin = 0; spin < G.spin && !ok; ++spin) {
@@ -214,7 +217,7 @@ struct DwX2Tile {
     if (!ok) report_expired(G.err, G.err_code);
   }
   f32x4 u = z4;          // GATE 1: the unit-seed dY of this lane
-  if constexpr (GATE == 1) {
+  if (gate == 1) {
     __syncthreads();     // role B's members have flagged their rows (written through): X and the unit-seed dY
     // The write-through rows are read with inline-asm sc1 loads, which hipcc neither counts nor orders: they are
     // issued UNCONDITIONALLY, from clamped addresses, in one straight line up to the explicit wait — a load under a
@@ -266,7 +269,7 @@ struct DwX2Tile {
   }
   // ---- the late numbers: per-row seeds (GATE 1) / du (GATE 2), then this lane's four dY elements
   f32x4 v = z4;
-  if constexpr (GATE == 1) {
+  if (gate == 1) {
     float sd = 0.f;
     if (bb < hB && G.n_seed > 0) {
       unsigned long long x = 0;
@@ -461,10 +464,10 @@ struct DwX2Tile {
   }
 };
 
-template <int GATE, class KArgs = DwKArgs>
-__device__ __forceinline__ void dw_tile_x2(const KArgs& A, float* lds, int bx) {
-  DwX2Tile<GATE, KArgs> T;
-  T.begin(A, lds, bx);
+template <class KArgs = DwKArgs>
+__device__ __forceinline__ void dw_tile_x2(const KArgs& A, float* lds, int bx, int gate) {
+  DwX2Tile<KArgs> T;
+  T.begin(A, lds, bx, gate);
   T.finish();
 }
 

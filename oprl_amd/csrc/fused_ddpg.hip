@@ -554,13 +554,14 @@ __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D =
   return -1;
 }
 
-// the tile a workgroup of a merged phase-1 launch ended up with (the one inlined copy of the tile code per kernel)
+// the tile a workgroup of a merged launch ended up with (the one inlined copy of the tile code per kernel); gate 1: a
+// critic tile of phase 1's launch, 2: an actor tile of phase 2's
 template <class P, class KA>
-__device__ __forceinline__ void ddpg_phase1_tile(const KA* D, int tile) {
+__device__ __forceinline__ void ddpg_tile(const KA* D, int tile, int gate) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (tile < 0) return;
   if constexpr (P::kX2 && kDwTileX2) {
-    dw_tile_x2<1, KA>(*D, smem, tile);        // the 16 x 64 split-product tile (dw_tile_x2.h), all 16 waves
+    dw_tile_x2<KA>(*D, smem, tile, gate);     // the 16 x 64 split-product tile (dw_tile_x2.h), all 16 waves
   } else if constexpr (std::is_same<KA, DwKArgs>::value) {
     if (threadIdx.x >= kDwThreads) return;    // a tile workgroup is the first 8 waves (the stand-alone kernel's shape and arithmetic)
     // (said again where the compiler sees it: without it the body's "one past the tiles" path — the temperature's Adam
@@ -581,7 +582,7 @@ constexpr size_t kMergedDwOffset = (sizeof(DdpgArgs) + alignof(DwKArgs) - 1) / a
 template <class P, bool WIDE = false>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase1_dw(const DdpgArgs A, const DwKArgs D) {
   const DwKArgs* Dp = (const DwKArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kMergedDwOffset);
-  ddpg_phase1_tile<P, DwKArgs>(Dp, ddpg_phase1_body<256, true, false, P, WIDE, true>(A, Dp));
+  ddpg_tile<P, DwKArgs>(Dp, ddpg_phase1_body<256, true, false, P, WIDE, true>(A, Dp), 1);
 }
 
 
@@ -904,8 +905,10 @@ __device__ __forceinline__ void wait_flags(const unsigned long long* flags, int 
   }
 }
 
-template <class P, class KA = DwKArgs>
-__device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const KA* D, int by_in = -1) {
+// (returns the actor tile this workgroup is, -1 for the pass's and the prefetch row's workgroups: ddpg_tile runs it)
+// PF: the launch may carry the prefetch row (the two-launch form; k_ddpg_update's rides on phase 1's rows)
+template <class P, class KA = DwKArgs, bool PF = true>
+__device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D, int by_in = -1) {
   static_assert(P::kX2 && kDwTileX2, "the merged phase 2 exists for PrecX2 learners");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<256>;
@@ -914,20 +917,19 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const KA* D
   const int B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
   const int slice = blockIdx.x, row0 = slice * kR;
   const int y = by_in < 0 ? (int)blockIdx.y : by_in;
-  const int yP = NMC, yT = yP + (A.prefetch_next ? 1 : 0);
+  const int yP = NMC, yT = yP + ((PF && A.prefetch_next) ? 1 : 0);
   if (y >= yT) {   // a tile workgroup: all 16 waves (16 minibatch rows each)
     const int tile = (y - yT) * (int)gridDim.x + slice;
-    if (tile >= dw_total(*D)) return;
+    if (tile >= dw_total(*D)) return -1;
     if (A.whole) {      // (k_ddpg_update: the rows this tile reads are role C's of this very launch)
       wait_flags(A.w_flags, 4 * (int)gridDim.x, A.epoch, A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
       __syncthreads();
       asm volatile("buffer_inv sc0" ::: "memory");
     }
-    dw_tile_x2<2, KA>(*D, smem, tile);
-    return;
+    return tile;
   }
   float* xa = smem + LY::xa;
-  if (y == yP) {
+  if (PF && y == yP) {
     // ---- prefetch row: the next update's rows (as in ddpg_phase2_body)
     float* xb = smem + LY::xb;
     float* rS = smem + LY::misc;
@@ -946,7 +948,7 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const KA* D
       const_cast<float*>(A.next.r)[row0 + tid] = rS[tid];
       const_cast<float*>(A.next.d)[row0 + tid] = dS[tid];
     }
-    return;
+    return -1;
   }
   // ---- the critic pass: q = critic(s, pi) forward + constant-seed backward to the action columns -> du -> granules
   float* h1 = smem + LY::h;
@@ -1104,12 +1106,13 @@ __device__ __forceinline__ void ddpg_phase2m_body(const DdpgArgs& A, const KA* D
     granule_put(const_cast<unsigned long long*>(A.g1_granules) + ((size_t)(2 * c + et) * B + row0 + er) * 16 + ec, A.epoch, v);
   }
   stamp();
+  return -1;
 }
 
 template <class P>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase2_dw(const DdpgArgs A, const DwKArgs D) {
   const DwKArgs* Dp = (const DwKArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kMergedDwOffset);
-  ddpg_phase2m_body<P>(A, Dp);
+  ddpg_tile<P, DwKArgs>(Dp, ddpg_phase2m_body<P>(A, Dp), 2);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1136,9 +1139,16 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_update(const DdpgArgs A, cons
   const int tc = Dcp->tile_end[kDwFusedItems - 1];
   const int rows1 = 3 * 4 + 4 + ((tc > 8 * slices ? tc - 8 * slices : 0) + slices - 1) / slices;
   const int y = (int)blockIdx.y;
-  if (y < rows1 || (A.prefetch_p1 && y == (int)gridDim.y - 1))
-    ddpg_phase1_tile<P, DwKArgs4>(Dcp, ddpg_phase1_body<256, true, false, P, true, true, DwKArgs4>(A, Dcp, y));
-  else ddpg_phase2m_body<P, DwKArgs4>(A, Dap, y - rows1);
+  // (whatever a workgroup was — a role, the pass, a row of tiles — the tile it ends up with runs in ONE place)
+  int tile, gate;
+  if (y < rows1 || (A.prefetch_p1 && y == (int)gridDim.y - 1)) {
+    tile = ddpg_phase1_body<256, true, false, P, true, true, DwKArgs4>(A, Dcp, y);
+    gate = 1;
+  } else {
+    tile = ddpg_phase2m_body<P, DwKArgs4, false>(A, Dap, y - rows1);
+    gate = 2;
+  }
+  ddpg_tile<P, DwKArgs4>(gate == 1 ? Dcp : Dap, tile, gate);
 }
 
 static_assert(FusedLds<256>::total >= kDwLdsFloats && FusedLds<256>::total >= DwLds<16>::floats && FusedLds<256>::total >= DwX2Lds::floats, "a tile workgroup fits the phase kernels' LDS");
