@@ -270,9 +270,10 @@ __device__ __forceinline__ int dw_total(const DwKArgs4& d) { return d.tile_end[k
 // Returns the critic tile this workgroup goes on with (merged launches; -1: none): the caller runs it — ONE inlined copy
 // of the tile code per kernel instead of one per place a workgroup may turn into a tile (instruction cache, r03-14 / -25).
 // MERGED kernels are single-critic, non-SAC by their launchers' rules: the twin paths are compiled out of them.
-template <int WIDTH, bool LEAN, bool SAC, class P, bool WIDE = false, bool MERGED = false, class KA = DwKArgs>
+// (SINGLE: the caller's launcher admits one critic only — the merged kernels, the packed learners' group kernel)
+template <int WIDTH, bool LEAN, bool SAC, class P, bool WIDE = false, bool MERGED = false, class KA = DwKArgs, bool SINGLE = MERGED>
 __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D = nullptr, int by_in = -1) {
-  constexpr bool TWIN = !MERGED;            // twin critics / twin_split can occur at all
+  constexpr bool TWIN = !SINGLE;            // twin critics / twin_split can occur at all
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int by = by_in < 0 ? (int)blockIdx.y : by_in;
   // the last grid row of a step_n launch may be the PREFETCH row: the next update's rows (dispatched last: these
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1_dw(const DdpgArgs A, c
 // does not fit the kernel-argument segment), every field read is a scalar load through one uniform pointer.
 template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase1_group(const DdpgArgs* __restrict__ batch) {
-  (void)ddpg_phase1_body<WIDTH, LEAN, SAC, P>(batch[blockIdx.z]);
+  (void)ddpg_phase1_body<WIDTH, LEAN, SAC, P, false, false, DwKArgs, true>(batch[blockIdx.z]);      // (DDPG only: launch_ddpg_phase1_group)
 }
 
 // WIDE (DDPG / TD3, fp32 lean passes): the critic's forward + backward pass — two thirds of this kernel, on a
