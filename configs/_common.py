@@ -45,7 +45,7 @@ class TrainingScript:
 
     def make_algo(self, logger):
         return self.algo_cls(logger=logger, state_dim=self.state_dim, action_dim=self.action_dim,
-                             device=self.args.device).create()
+                             device=self.args.device, precision=self.args.precision).create()
 
     def make_replay_buffer(self):
         return EpisodicReplayBuffer(buffer_size_transitions=max(self.config.num_steps, REPLAY_TRANSITIONS),

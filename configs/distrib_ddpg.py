@@ -57,7 +57,8 @@ def make_policy():
 
 def make_algo(logger, **overrides):
     """``overrides``: what a data-parallel rank needs on top (device=cuda:<rank>, export_grads=True)."""
-    return DDPG(logger=logger, state_dim=OBS_DIM, action_dim=ACT_DIM, **{"device": cli.device, **overrides}).create()
+    return DDPG(logger=logger, state_dim=OBS_DIM, action_dim=ACT_DIM,
+                **{"device": cli.device, "precision": cli.precision, **overrides}).create()
 
 
 def make_replay_buffer(**overrides):

@@ -10,6 +10,9 @@ _SHARED = (
     ("--config", str, None, "path of a config file (accepted for compatibility; the scripts are the config)"),
     ("--env", str, "cartpole-balance", "environment name, e.g. walker-walk"),
     ("--device", str, "cuda", "device of the learner (a ROCm GPU; there is no CPU path)"),
+    # extension: the learner's arithmetic mode.  The scripts default to the faster of the two
+    # parity modes; the algorithm classes themselves default to "f32"
+    ("--precision", str, "x2", "x2 (fp32 as fp16 hi + lo on the matrix cores, parity mode) | f32 (exact fp32 MFMA) | bf16"),
 )
 _SINGLE = (
     ("--seeds", int, 1, "how many seeds to train, one process each"),
