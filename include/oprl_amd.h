@@ -180,7 +180,8 @@ int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, int32_t B, 
  * for the forward-only chains where that still fits the chip (DDPG's target chain, DDPG / TD3's critic pass of
  * the actor step; exact-fp32 mode, action_dim <= 8) — lowest latency for a learner that has the GPU (nearly) to
  * itself; such launches want every CU, so learners that share a GPU with more than two others (seeds packed on
- * streams, one process per seed on one GPU) use 4: clusters of four only (also OPRL_AMD_NO_WIDE=1).  2 or 1:
+ * streams, one process per seed on one GPU) use 4: clusters of four only (also OPRL_AMD_NO_WIDE=1), and the dW + Adam
+ * tiles as launches of their own instead of workgroups riding on the phase launches.  2 or 1:
  * least CU time per update (what oprl_group uses).  Results differ in the last bits between settings (order of
  * the exchange sums); a setting is part of a run's configuration like the seed. */
 int oprl_learner_set_cluster(oprl_learner* h, int32_t nc);

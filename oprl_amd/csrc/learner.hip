@@ -375,6 +375,7 @@ struct oprl_learner {
   int ncl = 1;                 // CUs per slice cluster in the fused path (csrc/tp3.h)
   int n_cus = 256;
   int no_lean = 0;
+  bool shared_chip = false;    // oprl_learner_set_cluster(< 8): this learner is one of several on the GPU
   int no_merge = 0;            // OPRL_AMD_NO_MERGE: dW launches of their own
   int no_merge2 = 0;           // OPRL_AMD_NO_MERGE2: phase 2 runs the actor's backward itself, the actor's dW is a launch of its own
   // merged phase 2 (DdpgArgs::merged bit 1): du granules [Bm][kDuLd], the first layer's dz1 granules [16][Bm][16] and the
@@ -984,7 +985,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   }
   // merged launches (DDPG, lean passes, one 256-row chunk, this rank's own Adam step): the critic's dW tiles ride
   // on phase 1 — whose role A then stays on a cluster of four: 64 CUs must be free for tile workgroups from the start
-  if (!h->no_merge && h->nc == 1 && !a.sac && B <= 256 && !h->cfg.export_grads && !h->dp_inline && fused_ddpg_is_lean(a)) {
+  if (!h->no_merge && !h->shared_chip && h->nc == 1 && !a.sac && B <= 256 && !h->cfg.export_grads && !h->dp_inline && fused_ddpg_is_lean(a)) {
     a.merged |= 1;
     if (!(a.x2 && fused_x2_tiles())) a.wide &= ~1;     // (the 84 16 x 64 tiles of a PrecX2 learner get along with role A on eight)
   }
@@ -992,7 +993,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   // du, the first layer's comes from one more backward step of the critic pass's members (csrc/fused_ddpg.hip).
   // PrecX2 learners only, the pass on clusters of eight: with the exact-fp32 tiles the merged form measured no faster
   // than the two launches (34.9 vs 34.7 us)
-  if (!h->no_merge2 && a.x2 && fused_x2_tiles() && h->du_granules != nullptr && !a.sac && B <= 256 && !h->cfg.export_grads && !h->dp_inline &&
+  if (!h->no_merge2 && !h->shared_chip && a.x2 && fused_x2_tiles() && h->du_granules != nullptr && !a.sac && B <= 256 && !h->cfg.export_grads && !h->dp_inline &&
       fused_ddpg_is_lean(a) && c.actor.theta_target != nullptr && (a.wide & 2) != 0) {
     a.merged |= 2;
     a.du_granules = h->du_granules;
@@ -2537,6 +2538,9 @@ extern "C" int oprl_learner_set_cluster(oprl_learner* h, int32_t nc) {
   h->ncl = nc == 8 ? 4 : nc;
   static const bool env_off = [] { const char* e = getenv("OPRL_AMD_NO_WIDE"); return e != nullptr && atoi(e) != 0; }();
   h->no_wide = (nc == 8 && !env_off) ? 0 : 1;
+  // ... and a learner that shares the chip (anything but 8) keeps to the launch forms whose workgroups only wait within
+  // their cluster: no tile workgroups riding on the phase launches (measured: 8 learners on 8 streams 47k -> 60k aggregate)
+  h->shared_chip = nc != 8;
   return OPRL_OK;
 }
 
