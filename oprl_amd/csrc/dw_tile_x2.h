@@ -367,6 +367,18 @@ struct DwX2Tile {
 #pragma unroll
   for (int q = 0; q < 8; ++q) gsum += part[((size_t)q * 16 + nl) * LDT + kl];
   gsum *= ad.grad_scale;
+  if (!ad.do_adam) {
+    // a gradient-exporting (data-parallel) learner: the tile leaves dW / db in the gradient arena for the all-reduce;
+    // Adam, Polyak and the packs are the apply launch's (k_dw_adam, apply_only)
+    if (e_ok && I.w_g != nullptr) I.w_g[eo] = gsum;
+    if (b_own && I.b_g != nullptr) {
+      float gb = 0.f;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) gb += bpart[q * 16 + tid];
+      I.b_g[n_base + tid] = gb * ad.grad_scale;
+    }
+    return;
+  }
   float th_new = 0.f, tt_new = 0.f;
   if (e_ok) {
     float mm = p_m, vv = p_v, th = p_th;

@@ -985,7 +985,10 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   }
   // merged launches (DDPG, lean passes, one 256-row chunk, this rank's own Adam step): the critic's dW tiles ride
   // on phase 1 — whose role A then stays on a cluster of four: 64 CUs must be free for tile workgroups from the start
-  if (!h->no_merge && !h->shared_chip && h->nc == 1 && !a.sac && B <= 256 && !h->cfg.export_grads && !h->dp_inline && fused_ddpg_is_lean(a)) {
+  // (a gradient-exporting learner — data parallel over RCCL — merges only with the PrecX2 tiles, which know how to leave
+  // dW in the gradient arena instead of running Adam: four launches per data-parallel update instead of six)
+  const bool xport_ok = !h->cfg.export_grads || (a.x2 && fused_x2_tiles());
+  if (!h->no_merge && !h->shared_chip && h->nc == 1 && !a.sac && B <= 256 && xport_ok && !h->dp_inline && fused_ddpg_is_lean(a)) {
     a.merged |= 1;
     if (!(a.x2 && fused_x2_tiles())) a.wide &= ~1;     // (the 84 16 x 64 tiles of a PrecX2 learner get along with role A on eight)
   }
@@ -993,7 +996,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   // du, the first layer's comes from one more backward step of the critic pass's members (csrc/fused_ddpg.hip).
   // PrecX2 learners only, the pass on clusters of eight: with the exact-fp32 tiles the merged form measured no faster
   // than the two launches (34.9 vs 34.7 us)
-  if (!h->no_merge2 && !h->shared_chip && a.x2 && fused_x2_tiles() && h->du_granules != nullptr && !a.sac && B <= 256 && !h->cfg.export_grads && !h->dp_inline &&
+  if (!h->no_merge2 && !h->shared_chip && a.x2 && fused_x2_tiles() && h->du_granules != nullptr && !a.sac && B <= 256 && !h->dp_inline &&
       fused_ddpg_is_lean(a) && c.actor.theta_target != nullptr && (a.wide & 2) != 0) {
     a.merged |= 2;
     a.du_granules = h->du_granules;
@@ -1002,7 +1005,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   }
   // the whole update as ONE launch (k_ddpg_update): both merged forms, role A and the critic pass on eight, the 16 x 64
   // tiles, and everything the roles hand to each other in uncached memory
-  if (!h->no_whole && a.x2 && fused_x2_tiles() && h->nc == 1 && (a.merged & 3) == 3 && (a.wide & 3) == 3 && h->uc_pool &&
+  if (!h->no_whole && !h->cfg.export_grads && a.x2 && fused_x2_tiles() && h->nc == 1 && (a.merged & 3) == 3 && (a.wide & 3) == 3 && h->uc_pool &&
       h->uc_base != nullptr && h->w_flags != nullptr) {
     a.whole = 1;
     a.w_flags = h->w_flags;

@@ -470,10 +470,12 @@ def _mk_logger():
     return NullLogger("/tmp/oprl_amd_test")
 
 
-def test_native_dp_single_rank_equals_export_split():
+@pytest.mark.parametrize("precision", ["f32", "x2"])
+def test_native_dp_single_rank_equals_export_split(precision):
     """World-size-1 RCCL communicator on this GPU: the C data-parallel loop
     (dp_step_n: phase -> ncclAllReduce -> apply, twice per update) must reproduce the
-    python-driven export_grads split bit for bit."""
+    python-driven export_grads split bit for bit.  (x2: the phases are the merged launches whose tiles leave dW in the
+    gradient arena; and the result must be the single-GPU update's within the parity gate.)"""
     import os
     import tempfile
     import torch.distributed as dist
@@ -486,7 +488,7 @@ def test_native_dp_single_rank_equals_export_split():
         created = True
     try:
         K, B = 6, 64
-        a1, a2 = _ddpg(max_batch=B, export_grads=True), _ddpg(max_batch=B, export_grads=True)
+        a1, a2 = _ddpg(max_batch=B, export_grads=True, precision=precision), _ddpg(max_batch=B, export_grads=True, precision=precision)
         buf = _filled_buffer()
         dp = DataParallelLearner(a1)
         dp.init_native_comm()
@@ -509,6 +511,14 @@ def test_native_dp_single_rank_equals_export_split():
         for m in ("actor", "critic", "actor_target", "critic_target"):
             assert t.equal(getattr(a1, m)._oprl_arena, getattr(a2, m)._oprl_arena), m
         assert float(dp.replica_checksum().abs().max()) == 0
+        # ... and against the single-GPU fused update on the same rows (another launch structure: tolerance)
+        a3 = _ddpg(max_batch=B, precision=precision)
+        buf3 = _filled_buffer()
+        a3.learner.step_n(buf3.handle, K, B, seed=buf.seed)
+        t.cuda.synchronize()
+        for m in ("actor", "critic"):
+            x, y = getattr(a1, m)._oprl_arena, getattr(a3, m)._oprl_arena
+            assert float((x - y).abs().max() / y.abs().max()) < 2e-5, m
     finally:
         if created:
             dist.destroy_process_group()
