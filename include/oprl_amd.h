@@ -56,7 +56,17 @@ typedef enum oprl_algo { OPRL_DDPG = 0, OPRL_TD3 = 1, OPRL_SAC = 2, OPRL_TQC = 3
  *          backward, generic fall-back launches for shapes the fused kernels do not cover) a BF16
  *          learner computes in fp32 from the fp32 packs.  Deviation from the reference: ~1e-3..1e-2
  *          relative on Q (bf16 inputs cannot meet the 1e-4 gate; tests/test_gpu_bf16.py states and
- *          measures the tolerance). */
+ *          measures the tolerance).
+ *   X2   = every fp32 operand as the sum of two fp16 numbers (hi + lo), three v_mfma_f32_16x16x32_f16 per product
+ *          (lo*hi + hi*lo + hi*hi) with fp32 accumulation: 22 mantissa bits per operand at 3/16 of the exact-fp32
+ *          MFMA time.  Weights are kept as fp16 pairs of 2^8 w (packs of two planes the library owns), activations
+ *          and gradient tiles enter scaled by a power of two (csrc/engine.h, PrecX2); accumulators, master weights,
+ *          Adam and Polyak are fp32.  A PARITY mode: held to the reference's golden vectors and the CPU oracle at the
+ *          F32 mode's gates (tests/test_gpu_x2.py); measured rms error of a 256-deep dot product 1.45e-7 relative (the
+ *          fp32 MFMA chain: 2.8e-7).  Covers the fused DDPG / TD3 / SAC kernels — DDPG's whole update as ONE launch,
+ *          k_ddpg_update — and the hidden layers of TQC's 512-wide critics; everything else runs exact fp32.  The fp32
+ *          packs of such a learner are not kept current by its updates: every entry point that reads them
+ *          (oprl_mlp_forward / backward / act, the generic launches) rebuilds them first. */
 typedef enum oprl_precision { OPRL_PREC_F32 = 0, OPRL_PREC_BF16 = 1, OPRL_PREC_X2 = 2 } oprl_precision;
 
 /* One MLP (ReLU hidden layers, identity output), parameters laid out exactly
