@@ -112,6 +112,39 @@ def test_block_write_equals_transition_writes_on_device():
         assert t.equal(x, y)
 
 
+def test_eager_flush_equals_batched_writes_on_device():
+    """The trainer loop's add_transition (EpisodicReplayBuffer.eager_flush: one library call per transition —
+    oprl_replay_write_flush — whose ingest kernel reads the pinned staging row and the changed tail of the episode table)
+    against the batched path (rows staged, table uploaded, one scatter at the next sample): identical storage, episode
+    table and draws, across ring wrap-around, with samples taken in between."""
+    import numpy as np
+    import torch as t
+    from oprl_amd.buffers.episodic_buffer import EpisodicReplayBuffer
+
+    def mk(eager):
+        b = EpisodicReplayBuffer(buffer_size_transitions=600, state_dim=5, action_dim=2, max_episode_lenth=50,
+                                 device="cuda", seed=9).create()
+        b.eager_flush = eager
+        return b
+    a, b = mk(True), mk(False)
+    rs = np.random.RandomState(3)
+    for ep in range(30):                       # 12 slots of 50: wraps twice
+        n = int(rs.randint(20, 51))
+        for k in range(n):
+            s, ac, r = rs.standard_normal(5).astype(np.float32), rs.uniform(-1, 1, 2), float(rs.uniform())
+            for buf in (a, b):
+                buf.add_transition(s, ac, r, False, episode_done=(k == n - 1))
+            if (ep * 50 + k) % 37 == 0:        # a draw in the middle of an episode: the table's tail just changed
+                for x, y in zip(a.sample(16), b.sample(16)):
+                    assert t.equal(x, y)
+    assert a.ep_lens == b.ep_lens and len(a) == len(b)
+    inds = np.random.RandomState(2).randint(0, len(a), 256)
+    for x, y in zip(a.sample(256, inds=inds), b.sample(256, inds=inds)):
+        assert t.equal(x, y)
+    for k in ("states", "actions", "rewards", "dones"):
+        assert t.equal(getattr(a, k), getattr(b, k)), k
+
+
 def test_index_map_with_more_episodes_than_the_lds_table_holds():
     """5000 short episodes (> the 2048-entry LDS table: coarse table + global finish, csrc/replay_index.h), ragged
     lengths: injected flat indices must map to the (episode, step) numpy's cumulative-ends rule gives — the gather
