@@ -74,3 +74,34 @@ def test_packed_learners_and_long_runs_stay_clean():
     for a in algos:
         a.learner.check()
         assert bool(t.isfinite(a.critic._oprl_arena).all()) and bool(t.isfinite(a.actor._oprl_arena).all())
+
+
+def test_learners_come_and_go_in_one_process():
+    """Regression (profiles/r03_experiments.txt r03-15): PrecX2 learners keep their packs and workspace in UNCACHED device
+    memory; after such a block had been handed back to the runtime, later learners of the same process — exact-fp32 ones
+    included — lost flag granules and their bounded waits expired.  The blocks now stay in a process-wide cache.  Here:
+    learners of every kind created, stepped and destroyed in turn; no wait may expire, every result stays finite."""
+    import gc
+    import importlib
+    import numpy as np
+    from oprl_amd.logging import NullLogger
+    from tests.test_gpu_callers import _filled_buffer
+    rs = np.random.RandomState(0)
+    for rep in range(4):
+        for name, prec in (("ddpg", "f32"), ("ddpg", "x2"), ("sac", "f32"), ("td3", "x2"), ("sac", "x2")):
+            cls = getattr(importlib.import_module(f"oprl_amd.algos.{name}"), name.upper())
+            t.manual_seed(rep)
+            pair = [cls(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=64, precision=prec).create()
+                    for _ in range(2)]
+            bufs = [_filled_buffer(), _filled_buffer()]
+            for k in range(4):
+                obs = rs.standard_normal(24).astype(np.float32)
+                pair[0].update_from_buffer(bufs[0], 64, act_next=obs)
+                pair[0]._actor_mlp().hip_act(obs)
+                pair[1].update_from_buffer(bufs[1], 64)
+            t.cuda.synchronize()
+            for a in pair:
+                a.learner.check()
+                assert bool(t.isfinite(a.critic._oprl_arena).all()), (rep, name, prec)
+            del pair, bufs
+            gc.collect()
