@@ -3,8 +3,13 @@ import sys
 import time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import ctypes
+import os
 import numpy as np
 import torch as t
+if "--spin-flag" in sys.argv:      # hipDeviceScheduleSpin before the context exists: synchronize busy-waits
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(t.__file__), "lib", "libamdhip64.so"))
+    print("hipSetDeviceFlags(hipDeviceScheduleSpin) ->", hip.hipSetDeviceFlags(ctypes.c_uint(1)), flush=True)
 import bench
 
 dev = t.device("cuda", 0)
