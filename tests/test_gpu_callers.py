@@ -524,6 +524,35 @@ def test_native_dp_single_rank_equals_export_split(precision):
             dist.destroy_process_group()
 
 
+def test_export_split_in_the_x2_mode_matches_the_fp32_split_for_td3():
+    """The data-parallel phases of an x2 TD3 learner (twin critics: un-merged phase 1 + an exporting dW launch; the actor
+    step every other update as the merged phase-2 launch whose tiles leave dW in the gradient arena) against the same
+    split in exact fp32, same rows, same device noise keys: parameters within the parity gate after six updates."""
+    from oprl_amd.algos.td3 import TD3
+    from oprl_amd.logging import NullLogger
+
+    def make(prec):
+        t.manual_seed(0)
+        return TD3(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=64,
+                   export_grads=True, precision=prec, log_every=10 ** 9).create()
+    a32, ax2 = make("f32"), make("x2")
+    buf = _filled_buffer()
+    for k in range(6):
+        buf._sample_counter = k
+        batch = buf.sample(64)
+        for a in (a32, ax2):
+            L = a.learner
+            L.update_phase(0, *batch); L.apply(0, 1.0)
+            L.update_phase(1, *batch); L.apply(1, 1.0)
+    t.cuda.synchronize()
+    for a in (a32, ax2):
+        a.learner.check()
+    for m in ("actor", "critic", "actor_target", "critic_target"):
+        x, y = getattr(ax2, m)._oprl_arena, getattr(a32, m)._oprl_arena
+        dev = float((x - y).abs().max() / y.abs().max())
+        assert dev < 1e-4, (m, dev)
+
+
 @pytest.mark.parametrize("algo,precision", [("ddpg", "f32"), ("td3", "f32"), ("sac", "f32"), ("tqc", "f32"),
                                             ("ddpg", "bf16"), ("tqc", "bf16"), ("sac", "bf16"),
                                             ("ddpg", "x2"), ("td3", "x2"), ("sac", "x2"), ("tqc", "x2")])
