@@ -207,8 +207,8 @@ __device__ __forceinline__ void dw_write_packs(const DwItem& I, const float (*ti
 
 // GATE: 0 = a launch of its own, 1 = the critic's tiles on phase 1's launch (above).  (The actor's tiles on phase 2's
 // launch — GATE 2 of DwGate — exist as PrecX2 tiles only: csrc/dw_tile_x2.h.)
-template <bool XCHG, int GATE = 0, int NW = kDwWaves>
-__device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int bx) {   // bx: the tile (bx of a stand-alone launch)
+template <bool XCHG, int GATE = 0, int NW = kDwWaves, class KAT = DwKArgs>
+__device__ __forceinline__ void dw_adam_body(const KAT& A, float* lds, int bx) {   // bx: the tile (bx of a stand-alone launch)
   constexpr bool GATED = GATE == 1;
   constexpr int TN = kDwTileN, TK = kDwTile, LD = TK + 4;
   using DL = DwLds<NW>;
@@ -221,7 +221,7 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int b
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // this workgroup's layer, straight from the kernel-argument segment (dynamic index into a
   // by-value array: through the segment pointer it is a scalar load, not a scratch copy)
-  const DwKArgs* KA = &A;
+  const KAT* KA = &A;
   // this workgroup's layer: the first four prefix ends in ONE scalar load (a loop with a load and a wait per
   // item cost two dependent round trips before the first row request); entries past the last item hold the
   // launch's total (fill_dw_kargs), so launches of up to four layers never look further, and the workgroup one
@@ -239,14 +239,14 @@ __device__ __forceinline__ void dw_adam_body(const DwKArgs& A, float* lds, int b
                "s"(ad.omtau), "s"(ad.tau), "s"(ad.grad_scale), "s"(ad.step_size_host), "s"(ad.bc2_sqrt_host));
   int item = (bx >= te0 ? 1 : 0) + (bx >= te1 ? 1 : 0) + (bx >= te2 ? 1 : 0) + (bx >= te3 ? 1 : 0);
   if (bx >= te3) {
-    if (bx >= KA->tile_end[kDwMaxItems - 1]) {
+    if (bx >= KA->tile_end[KAT::kItems - 1]) {
       const AlphaJob& J = A.alpha;
       alpha_step_block(J.log_alpha, J.m, J.v, J.logp, J.B, J.target_entropy, J.lr, J.beta1, J.beta2, J.eps, J.bc1,
                        J.bc2_sqrt, nullptr, nullptr, 1.f);
       return;
     }
 #pragma unroll
-    for (int j = 4; j + 1 < kDwMaxItems; ++j) item += bx >= KA->tile_end[j] ? 1 : 0;   // more than four layers (TQC)
+    for (int j = 4; j + 1 < KAT::kItems; ++j) item += bx >= KA->tile_end[j] ? 1 : 0;   // more than four layers (TQC)
   }
   const DwItem I = KA->items[item];
   const int lt = bx - (item > 0 ? KA->tile_end[item - 1] : 0);

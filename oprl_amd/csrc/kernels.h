@@ -249,9 +249,11 @@ struct DwGate {
 constexpr int kDuLd = 8;               // du granules per minibatch row (action_dim <= 8)
 
 constexpr int kDwMaxItems = 20;        // 5 critics x 4 layers (TQC)
-struct DwKArgs {
-  int tile_end[kDwMaxItems];           // exclusive prefix ends, relative to this launch
-  DwItem items[kDwMaxItems];
+template <int NI>
+struct DwKArgsN {
+  static constexpr int kItems = NI;
+  int tile_end[NI];                    // exclusive prefix ends, relative to this launch
+  DwItem items[NI];
   int n_items, B, n_part, dy_tiled;
   AdamScalars ad;
   long long* trace;
@@ -262,6 +264,11 @@ struct DwKArgs {
   AlphaJob alpha;                      // workgroup `tile_end[n_items - 1]` (one past the tiles) runs it
   DwGate gate;                         // dw_adam_body<*, GATED> only
 };
+using DwKArgs = DwKArgsN<kDwMaxItems>;
+// the packed learners' launches (oprl_group_step_n) read N of these from device memory, uploaded per update: a DDPG
+// net's three layers need 1.4 KB of the 5 KB
+constexpr int kDwGroupItems = 4;
+using DwKArgsG = DwKArgsN<kDwGroupItems>;
 
 // the same for the tiles of dw_tile_x2.h (PrecX2 learners: at most four layers per net), a quarter of the bytes: the
 // whole-update launch carries two of them beside its DdpgArgs

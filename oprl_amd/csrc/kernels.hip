@@ -107,11 +107,11 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A, const P
 }
 
 // N learners' dW + Adam launches as one (grid.z = learner; argument blocks in device memory)
-__global__ __launch_bounds__(kDwThreads) void k_dw_adam_group(const DwKArgs* __restrict__ batch) {
-  const DwKArgs& A = batch[blockIdx.z];
-  if ((int)blockIdx.x >= A.tile_end[kDwMaxItems - 1]) return;   // (entries past the last item hold the total)
+__global__ __launch_bounds__(kDwThreads) void k_dw_adam_group(const DwKArgsG* __restrict__ batch) {
+  const DwKArgsG& A = batch[blockIdx.z];
+  if ((int)blockIdx.x >= A.tile_end[kDwGroupItems - 1]) return;   // (entries past the last item hold the total)
   __shared__ __attribute__((aligned(16))) float dw_lds[kDwLdsFloats];
-  dw_adam_body<false>(A, dw_lds, (int)blockIdx.x);
+  dw_adam_body<false, 0, kDwWaves, DwKArgsG>(A, dw_lds, (int)blockIdx.x);
 }
 
 // flat Adam over an arena (data-parallel apply after the all-reduce; alpha-free)
@@ -359,7 +359,16 @@ int fill_dw_kargs(const DwArgs& a, DwKArgs* k, int tile_k) {
   return k->one != nullptr ? total : -1;
 }
 
-hipError_t launch_dw_adam_group(const DwKArgs* batch_dev, int n, int tiles, hipStream_t st) {
+// (the compact argument block of a packed learner's launch: the first kDwGroupItems layers of a full one)
+int compact_dw_kargs(const DwKArgs& k, DwKArgsG* o) {
+  if (k.n_items > kDwGroupItems) return -1;
+  for (int j = 0; j < kDwGroupItems; ++j) { o->tile_end[j] = k.tile_end[j]; o->items[j] = k.items[j]; }
+  o->n_items = k.n_items; o->B = k.B; o->n_part = k.n_part; o->dy_tiled = k.dy_tiled; o->ad = k.ad; o->trace = k.trace;
+  o->use_row_scale = k.use_row_scale; o->one = k.one; o->apply_only = k.apply_only;
+  o->xchg = k.xchg; o->alpha = k.alpha; o->gate = k.gate;
+  return k.tile_end[kDwMaxItems - 1];
+}
+hipError_t launch_dw_adam_group(const DwKArgsG* batch_dev, int n, int tiles, hipStream_t st) {
   hipLaunchKernelGGL(k_dw_adam_group, dim3(tiles, 1, n), dim3(kDwThreads), 0, st, batch_dev);
   return hipGetLastError();
 }

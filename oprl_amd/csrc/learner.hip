@@ -136,7 +136,8 @@ hipError_t launch_ddpg_phase1_group(const DdpgArgs& a0, const DdpgArgs* batch_de
 hipError_t launch_ddpg_phase2_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
 int fill_dw_kargs(const DwArgs& a, DwKArgs* k, int tile_k = 32);
 bool fused_x2_tiles();
-hipError_t launch_dw_adam_group(const DwKArgs* batch_dev, int n, int tiles, hipStream_t st);
+hipError_t launch_dw_adam_group(const DwKArgsG* batch_dev, int n, int tiles, hipStream_t st);
+int compact_dw_kargs(const DwKArgs& k, DwKArgsG* o);
 
 }  // namespace oprl
 
@@ -2472,20 +2473,22 @@ extern "C" int oprl_learner_act_wait(oprl_learner* h, float* out_host, int32_t n
 // each other on the 256 CUs, and a learner's result does not depend on who else is in the launch.
 struct oprl_group {
   std::vector<oprl_learner*> L;
-  DdpgArgs* p_dev[2] = {nullptr, nullptr};     // phase 1 / phase 2 argument blocks [N]
-  DwKArgs* dw_dev[2] = {nullptr, nullptr};     // critic / actor dW + Adam argument blocks [N]
-  char* stage[2] = {nullptr, nullptr};         // pinned host staging (double buffered)
+  // The argument blocks of kGroupChunk updates — per update [N x DdpgArgs phase 1][N x DdpgArgs phase 2][N x DwKArgsG
+  // critic][N x DwKArgsG actor] — are built ahead on the host and go up in ONE copy per chunk (four copies per update
+  // of the 5 KB blocks stood for 56 of 424 us per group update of 32 members).
+  char* dev = nullptr;                         // [kGroupChunk][bytes]
+  char* stage[2] = {nullptr, nullptr};         // pinned host staging (double buffered), the same layout
   hipEvent_t stage_ev[2] = {nullptr, nullptr};
   bool stage_busy[2] = {false, false};
   int cur = 0;
-  size_t bytes = 0;
+  size_t bytes = 0;                            // one update's blocks
   int device = 0;                              // the device the group's buffers (and its members) live on
 };
+constexpr int kGroupChunk = 4;
 
 static void group_free(oprl_group* g) {
+  if (g->dev) (void)hipFree(g->dev);
   for (int i = 0; i < 2; ++i) {
-    if (g->p_dev[i]) (void)hipFree(g->p_dev[i]);
-    if (g->dw_dev[i]) (void)hipFree(g->dw_dev[i]);
     if (g->stage[i]) (void)hipHostFree(g->stage[i]);
     if (g->stage_ev[i]) (void)hipEventDestroy(g->stage_ev[i]);
   }
@@ -2496,20 +2499,39 @@ extern "C" int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group*
   if (!learners || !out || n < 1 || n > 64) { set_err("oprl_group_create: invalid argument"); return OPRL_ERR_INVALID; }
   for (int i = 0; i < n; ++i) {
     oprl_learner* h = learners[i];
-    if (!h || h->cfg.algo != OPRL_DDPG || !h->fused || h->cfg.export_grads || h->bf16 || h->x2 || h->S != learners[0]->S ||
-        h->A != learners[0]->A || h->Bmax != learners[0]->Bmax) {
-      set_err("oprl_group_create: member %d is not a fused fp32 DDPG learner of the group's shape", i);
+    if (!h || h->cfg.algo != OPRL_DDPG || !h->fused || h->cfg.export_grads || h->bf16 != learners[0]->bf16 || h->x2 != learners[0]->x2 ||
+        h->S != learners[0]->S || h->A != learners[0]->A || h->Bmax != learners[0]->Bmax) {
+      set_err("oprl_group_create: member %d is not a fused DDPG learner of the group's shape and precision", i);
+      return OPRL_ERR_INVALID;
+    }
+  }
+  // The members' launch form.  Exact fp32: the generic single-CU-per-slice passes (cluster size 1) — no workgroup of such
+  // a launch waits for another, and 32 members measure 71k updates/s against 58k on clusters of four.  bf16 / x2: the
+  // lean passes on clusters of four (the only form these precisions exist in).  OPRL_AMD_GROUP_NC=4: clusters of four
+  // for exact fp32 as well.
+  int group_nc = 4;
+  {
+    static const int env_nc = [] { const char* e = getenv("OPRL_AMD_GROUP_NC"); return e != nullptr ? atoi(e) : 0; }();
+    oprl_learner* h0 = learners[0];
+    const int keep_ncl = h0->ncl;
+    const bool keep_sc = h0->shared_chip;
+    const int keep_nw = h0->no_wide;
+    h0->ncl = 4; h0->shared_chip = true; h0->no_wide = 1;
+    const bool lean = fused_ddpg_is_lean(ddpg_args(h0, h0->Bmax));
+    h0->ncl = keep_ncl; h0->shared_chip = keep_sc; h0->no_wide = keep_nw;
+    if (!lean || (!h0->bf16 && !h0->x2 && env_nc != 4)) group_nc = 1;
+    if (group_nc == 1 && (h0->bf16 || h0->x2)) {
+      set_err("oprl_group_create: the bf16 / x2 modes need nets the lean passes take (256-wide hidden layers, narrow inputs)");
       return OPRL_ERR_INVALID;
     }
   }
   auto* g = new oprl_group();
   g->L.assign(learners, learners + n);
   (void)hipGetDevice(&g->device);
-  g->bytes = (size_t)n * (2 * sizeof(DdpgArgs) + 2 * sizeof(DwKArgs));
-  bool ok = true;
+  g->bytes = (size_t)n * (2 * sizeof(DdpgArgs) + 2 * sizeof(DwKArgsG));
+  bool ok = hipMalloc((void**)&g->dev, g->bytes * kGroupChunk) == hipSuccess;
   for (int i = 0; i < 2 && ok; ++i) {
-    ok = hipMalloc(&g->p_dev[i], sizeof(DdpgArgs) * n) == hipSuccess && hipMalloc(&g->dw_dev[i], sizeof(DwKArgs) * n) == hipSuccess &&
-         hipHostMalloc((void**)&g->stage[i], g->bytes) == hipSuccess &&
+    ok = hipHostMalloc((void**)&g->stage[i], g->bytes * kGroupChunk) == hipSuccess &&
          hipEventCreateWithFlags(&g->stage_ev[i], hipEventDisableTiming) == hipSuccess;
   }
   if (!ok) {      // (nothing is kept of a failed create: the partial allocations go, the members stay as they were)
@@ -2517,7 +2539,8 @@ extern "C" int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group*
     set_err("oprl_group_create: allocation failed");
     return OPRL_ERR_NOMEM;
   }
-  for (oprl_learner* h : g->L) h->ncl = 1;       // single-CU slices (see above); a solo run for comparison sets the same
+  // (a solo run for comparison: oprl_learner_set_cluster(h, 4) — the un-merged lean launches — or (h, 1))
+  for (oprl_learner* h : g->L) { h->ncl = group_nc; h->shared_chip = true; h->no_wide = 1; }
   *out = g;
   return OPRL_OK;
 }
@@ -2574,53 +2597,63 @@ extern "C" int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, 
     h->staged_ready = false;
     h->last_B = B;
   }
-  for (int k = 0; k < K; ++k) {
+  static_assert(sizeof(DdpgArgs) % 8 == 0 && sizeof(DwKArgsG) % 8 == 0, "the blocks of an update lie back to back");
+  for (int k0 = 0; k0 < K; k0 += kGroupChunk) {
+    const int m = K - k0 < kGroupChunk ? K - k0 : kGroupChunk;
     const int c = g->cur;
     if (g->stage_busy[c]) { HIPC(hipEventSynchronize(g->stage_ev[c])); g->stage_busy[c] = false; }
-    DdpgArgs* p1 = reinterpret_cast<DdpgArgs*>(g->stage[c]);
-    DdpgArgs* p2 = p1 + n;
-    DwKArgs* dc = reinterpret_cast<DwKArgs*>(p2 + n);
-    DwKArgs* da = dc + n;
     int tiles_c = 0, tiles_a = 0;
-    for (int l = 0; l < n; ++l) {
-      oprl_learner* h = g->L[l];
-      const oprl_learner_config& cf = h->cfg;
-      h->src.counter = (unsigned long long)h->update_count;
-      h->next_src.counter = h->src.counter + 1;
-      h->src.gather = h->staged_ready ? 0 : 1;
-      const int prefetch = (k + 1 < K) ? 1 : 0;
-      h->epoch += 1;
-      if (h->epoch == 0) { h->epoch = 1; HIPC(hipMemsetAsync(h->y_granules, 0, ((size_t)3 * h->Bmax + 256) * sizeof(unsigned long long), st)); }
-      p1[l] = ddpg_args(h, B);
-      RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &p1[l].cluster_tag));
-      p2[l] = ddpg_args(h, B);
-      p2[l].cluster_tag = p1[l].cluster_tag;
-      p2[l].prefetch_next = prefetch;
-      h->staged_ready = prefetch != 0;
-      h->opt_step_critic += 1;
-      h->opt_step_actor += 1;
-      DwArgs dw;
-      dw.items = h->items_host.data(); dw.n_items = h->n_items_critic; dw.total_tiles = h->tiles_critic;
-      dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.use_row_scale = 0; dw.apply_only = 0;
-      dw.ad = adam_scalars(h, cf.hp.lr_critic, h->opt_step_critic, true, 1.0f);
-      tiles_c = fill_dw_kargs(dw, &dc[l]);
-      dw.items = h->items_host.data() + h->n_items_critic; dw.n_items = h->n_items_actor; dw.total_tiles = h->tiles_actor;
-      dw.ad = adam_scalars(h, cf.hp.lr_actor, h->opt_step_actor, cf.actor.theta_target != nullptr, 1.0f);
-      tiles_a = fill_dw_kargs(dw, &da[l]);
-      if (tiles_c < 0 || tiles_a < 0 || p1[l].nc != 1) { set_err("oprl_group_step_n: internal: bad launch arguments"); return OPRL_ERR_INVALID; }
-      h->update_count += 1;
+    DdpgArgs first[kGroupChunk][2];           // member 0's blocks of each update (for the grids)
+    for (int j = 0; j < m; ++j) {
+      const int k = k0 + j;
+      DdpgArgs* p1 = reinterpret_cast<DdpgArgs*>(g->stage[c] + (size_t)j * g->bytes);
+      DdpgArgs* p2 = p1 + n;
+      DwKArgsG* dc = reinterpret_cast<DwKArgsG*>(p2 + n);
+      DwKArgsG* da = dc + n;
+      for (int l = 0; l < n; ++l) {
+        oprl_learner* h = g->L[l];
+        const oprl_learner_config& cf = h->cfg;
+        h->src.counter = (unsigned long long)h->update_count;
+        h->next_src.counter = h->src.counter + 1;
+        h->src.gather = h->staged_ready ? 0 : 1;
+        const int prefetch = (k + 1 < K) ? 1 : 0;
+        h->epoch += 1;
+        if (h->epoch == 0) { h->epoch = 1; HIPC(hipMemsetAsync(h->y_granules, 0, ((size_t)3 * h->Bmax + 256) * sizeof(unsigned long long), st)); }
+        p1[l] = ddpg_args(h, B);
+        RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &p1[l].cluster_tag));
+        p2[l] = ddpg_args(h, B);
+        RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &p2[l].cluster_tag));   // (a launch, a tag)
+        p2[l].prefetch_next = prefetch;
+        h->staged_ready = prefetch != 0;
+        DwKArgs kd;
+        DwArgs dw = dw_build(h, true, B, true, false);        // (as the un-merged launches of a solo learner)
+        const int tc = fill_dw_kargs(dw, &kd) < 0 ? -1 : compact_dw_kargs(kd, &dc[l]);
+        dw = dw_build(h, false, B, cf.actor.theta_target != nullptr, false);
+        const int ta = fill_dw_kargs(dw, &kd) < 0 ? -1 : compact_dw_kargs(kd, &da[l]);
+        if (l == 0 && j == 0) { tiles_c = tc; tiles_a = ta; }
+        if (tc < 0 || ta < 0 || tc != tiles_c || ta != tiles_a || p1[l].nc != p1[0].nc || p1[l].merged || p1[l].wide || p1[l].whole) {
+          set_err("oprl_group_step_n: internal: bad launch arguments");
+          return OPRL_ERR_INVALID;
+        }
+        h->update_count += 1;
+      }
+      first[j][0] = p1[0];
+      first[j][1] = p2[0];
     }
-    HIPC(hipMemcpyAsync(g->p_dev[0], p1, sizeof(DdpgArgs) * n, hipMemcpyHostToDevice, st));
-    HIPC(hipMemcpyAsync(g->p_dev[1], p2, sizeof(DdpgArgs) * n, hipMemcpyHostToDevice, st));
-    HIPC(hipMemcpyAsync(g->dw_dev[0], dc, sizeof(DwKArgs) * n, hipMemcpyHostToDevice, st));
-    HIPC(hipMemcpyAsync(g->dw_dev[1], da, sizeof(DwKArgs) * n, hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(g->dev, g->stage[c], g->bytes * m, hipMemcpyHostToDevice, st));
     HIPC(hipEventRecord(g->stage_ev[c], st));
     g->stage_busy[c] = true;
     g->cur ^= 1;
-    HIPC(launch_ddpg_phase1_group(p1[0], g->p_dev[0], n, st));
-    HIPC(launch_dw_adam_group(g->dw_dev[0], n, tiles_c, st));
-    HIPC(launch_ddpg_phase2_group(p2[0], g->p_dev[1], n, st));
-    HIPC(launch_dw_adam_group(g->dw_dev[1], n, tiles_a, st));
+    for (int j = 0; j < m; ++j) {
+      const DdpgArgs* p1 = reinterpret_cast<const DdpgArgs*>(g->dev + (size_t)j * g->bytes);
+      const DdpgArgs* p2 = p1 + n;
+      const DwKArgsG* dc = reinterpret_cast<const DwKArgsG*>(p2 + n);
+      const DwKArgsG* da = dc + n;
+      HIPC(launch_ddpg_phase1_group(first[j][0], p1, n, st));
+      HIPC(launch_dw_adam_group(dc, n, tiles_c, st));
+      HIPC(launch_ddpg_phase2_group(first[j][1], p2, n, st));
+      HIPC(launch_dw_adam_group(da, n, tiles_a, st));
+    }
   }
   for (oprl_learner* h : g->L) { h->src.gather = 0; h->prefetch_next = 0; h->staged_ready = false; }
   return OPRL_OK;

@@ -672,7 +672,8 @@ def test_device_noise_stream_is_standard_normal_and_keyed_by_seed_rank_counter()
     assert abs(np.corrcoef(y.ravel(), z.ravel())[0, 1]) < 4 / np.sqrt(n)
 
 
-def test_packed_learner_group_members_against_the_cpu_oracle():
+@pytest.mark.parametrize("precision", ["f32", "x2"])
+def test_packed_learner_group_members_against_the_cpu_oracle(precision):
     """N3 against the ORACLE (not only against the same kernels run solo): three members with the oracle's
     fixture weights, stepped as a group over the replay; the oracle's DDPG (oracle/oprl_oracle.py, pinned to the
     reference by tests/test_oracle_golden.py) is fed the same rows — the buffer's own Philox draw for each member's
@@ -690,7 +691,8 @@ def test_packed_learner_group_members_against_the_cpu_oracle():
     nets = [(fx.make_net(300 + 2 * i, fx.actor_dims(S, A)), fx.make_net(301 + 2 * i, fx.critic_dims(S, A))) for i in range(3)]
     members = []
     for actor, critic in nets:
-        m = DDPG(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=S, action_dim=A, device="cuda", max_batch=B).create()
+        m = DDPG(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=S, action_dim=A, device="cuda", max_batch=B,
+                 precision=precision).create()
         for mod, p in ((m.actor, actor), (m.actor_target, actor), (m.critic, critic), (m.critic_target, critic)):
             ha.load_params(mod, p)
         members.append(m)
@@ -714,10 +716,11 @@ def test_packed_learner_group_members_against_the_cpu_oracle():
     g.close()
 
 
-def test_packed_learner_group_equals_solo_learners():
+@pytest.mark.parametrize("precision", ["f32", "x2", "bf16"])
+def test_packed_learner_group_equals_solo_learners(precision):
     """N3: three independent DDPG learners stepped as a group (four launches per update for all of them) end
-    with exactly the parameters, targets and Adam moments each of them reaches alone at cluster size 1 — and
-    remain ordinary learners afterwards."""
+    with exactly the parameters, targets and Adam moments each of them reaches alone with the same launch form
+    (exact fp32: cluster size 1; x2 / bf16: the un-merged lean launches on clusters of four, set_cluster(h, 4)) — and remain ordinary learners afterwards."""
     from oprl_amd.group import LearnerGroup
     B, K = 64, 7
     buf = _filled_buffer()
@@ -726,14 +729,15 @@ def test_packed_learner_group_equals_solo_learners():
         t.manual_seed(40 + i)
         from oprl_amd.algos.ddpg import DDPG
         from oprl_amd.logging import NullLogger
-        return DDPG(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=B).create()
+        return DDPG(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=B,
+                    precision=precision).create()
     group_members, solo = [member(i) for i in range(3)], [member(i) for i in range(3)]
     seeds = [11, 12, 13]
     g = LearnerGroup(group_members)
     g.step_n(buf.handle, K, B, seeds)
     g.step_n(buf.handle, 2, B, seeds)             # a second call continues the streams
     for a, s in zip(solo, seeds):
-        assert a.learner.lib.oprl_learner_set_cluster(a.learner.handle, 1) == 0
+        assert a.learner.lib.oprl_learner_set_cluster(a.learner.handle, 1 if precision == "f32" else 4) == 0
         a.learner.step_n(buf.handle, K, B, seed=s)
         a.learner.step_n(buf.handle, 2, B, seed=s)
     t.cuda.synchronize()
