@@ -346,7 +346,7 @@ def packed_group(n, dev, local_rank, steps):
     g.close()
     return dict(learners=n, value=round(n * steps / dt, 1), unit="steps/s (aggregate)",
                 us_per_group_update=round(dt / steps * 1e6, 1), steps_each=steps,
-                path="oprl_group_step_n: 4 launches per update for the whole group (grid.z = learner), fp32, cluster size 1",
+                path="oprl_group_step_n: 4 launches per update for the whole group (grid.z = learner; one argument copy per 4 updates), exact fp32, cluster size 1",
                 verified=dict(all_finite=finite, member0_equals_solo_run_at_cluster_1=same))
 
 
