@@ -176,13 +176,17 @@ int oprl_learner_step_act(oprl_learner* h, oprl_replay* replay, int32_t B, uint6
 int oprl_learner_act_wait(oprl_learner* h, float* out_host, int32_t n_out, int64_t timeout_us);
 
 /* ---- packed learners: the reference's --seeds fan-out (runners/train.py:24-50) on ONE GPU ----------------
- * A group steps N independent fused DDPG learners of one shape and one precision (own weights, own sampler keys
+ * A group steps N independent fused DDPG, TD3 or SAC learners of one algorithm, shape and precision (own weights, own sampler keys
  * seeds[i], one shared HBM replay) with FOUR launches per update for all of them (grid.z = learner; the
  * argument blocks of four updates travel to device memory in one copy).  OPRL_PREC_F32 members run on
  * single-CU slices (oprl_learner_set_cluster(h, 1) is applied to them), OPRL_PREC_X2 / OPRL_PREC_BF16 members on
  * clusters of four ((h, 4): the form those precisions exist in): a member's result is bit-identical to the same
- * learner stepped alone with that cluster size, whoever else is in the group.  The members stay ordinary
- * learners (update / step_n / checkpoints) between group calls. */
+ * learner stepped alone with that cluster size, whoever else is in the group.  TD3 / SAC members (fused in the lean
+ * form only): clusters of four in every precision, the twin critics back to back (OPRL_AMD_NO_TWIN_SPLIT=1 /
+ * OPRL_AMD_NO_P2_PAIR=1 give a solo learner the same form); TD3's delayed actor step is taken by all members at
+ * once — members whose update counts differ modulo policy_freq are refused (OPRL_ERR_STATE); SAC's temperature
+ * step rides on the actor's dW launch.  The members stay ordinary learners (update / step_n / checkpoints)
+ * between group calls. */
 typedef struct oprl_group oprl_group;
 int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group** out);
 int oprl_group_destroy(oprl_group* g);

@@ -589,15 +589,17 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1_dw(const DdpgArgs A, c
 
 // N independent learners in ONE launch (grid.z = learner): the argument blocks live in device memory (N x 1.7 KB
 // does not fit the kernel-argument segment), every field read is a scalar load through one uniform pointer.
-template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32>
+// (SINGLE: DDPG members — the twin-critic paths compiled out; TD3 / SAC members: the lean passes, SINGLE = false)
+template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32, bool SINGLE = true>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase1_group(const DdpgArgs* __restrict__ batch) {
-  // (DDPG only: launch_ddpg_phase1_group.)  Generic passes: grid (slices, 1, 3 roles x n learners), ROLE-major — every
+  // Generic passes (DDPG members in exact fp32): grid (slices, 1, 3 roles x n learners), ROLE-major — every
   // learner's role A, then every learner's role B ...: a role B workgroup finds its TD target written long ago instead
   // of spinning for it on a compute unit beside role A's (dispatch is in block order): 32 members 71.6k -> 75.2k
   // updates/s.  Lean passes: grid (slices, 3 x 4, n), learner-major (role-major measured 2-3 % slower there).
   if constexpr (LEAN) {
-    (void)ddpg_phase1_body<WIDTH, LEAN, SAC, P, false, false, DwKArgs, true>(batch[blockIdx.z]);
+    (void)ddpg_phase1_body<WIDTH, LEAN, SAC, P, false, false, DwKArgs, SINGLE>(batch[blockIdx.z]);
   } else {
+    static_assert(LEAN || SINGLE, "the generic passes: DDPG members only");
     const int n = (int)gridDim.z / 3, role = (int)blockIdx.z / n, l = (int)blockIdx.z - role * n;
     (void)ddpg_phase1_body<WIDTH, LEAN, SAC, P, false, false, DwKArgs, true>(batch[l], nullptr, role * (int)gridDim.y + (int)blockIdx.y);
   }
@@ -1190,6 +1192,15 @@ hipError_t init_fused_attrs() {
                       reinterpret_cast<const void*>(&k_ddpg_phase2_group<256, true, false, PrecBF16>),
                       reinterpret_cast<const void*>(&k_ddpg_phase1_group<256, true, false, PrecX2>),
                       reinterpret_cast<const void*>(&k_ddpg_phase2_group<256, true, false, PrecX2>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_group<256, true, false, PrecF32, false>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_group<256, true, false, PrecBF16, false>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_group<256, true, false, PrecX2, false>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_group<256, true, true, PrecF32, false>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_group<256, true, true, PrecBF16, false>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_group<256, true, true, PrecX2, false>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2_group<256, true, true, PrecF32>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2_group<256, true, true, PrecBF16>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase2_group<256, true, true, PrecX2>),
                       reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, false, PrecF32, true>),
                       reinterpret_cast<const void*>(&k_ddpg_phase2<256, true, false, PrecF32, true>),
                       reinterpret_cast<const void*>(&k_ddpg_phase1<256, true, false, PrecX2, true>),
@@ -1215,30 +1226,46 @@ hipError_t init_fused_attrs() {
 //           out its workgroups in order: at most two clusters per XCD are partly resident at any time, every other
 //           resident workgroup belongs to a complete cluster and retires — any number of learners may queue up.
 bool fused_ddpg_is_lean(const DdpgArgs& a);
+// (TD3 / SAC members: lean passes only, the twin critics' co-residency forms — twin_split, p2_pair — off)
+template <class P>
+static void launch_p1_group_lean(const DdpgArgs& a0, dim3 grid, const DdpgArgs* batch_dev, hipStream_t st) {
+  const dim3 blk(kThreads);
+  const size_t lds = fused_ddpg_lds_bytes();
+  if (a0.sac) hipLaunchKernelGGL((k_ddpg_phase1_group<256, true, true, P, false>), grid, blk, lds, st, batch_dev);
+  else if (a0.n_critics == 2) hipLaunchKernelGGL((k_ddpg_phase1_group<256, true, false, P, false>), grid, blk, lds, st, batch_dev);
+  else hipLaunchKernelGGL((k_ddpg_phase1_group<256, true, false, P, true>), grid, blk, lds, st, batch_dev);
+}
+template <class P>
+static void launch_p2_group_lean(const DdpgArgs& a0, dim3 grid, const DdpgArgs* batch_dev, hipStream_t st) {
+  const dim3 blk(kThreads);
+  const size_t lds = fused_ddpg_lds_bytes();
+  if (a0.sac) hipLaunchKernelGGL((k_ddpg_phase2_group<256, true, true, P>), grid, blk, lds, st, batch_dev);
+  else hipLaunchKernelGGL((k_ddpg_phase2_group<256, true, false, P>), grid, blk, lds, st, batch_dev);
+}
 hipError_t launch_ddpg_phase1_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st) {
-  if (a0.sac || a0.n_critics != 1 || a0.merged || a0.wide || a0.whole) return hipErrorInvalidValue;
-  dim3 grid((a0.B + kR - 1) / kR, 3 * a0.nc, n);
+  if (a0.merged || a0.wide || a0.whole || a0.twin_split || a0.prefetch_p1 || (a0.sac && a0.n_critics != 2)) return hipErrorInvalidValue;
+  dim3 grid((a0.B + kR - 1) / kR, (2 + a0.n_critics) * a0.nc, n);
   if (a0.nc == 4 && fused_ddpg_is_lean(a0)) {
-    if (a0.x2) hipLaunchKernelGGL((k_ddpg_phase1_group<256, true, false, PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, batch_dev);
-    else if (a0.bf16) hipLaunchKernelGGL((k_ddpg_phase1_group<256, true, false, PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, batch_dev);
-    else hipLaunchKernelGGL((k_ddpg_phase1_group<256, true, false, PrecF32>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, batch_dev);
+    if (a0.x2) launch_p1_group_lean<PrecX2>(a0, grid, batch_dev, st);
+    else if (a0.bf16) launch_p1_group_lean<PrecBF16>(a0, grid, batch_dev, st);
+    else launch_p1_group_lean<PrecF32>(a0, grid, batch_dev, st);
     return hipGetLastError();
   }
-  if (a0.nc != 1 || a0.bf16 || a0.x2) return hipErrorInvalidValue;
+  if (a0.nc != 1 || a0.bf16 || a0.x2 || a0.sac || a0.n_critics != 1) return hipErrorInvalidValue;
   grid = dim3((a0.B + kR - 1) / kR, 1, 3 * n);      // role-major (k_ddpg_phase1_group)
   hipLaunchKernelGGL((k_ddpg_phase1_group<256, false, false>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, batch_dev);
   return hipGetLastError();
 }
 hipError_t launch_ddpg_phase2_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st) {
-  if (a0.sac || a0.n_critics != 1 || a0.merged || a0.wide || a0.whole) return hipErrorInvalidValue;
+  if (a0.merged || a0.wide || a0.whole || a0.p2_pair || (a0.sac && a0.n_critics != 2)) return hipErrorInvalidValue;
   const dim3 grid((a0.B + kR - 1) / kR, a0.nc + (a0.prefetch_next ? 1 : 0), n);
   if (a0.nc == 4 && fused_ddpg_is_lean(a0)) {
-    if (a0.x2) hipLaunchKernelGGL((k_ddpg_phase2_group<256, true, false, PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, batch_dev);
-    else if (a0.bf16) hipLaunchKernelGGL((k_ddpg_phase2_group<256, true, false, PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, batch_dev);
-    else hipLaunchKernelGGL((k_ddpg_phase2_group<256, true, false, PrecF32>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, batch_dev);
+    if (a0.x2) launch_p2_group_lean<PrecX2>(a0, grid, batch_dev, st);
+    else if (a0.bf16) launch_p2_group_lean<PrecBF16>(a0, grid, batch_dev, st);
+    else launch_p2_group_lean<PrecF32>(a0, grid, batch_dev, st);
     return hipGetLastError();
   }
-  if (a0.nc != 1 || a0.bf16 || a0.x2) return hipErrorInvalidValue;
+  if (a0.nc != 1 || a0.bf16 || a0.x2 || a0.sac || a0.n_critics != 1) return hipErrorInvalidValue;
   hipLaunchKernelGGL((k_ddpg_phase2_group<256, false, false>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, batch_dev);
   return hipGetLastError();
 }

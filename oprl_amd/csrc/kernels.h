@@ -267,8 +267,10 @@ struct DwKArgsN {
 using DwKArgs = DwKArgsN<kDwMaxItems>;
 // the packed learners' launches (oprl_group_step_n) read N of these from device memory, uploaded per update: a DDPG
 // net's three layers need 1.4 KB of the 5 KB
-constexpr int kDwGroupItems = 4;
+constexpr int kDwGroupItems = 4;        // one net of up to four layers
 using DwKArgsG = DwKArgsN<kDwGroupItems>;
+constexpr int kDwGroupItems2 = 8;       // twin critics (TD3 / SAC members)
+using DwKArgsG2 = DwKArgsN<kDwGroupItems2>;
 
 // the same for the tiles of dw_tile_x2.h (PrecX2 learners: at most four layers per net), a quarter of the bytes: the
 // whole-update launch carries two of them beside its DdpgArgs

@@ -106,12 +106,16 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A, const P
   dw_adam_body<XCHG>(*(const DwKArgs*)__builtin_amdgcn_kernarg_segment_ptr(), dw_lds, (int)blockIdx.x);
 }
 
-// N learners' dW + Adam launches as one (grid.z = learner; argument blocks in device memory)
-__global__ __launch_bounds__(kDwThreads) void k_dw_adam_group(const DwKArgsG* __restrict__ batch) {
-  const DwKArgsG& A = batch[blockIdx.z];
-  if ((int)blockIdx.x >= A.tile_end[kDwGroupItems - 1]) return;   // (entries past the last item hold the total)
+// N learners' dW + Adam launches as one (grid.z = learner; argument blocks in device memory; NI = 4: one net of up
+// to four layers (DDPG's critic, every actor), 8: twin critics).  grid.x = the tiles + 1: the last workgroup is the
+// temperature step of a SAC member (AlphaJob), if it has one.
+template <int NI>
+__global__ __launch_bounds__(kDwThreads) void k_dw_adam_group(const DwKArgsN<NI>* __restrict__ batch) {
+  const DwKArgsN<NI>& A = batch[blockIdx.z];
+  const int total = A.tile_end[NI - 1];                          // (entries past the last item hold the total)
+  if ((int)blockIdx.x > total || ((int)blockIdx.x == total && A.alpha.log_alpha == nullptr)) return;
   __shared__ __attribute__((aligned(16))) float dw_lds[kDwLdsFloats];
-  dw_adam_body<false, 0, kDwWaves, DwKArgsG>(A, dw_lds, (int)blockIdx.x);
+  dw_adam_body<false, 0, kDwWaves, DwKArgsN<NI>>(A, dw_lds, (int)blockIdx.x);
 }
 
 // flat Adam over an arena (data-parallel apply after the all-reduce; alpha-free)
@@ -353,23 +357,33 @@ int fill_dw_kargs(const DwArgs& a, DwKArgs* k, int tile_k) {
   k->n_items = a.n_items; k->B = a.B; k->n_part = a.n_part; k->dy_tiled = a.dy_tiled; k->ad = a.ad; k->trace = a.trace;
   k->use_row_scale = a.use_row_scale; k->one = dw_one_dev();
   k->apply_only = a.apply_only;
-  k->alpha = AlphaJob{};
+  k->alpha = a.alpha;                  // (a temperature step riding on the launch: the workgroup one past the tiles)
   k->gate = DwGate{};
   memset(&k->xchg, 0, sizeof k->xchg);
   return k->one != nullptr ? total : -1;
 }
 
-// (the compact argument block of a packed learner's launch: the first kDwGroupItems layers of a full one)
-int compact_dw_kargs(const DwKArgs& k, DwKArgsG* o) {
-  if (k.n_items > kDwGroupItems) return -1;
-  for (int j = 0; j < kDwGroupItems; ++j) { o->tile_end[j] = k.tile_end[j]; o->items[j] = k.items[j]; }
+// (the compact argument block of a packed learner's launch: the first NI layers of a full one)
+template <int NI>
+static int compact_dw_kargs_n(const DwKArgs& k, DwKArgsN<NI>* o) {
+  if (k.n_items > NI) return -1;
+  for (int j = 0; j < NI; ++j) { o->tile_end[j] = k.tile_end[j]; o->items[j] = k.items[j]; }
   o->n_items = k.n_items; o->B = k.B; o->n_part = k.n_part; o->dy_tiled = k.dy_tiled; o->ad = k.ad; o->trace = k.trace;
   o->use_row_scale = k.use_row_scale; o->one = k.one; o->apply_only = k.apply_only;
   o->xchg = k.xchg; o->alpha = k.alpha; o->gate = k.gate;
   return k.tile_end[kDwMaxItems - 1];
 }
-hipError_t launch_dw_adam_group(const DwKArgsG* batch_dev, int n, int tiles, hipStream_t st) {
-  hipLaunchKernelGGL(k_dw_adam_group, dim3(tiles, 1, n), dim3(kDwThreads), 0, st, batch_dev);
+size_t dw_group_block_bytes(int ni) { return ni == kDwGroupItems ? sizeof(DwKArgsG) : sizeof(DwKArgsG2); }
+int compact_dw_kargs(const DwKArgs& k, void* o, int ni) {
+  if (ni == kDwGroupItems) return compact_dw_kargs_n(k, (DwKArgsG*)o);
+  if (ni == kDwGroupItems2) return compact_dw_kargs_n(k, (DwKArgsG2*)o);
+  return -1;
+}
+hipError_t launch_dw_adam_group(const void* batch_dev, int ni, int n, int tiles, hipStream_t st) {
+  const dim3 grid(tiles + 1, 1, n);
+  if (ni == kDwGroupItems) hipLaunchKernelGGL(k_dw_adam_group<kDwGroupItems>, grid, dim3(kDwThreads), 0, st, (const DwKArgsG*)batch_dev);
+  else if (ni == kDwGroupItems2) hipLaunchKernelGGL(k_dw_adam_group<kDwGroupItems2>, grid, dim3(kDwThreads), 0, st, (const DwKArgsG2*)batch_dev);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

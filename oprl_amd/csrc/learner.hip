@@ -136,8 +136,9 @@ hipError_t launch_ddpg_phase1_group(const DdpgArgs& a0, const DdpgArgs* batch_de
 hipError_t launch_ddpg_phase2_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
 int fill_dw_kargs(const DwArgs& a, DwKArgs* k, int tile_k = 32);
 bool fused_x2_tiles();
-hipError_t launch_dw_adam_group(const DwKArgsG* batch_dev, int n, int tiles, hipStream_t st);
-int compact_dw_kargs(const DwKArgs& k, DwKArgsG* o);
+hipError_t launch_dw_adam_group(const void* batch_dev, int ni, int n, int tiles, hipStream_t st);
+int compact_dw_kargs(const DwKArgs& k, void* o, int ni);
+size_t dw_group_block_bytes(int ni);
 
 }  // namespace oprl
 
@@ -2473,8 +2474,8 @@ extern "C" int oprl_learner_act_wait(oprl_learner* h, float* out_host, int32_t n
 // each other on the 256 CUs, and a learner's result does not depend on who else is in the launch.
 struct oprl_group {
   std::vector<oprl_learner*> L;
-  // The argument blocks of kGroupChunk updates — per update [N x DdpgArgs phase 1][N x DdpgArgs phase 2][N x DwKArgsG
-  // critic][N x DwKArgsG actor] — are built ahead on the host and go up in ONE copy per chunk (four copies per update
+  // The argument blocks of kGroupChunk updates — per update [N x DdpgArgs phase 1][N x DdpgArgs phase 2][N x DwKArgsN<ni_c>
+  // critic(s)][N x DwKArgsG actor] — are built ahead on the host and go up in ONE copy per chunk (four copies per update
   // of the 5 KB blocks stood for 56 of 424 us per group update of 32 members).
   char* dev = nullptr;                         // [kGroupChunk][bytes]
   char* stage[2] = {nullptr, nullptr};         // pinned host staging (double buffered), the same layout
@@ -2482,6 +2483,7 @@ struct oprl_group {
   bool stage_busy[2] = {false, false};
   int cur = 0;
   size_t bytes = 0;                            // one update's blocks
+  int ni_c = kDwGroupItems;                    // layers per critic-step dW block (twin critics: kDwGroupItems2)
   int device = 0;                              // the device the group's buffers (and its members) live on
 };
 constexpr int kGroupChunk = 4;
@@ -2497,18 +2499,21 @@ static void group_free(oprl_group* g) {
 
 extern "C" int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group** out) {
   if (!learners || !out || n < 1 || n > 64) { set_err("oprl_group_create: invalid argument"); return OPRL_ERR_INVALID; }
+  const int algo0 = learners[0] ? learners[0]->cfg.algo : -1;
   for (int i = 0; i < n; ++i) {
     oprl_learner* h = learners[i];
-    if (!h || h->cfg.algo != OPRL_DDPG || !h->fused || h->cfg.export_grads || h->bf16 != learners[0]->bf16 || h->x2 != learners[0]->x2 ||
-        h->S != learners[0]->S || h->A != learners[0]->A || h->Bmax != learners[0]->Bmax) {
-      set_err("oprl_group_create: member %d is not a fused DDPG learner of the group's shape and precision", i);
+    if (!h || (algo0 != OPRL_DDPG && algo0 != OPRL_TD3 && algo0 != OPRL_SAC) || h->cfg.algo != algo0 || !h->fused || h->cfg.export_grads ||
+        h->bf16 != learners[0]->bf16 || h->x2 != learners[0]->x2 || h->S != learners[0]->S || h->A != learners[0]->A ||
+        h->Bmax != learners[0]->Bmax || h->cfg.hp.policy_freq != learners[0]->cfg.hp.policy_freq ||
+        (alpha_ptr(h) != nullptr) != (alpha_ptr(learners[0]) != nullptr)) {
+      set_err("oprl_group_create: member %d is not a fused DDPG / TD3 / SAC learner of the group's algorithm, shape and precision", i);
       return OPRL_ERR_INVALID;
     }
   }
   // The members' launch form.  Exact fp32: the generic single-CU-per-slice passes (cluster size 1) — no workgroup of such
   // a launch waits for another, and 32 members measure 71k updates/s against 58k on clusters of four.  bf16 / x2: the
   // lean passes on clusters of four (the only form these precisions exist in).  OPRL_AMD_GROUP_NC=4: clusters of four
-  // for exact fp32 as well.
+  // for exact fp32 as well.  TD3 / SAC members (fused in the lean form only): clusters of four in every precision.
   int group_nc = 4;
   {
     static const int env_nc = [] { const char* e = getenv("OPRL_AMD_GROUP_NC"); return e != nullptr ? atoi(e) : 0; }();
@@ -2519,16 +2524,17 @@ extern "C" int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group*
     h0->ncl = 4; h0->shared_chip = true; h0->no_wide = 1;
     const bool lean = fused_ddpg_is_lean(ddpg_args(h0, h0->Bmax));
     h0->ncl = keep_ncl; h0->shared_chip = keep_sc; h0->no_wide = keep_nw;
-    if (!lean || (!h0->bf16 && !h0->x2 && env_nc != 4)) group_nc = 1;
-    if (group_nc == 1 && (h0->bf16 || h0->x2)) {
-      set_err("oprl_group_create: the bf16 / x2 modes need nets the lean passes take (256-wide hidden layers, narrow inputs)");
+    if (!lean || (algo0 == OPRL_DDPG && !h0->bf16 && !h0->x2 && env_nc != 4)) group_nc = 1;
+    if (group_nc == 1 && (h0->bf16 || h0->x2 || algo0 != OPRL_DDPG)) {
+      set_err("oprl_group_create: TD3 / SAC members and the bf16 / x2 modes need nets the lean passes take (256-wide hidden layers, narrow inputs)");
       return OPRL_ERR_INVALID;
     }
   }
   auto* g = new oprl_group();
   g->L.assign(learners, learners + n);
   (void)hipGetDevice(&g->device);
-  g->bytes = (size_t)n * (2 * sizeof(DdpgArgs) + 2 * sizeof(DwKArgsG));
+  g->ni_c = learners[0]->nc == 2 ? kDwGroupItems2 : kDwGroupItems;
+  g->bytes = (size_t)n * (2 * sizeof(DdpgArgs) + dw_group_block_bytes(g->ni_c) + dw_group_block_bytes(kDwGroupItems));
   bool ok = hipMalloc((void**)&g->dev, g->bytes * kGroupChunk) == hipSuccess;
   for (int i = 0; i < 2 && ok; ++i) {
     ok = hipHostMalloc((void**)&g->stage[i], g->bytes * kGroupChunk) == hipSuccess &&
@@ -2540,7 +2546,8 @@ extern "C" int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group*
     return OPRL_ERR_NOMEM;
   }
   // (a solo run for comparison: oprl_learner_set_cluster(h, 4) — the un-merged lean launches — or (h, 1))
-  for (oprl_learner* h : g->L) { h->ncl = group_nc; h->shared_chip = true; h->no_wide = 1; }
+  // (the twin critics' side-by-side forms want all of a slice's clusters resident at once: not in a queue of members)
+  for (oprl_learner* h : g->L) { h->ncl = group_nc; h->shared_chip = true; h->no_wide = 1; h->no_twin_split = true; h->no_p2_pair = true; }
   *out = g;
   return OPRL_OK;
 }
@@ -2597,48 +2604,61 @@ extern "C" int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, 
     h->staged_ready = false;
     h->last_B = B;
   }
-  static_assert(sizeof(DdpgArgs) % 8 == 0 && sizeof(DwKArgsG) % 8 == 0, "the blocks of an update lie back to back");
+  static_assert(sizeof(DdpgArgs) % 8 == 0 && sizeof(DwKArgsG) % 8 == 0 && sizeof(DwKArgsG2) % 8 == 0, "the blocks of an update lie back to back");
+  const size_t dc_bytes = dw_group_block_bytes(g->ni_c), da_bytes = dw_group_block_bytes(kDwGroupItems);
+  for (oprl_learner* h : g->L) h->noise1_pending = nullptr;
   for (int k0 = 0; k0 < K; k0 += kGroupChunk) {
     const int m = K - k0 < kGroupChunk ? K - k0 : kGroupChunk;
     const int c = g->cur;
     if (g->stage_busy[c]) { HIPC(hipEventSynchronize(g->stage_ev[c])); g->stage_busy[c] = false; }
     int tiles_c = 0, tiles_a = 0;
     DdpgArgs first[kGroupChunk][2];           // member 0's blocks of each update (for the grids)
+    bool due[kGroupChunk];                    // TD3: the actor steps every policy_freq updates — of ALL members at once
     for (int j = 0; j < m; ++j) {
       const int k = k0 + j;
       DdpgArgs* p1 = reinterpret_cast<DdpgArgs*>(g->stage[c] + (size_t)j * g->bytes);
       DdpgArgs* p2 = p1 + n;
-      DwKArgsG* dc = reinterpret_cast<DwKArgsG*>(p2 + n);
-      DwKArgsG* da = dc + n;
+      char* dc = reinterpret_cast<char*>(p2 + n);
+      char* da = dc + (size_t)n * dc_bytes;
+      due[j] = actor_due(g->L[0]);
       for (int l = 0; l < n; ++l) {
         oprl_learner* h = g->L[l];
         const oprl_learner_config& cf = h->cfg;
+        if (actor_due(h) != due[j]) { set_err("oprl_group_step_n: the members' delayed actor steps are out of phase (update counts differ modulo policy_freq)"); return OPRL_ERR_STATE; }
         h->src.counter = (unsigned long long)h->update_count;
         h->next_src.counter = h->src.counter + 1;
         h->src.gather = h->staged_ready ? 0 : 1;
-        const int prefetch = (k + 1 < K) ? 1 : 0;
+        h->staged_ready = false;
+        const int prefetch = (k + 1 < K && due[j]) ? 1 : 0;     // (the row of phase 2's launch: actor steps only)
         h->epoch += 1;
         if (h->epoch == 0) { h->epoch = 1; HIPC(hipMemsetAsync(h->y_granules, 0, ((size_t)3 * h->Bmax + 256) * sizeof(unsigned long long), st)); }
         p1[l] = ddpg_args(h, B);
         RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &p1[l].cluster_tag));
-        p2[l] = ddpg_args(h, B);
-        RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &p2[l].cluster_tag));   // (a launch, a tag)
-        p2[l].prefetch_next = prefetch;
-        h->staged_ready = prefetch != 0;
         DwKArgs kd;
-        DwArgs dw = dw_build(h, true, B, true, false);        // (as the un-merged launches of a solo learner)
-        const int tc = fill_dw_kargs(dw, &kd) < 0 ? -1 : compact_dw_kargs(kd, &dc[l]);
-        dw = dw_build(h, false, B, cf.actor.theta_target != nullptr, false);
-        const int ta = fill_dw_kargs(dw, &kd) < 0 ? -1 : compact_dw_kargs(kd, &da[l]);
-        if (l == 0 && j == 0) { tiles_c = tc; tiles_a = ta; }
-        if (tc < 0 || ta < 0 || tc != tiles_c || ta != tiles_a || p1[l].nc != p1[0].nc || p1[l].merged || p1[l].wide || p1[l].whole) {
+        // (as the un-merged launches of a solo learner; TD3 moves its targets on actor steps only)
+        DwArgs dw = dw_build(h, true, B, cf.algo == OPRL_TD3 ? due[j] : true, false);
+        const int tc = fill_dw_kargs(dw, &kd) < 0 ? -1 : compact_dw_kargs(kd, dc + (size_t)l * dc_bytes, g->ni_c);
+        int ta = tiles_a;
+        if (due[j]) {
+          p2[l] = ddpg_args(h, B);
+          RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &p2[l].cluster_tag));   // (a launch, a tag)
+          p2[l].prefetch_next = prefetch;
+          h->staged_ready = prefetch != 0;
+          dw = dw_build(h, false, B, cf.actor.theta_target != nullptr, alpha_rides(h));    // (SAC: the temperature step rides)
+          ta = fill_dw_kargs(dw, &kd) < 0 ? -1 : compact_dw_kargs(kd, da + (size_t)l * da_bytes, kDwGroupItems);
+          if (l == 0 && tiles_a == 0) tiles_a = ta;
+          if (ta < 0 || ta != tiles_a || p2[l].nc != p1[l].nc || p2[l].merged || p2[l].wide || p2[l].whole || p2[l].p2_pair) ta = -1;
+        }
+        if (l == 0 && j == 0) tiles_c = tc;
+        if (tc < 0 || ta < 0 || tc != tiles_c || p1[l].nc != p1[0].nc || p1[l].merged || p1[l].wide || p1[l].whole || p1[l].twin_split) {
           set_err("oprl_group_step_n: internal: bad launch arguments");
           return OPRL_ERR_INVALID;
         }
+        h->actor_updated_last = due[j];
         h->update_count += 1;
       }
       first[j][0] = p1[0];
-      first[j][1] = p2[0];
+      if (due[j]) first[j][1] = p2[0];
     }
     HIPC(hipMemcpyAsync(g->dev, g->stage[c], g->bytes * m, hipMemcpyHostToDevice, st));
     HIPC(hipEventRecord(g->stage_ev[c], st));
@@ -2647,12 +2667,13 @@ extern "C" int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, 
     for (int j = 0; j < m; ++j) {
       const DdpgArgs* p1 = reinterpret_cast<const DdpgArgs*>(g->dev + (size_t)j * g->bytes);
       const DdpgArgs* p2 = p1 + n;
-      const DwKArgsG* dc = reinterpret_cast<const DwKArgsG*>(p2 + n);
-      const DwKArgsG* da = dc + n;
+      const char* dc = reinterpret_cast<const char*>(p2 + n);
+      const char* da = dc + (size_t)n * dc_bytes;
       HIPC(launch_ddpg_phase1_group(first[j][0], p1, n, st));
-      HIPC(launch_dw_adam_group(dc, n, tiles_c, st));
+      HIPC(launch_dw_adam_group(dc, g->ni_c, n, tiles_c, st));
+      if (!due[j]) continue;
       HIPC(launch_ddpg_phase2_group(first[j][1], p2, n, st));
-      HIPC(launch_dw_adam_group(da, n, tiles_a, st));
+      HIPC(launch_dw_adam_group(da, kDwGroupItems, n, tiles_a, st));
     }
   }
   for (oprl_learner* h : g->L) { h->src.gather = 0; h->prefetch_next = 0; h->staged_ready = false; }

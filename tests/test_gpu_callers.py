@@ -716,6 +716,58 @@ def test_packed_learner_group_members_against_the_cpu_oracle(precision):
     g.close()
 
 
+@pytest.mark.parametrize("algo,precision", [("td3", "f32"), ("td3", "x2"), ("td3", "bf16"), ("sac", "f32"), ("sac", "x2"),
+                                            ("sac_tuned", "x2"), ("sac_tuned", "bf16")])
+def test_packed_twin_critic_group_equals_solo_learners(algo, precision, monkeypatch):
+    """N3 for the twin-critic algorithms (the reference's --seeds fan-out is algorithm-agnostic, runners/train.py:24-50):
+    three TD3 / SAC learners stepped as a group end bit-identical to each of them alone on clusters of four with the
+    twin critics back to back (the form group members run: no co-residency requirement between clusters) — TD3's
+    delayed actor steps (phase 2 every other update for all members at once), SAC's learned temperature riding on the
+    actor's dW launch, the device noise streams keyed per member."""
+    from oprl_amd.group import LearnerGroup
+    from oprl_amd.logging import NullLogger
+    monkeypatch.setenv("OPRL_AMD_NO_TWIN_SPLIT", "1")
+    monkeypatch.setenv("OPRL_AMD_NO_P2_PAIR", "1")
+    B, K = 64, 7
+    buf = _filled_buffer()
+
+    def member(i):
+        t.manual_seed(70 + i)
+        kw = dict(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=B,
+                  precision=precision, log_every=10 ** 9)
+        if algo == "td3":
+            from oprl_amd.algos.td3 import TD3
+            return TD3(**kw).create()
+        from oprl_amd.algos.sac import SAC
+        return SAC(tune_alpha=algo == "sac_tuned", **kw).create()
+    group_members, solo = [member(i) for i in range(3)], [member(i) for i in range(3)]
+    seeds = [31, 32, 33]
+    g = LearnerGroup(group_members)
+    g.step_n(buf.handle, K, B, seeds)
+    g.step_n(buf.handle, 3, B, seeds)             # a second call continues the streams (TD3: starting on a critic-only step)
+    for a, s in zip(solo, seeds):
+        assert a.learner.lib.oprl_learner_set_cluster(a.learner.handle, 4) == 0
+        a.learner.step_n(buf.handle, K, B, seed=s)
+        a.learner.step_n(buf.handle, 3, B, seed=s)
+    t.cuda.synchronize()
+    nets = ("actor", "critic", "actor_target", "critic_target") if algo == "td3" else ("actor", "critic", "critic_target")
+    for a, b in zip(group_members, solo):
+        for m in nets:
+            assert t.equal(getattr(a, m)._oprl_arena, getattr(b, m)._oprl_arena), m
+        assert t.equal(a.learner.critic_m, b.learner.critic_m) and t.equal(a.learner.actor_v, b.learner.actor_v)
+        assert a.update_step == b.update_step == K + 3
+        if algo == "sac_tuned":
+            assert a.alpha == b.alpha and a.alpha != 0.2
+        a.learner.check()
+    # a member out of phase is refused, not silently stepped
+    if algo == "td3":
+        batch = buf.sample(B)
+        group_members[1].update(*batch)
+        with pytest.raises(RuntimeError, match="out of phase"):
+            g.step_n(buf.handle, 2, B, seeds)
+    g.close()
+
+
 @pytest.mark.parametrize("precision", ["f32", "x2", "bf16"])
 def test_packed_learner_group_equals_solo_learners(precision):
     """N3: three independent DDPG learners stepped as a group (four launches per update for all of them) end
