@@ -81,6 +81,14 @@ struct MlpArgs {
   const float* pf16[kMaxLayers]; const float* pb16[kMaxLayers];
 };
 
+// k_lw_mid_pair (csrc/layerwise.hip): the flag granules of the launches that run two hidden layers as one, the tag of
+// the next such launch (the caller advances it by one per launch made: launch_mlp_layerwise reports how many in `used`)
+struct LwPairBuf {
+  unsigned long long* flags; int n_flags;
+  unsigned next_tag; int spin; unsigned* err;
+  int use;                             // bit 0: forward pairs, bit 1: backward pairs
+  mutable int used;                    // launches made with next_tag, next_tag + 1, ...
+};
 constexpr int kMaxMulti = 5;           // nets per k_mlp_slice_multi launch (TQC: 5 quantile critics)
 struct MlpMultiArgs { MlpArgs a[kMaxMulti]; };
 

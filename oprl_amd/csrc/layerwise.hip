@@ -144,8 +144,16 @@ struct LwRun2 { int slices, nets, rpn, base, rem, ppx; };   // runs per net; til
 
 // (the body as a function of the workgroup index bx: the launch below, and the riding form k_slice_tp_fin)
 // KM: the nets' arguments in the kernel-argument segment; net0: R's nets are KM->a[net0 ..]
-template <int MODE, class P>
-__device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, const LwRun2& R, int bx, int net0) {
+// ROLE (k_lw_mid_pair: two consecutive layers in ONE launch): 1 = the first layer's workgroup — its result rows leave
+// written through (sc1) and, once every wave's stores are acknowledged, flag X.flags[(net, slice, run)] = {tag, *} goes
+// up; 2 = the second layer's — weight fragments, bias / masks first, then a bounded wait for the rpn flags of its
+// (net, slice), then the rows with sc1 loads.  MAXRUN: the longest run of column tiles (the partial tiles' LDS).
+struct LwPair { unsigned long long* flags; unsigned tag; int spin; unsigned* err; };
+constexpr int kLwFlagStride = 32;             // flags per (net, slice): rpn <= 32
+template <int MODE, class P, int ROLE = 0, int MAXRUN = 6>
+__device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, const LwRun2& R, int bx, int net0,
+                                                 const LwPair* X = nullptr) {
+  static_assert(!(MODE == 2 && ROLE == 2), "the first hidden layer has no producer in the launch");
   constexpr bool BWD = MODE == 1, FIN = MODE == 2;
   constexpr int NSE = 64 / P::KS;               // macro steps of a K-eighth (64 columns): 4 / 2
   constexpr int NSW = 512 / P::KS;
@@ -186,7 +194,7 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
         w0f[q][st] = st < NS0 ? ld4(A.net.pf[0] + (((size_t)tile * NS0 + st) * 64 + lane) * 4)
                               : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  } else {
+  } else if constexpr (ROLE != 2) {
     const float* src = BWD ? A.dYg[l] : A.Xg[l];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
@@ -218,9 +226,9 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int e = tid + k * kThreads;
-    const int ot = e >> 8, r = e & 255, rt = ot / kLw2MaxRun, tl = ot - rt * kLw2MaxRun;
+    const int ot = e >> 8, r = e & 255, rt = ot / MAXRUN, tl = ot - rt * MAXRUN;
     const int gr = row0 + rt * 16 + (r >> 4), col = (t0 + tl) * 16 + (r & 15);
-    e_ok[k] = tl < nt && gr < B;
+    e_ok[k] = ot < 2 * MAXRUN && tl < nt && gr < B;
     e_off[k] = e_ok[k] ? (size_t)gr * WIDTH + col : 0;
     e_x[k] = 0.f;
     if (e_ok[k]) e_x[k] = BWD ? A.Xg[l][e_off[k]] : A.net.b[l][col];
@@ -257,6 +265,45 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
         *reinterpret_cast<f32x4*>(A.Xg[1] + (size_t)(row0 + row) * WIDTH + col) = ld4(xs + row * WL + col);
     }
   } else {
+    if constexpr (ROLE == 2) {
+      // the producers of this (net, slice): one flag per run of the layer before, lanes of wave 0 poll
+      int* s_okp = reinterpret_cast<int*>(xin);              // (a word behind the rows: no static LDS — two workgroups per CU)
+      if (wave == 0) {
+        bool ok = true;
+        if (lane < R.rpn) {
+          const unsigned long long* f = X->flags + ((size_t)(net0 + net) * R.slices + slice) * kLwFlagStride + lane;
+          ok = false;
+          for (int spin = 0; spin < X->spin && !ok; ++spin) {
+            ok = (unsigned)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == X->tag;
+            if (!ok) __builtin_amdgcn_s_sleep(2);
+          }
+        }
+        const bool all = __all(ok);
+        if (lane == 0) {
+          *s_okp = all ? 1 : 0;
+          if (!all) report_expired(X->err, (KERN_LW_PAIR << 8) | SITE_LW_PAIR);
+        }
+      }
+      __syncthreads();
+      const bool ok = *s_okp != 0;
+      const float* src = BWD ? A.dYg[l] : A.Xg[l];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int idx = tid + h * kThreads;
+        const int row = idx >> 7, col = (idx & 127) * 4, gr = row0 + row;
+        v[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (gr < B) {
+          // agent-scope loads (sc1: past this XCD's L2), as loads the compiler counts — an inline-asm load's result
+          // registers are copied and reused before it has returned (seen in the bf16 instance: a memory fault)
+          const unsigned long long* q = reinterpret_cast<const unsigned long long*>(src + (size_t)gr * WIDTH + col);
+          const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v[h] = f32x4{__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                       __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32))};
+        }
+        if (!ok) v[h] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};   // a lost producer shows up as NaN
+      }
+    }
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       const int idx = tid + h * kThreads;
@@ -320,7 +367,7 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
     if (tl < nt)
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
-        *reinterpret_cast<f32x4*>(scr + ((size_t)((rt * kLw2MaxRun + tl) * 8 + ke) * 64 + lane) * 4) = acc[q][rt];
+        *reinterpret_cast<f32x4*>(scr + ((size_t)((rt * MAXRUN + tl) * 8 + ke) * 64 + lane) * 4) = acc[q][rt];
   }
   __syncthreads();
 
@@ -335,8 +382,17 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
     float vs = 0.f;
 #pragma unroll
     for (int p = 0; p < 8; ++p) vs += sp[p * 256];
-    if constexpr (BWD) dst[e_off[k]] = e_x[k] > 0.f ? vs : 0.f;
-    else dst[e_off[k]] = fmaxf(vs + e_x[k], 0.f);
+    const float res = BWD ? (e_x[k] > 0.f ? vs : 0.f) : fmaxf(vs + e_x[k], 0.f);
+    if constexpr (ROLE == 1) __hip_atomic_store(dst + e_off[k], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written through
+    else dst[e_off[k]] = res;
+  }
+  if constexpr (ROLE == 1) {
+    // every wave's rows are out before the workgroup says so
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_store(X->flags + ((size_t)(net0 + net) * R.slices + slice) * kLwFlagStride + run, (unsigned long long)X->tag << 32,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -350,6 +406,23 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid_run2(const MlpMultiArgs M, 
 // TQC's critic step opens with the actor's forward on s' on 64 of 256 CUs; the online critics' first two layers on
 // (s, a) need nothing of it, and as a launch of their own they are the next 10-16 us of the chain.
 // `host` is a multiple of 8, so a rider's bx & 7 is still its XCD.
+// Two consecutive hidden-layer launches as ONE (forward: the first hidden layer with the net input folded in + the
+// second; backward: through the second + through the first).  Blocks [0, nb) are the first layer's, [nb, 2 nb) the
+// second layer's: dispatched behind their producers — a workgroup only ever waits for workgroups dispatched before it —
+// they take in their weight fragments (what bounds these launches) while the first layer's last workgroups are still
+// running, and wait for the flags of their (net, slice) only then.  One workgroup per compute unit (113-121 registers
+// in the x2 mode, 96 KB of partial tiles): the second layer's workgroups start as the first layer's retire — what is
+// saved is the launch boundary (drain, dispatch ramp, cold instruction fetch) and the fragments' round trip.
+constexpr int kLwPairMaxRun = kLw2MaxRun;
+constexpr size_t kLwPairLds = sizeof(float) * (2 * kLwPairMaxRun * 8 * 256);
+static_assert(kLwPairLds >= sizeof(float) * (kLw2Rows * lds_ld(512) + kLw2Rows * kX0Ld + 4), "rows + net input fit under the partial tiles");
+template <int MODE_A, int MODE_B, class P>
+__global__ __launch_bounds__(kThreads) void k_lw_mid_pair(const MlpMultiArgs M, int la, int lb, const LwRun2 R, int nb, const LwPair X) {
+  const MlpMultiArgs* KM = (const MlpMultiArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  if ((int)blockIdx.x < nb) lw_mid_run2_body<MODE_A, P, 1, kLwPairMaxRun>(KM, la, R, (int)blockIdx.x, 0, &X);
+  else lw_mid_run2_body<MODE_B, P, 2, kLwPairMaxRun>(KM, lb, R, (int)blockIdx.x - nb, 0, &X);
+}
+
 template <class P>
 __global__ __launch_bounds__(kThreads) void k_slice_tp_fin(const MlpMultiArgs M, const MlpArgs A, const LwRun2 R, int host,
                                                            int slices) {
@@ -582,6 +655,13 @@ hipError_t init_layerwise_attrs() {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLwRun2Lds);
     if (e != hipSuccess) return e;
   }
+  const void* kp[6] = {reinterpret_cast<const void*>(&k_lw_mid_pair<2, 0, PrecF32>), reinterpret_cast<const void*>(&k_lw_mid_pair<1, 1, PrecF32>),
+                       reinterpret_cast<const void*>(&k_lw_mid_pair<2, 0, PrecBF16>), reinterpret_cast<const void*>(&k_lw_mid_pair<1, 1, PrecBF16>),
+                       reinterpret_cast<const void*>(&k_lw_mid_pair<2, 0, PrecX2>), reinterpret_cast<const void*>(&k_lw_mid_pair<1, 1, PrecX2>)};
+  for (const void* k : kp) {
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLwPairLds);
+    if (e != hipSuccess) return e;
+  }
   return hipSuccess;
 }
 
@@ -663,7 +743,7 @@ hipError_t launch_mlp_layerwise_first(const MlpArgs* t, int t_n, int t0, int wid
 //   tail[tail0 ..] rides on this launch's heads (LwFinTail); null: nothing
 hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, int prec, const TqcJob* job,
                                 const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, int tail_prec,
-                                const PrefetchJob* prefetch) {
+                                const PrefetchJob* prefetch, const LwPairBuf* pairs) {
   if (!mlp_layerwise_ok(a, n, width)) return hipErrorInvalidValue;
   if (first_done && !mlp_layerwise_fin_ok(a, n, width)) return hipErrorInvalidValue;
   if (tail != nullptr && (!mlp_layerwise_fin_ok(tail, tail_n, width) || tail0 < 0 || tail0 >= tail_n || tail[0].B != a[0].B))
@@ -697,14 +777,38 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
       else hipLaunchKernelGGL((k_lw_mid_run2<2>), runs2, blk, kLwRun2Lds, st, m, l, r2, 0);
     }
   };
+  // two hidden layers (TQC's critics): each direction's two launches as one (k_lw_mid_pair)
+  const LwRun2 rp = lw_run2(a[0].B, n, n_cus > 0 ? n_cus : 256);
+  const bool pair_ok = pairs != nullptr && pairs->flags != nullptr && L == 4 && rp.base + (rp.rem ? 1 : 0) <= kLwPairMaxRun &&
+                       rp.rpn <= kLwFlagStride && n * rp.slices * kLwFlagStride <= pairs->n_flags;
+  auto pair = [&](int dir, int la, int lb) {       // dir 0: forward (first layer folded in) + forward, 1: backward + backward
+    LwPair X;
+    X.flags = pairs->flags; X.tag = pairs->next_tag + (unsigned)pairs->used; X.spin = pairs->spin; X.err = pairs->err;
+    pairs->used += 1;
+    const int nb = 8 * rp.ppx * rp.slices;
+    const dim3 grid(2 * nb);
+    if (dir == 0) {
+      if (prec == 2) hipLaunchKernelGGL((k_lw_mid_pair<2, 0, PrecX2>), grid, blk, kLwPairLds, st, m, la, lb, rp, nb, X);
+      else if (prec == 1) hipLaunchKernelGGL((k_lw_mid_pair<2, 0, PrecBF16>), grid, blk, kLwPairLds, st, m, la, lb, rp, nb, X);
+      else hipLaunchKernelGGL((k_lw_mid_pair<2, 0, PrecF32>), grid, blk, kLwPairLds, st, m, la, lb, rp, nb, X);
+    } else {
+      if (prec == 2) hipLaunchKernelGGL((k_lw_mid_pair<1, 1, PrecX2>), grid, blk, kLwPairLds, st, m, la, lb, rp, nb, X);
+      else if (prec == 1) hipLaunchKernelGGL((k_lw_mid_pair<1, 1, PrecBF16>), grid, blk, kLwPairLds, st, m, la, lb, rp, nb, X);
+      else hipLaunchKernelGGL((k_lw_mid_pair<1, 1, PrecF32>), grid, blk, kLwPairLds, st, m, la, lb, rp, nb, X);
+    }
+  };
   if (a[0].do_fwd) {
     // a narrow net input (two macro steps) is folded into the first hidden layer's launch
     bool fuse_in = L >= 3;
     for (int j = 0; j < n; ++j) fuse_in = fuse_in && a[j].net.dims[0] <= 32;
     if (!fuse_in) hipLaunchKernelGGL(k_lw_in<512>, wide, blk, 0, st, m, g);
-    for (int l = 1; l + 1 < L; ++l) {
-      if (l == 1 && first_done) continue;
-      mid(l == 1 && fuse_in ? 2 : 0, l);
+    if (pair_ok && fuse_in && !first_done && (pairs->use & 1) != 0) {
+      pair(0, 1, 2);
+    } else {
+      for (int l = 1; l + 1 < L; ++l) {
+        if (l == 1 && first_done) continue;
+        mid(l == 1 && fuse_in ? 2 : 0, l);
+      }
     }
   }
   {
@@ -728,8 +832,12 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
                        rider != nullptr ? *rider : a[0], n, *ft);
   }
   if (a[0].do_bwd) {
-    for (int l = L - 2; l >= 1; --l) {
-      mid(1, l);
+    if (pair_ok && (pairs->use & 2) != 0) {
+      pair(1, 2, 1);
+    } else {
+      for (int l = L - 2; l >= 1; --l) {
+        mid(1, l);
+      }
     }
     if (a[0].dact_cols > 0) {
       static const PrefetchJob no_job = [] { PrefetchJob j; memset((void*)&j, 0, sizeof j); j.z0 = -1; return j; }();

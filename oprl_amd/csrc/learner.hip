@@ -89,7 +89,7 @@ hipError_t launch_mlp_slice_multi(const MlpArgs* a, int n, int width, hipStream_
 bool mlp_layerwise_ok(const MlpArgs* a, int n, int width);
 hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, int prec, const TqcJob* job,
                                 const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, int tail_prec,
-                                const PrefetchJob* prefetch);
+                                const PrefetchJob* prefetch, const LwPairBuf* pairs);
 bool mlp_layerwise_fin_ok(const MlpArgs* a, int n, int width);
 int mlp_layerwise_fin_fit(const MlpArgs* a, int n, int host_wgs, int n_cus);
 hipError_t launch_slice_tp_with_fin(const MlpArgs& host, const MlpArgs* a, int n, int n_ride, int width, int n_cus, hipStream_t st,
@@ -357,6 +357,7 @@ struct oprl_learner {
   bool fin16 = false;
   bool fin_done = false;       // TQC: the online critics' first hidden launch rode on the actor's forward on s' (critic_phase step 1); step 3 skips it
   bool no_fin_ride = false;    // OPRL_AMD_NO_FIN_RIDE: it stays the first launch of step 3 (tests / A-B)
+  LwPairBuf lw_pairs = {nullptr, 0, 1u, 1 << 20, nullptr, 3, 0};   // k_lw_mid_pair: flags (own allocation), tags; OPRL_AMD_LW_PAIR: bit 0 forward, bit 1 backward pairs (default 3)
   float* lw_scratch = nullptr; // [critics][layers 1 .. L-1][Bmax x 512]: activations of forward-only layer-by-layer launches (the target pass) — not the nets' dW exchange buffers, which the early first launch has already filled
   MlpArgs rider;               // TQC: the actor's forward on s, prepared in critic_phase to ride on the critic step's head launch ...
   bool rider_pending = false;  // ... offered to the next for_each_net; taken: rider_done, and actor_phase skips its step 5
@@ -817,7 +818,13 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
         h->prefetch_done = true;
       }
       hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, h->n_cus, st, lw16 ? (h->x2 ? 2 : 1) : 0, job, rider, first_done,
-                                          tail, h->nc, tail0, h->fin16 ? (h->x2 ? 2 : 1) : 0, pf);
+                                          tail, h->nc, tail0, h->fin16 ? (h->x2 ? 2 : 1) : 0, pf, &h->lw_pairs);
+      // (a tag per pair launch; 2^32 launches on: every flag is retired before a tag can come round again)
+      if (h->lw_pairs.next_tag + (unsigned)h->lw_pairs.used < h->lw_pairs.next_tag && h->lw_pairs.flags != nullptr)
+        (void)hipMemsetAsync(h->lw_pairs.flags, 0, (size_t)h->lw_pairs.n_flags * sizeof(unsigned long long), st);
+      h->lw_pairs.next_tag += (unsigned)h->lw_pairs.used;
+      if (h->lw_pairs.next_tag == 0) h->lw_pairs.next_tag = 1;
+      h->lw_pairs.used = 0;
       prof_end(st);
       HIPC(e);
     } else if (same) {
@@ -1580,19 +1587,20 @@ int check_device_error(const oprl_learner* h) {
   if (h == nullptr || h->err_host == nullptr) return OPRL_OK;
   const unsigned code = *(volatile const unsigned*)h->err_host;
   if (code == 0) return OPRL_OK;
-  static const char* kern[] = {"?", "k_ddpg_phase1", "k_ddpg_phase2", "k_mlp_slice_tp", "k_dw_adam<exchange>", "peer-window all-reduce"};
+  static const char* kern[] = {"?", "k_ddpg_phase1", "k_ddpg_phase2", "k_mlp_slice_tp", "k_dw_adam<exchange>", "peer-window all-reduce", "k_lw_mid_pair"};
   static const char* site[] = {"?", "cluster all-reduce (a member of a 4-CU slice cluster never published its partial)",
                                "TD-target hand-off (role B never received y from role A)",
                                "twin-target exchange between role A and the role-C cluster",
                                "SAC phase 2 pair exchange (critic 2's cluster never delivered)",
                                "gradient tile exchange with another rank", "peer-window flag of another rank",
-                               "gate of the dW tiles riding on a phase launch (a role never flagged its rows / seeds)"};
+                               "gate of the dW tiles riding on a phase launch (a role never flagged its rows / seeds)",
+                               "hand-over between the two hidden layers of one launch (a first-layer workgroup never flagged its rows)"};
   const unsigned k = (code >> 8) & 0xff, w = code & 0xff;
   set_err("device error 0x%x: a bounded cross-workgroup wait expired in %s at the %s; the results of that "
           "update (and everything after it) are poisoned with NaN.  Typical causes: the launch's workgroups were "
           "not co-resident (another process or learner held the GPU's compute units for longer than the wait bound), "
           "or a data-parallel peer died.  Restore a checkpoint, then oprl_learner_clear_error().",
-          code, k < 6 ? kern[k] : "?", w < 8 ? site[w] : "?");
+          code, k < 7 ? kern[k] : "?", w < 9 ? site[w] : "?");
   return OPRL_ERR_STATE;
 }
 
@@ -1620,8 +1628,9 @@ extern "C" int oprl_debug_noise(oprl_learner* h, int32_t stream_id, uint64_t cou
 }
 
 extern "C" int oprl_learner_debug_expire(oprl_learner* h, int32_t site) {
-  if (!h || site < 0 || site > 7) { set_err("oprl_learner_debug_expire: invalid argument"); return OPRL_ERR_INVALID; }
+  if (!h || site < 0 || site > 8) { set_err("oprl_learner_debug_expire: invalid argument"); return OPRL_ERR_INVALID; }
   h->debug_expire = site;
+  h->lw_pairs.spin = site == 8 ? 0 : (1 << 20);      // (8: the hand-over inside k_lw_mid_pair)
   return OPRL_OK;
 }
 
@@ -2105,6 +2114,17 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     if (cfg->algo == OPRL_TQC && h->w_critic == 512) {
       const size_t n = (size_t)nc * (kMaxLayers - 1) * (size_t)h->Bmax * 512;
       if (hipMalloc(&h->lw_scratch, n * sizeof(float)) != hipSuccess) h->lw_scratch = nullptr;   // (then: the nets' own buffers, no early launch)
+      {
+        const char* pe = getenv("OPRL_AMD_LW_PAIR");
+        const int pair_env = pe != nullptr ? atoi(pe) : 3;
+        const int nf = kMaxMulti * ((h->Bmax + 31) / 32) * 32;
+        void* fl = nullptr;
+        if (pair_env != 0 && hipMalloc(&fl, (size_t)nf * sizeof(unsigned long long)) == hipSuccess) {
+          (void)hipMemset(fl, 0, (size_t)nf * sizeof(unsigned long long));
+          h->lw_pairs.flags = (unsigned long long*)fl; h->lw_pairs.n_flags = nf; h->lw_pairs.use = pair_env & 3;
+          h->lw_pairs.err = h->err_dev;
+        }
+      }
     }
     const char* nar = getenv("OPRL_AMD_NO_AF_RIDE");
     h->no_af_ride = (nar != nullptr && atoi(nar) != 0);
@@ -2204,6 +2224,7 @@ extern "C" int oprl_learner_destroy(oprl_learner* h) {
   if (h->xbuf) (void)hipFree(h->xbuf);
   if (h->tqc_counter) (void)hipFree(h->tqc_counter);
   if (h->lw_scratch) (void)hipFree(h->lw_scratch);
+  if (h->lw_pairs.flags) (void)hipFree(h->lw_pairs.flags);
   if (h->batch_alt) (void)hipFree(h->batch_alt);
   dev_free(h->uc_base);
   if (h->err_host) (void)hipHostFree(h->err_host);

@@ -50,6 +50,36 @@ def test_expired_wait_is_reported_not_silent(site, text):
     assert bool(t.isfinite(algo.critic._oprl_arena).all()) and bool(t.isfinite(algo.actor._oprl_arena).all())
 
 
+def test_expired_hand_over_inside_the_hidden_layer_pair_launch_is_reported():
+    """TQC: two hidden layers run as one launch (k_lw_mid_pair); a second-layer workgroup whose first-layer producers
+    never flag their rows gives up after its bound, poisons its rows with NaN and reports (kernel, site)."""
+    from oprl_amd.algos.tqc import TQC
+    t.manual_seed(0)
+    algo = TQC(logger=NullLogger(), state_dim=S, action_dim=A, device="cuda", max_batch=B, log_every=10 ** 9).create()
+    L = algo.learner
+    batch = [x.cuda() for x in fx.make_batch(3, B, S, A)]
+    for _ in range(2):
+        algo.update(*batch)
+    t.cuda.synchronize()
+    L.check()
+    good = L.state_dict()
+    assert L.lib.oprl_learner_debug_expire(L.handle, 8) == 0
+    with pytest.raises(RuntimeError, match="hand-over between the two hidden layers"):
+        algo.update(*batch)                     # (the actor phase's entry check may already see the critic phase's report)
+        t.cuda.synchronize()
+        algo.update(*batch)
+    t.cuda.synchronize()
+    assert not bool(t.isfinite(algo.critic._oprl_arena).all())
+    assert L.lib.oprl_learner_debug_expire(L.handle, 0) == 0
+    L.clear_error()
+    L.load_state_dict(good)
+    for _ in range(2):
+        algo.update(*batch)
+    t.cuda.synchronize()
+    L.check()
+    assert bool(t.isfinite(algo.critic._oprl_arena).all()) and bool(t.isfinite(algo.actor._oprl_arena).all())
+
+
 def test_packed_learners_and_long_runs_stay_clean():
     """Two learners driven from two host threads on two streams (the default multi-seed layout), 2000
     updates each: no wait expires, every parameter stays finite."""

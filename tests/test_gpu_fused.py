@@ -467,6 +467,40 @@ def test_tqc_early_first_launch_equals_in_place(B, prec, monkeypatch):
         assert se[k] == si[k], k
 
 
+@pytest.mark.parametrize("B,prec", [(256, "f32"), (100, "x2"), (256, "x2"), (256, "bf16"), (40, "bf16")])
+def test_tqc_hidden_layer_pairs_equal_separate_launches(B, prec, monkeypatch):
+    """TQC's two hidden layers per direction as ONE launch (k_lw_mid_pair: the second layer's workgroups wait for the
+    flags of the first layer's, rows handed over written through) against a launch per layer: the same workgroup
+    arithmetic on the same rows — bit-identical, through update() at full and ragged batches and through step_n."""
+    from oprl_amd.algos.tqc import TQC
+    from oprl_amd.logging import NullLogger
+    from tests.test_gpu_callers import _filled_buffer
+
+    def make():
+        t.manual_seed(0)
+        return TQC(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=256,
+                   precision=prec).create()
+
+    paired = make()
+    monkeypatch.setenv("OPRL_AMD_LW_PAIR", "0")          # (read when the learner is created)
+    single = make()
+    for step in range(3):
+        batch = [x.cuda() for x in fx.make_batch(90 + step, B, 24, 6)]
+        paired.update(*batch)
+        single.update(*batch)
+    buf = _filled_buffer()
+    paired.learner.step_n(buf.handle, 10, 64, seed=9)
+    single.learner.step_n(buf.handle, 10, 64, seed=9)
+    t.cuda.synchronize()
+    paired.learner.check()
+    assert t.isfinite(paired.critic._oprl_arena).all()
+    for m in ("actor", "critic", "critic_target"):
+        assert t.equal(getattr(paired, m)._oprl_arena, getattr(single, m)._oprl_arena), m
+    sp, ss = paired.learner.read_scalars(), single.learner.read_scalars()
+    for k in ("critic_loss", "actor_loss", "alpha"):
+        assert sp[k] == ss[k], k
+
+
 @pytest.mark.parametrize("B", [64, 100])
 def test_tqc_step_n_rows_gathered_by_riders_equal_gather_launches(B, monkeypatch):
     """TQC's step_n: the next update's minibatch rows gathered by riding workgroups of the k_lw_dact launch (same
