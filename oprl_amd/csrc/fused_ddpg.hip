@@ -138,7 +138,7 @@ __device__ __forceinline__ void gauss_head(const float* outS, int row0, int B, i
 
 template <int WIDTH, bool LEAN, class P, class ST>
 __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, float* const* cX, float* const* cdY,
-                                       float* partials, bool diag, int j, float* smem, Tp& tp, ST& stamp) {
+                                       float* partials, bool diag, int j, float* smem, Tp& tp, ST& stamp, int slice) {
   using LY = FusedLds<WIDTH>;
   constexpr int WL = lds_ld(WIDTH);
   constexpr int HB = kR * WL;
@@ -149,7 +149,7 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
   float* auxS = smem + LY::aux;
   float* scr = smem + LY::scr;
   float* yS = smem + LY::misc + 2 * kR;
-  const int slice = blockIdx.x, row0 = slice * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
+  const int row0 = slice * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
   const bool lead = tp.c == 0;
   const bool wt = LEAN && (A.merged & 1) != 0;   // the dW tiles of this very launch read what this role stores
   const Tp3Store st{cX[1], cX[2], cdY[1], cdY[0], A.cdY0_stride, LEAN ? B : 0, wt};   // lean: tile-major dz1 partials
@@ -272,7 +272,7 @@ __device__ __forceinline__ int dw_total(const DwKArgs4& d) { return d.tile_end[k
 // MERGED kernels are single-critic, non-SAC by their launchers' rules: the twin paths are compiled out of them.
 // (SINGLE: the caller's launcher admits one critic only — the merged kernels, the packed learners' group kernel)
 template <int WIDTH, bool LEAN, bool SAC, class P, bool WIDE = false, bool MERGED = false, class KA = DwKArgs, bool SINGLE = MERGED>
-__device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D = nullptr, int by_in = -1) {
+__device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D = nullptr, int by_in = -1, int bx_in = -1) {   // (bx_in: the slice, where the caller deals the workgroups out itself — the group launches)
   constexpr bool TWIN = !SINGLE;            // twin critics / twin_split can occur at all
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int by = by_in < 0 ? (int)blockIdx.y : by_in;
@@ -303,7 +303,7 @@ __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D =
   int* meta = reinterpret_cast<int*>(yS + kR);
   int* endsS = reinterpret_cast<int*>(smem + LY::misc + 96);
   const int B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
-  int slice = blockIdx.x;
+  int slice = bx_in < 0 ? (int)blockIdx.x : bx_in;
   // roles: 0 = A target chain, 1 .. n_critics = B (one per online critic), last = C actor forward.
   // Order in the grid (= dispatch order when the grid over-subscribes the chip): whoever is waited for comes
   // first — generic passes A | B.. | C (the B roles wait for A's TD target), lean passes B.. | A | C (role A
@@ -543,8 +543,8 @@ __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D =
   // critic gets its own copy of the code (a runtime-selected Net would leave the kernel-argument
   // registers: profiles/r01b_experiments.txt #10).
   if constexpr (TWIN)
-    if (role == 2) { role_b<WIDTH, LEAN, P>(A, A.critic2, A.c2X, A.c2dY, A.partials_c + (size_t)gridDim.x * 4, false, 1, smem, tp, stamp); return -1; }
-  role_b<WIDTH, LEAN, P>(A, A.critic, A.cX, A.cdY, A.partials_c, true, 0, smem, tp, stamp);
+    if (role == 2) { role_b<WIDTH, LEAN, P>(A, A.critic2, A.c2X, A.c2dY, A.partials_c + (size_t)gridDim.x * 4, false, 1, smem, tp, stamp, slice); return -1; }
+  role_b<WIDTH, LEAN, P>(A, A.critic, A.cX, A.cdY, A.partials_c, true, 0, smem, tp, stamp, slice);
   if constexpr (MERGED && P::kX2 && kDwTileX2) {
     if (A.whole) {       // (as role C above: this workgroup goes on as critic tile (slice, member))
       __syncthreads();
@@ -590,18 +590,42 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1_dw(const DdpgArgs A, c
 // N independent learners in ONE launch (grid.z = learner): the argument blocks live in device memory (N x 1.7 KB
 // does not fit the kernel-argument segment), every field read is a scalar load through one uniform pointer.
 // (SINGLE: DDPG members — the twin-critic paths compiled out; TD3 / SAC members: the lean passes, SINGLE = false)
+// Who is workgroup q of a group launch?  The hardware deals workgroups out to the eight XCDs round-robin by their
+// linear index (q % 8), and a member's slices all stream the SAME weights: dealt out slice-fastest, every XCD's L2
+// fetched every member's weights (8 x the weight bytes over the fabric — which is what bounded these launches:
+// 375 MB per phase-1 launch of 32 members at ~3 TB/s = the 130 us it took).  Here member l lives on XCD l % 8:
+// consecutive workgroups are the same position of eight consecutive members.  (n % 8 != 0: the plain order.)
 template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32, bool SINGLE = true>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase1_group(const DdpgArgs* __restrict__ batch) {
-  // Generic passes (DDPG members in exact fp32): grid (slices, 1, 3 roles x n learners), ROLE-major — every
-  // learner's role A, then every learner's role B ...: a role B workgroup finds its TD target written long ago instead
-  // of spinning for it on a compute unit beside role A's (dispatch is in block order): 32 members 71.6k -> 75.2k
-  // updates/s.  Lean passes: grid (slices, 3 x 4, n), learner-major (role-major measured 2-3 % slower there).
+  const int S = (int)gridDim.x;
   if constexpr (LEAN) {
-    (void)ddpg_phase1_body<WIDTH, LEAN, SAC, P, false, false, DwKArgs, SINGLE>(batch[blockIdx.z]);
+    // Lean passes: grid (slices, 3 or 4 roles x 4 members, n), learner-major (role-major measured 2-3 % slower there); inside
+    // a member role-major, a cluster's four members consecutive (co-dispatched)
+    const int R = (int)gridDim.y, n = (int)gridDim.z;
+    int l = (int)blockIdx.z, slice = (int)blockIdx.x, by = (int)blockIdx.y;
+    if ((n & 7) == 0) {
+      const int q = (int)blockIdx.x + S * ((int)blockIdx.y + R * (int)blockIdx.z);
+      const int p = q >> 3, inner = p % (S * R), c = inner >> 2;
+      l = (q & 7) + 8 * (p / (S * R));
+      slice = c % S;
+      by = (c / S) * 4 + (inner & 3);
+    }
+    (void)ddpg_phase1_body<WIDTH, LEAN, SAC, P, false, false, DwKArgs, SINGLE>(batch[l], nullptr, by, slice);
   } else {
+    // Generic passes (DDPG members in exact fp32): grid (slices, 1, 3 roles x n learners), ROLE-major — every learner's
+    // role A, then every learner's role B ...: a role B workgroup finds its TD target written long ago instead of spinning
+    // for it on a compute unit beside role A's (dispatch is in block order): 32 members 71.6k -> 75.2k updates/s
     static_assert(LEAN || SINGLE, "the generic passes: DDPG members only");
-    const int n = (int)gridDim.z / 3, role = (int)blockIdx.z / n, l = (int)blockIdx.z - role * n;
-    (void)ddpg_phase1_body<WIDTH, LEAN, SAC, P, false, false, DwKArgs, true>(batch[l], nullptr, role * (int)gridDim.y + (int)blockIdx.y);
+    const int n = (int)gridDim.z / 3, role = (int)blockIdx.z / n;
+    int l = (int)blockIdx.z - role * n, slice = (int)blockIdx.x;
+    const int G = batch[0].group_span;               // XCDs per member: its slices in G parts
+    if (G < 8 && ((n * G) & 7) == 0 && S % G == 0) {
+      const int r = (int)blockIdx.x + S * (int)blockIdx.z - role * S * n, Sp = S / G;
+      const int v = (r & 7) + 8 * ((r >> 3) / Sp);   // (member, part)
+      l = v / G;
+      slice = (v - l * G) * Sp + (r >> 3) % Sp;
+    }
+    (void)ddpg_phase1_body<WIDTH, LEAN, SAC, P, false, false, DwKArgs, true>(batch[l], nullptr, role * (int)gridDim.y + (int)blockIdx.y, slice);
   }
 }
 
@@ -610,7 +634,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1_group(const DdpgArgs* 
 // partials leave it); members 4..7 are done after it, members 0..3 go on to the actor's backward (clusters of 4,
 // no exchange), so the actor's dW launch still sums four partial buffers.
 template <int WIDTH, bool LEAN, bool SAC, class P, bool WIDE = false>
-__device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A) {
+__device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A, int bx_in = -1, int by_in = -1) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<WIDTH>;
   constexpr int WL = lds_ld(WIDTH);
@@ -625,15 +649,16 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A) {
   float* scr = smem + LY::scr;
   float* piS = smem + LY::xb;        // [kR][kX0Ld] tile reused for pi
   const int B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
-  const int slice = blockIdx.x;
+  const int slice = bx_in < 0 ? (int)blockIdx.x : bx_in;
+  const int by = by_in < 0 ? (int)blockIdx.y : by_in;
   const int row0 = slice * kR;
   // SAC with p2_pair: two clusters per slice, one per online critic (g = 0 / 1), side by side
   static_assert(!(WIDE && SAC), "SAC's phase 2 runs its twin critics on two clusters of 4");
   constexpr int NMC = (LEAN && WIDE) ? 8 : 4;          // members of the critic pass's clusters (lean passes)
   const int ncl = (LEAN && WIDE) ? 8 : A.nc;           // rows of the grid per cluster
   const int n_clus = SAC ? 1 + A.p2_pair : 1;
-  const int g = (SAC && (int)blockIdx.y < n_clus * ncl) ? (int)blockIdx.y / ncl : 0;
-  Tp tp{(int)blockIdx.y - g * ncl, ncl,
+  const int g = (SAC && by < n_clus * ncl) ? by / ncl : 0;
+  Tp tp{by - g * ncl, ncl,
         A.xbuf + ((size_t)g * gridDim.x + slice) * kTpStages * A.xnc * kTpBlk, A.cluster_tag, 0,
         A.err, KERN_PHASE2 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
   const bool lead = tp.c == 0;
@@ -647,7 +672,7 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A) {
     }
     ++n_stamp;
   };
-  if ((int)blockIdx.y == n_clus * ncl) {
+  if (by == n_clus * ncl) {
     // ---- prefetch row: gather the next update's rows (same draw as load_batch will not have
     // to make) and leave them contiguous for phase 1 of the next step
     float* xb = smem + LY::xb;
@@ -880,7 +905,32 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2(const DdpgArgs A) { dd
 
 template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase2_group(const DdpgArgs* __restrict__ batch) {
-  ddpg_phase2_body<WIDTH, LEAN, SAC, P>(batch[blockIdx.z]);
+  // grid (slices, cluster size [+ 1: the prefetch row], n); member l on XCD l % 8 (k_ddpg_phase1_group)
+  const int S = (int)gridDim.x, R = (int)gridDim.y, n = (int)gridDim.z;
+  int l = (int)blockIdx.z, slice = (int)blockIdx.x, by = (int)blockIdx.y;
+  if ((n & 7) == 0) {
+    const int q = (int)blockIdx.x + S * ((int)blockIdx.y + R * (int)blockIdx.z);
+    const int p = q >> 3, inner = p % (S * R);
+    l = (q & 7) + 8 * (p / (S * R));
+    if constexpr (LEAN) {           // a cluster's four members consecutive, the prefetch row's workgroups behind them
+      if (inner < 4 * S) { slice = inner >> 2; by = inner & 3; }
+      else { slice = inner - 4 * S; by = 4; }
+    } else {                        // (cluster size 1: row 0 the pass, row 1 the prefetch row)
+      slice = inner % S;
+      by = inner / S;
+      const int G = batch[0].group_span;
+      if (G > 1 && G < 8 && S % G == 0) {      // a member's slices in G parts on G XCDs
+        const int Sp = S / G, pr = p % (Sp * R);
+        const int v = (q & 7) + 8 * (p / (Sp * R));
+        l = v / G;
+        slice = (v - l * G) * Sp + pr % Sp;
+        by = pr / Sp;
+      } else if (G >= 8) {
+        l = (int)blockIdx.z; slice = (int)blockIdx.x; by = (int)blockIdx.y;
+      }
+    }
+  }
+  ddpg_phase2_body<WIDTH, LEAN, SAC, P>(batch[l], slice, by);
 }
 
 

@@ -111,11 +111,18 @@ __global__ __launch_bounds__(kDwThreads) void k_dw_adam(const DwKArgs A, const P
 // temperature step of a SAC member (AlphaJob), if it has one.
 template <int NI>
 __global__ __launch_bounds__(kDwThreads) void k_dw_adam_group(const DwKArgsN<NI>* __restrict__ batch) {
-  const DwKArgsN<NI>& A = batch[blockIdx.z];
+  // member l on XCD l % 8 (its tiles share their X / dY rows in that XCD's L2: k_ddpg_phase1_group, csrc/fused_ddpg.hip)
+  int l = (int)blockIdx.z, bx = (int)blockIdx.x;
+  if ((gridDim.z & 7) == 0) {
+    const int q = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.z, p = q >> 3;
+    l = (q & 7) + 8 * (p / (int)gridDim.x);
+    bx = p % (int)gridDim.x;
+  }
+  const DwKArgsN<NI>& A = batch[l];
   const int total = A.tile_end[NI - 1];                          // (entries past the last item hold the total)
-  if ((int)blockIdx.x > total || ((int)blockIdx.x == total && A.alpha.log_alpha == nullptr)) return;
+  if (bx > total || (bx == total && A.alpha.log_alpha == nullptr)) return;
   __shared__ __attribute__((aligned(16))) float dw_lds[kDwLdsFloats];
-  dw_adam_body<false, 0, kDwWaves, DwKArgsN<NI>>(A, dw_lds, (int)blockIdx.x);
+  dw_adam_body<false, 0, kDwWaves, DwKArgsN<NI>>(A, dw_lds, bx);
 }
 
 // flat Adam over an arena (data-parallel apply after the all-reduce; alpha-free)

@@ -2504,6 +2504,7 @@ struct oprl_group {
   bool stage_busy[2] = {false, false};
   int cur = 0;
   size_t bytes = 0;                            // one update's blocks
+  int span = 1;                                // XCDs a member's slices are dealt out to (generic passes; OPRL_AMD_GROUP_SPAN)
   int ni_c = kDwGroupItems;                    // layers per critic-step dW block (twin critics: kDwGroupItems2)
   int device = 0;                              // the device the group's buffers (and its members) live on
 };
@@ -2555,6 +2556,7 @@ extern "C" int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group*
   g->L.assign(learners, learners + n);
   (void)hipGetDevice(&g->device);
   g->ni_c = learners[0]->nc == 2 ? kDwGroupItems2 : kDwGroupItems;
+  { const char* e = getenv("OPRL_AMD_GROUP_SPAN"); g->span = e != nullptr ? atoi(e) : 1; if (g->span != 1 && g->span != 2 && g->span != 4 && g->span != 8) g->span = 1; }
   g->bytes = (size_t)n * (2 * sizeof(DdpgArgs) + dw_group_block_bytes(g->ni_c) + dw_group_block_bytes(kDwGroupItems));
   bool ok = hipMalloc((void**)&g->dev, g->bytes * kGroupChunk) == hipSuccess;
   for (int i = 0; i < 2 && ok; ++i) {
@@ -2654,6 +2656,7 @@ extern "C" int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, 
         h->epoch += 1;
         if (h->epoch == 0) { h->epoch = 1; HIPC(hipMemsetAsync(h->y_granules, 0, ((size_t)3 * h->Bmax + 256) * sizeof(unsigned long long), st)); }
         p1[l] = ddpg_args(h, B);
+        p1[l].group_span = g->span;
         RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &p1[l].cluster_tag));
         DwKArgs kd;
         // (as the un-merged launches of a solo learner; TD3 moves its targets on actor steps only)
@@ -2662,6 +2665,7 @@ extern "C" int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, 
         int ta = tiles_a;
         if (due[j]) {
           p2[l] = ddpg_args(h, B);
+          p2[l].group_span = g->span;
           RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &p2[l].cluster_tag));   // (a launch, a tag)
           p2[l].prefetch_next = prefetch;
           h->staged_ready = prefetch != 0;

@@ -716,9 +716,10 @@ def test_packed_learner_group_members_against_the_cpu_oracle(precision):
     g.close()
 
 
-@pytest.mark.parametrize("algo,precision", [("td3", "f32"), ("td3", "x2"), ("td3", "bf16"), ("sac", "f32"), ("sac", "x2"),
-                                            ("sac_tuned", "x2"), ("sac_tuned", "bf16")])
-def test_packed_twin_critic_group_equals_solo_learners(algo, precision, monkeypatch):
+@pytest.mark.parametrize("algo,precision,n_members", [("td3", "f32", 3), ("td3", "x2", 3), ("td3", "bf16", 3), ("sac", "f32", 3),
+                                                      ("sac", "x2", 3), ("sac_tuned", "x2", 3), ("sac_tuned", "bf16", 3),
+                                                      ("td3", "x2", 8), ("sac_tuned", "x2", 8)])
+def test_packed_twin_critic_group_equals_solo_learners(algo, precision, n_members, monkeypatch):
     """N3 for the twin-critic algorithms (the reference's --seeds fan-out is algorithm-agnostic, runners/train.py:24-50):
     three TD3 / SAC learners stepped as a group end bit-identical to each of them alone on clusters of four with the
     twin critics back to back (the form group members run: no co-residency requirement between clusters) — TD3's
@@ -740,8 +741,8 @@ def test_packed_twin_critic_group_equals_solo_learners(algo, precision, monkeypa
             return TD3(**kw).create()
         from oprl_amd.algos.sac import SAC
         return SAC(tune_alpha=algo == "sac_tuned", **kw).create()
-    group_members, solo = [member(i) for i in range(3)], [member(i) for i in range(3)]
-    seeds = [31, 32, 33]
+    group_members, solo = [member(i) for i in range(n_members)], [member(i) for i in range(n_members)]
+    seeds = [31 + i for i in range(n_members)]
     g = LearnerGroup(group_members)
     g.step_n(buf.handle, K, B, seeds)
     g.step_n(buf.handle, 3, B, seeds)             # a second call continues the streams (TD3: starting on a critic-only step)
@@ -768,9 +769,9 @@ def test_packed_twin_critic_group_equals_solo_learners(algo, precision, monkeypa
     g.close()
 
 
-@pytest.mark.parametrize("precision", ["f32", "x2", "bf16"])
-def test_packed_learner_group_equals_solo_learners(precision):
-    """N3: three independent DDPG learners stepped as a group (four launches per update for all of them) end
+@pytest.mark.parametrize("precision,n_members", [("f32", 3), ("x2", 3), ("bf16", 3), ("f32", 8), ("x2", 8), ("f32", 16)])
+def test_packed_learner_group_equals_solo_learners(precision, n_members):
+    """N3: three / eight / sixteen independent DDPG learners stepped as a group (four launches per update for all of them) end
     with exactly the parameters, targets and Adam moments each of them reaches alone with the same launch form
     (exact fp32: cluster size 1; x2 / bf16: the un-merged lean launches on clusters of four, set_cluster(h, 4)) — and remain ordinary learners afterwards."""
     from oprl_amd.group import LearnerGroup
@@ -783,8 +784,9 @@ def test_packed_learner_group_equals_solo_learners(precision):
         from oprl_amd.logging import NullLogger
         return DDPG(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=B,
                     precision=precision).create()
-    group_members, solo = [member(i) for i in range(3)], [member(i) for i in range(3)]
-    seeds = [11, 12, 13]
+    # (a multiple of eight members: member l's workgroups are dealt out to XCD l % 8, csrc/fused_ddpg.hip k_ddpg_phase1_group)
+    group_members, solo = [member(i) for i in range(n_members)], [member(i) for i in range(n_members)]
+    seeds = [11 + i for i in range(n_members)]
     g = LearnerGroup(group_members)
     g.step_n(buf.handle, K, B, seeds)
     g.step_n(buf.handle, 2, B, seeds)             # a second call continues the streams
