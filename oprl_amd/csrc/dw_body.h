@@ -109,15 +109,9 @@ __device__ __forceinline__ bool dw_gate_wait(const unsigned long long* flags, in
   }
   return ok;
 }
-// 16-byte / 4-byte loads that see what another XCD has just written through (sc1): a GATED tile's rows
-__device__ __forceinline__ f32x4 ld4_sc1(const float* p) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-// after an explicit s_waitcnt for such loads: redefine the loaded register, so that nothing computed from it can be
-// scheduled above the wait (volatile asms keep their order; plain arithmetic on an asm's output does not)
-__device__ __forceinline__ void sc1_arrived(f32x4& v) { asm volatile("" : "+v"(v)); }
+// loads that see what another XCD has just written through (sc1): a GATED tile's rows come in through ld4_agent
+// (engine.h: raw buffer loads with the cache policy in the instruction — loads the compiler counts), the 4-byte seeds as
+// agent-scope atomic loads
 __device__ __forceinline__ float ld1_sc1(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -337,14 +331,16 @@ __device__ __forceinline__ void dw_adam_body(const KAT& A, float* lds, int bx) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) va[h][m] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (bb < hB && an_ok) {
-        const float* src = tiled ? I.dY + ((size_t)((n_base + an) >> 4) * hB + bb) * 16 + ((n_base + an) & 15)
-                                 : I.dY + (size_t)bb * I.ldy + n_base + an;
-        va[h][0] = GATED ? ld4_sc1(src) : ld4(src);
+        const size_t off = tiled ? ((size_t)((n_base + an) >> 4) * hB + bb) * 16 + ((n_base + an) & 15)
+                                 : (size_t)bb * I.ldy + n_base + an;
+        const float* src = I.dY + off;
+        va[h][0] = GATED ? ld4_agent(I.dY, (unsigned)off) : ld4(src);
         // tensor-parallel slices leave the first layer's dz as n_part (<= 4) partial buffers
         // (csrc/tp3.h): all requested up front, summed below in member order
 #pragma unroll
         for (int m = 1; m < 4; ++m)
-          if (m < npart) va[h][m] = GATED ? ld4_sc1(src + (size_t)m * I.dY_part_stride) : ld4(src + (size_t)m * I.dY_part_stride);
+          if (m < npart)
+            va[h][m] = GATED ? ld4_agent(I.dY, (unsigned)(off + (size_t)m * I.dY_part_stride)) : ld4(src + (size_t)m * I.dY_part_stride);
       }
     };
     auto load_rs = [&](int h) {
@@ -362,8 +358,8 @@ __device__ __forceinline__ void dw_adam_body(const KAT& A, float* lds, int bx) {
       const int bb = base + xr + 8 * j;
       vx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (bb < hB && xk_ok) {
-        const float* src = I.X + (size_t)bb * I.ldx + k_base + xk;
-        vx[j] = GATED ? ld4_sc1(src) : ld4(src);
+        const size_t off = (size_t)bb * I.ldx + k_base + xk;
+        vx[j] = GATED ? ld4_agent(I.X, (unsigned)off) : ld4(I.X + off);
       }
     }
     if constexpr (GATED) {
@@ -393,8 +389,6 @@ __device__ __forceinline__ void dw_adam_body(const KAT& A, float* lds, int bx) {
           if (n_base + an == 0 && bb < hB) va[h][0][0] = sd;   // (rows past the minibatch stay zero)
         }
       }
-      // the sc1 row loads are inline asm: hipcc does not count them — wait for them here, before the rows are staged
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     stamp();   // rows requested
 #pragma unroll

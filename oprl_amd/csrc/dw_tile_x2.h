@@ -219,9 +219,9 @@ struct DwX2Tile {
   f32x4 u = z4;          // GATE 1: the unit-seed dY of this lane
   if (gate == 1) {
     __syncthreads();     // role B's members have flagged their rows (written through): X and the unit-seed dY
-    // The write-through rows are read with inline-asm sc1 loads, which hipcc neither counts nor orders: they are
-    // issued UNCONDITIONALLY, from clamped addresses, in one straight line up to the explicit wait — a load under a
-    // branch gets its result register copied (and then reused) at the branch's end, before the data has arrived.
+    // The write-through rows are read past this XCD's L2 (sc1) with raw buffer loads (engine.h ld4_agent: loads the
+    // compiler counts; round 3's first form — the same instruction as inline asm + an explicit wait — left the result
+    // registers open to being copied before the data had arrived); from clamped addresses, unconditionally.
     const bool late = I.dY == G.late_dY;          // the output layer: dY IS the seed (one column): U = e_0
     const int npart = I.dY_part_stride > 0 ? h_n_part : 1;
     const bool tiled = I.dY_part_stride > 0 && h_tiled != 0;
@@ -229,17 +229,12 @@ struct DwX2Tile {
     const bool c0 = k_base + xq < I.ldx, c1 = k_base + 32 + xq < I.ldx;
     const int xc0 = c0 ? k_base + xq : 0, xc1 = c1 ? k_base + 32 + xq : 0;
     const int ub = bb < hB ? bb : hB - 1, uc = (an_ok && !late) ? ncol : 0;
-    const float* usrc = tiled ? I.dY + ((size_t)(uc >> 4) * hB + ub) * 16 + (uc & 15) : I.dY + (size_t)ub * I.ldy + uc;
-    const size_t ps = (size_t)I.dY_part_stride;
-    f32x4 r00 = ld4_sc1(I.X + (size_t)xr0 * I.ldx + xc0), r01 = ld4_sc1(I.X + (size_t)xr1 * I.ldx + xc0);
-    f32x4 r10 = ld4_sc1(I.X + (size_t)xr0 * I.ldx + xc1), r11 = ld4_sc1(I.X + (size_t)xr1 * I.ldx + xc1);
-    f32x4 pa0 = ld4_sc1(usrc), pa1 = ld4_sc1(usrc + (npart > 1 ? ps : 0)), pa2 = ld4_sc1(usrc + (npart > 2 ? 2 * ps : 0)),
-          pa3 = ld4_sc1(usrc + (npart > 3 ? 3 * ps : 0));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // (... and every loaded register is REDEFINED by an asm placed after the wait: arithmetic on an asm's output has
-    // no dependence on a later asm, and hipcc had hoisted the 2^4 scaling of the X rows above the wait)
-    sc1_arrived(r00); sc1_arrived(r01); sc1_arrived(r10); sc1_arrived(r11);
-    sc1_arrived(pa0); sc1_arrived(pa1); sc1_arrived(pa2); sc1_arrived(pa3);
+    const unsigned uoff = tiled ? (unsigned)(((uc >> 4) * hB + ub) * 16 + (uc & 15)) : (unsigned)(ub * I.ldy + uc);
+    const unsigned ps = (unsigned)I.dY_part_stride;
+    const f32x4 r00 = ld4_agent(I.X, (unsigned)(xr0 * I.ldx + xc0)), r01 = ld4_agent(I.X, (unsigned)(xr1 * I.ldx + xc0));
+    const f32x4 r10 = ld4_agent(I.X, (unsigned)(xr0 * I.ldx + xc1)), r11 = ld4_agent(I.X, (unsigned)(xr1 * I.ldx + xc1));
+    const f32x4 pa0 = ld4_agent(I.dY, uoff), pa1 = ld4_agent(I.dY, uoff + (npart > 1 ? ps : 0u)),
+                pa2 = ld4_agent(I.dY, uoff + (npart > 2 ? 2u * ps : 0u)), pa3 = ld4_agent(I.dY, uoff + (npart > 3 ? 3u * ps : 0u));
     vx[0][0] = (c0 && xb0 < hB) ? r00 : z4;
     vx[0][1] = (c0 && xb0 + 1 < hB) ? r01 : z4;
     vx[1][0] = (c1 && xb0 < hB) ? r10 : z4;

@@ -111,6 +111,17 @@ __device__ __forceinline__ bf16x8 cvt_bf16x8(const f32x4 lo, const f32x4 hi) {
   return __builtin_convertvector(v, bf16x8);
 }
 
+// A 16-byte load that goes past this XCD's L2 (sc1: what a workgroup on another XCD has just written through) as a
+// load the COMPILER sees: a raw buffer load with the cache policy in its aux operand.  (The same instruction as inline
+// asm is invisible to hipcc's wait-count insertion and to its register allocator — result registers copied or reused
+// before the explicit s_waitcnt: r03-37, tools/check_asm_loads.py.)
+typedef unsigned u32x4_ld __attribute__((ext_vector_type(4)));
+// `base`: the same in every lane (the buffer resource lives in scalar registers), `float_off` < 2^29: this lane's element.
+__device__ __forceinline__ f32x4 ld4_agent(const float* base, unsigned float_off) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, float_off * 4u, 0, 16 /* sc1 */));
+}
+
 struct PrecF32 {
   static constexpr int KS = 16;
   static constexpr bool kBf16 = false;

@@ -293,13 +293,9 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
         const int row = idx >> 7, col = (idx & 127) * 4, gr = row0 + row;
         v[h] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (gr < B) {
-          // agent-scope loads (sc1: past this XCD's L2), as loads the compiler counts — an inline-asm load's result
-          // registers are copied and reused before it has returned (seen in the bf16 instance: a memory fault)
-          const unsigned long long* q = reinterpret_cast<const unsigned long long*>(src + (size_t)gr * WIDTH + col);
-          const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          v[h] = f32x4{__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
-                       __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32))};
+          // an agent-scope load (sc1: past this XCD's L2) the compiler counts (engine.h ld4_agent) — an inline-asm load's
+          // result registers were copied and reused before it had returned (the bf16 instance: a GPU memory fault)
+          v[h] = ld4_agent(src, (unsigned)(gr * WIDTH + col));
         }
         if (!ok) v[h] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};   // a lost producer shows up as NaN
       }

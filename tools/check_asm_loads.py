@@ -2,7 +2,8 @@
 load is asynchronous, so nothing stops it from copying or reusing the result registers before the explicit
 `s_waitcnt vmcnt(0)` that follows in the source (seen once: k_lw_mid_pair<.., PrecBF16>, a memory fault — r03-37).
 For every `global_load` inside an ASMSTART / ASMEND bracket, no instruction up to the next `s_waitcnt vmcnt(0)` may
-name one of its result registers.
+name one of its result registers.  (Since r03-40 the kernels hold no such load: engine.h ld4_agent, a raw buffer load
+the compiler counts.  The check stays as a guard.)
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S x.hip -o x.s && python tools/check_asm_loads.py x.s
 """
