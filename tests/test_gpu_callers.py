@@ -716,6 +716,41 @@ def test_packed_learner_group_members_against_the_cpu_oracle(precision):
     g.close()
 
 
+@pytest.mark.parametrize("precision", ["f32", "x2"])
+def test_packed_learner_group_ragged_batch_and_checkpoint(precision):
+    """Eight members at a ragged batch (B = 100: seven slices, the last one partial — the member -> XCD deal of the group
+    launches with a slice count that is not a multiple of eight), a member restored from its own checkpoint in between:
+    still bit-identical to the solo twins."""
+    from oprl_amd.algos.ddpg import DDPG
+    from oprl_amd.group import LearnerGroup
+    from oprl_amd.logging import NullLogger
+    B, n = 100, 8
+    buf = _filled_buffer()
+
+    def member(i):
+        t.manual_seed(140 + i)
+        return DDPG(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=128,
+                    precision=precision).create()
+    members, solo = [member(i) for i in range(n)], [member(i) for i in range(n)]
+    seeds = [51 + i for i in range(n)]
+    g = LearnerGroup(members)
+    g.step_n(buf.handle, 5, B, seeds)
+    t.cuda.synchronize()
+    sd = members[3].learner.state_dict()
+    members[3].learner.load_state_dict(sd)           # (packs rebuilt from the masters, counters restored)
+    g.step_n(buf.handle, 4, B, seeds)
+    for a, s in zip(solo, seeds):
+        assert a.learner.lib.oprl_learner_set_cluster(a.learner.handle, 1 if precision == "f32" else 4) == 0
+        a.learner.step_n(buf.handle, 5, B, seed=s)
+        a.learner.step_n(buf.handle, 4, B, seed=s)
+    t.cuda.synchronize()
+    for a, b in zip(members, solo):
+        for m in ("actor", "critic", "actor_target", "critic_target"):
+            assert t.equal(getattr(a, m)._oprl_arena, getattr(b, m)._oprl_arena), m
+        a.learner.check()
+    g.close()
+
+
 @pytest.mark.parametrize("algo,precision,n_members", [("td3", "f32", 3), ("td3", "x2", 3), ("td3", "bf16", 3), ("sac", "f32", 3),
                                                       ("sac", "x2", 3), ("sac_tuned", "x2", 3), ("sac_tuned", "bf16", 3),
                                                       ("td3", "x2", 8), ("sac_tuned", "x2", 8)])
