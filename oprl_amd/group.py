@@ -23,6 +23,8 @@ class LearnerGroup:
         self.algos = list(algos)
         self.lib = _capi.load()
         self.device = self.algos[0].learner.device
+        if any(a.learner.device != self.device for a in self.algos):
+            raise ValueError("LearnerGroup: every member must live on the same GPU")
         handles = (C.c_void_p * len(self.algos))(*[a.learner.handle for a in self.algos])
         g = C.c_void_p()
         with _capi.on_device(self.device):
