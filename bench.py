@@ -344,10 +344,46 @@ def packed_group(n, dev, local_rank, steps):
     for a in algos:
         a.learner.check()
     g.close()
+    del algos, g, solo
     return dict(learners=n, value=round(n * steps / dt, 1), unit="steps/s (aggregate)",
                 us_per_group_update=round(dt / steps * 1e6, 1), steps_each=steps,
-                path="oprl_group_step_n: 4 launches per update for the whole group (grid.z = learner; one argument copy per 4 updates), exact fp32, cluster size 1",
-                verified=dict(all_finite=finite, member0_equals_solo_run_at_cluster_1=same))
+                path="oprl_group_step_n: 4 launches per update for the whole group (grid.z = learner, member l on XCD l % 8; one argument copy per 4 updates), exact fp32, cluster size 1",
+                verified=dict(all_finite=finite, member0_equals_solo_run_at_cluster_1=same),
+                other_members=packed_group_variants(n, dev, local_rank, handle, max(100, steps // 3)))
+
+
+def packed_group_variants(n, dev, local_rank, handle, steps):
+    """The same group call with members of the other kinds it takes (TD3 / SAC: the reference's --seeds fan-out is
+    algorithm-agnostic; the x2 parity mode): lean passes on clusters of four.  Short runs; verified finite and clean."""
+    from oprl_amd.algos.ddpg import DDPG
+    from oprl_amd.algos.sac import SAC
+    from oprl_amd.algos.td3 import TD3
+    from oprl_amd.group import LearnerGroup
+    from oprl_amd.logging import NullLogger
+    out = []
+    for name, cls, kw, prec in (("DDPG", DDPG, {}, "x2"), ("TD3", TD3, dict(log_every=10 ** 9), "x2"),
+                                ("SAC (learned temperature)", SAC, dict(log_every=10 ** 9, tune_alpha=True), "x2")):
+        algos = []
+        for i in range(n):
+            t.manual_seed(300 + i)
+            algos.append(cls(logger=NullLogger(), state_dim=S, action_dim=A, device=f"cuda:{local_rank}", max_batch=B,
+                             precision=prec, **kw).create())
+        g = LearnerGroup(algos)
+        seeds = [2000 + i for i in range(n)]
+        g.step_n(handle, 50, B, seeds)
+        t.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        g.step_n(handle, steps, B, seeds)
+        t.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        for a in algos:
+            a.learner.check()
+        finite = all(bool(t.isfinite(a.actor._oprl_arena).all()) and bool(t.isfinite(a.critic._oprl_arena).all()) for a in algos)
+        g.close()
+        del algos, g
+        out.append(dict(algo=name, dtype=DTYPE_OF[prec], learners=n, value=round(n * steps / dt, 1), unit="steps/s (aggregate)",
+                        steps_each=steps, all_finite=finite))
+    return out
 
 
 def dp_single_rank(dev, local_rank, replay, precision, steps):
