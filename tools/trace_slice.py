@@ -17,6 +17,9 @@ t.manual_seed(0)
 algo = DDPG(logger=NullLogger(), state_dim=S, action_dim=A, device="cuda", max_batch=B,
             no_fuse="--generic" in sys.argv, precision="bf16" if "--bf16" in sys.argv else ("x2" if "--x2" in sys.argv else "f32")).create()
 L = algo.learner
+for a in sys.argv:             # --cluster=1: the single-CU-per-slice passes (what packed exact-fp32 learners run)
+    if a.startswith("--cluster="):
+        L.set_cluster(int(a.split("=")[1]))
 NS, NST = 24, 24
 buf = t.zeros((NS, 64, NST, 2), dtype=t.int64, device="cuda")
 batch = [t.randn(B, S, device="cuda"), t.rand(B, A, device="cuda") * 2 - 1, t.rand(B, 1, device="cuda"),
