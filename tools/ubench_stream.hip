@@ -28,6 +28,12 @@ __global__ void k_stream(const float* __restrict__ w, long wg_stride_f, long byt
         long c = c0 + (long)u * nw;
         long off;
         if (PATTERN == 0) off = c * 256 + lane * 4;
+        else if (PATTERN == 2) {
+          // what gemm_packed's wide path does: wave w streams ITS tile's 16 macro steps (16 KB, consecutive 1 KB blocks),
+          // the waves of a workgroup are 16 KB apart; tiles w, w + nw, ... (c = wave + k * nw -> tile = c % nw + nw * (k / 16), step = k % 16)
+          const long k = c / nw, wv = c % nw;
+          off = ((k / 16) * nw + wv) * 4096 + (k % 16) * 256 + lane * 4;
+        }
         else { long blk = c / 16, sub = c % 16; off = blk * 4096 + (lane & 15) * 256 + sub * 16 + (lane >> 4) * 4; }
         v[u] = (c * 256 < nf) ? *reinterpret_cast<const f32x4*>(base + off) : f32x4{0, 0, 0, 0};
       }
@@ -68,6 +74,9 @@ int main() {
   hipMemset(w, 0, total_f * 4);
   const long KB256 = 256 * 1024;
   for (int thr : {256, 512, 1024}) {
+    run<2, 8>("tile-per-wave u8 ", w, total_f, 16, thr, KB256, true, 3, out, cyc);
+    run<2, 8>("tile-per-wave u8 ", w, total_f, 256, thr, KB256, true, 3, out, cyc);
+    run<0, 8>("contig  unroll8  ", w, total_f, 256, thr, KB256, true, 3, out, cyc);
     run<0, 8>("contig  unroll8  ", w, total_f, 16, thr, KB256, true, 3, out, cyc);
     run<1, 8>("frag16x64 unroll8", w, total_f, 16, thr, KB256, true, 3, out, cyc);
   }
