@@ -31,8 +31,23 @@ __global__ void k_stream(const float* __restrict__ w, long wg_stride_f, long byt
         else if (PATTERN == 2) {
           // what gemm_packed's wide path does: wave w streams ITS tile's 16 macro steps (16 KB, consecutive 1 KB blocks),
           // the waves of a workgroup are 16 KB apart; tiles w, w + nw, ... (c = wave + k * nw -> tile = c % nw + nw * (k / 16), step = k % 16)
-          const long k = c / nw, wv = c % nw;
-          off = ((k / 16) * nw + wv) * 4096 + (k % 16) * 256 + lane * 4;
+          const int lg = 31 - __builtin_clz(nw);                     // (nw is a power of two: no 64-bit divisions in the address)
+          const int ci = (int)c, k = ci >> lg, wv = ci & (nw - 1);
+          off = (long)((((k >> 4) << lg) + wv) * 4096 + (k & 15) * 256 + lane * 4);
+        }
+        else if (PATTERN == 5 || PATTERN == 6) {
+          // tile-per-wave, a wave's consecutive requests 4 KB (5) / 2 KB (6) apart inside its tile: steps 0, 4, 8, 12, 1, 5, ...
+          const int lg = 31 - __builtin_clz(nw);
+          const int ci = (int)c, k = ci >> lg, wv = ci & (nw - 1), kk = k & 15;
+          const int st = PATTERN == 5 ? (kk & 3) * 4 + (kk >> 2) : (kk & 7) * 2 + (kk >> 3);
+          off = (long)((((k >> 4) << lg) + wv) * 4096 + st * 256 + lane * 4);
+        }
+        else if (PATTERN == 3 || PATTERN == 4) {
+          // tile-per-wave with a per-wave skew of the step order: wave w starts at step w (3) / 4 w (4) of its tile
+          const int lg = 31 - __builtin_clz(nw);
+          const int ci = (int)c, k = ci >> lg, wv = ci & (nw - 1);
+          const int st = ((k & 15) + (PATTERN == 3 ? wv : 4 * wv)) & 15;
+          off = (long)((((k >> 4) << lg) + wv) * 4096 + st * 256 + lane * 4);
         }
         else { long blk = c / 16, sub = c % 16; off = blk * 4096 + (lane & 15) * 256 + sub * 16 + (lane >> 4) * 4; }
         v[u] = (c * 256 < nf) ? *reinterpret_cast<const f32x4*>(base + off) : f32x4{0, 0, 0, 0};
@@ -76,6 +91,12 @@ int main() {
   for (int thr : {256, 512, 1024}) {
     run<2, 8>("tile-per-wave u8 ", w, total_f, 16, thr, KB256, true, 3, out, cyc);
     run<2, 8>("tile-per-wave u8 ", w, total_f, 256, thr, KB256, true, 3, out, cyc);
+    run<5, 8>("tile-per-wave str4K", w, total_f, 256, thr, KB256, true, 3, out, cyc);
+    run<6, 8>("tile-per-wave str2K", w, total_f, 256, thr, KB256, true, 3, out, cyc);
+    run<3, 8>("tile-per-wave skew1", w, total_f, 256, thr, KB256, true, 3, out, cyc);
+    run<4, 8>("tile-per-wave skew4", w, total_f, 256, thr, KB256, true, 3, out, cyc);
+    run<2, 4>("tile-per-wave u4 ", w, total_f, 256, thr, KB256, true, 3, out, cyc);
+    run<2, 16>("tile-per-wave u16", w, total_f, 256, thr, KB256, true, 3, out, cyc);
     run<0, 8>("contig  unroll8  ", w, total_f, 256, thr, KB256, true, 3, out, cyc);
     run<0, 8>("contig  unroll8  ", w, total_f, 16, thr, KB256, true, 3, out, cyc);
     run<1, 8>("frag16x64 unroll8", w, total_f, 16, thr, KB256, true, 3, out, cyc);
