@@ -248,6 +248,14 @@ struct PrecX2 {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
   }
+  // ... the same with the A operand split ONCE by the caller (an A block that meets several B tiles: the split is 16
+  // VALU operations, the three MFMAs are 96 cycles of the matrix pipe)
+  __device__ static __forceinline__ void mma3_split(const f16x8 ah, const f16x8 al, const Frag& b, f32x4& acc) {
+    const f16x8 bh = __builtin_bit_cast(f16x8, b.hi), bl = __builtin_bit_cast(f16x8, b.lo);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+  }
   __device__ static __forceinline__ void mac(const float* xr, int s, const Frag& b, f32x4& acc) {
     mma3(ld4(xr + 32 * s), ld4(xr + 32 * s + 16), b, acc);
   }

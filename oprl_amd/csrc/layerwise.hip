@@ -149,6 +149,12 @@ struct LwRun2 { int slices, nets, rpn, base, rem, ppx; };   // runs per net; til
 // up; 2 = the second layer's — weight fragments, bias / masks first, then a bounded wait for the rpn flags of its
 // (net, slice), then the rows with sc1 loads.  MAXRUN: the longest run of column tiles (the partial tiles' LDS).
 struct LwPair { unsigned long long* flags; unsigned tag; int spin; unsigned* err; };
+#ifdef LW_TRACE            // tools/ubench_lw.hip: stage stamps of the hidden-layer workgroups (100 MHz wall clock)
+__device__ unsigned long long g_lw_trace[4096 * 8];
+#define LW_STAMP(k) do { if (threadIdx.x == 0 && bx < 4096) g_lw_trace[bx * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define LW_STAMP(k) do { } while (0)
+#endif
 constexpr int kLwFlagStride = 32;             // flags per (net, slice): rpn <= 32
 template <int MODE, class P, int ROLE = 0, int MAXRUN = 6>
 __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, const LwRun2& R, int bx, int net0,
@@ -174,6 +180,7 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
   const MlpArgs& A = KM->a[net0 + net];
   const int row0 = slice * kLw2Rows, B = A.B;
   const int ke = wave & 7, par = wave >> 3;
+  LW_STAMP(0);
 
   // ---- requests, in the order of use: rows, (first-layer fragments,) B fragments, bias / masks
   f32x4 v[4];
@@ -234,6 +241,7 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
     if (e_ok[k]) e_x[k] = BWD ? A.Xg[l][e_off[k]] : A.net.b[l][col];
   }
   __builtin_amdgcn_sched_barrier(0);
+  LW_STAMP(1);
 
   if constexpr (FIN) {
     xin[(tid >> 5) * kX0Ld + (tid & 31)] = x0v;
@@ -308,6 +316,7 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
     __syncthreads();
   }
 
+  LW_STAMP(2);
   // ---- partial tiles: the wave's K-eighth of its tiles, both row tiles against the same B fragments
   f32x4 acc[3][2];
   if constexpr (P::kX2) {
@@ -332,6 +341,13 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
     const float s1 = P::a_scale(m), un = P::kOut / s1;
+    // the A block meets up to three B tiles: split into its fp16 hi / lo planes ONCE (per tile it was 2/3 of the VALU
+    // work of this phase, r03-42: 96 v_fma_mix + 96 v_cvt per wave for 36 MFMAs)
+    f16x8 ah[2][NSE], al[2][NSE];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int s = 0; s < NSE; ++s) x2_split8(xa[rt][s][0] * s1, xa[rt][s][1] * s1, ah[rt][s], al[rt][s]);
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -339,7 +355,7 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
         acc[q][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (par + 2 * q < nt) {
 #pragma unroll
-          for (int s = 0; s < NSE; ++s) P::mma3(xa[rt][s][0] * s1, xa[rt][s][1] * s1, b[q][s], acc[q][rt]);
+          for (int s = 0; s < NSE; ++s) P::mma3_split(ah[rt][s], al[rt][s], b[q][s], acc[q][rt]);
           acc[q][rt] *= un;
         }
       }
@@ -356,7 +372,9 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
         }
       }
   }
+  LW_STAMP(3);
   __syncthreads();                            // every wave is done with the rows: the partial tiles go over them
+  LW_STAMP(4);
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     const int tl = par + 2 * q;
@@ -366,6 +384,7 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
         *reinterpret_cast<f32x4*>(scr + ((size_t)((rt * MAXRUN + tl) * 8 + ke) * 64 + lane) * 4) = acc[q][rt];
   }
   __syncthreads();
+  LW_STAMP(5);
 
   // ---- K-ordered sum, bias + ReLU (forward) or ReLU mask (backward), rows out
   float* dst = BWD ? A.dYg[l - 1] : A.Xg[l + 1];
@@ -382,6 +401,7 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
     if constexpr (ROLE == 1) __hip_atomic_store(dst + e_off[k], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written through
     else dst[e_off[k]] = res;
   }
+  LW_STAMP(6);
   if constexpr (ROLE == 1) {
     // every wave's rows are out before the workgroup says so
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
