@@ -124,6 +124,7 @@ __device__ __forceinline__ f32x4 ld4_agent(const float* base, unsigned float_off
 
 struct PrecF32 {
   static constexpr int KS = 16;
+  __device__ static __forceinline__ bool range_ok(float) { return true; }   // (PrecX2's forward range check: nothing to check here)
   static constexpr bool kBf16 = false;
   static constexpr bool kX2 = false;
   // the policy-independent part of the interface (PrecX2 below is where it matters): a macro step's B fragment, the
@@ -152,6 +153,7 @@ struct PrecF32 {
 
 struct PrecBF16 {
   static constexpr int KS = 32;
+  __device__ static __forceinline__ bool range_ok(float) { return true; }   // (PrecX2's forward range check: nothing to check here)
   static constexpr bool kBf16 = true;
   static constexpr bool kX2 = false;
   typedef f32x4 Frag;
@@ -196,8 +198,12 @@ struct PrecBF16 {
 //     elements sit far below fp16's normal range (2^-14).  a_scale(m) = 2^(10 - exponent of m), m the largest
 //     magnitude the tile can hold; below 2^-25 of that an element contributes its hi part only (fixed point).
 //   Accumulators come out as 2^8 a_scale times the product: every epilogue multiplies by kOut / a_scale (exact).
-// Range: forward activations go in unscaled, |x| < 65504 (fp16's largest number; beyond that the split is inf - inf
-// = NaN and the poison reaches every output: loud, not silent).
+// Range: forward activations go in as 2^4 x (kFwdA): |x| < 4094 (PrecX2::kActMax) — beyond that the hi plane is inf, the
+// residual -inf and every product NaN, which a ReLU would quietly turn into 0.  So every stage of the lean passes that
+// writes activations for a later stage checks what it writes (PrecX2::range_ok: NaN or >= kActMax -> the learner's error
+// word, SITE_X2_RANGE: the host raises on the same update); raw observations are caught by the first layer's check
+// (their NaN products), weights by the same route (|w| >= 256 overflows the 2^8 w packs).  Gradient tiles scale
+// themselves (a_scale) and have no such limit.
 // ---------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned x2u4 __attribute__((ext_vector_type(4)));
@@ -268,11 +274,17 @@ struct PrecX2 {
     const f32x4 hi = (2 * s + 1 < k16) ? ld4(xr + 32 * s + 16) : f32x4{0.f, 0.f, 0.f, 0.f};
     mma3(lo * sc, hi * sc, b, acc);
   }
-  // 2^(10 - e) for m in [2^e, 2^(e+1)); 1 for m = 0 (an all-zero tile)
+  // 2^(10 - e) for m in [2^e, 2^(e+1)); 1 for m = 0 (an all-zero tile).  The scale's exponent field is clamped to 254
+  // (2^127): a tile whose largest magnitude lies below 2^-117 would otherwise get inf (or a sign bit) for a scale, and
+  // inf times the tile's zeros is NaN
   __device__ static __forceinline__ float a_scale(float m) {
     const unsigned e = (__float_as_uint(m) >> 23) & 0xffu;
-    return e == 0u ? 1.f : __uint_as_float((unsigned)(127 + 10 + 127 - (int)e) << 23);
+    const unsigned f = 127u + 10u + 127u - e;
+    return e == 0u ? 1.f : __uint_as_float((f > 254u ? 254u : f) << 23);
   }
+  // what a forward stage may hand to the next one: finite and below fp16's range after the 2^4 scale
+  static constexpr float kActMax = 4094.f;
+  __device__ static __forceinline__ bool range_ok(float pre) { return pre < kActMax; }     // (false for NaN)
   // the first matrix element of a fragment block (pointer at the lane's hi quad)
   __device__ static __forceinline__ float first(const float* frag) {
     const unsigned h = *reinterpret_cast<const unsigned*>(frag) & 0xffffu, l = *reinterpret_cast<const unsigned*>(frag + 256) & 0xffffu;

@@ -1596,10 +1596,18 @@ int check_device_error(const oprl_learner* h) {
                                "gate of the dW tiles riding on a phase launch (a role never flagged its rows / seeds)",
                                "hand-over between the two hidden layers of one launch (a first-layer workgroup never flagged its rows)"};
   const unsigned k = (code >> 8) & 0xff, w = code & 0xff;
+  if (w == 9) {     // SITE_X2_RANGE (csrc/tp3.h): not a wait
+    set_err("device error 0x%x: an activation left the range of the split-fp16 mode (precision='x2': |x| < 4094 for observations and "
+            "hidden activations, |w| < 256 for weights) in %s; the results of that update (and everything after it) are poisoned.  "
+            "Normalise the observations or create the learner with precision='f32' (exact fp32, no such range).  Restore a "
+            "checkpoint, then oprl_learner_clear_error().", code, k < 7 ? kern[k] : "?");
+    return OPRL_ERR_STATE;
+  }
   set_err("device error 0x%x: a bounded cross-workgroup wait expired in %s at the %s; the results of that "
           "update (and everything after it) are poisoned with NaN.  Typical causes: the launch's workgroups were "
           "not co-resident (another process or learner held the GPU's compute units for longer than the wait bound), "
-          "or a data-parallel peer died.  Restore a checkpoint, then oprl_learner_clear_error().",
+          "or a data-parallel peer died.  Restore a checkpoint, then oprl_learner_clear_error() — after which this learner "
+          "runs the launch forms for a shared GPU (set_cluster(4): no workgroup waits for another role of its own launch).",
           code, k < 7 ? kern[k] : "?", w < 9 ? site[w] : "?");
   return OPRL_ERR_STATE;
 }
@@ -1616,7 +1624,20 @@ extern "C" int oprl_learner_check(oprl_learner* h) {
 
 extern "C" int oprl_learner_clear_error(oprl_learner* h) {
   if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
-  if (h->err_host) *(volatile unsigned*)h->err_host = 0;
+  if (h->err_host) {
+    // A bounded wait that expired inside a launch whose workgroups wait for each other ACROSS roles (the whole-update
+    // and merged launches: tiles for roles, the critic pass for tiles) means those workgroups were not running side by
+    // side — the chip is shared (another process, an eval / actor process on the same GPU, a partitioned device).  The
+    // learner then goes on, after the caller's restore, with the forms that cross a kernel boundary instead:
+    // set_cluster(< 8) semantics, as for learners that share a GPU by design.
+    const unsigned code = *(volatile unsigned*)h->err_host, w = code & 0xff;
+    if (code != 0 && w != 9 /* SITE_X2_RANGE */ && w != 5 && w != 6 /* data-parallel peers */ && !h->debug_expire && !h->shared_chip) {
+      h->shared_chip = true;
+      h->no_whole = 1;
+      h->no_wide = 1;
+    }
+    *(volatile unsigned*)h->err_host = 0;
+  }
   return OPRL_OK;
 }
 
@@ -2612,9 +2633,35 @@ extern "C" int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, 
   if (S != h0->S || A != h0->A) { set_err("replay dims (%d,%d) != group dims (%d,%d)", S, A, h0->S, h0->A); return OPRL_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   RC(oprl_replay_flush(replay, stream));
+  // everything that can be refused is checked BEFORE any member's counters move: the members advance together, so
+  // being in phase now is being in phase for all K updates
+  for (int l = 0; l < n; ++l) {
+    RC(check_device_error(g->L[l]));
+    if (actor_due(g->L[l]) != actor_due(h0) || g->L[l]->cfg.hp.policy_freq != h0->cfg.hp.policy_freq) {
+      set_err("oprl_group_step_n: the members' delayed actor steps are out of phase (update counts differ modulo policy_freq)");
+      return OPRL_ERR_STATE;
+    }
+  }
+  // (what is left — an internal inconsistency of the launch tables — rolls the members' counters back to here)
+  struct Snap { unsigned epoch, tp_tag; long long update_count; int oc, oa, oal; bool staged, aul, s0, s1; };
+  std::vector<Snap> snap(n);
+  auto take = [&]() {
+    for (int l = 0; l < n; ++l) {
+      const oprl_learner* h = g->L[l];
+      snap[l] = Snap{h->epoch, h->tp_tag, (long long)h->update_count, (int)h->opt_step_critic, (int)h->opt_step_actor, (int)h->opt_step_alpha,
+                     h->staged_ready, h->actor_updated_last, h->stale32[0], h->stale32[1]};
+    }
+  };
+  auto roll_back = [&]() {
+    for (int l = 0; l < n; ++l) {
+      oprl_learner* h = g->L[l];
+      const Snap& q = snap[l];
+      h->epoch = q.epoch; h->tp_tag = q.tp_tag; h->update_count = q.update_count; h->opt_step_critic = q.oc; h->opt_step_actor = q.oa;
+      h->opt_step_alpha = q.oal; h->staged_ready = q.staged; h->actor_updated_last = q.aul; h->stale32[0] = q.s0; h->stale32[1] = q.s1;
+    }
+  };
   for (int l = 0; l < n; ++l) {
     oprl_learner* h = g->L[l];
-    RC(check_device_error(h));
     BatchSrc& sc = h->src;
     long n_tr = 0;
     replay_view(replay, &sc.states, &sc.actions, &sc.rewards, &sc.dones, &sc.ends, &sc.n_eps, &sc.L, &n_tr);
@@ -2634,6 +2681,7 @@ extern "C" int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, 
     const int m = K - k0 < kGroupChunk ? K - k0 : kGroupChunk;
     const int c = g->cur;
     if (g->stage_busy[c]) { HIPC(hipEventSynchronize(g->stage_ev[c])); g->stage_busy[c] = false; }
+    take();                                   // nothing of this chunk has been launched until its blocks are complete
     int tiles_c = 0, tiles_a = 0;
     DdpgArgs first[kGroupChunk][2];           // member 0's blocks of each update (for the grids)
     bool due[kGroupChunk];                    // TD3: the actor steps every policy_freq updates — of ALL members at once
@@ -2647,7 +2695,7 @@ extern "C" int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, 
       for (int l = 0; l < n; ++l) {
         oprl_learner* h = g->L[l];
         const oprl_learner_config& cf = h->cfg;
-        if (actor_due(h) != due[j]) { set_err("oprl_group_step_n: the members' delayed actor steps are out of phase (update counts differ modulo policy_freq)"); return OPRL_ERR_STATE; }
+        if (actor_due(h) != due[j]) { roll_back(); set_err("oprl_group_step_n: the members' delayed actor steps are out of phase (update counts differ modulo policy_freq)"); return OPRL_ERR_STATE; }
         h->src.counter = (unsigned long long)h->update_count;
         h->next_src.counter = h->src.counter + 1;
         h->src.gather = h->staged_ready ? 0 : 1;
@@ -2676,6 +2724,7 @@ extern "C" int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, 
         }
         if (l == 0 && j == 0) tiles_c = tc;
         if (tc < 0 || ta < 0 || tc != tiles_c || p1[l].nc != p1[0].nc || p1[l].merged || p1[l].wide || p1[l].whole || p1[l].twin_split) {
+          roll_back();
           set_err("oprl_group_step_n: internal: bad launch arguments");
           return OPRL_ERR_INVALID;
         }

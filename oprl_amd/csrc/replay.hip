@@ -355,13 +355,16 @@ extern "C" int oprl_replay_set_lens(oprl_replay* h, const int32_t* ep_lens_host,
     return OPRL_ERR_INVALID;
   }
   (void)stream;      // (the table goes up with the next flush — every reader flushes first — on ITS stream)
+  // validate the whole table BEFORE touching the mirrors: a bad entry midway must not leave ends_last ahead of what
+  // the device holds (the next valid call would then see "no difference" and never upload those entries)
+  for (int i = 0; i < episodes_counter; ++i)
+    if (ep_lens_host[i] < 0 || ep_lens_host[i] > h->L) { set_err("ep_lens[%d]=%d out of range", i, ep_lens_host[i]); return OPRL_ERR_INVALID; }
   const int c = h->ends_cur;
   if (!h->ends_pending && h->ends_busy[c]) { HIPC(hipEventSynchronize(h->ends_ev[c])); h->ends_busy[c] = false; }
   long acc = 0;
   int first = -1;
   if ((int)h->ends_last.size() < episodes_counter) h->ends_last.resize(episodes_counter, -1);
   for (int i = 0; i < episodes_counter; ++i) {
-    if (ep_lens_host[i] < 0 || ep_lens_host[i] > h->L) { set_err("ep_lens[%d]=%d out of range", i, ep_lens_host[i]); return OPRL_ERR_INVALID; }
     acc += ep_lens_host[i];
     h->ends_host[c][i] = (int)acc;
     if (h->ends_last[i] != (int)acc) {

@@ -44,7 +44,8 @@ struct Tp {
 };
 
 // Wait sites (low byte of the error word) and kernels (second byte): oprl_learner_check() decodes them.
-enum WaitSite : unsigned { SITE_CLUSTER = 1, SITE_TD_TARGET = 2, SITE_TWIN_SPLIT = 3, SITE_P2_PAIR = 4, SITE_DW_TILE = 5, SITE_WINDOW = 6, SITE_DW_GATE = 7, SITE_LW_PAIR = 8 };
+enum WaitSite : unsigned { SITE_CLUSTER = 1, SITE_TD_TARGET = 2, SITE_TWIN_SPLIT = 3, SITE_P2_PAIR = 4, SITE_DW_TILE = 5, SITE_WINDOW = 6, SITE_DW_GATE = 7, SITE_LW_PAIR = 8,
+                           SITE_X2_RANGE = 9 /* not a wait: an activation left the split-fp16 range (engine.h PrecX2) */ };
 enum WaitKernel : unsigned { KERN_PHASE1 = 1, KERN_PHASE2 = 2, KERN_SLICE_TP = 3, KERN_DW_XCHG = 4, KERN_P2P = 5, KERN_LW_PAIR = 6 };
 // First report wins (the word is host-mapped memory: one system-scope store, only ever on the error path).
 __device__ __forceinline__ void report_expired(unsigned* err, unsigned code) {

@@ -315,8 +315,14 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
     for (int s = 0; s < NS::S0; ++s)
       if (s < NS0) P::mac_s(xr, s, w0[s], acc, P::kFwdA);
     float* o = h1 + (kk * 4) * kWL4 + 16 * wave + i;
+    bool ok = true;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r * kWL4] = fmaxf(acc[r] * kO + bias0, 0.f);
+    for (int r = 0; r < 4; ++r) {
+      const float pre = acc[r] * kO + bias0;
+      ok = ok && P::range_ok(pre);
+      o[r * kWL4] = fmaxf(pre, 0.f);
+    }
+    if (__builtin_expect(!ok, 0)) report_expired(tp.err, tp.err_code | SITE_X2_RANGE);
   }
   sf();
   __syncthreads();   // h1 visible
@@ -335,7 +341,9 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
     float v = sp[0];
 #pragma unroll
     for (int q = 1; q < SH::KP; ++q) v += sp[q * SH::TPM * 256];
-    h2[(4 * (rl >> 4) + rr) * kWL4 + c0 + 16 * rt + (rl & 15)] = fmaxf(v * kO + bias1, 0.f);
+    const float pre = v * kO + bias1;
+    if (__builtin_expect(!P::range_ok(pre), 0)) report_expired(tp.err, tp.err_code | SITE_X2_RANGE);
+    h2[(4 * (rl >> 4) + rr) * kWL4 + c0 + 16 * rt + (rl & 15)] = fmaxf(pre, 0.f);
   }
   __syncthreads();   // the member's h2 columns visible
 
@@ -587,8 +595,14 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
     for (int s = 0; s < NS::S0; ++s)
       if (s < NS0) P::mac_s(xr, s, w0[s], acc, P::kFwdA);
     float* o = h1 + (kk * 4) * kWL4 + 16 * wave + i;
+    bool ok = true;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r * kWL4] = fmaxf(acc[r] * kO + bias0, 0.f);
+    for (int r = 0; r < 4; ++r) {
+      const float pre = acc[r] * kO + bias0;
+      ok = ok && P::range_ok(pre);
+      o[r * kWL4] = fmaxf(pre, 0.f);
+    }
+    if (__builtin_expect(!ok, 0)) report_expired(tp.err, tp.err_code | SITE_X2_RANGE);
   }
   {
     const float* q1 = net.pb[1] + ((size_t)wave * NS::W + c * SH::M) * BK + lane * 4;
@@ -612,7 +626,9 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
     float sum = sp[0];
 #pragma unroll
     for (int q = 1; q < SH::KP; ++q) sum += sp[q * SH::TPM * 256];
-    const float v = fmaxf(sum * kO + bias1, 0.f);
+    const float pre = sum * kO + bias1;
+    if (__builtin_expect(!P::range_ok(pre), 0)) report_expired(tp.err, tp.err_code | SITE_X2_RANGE);
+    const float v = fmaxf(pre, 0.f);
     const int off = (4 * (rl >> 4) + rr) * kWL4 + c0 + 16 * rt + (rl & 15);
     h2[off] = v;
     g2[off] = v > 0.f ? seed * w3 : 0.f;

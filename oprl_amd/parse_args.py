@@ -10,9 +10,11 @@ _SHARED = (
     ("--config", str, None, "path of a config file (accepted for compatibility; the scripts are the config)"),
     ("--env", str, "cartpole-balance", "environment name, e.g. walker-walk"),
     ("--device", str, "cuda", "device of the learner (a ROCm GPU; there is no CPU path)"),
-    # extension: the learner's arithmetic mode.  The scripts default to the faster of the two
-    # parity modes; the algorithm classes themselves default to "f32"
-    ("--precision", str, "x2", "x2 (fp32 as fp16 hi + lo on the matrix cores, parity mode) | f32 (exact fp32 MFMA) | bf16"),
+    # extension: the learner's arithmetic mode.  Scripts and algorithm classes alike default to
+    # exact fp32 — the reference's arithmetic, no input range.  "x2" is the faster parity mode, opt-in: it has a finite
+    # range (|observation|, |hidden activation| < 4094, |w| < 256; leaving it raises from update() / check(), it is never
+    # silent) — meant for normalised observations
+    ("--precision", str, "f32", "f32 (exact fp32 MFMA, the default) | x2 (fp32 as fp16 hi + lo on the matrix cores: parity mode, |obs| < 4094) | bf16"),
 )
 _SINGLE = (
     ("--seeds", int, 1, "how many seeds to train, one process each"),
