@@ -40,6 +40,9 @@ __device__ __forceinline__ float wave_max(float v) {
   return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+__device__ __forceinline__ float ld_ag(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_ag(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 struct DwX2Lds {   // floats
   // minibatch extent of a transposed row, padded such that the compute lanes' b128 reads (16 rows i, 16 bytes each)
   // fall into 16 different groups of four banks — fp32 rows 260 dwords apart, fp16 rows 264 halfs = 132 dwords
@@ -59,9 +62,19 @@ static_assert(2 * 16 * DwX2Lds::LDT <= 16 * DwX2Lds::LDF, "the staged tiles fit 
 // (`gate` — 1: the critic's tiles, 2: the actor's — is a RUN-TIME member: k_ddpg_update runs both kinds and carries ONE copy
 // of this code for them, 10 KB less in a kernel whose speed follows its instruction-cache footprint (r03-25 / -26); in
 // the two-launch kernels the value is a constant at the only call site and the other kind's branches fold away)
+// A tile of a launch that runs SEVERAL updates (k_ddpg_chain, fused_ddpg.hip): what the host bakes into the argument
+// block of a one-update launch changes from update to update there — the gate's tag, Adam's bias-correction terms, the
+// output-layer snapshot — and is read from the launch's ChainArgs where it is used (two registers carried through the
+// tile instead of a dozen: these kernels sit at the scalar-register limit).  chain == null: a one-update launch.
+struct DwX2Ovr {
+  const ChainArgs* chain = nullptr;
+  int u = 0;                             // the update's index in the launch
+};
+
 template <class KArgs = DwKArgs>
 struct DwX2Tile {
   static constexpr int TK = kDwX2TileK, LDF = DwX2Lds::LDF, LDH = DwX2Lds::LDH, LDT = DwX2Lds::LDT;
+  DwX2Ovr ov;
   // (only what must survive between begin() and finish(): the layer's table entry, the tile's coordinates and flags are
   // formed again in finish() — scalar work — instead of being carried through whatever runs in between)
   const KArgs* KA;
@@ -105,17 +118,19 @@ struct DwX2Tile {
     const bool e_ok = en < I.N && ek < I.K;
     const size_t eo = (size_t)en * I.K + ek;
     p_th = p_m = p_v = p_tt = 0.f;
+    // (masters and moments travel past the L2 — agent-scope loads here, agent-scope stores in finish(): inside a launch
+    // that runs several updates a tile's next incarnation sits on another compute unit, possibly another XCD)
     if (e_ok) {
-      p_th = I.w[eo]; p_m = I.w_m[eo]; p_v = I.w_v[eo];
-      if (polyak) p_tt = I.w_t[eo];
+      p_th = ld_ag(I.w + eo); p_m = ld_ag(I.w_m + eo); p_v = ld_ag(I.w_v + eo);
+      if (polyak) p_tt = ld_ag(I.w_t + eo);
     }
     const bool b_own = tk == 0 && tid < kDwTileN && n_base + tid < I.N;
     const bool b_pol = ad.do_polyak && I.b_t != nullptr;
     q_th = q_m = q_v = q_tt = 0.f;
     if (b_own) {
       const int n = n_base + tid;
-      q_th = I.b[n]; q_m = I.b_m[n]; q_v = I.b_v[n];
-      if (b_pol) q_tt = I.b_t[n];
+      q_th = ld_ag(I.b + n); q_m = ld_ag(I.b_m + n); q_v = ld_ag(I.b_v + n);
+      if (b_pol) q_tt = ld_ag(I.b_t + n);
     }
     // ---- loaders (wave w: minibatch rows 16 w .. 16 w + 15).  X: lane = (row pair p = lane >> 3, quad q = lane & 7) x
     // two column halves — two ADJACENT rows per lane, so that a transposed fp16 pair is one dword
@@ -166,7 +181,11 @@ struct DwX2Tile {
   if (gate == 2) kind = item == 0 ? G.kind[0] : (item == 1 ? G.kind[1] : (item == 2 ? G.kind[2] : G.kind[3]));
   const int ptile = n_base >> 4;
   const int i = lane & 15, kk = lane >> 4;
-  const float step_size = ad.step_size_host, bc2_sqrt = ad.bc2_sqrt_host;   // (the host knows the step in the merged launches)
+  // (the host knows the step in the merged launches; k_ddpg_chain: per update)
+  const bool chained = ov.chain != nullptr;
+  const float step_size = chained ? (gate == 1 ? ov.chain->c_step[ov.u] : ov.chain->a_step[ov.u]) : ad.step_size_host;
+  const float bc2_sqrt = chained ? (gate == 1 ? ov.chain->c_bc2[ov.u] : ov.chain->a_bc2[ov.u]) : ad.bc2_sqrt_host;
+  const unsigned gtag = G.tag + (unsigned)ov.u;
   const int nl = tid >> 6, kl = tid & 63;
   const int xp = lane >> 3, xq = (lane & 7) * 4;
   const int xb0 = 16 * wave + 2 * xp;
@@ -184,7 +203,7 @@ struct DwX2Tile {
     if (kind == 1 && an_ok) {
 #pragma unroll
       for (int j = 0; j < kDuLd; ++j)
-        if (j < G.n_act) va[j] = ld4(G.w3 + (size_t)j * I.ldy + ncol);
+        if (j < G.n_act) va[j] = ld4((chained ? ov.chain->w3buf[ov.u & 1] : G.w3) + (size_t)j * I.ldy + ncol);
     }
   }
   // first attempts at what the tile waits for, requested with the rows
@@ -203,16 +222,16 @@ struct DwX2Tile {
     }
 #pragma unroll
     for (int j = 0; j < kDuLd; ++j)
-      g[j] = j < n_g ? __hip_atomic_load(gsrc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)G.tag << 32);
+      g[j] = j < n_g ? __hip_atomic_load(gsrc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)gtag << 32);
   }
   // (GATE 2 waits for granules only: what the critic pass reads of the actor's packs it has taken in BEFORE it publishes
   // du, and no tile stores before it has du)
   if (gate == 1) {
     const unsigned long long* myf = G.rows + (tid < G.n_rows ? tid : 0);
-    bool ok = (unsigned)(__hip_atomic_load(myf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == G.tag;
+    bool ok = (unsigned)(__hip_atomic_load(myf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == gtag;
     for (int spin = 0; spin < G.spin && !ok; ++spin) {
       __builtin_amdgcn_s_sleep(2);
-      ok = (unsigned)(__hip_atomic_load(myf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == G.tag;
+      ok = (unsigned)(__hip_atomic_load(myf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == gtag;
     }
     if (!ok) report_expired(G.err, G.err_code);
   }
@@ -271,7 +290,7 @@ struct DwX2Tile {
       bool ok = false;
       for (int spin = 0; spin < G.spin && !ok; ++spin) {
         x = __hip_atomic_load(G.seed + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = (unsigned)(x >> 32) == G.tag;
+        ok = (unsigned)(x >> 32) == gtag;
         if (!ok) __builtin_amdgcn_s_sleep(1);
       }
       if (!ok) report_expired(G.err, G.err_code);
@@ -283,7 +302,7 @@ struct DwX2Tile {
     float du[kDuLd];
     bool ok = true;
 #pragma unroll
-    for (int j = 0; j < kDuLd; ++j) ok = ok && (unsigned)(g[j] >> 32) == G.tag;
+    for (int j = 0; j < kDuLd; ++j) ok = ok && (unsigned)(g[j] >> 32) == gtag;
     for (int spin = 0; spin < G.spin && !ok; ++spin) {
       __builtin_amdgcn_s_sleep(1);
 #pragma unroll
@@ -291,7 +310,7 @@ struct DwX2Tile {
         if (j < n_g) g[j] = __hip_atomic_load(gsrc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ok = true;
 #pragma unroll
-      for (int j = 0; j < kDuLd; ++j) ok = ok && (unsigned)(g[j] >> 32) == G.tag;
+      for (int j = 0; j < kDuLd; ++j) ok = ok && (unsigned)(g[j] >> 32) == gtag;
     }
     if (!ok) report_expired(G.err, G.err_code);
 #pragma unroll
@@ -384,11 +403,13 @@ struct DwX2Tile {
     if (polyak) tt_new = p_tt * ad.omtau + ad.tau * th;
     e_m = mm; e_v = vv;
     if (!flagged) {
-      I.w_m[eo] = mm;
-      I.w_v[eo] = vv;
-      I.w[eo] = th;
-      if (polyak) I.w_t[eo] = tt_new;
+      st_ag(I.w_m + eo, mm);
+      st_ag(I.w_v + eo, vv);
+      st_ag(I.w + eo, th);
+      if (polyak) st_ag(I.w_t + eo, tt_new);
     }
+    // (the actor's output layer, row-major, for whoever reads it in the next update of this launch)
+    if (chained && gate == 2 && kind == 0) ov.chain->w3buf[(ov.u + 1) & 1][eo] = th;
   }
   tileW[nl * LDT + kl] = th_new;      // (the dY area: every wave is past its MFMAs)
   tileT[nl * LDT + kl] = tt_new;
@@ -403,10 +424,14 @@ struct DwX2Tile {
     vv = vv * ad.beta2 + ad.omb2 * gb * gb;
     th = th - step_size * (mm / (sqrtf(vv) / bc2_sqrt + ad.eps));
     if (I.b16 != nullptr) I.b16[n] = th;      // (uncached copy for readers inside the same launch)
-    I.b_m[n] = mm;
-    I.b_v[n] = vv;
-    I.b[n] = th;
-    if (b_pol) I.b_t[n] = q_tt * ad.omtau + ad.tau * th;
+    st_ag(I.b_m + n, mm);
+    st_ag(I.b_v + n, vv);
+    st_ag(I.b + n, th);
+    if (b_pol) {
+      const float tb = q_tt * ad.omtau + ad.tau * th;
+      st_ag(I.b_t + n, tb);
+      if (I.bt16 != nullptr) I.bt16[n] = tb;
+    }
   }
   __syncthreads();       // the updated tile is staged
 
@@ -447,12 +472,12 @@ struct DwX2Tile {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0)
-      __hip_atomic_store(G.done + bx_, (unsigned long long)G.tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(G.done + bx_, (unsigned long long)gtag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (e_ok) {
-      I.w_m[eo] = e_m;
-      I.w_v[eo] = e_v;
-      I.w[eo] = th_new;
-      if (polyak) I.w_t[eo] = tt_new;
+      st_ag(I.w_m + eo, e_m);
+      st_ag(I.w_v + eo, e_v);
+      st_ag(I.w + eo, th_new);
+      if (polyak) st_ag(I.w_t + eo, tt_new);
     }
     if (I.pf16 != nullptr && polyak && I.tpf16 != nullptr && tid >= 128 && tid < 256) {
       const int NSk2 = cdiv(I.K, 32);
@@ -468,12 +493,21 @@ struct DwX2Tile {
     }
   }
   stamp();   // stores issued
+  if (chained) {
+    // (a launch that runs several updates: the next update's roles and this tile's next incarnation read what this
+    // tile has written — masters, moments, every pack — after THIS flag)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_store((gate == 1 ? ov.chain->ct_fin : ov.chain->at_fin) + bx_, (unsigned long long)gtag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   }
 };
 
 template <class KArgs = DwKArgs>
-__device__ __forceinline__ void dw_tile_x2(const KArgs& A, float* lds, int bx, int gate) {
+__device__ __forceinline__ void dw_tile_x2(const KArgs& A, float* lds, int bx, int gate, const DwX2Ovr& ov = DwX2Ovr()) {
   DwX2Tile<KArgs> T;
+  T.ov = ov;
   T.begin(A, lds, bx, gate);
   T.finish();
 }

@@ -969,8 +969,16 @@ __device__ __forceinline__ void wait_flags(const unsigned long long* flags, int 
 
 // (returns the actor tile this workgroup is, -1 for the pass's and the prefetch row's workgroups: ddpg_tile runs it)
 // PF: the launch may carry the prefetch row (the two-launch form; k_ddpg_update's rides on phase 1's rows)
+// (what changes from update to update inside k_ddpg_chain; the one-update launches pass their argument block's values)
+struct PassCtx {
+  unsigned epoch;               // tag of this update's flags and granules
+  unsigned tag;                 // the pass's cluster-exchange tag
+  const float* w3;              // the actor's output layer [A][256] as it is before this update's actor step
+  const float* cb[3];           // the critic's biases as this update's tiles leave them (uncached copies)
+  long long* trace;
+};
 template <class P, class KA = DwKArgs, bool PF = true>
-__device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D, int by_in = -1) {
+__device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D, int by_in, const PassCtx& cx) {
   static_assert(P::kX2 && kDwTileX2, "the merged phase 2 exists for PrecX2 learners");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<256>;
@@ -984,7 +992,7 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
     const int tile = (y - yT) * (int)gridDim.x + slice;
     if (tile >= dw_total(*D)) return -1;
     if (A.whole) {      // (k_ddpg_update: the rows this tile reads are role C's of this very launch)
-      wait_flags(A.w_flags, 4 * (int)gridDim.x, A.epoch, A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
+      wait_flags(A.w_flags, 4 * (int)gridDim.x, cx.epoch, A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
       __syncthreads();
       asm volatile("buffer_inv sc0" ::: "memory");
     }
@@ -1024,12 +1032,12 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   float* w3s = smem + LY::misc + 96;               // [kDuLd][256] the output layer's rows (the prefetch rows' ends table is not in use here)
   static_assert(2 * HB >= 2 * 8 * 512, "the shard fits the two spare hidden buffers");
   static_assert(kMaxEnds >= kDuLd * 256, "W3 fits the ends table's area");
-  Tp tp{y, NMC, A.xbuf + (size_t)slice * kTpStages * A.xnc * kTpBlk, A.whole ? A.cluster_tag2 : A.cluster_tag, 0,
+  Tp tp{y, NMC, A.xbuf + (size_t)slice * kTpStages * A.xnc * kTpBlk, cx.tag, 0,
         A.err, KERN_PHASE2 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
   const bool lead = tp.c == 0;
   const int c = tp.c;
   const int lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
-  long long* const trace = A.whole ? A.trace2 : A.trace;
+  long long* const trace = cx.trace;
   int n_stamp = 0;
   auto stamp = [&]() {
     if (kTraceOn && trace != nullptr && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
@@ -1042,11 +1050,11 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   };
   stamp();
   const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
-  Net critic = A.critic;
+  BiasOv cbo;
   if (A.whole) {
     // (k_ddpg_update) role C of this launch wrote s, pi and the actor's activations — uncached memory: its members'
     // flags, then an invalidate of this CU's L1; the critic's packs and biases follow below, behind the rows
-    wait_flags(A.w_flags, 4 * (int)gridDim.x, A.epoch, A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
+    wait_flags(A.w_flags, 4 * (int)gridDim.x, cx.epoch, A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
     __syncthreads();
     asm volatile("buffer_inv sc0" ::: "memory");
   }
@@ -1064,7 +1072,7 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};
   if (row0 + hr < B) hv = ld4(A.aX[2] + (size_t)(row0 + hr) * kW4 + hc);
   f32x4 w3q = f32x4{0.f, 0.f, 0.f, 0.f};                         // W3[tid >> 6][4 (tid & 63) ..]: rows beyond A stay zero
-  if ((tid >> 6) < Ad) w3q = ld4(A.w3_snap + (size_t)tid * 4);
+  if ((tid >> 6) < Ad) w3q = ld4(cx.w3 + (size_t)tid * 4);
   const int et = (tid >> 8) & 1, er = (tid >> 4) & 15, ec = tid & 15;   // g1 element (threads < 512): tile et, row er, column ec
   float m1 = 0.f;
   if (tid < 512 && row0 + er < B) m1 = A.aX[1][(size_t)(row0 + er) * kW4 + 32 * c + 16 * et + ec];
@@ -1098,14 +1106,14 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
     if (tid < A.n_ct) {
       bool ok = false;
       for (int spin = 0; spin < kTpSpin && !ok; ++spin) {
-        ok = (unsigned)(__hip_atomic_load(A.ct_done + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == A.epoch;
+        ok = (unsigned)(__hip_atomic_load(A.ct_done + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == cx.epoch;
         if (!ok) __builtin_amdgcn_s_sleep(1);
       }
       if (!ok) report_expired(A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
     }
     __syncthreads();
     asm volatile("buffer_inv sc0" ::: "memory");
-    critic.b[0] = A.critic_b16[0]; critic.b[1] = A.critic_b16[1]; critic.b[2] = A.critic_b16[2];
+    cbo.b0 = cx.cb[0]; cbo.b1 = cx.cb[1]; cbo.b2 = cx.cb[2];
   }
   stamp();
   float* qsum = nullptr;
@@ -1113,12 +1121,12 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
     qsum = A.partials_a + slice * 4 + 1;
     if (tid == 0) { A.partials_a[slice * 4 + 0] = 0.f; A.partials_a[slice * 4 + 2] = 0.f; }
   }
-  tp4_scalar_fb<P, NMC>(critic, xa, h1, h2, g2, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum);
+  tp4_scalar_fb<P, NMC>(A.critic, xa, h1, h2, g2, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum, cbo);
   stamp();   // da ready
   // du = da (1 - pi^2): every member holds the same da; the lead member publishes (rows beyond B are never polled)
   if (lead && okp) {
     const float du = auxS[rp_ * kOutLd + cp_] * (1.f - vp * vp);
-    granule_put(A.du_granules + (size_t)(row0 + rp_) * kDuLd + cp_, A.epoch, du);
+    granule_put(A.du_granules + (size_t)(row0 + rp_) * kDuLd + cp_, cx.epoch, du);
     A.adY[2][(size_t)(row0 + rp_) * A.alddo + cp_] = du;
   }
   // ---- the backward step through the second hidden layer, this member's 32 columns of the first one's dY
@@ -1165,7 +1173,7 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
 #pragma unroll
     for (int ws = 0; ws < 8; ++ws) v += scr[(2 * ws + et) * 256 + er * 16 + ec];
     v = (mbits & 16u) != 0u ? v : 0.f;
-    granule_put(const_cast<unsigned long long*>(A.g1_granules) + ((size_t)(2 * c + et) * B + row0 + er) * 16 + ec, A.epoch, v);
+    granule_put(const_cast<unsigned long long*>(A.g1_granules) + ((size_t)(2 * c + et) * B + row0 + er) * 16 + ec, cx.epoch, v);
   }
   stamp();
   return -1;
@@ -1174,7 +1182,8 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
 template <class P>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase2_dw(const DdpgArgs A, const DwKArgs D) {
   const DwKArgs* Dp = (const DwKArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kMergedDwOffset);
-  ddpg_tile<P, DwKArgs>(Dp, ddpg_phase2m_body<P>(A, Dp), 2);
+  const PassCtx cx{A.epoch, A.cluster_tag, A.w3_snap, {A.critic_b16[0], A.critic_b16[1], A.critic_b16[2]}, A.trace};
+  ddpg_tile<P, DwKArgs>(Dp, ddpg_phase2m_body<P>(A, Dp, -1, cx), 2);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1207,10 +1216,308 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_update(const DdpgArgs A, cons
     tile = ddpg_phase1_body<256, true, false, P, true, true, DwKArgs4>(A, Dcp, y);
     gate = 1;
   } else {
-    tile = ddpg_phase2m_body<P, DwKArgs4, false>(A, Dap, y - rows1);
+    const PassCtx cx{A.epoch, A.cluster_tag2, A.w3_snap, {A.critic_b16[0], A.critic_b16[1], A.critic_b16[2]}, A.trace2};
+    tile = ddpg_phase2m_body<P, DwKArgs4, false>(A, Dap, y - rows1, cx);
     gate = 2;
   }
   ddpg_tile<P, DwKArgs4>(gate == 1 ? Dcp : Dap, tile, gate);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// SEVERAL updates as one launch (k_ddpg_chain; PrecX2 learners, DDPG, B <= 256, a chip that holds one update's
+// workgroups at once): step_n's K-loop moves inside the launch.
+//
+// Every update is ONE block of 16 grid rows = (16 x slices) workgroups, dispatched in order A (8 rows) | B (4) | C (4),
+// and every workgroup runs a CHAIN of stages for its update, handing results on through the flags and granules of
+// k_ddpg_update:
+//     role A (target chain -> seeds)        -> goes on as the critic pass's member (slice, member)
+//     role B (critic forward + unit-seed backward), role C (actor forward)
+//                                           -> the critic's tile -> the actor's tile (same index) [-> the next rows]
+// No extra rows of tile / pass workgroups: nothing has to be dispatched inside an update.  The NEXT update's block is
+// dispatched as compute units come free — role A's 128 workgroups are resident (rows in, waiting) several microseconds
+// before the previous update's last tile raises its flag — so what an update boundary costs is one flag hop instead of
+// end-of-kernel + dispatch + cold instruction caches + the rows' round trip.
+// What crosses an update boundary without a kernel boundary:
+//   * fp16 packs, biases (uncached copies b16 / bt16), the actor's output layer (w3buf[parity]): uncached memory, read
+//     after the tiles' FIN flags (every store acknowledged) and an L1 invalidate;
+//   * masters and Adam moments: agent-scope loads / stores (dw_tile_x2.h), the same tile's next incarnation after FIN;
+//   * the next rows: two staging sets by parity, gathered by 16 tile-less role-C workgroups, flag pf_done[slice].
+// Update 0 of a launch reads what the launch before left (masters' biases, the row-major W3, staged or gathered rows).
+// Waits (all on workgroups of the same or an EARLIER update, or — inside an update — on roles that are resident
+// together: one update's 16 x slices workgroups must fit the chip, the launcher checks):
+//   role A(u), C(u): every ct_fin / at_fin flag of update u - 1;  role B(u): ct_fin(u - 1);  all: pf_done[slice](u - 1).
+// Write-after-read across updates is ordered by the same flags (role B(u + 1) rewrites the rows the critic's tiles of u
+// read: after ct_fin(u); role C(u + 1) rewrites pi / the actor's activations: after at_fin(u); the prefetch of u rewrites
+// the staging set the roles of u - 1 read: its workgroup was role C(u), i.e. after at_fin(u - 1); granules and exchange
+// areas carry the update's tag).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chain_wait2(const unsigned long long* f0, int n0, const unsigned long long* f1, int n1,
+                                            const unsigned long long* f2, int n2, unsigned tag, unsigned* err, unsigned code) {
+  const int k = (int)threadIdx.x;
+  const unsigned long long* f = k < n0 ? f0 + k : (k < n0 + n1 ? f1 + (k - n0) : (k < n0 + n1 + n2 ? f2 + (k - n0 - n1) : nullptr));
+  if (f != nullptr) {
+    bool ok = false;
+    for (int spin = 0; spin < kTpSpin && !ok; ++spin) {
+      ok = (unsigned)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == tag;
+      if (!ok) __builtin_amdgcn_s_sleep(4);
+    }
+    if (!ok) report_expired(err, code);
+  }
+  __syncthreads();
+  asm volatile("buffer_inv sc0" ::: "memory");
+}
+
+constexpr size_t kChainCOffset = (kWholeDaOffset + sizeof(DwKArgs4) + alignof(ChainArgs) - 1) / alignof(ChainArgs) * alignof(ChainArgs);
+template <class P>
+__global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const DwKArgs4 Dc, const DwKArgs4 Da, const ChainArgs C_) {
+  static_assert(P::kX2 && kDwTileX2, "the chain launch exists for PrecX2 learners");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  const DwKArgs4* Dcp = (const DwKArgs4*)(ka + kWholeDcOffset);
+  const DwKArgs4* Dap = (const DwKArgs4*)(ka + kWholeDaOffset);
+  // (read through the segment pointer: a run-time subscript into a by-value argument — c_step[u] — would make hipcc
+  // pull the whole block into registers / scratch)
+  const ChainArgs& C = *(const ChainArgs*)(ka + kChainCOffset);
+  using LY = FusedLds<256>;
+  constexpr int HB = kR * kWL4;
+  const int slices = (int)gridDim.x, slice = (int)blockIdx.x;
+  const int u = (int)blockIdx.y >> 4, yy = (int)blockIdx.y & 15;
+  const int B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x, row0 = slice * kR;
+  const unsigned ep = A.epoch + (unsigned)u;
+  const unsigned tag1 = A.cluster_tag + 2u * (unsigned)u, tag2 = tag1 + 1u;
+  const int tc = Dcp->tile_end[kDwFusedItems - 1], ta = Dap->tile_end[kDwFusedItems - 1];
+  const int par = u & 1;
+  float* xa = smem + LY::xa;
+  float* xb = smem + LY::xb;
+  float* h1 = smem + LY::h;
+  float* h2 = h1 + HB;
+  float* outS = smem + LY::out;
+  float* scr = smem + LY::scr;
+  float* rS = smem + LY::misc;
+  float* dS = rS + kR;
+  float* yS = dS + kR;
+  int* meta = reinterpret_cast<int*>(yS + kR);
+  int* endsS = reinterpret_cast<int*>(smem + LY::misc + 96);
+  const int role = yy < 8 ? 0 : (yy < 12 ? 1 : 2);
+  const int member = yy < 8 ? yy : (yy - 8) & 3;
+  const bool lead = member == 0;
+  const int spin = A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin;
+  // in-kernel stage stamps (liboprl_amd_trace.so): update C.trace_u of the launch, the slots of k_ddpg_update
+  const bool traced = kTraceOn && A.trace != nullptr && u == C.trace_u;
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if (traced && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
+      const int slot = tid == 0 ? slice : 16 + (tid >> 6);
+      long long* tr = A.trace + (((size_t)role * 64 + slot) * kTraceStamps + n_stamp) * 2;
+      tr[0] = (long long)__builtin_readcyclecounter();
+      tr[1] = (long long)wall_clock64();
+    }
+    ++n_stamp;
+  };
+  stamp();   // entry
+
+  // ---- what the update before (of this launch) must have finished; then this slice's rows
+  if (u > 0) {
+    const unsigned prev = ep - 1u;
+    chain_wait2(C.ct_fin, tc, C.at_fin, role == 1 ? 0 : ta, C.pf_done + slice, 1, prev, A.err, (KERN_PHASE1 << 8) | SITE_DW_GATE);
+  }
+  if (u == 0 && C.first_gather) {
+    load_batch(A.src, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);      // (gather = 1, this update's counter: the host's)
+  } else {
+    // staged rows of this update's parity (or, update 0 of an update() call, the caller's rows: set0)
+    const float* ps = par ? C.set1[0] : C.set0[0]; const float* pa = par ? C.set1[1] : C.set0[1];
+    const float* pr = par ? C.set1[2] : C.set0[2]; const float* pd = par ? C.set1[3] : C.set0[3];
+    const float* ps2 = par ? C.set1[4] : C.set0[4];
+    lds_zero(xa, 2 * kR * kX0Ld);   // xa and xb are adjacent
+    __syncthreads();
+    load_rows(xa, kX0Ld, 0, ps, S, S, row0, B);
+    load_rows(xa, kX0Ld, S, pa, Ad, Ad, row0, B);
+    load_rows(xb, kX0Ld, 0, ps2, S, S, row0, B);
+    if (tid < kR) {
+      const int gr = row0 + tid;
+      rS[tid] = gr < B ? pr[gr] : 0.f;
+      dS[tid] = gr < B ? pd[gr] : 0.f;
+    }
+  }
+  stamp();   // batch rows requested
+  const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
+  // (later updates: the biases as the tiles of the update before left them — uncached copies; update 0: the masters)
+  auto bias_of = [&](int which) {
+    BiasOv bo;
+    if (u > 0) { bo.b0 = C.b16[which][0]; bo.b1 = C.b16[which][1]; bo.b2 = C.b16[which][2]; }
+    return bo;
+  };
+
+  if (role == 0) {
+    // ---- role A: a' = tanh(actor_target(s')), q' = critic_target(s', a'), TD target, seeds       (ddpg.py:94-95)
+    Tp tp{member, 8, A.xbuf + (size_t)slice * kTpStages * A.xnc * kTpBlk, tag1, 0, A.err, KERN_PHASE1 << 8, spin};
+    tp4_forward<P, 8>(A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp, bias_of(1));
+    for (int idx = tid; idx < kR * Ad; idx += kThreads) {
+      const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
+      xb[row * kX0Ld + S + col] = gr < B ? tanhf(outS[row * kOutLd + col]) : 0.f;
+    }
+    // role B's q granules are requested from inside the second pass (after its layer-1 stage)
+    unsigned long long gq = 0ull;
+    int hook_n = 0;
+    const unsigned long long* gq_src = A.y_granules + A.gran_stride + min(row0 + (tid & (kR - 1)), B - 1);
+    auto hook = [&]() {
+      stamp();
+      if (++hook_n == 2) gq = __hip_atomic_load(gq_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    tp4_forward<P, 8>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, hook, bias_of(3));
+    if (lead && tid < 64) {
+      const int gr = row0 + tid;
+      const bool row_ok = tid < kR && gr < B;
+      const float qn = row_ok ? outS[tid * kOutLd] : 0.f;
+      const float y = row_ok ? rS[tid] + ((1.f - dS[tid]) * A.gamma) * qn : 0.f;
+      const int lim = A.debug_expire == (int)SITE_TD_TARGET ? 0 : (1 << 20);
+      float q = 0.f;
+      if (row_ok) {
+        unsigned long long g = gq;
+        bool ok = lim > 0 && (unsigned)(g >> 32) == ep;
+        for (int sp = 0; sp < lim && !ok; ++sp) {
+          g = __hip_atomic_load(A.y_granules + (size_t)A.gran_stride + gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = (unsigned)(g >> 32) == ep;
+          if (!ok) __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) report_expired(A.err, (KERN_PHASE1 << 8) | SITE_TD_TARGET);
+        q = ok ? __uint_as_float((unsigned)g) : __builtin_nanf("");
+        const float seed = 2.f * (q - y) * A.inv_B;
+        A.cdY[2][(size_t)gr * A.clddo] = seed;
+        __hip_atomic_store(A.y_granules + gr, ((unsigned long long)ep << 32) | (unsigned long long)__float_as_uint(seed),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (A.y_out != nullptr) A.y_out[gr] = y;
+        if (A.q_out != nullptr) A.q_out[gr] = q;
+      }
+      if (A.partials_c != nullptr) {
+        float v[3] = {row_ok ? (q - y) * (q - y) : 0.f, row_ok ? q : 0.f, row_ok ? y : 0.f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float sum = row16_sum(v[k]);
+          if (tid == 0) A.partials_c[(size_t)slice * 4 + k] = sum;
+        }
+      }
+    }
+    stamp();
+    __syncthreads();       // (the pass below reuses this workgroup's LDS)
+    // ---- ... and goes on as member `member` of this slice's critic pass (update and member formed again from the block
+    // index: nothing of the role stays in a register through the pass)
+    int by2 = (int)blockIdx.y;
+    asm volatile("" : "+s"(by2));
+    const int u2 = by2 >> 4;
+    const PassCtx cx{A.epoch + (unsigned)u2, A.cluster_tag + 2u * (unsigned)u2 + 1u, C.w3buf[u2 & 1], {C.b16[2][0], C.b16[2][1], C.b16[2][2]},
+                     (kTraceOn && u2 == C.trace_u) ? A.trace2 : nullptr};
+    (void)ddpg_phase2m_body<P, DwKArgs4, false>(A, Dap, by2 & 15, cx);
+    return;
+  }
+
+  if (role == 1) {
+    // ---- role B: q = critic(s, a) forward and its whole backward with unit seed (tp4_scalar_fb)      (ddpg.py:96-100)
+    Tp tp{member, 4, A.xbuf + ((size_t)1 * slices + slice) * kTpStages * A.xnc * kTpBlk, tag1, 0, A.err, KERN_PHASE1 << 8, spin};
+    const Tp3Store st{A.cX[1], A.cX[2], A.cdY[1], A.cdY[0], A.cdY0_stride, B, true};
+    tp4_scalar_fb<P>(A.critic, xa, h1, h2, h1 + 2 * HB, outS, scr, tp, st, row0, B, 1.f, 0, 0, nullptr, stamp, nullptr, bias_of(2));
+    if (lead) {
+      for (int idx = tid; idx < kR * (S + Ad); idx += kThreads) {
+        const int row = idx / (S + Ad), col = idx - row * (S + Ad), gr = row0 + row;
+        if (gr < B) __hip_atomic_store(A.cX[0] + (size_t)gr * A.cldx0 + col, xa[row * kX0Ld + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_store(A.gate_flags + slice * 4 + member, (unsigned long long)ep << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lead && tid < kR && row0 + tid < B)
+      __hip_atomic_store(A.y_granules + (size_t)A.gran_stride + row0 + tid,
+                         ((unsigned long long)ep << 32) | (unsigned long long)__float_as_uint(outS[tid * kOutLd]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stamp();   // q published
+  } else {
+    // ---- role C: actor(s) forward, pi = tanh(.) and the activations for the actor's tiles / the critic pass
+    Tp tp{member, 4, A.xbuf + ((size_t)2 * slices + slice) * kTpStages * A.xnc * kTpBlk, tag1, 0, A.err, KERN_PHASE1 << 8, spin};
+    const Tp3Store st{A.aX[1], A.aX[2], nullptr, nullptr, 0};
+    tp4_forward<P>(A.actor, xa, h1, h2, outS, scr, tp, st, row0, B, stamp, bias_of(0));
+    if (lead) {
+      for (int idx = tid; idx < kR * Ad; idx += kThreads) {
+        const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
+        if (gr < B) A.pi[(size_t)gr * Ad + col] = tanhf(outS[row * kOutLd + col]);
+      }
+      store_rows(xa, kX0Ld, A.aX[0], A.aldx0, S, row0, B);
+      // update 0: the row-major output layer as the launch before left it -> w3buf[0] (later updates: the output
+      // layer's tiles of the update before wrote w3buf[parity] themselves)
+      if (u == 0 && slice == 0)
+        for (int idx = tid * 4; idx < Ad * kW4; idx += kThreads * 4)
+          *reinterpret_cast<f32x4*>(C.w3buf[0] + idx) = ld4(A.w3_src + idx);
+    }
+    stamp();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_store(A.w_flags + slice * 4 + member, (unsigned long long)ep << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  // ---- from here on the workgroup is (update, index among the 8 x slices workgroups of roles B and C) and nothing else:
+  // both are formed AGAIN from the block index, laundered through an empty asm, so that no value of the role above stays
+  // in a register through the tiles (these kernels sit at the scalar-register limit; what does not fit is spilled)
+  int by2 = (int)blockIdx.y, bx2 = (int)blockIdx.x, nx2 = (int)gridDim.x;
+  asm volatile("" : "+s"(by2), "+s"(bx2), "+s"(nx2));
+  const int u2 = by2 >> 4, wg2 = ((by2 & 15) - 8) * nx2 * 0 + (((by2 & 15) >= 12) ? 4 * nx2 : 0) + bx2 * 4 + ((by2 - 8) & 3);
+  const int n_bc = 8 * nx2;
+  const unsigned ep2 = A.epoch + (unsigned)u2;
+
+  // ---- the next update's rows: the last `slices` of these workgroups, before their tiles (at B = 256 they have none)
+  {
+    const int p = n_bc - 1 - wg2;
+    if (p < nx2 && (u2 + 1 < C.n_upd || C.pf_last)) {
+      const int par2 = u2 & 1;
+      BatchSrc nx = A.next;                 // (the replay's view; gather = 1)
+      nx.s = par2 ? C.set0[0] : C.set1[0]; nx.a = par2 ? C.set0[1] : C.set1[1]; nx.r = par2 ? C.set0[2] : C.set1[2];
+      nx.d = par2 ? C.set0[3] : C.set1[3]; nx.s2 = par2 ? C.set0[4] : C.set1[4];
+      nx.counter = A.next.counter + (unsigned long long)u2;
+      prefetch_rows_src(nx, A.S, A.A, A.B, p, smem);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0)
+        __hip_atomic_store(C.pf_done + p, (unsigned long long)ep2 << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // ---- the critic's tile (GATE 1: rows of role B, seeds of role A), then the actor's (GATE 2: role C's rows — this
+  // launch's, uncached: its flags and an L1 invalidate — and du)
+  // (two inlined copies of the tile code, each with its kind folded in: ONE copy inside a two-trip loop keeps the
+  // thread-index arithmetic of both trips live across the tile and spills 14 vector registers)
+  {
+    const int tile = wg2 < Dcp->tile_end[kDwFusedItems - 1] ? wg2 : -1;
+    if (tile >= 0) {
+      DwX2Ovr ov;
+      ov.chain = &C; ov.u = u2;
+      dw_tile_x2<DwKArgs4>(*Dcp, smem, tile, 1, ov);
+    }
+  }
+  {
+    int by3 = (int)blockIdx.y, bx3 = (int)blockIdx.x, nx3 = (int)gridDim.x;
+    asm volatile("" : "+s"(by3), "+s"(bx3), "+s"(nx3));
+    const int wg3 = (((by3 & 15) >= 12) ? 4 * nx3 : 0) + bx3 * 4 + ((by3 - 8) & 3);
+    const int tile = wg3 < Dap->tile_end[kDwFusedItems - 1] ? wg3 : -1;
+    if (tile >= 0) {
+      __syncthreads();
+      wait_flags(A.w_flags, 4 * nx3, A.epoch + (unsigned)(by3 >> 4), A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
+      // (its own masters and moments: this tile's incarnation of the update before — implied by the seeds a workgroup
+      // that was a critic tile has just consumed, said for the one that was not)
+      if ((by3 >> 4) > 0 && threadIdx.x == kThreads - 1) {
+        bool ok = false;
+        for (int sp = 0; sp < kTpSpin && !ok; ++sp) {
+          ok = (unsigned)(__hip_atomic_load(C.at_fin + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == A.epoch + (unsigned)(by3 >> 4) - 1u;
+          if (!ok) __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) report_expired(A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
+      }
+      __syncthreads();
+      asm volatile("buffer_inv sc0" ::: "memory");
+      DwX2Ovr ov;
+      ov.chain = &C; ov.u = by3 >> 4;
+      dw_tile_x2<DwKArgs4>(*Dap, smem, tile, 2, ov);
+    }
+  }
 }
 
 static_assert(FusedLds<256>::total >= kDwLdsFloats && FusedLds<256>::total >= DwLds<16>::floats && FusedLds<256>::total >= DwX2Lds::floats, "a tile workgroup fits the phase kernels' LDS");
@@ -1260,7 +1567,8 @@ hipError_t init_fused_attrs() {
                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecX2>),
                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecX2, true>),
                       reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecX2>),
-                      reinterpret_cast<const void*>(&k_ddpg_update<PrecX2>)};
+                      reinterpret_cast<const void*>(&k_ddpg_update<PrecX2>),
+                      reinterpret_cast<const void*>(&k_ddpg_chain<PrecX2>)};
   for (const void* k : ks) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -1365,6 +1673,21 @@ hipError_t launch_ddpg_update(const DdpgArgs& a, const DwKArgs4& dc, const DwKAr
   const int ownc = tc > 8 * slices ? tc - 8 * slices : 0;
   const dim3 grid(slices, 16 + (ownc + slices - 1) / slices + 8 + (ta + slices - 1) / slices + (a.prefetch_p1 ? 1 : 0));
   hipLaunchKernelGGL((k_ddpg_update<PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, dc, da);
+  return hipGetLastError();
+}
+
+// n_upd updates as one launch (k_ddpg_chain): `a` / `dc` / `da` as for launch_ddpg_update (the gates' tags = the FIRST
+// update's epoch), `c` = what changes per update
+hipError_t launch_ddpg_chain(const DdpgArgs& a, const DwKArgs4& dc, const DwKArgs4& da, const ChainArgs& c, hipStream_t st) {
+  if (!lean_ok(a) || a.sac || !a.x2 || !kDwTileX2 || a.n_critics != 1 || !a.whole || (a.merged & 3) != 3 || (a.wide & 3) != 3 ||
+      a.xnc < 8 || a.A > kDuLd || a.B > 256 || a.prefetch_next || a.prefetch_p1 || c.n_upd < 1 || c.n_upd > kChainMax)
+    return hipErrorInvalidValue;
+  const int slices = (a.B + kR - 1) / kR;
+  const int tc = dc.tile_end[kDwFusedItems - 1], ta = da.tile_end[kDwFusedItems - 1];
+  if (tc + ta + 1 > kThreads) return hipErrorInvalidValue;       // (one poller per flag: chain_wait2)
+  if (tc > 8 * slices || ta > 8 * slices) return hipErrorInvalidValue;   // a tile of each kind per role-B / role-C workgroup
+  const dim3 grid(slices, 16 * c.n_upd);
+  hipLaunchKernelGGL((k_ddpg_chain<PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, dc, da, c);
   return hipGetLastError();
 }
 

@@ -102,6 +102,7 @@ struct DwItem {      // one Linear layer of one net
   float *pf16, *pb16, *tpf16;          // the same three as bf16 packs (PrecBF16, engine.h), or null: fp32-only learner
   int x2;                              // 1: those three are PrecX2 packs (blocks of two fp16 planes, 2^8 w)
   float* b16;                          // copy of the bias in UNCACHED memory (or null): what a workgroup of the same launch reads (k_ddpg_update's critic pass)
+  float* bt16;                         // ... of the TARGET net's bias (or null): k_ddpg_chain's later updates
   int tiles_k, tile_begin, tile_end;
   int tile_n;                          // n rows per tile: kDwTileN, or 8 for a layer that sums dz1 partials
   long dY_part_stride;                 // > 0: dY is the sum of DwArgs::n_part buffers this many floats apart
@@ -395,6 +396,24 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   long long* trace;
   unsigned* err;                       // host-visible error word: an expired bounded wait stores (kernel << 8 | site) there
   int debug_expire;                    // test hook: this wait site (WaitSite, tp3.h) gives up at once
+};
+
+// k_ddpg_chain (csrc/fused_ddpg.hip): what changes from update to update inside a launch that runs several
+constexpr int kChainMax = 32;
+struct ChainArgs {
+  int n_upd;                           // updates in this launch (<= kChainMax)
+  int first_gather;                    // 1: update 0 gathers its own rows from the replay (nothing staged them)
+  int pf_last;                         // 1: the last update stages the next rows as well (another launch follows)
+  int trace_u;                         // trace build: the update whose stages are stamped
+  float c_step[kChainMax], c_bc2[kChainMax];   // Adam's lr / (1 - b1^t) and sqrt(1 - b2^t) of the critic's step, per update
+  float a_step[kChainMax], a_bc2[kChainMax];   // ... of the actor's
+  const float* set0[5];                // staging rows s, a, r, d, s2: update u reads set (u & 1), its prefetch fills the other
+  const float* set1[5];
+  unsigned long long* ct_fin;          // [critic tiles] {epoch, *}: every store of the tile acknowledged
+  unsigned long long* at_fin;          // [actor tiles]
+  unsigned long long* pf_done;         // [slices]: the rows of the update after `epoch` are staged
+  const float* b16[4][kMaxLayers];     // uncached bias copies the tiles leave: 0 actor, 1 actor target, 2 critic, 3 critic target
+  float* w3buf[2];                     // the actor's output layer [A][256] before update u: w3buf[u & 1]
 };
 
 constexpr int kDwTile = 32;      // k (fan-in) extent of a dW tile

@@ -132,6 +132,7 @@ bool fused_ddpg_is_lean(const DdpgArgs& a);
 hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st);
 hipError_t launch_ddpg_phase2_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st);
 hipError_t launch_ddpg_update(const DdpgArgs& a, const DwKArgs4& dc, const DwKArgs4& da, hipStream_t st);
+hipError_t launch_ddpg_chain(const DdpgArgs& a, const DwKArgs4& dc, const DwKArgs4& da, const ChainArgs& c, hipStream_t st);
 hipError_t launch_ddpg_phase1_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
 hipError_t launch_ddpg_phase2_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
 int fill_dw_kargs(const DwArgs& a, DwKArgs* k, int tile_k = 32);
@@ -442,6 +443,16 @@ struct oprl_learner {
   // k_ddpg_update (the whole update as one launch): role C's / the critic tiles' flags, the critic's uncached bias copies
   unsigned long long* w_flags = nullptr;
   float* critic_b16 = nullptr;
+  // k_ddpg_chain (several updates per launch): the tiles' FIN flags, the prefetch flags, the uncached bias copies of all
+  // four nets ([0] actor, [1] actor target, [2] critic = critic_b16, [3] critic target) and the output layer's two buffers
+  unsigned long long* chain_flags = nullptr;   // [ct_fin 192 | at_fin 192 | pf_done 64]
+  float* chain_b16 = nullptr;                  // [4][kMaxLayers][256]
+  float* w3buf1 = nullptr;                     // (w3buf[0] = w3_snap)
+  int chain_u = 1;             // step_n: updates the next whole-update launch runs (k_ddpg_chain)
+  bool chain_pf_last = false;  // ... and whether its last update stages the rows of the update after it
+  const float* chain_set1[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // the other staging set (set 0 = the update's rows)
+  int no_chain = 0;            // OPRL_AMD_NO_CHAIN: one update per launch (k_ddpg_update)
+  int chain_max = kChainMax;   // OPRL_AMD_CHAIN=n: at most n updates per launch
   int no_whole = 0;            // OPRL_AMD_NO_WHOLE: two launches per update (merged phase 1, merged phase 2)
   bool whole_done = false;     // this update's actor phase was part of the critic phase's launch
   float* pack16[OPRL_MAX_CRITICS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1128,13 +1139,14 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
   const oprl_learner_config& c = h->cfg;
   if (use_fused(h, B)) {
     h->epoch += 1;
-    if (h->epoch == 0) {   // the TD-target tag wrapped: retire every stale granule
+    if (h->epoch == 0 || h->epoch > 0xFFFFFFFFu - (unsigned)kChainMax) {   // the TD-target tag wrapped (or would inside a chain launch): retire every stale granule
       h->epoch = 1;
       HIPC(hipMemsetAsync(h->y_granules, 0, ((size_t)3 * h->Bmax + 256) * sizeof(unsigned long long), st));
       if (h->du_granules != nullptr) {
         HIPC(hipMemsetAsync(h->du_granules, 0, (size_t)(h->Bmax < 256 ? h->Bmax : 256) * kDuLd * sizeof(unsigned long long), st));
         HIPC(hipMemsetAsync(h->g1_granules, 0, (size_t)16 * (h->Bmax < 256 ? h->Bmax : 256) * 16 * sizeof(unsigned long long), st));
         HIPC(hipMemsetAsync(h->w_flags, 0, 256 * sizeof(unsigned long long), st));
+        HIPC(hipMemsetAsync(h->chain_flags, 0, (192 + 192 + 64) * sizeof(unsigned long long), st));
       }
     }
     DdpgArgs fa = ddpg_args(h, B);
@@ -1186,6 +1198,54 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
         kd.gate.g1 = fa.g1_granules;
         kd.gate.n_act = h->A;
         compact(kd, &ka);
+      }
+      // (every tile must find a role-B / role-C workgroup to be the continuation of: 8 per slice)
+      const bool chain_fits = kc.tile_end[kDwFusedItems - 1] <= 8 * slices && ka.tile_end[kDwFusedItems - 1] <= 8 * slices;
+      const int U = (h->no_chain || h->chain_flags == nullptr || !chain_fits) ? 1 : h->chain_u;
+      if (!h->no_chain && h->chain_flags != nullptr && chain_fits) {
+        // SEVERAL updates as one launch (k_ddpg_chain): the tables above are update 0's; what changes per update — Adam's
+        // bias-correction terms, epochs, exchange tags, the staging set — is in ChainArgs
+        ChainArgs ca;
+        memset((void*)&ca, 0, sizeof ca);
+        ca.n_upd = U;
+        ca.first_gather = fa.src.gather;
+        ca.pf_last = h->chain_pf_last ? 1 : 0;
+        ca.trace_u = U - 1;
+        ca.c_step[0] = kc.ad.step_size_host; ca.c_bc2[0] = kc.ad.bc2_sqrt_host;
+        ca.a_step[0] = ka.ad.step_size_host; ca.a_bc2[0] = ka.ad.bc2_sqrt_host;
+        for (int u = 1; u < U; ++u) {          // (dw_build advances the optimisers' step counts: once per update and net)
+          const DwArgs dc = dw_build(h, true, B, true, false);
+          const DwArgs da = dw_build(h, false, B, true, false);
+          ca.c_step[u] = dc.ad.step_size_host; ca.c_bc2[u] = dc.ad.bc2_sqrt_host;
+          ca.a_step[u] = da.ad.step_size_host; ca.a_bc2[u] = da.ad.bc2_sqrt_host;
+        }
+        ca.set0[0] = fa.src.s; ca.set0[1] = fa.src.a; ca.set0[2] = fa.src.r; ca.set0[3] = fa.src.d; ca.set0[4] = fa.src.s2;
+        for (int i = 0; i < 5; ++i) ca.set1[i] = h->chain_set1[i];
+        if ((U > 1 || ca.pf_last) && ca.set1[0] == nullptr) { set_err("chain launch: no second staging set"); return OPRL_ERR_STATE; }
+        ca.ct_fin = h->chain_flags; ca.at_fin = h->chain_flags + 192; ca.pf_done = h->chain_flags + 384;
+        for (int w = 0; w < 4; ++w)
+          for (int l = 0; l < kMaxLayers; ++l) ca.b16[w][l] = h->chain_b16 + ((size_t)w * kMaxLayers + l) * 256;
+        ca.w3buf[0] = h->w3_snap; ca.w3buf[1] = h->w3buf1;
+        if (kc.tile_end[kDwFusedItems - 1] > 192 || ka.tile_end[kDwFusedItems - 1] > 192 || slices > 64) { set_err("chain launch: too many tiles"); return OPRL_ERR_INVALID; }
+        // exchange tags: two per update (the roles', the critic pass's), consecutive: cluster_tag = the first
+        {
+          unsigned& ctr = h->tp_tag;
+          if ((ctr & 0x03FFFFFFu) + 2u * (unsigned)U + 2u >= 0x03FFFFFFu) {      // (would wrap inside the launch: wrap now)
+            ctr = (ctr | 0x03FFFFFFu) + 1u;
+            HIPC(hipMemsetAsync(h->xbuf, 0, h->xbuf_granules * sizeof(unsigned long long), st));
+          }
+          fa.cluster_tag = (ctr + 1u) & 0x03FFFFFFu;
+          ctr += 2u * (unsigned)U;
+        }
+        fa.prefetch_p1 = 0;
+        fa.trace2 = fa.trace != nullptr ? h->trace + (size_t)3 * 64 * kTraceStamps * 2 : nullptr;
+        h->epoch += (unsigned)(U - 1);
+        prof_begin(4, st);
+        hipError_t e = launch_ddpg_chain(fa, kc, ka, ca, st);
+        prof_end(st);
+        HIPC(e);
+        h->whole_done = true;
+        return OPRL_OK;
       }
       prof_begin(4, st);
       hipError_t e = launch_ddpg_update(fa, kc, ka, st);
@@ -1998,6 +2058,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   const int Bm = B < 256 ? B : 256;             // merged phase 2 serves one 256-row chunk
   const bool merge2_bufs = h->fused && cfg->algo != OPRL_SAC && A <= kDuLd;
   if (merge2_bufs) floats += 2 * ((size_t)Bm * kDuLd + 64) + 2 * 256 + 128 + 2 * (size_t)16 * Bm * 16 + 64 + 16 * 256 + 4 * 64 + 2 * 256 + 64 + kMaxLayers * 256 + 64;
+  if (merge2_bufs) floats += 2 * (192 + 192 + 64) + 64 + 4 * kMaxLayers * 256 + 64 + 16 * 256 + 64;      // (k_ddpg_chain)
   if (h->bf16 || h->x2) {
     floats += 2 * ((size_t)net_pack16_floats(cfg->actor, h->planes) + 64);
     for (int j = 0; j < nc; ++j) floats += 2 * ((size_t)net_pack16_floats(cfg->critics[j], h->planes) + 64);
@@ -2050,7 +2111,10 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->g1_granules = p.take<unsigned long long>((size_t)16 * Bm * 16);
     h->w3_snap = p.take<float>(16 * 256);
     h->w_flags = p.take<unsigned long long>(256);
-    h->critic_b16 = p.take<float>(kMaxLayers * 256);
+    h->chain_flags = p.take<unsigned long long>(192 + 192 + 64);
+    h->chain_b16 = p.take<float>(4 * kMaxLayers * 256);
+    h->critic_b16 = h->chain_b16 + 2 * kMaxLayers * 256;
+    h->w3buf1 = p.take<float>(16 * 256);
   }
   h->bs = p.take<float>((size_t)B * S);
   h->ba = p.take<float>((size_t)B * A);
@@ -2092,9 +2156,17 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     fill_items(cfg->critics[j], h->ws_critic[j], items, &h->tiles_critic, h->fused, h->pack16[1 + j], h->pack16_t[1 + j], h->planes);
   h->n_items_critic = (int)items.size();
   if (h->critic_b16 != nullptr && nc == 1)
-    for (int l = 0; l < h->n_items_critic; ++l) items[l].b16 = h->critic_b16 + 256 * l;
+    for (int l = 0; l < h->n_items_critic; ++l) {
+      items[l].b16 = h->critic_b16 + 256 * l;
+      items[l].bt16 = h->chain_b16 + (3 * kMaxLayers + l) * 256;
+    }
   fill_items(cfg->actor, h->ws_actor, items, &h->tiles_actor, h->fused, h->pack16[0], h->pack16_t[0], h->planes);
   h->n_items_actor = (int)items.size() - h->n_items_critic;
+  if (h->chain_b16 != nullptr && nc == 1)
+    for (int l = 0; l < h->n_items_actor; ++l) {
+      items[h->n_items_critic + l].b16 = h->chain_b16 + (0 * kMaxLayers + l) * 256;
+      items[h->n_items_critic + l].bt16 = h->chain_b16 + (1 * kMaxLayers + l) * 256;
+    }
   h->items_host = items;
   std::vector<RepackItem> rp[3];
   {
@@ -2128,7 +2200,10 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->no_gather_ride = (ngr != nullptr && atoi(ngr) != 0);
     if (cfg->algo == OPRL_TQC || h->du_granules != nullptr) {
       const size_t n = (size_t)h->Bmax * (2 * (size_t)h->S + h->A + 2);
-      if (hipMalloc(&h->batch_alt, n * sizeof(float)) != hipSuccess) h->batch_alt = nullptr;   // (then: a gather launch per update)
+      // (PrecX2 learners: uncached, like the first staging set in the pool — inside k_ddpg_chain an update reads rows a
+      // workgroup of the update before has gathered)
+      if ((h->uc_pool ? uc_alloc((void**)&h->batch_alt, n * sizeof(float)) : hipMalloc(&h->batch_alt, n * sizeof(float))) != hipSuccess)
+        h->batch_alt = nullptr;   // (then: a gather launch per update)
     }
     const char* nfr = getenv("OPRL_AMD_NO_FIN_RIDE");
     h->no_fin_ride = (nfr != nullptr && atoi(nfr) != 0);
@@ -2168,6 +2243,9 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->no_merge = (nmg != nullptr && atoi(nmg) != 0) ? 1 : 0;
     const char* nm2 = getenv("OPRL_AMD_NO_MERGE2");
     h->no_merge2 = (nm2 != nullptr && atoi(nm2) != 0) ? 1 : 0;
+    const char* nch = getenv("OPRL_AMD_NO_CHAIN");
+    h->no_chain = (nch != nullptr && atoi(nch) != 0) ? 1 : 0;
+    if (const char* cm = getenv("OPRL_AMD_CHAIN")) { const int v = atoi(cm); if (v >= 1 && v <= kChainMax) h->chain_max = v; }
     const char* nwh = getenv("OPRL_AMD_NO_WHOLE");
     h->no_whole = (nwh != nullptr && atoi(nwh) != 0) ? 1 : 0;
     const char* nw = getenv("OPRL_AMD_NO_WIDE");
@@ -2246,7 +2324,7 @@ extern "C" int oprl_learner_destroy(oprl_learner* h) {
   if (h->tqc_counter) (void)hipFree(h->tqc_counter);
   if (h->lw_scratch) (void)hipFree(h->lw_scratch);
   if (h->lw_pairs.flags) (void)hipFree(h->lw_pairs.flags);
-  if (h->batch_alt) (void)hipFree(h->batch_alt);
+  dev_free(h->batch_alt);
   dev_free(h->uc_base);
   if (h->err_host) (void)hipHostFree(h->err_host);
   if (h->act_pin) (void)hipHostFree(h->act_pin);
@@ -2357,10 +2435,46 @@ extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t
     float* alt = h->batch_alt;
     float* set[2][5] = {{h->bs, h->ba, h->br, h->bd, h->bs2},
                         {alt, alt + Bm * h->S, alt + Bm * (h->S + h->A), alt + Bm * (h->S + h->A + 1), alt + Bm * (h->S + h->A + 2)}};
-    h->prefetch_p1 = alt != nullptr && (ddpg_args(h, B).merged & 2) != 0;
+    const DdpgArgs probe = ddpg_args(h, B);
+    // k_ddpg_chain: up to chain_max updates per launch, the rows of update u + 1 staged by update u inside the launch
+    int tiles64[2] = {0, 0};                 // 16 x 64 tiles of the critic / the actor (dw_tile_x2.h)
+    for (size_t i = 0; i < h->items_host.size(); ++i)
+      tiles64[(int)i < h->n_items_critic ? 0 : 1] += ((h->items_host[i].N + 15) / 16) * ((h->items_host[i].K + 63) / 64);
+    const int bc_wgs = 8 * ((B + kR - 1) / kR);
+    const bool chain = probe.whole && B <= 256 && !h->no_chain && h->chain_flags != nullptr && alt != nullptr &&
+                       tiles64[0] <= bc_wgs && tiles64[1] <= bc_wgs;
+    h->prefetch_p1 = !chain && alt != nullptr && (probe.merged & 2) != 0;
     int cur = 0;
     int rc = OPRL_OK;
     h->staged_ready = false;
+    if (chain) {
+      for (int k = 0; k < K && rc == OPRL_OK;) {
+        const int U = K - k < h->chain_max ? K - k : h->chain_max;
+        float** b = set[cur];
+        float** nb = set[cur ^ 1];
+        for (int i = 0; i < 5; ++i) h->chain_set1[i] = nb[i];
+        sc.counter = (unsigned long long)h->update_count;
+        h->next_src.counter = sc.counter + 1;
+        h->next_src.s = nb[0]; h->next_src.a = nb[1]; h->next_src.r = nb[2]; h->next_src.d = nb[3]; h->next_src.s2 = nb[4];
+        h->prefetch_next = 0;
+        sc.gather = h->staged_ready ? 0 : 1;
+        sc.s = b[0]; sc.a = b[1]; sc.r = b[2]; sc.d = b[3]; sc.s2 = b[4];      // (set 0 of the launch, gathered or staged)
+        h->chain_u = U;
+        h->chain_pf_last = k + U < K;
+        rc = oprl_learner_update(h, b[0], b[1], b[2], b[3], b[4], B, nullptr, nullptr, stream);
+        h->chain_u = 1;
+        if (rc == OPRL_OK) h->update_count += U - 1;        // (update() counted one)
+        h->staged_ready = h->chain_pf_last;                 // the launch's last update staged the next rows: set (cur + U) & 1
+        h->chain_pf_last = false;
+        for (int i = 0; i < 5; ++i) h->chain_set1[i] = nullptr;
+        cur = (cur + U) & 1;
+        k += U;
+      }
+      sc.gather = 0;
+      h->prefetch_next = 0;
+      h->staged_ready = false;
+      return rc;
+    }
     // OPRL_AMD_GRAPH_PROBE=1 (measurement only, profiles/r03_experiments.txt): the K updates' launches are captured into a
     // hipGraph — every node with its own argument block: epoch, counters and staging set are baked in at capture — and
     // replayed once; the call returns when the graph has run.  Does the boundary between two launches move?

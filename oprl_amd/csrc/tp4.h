@@ -86,6 +86,10 @@ __device__ __forceinline__ float tp4_tile_amax(const float* T, int ncols16) {
   return m;
 }
 
+// Biases from somewhere else than the net's master arena (k_ddpg_chain's later updates: the uncached copies the
+// tiles of the update before left); null members = the net's own.
+struct BiasOv { const float* b0 = nullptr; const float* b1 = nullptr; const float* b2 = nullptr; };
+
 __host__ __device__ inline bool tp4_shape_ok(int width, int fan_in, int n_out) {
   return width == kW4 && fan_in <= 16 * kMaxS0 && n_out <= kNarrowMax;
 }
@@ -249,12 +253,15 @@ __device__ __forceinline__ void tp4_store_dz1(const Tp3Store& st, int c, const f
 template <class P = PrecF32, int NM = 4, class ST = NoStamp>
 __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, float* h1, float* h2,
                                             float* outS, float* scr, Tp& tp, const Tp3Store& st, int row0, int B,
-                                            ST sf = ST()) {
+                                            ST sf = ST(), const BiasOv bo = BiasOv()) {
   using NS = Tp4Steps<P>;
   using SH = Tp4Shape<P, NM>;
+  const float* const nb0 = bo.b0 != nullptr ? bo.b0 : net.b[0];
+  const float* const nb1 = bo.b1 != nullptr ? bo.b1 : net.b[1];
+  const float* const nb2 = bo.b2 != nullptr ? bo.b2 : net.b[2];
   // the net's pointers and dims, fetched from the kernel arguments TOGETHER (one scalar wait): left to the
   // compiler they come in where first used, a scalar load and a wait in front of every group of fragment requests
-  asm volatile("" :: "s"(net.pf[0]), "s"(net.pf[1]), "s"(net.pf[2]), "s"(net.b[0]), "s"(net.b[1]), "s"(net.b[2]),
+  asm volatile("" :: "s"(net.pf[0]), "s"(net.pf[1]), "s"(net.pf[2]), "s"(nb0), "s"(nb1), "s"(nb2),
                "s"(net.dims[0]), "s"(net.dims[3]));
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -281,13 +288,13 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
 #pragma unroll
     for (int s = 0; s < NS::S0; ++s) w0[s] = s < NS0 ? P::ldf(p0 + s * BK) : P::zf();
   }
-  const float bias0 = net.b[0][16 * wave + i];
+  const float bias0 = nb0[16 * wave + i];
   {
     const float* p1 = net.pf[1] + ((size_t)(c * SH::TPM + t1) * NS::W + kq * NQ) * BK + lane * 4;
 #pragma unroll
     for (int s = 0; s < NQ; ++s) w1[s] = P::ldf(p1 + s * BK);
   }
-  const float bias1 = net.b[1][c0 + 16 * (r_mine ? rt : 0) + (rl & 15)];
+  const float bias1 = nb1[c0 + 16 * (r_mine ? rt : 0) + (rl & 15)];
   float bias2 = 0.f, bias2e[2] = {0.f, 0.f};   // output bias: of this lane's column / of its narrow-exchange elements
 #pragma unroll
   for (int s = 0; s < SH::M; ++s) w2[s] = P::zf();
@@ -295,12 +302,12 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
     const float* p2 = net.pf[2] + ((size_t)t2 * NS::W + c * SH::M) * BK + lane * 4;
 #pragma unroll
     for (int s = 0; s < SH::M; ++s) w2[s] = P::ldf(p2 + s * BK);
-    if (16 * t2 + i < N) bias2 = net.b[2][16 * t2 + i];
+    if (16 * t2 + i < N) bias2 = nb2[16 * t2 + i];
     if constexpr (NM == 8) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int k = tp4_narrow_elem(j, N);
-        if (k >= 0) bias2e[j] = net.b[2][k];
+        if (k >= 0) bias2e[j] = nb2[k];
       }
     }
   }
@@ -528,7 +535,10 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
                                               float* g2, float* outS, float* scr, Tp& tp,
                                               const Tp3Store& st, int row0, int B, float seed,
                                               int dact_col0, int dact_cols, float* dactS, ST sf = ST(),
-                                              float* q_sum_out = nullptr) {
+                                              float* q_sum_out = nullptr, const BiasOv bo = BiasOv()) {
+  const float* const nb0 = bo.b0 != nullptr ? bo.b0 : net.b[0];
+  const float* const nb1 = bo.b1 != nullptr ? bo.b1 : net.b[1];
+  const float* const nb2 = bo.b2 != nullptr ? bo.b2 : net.b[2];
   // q_sum_out (optional, one float): sum of q over the slice's valid rows, written by the wave
   // that finishes the q all-reduce (diagnostics without a barrier on the main path)
   const int lane = threadIdx.x & 63;
@@ -537,7 +547,7 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   using NS = Tp4Steps<P>;
   using SH = Tp4Shape<P, NM>;
   asm volatile("" :: "s"(net.pf[0]), "s"(net.pf[1]), "s"(net.pf[2]), "s"(net.pb[0]), "s"(net.pb[1]), "s"(net.pb[2]),
-               "s"(net.b[0]), "s"(net.b[1]), "s"(net.b[2]), "s"(net.dims[0]));   // (as in tp4_forward)
+               "s"(nb0), "s"(nb1), "s"(nb2), "s"(net.dims[0]));   // (as in tp4_forward)
   const int c = tp.c, c0 = c * SH::COLS;
   const int NS0 = (net.dims[0] + P::KS - 1) / P::KS;   // layer-0 steps
   const bool dact = dact_cols > 0;
@@ -567,13 +577,13 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
 #pragma unroll
     for (int s = 0; s < NS::S0; ++s) w0[s] = s < NS0 ? P::ldf(p0 + s * BK) : P::zf();
   }
-  const float bias0 = net.b[0][16 * wave + i];
+  const float bias0 = nb0[16 * wave + i];
   {
     const float* p1 = net.pf[1] + ((size_t)(c * SH::TPM + t1) * NS::W + kq * NQ) * BK + lane * 4;
 #pragma unroll
     for (int s = 0; s < NQ; ++s) w1[s] = P::ldf(p1 + s * BK);
   }
-  const float bias1 = net.b[1][c0 + 16 * (r_mine ? rt : 0) + (rl & 15)];
+  const float bias1 = nb1[c0 + 16 * (r_mine ? rt : 0) + (rl & 15)];
   const float w3 = P::first(net.pb[2] + (size_t)(c * SH::TPM + (r_mine ? rt : 0)) * BK + (rl & 15) * 4);   // W3[c0 + 16 rt + col]  (one step)
   float bias2 = 0.f;
 #pragma unroll
@@ -582,7 +592,7 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
     const float* p2 = net.pf[2] + ((size_t)c * SH::M) * BK + lane * 4;
 #pragma unroll
     for (int s = 0; s < SH::M; ++s) w2[s] = P::ldf(p2 + s * BK);
-    if (i == 0 || NM == 8) bias2 = net.b[2][0];
+    if (i == 0 || NM == 8) bias2 = nb2[0];
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();   // x0 visible

@@ -35,7 +35,8 @@ if "--step-n" in sys.argv:     # the benchmarked mode: in-kernel replay gather
 for _ in range(3):
     buf.zero_()
     if replay is not None:
-        L.step_n(replay.handle, 4, B, seed=5)     # the stamps left are the LAST update's: rows staged by its predecessor's phase 2
+        n_chain = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--chain=")), 4)
+        L.step_n(replay.handle, n_chain, B, seed=5)     # the stamps left are the LAST update's: rows staged by its predecessor (k_ddpg_chain: the last update of the launch)
     else:
         algo.update(*batch)
 t.cuda.synchronize()
