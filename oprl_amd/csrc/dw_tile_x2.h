@@ -198,6 +198,28 @@ struct DwX2Tile {
 #pragma unroll
   for (int j = 0; j < kDuLd; ++j) va[j] = z4;
   if (gate == 2) {
+    if (kind == 3) {
+      // unit-seed rows G_j[bb][ncol .. ncol + 3] of the critic pass's members (uncached memory): their flags, an L1
+      // invalidate, then the rows — all long before du
+      {
+        const int k = tid;
+        if (k < G.n_gu_flags) {
+          bool ok = false;
+          for (int spin = 0; spin < G.spin && !ok; ++spin) {
+            ok = (unsigned)(__hip_atomic_load(G.gu_flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == gtag;
+            if (!ok) __builtin_amdgcn_s_sleep(2);
+          }
+          if (!ok) report_expired(G.err, G.err_code);
+        }
+        __syncthreads();
+        asm volatile("buffer_inv sc0" ::: "memory");
+      }
+      if (an_ok && bb < hB) {
+#pragma unroll
+        for (int j = 0; j < kDuLd; ++j)
+          if (j < G.n_act) va[j] = ld4(G.gu + ((size_t)j * hB + bb) * I.ldy + ncol);
+      }
+    }
     // the output layer's rows W3[j][ncol .. ncol + 3] (a few hundred bytes, shared by every tile of the layer: not
     // worth eight registers per lane through role U)
     if (kind == 1 && an_ok) {
@@ -324,6 +346,9 @@ struct DwX2Tile {
       for (int j = 0; j < kDuLd; ++j) v += va[j] * du[j];
 #pragma unroll
       for (int t = 0; t < 4; ++t) v[t] = hmask[t] > 0.f ? v[t] : 0.f;
+    } else if (kind == 3) {
+#pragma unroll
+      for (int j = 0; j < kDuLd; ++j) v += va[j] * du[j];      // (the masks are in the unit-seed rows)
     } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {

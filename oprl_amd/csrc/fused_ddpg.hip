@@ -977,7 +977,11 @@ struct PassCtx {
   const float* cb[3];           // the critic's biases as this update's tiles leave them (uncached copies)
   long long* trace;
 };
-template <class P, class KA = DwKArgs, bool PF = true>
+// GE (k_ddpg_chain): the first hidden layer's dY leaves this pass as UNIT-SEED rows G_j = dz1 / d(du_j), j < A — the
+// actor's backward is linear in du — computed and stored BEFORE the critic's new weights arrive (the pass's members sit
+// idle, rows in, until the critic's tiles flag), so that every actor tile waits for du only and nothing follows du
+// here.  Otherwise: the backward step after du, its result as granules (the two-launch form, whose pass starts at once).
+template <class P, class KA = DwKArgs, bool PF = true, bool GE = false>
 __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D, int by_in, const PassCtx& cx) {
   static_assert(P::kX2 && kDwTileX2, "the merged phase 2 exists for PrecX2 learners");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1075,7 +1079,7 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   if ((tid >> 6) < Ad) w3q = ld4(cx.w3 + (size_t)tid * 4);
   const int et = (tid >> 8) & 1, er = (tid >> 4) & 15, ec = tid & 15;   // g1 element (threads < 512): tile et, row er, column ec
   float m1 = 0.f;
-  if (tid < 512 && row0 + er < B) m1 = A.aX[1][(size_t)(row0 + er) * kW4 + 32 * c + 16 * et + ec];
+  if ((GE || tid < 512) && row0 + er < B) m1 = A.aX[1][(size_t)(row0 + er) * kW4 + 32 * c + 16 * et + ec];
   // [s | pi]: loads first, then the zero fill and the stores
   const int rs_ = tid / S, cs_ = tid - rs_ * S;
   const bool oks = tid < kR * S && row0 + rs_ < B;
@@ -1099,6 +1103,56 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   // (the masks stay in one register through the pass: bits 0..3 the h2 quad, bit 4 the h1 element)
   const unsigned mbits = (hv[0] > 0.f ? 1u : 0u) | (hv[1] > 0.f ? 2u : 0u) | (hv[2] > 0.f ? 4u : 0u) | (hv[3] > 0.f ? 8u : 0u) |
                          (m1 > 0.f ? 16u : 0u);
+  if constexpr (GE) {
+    // ---- unit-seed backward through the second hidden layer, this member's 32 columns of the first one's dY:
+    //     G_j[b, k] = (h1[b, k] > 0) sum_n (h2[b, n] > 0) W3[j, n] W2[n, k]          (dz1 = sum_j du_j G_j)
+    // the mask tile -> h1; wave = (tile t1 of the member's two, macro step ws of eight) keeps its W2^T fragment and runs
+    // two seeds per round (partials in h2 | g2), thread = element sums the eight steps; rows written to A.gu [A][B][256]
+    float* mS = h1;
+    float* part = h2;                                        // [2 seeds][16 waves][256]
+    static_assert(2 * HB >= 2 * 16 * 256, "two seeds' partial tiles fit two hidden buffers");
+    *reinterpret_cast<f32x4*>(mS + hr * kWL4 + hc) = f32x4{(mbits & 1u) ? 1.f : 0.f, (mbits & 2u) ? 1.f : 0.f, (mbits & 4u) ? 1.f : 0.f, (mbits & 8u) ? 1.f : 0.f};
+    __syncthreads();                                         // mask tile, W2^T shard, W3 rows in LDS
+    const int t1 = wave & 1, ws = wave >> 1;
+    const float* bw = Wl + ((size_t)t1 * 8 + ws) * 512 + lane * 4;
+    const FragX2 bf{ld4(bw), ld4(bw + 256)};
+    const f32x4 ma = ld4(mS + i * kWL4 + 32 * ws + 4 * kk), mb = ld4(mS + i * kWL4 + 32 * ws + 16 + 4 * kk);
+    for (int j0 = 0; j0 < Ad; j0 += 2) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = j0 + jj;
+        if (j < Ad) {
+          const f32x4 x0 = ma * ld4(w3s + j * 256 + 32 * ws + 4 * kk), x1 = mb * ld4(w3s + j * 256 + 32 * ws + 16 + 4 * kk);
+          float m = fmaxf(fmaxf(fmaxf(fabsf(x0[0]), fabsf(x0[1])), fmaxf(fabsf(x0[2]), fabsf(x0[3]))),
+                          fmaxf(fmaxf(fabsf(x1[0]), fabsf(x1[1])), fmaxf(fabsf(x1[2]), fabsf(x1[3]))));
+          m = wave_max(m);
+          const float sa = P::a_scale(m), un = PrecX2::kOut / sa;
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+          PrecX2::mma3(x0 * sa, x1 * sa, bf, acc);
+          float* o = part + ((size_t)jj * 16 + wave) * 256;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[(4 * kk + r) * 16 + i] = acc[r] * un;
+        }
+      }
+      __syncthreads();
+      {
+        const int jj = tid >> 9, j = j0 + jj;              // threads 0..511: the round's first seed, 512..1023: its second
+        if (j < Ad && row0 + er < B) {
+          float v = 0.f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v += part[((size_t)jj * 16 + 2 * q + et) * 256 + er * 16 + ec];
+          A.gu[((size_t)j * B + row0 + er) * kW4 + 32 * c + 16 * et + ec] = (mbits & 16u) != 0u ? v : 0.f;
+        }
+      }
+      __syncthreads();                                       // (the next round rewrites the partial tiles)
+    }
+    // every wave's rows are out before the member says so (uncached memory): the first-layer tiles read them after this
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_store(A.gu_flags + slice * NMC + c, (unsigned long long)cx.epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stamp();   // unit-seed rows out
+  }
   if (A.whole) {
     // ... the critic's TILES of this launch wrote the critic's fp16 packs and biases (uncached memory): their flags
     // (one poller each), the invalidate; the biases come from the tiles' uncached copies (the masters sit dirty in
@@ -1129,6 +1183,7 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
     granule_put(A.du_granules + (size_t)(row0 + rp_) * kDuLd + cp_, cx.epoch, du);
     A.adY[2][(size_t)(row0 + rp_) * A.alddo + cp_] = du;
   }
+  if constexpr (GE) { stamp(); return -1; }      // (the first layer's dY left as unit-seed rows before the pass: nothing follows du)
   // ---- the backward step through the second hidden layer, this member's 32 columns of the first one's dY
   {
     // g2[hr][hc ..] = (h2 > 0) sum_j du[hr][j] W3[j][hc ..] (wave = minibatch row hr; du once more from da and pi, both
@@ -1260,7 +1315,7 @@ __device__ __forceinline__ void chain_wait2(const unsigned long long* f0, int n0
     bool ok = false;
     for (int spin = 0; spin < kTpSpin && !ok; ++spin) {
       ok = (unsigned)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == tag;
-      if (!ok) __builtin_amdgcn_s_sleep(4);
+      if (!ok) __builtin_amdgcn_s_sleep(1);
     }
     if (!ok) report_expired(err, code);
   }
@@ -1318,10 +1373,9 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   stamp();   // entry
 
   // ---- what the update before (of this launch) must have finished; then this slice's rows
-  if (u > 0) {
-    const unsigned prev = ep - 1u;
-    chain_wait2(C.ct_fin, tc, C.at_fin, role == 1 ? 0 : ta, C.pf_done + slice, 1, prev, A.err, (KERN_PHASE1 << 8) | SITE_DW_GATE);
-  }
+  // (the rows first — they need the prefetch's flag only — then the flags of the tiles: a workgroup that is resident
+  // before the update before has finished has its rows in LDS when the last tile flags)
+  if (u > 0) chain_wait2(C.pf_done + slice, 1, nullptr, 0, nullptr, 0, ep - 1u, A.err, (KERN_PHASE1 << 8) | SITE_DW_GATE);
   if (u == 0 && C.first_gather) {
     load_batch(A.src, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);      // (gather = 1, this update's counter: the host's)
   } else {
@@ -1341,6 +1395,11 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
     }
   }
   stamp();   // batch rows requested
+  if (u > 0) {
+    __syncthreads();
+    chain_wait2(C.ct_fin, tc, C.at_fin, role == 1 ? 0 : ta, nullptr, 0, ep - 1u, A.err, (KERN_PHASE1 << 8) | SITE_DW_GATE);
+  }
+  stamp();   // the update before has finished
   const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
   // (later updates: the biases as the tiles of the update before left them — uncached copies; update 0: the masters)
   auto bias_of = [&](int which) {
@@ -1408,7 +1467,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
     const int u2 = by2 >> 4;
     const PassCtx cx{A.epoch + (unsigned)u2, A.cluster_tag + 2u * (unsigned)u2 + 1u, C.w3buf[u2 & 1], {C.b16[2][0], C.b16[2][1], C.b16[2][2]},
                      (kTraceOn && u2 == C.trace_u) ? A.trace2 : nullptr};
-    (void)ddpg_phase2m_body<P, DwKArgs4, false>(A, Dap, by2 & 15, cx);
+    (void)ddpg_phase2m_body<P, DwKArgs4, false, true>(A, Dap, by2 & 15, cx);
     return;
   }
 

@@ -254,6 +254,11 @@ struct DwGate {
   const float* w3 = nullptr;           // the output layer [A][256] (row-major) as it was BEFORE this launch
   const unsigned long long* g1 = nullptr;
   int n_act = 0;
+  //   kind 3  first hidden (k_ddpg_chain): dY[b, n] = sum_j du[b, j] G_j[b, n], G = unit-seed rows [A][B][256] the critic
+  //           pass's members wrote BEFORE the pass (flags gu_flags[8 x slices] {tag, *}): the tile waits for du only
+  const float* gu = nullptr;
+  const unsigned long long* gu_flags = nullptr;
+  int n_gu_flags = 0;
 };
 constexpr int kDuLd = 8;               // du granules per minibatch row (action_dim <= 8)
 
@@ -375,6 +380,8 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   unsigned long long* gate_flags;
   unsigned long long* du_granules;     // [B][kDuLd] {epoch, du}
   unsigned long long* g1_granules;     // [16 tiles][B][16] {epoch, dz1 of the actor}
+  float* gu;                           // k_ddpg_chain: [A][B][256] unit-seed dz1 rows of the actor (DwGate kind 3)
+  unsigned long long* gu_flags;        // [8 x slices] {epoch, *}: a pass member's share of them is out
   // k_ddpg_update: phase 1's roles, the critic's tiles, phase 2's critic pass and the actor's tiles in ONE
   // launch.  What a role hands to a later one crosses no kernel boundary: it lives in uncached memory (the learner's
   // workspace and fp16 packs), is written before a flag {epoch, *} — w_flags[0, 64): role C's members, the critic's tiles
