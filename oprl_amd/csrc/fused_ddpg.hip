@@ -1062,6 +1062,7 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
     __syncthreads();
     asm volatile("buffer_inv sc0" ::: "memory");
   }
+  stamp();   // role C's flags seen
   {
     const float* p0 = A.aX[0]; const float* p3 = A.pi; const int ld0 = A.aldx0;
     asm volatile("" :: "s"(p0), "s"(p3), "s"(ld0));
@@ -1079,7 +1080,15 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   if ((tid >> 6) < Ad) w3q = ld4(cx.w3 + (size_t)tid * 4);
   const int et = (tid >> 8) & 1, er = (tid >> 4) & 15, ec = tid & 15;   // g1 element (threads < 512): tile et, row er, column ec
   float m1 = 0.f;
-  if ((GE || tid < 512) && row0 + er < B) m1 = A.aX[1][(size_t)(row0 + er) * kW4 + 32 * c + 16 * et + ec];
+  if (!GE && tid < 512 && row0 + er < B) m1 = A.aX[1][(size_t)(row0 + er) * kW4 + 32 * c + 16 * et + ec];
+  // (GE: the h1 elements — ReLU masks — of this lane's four unit-seed outputs, requested with everything else: a load
+  // issued later would be waited for at the next barrier, a cold round trip inside the unit-seed stage)
+  f32x4 gm1 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (GE) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (row0 + 4 * kk + r < B) gm1[r] = A.aX[1][(size_t)(row0 + 4 * kk + r) * kW4 + 32 * c + 16 * (wave & 1) + i];
+  }
   // [s | pi]: loads first, then the zero fill and the stores
   const int rs_ = tid / S, cs_ = tid - rs_ * S;
   const bool oks = tid < kR * S && row0 + rs_ < B;
@@ -1103,55 +1112,64 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   // (the masks stay in one register through the pass: bits 0..3 the h2 quad, bit 4 the h1 element)
   const unsigned mbits = (hv[0] > 0.f ? 1u : 0u) | (hv[1] > 0.f ? 2u : 0u) | (hv[2] > 0.f ? 4u : 0u) | (hv[3] > 0.f ? 8u : 0u) |
                          (m1 > 0.f ? 16u : 0u);
+  stamp();   // rows and shard staged in LDS
   if constexpr (GE) {
     // ---- unit-seed backward through the second hidden layer, this member's 32 columns of the first one's dY:
     //     G_j[b, k] = (h1[b, k] > 0) sum_n (h2[b, n] > 0) W3[j, n] W2[n, k]          (dz1 = sum_j du_j G_j)
-    // the mask tile -> h1; wave = (tile t1 of the member's two, macro step ws of eight) keeps its W2^T fragment and runs
-    // two seeds per round (partials in h2 | g2), thread = element sums the eight steps; rows written to A.gu [A][B][256]
-    float* mS = h1;
-    float* part = h2;                                        // [2 seeds][16 waves][256]
-    static_assert(2 * HB >= 2 * 16 * 256, "two seeds' partial tiles fit two hidden buffers");
-    *reinterpret_cast<f32x4*>(mS + hr * kWL4 + hc) = f32x4{(mbits & 1u) ? 1.f : 0.f, (mbits & 2u) ? 1.f : 0.f, (mbits & 4u) ? 1.f : 0.f, (mbits & 8u) ? 1.f : 0.f};
-    __syncthreads();                                         // mask tile, W2^T shard, W3 rows in LDS
-    const int t1 = wave & 1, ws = wave >> 1;
-    const float* bw = Wl + ((size_t)t1 * 8 + ws) * 512 + lane * 4;
-    const FragX2 bf{ld4(bw), ld4(bw + 256)};
-    const f32x4 ma = ld4(mS + i * kWL4 + 32 * ws + 4 * kk), mb = ld4(mS + i * kWL4 + 32 * ws + 16 + 4 * kk);
-    for (int j0 = 0; j0 < Ad; j0 += 2) {
+    // The A operand (h2 > 0) W3[j, :] is a MASKED copy of one row for all 16 minibatch rows: the row is split into its
+    // two fp16 planes ONCE (wave j = row j: scaled by the power of two of its largest magnitude), the masks become
+    // 0 / 0xffff halfs, and a macro step's operand is two ANDs — no per-step scaling, no per-step split (a first form
+    // that split mask * W3 per step was bound by vector instructions: 4.3 us).  wave = (tile t1 of the member's two,
+    // seed j) runs the whole 256-deep contraction itself: nothing is exchanged between waves, one barrier.  The rows
+    // go to A.gu [A][B][256]; their flag is raised after the wait for the critic's tiles below.
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    _Float16* mH = reinterpret_cast<_Float16*>(h1);                   // [16 rows][8 steps][4 kk][8 halfs] masks
+    _Float16* wH = reinterpret_cast<_Float16*>(h1 + 2048);            // [kDuLd][8][4][8] hi plane of s_j W3[j]
+    _Float16* wL = reinterpret_cast<_Float16*>(h1 + 2048 + 1024);     // ... lo plane
+    float* sJ = h1 + 2048 + 2048;                                      // [kDuLd] s_j
+    static_assert(HB >= 2048 + 2048 + 16, "masks and the output layer's planes fit one hidden buffer");
+    {
+      const int l = tid & 63, ws_ = l >> 3, half_ = (l >> 2) & 1, kq_ = l & 3;
+      const int off = ((ws_ * 4 + kq_) * 8) + 4 * half_;             // halfs, inside a (row | seed) block of 256
+      union { f16x4 v; unsigned short b[4]; } mk;
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int j = j0 + jj;
-        if (j < Ad) {
-          const f32x4 x0 = ma * ld4(w3s + j * 256 + 32 * ws + 4 * kk), x1 = mb * ld4(w3s + j * 256 + 32 * ws + 16 + 4 * kk);
-          float m = fmaxf(fmaxf(fmaxf(fabsf(x0[0]), fabsf(x0[1])), fmaxf(fabsf(x0[2]), fabsf(x0[3]))),
-                          fmaxf(fmaxf(fabsf(x1[0]), fabsf(x1[1])), fmaxf(fabsf(x1[2]), fabsf(x1[3]))));
-          m = wave_max(m);
-          const float sa = P::a_scale(m), un = PrecX2::kOut / sa;
-          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-          PrecX2::mma3(x0 * sa, x1 * sa, bf, acc);
-          float* o = part + ((size_t)jj * 16 + wave) * 256;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[(4 * kk + r) * 16 + i] = acc[r] * un;
-        }
+      for (int t = 0; t < 4; ++t) mk.b[t] = ((mbits >> t) & 1u) ? 0xffffu : 0u;
+      *reinterpret_cast<f16x4*>(mH + hr * 256 + off) = mk.v;          // thread = (row hr, columns hc .. hc + 3), hc = 4 l
+      if ((tid >> 6) < kDuLd) {                                       // wave j: row j of the output layer (w3q; zero beyond A)
+        float m = fmaxf(fmaxf(fabsf(w3q[0]), fabsf(w3q[1])), fmaxf(fabsf(w3q[2]), fabsf(w3q[3])));
+        m = wave_max(m);
+        const float sj = P::a_scale(m);
+        f16x8 hi8, lo8;
+        x2_split8(w3q * sj, f32x4{0.f, 0.f, 0.f, 0.f}, hi8, lo8);
+        *reinterpret_cast<f16x4*>(wH + (tid >> 6) * 256 + off) = __builtin_shufflevector(hi8, hi8, 0, 1, 2, 3);
+        *reinterpret_cast<f16x4*>(wL + (tid >> 6) * 256 + off) = __builtin_shufflevector(lo8, lo8, 0, 1, 2, 3);
+        if (l == 0) sJ[tid >> 6] = sj;
       }
-      __syncthreads();
-      {
-        const int jj = tid >> 9, j = j0 + jj;              // threads 0..511: the round's first seed, 512..1023: its second
-        if (j < Ad && row0 + er < B) {
-          float v = 0.f;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v += part[((size_t)jj * 16 + 2 * q + et) * 256 + er * 16 + ec];
-          A.gu[((size_t)j * B + row0 + er) * kW4 + 32 * c + 16 * et + ec] = (mbits & 16u) != 0u ? v : 0.f;
-        }
-      }
-      __syncthreads();                                       // (the next round rewrites the partial tiles)
     }
-    // every wave's rows are out before the member says so (uncached memory): the first-layer tiles read them after this
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0)
-      __hip_atomic_store(A.gu_flags + slice * NMC + c, (unsigned long long)cx.epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    stamp();   // unit-seed rows out
+    __syncthreads();                                         // masks, planes, W2^T shard in LDS
+    const int t1 = wave & 1, j = wave >> 1;
+    if (j < Ad) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int ws = 0; ws < 8; ++ws) {
+        const float* bw = Wl + ((size_t)t1 * 8 + ws) * 512 + lane * 4;
+        const f16x8 bh = __builtin_bit_cast(f16x8, ld4(bw)), bl = __builtin_bit_cast(f16x8, ld4(bw + 256));
+        const u32x4v mk = *reinterpret_cast<const u32x4v*>(mH + i * 256 + (ws * 4 + kk) * 8);
+        const u32x4v h4 = *reinterpret_cast<const u32x4v*>(wH + j * 256 + (ws * 4 + kk) * 8);
+        const u32x4v l4 = *reinterpret_cast<const u32x4v*>(wL + j * 256 + (ws * 4 + kk) * 8);
+        const f16x8 ah = __builtin_bit_cast(f16x8, h4 & mk), al = __builtin_bit_cast(f16x8, l4 & mk);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+      }
+      const float un = PrecX2::kOut / sJ[j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (row0 + 4 * kk + r < B)
+          A.gu[((size_t)j * B + row0 + 4 * kk + r) * kW4 + 32 * c + 16 * t1 + i] = gm1[r] > 0.f ? acc[r] * un : 0.f;
+    }
+    stamp();   // unit-seed rows requested out
   }
   if (A.whole) {
     // ... the critic's TILES of this launch wrote the critic's fp16 packs and biases (uncached memory): their flags
@@ -1168,6 +1186,13 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
     __syncthreads();
     asm volatile("buffer_inv sc0" ::: "memory");
     cbo.b0 = cx.cb[0]; cbo.b1 = cx.cb[1]; cbo.b2 = cx.cb[2];
+  }
+  if constexpr (GE) {
+    // (every wave's unit-seed rows are out — uncached memory — before the member says so: the first-layer tiles read them after this)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_store(A.gu_flags + slice * NMC + c, (unsigned long long)cx.epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   stamp();
   float* qsum = nullptr;
@@ -1417,12 +1442,19 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
       xb[row * kX0Ld + S + col] = gr < B ? tanhf(outS[row * kOutLd + col]) : 0.f;
     }
     // role B's q granules are requested from inside the second pass (after its layer-1 stage)
-    unsigned long long gq = 0ull;
+    // (role B's members leave their PARTIAL q — no exchange at the end of role B: summed here, in member order, with the
+    // output bias: the cluster all-reduce's arithmetic)
+    unsigned long long gq[4] = {0ull, 0ull, 0ull, 0ull};
+    float qb = 0.f;
     int hook_n = 0;
-    const unsigned long long* gq_src = A.y_granules + A.gran_stride + min(row0 + (tid & (kR - 1)), B - 1);
+    const unsigned long long* gq_src = C.qp + (size_t)slice * 64 + (tid & (kR - 1));
     auto hook = [&]() {
       stamp();
-      if (++hook_n == 2) gq = __hip_atomic_load(gq_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (++hook_n == 2) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) gq[m] = __hip_atomic_load(gq_src + m * kR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        qb = (u > 0 ? C.b16[2][2] : A.critic.b[2])[0];
+      }
     };
     tp4_forward<P, 8>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, hook, bias_of(3));
     if (lead && tid < 64) {
@@ -1433,15 +1465,22 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
       const int lim = A.debug_expire == (int)SITE_TD_TARGET ? 0 : (1 << 20);
       float q = 0.f;
       if (row_ok) {
-        unsigned long long g = gq;
-        bool ok = lim > 0 && (unsigned)(g >> 32) == ep;
+        bool ok = lim > 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) ok = ok && (unsigned)(gq[m] >> 32) == ep;
         for (int sp = 0; sp < lim && !ok; ++sp) {
-          g = __hip_atomic_load(A.y_granules + (size_t)A.gran_stride + gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = (unsigned)(g >> 32) == ep;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) gq[m] = __hip_atomic_load(gq_src + m * kR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = true;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) ok = ok && (unsigned)(gq[m] >> 32) == ep;
           if (!ok) __builtin_amdgcn_s_sleep(1);
         }
         if (!ok) report_expired(A.err, (KERN_PHASE1 << 8) | SITE_TD_TARGET);
-        q = ok ? __uint_as_float((unsigned)g) : __builtin_nanf("");
+        float qs = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) qs += __uint_as_float((unsigned)gq[m]);
+        q = ok ? qs + qb : __builtin_nanf("");
         const float seed = 2.f * (q - y) * A.inv_B;
         A.cdY[2][(size_t)gr * A.clddo] = seed;
         __hip_atomic_store(A.y_granules + gr, ((unsigned long long)ep << 32) | (unsigned long long)__float_as_uint(seed),
@@ -1475,22 +1514,21 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
     // ---- role B: q = critic(s, a) forward and its whole backward with unit seed (tp4_scalar_fb)      (ddpg.py:96-100)
     Tp tp{member, 4, A.xbuf + ((size_t)1 * slices + slice) * kTpStages * A.xnc * kTpBlk, tag1, 0, A.err, KERN_PHASE1 << 8, spin};
     const Tp3Store st{A.cX[1], A.cX[2], A.cdY[1], A.cdY[0], A.cdY0_stride, B, true};
-    tp4_scalar_fb<P>(A.critic, xa, h1, h2, h1 + 2 * HB, outS, scr, tp, st, row0, B, 1.f, 0, 0, nullptr, stamp, nullptr, bias_of(2));
-    if (lead) {
+    if (lead) {        // (the input rows for the critic's first-layer tiles: out before the pass)
+      __syncthreads();
       for (int idx = tid; idx < kR * (S + Ad); idx += kThreads) {
         const int row = idx / (S + Ad), col = idx - row * (S + Ad), gr = row0 + row;
         if (gr < B) __hip_atomic_store(A.cX[0] + (size_t)gr * A.cldx0 + col, xa[row * kX0Ld + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    // q leaves as the members' partial sums (granules, no exchange): role A adds them up
+    const QPart qp{C.qp + (size_t)slice * 64, ep};
+    tp4_scalar_fb<P>(A.critic, xa, h1, h2, h1 + 2 * HB, outS, scr, tp, st, row0, B, 1.f, 0, 0, nullptr, stamp, nullptr, bias_of(2), qp);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0)
       __hip_atomic_store(A.gate_flags + slice * 4 + member, (unsigned long long)ep << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (lead && tid < kR && row0 + tid < B)
-      __hip_atomic_store(A.y_granules + (size_t)A.gran_stride + row0 + tid,
-                         ((unsigned long long)ep << 32) | (unsigned long long)__float_as_uint(outS[tid * kOutLd]),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    stamp();   // q published
+    stamp();   // rows flagged
   } else {
     // ---- role C: actor(s) forward, pi = tanh(.) and the activations for the actor's tiles / the critic pass
     Tp tp{member, 4, A.xbuf + ((size_t)2 * slices + slice) * kTpStages * A.xnc * kTpBlk, tag1, 0, A.err, KERN_PHASE1 << 8, spin};

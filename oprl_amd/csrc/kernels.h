@@ -421,6 +421,7 @@ struct ChainArgs {
   unsigned long long* pf_done;         // [slices]: the rows of the update after `epoch` are staged
   const float* b16[4][kMaxLayers];     // uncached bias copies the tiles leave: 0 actor, 1 actor target, 2 critic, 3 critic target
   float* w3buf[2];                     // the actor's output layer [A][256] before update u: w3buf[u & 1]
+  unsigned long long* qp;              // [slices][4 members][16 rows] {epoch, partial q}: role B -> role A (tp4.h QPart)
 };
 
 constexpr int kDwTile = 32;      // k (fan-in) extent of a dW tile

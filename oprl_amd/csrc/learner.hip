@@ -445,7 +445,7 @@ struct oprl_learner {
   float* critic_b16 = nullptr;
   // k_ddpg_chain (several updates per launch): the tiles' FIN flags, the prefetch flags, the uncached bias copies of all
   // four nets ([0] actor, [1] actor target, [2] critic = critic_b16, [3] critic target) and the output layer's two buffers
-  unsigned long long* chain_flags = nullptr;   // [ct_fin 192 | at_fin 192 | pf_done 64 | gu_flags 128]
+  unsigned long long* chain_flags = nullptr;   // [ct_fin 192 | at_fin 192 | pf_done 64 | gu_flags 128 | partial q 1024]
   float* gu = nullptr;                         // [kDuLd][Bm][256] the actor's unit-seed dz1 rows (DwGate kind 3)
   float* chain_b16 = nullptr;                  // [4][kMaxLayers][256]
   float* w3buf1 = nullptr;                     // (w3buf[0] = w3_snap)
@@ -1147,7 +1147,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
         HIPC(hipMemsetAsync(h->du_granules, 0, (size_t)(h->Bmax < 256 ? h->Bmax : 256) * kDuLd * sizeof(unsigned long long), st));
         HIPC(hipMemsetAsync(h->g1_granules, 0, (size_t)16 * (h->Bmax < 256 ? h->Bmax : 256) * 16 * sizeof(unsigned long long), st));
         HIPC(hipMemsetAsync(h->w_flags, 0, 256 * sizeof(unsigned long long), st));
-        HIPC(hipMemsetAsync(h->chain_flags, 0, (192 + 192 + 64 + 128) * sizeof(unsigned long long), st));
+        HIPC(hipMemsetAsync(h->chain_flags, 0, (192 + 192 + 64 + 128 + 1024) * sizeof(unsigned long long), st));
       }
     }
     DdpgArgs fa = ddpg_args(h, B);
@@ -1228,6 +1228,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
           for (int l = 0; l < kMaxLayers; ++l) ca.b16[w][l] = h->chain_b16 + ((size_t)w * kMaxLayers + l) * 256;
         ca.w3buf[0] = h->w3_snap; ca.w3buf[1] = h->w3buf1;
         // the first hidden layer's dY from the unit-seed rows the pass's members leave before the pass (DwGate kind 3)
+        ca.qp = h->chain_flags + 576;
         fa.gu = h->gu; fa.gu_flags = h->chain_flags + 448;
         ka.gate.kind[0] = 3; ka.gate.gu = h->gu; ka.gate.gu_flags = fa.gu_flags; ka.gate.n_gu_flags = 8 * slices;
         if (kc.tile_end[kDwFusedItems - 1] > 192 || ka.tile_end[kDwFusedItems - 1] > 192 || slices > 64) { set_err("chain launch: too many tiles"); return OPRL_ERR_INVALID; }
@@ -2062,7 +2063,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   const int Bm = B < 256 ? B : 256;             // merged phase 2 serves one 256-row chunk
   const bool merge2_bufs = h->fused && cfg->algo != OPRL_SAC && A <= kDuLd;
   if (merge2_bufs) floats += 2 * ((size_t)Bm * kDuLd + 64) + 2 * 256 + 128 + 2 * (size_t)16 * Bm * 16 + 64 + 16 * 256 + 4 * 64 + 2 * 256 + 64 + kMaxLayers * 256 + 64;
-  if (merge2_bufs) floats += 2 * (192 + 192 + 64 + 128) + 64 + 4 * kMaxLayers * 256 + 64 + 16 * 256 + 64 + (size_t)kDuLd * Bm * 256 + 64;      // (k_ddpg_chain)
+  if (merge2_bufs) floats += 2 * (192 + 192 + 64 + 128 + 1024) + 64 + 4 * kMaxLayers * 256 + 64 + 16 * 256 + 64 + (size_t)kDuLd * Bm * 256 + 64;      // (k_ddpg_chain)
   if (h->bf16 || h->x2) {
     floats += 2 * ((size_t)net_pack16_floats(cfg->actor, h->planes) + 64);
     for (int j = 0; j < nc; ++j) floats += 2 * ((size_t)net_pack16_floats(cfg->critics[j], h->planes) + 64);
@@ -2115,7 +2116,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->g1_granules = p.take<unsigned long long>((size_t)16 * Bm * 16);
     h->w3_snap = p.take<float>(16 * 256);
     h->w_flags = p.take<unsigned long long>(256);
-    h->chain_flags = p.take<unsigned long long>(192 + 192 + 64 + 128);
+    h->chain_flags = p.take<unsigned long long>(192 + 192 + 64 + 128 + 1024);
     h->gu = p.take<float>((size_t)kDuLd * Bm * 256);
     h->chain_b16 = p.take<float>(4 * kMaxLayers * 256);
     h->critic_b16 = h->chain_b16 + 2 * kMaxLayers * 256;

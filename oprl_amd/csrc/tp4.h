@@ -89,6 +89,10 @@ __device__ __forceinline__ float tp4_tile_amax(const float* T, int ncols16) {
 // Biases from somewhere else than the net's master arena (k_ddpg_chain's later updates: the uncached copies the
 // tiles of the update before left); null members = the net's own.
 struct BiasOv { const float* b0 = nullptr; const float* b1 = nullptr; const float* b2 = nullptr; };
+// tp4_scalar_fb, clusters of four: q leaves as the members' PARTIAL sums — granules out[member * kR + row] {tag, value},
+// no exchange inside the pass — for a consumer that adds them up itself in member order (+ the output bias): role B of
+// k_ddpg_chain, whose q only role A reads.  out == null: the cluster all-reduce.
+struct QPart { unsigned long long* out = nullptr; unsigned tag = 0; };
 
 __host__ __device__ inline bool tp4_shape_ok(int width, int fan_in, int n_out) {
   return width == kW4 && fan_in <= 16 * kMaxS0 && n_out <= kNarrowMax;
@@ -535,7 +539,7 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
                                               float* g2, float* outS, float* scr, Tp& tp,
                                               const Tp3Store& st, int row0, int B, float seed,
                                               int dact_col0, int dact_cols, float* dactS, ST sf = ST(),
-                                              float* q_sum_out = nullptr, const BiasOv bo = BiasOv()) {
+                                              float* q_sum_out = nullptr, const BiasOv bo = BiasOv(), const QPart qp = QPart()) {
   const float* const nb0 = bo.b0 != nullptr ? bo.b0 : net.b[0];
   const float* const nb1 = bo.b1 != nullptr ? bo.b1 : net.b[1];
   const float* const nb2 = bo.b2 != nullptr ? bo.b2 : net.b[2];
@@ -699,6 +703,14 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
         const float qv = (lane < kR && row0 + lane < B) ? outS[lane * kOutLd] : 0.f;
         const float qs = row16_sum(qv);
         if (lane == 0) *q_sum_out = qs;
+      }
+    } else if (qp.out != nullptr) {
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __hip_atomic_store(qp.out + tp.c * kR + 4 * kk + r,
+                             ((unsigned long long)qp.tag << 32) | (unsigned long long)__float_as_uint(qpart[r]),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
     const f32x4 sum = tp4_allreduce_regs<NM>(qpart, i, valid, tp);
