@@ -135,7 +135,7 @@ def cpu_baseline(budget_s: float = 14.0):
 # ---- the other BASELINE.json configurations, the bf16 mode and the through-the-API rate --------
 PEAK_BF16_MATRIX_TFLOPS = 2500.0       # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F16_MATRIX_TFLOPS = 2500.0        # dense fp16 MFMA; the x2 mode spends three products per algorithmic one
-PMC_FILE = {"f32": "r03_pmc_traffic_f32.json", "bf16": "r03_pmc_traffic_bf16.json", "x2": "r03_pmc_traffic_x2.json"}
+PMC_FILE = {"f32": "r04_pmc_traffic_f32.json", "bf16": "r04_pmc_traffic_bf16.json", "x2": "r04_pmc_traffic_x2.json"}
 PEAK_OF = {"f32": PEAK_F32_MATRIX_TFLOPS, "bf16": PEAK_BF16_MATRIX_TFLOPS, "x2": PEAK_F16_MATRIX_TFLOPS / 3.0}
 DTYPE_OF = {"f32": "f32 (exact-fp32 MFMA)", "bf16": "bf16 (fp32 accumulate / master / Adam)",
             "x2": "f32 as split fp16x2 (hi + lo, 3 fp16 MFMAs per product, fp32 accumulate / master / Adam)"}
@@ -720,13 +720,17 @@ def measure(args, wd):
             # is counted in phase 1's slot), the merged launches (phase 1 + the critic's tiles | phase 2 [+ the actor's
             # tiles]), or the plain sequence
             whole = "k_ddpg_phase1" in kern and "k_ddpg_phase2" not in kern and "k_dw_adam" not in kern
+            # ... or SEVERAL updates per launch (k_ddpg_chain: step_n's K-loop inside the launch, up to 32 updates each)
+            upl = 1.0
             if whole:
-                kern["k_ddpg_update"] = kern.pop("k_ddpg_phase1")
-            dom = "k_ddpg_update" if whole else ("k_ddpg_phase1" if "k_ddpg_phase1" in kern else "k_mlp_slice")
+                upl = 1.0 / max(kern["k_ddpg_phase1"]["launches_per_step"], 1e-9)
+                kern["k_ddpg_chain" if upl > 1.01 else "k_ddpg_update"] = kern.pop("k_ddpg_phase1")
+            dom = ("k_ddpg_chain" if upl > 1.01 else "k_ddpg_update") if whole else ("k_ddpg_phase1" if "k_ddpg_phase1" in kern else "k_mlp_slice")
             merged = dom == "k_ddpg_phase1" and kern.get("k_dw_adam", {}).get("launches_per_step", 2.0) < 1.5
             if whole:
-                macs = MACS_SLICE + MACS_DW
-                nbytes = STATE_BYTES + 4 * B * (2 * S + A + 2)
+                # (per LAUNCH, as the contract asks: one update's algorithmic work x the updates one launch runs)
+                macs = (MACS_SLICE + MACS_DW) * upl
+                nbytes = (STATE_BYTES + 4 * B * (2 * S + A + 2)) * upl
             elif dom == "k_ddpg_phase1":
                 macs = MACS_P1 + (F_CRITIC if merged else 0)
                 nbytes = (32 * (F_CRITIC + HID * 2 + 1) if merged else 0) + 4 * B * (2 * S + A + 2)
@@ -742,12 +746,21 @@ def measure(args, wd):
             # the binding roof is the one whose ideal time for this launch is longer
             t_mfma, t_hbm = flop_per_launch / (peak * 1e12), nbytes / (PEAK_HBM_TBS * 1e12)
             hbm_bound = t_hbm > t_mfma
-            traffic = mfma_util = None
-            try:   # HBM bytes per launch and matrix-core utilisation from the committed rocprofv3 PMC passes of this same command
+            # HBM bytes and matrix-core utilisation are NOT measured in this run: they are read from the committed rocprofv3
+            # --pmc passes of this same command (the builder's run: tools/profile_round.sh) and labelled as such;
+            # `traffic` is per launch like `achieved` — the file's per-update figure x the updates this run's launches held
+            traffic = mfma_util = traffic_per_update = None
+            counters_source = None
+            try:
                 pmc = json.load(open(ROOT / "profiles" / PMC_FILE[args.precision]))
                 pk = next((k for k in (dom, dom + "_dw") if k in pmc), dom)
-                traffic = pmc.get(pk, {}).get("hbm_bytes_per_launch")
-                mfma_util = pmc.get(pk, {}).get("mfma_util")
+                if pk in pmc:
+                    per_upd = pmc[pk].get("hbm_bytes_per_update", pmc[pk].get("hbm_bytes_per_launch"))
+                    traffic_per_update = per_upd
+                    traffic = int(per_upd * upl) if per_upd is not None else None
+                    mfma_util = pmc[pk].get("mfma_util")
+                    counters_source = (f"profiles/{PMC_FILE[args.precision]} (builder's rocprofv3 --pmc passes of this command, "
+                                       "tools/profile_round.sh; not measured in this run)")
             except Exception:  # noqa: BLE001
                 pass
             arith = {"f32": "exact-fp32 v_mfma_f32_16x16x4_f32", "bf16": "v_mfma_f32_16x16x32_bf16, fp32 accumulate",
@@ -755,6 +768,10 @@ def measure(args, wd):
             what = {"k_ddpg_update": "k_ddpg_update (the WHOLE update as one launch: target chain, critic forward / backward, "
                                      "the critic's dW + Adam + Polyak tiles, critic pass for the actor loss, the actor's "
                                      "backward and dW + Adam + Polyak tiles, next batch's gather; ",
+                    "k_ddpg_chain": f"k_ddpg_chain ({upl:.1f} WHOLE updates per launch — step_n's K-loop inside the launch: per "
+                                    "update the target chain, critic forward / backward, the critic's dW + Adam + Polyak tiles, "
+                                    "the critic pass for the actor loss, the actor's unit-seed backward and dW + Adam + Polyak "
+                                    "tiles, the next batch's gather; an update's roles start behind the flags of the one before; ",
                     "k_ddpg_phase1": ("k_ddpg_phase1_dw (phase 1 + the critic's dW / Adam tiles in one launch; " if merged
                                       else "k_ddpg_phase1<256> ("),
                     "k_mlp_slice": "k_mlp_slice ("}[dom]
@@ -762,6 +779,8 @@ def measure(args, wd):
                         achieved=round(ach_bytes if hbm_bound else ach_flops, 3),
                         peak=PEAK_HBM_TBS * 1e3 if hbm_bound else round(peak, 1), unit="GB/s" if hbm_bound else "TFLOP/s",
                         frac=round((t_hbm if hbm_bound else t_mfma) / dur, 5), traffic=traffic, mfma_util=mfma_util,
+                        traffic_per_update=traffic_per_update, counters_source=counters_source,
+                        updates_per_launch=round(upl, 2), us_per_update=round(dur * 1e6 / upl, 3),
                         flop_per_launch=flop_per_launch, bytes_per_launch=nbytes,
                         other_roof=dict(bound="mfma" if hbm_bound else "hbm",
                                         achieved=round(ach_flops if hbm_bound else ach_bytes, 3),
@@ -776,7 +795,7 @@ def measure(args, wd):
                              f"(serialised pass of {P} steps) minus event_overhead_us, the per-launch "
                              "excess of that pass over the un-instrumented timed loop (where the same "
                              "launches run back to back, so a step is the sum of their durations); they "
-                             "agree with rocprofv3 --kernel-trace --stats (profiles/r03_kernel_stats_*.csv); "
+                             "agree with rocprofv3 --kernel-trace --stats (profiles/r04_kernel_stats_*.csv); "
                              "sum of kernel time per step = "
                              f"{sum(k['us_per_step'] for k in kern.values()):.1f} us; bytes_per_launch = 32 B per trained "
                              "parameter (theta, m, v, theta_target read + written) + the gathered minibatch rows; "
@@ -787,8 +806,8 @@ def measure(args, wd):
                              "passes, tools/profile_round.sh).  Neither roof binds: an update is a CHAIN of dependent "
                              "16-row-slice stages (target chain -> TD seeds -> critic tiles -> critic pass -> du -> actor "
                              "tiles) whose length is set by cross-workgroup flag hops, cold weight-shard loads and "
-                             "workgroup dispatch, not by bandwidth or the matrix cores (DESIGN.md section 6; timeline in "
-                             "profiles/r03_stage_stamps.txt)")
+                             "workgroup dispatch, not by bandwidth or the matrix cores (DESIGN.md section 0.2; timeline in "
+                             "profiles/r04_stage_stamps.txt)")
         multi = None
         group = None
         if not use_dp and args.learners > 1:

@@ -1400,7 +1400,10 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   // ---- what the update before (of this launch) must have finished; then this slice's rows
   // (the rows first — they need the prefetch's flag only — then the flags of the tiles: a workgroup that is resident
   // before the update before has finished has its rows in LDS when the last tile flags)
-  if (u > 0) chain_wait2(C.pf_done + slice, 1, nullptr, 0, nullptr, 0, ep - 1u, A.err, (KERN_PHASE1 << 8) | SITE_DW_GATE);
+  // (role A is resident long before the update before has finished: pf -> rows -> the tiles' flags; roles B and C are
+  // dispatched when it is all but over: one look at everything they wait for)
+  if (u > 0 && role == 0) chain_wait2(C.pf_done + slice, 1, nullptr, 0, nullptr, 0, ep - 1u, A.err, (KERN_PHASE1 << 8) | SITE_DW_GATE);
+  if (u > 0 && role != 0) chain_wait2(C.ct_fin, tc, C.at_fin, role == 1 ? 0 : ta, C.pf_done + slice, 1, ep - 1u, A.err, (KERN_PHASE1 << 8) | SITE_DW_GATE);
   if (u == 0 && C.first_gather) {
     load_batch(A.src, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);      // (gather = 1, this update's counter: the host's)
   } else {
@@ -1420,9 +1423,9 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
     }
   }
   stamp();   // batch rows requested
-  if (u > 0) {
+  if (u > 0 && role == 0) {
     __syncthreads();
-    chain_wait2(C.ct_fin, tc, C.at_fin, role == 1 ? 0 : ta, nullptr, 0, ep - 1u, A.err, (KERN_PHASE1 << 8) | SITE_DW_GATE);
+    chain_wait2(C.ct_fin, tc, C.at_fin, ta, nullptr, 0, ep - 1u, A.err, (KERN_PHASE1 << 8) | SITE_DW_GATE);
   }
   stamp();   // the update before has finished
   const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};

@@ -38,6 +38,14 @@ for k in fetch:
     w_kb = write.get(k, (0.0, 0))[0]
     out[k] = {"FETCH_SIZE_KB_per_launch_raw": round(f_kb, 1), "WRITE_SIZE_KB_per_launch": round(w_kb, 1),
               "launches": n, "hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024)}
+# k_ddpg_chain runs several updates per launch (OPRL_UPL of them in the profiled command, tools/profile_round.sh)
+import os
+_upl = float(os.environ.get("OPRL_UPL", "0") or 0)
+if _upl > 0 and "k_ddpg_chain" in out:
+    out["k_ddpg_chain"]["updates_per_launch"] = _upl
+    out["k_ddpg_chain"]["hbm_bytes_per_update"] = int(out["k_ddpg_chain"]["hbm_bytes_per_launch"] / _upl)
+
+
 def stats_ns(path):
     """kernel short name -> average duration (ns) from a rocprofv3 --stats kernel_stats.csv"""
     out = {}
