@@ -1362,7 +1362,8 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   using LY = FusedLds<256>;
   constexpr int HB = kR * kWL4;
   const int slices = (int)gridDim.x, slice = (int)blockIdx.x;
-  const int u = (int)blockIdx.y >> 4, yy = (int)blockIdx.y & 15;
+  const int R = C.rows;                      // grid rows per update: A 8 | B 4 | C 4 | T (tile-only rows: small batches)
+  const int u = (int)blockIdx.y / R, yy = (int)blockIdx.y - u * R;
   const int B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x, row0 = slice * kR;
   const unsigned ep = A.epoch + (unsigned)u;
   const unsigned tag1 = A.cluster_tag + 2u * (unsigned)u, tag2 = tag1 + 1u;
@@ -1379,15 +1380,17 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   float* yS = dS + kR;
   int* meta = reinterpret_cast<int*>(yS + kR);
   int* endsS = reinterpret_cast<int*>(smem + LY::misc + 96);
-  const int role = yy < 8 ? 0 : (yy < 12 ? 1 : 2);
-  const int member = yy < 8 ? yy : (yy - 8) & 3;
+  // (role 3 = T: where roles B and C have fewer workgroups than a net has tiles — batches of fewer than 11 slices —
+  // the remaining tiles are rows of workgroups of their own, dispatched behind role C)
+  const int role = yy < 8 ? 0 : (yy < 12 ? 1 : (yy < 16 ? 2 : 3));
+  const int member = yy < 8 ? yy : (yy < 16 ? (yy - 8) & 3 : 1);
   const bool lead = member == 0;
   const int spin = A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin;
   // in-kernel stage stamps (liboprl_amd_trace.so): update C.trace_u of the launch, the slots of k_ddpg_update
   const bool traced = kTraceOn && A.trace != nullptr && u == C.trace_u;
   int n_stamp = 0;
   auto stamp = [&]() {
-    if (traced && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
+    if (traced && role < 3 && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
       const int slot = tid == 0 ? slice : 16 + (tid >> 6);
       long long* tr = A.trace + (((size_t)role * 64 + slot) * kTraceStamps + n_stamp) * 2;
       tr[0] = (long long)__builtin_readcyclecounter();
@@ -1403,8 +1406,10 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   // (role A is resident long before the update before has finished: pf -> rows -> the tiles' flags; roles B and C are
   // dispatched when it is all but over: one look at everything they wait for)
   if (u > 0 && role == 0) chain_wait2(C.pf_done + slice, 1, nullptr, 0, nullptr, 0, ep - 1u, A.err, (KERN_PHASE1 << 8) | SITE_DW_GATE);
-  if (u > 0 && role != 0) chain_wait2(C.ct_fin, tc, C.at_fin, role == 1 ? 0 : ta, C.pf_done + slice, 1, ep - 1u, A.err, (KERN_PHASE1 << 8) | SITE_DW_GATE);
-  if (u == 0 && C.first_gather) {
+  if (u > 0 && role != 0) chain_wait2(C.ct_fin, tc, C.at_fin, role == 1 ? 0 : ta, C.pf_done + slice, role == 3 ? 0 : 1, ep - 1u, A.err, (KERN_PHASE1 << 8) | SITE_DW_GATE);
+  if (role == 3) {
+    // (a tile-only workgroup: no rows)
+  } else if (u == 0 && C.first_gather) {
     load_batch(A.src, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);      // (gather = 1, this update's counter: the host's)
   } else {
     // staged rows of this update's parity (or, update 0 of an update() call, the caller's rows: set0)
@@ -1506,10 +1511,10 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
     // index: nothing of the role stays in a register through the pass)
     int by2 = (int)blockIdx.y;
     asm volatile("" : "+s"(by2));
-    const int u2 = by2 >> 4;
+    const int u2 = by2 / C.rows;
     const PassCtx cx{A.epoch + (unsigned)u2, A.cluster_tag + 2u * (unsigned)u2 + 1u, C.w3buf[u2 & 1], {C.b16[2][0], C.b16[2][1], C.b16[2][2]},
                      (kTraceOn && u2 == C.trace_u) ? A.trace2 : nullptr};
-    (void)ddpg_phase2m_body<P, DwKArgs4, false, true>(A, Dap, by2 & 15, cx);
+    (void)ddpg_phase2m_body<P, DwKArgs4, false, true>(A, Dap, by2 - u2 * C.rows, cx);
     return;
   }
 
@@ -1532,7 +1537,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
     if (tid == 0)
       __hip_atomic_store(A.gate_flags + slice * 4 + member, (unsigned long long)ep << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     stamp();   // rows flagged
-  } else {
+  } else if (role == 2) {
     // ---- role C: actor(s) forward, pi = tanh(.) and the activations for the actor's tiles / the critic pass
     Tp tp{member, 4, A.xbuf + ((size_t)2 * slices + slice) * kTpStages * A.xnc * kTpBlk, tag1, 0, A.err, KERN_PHASE1 << 8, spin};
     const Tp3Store st{A.aX[1], A.aX[2], nullptr, nullptr, 0};
@@ -1561,14 +1566,16 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   // in a register through the tiles (these kernels sit at the scalar-register limit; what does not fit is spilled)
   int by2 = (int)blockIdx.y, bx2 = (int)blockIdx.x, nx2 = (int)gridDim.x;
   asm volatile("" : "+s"(by2), "+s"(bx2), "+s"(nx2));
-  const int u2 = by2 >> 4, wg2 = ((by2 & 15) - 8) * nx2 * 0 + (((by2 & 15) >= 12) ? 4 * nx2 : 0) + bx2 * 4 + ((by2 - 8) & 3);
+  // (index among the tile workgroups: role B slice-major, role C behind it, then T's rows)
+  const int u2 = by2 / C.rows, y2 = by2 - u2 * C.rows;
+  const int wg2 = y2 < 16 ? ((y2 >= 12) ? 4 * nx2 : 0) + bx2 * 4 + ((y2 - 8) & 3) : 8 * nx2 + (y2 - 16) * nx2 + bx2;
   const int n_bc = 8 * nx2;
   const unsigned ep2 = A.epoch + (unsigned)u2;
 
   // ---- the next update's rows: the last `slices` of these workgroups, before their tiles (at B = 256 they have none)
   {
     const int p = n_bc - 1 - wg2;
-    if (p < nx2 && (u2 + 1 < C.n_upd || C.pf_last)) {
+    if (p >= 0 && p < nx2 && (u2 + 1 < C.n_upd || C.pf_last)) {
       const int par2 = u2 & 1;
       BatchSrc nx = A.next;                 // (the replay's view; gather = 1)
       nx.s = par2 ? C.set0[0] : C.set1[0]; nx.a = par2 ? C.set0[1] : C.set1[1]; nx.r = par2 ? C.set0[2] : C.set1[2];
@@ -1596,17 +1603,18 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   {
     int by3 = (int)blockIdx.y, bx3 = (int)blockIdx.x, nx3 = (int)gridDim.x;
     asm volatile("" : "+s"(by3), "+s"(bx3), "+s"(nx3));
-    const int wg3 = (((by3 & 15) >= 12) ? 4 * nx3 : 0) + bx3 * 4 + ((by3 - 8) & 3);
+    const int u3 = by3 / C.rows, y3 = by3 - u3 * C.rows;
+    const int wg3 = y3 < 16 ? ((y3 >= 12) ? 4 * nx3 : 0) + bx3 * 4 + ((y3 - 8) & 3) : 8 * nx3 + (y3 - 16) * nx3 + bx3;
     const int tile = wg3 < Dap->tile_end[kDwFusedItems - 1] ? wg3 : -1;
     if (tile >= 0) {
       __syncthreads();
-      wait_flags(A.w_flags, 4 * nx3, A.epoch + (unsigned)(by3 >> 4), A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
+      wait_flags(A.w_flags, 4 * nx3, A.epoch + (unsigned)u3, A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
       // (its own masters and moments: this tile's incarnation of the update before — implied by the seeds a workgroup
       // that was a critic tile has just consumed, said for the one that was not)
-      if ((by3 >> 4) > 0 && threadIdx.x == kThreads - 1) {
+      if (u3 > 0 && threadIdx.x == kThreads - 1) {
         bool ok = false;
         for (int sp = 0; sp < kTpSpin && !ok; ++sp) {
-          ok = (unsigned)(__hip_atomic_load(C.at_fin + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == A.epoch + (unsigned)(by3 >> 4) - 1u;
+          ok = (unsigned)(__hip_atomic_load(C.at_fin + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == A.epoch + (unsigned)u3 - 1u;
           if (!ok) __builtin_amdgcn_s_sleep(2);
         }
         if (!ok) report_expired(A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
@@ -1614,7 +1622,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
       __syncthreads();
       asm volatile("buffer_inv sc0" ::: "memory");
       DwX2Ovr ov;
-      ov.chain = &C; ov.u = by3 >> 4;
+      ov.chain = &C; ov.u = u3;
       dw_tile_x2<DwKArgs4>(*Dap, smem, tile, 2, ov);
     }
   }
@@ -1785,8 +1793,10 @@ hipError_t launch_ddpg_chain(const DdpgArgs& a, const DwKArgs4& dc, const DwKArg
   const int slices = (a.B + kR - 1) / kR;
   const int tc = dc.tile_end[kDwFusedItems - 1], ta = da.tile_end[kDwFusedItems - 1];
   if (tc + ta + 1 > kThreads) return hipErrorInvalidValue;       // (one poller per flag: chain_wait2)
-  if (tc > 8 * slices || ta > 8 * slices) return hipErrorInvalidValue;   // a tile of each kind per role-B / role-C workgroup
-  const dim3 grid(slices, 16 * c.n_upd);
+  const int mt = tc > ta ? tc : ta;
+  const int rows = 16 + (mt > 8 * slices ? (mt - 8 * slices + slices - 1) / slices : 0);    // A 8 | B 4 | C 4 | T
+  if (c.rows != rows) return hipErrorInvalidValue;
+  const dim3 grid(slices, rows * c.n_upd);
   hipLaunchKernelGGL((k_ddpg_chain<PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, dc, da, c);
   return hipGetLastError();
 }

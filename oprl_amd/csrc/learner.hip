@@ -1201,7 +1201,10 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
         compact(kd, &ka);
       }
       // (every tile must find a role-B / role-C workgroup to be the continuation of: 8 per slice)
-      const bool chain_fits = kc.tile_end[kDwFusedItems - 1] <= 8 * slices && ka.tile_end[kDwFusedItems - 1] <= 8 * slices;
+      const int max_tiles = kc.tile_end[kDwFusedItems - 1] > ka.tile_end[kDwFusedItems - 1] ? kc.tile_end[kDwFusedItems - 1] : ka.tile_end[kDwFusedItems - 1];
+      const int t_rows = max_tiles > 8 * slices ? (max_tiles - 8 * slices + slices - 1) / slices : 0;
+      // (one update's workgroups — 16 role rows per slice + the tile-only rows — wait for each other: all must fit the chip)
+      const bool chain_fits = (16 + t_rows) * slices <= h->n_cus;
       const int U = (h->no_chain || h->chain_flags == nullptr || !chain_fits) ? 1 : h->chain_u;
       if (!h->no_chain && h->chain_flags != nullptr && chain_fits) {
         // SEVERAL updates as one launch (k_ddpg_chain): the tables above are update 0's; what changes per update — Adam's
@@ -1212,6 +1215,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
         ca.first_gather = fa.src.gather;
         ca.pf_last = h->chain_pf_last ? 1 : 0;
         ca.trace_u = U - 1;
+        ca.rows = 16 + t_rows;
         ca.c_step[0] = kc.ad.step_size_host; ca.c_bc2[0] = kc.ad.bc2_sqrt_host;
         ca.a_step[0] = ka.ad.step_size_host; ca.a_bc2[0] = ka.ad.bc2_sqrt_host;
         for (int u = 1; u < U; ++u) {          // (dw_build advances the optimisers' step counts: once per update and net)
@@ -2446,9 +2450,10 @@ extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t
     int tiles64[2] = {0, 0};                 // 16 x 64 tiles of the critic / the actor (dw_tile_x2.h)
     for (size_t i = 0; i < h->items_host.size(); ++i)
       tiles64[(int)i < h->n_items_critic ? 0 : 1] += ((h->items_host[i].N + 15) / 16) * ((h->items_host[i].K + 63) / 64);
-    const int bc_wgs = 8 * ((B + kR - 1) / kR);
+    const int sl = (B + kR - 1) / kR, mt64 = tiles64[0] > tiles64[1] ? tiles64[0] : tiles64[1];
+    const int t_rows = mt64 > 8 * sl ? (mt64 - 8 * sl + sl - 1) / sl : 0;
     const bool chain = probe.whole && B <= 256 && !h->no_chain && h->chain_flags != nullptr && alt != nullptr &&
-                       tiles64[0] <= bc_wgs && tiles64[1] <= bc_wgs;
+                       (16 + t_rows) * sl <= h->n_cus;
     h->prefetch_p1 = !chain && alt != nullptr && (probe.merged & 2) != 0;
     int cur = 0;
     int rc = OPRL_OK;
