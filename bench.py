@@ -414,9 +414,30 @@ def dp_single_rank(dev, local_rank, replay, precision, steps):
         dt = time.perf_counter() - t0
         ok = dp.healthy()
         finite = bool(t.isfinite(algo.actor._oprl_arena).all() and t.isfinite(algo.critic._oprl_arena).all())
-        return dict(value=round(steps / dt, 1), unit="steps/s", us_per_step=round(dt / steps * 1e6, 2), steps=steps,
-                    dtype=precision, exchange="rccl", healthy=bool(ok), finite=finite,
-                    path="oprl_learner_dp_step_n at world size 1 (the --gpus N path per rank, RCCL all-reduce of one rank)")
+        out = dict(value=round(steps / dt, 1), unit="steps/s", us_per_step=round(dt / steps * 1e6, 2), steps=steps,
+                   dtype=precision, exchange="rccl", healthy=bool(ok), finite=finite,
+                   path="oprl_learner_dp_step_n at world size 1 (the --gpus N path per rank, RCCL all-reduce of one rank)")
+        # ... and the same loop with the exchange INSIDE the dW tiles (peer windows, `--p2p` at N > 1): for a PrecX2
+        # learner the data-parallel update is then the single-GPU launch itself (k_ddpg_chain; dw_tile_x2.h), for the
+        # others the dW launches exchange their own tiles (k_dw_adam<true>).  One rank: no peer, the structure's fixed price.
+        try:
+            if dp.init_p2p(2):
+                dp.step_n(replay.handle, 300, B, seed=0)
+                t.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                dp.step_n(replay.handle, steps, B, seed=0)
+                t.cuda.synchronize(dev)
+                dt2 = time.perf_counter() - t0
+                fin2 = bool(t.isfinite(algo.actor._oprl_arena).all() and t.isfinite(algo.critic._oprl_arena).all())
+                out["inline"] = dict(value=round(steps / dt2, 1), unit="steps/s", us_per_step=round(dt2 / steps * 1e6, 2),
+                                     exchange="p2p-inline", healthy=bool(dp.healthy()), finite=fin2,
+                                     path="the same loop, the gradient exchange inside the dW tiles of the update's own "
+                                          "launch(es) over peer windows (one rank: no peer)")
+            else:
+                out["inline"] = dict(value=None, error=dp.p2p_error[:200])
+        except Exception as exc:  # noqa: BLE001
+            out["inline"] = dict(value=None, error=f"{type(exc).__name__}: {exc}"[:300])
+        return out
     finally:
         dist.destroy_process_group()
 

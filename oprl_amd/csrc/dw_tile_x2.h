@@ -405,6 +405,72 @@ struct DwX2Tile {
   float gsum = 0.f;
 #pragma unroll
   for (int q = 0; q < 8; ++q) gsum += part[((size_t)q * 16 + nl) * LDT + kl];
+  // ---- data parallel over peer windows (csrc/p2p.hip; dw_body.h's XCHG for this tile): the tile's 1024 gradient
+  // elements (+ the 16 bias sums of a k-block-0 tile) are all-reduced with the same tile of the other ranks BEFORE Adam —
+  // 8-byte {sequence, value} granules written at system scope into the tile's slot of the OWNER's window (tile % world),
+  // who sums the partial tiles in rank order and sends the sum back: every replica applies the very same bits, and a
+  // data-parallel update is the single-GPU launch + these two hops per tile, no all-reduce or apply launches.
+  float gb_x = 0.f;
+  bool xchg_on = false;
+  if (A.xchg.world > 1) {
+    const DwXchg& X = A.xchg;
+    xchg_on = true;
+    float gbw = 0.f;
+    if (b_own) {
+#pragma unroll
+      for (int q = 0; q < 32; ++q) gbw += bpart[q * 16 + tid];
+    }
+    const unsigned long long seq = X.seq + (chained ? 2ull * (unsigned long long)ov.u : 0ull) + (unsigned long long)(gate == 2 ? 1 : 0);
+    const unsigned tag = (unsigned)seq;
+    const int parity = (int)(seq & 1ull);
+    const int owner = (int)((unsigned)bx_ % (unsigned)X.world);
+    auto slot = [&](char* base, int src_slot) {
+      return reinterpret_cast<unsigned long long*>(base) +
+             (((size_t)parity * (X.world + 1) + src_slot) * X.max_tiles + bx_) * kDwXchgTile;
+    };
+    auto put = [&](unsigned long long* dst, float v, float vb) {
+      __hip_atomic_store(dst + tid, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (tid < kDwTileN)
+        __hip_atomic_store(dst + 1024 + tid, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(vb),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    auto get = [&](const unsigned long long* src, float* v, float* vb) {
+      unsigned long long x = 0, xb = 0;
+      bool ok = false;
+      for (int spin = 0; spin < (1 << 20) && !ok; ++spin) {
+        x = __hip_atomic_load(src + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        xb = tid < kDwTileN ? __hip_atomic_load(src + 1024 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : x;
+        ok = (unsigned)(x >> 32) == tag && (unsigned)(xb >> 32) == tag;
+        if (!ok) __builtin_amdgcn_s_sleep(2);
+      }
+      *v = __uint_as_float((unsigned)x);
+      *vb = __uint_as_float((unsigned)xb);
+      return ok;
+    };
+    float gs = 0.f, gbs = 0.f;
+    bool all_ok = true;
+    if (X.rank == owner) {
+      for (int r = 0; r < X.world; ++r) {    // rank order
+        float v = gsum, vb = gbw;
+        if (r != X.rank) all_ok = get(slot(X.window, r), &v, &vb) && all_ok;
+        gs += v;
+        gbs += vb;
+      }
+      if (!all_ok) { gs = __builtin_nanf(""); gbs = gs; }   // (the poison travels to every replica)
+      for (int p = 0; p < X.world; ++p)
+        if (p != X.rank) put(slot(X.peer[p], X.world), gs, gbs);
+    } else {
+      put(slot(X.peer[owner], X.rank), gsum, gbw);
+      all_ok = get(slot(X.window, X.world), &gs, &gbs);
+    }
+    if (!all_ok) {   // bounded wait: a lost rank is reported and poisons the tile instead of hanging
+      report_expired(X.err, (KERN_DW_XCHG << 8) | SITE_DW_TILE);
+      gs = __builtin_nanf(""); gbs = gs;
+    }
+    gsum = gs;
+    gb_x = gbs;
+  }
   gsum *= ad.grad_scale;
   if (!ad.do_adam) {
     // a gradient-exporting (data-parallel) learner: the tile leaves dW / db in the gradient arena for the all-reduce;
@@ -443,6 +509,7 @@ struct DwX2Tile {
     float gb = 0.f;
 #pragma unroll
     for (int q = 0; q < 32; ++q) gb += bpart[q * 16 + tid];
+    if (xchg_on) gb = gb_x;          // (the all-reduced bias sums)
     gb *= ad.grad_scale;
     float mm = q_m, vv = q_v, th = q_th;
     mm = mm + (gb - mm) * ad.omb1;

@@ -166,7 +166,7 @@ __device__ __forceinline__ int adam_polyak_elem(float g, float* th, float* m, fl
 // separate all-reduce and apply launches of the RCCL path disappear.  Tile region of a window:
 // [parity][source rank, or `world` = the owner's summed tile][tile][kDwXchgTile] 8-byte {sequence, value}
 // granules.
-constexpr int kDwXchgTile = 512 + 16;
+constexpr int kDwXchgTile = 1024 + 16;   // one 16 x 64 tile of dw_tile_x2.h + 16 bias sums (the 16 x 32 tiles of dw_body.h use the first 512 + their 16 at 512)
 constexpr int kDwXchgMaxWorld = 8;
 struct DwXchg {
   char* peer[kDwXchgMaxWorld];         // every rank's tile region as mapped here
@@ -296,6 +296,7 @@ struct DwKArgs4 {
   AdamScalars ad;
   long long* trace;
   DwGate gate;
+  DwXchg xchg;                         // world > 1: the tile all-reduces its gradient with the other ranks' before Adam (dw_tile_x2.h)
 };
 
 struct BatchSrc {

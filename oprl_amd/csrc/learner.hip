@@ -1009,7 +1009,10 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   // (a gradient-exporting learner — data parallel over RCCL — merges only with the PrecX2 tiles, which know how to leave
   // dW in the gradient arena instead of running Adam: four launches per data-parallel update instead of six)
   const bool xport_ok = !h->cfg.export_grads || (a.x2 && fused_x2_tiles());
-  if (!h->no_merge && !h->shared_chip && h->nc == 1 && !a.sac && B <= 256 && xport_ok && !h->dp_inline && fused_ddpg_is_lean(a)) {
+  // (dp_inline: the gradient exchange inside the dW tiles — the 16 x 32 tiles of k_dw_adam<true> as launches of their own,
+  // or, PrecX2 learners, the 16 x 64 tiles of the merged / whole-update launches themselves: dw_tile_x2.h)
+  const bool inline_x2 = h->dp_inline && a.x2 && fused_x2_tiles() && h->nc == 1;
+  if (!h->no_merge && !h->shared_chip && h->nc == 1 && !a.sac && B <= 256 && xport_ok && (!h->dp_inline || inline_x2) && fused_ddpg_is_lean(a)) {
     a.merged |= 1;
     if (!(a.x2 && fused_x2_tiles())) a.wide &= ~1;     // (the 84 16 x 64 tiles of a PrecX2 learner get along with role A on eight)
   }
@@ -1017,7 +1020,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   // du, the first layer's comes from one more backward step of the critic pass's members (csrc/fused_ddpg.hip).
   // PrecX2 learners only, the pass on clusters of eight: with the exact-fp32 tiles the merged form measured no faster
   // than the two launches (34.9 vs 34.7 us)
-  if (!h->no_merge2 && !h->shared_chip && a.x2 && fused_x2_tiles() && h->du_granules != nullptr && !a.sac && B <= 256 && !h->dp_inline &&
+  if (!h->no_merge2 && !h->shared_chip && a.x2 && fused_x2_tiles() && h->du_granules != nullptr && !a.sac && B <= 256 && (!h->dp_inline || inline_x2) &&
       fused_ddpg_is_lean(a) && c.actor.theta_target != nullptr && (a.wide & 2) != 0) {
     a.merged |= 2;
     a.du_granules = h->du_granules;
@@ -1026,7 +1029,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   }
   // the whole update as ONE launch (k_ddpg_update): both merged forms, role A and the critic pass on eight, the 16 x 64
   // tiles, and everything the roles hand to each other in uncached memory
-  if (!h->no_whole && !h->cfg.export_grads && a.x2 && fused_x2_tiles() && h->nc == 1 && (a.merged & 3) == 3 && (a.wide & 3) == 3 && h->uc_pool &&
+  if (!h->no_whole && (!h->cfg.export_grads || inline_x2) && a.x2 && fused_x2_tiles() && h->nc == 1 && (a.merged & 3) == 3 && (a.wide & 3) == 3 && h->uc_pool &&
       h->uc_base != nullptr && h->w_flags != nullptr) {
     a.whole = 1;
     a.w_flags = h->w_flags;
@@ -1173,6 +1176,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
         for (int j = 0; j < kDwFusedItems; ++j) { o->tile_end[j] = k.tile_end[j]; o->items[j] = k.items[j]; }
         o->n_items = k.n_items; o->B = k.B; o->n_part = k.n_part; o->dy_tiled = k.dy_tiled; o->ad = k.ad; o->trace = k.trace;
         o->gate = k.gate;
+        memset((void*)&o->xchg, 0, sizeof o->xchg);
       };
       {
         DwArgs dw = dw_build(h, true, B, true, false);
@@ -1206,6 +1210,26 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
       // (one update's workgroups — 16 role rows per slice + the tile-only rows — wait for each other: all must fit the chip)
       const bool chain_fits = (16 + t_rows) * slices <= h->n_cus;
       const int U = (h->no_chain || h->chain_flags == nullptr || !chain_fits) ? 1 : h->chain_u;
+      memset((void*)&kc.xchg, 0, sizeof kc.xchg);
+      memset((void*)&ka.xchg, 0, sizeof ka.xchg);
+      if (h->dp_inline) {
+        // data parallel on peer windows: the tiles of this launch all-reduce their gradients themselves and run Adam on
+        // the mean (dw_tile_x2.h): exchange sequence numbers seq0 + 2 u (critic) / + 1 (actor) for update u of the launch
+        P2pState& P = h->p2p;
+        if (max_tiles > h->p2p_max_tiles) { set_err("data-parallel whole update: the windows hold %d tiles, the launch has %d", h->p2p_max_tiles, max_tiles); return OPRL_ERR_STATE; }
+        DwXchg X;
+        memset((void*)&X, 0, sizeof X);
+        for (int r = 0; r < kDwXchgMaxWorld; ++r) X.peer[r] = r < P.world ? P.peer[r] + P.tile_off : nullptr;
+        X.window = P.window + P.tile_off;
+        X.world = P.world; X.rank = P.rank; X.max_tiles = h->p2p_max_tiles;
+        X.seq = P.tile_seq + 1; X.parity = 0;        // (parity = the exchange's sequence number & 1, formed in the tile)
+        X.err = h->err_dev;
+        P.tile_seq += 2ull * (unsigned long long)U;
+        kc.xchg = X; ka.xchg = X;
+        kc.ad.do_adam = 1; ka.ad.do_adam = 1;
+        kc.ad.grad_scale = 1.0f / (float)P.world; ka.ad.grad_scale = 1.0f / (float)P.world;
+        h->stale32[0] = true; h->stale32[1] = true;  // (the tiles write the fp16 packs only)
+      }
       if (!h->no_chain && h->chain_flags != nullptr && chain_fits) {
         // SEVERAL updates as one launch (k_ddpg_chain): the tables above are update 0's; what changes per update — Adam's
         // bias-correction terms, epochs, exchange tags, the staging set — is in ChainArgs
@@ -1884,6 +1908,11 @@ int dp_all_reduce(oprl_learner* h, void* buf, size_t n, bool as_double, hipStrea
 }
 }  // namespace
 
+namespace {
+int chain_loop(oprl_learner* h, int K, int B, float* (*set)[5], void* stream);
+bool chain_ok(oprl_learner* h, int B);
+}  // namespace
+
 extern "C" int oprl_learner_dp_update(oprl_learner* h, const float* s, const float* a, const float* r,
                                       const float* d, const float* s2, int32_t B, const float* noise0,
                                       const float* noise1, void* stream) {
@@ -1940,6 +1969,22 @@ extern "C" int oprl_learner_dp_step_n(oprl_learner* h, oprl_replay* replay, int3
     sc.gather = 1;
     // as in oprl_learner_step_n: phase 2 of every update gathers the next update's rows
     h->next_src = sc;
+    // The gradient exchange inside the tiles of the whole-update launch (peer windows, PrecX2 learners): the data-parallel
+    // K-loop IS the single-GPU one — k_ddpg_chain, up to chain_max updates per launch, every tile all-reducing its
+    // gradient with the other ranks' before Adam.  No all-reduce launches, no apply launches.
+    if (h->p2p_ok && h->p2p_inline && !h->no_dp_inline && h->p2p.tile_bytes > 0) {
+      h->dp_inline = true;
+      if (chain_ok(h, B)) {
+        const size_t Bm = (size_t)h->Bmax;
+        float* alt = h->batch_alt;
+        float* set[2][5] = {{h->bs, h->ba, h->br, h->bd, h->bs2},
+                            {alt, alt + Bm * h->S, alt + Bm * (h->S + h->A), alt + Bm * (h->S + h->A + 1), alt + Bm * (h->S + h->A + 2)}};
+        const int rc_chain = chain_loop(h, K, B, set, stream);
+        h->dp_inline = false;
+        return rc_chain;
+      }
+      h->dp_inline = false;
+    }
     h->next_src.s = h->bs; h->next_src.a = h->ba; h->next_src.r = h->br; h->next_src.d = h->bd;
     h->next_src.s2 = h->bs2;
     int rc = OPRL_OK;
@@ -2418,6 +2463,54 @@ extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, double grad_sc
   return OPRL_ERR_INVALID;
 }
 
+namespace {
+// step_n's K-loop as launches of up to chain_max updates each (k_ddpg_chain); h->src: the replay's view, seed set.
+// set[2][5]: the two staging sets.  Also the data-parallel loop when the gradient exchange is inside the tiles.
+int chain_loop(oprl_learner* h, int K, int B, float* (*set)[5], void* stream) {
+  BatchSrc& sc = h->src;
+  int cur = 0;
+  int rc = OPRL_OK;
+  h->staged_ready = false;
+  for (int k = 0; k < K && rc == OPRL_OK;) {
+    const int U = K - k < h->chain_max ? K - k : h->chain_max;
+    float** b = set[cur];
+    float** nb = set[cur ^ 1];
+    for (int i = 0; i < 5; ++i) h->chain_set1[i] = nb[i];
+    sc.counter = (unsigned long long)h->update_count;
+    h->next_src.counter = sc.counter + 1;
+    h->next_src.s = nb[0]; h->next_src.a = nb[1]; h->next_src.r = nb[2]; h->next_src.d = nb[3]; h->next_src.s2 = nb[4];
+    h->prefetch_next = 0;
+    sc.gather = h->staged_ready ? 0 : 1;
+    sc.s = b[0]; sc.a = b[1]; sc.r = b[2]; sc.d = b[3]; sc.s2 = b[4];      // (set 0 of the launch, gathered or staged)
+    h->chain_u = U;
+    h->chain_pf_last = k + U < K;
+    rc = oprl_learner_update(h, b[0], b[1], b[2], b[3], b[4], B, nullptr, nullptr, stream);
+    h->chain_u = 1;
+    if (rc == OPRL_OK) h->update_count += U - 1;        // (update() counted one)
+    h->staged_ready = h->chain_pf_last;                 // the launch's last update staged the next rows: set (cur + U) & 1
+    h->chain_pf_last = false;
+    for (int i = 0; i < 5; ++i) h->chain_set1[i] = nullptr;
+    cur = (cur + U) & 1;
+    k += U;
+  }
+  sc.gather = 0;
+  h->prefetch_next = 0;
+  h->staged_ready = false;
+  return rc;
+}
+
+// does step_n at this batch run as chain launches?
+bool chain_ok(oprl_learner* h, int B) {
+  const DdpgArgs probe = ddpg_args(h, B);
+  int tiles64[2] = {0, 0};                 // 16 x 64 tiles of the critic / the actor (dw_tile_x2.h)
+  for (size_t i = 0; i < h->items_host.size(); ++i)
+    tiles64[(int)i < h->n_items_critic ? 0 : 1] += ((h->items_host[i].N + 15) / 16) * ((h->items_host[i].K + 63) / 64);
+  const int sl = (B + kR - 1) / kR, mt64 = tiles64[0] > tiles64[1] ? tiles64[0] : tiles64[1];
+  const int t_rows = mt64 > 8 * sl ? (mt64 - 8 * sl + sl - 1) / sl : 0;
+  return probe.whole && B <= 256 && !h->no_chain && h->chain_flags != nullptr && h->batch_alt != nullptr && (16 + t_rows) * sl <= h->n_cus;
+}
+}  // namespace
+
 extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t K, int32_t B,
                                    uint64_t seed, void* stream) {
   if (!h || !replay) { set_err("oprl_learner_step_n: null handle"); return OPRL_ERR_INVALID; }
@@ -2445,47 +2538,14 @@ extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t
     float* alt = h->batch_alt;
     float* set[2][5] = {{h->bs, h->ba, h->br, h->bd, h->bs2},
                         {alt, alt + Bm * h->S, alt + Bm * (h->S + h->A), alt + Bm * (h->S + h->A + 1), alt + Bm * (h->S + h->A + 2)}};
-    const DdpgArgs probe = ddpg_args(h, B);
     // k_ddpg_chain: up to chain_max updates per launch, the rows of update u + 1 staged by update u inside the launch
-    int tiles64[2] = {0, 0};                 // 16 x 64 tiles of the critic / the actor (dw_tile_x2.h)
-    for (size_t i = 0; i < h->items_host.size(); ++i)
-      tiles64[(int)i < h->n_items_critic ? 0 : 1] += ((h->items_host[i].N + 15) / 16) * ((h->items_host[i].K + 63) / 64);
-    const int sl = (B + kR - 1) / kR, mt64 = tiles64[0] > tiles64[1] ? tiles64[0] : tiles64[1];
-    const int t_rows = mt64 > 8 * sl ? (mt64 - 8 * sl + sl - 1) / sl : 0;
-    const bool chain = probe.whole && B <= 256 && !h->no_chain && h->chain_flags != nullptr && alt != nullptr &&
-                       (16 + t_rows) * sl <= h->n_cus;
+    const bool chain = chain_ok(h, B);
+    const DdpgArgs probe = ddpg_args(h, B);
     h->prefetch_p1 = !chain && alt != nullptr && (probe.merged & 2) != 0;
     int cur = 0;
     int rc = OPRL_OK;
     h->staged_ready = false;
-    if (chain) {
-      for (int k = 0; k < K && rc == OPRL_OK;) {
-        const int U = K - k < h->chain_max ? K - k : h->chain_max;
-        float** b = set[cur];
-        float** nb = set[cur ^ 1];
-        for (int i = 0; i < 5; ++i) h->chain_set1[i] = nb[i];
-        sc.counter = (unsigned long long)h->update_count;
-        h->next_src.counter = sc.counter + 1;
-        h->next_src.s = nb[0]; h->next_src.a = nb[1]; h->next_src.r = nb[2]; h->next_src.d = nb[3]; h->next_src.s2 = nb[4];
-        h->prefetch_next = 0;
-        sc.gather = h->staged_ready ? 0 : 1;
-        sc.s = b[0]; sc.a = b[1]; sc.r = b[2]; sc.d = b[3]; sc.s2 = b[4];      // (set 0 of the launch, gathered or staged)
-        h->chain_u = U;
-        h->chain_pf_last = k + U < K;
-        rc = oprl_learner_update(h, b[0], b[1], b[2], b[3], b[4], B, nullptr, nullptr, stream);
-        h->chain_u = 1;
-        if (rc == OPRL_OK) h->update_count += U - 1;        // (update() counted one)
-        h->staged_ready = h->chain_pf_last;                 // the launch's last update staged the next rows: set (cur + U) & 1
-        h->chain_pf_last = false;
-        for (int i = 0; i < 5; ++i) h->chain_set1[i] = nullptr;
-        cur = (cur + U) & 1;
-        k += U;
-      }
-      sc.gather = 0;
-      h->prefetch_next = 0;
-      h->staged_ready = false;
-      return rc;
-    }
+    if (chain) return chain_loop(h, K, B, set, stream);
     // OPRL_AMD_GRAPH_PROBE=1 (measurement only, profiles/r03_experiments.txt): the K updates' launches are captured into a
     // hipGraph — every node with its own argument block: epoch, counters and staging set are baked in at capture — and
     // replayed once; the call returns when the graph has run.  Does the boundary between two launches move?

@@ -14,11 +14,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main() -> None:
     rank, world, rdv, out, algo_name, K, B, level = (int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4],
                                                       sys.argv[5], int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8]))
+    prec = sys.argv[9] if len(sys.argv) > 9 else "f32"
+    if prec == "x2":
+        # two ranks share this GPU: one update per launch (k_ddpg_chain with several would queue the NEXT update's
+        # workgroups of the rank that launched first into every free compute unit, and they wait — through its tiles'
+        # exchange — for the other rank's workgroups, which then find none: ranks of a real job own their GPU)
+        os.environ["OPRL_AMD_CHAIN"] = "1"
     dist.init_process_group("gloo", init_method=f"file://{rdv}", rank=rank, world_size=world)
     from oprl_amd.logging import NullLogger
     from oprl_amd.parallel import DataParallelLearner
     from tests.test_gpu_p2p import make_algo, make_shard
-    algo = make_algo(algo_name, B, export_grads=True)
+    algo = make_algo(algo_name, B, export_grads=True, precision=prec)
     buf = make_shard(rank)
     dp = DataParallelLearner(algo, dist.group.WORLD)
     ok = dp.init_p2p(level)

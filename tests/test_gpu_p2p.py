@@ -44,15 +44,19 @@ def make_shard(rank):
 # share this GPU, so a rank's waiting dW workgroups (level 2) and the other rank's one-workgroup-per-CU
 # phase kernels compete for the same CUs: DDPG at a small batch leaves room for both, SAC's twice as many
 # dW tiles do not — SAC is exercised at level 1 (which also covers the 64-bit temperature exchange).
-@pytest.mark.parametrize("algo_name,level", [("ddpg", 2), ("ddpg", 1), ("sac", 1), ("td3", 1)])
-def test_two_process_p2p_data_parallel_step(algo_name, level):
+# ("ddpg", 2, "x2"): the split-fp16 learner's data-parallel update is its SINGLE-GPU launch — k_ddpg_chain, the whole
+# update — whose 16 x 64 dW tiles all-reduce their gradients with the other rank's before Adam (dw_tile_x2.h): no
+# all-reduce launches, no apply launches.
+@pytest.mark.parametrize("algo_name,level,prec", [("ddpg", 2, "f32"), ("ddpg", 1, "f32"), ("sac", 1, "f32"), ("td3", 1, "f32"),
+                                                  ("ddpg", 2, "x2")])
+def test_two_process_p2p_data_parallel_step(algo_name, level, prec):
     K, B, world = 6, 32, 2
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as td:
         rdv, out = os.path.join(td, "rdv"), os.path.join(td, "out")
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "p2p_worker.py"), str(r), str(world),
-                                   rdv, out, algo_name, str(K), str(B), str(level)], env=env, cwd=root)
+                                   rdv, out, algo_name, str(K), str(B), str(level), prec], env=env, cwd=root)
                  for r in range(world)]
         for p in procs:
             assert p.wait(timeout=300) == 0
@@ -63,7 +67,7 @@ def test_two_process_p2p_data_parallel_step(algo_name, level):
         assert t.equal(res[0]["arenas"][m], res[1]["arenas"][m]), f"replicas diverged: {m} (max |d| = {d:.3e})"
         assert t.isfinite(res[0]["arenas"][m]).all()
     # single-process emulation: two export_grads learners, gradients summed in rank order
-    L = [make_algo(algo_name, B, export_grads=True) for _ in range(world)]
+    L = [make_algo(algo_name, B, export_grads=True, precision=prec) for _ in range(world)]
     for r in range(world):
         L[r].learner.set_seed(0, r)      # as the ranks of the job: every rank draws its own noise
     shards = [make_shard(r) for r in range(world)]
@@ -91,6 +95,12 @@ def test_two_process_p2p_data_parallel_step(algo_name, level):
         d = (getattr(L[0], m)._oprl_arena.cpu() - res[0]["arenas"][m]).abs().max().item()
         if level == 1:     # same kernels as the emulation: bit for bit
             assert t.equal(getattr(L[0], m)._oprl_arena.cpu(), res[0]["arenas"][m]), f"{m}: max |d| vs emulation = {d:.3e}"
+        elif prec == "x2":
+            # the emulation's phases leave dW from the 16 x 32 exact-fp32 tiles (k_dw_adam), the ranks' launches from the
+            # 16 x 64 split-fp16 tiles: two parity arithmetics (tests/test_gpu_x2.py::test_x2_launch_forms_agree: 2e-6)
+            scale = getattr(L[0], m)._oprl_arena.abs().max().item()
+            print(f"x2 inline exchange, {m}: max |d| vs emulation = {d:.3e} (max |theta| = {scale:.3e})")
+            assert d <= 2e-6 * max(scale, 1.0), f"{m}: max |d| vs emulation = {d:.3e}"
         else:              # k_dw_adam<true> is another instance of the kernel (its own FMA contraction): 1-ulp level
             assert d <= 1e-6, f"{m}: max |d| vs emulation = {d:.3e}"
 
