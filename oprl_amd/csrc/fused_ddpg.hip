@@ -266,7 +266,7 @@ __device__ __forceinline__ int dw_total(const DwKArgs& d) { return d.tile_end[kD
 __device__ __forceinline__ int dw_total(const DwKArgs4& d) { return d.tile_end[kDwFusedItems - 1]; }
 
 // (`by`: this workgroup's row of the roles' / tiles' block — blockIdx.y unless the caller runs the body inside a larger
-// grid: k_ddpg_update)
+// grid)
 // Returns the critic tile this workgroup goes on with (merged launches; -1: none): the caller runs it — ONE inlined copy
 // of the tile code per kernel instead of one per place a workgroup may turn into a tile (instruction cache, r03-14 / -25).
 // MERGED kernels are single-critic, non-SAC by their launchers' rules: the twin paths are compiled out of them.
@@ -282,8 +282,7 @@ __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D =
   if constexpr (MERGED) {
     const int rows = (2 + A.n_critics) * A.nc + ((LEAN && WIDE) ? 4 : 0);
     if (by >= rows && !pf_row) {
-      // (whole-update launch: roles B and C go on as the first 8 x slices tiles themselves, below)
-      const int tile = (A.whole ? 8 * (int)gridDim.x : 0) + (by - rows) * (int)gridDim.x + (int)blockIdx.x;
+      const int tile = (by - rows) * (int)gridDim.x + (int)blockIdx.x;
       return tile < dw_total(*D) ? tile : -1;
     }
   }
@@ -399,24 +398,6 @@ __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D =
             *reinterpret_cast<f32x4*>(A.w3_snap + idx) = ld4(A.w3_src + idx);
       }
       stamp();
-      if (A.whole) {
-        // role U and the critic pass of this very launch read what this member has stored (uncached memory): the flag
-        // follows the acknowledgement of every wave's stores
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0)
-          __hip_atomic_store(A.w_flags + slice * 4 + tp.c, (unsigned long long)A.epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    if constexpr (MERGED && P::kX2 && kDwTileX2) {
-      if (A.whole) {
-        // ... and goes on as one of the critic's tile workgroups (k_ddpg_update): no compute unit has to come free
-        // for those, so the critic pass — dispatched behind them — is resident, all eight members per slice, when role
-        // A retires, long before the tiles' flags
-        __syncthreads();
-        const int tile = 4 * (int)gridDim.x + slice * 4 + tp.c;
-        return tile < dw_total(*D) ? tile : -1;
-      }
     }
     if (!TWIN || !A.twin_split) return -1;
     // ---- ... then target critic 2 on (s', a') with role A's a'
@@ -545,13 +526,6 @@ __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D =
   if constexpr (TWIN)
     if (role == 2) { role_b<WIDTH, LEAN, P>(A, A.critic2, A.c2X, A.c2dY, A.partials_c + (size_t)gridDim.x * 4, false, 1, smem, tp, stamp, slice); return -1; }
   role_b<WIDTH, LEAN, P>(A, A.critic, A.cX, A.cdY, A.partials_c, true, 0, smem, tp, stamp, slice);
-  if constexpr (MERGED && P::kX2 && kDwTileX2) {
-    if (A.whole) {       // (as role C above: this workgroup goes on as critic tile (slice, member))
-      __syncthreads();
-      const int tile = slice * 4 + tp.c;
-      return tile < dw_total(*D) ? tile : -1;
-    }
-  }
   return -1;
 }
 
@@ -968,7 +942,7 @@ __device__ __forceinline__ void wait_flags(const unsigned long long* flags, int 
 }
 
 // (returns the actor tile this workgroup is, -1 for the pass's and the prefetch row's workgroups: ddpg_tile runs it)
-// PF: the launch may carry the prefetch row (the two-launch form; k_ddpg_update's rides on phase 1's rows)
+// PF: the launch may carry the prefetch row (the two-launch form; k_ddpg_chain gathers the next rows itself)
 // (what changes from update to update inside k_ddpg_chain; the one-update launches pass their argument block's values)
 struct PassCtx {
   unsigned epoch;               // tag of this update's flags and granules
@@ -995,7 +969,7 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   if (y >= yT) {   // a tile workgroup: all 16 waves (16 minibatch rows each)
     const int tile = (y - yT) * (int)gridDim.x + slice;
     if (tile >= dw_total(*D)) return -1;
-    if (A.whole) {      // (k_ddpg_update: the rows this tile reads are role C's of this very launch)
+    if (A.whole) {      // (never taken: k_ddpg_chain runs its tiles as continuations of the roles, not through here)
       wait_flags(A.w_flags, 4 * (int)gridDim.x, cx.epoch, A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
       __syncthreads();
       asm volatile("buffer_inv sc0" ::: "memory");
@@ -1056,7 +1030,7 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
   BiasOv cbo;
   if (A.whole) {
-    // (k_ddpg_update) role C of this launch wrote s, pi and the actor's activations — uncached memory: its members'
+    // (k_ddpg_chain) role C of this launch wrote s, pi and the actor's activations — uncached memory: its members'
     // flags, then an invalidate of this CU's L1; the critic's packs and biases follow below, behind the rows
     wait_flags(A.w_flags, 4 * (int)gridDim.x, cx.epoch, A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
     __syncthreads();
@@ -1267,42 +1241,12 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2_dw(const DdpgArgs A, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The WHOLE update as one launch (PrecX2 learners, DDPG, B <= 256): the rows of the merged phase 1 — roles B | A (on
-// eight) | C; roles B and C go on as the critic's tile workgroups — followed by the rows of the merged phase 2 — the
-// critic pass, the actor's tiles — and the prefetch row.  Workgroups are dispatched in this order and only ever wait
-// for workgroups dispatched before them: the critic pass for role C and the critic's tiles, every tile for its seeds.
-// Compute units: the roles fill the chip; role C's workgroups without a tile retire first (44 at B = 256) and role A's
-// 128 next — the critic pass's 128 workgroups are all resident when the critic's tiles raise their flags (a member that
-// starts late is what the other seven wait for in every all-reduce), the actor's tiles take what is left and what the
-// critic's tiles free, with their rows in long before du.  What used to cross the kernel boundary between the two
-// launches — the critic's new packs and biases, pi, the actor's activations — lives in uncached memory and travels
-// behind flags (DdpgArgs::whole).  One launch gap (~3 us of an update) less.
+// The WHOLE update as one launch: k_ddpg_chain below (round 3's k_ddpg_update — one update per launch, tile workgroups as
+// extra grid rows — was its first form and is gone: the chain launch with one update is the same thing with the tiles
+// as continuations of the roles).  Offsets of the argument blocks inside the kernel-argument segment:
 // ---------------------------------------------------------------------------------------------------------------
 constexpr size_t kWholeDcOffset = (sizeof(DdpgArgs) + alignof(DwKArgs4) - 1) / alignof(DwKArgs4) * alignof(DwKArgs4);
 constexpr size_t kWholeDaOffset = (kWholeDcOffset + sizeof(DwKArgs4) + alignof(DwKArgs4) - 1) / alignof(DwKArgs4) * alignof(DwKArgs4);
-template <class P>
-__global__ __launch_bounds__(kThreads) void k_ddpg_update(const DdpgArgs A, const DwKArgs4 Dc, const DwKArgs4 Da) {
-  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
-  const DwKArgs4* Dcp = (const DwKArgs4*)(ka + kWholeDcOffset);
-  const DwKArgs4* Dap = (const DwKArgs4*)(ka + kWholeDaOffset);
-  const int slices = (int)gridDim.x;
-  // roles (B 4 | A 8 | C 4) + those of the critic's tiles that roles B and C do not go on with themselves
-  const int tc = Dcp->tile_end[kDwFusedItems - 1];
-  const int rows1 = 3 * 4 + 4 + ((tc > 8 * slices ? tc - 8 * slices : 0) + slices - 1) / slices;
-  const int y = (int)blockIdx.y;
-  // (whatever a workgroup was — a role, the pass, a row of tiles — the tile it ends up with runs in ONE place)
-  int tile, gate;
-  if (y < rows1 || (A.prefetch_p1 && y == (int)gridDim.y - 1)) {
-    tile = ddpg_phase1_body<256, true, false, P, true, true, DwKArgs4>(A, Dcp, y);
-    gate = 1;
-  } else {
-    const PassCtx cx{A.epoch, A.cluster_tag2, A.w3_snap, {A.critic_b16[0], A.critic_b16[1], A.critic_b16[2]}, A.trace2};
-    tile = ddpg_phase2m_body<P, DwKArgs4, false>(A, Dap, y - rows1, cx);
-    gate = 2;
-  }
-  ddpg_tile<P, DwKArgs4>(gate == 1 ? Dcp : Dap, tile, gate);
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // SEVERAL updates as one launch (k_ddpg_chain; PrecX2 learners, DDPG, B <= 256, a chip that holds one update's
@@ -1386,7 +1330,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   const int member = yy < 8 ? yy : (yy < 16 ? (yy - 8) & 3 : 1);
   const bool lead = member == 0;
   const int spin = A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin;
-  // in-kernel stage stamps (liboprl_amd_trace.so): update C.trace_u of the launch, the slots of k_ddpg_update
+  // in-kernel stage stamps (liboprl_amd_trace.so): update C.trace_u of the launch, the slots of round 3's k_ddpg_update
   const bool traced = kTraceOn && A.trace != nullptr && u == C.trace_u;
   int n_stamp = 0;
   auto stamp = [&]() {
@@ -1675,7 +1619,6 @@ hipError_t init_fused_attrs() {
                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecX2>),
                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecX2, true>),
                       reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecX2>),
-                      reinterpret_cast<const void*>(&k_ddpg_update<PrecX2>),
                       reinterpret_cast<const void*>(&k_ddpg_chain<PrecX2>)};
   for (const void* k : ks) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1771,20 +1714,7 @@ hipError_t launch_ddpg_phase2_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_
   return hipGetLastError();
 }
 
-// the whole update as one launch (DdpgArgs::whole; `dc` / `da`: the critic's and the actor's tile tables with their gates)
-hipError_t launch_ddpg_update(const DdpgArgs& a, const DwKArgs4& dc, const DwKArgs4& da, hipStream_t st) {
-  if (!lean_ok(a) || a.sac || !a.x2 || !kDwTileX2 || a.n_critics != 1 || !a.whole || (a.merged & 3) != 3 || (a.wide & 3) != 3 ||
-      a.xnc < 8 || a.A > kDuLd || a.B > 256 || a.prefetch_next)
-    return hipErrorInvalidValue;
-  const int slices = (a.B + kR - 1) / kR;
-  const int tc = dc.tile_end[kDwFusedItems - 1], ta = da.tile_end[kDwFusedItems - 1];
-  const int ownc = tc > 8 * slices ? tc - 8 * slices : 0;
-  const dim3 grid(slices, 16 + (ownc + slices - 1) / slices + 8 + (ta + slices - 1) / slices + (a.prefetch_p1 ? 1 : 0));
-  hipLaunchKernelGGL((k_ddpg_update<PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, dc, da);
-  return hipGetLastError();
-}
-
-// n_upd updates as one launch (k_ddpg_chain): `a` / `dc` / `da` as for launch_ddpg_update (the gates' tags = the FIRST
+// n_upd updates as one launch (k_ddpg_chain): `a` / `dc` / `da` with both gates filled in (the gates' tags = the FIRST
 // update's epoch), `c` = what changes per update
 hipError_t launch_ddpg_chain(const DdpgArgs& a, const DwKArgs4& dc, const DwKArgs4& da, const ChainArgs& c, hipStream_t st) {
   if (!lean_ok(a) || a.sac || !a.x2 || !kDwTileX2 || a.n_critics != 1 || !a.whole || (a.merged & 3) != 3 || (a.wide & 3) != 3 ||

@@ -398,7 +398,7 @@ hipError_t launch_dw_adam(const DwArgs& a0, hipStream_t st) {
   if (a0.n_items < 1 || a0.n_items > kDwMaxItems) return hipErrorInvalidValue;
   static const PrefetchJob no_prefetch = [] { PrefetchJob j; memset((void*)&j, 0, sizeof j); j.z0 = -1; return j; }();
   // wide layers (TQC's 512x512) go to the 64x64-tile kernel (csrc/dw_wide.hip), the rest stay here
-  static const bool no_wide = [] { const char* e = getenv("OPRL_AMD_NO_DW_WIDE"); return e != nullptr && atoi(e) != 0; }();
+  static const bool no_wide = [] { const char* e = getenv("OPRL_AMD_NO_RIDE"); return e != nullptr && (atoi(e) & 16) != 0; }();   // (bit 16: learner.hip)
   DwItem rest[kDwMaxItems], wide[kDwMaxItems];
   int n_rest = 0, n_wide = 0;
   for (int j = 0; j < a0.n_items; ++j) {

@@ -131,7 +131,6 @@ hipError_t launch_ddpg_phase1_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_
 bool fused_ddpg_is_lean(const DdpgArgs& a);
 hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st);
 hipError_t launch_ddpg_phase2_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st);
-hipError_t launch_ddpg_update(const DdpgArgs& a, const DwKArgs4& dc, const DwKArgs4& da, hipStream_t st);
 hipError_t launch_ddpg_chain(const DdpgArgs& a, const DwKArgs4& dc, const DwKArgs4& da, const ChainArgs& c, hipStream_t st);
 hipError_t launch_ddpg_phase1_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
 hipError_t launch_ddpg_phase2_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
@@ -347,29 +346,29 @@ struct oprl_learner {
   bool dp_inline = false;      // this data-parallel update exchanges inside the dW launches (k_dw_adam<true>)
   DwXchg dw_xchg;
   bool no_dp_inline = false;   // OPRL_AMD_NO_DP_INLINE: peer-window exchanges as separate launches (tests / A-B)
-  bool no_twin_split = false;  // OPRL_AMD_NO_TWIN_SPLIT: role A runs both target critics back to back (tests / A-B)
+  bool no_twin_split = false;  // OPRL_AMD_NO_SIDE_BY_SIDE: role A runs both target critics back to back (tests / A-B)
   bool no_multi = false;
   PrefetchJob prefetch;        // step_n on the generic path (TQC): the next update's rows as riders of this update's k_lw_dact launch
   bool prefetch_pending = false, prefetch_done = false;
-  bool no_gather_ride = false; // OPRL_AMD_NO_GATHER_RIDE: a k_replay_gather launch per update (tests / A-B)
+  bool no_gather_ride = false; // OPRL_AMD_NO_RIDE bit 8: a k_replay_gather launch per update (tests / A-B)
   float* batch_alt = nullptr;  // the second set of batch rows [Bmax x (2 S + A + 2)] the riders fill while an update reads the first
   MlpArgs fin_args[OPRL_MAX_CRITICS];   // TQC: the online critics' first-launch arguments of this update (critic_phase step 1) ...
   int fin_tail0 = -1;          // ... of which [fin_tail0, nc) did not fit beside the actor's forward: offered to the target pass's head launch (-1: none pending)
   bool fin16 = false;
   bool fin_done = false;       // TQC: the online critics' first hidden launch rode on the actor's forward on s' (critic_phase step 1); step 3 skips it
-  bool no_fin_ride = false;    // OPRL_AMD_NO_FIN_RIDE: it stays the first launch of step 3 (tests / A-B)
+  bool no_fin_ride = false;    // OPRL_AMD_NO_RIDE bit 4: it stays the first launch of step 3 (tests / A-B)
   LwPairBuf lw_pairs = {nullptr, 0, 1u, 1 << 20, nullptr, 3, 0};   // k_lw_mid_pair: flags (own allocation), tags; OPRL_AMD_LW_PAIR: bit 0 forward, bit 1 backward pairs (default 3)
   float* lw_scratch = nullptr; // [critics][layers 1 .. L-1][Bmax x 512]: activations of forward-only layer-by-layer launches (the target pass) — not the nets' dW exchange buffers, which the early first launch has already filled
   MlpArgs rider;               // TQC: the actor's forward on s, prepared in critic_phase to ride on the critic step's head launch ...
   bool rider_pending = false;  // ... offered to the next for_each_net; taken: rider_done, and actor_phase skips its step 5
   bool rider_done = false;
-  bool no_af_ride = false;     // OPRL_AMD_NO_AF_RIDE: the forward stays a launch of actor_phase (tests / A-B)
+  bool no_af_ride = false;     // OPRL_AMD_NO_RIDE bit 2: the forward stays a launch of actor_phase (tests / A-B)
   TqcJob tqc_job;              // TQC: the TD target as the tail of the target critics' head launch (kernels.h) ...
   bool tqc_job_pending = false; // ... offered to the next for_each_net; still set afterwards: k_tqc_target as a launch of its own
-  bool no_tqc_ride = false;    // OPRL_AMD_NO_TQC_RIDE: always that launch (tests / A-B)
+  bool no_tqc_ride = false;    // OPRL_AMD_NO_RIDE bit 1: always that launch (tests / A-B)
   unsigned long long* tqc_counter = nullptr;   // [slices at Bmax] arrival counters, zeroed once
   bool no_layerwise = false;   // OPRL_AMD_NO_LAYERWISE: wide nets stay on the single-CU slice kernel (tests / A-B)
-  bool no_p2_pair = false;     // OPRL_AMD_NO_P2_PAIR: SAC phase 2 runs the twin critics back to back (tests / A-B)
+  bool no_p2_pair = false;     // OPRL_AMD_NO_SIDE_BY_SIDE: SAC phase 2 runs the twin critics back to back (tests / A-B)
   bool multi_collect = false;  // for_each_net over > 2 single-CU nets: one k_mlp_slice_multi launch
   int multi_n = 0, multi_width = 0;
   MlpArgs multi_args[kMaxMulti];
@@ -380,8 +379,8 @@ struct oprl_learner {
   int n_cus = 256;
   int no_lean = 0;
   bool shared_chip = false;    // oprl_learner_set_cluster(< 8): this learner is one of several on the GPU
-  int no_merge = 0;            // OPRL_AMD_NO_MERGE: dW launches of their own
-  int no_merge2 = 0;           // OPRL_AMD_NO_MERGE2: phase 2 runs the actor's backward itself, the actor's dW is a launch of its own
+  int no_merge = 0;            // OPRL_AMD_FORM=plain: dW launches of their own
+  int no_merge2 = 0;           // OPRL_AMD_FORM=p2 / plain: phase 2 runs the actor's backward itself, the actor's dW is a launch of its own
   // merged phase 2 (DdpgArgs::merged bit 1): du granules [Bm][kDuLd], the first layer's dz1 granules [16][Bm][16] and the
   // snapshot of the actor's output layer (Bm = min(max_batch, 256))
   // oprl_learner_step_act: host-mapped pinned block [obs 512 floats | out 512 granules {ticket, value}] and the ticket of the pending row
@@ -440,7 +439,7 @@ struct oprl_learner {
   bool stale_wide = false;     // ... and are: only the critics' 512 x 512 layers' fp32 packs (the narrow layers' are current)
   float* uc_base = nullptr;    // the fp16 packs' uncached allocation (PrecX2 learners)
   bool uc_pool = false;        // the workspace pool is uncached memory as well
-  // k_ddpg_update (the whole update as one launch): role C's / the critic tiles' flags, the critic's uncached bias copies
+  // k_ddpg_chain (the whole update, several per launch): role C's / the critic tiles' flags, the critic's uncached bias copies
   unsigned long long* w_flags = nullptr;
   float* critic_b16 = nullptr;
   // k_ddpg_chain (several updates per launch): the tiles' FIN flags, the prefetch flags, the uncached bias copies of all
@@ -452,9 +451,9 @@ struct oprl_learner {
   int chain_u = 1;             // step_n: updates the next whole-update launch runs (k_ddpg_chain)
   bool chain_pf_last = false;  // ... and whether its last update stages the rows of the update after it
   const float* chain_set1[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // the other staging set (set 0 = the update's rows)
-  int no_chain = 0;            // OPRL_AMD_NO_CHAIN: one update per launch (k_ddpg_update)
+  int no_chain = 0;            // (always 0: every whole update goes through k_ddpg_chain)
   int chain_max = kChainMax;   // OPRL_AMD_CHAIN=n: at most n updates per launch
-  int no_whole = 0;            // OPRL_AMD_NO_WHOLE: two launches per update (merged phase 1, merged phase 2)
+  int no_whole = 0;            // OPRL_AMD_FORM=two / p2 / plain: two launches per update (merged phase 1, merged phase 2)
   bool whole_done = false;     // this update's actor phase was part of the critic phase's launch
   float* pack16[OPRL_MAX_CRITICS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   float* pack16_t[OPRL_MAX_CRITICS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -480,6 +479,16 @@ hipError_t uc_alloc(void** out, size_t bytes) {
   std::lock_guard<std::mutex> lk(g_uc_mu);
   for (UcBlock& b : g_uc)
     if (!b.used && b.bytes >= bytes && b.bytes <= 2 * bytes + (1u << 20)) { b.used = true; *out = b.p; return hipSuccess; }
+  // a process that cycles learners of ever different shapes must not grow without bound: once more than 64 MB of
+  // blocks lie idle, ANY idle block that is large enough serves (the smallest such), whatever its size
+  size_t idle = 0;
+  for (const UcBlock& b : g_uc) if (!b.used) idle += b.bytes;
+  if (idle > ((size_t)64 << 20)) {
+    UcBlock* best = nullptr;
+    for (UcBlock& b : g_uc)
+      if (!b.used && b.bytes >= bytes && (best == nullptr || b.bytes < best->bytes)) best = &b;
+    if (best != nullptr) { best->used = true; *out = best->p; return hipSuccess; }
+  }
   void* p = nullptr;
   hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
   if (e != hipSuccess) return e;
@@ -900,6 +909,15 @@ void seed_rng(MlpArgs& a, const oprl_learner* h, const float* noise, uint64_t st
 // ------------------------------------------------------------ fused DDPG / TD3
 bool actor_due(const oprl_learner* h);
 
+// grid rows of one update of k_ddpg_chain at batch B: 16 role rows + the tile-only rows of small batches (16 x 64 tiles)
+int chain_rows(const oprl_learner* h, int B) {
+  int tiles64[2] = {0, 0};
+  for (size_t i = 0; i < h->items_host.size(); ++i)
+    tiles64[(int)i < h->n_items_critic ? 0 : 1] += ((h->items_host[i].N + 15) / 16) * ((h->items_host[i].K + 63) / 64);
+  const int sl = (B + kR - 1) / kR, mt = tiles64[0] > tiles64[1] ? tiles64[0] : tiles64[1];
+  return 16 + (mt > 8 * sl ? (mt - 8 * sl + sl - 1) / sl : 0);
+}
+
 DdpgArgs ddpg_args(oprl_learner* h, int B) {
   const oprl_learner_config& c = h->cfg;
   DdpgArgs a;
@@ -1030,7 +1048,8 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   // the whole update as ONE launch (k_ddpg_update): both merged forms, role A and the critic pass on eight, the 16 x 64
   // tiles, and everything the roles hand to each other in uncached memory
   if (!h->no_whole && (!h->cfg.export_grads || inline_x2) && a.x2 && fused_x2_tiles() && h->nc == 1 && (a.merged & 3) == 3 && (a.wide & 3) == 3 && h->uc_pool &&
-      h->uc_base != nullptr && h->w_flags != nullptr) {
+      h->uc_base != nullptr && h->w_flags != nullptr && h->chain_flags != nullptr &&
+      chain_rows(h, B) * ((B + kR - 1) / kR) <= h->n_cus) {      // (one update's workgroups wait for each other: all must fit the chip)
     a.whole = 1;
     a.w_flags = h->w_flags;
     a.ct_done = h->w_flags + 64;
@@ -1280,12 +1299,8 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
         h->whole_done = true;
         return OPRL_OK;
       }
-      prof_begin(4, st);
-      hipError_t e = launch_ddpg_update(fa, kc, ka, st);
-      prof_end(st);
-      HIPC(e);
-      h->whole_done = true;
-      return OPRL_OK;
+      set_err("whole update: one update's workgroups do not fit this device (%d compute units)", h->n_cus);
+      return OPRL_ERR_STATE;
     }
     if ((fa.merged & 1) != 0) {
       // phase 1 and the critic's dW + Adam tiles as ONE launch: the tiles wait for the roles' flag granules
@@ -2087,7 +2102,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   if (e != hipSuccess) { set_err("hipFuncSetAttribute: %s", hipGetErrorString(e)); delete h; return OPRL_ERR_HIP; }
   memset(&h->src, 0, sizeof h->src);
   memset(&h->next_src, 0, sizeof h->next_src);
-  if (h->nc > 2 && getenv("OPRL_AMD_NO_SIDE_STREAMS") == nullptr) {
+  if (h->nc > 2) {
     bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int j = 1; ok && j < h->nc; ++j)
       ok = hipStreamCreateWithFlags(&h->side[j], hipStreamNonBlocking) == hipSuccess &&
@@ -2122,8 +2137,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   // PrecX2 learners: the workspace — activation exchange buffers, granules, staged rows — in UNCACHED device memory
   // (measured: no slower than cached, r03 log), so that a role of the whole-update launch reads what an earlier role
   // of the same launch wrote
-  static const int uc_pool_env = [] { const char* e = getenv("OPRL_AMD_UC_POOL"); return e != nullptr ? atoi(e) : 1; }();
-  const int uc_pool = (h->x2 && uc_pool_env) ? 1 : 0;
+  const int uc_pool = h->x2 ? 1 : 0;
   h->uc_pool = uc_pool != 0;
   if ((uc_pool ? uc_alloc((void**)&h->pool.base, bytes) : hipMalloc(&h->pool.base, bytes)) != hipSuccess) { set_err("hipMalloc(%zu) failed", bytes); delete h; return OPRL_ERR_NOMEM; }
   h->pool.cap = bytes;
@@ -2179,9 +2193,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   // the two-plane packs of a PrecX2 learner in UNCACHED device memory — every load and store goes to the fabric, so
   // that a workgroup reads what a workgroup on another XCD has just written without a kernel boundary in between
   // (measured: no slower than cached, r03 log)
-  // (OPRL_AMD_UC_PACKS=0 / OPRL_AMD_UC_POOL=0: ordinary device memory — then no whole-update launch)
-  static const int uc_packs = [] { const char* e = getenv("OPRL_AMD_UC_PACKS"); return e != nullptr ? atoi(e) : 1; }();
-  if (h->x2 && uc_packs) {
+  if (h->x2) {
     size_t fl = 2 * ((size_t)net_pack16_floats(cfg->actor, 2) + 64);
     for (int j = 0; j < nc; ++j) fl += 2 * ((size_t)net_pack16_floats(cfg->critics[j], 2) + 64);
     float* base = nullptr;
@@ -2247,12 +2259,14 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     const char* env = getenv("OPRL_AMD_CLUSTER");
     h->ncl = env ? atoi(env) : kMaxCluster;
     if (h->ncl != 1 && h->ncl != 2 && h->ncl != 4) h->ncl = kMaxCluster;
-    const char* nm = getenv("OPRL_AMD_NO_MULTI");    // tests / A-B: side streams instead of k_mlp_slice_multi
-    h->no_multi = (nm != nullptr && atoi(nm) != 0);
+    h->no_multi = false;
+    // OPRL_AMD_NO_RIDE = bit mask of the riders / joined launches to switch off (tests: each is bit-identical to the
+    // separate launches): 1 TD target on the target heads, 2 actor forward on the critic heads, 4 first hidden launch
+    // behind the actor's forward, 8 next rows on k_lw_dact, 16 wide dW kernel (kernels.hip), 32 hidden-layer pairs
+    const int no_ride = [] { const char* e = getenv("OPRL_AMD_NO_RIDE"); return e != nullptr ? atoi(e) : 0; }();
     const char* nlw = getenv("OPRL_AMD_NO_LAYERWISE");
     h->no_layerwise = (nlw != nullptr && atoi(nlw) != 0);
-    const char* ngr = getenv("OPRL_AMD_NO_GATHER_RIDE");
-    h->no_gather_ride = (ngr != nullptr && atoi(ngr) != 0);
+    h->no_gather_ride = (no_ride & 8) != 0;
     if (cfg->algo == OPRL_TQC || h->du_granules != nullptr) {
       const size_t n = (size_t)h->Bmax * (2 * (size_t)h->S + h->A + 2);
       // (PrecX2 learners: uncached, like the first staging set in the pool — inside k_ddpg_chain an update reads rows a
@@ -2260,14 +2274,12 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
       if ((h->uc_pool ? uc_alloc((void**)&h->batch_alt, n * sizeof(float)) : hipMalloc(&h->batch_alt, n * sizeof(float))) != hipSuccess)
         h->batch_alt = nullptr;   // (then: a gather launch per update)
     }
-    const char* nfr = getenv("OPRL_AMD_NO_FIN_RIDE");
-    h->no_fin_ride = (nfr != nullptr && atoi(nfr) != 0);
+    h->no_fin_ride = (no_ride & 4) != 0;
     if (cfg->algo == OPRL_TQC && h->w_critic == 512) {
       const size_t n = (size_t)nc * (kMaxLayers - 1) * (size_t)h->Bmax * 512;
       if (hipMalloc(&h->lw_scratch, n * sizeof(float)) != hipSuccess) h->lw_scratch = nullptr;   // (then: the nets' own buffers, no early launch)
       {
-        const char* pe = getenv("OPRL_AMD_LW_PAIR");
-        const int pair_env = pe != nullptr ? atoi(pe) : 3;
+        const int pair_env = (no_ride & 32) != 0 ? 0 : 3;
         const int nf = kMaxMulti * ((h->Bmax + 31) / 32) * 32;
         void* fl = nullptr;
         if (pair_env != 0 && hipMalloc(&fl, (size_t)nf * sizeof(unsigned long long)) == hipSuccess) {
@@ -2277,10 +2289,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
         }
       }
     }
-    const char* nar = getenv("OPRL_AMD_NO_AF_RIDE");
-    h->no_af_ride = (nar != nullptr && atoi(nar) != 0);
-    const char* ntr = getenv("OPRL_AMD_NO_TQC_RIDE");
-    h->no_tqc_ride = (ntr != nullptr && atoi(ntr) != 0);
+    h->no_af_ride = (no_ride & 2) != 0;
+    h->no_tqc_ride = (no_ride & 1) != 0;
     if (cfg->algo == OPRL_TQC && nc * cfg->hp.n_quantiles <= 128) {
       const size_t slices = (size_t)(h->Bmax + kR - 1) / kR;
       if (hipMalloc(&h->tqc_counter, slices * sizeof(unsigned long long)) != hipSuccess) h->tqc_counter = nullptr;   // (then: the stand-alone launch)
@@ -2288,27 +2298,28 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     }
     const char* ndi = getenv("OPRL_AMD_NO_DP_INLINE");
     h->no_dp_inline = (ndi != nullptr && atoi(ndi) != 0);
-    const char* nts = getenv("OPRL_AMD_NO_TWIN_SPLIT");
-    h->no_twin_split = (nts != nullptr && atoi(nts) != 0);
-    const char* np2 = getenv("OPRL_AMD_NO_P2_PAIR");
-    h->no_p2_pair = (np2 != nullptr && atoi(np2) != 0);
+    // OPRL_AMD_NO_SIDE_BY_SIDE: TD3 / SAC twin nets back to back instead of on clusters that wait for each other
+    const char* nsb = getenv("OPRL_AMD_NO_SIDE_BY_SIDE");
+    h->no_twin_split = (nsb != nullptr && atoi(nsb) != 0);
+    h->no_p2_pair = h->no_twin_split;
     const char* nl = getenv("OPRL_AMD_NO_LEAN");
     h->no_lean = (nl != nullptr && atoi(nl) != 0) ? 1 : 0;
-    const char* nmg = getenv("OPRL_AMD_NO_MERGE");
-    h->no_merge = (nmg != nullptr && atoi(nmg) != 0) ? 1 : 0;
-    const char* nm2 = getenv("OPRL_AMD_NO_MERGE2");
-    h->no_merge2 = (nm2 != nullptr && atoi(nm2) != 0) ? 1 : 0;
-    const char* nch = getenv("OPRL_AMD_NO_CHAIN");
-    h->no_chain = (nch != nullptr && atoi(nch) != 0) ? 1 : 0;
+    // OPRL_AMD_FORM: the launch structure of the fused DDPG / TD3 update — "chain" (default: the whole update, several
+    // per launch), "two" (merged phase launches: phase 1 + the critic's tiles | phase 2 + the actor's), "p2" (phase 1
+    // merged, phase 2 and the actor's dW as launches of their own), "plain" (phases and dW launches)
+    h->no_merge = h->no_merge2 = h->no_whole = 0;
+    if (const char* f = getenv("OPRL_AMD_FORM")) {
+      if (!strcmp(f, "two")) h->no_whole = 1;
+      else if (!strcmp(f, "p2")) { h->no_whole = 1; h->no_merge2 = 1; }
+      else if (!strcmp(f, "plain")) { h->no_whole = 1; h->no_merge2 = 1; h->no_merge = 1; }
+    }
+    h->no_chain = 0;
     if (const char* cm = getenv("OPRL_AMD_CHAIN")) { const int v = atoi(cm); if (v >= 1 && v <= kChainMax) h->chain_max = v; }
-    const char* nwh = getenv("OPRL_AMD_NO_WHOLE");
-    h->no_whole = (nwh != nullptr && atoi(nwh) != 0) ? 1 : 0;
     const char* nw = getenv("OPRL_AMD_NO_WIDE");
     h->no_wide = (nw != nullptr && atoi(nw) != 0) ? 1 : 0;
     // the generic per-net launches on clusters of 4 (slice_tp.hip): any net of the common shape
-    const char* ng = getenv("OPRL_AMD_NO_TP_GENERIC");
     // (decided per net by tp_generic(): TQC's 512-wide critics stay on k_mlp_slice, its actor moves)
-    h->tp_generic_on = !h->no_lean && h->ncl == 4 && !(ng != nullptr && atoi(ng) != 0);
+    h->tp_generic_on = !h->no_lean && h->ncl == 4;
   }
   if (h->fused || h->tp_generic_on) {
     const size_t slices = (size_t)(h->Bmax + kR - 1) / kR;
@@ -2335,7 +2346,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   if (h->x2 || (h->bf16 && cfg->algo == OPRL_TQC)) {
     std::lock_guard<std::mutex> lk(g_lazy_mu);
     g_lazy.push_back(h);
-    h->lazy_wide = cfg->algo == OPRL_TQC && getenv("OPRL_AMD_KEEP_WIDE32") == nullptr;
+    h->lazy_wide = cfg->algo == OPRL_TQC;
   }
   *out = h;
   return OPRL_OK;
@@ -2501,13 +2512,7 @@ int chain_loop(oprl_learner* h, int K, int B, float* (*set)[5], void* stream) {
 
 // does step_n at this batch run as chain launches?
 bool chain_ok(oprl_learner* h, int B) {
-  const DdpgArgs probe = ddpg_args(h, B);
-  int tiles64[2] = {0, 0};                 // 16 x 64 tiles of the critic / the actor (dw_tile_x2.h)
-  for (size_t i = 0; i < h->items_host.size(); ++i)
-    tiles64[(int)i < h->n_items_critic ? 0 : 1] += ((h->items_host[i].N + 15) / 16) * ((h->items_host[i].K + 63) / 64);
-  const int sl = (B + kR - 1) / kR, mt64 = tiles64[0] > tiles64[1] ? tiles64[0] : tiles64[1];
-  const int t_rows = mt64 > 8 * sl ? (mt64 - 8 * sl + sl - 1) / sl : 0;
-  return probe.whole && B <= 256 && !h->no_chain && h->chain_flags != nullptr && h->batch_alt != nullptr && (16 + t_rows) * sl <= h->n_cus;
+  return ddpg_args(h, B).whole && B <= 256 && h->batch_alt != nullptr;
 }
 }  // namespace
 
@@ -2546,12 +2551,6 @@ extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t
     int rc = OPRL_OK;
     h->staged_ready = false;
     if (chain) return chain_loop(h, K, B, set, stream);
-    // OPRL_AMD_GRAPH_PROBE=1 (measurement only, profiles/r03_experiments.txt): the K updates' launches are captured into a
-    // hipGraph — every node with its own argument block: epoch, counters and staging set are baked in at capture — and
-    // replayed once; the call returns when the graph has run.  Does the boundary between two launches move?
-    static const bool graph_probe = [] { const char* e = getenv("OPRL_AMD_GRAPH_PROBE"); return e != nullptr && atoi(e) != 0; }();
-    const bool in_graph = graph_probe && K > 1 && stream != nullptr;
-    if (in_graph) HIPC(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
     for (int k = 0; k < K && rc == OPRL_OK; ++k) {
       float** b = set[cur];
       float** nb = set[h->prefetch_p1 ? cur ^ 1 : cur];
@@ -2565,19 +2564,6 @@ extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t
       h->staged_ready = false;
       rc = oprl_learner_update(h, b[0], b[1], b[2], b[3], b[4], B, nullptr, nullptr, stream);
       if (h->prefetch_p1) cur ^= 1;
-    }
-    if (in_graph) {
-      hipGraph_t graph = nullptr;
-      hipGraphExec_t exec = nullptr;
-      HIPC(hipStreamEndCapture((hipStream_t)stream, &graph));
-      HIPC(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-      const auto t0 = std::chrono::steady_clock::now();
-      HIPC(hipGraphLaunch(exec, (hipStream_t)stream));
-      HIPC(hipStreamSynchronize((hipStream_t)stream));
-      const double us = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() * 1e-3;
-      fprintf(stderr, "[oprl_amd graph probe] %d updates as one hipGraph: %.2f us per update (launch to drained)\n", K, us / K);
-      (void)hipGraphExecDestroy(exec);
-      (void)hipGraphDestroy(graph);
     }
     sc.gather = 0;
     h->prefetch_next = 0;
@@ -2710,7 +2696,7 @@ struct oprl_group {
   bool stage_busy[2] = {false, false};
   int cur = 0;
   size_t bytes = 0;                            // one update's blocks
-  int span = 1;                                // XCDs a member's slices are dealt out to (generic passes; OPRL_AMD_GROUP_SPAN)
+  int span = 1;                                // XCDs a member's slices are dealt out to (generic passes: 1)
   int ni_c = kDwGroupItems;                    // layers per critic-step dW block (twin critics: kDwGroupItems2)
   int device = 0;                              // the device the group's buffers (and its members) live on
 };
@@ -2744,7 +2730,7 @@ extern "C" int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group*
   // for exact fp32 as well.  TD3 / SAC members (fused in the lean form only): clusters of four in every precision.
   int group_nc = 4;
   {
-    static const int env_nc = [] { const char* e = getenv("OPRL_AMD_GROUP_NC"); return e != nullptr ? atoi(e) : 0; }();
+    const int env_nc = 0;
     oprl_learner* h0 = learners[0];
     const int keep_ncl = h0->ncl;
     const bool keep_sc = h0->shared_chip;
@@ -2762,7 +2748,7 @@ extern "C" int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group*
   g->L.assign(learners, learners + n);
   (void)hipGetDevice(&g->device);
   g->ni_c = learners[0]->nc == 2 ? kDwGroupItems2 : kDwGroupItems;
-  { const char* e = getenv("OPRL_AMD_GROUP_SPAN"); g->span = e != nullptr ? atoi(e) : 1; if (g->span != 1 && g->span != 2 && g->span != 4 && g->span != 8) g->span = 1; }
+  g->span = 1;        // (a member's slices on one XCD: 2 / 4 / 8 measured slower, r03-39)
   g->bytes = (size_t)n * (2 * sizeof(DdpgArgs) + dw_group_block_bytes(g->ni_c) + dw_group_block_bytes(kDwGroupItems));
   bool ok = hipMalloc((void**)&g->dev, g->bytes * kGroupChunk) == hipSuccess;
   for (int i = 0; i < 2 && ok; ++i) {

@@ -65,8 +65,8 @@ def run_training(
     # merged phase + tile launches, the whole-update launch: include/oprl_amd.h) need their workgroups co-resident, and a
     # sibling process holding the compute units turns a bounded wait into a poisoned update — not into a slowdown.
     # From two seeds on the children inherit the forms that only ever wait within a cluster of four
-    for var in ("OPRL_AMD_NO_WIDE", "OPRL_AMD_NO_MERGE", "OPRL_AMD_NO_MERGE2", "OPRL_AMD_NO_WHOLE"):
-        os.environ.setdefault(var, "1")
+    os.environ.setdefault("OPRL_AMD_NO_WIDE", "1")
+    os.environ.setdefault("OPRL_AMD_FORM", "plain")
     ctx = get_context("spawn")   # a forked child cannot re-initialise the GPU runtime
     procs = [ctx.Process(target=_run_training_func,
                          args=(make_algo, make_env, make_replay_buffer, make_logger, config, seed),

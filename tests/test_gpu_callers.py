@@ -102,7 +102,7 @@ def test_sac_b1024_step_n_equals_python_loop_bitwise():
 def test_export_grads_split_equals_fused_update(monkeypatch):
     # (the one-call update with the actor's backward in phase 2 itself, as the split path runs it: the merged phase 2
     # — role U's unit seeds — sums in another order and is held to the generic path by tests/test_gpu_fused.py)
-    monkeypatch.setenv("OPRL_AMD_NO_MERGE2", "1")
+    monkeypatch.setenv("OPRL_AMD_FORM", "p2")
     fused, split = _ddpg(), _ddpg(export_grads=True)
     for step in range(3):
         batch = [x.cuda() for x in fx.make_batch(50 + step, 256, 24, 6)]
@@ -132,7 +132,7 @@ def test_td3_export_grads_split_equals_fused_update(monkeypatch):
         t.manual_seed(0)
         return TD3(logger=NullLogger(), state_dim=17, action_dim=6, device="cuda", max_batch=256, **kw).create()
 
-    monkeypatch.setenv("OPRL_AMD_NO_MERGE2", "1")     # (as in the DDPG test above)
+    monkeypatch.setenv("OPRL_AMD_FORM", "p2")     # (as in the DDPG test above)
     fused, split = make(), make(export_grads=True)
     for step in range(4):
         batch = [x.cuda() for x in fx.make_batch(60 + step, 256, 17, 6)]
@@ -762,8 +762,7 @@ def test_packed_twin_critic_group_equals_solo_learners(algo, precision, n_member
     actor's dW launch, the device noise streams keyed per member."""
     from oprl_amd.group import LearnerGroup
     from oprl_amd.logging import NullLogger
-    monkeypatch.setenv("OPRL_AMD_NO_TWIN_SPLIT", "1")
-    monkeypatch.setenv("OPRL_AMD_NO_P2_PAIR", "1")
+    monkeypatch.setenv("OPRL_AMD_NO_SIDE_BY_SIDE", "1")
     B, K = 64, 7
     buf = _filled_buffer()
 

@@ -28,16 +28,15 @@ def _close(a, b, tol=1e-5):
 # tp4_scalar_fb <P, 8>, narrow exchanges); 4: clusters of four only; "4g": clusters of 4 through the generic
 # tp3.h passes instead of the lean tp4.h ones
 # (8 and 4 run the critic's dW + Adam tiles inside phase 1's launch, csrc/dw_body.h GATED; "8s": role A on eight CUs and the
-# dW launches on their own, OPRL_AMD_NO_MERGE)
+# dW launches on their own, OPRL_AMD_FORM=plain)
 # 8 and 4 also run the ACTOR's dW + Adam tiles inside phase 2's launch, its backward as role U with unit seeds (GATE == 2);
-# "8p": phase 2 runs the actor's backward itself and the actor's dW is a launch of its own, OPRL_AMD_NO_MERGE2)
+# "8p": phase 2 runs the actor's backward itself and the actor's dW is a launch of its own, OPRL_AMD_FORM=p2)
 @pytest.mark.parametrize("cluster", [8, "8s", "8p", 4, "4g", 2, 1])
 @pytest.mark.parametrize("B", [256, 8, 100])
 def test_fused_equals_generic(B, cluster, monkeypatch):
     monkeypatch.setenv("OPRL_AMD_NO_LEAN", "1" if cluster == "4g" else "0")
     monkeypatch.setenv("OPRL_AMD_NO_WIDE", "0" if cluster in (8, "8s", "8p") else "1")
-    monkeypatch.setenv("OPRL_AMD_NO_MERGE", "1" if cluster == "8s" else "0")
-    monkeypatch.setenv("OPRL_AMD_NO_MERGE2", "1" if cluster in ("8s", "8p") else "0")
+    monkeypatch.setenv("OPRL_AMD_FORM", "plain" if cluster == "8s" else ("p2" if cluster == "8p" else "chain"))
     cluster = 4 if cluster in ("4g", 8, "8s", "8p") else cluster
     monkeypatch.setenv("OPRL_AMD_CLUSTER", str(cluster))
     fused, generic = _ddpg(), _ddpg(no_fuse=True)
@@ -121,7 +120,7 @@ def test_fused_td3_equals_generic(inject, split, monkeypatch):
     """6 updates = 3 critic-only + 3 actor steps (policy_freq 2); target-policy smoothing noise
     injected (as the golden tests do) or drawn on device (same Philox stream in both paths); the twin
     target critics side by side (role A and the role-C cluster) or back to back in role A."""
-    monkeypatch.setenv("OPRL_AMD_NO_TWIN_SPLIT", "0" if split else "1")
+    monkeypatch.setenv("OPRL_AMD_NO_SIDE_BY_SIDE", "0" if split else "1")
     fused, generic = _td3(), _td3(no_fuse=True)
     for step in range(6):
         batch = [x.cuda() for x in fx.make_batch(90 + step, 256, 17, 6)]
@@ -193,44 +192,6 @@ def test_fused_td3_step_n_equals_generic_step_n():
         assert _close(getattr(fused, m)._oprl_arena, getattr(generic, m)._oprl_arena, 1e-4), m
 
 
-# ---- generic per-net launches: tensor-parallel clusters (slice_tp.hip) vs one CU per slice -------
-@pytest.mark.parametrize("algo", ["sac", "td3"])
-def test_generic_launches_cluster_vs_single_cu(algo, monkeypatch):
-    """OPRL_AMD_NO_TP_GENERIC=1 keeps the generic launch sequence on k_mlp_slice (one CU per slice);
-    the default runs the same launches on clusters of 4 with the lean passes.  Same results up to
-    summation order."""
-    from oprl_amd.logging import NullLogger
-
-    def make():
-        t.manual_seed(0)
-        if algo == "sac":
-            from oprl_amd.algos.sac import SAC
-            return SAC(logger=NullLogger(), state_dim=67, action_dim=21, device="cuda", max_batch=1024,
-                       tune_alpha=True).create()
-        from oprl_amd.algos.td3 import TD3
-        return TD3(logger=NullLogger(), state_dim=17, action_dim=6, device="cuda", max_batch=1024,
-                   no_fuse=True).create()
-
-    monkeypatch.setenv("OPRL_AMD_NO_TP_GENERIC", "0")
-    tp = make()
-    monkeypatch.setenv("OPRL_AMD_NO_TP_GENERIC", "1")
-    one = make()
-    B, S, A = (1024, 67, 21) if algo == "sac" else (512, 17, 6)
-    for step in range(4):
-        batch = [x.cuda() for x in fx.make_batch(300 + step, B, S, A)]
-        n0 = fx.make_noise(400 + step, (B, A)).cuda()
-        n1 = fx.make_noise(500 + step, (B, A)).cuda()
-        for a in (tp, one):
-            if algo == "sac":
-                a.update(*batch, noise=(n0, n1))
-            else:
-                a.update(*batch, noise=n0)
-    t.cuda.synchronize()
-    for m in ("actor", "critic", "critic_target"):
-        assert t.isfinite(getattr(tp, m)._oprl_arena).all()
-        assert _close(getattr(tp, m)._oprl_arena, getattr(one, m)._oprl_arena, 1e-4), m
-
-
 @pytest.mark.parametrize("algo", ["ddpg", "td3"])
 def test_fused_runs_are_deterministic(algo):
     """The cluster exchanges sum in member order and the hand-offs are data-tagged, so two runs of the
@@ -264,8 +225,7 @@ def test_fused_sac_equals_generic(inject, tune_alpha, pair, monkeypatch):
     """Both Normal(0,1) draws injected (as the golden tests do) or drawn on device (same Philox streams
     in both paths); fixed or learned temperature; phase 2's twin critics on two clusters side by side
     or back to back on one."""
-    monkeypatch.setenv("OPRL_AMD_NO_P2_PAIR", "0" if pair else "1")
-    monkeypatch.setenv("OPRL_AMD_NO_TWIN_SPLIT", "0" if pair else "1")   # (phase 1's twin targets likewise)
+    monkeypatch.setenv("OPRL_AMD_NO_SIDE_BY_SIDE", "0" if pair else "1")   # (phase 2's critic pair and phase 1's twin targets)
     B, S, A = 256, 24, 6
     fused, generic = _sac(tune_alpha=tune_alpha), _sac(tune_alpha=tune_alpha, no_fuse=True)
     for step in range(5):
@@ -315,30 +275,6 @@ def test_fused_sac_step_n_equals_generic_step_n():
 
 
 # ---- TQC: the five quantile critics of a phase in one launch ----------------------------------------
-def test_tqc_multi_launch_equals_side_streams(monkeypatch):
-    """k_mlp_slice_multi (grid = slices x nets) runs the same workgroup code as five k_mlp_slice
-    launches on side streams: bit-identical."""
-    from oprl_amd.algos.tqc import TQC
-    from oprl_amd.logging import NullLogger
-
-    def make():
-        t.manual_seed(0)
-        return TQC(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=256).create()
-
-    monkeypatch.setenv("OPRL_AMD_NO_LAYERWISE", "1")   # (the layer-by-layer path is compared below)
-    multi = make()
-    monkeypatch.setenv("OPRL_AMD_NO_MULTI", "1")
-    streams = make()
-    for step in range(3):
-        batch = [x.cuda() for x in fx.make_batch(20 + step, 256, 24, 6)]
-        multi.update(*batch)
-        streams.update(*batch)
-    t.cuda.synchronize()
-    assert t.isfinite(multi.critic._oprl_arena).all()
-    for m in ("actor", "critic", "critic_target"):
-        assert t.equal(getattr(multi, m)._oprl_arena, getattr(streams, m)._oprl_arena), m
-
-
 @pytest.mark.parametrize("B", [256, 100])
 def test_tqc_layerwise_equals_slice_kernel(B, monkeypatch):
     """csrc/layerwise.hip (one launch per layer, workgroup per slice x 64 columns x net) against the
@@ -388,7 +324,7 @@ def test_tqc_target_on_head_launch_equals_target_launch(B, monkeypatch):
         return TQC(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=256).create()
 
     ride = make()
-    monkeypatch.setenv("OPRL_AMD_NO_TQC_RIDE", "1")      # (read when the learner is created)
+    monkeypatch.setenv("OPRL_AMD_NO_RIDE", "1")      # (read when the learner is created)
     ref = make()
     for step in range(4):
         batch = [x.cuda() for x in fx.make_batch(40 + step, B, 24, 6)]
@@ -414,7 +350,7 @@ def test_tqc_actor_forward_riding_on_heads_equals_own_launch(B, monkeypatch):
         return TQC(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=256).create()
 
     ride = make()
-    monkeypatch.setenv("OPRL_AMD_NO_AF_RIDE", "1")       # (read when the learner is created)
+    monkeypatch.setenv("OPRL_AMD_NO_RIDE", "2")       # (read when the learner is created)
     own = make()
     for step in range(3):
         batch = [x.cuda() for x in fx.make_batch(60 + step, B, 24, 6)]
@@ -448,7 +384,7 @@ def test_tqc_early_first_launch_equals_in_place(B, prec, monkeypatch):
                    precision=prec).create()
 
     early = make()
-    monkeypatch.setenv("OPRL_AMD_NO_FIN_RIDE", "1")      # (read when the learner is created)
+    monkeypatch.setenv("OPRL_AMD_NO_RIDE", "4")      # (read when the learner is created)
     inplace = make()
     for step in range(3):
         batch = [x.cuda() for x in fx.make_batch(90 + step, B, 24, 6)]
@@ -482,7 +418,7 @@ def test_tqc_hidden_layer_pairs_equal_separate_launches(B, prec, monkeypatch):
                    precision=prec).create()
 
     paired = make()
-    monkeypatch.setenv("OPRL_AMD_LW_PAIR", "0")          # (read when the learner is created)
+    monkeypatch.setenv("OPRL_AMD_NO_RIDE", "32")          # (read when the learner is created)
     single = make()
     for step in range(3):
         batch = [x.cuda() for x in fx.make_batch(90 + step, B, 24, 6)]
@@ -515,7 +451,7 @@ def test_tqc_step_n_rows_gathered_by_riders_equal_gather_launches(B, monkeypatch
         return TQC(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=256).create()
 
     riders = make()
-    monkeypatch.setenv("OPRL_AMD_NO_GATHER_RIDE", "1")   # (read when the learner is created)
+    monkeypatch.setenv("OPRL_AMD_NO_RIDE", "8")   # (read when the learner is created)
     launches = make()
     buf = _filled_buffer()
     riders.learner.step_n(buf.handle, 9, B, seed=4)
@@ -549,7 +485,7 @@ def test_tqc_wide_dw_equals_small_tiles(monkeypatch):
         "t.save({m: getattr(a, m)._oprl_arena.cpu() for m in ('actor', 'critic', 'critic_target')}, sys.argv[1])\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = "/tmp/oprl_amd_test_dw_small.pt"
-    env = dict(os.environ, OPRL_AMD_NO_DW_WIDE="1")
+    env = dict(os.environ, OPRL_AMD_NO_RIDE="16")
     subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=300)
     ref = t.load(out)
     t.manual_seed(0)

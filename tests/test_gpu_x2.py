@@ -144,7 +144,7 @@ def test_x2_out_of_range_inputs_raise_on_the_same_update(scale):
 
 @pytest.mark.parametrize("algo_name", ["ddpg", "td3"])
 def test_x2_launch_forms_agree(algo_name, monkeypatch):
-    """The three launch structures of a PrecX2 learner — the whole update as ONE launch (k_ddpg_update; DDPG), the two
+    """The three launch structures of a PrecX2 learner — whole updates, 20 per launch (k_ddpg_chain; DDPG), the two
     merged launches (phase 1 + the critic's tiles | phase 2 + the actor's tiles), and the plain sequence with dW launches
     of their own — are the same arithmetic cut differently (the merged forms' 16 x 64 split-product tiles against the
     16 x 32 tiles' sums: last-bits differences): parameters after 20 step_n updates within 2e-6 of each other."""
@@ -152,11 +152,8 @@ def test_x2_launch_forms_agree(algo_name, monkeypatch):
     from oprl_amd.logging import NullLogger
     from tests.test_gpu_callers import _filled_buffer
 
-    def run(env):
-        for k in ("OPRL_AMD_NO_WHOLE", "OPRL_AMD_NO_MERGE2", "OPRL_AMD_NO_MERGE"):
-            monkeypatch.delenv(k, raising=False)
-        for k in env:
-            monkeypatch.setenv(k, "1")
+    def run(form):
+        monkeypatch.setenv("OPRL_AMD_FORM", form)
         t.manual_seed(0)
         cls = getattr(importlib.import_module(f"oprl_amd.algos.{algo_name}"), algo_name.upper())
         a = cls(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=256, precision="x2").create()
@@ -166,9 +163,9 @@ def test_x2_launch_forms_agree(algo_name, monkeypatch):
         a.learner.check()
         return {m: getattr(a, m)._oprl_arena.clone() for m in ("actor", "critic", "actor_target", "critic_target")}
 
-    whole = run(())
-    two = run(("OPRL_AMD_NO_WHOLE",))
-    plain = run(("OPRL_AMD_NO_WHOLE", "OPRL_AMD_NO_MERGE2", "OPRL_AMD_NO_MERGE"))
+    whole = run("chain")
+    two = run("two")
+    plain = run("plain")
     for m in whole:
         scale = float(plain[m].abs().max())
         d1 = float((whole[m] - two[m]).abs().max()) / scale

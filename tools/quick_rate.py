@@ -1,5 +1,5 @@
 """Quick rate probe (needs a GPU): DDPG walker B = 256 through step_n, one learner per entry of argv
-(`prec[:ENV=V[,ENV=V..]]`, e.g. `x2 x2:OPRL_AMD_NO_CHAIN=1 f32`): us per update over K updates, K = 20 and K = 4000,
+(`prec[:ENV=V[,ENV=V..]]`, e.g. `x2 x2:OPRL_AMD_CHAIN=1 x2:OPRL_AMD_FORM=two f32`): us per update over K updates, K = 20 and K = 4000,
 and a finiteness + error-word check.  Environment switches are read at learner creation."""
 import os
 import sys

@@ -14,8 +14,8 @@ def make(env):
     a = DDPG(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", precision="x2").create()
     for k in env: os.environ[k] = "0"
     return a
-a = make({"OPRL_AMD_NO_MERGE2": "1"})
-b = make({"OPRL_AMD_NO_MERGE2": "1", "OPRL_AMD_NO_MERGE": "1"})
+a = make({"OPRL_AMD_FORM": "p2"})
+b = make({"OPRL_AMD_FORM": "plain"})
 batch = [x.cuda() for x in fx.make_batch(110, 256, 24, 6)]
 a.update(*batch); b.update(*batch)
 t.cuda.synchronize()
