@@ -18,3 +18,4 @@ head -1 $OUT/stats/*kernel_stats.csv > $OUT/kernel_stats.csv
 grep -E "oprl|k_replay" $OUT/stats/*kernel_stats.csv >> $OUT/kernel_stats.csv
 OPRL_UPL=32 python tools/pmc_summary.py $OUT/fetch $OUT/write $OUT/pmc_traffic.json $OUT/mfma $OUT/kernel_stats.csv > /dev/null
 cat $OUT/pmc_traffic.json
+rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/mfma       # (raw traces: scratch)
