@@ -63,8 +63,11 @@ typedef enum oprl_algo { OPRL_DDPG = 0, OPRL_TD3 = 1, OPRL_SAC = 2, OPRL_TQC = 3
  *          and gradient tiles enter scaled by a power of two (csrc/engine.h, PrecX2); accumulators, master weights,
  *          Adam and Polyak are fp32.  A PARITY mode: held to the reference's golden vectors and the CPU oracle at the
  *          F32 mode's gates (tests/test_gpu_x2.py); measured rms error of a 256-deep dot product 1.45e-7 relative (the
- *          fp32 MFMA chain: 2.8e-7).  Covers the fused DDPG / TD3 / SAC kernels — DDPG's whole update as ONE launch,
- *          k_ddpg_update — and the hidden layers of TQC's 512-wide critics; everything else runs exact fp32.  The fp32
+ *          fp32 MFMA chain: 2.8e-7).  Covers the fused DDPG / TD3 / SAC kernels — DDPG's whole updates, up to 32 per
+ *          launch (k_ddpg_chain; oprl_learner_step_n) — and the hidden layers of TQC's 512-wide critics; everything else
+ *          runs exact fp32.  RANGE: observations and hidden activations below 4094 in magnitude, weights below 256;
+ *          leaving it is reported through the error word (oprl_learner_check / the next update return OPRL_ERR_STATE,
+ *          "split-fp16 range"), never silent; F32 has no such range and is the default of the Python classes.  The fp32
  *          packs of such a learner are not kept current by its updates: every entry point that reads them
  *          (oprl_mlp_forward / backward / act, the generic launches) rebuilds them first. */
 typedef enum oprl_precision { OPRL_PREC_F32 = 0, OPRL_PREC_BF16 = 1, OPRL_PREC_X2 = 2 } oprl_precision;

@@ -2,8 +2,10 @@
 
 Same dataclass fields, ``create()`` / ``update()`` contract and attributes as
 the reference (/root/reference/src/oprl/algos/ddpg.py:16-107); ``update()`` is
-one call into liboprl_amd.so (3 kernel launches on the fused path — phase 1 with the critic's dW + Adam tiles riding on it, phase 2, the actor's dW + Adam — no host sync) instead of
-autograd + two torch Adam steps + 12 Polyak tensor ops."""
+one call into liboprl_amd.so — no host sync — instead of autograd + two torch Adam steps + 12 Polyak
+tensor ops: in the exact-fp32 and bf16 modes 3 kernel launches (phase 1 with the critic's dW + Adam tiles
+riding on it, phase 2, the actor's dW + Adam); in the x2 mode ONE launch for the whole update
+(k_ddpg_chain — through ``learner.step_n`` up to 32 updates per launch)."""
 from __future__ import annotations
 
 from dataclasses import dataclass, field
@@ -34,7 +36,7 @@ class DDPG(OffPolicyAlgorithm):
     max_batch: int = 4096          # rows the HIP workspace is sized for
     export_grads: bool = False     # data-parallel learner: reduce grads between phases
     no_fuse: bool = False          # force the generic per-net launch sequence (tests / A-B)
-    precision: str = "f32"        # "f32": exact-fp32 MFMA (parity mode); "bf16": bf16 MFMA inputs, fp32 accumulate / master / Adam (include/oprl_amd.h)
+    precision: str = "f32"        # "f32": exact-fp32 MFMA (parity mode, no input range); "x2": fp32 as fp16 hi + lo (parity mode, |obs| < 4094: leaving the range raises); "bf16": bf16 MFMA inputs, fp32 accumulate / master / Adam (include/oprl_amd.h)
 
     actor: PolicyProtocol = field(init=False)
     actor_target: PolicyProtocol = field(init=False)
