@@ -71,7 +71,12 @@ struct DwX2Ovr {
   int u = 0;                             // the update's index in the launch
 };
 
-template <class KArgs = DwKArgs>
+// P: PrecX2 (the split-fp16 products above) or PrecF32 — the SAME tile with exact-fp32 arithmetic (round 4: the
+// exact-fp32 learner's whole-update launch): X transposed into ONE fp32 plane in LDS (the two fp16 planes' bytes), eight
+// v_mfma_f32_16x16x4_f32 per 16 x 16 output tile and 32-row group, no scales, the fp32 fragment packs written from the
+// staged tile (DwItem::pf / pb / tpf: for such a learner they point at the library's uncached mirrors of the caller's
+// packs, learner.hip).
+template <class KArgs = DwKArgs, class P = PrecX2>
 struct DwX2Tile {
   static constexpr int TK = kDwX2TileK, LDF = DwX2Lds::LDF, LDH = DwX2Lds::LDH, LDT = DwX2Lds::LDT;
   DwX2Ovr ov;
@@ -284,9 +289,21 @@ struct DwX2Tile {
     if (late) u = f32x4{ncol == 0 ? 1.f : 0.f, 0.f, 0.f, 0.f};
     if (!(bb < hB && (an_ok || late))) u = z4;
   }
+  float* xt = lds + DwX2Lds::xh;       // PrecF32: ONE fp32 plane [64 k][LDF] over the two fp16 planes' area
+  static_assert(64 * DwX2Lds::LDF <= 64 * DwX2Lds::LDH, "the fp32 plane fits the two fp16 planes");
+  if constexpr (!P::kX2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool k_in = k_base + 32 * h + xq + t < I.K;
+        *reinterpret_cast<f32x2*>(xt + (size_t)(32 * h + xq + t) * LDF + xb0) = f32x2{k_in ? vx[h][0][t] : 0.f, k_in ? vx[h][1][t] : 0.f};
+      }
+    }
+  }
   // X -> 2^4 X -> two fp16 planes, transposed: plane[k][b], the two rows of this lane side by side
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; P::kX2 && h < 2; ++h) {
     f32x4 a = vx[h][0] * PrecX2::kFwdA, b = vx[h][1] * PrecX2::kFwdA;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -364,7 +381,27 @@ struct DwX2Tile {
   __syncthreads();       // dY and both planes of X are in LDS
 
   // ---- wave = (32-row group g, half of the k columns): two output tiles over the group's rows
-  {
+  if constexpr (!P::kX2) {
+    // exact fp32: per output tile 2 x (one b128 of dY^T, one of X^T, four v_mfma_f32_16x16x4_f32) — the lane group kk of a
+    // quad takes minibatch rows 4 kk + t of its 16-row half in both operands (any order inside a macro step, engine.h)
+    const int grp = wave >> 1, half = wave & 1;
+    const float* arow = dyt + (size_t)i * LDF + 32 * grp + 4 * kk;
+    const f32x4 a0 = ld4(arow), a1 = ld4(arow + 16);
+    if (half == 0) bpart[(grp * 4 + kk) * 16 + i] = ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a1[0] + a1[1]) + (a1[2] + a1[3]));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float* brow = xt + (size_t)(32 * half + 16 * t + i) * LDF + 32 * grp + 4 * kk;
+      const f32x4 b0 = ld4(brow), b1 = ld4(brow + 16);
+      f32x4 acc = z4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = mfma4(a0[e], b0[e], acc);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = mfma4(a1[e], b1[e], acc);
+      float* o = part + ((size_t)grp * 16 + 4 * kk) * LDT + 32 * half + 16 * t + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r * LDT] = acc[r];
+    }
+  } else {
     const int grp = wave >> 1, half = wave & 1;
     const float* arow = dyt + (size_t)i * LDF + 32 * grp + 8 * kk;
     const f32x4 a0 = ld4(arow), a1 = ld4(arow + 4);
@@ -530,7 +567,29 @@ struct DwX2Tile {
   // ---- the two-plane fp16 packs (hi = fp16(2^8 w), lo = fp16(2^8 w - hi); the lo plane 256 floats behind the hi
   // plane of a block), in pack order: threads 0..255 the forward packs (online | target) x two 32-column macro
   // steps, threads 256..511 the W^T pack's four 16-row k tiles (this tile's n columns are one HALF of their block)
-  if (I.pf16 != nullptr) {
+  if constexpr (!P::kX2) {
+    // ---- the fp32 fragment packs (engine.h: pack[((tile NS + s) 64 + lane) 4 + t] = M[16 tile + (lane & 15)][16 s + 4 (lane >> 4) + t])
+    // in pack order, 16-byte stores: threads 0..255 the forward pack's four 16-column macro steps of this tile's n tile,
+    // 256..511 the target's, 512..767 the W^T pack (tiles over k: this tile's four; its 16 n are ONE macro step there)
+    if (I.pf != nullptr) {
+      const int NSk = cdiv(I.K, 16), NSn = cdiv(I.N, 16);
+      const int grp3 = tid >> 8, q = tid & 255, j = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
+      if (grp3 < 2) {
+        float* dst = grp3 == 0 ? I.pf : (polyak ? I.tpf : nullptr);
+        if (dst != nullptr && 4 * tk + j < NSk && !(flagged && grp3 == 1))
+          *reinterpret_cast<f32x4*>(dst + (((size_t)ptile * NSk + 4 * tk + j) * 64 + l) * 4) = ld4((grp3 == 0 ? tileW : tileT) + li * LDT + 16 * j + 4 * lk);
+      } else if (grp3 == 2 && I.pb != nullptr) {
+        const int ktile = 4 * tk + j;
+        if (16 * ktile < I.K) {
+          f32x4 w4;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) w4[t] = tileW[(4 * lk + t) * LDT + 16 * j + li];
+          *reinterpret_cast<f32x4*>(I.pb + (((size_t)ktile * NSn + ptile) * 64 + l) * 4) = w4;
+        }
+      }
+    }
+  }
+  if (P::kX2 && I.pf16 != nullptr) {
     const int NSk2 = cdiv(I.K, 32), NSn2 = cdiv(I.N, 32);
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     if (tid < 256) {
@@ -571,7 +630,15 @@ struct DwX2Tile {
       st_ag(I.w + eo, th_new);
       if (polyak) st_ag(I.w_t + eo, tt_new);
     }
-    if (I.pf16 != nullptr && polyak && I.tpf16 != nullptr && tid >= 128 && tid < 256) {
+    if constexpr (!P::kX2) {       // (the target's forward pack: after the flag)
+      if (I.pf != nullptr && polyak && I.tpf != nullptr && tid >= 256 && tid < 512) {
+        const int NSk = cdiv(I.K, 16);
+        const int q = tid & 255, j = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
+        if (4 * tk + j < NSk)
+          *reinterpret_cast<f32x4*>(I.tpf + (((size_t)ptile * NSk + 4 * tk + j) * 64 + l) * 4) = ld4(tileT + li * LDT + 16 * j + 4 * lk);
+      }
+    }
+    if (P::kX2 && I.pf16 != nullptr && polyak && I.tpf16 != nullptr && tid >= 128 && tid < 256) {
       const int NSk2 = cdiv(I.K, 32);
       const int hb = (tid >> 6) & 1, l = tid & 63, li = l & 15, lk = l >> 4;
       if (2 * tk + hb < NSk2) {
@@ -596,9 +663,9 @@ struct DwX2Tile {
   }
 };
 
-template <class KArgs = DwKArgs>
+template <class KArgs = DwKArgs, class P = PrecX2>
 __device__ __forceinline__ void dw_tile_x2(const KArgs& A, float* lds, int bx, int gate, const DwX2Ovr& ov = DwX2Ovr()) {
-  DwX2Tile<KArgs> T;
+  DwX2Tile<KArgs, P> T;
   T.ov = ov;
   T.begin(A, lds, bx, gate);
   T.finish();

@@ -957,7 +957,7 @@ struct PassCtx {
 // here.  Otherwise: the backward step after du, its result as granules (the two-launch form, whose pass starts at once).
 template <class P, class KA = DwKArgs, bool PF = true, bool GE = false>
 __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D, int by_in, const PassCtx& cx) {
-  static_assert(P::kX2 && kDwTileX2, "the merged phase 2 exists for PrecX2 learners");
+  static_assert((P::kX2 || (GE && !P::kBf16)) && kDwTileX2, "the merged phase 2: PrecX2 learners; with the unit-seed rows (k_ddpg_chain) exact fp32 as well");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<256>;
   constexpr int HB = kR * kWL4;
@@ -1087,7 +1087,30 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   const unsigned mbits = (hv[0] > 0.f ? 1u : 0u) | (hv[1] > 0.f ? 2u : 0u) | (hv[2] > 0.f ? 4u : 0u) | (hv[3] > 0.f ? 8u : 0u) |
                          (m1 > 0.f ? 16u : 0u);
   stamp();   // rows and shard staged in LDS
-  if constexpr (GE) {
+  if constexpr (GE && !P::kX2) {
+    // ---- the same unit-seed rows in exact fp32: the A operand (h2 > 0) W3[j, :] formed per macro step from a 0 / 1
+    // mask tile and the row (4 multiplies), 64 v_mfma_f32_16x16x4_f32 per (tile, seed) wave — 2.6 us of the matrix pipe,
+    // inside the pass's wait for the critic's tiles
+    float* mS = h1;
+    *reinterpret_cast<f32x4*>(mS + hr * kWL4 + hc) = f32x4{(mbits & 1u) ? 1.f : 0.f, (mbits & 2u) ? 1.f : 0.f, (mbits & 4u) ? 1.f : 0.f, (mbits & 8u) ? 1.f : 0.f};
+    __syncthreads();                                         // mask tile, W2^T shard, W3 rows in LDS
+    const int t1 = wave & 1, j = wave >> 1;
+    if (j < Ad) {
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll 4
+      for (int sx = 0; sx < 16; ++sx) {
+        const f32x4 b4 = ld4(Wl + ((size_t)t1 * 16 + sx) * 256 + lane * 4);
+        const f32x4 a4 = ld4(mS + i * kWL4 + 16 * sx + 4 * kk) * ld4(w3s + j * 256 + 16 * sx + 4 * kk);
+        if (sx & 1) { mac4(a4, b4, acc1); } else { mac4(a4, b4, acc0); }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (row0 + 4 * kk + r < B)
+          A.gu[((size_t)j * B + row0 + 4 * kk + r) * kW4 + 32 * c + 16 * t1 + i] = gm1[r] > 0.f ? acc0[r] + acc1[r] : 0.f;
+    }
+    stamp();   // unit-seed rows requested out
+  }
+  if constexpr (GE && P::kX2) {
     // ---- unit-seed backward through the second hidden layer, this member's 32 columns of the first one's dY:
     //     G_j[b, k] = (h1[b, k] > 0) sum_n (h2[b, n] > 0) W3[j, n] W2[n, k]          (dz1 = sum_j du_j G_j)
     // The A operand (h2 > 0) W3[j, :] is a MASKED copy of one row for all 16 minibatch rows: the row is split into its
@@ -1184,7 +1207,7 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   }
   if constexpr (GE) { stamp(); return -1; }      // (the first layer's dY left as unit-seed rows before the pass: nothing follows du)
   // ---- the backward step through the second hidden layer, this member's 32 columns of the first one's dY
-  {
+  if constexpr (P::kX2 && !GE) {
     // g2[hr][hc ..] = (h2 > 0) sum_j du[hr][j] W3[j][hc ..] (wave = minibatch row hr; du once more from da and pi, both
     // in LDS since the pass: no exchange) -> h1 (the critic's buffers are free), each ROW scaled by the power of two
     // that brings its largest magnitude to [2^10, 2^11) — the fp16 split's range, as tp4_backward scales its tiles
@@ -1295,7 +1318,7 @@ __device__ __forceinline__ void chain_wait2(const unsigned long long* f0, int n0
 constexpr size_t kChainCOffset = (kWholeDaOffset + sizeof(DwKArgs4) + alignof(ChainArgs) - 1) / alignof(ChainArgs) * alignof(ChainArgs);
 template <class P>
 __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const DwKArgs4 Dc, const DwKArgs4 Da, const ChainArgs C_) {
-  static_assert(P::kX2 && kDwTileX2, "the chain launch exists for PrecX2 learners");
+  static_assert(!P::kBf16 && kDwTileX2, "the chain launch: the two parity arithmetics (split fp16, exact fp32)");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
   const DwKArgs4* Dcp = (const DwKArgs4*)(ka + kWholeDcOffset);
@@ -1541,7 +1564,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
     if (tile >= 0) {
       DwX2Ovr ov;
       ov.chain = &C; ov.u = u2;
-      dw_tile_x2<DwKArgs4>(*Dcp, smem, tile, 1, ov);
+      dw_tile_x2<DwKArgs4, P>(*Dcp, smem, tile, 1, ov);
     }
   }
   {
@@ -1567,7 +1590,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
       asm volatile("buffer_inv sc0" ::: "memory");
       DwX2Ovr ov;
       ov.chain = &C; ov.u = u3;
-      dw_tile_x2<DwKArgs4>(*Dap, smem, tile, 2, ov);
+      dw_tile_x2<DwKArgs4, P>(*Dap, smem, tile, 2, ov);
     }
   }
 }
@@ -1619,7 +1642,8 @@ hipError_t init_fused_attrs() {
                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecX2>),
                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecX2, true>),
                       reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecX2>),
-                      reinterpret_cast<const void*>(&k_ddpg_chain<PrecX2>)};
+                      reinterpret_cast<const void*>(&k_ddpg_chain<PrecX2>),
+                      reinterpret_cast<const void*>(&k_ddpg_chain<PrecF32>)};
   for (const void* k : ks) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -1717,7 +1741,7 @@ hipError_t launch_ddpg_phase2_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_
 // n_upd updates as one launch (k_ddpg_chain): `a` / `dc` / `da` with both gates filled in (the gates' tags = the FIRST
 // update's epoch), `c` = what changes per update
 hipError_t launch_ddpg_chain(const DdpgArgs& a, const DwKArgs4& dc, const DwKArgs4& da, const ChainArgs& c, hipStream_t st) {
-  if (!lean_ok(a) || a.sac || !a.x2 || !kDwTileX2 || a.n_critics != 1 || !a.whole || (a.merged & 3) != 3 || (a.wide & 3) != 3 ||
+  if (!lean_ok(a) || a.sac || a.bf16 || !kDwTileX2 || a.n_critics != 1 || !a.whole || (a.merged & 3) != 3 || (a.wide & 3) != 3 ||
       a.xnc < 8 || a.A > kDuLd || a.B > 256 || a.prefetch_next || a.prefetch_p1 || c.n_upd < 1 || c.n_upd > kChainMax)
     return hipErrorInvalidValue;
   const int slices = (a.B + kR - 1) / kR;
@@ -1727,7 +1751,8 @@ hipError_t launch_ddpg_chain(const DdpgArgs& a, const DwKArgs4& dc, const DwKArg
   const int rows = 16 + (mt > 8 * slices ? (mt - 8 * slices + slices - 1) / slices : 0);    // A 8 | B 4 | C 4 | T
   if (c.rows != rows) return hipErrorInvalidValue;
   const dim3 grid(slices, rows * c.n_upd);
-  hipLaunchKernelGGL((k_ddpg_chain<PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, dc, da, c);
+  if (a.x2) hipLaunchKernelGGL((k_ddpg_chain<PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, dc, da, c);
+  else hipLaunchKernelGGL((k_ddpg_chain<PrecF32>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, dc, da, c);
   return hipGetLastError();
 }
 

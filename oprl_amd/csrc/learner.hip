@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <string>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -439,6 +440,12 @@ struct oprl_learner {
   bool stale_wide = false;     // ... and are: only the critics' 512 x 512 layers' fp32 packs (the narrow layers' are current)
   float* uc_base = nullptr;    // the fp16 packs' uncached allocation (PrecX2 learners)
   bool uc_pool = false;        // the workspace pool is uncached memory as well
+  // exact-fp32 DDPG learners (fchain): the fused kernels' fp32 fragment packs are library-owned UNCACHED mirrors of the
+  // caller's pack arenas (same layout) — what k_ddpg_chain<PrecF32>'s tiles write, the next update's roles read without a
+  // kernel boundary; the caller's packs are rebuilt from the masters when something outside reads them (fresh32).
+  // fnet[0] = the actor, fnet[1] = the critic with pack / pack_target -> the mirrors (uc_base holds them)
+  bool fchain = false;
+  oprl_net fnet[2];
   // k_ddpg_chain (the whole update, several per launch): role C's / the critic tiles' flags, the critic's uncached bias copies
   unsigned long long* w_flags = nullptr;
   float* critic_b16 = nullptr;
@@ -465,6 +472,42 @@ struct oprl_learner {
 namespace {
 
 // learners with lazily maintained fp32 packs, by pack pointer (oprl_mlp_* know a net, not its learner)
+// Whole-update launches (k_ddpg_chain) take the whole chip for up to 32 updates.  Learners of one process that launch them
+// from different streams (one host thread per learner: the multi-seed layout) take TURNS: a launch waits for the event
+// behind the last whole-update launch of another stream — two such launches side by side would only hold each other's
+// compute units with waiting workgroups (bounded waits would expire).  Nothing is recorded while the process has one
+// learner (the headline path: no event, no barrier packet).
+struct ChipTurn {
+  std::mutex mu;
+  hipEvent_t ev[16] = {};
+  hipStream_t stream[16] = {};
+  bool rec[16] = {};
+};
+ChipTurn g_turn;
+std::atomic<int> g_live{0};
+
+hipError_t chip_turn_begin(hipStream_t st, int* dev_out) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  *dev_out = dev & 15;
+  if (g_turn.rec[*dev_out] && g_turn.stream[*dev_out] != st) return hipStreamWaitEvent(st, g_turn.ev[*dev_out], 0);
+  return hipSuccess;
+}
+void chip_turn_end(hipStream_t st, int dev) {
+  if (g_live.load() <= 1) { g_turn.rec[dev] = false; return; }
+  if (g_turn.ev[dev] == nullptr && hipEventCreateWithFlags(&g_turn.ev[dev], hipEventDisableTiming) != hipSuccess) { g_turn.ev[dev] = nullptr; return; }
+  if (hipEventRecord(g_turn.ev[dev], st) == hipSuccess) { g_turn.rec[dev] = true; g_turn.stream[dev] = st; }
+}
+
+// the net the fused kernels of `h` see (fchain: the one with the mirrored packs)
+const oprl_net& eff(const oprl_learner* h, const oprl_net& n) {
+  if (h->fchain) {
+    if (&n == &h->cfg.actor) return h->fnet[0];
+    if (&n == &h->cfg.critics[0]) return h->fnet[1];
+  }
+  return n;
+}
+
 std::mutex g_lazy_mu;
 std::vector<oprl_learner*> g_lazy;
 
@@ -649,7 +692,7 @@ MlpArgs base_args(oprl_learner* h, const oprl_net& n, bool target, int B) {
   }
   if (h->trace != nullptr && h->trace_slot < OPRL_TRACE_SLOTS)
     a.trace = h->trace + (size_t)(h->trace_slot++) * 64 * kTraceStamps * 2;
-  a.net = net_view(n, target);
+  a.net = net_view(eff(h, n), target);
   a.err = h->err_dev;
   if (h->bf16 || h->x2) {     // (the 16-bit packs of the net's layers: bf16, or two fp16 planes per block)
     int idx = -1;                                      // 0 = actor, 1 + j = critic j
@@ -922,10 +965,10 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   const oprl_learner_config& c = h->cfg;
   DdpgArgs a;
   memset(&a, 0, sizeof a);
-  a.actor = net_view(c.actor, false);
-  a.actor_t = net_view(c.actor, true);
-  a.critic = net_view(c.critics[0], false);
-  a.critic_t = net_view(c.critics[0], true);
+  a.actor = net_view(eff(h, c.actor), false);
+  a.actor_t = net_view(eff(h, c.actor), true);
+  a.critic = net_view(eff(h, c.critics[0]), false);
+  a.critic_t = net_view(eff(h, c.critics[0]), true);
   a.n_critics = h->nc;
   a.do_actor = 1;
   if (h->nc == 2) {      // TD3 / SAC: twin critic
@@ -1030,15 +1073,21 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   // (dp_inline: the gradient exchange inside the dW tiles — the 16 x 32 tiles of k_dw_adam<true> as launches of their own,
   // or, PrecX2 learners, the 16 x 64 tiles of the merged / whole-update launches themselves: dw_tile_x2.h)
   const bool inline_x2 = h->dp_inline && a.x2 && fused_x2_tiles() && h->nc == 1;
+  // exact-fp32 learners with mirrored packs: the whole update as k_ddpg_chain<PrecF32> when that form is possible at all
+  // (there is no merged phase 2 with the fp32 tiles on its own: with the whole form out of reach the two bits below stay
+  // what they were — merged phase 1 with role A on four, phase 2 and the actor's dW as launches)
+  const bool whole_f32 = h->fchain && fused_x2_tiles() && !a.x2 && !a.bf16 && !h->no_whole && !h->no_merge && !h->no_merge2 && !h->shared_chip &&
+                         !h->dp_inline && B <= 256 && fused_ddpg_is_lean(a) && (a.wide & 3) == 3 && h->chain_flags != nullptr &&
+                         chain_rows(h, B) * ((B + kR - 1) / kR) <= h->n_cus;
   if (!h->no_merge && !h->shared_chip && h->nc == 1 && !a.sac && B <= 256 && xport_ok && (!h->dp_inline || inline_x2) && fused_ddpg_is_lean(a)) {
     a.merged |= 1;
-    if (!(a.x2 && fused_x2_tiles())) a.wide &= ~1;     // (the 84 16 x 64 tiles of a PrecX2 learner get along with role A on eight)
+    if (!(a.x2 && fused_x2_tiles()) && !whole_f32) a.wide &= ~1;     // (the 84 16 x 64 tiles of a PrecX2 learner get along with role A on eight)
   }
   // ... and the ACTOR's tiles on phase 2 (DDPG / TD3: the tanh head, action_dim <= kDuLd): the tiles form their dY from
   // du, the first layer's comes from one more backward step of the critic pass's members (csrc/fused_ddpg.hip).
   // PrecX2 learners only, the pass on clusters of eight: with the exact-fp32 tiles the merged form measured no faster
   // than the two launches (34.9 vs 34.7 us)
-  if (!h->no_merge2 && !h->shared_chip && a.x2 && fused_x2_tiles() && h->du_granules != nullptr && !a.sac && B <= 256 && (!h->dp_inline || inline_x2) &&
+  if (!h->no_merge2 && !h->shared_chip && ((a.x2 && fused_x2_tiles()) || whole_f32) && h->du_granules != nullptr && !a.sac && B <= 256 && (!h->dp_inline || inline_x2) &&
       fused_ddpg_is_lean(a) && c.actor.theta_target != nullptr && (a.wide & 2) != 0) {
     a.merged |= 2;
     a.du_granules = h->du_granules;
@@ -1047,13 +1096,18 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   }
   // the whole update as ONE launch (k_ddpg_update): both merged forms, role A and the critic pass on eight, the 16 x 64
   // tiles, and everything the roles hand to each other in uncached memory
-  if (!h->no_whole && (!h->cfg.export_grads || inline_x2) && a.x2 && fused_x2_tiles() && h->nc == 1 && (a.merged & 3) == 3 && (a.wide & 3) == 3 && h->uc_pool &&
+  if (!h->no_whole && (!h->cfg.export_grads || inline_x2) && ((a.x2 && fused_x2_tiles()) || whole_f32) && h->nc == 1 && (a.merged & 3) == 3 && (a.wide & 3) == 3 && h->uc_pool &&
       h->uc_base != nullptr && h->w_flags != nullptr && h->chain_flags != nullptr &&
       chain_rows(h, B) * ((B + kR - 1) / kR) <= h->n_cus) {      // (one update's workgroups wait for each other: all must fit the chip)
     a.whole = 1;
     a.w_flags = h->w_flags;
     a.ct_done = h->w_flags + 64;
     for (int l = 0; l < c.critics[0].n_layers; ++l) a.critic_b16[l] = h->critic_b16 + 256 * l;
+  }
+  if (!a.x2 && (a.merged & 2) != 0 && !a.whole) {     // (exact fp32: no merged phase 2 outside the whole form)
+    a.merged &= ~2;
+    a.wide &= ~1;
+    a.du_granules = nullptr; a.g1_granules = nullptr; a.w3_snap = nullptr;
   }
   return a;
 }
@@ -1113,6 +1167,7 @@ DwArgs dw_build(oprl_learner* h, bool critic, int B, bool polyak, bool with_alph
     dw.skip32 = 1;
     h->stale32[critic ? 0 : 1] = true;
   }
+  if (h->fchain) h->stale32[critic ? 0 : 1] = true;   // (the tiles write the mirrors: the caller's packs fall behind)
   return dw;
 }
 
@@ -1293,7 +1348,14 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
         fa.trace2 = fa.trace != nullptr ? h->trace + (size_t)3 * 64 * kTraceStamps * 2 : nullptr;
         h->epoch += (unsigned)(U - 1);
         prof_begin(4, st);
-        hipError_t e = launch_ddpg_chain(fa, kc, ka, ca, st);
+        hipError_t e;
+        {
+          std::lock_guard<std::mutex> lk(g_turn.mu);
+          int dev = 0;
+          e = chip_turn_begin(st, &dev);
+          if (e == hipSuccess) e = launch_ddpg_chain(fa, kc, ka, ca, st);
+          if (e == hipSuccess) chip_turn_end(st, dev);
+        }
         prof_end(st);
         HIPC(e);
         h->whole_done = true;
@@ -2137,7 +2199,9 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   // PrecX2 learners: the workspace — activation exchange buffers, granules, staged rows — in UNCACHED device memory
   // (measured: no slower than cached, r03 log), so that a role of the whole-update launch reads what an earlier role
   // of the same launch wrote
-  const int uc_pool = h->x2 ? 1 : 0;
+  h->fchain = h->fused && !h->x2 && !h->bf16 && cfg->algo == OPRL_DDPG && nc == 1 && !cfg->export_grads && merge2_bufs &&
+              cfg->actor.theta_target != nullptr && cfg->critics[0].theta_target != nullptr && cfg->actor.n_layers == 3 && cfg->critics[0].n_layers == 3;
+  const int uc_pool = (h->x2 || h->fchain) ? 1 : 0;
   h->uc_pool = uc_pool != 0;
   if ((uc_pool ? uc_alloc((void**)&h->pool.base, bytes) : hipMalloc(&h->pool.base, bytes)) != hipSuccess) { set_err("hipMalloc(%zu) failed", bytes); delete h; return OPRL_ERR_NOMEM; }
   h->pool.cap = bytes;
@@ -2209,6 +2273,23 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
       h->pack16[1 + j] = take((size_t)net_pack16_floats(cfg->critics[j], 2));
       h->pack16_t[1 + j] = take((size_t)net_pack16_floats(cfg->critics[j], 2));
     }
+  } else if (h->fchain) {
+    // (the mirrors of the fp32 fragment packs: see oprl_learner::fchain)
+    const oprl_net* src[2] = {&h->cfg.actor, &h->cfg.critics[0]};
+    size_t fl = 0;
+    for (int k = 0; k < 2; ++k) fl += 2 * (((size_t)oprl_net_pack_floats(src[k]) + 63) & ~(size_t)63);
+    float* base = nullptr;
+    if (uc_alloc((void**)&base, fl * sizeof(float)) != hipSuccess) {
+      set_err("hipExtMallocWithFlags(uncached packs) failed"); dev_free(p.base); delete h; return OPRL_ERR_NOMEM;
+    }
+    (void)hipMemset(base, 0, fl * sizeof(float));
+    h->uc_base = base;
+    for (int k = 0; k < 2; ++k) {
+      const size_t n = ((size_t)oprl_net_pack_floats(src[k]) + 63) & ~(size_t)63;
+      h->fnet[k] = *src[k];
+      h->fnet[k].pack = base; base += n;
+      h->fnet[k].pack_target = base; base += n;
+    }
   } else
   if (h->bf16 || h->x2) {   // (the pool is zeroed: pad positions of the packs stay zero for good)
     h->pack16[0] = p.take<float>((size_t)net_pack16_floats(cfg->actor, h->planes));
@@ -2220,14 +2301,14 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   }
   std::vector<DwItem> items;
   for (int j = 0; j < nc; ++j)
-    fill_items(cfg->critics[j], h->ws_critic[j], items, &h->tiles_critic, h->fused, h->pack16[1 + j], h->pack16_t[1 + j], h->planes);
+    fill_items(eff(h, h->cfg.critics[j]), h->ws_critic[j], items, &h->tiles_critic, h->fused, h->pack16[1 + j], h->pack16_t[1 + j], h->planes);
   h->n_items_critic = (int)items.size();
   if (h->critic_b16 != nullptr && nc == 1)
     for (int l = 0; l < h->n_items_critic; ++l) {
       items[l].b16 = h->critic_b16 + 256 * l;
       items[l].bt16 = h->chain_b16 + (3 * kMaxLayers + l) * 256;
     }
-  fill_items(cfg->actor, h->ws_actor, items, &h->tiles_actor, h->fused, h->pack16[0], h->pack16_t[0], h->planes);
+  fill_items(eff(h, h->cfg.actor), h->ws_actor, items, &h->tiles_actor, h->fused, h->pack16[0], h->pack16_t[0], h->planes);
   h->n_items_actor = (int)items.size() - h->n_items_critic;
   if (h->chain_b16 != nullptr && nc == 1)
     for (int l = 0; l < h->n_items_actor; ++l) {
@@ -2341,13 +2422,18 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     for (int j = 0; j < nc; ++j) { p16[j] = h->pack16[1 + j]; p16t[j] = h->pack16_t[1 + j]; }
     p16[nc] = h->pack16[0]; p16t[nc] = h->pack16_t[0];
     int prc = repack_nets(nets, nc + 1, 3, nullptr, (h->bf16 || h->x2) ? p16 : nullptr, (h->bf16 || h->x2) ? p16t : nullptr, h->planes);
+    if (prc == OPRL_OK && h->fchain) {
+      const oprl_net* fn[2] = {&h->fnet[0], &h->fnet[1]};
+      prc = repack_nets(fn, 2, 3, nullptr);
+    }
     if (prc != OPRL_OK) { dev_free(p.base); delete h; return prc; }
   }
-  if (h->x2 || (h->bf16 && cfg->algo == OPRL_TQC)) {
+  if (h->x2 || h->fchain || (h->bf16 && cfg->algo == OPRL_TQC)) {
     std::lock_guard<std::mutex> lk(g_lazy_mu);
     g_lazy.push_back(h);
     h->lazy_wide = cfg->algo == OPRL_TQC;
   }
+  if (g_live.fetch_add(1) >= 1) (void)hipDeviceSynchronize();      // (from here on whole-update launches take turns: ChipTurn)
   *out = h;
   return OPRL_OK;
 }
@@ -2362,6 +2448,10 @@ extern "C" int oprl_learner_sync_params(oprl_learner* h, void* stream) {
   p16[h->nc] = h->pack16[0]; p16t[h->nc] = h->pack16_t[0];
   h->stale32[0] = h->stale32[1] = false;     // (every pack is rebuilt from the master here)
   h->stale_wide = false;
+  if (h->fchain) {
+    const oprl_net* fn[2] = {&h->fnet[0], &h->fnet[1]};
+    RC(repack_nets(fn, 2, 3, (hipStream_t)stream));
+  }
   return repack_nets(nets, h->nc + 1, 3, (hipStream_t)stream, (h->bf16 || h->x2) ? p16 : nullptr, (h->bf16 || h->x2) ? p16t : nullptr, h->planes);
 }
 
@@ -2385,6 +2475,7 @@ extern "C" int oprl_learner_destroy(oprl_learner* h) {
     g_lazy.erase(std::remove(g_lazy.begin(), g_lazy.end(), h), g_lazy.end());
   }
   (void)hipDeviceSynchronize();
+  g_live.fetch_sub(1);
   if (h->rccl.comm && h->rccl.comm_destroy) (void)h->rccl.comm_destroy(h->rccl.comm);
   if (h->xbuf) (void)hipFree(h->xbuf);
   if (h->tqc_counter) (void)hipFree(h->tqc_counter);

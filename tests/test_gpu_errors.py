@@ -80,14 +80,16 @@ def test_expired_hand_over_inside_the_hidden_layer_pair_launch_is_reported():
     assert bool(t.isfinite(algo.critic._oprl_arena).all()) and bool(t.isfinite(algo.actor._oprl_arena).all())
 
 
-def test_packed_learners_and_long_runs_stay_clean():
+@pytest.mark.parametrize("prec", ["f32", "x2"])
+def test_packed_learners_and_long_runs_stay_clean(prec):
     """Two learners driven from two host threads on two streams (the default multi-seed layout), 2000
-    updates each: no wait expires, every parameter stays finite."""
+    updates each: no wait expires, every parameter stays finite.  (Their whole-update launches — 32 updates, the whole
+    chip — take turns: ChipTurn in csrc/learner.hip.)"""
     import threading
     import bench
     replay = bench.make_replay(t.device("cuda", 0), seed=3)
     handle = replay.handle
-    algos = [_algo() for _ in range(2)]
+    algos = [_algo(precision=prec) for _ in range(2)]
     streams = [t.cuda.Stream() for _ in range(2)]
 
     def run(i):

@@ -142,9 +142,11 @@ def test_x2_out_of_range_inputs_raise_on_the_same_update(scale):
     assert all(t.isfinite(getattr(b, m)._oprl_arena).all() for m in ("actor", "critic"))
 
 
-@pytest.mark.parametrize("algo_name", ["ddpg", "td3"])
-def test_x2_launch_forms_agree(algo_name, monkeypatch):
-    """The three launch structures of a PrecX2 learner — whole updates, 20 per launch (k_ddpg_chain; DDPG), the two
+@pytest.mark.parametrize("algo_name,prec", [("ddpg", "x2"), ("td3", "x2"), ("ddpg", "f32")])
+def test_x2_launch_forms_agree(algo_name, prec, monkeypatch):
+    """(f32: the exact-fp32 DDPG learner takes the same three forms — k_ddpg_chain<PrecF32> with 16 x 64 fp32 tiles on
+    library-owned uncached mirrors of the fragment packs; "two" is then merged phase 1 + phase 2 + the actor's dW.)
+    The three launch structures of a PrecX2 learner — whole updates, 20 per launch (k_ddpg_chain; DDPG), the two
     merged launches (phase 1 + the critic's tiles | phase 2 + the actor's tiles), and the plain sequence with dW launches
     of their own — are the same arithmetic cut differently (the merged forms' 16 x 64 split-product tiles against the
     16 x 32 tiles' sums: last-bits differences): parameters after 20 step_n updates within 2e-6 of each other."""
@@ -156,7 +158,7 @@ def test_x2_launch_forms_agree(algo_name, monkeypatch):
         monkeypatch.setenv("OPRL_AMD_FORM", form)
         t.manual_seed(0)
         cls = getattr(importlib.import_module(f"oprl_amd.algos.{algo_name}"), algo_name.upper())
-        a = cls(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=256, precision="x2").create()
+        a = cls(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=256, precision=prec).create()
         buf = _filled_buffer(n_eps=8, L=120)
         a.learner.step_n(buf.handle, 20, 256, seed=3)
         t.cuda.synchronize()
