@@ -515,7 +515,7 @@ def main():
                          "its `exact_f32` / `bf16` blocks)")
     ap.add_argument("--group", type=int, default=32,
                     help="extra measurement: a LearnerGroup of this many learners stepped by one launch sequence")
-    ap.add_argument("--pre-warm", type=int, default=3000,
+    ap.add_argument("--pre-warm", type=int, default=20000,
                     help="untimed updates BEFORE the --warmup ones (GPU clock ramp, first touches): the driver's short "
                          "runs (--steps 20 --warmup 5) otherwise time the learner at ramping clocks, 5 %% low")
     ap.add_argument("--no-configs", action="store_true",
@@ -603,6 +603,8 @@ def measure(args, wd):
         def run(n):
             learner.step_n(replay.handle, n, B, seed=0)
         run(args.pre_warm)          # clock ramp / first-touch, before the W warm-up steps of the contract
+        for _ in range(3 if args.pre_warm > 0 else 0):
+            run(min(K, 32))         # (... and calls of the timed call's own shape: host-side first touches)
         run(W)
     else:
         from oprl_amd.parallel import DataParallelLearner
