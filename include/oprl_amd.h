@@ -250,6 +250,8 @@ int oprl_debug_noise(oprl_learner* h, int32_t stream_id, uint64_t counter, int32
 /* device pointer to the per-row Q / TD-target of the last critic step ([B] each,
  * critic 0), for parity tests. */
 int oprl_learner_debug_ptrs(oprl_learner* h, const float** q, const float** y);
+/* (debug) device views of what a fused DDPG update leaves in the workspace; `which` as listed at the definition */
+int oprl_learner_debug_view(oprl_learner* h, int32_t which, const void** ptr, int64_t* n_bytes);
 
 /* ---- building blocks (nn_models.py forward; used by Module.__call__) ----- */
 /* floats needed for ONE pack buffer of this net (dims only are read) */

@@ -94,6 +94,7 @@ SIGNATURES = {
     "oprl_debug_noise": (C.c_int, [_P, _I32, _U64, _I32, _I32, _P, _P]),
     "oprl_learner_set_seed": (C.c_int, [_P, _U64, _I32]),
     "oprl_learner_debug_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
+    "oprl_learner_debug_view": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "oprl_net_pack_floats": (_I64, [C.POINTER(OprlNet)]),
     "oprl_net_repack": (C.c_int, [C.POINTER(OprlNet), _I32, _P]),
     "oprl_learner_sync_params": (C.c_int, [_P, _P]),

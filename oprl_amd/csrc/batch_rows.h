@@ -66,10 +66,13 @@ __device__ __forceinline__ void load_batch(const BatchSrc& P, int row0, int B, i
 
 // The next update's rows, gathered by one workgroup per 16-row slice and left as plain rows in N.s / a / r / d / s2.
 // smem: 2 * kR * kX0Ld + 96 + kMaxEnds floats.  (PrefetchJob: kernels.h)
+// (WT: the rows are read by workgroups of the SAME launch behind a flag — k_ddpg_chain: written through)
+template <bool WT = false>
 __device__ __forceinline__ void prefetch_rows_src(const BatchSrc& N, int S, int Ad, int B, int slice, float* smem);
 __device__ __forceinline__ void prefetch_rows_body(const PrefetchJob& J, int slice, float* smem) {
   prefetch_rows_src(J.next, J.S, J.A, J.B, slice, smem);
 }
+template <bool WT>
 __device__ __forceinline__ void prefetch_rows_src(const BatchSrc& N, int S, int Ad, int B, int slice, float* smem) {
   const int tid = threadIdx.x, row0 = slice * kR;
   float* xa = smem;
@@ -80,6 +83,16 @@ __device__ __forceinline__ void prefetch_rows_src(const BatchSrc& N, int S, int 
   int* endsS = reinterpret_cast<int*>(rS + 96);
   load_batch(N, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
   __syncthreads();
+  if constexpr (WT) {
+    store_rows_wt(xa, kX0Ld, const_cast<float*>(N.s), S, S, row0, B);
+    store_rows_wt(xb, kX0Ld, const_cast<float*>(N.s2), S, S, row0, B);
+    store_rows_wt(xa + S, kX0Ld, const_cast<float*>(N.a), Ad, Ad, row0, B);
+    if (tid < kR && row0 + tid < B) {
+      __hip_atomic_store(const_cast<float*>(N.r) + row0 + tid, rS[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(const_cast<float*>(N.d) + row0 + tid, dS[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   store_rows(xa, kX0Ld, const_cast<float*>(N.s), S, S, row0, B);
   store_rows(xb, kX0Ld, const_cast<float*>(N.s2), S, S, row0, B);
   for (int idx = tid; idx < kR * Ad; idx += kThreads) {

@@ -42,6 +42,18 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ float ld_ag(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_ag(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16- / 8-byte stores WRITTEN THROUGH (engine.h st16_agent): what a tile hands to readers of the SAME launch — packs, bias
+// copies, the output layer's rows — is acknowledged by memory, not by this XCD's L2, before the tile's flag goes up
+template <class V16>
+__device__ __forceinline__ void st16_wt(void* p, const V16 v) {
+  static_assert(sizeof(V16) == 16, "16-byte vector");
+  st16_agent(p, __builtin_bit_cast(f32x4, v));
+}
+template <class V8>
+__device__ __forceinline__ void st8_wt(void* p, const V8 v) {
+  static_assert(sizeof(V8) == 8, "8-byte vector");
+  st8_agent(p, __builtin_bit_cast(unsigned long long, v));
+}
 
 struct DwX2Lds {   // floats
   // minibatch extent of a transposed row, padded such that the compute lanes' b128 reads (16 rows i, 16 bytes each)
@@ -537,7 +549,7 @@ struct DwX2Tile {
       if (polyak) st_ag(I.w_t + eo, tt_new);
     }
     // (the actor's output layer, row-major, for whoever reads it in the next update of this launch)
-    if (chained && gate == 2 && kind == 0) ov.chain->w3buf[(ov.u + 1) & 1][eo] = th;
+    if (chained && gate == 2 && kind == 0) st_ag(ov.chain->w3buf[(ov.u + 1) & 1] + eo, th);
   }
   tileW[nl * LDT + kl] = th_new;      // (the dY area: every wave is past its MFMAs)
   tileT[nl * LDT + kl] = tt_new;
@@ -552,14 +564,14 @@ struct DwX2Tile {
     mm = mm + (gb - mm) * ad.omb1;
     vv = vv * ad.beta2 + ad.omb2 * gb * gb;
     th = th - step_size * (mm / (sqrtf(vv) / bc2_sqrt + ad.eps));
-    if (I.b16 != nullptr) I.b16[n] = th;      // (uncached copy for readers inside the same launch)
+    if (I.b16 != nullptr) st_ag(I.b16 + n, th);      // (uncached copy for readers inside the same launch)
     st_ag(I.b_m + n, mm);
     st_ag(I.b_v + n, vv);
     st_ag(I.b + n, th);
     if (b_pol) {
       const float tb = q_tt * ad.omtau + ad.tau * th;
       st_ag(I.b_t + n, tb);
-      if (I.bt16 != nullptr) I.bt16[n] = tb;
+      if (I.bt16 != nullptr) st_ag(I.bt16 + n, tb);
     }
   }
   __syncthreads();       // the updated tile is staged
@@ -577,14 +589,14 @@ struct DwX2Tile {
       if (grp3 < 2) {
         float* dst = grp3 == 0 ? I.pf : (polyak ? I.tpf : nullptr);
         if (dst != nullptr && 4 * tk + j < NSk && !(flagged && grp3 == 1))
-          *reinterpret_cast<f32x4*>(dst + (((size_t)ptile * NSk + 4 * tk + j) * 64 + l) * 4) = ld4((grp3 == 0 ? tileW : tileT) + li * LDT + 16 * j + 4 * lk);
+          st16_wt(dst + (((size_t)ptile * NSk + 4 * tk + j) * 64 + l) * 4, ld4((grp3 == 0 ? tileW : tileT) + li * LDT + 16 * j + 4 * lk));
       } else if (grp3 == 2 && I.pb != nullptr) {
         const int ktile = 4 * tk + j;
         if (16 * ktile < I.K) {
           f32x4 w4;
 #pragma unroll
           for (int t = 0; t < 4; ++t) w4[t] = tileW[(4 * lk + t) * LDT + 16 * j + li];
-          *reinterpret_cast<f32x4*>(I.pb + (((size_t)ktile * NSn + ptile) * 64 + l) * 4) = w4;
+          st16_wt(I.pb + (((size_t)ktile * NSn + ptile) * 64 + l) * 4, w4);
         }
       }
     }
@@ -600,8 +612,8 @@ struct DwX2Tile {
         f16x8 hi, lo;
         x2_split8(ld4(src + 4 * lk) * PrecX2::kWScale, ld4(src + 16 + 4 * lk) * PrecX2::kWScale, hi, lo);
         float* d = dst + ((size_t)ptile * NSk2 + 2 * tk + hb) * 512 + (size_t)l * 4;
-        *reinterpret_cast<f16x8*>(d) = hi;
-        *reinterpret_cast<f16x8*>(d + 256) = lo;
+        st16_wt(d, hi);
+        st16_wt(d + 256, lo);
       }
     } else if (tid < 512 && I.pb16 != nullptr) {
       const int q = tid - 256, blk = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
@@ -614,8 +626,8 @@ struct DwX2Tile {
         const f16x4 hi = __builtin_convertvector(vs, f16x4);
         const f32x4 r = vs - __builtin_convertvector(hi, f32x4);
         float* d = I.pb16 + ((size_t)ktile * NSn2 + (n_base >> 5)) * 512 + (size_t)l * 4 + 2 * ((n_base >> 4) & 1);
-        *reinterpret_cast<f16x4*>(d) = hi;
-        *reinterpret_cast<f16x4*>(d + 256) = __builtin_convertvector(r, f16x4);
+        st8_wt(d, hi);
+        st8_wt(d + 256, __builtin_convertvector(r, f16x4));
       }
     }
   }
@@ -635,7 +647,7 @@ struct DwX2Tile {
         const int NSk = cdiv(I.K, 16);
         const int q = tid & 255, j = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
         if (4 * tk + j < NSk)
-          *reinterpret_cast<f32x4*>(I.tpf + (((size_t)ptile * NSk + 4 * tk + j) * 64 + l) * 4) = ld4(tileT + li * LDT + 16 * j + 4 * lk);
+          st16_wt(I.tpf + (((size_t)ptile * NSk + 4 * tk + j) * 64 + l) * 4, ld4(tileT + li * LDT + 16 * j + 4 * lk));
       }
     }
     if (P::kX2 && I.pf16 != nullptr && polyak && I.tpf16 != nullptr && tid >= 128 && tid < 256) {
@@ -646,8 +658,8 @@ struct DwX2Tile {
         f16x8 hi, lo;
         x2_split8(ld4(src + 4 * lk) * PrecX2::kWScale, ld4(src + 16 + 4 * lk) * PrecX2::kWScale, hi, lo);
         float* d = I.tpf16 + ((size_t)ptile * NSk2 + 2 * tk + hb) * 512 + (size_t)l * 4;
-        *reinterpret_cast<f16x8*>(d) = hi;
-        *reinterpret_cast<f16x8*>(d + 256) = lo;
+        st16_wt(d, hi);
+        st16_wt(d + 256, lo);
       }
     }
   }

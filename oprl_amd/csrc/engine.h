@@ -122,6 +122,20 @@ __device__ __forceinline__ f32x4 ld4_agent(const float* base, unsigned float_off
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, float_off * 4u, 0, 16 /* sc1 */));
 }
 
+// 16- / 8-byte stores WRITTEN THROUGH (agent scope: sc1) as stores the COMPILER sees — 64-bit atomic stores.  (The same
+// thing as `global_store_dwordx4 ... sc1` in inline asm is invisible to hipcc's hazard recogniser: a vector-memory store of
+// more than 64 bits reads its data registers late, and a following VALU write of those registers needs a wait state the
+// compiler only inserts for stores it knows — the first dword of a 16-byte store came out wrong now and then, r04-18.)
+__device__ __forceinline__ void st16_agent(void* p, const f32x4 v) {
+  typedef unsigned long long u64x2_st __attribute__((ext_vector_type(2)));
+  const u64x2_st q = __builtin_bit_cast(u64x2_st, v);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p) + 1, q[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st8_agent(void* p, unsigned long long v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct PrecF32 {
   static constexpr int KS = 16;
   __device__ static __forceinline__ bool range_ok(float) { return true; }   // (PrecX2's forward range check: nothing to check here)
@@ -477,6 +491,16 @@ __device__ __forceinline__ void store_rows(const float* __restrict__ Xs, int ldx
     const int row = idx / k, col = idx - row * k;
     const int gr = row0 + row;
     if (gr < B) G[(size_t)gr * ldg + col] = Xs[row * ldx + col];
+  }
+}
+
+// ... written through (agent-scope stores): rows a workgroup of the SAME launch reads behind a flag
+__device__ __forceinline__ void store_rows_wt(const float* __restrict__ Xs, int ldx,
+                                              float* __restrict__ G, int ldg, int k, int row0, int B) {
+  for (int idx = threadIdx.x; idx < kR * k; idx += kThreads) {
+    const int row = idx / k, col = idx - row * k;
+    const int gr = row0 + row;
+    if (gr < B) __hip_atomic_store(G + (size_t)gr * ldg + col, Xs[row * ldx + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

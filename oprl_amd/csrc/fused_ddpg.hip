@@ -1106,7 +1106,7 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (row0 + 4 * kk + r < B)
-          A.gu[((size_t)j * B + row0 + 4 * kk + r) * kW4 + 32 * c + 16 * t1 + i] = gm1[r] > 0.f ? acc0[r] + acc1[r] : 0.f;
+          st_ag(A.gu + ((size_t)j * B + row0 + 4 * kk + r) * kW4 + 32 * c + 16 * t1 + i, gm1[r] > 0.f ? acc0[r] + acc1[r] : 0.f);
     }
     stamp();   // unit-seed rows requested out
   }
@@ -1164,7 +1164,7 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (row0 + 4 * kk + r < B)
-          A.gu[((size_t)j * B + row0 + 4 * kk + r) * kW4 + 32 * c + 16 * t1 + i] = gm1[r] > 0.f ? acc[r] * un : 0.f;
+          st_ag(A.gu + ((size_t)j * B + row0 + 4 * kk + r) * kW4 + 32 * c + 16 * t1 + i, gm1[r] > 0.f ? acc[r] * un : 0.f);
     }
     stamp();   // unit-seed rows requested out
   }
@@ -1507,19 +1507,21 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   } else if (role == 2) {
     // ---- role C: actor(s) forward, pi = tanh(.) and the activations for the actor's tiles / the critic pass
     Tp tp{member, 4, A.xbuf + ((size_t)2 * slices + slice) * kTpStages * A.xnc * kTpBlk, tag1, 0, A.err, KERN_PHASE1 << 8, spin};
-    const Tp3Store st{A.aX[1], A.aX[2], nullptr, nullptr, 0};
+    // (everything role C leaves is read by workgroups of this launch — the critic pass, the actor's tiles — behind its
+    // flags: written through)
+    const Tp3Store st{A.aX[1], A.aX[2], nullptr, nullptr, 0, 0, true};
     tp4_forward<P>(A.actor, xa, h1, h2, outS, scr, tp, st, row0, B, stamp, bias_of(0));
     if (lead) {
       for (int idx = tid; idx < kR * Ad; idx += kThreads) {
         const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
-        if (gr < B) A.pi[(size_t)gr * Ad + col] = tanhf(outS[row * kOutLd + col]);
+        if (gr < B) st_ag(A.pi + (size_t)gr * Ad + col, tanhf(outS[row * kOutLd + col]));
       }
-      store_rows(xa, kX0Ld, A.aX[0], A.aldx0, S, row0, B);
+      store_rows_wt(xa, kX0Ld, A.aX[0], A.aldx0, S, row0, B);
       // update 0: the row-major output layer as the launch before left it -> w3buf[0] (later updates: the output
       // layer's tiles of the update before wrote w3buf[parity] themselves)
       if (u == 0 && slice == 0)
         for (int idx = tid * 4; idx < Ad * kW4; idx += kThreads * 4)
-          *reinterpret_cast<f32x4*>(C.w3buf[0] + idx) = ld4(A.w3_src + idx);
+          st16_wt(C.w3buf[0] + idx, ld4(A.w3_src + idx));
     }
     stamp();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1548,7 +1550,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
       nx.s = par2 ? C.set0[0] : C.set1[0]; nx.a = par2 ? C.set0[1] : C.set1[1]; nx.r = par2 ? C.set0[2] : C.set1[2];
       nx.d = par2 ? C.set0[3] : C.set1[3]; nx.s2 = par2 ? C.set0[4] : C.set1[4];
       nx.counter = A.next.counter + (unsigned long long)u2;
-      prefetch_rows_src(nx, A.S, A.A, A.B, p, smem);
+      prefetch_rows_src<true>(nx, A.S, A.A, A.B, p, smem);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0)

@@ -3113,6 +3113,36 @@ extern "C" int oprl_learner_debug_ptrs(oprl_learner* h, const float** q, const f
   return OPRL_OK;
 }
 
+// (debug) device views of the workspace a fused DDPG update leaves behind: tools/race_hunt.py compares them between a
+// chain learner and a one-update-per-launch learner.  which: 0..2 the actor's X rows, 3 pi, 4 unit-seed rows, 5 du granules
+// (8 bytes each), 6..8 the critic's X rows, 9 / 10 the critic's dY rows (first hidden partials | second hidden), 11 the TD
+// seed granules, 12 the batch rows of the last update's set (s), 13 the other set
+extern "C" int oprl_learner_debug_view(oprl_learner* h, int32_t which, const void** ptr, int64_t* n_bytes) {
+  if (!h || !ptr || !n_bytes) { set_err("oprl_learner_debug_view: invalid argument"); return OPRL_ERR_INVALID; }
+  const size_t B = (size_t)h->Bmax;
+  const void* p = nullptr;
+  size_t n = 0;
+  switch (which) {
+    case 0: p = h->ws_actor.X[0]; n = B * h->ws_actor.ldx0 * 4; break;
+    case 1: p = h->ws_actor.X[1]; n = B * h->ws_actor.width * 4; break;
+    case 2: p = h->ws_actor.X[2]; n = B * h->ws_actor.width * 4; break;
+    case 3: p = h->pi; n = B * h->A * 4; break;
+    case 4: p = h->gu; n = h->gu ? (size_t)h->A * (B < 256 ? B : 256) * 256 * 4 : 0; break;
+    case 5: p = h->du_granules; n = h->du_granules ? (B < 256 ? B : 256) * kDuLd * 8 : 0; break;
+    case 6: p = h->ws_critic[0].X[0]; n = B * h->ws_critic[0].ldx0 * 4; break;
+    case 7: p = h->ws_critic[0].X[1]; n = B * h->ws_critic[0].width * 4; break;
+    case 8: p = h->ws_critic[0].X[2]; n = B * h->ws_critic[0].width * 4; break;
+    case 9: p = h->ws_critic[0].dY[0]; n = B * h->ws_critic[0].width * 4; break;
+    case 10: p = h->ws_critic[0].dY[1]; n = B * h->ws_critic[0].width * 4; break;
+    case 11: p = h->y_granules; n = B * 8; break;
+    case 12: p = h->bs; n = B * h->S * 4; break;
+    case 13: p = h->batch_alt; n = h->batch_alt ? B * h->S * 4 : 0; break;
+    default: set_err("oprl_learner_debug_view: no such view"); return OPRL_ERR_INVALID;
+  }
+  *ptr = p; *n_bytes = (int64_t)n;
+  return OPRL_OK;
+}
+
 // ---------------------------------------------------------------- building blocks
 namespace {
 struct TmpBuf {  // small per-thread device scratch for the stand-alone MLP calls

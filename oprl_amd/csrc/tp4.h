@@ -227,7 +227,7 @@ __device__ __forceinline__ void tp4_allreduce_narrow(const f32x4 mine, int i_fir
 
 // a 16-byte store of what k_dw_adam reads: plain, or written through (Tp3Store::wt)
 __device__ __forceinline__ void tp4_st4(float* p, const f32x4 v, bool wt) {
-  if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+  if (wt) st16_agent(p, v);
   else *reinterpret_cast<f32x4*>(p) = v;
 }
 

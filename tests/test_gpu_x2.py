@@ -174,3 +174,36 @@ def test_x2_launch_forms_agree(algo_name, prec, monkeypatch):
         d2 = float((two[m] - plain[m]).abs().max()) / scale
         print(f"{algo_name} {m}: whole vs two launches {d1:.2e}, two launches vs plain {d2:.2e}")
         assert d1 < 2e-6 and d2 < 2e-6, (m, d1, d2)
+
+
+@pytest.mark.parametrize("prec", ["x2", "f32"])
+def test_chain_launches_equal_one_update_launches_bitwise(prec, monkeypatch):
+    """k_ddpg_chain (several updates per launch, roles of update u + 1 behind the flags of update u) against the same
+    kernel with ONE update per launch (OPRL_AMD_CHAIN=1: a kernel boundary between updates): the same arithmetic, so the
+    same bits — over many short calls that each start on an idle GPU, where hand-over races showed (r04-18: inline-asm
+    write-through stores whose data registers were reused a wait state early; one event in some thousand updates)."""
+    from oprl_amd.algos.ddpg import DDPG
+    from oprl_amd.logging import NullLogger
+    from tests.test_gpu_callers import _filled_buffer
+    buf = _filled_buffer()
+
+    def make(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        t.manual_seed(0)
+        a = DDPG(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=256, precision=prec).create()
+        for k in env:
+            monkeypatch.delenv(k)
+        return a
+
+    ref, chain = make({"OPRL_AMD_CHAIN": "1"}), make({})
+    for c in range(160):
+        K = (33, 4, 7, 20)[c % 4]
+        chain.learner.step_n(buf.handle, K, 256, seed=21 + c)
+        t.cuda.synchronize()
+        ref.learner.step_n(buf.handle, K, 256, seed=21 + c)
+        t.cuda.synchronize()
+        for m in ("actor", "critic", "actor_target", "critic_target"):
+            assert t.equal(getattr(ref, m)._oprl_arena, getattr(chain, m)._oprl_arena), (c, K, m)
+    ref.learner.check()
+    chain.learner.check()

@@ -46,3 +46,23 @@ def test_no_instruction_touches_an_inline_asm_loads_result_before_its_wait(tmp_p
     # __builtin_amdgcn_raw_buffer_load_b128, engine.h ld4_agent — and the sc1 loads must still be there)
     text = "".join(o.read_text() for o in outs)
     assert text.count("buffer_load_dwordx4") > 0 and " sc1" in text
+
+
+def test_no_vector_memory_instruction_is_written_as_inline_asm():
+    """Round 4 (profiles/r04_experiments.txt r04-18): `global_store_dwordx4 ... sc1` as inline asm — how the role
+    workgroups wrote the rows their tile workgroups read — is invisible to hipcc's hazard recogniser: a vector-memory store
+    of more than 64 bits reads its data registers late and a VALU write of those registers right behind it needs a wait
+    state the compiler only inserts for stores it knows.  Under memory back-pressure the first dword of such a store came
+    out wrong (one event in some thousand updates; bit-identical runs diverged).  Loads had the mirror problem (above).
+    Every vector-memory access of the kernels is therefore a builtin the compiler sees; inline asm is for waits, cache
+    invalidates and scheduling fences only."""
+    import re
+    bad = []
+    for src in sorted((ROOT / "oprl_amd" / "csrc").glob("*")):
+        if src.suffix not in (".h", ".hip"):
+            continue
+        for n, line in enumerate(src.read_text().splitlines(), 1):
+            code = line.split("//")[0]
+            if "asm" in code and re.search(r'"\s*(global|buffer|flat|scratch|ds)_(load|store|atomic|read|write)', code):
+                bad.append(f"{src.name}:{n}: {line.strip()}")
+    assert not bad, "\n".join(bad)
