@@ -15,7 +15,9 @@ from oprl_amd.logging import NullLogger
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 prec = sys.argv[2] if len(sys.argv) > 2 else "x2"      # the arithmetic mode of every learner of the run
-CASES = [("DDPG B=256", DDPG, 256, 300_000, {}), ("DDPG B=512 (over-subscribed grid)", DDPG, 512, 100_000, {}),
+CASES = [("DDPG B=256", DDPG, 256, 300_000, {}),
+         # (every call starts on an idle GPU: where hand-over races of the several-updates launch showed, r04-18)
+         ("DDPG B=256, short idle-start calls", DDPG, 256, 60_000, dict(_calls=(33, 4, 7, 20, 500))), ("DDPG B=512 (over-subscribed grid)", DDPG, 512, 100_000, {}),
          ("TD3 B=256", TD3, 256, 300_000, dict(log_every=10 ** 9)),
          ("SAC B=256 tuned alpha", SAC, 256, 300_000, dict(log_every=10 ** 9, tune_alpha=True)),
          ("SAC B=1024", SAC, 1024, 50_000, dict(log_every=10 ** 9)),
@@ -28,12 +30,18 @@ for name, cls, B, n, kw in CASES:
     t0 = time.perf_counter()
     for rep in range(2):
         t.manual_seed(0)
-        algo = cls(logger=NullLogger(), state_dim=bench.S, action_dim=bench.A, device="cuda", max_batch=B, precision=prec, **kw).create()
+        calls = kw.get("_calls")
+        algo = cls(logger=NullLogger(), state_dim=bench.S, action_dim=bench.A, device="cuda", max_batch=B, precision=prec,
+                   **{k_: v_ for k_, v_ in kw.items() if not k_.startswith("_")}).create()
         done = 0
+        c = 0
         while done < n:
-            k = min(20_000, n - done)
+            k = min(20_000 if calls is None else calls[c % len(calls)], n - done)
             algo.learner.step_n(replay.handle, k, B, seed=7)
+            if calls is not None:
+                t.cuda.synchronize()
             done += k
+            c += 1
         t.cuda.synchronize()
         arenas = [algo.actor._oprl_arena, algo.critic._oprl_arena]
         finite = all(bool(t.isfinite(a).all()) for a in arenas)
