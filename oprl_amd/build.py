@@ -21,7 +21,8 @@ OBJ = HERE / "lib" / "obj"
 # without them).  OPRL_AMD_TRACE=1 makes _capi load this one.
 OUT_TRACE = HERE / "lib" / "liboprl_amd_trace.so"
 OBJ_TRACE = HERE / "lib" / "obj_trace"
-SOURCES = ["kernels.hip", "fused_ddpg.hip", "slice_tp.hip", "layerwise.hip", "dw_wide.hip", "p2p.hip", "replay.hip", "policy_act.hip", "learner.hip"]
+SOURCES = ["kernels.hip", "fused_ddpg.hip", "slice_tp.hip", "layerwise.hip", "dw_wide.hip", "p2p.hip", "replay.hip", "policy_act.hip", "learner.hip",
+           "learner_create.hip", "learner_dp.hip", "learner_group.hip", "learner_misc.hip"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-ldl"]
 

@@ -6,24 +6,7 @@
 // loss sees the post-Adam critic, Polyak sees both updated nets):
 //   DDPG  algos/ddpg.py:61-107      TD3  algos/td3.py:71-146
 //   SAC   algos/sac.py:75-155       TQC  algos/tqc.py:116-189
-#include <algorithm>
-#include <chrono>
-#include <dlfcn.h>
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include <stdarg.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include <string>
-#include <atomic>
-#include <mutex>
-#include <vector>
-
-#include "../../include/oprl_amd.h"
-#include "kernels.h"
-#include "p2p.h"
+#include "learner_internal.h"
 
 namespace oprl {
 
@@ -80,396 +63,9 @@ void prof_end(hipStream_t st) {
   (void)hipEventRecord(g_prof.ev.back(), st);
 }
 
-// (Learners that share a GPU: the fused phase kernels contain bounded cross-workgroup waits that rely on a launch's
-// workgroups becoming resident together.  An event chain that serialised the phase launches of all learners of a process
-// was measured in round 1 — 8 packed learners 45k -> 17.7k steps/s — and removed in round 3; what protects such runs is
-// the clusters-of-four setting (oprl_learner_set_cluster, runners/train.py) and bench.py's verified multi_learner run.)
-size_t mlp_slice_lds_bytes(int width, int n_layers);
-hipError_t launch_mlp_slice(const MlpArgs& a, int width, hipStream_t st);
-hipError_t launch_mlp_slice_multi(const MlpArgs* a, int n, int width, hipStream_t st);
-bool mlp_layerwise_ok(const MlpArgs* a, int n, int width);
-hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, int prec, const TqcJob* job,
-                                const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, int tail_prec,
-                                const PrefetchJob* prefetch, const LwPairBuf* pairs);
-bool mlp_layerwise_fin_ok(const MlpArgs* a, int n, int width);
-int mlp_layerwise_fin_fit(const MlpArgs* a, int n, int host_wgs, int n_cus);
-hipError_t launch_slice_tp_with_fin(const MlpArgs& host, const MlpArgs* a, int n, int n_ride, int width, int n_cus, hipStream_t st,
-                                    int prec);
-hipError_t launch_mlp_layerwise_first(const MlpArgs* t, int t_n, int t0, int width, int n_cus, hipStream_t st, int prec);
-bool mlp_layerwise_rider_ok(const MlpArgs* a, int n, const MlpArgs& rider, int n_cus);
-hipError_t init_layerwise_attrs();
-hipError_t launch_mlp_slice_tp(const MlpArgs& a, hipStream_t st);
-hipError_t launch_mlp_slice_tp2(const MlpArgs& a0, const MlpArgs& a1, int n_cus, hipStream_t st);
-hipError_t init_slice_tp_attrs();
-bool mlp_slice_tp_shape_ok(const MlpArgs& a, int width);
-hipError_t init_kernel_attrs();
-hipError_t launch_dw_adam(const DwArgs& a, hipStream_t st);
-hipError_t launch_repack(const RepackItem* items_dev, int n_items, int total_blocks, hipStream_t st);
-hipError_t launch_adam_flat(float* th, float* m, float* v, float* tt, const float* g, long n,
-                            const AdamScalars& ad, hipStream_t st);
-hipError_t launch_polyak_flat(float* tt, const float* th, long n, double tau, hipStream_t st);
-hipError_t launch_alpha_step(double* log_alpha, double* m, double* v, const float* logp, int B,
-                             float target_entropy, double lr, double beta1, double beta2, double eps,
-                             int step, double* grad_out, const double* grad_in, float grad_scale,
-                             hipStream_t st);
-hipError_t launch_reduce_partials(const float* partials, int n_slices, float* out, int out_off,
-                                  float scale_loss, float scale_mean, hipStream_t st);
-hipError_t launch_sum(const float* x, int n, float* out, int out_off, float scale, hipStream_t st);
-hipError_t launch_tqc_target(const float* z, long net_stride, int ldz, int n_nets, int Q, int drop,
-                             const float* r, const float* d, const float* logp,
-                             const double* log_alpha, float gamma, int B, float* target,
-                             hipStream_t st);
-int replay_dims(const oprl_replay* h, int* S, int* A);
-int replay_view(const oprl_replay* h, const float** states, const float** actions,
-                const float** rewards, const float** dones, const int** ends, int* n_eps, int* L,
-                long* n_transitions);
-hipError_t launch_debug_normal(unsigned long long seed, unsigned long long ctr, int rows, int cols, float* out,
-                               hipStream_t st);
-hipError_t init_fused_attrs();
-size_t fused_xbuf_granules_per_cluster(int nc);
-hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st);
-hipError_t launch_ddpg_phase1_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st);
-bool fused_ddpg_is_lean(const DdpgArgs& a);
-hipError_t launch_ddpg_phase2(const DdpgArgs& a, hipStream_t st);
-hipError_t launch_ddpg_phase2_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st);
-hipError_t launch_ddpg_chain(const DdpgArgs& a, const DwKArgs4& dc, const DwKArgs4& da, const ChainArgs& c, hipStream_t st);
-hipError_t launch_ddpg_phase1_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
-hipError_t launch_ddpg_phase2_group(const DdpgArgs& a0, const DdpgArgs* batch_dev, int n, hipStream_t st);
-int fill_dw_kargs(const DwArgs& a, DwKArgs* k, int tile_k = 32);
-bool fused_x2_tiles();
-hipError_t launch_dw_adam_group(const void* batch_dev, int ni, int n, int tiles, hipStream_t st);
-int compact_dw_kargs(const DwKArgs& k, void* o, int ni);
-size_t dw_group_block_bytes(int ni);
-
 }  // namespace oprl
 
-using namespace oprl;
-
-// ---- minimal run-time binding of RCCL (NCCL API; enum values are the API's) ----
-namespace {
-struct NcclId { char internal[OPRL_COMM_ID_BYTES]; };
-typedef int (*fn_get_unique_id)(NcclId*);
-typedef int (*fn_comm_init_rank)(void**, int, NcclId, int);
-typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
-typedef int (*fn_broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t);
-typedef int (*fn_comm_destroy)(void*);
-typedef const char* (*fn_get_error_string)(int);
-constexpr int kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0;
-
-struct Rccl {
-  void* lib = nullptr;
-  fn_get_unique_id get_unique_id = nullptr;
-  fn_comm_init_rank comm_init_rank = nullptr;
-  fn_all_reduce all_reduce = nullptr;
-  fn_broadcast broadcast = nullptr;
-  fn_comm_destroy comm_destroy = nullptr;
-  fn_get_error_string err_str = nullptr;
-  void* comm = nullptr;
-  int rank = 0, world = 1;
-};
-
-int rccl_bind(Rccl& r, const char* path) {
-  if (r.lib) return OPRL_OK;
-  r.lib = dlopen(path && path[0] ? path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!r.lib) { set_err("dlopen(%s) failed: %s", path ? path : "librccl.so", dlerror()); return OPRL_ERR_INVALID; }
-  r.get_unique_id = (fn_get_unique_id)dlsym(r.lib, "ncclGetUniqueId");
-  r.comm_init_rank = (fn_comm_init_rank)dlsym(r.lib, "ncclCommInitRank");
-  r.all_reduce = (fn_all_reduce)dlsym(r.lib, "ncclAllReduce");
-  r.broadcast = (fn_broadcast)dlsym(r.lib, "ncclBroadcast");
-  r.comm_destroy = (fn_comm_destroy)dlsym(r.lib, "ncclCommDestroy");
-  r.err_str = (fn_get_error_string)dlsym(r.lib, "ncclGetErrorString");
-  if (!r.get_unique_id || !r.comm_init_rank || !r.all_reduce) {
-    set_err("%s does not export the NCCL API", path ? path : "librccl.so");
-    return OPRL_ERR_INVALID;
-  }
-  return OPRL_OK;
-}
-}  // namespace
-
-#define HIPC(x)                                                                        \
-  do {                                                                                 \
-    hipError_t _e = (x);                                                               \
-    if (_e != hipSuccess) {                                                            \
-      set_err("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
-      return OPRL_ERR_HIP;                                                             \
-    }                                                                                  \
-  } while (0)
-#define RC(x)                      \
-  do {                             \
-    int _rc = (x);                 \
-    if (_rc != OPRL_OK) return _rc; \
-  } while (0)
-
-namespace {
-
-long net_param_count(const oprl_net& n) {
-  long c = 0;
-  for (int l = 0; l < n.n_layers; ++l) c += (long)n.dims[l + 1] * n.dims[l] + n.dims[l + 1];
-  return c;
-}
-
-long w_off(const oprl_net& n, int l) {
-  long c = 0;
-  for (int j = 0; j < l; ++j) c += (long)n.dims[j + 1] * n.dims[j] + n.dims[j + 1];
-  return c;
-}
-long b_off(const oprl_net& n, int l) { return w_off(n, l) + (long)n.dims[l + 1] * n.dims[l]; }
-
-int check_net(const oprl_net& n, const char* name, int* width) {
-  if (n.n_layers < 2 || n.n_layers > OPRL_MAX_LAYERS) {
-    set_err("%s: n_layers=%d unsupported (2..%d)", name, n.n_layers, OPRL_MAX_LAYERS);
-    return OPRL_ERR_INVALID;
-  }
-  const int w = n.dims[1];
-  if (w != 256 && w != 512) { set_err("%s: hidden width %d unsupported (256 or 512)", name, w); return OPRL_ERR_INVALID; }
-  for (int l = 1; l < n.n_layers; ++l)
-    if (n.dims[l] != w) { set_err("%s: hidden widths must be equal", name); return OPRL_ERR_INVALID; }
-  if (n.dims[0] < 1 || n.dims[0] > 96) { set_err("%s: input dim %d unsupported (1..96)", name, n.dims[0]); return OPRL_ERR_INVALID; }
-  if (n.dims[n.n_layers] < 1 || n.dims[n.n_layers] > kNarrowMax) {
-    set_err("%s: output dim %d unsupported (1..%d)", name, n.dims[n.n_layers], kNarrowMax);
-    return OPRL_ERR_INVALID;
-  }
-  if (!n.theta) { set_err("%s: theta is null", name); return OPRL_ERR_INVALID; }
-  if (!n.pack) { set_err("%s: pack buffer is null (see oprl_net_pack_floats)", name); return OPRL_ERR_INVALID; }
-  if (n.theta_target && !n.pack_target) { set_err("%s: pack_target is null", name); return OPRL_ERR_INVALID; }
-  *width = w;
-  return OPRL_OK;
-}
-
-// offsets (floats) of layer l's forward / backward pack inside a pack buffer
-long pack_off_fwd(const oprl_net& n, int l) {
-  long c = 0;
-  for (int j = 0; j < l; ++j) c += 2 * pack_floats(n.dims[j + 1], n.dims[j]);
-  return c;
-}
-long pack_off_bwd(const oprl_net& n, int l) { return pack_off_fwd(n, l) + pack_floats(n.dims[l + 1], n.dims[l]); }
-long net_pack_floats(const oprl_net& n) { return pack_off_fwd(n, n.n_layers); }
-
-// the same for the bf16 packs (library-owned, oprl_learner::pack16 / pack16_t), in floats (16-byte fragments)
-// (pl = fp16 / bf16 planes per block: 1 for the bf16 packs, 2 for the PrecX2 packs — hi | lo)
-long pack16_off_fwd(const oprl_net& n, int l, int pl = 1) {
-  long c = 0;
-  for (int j = 0; j < l; ++j) c += pl * (pack16_floats(n.dims[j + 1], n.dims[j]) + pack16_floats(n.dims[j], n.dims[j + 1]));
-  return c;
-}
-long pack16_off_bwd(const oprl_net& n, int l, int pl = 1) { return pack16_off_fwd(n, l, pl) + pl * pack16_floats(n.dims[l + 1], n.dims[l]); }
-long net_pack16_floats(const oprl_net& n, int pl = 1) { return pack16_off_fwd(n, n.n_layers, pl); }
-
-Net net_view(const oprl_net& n, bool target) {
-  Net v;
-  memset(&v, 0, sizeof v);
-  v.n_layers = n.n_layers;
-  for (int l = 0; l <= n.n_layers; ++l) v.dims[l] = n.dims[l];
-  const float* base = target ? n.theta_target : n.theta;
-  const float* pk = target ? n.pack_target : n.pack;
-  for (int l = 0; l < n.n_layers; ++l) {
-    v.b[l] = base + b_off(n, l);
-    v.pf[l] = pk + pack_off_fwd(n, l);
-    v.pb[l] = pk + pack_off_bwd(n, l);
-  }
-  return v;
-}
-
-// per-net activation / gradient exchange buffers (HBM, sized for max_batch rows)
-constexpr int kMaxCluster = 4;   // CUs per tensor-parallel slice cluster (csrc/tp3.h)
-
-// a Net whose pf / pb point at the bf16 packs (for the PrecBF16 kernels only)
-Net net_view16(const oprl_net& n, bool target, const float* pk16, int pl = 1) {
-  Net v = net_view(n, target);
-  for (int l = 0; l < n.n_layers; ++l) {
-    v.pf[l] = pk16 + pack16_off_fwd(n, l, pl);
-    v.pb[l] = pk16 + pack16_off_bwd(n, l, pl);
-  }
-  return v;
-}
-
-struct NetWs {
-  float* X[kMaxLayers] = {nullptr, nullptr, nullptr, nullptr};
-  float* dY[kMaxLayers] = {nullptr, nullptr, nullptr, nullptr};
-  int ldx0 = 0, lddo = 0, width = 0;
-  long dY0_stride = 0;   // dY[0] is kMaxCluster buffers this many floats apart (dz1 partials)
-};
-
-struct Pool {  // one hipMalloc, bump allocated
-  char* base = nullptr;
-  size_t cap = 0, used = 0;
-  template <class T>
-  T* take(size_t n) {
-    used = (used + 255) & ~(size_t)255;
-    T* p = reinterpret_cast<T*>(base + used);
-    used += n * sizeof(T);
-    return p;
-  }
-};
-
-}  // namespace
-
-struct oprl_learner {
-  oprl_learner_config cfg;
-  int S, A, Bmax, nc;
-  int w_actor = 0, w_critic = 0;
-  Pool pool;
-  NetWs ws_actor, ws_critic[OPRL_MAX_CRITICS];
-  std::vector<DwItem> items_host;  // [critic items..., actor items...] (travel in the kernel arguments)
-  int n_items_critic = 0, n_items_actor = 0, tiles_critic = 0, tiles_actor = 0;
-  // batch-sized scratch
-  float *a2 = nullptr, *logp2 = nullptr, *qn = nullptr /*[nc][B][ldq]*/, *pi = nullptr,
-        *raw = nullptr, *logp = nullptr, *da = nullptr /*[nc][B][A]*/, *qpi = nullptr /*[nc][B]*/,
-        *target = nullptr, *ydbg = nullptr, *qdbg = nullptr;
-  int ldq = 0;
-  float *part_c = nullptr /*[nc][slices][4]*/, *part_a = nullptr, *scalars = nullptr;
-  double* alpha_grad = nullptr;
-  // step_n batch buffers
-  float *bs = nullptr, *ba = nullptr, *br = nullptr, *bd = nullptr, *bs2 = nullptr;
-  int64_t update_count = 0;
-  int opt_step_critic = 0, opt_step_actor = 0, opt_step_alpha = 0;
-  int last_B = 0;
-  bool actor_updated_last = false;
-  long long* trace = nullptr;
-  int trace_slot = 0;
-  Rccl rccl;
-  long n_critic_params = 0, n_actor_params = 0;
-  // side streams: independent per-net launches (twin / quantile critics) run concurrently
-  hipStream_t side[OPRL_MAX_CRITICS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[OPRL_MAX_CRITICS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  bool have_side = false;
-  bool fused = false;          // DDPG / TD3 / SAC two-kernel path (csrc/fused_ddpg.hip) is built for this learner
-  const float* noise1_pending = nullptr;   // update()'s injected actor-phase draws: SAC's role C runs in phase 1
-  bool tp_generic_on = false;  // the generic per-net launches may run on clusters of 4 (csrc/slice_tp.hip)
-  unsigned tp_tag = 0;         // launch-unique tag source of the cluster exchanges (fused and generic)
-  // for_each_net over two nets: their cluster launches are collected and go out as one (k_mlp_slice_tp2)
-  bool pair_collect = false;
-  int pair_n = 0;
-  MlpArgs pair_args[2];
-  P2pState p2p;                // one-shot all-reduce windows (csrc/p2p.hip); used when p2p_ok
-  bool p2p_ok = false, p2p_tested = false, p2p_inline = false;
-  int p2p_max_tiles = 0;
-  bool dp_inline = false;      // this data-parallel update exchanges inside the dW launches (k_dw_adam<true>)
-  DwXchg dw_xchg;
-  bool no_dp_inline = false;   // OPRL_AMD_NO_DP_INLINE: peer-window exchanges as separate launches (tests / A-B)
-  bool no_twin_split = false;  // OPRL_AMD_NO_SIDE_BY_SIDE: role A runs both target critics back to back (tests / A-B)
-  bool no_multi = false;
-  PrefetchJob prefetch;        // step_n on the generic path (TQC): the next update's rows as riders of this update's k_lw_dact launch
-  bool prefetch_pending = false, prefetch_done = false;
-  bool no_gather_ride = false; // OPRL_AMD_NO_RIDE bit 8: a k_replay_gather launch per update (tests / A-B)
-  float* batch_alt = nullptr;  // the second set of batch rows [Bmax x (2 S + A + 2)] the riders fill while an update reads the first
-  MlpArgs fin_args[OPRL_MAX_CRITICS];   // TQC: the online critics' first-launch arguments of this update (critic_phase step 1) ...
-  int fin_tail0 = -1;          // ... of which [fin_tail0, nc) did not fit beside the actor's forward: offered to the target pass's head launch (-1: none pending)
-  bool fin16 = false;
-  bool fin_done = false;       // TQC: the online critics' first hidden launch rode on the actor's forward on s' (critic_phase step 1); step 3 skips it
-  bool no_fin_ride = false;    // OPRL_AMD_NO_RIDE bit 4: it stays the first launch of step 3 (tests / A-B)
-  LwPairBuf lw_pairs = {nullptr, 0, 1u, 1 << 20, nullptr, 3, 0};   // k_lw_mid_pair: flags (own allocation), tags; OPRL_AMD_LW_PAIR: bit 0 forward, bit 1 backward pairs (default 3)
-  float* lw_scratch = nullptr; // [critics][layers 1 .. L-1][Bmax x 512]: activations of forward-only layer-by-layer launches (the target pass) — not the nets' dW exchange buffers, which the early first launch has already filled
-  MlpArgs rider;               // TQC: the actor's forward on s, prepared in critic_phase to ride on the critic step's head launch ...
-  bool rider_pending = false;  // ... offered to the next for_each_net; taken: rider_done, and actor_phase skips its step 5
-  bool rider_done = false;
-  bool no_af_ride = false;     // OPRL_AMD_NO_RIDE bit 2: the forward stays a launch of actor_phase (tests / A-B)
-  TqcJob tqc_job;              // TQC: the TD target as the tail of the target critics' head launch (kernels.h) ...
-  bool tqc_job_pending = false; // ... offered to the next for_each_net; still set afterwards: k_tqc_target as a launch of its own
-  bool no_tqc_ride = false;    // OPRL_AMD_NO_RIDE bit 1: always that launch (tests / A-B)
-  unsigned long long* tqc_counter = nullptr;   // [slices at Bmax] arrival counters, zeroed once
-  bool no_layerwise = false;   // OPRL_AMD_NO_LAYERWISE: wide nets stay on the single-CU slice kernel (tests / A-B)
-  bool no_p2_pair = false;     // OPRL_AMD_NO_SIDE_BY_SIDE: SAC phase 2 runs the twin critics back to back (tests / A-B)
-  bool multi_collect = false;  // for_each_net over > 2 single-CU nets: one k_mlp_slice_multi launch
-  int multi_n = 0, multi_width = 0;
-  MlpArgs multi_args[kMaxMulti];
-  bool staged_ready = false;   // step_n: the staging batch holds the next update's rows (written by phase 2)
-  unsigned long long* y_granules = nullptr;   // [Bmax] TD-target hand-off (fused DDPG)
-  unsigned epoch = 0;          // monotonically increasing, never reset
-  int ncl = 1;                 // CUs per slice cluster in the fused path (csrc/tp3.h)
-  int n_cus = 256;
-  int no_lean = 0;
-  bool shared_chip = false;    // oprl_learner_set_cluster(< 8): this learner is one of several on the GPU
-  int no_merge = 0;            // OPRL_AMD_FORM=plain: dW launches of their own
-  int no_merge2 = 0;           // OPRL_AMD_FORM=p2 / plain: phase 2 runs the actor's backward itself, the actor's dW is a launch of its own
-  // merged phase 2 (DdpgArgs::merged bit 1): du granules [Bm][kDuLd], the first layer's dz1 granules [16][Bm][16] and the
-  // snapshot of the actor's output layer (Bm = min(max_batch, 256))
-  // oprl_learner_step_act: host-mapped pinned block [obs 512 floats | out 512 granules {ticket, value}] and the ticket of the pending row
-  float* act_pin = nullptr;
-  float* act_map = nullptr;
-  unsigned act_ticket = 0;
-  bool act_pending = false;
-  unsigned long long* du_granules = nullptr;
-  unsigned long long* g1_granules = nullptr;
-  float* w3_snap = nullptr;
-  int no_wide = 0;             // OPRL_AMD_NO_WIDE: never run role A / phase 2's critic pass on clusters of eight
-  int xnc = kMaxCluster;       // members an exchange area of xbuf is laid out for
-  unsigned long long* xbuf = nullptr;
-  size_t xbuf_granules = 0;
-  // Largest cluster size for which ONE role's clusters (c x slices workgroups, one per CU) fit on the
-  // chip.  Phase 1's grid may then exceed the CU count (B > 256): workgroups are dispatched in block
-  // order — role A's clusters, then B's, then C's — role A waits for nobody, the members of a cluster
-  // are dispatched together, and a B workgroup only ever waits for an A workgroup dispatched before it,
-  // so later roles simply start as earlier workgroups retire.
-  // Measured (profiles/r01g_batch_sweep.txt): worth it for the lean clusters of 4 (B = 512: 76 -> 51 us
-  // per DDPG update); the generic passes on smaller clusters do better fully co-resident.
-  int nc_cluster(int B) const {
-    const int slices = (B + kR - 1) / kR;
-    if (ncl == 4 && 4 * slices <= n_cus) return 4;
-    const int roles = 2 + nc;
-    int c = ncl;
-    while (c > 1 && roles * c * slices > n_cus) c >>= 1;
-    return c;
-  }
-  BatchSrc src;                // where the current update's minibatch comes from
-  BatchSrc next_src;           // step_n: what phase 2 should gather for the next update
-  int prefetch_next = 0;
-  bool prefetch_p1 = false;    // step_n: phase 1 carries the next update's rows (two staging sets), not phase 2
-  // key of the in-update noise streams (TD3 smoothing, SAC / TQC reparameterisation draws): the run
-  // seed and, in a data-parallel job, the rank — every seed and every rank draws its own eps
-  uint64_t noise_seed = 0;
-  int noise_rank = 0;
-  // OPRL_PREC_BF16: bf16 fragment packs of every net (online: forward + backward, target: forward),
-  // derived state owned by the library and written by the dW + Adam epilogues / k_repack; index 0 = actor,
-  // 1 + j = critic j
-  // Bounded cross-workgroup waits (cluster all-reduce, TD-target hand-off, twin exchanges, gradient tile /
-  // window exchanges) REPORT an expiry here besides poisoning their result with NaN: one word of
-  // host-mapped memory, written by the device only on that error path (tp3.h report_expired), read by
-  // the host at the start of every update / step_n / apply / read_scalars call — no copy, no sync.
-  unsigned* err_host = nullptr;
-  unsigned* err_dev = nullptr;
-  int debug_expire = 0;        // test hook (oprl_learner_debug_expire): this wait site gives up at once
-  bool bf16 = false;
-  bool x2 = false;             // OPRL_PREC_X2: the lean fused kernels run PrecX2 (engine.h) from packs of two fp16 planes, kept in pack16 / pack16_t
-  int planes = 1;              // fp16 / bf16 planes per block of those packs
-  // PrecX2 learners: the fused updates do not write the fp32 packs (nothing of theirs reads them); whoever does —
-  // the nets' own forward (oprl_mlp_forward / act / backward), a generic launch sequence — gets them rebuilt from the
-  // master first (fresh32): [0] the critics' (online + target), [1] the actor's
-  bool stale32[2] = {false, false};
-  bool lazy_wide = false;      // this learner is in g_lazy and its wide layers' fp32 packs may be left stale (16-bit TQC)
-  bool stale_wide = false;     // ... and are: only the critics' 512 x 512 layers' fp32 packs (the narrow layers' are current)
-  float* uc_base = nullptr;    // the fp16 packs' uncached allocation (PrecX2 learners)
-  bool uc_pool = false;        // the workspace pool is uncached memory as well
-  // exact-fp32 DDPG learners (fchain): the fused kernels' fp32 fragment packs are library-owned UNCACHED mirrors of the
-  // caller's pack arenas (same layout) — what k_ddpg_chain<PrecF32>'s tiles write, the next update's roles read without a
-  // kernel boundary; the caller's packs are rebuilt from the masters when something outside reads them (fresh32).
-  // fnet[0] = the actor, fnet[1] = the critic with pack / pack_target -> the mirrors (uc_base holds them)
-  bool fchain = false;
-  oprl_net fnet[2];
-  // k_ddpg_chain (the whole update, several per launch): role C's / the critic tiles' flags, the critic's uncached bias copies
-  unsigned long long* w_flags = nullptr;
-  float* critic_b16 = nullptr;
-  // k_ddpg_chain (several updates per launch): the tiles' FIN flags, the prefetch flags, the uncached bias copies of all
-  // four nets ([0] actor, [1] actor target, [2] critic = critic_b16, [3] critic target) and the output layer's two buffers
-  unsigned long long* chain_flags = nullptr;   // [ct_fin 192 | at_fin 192 | pf_done 64 | gu_flags 128 | partial q 1024]
-  float* gu = nullptr;                         // [kDuLd][Bm][256] the actor's unit-seed dz1 rows (DwGate kind 3)
-  float* chain_b16 = nullptr;                  // [4][kMaxLayers][256]
-  float* w3buf1 = nullptr;                     // (w3buf[0] = w3_snap)
-  int chain_u = 1;             // step_n: updates the next whole-update launch runs (k_ddpg_chain)
-  bool chain_pf_last = false;  // ... and whether its last update stages the rows of the update after it
-  const float* chain_set1[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // the other staging set (set 0 = the update's rows)
-  int no_chain = 0;            // (always 0: every whole update goes through k_ddpg_chain)
-  int chain_max = kChainMax;   // OPRL_AMD_CHAIN=n: at most n updates per launch
-  int no_whole = 0;            // OPRL_AMD_FORM=two / p2 / plain: two launches per update (merged phase 1, merged phase 2)
-  bool whole_done = false;     // this update's actor phase was part of the critic phase's launch
-  float* pack16[OPRL_MAX_CRITICS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  float* pack16_t[OPRL_MAX_CRITICS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  // prebuilt device repack tables: [0] critics online, [1] critics online+target, [2] actor (+target)
-  RepackItem* rp_dev[3] = {nullptr, nullptr, nullptr};
-  int rp_n[3] = {0, 0, 0}, rp_blocks[3] = {0, 0, 0};
-};
-
-namespace {
+namespace oprl_host {
 
 // learners with lazily maintained fp32 packs, by pack pointer (oprl_mlp_* know a net, not its learner)
 // Whole-update launches (k_ddpg_chain) take the whole chip for up to 32 updates.  Learners of one process that launch them
@@ -580,8 +176,8 @@ int fresh32(const oprl_net* net, hipStream_t st) {
   return OPRL_OK;
 }
 
-void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int* tiles, bool small_partial_tiles = false,
-                float* pk16 = nullptr, float* pk16_t = nullptr, int pl = 1) {
+void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int* tiles, bool small_partial_tiles,
+                float* pk16, float* pk16_t, int pl) {
   for (int l = 0; l < n.n_layers; ++l) {
     DwItem it;
     memset(&it, 0, sizeof it);
@@ -1695,7 +1291,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
 // table goes through a small device scratch; synchronous on `st` only.
 void build_repack_items(const oprl_net* const* nets, int n_nets, int which,
                         std::vector<RepackItem>& items, int* blocks_out,
-                        float* const* pk16 = nullptr, float* const* pk16_t = nullptr, int pl = 1) {
+                        float* const* pk16, float* const* pk16_t, int pl) {
   int blocks = 0;
   for (int i = 0; i < n_nets; ++i) {
     const oprl_net& n = *nets[i];
@@ -1725,7 +1321,7 @@ void build_repack_items(const oprl_net* const* nets, int n_nets, int which,
 }
 
 int repack_nets(const oprl_net* const* nets, int n_nets, int which, hipStream_t st,
-                float* const* pk16 = nullptr, float* const* pk16_t = nullptr, int pl = 1) {
+                float* const* pk16, float* const* pk16_t, int pl) {
   std::vector<RepackItem> items;
   int blocks = 0;
   build_repack_items(nets, n_nets, which, items, &blocks, pk16, pk16_t, pl);
@@ -1782,7 +1378,7 @@ int check_device_error(const oprl_learner* h) {
   return OPRL_ERR_STATE;
 }
 
-}  // namespace
+}  // namespace oprl_host
 
 // =========================================================================== C-ABI
 extern "C" const char* oprl_last_error(void) { return g_err.c_str(); }
@@ -1826,266 +1422,6 @@ extern "C" int oprl_learner_debug_expire(oprl_learner* h, int32_t site) {
 }
 
 
-#define NCCLC(h, x)                                                                   \
-  do {                                                                                 \
-    int _r = (x);                                                                      \
-    if (_r != 0) {                                                                     \
-      set_err("%s failed: %s", #x, (h)->rccl.err_str ? (h)->rccl.err_str(_r) : "nccl error"); \
-      return OPRL_ERR_HIP;                                                             \
-    }                                                                                  \
-  } while (0)
-
-extern "C" int oprl_comm_unique_id(const char* rccl_path, char id_out[OPRL_COMM_ID_BYTES]) {
-  if (!id_out) { set_err("oprl_comm_unique_id: null output"); return OPRL_ERR_INVALID; }
-  static Rccl r;
-  RC(rccl_bind(r, rccl_path));
-  NcclId id;
-  const int rc = r.get_unique_id(&id);
-  if (rc != 0) { set_err("ncclGetUniqueId failed (%d)", rc); return OPRL_ERR_HIP; }
-  memcpy(id_out, id.internal, OPRL_COMM_ID_BYTES);
-  return OPRL_OK;
-}
-
-namespace {
-// the gradient arenas must be contiguous per group (critics back to back)
-int dp_arena_sizes(oprl_learner* h) {
-  long off = 0;
-  for (int j = 0; j < h->nc; ++j) {
-    if (h->cfg.critics[j].grad != h->cfg.critics[0].grad + off) { set_err("critic gradient arenas are not contiguous"); return OPRL_ERR_INVALID; }
-    off += net_param_count(h->cfg.critics[j]);
-  }
-  h->n_critic_params = off;
-  h->n_actor_params = net_param_count(h->cfg.actor);
-  return OPRL_OK;
-}
-}  // namespace
-
-extern "C" int oprl_comm_init(oprl_learner* h, const char* rccl_path, int32_t rank, int32_t world,
-                              const char id[OPRL_COMM_ID_BYTES]) {
-  if (!h || !id || world < 1 || rank < 0 || rank >= world) { set_err("oprl_comm_init: invalid argument"); return OPRL_ERR_INVALID; }
-  if (!h->cfg.export_grads) { set_err("oprl_comm_init: learner was not created with export_grads"); return OPRL_ERR_STATE; }
-  RC(dp_arena_sizes(h));
-  RC(rccl_bind(h->rccl, rccl_path));
-  NcclId nid;
-  memcpy(nid.internal, id, OPRL_COMM_ID_BYTES);
-  NCCLC(h, h->rccl.comm_init_rank(&h->rccl.comm, world, nid, rank));
-  h->rccl.rank = rank;
-  h->rccl.world = world;
-  h->noise_rank = rank;          // every rank draws its own in-update noise
-  return OPRL_OK;
-}
-
-// Every replica identical to rank `root`: parameters, targets, Adam moments (and the temperature with its
-// moments) of all nets by ncclBroadcast, then the derived packs rebuilt.  Done once after oprl_comm_init
-// ("parameters, targets and Adam state replicated, broadcast from rank 0 once").
-extern "C" int oprl_comm_broadcast_params(oprl_learner* h, int32_t root, void* stream) {
-  if (!h || !h->rccl.comm) { set_err("oprl_comm_broadcast_params: call oprl_comm_init first"); return OPRL_ERR_STATE; }
-  if (!h->rccl.broadcast) { set_err("the RCCL library does not export ncclBroadcast"); return OPRL_ERR_INVALID; }
-  if (root < 0 || root >= h->rccl.world) { set_err("oprl_comm_broadcast_params: bad root %d", root); return OPRL_ERR_INVALID; }
-  hipStream_t st = (hipStream_t)stream;
-  const oprl_learner_config& c = h->cfg;
-  auto bc_net = [&](const oprl_net& n) -> int {
-    const size_t cnt = (size_t)net_param_count(n);
-    float* arenas[4] = {n.theta, n.theta_target, n.adam_m, n.adam_v};
-    for (float* a : arenas)
-      if (a != nullptr) NCCLC(h, h->rccl.broadcast(a, a, cnt, kNcclFloat32, root, h->rccl.comm, st));
-    return OPRL_OK;
-  };
-  RC(bc_net(c.actor));
-  for (int j = 0; j < h->nc; ++j) RC(bc_net(c.critics[j]));
-  double* scalars[3] = {c.log_alpha, c.log_alpha_m, c.log_alpha_v};
-  for (double* p : scalars)
-    if (p != nullptr) NCCLC(h, h->rccl.broadcast(p, p, 1, kNcclFloat64, root, h->rccl.comm, st));
-  return oprl_learner_sync_params(h, stream);
-}
-
-// ---- one-shot all-reduce over peer windows (csrc/p2p.hip) -------------------------------------------
-extern "C" int oprl_p2p_create(oprl_learner* h, int32_t rank, int32_t world, char handle_out[OPRL_P2P_HANDLE_BYTES]) {
-  if (!h || !handle_out) { set_err("oprl_p2p_create: invalid argument"); return OPRL_ERR_INVALID; }
-  if (!h->cfg.export_grads) { set_err("oprl_p2p_create: learner was not created with export_grads"); return OPRL_ERR_STATE; }
-  if (h->p2p.window != nullptr) { set_err("oprl_p2p_create: window already exists"); return OPRL_ERR_STATE; }
-  RC(dp_arena_sizes(h));
-  const size_t n = (size_t)std::max(h->n_critic_params, h->n_actor_params);
-  // second region: the per-tile exchange of k_dw_adam<true> (fused learners; a few MB)
-  h->p2p_max_tiles = std::max(h->tiles_critic, h->tiles_actor);
-  size_t tile_bytes = h->fused ? dw_xchg_bytes(world, h->p2p_max_tiles) : 0;
-  if (tile_bytes > ((size_t)256 << 20)) tile_bytes = 0;
-  h->noise_rank = rank;
-  h->p2p.err = h->err_dev;
-  hipError_t e = p2p_create(h->p2p, rank, world, n, tile_bytes, handle_out);
-  if (e != hipSuccess) {
-    set_err("oprl_p2p_create: %s", hipGetErrorString(e));
-    (void)hipGetLastError();
-    p2p_destroy(h->p2p);
-    return OPRL_ERR_HIP;
-  }
-  return OPRL_OK;
-}
-
-extern "C" int oprl_p2p_connect(oprl_learner* h, const char* handles) {
-  if (!h || !handles || h->p2p.window == nullptr) { set_err("oprl_p2p_connect: call oprl_p2p_create first"); return OPRL_ERR_STATE; }
-  hipError_t e = p2p_connect(h->p2p, handles);
-  if (e != hipSuccess) { set_err("oprl_p2p_connect: %s", hipGetErrorString(e)); (void)hipGetLastError(); return OPRL_ERR_HIP; }
-  return OPRL_OK;
-}
-
-// Every rank contributes (rank + 1) * (1 + i mod 7) at element i of its critic gradient arena; the
-// windows are kept only if this rank's sum is exact everywhere.  (The ranks decide together: the
-// host reduces the verdicts, oprl_amd/parallel.py.)
-extern "C" int oprl_p2p_selftest(oprl_learner* h, void* stream) {
-  if (!h || !h->p2p.connected) { set_err("oprl_p2p_selftest: windows are not connected"); return OPRL_ERR_STATE; }
-  hipStream_t st = (hipStream_t)stream;
-  const size_t n = (size_t)h->n_critic_params;
-  float* g = h->cfg.critics[0].grad;
-  std::vector<float> host(n);
-  bool all_ok = true;
-  for (int round = 0; round < 3 && all_ok; ++round) {   // three rounds: both window halves and a reuse
-    for (size_t i = 0; i < n; ++i) host[i] = (float)((h->p2p.rank + 1) * (1 + (int)((i + round) % 7)));
-    HIPC(hipMemcpyAsync(g, host.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
-    HIPC(p2p_all_reduce(h->p2p, g, n, false, st));
-    HIPC(hipMemcpyAsync(host.data(), g, n * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIPC(hipStreamSynchronize(st));
-    const int tri = h->p2p.world * (h->p2p.world + 1) / 2;
-    for (size_t i = 0; i < n && all_ok; ++i) all_ok = host[i] == (float)(tri * (1 + (int)((i + round) % 7)));
-  }
-  HIPC(hipMemsetAsync(g, 0, n * sizeof(float), st));
-  if (const char* f = getenv("OPRL_AMD_P2P_SELFTEST_FAIL")) {   // tests: exercise the fall-back to RCCL
-    if (atoi(f) != 0) all_ok = false;
-  }
-  h->p2p_tested = all_ok;
-  if (!all_ok) { set_err("oprl_p2p_selftest: the exchanged sum is wrong; staying on RCCL"); return OPRL_ERR_STATE; }
-  return OPRL_OK;
-}
-
-// The ranks agree on the host (every self-test passed) and then switch together.
-extern "C" int oprl_p2p_enable(oprl_learner* h, int32_t on) {
-  if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
-  if (on && !h->p2p_tested) { set_err("oprl_p2p_enable: the self-test has not passed on this rank"); return OPRL_ERR_STATE; }
-  if (on < 0 || on > 2) { set_err("oprl_p2p_enable: level must be 0, 1 or 2"); return OPRL_ERR_INVALID; }
-  h->p2p_ok = on != 0;
-  h->p2p_inline = on == 2;     // 2: fused learners also exchange inside their dW launches (k_dw_adam<true>)
-  return OPRL_OK;
-}
-
-namespace {
-int dp_world(const oprl_learner* h) { return h->p2p_ok ? h->p2p.world : h->rccl.world; }
-int dp_rank(const oprl_learner* h) { return h->p2p_ok ? h->p2p.rank : h->rccl.rank; }
-// in-place sum over ranks of a float (or one-double) buffer: peer windows when they passed the self-test, else RCCL
-int dp_all_reduce(oprl_learner* h, void* buf, size_t n, bool as_double, hipStream_t st) {
-  // The one-shot exchange sends the whole arena to every peer: right for the latency-bound ~300 KB
-  // arenas of the 256-wide nets, wrong for TQC's 11 MB critic arena, where a ring moves 2 x 7/8 of the
-  // bytes instead of 7 x — those stay on RCCL when a communicator exists.
-  const bool small = n * (as_double ? 8 : 4) <= ((size_t)1 << 20);
-  if (h->p2p_ok && (small || !h->rccl.comm)) {
-    HIPC(p2p_all_reduce(h->p2p, buf, n, as_double, st));
-    return OPRL_OK;
-  }
-  NCCLC(h, h->rccl.all_reduce(buf, buf, n, as_double ? kNcclFloat64 : kNcclFloat32, kNcclSum, h->rccl.comm, st));
-  return OPRL_OK;
-}
-}  // namespace
-
-namespace {
-int chain_loop(oprl_learner* h, int K, int B, float* (*set)[5], void* stream);
-bool chain_ok(oprl_learner* h, int B);
-}  // namespace
-
-extern "C" int oprl_learner_dp_update(oprl_learner* h, const float* s, const float* a, const float* r,
-                                      const float* d, const float* s2, int32_t B, const float* noise0,
-                                      const float* noise1, void* stream) {
-  if (!h || (!h->rccl.comm && !h->p2p_ok)) { set_err("oprl_learner_dp_update: call oprl_comm_init (or connect the peer windows) first"); return OPRL_ERR_STATE; }
-  hipStream_t st = (hipStream_t)stream;
-  const oprl_learner_config& c = h->cfg;
-  const double scale = 1.0 / (double)dp_world(h);
-  // Fused learners on peer windows: the two dW launches exchange their own tiles (k_dw_adam<true>) and
-  // run Adam on the mean — no separate all-reduce or apply launches.
-  if (h->p2p_ok && h->p2p_inline && !h->no_dp_inline && h->p2p.tile_bytes > 0 && use_fused(h, B)) {
-    h->dp_inline = true;
-    int rc = oprl_learner_update_phase(h, 0, s, a, r, d, s2, B, noise0, noise1, stream);
-    if (rc == OPRL_OK) rc = oprl_learner_update_phase(h, 1, s, a, r, d, s2, B, noise0, noise1, stream);
-    h->dp_inline = false;
-    RC(rc);
-    if (h->actor_updated_last && alpha_ptr(h) != nullptr) {   // the temperature: one double, exchanged on its own
-      RC(dp_all_reduce(h, h->alpha_grad, 1, true, st));
-      HIPC(launch_alpha_step(c.log_alpha, c.log_alpha_m, c.log_alpha_v, nullptr, 1, (float)c.hp.target_entropy,
-                             c.hp.lr_alpha, c.hp.beta1, c.hp.beta2, c.hp.adam_eps, h->opt_step_alpha,
-                             nullptr, h->alpha_grad, (float)scale, st));
-    }
-    return OPRL_OK;
-  }
-  RC(oprl_learner_update_phase(h, 0, s, a, r, d, s2, B, noise0, noise1, stream));
-  RC(dp_all_reduce(h, c.critics[0].grad, (size_t)h->n_critic_params, false, st));
-  RC(oprl_learner_apply(h, 0, scale, stream));
-  RC(oprl_learner_update_phase(h, 1, s, a, r, d, s2, B, noise0, noise1, stream));
-  if (h->actor_updated_last) {
-    RC(dp_all_reduce(h, c.actor.grad, (size_t)h->n_actor_params, false, st));
-    if (alpha_ptr(h) != nullptr) RC(dp_all_reduce(h, h->alpha_grad, 1, true, st));
-    RC(oprl_learner_apply(h, 1, scale, stream));
-  }
-  return OPRL_OK;
-}
-
-extern "C" int oprl_learner_dp_step_n(oprl_learner* h, oprl_replay* replay, int32_t K, int32_t B,
-                                      uint64_t seed, void* stream) {
-  if (!h || !replay) { set_err("oprl_learner_dp_step_n: null handle"); return OPRL_ERR_INVALID; }
-  if (!h->rccl.comm && !h->p2p_ok) { set_err("oprl_learner_dp_step_n: call oprl_comm_init (or connect the peer windows) first"); return OPRL_ERR_STATE; }
-  int S = 0, A = 0;
-  replay_dims(replay, &S, &A);
-  if (S != h->S || A != h->A) { set_err("replay dims (%d,%d) != learner dims (%d,%d)", S, A, h->S, h->A); return OPRL_ERR_INVALID; }
-  if (K < 0 || B < 1 || B > h->Bmax) { set_err("dp_step_n: bad K/B"); return OPRL_ERR_INVALID; }
-  // every rank samples its own shard: the Philox key mixes the rank in
-  const uint64_t rseed = seed * 0x9E3779B97F4A7C15ull + (uint64_t)dp_rank(h);
-  if (use_fused(h, B)) {
-    BatchSrc& sc = h->src;
-    RC(oprl_replay_flush(replay, stream));
-    long n_tr = 0;
-    replay_view(replay, &sc.states, &sc.actions, &sc.rewards, &sc.dones, &sc.ends, &sc.n_eps, &sc.L, &n_tr);
-    if (n_tr <= 0 || sc.n_eps <= 0) { set_err("dp_step_n: replay buffer is empty"); return OPRL_ERR_STATE; }
-    sc.n_transitions = n_tr;
-    sc.seed = rseed;
-    sc.gather = 1;
-    // as in oprl_learner_step_n: phase 2 of every update gathers the next update's rows
-    h->next_src = sc;
-    // The gradient exchange inside the tiles of the whole-update launch (peer windows, PrecX2 learners): the data-parallel
-    // K-loop IS the single-GPU one — k_ddpg_chain, up to chain_max updates per launch, every tile all-reducing its
-    // gradient with the other ranks' before Adam.  No all-reduce launches, no apply launches.
-    if (h->p2p_ok && h->p2p_inline && !h->no_dp_inline && h->p2p.tile_bytes > 0) {
-      h->dp_inline = true;
-      if (chain_ok(h, B)) {
-        const size_t Bm = (size_t)h->Bmax;
-        float* alt = h->batch_alt;
-        float* set[2][5] = {{h->bs, h->ba, h->br, h->bd, h->bs2},
-                            {alt, alt + Bm * h->S, alt + Bm * (h->S + h->A), alt + Bm * (h->S + h->A + 1), alt + Bm * (h->S + h->A + 2)}};
-        const int rc_chain = chain_loop(h, K, B, set, stream);
-        h->dp_inline = false;
-        return rc_chain;
-      }
-      h->dp_inline = false;
-    }
-    h->next_src.s = h->bs; h->next_src.a = h->ba; h->next_src.r = h->br; h->next_src.d = h->bd;
-    h->next_src.s2 = h->bs2;
-    int rc = OPRL_OK;
-    for (int k = 0; k < K && rc == OPRL_OK; ++k) {
-      sc.counter = (unsigned long long)h->update_count;
-      h->next_src.counter = sc.counter + 1;
-      h->prefetch_next = (k + 1 < K) ? 1 : 0;
-      sc.gather = h->staged_ready ? 0 : 1;
-      h->staged_ready = false;
-      rc = oprl_learner_dp_update(h, h->bs, h->ba, h->br, h->bd, h->bs2, B, nullptr, nullptr, stream);
-    }
-    sc.gather = 0;
-    h->prefetch_next = 0;
-    h->staged_ready = false;
-    return rc;
-  }
-  for (int k = 0; k < K; ++k) {
-    RC(oprl_replay_sample(replay, B, nullptr, rseed, (uint64_t)h->update_count, h->bs, h->ba, h->br,
-                          h->bd, h->bs2, nullptr, nullptr, stream));
-    RC(oprl_learner_dp_update(h, h->bs, h->ba, h->br, h->bd, h->bs2, B, nullptr, nullptr, stream));
-  }
-  return OPRL_OK;
-}
-
 extern "C" int oprl_profile_enable(int32_t on) {
   if (!on) prof_fold();
   g_prof.on = on != 0;
@@ -2103,398 +1439,6 @@ extern "C" int oprl_profile_read(int64_t* counts_host, double* ms_host, int32_t 
   return OPRL_OK;
 }
 extern "C" int oprl_abi_version(void) { return OPRL_ABI_VERSION; }
-
-extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner** out) {
-  if (!cfg || !out) { set_err("oprl_learner_create: null argument"); return OPRL_ERR_INVALID; }
-  if (cfg->abi_version != OPRL_ABI_VERSION) { set_err("ABI version mismatch: caller %d, library %d", cfg->abi_version, OPRL_ABI_VERSION); return OPRL_ERR_INVALID; }
-  if (cfg->algo < OPRL_DDPG || cfg->algo > OPRL_TQC) { set_err("unknown algo %d", cfg->algo); return OPRL_ERR_INVALID; }
-  if (cfg->precision != OPRL_PREC_F32 && cfg->precision != OPRL_PREC_BF16 && cfg->precision != OPRL_PREC_X2) { set_err("precision %d unknown", cfg->precision); return OPRL_ERR_INVALID; }
-  const int nc_expect = cfg->algo == OPRL_DDPG ? 1 : (cfg->algo == OPRL_TQC ? cfg->n_critics : 2);
-  if (cfg->n_critics != nc_expect || cfg->n_critics < 1 || cfg->n_critics > OPRL_MAX_CRITICS) {
-    set_err("n_critics=%d invalid for algo %d", cfg->n_critics, cfg->algo);
-    return OPRL_ERR_INVALID;
-  }
-  if (cfg->max_batch < 1 || cfg->state_dim < 1 || cfg->action_dim < 1) { set_err("bad dims"); return OPRL_ERR_INVALID; }
-  auto* h = new oprl_learner();
-  h->cfg = *cfg;
-  h->S = cfg->state_dim; h->A = cfg->action_dim; h->Bmax = cfg->max_batch; h->nc = cfg->n_critics;
-  h->bf16 = cfg->precision == OPRL_PREC_BF16;
-  h->x2 = cfg->precision == OPRL_PREC_X2;
-  h->planes = h->x2 ? 2 : 1;
-  int rc = check_net(cfg->actor, "actor", &h->w_actor);
-  for (int j = 0; rc == OPRL_OK && j < h->nc; ++j) {
-    int w = 0;
-    rc = check_net(cfg->critics[j], "critic", &w);
-    if (rc == OPRL_OK && j > 0 && w != h->w_critic) { set_err("critics differ in width"); rc = OPRL_ERR_INVALID; }
-    h->w_critic = w;
-    if (rc == OPRL_OK && cfg->critics[j].dims[0] != h->S + h->A) { set_err("critic input dim != S+A"); rc = OPRL_ERR_INVALID; }
-    if (rc == OPRL_OK && (!cfg->critics[j].theta_target || !cfg->critics[j].adam_m || !cfg->critics[j].adam_v)) {
-      set_err("critic %d: theta_target/adam_m/adam_v required", j); rc = OPRL_ERR_INVALID;
-    }
-  }
-  const bool gauss = cfg->algo == OPRL_SAC || cfg->algo == OPRL_TQC;
-  if (rc == OPRL_OK && cfg->actor.dims[0] != h->S) { set_err("actor input dim != S"); rc = OPRL_ERR_INVALID; }
-  if (rc == OPRL_OK && cfg->actor.dims[cfg->actor.n_layers] != (gauss ? 2 : 1) * h->A) { set_err("actor output dim mismatch"); rc = OPRL_ERR_INVALID; }
-  if (rc == OPRL_OK && (!cfg->actor.adam_m || !cfg->actor.adam_v)) { set_err("actor adam state required"); rc = OPRL_ERR_INVALID; }
-  if (rc == OPRL_OK && !gauss && !cfg->actor.theta_target) { set_err("actor target required for DDPG/TD3"); rc = OPRL_ERR_INVALID; }
-  if (rc == OPRL_OK && cfg->algo == OPRL_TQC) {
-    const int Q = cfg->hp.n_quantiles;
-    if (Q < 1 || Q > kNarrowMax || h->nc * Q > 128 || cfg->hp.top_quantiles_to_drop < 0 ||
-        cfg->hp.top_quantiles_to_drop >= h->nc * Q || cfg->critics[0].dims[cfg->critics[0].n_layers] != Q) {
-      set_err("TQC quantile configuration unsupported"); rc = OPRL_ERR_INVALID;
-    }
-  }
-  const bool learned_alpha = cfg->algo == OPRL_TQC || (cfg->algo == OPRL_SAC && cfg->hp.tune_alpha);
-  if (rc == OPRL_OK && learned_alpha && (!cfg->log_alpha || !cfg->log_alpha_m || !cfg->log_alpha_v)) {
-    set_err("log_alpha and its Adam state are required"); rc = OPRL_ERR_INVALID;
-  }
-  if (rc == OPRL_OK && cfg->export_grads && learned_alpha && !cfg->log_alpha_grad) {
-    set_err("export_grads with a learned temperature needs log_alpha_grad"); rc = OPRL_ERR_INVALID;
-  }
-  if (rc == OPRL_OK && cfg->export_grads) {
-    if (!cfg->actor.grad) { set_err("export_grads needs grad arenas"); rc = OPRL_ERR_INVALID; }
-    for (int j = 0; j < h->nc; ++j) if (!cfg->critics[j].grad) { set_err("export_grads needs grad arenas"); rc = OPRL_ERR_INVALID; }
-  }
-  if (rc != OPRL_OK) { delete h; return rc; }
-
-  hipError_t e = init_kernel_attrs();
-  if (e == hipSuccess) e = init_fused_attrs();
-  if (e == hipSuccess) e = init_slice_tp_attrs();
-  if (e == hipSuccess) e = init_layerwise_attrs();
-  if (e != hipSuccess) { set_err("hipFuncSetAttribute: %s", hipGetErrorString(e)); delete h; return OPRL_ERR_HIP; }
-  memset(&h->src, 0, sizeof h->src);
-  memset(&h->next_src, 0, sizeof h->next_src);
-  if (h->nc > 2) {
-    bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
-    for (int j = 1; ok && j < h->nc; ++j)
-      ok = hipStreamCreateWithFlags(&h->side[j], hipStreamNonBlocking) == hipSuccess &&
-           hipEventCreateWithFlags(&h->ev_join[j], hipEventDisableTiming) == hipSuccess;
-    h->have_side = ok;
-  }
-  h->fused = (cfg->algo == OPRL_DDPG || cfg->algo == OPRL_TD3 || (cfg->algo == OPRL_SAC && h->nc == 2)) &&
-             !cfg->no_fuse && h->w_actor == 256 && h->w_critic == 256 && cfg->actor.n_layers == 3 &&
-             cfg->critics[0].n_layers == 3;
-
-  const int B = h->Bmax, S = h->S, A = h->A, nc = h->nc;
-  // scalar critics: q' is read with stride 1 by the TD seed; TQC: [B][ldq] quantile rows
-  h->ldq = cfg->algo == OPRL_TQC ? round_up(cfg->critics[0].dims[cfg->critics[0].n_layers], 4) : 1;
-  const int n_slices = (B + kR - 1) / kR;
-  size_t floats = net_ws_floats(cfg->actor, B);
-  for (int j = 0; j < nc; ++j) floats += net_ws_floats(cfg->critics[j], B);
-  floats += (size_t)B * A + B + (size_t)nc * B * h->ldq + (size_t)B * A + (size_t)B * 2 * A + B +
-            (size_t)nc * B * A + (size_t)nc * B + (size_t)B * 128 + 2 * (size_t)B;
-  floats += (size_t)(nc + 1) * n_slices * 4 + 16;
-  floats += (size_t)B * (2 * S + A + 2);
-  floats += 64 * 32 + 6 * (size_t)B + 512;      // (granule arrays: y, q1, q2; 256 gate flags)
-  const int Bm = B < 256 ? B : 256;             // merged phase 2 serves one 256-row chunk
-  const bool merge2_bufs = h->fused && cfg->algo != OPRL_SAC && A <= kDuLd;
-  if (merge2_bufs) floats += 2 * ((size_t)Bm * kDuLd + 64) + 2 * 256 + 128 + 2 * (size_t)16 * Bm * 16 + 64 + 16 * 256 + 4 * 64 + 2 * 256 + 64 + kMaxLayers * 256 + 64;
-  if (merge2_bufs) floats += 2 * (192 + 192 + 64 + 128 + 1024) + 64 + 4 * kMaxLayers * 256 + 64 + 16 * 256 + 64 + (size_t)kDuLd * Bm * 256 + 64;      // (k_ddpg_chain)
-  if (h->bf16 || h->x2) {
-    floats += 2 * ((size_t)net_pack16_floats(cfg->actor, h->planes) + 64);
-    for (int j = 0; j < nc; ++j) floats += 2 * ((size_t)net_pack16_floats(cfg->critics[j], h->planes) + 64);
-  }
-  const size_t bytes = floats * sizeof(float) + 8192 + sizeof(DwItem) * (size_t)(nc + 1) * kMaxLayers +
-                       sizeof(RepackItem) * (size_t)(4 * nc + 4) * kMaxLayers;
-  // PrecX2 learners: the workspace — activation exchange buffers, granules, staged rows — in UNCACHED device memory
-  // (measured: no slower than cached, r03 log), so that a role of the whole-update launch reads what an earlier role
-  // of the same launch wrote
-  h->fchain = h->fused && !h->x2 && !h->bf16 && cfg->algo == OPRL_DDPG && nc == 1 && !cfg->export_grads && merge2_bufs &&
-              cfg->actor.theta_target != nullptr && cfg->critics[0].theta_target != nullptr && cfg->actor.n_layers == 3 && cfg->critics[0].n_layers == 3;
-  const int uc_pool = (h->x2 || h->fchain) ? 1 : 0;
-  h->uc_pool = uc_pool != 0;
-  if ((uc_pool ? uc_alloc((void**)&h->pool.base, bytes) : hipMalloc(&h->pool.base, bytes)) != hipSuccess) { set_err("hipMalloc(%zu) failed", bytes); delete h; return OPRL_ERR_NOMEM; }
-  h->pool.cap = bytes;
-  (void)hipMemset(h->pool.base, 0, bytes);
-  {
-    // the error word: host memory the device can write (only ever on the error path)
-    void* eh = nullptr; void* ed = nullptr;
-    if (hipHostMalloc(&eh, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-        hipHostGetDevicePointer(&ed, eh, 0) != hipSuccess) {
-      set_err("hipHostMalloc(error word) failed");
-      if (eh) (void)hipHostFree(eh);
-      dev_free(h->pool.base); delete h; return OPRL_ERR_NOMEM;
-    }
-    memset(eh, 0, 64);
-    h->err_host = (unsigned*)eh;
-    h->err_dev = (unsigned*)ed;
-  }
-  Pool& p = h->pool;
-  alloc_net_ws(p, cfg->actor, B, &h->ws_actor);
-  for (int j = 0; j < nc; ++j) alloc_net_ws(p, cfg->critics[j], B, &h->ws_critic[j]);
-  h->a2 = p.take<float>((size_t)B * A);
-  h->logp2 = p.take<float>(B);
-  h->qn = p.take<float>((size_t)nc * B * h->ldq);
-  h->pi = p.take<float>((size_t)B * A);
-  h->raw = p.take<float>((size_t)B * 2 * A);
-  h->logp = p.take<float>(B);
-  h->da = p.take<float>((size_t)nc * B * A);
-  h->qpi = p.take<float>((size_t)nc * B);
-  h->target = p.take<float>((size_t)B * 128);
-  h->ydbg = p.take<float>(B);
-  h->qdbg = p.take<float>(B);
-  h->part_c = p.take<float>((size_t)nc * n_slices * 4);
-  h->part_a = p.take<float>((size_t)n_slices * 4);
-  h->scalars = p.take<float>(16);
-  h->alpha_grad = cfg->log_alpha_grad ? cfg->log_alpha_grad : p.take<double>(2);
-  h->y_granules = p.take<unsigned long long>((size_t)3 * B + 256);
-  if (merge2_bufs) {
-    h->du_granules = p.take<unsigned long long>((size_t)Bm * kDuLd);
-    h->g1_granules = p.take<unsigned long long>((size_t)16 * Bm * 16);
-    h->w3_snap = p.take<float>(16 * 256);
-    h->w_flags = p.take<unsigned long long>(256);
-    h->chain_flags = p.take<unsigned long long>(192 + 192 + 64 + 128 + 1024);
-    h->gu = p.take<float>((size_t)kDuLd * Bm * 256);
-    h->chain_b16 = p.take<float>(4 * kMaxLayers * 256);
-    h->critic_b16 = h->chain_b16 + 2 * kMaxLayers * 256;
-    h->w3buf1 = p.take<float>(16 * 256);
-  }
-  h->bs = p.take<float>((size_t)B * S);
-  h->ba = p.take<float>((size_t)B * A);
-  h->br = p.take<float>(B);
-  h->bd = p.take<float>(B);
-  h->bs2 = p.take<float>((size_t)B * S);
-  // the two-plane packs of a PrecX2 learner in UNCACHED device memory — every load and store goes to the fabric, so
-  // that a workgroup reads what a workgroup on another XCD has just written without a kernel boundary in between
-  // (measured: no slower than cached, r03 log)
-  if (h->x2) {
-    size_t fl = 2 * ((size_t)net_pack16_floats(cfg->actor, 2) + 64);
-    for (int j = 0; j < nc; ++j) fl += 2 * ((size_t)net_pack16_floats(cfg->critics[j], 2) + 64);
-    float* base = nullptr;
-    if (uc_alloc((void**)&base, fl * sizeof(float)) != hipSuccess) {
-      set_err("hipExtMallocWithFlags(uncached packs) failed"); dev_free(p.base); delete h; return OPRL_ERR_NOMEM;
-    }
-    (void)hipMemset(base, 0, fl * sizeof(float));
-    h->uc_base = base;
-    auto take = [&](size_t n) { float* q = base; base += (n + 63) & ~(size_t)63; return q; };
-    h->pack16[0] = take((size_t)net_pack16_floats(cfg->actor, 2));
-    h->pack16_t[0] = take((size_t)net_pack16_floats(cfg->actor, 2));
-    for (int j = 0; j < nc; ++j) {
-      h->pack16[1 + j] = take((size_t)net_pack16_floats(cfg->critics[j], 2));
-      h->pack16_t[1 + j] = take((size_t)net_pack16_floats(cfg->critics[j], 2));
-    }
-  } else if (h->fchain) {
-    // (the mirrors of the fp32 fragment packs: see oprl_learner::fchain)
-    const oprl_net* src[2] = {&h->cfg.actor, &h->cfg.critics[0]};
-    size_t fl = 0;
-    for (int k = 0; k < 2; ++k) fl += 2 * (((size_t)oprl_net_pack_floats(src[k]) + 63) & ~(size_t)63);
-    float* base = nullptr;
-    if (uc_alloc((void**)&base, fl * sizeof(float)) != hipSuccess) {
-      set_err("hipExtMallocWithFlags(uncached packs) failed"); dev_free(p.base); delete h; return OPRL_ERR_NOMEM;
-    }
-    (void)hipMemset(base, 0, fl * sizeof(float));
-    h->uc_base = base;
-    for (int k = 0; k < 2; ++k) {
-      const size_t n = ((size_t)oprl_net_pack_floats(src[k]) + 63) & ~(size_t)63;
-      h->fnet[k] = *src[k];
-      h->fnet[k].pack = base; base += n;
-      h->fnet[k].pack_target = base; base += n;
-    }
-  } else
-  if (h->bf16 || h->x2) {   // (the pool is zeroed: pad positions of the packs stay zero for good)
-    h->pack16[0] = p.take<float>((size_t)net_pack16_floats(cfg->actor, h->planes));
-    h->pack16_t[0] = p.take<float>((size_t)net_pack16_floats(cfg->actor, h->planes));
-    for (int j = 0; j < nc; ++j) {
-      h->pack16[1 + j] = p.take<float>((size_t)net_pack16_floats(cfg->critics[j], h->planes));
-      h->pack16_t[1 + j] = p.take<float>((size_t)net_pack16_floats(cfg->critics[j], h->planes));
-    }
-  }
-  std::vector<DwItem> items;
-  for (int j = 0; j < nc; ++j)
-    fill_items(eff(h, h->cfg.critics[j]), h->ws_critic[j], items, &h->tiles_critic, h->fused, h->pack16[1 + j], h->pack16_t[1 + j], h->planes);
-  h->n_items_critic = (int)items.size();
-  if (h->critic_b16 != nullptr && nc == 1)
-    for (int l = 0; l < h->n_items_critic; ++l) {
-      items[l].b16 = h->critic_b16 + 256 * l;
-      items[l].bt16 = h->chain_b16 + (3 * kMaxLayers + l) * 256;
-    }
-  fill_items(eff(h, h->cfg.actor), h->ws_actor, items, &h->tiles_actor, h->fused, h->pack16[0], h->pack16_t[0], h->planes);
-  h->n_items_actor = (int)items.size() - h->n_items_critic;
-  if (h->chain_b16 != nullptr && nc == 1)
-    for (int l = 0; l < h->n_items_actor; ++l) {
-      items[h->n_items_critic + l].b16 = h->chain_b16 + (0 * kMaxLayers + l) * 256;
-      items[h->n_items_critic + l].bt16 = h->chain_b16 + (1 * kMaxLayers + l) * 256;
-    }
-  h->items_host = items;
-  std::vector<RepackItem> rp[3];
-  {
-    const oprl_net* cn[OPRL_MAX_CRITICS];
-    for (int j = 0; j < nc; ++j) cn[j] = &h->cfg.critics[j];
-    const oprl_net* an[1] = {&h->cfg.actor};
-    build_repack_items(cn, nc, 1, rp[0], &h->rp_blocks[0]);
-    build_repack_items(cn, nc, 3, rp[1], &h->rp_blocks[1]);
-    build_repack_items(an, 1, 3, rp[2], &h->rp_blocks[2]);
-    for (int k = 0; k < 3; ++k) {
-      h->rp_n[k] = (int)rp[k].size();
-      h->rp_dev[k] = p.take<RepackItem>(rp[k].size());
-    }
-  }
-  if (p.used > p.cap) { set_err("internal: workspace pool overflow (%zu > %zu)", p.used, p.cap); dev_free(p.base); delete h; return OPRL_ERR_NOMEM; }
-  for (int k = 0; k < 3; ++k)
-    if (!rp[k].empty()) (void)hipMemcpy(h->rp_dev[k], rp[k].data(), sizeof(RepackItem) * rp[k].size(), hipMemcpyHostToDevice);
-  {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      h->n_cus = prop.multiProcessorCount;
-    const char* env = getenv("OPRL_AMD_CLUSTER");
-    h->ncl = env ? atoi(env) : kMaxCluster;
-    if (h->ncl != 1 && h->ncl != 2 && h->ncl != 4) h->ncl = kMaxCluster;
-    h->no_multi = false;
-    // OPRL_AMD_NO_RIDE = bit mask of the riders / joined launches to switch off (tests: each is bit-identical to the
-    // separate launches): 1 TD target on the target heads, 2 actor forward on the critic heads, 4 first hidden launch
-    // behind the actor's forward, 8 next rows on k_lw_dact, 16 wide dW kernel (kernels.hip), 32 hidden-layer pairs
-    const int no_ride = [] { const char* e = getenv("OPRL_AMD_NO_RIDE"); return e != nullptr ? atoi(e) : 0; }();
-    const char* nlw = getenv("OPRL_AMD_NO_LAYERWISE");
-    h->no_layerwise = (nlw != nullptr && atoi(nlw) != 0);
-    h->no_gather_ride = (no_ride & 8) != 0;
-    if (cfg->algo == OPRL_TQC || h->du_granules != nullptr) {
-      const size_t n = (size_t)h->Bmax * (2 * (size_t)h->S + h->A + 2);
-      // (PrecX2 learners: uncached, like the first staging set in the pool — inside k_ddpg_chain an update reads rows a
-      // workgroup of the update before has gathered)
-      if ((h->uc_pool ? uc_alloc((void**)&h->batch_alt, n * sizeof(float)) : hipMalloc(&h->batch_alt, n * sizeof(float))) != hipSuccess)
-        h->batch_alt = nullptr;   // (then: a gather launch per update)
-    }
-    h->no_fin_ride = (no_ride & 4) != 0;
-    if (cfg->algo == OPRL_TQC && h->w_critic == 512) {
-      const size_t n = (size_t)nc * (kMaxLayers - 1) * (size_t)h->Bmax * 512;
-      if (hipMalloc(&h->lw_scratch, n * sizeof(float)) != hipSuccess) h->lw_scratch = nullptr;   // (then: the nets' own buffers, no early launch)
-      {
-        const int pair_env = (no_ride & 32) != 0 ? 0 : 3;
-        const int nf = kMaxMulti * ((h->Bmax + 31) / 32) * 32;
-        void* fl = nullptr;
-        if (pair_env != 0 && hipMalloc(&fl, (size_t)nf * sizeof(unsigned long long)) == hipSuccess) {
-          (void)hipMemset(fl, 0, (size_t)nf * sizeof(unsigned long long));
-          h->lw_pairs.flags = (unsigned long long*)fl; h->lw_pairs.n_flags = nf; h->lw_pairs.use = pair_env & 3;
-          h->lw_pairs.err = h->err_dev;
-        }
-      }
-    }
-    h->no_af_ride = (no_ride & 2) != 0;
-    h->no_tqc_ride = (no_ride & 1) != 0;
-    if (cfg->algo == OPRL_TQC && nc * cfg->hp.n_quantiles <= 128) {
-      const size_t slices = (size_t)(h->Bmax + kR - 1) / kR;
-      if (hipMalloc(&h->tqc_counter, slices * sizeof(unsigned long long)) != hipSuccess) h->tqc_counter = nullptr;   // (then: the stand-alone launch)
-      else (void)hipMemset(h->tqc_counter, 0, slices * sizeof(unsigned long long));
-    }
-    const char* ndi = getenv("OPRL_AMD_NO_DP_INLINE");
-    h->no_dp_inline = (ndi != nullptr && atoi(ndi) != 0);
-    // OPRL_AMD_NO_SIDE_BY_SIDE: TD3 / SAC twin nets back to back instead of on clusters that wait for each other
-    const char* nsb = getenv("OPRL_AMD_NO_SIDE_BY_SIDE");
-    h->no_twin_split = (nsb != nullptr && atoi(nsb) != 0);
-    h->no_p2_pair = h->no_twin_split;
-    const char* nl = getenv("OPRL_AMD_NO_LEAN");
-    h->no_lean = (nl != nullptr && atoi(nl) != 0) ? 1 : 0;
-    // OPRL_AMD_FORM: the launch structure of the fused DDPG / TD3 update — "chain" (default: the whole update, several
-    // per launch), "two" (merged phase launches: phase 1 + the critic's tiles | phase 2 + the actor's), "p2" (phase 1
-    // merged, phase 2 and the actor's dW as launches of their own), "plain" (phases and dW launches)
-    h->no_merge = h->no_merge2 = h->no_whole = 0;
-    if (const char* f = getenv("OPRL_AMD_FORM")) {
-      if (!strcmp(f, "two")) h->no_whole = 1;
-      else if (!strcmp(f, "p2")) { h->no_whole = 1; h->no_merge2 = 1; }
-      else if (!strcmp(f, "plain")) { h->no_whole = 1; h->no_merge2 = 1; h->no_merge = 1; }
-    }
-    h->no_chain = 0;
-    if (const char* cm = getenv("OPRL_AMD_CHAIN")) { const int v = atoi(cm); if (v >= 1 && v <= kChainMax) h->chain_max = v; }
-    const char* nw = getenv("OPRL_AMD_NO_WIDE");
-    h->no_wide = (nw != nullptr && atoi(nw) != 0) ? 1 : 0;
-    // the generic per-net launches on clusters of 4 (slice_tp.hip): any net of the common shape
-    // (decided per net by tp_generic(): TQC's 512-wide critics stay on k_mlp_slice, its actor moves)
-    h->tp_generic_on = !h->no_lean && h->ncl == 4;
-  }
-  if (h->fused || h->tp_generic_on) {
-    const size_t slices = (size_t)(h->Bmax + kR - 1) / kR;
-    // (areas laid out for clusters of eight where wide clusters may run: DDPG / TD3, fp32, lean passes)
-    h->xnc = (h->fused && !h->bf16 && !h->no_lean && !h->no_wide && h->ncl == 4 &&
-              (cfg->algo == OPRL_DDPG || cfg->algo == OPRL_TD3)) ? 8 : kMaxCluster;
-    h->xbuf_granules = (size_t)(2 + nc) * slices * fused_xbuf_granules_per_cluster(h->xnc);
-    if (hipMalloc(&h->xbuf, h->xbuf_granules * sizeof(unsigned long long)) != hipSuccess) {
-      set_err("hipMalloc(cluster exchange area, %zu MB) failed", (h->xbuf_granules * 8) >> 20);
-      dev_free(p.base); delete h; return OPRL_ERR_NOMEM;
-    }
-    (void)hipMemset(h->xbuf, 0, h->xbuf_granules * sizeof(unsigned long long));
-  }
-  {
-    const oprl_net* nets[OPRL_MAX_CRITICS + 1];
-    for (int j = 0; j < nc; ++j) nets[j] = &h->cfg.critics[j];
-    nets[nc] = &h->cfg.actor;
-    float *p16[OPRL_MAX_CRITICS + 1], *p16t[OPRL_MAX_CRITICS + 1];
-    for (int j = 0; j < nc; ++j) { p16[j] = h->pack16[1 + j]; p16t[j] = h->pack16_t[1 + j]; }
-    p16[nc] = h->pack16[0]; p16t[nc] = h->pack16_t[0];
-    int prc = repack_nets(nets, nc + 1, 3, nullptr, (h->bf16 || h->x2) ? p16 : nullptr, (h->bf16 || h->x2) ? p16t : nullptr, h->planes);
-    if (prc == OPRL_OK && h->fchain) {
-      const oprl_net* fn[2] = {&h->fnet[0], &h->fnet[1]};
-      prc = repack_nets(fn, 2, 3, nullptr);
-    }
-    if (prc != OPRL_OK) { dev_free(p.base); delete h; return prc; }
-  }
-  if (h->x2 || h->fchain || (h->bf16 && cfg->algo == OPRL_TQC)) {
-    std::lock_guard<std::mutex> lk(g_lazy_mu);
-    g_lazy.push_back(h);
-    h->lazy_wide = cfg->algo == OPRL_TQC;
-  }
-  if (g_live.fetch_add(1) >= 1) (void)hipDeviceSynchronize();      // (from here on whole-update launches take turns: ChipTurn)
-  *out = h;
-  return OPRL_OK;
-}
-
-extern "C" int oprl_learner_sync_params(oprl_learner* h, void* stream) {
-  if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
-  const oprl_net* nets[OPRL_MAX_CRITICS + 1];
-  for (int j = 0; j < h->nc; ++j) nets[j] = &h->cfg.critics[j];
-  nets[h->nc] = &h->cfg.actor;
-  float *p16[OPRL_MAX_CRITICS + 1], *p16t[OPRL_MAX_CRITICS + 1];
-  for (int j = 0; j < h->nc; ++j) { p16[j] = h->pack16[1 + j]; p16t[j] = h->pack16_t[1 + j]; }
-  p16[h->nc] = h->pack16[0]; p16t[h->nc] = h->pack16_t[0];
-  h->stale32[0] = h->stale32[1] = false;     // (every pack is rebuilt from the master here)
-  h->stale_wide = false;
-  if (h->fchain) {
-    const oprl_net* fn[2] = {&h->fnet[0], &h->fnet[1]};
-    RC(repack_nets(fn, 2, 3, (hipStream_t)stream));
-  }
-  return repack_nets(nets, h->nc + 1, 3, (hipStream_t)stream, (h->bf16 || h->x2) ? p16 : nullptr, (h->bf16 || h->x2) ? p16t : nullptr, h->planes);
-}
-
-extern "C" int64_t oprl_net_pack_floats(const oprl_net* net) {
-  if (!net || net->n_layers < 1 || net->n_layers > OPRL_MAX_LAYERS) return -1;
-  return net_pack_floats(*net);
-}
-
-extern "C" int oprl_net_repack(const oprl_net* net, int32_t which, void* stream) {
-  if (!net) { set_err("oprl_net_repack: null net"); return OPRL_ERR_INVALID; }
-  int width = 0;
-  RC(check_net(*net, "net", &width));
-  const oprl_net* nets[1] = {net};
-  return repack_nets(nets, 1, which, (hipStream_t)stream);
-}
-
-extern "C" int oprl_learner_destroy(oprl_learner* h) {
-  if (!h) return OPRL_OK;
-  {
-    std::lock_guard<std::mutex> lk(g_lazy_mu);
-    g_lazy.erase(std::remove(g_lazy.begin(), g_lazy.end(), h), g_lazy.end());
-  }
-  (void)hipDeviceSynchronize();
-  g_live.fetch_sub(1);
-  if (h->rccl.comm && h->rccl.comm_destroy) (void)h->rccl.comm_destroy(h->rccl.comm);
-  if (h->xbuf) (void)hipFree(h->xbuf);
-  if (h->tqc_counter) (void)hipFree(h->tqc_counter);
-  if (h->lw_scratch) (void)hipFree(h->lw_scratch);
-  if (h->lw_pairs.flags) (void)hipFree(h->lw_pairs.flags);
-  dev_free(h->batch_alt);
-  dev_free(h->uc_base);
-  if (h->err_host) (void)hipHostFree(h->err_host);
-  if (h->act_pin) (void)hipHostFree(h->act_pin);
-  if (h->p2p.window) p2p_destroy(h->p2p);
-  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-  for (int j = 1; j < OPRL_MAX_CRITICS; ++j) {
-    if (h->ev_join[j]) (void)hipEventDestroy(h->ev_join[j]);
-    if (h->side[j]) (void)hipStreamDestroy(h->side[j]);
-  }
-  dev_free(h->pool.base);
-  delete h;
-  return OPRL_OK;
-}
 
 extern "C" int oprl_learner_update_phase(oprl_learner* h, int32_t phase, const float* s,
                                          const float* a, const float* r, const float* d,
@@ -2565,7 +1509,7 @@ extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, double grad_sc
   return OPRL_ERR_INVALID;
 }
 
-namespace {
+namespace oprl_host {
 // step_n's K-loop as launches of up to chain_max updates each (k_ddpg_chain); h->src: the replay's view, seed set.
 // set[2][5]: the two staging sets.  Also the data-parallel loop when the gradient exchange is inside the tiles.
 int chain_loop(oprl_learner* h, int K, int B, float* (*set)[5], void* stream) {
@@ -2605,7 +1549,7 @@ int chain_loop(oprl_learner* h, int K, int B, float* (*set)[5], void* stream) {
 bool chain_ok(oprl_learner* h, int B) {
   return ddpg_args(h, B).whole && B <= 256 && h->batch_alt != nullptr;
 }
-}  // namespace
+}  // namespace oprl_host
 
 extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t K, int32_t B,
                                    uint64_t seed, void* stream) {
@@ -2769,524 +1713,3 @@ extern "C" int oprl_learner_act_wait(oprl_learner* h, float* out_host, int32_t n
   return OPRL_OK;
 }
 
-// ===================================================================== packed learners
-// The reference trains several seeds as several processes (runners/train.py:36-50).  One DDPG learner at B = 256
-// is a chain of four latency-bound launches that keeps a fraction of the chip busy; a GROUP steps N independent
-// learners (own weights, own replay keys) with FOUR launches per update for all of them: grid.z = learner, the
-// argument blocks in device memory.  Group members run the single-CU-per-slice passes (cluster size 1): no
-// workgroup of such a launch waits for a later one, so the N x 48 phase-1 workgroups may simply queue behind
-// each other on the 256 CUs, and a learner's result does not depend on who else is in the launch.
-struct oprl_group {
-  std::vector<oprl_learner*> L;
-  // The argument blocks of kGroupChunk updates — per update [N x DdpgArgs phase 1][N x DdpgArgs phase 2][N x DwKArgsN<ni_c>
-  // critic(s)][N x DwKArgsG actor] — are built ahead on the host and go up in ONE copy per chunk (four copies per update
-  // of the 5 KB blocks stood for 56 of 424 us per group update of 32 members).
-  char* dev = nullptr;                         // [kGroupChunk][bytes]
-  char* stage[2] = {nullptr, nullptr};         // pinned host staging (double buffered), the same layout
-  hipEvent_t stage_ev[2] = {nullptr, nullptr};
-  bool stage_busy[2] = {false, false};
-  int cur = 0;
-  size_t bytes = 0;                            // one update's blocks
-  int span = 1;                                // XCDs a member's slices are dealt out to (generic passes: 1)
-  int ni_c = kDwGroupItems;                    // layers per critic-step dW block (twin critics: kDwGroupItems2)
-  int device = 0;                              // the device the group's buffers (and its members) live on
-};
-constexpr int kGroupChunk = 4;
-
-static void group_free(oprl_group* g) {
-  if (g->dev) (void)hipFree(g->dev);
-  for (int i = 0; i < 2; ++i) {
-    if (g->stage[i]) (void)hipHostFree(g->stage[i]);
-    if (g->stage_ev[i]) (void)hipEventDestroy(g->stage_ev[i]);
-  }
-  delete g;
-}
-
-extern "C" int oprl_group_create(oprl_learner** learners, int32_t n, oprl_group** out) {
-  if (!learners || !out || n < 1 || n > 64) { set_err("oprl_group_create: invalid argument"); return OPRL_ERR_INVALID; }
-  const int algo0 = learners[0] ? learners[0]->cfg.algo : -1;
-  for (int i = 0; i < n; ++i) {
-    oprl_learner* h = learners[i];
-    if (!h || (algo0 != OPRL_DDPG && algo0 != OPRL_TD3 && algo0 != OPRL_SAC) || h->cfg.algo != algo0 || !h->fused || h->cfg.export_grads ||
-        h->bf16 != learners[0]->bf16 || h->x2 != learners[0]->x2 || h->S != learners[0]->S || h->A != learners[0]->A ||
-        h->Bmax != learners[0]->Bmax || h->cfg.hp.policy_freq != learners[0]->cfg.hp.policy_freq ||
-        (alpha_ptr(h) != nullptr) != (alpha_ptr(learners[0]) != nullptr)) {
-      set_err("oprl_group_create: member %d is not a fused DDPG / TD3 / SAC learner of the group's algorithm, shape and precision", i);
-      return OPRL_ERR_INVALID;
-    }
-  }
-  // The members' launch form.  Exact fp32: the generic single-CU-per-slice passes (cluster size 1) — no workgroup of such
-  // a launch waits for another, and 32 members measure 71k updates/s against 58k on clusters of four.  bf16 / x2: the
-  // lean passes on clusters of four (the only form these precisions exist in).  OPRL_AMD_GROUP_NC=4: clusters of four
-  // for exact fp32 as well.  TD3 / SAC members (fused in the lean form only): clusters of four in every precision.
-  int group_nc = 4;
-  {
-    const int env_nc = 0;
-    oprl_learner* h0 = learners[0];
-    const int keep_ncl = h0->ncl;
-    const bool keep_sc = h0->shared_chip;
-    const int keep_nw = h0->no_wide;
-    h0->ncl = 4; h0->shared_chip = true; h0->no_wide = 1;
-    const bool lean = fused_ddpg_is_lean(ddpg_args(h0, h0->Bmax));
-    h0->ncl = keep_ncl; h0->shared_chip = keep_sc; h0->no_wide = keep_nw;
-    if (!lean || (algo0 == OPRL_DDPG && !h0->bf16 && !h0->x2 && env_nc != 4)) group_nc = 1;
-    if (group_nc == 1 && (h0->bf16 || h0->x2 || algo0 != OPRL_DDPG)) {
-      set_err("oprl_group_create: TD3 / SAC members and the bf16 / x2 modes need nets the lean passes take (256-wide hidden layers, narrow inputs)");
-      return OPRL_ERR_INVALID;
-    }
-  }
-  auto* g = new oprl_group();
-  g->L.assign(learners, learners + n);
-  (void)hipGetDevice(&g->device);
-  g->ni_c = learners[0]->nc == 2 ? kDwGroupItems2 : kDwGroupItems;
-  g->span = 1;        // (a member's slices on one XCD: 2 / 4 / 8 measured slower, r03-39)
-  g->bytes = (size_t)n * (2 * sizeof(DdpgArgs) + dw_group_block_bytes(g->ni_c) + dw_group_block_bytes(kDwGroupItems));
-  bool ok = hipMalloc((void**)&g->dev, g->bytes * kGroupChunk) == hipSuccess;
-  for (int i = 0; i < 2 && ok; ++i) {
-    ok = hipHostMalloc((void**)&g->stage[i], g->bytes * kGroupChunk) == hipSuccess &&
-         hipEventCreateWithFlags(&g->stage_ev[i], hipEventDisableTiming) == hipSuccess;
-  }
-  if (!ok) {      // (nothing is kept of a failed create: the partial allocations go, the members stay as they were)
-    group_free(g);
-    set_err("oprl_group_create: allocation failed");
-    return OPRL_ERR_NOMEM;
-  }
-  // (a solo run for comparison: oprl_learner_set_cluster(h, 4) — the un-merged lean launches — or (h, 1))
-  // (the twin critics' side-by-side forms want all of a slice's clusters resident at once: not in a queue of members)
-  for (oprl_learner* h : g->L) { h->ncl = group_nc; h->shared_chip = true; h->no_wide = 1; h->no_twin_split = true; h->no_p2_pair = true; }
-  *out = g;
-  return OPRL_OK;
-}
-
-extern "C" int oprl_group_destroy(oprl_group* g) {
-  if (!g) return OPRL_OK;
-  // the group's OWN device, whatever the caller's current one is: launches that read the argument blocks may be in flight
-  int cur = 0;
-  const int dev = g->device;
-  (void)hipGetDevice(&cur);
-  if (cur != dev) (void)hipSetDevice(dev);
-  (void)hipDeviceSynchronize();
-  group_free(g);
-  if (cur != dev) (void)hipSetDevice(cur);
-  return OPRL_OK;
-}
-
-extern "C" int oprl_learner_set_cluster(oprl_learner* h, int32_t nc) {
-  if (!h || (nc != 1 && nc != 2 && nc != 4 && nc != 8)) { set_err("oprl_learner_set_cluster: cluster size must be 1, 2, 4 or 8"); return OPRL_ERR_INVALID; }
-  // 8 = clusters of four, and of eight where the fused kernels have them (the default); 4 = never eight
-  h->ncl = nc == 8 ? 4 : nc;
-  static const bool env_off = [] { const char* e = getenv("OPRL_AMD_NO_WIDE"); return e != nullptr && atoi(e) != 0; }();
-  h->no_wide = (nc == 8 && !env_off) ? 0 : 1;
-  // ... and a learner that shares the chip (anything but 8) keeps to the launch forms whose workgroups only wait within
-  // their cluster: no tile workgroups riding on the phase launches (measured: 8 learners on 8 streams 47k -> 60k aggregate)
-  h->shared_chip = nc != 8;
-  return OPRL_OK;
-}
-
-// K updates of every member: per update one H2D copy of the N x 4 argument blocks and four launches.
-extern "C" int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, int32_t B, const uint64_t* seeds,
-                                 void* stream) {
-  if (!g || !replay || !seeds || K < 0) { set_err("oprl_group_step_n: invalid argument"); return OPRL_ERR_INVALID; }
-  const int n = (int)g->L.size();
-  oprl_learner* h0 = g->L[0];
-  if (B < 1 || B > h0->Bmax) { set_err("oprl_group_step_n: bad batch %d", B); return OPRL_ERR_INVALID; }
-  int S = 0, A = 0;
-  replay_dims(replay, &S, &A);
-  if (S != h0->S || A != h0->A) { set_err("replay dims (%d,%d) != group dims (%d,%d)", S, A, h0->S, h0->A); return OPRL_ERR_INVALID; }
-  hipStream_t st = (hipStream_t)stream;
-  RC(oprl_replay_flush(replay, stream));
-  // everything that can be refused is checked BEFORE any member's counters move: the members advance together, so
-  // being in phase now is being in phase for all K updates
-  for (int l = 0; l < n; ++l) {
-    RC(check_device_error(g->L[l]));
-    if (actor_due(g->L[l]) != actor_due(h0) || g->L[l]->cfg.hp.policy_freq != h0->cfg.hp.policy_freq) {
-      set_err("oprl_group_step_n: the members' delayed actor steps are out of phase (update counts differ modulo policy_freq)");
-      return OPRL_ERR_STATE;
-    }
-  }
-  // (what is left — an internal inconsistency of the launch tables — rolls the members' counters back to here)
-  struct Snap { unsigned epoch, tp_tag; long long update_count; int oc, oa, oal; bool staged, aul, s0, s1; };
-  std::vector<Snap> snap(n);
-  auto take = [&]() {
-    for (int l = 0; l < n; ++l) {
-      const oprl_learner* h = g->L[l];
-      snap[l] = Snap{h->epoch, h->tp_tag, (long long)h->update_count, (int)h->opt_step_critic, (int)h->opt_step_actor, (int)h->opt_step_alpha,
-                     h->staged_ready, h->actor_updated_last, h->stale32[0], h->stale32[1]};
-    }
-  };
-  auto roll_back = [&]() {
-    for (int l = 0; l < n; ++l) {
-      oprl_learner* h = g->L[l];
-      const Snap& q = snap[l];
-      h->epoch = q.epoch; h->tp_tag = q.tp_tag; h->update_count = q.update_count; h->opt_step_critic = q.oc; h->opt_step_actor = q.oa;
-      h->opt_step_alpha = q.oal; h->staged_ready = q.staged; h->actor_updated_last = q.aul; h->stale32[0] = q.s0; h->stale32[1] = q.s1;
-    }
-  };
-  for (int l = 0; l < n; ++l) {
-    oprl_learner* h = g->L[l];
-    BatchSrc& sc = h->src;
-    long n_tr = 0;
-    replay_view(replay, &sc.states, &sc.actions, &sc.rewards, &sc.dones, &sc.ends, &sc.n_eps, &sc.L, &n_tr);
-    if (n_tr <= 0 || sc.n_eps <= 0) { set_err("oprl_group_step_n: replay buffer is empty"); return OPRL_ERR_STATE; }
-    sc.n_transitions = n_tr;
-    sc.seed = seeds[l];
-    sc.gather = 1;
-    sc.s = h->bs; sc.a = h->ba; sc.r = h->br; sc.d = h->bd; sc.s2 = h->bs2;
-    h->next_src = sc;
-    h->staged_ready = false;
-    h->last_B = B;
-  }
-  static_assert(sizeof(DdpgArgs) % 8 == 0 && sizeof(DwKArgsG) % 8 == 0 && sizeof(DwKArgsG2) % 8 == 0, "the blocks of an update lie back to back");
-  const size_t dc_bytes = dw_group_block_bytes(g->ni_c), da_bytes = dw_group_block_bytes(kDwGroupItems);
-  for (oprl_learner* h : g->L) h->noise1_pending = nullptr;
-  for (int k0 = 0; k0 < K; k0 += kGroupChunk) {
-    const int m = K - k0 < kGroupChunk ? K - k0 : kGroupChunk;
-    const int c = g->cur;
-    if (g->stage_busy[c]) { HIPC(hipEventSynchronize(g->stage_ev[c])); g->stage_busy[c] = false; }
-    take();                                   // nothing of this chunk has been launched until its blocks are complete
-    int tiles_c = 0, tiles_a = 0;
-    DdpgArgs first[kGroupChunk][2];           // member 0's blocks of each update (for the grids)
-    bool due[kGroupChunk];                    // TD3: the actor steps every policy_freq updates — of ALL members at once
-    for (int j = 0; j < m; ++j) {
-      const int k = k0 + j;
-      DdpgArgs* p1 = reinterpret_cast<DdpgArgs*>(g->stage[c] + (size_t)j * g->bytes);
-      DdpgArgs* p2 = p1 + n;
-      char* dc = reinterpret_cast<char*>(p2 + n);
-      char* da = dc + (size_t)n * dc_bytes;
-      due[j] = actor_due(g->L[0]);
-      for (int l = 0; l < n; ++l) {
-        oprl_learner* h = g->L[l];
-        const oprl_learner_config& cf = h->cfg;
-        if (actor_due(h) != due[j]) { roll_back(); set_err("oprl_group_step_n: the members' delayed actor steps are out of phase (update counts differ modulo policy_freq)"); return OPRL_ERR_STATE; }
-        h->src.counter = (unsigned long long)h->update_count;
-        h->next_src.counter = h->src.counter + 1;
-        h->src.gather = h->staged_ready ? 0 : 1;
-        h->staged_ready = false;
-        const int prefetch = (k + 1 < K && due[j]) ? 1 : 0;     // (the row of phase 2's launch: actor steps only)
-        h->epoch += 1;
-        if (h->epoch == 0) { h->epoch = 1; HIPC(hipMemsetAsync(h->y_granules, 0, ((size_t)3 * h->Bmax + 256) * sizeof(unsigned long long), st)); }
-        p1[l] = ddpg_args(h, B);
-        p1[l].group_span = g->span;
-        RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &p1[l].cluster_tag));
-        DwKArgs kd;
-        // (as the un-merged launches of a solo learner; TD3 moves its targets on actor steps only)
-        DwArgs dw = dw_build(h, true, B, cf.algo == OPRL_TD3 ? due[j] : true, false);
-        const int tc = fill_dw_kargs(dw, &kd) < 0 ? -1 : compact_dw_kargs(kd, dc + (size_t)l * dc_bytes, g->ni_c);
-        int ta = tiles_a;
-        if (due[j]) {
-          p2[l] = ddpg_args(h, B);
-          p2[l].group_span = g->span;
-          RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &p2[l].cluster_tag));   // (a launch, a tag)
-          p2[l].prefetch_next = prefetch;
-          h->staged_ready = prefetch != 0;
-          dw = dw_build(h, false, B, cf.actor.theta_target != nullptr, alpha_rides(h));    // (SAC: the temperature step rides)
-          ta = fill_dw_kargs(dw, &kd) < 0 ? -1 : compact_dw_kargs(kd, da + (size_t)l * da_bytes, kDwGroupItems);
-          if (l == 0 && tiles_a == 0) tiles_a = ta;
-          if (ta < 0 || ta != tiles_a || p2[l].nc != p1[l].nc || p2[l].merged || p2[l].wide || p2[l].whole || p2[l].p2_pair) ta = -1;
-        }
-        if (l == 0 && j == 0) tiles_c = tc;
-        if (tc < 0 || ta < 0 || tc != tiles_c || p1[l].nc != p1[0].nc || p1[l].merged || p1[l].wide || p1[l].whole || p1[l].twin_split) {
-          roll_back();
-          set_err("oprl_group_step_n: internal: bad launch arguments");
-          return OPRL_ERR_INVALID;
-        }
-        h->actor_updated_last = due[j];
-        h->update_count += 1;
-      }
-      first[j][0] = p1[0];
-      if (due[j]) first[j][1] = p2[0];
-    }
-    HIPC(hipMemcpyAsync(g->dev, g->stage[c], g->bytes * m, hipMemcpyHostToDevice, st));
-    HIPC(hipEventRecord(g->stage_ev[c], st));
-    g->stage_busy[c] = true;
-    g->cur ^= 1;
-    for (int j = 0; j < m; ++j) {
-      const DdpgArgs* p1 = reinterpret_cast<const DdpgArgs*>(g->dev + (size_t)j * g->bytes);
-      const DdpgArgs* p2 = p1 + n;
-      const char* dc = reinterpret_cast<const char*>(p2 + n);
-      const char* da = dc + (size_t)n * dc_bytes;
-      HIPC(launch_ddpg_phase1_group(first[j][0], p1, n, st));
-      HIPC(launch_dw_adam_group(dc, g->ni_c, n, tiles_c, st));
-      if (!due[j]) continue;
-      HIPC(launch_ddpg_phase2_group(first[j][1], p2, n, st));
-      HIPC(launch_dw_adam_group(da, kDwGroupItems, n, tiles_a, st));
-    }
-  }
-  for (oprl_learner* h : g->L) { h->src.gather = 0; h->prefetch_next = 0; h->staged_ready = false; }
-  return OPRL_OK;
-}
-
-extern "C" int oprl_learner_read_scalars(oprl_learner* h, float* out_host, int32_t n, void* stream) {
-  if (!h || !out_host || n < 1) { set_err("oprl_learner_read_scalars: invalid argument"); return OPRL_ERR_INVALID; }
-  hipStream_t st = (hipStream_t)stream;
-  const int B = h->last_B > 0 ? h->last_B : 1;
-  const int n_slices = (B + kR - 1) / kR;
-  const oprl_learner_config& c = h->cfg;
-  float loss_scale = 1.0f / (float)B;
-  if (c.algo == OPRL_TQC) {
-    const int Q = c.hp.n_quantiles, M = h->nc * Q - c.hp.top_quantiles_to_drop;
-    loss_scale = 1.0f / ((float)B * (float)h->nc * (float)Q * (float)M);
-  }
-  // critic partials of all critics are contiguous: loss sums over critics (td1 + td2)
-  HIPC(launch_reduce_partials(h->part_c, n_slices * h->nc, h->scalars, 0, loss_scale,
-                              1.0f / ((float)B * (float)h->nc), st));
-  HIPC(launch_reduce_partials(h->part_a, n_slices, h->scalars, 4, 0.f, -1.0f / (float)B, st));
-  // critic 0 alone (the reference logs q1, not the twin mean) and the mean log-density of the actor step
-  HIPC(launch_reduce_partials(h->part_c, n_slices, h->scalars, 8, loss_scale, 1.0f / (float)B, st));
-  const bool gauss = c.algo == OPRL_SAC || c.algo == OPRL_TQC;
-  if (gauss) HIPC(launch_sum(h->logp, B, h->scalars, 12, 1.0f / (float)B, st));
-  float host[16] = {0};
-  HIPC(hipMemcpyAsync(host, h->scalars, sizeof(float) * 13, hipMemcpyDeviceToHost, st));
-  double la = 0.0;
-  const double* lap = alpha_ptr(h);
-  if (lap) HIPC(hipMemcpyAsync(&la, lap, sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPC(hipStreamSynchronize(st));
-  RC(check_device_error(h));      // after the synchronisation: definitive for everything launched so far
-  float res[6];
-  res[0] = host[0];                 // critic loss
-  res[1] = host[5];                 // actor loss (-mean q part)
-  res[2] = host[1];                 // mean q
-  res[3] = host[2];                 // mean TD target
-  res[4] = lap ? (float)exp(la) : (float)c.hp.alpha_init;
-  res[5] = (float)h->update_count;
-  float res2[4];
-  res2[0] = host[9];                                  // mean q of critic 0 (the reference's "q1")
-  res2[1] = gauss ? host[12] : 0.f;                   // mean log pi(a|s) of the last actor step
-  // SAC / TQC actor loss as the reference forms it: alpha * mean(log pi) - mean(min q)   (sac.py:124-126)
-  res2[2] = gauss ? res[4] * res2[1] + res[1] : res[1];
-  // temperature loss -log_alpha * (target_entropy + mean log pi)   (sac.py:133-135; with the CURRENT log_alpha)
-  res2[3] = lap ? (float)(-la * (c.hp.target_entropy + (double)res2[1])) : 0.f;
-  for (int i = 0; i < n && i < 6; ++i) out_host[i] = res[i];
-  for (int i = 6; i < n && i < 10; ++i) out_host[i] = res2[i - 6];
-  return OPRL_OK;
-}
-
-extern "C" int oprl_learner_set_trace(oprl_learner* h, int64_t* buf) {
-  if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
-  h->trace = (long long*)buf;
-  return OPRL_OK;
-}
-
-extern "C" int oprl_learner_update_count(oprl_learner* h, int64_t* out_host) {
-  if (!h || !out_host) { set_err("null argument"); return OPRL_ERR_INVALID; }
-  *out_host = h->update_count;
-  return OPRL_OK;
-}
-
-extern "C" int oprl_learner_set_update_count(oprl_learner* h, int64_t count) {
-  if (!h || count < 0) { set_err("invalid argument"); return OPRL_ERR_INVALID; }
-  h->update_count = count;
-  return OPRL_OK;
-}
-
-extern "C" int oprl_learner_set_seed(oprl_learner* h, uint64_t seed, int32_t rank) {
-  if (!h || rank < 0) { set_err("oprl_learner_set_seed: invalid argument"); return OPRL_ERR_INVALID; }
-  h->noise_seed = seed;
-  h->noise_rank = rank;
-  return OPRL_OK;
-}
-
-extern "C" int oprl_learner_get_counters(oprl_learner* h, int64_t out_host[OPRL_N_COUNTERS]) {
-  if (!h || !out_host) { set_err("null argument"); return OPRL_ERR_INVALID; }
-  out_host[0] = h->update_count;
-  out_host[1] = h->opt_step_critic;
-  out_host[2] = h->opt_step_actor;
-  out_host[3] = h->opt_step_alpha;
-  return OPRL_OK;
-}
-
-extern "C" int oprl_learner_set_counters(oprl_learner* h, const int64_t in_host[OPRL_N_COUNTERS]) {
-  if (!h || !in_host) { set_err("null argument"); return OPRL_ERR_INVALID; }
-  for (int k = 0; k < OPRL_N_COUNTERS; ++k)
-    if (in_host[k] < 0 || in_host[k] > 0x7fffffffLL) { set_err("counter %d out of range", k); return OPRL_ERR_INVALID; }
-  h->update_count = in_host[0];
-  h->opt_step_critic = (int)in_host[1];
-  h->opt_step_actor = (int)in_host[2];
-  h->opt_step_alpha = (int)in_host[3];
-  return OPRL_OK;
-}
-
-extern "C" int oprl_learner_debug_ptrs(oprl_learner* h, const float** q, const float** y) {
-  if (!h) { set_err("null learner handle"); return OPRL_ERR_INVALID; }
-  if (q) *q = h->qdbg;
-  if (y) *y = h->ydbg;
-  return OPRL_OK;
-}
-
-// (debug) device views of the workspace a fused DDPG update leaves behind: tools/race_hunt.py compares them between a
-// chain learner and a one-update-per-launch learner.  which: 0..2 the actor's X rows, 3 pi, 4 unit-seed rows, 5 du granules
-// (8 bytes each), 6..8 the critic's X rows, 9 / 10 the critic's dY rows (first hidden partials | second hidden), 11 the TD
-// seed granules, 12 the batch rows of the last update's set (s), 13 the other set
-extern "C" int oprl_learner_debug_view(oprl_learner* h, int32_t which, const void** ptr, int64_t* n_bytes) {
-  if (!h || !ptr || !n_bytes) { set_err("oprl_learner_debug_view: invalid argument"); return OPRL_ERR_INVALID; }
-  const size_t B = (size_t)h->Bmax;
-  const void* p = nullptr;
-  size_t n = 0;
-  switch (which) {
-    case 0: p = h->ws_actor.X[0]; n = B * h->ws_actor.ldx0 * 4; break;
-    case 1: p = h->ws_actor.X[1]; n = B * h->ws_actor.width * 4; break;
-    case 2: p = h->ws_actor.X[2]; n = B * h->ws_actor.width * 4; break;
-    case 3: p = h->pi; n = B * h->A * 4; break;
-    case 4: p = h->gu; n = h->gu ? (size_t)h->A * (B < 256 ? B : 256) * 256 * 4 : 0; break;
-    case 5: p = h->du_granules; n = h->du_granules ? (B < 256 ? B : 256) * kDuLd * 8 : 0; break;
-    case 6: p = h->ws_critic[0].X[0]; n = B * h->ws_critic[0].ldx0 * 4; break;
-    case 7: p = h->ws_critic[0].X[1]; n = B * h->ws_critic[0].width * 4; break;
-    case 8: p = h->ws_critic[0].X[2]; n = B * h->ws_critic[0].width * 4; break;
-    case 9: p = h->ws_critic[0].dY[0]; n = B * h->ws_critic[0].width * 4; break;
-    case 10: p = h->ws_critic[0].dY[1]; n = B * h->ws_critic[0].width * 4; break;
-    case 11: p = h->y_granules; n = B * 8; break;
-    case 12: p = h->bs; n = B * h->S * 4; break;
-    case 13: p = h->batch_alt; n = h->batch_alt ? B * h->S * 4 : 0; break;
-    default: set_err("oprl_learner_debug_view: no such view"); return OPRL_ERR_INVALID;
-  }
-  *ptr = p; *n_bytes = (int64_t)n;
-  return OPRL_OK;
-}
-
-// ---------------------------------------------------------------- building blocks
-namespace {
-struct TmpBuf {  // small per-thread device scratch for the stand-alone MLP calls
-  float* p = nullptr;
-  size_t cap = 0;
-  float* get(size_t floats) {
-    if (floats > cap) {
-      if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; cap = 0; }
-      if (hipMalloc(&p, floats * sizeof(float)) != hipSuccess) return nullptr;
-      cap = floats;
-    }
-    return p;
-  }
-};
-thread_local TmpBuf g_tmp;
-bool g_attrs_done = false;
-}  // namespace
-
-extern "C" int oprl_mlp_forward(const oprl_net* net, int32_t use_target, const float* x0, int32_t k0,
-                                const float* x1, int32_t k1, int32_t B, int32_t out_act, float* out,
-                                void* stream) {
-  if (!net || !x0 || !out || B < 1) { set_err("oprl_mlp_forward: invalid argument"); return OPRL_ERR_INVALID; }
-  int width = 0;
-  RC(check_net(*net, "net", &width));
-  if (use_target && !net->theta_target) { set_err("oprl_mlp_forward: no target arena"); return OPRL_ERR_INVALID; }
-  if (k0 + (x1 ? k1 : 0) != net->dims[0]) { set_err("oprl_mlp_forward: k0+k1=%d != input dim %d", k0 + (x1 ? k1 : 0), net->dims[0]); return OPRL_ERR_INVALID; }
-  if (out_act != ACT_NONE && out_act != ACT_TANH && out_act != ACT_GAUSS_MEAN) { set_err("oprl_mlp_forward: out_act %d unsupported here", out_act); return OPRL_ERR_INVALID; }
-  if (!g_attrs_done) { HIPC(init_kernel_attrs()); g_attrs_done = true; }
-  RC(fresh32(net, (hipStream_t)stream));
-  MlpArgs a;
-  memset(&a, 0, sizeof a);
-  a.net = net_view(*net, use_target != 0);
-  a.B = B; a.do_fwd = 1;
-  a.x0 = x0; a.k0 = k0; a.x1 = x1; a.k1 = x1 ? k1 : 0;
-  a.out_act = out_act;
-  const int nout = net->dims[net->n_layers];
-  a.action_dim = nout / 2;
-  a.out = out; a.ldo = (out_act == ACT_GAUSS_MEAN) ? nout / 2 : nout;
-  return launch(a, width, (hipStream_t)stream);
-}
-
-// One observation in HOST memory -> one output row in HOST memory: what a policy's explore() /
-// exploit() does once per environment step (reference nn_models.py:138-150, 180-195: as_tensor ->
-// forward -> .cpu()).  Pinned staging rows on both sides, one H2D copy, one slice launch, one D2H
-// copy and a stream sync — four runtime calls instead of the dozen torch dispatches around
-// oprl_mlp_forward (37 us for as_tensor alone).
-namespace {
-struct ActStage {
-  std::mutex mu;
-  float* host = nullptr;   // pinned: [0, 256) observation, [256, 512) output
-  float* dev = nullptr;    // device: same layout
-};
-ActStage g_act;
-}  // namespace
-
-extern "C" int oprl_mlp_act(const oprl_net* net, const float* obs_host, int32_t k0, int32_t out_act,
-                            float* out_host, int32_t n_out, void* stream) {
-  if (!net || !obs_host || !out_host) { set_err("oprl_mlp_act: invalid argument"); return OPRL_ERR_INVALID; }
-  int width = 0;
-  RC(check_net(*net, "net", &width));
-  const int nout = net->dims[net->n_layers];
-  const int want = (out_act == ACT_GAUSS_MEAN) ? nout / 2 : nout;
-  if (k0 != net->dims[0] || k0 > 256 || n_out != want || want > 256) {
-    set_err("oprl_mlp_act: dims (%d in, %d out) do not match the net (%d in, %d out)", k0, n_out, net->dims[0], want);
-    return OPRL_ERR_INVALID;
-  }
-  if (out_act != ACT_NONE && out_act != ACT_TANH && out_act != ACT_GAUSS_MEAN) { set_err("oprl_mlp_act: out_act %d unsupported here", out_act); return OPRL_ERR_INVALID; }
-  if (!g_attrs_done) { HIPC(init_kernel_attrs()); g_attrs_done = true; }
-  hipStream_t st = (hipStream_t)stream;
-  RC(fresh32(net, st));
-  std::lock_guard<std::mutex> lk(g_act.mu);
-  if (g_act.host == nullptr) {
-    HIPC(hipHostMalloc((void**)&g_act.host, 512 * sizeof(float), hipHostMallocDefault));
-    HIPC(hipMalloc((void**)&g_act.dev, 512 * sizeof(float)));
-  }
-  memcpy(g_act.host, obs_host, sizeof(float) * k0);
-  HIPC(hipMemcpyAsync(g_act.dev, g_act.host, sizeof(float) * k0, hipMemcpyHostToDevice, st));
-  MlpArgs a;
-  memset(&a, 0, sizeof a);
-  a.net = net_view(*net, false);
-  a.B = 1; a.do_fwd = 1;
-  a.x0 = g_act.dev; a.k0 = k0;
-  a.out_act = out_act;
-  a.action_dim = nout / 2;
-  a.out = g_act.dev + 256; a.ldo = want;
-  RC(launch(a, width, st));
-  HIPC(hipMemcpyAsync(g_act.host + 256, g_act.dev + 256, sizeof(float) * want, hipMemcpyDeviceToHost, st));
-  HIPC(hipStreamSynchronize(st));
-  memcpy(out_host, g_act.host + 256, sizeof(float) * want);
-  return OPRL_OK;
-}
-
-extern "C" int oprl_mlp_backward(const oprl_net* net, const float* x0, int32_t k0, const float* x1,
-                                 int32_t k1, int32_t B, const float* dout, float* dx, void* stream) {
-  if (!net || !x0 || !dout || B < 1 || !net->grad) { set_err("oprl_mlp_backward: invalid argument (grad arena required)"); return OPRL_ERR_INVALID; }
-  int width = 0;
-  RC(check_net(*net, "net", &width));
-  if (k0 + (x1 ? k1 : 0) != net->dims[0]) { set_err("oprl_mlp_backward: input dims mismatch"); return OPRL_ERR_INVALID; }
-  if (!g_attrs_done) { HIPC(init_kernel_attrs()); g_attrs_done = true; }
-  hipStream_t st = (hipStream_t)stream;
-  RC(fresh32(net, st));
-  NetWs ws;
-  float* base = g_tmp.get(net_ws_floats(*net, B) + sizeof(DwItem) * kMaxLayers / sizeof(float) + 2048);
-  if (!base) { set_err("oprl_mlp_backward: scratch allocation failed"); return OPRL_ERR_NOMEM; }
-  Pool p; p.base = (char*)base; p.cap = (size_t)-1;
-  alloc_net_ws(p, *net, B, &ws);
-  std::vector<DwItem> items;
-  int tiles = 0;
-  fill_items(*net, ws, items, &tiles);
-  MlpArgs a;
-  memset(&a, 0, sizeof a);
-  a.net = net_view(*net, false);
-  a.B = B; a.do_fwd = 1; a.do_bwd = 1;
-  a.x0 = x0; a.k0 = k0; a.x1 = x1; a.k1 = x1 ? k1 : 0;
-  with_store(a, ws, true, true);
-  a.seed_mode = SEED_PTR;
-  const int nout = net->dims[net->n_layers];
-  a.seed.p0 = dout; a.seed.ld0 = nout;
-  if (dx) { a.dact_col0 = 0; a.dact_cols = net->dims[0]; a.dact = dx; a.lddact = net->dims[0]; }
-  if (dx && net->dims[0] > kNarrowMax) { set_err("oprl_mlp_backward: dx supported for input dim <= %d", kNarrowMax); return OPRL_ERR_INVALID; }
-  RC(launch(a, width, st));
-  DwArgs dw;
-  dw.items = items.data(); dw.n_items = (int)items.size(); dw.total_tiles = tiles; dw.B = B; dw.n_part = 1; dw.trace = nullptr; dw.use_row_scale = 0; dw.apply_only = 0; dw.apply_only = 0;
-  memset(&dw.ad, 0, sizeof dw.ad);
-  set_adam(dw.ad, 0.0, 0.9, 0.999, 1e-8, 0.0);
-  set_step(dw.ad, 1); dw.ad.grad_scale = 1.0f; dw.ad.do_adam = 0;
-  HIPC(launch_dw_prof(dw, st));
-  return OPRL_OK;
-}
-
-extern "C" int oprl_adam_step(float* theta, float* m, float* v, const float* grad, int64_t n,
-                              int32_t step, double lr, double beta1, double beta2, double eps,
-                              double grad_scale, void* stream) {
-  if (!theta || !m || !v || !grad || n < 1 || step < 1) { set_err("oprl_adam_step: invalid argument"); return OPRL_ERR_INVALID; }
-  AdamScalars ad;
-  memset(&ad, 0, sizeof ad);
-  set_adam(ad, lr, beta1, beta2, eps, 0.0);
-  set_step(ad, step); ad.do_adam = 1; ad.grad_scale = (float)grad_scale;
-  HIPC(launch_adam_flat(theta, m, v, nullptr, grad, (long)n, ad, (hipStream_t)stream));
-  return OPRL_OK;
-}
-
-extern "C" int oprl_polyak(float* target, const float* source, int64_t n, double tau, void* stream) {
-  if (!target || !source || n < 1) { set_err("oprl_polyak: invalid argument"); return OPRL_ERR_INVALID; }
-  HIPC(launch_polyak_flat(target, source, (long)n, tau, (hipStream_t)stream));
-  return OPRL_OK;
-}
