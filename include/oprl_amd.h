@@ -46,7 +46,11 @@ typedef enum oprl_algo { OPRL_DDPG = 0, OPRL_TD3 = 1, OPRL_SAC = 2, OPRL_TQC = 3
 
 /* Arithmetic mode of the MLP GEMMs.
  *   F32  = exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), the parity mode: Q-values and gradients within
- *          1e-4 of the reference (measured <= 2e-6).
+ *          1e-4 of the reference (measured <= 2e-6).  A fused single-critic DDPG learner (own Adam step) runs whole
+ *          updates, up to 32 per launch, in this mode too (k_ddpg_chain<PrecF32>): its kernels read and write
+ *          library-owned UNCACHED mirrors of the packs below, and the caller's `pack` / `pack_target` are then
+ *          maintained like an X2 learner's fp32 packs — rebuilt from the masters by every entry point that reads
+ *          them (oprl_mlp_forward / backward / act, oprl_net_repack), not by the updates.
  *   BF16 = v_mfma_f32_16x16x32_bf16 with fp32 accumulation (16x the matrix rate, half the weight
  *          bytes): both GEMM operands of the forward and backward passes of the fused update kernels
  *          (DDPG / TD3 / SAC phase kernels, TQC's layer-wise critic kernels) are rounded to bf16 on the
@@ -88,8 +92,12 @@ typedef struct oprl_net {
   /* Fragment-order weight packs (device, caller-owned, oprl_net_pack_floats()
    * floats each, zero-initialised by the caller): the layout the MFMA kernels
    * stream (csrc/engine.h).  The library keeps them in step with theta /
-   * theta_target whenever IT changes those (update, apply); after an outside
-   * change of the master (load_state_dict ...) call oprl_net_repack(). */
+   * theta_target whenever IT changes those (update, apply) — or, for the
+   * learners named under oprl_precision, rebuilds them when one of its entry
+   * points reads them; after an outside change of the master
+   * (load_state_dict ...) call oprl_learner_sync_params() (every pack of the
+   * learner, the library-owned ones included) or, for a net no learner of a
+   * BF16 / X2 / chain kind owns, oprl_net_repack(). */
   float* pack;
   float* pack_target;                   /* NULL when there is no target */
 } oprl_net;
