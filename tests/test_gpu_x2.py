@@ -207,3 +207,37 @@ def test_chain_launches_equal_one_update_launches_bitwise(prec, monkeypatch):
             assert t.equal(getattr(ref, m)._oprl_arena, getattr(chain, m)._oprl_arena), (c, K, m)
     ref.learner.check()
     chain.learner.check()
+
+
+@pytest.mark.parametrize("prec", ["x2", "f32"])
+def test_module_forward_after_chain_updates_reads_current_weights(prec):
+    """The whole-update launches of both parity modes never touch the caller's fp32 packs (x2: they run on the fp16
+    packs; exact fp32: on library-owned uncached mirrors); what reads those packs afterwards — a module's forward,
+    oprl_mlp_forward — must find them rebuilt from the masters.  Module forward after 70 chain updates == a plain
+    fp32 matmul chain over the master arenas, and == the same forward after an explicit sync_params()."""
+    from oprl_amd.algos.ddpg import DDPG
+    from oprl_amd.logging import NullLogger
+    from tests.test_gpu_callers import _filled_buffer
+    t.manual_seed(0)
+    a = DDPG(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=256, precision=prec).create()
+    buf = _filled_buffer()
+    x = t.randn(64, 24, device="cuda")
+    before = a.actor(x).clone()
+    a.learner.step_n(buf.handle, 70, 256, seed=5)
+    t.cuda.synchronize()
+    after = a.actor(x).clone()
+    assert float((after - before).abs().max()) > 1e-5            # (the updates did move the actor)
+    # masters -> a plain fp32 forward
+    th = a.actor._oprl_arena
+    dims, off, h = [24, 256, 256, 6], 0, x
+    for l in range(3):
+        W = th[off:off + dims[l + 1] * dims[l]].view(dims[l + 1], dims[l]); off += dims[l + 1] * dims[l]
+        b = th[off:off + dims[l + 1]]; off += dims[l + 1]
+        h = h @ W.t() + b
+        if l < 2:
+            h = t.relu(h)
+    want = t.tanh(h)                                             # (DeterministicPolicy.forward: tanh(mlp(s)))
+    assert t.allclose(after, want, atol=2e-5), float((after - want).abs().max())
+    a.learner.sync_params()
+    t.cuda.synchronize()
+    assert t.equal(a.actor(x), after)
