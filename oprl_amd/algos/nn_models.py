@@ -35,7 +35,14 @@ def initialize_weight_orthogonal(m: nn.Module, gain: float = nn.init.calculate_g
     """Orthogonal weights (gain sqrt(2)) and zero bias for Linear layers
     (reference nn_models.py:14-24; its conv branch is unused on this path)."""
     if isinstance(m, nn.Linear):
-        nn.init.orthogonal_(m.weight.data, gain)
+        # (the QR behind orthogonal_ on ONE host thread: on a 256-core GPU host torch's intra-op pool turned each of these
+        # 256 x 256 factorisations into tens of milliseconds of thread wake-ups — 100-200 ms per DDPG / TD3 create())
+        n = t.get_num_threads()
+        t.set_num_threads(1)
+        try:
+            nn.init.orthogonal_(m.weight.data, gain)
+        finally:
+            t.set_num_threads(n)
         m.bias.data.zero_()
 
 

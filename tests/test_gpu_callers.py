@@ -113,7 +113,7 @@ def test_export_grads_split_equals_fused_update(monkeypatch):
     t.cuda.synchronize()
     for m in ("actor", "critic", "actor_target", "critic_target"):
         a, b = getattr(fused, m)._oprl_arena, getattr(split, m)._oprl_arena
-        assert (a - b).abs().max().item() <= 1e-7 * max(1.0, a.abs().max().item()), m
+        assert (a - b).abs().max().item() <= 2e-7 * max(1.0, a.abs().max().item()), m     # (two summation orders: an ulp or two)
     # packs were rebuilt by apply(): the module forward (reads packs) agrees with the masters
     s, a, *_ = (x.cuda() for x in fx.make_batch(99, 64, 24, 6))
     q_split = split.critic(s, a)

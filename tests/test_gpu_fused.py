@@ -50,8 +50,14 @@ def test_fused_equals_generic(B, cluster, monkeypatch):
     # minibatch gradient nearly cancels — tests/scenarios.py::compare); outputs below: 1e-5
     for m in ("actor", "critic", "actor_target", "critic_target"):
         assert _close(getattr(fused, m)._oprl_arena, getattr(generic, m)._oprl_arena, 1e-4), m
+    # Adam's first moments: 1e-4 of the largest — for all but a thousandth of the elements, which may be off by up to 1e-3:
+    # two summation orders can leave a hidden pre-activation on either side of zero, and that ONE ReLU flip moves the
+    # gradient of that unit's row of weights (measured with these batches: 36 of 73734 elements above 1e-4, the largest
+    # 2.0e-4, in three of the 21 cases; every other case 3e-7 and below — tools/probe_fused_ratio.py)
     for which in ("actor_m", "critic_m"):
-        assert _close(getattr(fused.learner, which), getattr(generic.learner, which), 1e-4), which
+        a, b = getattr(fused.learner, which), getattr(generic.learner, which)
+        d = (a - b).abs() / max(b.abs().max().item(), 1e-12)
+        assert int((d > 1e-4).sum()) <= d.numel() // 1000 and float(d.max()) <= 1e-3, (which, int((d > 1e-4).sum()), float(d.max()))
     qf, yf = fused.learner.debug_q_y(B)
     qg, yg = generic.learner.debug_q_y(B)
     assert _close(qf, qg) and _close(yf, yg)
