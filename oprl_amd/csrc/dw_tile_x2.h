@@ -164,11 +164,11 @@ struct DwX2Tile {
       for (int h = 0; h < 2; ++h) {
         const int xc = k_base + 32 * h + xq;
         if (xc < I.ldx) {
-          if (xb0 < hB) vx[h][0] = ld4(I.X + (size_t)xb0 * I.ldx + xc);
-          if (xb0 + 1 < hB) vx[h][1] = ld4(I.X + (size_t)(xb0 + 1) * I.ldx + xc);
+          if (xb0 < hB) vx[h][0] = ld4c(I.X + (size_t)xb0 * I.ldx + xc);      // (coherent loads: role C of this launch may be the writer)
+          if (xb0 + 1 < hB) vx[h][1] = ld4c(I.X + (size_t)(xb0 + 1) * I.ldx + xc);
         }
       }
-      if (kind == 1 && ncol < I.ldy && bb < hB) hmask = ld4(G.h2 + (size_t)bb * I.ldy + ncol);
+      if (kind == 1 && ncol < I.ldy && bb < hB) hmask = ld4c(G.h2 + (size_t)bb * I.ldy + ncol);
     }
   }
 
@@ -234,7 +234,7 @@ struct DwX2Tile {
       if (an_ok && bb < hB) {
 #pragma unroll
         for (int j = 0; j < kDuLd; ++j)
-          if (j < G.n_act) va[j] = ld4(G.gu + ((size_t)j * hB + bb) * I.ldy + ncol);
+          if (j < G.n_act) va[j] = ld4c(G.gu + ((size_t)j * hB + bb) * I.ldy + ncol);
       }
     }
     // the output layer's rows W3[j][ncol .. ncol + 3] (a few hundred bytes, shared by every tile of the layer: not
@@ -242,7 +242,7 @@ struct DwX2Tile {
     if (kind == 1 && an_ok) {
 #pragma unroll
       for (int j = 0; j < kDuLd; ++j)
-        if (j < G.n_act) va[j] = ld4((chained ? ov.chain->w3buf[ov.u & 1] : G.w3) + (size_t)j * I.ldy + ncol);
+        if (j < G.n_act) va[j] = ld4c((chained ? ov.chain->w3buf[ov.u & 1] : G.w3) + (size_t)j * I.ldy + ncol);
     }
   }
   // first attempts at what the tile waits for, requested with the rows

@@ -74,6 +74,26 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// COHERENT loads: what another workgroup of the SAME launch wrote (behind its flag).  A plain load may hit this compute
+// unit's L1 — a line an earlier workgroup on this unit, or this one, loaded before the writer wrote — and `buffer_inv sc0`
+// does NOT drop such lines here (workgroup-scope invalidate: a no-op outside threadgroup-split mode); `buffer_inv sc1` does,
+// at 14.7 us (it walks the L2 as well).  Loads with a scope above the workgroup miss the L1: tools/ubench_handoff.hip —
+// plain loads behind `buffer_inv sc0`: every read stale; these: 0 of 1.3e10 (r04-23).  ldc: an agent-scope atomic load.
+// ld4c: ONE 16-byte load at agent scope (buffer_load_dwordx4 ... sc1 through the raw-buffer builtin: a load the compiler
+// tracks).  The buffer's base is the first active lane's pointer (v_readfirstlane), the other lanes' pointers go in as
+// unsigned byte offsets from it: the callers' addresses do not decrease with the lane index (base + f(wave) + g(lane), g
+// non-decreasing), which every use below satisfies.  (A volatile global load — sc0 sc1, system scope — is as coherent and
+// needs no such promise, but made an update 4 us longer.)
+__device__ __forceinline__ f32x4 ld4c(const float* p) {
+  typedef unsigned u32x4_c __attribute__((ext_vector_type(4)));
+  const unsigned long long pv = (unsigned long long)p;
+  const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)pv), bhi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
+  const unsigned long long bv = ((unsigned long long)bhi << 32) | (unsigned long long)blo;
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bv), 0, 0x7fffffff, 0x00020000);
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(pv - bv), 0, 16 /* sc1 */));
+}
+__device__ __forceinline__ float ldc(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // ---------------------------------------------------------------------------
 // Precision policies of the lean passes (tp4.h), the layer-wise kernels and the dW GEMMs.
 //
@@ -148,6 +168,12 @@ struct PrecF32 {
   static constexpr float kOut = 1.f;
   static constexpr float kFwdA = 1.f;
   __device__ static __forceinline__ Frag ldf(const float* p) { return ld4(p); }
+  __device__ static __forceinline__ float ldb(const float* p) { return *p; }     // a bias element
+  // N consecutive (tile, step) blocks of a pack from p on: w[s] = s < n ? ldf(p + s kBlk) : zf()
+  template <int N> __device__ static __forceinline__ void ldfn(Frag (&w)[N], const float* p, int n = N) {
+#pragma unroll
+    for (int s = 0; s < N; ++s) w[s] = s < n ? ldf(p + s * kBlk) : zf();
+  }
   __device__ static __forceinline__ Frag zf() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
   __device__ static __forceinline__ void mac_s(const float* xr, int s, const Frag b, f32x4& acc, float) { mac(xr, s, b, acc); }
   __device__ static __forceinline__ void mac_tail_s(const float* xr, int s, const Frag b, f32x4& acc, int k16, float) { mac_tail(xr, s, b, acc, k16); }
@@ -175,6 +201,12 @@ struct PrecBF16 {
   static constexpr float kOut = 1.f;
   static constexpr float kFwdA = 1.f;
   __device__ static __forceinline__ Frag ldf(const float* p) { return ld4(p); }
+  __device__ static __forceinline__ float ldb(const float* p) { return *p; }     // a bias element
+  // N consecutive (tile, step) blocks of a pack from p on: w[s] = s < n ? ldf(p + s kBlk) : zf()
+  template <int N> __device__ static __forceinline__ void ldfn(Frag (&w)[N], const float* p, int n = N) {
+#pragma unroll
+    for (int s = 0; s < N; ++s) w[s] = s < n ? ldf(p + s * kBlk) : zf();
+  }
   __device__ static __forceinline__ Frag zf() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
   __device__ static __forceinline__ void mac_s(const float* xr, int s, const Frag b, f32x4& acc, float) { mac(xr, s, b, acc); }
   __device__ static __forceinline__ void mac_tail_s(const float* xr, int s, const Frag b, f32x4& acc, int k16, float) { mac_tail(xr, s, b, acc, k16); }
@@ -259,6 +291,12 @@ struct PrecX2 {
   // below, |x| < 4094
   static constexpr float kFwdA = 16.f;
   __device__ static __forceinline__ Frag ldf(const float* p) { return FragX2{ld4(p), ld4(p + 256)}; }
+  __device__ static __forceinline__ float ldb(const float* p) { return *p; }     // a bias element
+  // N consecutive (tile, step) blocks of a pack from p on: w[s] = s < n ? ldf(p + s kBlk) : zf()
+  template <int N> __device__ static __forceinline__ void ldfn(Frag (&w)[N], const float* p, int n = N) {
+#pragma unroll
+    for (int s = 0; s < N; ++s) w[s] = s < n ? ldf(p + s * kBlk) : zf();
+  }
   __device__ static __forceinline__ Frag zf() { return FragX2{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}; }
   __device__ static __forceinline__ void mma3(const f32x4 x0, const f32x4 x1, const Frag& b, f32x4& acc) {
     f16x8 ah, al;
@@ -305,6 +343,48 @@ struct PrecX2 {
     return ((float)__builtin_bit_cast(_Float16, (unsigned short)h) + (float)__builtin_bit_cast(_Float16, (unsigned short)l)) * kOut;
   }
 };
+
+// Coh<P>: the policy P with COHERENT weight-fragment and bias loads — for the passes of a launch whose weights another
+// workgroup of the same launch has just written (k_ddpg_chain: the tiles of the update before / of this update).
+template <class P>
+struct Coh : P {
+  typedef typename P::Frag Frag;
+  // one buffer resource per call (two v_readfirstlane), the steps as constant offsets from it
+  template <int N> __device__ static __forceinline__ void ldfn(Frag (&w)[N], const float* p, int n = N) {
+    typedef unsigned u32x4_c __attribute__((ext_vector_type(4)));
+    const unsigned long long pv = (unsigned long long)p;
+    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)pv), bhi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
+    const unsigned long long bv = ((unsigned long long)bhi << 32) | (unsigned long long)blo;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bv), 0, 0x7fffffff, 0x00020000);
+    const unsigned vo = (unsigned)(pv - bv);
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+      if (s < n) {
+        if constexpr (P::kX2) {
+          w[s].hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vo, (unsigned)(s * P::kBlk * 4), 16));
+          w[s].lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vo, (unsigned)(s * P::kBlk * 4 + 1024), 16));
+        } else {
+          w[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vo, (unsigned)(s * P::kBlk * 4), 16));
+        }
+      } else {
+        w[s] = P::zf();
+      }
+    }
+  }
+  __device__ static __forceinline__ Frag ldf(const float* p) { Frag w[1]; ldfn<1>(w, p); return w[0]; }
+  __device__ static __forceinline__ float ldb(const float* p) { return ldc(p); }
+  __device__ static __forceinline__ float first(const float* frag) {
+    if constexpr (P::kX2) {
+      const unsigned h = __hip_atomic_load(reinterpret_cast<const unsigned*>(frag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffu;
+      const unsigned l = __hip_atomic_load(reinterpret_cast<const unsigned*>(frag + 256), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffu;
+      return ((float)__builtin_bit_cast(_Float16, (unsigned short)h) + (float)__builtin_bit_cast(_Float16, (unsigned short)l)) * P::kOut;
+    } else {
+      static_assert(!P::kBf16, "Coh: the parity arithmetics");
+      return ldc(frag);
+    }
+  }
+};
+
 
 // position (in bf16 elements) of M[r][c] inside its bf16 pack (NS = cdiv(cols, 32))
 __host__ __device__ inline long pack16_index(int r, int c, int NS) {
@@ -481,6 +561,17 @@ __device__ __forceinline__ void load_rows(float* __restrict__ Xs, int ldx, int c
     const int row = idx / k, col = idx - row * k;
     const int gr = row0 + row;
     Xs[row * ldx + c0 + col] = gr < B ? G[(size_t)gr * ldg + col] : 0.f;
+  }
+}
+
+// ... with coherent loads (rows another workgroup of the same launch staged)
+__device__ __forceinline__ void load_rows_c(float* __restrict__ Xs, int ldx, int c0,
+                                            const float* __restrict__ G, int ldg, int k, int row0,
+                                            int B) {
+  for (int idx = threadIdx.x; idx < kR * k; idx += kThreads) {
+    const int row = idx / k, col = idx - row * k;
+    const int gr = row0 + row;
+    Xs[row * ldx + c0 + col] = gr < B ? ldc(G + (size_t)gr * ldg + col) : 0.f;
   }
 }
 

@@ -695,14 +695,14 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A, int bx_in = 
     }
     const int rs_ = tid / S, cs_ = tid - rs_ * S;          // state rows: kR * S <= 2 * kThreads (S <= 96)
     const bool oks = tid < kR * S && row0 + rs_ < B;
-    const float vs = oks ? A.aX[0][(size_t)(row0 + rs_) * A.aldx0 + cs_] : 0.f;
+    const float vs = oks ? ldc(A.aX[0] + (size_t)(row0 + rs_) * A.aldx0 + cs_) : 0.f;
     const int tid2 = tid + kThreads;                       // elements kThreads .. kR * S of wide states
     const int rs2_ = tid2 / S, cs2_ = tid2 - rs2_ * S;
     const bool oks2 = tid2 < kR * S && row0 + rs2_ < B;
-    const float vs2 = oks2 ? A.aX[0][(size_t)(row0 + rs2_) * A.aldx0 + cs2_] : 0.f;
+    const float vs2 = oks2 ? ldc(A.aX[0] + (size_t)(row0 + rs2_) * A.aldx0 + cs2_) : 0.f;
     const int rp_ = tid / Ad, cp_ = tid - rp_ * Ad;
     const bool okp = tid < kR * Ad && row0 + rp_ < B;
-    const float vp = okp ? A.pi[(size_t)(row0 + rp_) * Ad + cp_] : 0.f;
+    const float vp = okp ? ldc(A.pi + (size_t)(row0 + rp_) * Ad + cp_) : 0.f;
     if constexpr (SAC) {
       if (okp && g == 0) {
         g_mu = A.raw[(size_t)(row0 + rp_) * 2 * Ad + cp_];
@@ -1046,22 +1046,22 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   const float* wsrc = A.actor.pb[1] + (size_t)c * 2 * 16 * 256;
   f32x4 wv[2];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) wv[q] = ld4(wsrc + ((size_t)q * kThreads + tid) * 4);
+  for (int q = 0; q < 2; ++q) wv[q] = ld4c(wsrc + ((size_t)q * kThreads + tid) * 4);      // (coherent loads throughout this prologue: engine.h ld4c)
   const int hr = tid >> 6, hc = (tid & 63) * 4;                  // g2 element quad: row hr, columns hc .. hc + 3
   f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (row0 + hr < B) hv = ld4(A.aX[2] + (size_t)(row0 + hr) * kW4 + hc);
+  if (row0 + hr < B) hv = ld4c(A.aX[2] + (size_t)(row0 + hr) * kW4 + hc);
   f32x4 w3q = f32x4{0.f, 0.f, 0.f, 0.f};                         // W3[tid >> 6][4 (tid & 63) ..]: rows beyond A stay zero
-  if ((tid >> 6) < Ad) w3q = ld4(cx.w3 + (size_t)tid * 4);
+  if ((tid >> 6) < Ad) w3q = ld4c(cx.w3 + (size_t)tid * 4);
   const int et = (tid >> 8) & 1, er = (tid >> 4) & 15, ec = tid & 15;   // g1 element (threads < 512): tile et, row er, column ec
   float m1 = 0.f;
-  if (!GE && tid < 512 && row0 + er < B) m1 = A.aX[1][(size_t)(row0 + er) * kW4 + 32 * c + 16 * et + ec];
+  if (!GE && tid < 512 && row0 + er < B) m1 = ldc(A.aX[1] + (size_t)(row0 + er) * kW4 + 32 * c + 16 * et + ec);
   // (GE: the h1 elements — ReLU masks — of this lane's four unit-seed outputs, requested with everything else: a load
   // issued later would be waited for at the next barrier, a cold round trip inside the unit-seed stage)
   f32x4 gm1 = f32x4{0.f, 0.f, 0.f, 0.f};
   if constexpr (GE) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (row0 + 4 * kk + r < B) gm1[r] = A.aX[1][(size_t)(row0 + 4 * kk + r) * kW4 + 32 * c + 16 * (wave & 1) + i];
+      if (row0 + 4 * kk + r < B) gm1[r] = ldc(A.aX[1] + (size_t)(row0 + 4 * kk + r) * kW4 + 32 * c + 16 * (wave & 1) + i);
   }
   // [s | pi]: loads first, then the zero fill and the stores
   const int rs_ = tid / S, cs_ = tid - rs_ * S;
@@ -1197,7 +1197,8 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
     qsum = A.partials_a + slice * 4 + 1;
     if (tid == 0) { A.partials_a[slice * 4 + 0] = 0.f; A.partials_a[slice * 4 + 2] = 0.f; }
   }
-  tp4_scalar_fb<P, NMC>(A.critic, xa, h1, h2, g2, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum, cbo);
+  // (GE — k_ddpg_chain: the critic's packs and biases are this launch's tiles' — coherent loads, engine.h Coh)
+  tp4_scalar_fb<typename std::conditional<GE, Coh<P>, P>::type, NMC>(A.critic, xa, h1, h2, g2, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum, cbo);
   stamp();   // da ready
   // du = da (1 - pi^2): every member holds the same da; the lead member publishes (rows beyond B are never polled)
   if (lead && okp) {
@@ -1385,13 +1386,14 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
     const float* ps2 = par ? C.set1[4] : C.set0[4];
     lds_zero(xa, 2 * kR * kX0Ld);   // xa and xb are adjacent
     __syncthreads();
-    load_rows(xa, kX0Ld, 0, ps, S, S, row0, B);
-    load_rows(xa, kX0Ld, S, pa, Ad, Ad, row0, B);
-    load_rows(xb, kX0Ld, 0, ps2, S, S, row0, B);
+    // (coherent loads: another workgroup of this launch staged these rows — engine.h ld4c / ldc)
+    load_rows_c(xa, kX0Ld, 0, ps, S, S, row0, B);
+    load_rows_c(xa, kX0Ld, S, pa, Ad, Ad, row0, B);
+    load_rows_c(xb, kX0Ld, 0, ps2, S, S, row0, B);
     if (tid < kR) {
       const int gr = row0 + tid;
-      rS[tid] = gr < B ? pr[gr] : 0.f;
-      dS[tid] = gr < B ? pd[gr] : 0.f;
+      rS[tid] = gr < B ? ldc(pr + gr) : 0.f;
+      dS[tid] = gr < B ? ldc(pd + gr) : 0.f;
     }
   }
   stamp();   // batch rows requested
@@ -1411,7 +1413,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   if (role == 0) {
     // ---- role A: a' = tanh(actor_target(s')), q' = critic_target(s', a'), TD target, seeds       (ddpg.py:94-95)
     Tp tp{member, 8, A.xbuf + (size_t)slice * kTpStages * A.xnc * kTpBlk, tag1, 0, A.err, KERN_PHASE1 << 8, spin};
-    tp4_forward<P, 8>(A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp, bias_of(1));
+    tp4_forward<Coh<P>, 8>(A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp, bias_of(1));
     for (int idx = tid; idx < kR * Ad; idx += kThreads) {
       const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
       xb[row * kX0Ld + S + col] = gr < B ? tanhf(outS[row * kOutLd + col]) : 0.f;
@@ -1428,10 +1430,10 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
       if (++hook_n == 2) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) gq[m] = __hip_atomic_load(gq_src + m * kR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        qb = (u > 0 ? C.b16[2][2] : A.critic.b[2])[0];
+        qb = ldc(u > 0 ? C.b16[2][2] : A.critic.b[2]);
       }
     };
-    tp4_forward<P, 8>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, hook, bias_of(3));
+    tp4_forward<Coh<P>, 8>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, hook, bias_of(3));
     if (lead && tid < 64) {
       const int gr = row0 + tid;
       const bool row_ok = tid < kR && gr < B;
@@ -1481,7 +1483,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
     const int u2 = by2 / C.rows;
     const PassCtx cx{A.epoch + (unsigned)u2, A.cluster_tag + 2u * (unsigned)u2 + 1u, C.w3buf[u2 & 1], {C.b16[2][0], C.b16[2][1], C.b16[2][2]},
                      (kTraceOn && u2 == C.trace_u) ? A.trace2 : nullptr};
-    (void)ddpg_phase2m_body<P, DwKArgs4, false, true>(A, Dap, by2 - u2 * C.rows, cx);
+    (void)ddpg_phase2m_body<P, DwKArgs4, false, true>(A, Dap, by2 - u2 * C.rows, cx);      // (GE: its pass runs on Coh<P>)
     return;
   }
 
@@ -1498,7 +1500,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
     }
     // q leaves as the members' partial sums (granules, no exchange): role A adds them up
     const QPart qp{C.qp + (size_t)slice * 64, ep};
-    tp4_scalar_fb<P>(A.critic, xa, h1, h2, h1 + 2 * HB, outS, scr, tp, st, row0, B, 1.f, 0, 0, nullptr, stamp, nullptr, bias_of(2), qp);
+    tp4_scalar_fb<Coh<P>>(A.critic, xa, h1, h2, h1 + 2 * HB, outS, scr, tp, st, row0, B, 1.f, 0, 0, nullptr, stamp, nullptr, bias_of(2), qp);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0)
@@ -1510,7 +1512,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
     // (everything role C leaves is read by workgroups of this launch — the critic pass, the actor's tiles — behind its
     // flags: written through)
     const Tp3Store st{A.aX[1], A.aX[2], nullptr, nullptr, 0, 0, true};
-    tp4_forward<P>(A.actor, xa, h1, h2, outS, scr, tp, st, row0, B, stamp, bias_of(0));
+    tp4_forward<Coh<P>>(A.actor, xa, h1, h2, outS, scr, tp, st, row0, B, stamp, bias_of(0));
     if (lead) {
       for (int idx = tid; idx < kR * Ad; idx += kThreads) {
         const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;

@@ -289,29 +289,26 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
   F w0[NS::S0], w1[NQ], w2[SH::M];
   {
     const float* p0 = net.pf[0] + (size_t)wave * NS0 * BK + lane * 4;
-#pragma unroll
-    for (int s = 0; s < NS::S0; ++s) w0[s] = s < NS0 ? P::ldf(p0 + s * BK) : P::zf();
+    P::template ldfn<NS::S0>(w0, p0, NS0);
   }
-  const float bias0 = nb0[16 * wave + i];
+  const float bias0 = P::ldb(nb0 + 16 * wave + i);
   {
     const float* p1 = net.pf[1] + ((size_t)(c * SH::TPM + t1) * NS::W + kq * NQ) * BK + lane * 4;
-#pragma unroll
-    for (int s = 0; s < NQ; ++s) w1[s] = P::ldf(p1 + s * BK);
+    P::template ldfn<NQ>(w1, p1);
   }
-  const float bias1 = nb1[c0 + 16 * (r_mine ? rt : 0) + (rl & 15)];
+  const float bias1 = P::ldb(nb1 + c0 + 16 * (r_mine ? rt : 0) + (rl & 15));
   float bias2 = 0.f, bias2e[2] = {0.f, 0.f};   // output bias: of this lane's column / of its narrow-exchange elements
 #pragma unroll
   for (int s = 0; s < SH::M; ++s) w2[s] = P::zf();
   if (l2_wave) {
     const float* p2 = net.pf[2] + ((size_t)t2 * NS::W + c * SH::M) * BK + lane * 4;
-#pragma unroll
-    for (int s = 0; s < SH::M; ++s) w2[s] = P::ldf(p2 + s * BK);
-    if (16 * t2 + i < N) bias2 = nb2[16 * t2 + i];
+    P::template ldfn<SH::M>(w2, p2);
+    if (16 * t2 + i < N) bias2 = P::ldb(nb2 + 16 * t2 + i);
     if constexpr (NM == 8) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int k = tp4_narrow_elem(j, N);
-        if (k >= 0) bias2e[j] = nb2[k];
+        if (k >= 0) bias2e[j] = P::ldb(nb2 + k);
       }
     }
   }
@@ -416,21 +413,17 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
   for (int s = 0; s < NS::O; ++s) wo[s] = P::zf();
   if (wave < kTpc4) {
     const float* q2 = net.pb[2] + (size_t)(c * kTpc4 + wave) * NSo * BK + lane * 4;
-#pragma unroll
-    for (int s = 0; s < NS::O; ++s)
-      if (s < NSo) wo[s] = P::ldf(q2 + s * BK);
+    P::template ldfn<NS::O>(wo, q2, NSo);
   }
   {
     const float* q1 = net.pb[1] + ((size_t)wave * NS::W + c * NS::M) * BK + lane * 4;
-#pragma unroll
-    for (int s = 0; s < NS::M; ++s) wz[s] = P::ldf(q1 + s * BK);
+    P::template ldfn<NS::M>(wz, q1);
   }
 #pragma unroll
   for (int s = 0; s < NS::M; ++s) wd[s] = P::zf();
   if (dact_wave) {
     const float* q0 = net.pb[0] + ((size_t)(dt0 + dt) * NS::W + dpart * NS::M) * BK + lane * 4;
-#pragma unroll
-    for (int s = 0; s < NS::M; ++s) wd[s] = P::ldf(q0 + s * BK);
+    P::template ldfn<NS::M>(wd, q0);
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();   // dout visible
@@ -578,25 +571,22 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   F w0[NS::S0], w1[NQ], w2[SH::M], wz[SH::M], wd[Q4];
   {
     const float* p0 = net.pf[0] + (size_t)wave * NS0 * BK + lane * 4;
-#pragma unroll
-    for (int s = 0; s < NS::S0; ++s) w0[s] = s < NS0 ? P::ldf(p0 + s * BK) : P::zf();
+    P::template ldfn<NS::S0>(w0, p0, NS0);
   }
-  const float bias0 = nb0[16 * wave + i];
+  const float bias0 = P::ldb(nb0 + 16 * wave + i);
   {
     const float* p1 = net.pf[1] + ((size_t)(c * SH::TPM + t1) * NS::W + kq * NQ) * BK + lane * 4;
-#pragma unroll
-    for (int s = 0; s < NQ; ++s) w1[s] = P::ldf(p1 + s * BK);
+    P::template ldfn<NQ>(w1, p1);
   }
-  const float bias1 = nb1[c0 + 16 * (r_mine ? rt : 0) + (rl & 15)];
+  const float bias1 = P::ldb(nb1 + c0 + 16 * (r_mine ? rt : 0) + (rl & 15));
   const float w3 = P::first(net.pb[2] + (size_t)(c * SH::TPM + (r_mine ? rt : 0)) * BK + (rl & 15) * 4);   // W3[c0 + 16 rt + col]  (one step)
   float bias2 = 0.f;
 #pragma unroll
   for (int s = 0; s < SH::M; ++s) w2[s] = P::zf();
   if (wave == kOutWave) {
     const float* p2 = net.pf[2] + ((size_t)c * SH::M) * BK + lane * 4;
-#pragma unroll
-    for (int s = 0; s < SH::M; ++s) w2[s] = P::ldf(p2 + s * BK);
-    if (i == 0 || NM == 8) bias2 = nb2[0];
+    P::template ldfn<SH::M>(w2, p2);
+    if (i == 0 || NM == 8) bias2 = P::ldb(nb2);
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();   // x0 visible
@@ -620,8 +610,7 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   }
   {
     const float* q1 = net.pb[1] + ((size_t)wave * NS::W + c * SH::M) * BK + lane * 4;
-#pragma unroll
-    for (int s = 0; s < SH::M; ++s) wz[s] = P::ldf(q1 + s * BK);
+    P::template ldfn<SH::M>(wz, q1);
   }
   sf();
   __syncthreads();   // h1 visible
@@ -651,8 +640,7 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   for (int s = 0; s < Q4; ++s) wd[s] = P::zf();
   if (dact_wave) {
     const float* q0 = net.pb[0] + ((size_t)(dt0 + dt) * NS::W + dpart * Q4) * BK + lane * 4;
-#pragma unroll
-    for (int s = 0; s < Q4; ++s) wd[s] = P::ldf(q0 + s * BK);
+    P::template ldfn<Q4>(wd, q0);
   }
   sf();
   __syncthreads();   // h2, g2 (the member's columns) visible
