@@ -45,9 +45,9 @@ __device__ __forceinline__ void st_ag(float* p, float v) { __hip_atomic_store(p,
 // 16- / 8-byte stores WRITTEN THROUGH (engine.h st16_agent): what a tile hands to readers of the SAME launch — packs, bias
 // copies, the output layer's rows — is acknowledged by memory, not by this XCD's L2, before the tile's flag goes up
 template <class V16>
-__device__ __forceinline__ void st16_wt(void* p, const V16 v) {
+__device__ __forceinline__ void st16_wt(float* base, size_t off, const V16 v) {      // base: wave-uniform
   static_assert(sizeof(V16) == 16, "16-byte vector");
-  st16_agent(p, __builtin_bit_cast(f32x4, v));
+  st16_agent_at(base, (unsigned)off, __builtin_bit_cast(f32x4, v));
 }
 template <class V8>
 __device__ __forceinline__ void st8_wt(void* p, const V8 v) {
@@ -217,7 +217,7 @@ struct DwX2Tile {
   if (gate == 2) {
     if (kind == 3) {
       // unit-seed rows G_j[bb][ncol .. ncol + 3] of the critic pass's members (uncached memory): their flags, an L1
-      // invalidate, then the rows — all long before du
+      // then the rows (coherent loads) — all long before du
       {
         const int k = tid;
         if (k < G.n_gu_flags) {
@@ -229,7 +229,6 @@ struct DwX2Tile {
           if (!ok) report_expired(G.err, G.err_code);
         }
         __syncthreads();
-        asm volatile("buffer_inv sc0" ::: "memory");
       }
       if (an_ok && bb < hB) {
 #pragma unroll
@@ -589,14 +588,14 @@ struct DwX2Tile {
       if (grp3 < 2) {
         float* dst = grp3 == 0 ? I.pf : (polyak ? I.tpf : nullptr);
         if (dst != nullptr && 4 * tk + j < NSk && !(flagged && grp3 == 1))
-          st16_wt(dst + (((size_t)ptile * NSk + 4 * tk + j) * 64 + l) * 4, ld4((grp3 == 0 ? tileW : tileT) + li * LDT + 16 * j + 4 * lk));
+          st16_wt(dst, (((size_t)ptile * NSk + 4 * tk + j) * 64 + l) * 4, ld4((grp3 == 0 ? tileW : tileT) + li * LDT + 16 * j + 4 * lk));
       } else if (grp3 == 2 && I.pb != nullptr) {
         const int ktile = 4 * tk + j;
         if (16 * ktile < I.K) {
           f32x4 w4;
 #pragma unroll
           for (int t = 0; t < 4; ++t) w4[t] = tileW[(4 * lk + t) * LDT + 16 * j + li];
-          st16_wt(I.pb + (((size_t)ktile * NSn + ptile) * 64 + l) * 4, w4);
+          st16_wt(I.pb, (((size_t)ktile * NSn + ptile) * 64 + l) * 4, w4);
         }
       }
     }
@@ -611,9 +610,9 @@ struct DwX2Tile {
         const float* src = (which == 0 ? tileW : tileT) + li * LDT + 32 * hb;
         f16x8 hi, lo;
         x2_split8(ld4(src + 4 * lk) * PrecX2::kWScale, ld4(src + 16 + 4 * lk) * PrecX2::kWScale, hi, lo);
-        float* d = dst + ((size_t)ptile * NSk2 + 2 * tk + hb) * 512 + (size_t)l * 4;
-        st16_wt(d, hi);
-        st16_wt(d + 256, lo);
+        const size_t d = ((size_t)ptile * NSk2 + 2 * tk + hb) * 512 + (size_t)l * 4;
+        st16_wt(dst, d, hi);
+        st16_wt(dst, d + 256, lo);
       }
     } else if (tid < 512 && I.pb16 != nullptr) {
       const int q = tid - 256, blk = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
@@ -647,7 +646,7 @@ struct DwX2Tile {
         const int NSk = cdiv(I.K, 16);
         const int q = tid & 255, j = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
         if (4 * tk + j < NSk)
-          st16_wt(I.tpf + (((size_t)ptile * NSk + 4 * tk + j) * 64 + l) * 4, ld4(tileT + li * LDT + 16 * j + 4 * lk));
+          st16_wt(I.tpf, (((size_t)ptile * NSk + 4 * tk + j) * 64 + l) * 4, ld4(tileT + li * LDT + 16 * j + 4 * lk));
       }
     }
     if (P::kX2 && I.pf16 != nullptr && polyak && I.tpf16 != nullptr && tid >= 128 && tid < 256) {
@@ -657,9 +656,9 @@ struct DwX2Tile {
         const float* src = tileT + li * LDT + 32 * hb;
         f16x8 hi, lo;
         x2_split8(ld4(src + 4 * lk) * PrecX2::kWScale, ld4(src + 16 + 4 * lk) * PrecX2::kWScale, hi, lo);
-        float* d = I.tpf16 + ((size_t)ptile * NSk2 + 2 * tk + hb) * 512 + (size_t)l * 4;
-        st16_wt(d, hi);
-        st16_wt(d + 256, lo);
+        const size_t d = ((size_t)ptile * NSk2 + 2 * tk + hb) * 512 + (size_t)l * 4;
+        st16_wt(I.tpf16, d, hi);
+        st16_wt(I.tpf16, d + 256, lo);
       }
     }
   }

@@ -152,6 +152,18 @@ __device__ __forceinline__ void st16_agent(void* p, const f32x4 v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p) + 1, q[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// ... and as ONE 16-byte instruction where the destination is `base` (wave-uniform at run time: it goes through
+// v_readfirstlane) + this lane's offset: a raw buffer store with the cache policy in its aux operand, the mirror of ld4c.
+// With coherent loads on the reader's side every store form hands over correctly (tools/ubench_handoff.hip); this one is
+// the fastest (1.96 us per hand-over against 2.37 for two 8-byte stores) and WRITE_SIZE counts it as 27 % less traffic.
+__device__ __forceinline__ void st16_agent_at(float* base, unsigned float_off, const f32x4 v) {
+  typedef unsigned u32x4_s __attribute__((ext_vector_type(4)));
+  const unsigned long long bv = (unsigned long long)base;
+  const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)bv), bhi = __builtin_amdgcn_readfirstlane((unsigned)(bv >> 32));
+  base = reinterpret_cast<float*>(((unsigned long long)bhi << 32) | (unsigned long long)blo);
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_s, v), r, float_off * 4u, 0, 16 /* sc1 */);
+}
 __device__ __forceinline__ void st8_agent(void* p, unsigned long long v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -972,7 +972,6 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
     if (A.whole) {      // (never taken: k_ddpg_chain runs its tiles as continuations of the roles, not through here)
       wait_flags(A.w_flags, 4 * (int)gridDim.x, cx.epoch, A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
       __syncthreads();
-      asm volatile("buffer_inv sc0" ::: "memory");
     }
     return tile;
   }
@@ -1031,10 +1030,10 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   BiasOv cbo;
   if (A.whole) {
     // (k_ddpg_chain) role C of this launch wrote s, pi and the actor's activations — uncached memory: its members'
-    // flags, then an invalidate of this CU's L1; the critic's packs and biases follow below, behind the rows
+    // flags, then COHERENT loads of what they wrote (engine.h ld4c / ldc: a plain load may hit a stale line of this CU's
+    // L1, and no cheap invalidate drops it); the critic's packs and biases follow below, behind the rows
     wait_flags(A.w_flags, 4 * (int)gridDim.x, cx.epoch, A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
     __syncthreads();
-    asm volatile("buffer_inv sc0" ::: "memory");
   }
   stamp();   // role C's flags seen
   {
@@ -1066,14 +1065,14 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   // [s | pi]: loads first, then the zero fill and the stores
   const int rs_ = tid / S, cs_ = tid - rs_ * S;
   const bool oks = tid < kR * S && row0 + rs_ < B;
-  const float vs = oks ? A.aX[0][(size_t)(row0 + rs_) * A.aldx0 + cs_] : 0.f;
+  const float vs = oks ? ldc(A.aX[0] + (size_t)(row0 + rs_) * A.aldx0 + cs_) : 0.f;
   const int tid2 = tid + kThreads;
   const int rs2_ = tid2 / S, cs2_ = tid2 - rs2_ * S;
   const bool oks2 = tid2 < kR * S && row0 + rs2_ < B;
-  const float vs2 = oks2 ? A.aX[0][(size_t)(row0 + rs2_) * A.aldx0 + cs2_] : 0.f;
+  const float vs2 = oks2 ? ldc(A.aX[0] + (size_t)(row0 + rs2_) * A.aldx0 + cs2_) : 0.f;
   const int rp_ = tid / Ad, cp_ = tid - rp_ * Ad;
   const bool okp = tid < kR * Ad && row0 + rp_ < B;
-  const float vp = okp ? A.pi[(size_t)(row0 + rp_) * Ad + cp_] : 0.f;
+  const float vp = okp ? ldc(A.pi + (size_t)(row0 + rp_) * Ad + cp_) : 0.f;
   lds_zero(xa, kR * kX0Ld);
   lds_zero(auxS, kR * kOutLd);
   __syncthreads();
@@ -1170,7 +1169,7 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   }
   if (A.whole) {
     // ... the critic's TILES of this launch wrote the critic's fp16 packs and biases (uncached memory): their flags
-    // (one poller each), the invalidate; the biases come from the tiles' uncached copies (the masters sit dirty in
+    // (one poller each), coherent loads after them (Coh<P>); the biases come from the tiles' uncached copies (the masters sit dirty in
     // another XCD's L2)
     if (tid < A.n_ct) {
       bool ok = false;
@@ -1181,7 +1180,6 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
       if (!ok) report_expired(A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
     }
     __syncthreads();
-    asm volatile("buffer_inv sc0" ::: "memory");
     cbo.b0 = cx.cb[0]; cbo.b1 = cx.cb[1]; cbo.b2 = cx.cb[2];
   }
   if constexpr (GE) {
@@ -1288,7 +1286,7 @@ constexpr size_t kWholeDaOffset = (kWholeDcOffset + sizeof(DwKArgs4) + alignof(D
 // end-of-kernel + dispatch + cold instruction caches + the rows' round trip.
 // What crosses an update boundary without a kernel boundary:
 //   * fp16 packs, biases (uncached copies b16 / bt16), the actor's output layer (w3buf[parity]): uncached memory, read
-//     after the tiles' FIN flags (every store acknowledged) and an L1 invalidate;
+//     after the tiles' FIN flags (every store acknowledged), with coherent loads (engine.h ld4c / ldc / Coh<P>);
 //   * masters and Adam moments: agent-scope loads / stores (dw_tile_x2.h), the same tile's next incarnation after FIN;
 //   * the next rows: two staging sets by parity, gathered by 16 tile-less role-C workgroups, flag pf_done[slice].
 // Update 0 of a launch reads what the launch before left (masters' biases, the row-major W3, staged or gathered rows).
@@ -1313,7 +1311,6 @@ __device__ __forceinline__ void chain_wait2(const unsigned long long* f0, int n0
     if (!ok) report_expired(err, code);
   }
   __syncthreads();
-  asm volatile("buffer_inv sc0" ::: "memory");
 }
 
 constexpr size_t kChainCOffset = (kWholeDaOffset + sizeof(DwKArgs4) + alignof(ChainArgs) - 1) / alignof(ChainArgs) * alignof(ChainArgs);
@@ -1523,7 +1520,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
       // layer's tiles of the update before wrote w3buf[parity] themselves)
       if (u == 0 && slice == 0)
         for (int idx = tid * 4; idx < Ad * kW4; idx += kThreads * 4)
-          st16_wt(C.w3buf[0] + idx, ld4(A.w3_src + idx));
+          st16_wt(C.w3buf[0], idx, ld4(A.w3_src + idx));
     }
     stamp();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1560,7 +1557,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
     }
   }
   // ---- the critic's tile (GATE 1: rows of role B, seeds of role A), then the actor's (GATE 2: role C's rows — this
-  // launch's, uncached: its flags and an L1 invalidate — and du)
+  // launch's, uncached: its flags, then coherent loads — and du)
   // (two inlined copies of the tile code, each with its kind folded in: ONE copy inside a two-trip loop keeps the
   // thread-index arithmetic of both trips live across the tile and spills 14 vector registers)
   {
@@ -1591,7 +1588,6 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
         if (!ok) report_expired(A.err, (KERN_PHASE2 << 8) | SITE_DW_GATE);
       }
       __syncthreads();
-      asm volatile("buffer_inv sc0" ::: "memory");
       DwX2Ovr ov;
       ov.chain = &C; ov.u = u3;
       dw_tile_x2<DwKArgs4, P>(*Dap, smem, tile, 2, ov);

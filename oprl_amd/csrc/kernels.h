@@ -386,7 +386,7 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   // k_ddpg_update: phase 1's roles, the critic's tiles, phase 2's critic pass and the actor's tiles in ONE
   // launch.  What a role hands to a later one crosses no kernel boundary: it lives in uncached memory (the learner's
   // workspace and fp16 packs), is written before a flag {epoch, *} — w_flags[0, 64): role C's members, the critic's tiles
-  // raise DwGate::done — and read after the flag and an L1 invalidate.
+  // raise DwGate::done — and read after the flag with coherent loads (engine.h ld4c).
   int group_span;                      // group launches: XCDs a member's slices are dealt out to (1, 2, 4 or 8; fused_ddpg.hip k_ddpg_phase1_group)
   int whole;
   unsigned cluster_tag2;               // the critic pass's exchange tag (phase 2's cluster_tag in the two-launch form)

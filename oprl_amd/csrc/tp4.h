@@ -226,9 +226,9 @@ __device__ __forceinline__ void tp4_allreduce_narrow(const f32x4 mine, int i_fir
 }
 
 // a 16-byte store of what k_dw_adam reads: plain, or written through (Tp3Store::wt)
-__device__ __forceinline__ void tp4_st4(float* p, const f32x4 v, bool wt) {
-  if (wt) st16_agent(p, v);
-  else *reinterpret_cast<f32x4*>(p) = v;
+__device__ __forceinline__ void tp4_st4(float* base, size_t off, const f32x4 v, bool wt) {
+  if (wt) st16_agent_at(base, (unsigned)off, v);
+  else *reinterpret_cast<f32x4*>(base + off) = v;
 }
 
 // This member's dz1 partial (the whole [16 x 256] tile in h1) -> its partial buffer, for k_dw_adam.
@@ -240,10 +240,10 @@ __device__ __forceinline__ void tp4_store_dz1(const Tp3Store& st, int c, const f
   const int idx = threadIdx.x;                       // 16 rows x 64 float4
   if (st.dY0_tile_rows > 0) {
     const int t = idx >> 6, row = (idx >> 2) & 15, c4 = (idx & 3) * 4, gr = row0 + row;
-    if (gr < B) tp4_st4(dst + ((size_t)t * st.dY0_tile_rows + gr) * 16 + c4, ld4(h1 + row * kWL4 + 16 * t + c4), st.wt);
+    if (gr < B) tp4_st4(dst, ((size_t)t * st.dY0_tile_rows + gr) * 16 + c4, ld4(h1 + row * kWL4 + 16 * t + c4), st.wt);
   } else {
     const int row = idx >> 6, col = (idx & 63) * 4, gr = row0 + row;
-    if (gr < B) tp4_st4(dst + (size_t)gr * kW4 + col, ld4(h1 + row * kWL4 + col), st.wt);
+    if (gr < B) tp4_st4(dst, (size_t)gr * kW4 + col, ld4(h1 + row * kWL4 + col), st.wt);
   }
 }
 
@@ -340,7 +340,7 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
       tp4_mac_steps<P, NQ>(h1 + i * kWL4 + SH::KW * kq + 4 * kk, w1);
   if (st.X1 != nullptr && c == 0) {
     const int row = (int)threadIdx.x >> 6, col = ((int)threadIdx.x & 63) * 4, gr = row0 + row;     // 16 rows x 64 float4
-    if (gr < B) tp4_st4(st.X1 + (size_t)gr * kW4 + col, ld4(h1 + row * kWL4 + col), st.wt);
+    if (gr < B) tp4_st4(st.X1, (size_t)gr * kW4 + col, ld4(h1 + row * kWL4 + col), st.wt);
   }
   sf();
   __syncthreads();   // partial tiles visible
@@ -378,7 +378,7 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
     constexpr int C4 = SH::COLS / 4;                 // float4 per row of the member's columns
     const int idx = (int)threadIdx.x - 512;          // 16 rows x C4 float4
     const int row = idx / C4, col = c0 + (idx - row * C4) * 4, gr = row0 + row;
-    if (gr < B) tp4_st4(st.X2 + (size_t)gr * kW4 + col, ld4(h2 + row * kWL4 + col), st.wt);
+    if (gr < B) tp4_st4(st.X2, (size_t)gr * kW4 + col, ld4(h2 + row * kWL4 + col), st.wt);
   }
   tp.stage += 1;
   sf();
@@ -468,7 +468,7 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
   if (st.dY1 != nullptr && wave >= 12) {
     const int idx = (int)threadIdx.x - 768;          // 16 rows x 16 float4 of dz2
     const int row = idx >> 4, col = c0 + (idx & 15) * 4, gr = row0 + row;
-    if (gr < B) tp4_st4(st.dY1 + (size_t)gr * kW4 + col, ld4(h2 + row * kWL4 + col), st.wt);
+    if (gr < B) tp4_st4(st.dY1, (size_t)gr * kW4 + col, ld4(h2 + row * kWL4 + col), st.wt);
   }
   sf();
   __syncthreads();   // dz1 partial visible
@@ -620,7 +620,7 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
       tp4_mac_steps<P, NQ>(h1 + i * kWL4 + SH::KW * kq + 4 * kk, w1);
   if (st.X1 != nullptr && c == 0) {
     const int row = (int)threadIdx.x >> 6, col = ((int)threadIdx.x & 63) * 4, gr = row0 + row;
-    if (gr < B) tp4_st4(st.X1 + (size_t)gr * kW4 + col, ld4(h1 + row * kWL4 + col), st.wt);
+    if (gr < B) tp4_st4(st.X1, (size_t)gr * kW4 + col, ld4(h1 + row * kWL4 + col), st.wt);
   }
   sf();
   __syncthreads();   // partial tiles visible
@@ -659,7 +659,7 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
       const float* src = wave < 8 ? h2 : g2;
       const int idx = (int)threadIdx.x - (wave < 8 ? 256 : 512);   // 16 rows x C4 float4
       const int row = idx / C4, col = c0 + (idx - row * C4) * 4, gr = row0 + row;
-      if (gr < B) tp4_st4(dstg + (size_t)gr * kW4 + col, ld4(src + row * kWL4 + col), st.wt);
+      if (gr < B) tp4_st4(dstg, (size_t)gr * kW4 + col, ld4(src + row * kWL4 + col), st.wt);
     }
   }
   sf();
