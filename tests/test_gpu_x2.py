@@ -180,8 +180,9 @@ def test_x2_launch_forms_agree(algo_name, prec, monkeypatch):
 def test_chain_launches_equal_one_update_launches_bitwise(prec, monkeypatch):
     """k_ddpg_chain (several updates per launch, roles of update u + 1 behind the flags of update u) against the same
     kernel with ONE update per launch (OPRL_AMD_CHAIN=1: a kernel boundary between updates): the same arithmetic, so the
-    same bits — over many short calls that each start on an idle GPU, where hand-over races showed (r04-18 / r04-20:
-    inline-asm and 16-byte write-through stores; one call in ~30 differed then, one in ~20000 is what is left)."""
+    same bits — over many short calls that each start on an idle GPU, where hand-over races showed (r04-18 … r04-23:
+    inline-asm stores whose data registers were reused early, and plain loads that hit stale L1 lines behind a no-op
+    invalidate; one call in ~30 differed then)."""
     from oprl_amd.algos.ddpg import DDPG
     from oprl_amd.logging import NullLogger
     from tests.test_gpu_callers import _filled_buffer

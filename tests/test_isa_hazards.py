@@ -53,7 +53,7 @@ def test_no_vector_memory_instruction_is_written_as_inline_asm():
     workgroups wrote the rows their tile workgroups read — is invisible to hipcc's hazard recogniser: a vector-memory store
     of more than 64 bits reads its data registers late and a VALU write of those registers right behind it needs a wait
     state the compiler only inserts for stores it knows.  Under memory back-pressure the first dword of such a store came
-    out wrong (one event in some thousand updates; bit-identical runs diverged).  Loads had the mirror problem (above).
+    out wrong (bit-identical runs diverged; the other half of that story — stale L1 lines on the reader's side — is r04-23).  Loads had the mirror problem (above).
     Every vector-memory access of the kernels is therefore a builtin the compiler sees; inline asm is for waits, cache
     invalidates and scheduling fences only."""
     import re
