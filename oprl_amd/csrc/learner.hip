@@ -69,30 +69,38 @@ namespace oprl_host {
 
 // learners with lazily maintained fp32 packs, by pack pointer (oprl_mlp_* know a net, not its learner)
 // Whole-update launches (k_ddpg_chain) take the whole chip for up to 32 updates.  Learners of one process that launch them
-// from different streams (one host thread per learner: the multi-seed layout) take TURNS: a launch waits for the event
+// from DIFFERENT STREAMS (one host thread per learner: the multi-seed layout) take TURNS: a launch waits for the event
 // behind the last whole-update launch of another stream — two such launches side by side would only hold each other's
-// compute units with waiting workgroups (bounded waits would expire).  Nothing is recorded while the process has one
-// learner (the headline path: no event, no barrier packet).
+// compute units with waiting workgroups (bounded waits would expire).  Nothing is recorded until a second stream shows
+// up (a process whose learners share one stream — the headline path, bench.py's blocks — pays no event, no barrier
+// packet); the first launch from a second stream drains the device on the host, once.
 struct ChipTurn {
   std::mutex mu;
   hipEvent_t ev[16] = {};
   hipStream_t stream[16] = {};
-  bool rec[16] = {};
+  bool any[16] = {}, multi[16] = {}, rec[16] = {};
 };
 ChipTurn g_turn;
-std::atomic<int> g_live{0};
 
 hipError_t chip_turn_begin(hipStream_t st, int* dev_out) {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  *dev_out = dev & 15;
-  if (g_turn.rec[*dev_out] && g_turn.stream[*dev_out] != st) return hipStreamWaitEvent(st, g_turn.ev[*dev_out], 0);
-  return hipSuccess;
+  dev &= 15;
+  *dev_out = dev;
+  if (!g_turn.any[dev] || g_turn.stream[dev] == st) return hipSuccess;
+  if (!g_turn.multi[dev]) {                       // the second stream of this process: from now on events
+    g_turn.multi[dev] = true;
+    return hipDeviceSynchronize();                // (once; the other stream's handle may be gone by now)
+  }
+  return g_turn.rec[dev] ? hipStreamWaitEvent(st, g_turn.ev[dev], 0) : hipSuccess;
 }
 void chip_turn_end(hipStream_t st, int dev) {
-  if (g_live.load() <= 1) { g_turn.rec[dev] = false; return; }
+  g_turn.any[dev] = true;
+  g_turn.stream[dev] = st;
+  g_turn.rec[dev] = false;
+  if (!g_turn.multi[dev]) return;
   if (g_turn.ev[dev] == nullptr && hipEventCreateWithFlags(&g_turn.ev[dev], hipEventDisableTiming) != hipSuccess) { g_turn.ev[dev] = nullptr; return; }
-  if (hipEventRecord(g_turn.ev[dev], st) == hipSuccess) { g_turn.rec[dev] = true; g_turn.stream[dev] = st; }
+  if (hipEventRecord(g_turn.ev[dev], st) == hipSuccess) g_turn.rec[dev] = true;
 }
 
 // the net the fused kernels of `h` see (fchain: the one with the mirrored packs)

@@ -331,7 +331,6 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     g_lazy.push_back(h);
     h->lazy_wide = cfg->algo == OPRL_TQC;
   }
-  if (g_live.fetch_add(1) >= 1) (void)hipDeviceSynchronize();      // (from here on whole-update launches take turns: ChipTurn)
   *out = h;
   return OPRL_OK;
 }
@@ -373,7 +372,6 @@ extern "C" int oprl_learner_destroy(oprl_learner* h) {
     g_lazy.erase(std::remove(g_lazy.begin(), g_lazy.end(), h), g_lazy.end());
   }
   (void)hipDeviceSynchronize();
-  g_live.fetch_sub(1);
   if (h->rccl.comm && h->rccl.comm_destroy) (void)h->rccl.comm_destroy(h->rccl.comm);
   if (h->xbuf) (void)hipFree(h->xbuf);
   if (h->tqc_counter) (void)hipFree(h->tqc_counter);

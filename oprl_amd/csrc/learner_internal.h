@@ -446,10 +446,9 @@ void fill_items(const oprl_net& n, const NetWs& ws, std::vector<DwItem>& v, int*
 DwArgs dw_build(oprl_learner* h, bool critic, int B, bool polyak, bool with_alpha);
 bool alpha_rides(const oprl_learner* h);
 int launch(const MlpArgs& a0, int width, hipStream_t st);
-// learners with lazily maintained fp32 packs (fresh32), the count of live learners (ChipTurn)
+// learners with lazily maintained fp32 packs (fresh32)
 extern std::mutex g_lazy_mu;
 extern std::vector<oprl_learner*> g_lazy;
-extern std::atomic<int> g_live;
 int repack_nets(const oprl_net* const* nets, int n_nets, int which, hipStream_t st,
                 float* const* pk16 = nullptr, float* const* pk16_t = nullptr, int pl = 1);
 // step_n's K-loop as launches of several updates each (k_ddpg_chain); also the inline data-parallel loop
