@@ -85,7 +85,6 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 // non-decreasing), which every use below satisfies.  (A volatile global load — sc0 sc1, system scope — is as coherent and
 // needs no such promise, but made an update 4 us longer.)
 __device__ __forceinline__ f32x4 ld4c(const float* p) {
-  typedef unsigned u32x4_c __attribute__((ext_vector_type(4)));
   const unsigned long long pv = (unsigned long long)p;
   const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)pv), bhi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
   const unsigned long long bv = ((unsigned long long)bhi << 32) | (unsigned long long)blo;
@@ -363,8 +362,7 @@ struct Coh : P {
   typedef typename P::Frag Frag;
   // one buffer resource per call (two v_readfirstlane), the steps as constant offsets from it
   template <int N> __device__ static __forceinline__ void ldfn(Frag (&w)[N], const float* p, int n = N) {
-    typedef unsigned u32x4_c __attribute__((ext_vector_type(4)));
-    const unsigned long long pv = (unsigned long long)p;
+      const unsigned long long pv = (unsigned long long)p;
     const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)pv), bhi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
     const unsigned long long bv = ((unsigned long long)bhi << 32) | (unsigned long long)blo;
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bv), 0, 0x7fffffff, 0x00020000);
