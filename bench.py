@@ -876,8 +876,9 @@ def measure(args, wd):
                                    f"{E}x{L} transitions resident in HBM, device-side uniform sampling, "
                                    + {"f32": "exact-fp32 MFMA (OPRL_PREC_F32, a parity mode)",
                                       "x2": "fp32 operands as fp16 hi + lo, three fp16 MFMAs per product, fp32 accumulate / "
-                                            "master / Adam (OPRL_PREC_X2, a parity mode: same gates against the reference's "
-                                            "golden vectors as the exact-fp32 mode, tests/test_gpu_x2.py)",
+                                            "master / Adam (OPRL_PREC_X2, a parity mode: the exact-fp32 mode's gates against the "
+                                            "reference's golden vectors - outputs 2e-5, parameter digests 1e-4 - except the Adam-moment "
+                                            "digests at 5e-3: one ReLU flip of one row; tests/test_gpu_x2.py, tests/scenarios.py)",
                                       "bf16": "bf16 MFMA inputs, fp32 accumulate / master / Adam (OPRL_PREC_BF16, NOT a "
                                               "parity mode)"}[args.precision],
                        "path": "oprl_learner_step_n" if not use_dp else
