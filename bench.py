@@ -587,7 +587,7 @@ def measure(args, wd):
         t.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
-        t.cuda.synchronize(dev)
+            t.cuda.synchronize(dev)
 
     def make_learner():
         t.manual_seed(0)                               # reference-style init, same on all ranks
