@@ -928,6 +928,16 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2_group(const DdpgArgs* 
 // compute units for 6 us per update that the whole-update launch needs for the pass itself — profiles/r03_experiments.txt.)
 // Grid rows: [0, 8) critic pass | prefetch row (step_n, two-launch form) | tiles.
 // ---------------------------------------------------------------------------------------------------------------
+// Do the members of this workgroup's slice cluster (same blockIdx.x, different blockIdx.y) share an XCD?  Workgroups go to
+// XCD (linear id) % 8 and the grid is (slices, rows): with slices a multiple of eight a slice's workgroups all land on XCD
+// blockIdx.x % 8 — checked against the hardware's XCC_ID, so that a part that maps differently simply publishes at agent
+// scope (tp3.h Tp::local: workgroup-scope granule stores reach the XCD's L2, where the peers' agent-scope polls find them;
+// A / B on one box: 25.94 against 26.10 us per update, r04-26).
+__device__ __forceinline__ bool cluster_on_one_xcd() {
+  const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;          // HW_REG_XCC_ID, bits 3:0
+  return ((int)gridDim.x & 7) == 0 && xcc == ((int)blockIdx.x & 7);
+}
+
 // one bounded wait for n flag granules {tag, *}: thread k polls flag k (n <= threads); the caller's barrier releases everybody
 __device__ __forceinline__ void wait_flags(const unsigned long long* flags, int n, unsigned tag, unsigned* err, unsigned code) {
   const int k = (int)threadIdx.x;
@@ -1011,6 +1021,7 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   static_assert(kMaxEnds >= kDuLd * 256, "W3 fits the ends table's area");
   Tp tp{y, NMC, A.xbuf + (size_t)slice * kTpStages * A.xnc * kTpBlk, cx.tag, 0,
         A.err, KERN_PHASE2 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
+  tp.local = GE && cluster_on_one_xcd();
   const bool lead = tp.c == 0;
   const int c = tp.c;
   const int lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
@@ -1410,6 +1421,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   if (role == 0) {
     // ---- role A: a' = tanh(actor_target(s')), q' = critic_target(s', a'), TD target, seeds       (ddpg.py:94-95)
     Tp tp{member, 8, A.xbuf + (size_t)slice * kTpStages * A.xnc * kTpBlk, tag1, 0, A.err, KERN_PHASE1 << 8, spin};
+    tp.local = cluster_on_one_xcd();
     tp4_forward<Coh<P>, 8>(A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp, bias_of(1));
     for (int idx = tid; idx < kR * Ad; idx += kThreads) {
       const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
@@ -1487,6 +1499,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   if (role == 1) {
     // ---- role B: q = critic(s, a) forward and its whole backward with unit seed (tp4_scalar_fb)      (ddpg.py:96-100)
     Tp tp{member, 4, A.xbuf + ((size_t)1 * slices + slice) * kTpStages * A.xnc * kTpBlk, tag1, 0, A.err, KERN_PHASE1 << 8, spin};
+    tp.local = cluster_on_one_xcd();
     const Tp3Store st{A.cX[1], A.cX[2], A.cdY[1], A.cdY[0], A.cdY0_stride, B, true};
     if (lead) {        // (the input rows for the critic's first-layer tiles: out before the pass)
       __syncthreads();
@@ -1506,6 +1519,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   } else if (role == 2) {
     // ---- role C: actor(s) forward, pi = tanh(.) and the activations for the actor's tiles / the critic pass
     Tp tp{member, 4, A.xbuf + ((size_t)2 * slices + slice) * kTpStages * A.xnc * kTpBlk, tag1, 0, A.err, KERN_PHASE1 << 8, spin};
+    tp.local = cluster_on_one_xcd();
     // (everything role C leaves is read by workgroups of this launch — the critic pass, the actor's tiles — behind its
     // flags: written through)
     const Tp3Store st{A.aX[1], A.aX[2], nullptr, nullptr, 0, 0, true};

@@ -41,6 +41,9 @@ struct Tp {
   unsigned* err = nullptr;
   unsigned err_code = 0;
   int spin = kTpSpin;
+  // every member of the cluster runs on the SAME XCD (the launch made sure): granules may be published at workgroup scope —
+  // they reach the XCD's L2, where the peers' agent-scope polls find them, without the trip to memory (r04-16 / -26)
+  bool local = false;
 };
 
 // Wait sites (low byte of the error word) and kernels (second byte): oprl_learner_check() decodes them.

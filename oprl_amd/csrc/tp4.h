@@ -117,9 +117,14 @@ __device__ __forceinline__ f32x4 tp4_allreduce_regs(const f32x4 mine, int col, b
   if (valid) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      __hip_atomic_store(slot + (size_t)tp.c * kTpBlk + r * kRs,
-                         ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(mine[r]),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tp.local)
+        __hip_atomic_store(slot + (size_t)tp.c * kTpBlk + r * kRs,
+                           ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(mine[r]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else
+        __hip_atomic_store(slot + (size_t)tp.c * kTpBlk + r * kRs,
+                           ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(mine[r]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // all peers' granules are requested together (one round trip per poll), then checked; the values are
     // summed straight from the granules in member order (this member's own term from its registers)
     bool ok = false;
@@ -190,10 +195,16 @@ __device__ __forceinline__ void tp4_allreduce_narrow(const f32x4 mine, int i_fir
     val[j] = wscr[row * 16 + i_first + k];
     off[j] = ((row & 3) * 4 + (row >> 2)) * kNarrowMax + cc_first + k;     // (r * 4 + kk) * kNarrowMax + col
     oidx[j] = row * kOutLd + cc_first + k;
-    if (have[j])
-      __hip_atomic_store(base + (size_t)tp.c * kTpBlk + off[j],
-                         ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(val[j]),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (have[j]) {
+      if (tp.local)
+        __hip_atomic_store(base + (size_t)tp.c * kTpBlk + off[j],
+                           ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(val[j]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else
+        __hip_atomic_store(base + (size_t)tp.c * kTpBlk + off[j],
+                           ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(val[j]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   (void)kRs;
   if (have[0]) {
