@@ -55,6 +55,16 @@ namespace oprl {
 // (kMaxEnds: batch_rows.h)
 
 // one MLP pass of a cluster: the lean tp4 routines or the generic tp3 ones
+// Do the members of this workgroup's slice cluster (same blockIdx.x, different blockIdx.y) share an XCD?  Workgroups go to
+// XCD (linear id) % 8 and the grid is (slices, rows): with slices a multiple of eight a slice's workgroups all land on XCD
+// blockIdx.x % 8 — checked against the hardware's XCC_ID, so that a part that maps differently simply publishes at agent
+// scope (tp3.h Tp::local: workgroup-scope granule stores reach the XCD's L2, where the peers' agent-scope polls find them;
+// A / B on one box: 25.94 against 26.10 us per update, r04-26).
+__device__ __forceinline__ bool cluster_on_one_xcd() {
+  const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;          // HW_REG_XCC_ID, bits 3:0
+  return ((int)gridDim.x & 7) == 0 && xcc == ((int)blockIdx.x & 7);
+}
+
 template <int WIDTH, bool LEAN, class P, int NM = 4, class ST>
 __device__ __forceinline__ void tp_fwd(const Net& net, const float* x0s, float* h1, float* h2, float* outS,
                                        float* scr, Tp& tp, const Tp3Store& st, int row0, int B, ST sf) {
@@ -330,6 +340,7 @@ __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D =
   Tp tp{member, role == 0 ? nA : A.nc,
         A.xbuf + ((size_t)role * gridDim.x + slice) * kTpStages * A.xnc * kTpBlk, A.cluster_tag, 0,
         A.err, KERN_PHASE1 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
+  tp.local = bx_in < 0 && cluster_on_one_xcd();      // (the launch's own (slice, row) grid: r04-26)
   const bool lead = tp.c == 0;                 // member 0 does the un-sliced global stores
   int n_stamp = 0;
   auto stamp = [&]() {
@@ -635,6 +646,7 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A, int bx_in = 
   Tp tp{by - g * ncl, ncl,
         A.xbuf + ((size_t)g * gridDim.x + slice) * kTpStages * A.xnc * kTpBlk, A.cluster_tag, 0,
         A.err, KERN_PHASE2 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
+  tp.local = bx_in < 0 && cluster_on_one_xcd();
   const bool lead = tp.c == 0;
   int n_stamp = 0;
   auto stamp = [&]() {
@@ -928,16 +940,6 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase2_group(const DdpgArgs* 
 // compute units for 6 us per update that the whole-update launch needs for the pass itself — profiles/r03_experiments.txt.)
 // Grid rows: [0, 8) critic pass | prefetch row (step_n, two-launch form) | tiles.
 // ---------------------------------------------------------------------------------------------------------------
-// Do the members of this workgroup's slice cluster (same blockIdx.x, different blockIdx.y) share an XCD?  Workgroups go to
-// XCD (linear id) % 8 and the grid is (slices, rows): with slices a multiple of eight a slice's workgroups all land on XCD
-// blockIdx.x % 8 — checked against the hardware's XCC_ID, so that a part that maps differently simply publishes at agent
-// scope (tp3.h Tp::local: workgroup-scope granule stores reach the XCD's L2, where the peers' agent-scope polls find them;
-// A / B on one box: 25.94 against 26.10 us per update, r04-26).
-__device__ __forceinline__ bool cluster_on_one_xcd() {
-  const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;          // HW_REG_XCC_ID, bits 3:0
-  return ((int)gridDim.x & 7) == 0 && xcc == ((int)blockIdx.x & 7);
-}
-
 // one bounded wait for n flag granules {tag, *}: thread k polls flag k (n <= threads); the caller's barrier releases everybody
 __device__ __forceinline__ void wait_flags(const unsigned long long* flags, int n, unsigned tag, unsigned* err, unsigned code) {
   const int k = (int)threadIdx.x;
