@@ -604,7 +604,9 @@ def measure(args, wd):
             learner.step_n(replay.handle, n, B, seed=0)
         run(args.pre_warm)          # clock ramp / first-touch, before the W warm-up steps of the contract
         for _ in range(3 if args.pre_warm > 0 else 0):
-            run(min(K, 32))         # (... and calls of the timed call's own shape: host-side first touches)
+            barrier()               # (... and calls of the timed call's own shape, bracketed like the timed region:
+            run(min(K, 32))         # host-side first touches; the first drained short call reads 8 us longer)
+        barrier()
         run(W)
     else:
         from oprl_amd.parallel import DataParallelLearner

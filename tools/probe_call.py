@@ -23,4 +23,17 @@ for K in (1, 20):
         t2 = time.perf_counter()
         enq.append((t1 - t0) * 1e6); tot.append((t2 - t0) * 1e6)
     enq.sort(); tot.sort()
-    print(f"K={K}: enqueue median {enq[100]:.1f} us (min {enq[0]:.1f}), call + drain median {tot[100]:.1f} us (min {tot[0]:.1f})", flush=True)
+    print(f"K={K}: enqueue median {enq[100]:.1f} us (min {enq[0]:.1f}), call + drain median {tot[100]:.1f} us (min {tot[0]:.1f}, p90 {tot[180]:.1f}, p99 {tot[197]:.1f}, max {tot[-1]:.1f})", flush=True)
+    ev = t.cuda.Event()
+    tot = []
+    for rep in range(200):
+        t.cuda.synchronize()
+        t0 = time.perf_counter()
+        L.step_n(replay.handle, K, 256, seed=0)
+        ev.record()
+        while not ev.query():
+            pass
+        t.cuda.synchronize()
+        tot.append((time.perf_counter() - t0) * 1e6)
+    tot.sort()
+    print(f"K={K}: the same with an event spin before synchronize: median {tot[100]:.1f} us (min {tot[0]:.1f}, p90 {tot[180]:.1f}, p99 {tot[197]:.1f}, max {tot[-1]:.1f})", flush=True)
