@@ -75,9 +75,14 @@ __device__ __forceinline__ void tp_allreduce(float* P, int ncols, const float* _
     const int row = e / ncols, col = e - row * ncols;
     const float mine = P[row * kOutLd + col];
     const float bv = bias != nullptr ? bias[col] : 0.f;
-    __hip_atomic_store(slot + (size_t)tp.c * kTpBlk + e,
-                       ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(mine),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tp.local)      // (every member on one XCD: the granule need not leave its L2 — Tp::local)
+      __hip_atomic_store(slot + (size_t)tp.c * kTpBlk + e,
+                         ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(mine),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+      __hip_atomic_store(slot + (size_t)tp.c * kTpBlk + e,
+                         ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(mine),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float sum = 0.f;
     for (int m = 0; m < tp.nc; ++m) {
       float v = mine;
