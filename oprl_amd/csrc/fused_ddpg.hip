@@ -45,6 +45,7 @@
 #include "batch_rows.h"
 #include "slice_head.h"
 #include "tp4.h"
+#include "lean.h"
 #include "dw_body.h"
 #include "dw_tile_x2.h"
 
@@ -90,7 +91,13 @@ struct FusedLds {   // floats
   static constexpr int aux2 = aux + kR * kOutLd;     // SAC phase 2: the twin critic's action gradient
   static constexpr int scr = aux2 + kR * kOutLd;
   static constexpr int misc = scr + kWaves * kR * 16;   // r[16] d[16] y[16] ep[16] t[16] + ends
-  static constexpr int total = misc + 96 + kMaxEnds;
+  static constexpr int lean_x0 = misc + 96 + kMaxEnds;  // the wave-specialised passes' layer-0 input planes (lean.h; PrecX2)
+  static constexpr int total = lean_x0 + kLeanX0Floats;
+  // ... their hidden tiles live in the hidden buffers: h1 over buffers 0-1, the member-local h2 / g2 in buffer 2
+  static constexpr int lean_h1 = h;
+  static constexpr int lean_h2 = h + 2 * kR * WL;
+  static constexpr int lean_g2 = lean_h2 + 1024;
+  static_assert(2 * kR * WL >= 16 * kLdH && 1024 >= 16 * kLdLH && 1024 >= 16 * kLdLF, "lean tiles fit the hidden buffers");
 };
 
 // one tagged 8-byte granule: the value is its own flag (as the cluster exchanges of tp3.h / tp4.h)
@@ -1180,6 +1187,8 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
     }
     stamp();   // unit-seed rows requested out
   }
+  // (GE: the wave-specialised pass of lean.h reads [s | pi] as planes — PrecX2 — written here, published by the barriers below)
+  if constexpr (GE && P::kX2) lean_x0_planes(xa, smem + LY::lean_x0, 0, 32 * ((S + Ad + 31) >> 5), tid, kThreads);
   if (A.whole) {
     // ... the critic's TILES of this launch wrote the critic's fp16 packs and biases (uncached memory): their flags
     // (one poller each), coherent loads after them (Coh<P>); the biases come from the tiles' uncached copies (the masters sit dirty in
@@ -1209,7 +1218,12 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
     if (tid == 0) { A.partials_a[slice * 4 + 0] = 0.f; A.partials_a[slice * 4 + 2] = 0.f; }
   }
   // (GE — k_ddpg_chain: the critic's packs and biases are this launch's tiles' — coherent loads, engine.h Coh)
-  tp4_scalar_fb<typename std::conditional<GE, Coh<P>, P>::type, NMC>(A.critic, xa, h1, h2, g2, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum, cbo);
+  if constexpr (GE) {
+    const LeanBufs LB{P::kX2 ? smem + LY::lean_x0 : xa, smem + LY::lean_h1, smem + LY::lean_h2, smem + LY::lean_g2, scr};
+    lean_scalar_fb<Coh<P>>(A.critic, LB, outS, tp, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum, cbo);
+  } else {
+    tp4_scalar_fb<P, NMC>(A.critic, xa, h1, h2, g2, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum, cbo);
+  }
   stamp();   // da ready
   // du = da (1 - pi^2): every member holds the same da; the lead member publishes (rows beyond B are never polled)
   if (lead && okp) {
@@ -1326,6 +1340,73 @@ __device__ __forceinline__ void chain_wait2(const unsigned long long* f0, int n0
   __syncthreads();
 }
 
+// Role A's tail (lean_role_a's TAIL, wave 0 of the lead member): role B's members leave their PARTIAL q as granules (no
+// exchange at the end of role B) — requested while the wave idles, summed here in member order with the output bias —
+// then the TD target, the per-row seeds 2 (q - y) / B as granules for the critic's tiles, the diagnostics.
+struct ChainTailCtx {
+  const DdpgArgs* A;
+  const unsigned long long* qp;        // this slice's [4 members][16 rows] partial q granules
+  const float* qbias;                  // the online critic's output bias
+  const float* rS; const float* dS;    // LDS: the slice's rewards / dones
+  unsigned ep;
+  int slice, row0;
+  bool lead;
+};
+struct ChainTail {
+  unsigned long long gq[4];
+  float qb;
+  __device__ __forceinline__ void request(const ChainTailCtx& X) {
+    const unsigned long long* src = X.qp + (threadIdx.x & (kR - 1));
+#pragma unroll
+    for (int m = 0; m < 4; ++m) gq[m] = __hip_atomic_load(src + m * kR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    qb = ldc(X.qbias);
+  }
+  __device__ __forceinline__ void finish(const ChainTailCtx& X, const float* outS) {
+    if (!X.lead) return;
+    const DdpgArgs& A = *X.A;
+    const int tid = threadIdx.x, gr = X.row0 + tid, B = A.B;
+    const unsigned ep = X.ep;
+    const unsigned long long* gq_src = X.qp + (tid & (kR - 1));
+    const bool row_ok = tid < kR && gr < B;
+    const float qn = row_ok ? outS[tid * kOutLd] : 0.f;
+    const float y = row_ok ? X.rS[tid] + ((1.f - X.dS[tid]) * A.gamma) * qn : 0.f;
+    const int lim = A.debug_expire == (int)SITE_TD_TARGET ? 0 : (1 << 20);
+    float q = 0.f;
+    if (row_ok) {
+      bool ok = lim > 0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) ok = ok && (unsigned)(gq[m] >> 32) == ep;
+      for (int sp = 0; sp < lim && !ok; ++sp) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) gq[m] = __hip_atomic_load(gq_src + m * kR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = true;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) ok = ok && (unsigned)(gq[m] >> 32) == ep;
+        if (!ok) __builtin_amdgcn_s_sleep(1);
+      }
+      if (!ok) report_expired(A.err, (KERN_PHASE1 << 8) | SITE_TD_TARGET);
+      float qs = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) qs += __uint_as_float((unsigned)gq[m]);
+      q = ok ? qs + qb : __builtin_nanf("");
+      const float seed = 2.f * (q - y) * A.inv_B;
+      A.cdY[2][(size_t)gr * A.clddo] = seed;
+      __hip_atomic_store(A.y_granules + gr, ((unsigned long long)ep << 32) | (unsigned long long)__float_as_uint(seed),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (A.y_out != nullptr) A.y_out[gr] = y;
+      if (A.q_out != nullptr) A.q_out[gr] = q;
+    }
+    if (A.partials_c != nullptr) {
+      float v[3] = {row_ok ? (q - y) * (q - y) : 0.f, row_ok ? q : 0.f, row_ok ? y : 0.f};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float sum = row16_sum(v[k]);
+        if (tid == 0) A.partials_c[(size_t)X.slice * 4 + k] = sum;
+      }
+    }
+  }
+};
+
 constexpr size_t kChainCOffset = (kWholeDaOffset + sizeof(DwKArgs4) + alignof(ChainArgs) - 1) / alignof(ChainArgs) * alignof(ChainArgs);
 template <class P>
 __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const DwKArgs4 Dc, const DwKArgs4 Da, const ChainArgs C_) {
@@ -1368,8 +1449,10 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   const bool traced = kTraceOn && A.trace != nullptr && u == C.trace_u;
   int n_stamp = 0;
   auto stamp = [&]() {
-    if (traced && role < 3 && (tid & 63) == 0 && (tid == 0 || slice == 0) && lead && n_stamp < kTraceStamps) {
-      const int slot = tid == 0 ? slice : 16 + (tid >> 6);
+    // (slice 0's other members of role A: their waves 0 and 8 -> slots 32 + member / 40 + member)
+    const bool mem_tr = role == 0 && slice == 0 && !lead && (tid == 0 || tid == 512);
+    if (traced && role < 3 && (tid & 63) == 0 && (((tid == 0 || slice == 0) && lead) || mem_tr) && n_stamp < kTraceStamps) {
+      const int slot = mem_tr ? (tid == 0 ? 32 : 40) + member : (tid == 0 ? slice : 16 + (tid >> 6));
       long long* tr = A.trace + (((size_t)role * 64 + slot) * kTraceStamps + n_stamp) * 2;
       tr[0] = (long long)__builtin_readcyclecounter();
       tr[1] = (long long)wall_clock64();
@@ -1407,11 +1490,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
     }
   }
   stamp();   // batch rows requested
-  if (u > 0 && role == 0) {
-    __syncthreads();
-    chain_wait2(C.ct_fin, tc, C.at_fin, ta, nullptr, 0, ep - 1u, A.err, (KERN_PHASE1 << 8) | SITE_DW_GATE);
-  }
-  stamp();   // the update before has finished
+  stamp();   // the update before has finished (role A: looks for itself below)
   const Tp3Store nostore{nullptr, nullptr, nullptr, nullptr, 0};
   // (later updates: the biases as the tiles of the update before left them — uncached copies; update 0: the masters)
   auto bias_of = [&](int which) {
@@ -1422,69 +1501,15 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
 
   if (role == 0) {
     // ---- role A: a' = tanh(actor_target(s')), q' = critic_target(s', a'), TD target, seeds       (ddpg.py:94-95)
+    // (lean.h: one job per wave; the waits for the tiles of the update before sit inside, where the weight requests are)
     Tp tp{member, 8, A.xbuf + (size_t)slice * kTpStages * A.xnc * kTpBlk, tag1, 0, A.err, KERN_PHASE1 << 8, spin};
     tp.local = cluster_on_one_xcd();
-    tp4_forward<Coh<P>, 8>(A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp, bias_of(1));
-    for (int idx = tid; idx < kR * Ad; idx += kThreads) {
-      const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
-      xb[row * kX0Ld + S + col] = gr < B ? tanhf(outS[row * kOutLd + col]) : 0.f;
-    }
-    // role B's q granules are requested from inside the second pass (after its layer-1 stage)
-    // (role B's members leave their PARTIAL q — no exchange at the end of role B: summed here, in member order, with the
-    // output bias: the cluster all-reduce's arithmetic)
-    unsigned long long gq[4] = {0ull, 0ull, 0ull, 0ull};
-    float qb = 0.f;
-    int hook_n = 0;
-    const unsigned long long* gq_src = C.qp + (size_t)slice * 64 + (tid & (kR - 1));
-    auto hook = [&]() {
-      stamp();
-      if (++hook_n == 2) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) gq[m] = __hip_atomic_load(gq_src + m * kR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        qb = ldc(u > 0 ? C.b16[2][2] : A.critic.b[2]);
-      }
-    };
-    tp4_forward<Coh<P>, 8>(A.critic_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, hook, bias_of(3));
-    if (lead && tid < 64) {
-      const int gr = row0 + tid;
-      const bool row_ok = tid < kR && gr < B;
-      const float qn = row_ok ? outS[tid * kOutLd] : 0.f;
-      const float y = row_ok ? rS[tid] + ((1.f - dS[tid]) * A.gamma) * qn : 0.f;
-      const int lim = A.debug_expire == (int)SITE_TD_TARGET ? 0 : (1 << 20);
-      float q = 0.f;
-      if (row_ok) {
-        bool ok = lim > 0;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) ok = ok && (unsigned)(gq[m] >> 32) == ep;
-        for (int sp = 0; sp < lim && !ok; ++sp) {
-#pragma unroll
-          for (int m = 0; m < 4; ++m) gq[m] = __hip_atomic_load(gq_src + m * kR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = true;
-#pragma unroll
-          for (int m = 0; m < 4; ++m) ok = ok && (unsigned)(gq[m] >> 32) == ep;
-          if (!ok) __builtin_amdgcn_s_sleep(1);
-        }
-        if (!ok) report_expired(A.err, (KERN_PHASE1 << 8) | SITE_TD_TARGET);
-        float qs = 0.f;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) qs += __uint_as_float((unsigned)gq[m]);
-        q = ok ? qs + qb : __builtin_nanf("");
-        const float seed = 2.f * (q - y) * A.inv_B;
-        A.cdY[2][(size_t)gr * A.clddo] = seed;
-        __hip_atomic_store(A.y_granules + gr, ((unsigned long long)ep << 32) | (unsigned long long)__float_as_uint(seed),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (A.y_out != nullptr) A.y_out[gr] = y;
-        if (A.q_out != nullptr) A.q_out[gr] = q;
-      }
-      if (A.partials_c != nullptr) {
-        float v[3] = {row_ok ? (q - y) * (q - y) : 0.f, row_ok ? q : 0.f, row_ok ? y : 0.f};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const float sum = row16_sum(v[k]);
-          if (tid == 0) A.partials_c[(size_t)slice * 4 + k] = sum;
-        }
-      }
-    }
+    const LeanBufs LB{P::kX2 ? smem + LY::lean_x0 : xb, smem + LY::lean_h1, smem + LY::lean_h2, smem + LY::lean_g2, scr};
+    __syncthreads();                                     // the rows are in xb
+    if constexpr (P::kX2) lean_x0_planes(xb, LB.x0, 0, 32 * ((S + Ad + 31) >> 5), tid, kThreads);
+    const LeanFlags LF{C.ct_fin, tc, C.at_fin, ta, ep - 1u, u > 0, A.err, (KERN_PHASE1 << 8) | SITE_DW_GATE};
+    const ChainTailCtx tcx{&A, C.qp + (size_t)slice * 64, u > 0 ? C.b16[2][2] : A.critic.b[2], rS, dS, ep, slice, row0, lead};
+    lean_role_a<Coh<P>, ChainTail>(A.actor_t, A.critic_t, bias_of(1), bias_of(3), LB, xb, outS, tp, S, Ad, row0, B, LF, stamp, tcx);
     stamp();
     __syncthreads();       // (the pass below reuses this workgroup's LDS)
     // ---- ... and goes on as member `member` of this slice's critic pass (update and member formed again from the block
