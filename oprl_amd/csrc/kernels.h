@@ -236,6 +236,7 @@ struct DwGate {
   const unsigned long long* seed = nullptr; int n_seed = 0;   // the per-row seeds (and `late_dY`) are out
   const float* late_dY = nullptr;      // dY buffer that is written with the seeds (the scalar critic's output layer)
   unsigned tag = 0; int spin = 0;
+  int what_if = 0;                     // timing experiments (oprl_learner_debug_expire, sites 101 ..; tools/what_if.py): 104 the seeds, 105 du, 106 the rows' flags count as seen
   unsigned* err = nullptr; unsigned err_code = 0;
   // GATE == 2 (the ACTOR's tiles on phase 2's launch, csrc/fused_ddpg.hip): no dY rows exist when the tiles start —
   // the actor's backward is linear in the output seed du = dLoss/d(pre-tanh) [B x A], and the two big layers' dY are

@@ -864,7 +864,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
         kd.gate.late_dY = h->ws_critic[0].dY[c.critics[0].n_layers - 1];
         kd.gate.tag = h->epoch; kd.gate.spin = h->debug_expire == 7 ? 0 : (1 << 20);
         kd.gate.err = h->err_dev; kd.gate.err_code = (1u << 8) | 7u;
-        kd.gate.done = fa.ct_done;
+        kd.gate.done = fa.ct_done; kd.gate.what_if = h->debug_expire;
         fa.n_ct = kd.tile_end[kDwMaxItems - 1];
         if (fa.n_ct > 192 - 64) { set_err("whole update: too many critic tiles"); return OPRL_ERR_INVALID; }
         compact(kd, &kc);
@@ -875,7 +875,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
         kd.gate.seed = fa.du_granules; kd.gate.n_seed = B;
         kd.gate.tag = h->epoch; kd.gate.spin = h->debug_expire == 7 ? 0 : (1 << 20);
         kd.gate.err = h->err_dev; kd.gate.err_code = (2u << 8) | 7u;
-        kd.gate.kind[0] = 2; kd.gate.kind[1] = 1; kd.gate.kind[2] = 0; kd.gate.kind[3] = 0;
+        kd.gate.kind[0] = 2; kd.gate.kind[1] = 1; kd.gate.kind[2] = 0; kd.gate.kind[3] = 0; kd.gate.what_if = h->debug_expire;
         kd.gate.h2 = h->ws_actor.X[2];
         kd.gate.w3 = fa.w3_snap;
         kd.gate.g1 = fa.g1_granules;
@@ -1427,7 +1427,7 @@ extern "C" int oprl_debug_noise(oprl_learner* h, int32_t stream_id, uint64_t cou
 }
 
 extern "C" int oprl_learner_debug_expire(oprl_learner* h, int32_t site) {
-  if (!h || site < 0 || site > 8) { set_err("oprl_learner_debug_expire: invalid argument"); return OPRL_ERR_INVALID; }
+  if (!h || site < 0 || (site > 8 && (site < 101 || site > 106 || site == 103))) { set_err("oprl_learner_debug_expire: invalid argument"); return OPRL_ERR_INVALID; }
   h->debug_expire = site;
   h->lw_pairs.spin = site == 8 ? 0 : (1 << 20);      // (8: the hand-over inside k_lw_mid_pair)
   return OPRL_OK;

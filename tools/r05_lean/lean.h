@@ -5,9 +5,12 @@
 // reduces), four waves share a SIMD's issue port, and a pass takes ~4-5 us whatever the precision (r04-6: "not a
 // memory stage: ~200 instructions per wave x 4 waves per SIMD").  The arithmetic of a pass is ~700 instructions for
 // the WHOLE workgroup.  Here
-//   * a stage runs on ONE QUARTET of waves (one wave per SIMD) — or on one wave — and a wave has ONE job per pass:
-//     its weight fragments and biases are requested straight into ITS registers as early as the data exists
-//     (the second pass's while the first one runs), all other waves sit in s_barrier;
+//   * a wave has ONE job per stage, a few dozen instructions, and its weight fragments and biases are requested straight
+//     into ITS registers as early as the data exists (the second pass's while the first one runs).  One wave issues one
+//     vector instruction per ~5 cycles whatever its neighbours do (tools/ubench_icache2.hip: 4.8 cycles with 1, 4 or 16
+//     waves per workgroup), so what a stage costs is the instruction count of its LONGEST wave: layer 0 and the dz1
+//     stage are one 16 x 16 tile per wave on all sixteen, the member's two layer-1 tiles run on a quartet, the output
+//     layer + cluster exchange on one wave; the others sit in s_barrier;
 //   * the products are formed TRANSPOSED, D^T = W-tile · X^T: the weight fragment is the MFMA's A operand (the packs'
 //     lane order serves either side), the activations the B operand, and a lane ends up with FOUR CONSECUTIVE
 //     FEATURES of one minibatch row — bias is one 16-byte load, the epilogue one LDS store;
@@ -112,97 +115,91 @@ __device__ __forceinline__ void lean_x0_planes(const float* x, float* planes, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The cluster all-reduce of a NARROW block (<= 8 columns) held TRANSPOSED in accumulator layout: lane (kk, i) has
-// features 4 kk + r of minibatch row i.  Valid features [f_first, f_first + ncols) travel as columns cc_first .. of the
-// exchange block and land in out[row * kOutLd + cc_first + k] (+ b0 / b1: the bias of this lane's element slot 0 / 1,
-// lean_elem_col).  One wave; wscr = 256 floats of LDS of its own.  Slots are feature-major (16 rows of a column
-// contiguous).  poll = false: publish only (a member that does not need the sum).
+// The cluster all-reduce of a NARROW block (<= 8 valid columns) held TRANSPOSED in accumulator layout — lane (kk, i) has
+// features 4 kk + r of minibatch row i — STRAIGHT FROM THE REGISTERS: no LDS transpose on either side of the exchange
+// (the first form went through LDS twice: 0.56 us from the last MFMA to the publish, profiles/r05_experiments.txt).
+// Valid features [f_first, f_first + ncols); the lane groups kk that hold one of them take part (at most three).  A
+// member's block: [16 rows][12 slots] granules from `slot0` on; a lane's four granules are 32 contiguous bytes, read
+// as two 16-byte loads per peer (each 8-byte half carries its own tag: a torn pair is two valid granules or a retry).
+// Returns whether this lane holds sums; sum[r] = the members' sum (member order) of feature 4 kk + r.
+// poll = false: publish only.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lean_elem_col(int j, int ncols) {     // column (0 .. ncols) of this lane's element slot j, -1: none
-  const int e = (int)(threadIdx.x & 63) + 64 * j;
-  return e < 16 * ncols ? e >> 4 : -1;
-}
 template <int NM, class ST = NoStamp>
-__device__ __forceinline__ void lean_allreduce(const f32x4 mine, int f_first, int ncols, int cc_first, float* wscr,
-                                               float b0, float b1, float* out, const Tp& tp, bool poll = true, ST sf = ST()) {
+__device__ __forceinline__ bool lean_ar(const f32x4 mine, int f_first, int ncols, int slot0, const Tp& tp, f32x4& sum,
+                                        bool poll = true, ST sf = ST()) {
   const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
   const unsigned tag = (tp.tag << 6) | (unsigned)(tp.stage & 63);
+  const int g = kk - (f_first >> 2), ng = ((f_first + ncols - 1) >> 2) - (f_first >> 2) + 1;
+  const bool in = g >= 0 && g < ng;
+  // (every group's four slots are written — zeros beyond the valid columns — so that a reader's 16-byte halves always
+  // find two tagged granules)
+  const int nh = (ncols + (f_first & 3)) > 2 ? 2 : 1;      // 16-byte halves a lane needs (wave-uniform)
+  unsigned long long* base = tp.xbuf + (size_t)tp.stage * NM * kTpBlk + slot0;
+  const int off = i * 12 + 4 * (in ? g : 0);
+  sum = mine;
+  if (!in) return false;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) wscr[(4 * kk + r) * 16 + i] = mine[r];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const int n = 16 * ncols;                     // <= 128
-  unsigned long long* base = tp.xbuf + (size_t)tp.stage * NM * kTpBlk;
-  float val[2];
-  const float bv[2] = {b0, b1};
-  int off[2], oidx[2];
-  bool have[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int e = lane + 64 * j;
-    have[j] = e < n;
-    const int fl = have[j] ? e >> 4 : 0, row = e & 15;
-    val[j] = wscr[(f_first + fl) * 16 + row];
-    off[j] = (cc_first + fl) * 16 + row;
-    oidx[j] = row * kOutLd + cc_first + fl;
-    if (have[j]) {
-      const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(val[j]);
-      if (tp.local) __hip_atomic_store(base + (size_t)tp.c * kTpBlk + off[j], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      else __hip_atomic_store(base + (size_t)tp.c * kTpBlk + off[j], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int r = 0; r < 4; ++r) {
+    const int f = 4 * kk + r;
+    const float v = (f >= f_first && f < f_first + ncols) ? mine[r] : 0.f;
+    const unsigned long long gv = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+    if (r < 2 * nh) {
+      if (tp.local) __hip_atomic_store(base + (size_t)tp.c * kTpBlk + off + r, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else __hip_atomic_store(base + (size_t)tp.c * kTpBlk + off + r, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   sf();     // published
-  if (!poll) return;
-  if (have[0]) {
-    auto issue = [&](unsigned long long (&x)[NM][2]) {
+  if (!poll) return true;
+  const float* fb = reinterpret_cast<const float*>(base);
+  f32x4 x[NM][2];
+  bool ok = false;
+  for (int spin = 0; spin < tp.spin && !ok; ++spin) {
 #pragma unroll
-      for (int m = 0; m < NM; ++m)
+    for (int m = 0; m < NM; ++m)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          x[m][j] = (m == tp.c || !have[j]) ? ((unsigned long long)tag << 32)
-                                            : __hip_atomic_load(base + (size_t)m * kTpBlk + off[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto good = [&](const unsigned long long (&x)[NM][2]) {
-      bool ok = true;
+      for (int h = 0; h < 2; ++h)
+        if (m != tp.c && h < nh) x[m][h] = ld4_agent(fb, (unsigned)(((size_t)m * kTpBlk + off + 2 * h) * 2));
+    ok = true;
 #pragma unroll
-      for (int m = 0; m < NM; ++m)
+    for (int m = 0; m < NM; ++m)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) ok = ok && (unsigned)(x[m][j] >> 32) == tag;
-      return ok;
-    };
-    auto finish = [&](const unsigned long long (&x)[NM][2], bool ok) {
+      for (int h = 0; h < 2; ++h)
+        if (m != tp.c && h < nh) ok = ok && __float_as_uint(x[m][h][1]) == tag && __float_as_uint(x[m][h][3]) == tag;
+    if (!ok) __builtin_amdgcn_s_sleep(1);
+  }
+  sf();     // all peers seen
+  if (!ok) {
+    report_expired(tp.err, tp.err_code | SITE_CLUSTER);
+    const float nan = __builtin_nanf("");
+    sum = f32x4{nan, nan, nan, nan};
+    return true;
+  }
+  sum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float sum = 0.f;
-#pragma unroll
-        for (int m = 0; m < NM; ++m) sum += (m == tp.c) ? val[j] : __uint_as_float((unsigned)x[m][j]);
-        if (have[j]) out[oidx[j]] = ok ? sum + bv[j] : __builtin_nanf("");
-      }
-    };
-    unsigned long long xa[NM][2];
-    bool ok = false;
-    // (one poll set at a time, a sleep between two: polling harder — two sets in flight, no sleep — made every exchange
-    // and every stage around it SLOWER, 26 -> 32 us per update: the polls queue in front of the very stores they wait for)
-    for (int spin = 0; spin < tp.spin && !ok; ++spin) {
-      issue(xa);
-      ok = good(xa);
-      if (!ok) __builtin_amdgcn_s_sleep(1);
-    }
-    sf();   // all peers seen
-    if (ok) finish(xa, true);
-    if (!ok) {
-      report_expired(tp.err, tp.err_code | SITE_CLUSTER);
-      finish(xa, false);
+  for (int m = 0; m < NM; ++m) {
+    if (m == tp.c) {
+      sum += mine;
+    } else {
+      sum[0] += x[m][0][0];
+      sum[1] += x[m][0][2];
+      if (nh > 1) { sum[2] += x[m][1][0]; sum[3] += x[m][1][2]; }
     }
   }
+  return true;
+}
+
+// tanh through the hardware's exp2 and reciprocal, 1 - 2 / (e^2x + 1): absolute error ~1.2e-7 (the library routine is ~40
+// instructions with a branch; four of them per lane sat behind the first exchange of role A)
+__device__ __forceinline__ float lean_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);      // e^(2x)
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Jobs.  `PL` = the precision policy, possibly Coh<> (engine.h); q = the wave's index inside its quartet.
-// Every job is load() — requests only, as early as the weights exist — and run().
+// Jobs.  `PL` = the precision policy, possibly Coh<> (engine.h).  Every job is load() — requests only, as early as
+// the weights exist — and run().
 // ---------------------------------------------------------------------------------------------------------------
-// Layer 0 (replicated): quartet wave q computes hidden tiles 4 q .. 4 q + 3 over the whole (short) contraction.
+// Layer 0 (replicated over the cluster's members): wave w computes hidden tile w over the whole (short) contraction.
 // S0P macro steps come from registers; inputs wider than that (humanoid) fetch the rest inside run().
 template <class PL>
 struct LeanL0 {
@@ -210,58 +207,39 @@ struct LeanL0 {
   static constexpr int S0P = X2 ? 1 : 2;             // 32 input columns
   using ACT = LeanAct<X2>;
   using LD = LeanLd<X2>;
-  typename PL::Frag w[4][S0P];
-  f32x4 b[4];
+  typename PL::Frag w[S0P];
+  f32x4 b;
   const float* pf;
   int ns0;
-  __device__ __forceinline__ void load(const float* pf0, const float* b0, int k0, int q) {
+  __device__ __forceinline__ void load(const float* pf0, const float* b0, int k0, int wave) {
     const int lane = threadIdx.x & 63, kk = lane >> 4;
     ns0 = (k0 + PL::KS - 1) / PL::KS;
-    pf = pf0 + (size_t)(4 * q) * ns0 * PL::kBlk + lane * 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) PL::template ldfn<S0P>(w[j], pf + (size_t)j * ns0 * PL::kBlk, ns0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = lean_ldb4<PL>(b0 + 16 * (4 * q + j) + 4 * kk);
+    pf = pf0 + (size_t)wave * ns0 * PL::kBlk + lane * 4;
+    PL::template ldfn<S0P>(w, pf, ns0);
+    b = lean_ldb4<PL>(b0 + 16 * wave + 4 * kk);
   }
   // x0: the input tile (planes / fp32 rows); h1: the hidden tile it writes.  Returns false if a value left PrecX2's range.
-  __device__ __forceinline__ bool run(const float* x0, float* h1, int q) {
+  __device__ __forceinline__ bool run(const float* x0, float* h1, int wave) {
     const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
     constexpr float kO = PL::kOut / PL::kFwdA;
-    f32x4 acc[4];
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < S0P; ++s) {
-      if (s < ns0) {
-        const typename ACT::Bop bx = ACT::template ldB<LD::X0>(x0, i, kk, s);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ACT::mma(acc[j], w[j][s], bx);
-      }
-    }
-    for (int s = S0P; s < ns0; ++s) {                 // (wide inputs: fragments fetched here)
-      const typename ACT::Bop bx = ACT::template ldB<LD::X0>(x0, i, kk, s);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const typename PL::Frag f = PL::ldf(pf + ((size_t)j * ns0 + s) * PL::kBlk);
-        ACT::mma(acc[j], f, bx);
-      }
-    }
+    for (int s = 0; s < S0P; ++s)
+      if (s < ns0) ACT::mma(acc, w[s], ACT::template ldB<LD::X0>(x0, i, kk, s));
+    for (int s = S0P; s < ns0; ++s)                   // (wide inputs: fragments fetched here)
+      ACT::mma(acc, PL::ldf(pf + (size_t)s * PL::kBlk), ACT::template ldB<LD::X0>(x0, i, kk, s));
+    const f32x4 pre = acc * kO + b;
     bool ok = true;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x4 pre = acc[j] * kO + b[j];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ok = ok && PL::range_ok(pre[r]);
-      const f32x4 v = f32x4{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f), fmaxf(pre[2], 0.f), fmaxf(pre[3], 0.f)};
-      ACT::template st4<LD::H>(h1, i, 16 * (4 * q + j) + 4 * kk, v, PL::kFwdA);
-    }
+    for (int r = 0; r < 4; ++r) ok = ok && PL::range_ok(pre[r]);
+    ACT::template st4<LD::H>(h1, i, 16 * wave + 4 * kk, f32x4{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f), fmaxf(pre[2], 0.f), fmaxf(pre[3], 0.f)}, PL::kFwdA);
     return ok;
   }
 };
 
 // Layer 1, member c of EIGHT: the member's two hidden tiles (columns 32 c ..), quartet wave q = (tile q & 1, half q >> 1
 // of the 256-deep contraction).  run_partial(): the wave's partial tile; the upper halves go through `scr` (2 x 256
-// floats), [barrier], finish(): waves q < 2 add them, bias + ReLU, and write the member-LOCAL tile h2 (32 columns).
+// floats), [barrier], finish_pre(): waves q < 2 add them + bias -> the pre-activation values of the member-LOCAL tile.
 template <class PL>
 struct LeanL1 {
   static constexpr bool X2 = PL::kX2;
@@ -296,9 +274,20 @@ struct LeanL1 {
     constexpr float kO = PL::kOut / PL::kFwdA;
     return (acc + ld4(scr + (q & 1) * 256 + lane * 4)) * kO + b;
   }
+  // ... ReLU'd and written to h2; false if a value left PrecX2's range
+  __device__ __forceinline__ bool finish(const float* scr, float* h2, int q) {
+    const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
+    const f32x4 pre = finish_pre(scr, q);
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ok = ok && PL::range_ok(pre[r]);
+    ACT::template st4<LD::L>(h2, i, 16 * q + 4 * kk, f32x4{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f), fmaxf(pre[2], 0.f), fmaxf(pre[3], 0.f)}, PL::kFwdA);
+    return ok;
+  }
 };
 
-// Output layer (<= 8 outputs: one tile) over the member's 32 columns + the cluster all-reduce: ONE wave.
+// Output layer (<= 8 outputs: one tile) over the member's 32 columns + the cluster all-reduce: ONE wave.  The sums
+// (+ bias) come back in the wave's registers: lane (kk, i) = outputs 4 kk + r of row i (kk < 2).
 template <class PL, int NM>
 struct LeanL2 {
   static constexpr bool X2 = PL::kX2;
@@ -306,42 +295,30 @@ struct LeanL2 {
   using ACT = LeanAct<X2>;
   using LD = LeanLd<X2>;
   typename PL::Frag w[M];
-  float bv[2];
+  f32x4 b;
   __device__ __forceinline__ void load(const float* pf2, const float* b2, int n_out, int c) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, kk = lane >> 4;
     PL::template ldfn<M>(w, pf2 + ((size_t)c * M) * PL::kBlk + lane * 4);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = lean_elem_col(j, n_out);
-      bv[j] = k >= 0 ? PL::ldb(b2 + k) : 0.f;
-    }
+    for (int r = 0; r < 4; ++r) b[r] = 4 * kk + r < n_out ? PL::ldb(b2 + 4 * kk + r) : 0.f;
   }
   template <class ST = NoStamp>
-  __device__ __forceinline__ void run(const float* h2, float* wscr, float* outS, int n_out, const Tp& tp, bool poll = true, ST sf = ST()) {
+  __device__ __forceinline__ bool run(const float* h2, int n_out, const Tp& tp, f32x4& out, bool poll = true, ST sf = ST()) {
     const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
     constexpr float kO = PL::kOut / PL::kFwdA;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < M; ++s) ACT::mma(acc, w[s], ACT::template ldB<LD::L>(h2, i, kk, s));
-    lean_allreduce<NM>(acc * kO, 0, n_out, 0, wscr, bv[0], bv[1], outS, tp, poll, sf);
+    f32x4 sum;
+    const bool in = lean_ar<NM>(acc * kO, 0, n_out, 0, tp, sum, poll, sf);
+    out = sum + b;
+    return in;
   }
 };
 
 // a pass's barrier (workgroup-wide; LDS traffic only — requests to memory stay in flight across it)
 __device__ __forceinline__ void lean_bar() { __syncthreads(); }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Scalar-output net (a critic), forward + constant-seed backward to the input columns [dcol0, dcol0 + dcols) (dcols <= 8,
-// inside at most two 16-column tiles), on a cluster of EIGHT — tp4_scalar_fb<P, 8>'s arithmetic, one job per wave:
-//   quartet 0: layer 0 -> h1                         [bar 1]
-//   quartet 1: layer 1 partial                       [bar 2]   waves 4, 5: h2 and the unit-seed g2 (member-local)   [bar 3]
-//   quartet 2: dz1 partial (4 tiles each) over the member's columns, masked in place over h1     [bar 4]
-//              wave 0 (idle since layer 0): q = output layer + all-reduce (the lead member's q_sum_out; the others publish only)
-//   quartet 3: input-column gradient, a quarter of the 256-deep contraction each -> scr          [bar 5]
-//              waves 12, 13: tile sums + all-reduce -> dactS                                       [bar 6]
-// The caller has x0 ready (visible after a barrier of its own or bar 0 below) and every wave calls this once.
-// tp.stage advances by 2 (q: stage, gradient: stage + 1).
-// ---------------------------------------------------------------------------------------------------------------
 struct LeanBufs {
   float* x0;        // layer-0 input: PrecX2 planes [2][16][kLd0H] halfs / fp32 rows [16][kX0Ld]
   float* h1;        // [2][16][kLdH] halfs / [16][kWL4] floats
@@ -350,9 +327,23 @@ struct LeanBufs {
   float* scr;       // >= 4096 floats
 };
 
-template <class PL, class ST = NoStamp>
-__device__ __forceinline__ void lean_scalar_fb(const Net& net, const LeanBufs& L, float* outS, Tp& tp, int row0, int B, float seed,
-                                               int dcol0, int dcols, float* dactS, ST sf, float* q_sum_out, const BiasOv bo) {
+// ---------------------------------------------------------------------------------------------------------------
+// Scalar-output net (a critic), forward + constant-seed backward to the input columns [dcol0, dcol0 + dcols) (dcols <= 8,
+// inside at most two 16-column tiles), on a cluster of EIGHT — tp4_scalar_fb<P, 8>'s arithmetic, one job per wave and stage:
+//   all waves : layer 0, tile = wave -> h1                                                      [bar 1]
+//   waves 4-7 : layer 1 partial                       [bar 2]   waves 4, 5: h2 and the unit-seed g2 (member-local)   [bar 3]
+//   all waves : dz1 partial, k tile = wave, over the member's columns, masked in place over h1  [bar 4]
+//   waves 12-15: input-column gradient, a quarter of the 256-deep contraction each -> scr        [bar 5]
+//               waves 12 (, 13): tile sums + all-reduce; the sums go to `done(sum, first column of the lane's four, row)`
+//               from the registers of the lanes that hold valid columns — no barrier behind them (need_sum false: a
+//               member that only contributes publishes and leaves)
+//   wave 0 (behind bar 5): q = output layer + all-reduce (for the lead member's q_sum_out; the other members publish only)
+// The caller has x0 ready (visible after bar 0 below at the latest) and every wave calls this once.
+// tp.stage advances by 2 (q: stage, gradient: stage + 1).
+// ---------------------------------------------------------------------------------------------------------------
+template <class PL, class ST, class DONE>
+__device__ __forceinline__ void lean_scalar_fb(const Net& net, const LeanBufs& L, Tp& tp, int row0, int B, float seed,
+                                               int dcol0, int dcols, ST sf, float* q_sum_out, const BiasOv bo, bool need_sum, DONE done) {
   constexpr bool X2 = PL::kX2;
   constexpr int NM = 8;
   using ACT = LeanAct<X2>;
@@ -371,33 +362,34 @@ __device__ __forceinline__ void lean_scalar_fb(const Net& net, const LeanBufs& L
   if constexpr (X2) sb = 4.f * PL::a_scale(fabsf(seed));
   const float ob = PL::kOut / sb;
   const int dt0 = dcol0 >> 4, dnt = ((dcol0 + dcols - 1) >> 4) - dt0 + 1;      // 1 or 2 tiles
-  if (quart == 0) {
-    LeanL0<PL> j0;
-    j0.load(net.pf[0], nb0, net.dims[0], q);
-    LeanL2<PL, NM> j2;
-    if (q == 0) j2.load(net.pf[2], nb2, 1, c);
-    lean_bar();                                   // bar 0: x0 visible
-    const bool ok = j0.run(L.x0, L.h1, q);
+
+  // A PROGRAM PER QUARTET (the same barrier sequence in each): what a quartet never holds costs it no registers — one
+  // common instruction stream with wave-uniform ifs makes every job's fragments live at once (39 registers spilled).
+  auto l0 = [&](LeanL0<PL>& j0) {
+    const bool ok = j0.run(L.x0, L.h1, wave);
     if (__builtin_expect(!ok, 0)) report_expired(tp.err, tp.err_code | SITE_X2_RANGE);
     sf();
-    lean_bar();                                   // 1
-    lean_bar();                                   // 2
-    lean_bar();                                   // 3: h2, g2 visible
-    if (q == 0) {
-      const bool lead = c == 0;
-      j2.run(L.h2, L.scr + 2048, outS, 1, tp, lead && q_sum_out != nullptr);
-      if (lead && q_sum_out != nullptr) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const float qv = (lane < kR && row0 + lane < B) ? outS[lane * kOutLd] : 0.f;
-        const float qs = row16_sum(qv);
-        if (lane == 0) *q_sum_out = qs;
-      }
-    }
-    lean_bar();                                   // 4
-    lean_bar();                                   // 5
-  } else if (quart == 1) {
+  };
+  // dz1 partial, k tile = wave, masked in place over h1 (a lane rewrites the positions whose masks it holds)
+  auto dz1 = [&](const typename PL::Frag (&wz)[M], const f32x4 mk) {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < M; ++s) ACT::mma(acc, wz[s], ACT::template ldB<LD::L>(L.g2, i, kk, s));
+    f32x4 d;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[r] = mk[r] > 0.f ? acc[r] * ob : 0.f;
+    ACT::template st4<LD::H>(L.h1, i, 16 * wave + 4 * kk, d, sb);
+    sf();
+  };
+  auto ld_wz = [&](typename PL::Frag (&wz)[M]) {       // dz1: k tile `wave` of W2^T over the member's 32 columns
+    PL::template ldfn<M>(wz, net.pb[1] + ((size_t)wave * W + c * M) * BK + lane * 4);
+  };
+  auto masks = [&]() { return ACT::template ld4pos<LD::H>(L.h1, i, 16 * wave + 4 * kk); };   // (h1 complete)
+  if (quart == 1) {
+    LeanL0<PL> j0;
+    j0.load(net.pf[0], nb0, net.dims[0], wave);
+    typename PL::Frag wz[M];
+    ld_wz(wz);
     LeanL1<PL> j1;
     j1.load(net.pf[1], nb1, c, q);
     // W3[32 c + 16 t + 4 kk + r], r < 4 (the critic's output layer through its W^T pack: one macro step, element 0 of lane
@@ -409,11 +401,13 @@ __device__ __forceinline__ void lean_scalar_fb(const Net& net, const LeanBufs& L
 #pragma unroll
       for (int r = 0; r < 4; ++r) w3[r] = PL::first(p + 4 * r);
     }
-    lean_bar();                                   // 0
-    lean_bar();                                   // 1: h1 visible
+    lean_bar();                                   // 0: x0 visible
+    l0(j0);
+    lean_bar();                                   // 1: h1
     j1.run_partial(L.h1, L.scr, q);
+    const f32x4 mk = masks();
     sf();
-    lean_bar();                                   // 2: upper halves visible
+    lean_bar();                                   // 2: upper halves
     if (q < 2) {
       const f32x4 pre = j1.finish_pre(L.scr, q);
       bool ok = true;
@@ -430,58 +424,28 @@ __device__ __forceinline__ void lean_scalar_fb(const Net& net, const LeanBufs& L
       ACT::template st4<LD::L>(L.g2, i, 16 * q + 4 * kk, g, sb);
     }
     sf();
-    lean_bar();                                   // 3
-    lean_bar();                                   // 4
+    lean_bar();                                   // 3: h2, g2
+    dz1(wz, mk);
+    lean_bar();                                   // 4: dz1 partial (over h1)
     lean_bar();                                   // 5
-  } else if (quart == 2) {
-    // dz1 partial: k tiles 4 q .. 4 q + 3 of W2^T, contraction over the member's 32 columns
-    typename PL::Frag wz[4][M];
-    {
-      const float* p = net.pb[1] + ((size_t)(4 * q) * W + c * M) * BK + lane * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) PL::template ldfn<M>(wz[j], p + (size_t)j * W * BK);
-    }
-    lean_bar();                                   // 0
-    lean_bar();                                   // 1
-    lean_bar();                                   // 2
-    // (the masks of this lane's outputs: h1 is complete since bar 1)
-    f32x4 mk[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) mk[j] = ACT::template ld4pos<LD::H>(L.h1, i, 16 * (4 * q + j) + 4 * kk);
-    lean_bar();                                   // 3: g2 visible
-    {
-      f32x4 acc[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < M; ++s) {
-        const typename ACT::Bop bx = ACT::template ldB<LD::L>(L.g2, i, kk, s);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ACT::mma(acc[j], wz[j][s], bx);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 d;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) d[r] = mk[j][r] > 0.f ? acc[j][r] * ob : 0.f;
-        ACT::template st4<LD::H>(L.h1, i, 16 * (4 * q + j) + 4 * kk, d, sb);
-      }
-    }
-    sf();
-    lean_bar();                                   // 4: dz1 partial visible (over h1)
-    lean_bar();                                   // 5
-  } else {
-    // input-column gradient: tiles dt0 (, dt0 + 1) of W0^T, quarter q of the 256-deep contraction
-    typename PL::Frag wd[2][Q4];
+  } else if (quart == 3) {
+    LeanL0<PL> j0;
+    j0.load(net.pf[0], nb0, net.dims[0], wave);
+    typename PL::Frag wz[M];
+    ld_wz(wz);
+    typename PL::Frag wd[2][Q4];                  // input-column gradient: tiles dt0 (, dt0 + 1) of W0^T, quarter q
     {
       const float* p = net.pb[0] + ((size_t)dt0 * W + q * Q4) * BK + lane * 4;
       PL::template ldfn<Q4>(wd[0], p);
       PL::template ldfn<Q4>(wd[1], p + (size_t)W * BK, dnt > 1 ? Q4 : 0);
     }
     lean_bar();                                   // 0
+    l0(j0);
     lean_bar();                                   // 1
+    const f32x4 mk = masks();
     lean_bar();                                   // 2
     lean_bar();                                   // 3
+    dz1(wz, mk);
     lean_bar();                                   // 4
     {
       f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
@@ -495,7 +459,7 @@ __device__ __forceinline__ void lean_scalar_fb(const Net& net, const LeanBufs& L
       *reinterpret_cast<f32x4*>(L.scr + (q * 2 + 1) * 256 + lane * 4) = a1;
     }
     sf();
-    lean_bar();                                   // 5: quarters visible
+    lean_bar();                                   // 5: quarters
     if (q < dnt) {
       Tp tp2 = tp;
       tp2.stage = tp.stage + 1;
@@ -506,52 +470,71 @@ __device__ __forceinline__ void lean_scalar_fb(const Net& net, const LeanBufs& L
       const int f_first = dcol0 > t0 ? dcol0 - t0 : 0;
       const int cc_first = t0 + f_first - dcol0;
       const int ncols = min(16 - f_first, dcols - cc_first);
-      lean_allreduce<NM>(part * ob, f_first, ncols, cc_first, L.scr + 2048 + 256 * (1 + q), 0.f, 0.f, dactS, tp2);
+      f32x4 sum;
+      if (lean_ar<NM>(part * ob, f_first, ncols, 192 * q, tp2, sum, need_sum, sf) && need_sum)
+        done(sum, t0 + 4 * kk - dcol0, i);        // (column of sum[0] relative to dcol0 — may be negative / beyond dcols: the callee masks)
+    }
+  } else {
+    // quartets 0 and 2: layer 0 and dz1 only; wave 0 also the logged q
+    LeanL0<PL> j0;
+    j0.load(net.pf[0], nb0, net.dims[0], wave);
+    typename PL::Frag wz[M];
+    ld_wz(wz);
+    LeanL2<PL, NM> j2;
+    if (wave == 0) j2.load(net.pf[2], nb2, 1, c);
+    lean_bar();                                   // 0
+    l0(j0);
+    lean_bar();                                   // 1
+    const f32x4 mk = masks();
+    lean_bar();                                   // 2
+    lean_bar();                                   // 3
+    dz1(wz, mk);
+    lean_bar();                                   // 4
+    lean_bar();                                   // 5
+    if (wave == 0) {
+      // q: logged only — the lead member sums it, the others publish; beside the gradient's exchange, nothing waits for it
+      const bool lead = c == 0;
+      f32x4 qv;
+      const bool in = j2.run(L.h2, 1, tp, qv, lead && q_sum_out != nullptr);
+      if (lead && q_sum_out != nullptr) {
+        const float qs = row16_sum((in && kk == 0 && row0 + i < B) ? qv[0] : 0.f);
+        if (lane == 0) *q_sum_out = qs;
+      }
     }
   }
   tp.stage += 2;
   sf();
-  lean_bar();                                     // 6: dactS (and outS) visible
 }
-
 
 // one WAVE waits for n (<= 192) flag granules {tag, *}; bounded; `wait` false: nothing to wait for
 __device__ __forceinline__ void lean_wave_wait(const unsigned long long* flags, int n, unsigned tag, bool wait, unsigned* err, unsigned code) {
   if (!wait) return;
   const int lane = threadIdx.x & 63;
   bool ok = false;
-  auto sample = [&](unsigned (&t)[3]) {
+  for (int spin = 0; spin < kTpSpin && !ok; ++spin) {
+    bool mine = true;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int idx = lane + 64 * k;
-      t[k] = idx < n ? (unsigned)(__hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) : tag;
+      if (idx < n) mine = mine && (unsigned)(__hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == tag;
     }
-  };
-  auto all_set = [&](const unsigned (&t)[3]) {
-    const bool mine = t[0] == tag && t[1] == tag && t[2] == tag;
-    return __builtin_amdgcn_ballot_w64(!mine) == 0ull;
-  };
-  unsigned ta[3];
-  for (int spin = 0; spin < kTpSpin && !ok; ++spin) {
-    sample(ta);
-    ok = all_set(ta);
+    ok = __builtin_amdgcn_ballot_w64(!mine) == 0ull;
     if (!ok) __builtin_amdgcn_s_sleep(2);
   }
   if (!ok && lane == 0) report_expired(err, code);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Role A of k_ddpg_chain — a' = tanh(actor_target(s')), q' = critic_target(s', a') — on a cluster of EIGHT, one job
-// per wave.  The target critic's weights are final since the critic's tiles of the update before (flags ct): their
-// requests go out BEFORE the actor's tiles (flags at) are waited for, into the registers of the waves that use them.
-//   waves 0-3   actor_t layer 0            | wave 0: critic_t output layer + all-reduce
-//   waves 4-7   actor_t layer 1
-//   waves 8-11  critic_t layer 0           | wave 8: actor_t output layer + all-reduce, a' = tanh(.) -> the input tile
-//   waves 12-15 critic_t layer 1           | wave 15: the flag waits
+// Role A of k_ddpg_chain — a' = tanh(actor_target(s')), q' = critic_target(s', a') — on a cluster of EIGHT.  The target
+// critic's weights are final since the critic's tiles of the update before (flags ct): their requests go out BEFORE the
+// actor's tiles (flags at) are waited for, into the registers of the waves that use them.
+//   all waves   layer 0 of both passes, tile = wave
+//   waves 4-7   actor_t layer 1                 | wave 8: actor_t output layer + all-reduce, a' = tanh(.) -> the input tile
+//   waves 12-15 critic_t layer 1                | wave 0: critic_t output layer + all-reduce, then TAIL
+//   wave 15     the flag waits
 // xb: the fp32 rows [s' | .] (a' is written there too); PrecX2: L.x0 = the planes of [s' | 0] (a' is added).
-// TAIL (wave 0 only): request(ctx) while the wave idles before its last job, finish(ctx, outS) right behind q' (outS[row *
-// kOutLd] = q', this wave's own writes) — the TD target and the seeds, no workgroup barrier in front of them.
-// tp.stage advances by 2.
+// TAIL (wave 0): request(ctx) before the second pass's layer 1, finish(ctx, q') right behind the exchange — lane i < 16 holds
+// row i's q' — the TD target and the seeds, no barrier in front of them.  tp.stage advances by 2.
 // ---------------------------------------------------------------------------------------------------------------
 struct LeanFlags {
   const unsigned long long* ct; int n_ct;
@@ -561,7 +544,7 @@ struct LeanFlags {
 };
 template <class PL, class TAIL, class ST, class TCTX>
 __device__ __forceinline__ void lean_role_a(const Net& actor_t, const Net& critic_t, const BiasOv ba, const BiasOv bc, const LeanBufs& L,
-                                            float* xb, float* outS, Tp& tp, int S, int Ad, int row0, int B, const LeanFlags F,
+                                            float* xb, Tp& tp, int S, int Ad, int row0, int B, const LeanFlags F,
                                             ST sf, const TCTX& tctx) {
   constexpr bool X2 = PL::kX2;
   constexpr int NM = 8;
@@ -577,129 +560,140 @@ __device__ __forceinline__ void lean_role_a(const Net& actor_t, const Net& criti
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int quart = wave >> 2, q = wave & 3;
   const int c = tp.c;
+  const float* const x0 = X2 ? L.x0 : xb;
+  // A PROGRAM PER QUARTET, the same barrier sequence in each (lean_scalar_fb)
+  auto l0 = [&](LeanL0<PL>& j) {
+    const bool ok = j.run(x0, L.h1, wave);
+    if (__builtin_expect(!ok, 0)) report_expired(tp.err, tp.err_code | SITE_X2_RANGE);
+  };
+  auto l1fin = [&](LeanL1<PL>& j1) {
+    if (q < 2) {
+      if (__builtin_expect(!j1.finish(L.scr, L.h2, q), 0)) report_expired(tp.err, tp.err_code | SITE_X2_RANGE);
+    }
+    sf();
+  };
   if (quart == 0) {
+    // ---- layer 0 of both passes; wave 0: the target critic's output layer, its exchange and the tail
+    LeanL0<PL> a0, c0;
     LeanL2<PL, NM> j2;
-    LeanL0<PL> j0;
-    TAIL tail;                                    // (wave 0: what follows q' — its state lives in this wave's registers only)
+    TAIL tail;
     lean_bar();                                   // a: the critic's tiles of the update before are done
+    c0.load(critic_t.pf[0], cb0, critic_t.dims[0], wave);
     if (q == 0) j2.load(critic_t.pf[2], cb2, 1, c);
     lean_bar();                                   // b: the actor's tiles as well; s' in place
-    j0.load(actor_t.pf[0], ab0, actor_t.dims[0], q);
-    const bool ok = j0.run(L.x0, L.h1, q);
-    if (__builtin_expect(!ok, 0)) report_expired(tp.err, tp.err_code | SITE_X2_RANGE);
+    a0.load(actor_t.pf[0], ab0, actor_t.dims[0], wave);
+    l0(a0);
     sf();
-    lean_bar();                                   // 1
+    lean_bar();                                   // 1: h1
     lean_bar();                                   // 2
     lean_bar();                                   // 3
-    lean_bar();                                   // 4
-    lean_bar();                                   // 5
+    lean_bar();                                   // 4: [s' | a'] complete
+    l0(c0);
     if (q == 0) tail.request(tctx);
+    sf();
+    lean_bar();                                   // 5
     lean_bar();                                   // 6
     lean_bar();                                   // 7: h2 of the second pass
     if (q == 0) {
       Tp tp2 = tp;
       tp2.stage = tp.stage + 1;
-      j2.run(L.h2, L.scr + 2304, outS, 1, tp2);
+      f32x4 o;
+      const bool in = j2.run(L.h2, 1, tp2, o, tail.wants(tctx), sf);      // (the members that only contribute publish and leave)
       sf();
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      tail.finish(tctx, outS);                    // (q' is this wave's own: no barrier in front of the seeds)
+      tail.finish(tctx, in && kk == 0, i, o[0]);  // (q' is in this wave's registers: nothing in front of the seeds)
     }
-    sf();
-  } else if (quart == 1) {
-    LeanL1<PL> j1;
-    lean_bar();                                   // a
-    lean_bar();                                   // b
-    j1.load(actor_t.pf[1], ab1, c, q);
-    lean_bar();                                   // 1: h1
-    j1.run_partial(L.h1, L.scr, q);
-    sf();
-    lean_bar();                                   // 2
-    if (q < 2) {
-      const f32x4 pre = j1.finish_pre(L.scr, q);
-      bool ok = true;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ok = ok && PL::range_ok(pre[r]);
-      if (__builtin_expect(!ok, 0)) report_expired(tp.err, tp.err_code | SITE_X2_RANGE);
-      ACT::template st4<LD::L>(L.h2, i, 16 * q + 4 * kk, f32x4{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f), fmaxf(pre[2], 0.f), fmaxf(pre[3], 0.f)}, PL::kFwdA);
-    }
-    sf();
-    lean_bar();                                   // 3
-    lean_bar();                                   // 4
-    lean_bar();                                   // 5
-    lean_bar();                                   // 6
-    lean_bar();                                   // 7
   } else if (quart == 2) {
-    LeanL0<PL> j0;
+    // ---- layer 0 of both passes; wave 8: the target actor's output layer, its exchange, a' = tanh(.)
+    LeanL0<PL> a0, c0;
     LeanL2<PL, NM> j2;
     lean_bar();                                   // a
-    j0.load(critic_t.pf[0], cb0, critic_t.dims[0], q);
+    c0.load(critic_t.pf[0], cb0, critic_t.dims[0], wave);
     lean_bar();                                   // b
+    a0.load(actor_t.pf[0], ab0, actor_t.dims[0], wave);
     if (q == 0) j2.load(actor_t.pf[2], ab2, Ad, c);
+    l0(a0);
+    sf();
     lean_bar();                                   // 1
     lean_bar();                                   // 2
     lean_bar();                                   // 3: h2 of the first pass
     if (q == 0) {
       sf();
-      j2.run(L.h2, L.scr + 2048, outS, Ad, tp, true, sf);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // a' = tanh(.) -> the input tile's action columns (rows beyond the batch: zero)
+      f32x4 o;
+      if (j2.run(L.h2, Ad, tp, o, true, sf)) {
+        // a' = tanh(.) -> the input tile's action columns (rows beyond the batch: zero) — this lane's four consecutive
+        // columns S + 4 kk ..
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int e = lane + 64 * j;
-        if (e < 16 * Ad) {
-          const int col = e >> 4, row = e & 15;
-          const float a = row0 + row < B ? tanhf(outS[row * kOutLd + col]) : 0.f;
-          xb[row * kX0Ld + S + col] = a;
-          if constexpr (X2) {
-            const float v = a * PL::kFwdA;
-            const _Float16 h = (_Float16)v;
-            _Float16* hp = reinterpret_cast<_Float16*>(L.x0) + row * kLd0H + lean_pos(S + col);
-            hp[0] = h;
-            hp[16 * kLd0H] = (_Float16)(v - (float)h);
+        for (int r = 0; r < 4; ++r)
+          if (4 * kk + r < Ad) {
+            const float a = row0 + i < B ? lean_tanh(o[r]) : 0.f;
+            xb[i * kX0Ld + S + 4 * kk + r] = a;
+            if constexpr (X2) {
+              const float v = a * PL::kFwdA;
+              const _Float16 h = (_Float16)v;
+              _Float16* hp = reinterpret_cast<_Float16*>(L.x0) + i * kLd0H + lean_pos(S + 4 * kk + r);
+              hp[0] = h;
+              hp[16 * kLd0H] = (_Float16)(v - (float)h);
+            }
           }
-        }
       }
     }
     sf();
-    lean_bar();                                   // 4: [s' | a'] complete
-    const bool ok = j0.run(X2 ? L.x0 : xb, L.h1, q);
-    if (__builtin_expect(!ok, 0)) report_expired(tp.err, tp.err_code | SITE_X2_RANGE);
+    lean_bar();                                   // 4
+    l0(c0);
+    sf();
+    lean_bar();                                   // 5
+    lean_bar();                                   // 6
+    lean_bar();                                   // 7
+  } else if (quart == 1) {
+    // ---- layer 0 of both passes, the target actor's layer 1
+    LeanL0<PL> a0, c0;
+    LeanL1<PL> j1;
+    lean_bar();                                   // a
+    c0.load(critic_t.pf[0], cb0, critic_t.dims[0], wave);
+    lean_bar();                                   // b
+    a0.load(actor_t.pf[0], ab0, actor_t.dims[0], wave);
+    j1.load(actor_t.pf[1], ab1, c, q);
+    l0(a0);
+    sf();
+    lean_bar();                                   // 1
+    j1.run_partial(L.h1, L.scr, q);
+    sf();
+    lean_bar();                                   // 2
+    l1fin(j1);
+    lean_bar();                                   // 3
+    lean_bar();                                   // 4
+    l0(c0);
     sf();
     lean_bar();                                   // 5
     lean_bar();                                   // 6
     lean_bar();                                   // 7
   } else {
+    // ---- layer 0 of both passes, the target critic's layer 1; wave 15: the flag waits
+    LeanL0<PL> a0, c0;
     LeanL1<PL> j1;
     if (q == 3) lean_wave_wait(F.ct, F.n_ct, F.tag, F.wait, F.err, F.code);
     lean_bar();                                   // a
+    c0.load(critic_t.pf[0], cb0, critic_t.dims[0], wave);
     j1.load(critic_t.pf[1], cb1, c, q);
     if (q == 3) lean_wave_wait(F.at, F.n_at, F.tag, F.wait, F.err, F.code);
     lean_bar();                                   // b
+    a0.load(actor_t.pf[0], ab0, actor_t.dims[0], wave);
+    l0(a0);
+    sf();
     lean_bar();                                   // 1
     lean_bar();                                   // 2
     lean_bar();                                   // 3
     lean_bar();                                   // 4
+    l0(c0);
+    sf();
     lean_bar();                                   // 5: h1 of the second pass
     j1.run_partial(L.h1, L.scr, q);
     sf();
     lean_bar();                                   // 6
-    if (q < 2) {
-      const f32x4 pre = j1.finish_pre(L.scr, q);
-      bool ok = true;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ok = ok && PL::range_ok(pre[r]);
-      if (__builtin_expect(!ok, 0)) report_expired(tp.err, tp.err_code | SITE_X2_RANGE);
-      ACT::template st4<LD::L>(L.h2, i, 16 * q + 4 * kk, f32x4{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f), fmaxf(pre[2], 0.f), fmaxf(pre[3], 0.f)}, PL::kFwdA);
-    }
-    sf();
+    l1fin(j1);
     lean_bar();                                   // 7
   }
   tp.stage += 2;
-  lean_bar();                                     // 8: q' in outS
   sf();
 }
 

@@ -108,15 +108,3 @@ if fused:
             print(f"  {names[slot]} — slice 0, stamp times per wave (us):")
             for w, r in enumerate(rows):
                 print(f"    wave {w:2d}: " + " ".join(f"{(r[k, 1] - base) / 100:6.2f}" if r[k, 1] != 0 else "   -  " for k in range(n)))
-
-    if "--members" in sys.argv:
-        # role A, slice 0: wave 0 (slots 32 + m) and wave 8 (slots 40 + m) of members 1..7, beside the lead's
-        x = tr[0]
-        base = x[0][0, 1]
-        n = int((x[0][:, 1] != 0).sum())
-        for nm, first in (("wave 0", 32), ("wave 8", 40)):
-            print(f"  role A members, {nm} (us from the lead's entry):")
-            lead_row = x[0] if first == 32 else x[16 + 8]
-            rows = [lead_row] + [x[first + m] for m in range(1, 8)]
-            for m, r in enumerate(rows):
-                print(f"    member {m}: " + " ".join(f"{(r[k, 1] - base) / 100:6.2f}" if r[k, 1] != 0 else "   -  " for k in range(n + 1)))
