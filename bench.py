@@ -11,15 +11,16 @@ timed region.
     python bench.py --gpus 1 --steps 20000 --warmup 1000
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-The timed learner runs the parity mode `x2` (OPRL_PREC_X2: every fp32 operand as the
-sum of two fp16 numbers, three v_mfma_f32_16x16x32_f16 per product, fp32 accumulate /
-master weights / Adam — at the same gates against the reference's golden vectors as the
-exact-fp32 MFMA mode, tests/test_gpu_x2.py); `--precision f32` times the exact-fp32
-MFMA mode, `--precision bf16` the reduced-precision one.  The default run reports all
-three (blocks `exact_f32`, `bf16`).
+The timed learner runs EXACT fp32 on the matrix cores (OPRL_PREC_F32,
+v_mfma_f32_16x16x4_f32: the arithmetic of the reference and the default of every class
+and script of the package).  `--precision x2` times the other parity mode (OPRL_PREC_X2:
+every fp32 operand as the sum of two fp16 numbers, three v_mfma_f32_16x16x32_f16 per
+product, fp32 accumulate / master weights / Adam — held to the reference's golden vectors
+at the exact-fp32 mode's gates, tests/test_gpu_x2.py), `--precision bf16` the
+reduced-precision one.  The default run reports all three (blocks `x2`, `bf16`).
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline     dominant kernel (x2: k_ddpg_update, the whole update as one launch):
+  roofline     dominant kernel (k_ddpg_chain: up to 32 whole updates per launch):
                algorithmic bytes / FLOP per launch over its average duration (HIP
                events on the launch stream, measured live in a separate instrumented
                pass) against the binding peak
@@ -508,11 +509,11 @@ def main():
     ap.add_argument("--learners", type=int, default=8,
                     help="extra measurement: this many independent learners (seeds) on separate "
                          "streams of the same GPU (multi-seed packing, runners/train.py --seeds); 0 = skip")
-    ap.add_argument("--precision", choices=("f32", "bf16", "x2"), default="x2",
-                    help="arithmetic mode of the TIMED learner: x2 = fp32 operands as fp16 hi + lo, three fp16 MFMAs per "
-                         "product (a parity mode: same gates against the reference's vectors as f32) and the headline; "
-                         "f32 = exact-fp32 MFMA; bf16 = the reduced-precision mode (the default run reports both in "
-                         "its `exact_f32` / `bf16` blocks)")
+    ap.add_argument("--precision", choices=("f32", "bf16", "x2"), default="f32",
+                    help="arithmetic mode of the TIMED learner: f32 = exact-fp32 MFMA, the reference's arithmetic, the "
+                         "package's default and the headline; x2 = fp32 operands as fp16 hi + lo, three fp16 MFMAs per "
+                         "product (a parity mode: same gates against the reference's vectors as f32); bf16 = the "
+                         "reduced-precision mode (the default run reports both in its `x2` / `bf16` blocks)")
     ap.add_argument("--group", type=int, default=32,
                     help="extra measurement: a LearnerGroup of this many learners stepped by one launch sequence")
     ap.add_argument("--pre-warm", type=int, default=20000,
@@ -741,8 +742,8 @@ def measure(args, wd):
                                    us_per_launch_raw=ms[i] * 1e3 / cnt[i],
                                    us_per_step=max(ms[i] * 1e3 / cnt[i] - ev_us, 0.0) * cnt[i] / P)
                     for i in range(NK) if cnt[i]}
-            # which launch structure ran (csrc/learner.hip): the whole update as ONE launch (x2: k_ddpg_update — it
-            # is counted in phase 1's slot), the merged launches (phase 1 + the critic's tiles | phase 2 [+ the actor's
+            # which launch structure ran (csrc/learner.hip): whole updates per launch (k_ddpg_chain — counted in phase 1's
+            # slot; a launch that holds ONE update is labelled k_ddpg_update below), the merged launches (phase 1 + the critic's tiles | phase 2 [+ the actor's
             # tiles]), or the plain sequence
             whole = "k_ddpg_phase1" in kern and "k_ddpg_phase2" not in kern and "k_dw_adam" not in kern
             # ... or SEVERAL updates per launch (k_ddpg_chain: step_n's K-loop inside the launch, up to 32 updates each)
@@ -839,7 +840,7 @@ def measure(args, wd):
             wd.kick("multi-learner + packed group")
             multi = multi_learner(args.learners, dev, local_rank, steps=max(200, min(K, 2000)))
             group = packed_group(args.group, dev, local_rank, steps=max(200, min(K, 1000)))
-        configs = bf16 = api = exact = dp1 = None
+        configs = bf16 = api = exact = dp1 = x2blk = None
         if not use_dp and not args.no_configs:
             cache = {(S, A): replay}
 
@@ -857,11 +858,18 @@ def measure(args, wd):
                         roofline_frac=d16["roofline_frac"], roof=d16["roof"], peak_tflops=PEAK_BF16_MATRIX_TFLOPS,
                         q_rel_dev_vs_f32_after_10_updates=round(bf16_q_deviation(dev, replay), 6),
                         note="OPRL_PREC_BF16: v_mfma_f32_16x16x32_bf16, fp32 accumulate / master / Adam; the "
-                             "headline `value` above is a parity mode")
+                             "headline `value` above is exact fp32")
             api = api_rate(dev, replay, args.precision)
             d32 = next(r for r in configs if r["name"].startswith("DDPG") and r["dtype"] == "f32")
             exact = dict(value=d32["steps_per_s"], unit="steps/s", us_per_step=d32["us_per_step"],
-                         note="OPRL_PREC_F32: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), the other parity mode")
+                         note="OPRL_PREC_F32: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), the headline's mode, from the config table's "
+                              f"{d32['steps']}-update run")
+            dx2 = next(r for r in configs if r["name"].startswith("DDPG") and r["dtype"] == "x2")
+            x2blk = dict(value=dx2["steps_per_s"], unit="steps/s", us_per_step=dx2["us_per_step"],
+                         roofline_frac=dx2["roofline_frac"], roof=dx2["roof"],
+                         note="OPRL_PREC_X2: fp32 operands as fp16 hi + lo, three fp16 MFMAs per product, fp32 accumulate / master / "
+                              "Adam; a parity mode (outputs 2e-5, parameter digests 1e-4 against the reference's golden vectors; "
+                              "Adam-moment digests 5e-3: one ReLU flip of one row), finite range |x| < 4094 (never silent)")
             wd.kick("single-rank data-parallel rate")
             try:
                 dp1 = dp_single_rank(dev, local_rank, replay, args.precision, max(200, min(K, 3000)))
@@ -889,7 +897,7 @@ def measure(args, wd):
                                    1: "one-shot peer-window all-reduce over xGMI, one kernel per exchange (csrc/p2p.hip)",
                                    0: "RCCL ncclAllReduce"}[p2p_level]),
                        "parallelism": f"dp{world}", "global_batch": B * world},
-            "roofline": roof, "cpu_baseline": cpu, "configs": configs, "exact_f32": exact, "bf16": bf16, "api_rate": api,
+            "roofline": roof, "cpu_baseline": cpu, "configs": configs, "exact_f32": exact, "x2": x2blk, "bf16": bf16, "api_rate": api,
             "dp_single_rank": dp1,
             "multi_learner": multi, "packed_group": group, "data_parallel_check": dp_check,
             "flop_per_step": 2.0 * B * (MACS_SLICE + MACS_DW), "state_bytes_per_step": STATE_BYTES,

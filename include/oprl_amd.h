@@ -239,10 +239,21 @@ int oprl_learner_set_counters(oprl_learner* h, const int64_t in_host[OPRL_N_COUN
  * return OPRL_ERR_STATE with the kernel and wait site in oprl_last_error() until it is cleared.
  * oprl_learner_check polls it explicitly (synchronise the stream first for a definitive answer);
  * oprl_learner_debug_expire (tests) makes one wait site (2 = TD-target hand-off, 1 = cluster all-reduce, 7 = gate of the dW tiles riding on phase 1's launch;
- * 0 = off) give up immediately in subsequent launches. */
+ * 0 = off) give up immediately in subsequent launches.  Sites 101, 102, 104, 105, 106 are TIMING experiments
+ * (tools/what_if.py): one cross-workgroup wait of k_ddpg_chain counts as satisfied — role B's q for role A's tail,
+ * the critic's tiles for the critic pass, role A's seeds / the pass's du / role B's rows for the tiles — so that
+ * the change of the update's period shows what that hand-over contributes; such a learner computes wrong numbers. */
 int oprl_learner_check(oprl_learner* h);
 int oprl_learner_clear_error(oprl_learner* h);
 int oprl_learner_debug_expire(oprl_learner* h, int32_t site);
+/* Which launch form an update of batch size B would take right now (tests/test_gpu_forms.py holds the selection —
+ * csrc/learner.hip ddpg_args / critic_phase — against a table).  out[12]: [0] 1 fused phase kernels / 0 the generic launch
+ * sequence, [1] lean (tp4.h) passes, [2] form 4 whole updates per launch (k_ddpg_chain) / 3 both merged launches / 2 merged
+ * phase 1 / 1 plain phase + dW launches / 0, [3] updates per chain launch, [4] wide bits (1 role A, 2 the critic pass on
+ * clusters of eight), [5] cluster size of the other roles, [6] twin_split, [7] p2_pair, [8] arithmetic 0 exact fp32 /
+ * 1 bf16 / 2 x2, [9] XCD-local cluster exchanges, [10] demoted to the shared-chip forms, [11] 0.  Reference: none (the
+ * reference has one path, autograd). */
+int oprl_learner_debug_form(oprl_learner* h, int32_t B, int32_t* out);
 /* Key of the learner's device-side noise streams (TD3 target smoothing, the SAC / TQC
  * reparameterisation draws, drawn with Philox when update() gets no injected noise): `seed` is the
  * run seed (the reference seeds torch's generator in runners/train.py:14-21), `rank` the
@@ -335,7 +346,9 @@ int oprl_learner_dp_step_n(oprl_learner* h, oprl_replay* replay, int32_t K, int3
  * hipEvents recorded on the launch stream.  oprl_profile_read synchronises the
  * device and returns, per kernel kind, the launch count and the summed
  * hipEventElapsedTime (ms).  Kinds: 0 k_mlp_slice, 1 k_dw_adam, 2 k_replay_gather,
- * 3 everything else, 4 k_ddpg_phase1, 5 k_ddpg_phase2.  bench.py's roofline uses this. */
+ * 3 everything else, 4 k_ddpg_phase1 — and every launch that starts with phase 1's roles: the merged
+ * k_ddpg_phase1_dw and k_ddpg_chain (whole updates, up to 32 per launch: one count per LAUNCH) —,
+ * 5 k_ddpg_phase2 (and k_ddpg_phase2_dw).  bench.py's roofline uses this. */
 #define OPRL_PROFILE_KINDS 6
 int oprl_profile_enable(int32_t on);
 int oprl_profile_read(int64_t* counts_host, double* ms_host, int32_t reset);

@@ -91,6 +91,7 @@ SIGNATURES = {
     "oprl_learner_check": (C.c_int, [_P]),
     "oprl_learner_clear_error": (C.c_int, [_P]),
     "oprl_learner_debug_expire": (C.c_int, [_P, _I32]),
+    "oprl_learner_debug_form": (C.c_int, [_P, _I32, _P]),
     "oprl_debug_noise": (C.c_int, [_P, _I32, _U64, _I32, _I32, _P, _P]),
     "oprl_learner_set_seed": (C.c_int, [_P, _U64, _I32]),
     "oprl_learner_debug_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),

@@ -38,6 +38,7 @@
 // (update()) or is gathered in-kernel from the HBM replay with the same Philox
 // draw and index map as k_replay_gather (step_n).
 #include <cstddef>
+#include <mutex>
 #include <type_traits>
 #include "kernels.h"
 #include "philox.h"
@@ -57,12 +58,21 @@ namespace oprl {
 // one MLP pass of a cluster: the lean tp4 routines or the generic tp3 ones
 // Do the members of this workgroup's slice cluster (same blockIdx.x, different blockIdx.y) share an XCD?  Workgroups go to
 // XCD (linear id) % 8 and the grid is (slices, rows): with slices a multiple of eight a slice's workgroups all land on XCD
-// blockIdx.x % 8 — checked against the hardware's XCC_ID, so that a part that maps differently simply publishes at agent
-// scope (tp3.h Tp::local: workgroup-scope granule stores reach the XCD's L2, where the peers' agent-scope polls find them;
-// A / B on one box: 25.94 against 26.10 us per update, r04-26).
-__device__ __forceinline__ bool cluster_on_one_xcd() {
+// blockIdx.x % 8.  Then the cluster's granules may be published at workgroup scope (tp3.h Tp::local: the stores stop in the
+// XCD's L2, where the peers' agent-scope polls find them; A / B on one box: 25.94 against 26.10 us per update, r04-26).
+// The decision must be the SAME for every member — one that published locally while a peer sits on another XCD would
+// never be seen by it — so it is made in three layers: (1) the host asks for it (DdpgArgs::xcd_local) only after a PROBE
+// launch of the same grid shape found every workgroup of a column on XCD column % 8 (xcd_map_ok below: the dispatcher
+// deals round robin over eight XCDs — not on a partitioned / masked device), not under OPRL_AMD_NO_XCD_LOCAL=1 and not
+// after an expired cluster wait of this learner; (2) the test depends on blockIdx.x and the hardware's XCC_ID only: members
+// that do share an XCD all answer alike; (3) a workgroup on an unexpected XCD publishes at agent scope.
+__device__ __forceinline__ bool cluster_on_one_xcd(const DdpgArgs& A) {
   const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;          // HW_REG_XCC_ID, bits 3:0
-  return ((int)gridDim.x & 7) == 0 && xcc == ((int)blockIdx.x & 7);
+  return A.xcd_local != 0 && ((int)gridDim.x & 7) == 0 && xcc == ((int)blockIdx.x & 7);
+}
+// the probe: every workgroup of a (16, 16) grid reports its XCD
+__global__ void k_xcc_probe(int* out) {
+  if (threadIdx.x == 0) out[blockIdx.y * gridDim.x + blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;
 }
 
 template <int WIDTH, bool LEAN, class P, int NM = 4, class ST>
@@ -340,7 +350,7 @@ __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D =
   Tp tp{member, role == 0 ? nA : A.nc,
         A.xbuf + ((size_t)role * gridDim.x + slice) * kTpStages * A.xnc * kTpBlk, A.cluster_tag, 0,
         A.err, KERN_PHASE1 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
-  tp.local = bx_in < 0 && cluster_on_one_xcd();      // (the launch's own (slice, row) grid: r04-26)
+  tp.local = bx_in < 0 && cluster_on_one_xcd(A);      // (the launch's own (slice, row) grid: r04-26)
   const bool lead = tp.c == 0;                 // member 0 does the un-sliced global stores
   int n_stamp = 0;
   auto stamp = [&]() {
@@ -646,7 +656,7 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A, int bx_in = 
   Tp tp{by - g * ncl, ncl,
         A.xbuf + ((size_t)g * gridDim.x + slice) * kTpStages * A.xnc * kTpBlk, A.cluster_tag, 0,
         A.err, KERN_PHASE2 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
-  tp.local = bx_in < 0 && cluster_on_one_xcd();
+  tp.local = bx_in < 0 && cluster_on_one_xcd(A);
   const bool lead = tp.c == 0;
   int n_stamp = 0;
   auto stamp = [&]() {
@@ -1023,7 +1033,7 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   static_assert(kMaxEnds >= kDuLd * 256, "W3 fits the ends table's area");
   Tp tp{y, NMC, A.xbuf + (size_t)slice * kTpStages * A.xnc * kTpBlk, cx.tag, 0,
         A.err, KERN_PHASE2 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
-  tp.local = GE && cluster_on_one_xcd();
+  tp.local = GE && cluster_on_one_xcd(A);
   const bool lead = tp.c == 0;
   const int c = tp.c;
   const int lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
@@ -1423,7 +1433,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   if (role == 0) {
     // ---- role A: a' = tanh(actor_target(s')), q' = critic_target(s', a'), TD target, seeds       (ddpg.py:94-95)
     Tp tp{member, 8, A.xbuf + (size_t)slice * kTpStages * A.xnc * kTpBlk, tag1, 0, A.err, KERN_PHASE1 << 8, spin};
-    tp.local = cluster_on_one_xcd();
+    tp.local = cluster_on_one_xcd(A);
     tp4_forward<Coh<P>, 8>(A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp, bias_of(1));
     for (int idx = tid; idx < kR * Ad; idx += kThreads) {
       const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
@@ -1502,7 +1512,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   if (role == 1) {
     // ---- role B: q = critic(s, a) forward and its whole backward with unit seed (tp4_scalar_fb)      (ddpg.py:96-100)
     Tp tp{member, 4, A.xbuf + ((size_t)1 * slices + slice) * kTpStages * A.xnc * kTpBlk, tag1, 0, A.err, KERN_PHASE1 << 8, spin};
-    tp.local = cluster_on_one_xcd();
+    tp.local = cluster_on_one_xcd(A);
     const Tp3Store st{A.cX[1], A.cX[2], A.cdY[1], A.cdY[0], A.cdY0_stride, B, true};
     if (lead) {        // (the input rows for the critic's first-layer tiles: out before the pass)
       __syncthreads();
@@ -1522,7 +1532,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   } else if (role == 2) {
     // ---- role C: actor(s) forward, pi = tanh(.) and the activations for the actor's tiles / the critic pass
     Tp tp{member, 4, A.xbuf + ((size_t)2 * slices + slice) * kTpStages * A.xnc * kTpBlk, tag1, 0, A.err, KERN_PHASE1 << 8, spin};
-    tp.local = cluster_on_one_xcd();
+    tp.local = cluster_on_one_xcd(A);
     // (everything role C leaves is read by workgroups of this launch — the critic pass, the actor's tiles — behind its
     // flags: written through)
     const Tp3Store st{A.aX[1], A.aX[2], nullptr, nullptr, 0, 0, true};
@@ -1617,6 +1627,32 @@ bool fused_x2_tiles() { return kDwTileX2; }
 
 size_t fused_ddpg_lds_bytes() { return sizeof(float) * FusedLds<256>::total; }
 size_t fused_xbuf_granules_per_cluster(int nc) { return (size_t)kTpStages * nc * kTpBlk; }
+
+// Does this device deal the workgroups of a (slices, rows) grid out round robin over eight XCDs — block (x, y) on XCD
+// (x + slices y) % 8, hence a whole column on XCD x % 8 for slices = 16?  Probed once per device (three launches).
+bool xcd_map_ok() {
+  static std::mutex mu;
+  static int known[16] = {0};            // 0: not probed, 1: yes, -1: no
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lk(mu);
+  int& k = known[dev & 15];
+  if (k != 0) return k > 0;
+  k = -1;
+  int* d = nullptr;
+  if (hipMalloc(&d, 256 * sizeof(int)) != hipSuccess) return false;
+  bool ok = true;
+  int h[256];
+  for (int rep = 0; rep < 3 && ok; ++rep) {
+    ok = hipMemset(d, 0xff, 256 * sizeof(int)) == hipSuccess;
+    if (ok) hipLaunchKernelGGL(k_xcc_probe, dim3(16, 16), dim3(64), 0, 0, d);
+    ok = ok && hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+    for (int b = 0; b < 256 && ok; ++b) ok = h[b] == (b & 7);
+  }
+  (void)hipFree(d);
+  if (ok) k = 1;
+  return ok;
+}
 
 hipError_t init_fused_attrs() {
   const void* ks[] = {reinterpret_cast<const void*>(&k_ddpg_phase1<256, false, false>),

@@ -398,6 +398,9 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   float* w3_snap;                      // the actor's output layer [A][256] as it is before phase 2, copied by phase 1's role C (slice 0)
   const float* w3_src;                 // ... from here (the row-major master)
   int no_lean;                         // 1: never use the tp4.h specialisation (OPRL_AMD_NO_LEAN, tests)
+  int xcd_local;                       // 1: a slice cluster whose members all see their expected XCD may publish its granules at workgroup scope
+                                       // (the HOST's decision — the dispatcher was probed, OPRL_AMD_NO_XCD_LOCAL, no expired cluster wait so far —
+                                       // and the same for every member: fused_ddpg.hip cluster_on_one_xcd)
   unsigned long long* xbuf;            // cluster exchange areas: [role][slice][kTpStages][nc][kTpBlk] granules
   unsigned cluster_tag;                // launch-unique
   long cdY0_stride, adY0_stride;       // floats between the members' dz1 partial buffers

@@ -621,6 +621,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   a.trace = nullptr;
   a.nc = h->nc_cluster(B);
   a.no_lean = h->no_lean;
+  a.xcd_local = h->xcd_local ? 1 : 0;
   // role A and the role-C cluster wait for each other: only with all four roles of a slice resident
   a.twin_split = (h->nc == 2 && a.nc == 4 && !h->no_lean && !h->no_twin_split &&
                   (2 + h->nc) * 4 * ((B + kR - 1) / kR) <= h->n_cus) ? 1 : 0;
@@ -1414,6 +1415,9 @@ extern "C" int oprl_learner_clear_error(oprl_learner* h) {
       h->no_whole = 1;
       h->no_wide = 1;
     }
+    // (an expired wait of any kind: the cluster exchanges go back to agent-scope publishes as well — if a member sat on an
+    // XCD the others did not expect, the demoted forms must not repeat it)
+    if (code != 0 && w != 9 && !h->debug_expire) h->xcd_local = false;
     *(volatile unsigned*)h->err_host = 0;
   }
   return OPRL_OK;

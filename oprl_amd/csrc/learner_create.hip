@@ -296,6 +296,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     if (const char* cm = getenv("OPRL_AMD_CHAIN")) { const int v = atoi(cm); if (v >= 1 && v <= kChainMax) h->chain_max = v; }
     const char* nw = getenv("OPRL_AMD_NO_WIDE");
     h->no_wide = (nw != nullptr && atoi(nw) != 0) ? 1 : 0;
+    const char* nxl = getenv("OPRL_AMD_NO_XCD_LOCAL");
+    h->xcd_local = h->fused && !(nxl != nullptr && atoi(nxl) != 0) && xcd_map_ok();
     // the generic per-net launches on clusters of 4 (slice_tp.hip): any net of the common shape
     // (decided per net by tp_generic(): TQC's 512-wide critics stay on k_mlp_slice, its actor moves)
     h->tp_generic_on = !h->no_lean && h->ncl == 4;

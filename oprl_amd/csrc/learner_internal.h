@@ -75,6 +75,7 @@ int replay_view(const oprl_replay* h, const float** states, const float** action
 hipError_t launch_debug_normal(unsigned long long seed, unsigned long long ctr, int rows, int cols, float* out,
                                hipStream_t st);
 hipError_t init_fused_attrs();
+bool xcd_map_ok();
 size_t fused_xbuf_granules_per_cluster(int nc);
 hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st);
 hipError_t launch_ddpg_phase1_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st);
@@ -344,6 +345,7 @@ struct oprl_learner {
   unsigned long long* g1_granules = nullptr;
   float* w3_snap = nullptr;
   int no_wide = 0;             // OPRL_AMD_NO_WIDE: never run role A / phase 2's critic pass on clusters of eight
+  bool xcd_local = false;      // XCD-local cluster exchanges (DdpgArgs::xcd_local): probed dispatcher, not OPRL_AMD_NO_XCD_LOCAL, cleared by an expired wait
   int xnc = kMaxCluster;       // members an exchange area of xbuf is laid out for
   unsigned long long* xbuf = nullptr;
   size_t xbuf_granules = 0;
@@ -429,6 +431,7 @@ hipError_t uc_alloc(void** out, size_t bytes);
 size_t net_ws_floats(const oprl_net& n, int B);
 int fresh32(const oprl_net* net, hipStream_t st);
 DdpgArgs ddpg_args(oprl_learner* h, int B);
+int chain_rows(const oprl_learner* h, int B);
 void build_repack_items(const oprl_net* const* nets, int n_nets, int which,
                         std::vector<RepackItem>& items, int* blocks_out,
                         float* const* pk16 = nullptr, float* const* pk16_t = nullptr, int pl = 1);

@@ -129,6 +129,41 @@ extern "C" int oprl_learner_debug_view(oprl_learner* h, int32_t which, const voi
   return OPRL_OK;
 }
 
+// Which LAUNCH FORM would an update of batch size B take right now?  The selection (learner.hip ddpg_args / critic_phase:
+// a dozen interacting conditions — precision, algorithm, batch size, cluster size, gradient export, the data-parallel
+// exchange, a shared chip, the environment switches) as numbers a test can hold against a table
+// (tests/test_gpu_forms.py), so that a mode falling off its fast form is a red test and not a line in a benchmark.
+//   out[0]  fused: 1 the fused phase kernels (DDPG / TD3 / SAC), 0 the generic launch sequence (TQC, no_fuse, odd shapes)
+//   out[1]  lean: 1 tp4.h's passes, 0 the generic tp3.h passes
+//   out[2]  form: 4 whole updates per launch (k_ddpg_chain), 3 both merged launches (phase 1 + critic tiles | phase 2 +
+//           actor tiles), 2 merged phase 1 only, 1 the plain phase launches + dW launches, 0 not fused
+//   out[3]  updates per chain launch step_n may run (1 unless form 4)
+//   out[4]  wide bits (1: role A on clusters of eight, 2: the critic pass)      out[5]  cluster size of the other roles
+//   out[6]  twin_split    out[7]  p2_pair    out[8]  arithmetic of the kernels: 0 exact fp32, 1 bf16, 2 x2
+//   out[9]  XCD-local cluster exchanges    out[10] the learner was demoted to the shared-chip forms    out[11] reserved (0)
+extern "C" int oprl_learner_debug_form(oprl_learner* h, int32_t B, int32_t* out) {
+  if (!h || !out || B < 1 || B > h->Bmax) { set_err("oprl_learner_debug_form: invalid argument"); return OPRL_ERR_INVALID; }
+  for (int i = 0; i < 12; ++i) out[i] = 0;
+  out[10] = h->shared_chip ? 1 : 0;
+  out[8] = h->x2 ? 2 : (h->bf16 ? 1 : 0);
+  if (!use_fused(h, B)) return OPRL_OK;
+  const DdpgArgs a = ddpg_args(h, B);
+  out[0] = 1;
+  out[1] = fused_ddpg_is_lean(a) ? 1 : 0;
+  const bool whole = a.whole && B <= 256;
+  out[2] = whole ? 4 : ((a.merged & 3) == 3 ? 3 : ((a.merged & 1) ? 2 : 1));
+  out[3] = 1;
+  if (whole) {
+    const int slices = (B + kR - 1) / kR;
+    const bool fits = chain_rows(h, B) * slices <= h->n_cus;
+    out[3] = (h->no_chain || h->chain_flags == nullptr || !fits) ? 1 : h->chain_max;
+  }
+  out[4] = a.wide; out[5] = a.nc; out[6] = a.twin_split; out[7] = a.p2_pair;
+  out[8] = a.x2 ? 2 : (a.bf16 ? 1 : 0);
+  out[9] = a.xcd_local;
+  return OPRL_OK;
+}
+
 // ---------------------------------------------------------------- building blocks
 namespace {
 struct TmpBuf {  // small per-thread device scratch for the stand-alone MLP calls
