@@ -18,6 +18,7 @@ with a plain reference module.  What differs is underneath:
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Final, Sequence
 
 import numpy as np
@@ -29,6 +30,7 @@ from torch.nn.functional import logsigmoid
 from oprl_amd import _capi
 
 LOG_STD_MIN_MAX: Final[tuple[float, float]] = (-20, 2)
+_INIT_LOCK = threading.Lock()
 
 
 def initialize_weight_orthogonal(m: nn.Module, gain: float = nn.init.calculate_gain("relu")) -> None:
@@ -37,12 +39,15 @@ def initialize_weight_orthogonal(m: nn.Module, gain: float = nn.init.calculate_g
     if isinstance(m, nn.Linear):
         # (the QR behind orthogonal_ on ONE host thread: on a 256-core GPU host torch's intra-op pool turned each of these
         # 256 x 256 factorisations into tens of milliseconds of thread wake-ups — 100-200 ms per DDPG / TD3 create())
-        n = t.get_num_threads()
-        t.set_num_threads(1)
-        try:
-            nn.init.orthogonal_(m.weight.data, gain)
-        finally:
-            t.set_num_threads(n)
+        # (torch's thread count is process-global: two host threads creating learners at once — the multi-seed layout —
+        # must not interleave their save / restore, or the process stays on one thread for good: ADVICE r4)
+        with _INIT_LOCK:
+            n = t.get_num_threads()
+            t.set_num_threads(1)
+            try:
+                nn.init.orthogonal_(m.weight.data, gain)
+            finally:
+                t.set_num_threads(n)
         m.bias.data.zero_()
 
 

@@ -74,6 +74,12 @@ namespace oprl_host {
 // compute units with waiting workgroups (bounded waits would expire).  Nothing is recorded until a second stream shows
 // up (a process whose learners share one stream — the headline path, bench.py's blocks — pays no event, no barrier
 // packet); the first launch from a second stream drains the device on the host, once.
+// Limits (deliberate): only the WHOLE-UPDATE launches take turns — another learner's merged / phase launches, or
+// any other kernel of the process on a second stream, can still hold compute units while a chain launch waits for its
+// own workgroups: the bounded wait then expires, the call reports it, and after clear_error the learner runs the
+// shared-chip forms (tested: tests/test_gpu_errors.py); a learner that is KNOWN to share the GPU says so up front
+// (set_cluster(4), OPRL_AMD_FORM=plain).  Streams are told apart by handle and devices by id & 15; the one
+// hipDeviceSynchronize (the first launch from a second stream) runs under the mutex, once per process and device.
 struct ChipTurn {
   std::mutex mu;
   hipEvent_t ev[16] = {};
@@ -849,6 +855,11 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
       if (h->trace != nullptr && c.algo == OPRL_DDPG) fa.trace2 = h->trace + (size_t)3 * 64 * kTraceStamps * 2;   // slot 3
       fa.prefetch_next = 0;
       const int slices = (B + kR - 1) / kR;
+      // (what this block advances — the optimisers' step counts, the exchange sequence numbers, the tags — is put back by
+      // every error return below: after a failed call Adam's bias corrections and, data parallel, this rank's tile sequence
+      // must not be ahead of the parameters / of the peers: ADVICE r4)
+      const struct { int c, a; unsigned long long seq; unsigned tag, epoch; } snap{h->opt_step_critic, h->opt_step_actor, h->p2p.tile_seq, h->tp_tag, h->epoch};
+      auto undo = [&]() { h->opt_step_critic = snap.c; h->opt_step_actor = snap.a; h->p2p.tile_seq = snap.seq; h->tp_tag = snap.tag; h->epoch = snap.epoch; };
       DwKArgs kd;
       DwKArgs4 kc, ka;
       auto compact = [&](const DwKArgs& k, DwKArgs4* o) {
@@ -859,7 +870,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
       };
       {
         DwArgs dw = dw_build(h, true, B, true, false);
-        if (fill_dw_kargs(dw, &kd, 64) < 0 || dw.n_items > kDwFusedItems) { set_err("whole update: bad critic dW table"); return OPRL_ERR_INVALID; }
+        if (fill_dw_kargs(dw, &kd, 64) < 0 || dw.n_items > kDwFusedItems) { undo(); set_err("whole update: bad critic dW table"); return OPRL_ERR_INVALID; }
         kd.gate.rows = fa.gate_flags; kd.gate.n_rows = 4 * slices;
         kd.gate.seed = fa.y_granules; kd.gate.n_seed = B;
         kd.gate.late_dY = h->ws_critic[0].dY[c.critics[0].n_layers - 1];
@@ -867,12 +878,12 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
         kd.gate.err = h->err_dev; kd.gate.err_code = (1u << 8) | 7u;
         kd.gate.done = fa.ct_done; kd.gate.what_if = h->debug_expire;
         fa.n_ct = kd.tile_end[kDwMaxItems - 1];
-        if (fa.n_ct > 192 - 64) { set_err("whole update: too many critic tiles"); return OPRL_ERR_INVALID; }
+        if (fa.n_ct > 192 - 64) { undo(); set_err("whole update: too many critic tiles"); return OPRL_ERR_INVALID; }
         compact(kd, &kc);
       }
       {
         DwArgs dw = dw_build(h, false, B, true, false);
-        if (fill_dw_kargs(dw, &kd, 64) < 0 || dw.n_items != 3) { set_err("whole update: bad actor dW table"); return OPRL_ERR_INVALID; }
+        if (fill_dw_kargs(dw, &kd, 64) < 0 || dw.n_items != 3) { undo(); set_err("whole update: bad actor dW table"); return OPRL_ERR_INVALID; }
         kd.gate.seed = fa.du_granules; kd.gate.n_seed = B;
         kd.gate.tag = h->epoch; kd.gate.spin = h->debug_expire == 7 ? 0 : (1 << 20);
         kd.gate.err = h->err_dev; kd.gate.err_code = (2u << 8) | 7u;
@@ -895,7 +906,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
         // data parallel on peer windows: the tiles of this launch all-reduce their gradients themselves and run Adam on
         // the mean (dw_tile_x2.h): exchange sequence numbers seq0 + 2 u (critic) / + 1 (actor) for update u of the launch
         P2pState& P = h->p2p;
-        if (max_tiles > h->p2p_max_tiles) { set_err("data-parallel whole update: the windows hold %d tiles, the launch has %d", h->p2p_max_tiles, max_tiles); return OPRL_ERR_STATE; }
+        if (max_tiles > h->p2p_max_tiles) { undo(); set_err("data-parallel whole update: the windows hold %d tiles, the launch has %d", h->p2p_max_tiles, max_tiles); return OPRL_ERR_STATE; }
         DwXchg X;
         memset((void*)&X, 0, sizeof X);
         for (int r = 0; r < kDwXchgMaxWorld; ++r) X.peer[r] = r < P.world ? P.peer[r] + P.tile_off : nullptr;
@@ -933,7 +944,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
         }
         ca.set0[0] = fa.src.s; ca.set0[1] = fa.src.a; ca.set0[2] = fa.src.r; ca.set0[3] = fa.src.d; ca.set0[4] = fa.src.s2;
         for (int i = 0; i < 5; ++i) ca.set1[i] = h->chain_set1[i];
-        if ((U > 1 || ca.pf_last) && ca.set1[0] == nullptr) { set_err("chain launch: no second staging set"); return OPRL_ERR_STATE; }
+        if ((U > 1 || ca.pf_last) && ca.set1[0] == nullptr) { undo(); set_err("chain launch: no second staging set"); return OPRL_ERR_STATE; }
         ca.ct_fin = h->chain_flags; ca.at_fin = h->chain_flags + 192; ca.pf_done = h->chain_flags + 384;
         for (int w = 0; w < 4; ++w)
           for (int l = 0; l < kMaxLayers; ++l) ca.b16[w][l] = h->chain_b16 + ((size_t)w * kMaxLayers + l) * 256;
@@ -942,7 +953,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
         ca.qp = h->chain_flags + 576;
         fa.gu = h->gu; fa.gu_flags = h->chain_flags + 448;
         ka.gate.kind[0] = 3; ka.gate.gu = h->gu; ka.gate.gu_flags = fa.gu_flags; ka.gate.n_gu_flags = 8 * slices;
-        if (kc.tile_end[kDwFusedItems - 1] > 192 || ka.tile_end[kDwFusedItems - 1] > 192 || slices > 64) { set_err("chain launch: too many tiles"); return OPRL_ERR_INVALID; }
+        if (kc.tile_end[kDwFusedItems - 1] > 192 || ka.tile_end[kDwFusedItems - 1] > 192 || slices > 64) { undo(); set_err("chain launch: too many tiles"); return OPRL_ERR_INVALID; }
         // exchange tags: two per update (the roles', the critic pass's), consecutive: cluster_tag = the first
         {
           unsigned& ctr = h->tp_tag;
@@ -966,10 +977,12 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
           if (e == hipSuccess) chip_turn_end(st, dev);
         }
         prof_end(st);
+        if (e != hipSuccess) undo();
         HIPC(e);
         h->whole_done = true;
         return OPRL_OK;
       }
+      undo();
       set_err("whole update: one update's workgroups do not fit this device (%d compute units)", h->n_cus);
       return OPRL_ERR_STATE;
     }

@@ -66,6 +66,31 @@ def test_fused_equals_generic(B, cluster, monkeypatch):
         assert abs(sf[k] - sg[k]) <= 1e-5 * max(abs(sg[k]), 1e-12), k
 
 
+@pytest.mark.parametrize("algo", ["ddpg", "sac"])
+@pytest.mark.parametrize("B", [256, 100])
+def test_generic_cluster_launches_equal_single_cu_launches(B, algo, monkeypatch):
+    """The GENERIC launch sequence (no_fuse: one launch per net pass) on tensor-parallel clusters of four (csrc/slice_tp.hip,
+    tp3.h / tp4.h through k_slice_tp) against the same sequence on one compute unit per slice (k_mlp_slice): the cluster
+    path — exchanges, partial dz1 buffers, XCD-local publishes — has a witness of its own outside the fused kernels."""
+    def make(cluster):
+        monkeypatch.setenv("OPRL_AMD_CLUSTER", str(cluster))
+        if algo == "ddpg":
+            return _ddpg(max_batch=B, no_fuse=True)
+        return _sac(max_batch=B, no_fuse=True, tune_alpha=True)
+    tp, one = make(4), make(1)
+    for step in range(4):
+        batch = [x.cuda() for x in fx.make_batch(170 + step, B, 24, 6)]
+        tp.update(*batch)
+        one.update(*batch)
+    t.cuda.synchronize()
+    tp.learner.check()
+    one.learner.check()
+    nets = ("actor", "critic", "actor_target", "critic_target") if algo == "ddpg" else ("actor", "critic", "critic_target")
+    for m in nets:
+        a, b = getattr(tp, m)._oprl_arena, getattr(one, m)._oprl_arena
+        assert t.isfinite(a).all() and _close(a, b, 1e-4), m
+
+
 @pytest.mark.parametrize("B", [512, 1024, 4096])
 def test_fused_large_batches(B):
     """Clusters of 4 (the lean passes) are kept while ONE role's clusters fit the chip,
