@@ -446,13 +446,21 @@ def dp_single_rank(dev, local_rank, replay, precision, steps):
 METRIC = "learner gradient steps/sec, DDPG batch=256 walker-walk"
 
 
+FALLBACK = {}      # what a later failure may still report: the RCCL probe of a multi-GPU run (measure() fills it)
+
+
 def failure_line(args, world, why):
-    """The one JSON line of a run that could not measure: same keys, value null, the reason."""
-    return json.dumps({"metric": METRIC, "value": None, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
-                       "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+    """The one JSON line of a run that could not finish: same keys, value null, the reason — or, when the RCCL probe of a
+    data-parallel run had already produced its number and a LATER phase (a peer-window probe, the rebuild) failed, that
+    probe's rate as `value` (its own step count; `fallback` says so)."""
+    fb = dict(FALLBACK)
+    return json.dumps({"metric": METRIC, "value": fb.get("value"), "unit": "steps/s", "n_gpus": world,
+                       "steps": fb.get("steps", args.steps), "warmup": fb.get("warmup", args.warmup),
+                       "ms_per_step": fb.get("ms_per_step"), "higher_is_better": True, "scaling": "weak",
                        "vs_baseline": None, "dtype": DTYPE_OF[args.precision], "data": "synthetic",
                        "config": {"workload": f"DDPG walker-walk dims S={S} A={A} B={B}", "parallelism": f"dp{world}"},
-                       "roofline": None, "cpu_baseline": None, "data_parallel_check": None, "error": why})
+                       "roofline": None, "cpu_baseline": None, "data_parallel_check": fb.get("data_parallel_check"),
+                       "fallback": fb.get("note"), "error": why})
 
 
 class Watchdog:
@@ -523,10 +531,12 @@ def main():
                     help="skip the extra blocks: the other BASELINE.json configs (TD3 / SAC / TQC, fp32 and bf16), the "
                          "bf16 DDPG line and the through-the-API rate")
     ap.add_argument("--config-steps", type=int, default=2000)
-    ap.add_argument("--p2p", action="store_true",
-                    help="data-parallel path: ALSO probe the peer-window exchanges (csrc/p2p.hip) and use the fastest "
-                         "healthy one.  Default: RCCL only — the windows have never run on a multi-GPU node")
-    ap.add_argument("--no-p2p", action="store_true", help="(accepted for compatibility: RCCL only is the default)")
+    ap.add_argument("--p2p", action="store_true", help="(accepted for compatibility: probing the peer windows is the default)")
+    ap.add_argument("--no-p2p", action="store_true",
+                    help="data-parallel path: RCCL only.  Default: after RCCL has produced its number, the peer-window "
+                         "exchanges (csrc/p2p.hip: one kernel per exchange | inside the dW tiles) are probed as well — each "
+                         "under the watchdog, the windows' self-test and the replica check — all three rates are reported "
+                         "and the fastest healthy one is measured")
     ap.add_argument("--watchdog", type=float, default=900.0,
                     help="seconds any one phase of the run may take before rank 0 prints a JSON line with value null "
                          "and the process exits (a hung collective must not leave the driver without a line)")
@@ -561,6 +571,16 @@ def measure(args, wd):
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: measuring WORLD_SIZE ranks", file=sys.stderr)
     assert t.cuda.is_available(), "bench.py needs an MI355X"
+    # REHEARSAL (tests/test_gpu_p2p.py, OPRL_BENCH_REHEARSAL=1): the N-rank path of this file — probes, rebuild, timed region,
+    # replica check, the line — with every rank on GPU 0: rendezvous over gloo, no RCCL (it refuses two ranks on one device),
+    # peer windows only, a small batch and one update per launch (two ranks' whole-chip launches cannot share a GPU).  Not a
+    # measurement: the line says so.
+    rehearsal = os.environ.get("OPRL_BENCH_REHEARSAL") == "1" and world > 1
+    if rehearsal:
+        global B
+        B = int(os.environ.get("OPRL_BENCH_REHEARSAL_B", "32"))
+        os.environ["OPRL_AMD_CHAIN"] = "1"
+        local_rank = 0
     t.cuda.set_device(local_rank)
     dev = t.device("cuda", local_rank)
 
@@ -578,8 +598,12 @@ def measure(args, wd):
         os.environ.setdefault("MASTER_PORT", "29517")
         import datetime
         wd.kick("RCCL rendezvous")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev,
-                                timeout=datetime.timedelta(seconds=max(60.0, args.watchdog)))
+        if rehearsal:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=max(60.0, args.watchdog)))
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev,
+                                    timeout=datetime.timedelta(seconds=max(60.0, args.watchdog)))
 
     replay = make_replay(dev, seed=rank)               # disjoint shard per rank
     K, W = args.steps, args.warmup
@@ -589,6 +613,12 @@ def measure(args, wd):
         if dist is not None:
             dist.barrier()
             t.cuda.synchronize(dev)
+
+    def all_max(x):
+        """max over ranks of a python float (the rehearsal's gloo group reduces on the host)"""
+        tt_ = t.tensor([x], dtype=t.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+        return float(tt_.item())
 
     def make_learner():
         t.manual_seed(0)                               # reference-style init, same on all ranks
@@ -620,8 +650,9 @@ def measure(args, wd):
         def build(level):
             algo_ = make_learner()
             dp_ = DataParallelLearner(algo_, dist.group.WORLD)
-            dp_.init_native_comm()
-            dp_.broadcast_parameters()             # (oprl_comm_broadcast_params: ncclBroadcast from rank 0 in C)
+            if not rehearsal:
+                dp_.init_native_comm()
+                dp_.broadcast_parameters()         # (oprl_comm_broadcast_params: ncclBroadcast from rank 0 in C)
             ok_ = True
             if level > 0:
                 try:
@@ -638,9 +669,15 @@ def measure(args, wd):
             return algo_, dp_, ok_
 
         probes = {}
-        # RCCL first, always: it is the exchange that is known to work; the peer-window levels (never yet run on a
-        # multi-GPU node) are probed only on request, AFTER RCCL has produced its number, each under the watchdog
-        for level in ((0, 1, 2) if (args.p2p and not args.no_p2p) else (0,)):
+        # RCCL first, always: it is the exchange that is known to work, and once it has produced its number a failure of
+        # anything later still reports that number (FALLBACK).  Then the peer-window levels — never yet run across real
+        # xGMI links — by default: each under the watchdog, the windows' self-test, two trial updates and the replica check;
+        # DESIGN.md section 6 holds the latency budget their rates are to be checked against.
+        levels = (0,) if args.no_p2p else (0, 1, 2)
+        if rehearsal:
+            levels = (1, 2)
+        n_probe = 1000 if not rehearsal else 60
+        for level in levels:
             wd.kick(f"data-parallel probe, exchange level {level}")
             try:
                 algo, dp, ok = build(level)
@@ -651,19 +688,23 @@ def measure(args, wd):
                     print(f"bench.py: exchange level {level} failed to build ({exc})", file=sys.stderr)
                 continue
             if ok:
-                dp.step_n(replay.handle, 300, B, seed=0)
+                dp.step_n(replay.handle, 300 if not rehearsal else 20, B, seed=0)
                 best = 1e30
-                for _rep in range(2):                     # best of two 1000-update probes
+                for _rep in range(2):                     # best of two n_probe-update probes
                     barrier()
                     tp0 = time.perf_counter()
-                    dp.step_n(replay.handle, 1000, B, seed=0)
+                    dp.step_n(replay.handle, n_probe, B, seed=0)
                     barrier()
-                    tp = t.tensor([time.perf_counter() - tp0], dtype=t.float64, device=dev)
-                    dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-                    best = min(best, float(tp.item()))
+                    best = min(best, all_max(time.perf_counter() - tp0))
                 ok = dp.healthy()
                 if ok:
-                    probes[level] = best / 1000 * 1e6
+                    probes[level] = best / n_probe * 1e6
+                    if level == 0 and rank == 0:
+                        FALLBACK.update(value=round(world * n_probe / best, 1), steps=n_probe, warmup=300,
+                                        ms_per_step=round(best / n_probe * 1e3, 5),
+                                        data_parallel_check={"exchange": "rccl", "probe_us_per_step": {"rccl": round(probes[0], 2)}},
+                                        note=f"the RCCL probe's rate ({n_probe} updates, barrier-bracketed, max over ranks): a later "
+                                             "phase of the run failed (see `error`)")
             if not ok and rank == 0:
                 print(f"bench.py: exchange level {level} unusable on this node", file=sys.stderr)
             del dp, algo
@@ -689,9 +730,7 @@ def measure(args, wd):
     dt = time.perf_counter() - t0
     wd.kick("checks + instrumented pass")
     if dist is not None:
-        tt = t.tensor([dt], dtype=t.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = all_max(dt)
     value = world * K / dt
     dp_check = None
     if use_dp:
@@ -900,6 +939,8 @@ def measure(args, wd):
             "roofline": roof, "cpu_baseline": cpu, "configs": configs, "exact_f32": exact, "x2": x2blk, "bf16": bf16, "api_rate": api,
             "dp_single_rank": dp1,
             "multi_learner": multi, "packed_group": group, "data_parallel_check": dp_check,
+            "rehearsal": ("every rank on GPU 0, gloo rendezvous, peer windows only, B = %d, one update per launch: a code-path "
+                          "rehearsal (tests/test_gpu_p2p.py), NOT a measurement" % B) if rehearsal else None,
             "flop_per_step": 2.0 * B * (MACS_SLICE + MACS_DW), "state_bytes_per_step": STATE_BYTES,
         }
         sys.stderr.flush()

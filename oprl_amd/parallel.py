@@ -167,6 +167,8 @@ class DataParallelLearner:
         """[max - min] over ranks of a parameter checksum: 0 iff replicas agree."""
         e = self.engine
         cs = t.stack([e.actor_arena.double().sum(), e.critic_arena.double().sum()])
+        if dist.get_backend(self.group) == "gloo":
+            cs = cs.cpu()                      # (gloo reduces on the host)
         hi, lo = cs.clone(), cs.clone()
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)

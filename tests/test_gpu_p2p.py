@@ -106,15 +106,16 @@ def test_two_process_p2p_data_parallel_step(algo_name, level, prec):
 
 
 @pytest.mark.parametrize("extra,fail,expect", [
-    ([], "0", "rccl"),                                        # the default: RCCL only, the windows are not even probed
-    (["--p2p", "--precision", "f32"], "0", "p2p-inline"),    # on request: the fastest healthy exchange
-    (["--p2p", "--precision", "f32"], "1", "rccl"),          # ... and back to RCCL when the windows' self-test fails
-    (["--p2p"], "0", None),                                   # the x2 learner: whichever is picked must be healthy
+    (["--no-p2p"], "0", "rccl"),                              # RCCL only: the windows are not even probed
+    (["--precision", "f32"], "0", "p2p-inline"),             # the default: all three probed, the fastest healthy one measured
+    (["--precision", "f32"], "1", "rccl"),                   # ... and back to RCCL when the windows' self-test fails
+    (["--precision", "x2"], "0", None),                      # the x2 learner: whichever is picked must be healthy
 ])
 def test_bench_picks_the_exchange_and_falls_back(extra, fail, expect):
-    """bench.py --force-dp (one rank): RCCL unless --p2p asks for the peer-window exchanges to be probed as well —
-    then the fastest exchange whose self-test and replica health check pass; with the self-test forced to fail it
-    must stay on RCCL and still report healthy replicas.  The JSON line is the LAST line of stdout."""
+    """bench.py --force-dp (one rank): RCCL first, then — by default since round 5 — the peer-window exchanges are probed
+    as well and the fastest exchange whose self-test and replica health check pass is measured; with the self-test
+    forced to fail it must stay on RCCL and still report healthy replicas; --no-p2p probes RCCL alone.  The JSON line is
+    the LAST line of stdout."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, OPRL_AMD_P2P_SELFTEST_FAIL=fail, MASTER_PORT="29533")
@@ -129,9 +130,36 @@ def test_bench_picks_the_exchange_and_falls_back(extra, fail, expect):
     assert chk["finite"] and chk["replicas_identical"], chk
     if expect is not None:
         assert chk["exchange"] == expect, chk
-    if not extra:
+    if extra == ["--no-p2p"]:
         assert list(chk["probe_us_per_step"]) == ["rccl"], chk
+    elif fail == "0":
+        assert set(chk["probe_us_per_step"]) == {"rccl", "p2p", "p2p-inline"}, chk
     assert d["n_gpus"] == 1 and d["value"] > 1000
+
+
+@pytest.mark.parametrize("prec", ["x2", "f32"])
+def test_bench_two_rank_rehearsal_on_one_gpu(prec):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, two ranks), both ranks on THIS GPU
+    (OPRL_BENCH_REHEARSAL=1: gloo rendezvous, peer windows only — RCCL refuses two ranks on one device — B = 32, one update
+    per launch): the N > 1 path of the file itself — probe of both window levels on fresh replicas, the rebuild of the
+    fastest, warm-up, the barrier-bracketed timed region with the max over ranks, the replica check, ONE line from rank 0 —
+    with the x2 learner's whole-update launches exchanging inside their tiles.  Not a measurement (the line says so)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OPRL_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("MASTER_PORT", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2",
+                          "--steps", "40", "--warmup", "5", "--pre-warm", "40", "--profile-steps", "40", "--precision", prec],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = [x for x in out.stdout.splitlines() if x.strip().startswith("{")][-1]
+    d = json.loads(line)
+    chk = d["data_parallel_check"]
+    assert d["n_gpus"] == 2 and d["steps"] == 40 and d["value"] > 0 and d["rehearsal"], d
+    assert chk["finite"] and chk["replicas_identical"], chk
+    assert set(chk["probe_us_per_step"]) == {"p2p", "p2p-inline"} and chk["exchange"] in ("p2p", "p2p-inline"), chk
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 64, d["config"]
 
 
 def test_bench_prints_its_line_when_the_run_fails():

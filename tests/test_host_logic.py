@@ -294,3 +294,23 @@ def test_add_transitions_block_equals_transition_by_transition():
         assert t.equal(a._tensors[k], b._tensors[k]), k
     with pytest.raises(IndexError):
         b.add_transitions(np.zeros((11, 8), np.float32))
+
+
+def test_bench_failure_line_keeps_the_rccl_probe():
+    """bench.py at N > 1: once the RCCL probe has produced its number, a failure of anything later (a peer-window probe
+    that hangs into the watchdog, the rebuild) still reports that number — with its own step count and a note — not
+    value null (the first multi-GPU run must produce the whole answer)."""
+    import argparse
+    import json
+    import bench
+    args = argparse.Namespace(steps=20, warmup=5, precision="f32")
+    try:
+        d = json.loads(bench.failure_line(args, 8, "watchdog: phase 'x' exceeded 900 s on rank 0"))
+        assert d["value"] is None and d["steps"] == 20 and d["n_gpus"] == 8 and d["fallback"] is None
+        bench.FALLBACK.update(value=123456.7, steps=1000, warmup=300, ms_per_step=0.0648, note="the RCCL probe's rate",
+                              data_parallel_check={"exchange": "rccl", "probe_us_per_step": {"rccl": 64.8}})
+        d = json.loads(bench.failure_line(args, 8, "watchdog: phase 'data-parallel probe, exchange level 1' exceeded 900 s"))
+        assert d["value"] == 123456.7 and d["steps"] == 1000 and d["data_parallel_check"]["exchange"] == "rccl"
+        assert "watchdog" in d["error"] and d["fallback"]
+    finally:
+        bench.FALLBACK.clear()
