@@ -136,7 +136,7 @@ def cpu_baseline(budget_s: float = 14.0):
 # ---- the other BASELINE.json configurations, the bf16 mode and the through-the-API rate --------
 PEAK_BF16_MATRIX_TFLOPS = 2500.0       # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F16_MATRIX_TFLOPS = 2500.0        # dense fp16 MFMA; the x2 mode spends three products per algorithmic one
-PMC_FILE = {"f32": "r04_pmc_traffic_f32.json", "bf16": "r04_pmc_traffic_bf16.json", "x2": "r04_pmc_traffic_x2.json"}
+PMC_FILE = {"f32": "r05_pmc_traffic_f32.json", "bf16": "r05_pmc_traffic_bf16.json", "x2": "r05_pmc_traffic_x2.json"}
 PEAK_OF = {"f32": PEAK_F32_MATRIX_TFLOPS, "bf16": PEAK_BF16_MATRIX_TFLOPS, "x2": PEAK_F16_MATRIX_TFLOPS / 3.0}
 DTYPE_OF = {"f32": "f32 (exact-fp32 MFMA)", "bf16": "bf16 (fp32 accumulate / master / Adam)",
             "x2": "f32 as split fp16x2 (hi + lo, 3 fp16 MFMAs per product, fp32 accumulate / master / Adam)"}

@@ -2,7 +2,7 @@
 # Round profile of the headline command (run on the GPU box through gpurun; writes under gpurun_out/prof_$TAG):
 #   kernel stats (rocprofv3 --kernel-trace --stats) and three separate --pmc passes (FETCH_SIZE / WRITE_SIZE / MFMA
 #   counters), as MI355X_MICROARCH.md prescribes (counters never combined with trace domains beyond --kernel-trace).
-# usage: tools/profile_round.sh TAG [extra bench.py args, e.g. --precision bf16]   (default mode: x2)
+# usage: tools/profile_round.sh TAG [extra bench.py args, e.g. --precision bf16]   (default mode: exact fp32)
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
