@@ -315,7 +315,8 @@ __device__ __forceinline__ void dw_adam_body(const KAT& A, float* lds, int bx) {
   const bool xk_ok = k_base + xk < I.ldx;
   // GATED: dY of a layer whose rows ARE the seeds (the scalar critic's output layer, written by the role that
   // publishes the seeds) waits for the second gate like the seeds themselves
-  const bool dy_late = GATED && I.dY == A.gate.late_dY;
+  const bool dy_late = GATED && (I.dY == A.gate.late_dY || (A.gate.late_dY2 != nullptr && I.dY == A.gate.late_dY2));
+  const unsigned long long* const gseed = (GATED && item >= A.gate.item_split) ? A.gate.seed2 : A.gate.seed;   // (twin critics: the second one's seeds)
   if constexpr (GATED) {
     const bool ok = dw_gate_wait(A.gate.rows, A.gate.n_rows, A.gate.tag, A.gate.spin);
     if (!ok) report_expired(A.gate.err, A.gate.err_code);
@@ -375,7 +376,7 @@ __device__ __forceinline__ void dw_adam_body(const KAT& A, float* lds, int bx) {
           unsigned long long g = 0;
           bool ok = false;
           for (int spin = 0; spin < A.gate.spin && !ok; ++spin) {
-            g = __hip_atomic_load(A.gate.seed + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g = __hip_atomic_load(gseed + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok = (unsigned)(g >> 32) == A.gate.tag;
             if (!ok) __builtin_amdgcn_s_sleep(1);
           }

@@ -119,7 +119,11 @@ struct DwX2Tile {
     const int te0 = KA->tile_end[0], te1 = KA->tile_end[1], te2 = KA->tile_end[2], te3 = KA->tile_end[3];
     const int hB = A.B;
     const AdamScalars& ad = A.ad;
-    item = (bx >= te0 ? 1 : 0) + (bx >= te1 ? 1 : 0) + (bx >= te2 ? 1 : 0) + (bx >= te3 ? 1 : 0);   // (<= 4 layers)
+    item = (bx >= te0 ? 1 : 0) + (bx >= te1 ? 1 : 0) + (bx >= te2 ? 1 : 0) + (bx >= te3 ? 1 : 0);
+    if constexpr (sizeof(KA->tile_end) / sizeof(int) > 4) {          // (twin critics on one launch: up to eight layers)
+#pragma unroll
+      for (int j = 4; j < 8; ++j) item += bx >= KA->tile_end[j] ? 1 : 0;
+    }
     const DwItem I = KA->items[item];
     const DwGate& G = KA->gate;
     lt = bx - (item > 0 ? KA->tile_end[item - 1] : 0);
@@ -279,7 +283,7 @@ struct DwX2Tile {
     // The write-through rows are read past this XCD's L2 (sc1) with raw buffer loads (engine.h ld4_agent: loads the
     // compiler counts; round 3's first form — the same instruction as inline asm + an explicit wait — left the result
     // registers open to being copied before the data had arrived); from clamped addresses, unconditionally.
-    const bool late = I.dY == G.late_dY;          // the output layer: dY IS the seed (one column): U = e_0
+    const bool late = I.dY == G.late_dY || (G.late_dY2 != nullptr && I.dY == G.late_dY2);          // the output layer: dY IS the seed (one column): U = e_0
     const int npart = I.dY_part_stride > 0 ? h_n_part : 1;
     const bool tiled = I.dY_part_stride > 0 && h_tiled != 0;
     const int xr0 = xb0 < hB ? xb0 : hB - 1, xr1 = xb0 + 1 < hB ? xb0 + 1 : hB - 1;
@@ -339,7 +343,7 @@ struct DwX2Tile {
       unsigned long long x = 0;
       bool ok = G.what_if == 104;
       for (int spin = 0; spin < G.spin && !ok; ++spin) {
-        x = __hip_atomic_load(G.seed + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = __hip_atomic_load((item >= G.item_split ? G.seed2 : G.seed) + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = (unsigned)(x >> 32) == gtag;
         if (!ok) __builtin_amdgcn_s_sleep(1);
       }
@@ -598,6 +602,30 @@ struct DwX2Tile {
           for (int t = 0; t < 4; ++t) w4[t] = tileW[(4 * lk + t) * LDT + 16 * j + li];
           st16_wt(I.pb, (((size_t)ktile * NSn + ptile) * 64 + l) * 4, w4);
         }
+      }
+    }
+  }
+  if (!P::kX2 && I.pf16 != nullptr && !I.x2) {
+    // ---- a bf16 learner's tile (exact-fp32 product above; merged launches): its bf16 packs as well — blocks of 64 lanes x
+    // 8 bf16 in pack16_index order: threads 0..255 the forward packs (online | target) x the tile's two 32-column steps,
+    // 256..511 the W^T pack's four 16-row k tiles (this tile's 16 n are one HALF of a 32-wide step there)
+    const int NSk2 = cdiv(I.K, 32), NSn2 = cdiv(I.N, 32);
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    if (tid < 256) {
+      const int which = tid >> 7, hb = (tid >> 6) & 1, l = tid & 63, li = l & 15, lk = l >> 4;
+      float* dst = which == 0 ? I.pf16 : (polyak ? I.tpf16 : nullptr);
+      if (dst != nullptr && 2 * tk + hb < NSk2) {
+        const float* src = (which == 0 ? tileW : tileT) + li * LDT + 32 * hb;
+        st16_wt(dst, (((size_t)ptile * NSk2 + 2 * tk + hb) * 64 + l) * 4, cvt_bf16x8(ld4(src + 4 * lk), ld4(src + 16 + 4 * lk)));
+      }
+    } else if (tid < 512 && I.pb16 != nullptr) {
+      const int q = tid - 256, blk = q >> 6, l = q & 63, li = l & 15, lk = l >> 4;
+      const int ktile = 4 * tk + blk;
+      if (16 * ktile < I.K) {
+        f32x4 w4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w4[t] = tileW[(4 * lk + t) * LDT + 16 * blk + li];
+        st8_wt(I.pb16 + (((size_t)ktile * NSn2 + (n_base >> 5)) * 64 + l) * 4 + 2 * ((n_base >> 4) & 1), __builtin_convertvector(w4, bf16x4));
       }
     }
   }

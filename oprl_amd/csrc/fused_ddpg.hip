@@ -49,7 +49,7 @@
 #include "dw_body.h"
 #include "dw_tile_x2.h"
 
-namespace oprl { constexpr bool kDwTileX2 = true; }    // PrecX2 learners: the 16 x 64 split-product tile of dw_tile_x2.h in the merged launches
+namespace oprl { constexpr bool kDwTileX2 = true; constexpr bool kMergedTile64 = true; }      // (kMergedTile64: every merged launch rides 16 x 64 tiles, whatever the arithmetic)    // PrecX2 learners: the 16 x 64 split-product tile of dw_tile_x2.h in the merged launches
 
 namespace oprl {
 
@@ -197,8 +197,8 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0)
-        __hip_atomic_store(A.gate_flags + slice * 4 + tp.c, (unsigned long long)A.epoch << 32, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);   // (merged launches: one critic, j == 0)
+        __hip_atomic_store(A.gate_flags + ((size_t)j * gridDim.x + slice) * 4 + tp.c, (unsigned long long)A.epoch << 32, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);   // (critic j's block of flags: twin critics on a merged launch)
     }
     // q goes to role A of this slice as granules — A, the last to finish, turns it into the per-row seed
     // 2 (q - y) / B and the diagnostics itself; this role is done (it used to wait here for y: one more hop
@@ -520,8 +520,8 @@ __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D =
             float* const* dYj = j == 0 ? A.cdY : A.c2dY;
             const float seed = 2.f * (q - y) * A.inv_B;
             dYj[2][(size_t)gr * A.clddo] = seed;
-            if ((A.merged & 1) != 0 && j == 0)   // ... and to the dW tiles of this very launch as a granule (the TD-target array is free in the lean form)
-              __hip_atomic_store(A.y_granules + gr, ((unsigned long long)A.epoch << 32) | (unsigned long long)__float_as_uint(seed),
+            if ((A.merged & 1) != 0)   // ... and to the dW tiles of this very launch as a granule (the TD-target array is free in the lean form; the twin's: an array of its own)
+              __hip_atomic_store((j == 0 ? A.y_granules : A.seed2_granules) + gr, ((unsigned long long)A.epoch << 32) | (unsigned long long)__float_as_uint(seed),
                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (j == 0 && A.y_out != nullptr) A.y_out[gr] = y;
             if (j == 0 && A.q_out != nullptr) A.q_out[gr] = q;
@@ -552,11 +552,16 @@ __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D =
 
 // the tile a workgroup of a merged launch ended up with (the one inlined copy of the tile code per kernel); gate 1: a
 // critic tile of phase 1's launch, 2: an actor tile of phase 2's
-template <class P, class KA>
+template <class P, class KA, bool T64 = false>
 __device__ __forceinline__ void ddpg_tile(const KA* D, int tile, int gate) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (tile < 0) return;
-  if constexpr (P::kX2 && kDwTileX2) {
+  if constexpr (kDwTileX2 && kMergedTile64 && T64) {
+    // the 16 x 64 tile of dw_tile_x2.h, all 16 waves: the split product (PrecX2) or the exact-fp32 one (the other learners:
+    // round 5 — TD3's twin critics: 2 x 84 tile workgroups behind the roles instead of 2 x 152; a single critic's 152 small
+    // tiles stay the shorter chain: DDPG bf16 29.9 us with them, 30.9 with 84 exact-fp32 16 x 64 tiles)
+    dw_tile_x2<KA, P>(*D, smem, tile, gate);
+  } else if constexpr (P::kX2 && kDwTileX2) {
     dw_tile_x2<KA>(*D, smem, tile, gate);     // the 16 x 64 split-product tile (dw_tile_x2.h), all 16 waves
   } else if constexpr (std::is_same<KA, DwKArgs>::value) {
     if (threadIdx.x >= kDwThreads) return;    // a tile workgroup is the first 8 waves (the stand-alone kernel's shape and arithmetic)
@@ -575,10 +580,11 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) { (v
 constexpr size_t kMergedDwOffset = (sizeof(DdpgArgs) + alignof(DwKArgs) - 1) / alignof(DwKArgs) * alignof(DwKArgs);
 // (WIDE: role A on clusters of eight — with the 84 16 x 64 tiles of a PrecX2 learner, which all find a compute unit when
 // roles C and B retire, long before the seeds; the 152 tiles of dw_body.h needed 64 free from the start)
-template <class P, bool WIDE = false>
+// (TWIN: TD3 — roles A | B1 | B2 | C with both critics' tiles riding; the single-critic instances carry none of the twin code)
+template <class P, bool WIDE = false, bool TWIN = false>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase1_dw(const DdpgArgs A, const DwKArgs D) {
   const DwKArgs* Dp = (const DwKArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kMergedDwOffset);
-  ddpg_tile<P, DwKArgs>(Dp, ddpg_phase1_body<256, true, false, P, WIDE, true>(A, Dp), 1);
+  ddpg_tile<P, DwKArgs, TWIN>(Dp, ddpg_phase1_body<256, true, false, P, WIDE, true, DwKArgs, !TWIN>(A, Dp), 1);
 }
 
 
@@ -1624,6 +1630,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
 
 static_assert(FusedLds<256>::total >= kDwLdsFloats && FusedLds<256>::total >= DwLds<16>::floats && FusedLds<256>::total >= DwX2Lds::floats, "a tile workgroup fits the phase kernels' LDS");
 bool fused_x2_tiles() { return kDwTileX2; }
+bool fused_tile64_all() { return kDwTileX2 && kMergedTile64; }
 
 size_t fused_ddpg_lds_bytes() { return sizeof(float) * FusedLds<256>::total; }
 size_t fused_xbuf_granules_per_cluster(int nc) { return (size_t)kTpStages * nc * kTpBlk; }
@@ -1694,6 +1701,9 @@ hipError_t init_fused_attrs() {
                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecBF16>),
                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecX2>),
                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecX2, true>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecF32, false, true>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecBF16, false, true>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecX2, false, true>),
                       reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecX2>),
                       reinterpret_cast<const void*>(&k_ddpg_chain<PrecX2>),
                       reinterpret_cast<const void*>(&k_ddpg_chain<PrecF32>)};
@@ -1768,10 +1778,17 @@ bool fused_ddpg_is_lean(const DdpgArgs& a) {
 // that launch with its gate filled in)
 hipError_t launch_ddpg_phase1_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st) {
   const bool wide = (a.wide & 1) != 0;
-  if (!lean_ok(a) || a.sac || a.n_critics != 1 || (a.merged & 1) == 0 || (wide && (!a.x2 || a.xnc < 8))) return hipErrorInvalidValue;
+  if (!lean_ok(a) || a.sac || a.n_critics < 1 || a.n_critics > 2 || (a.merged & 1) == 0 || (wide && (!a.x2 || a.xnc < 8 || a.n_critics != 1))) return hipErrorInvalidValue;
   const int slices = (a.B + kR - 1) / kR;
   const int tiles = d.tile_end[kDwMaxItems - 1];
-  const dim3 grid(slices, 3 * a.nc + (wide ? 4 : 0) + (tiles + slices - 1) / slices + (a.prefetch_p1 ? 1 : 0));
+  const dim3 grid(slices, (2 + a.n_critics) * a.nc + (wide ? 4 : 0) + (tiles + slices - 1) / slices + (a.prefetch_p1 ? 1 : 0));
+  if (a.n_critics == 2) {
+    if (a.seed2_granules == nullptr) return hipErrorInvalidValue;
+    if (a.x2) hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecX2, false, true>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
+    else if (a.bf16) hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecBF16, false, true>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
+    else hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecF32, false, true>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
+    return hipGetLastError();
+  }
   if (a.x2 && wide) hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecX2, true>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
   else if (a.x2) hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);
   else if (a.bf16) hipLaunchKernelGGL((k_ddpg_phase1_dw<PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, d);

@@ -235,6 +235,8 @@ struct DwGate {
   const unsigned long long* rows = nullptr; int n_rows = 0;   // every producer of X / dY rows has finished
   const unsigned long long* seed = nullptr; int n_seed = 0;   // the per-row seeds (and `late_dY`) are out
   const float* late_dY = nullptr;      // dY buffer that is written with the seeds (the scalar critic's output layer)
+  // TWIN critics on one merged launch (TD3): items >= item_split are the second critic's — its seeds, its output layer's dY
+  const unsigned long long* seed2 = nullptr; const float* late_dY2 = nullptr; int item_split = 1 << 30;
   unsigned tag = 0; int spin = 0;
   int what_if = 0;                     // timing experiments (oprl_learner_debug_expire, sites 101 ..; tools/what_if.py): 104 the seeds, 105 du, 106 the rows' flags count as seen
   unsigned* err = nullptr; unsigned err_code = 0;
@@ -380,6 +382,7 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   // first layer's come from the pass's own backward step, granules `g1_granules`
   int merged;
   unsigned long long* gate_flags;
+  unsigned long long* seed2_granules;  // [B] {epoch, seed} of the SECOND critic for the tiles of a merged launch (TD3); the first one's: y_granules[0 ..]
   unsigned long long* du_granules;     // [B][kDuLd] {epoch, du}
   unsigned long long* g1_granules;     // [16 tiles][B][16] {epoch, dz1 of the actor}
   float* gu;                           // k_ddpg_chain: [A][B][256] unit-seed dz1 rows of the actor (DwGate kind 3)

@@ -622,6 +622,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   a.y_out = h->ydbg; a.q_out = h->qdbg;
   a.y_granules = h->y_granules; a.gran_stride = h->Bmax;
   a.gate_flags = h->y_granules + (size_t)3 * h->Bmax;   // 256 flag granules behind the TD / q granules
+  a.seed2_granules = h->y_granules + (size_t)3 * h->Bmax + 256;
   a.merged = 0;
   a.epoch = h->epoch;
   a.trace = nullptr;
@@ -690,7 +691,10 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   const bool whole_f32 = h->fchain && fused_x2_tiles() && !a.x2 && !a.bf16 && !h->no_whole && !h->no_merge && !h->no_merge2 && !h->shared_chip &&
                          !h->dp_inline && B <= 256 && fused_ddpg_is_lean(a) && (a.wide & 3) == 3 && h->chain_flags != nullptr &&
                          chain_rows(h, B) * ((B + kR - 1) / kR) <= h->n_cus;
-  if (!h->no_merge && !h->shared_chip && h->nc == 1 && !a.sac && B <= 256 && xport_ok && (!h->dp_inline || inline_x2) && fused_ddpg_is_lean(a)) {
+  // (TD3: both critics' tiles ride — roles A | B1 | B2 | C are the whole chip at B = 256, the 2 x 84 / 2 x 152 tiles take the
+  // compute units the roles leave; this rank's own Adam step only)
+  const bool merge_twin = h->nc == 2 && c.algo == OPRL_TD3 && !h->cfg.export_grads && !h->dp_inline && !h->no_merge_twin;
+  if (!h->no_merge && !h->shared_chip && (h->nc == 1 || merge_twin) && !a.sac && B <= 256 && xport_ok && (!h->dp_inline || inline_x2) && fused_ddpg_is_lean(a)) {
     a.merged |= 1;
     if (!(a.x2 && fused_x2_tiles()) && !whole_f32) a.wide &= ~1;     // (the 84 16 x 64 tiles of a PrecX2 learner get along with role A on eight)
   }
@@ -830,7 +834,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     h->epoch += 1;
     if (h->epoch == 0 || h->epoch > 0xFFFFFFFFu - (unsigned)kChainMax) {   // the TD-target tag wrapped (or would inside a chain launch): retire every stale granule
       h->epoch = 1;
-      HIPC(hipMemsetAsync(h->y_granules, 0, ((size_t)3 * h->Bmax + 256) * sizeof(unsigned long long), st));
+      HIPC(hipMemsetAsync(h->y_granules, 0, ((size_t)4 * h->Bmax + 256) * sizeof(unsigned long long), st));
       if (h->du_granules != nullptr) {
         HIPC(hipMemsetAsync(h->du_granules, 0, (size_t)(h->Bmax < 256 ? h->Bmax : 256) * kDuLd * sizeof(unsigned long long), st));
         HIPC(hipMemsetAsync(h->g1_granules, 0, (size_t)16 * (h->Bmax < 256 ? h->Bmax : 256) * 16 * sizeof(unsigned long long), st));
@@ -988,13 +992,19 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     }
     if ((fa.merged & 1) != 0) {
       // phase 1 and the critic's dW + Adam tiles as ONE launch: the tiles wait for the roles' flag granules
-      DwArgs dw = dw_build(h, true, B, true, false);
+      // TD3 moves its targets only on actor steps (td3.py:135-146)
+      DwArgs dw = dw_build(h, true, B, c.algo == OPRL_TD3 ? actor_due(h) : true, false);
       DwKArgs kd;
-      if (fill_dw_kargs(dw, &kd, (fa.x2 && fused_x2_tiles()) ? 64 : 32) < 0) { set_err("merged phase 1: bad dW table"); return OPRL_ERR_INVALID; }
+      if (fill_dw_kargs(dw, &kd, ((fa.x2 && fused_x2_tiles()) || (h->nc == 2 && fused_tile64_all())) ? 64 : 32) < 0) { set_err("merged phase 1: bad dW table"); return OPRL_ERR_INVALID; }
       const int slices = (B + kR - 1) / kR;
-      kd.gate.rows = fa.gate_flags; kd.gate.n_rows = 4 * slices;
+      kd.gate.rows = fa.gate_flags; kd.gate.n_rows = 4 * slices * h->nc;
       kd.gate.seed = fa.y_granules; kd.gate.n_seed = B;      // the seeds come as granules, one per row
       kd.gate.late_dY = h->ws_critic[0].dY[c.critics[0].n_layers - 1];
+      if (h->nc == 2) {      // (twin critics: the second one's items, seeds and output-layer dY)
+        kd.gate.item_split = c.critics[0].n_layers;
+        kd.gate.seed2 = fa.seed2_granules;
+        kd.gate.late_dY2 = h->ws_critic[1].dY[c.critics[1].n_layers - 1];
+      }
       kd.gate.tag = h->epoch; kd.gate.spin = h->debug_expire == 7 ? 0 : (1 << 20);
       kd.gate.err = h->err_dev; kd.gate.err_code = (1u << 8) | 7u;      // KERN_PHASE1, SITE_DW_GATE (csrc/tp3.h)
       prof_begin(4, st);

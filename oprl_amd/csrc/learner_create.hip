@@ -83,7 +83,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
             (size_t)nc * B * A + (size_t)nc * B + (size_t)B * 128 + 2 * (size_t)B;
   floats += (size_t)(nc + 1) * n_slices * 4 + 16;
   floats += (size_t)B * (2 * S + A + 2);
-  floats += 64 * 32 + 6 * (size_t)B + 512;      // (granule arrays: y, q1, q2; 256 gate flags)
+  floats += 64 * 32 + 8 * (size_t)B + 512;      // (granule arrays: y, q1, q2, the twin's seeds; 256 gate flags)
   const int Bm = B < 256 ? B : 256;             // merged phase 2 serves one 256-row chunk
   const bool merge2_bufs = h->fused && cfg->algo != OPRL_SAC && A <= kDuLd;
   if (merge2_bufs) floats += 2 * ((size_t)Bm * kDuLd + 64) + 2 * 256 + 128 + 2 * (size_t)16 * Bm * 16 + 64 + 16 * 256 + 4 * 64 + 2 * 256 + 64 + kMaxLayers * 256 + 64;
@@ -135,7 +135,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   h->part_a = p.take<float>((size_t)n_slices * 4);
   h->scalars = p.take<float>(16);
   h->alpha_grad = cfg->log_alpha_grad ? cfg->log_alpha_grad : p.take<double>(2);
-  h->y_granules = p.take<unsigned long long>((size_t)3 * B + 256);
+  h->y_granules = p.take<unsigned long long>((size_t)4 * B + 256);      // [TD target / seeds | q1 | q2 | 256 gate flags | the twin critic's seeds]
   if (merge2_bufs) {
     h->du_granules = p.take<unsigned long long>((size_t)Bm * kDuLd);
     h->g1_granules = p.take<unsigned long long>((size_t)16 * Bm * 16);
@@ -296,6 +296,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     if (const char* cm = getenv("OPRL_AMD_CHAIN")) { const int v = atoi(cm); if (v >= 1 && v <= kChainMax) h->chain_max = v; }
     const char* nw = getenv("OPRL_AMD_NO_WIDE");
     h->no_wide = (nw != nullptr && atoi(nw) != 0) ? 1 : 0;
+    h->no_merge_twin = (no_ride & 64) != 0 ? 1 : 0;
     const char* nxl = getenv("OPRL_AMD_NO_XCD_LOCAL");
     h->xcd_local = h->fused && !(nxl != nullptr && atoi(nxl) != 0) && xcd_map_ok();
     // the generic per-net launches on clusters of 4 (slice_tp.hip): any net of the common shape

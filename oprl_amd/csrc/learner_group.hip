@@ -197,7 +197,7 @@ extern "C" int oprl_group_step_n(oprl_group* g, oprl_replay* replay, int32_t K, 
         h->staged_ready = false;
         const int prefetch = (k + 1 < K && due[j]) ? 1 : 0;     // (the row of phase 2's launch: actor steps only)
         h->epoch += 1;
-        if (h->epoch == 0) { h->epoch = 1; HIPC(hipMemsetAsync(h->y_granules, 0, ((size_t)3 * h->Bmax + 256) * sizeof(unsigned long long), st)); }
+        if (h->epoch == 0) { h->epoch = 1; HIPC(hipMemsetAsync(h->y_granules, 0, ((size_t)4 * h->Bmax + 256) * sizeof(unsigned long long), st)); }
         p1[l] = ddpg_args(h, B);
         p1[l].group_span = g->span;
         RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &p1[l].cluster_tag));

@@ -76,6 +76,7 @@ hipError_t launch_debug_normal(unsigned long long seed, unsigned long long ctr, 
                                hipStream_t st);
 hipError_t init_fused_attrs();
 bool xcd_map_ok();
+bool fused_tile64_all();
 size_t fused_xbuf_granules_per_cluster(int nc);
 hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st);
 hipError_t launch_ddpg_phase1_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_t st);
@@ -345,6 +346,7 @@ struct oprl_learner {
   unsigned long long* g1_granules = nullptr;
   float* w3_snap = nullptr;
   int no_wide = 0;             // OPRL_AMD_NO_WIDE: never run role A / phase 2's critic pass on clusters of eight
+  int no_merge_twin = 0;       // OPRL_AMD_NO_RIDE bit 64: TD3's critics' tiles as a launch of their own
   bool xcd_local = false;      // XCD-local cluster exchanges (DdpgArgs::xcd_local): probed dispatcher, not OPRL_AMD_NO_XCD_LOCAL, cleared by an expired wait
   int xnc = kMaxCluster;       // members an exchange area of xbuf is laid out for
   unsigned long long* xbuf = nullptr;
