@@ -388,8 +388,10 @@ struct Coh : P {
       const unsigned h = __hip_atomic_load(reinterpret_cast<const unsigned*>(frag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffu;
       const unsigned l = __hip_atomic_load(reinterpret_cast<const unsigned*>(frag + 256), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffu;
       return ((float)__builtin_bit_cast(_Float16, (unsigned short)h) + (float)__builtin_bit_cast(_Float16, (unsigned short)l)) * P::kOut;
+    } else if constexpr (P::kBf16) {
+      const unsigned h = __hip_atomic_load(reinterpret_cast<const unsigned*>(frag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return __uint_as_float((h & 0xffffu) << 16);
     } else {
-      static_assert(!P::kBf16, "Coh: the parity arithmetics");
       return ldc(frag);
     }
   }

@@ -978,6 +978,7 @@ struct PassCtx {
   const float* w3;              // the actor's output layer [A][256] as it is before this update's actor step
   const float* cb[3];           // the critic's biases as this update's tiles leave them (uncached copies)
   long long* trace;
+  const float* pb1_32 = nullptr;   // (bf16 learners) the actor's second hidden layer as its fp32 W^T pack: the unit-seed rows' B operand
 };
 // GE (k_ddpg_chain): the first hidden layer's dY leaves this pass as UNIT-SEED rows G_j = dz1 / d(du_j), j < A — the
 // actor's backward is linear in du — computed and stored BEFORE the critic's new weights arrive (the pass's members sit
@@ -985,7 +986,7 @@ struct PassCtx {
 // here.  Otherwise: the backward step after du, its result as granules (the two-launch form, whose pass starts at once).
 template <class P, class KA = DwKArgs, bool PF = true, bool GE = false>
 __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D, int by_in, const PassCtx& cx) {
-  static_assert((P::kX2 || (GE && !P::kBf16)) && kDwTileX2, "the merged phase 2: PrecX2 learners; with the unit-seed rows (k_ddpg_chain) exact fp32 as well");
+  static_assert((P::kX2 || GE) && kDwTileX2, "the merged phase 2: PrecX2 learners; with the unit-seed rows (k_ddpg_chain) every arithmetic");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using LY = FusedLds<256>;
   constexpr int HB = kR * kWL4;
@@ -1071,7 +1072,9 @@ __device__ __forceinline__ int ddpg_phase2m_body(const DdpgArgs& A, const KA* D,
   }
   // ---- requests.  For the backward step at the end: the member's W2^T shard (32 KB, two b128 per thread), the
   // output layer's rows, this thread's four h2 elements and (threads < 512) its h1 element — the ReLU masks
-  const float* wsrc = A.actor.pb[1] + (size_t)c * 2 * 16 * 256;
+  // (the member's W2^T shard: two 16-row k tiles x the whole contraction — 32 KB in the fp32 and x2 packs; a bf16 learner's
+  // unit-seed rows are formed in exact fp32 from the fp32 pack its tiles keep current)
+  const float* wsrc = ((P::kBf16 && cx.pb1_32 != nullptr) ? cx.pb1_32 : A.actor.pb[1]) + (size_t)c * 2 * 16 * 256;
   f32x4 wv[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) wv[q] = ld4c(wsrc + ((size_t)q * kThreads + tid) * 4);      // (coherent loads throughout this prologue: engine.h ld4c)
@@ -1345,7 +1348,7 @@ __device__ __forceinline__ void chain_wait2(const unsigned long long* f0, int n0
 constexpr size_t kChainCOffset = (kWholeDaOffset + sizeof(DwKArgs4) + alignof(ChainArgs) - 1) / alignof(ChainArgs) * alignof(ChainArgs);
 template <class P>
 __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const DwKArgs4 Dc, const DwKArgs4 Da, const ChainArgs C_) {
-  static_assert(!P::kBf16 && kDwTileX2, "the chain launch: the two parity arithmetics (split fp16, exact fp32)");
+  static_assert(kDwTileX2, "the chain launch runs the 16 x 64 tiles of dw_tile_x2.h");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
   const DwKArgs4* Dcp = (const DwKArgs4*)(ka + kWholeDcOffset);
@@ -1510,7 +1513,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
     asm volatile("" : "+s"(by2));
     const int u2 = by2 / C.rows;
     const PassCtx cx{A.epoch + (unsigned)u2, A.cluster_tag + 2u * (unsigned)u2 + 1u, C.w3buf[u2 & 1], {C.b16[2][0], C.b16[2][1], C.b16[2][2]},
-                     (kTraceOn && u2 == C.trace_u) ? A.trace2 : nullptr};
+                     (kTraceOn && u2 == C.trace_u) ? A.trace2 : nullptr, A.actor_pb1_f32};
     (void)ddpg_phase2m_body<P, DwKArgs4, false, true>(A, Dap, by2 - u2 * C.rows, cx);      // (GE: its pass runs on Coh<P>)
     return;
   }
@@ -1706,7 +1709,8 @@ hipError_t init_fused_attrs() {
                       reinterpret_cast<const void*>(&k_ddpg_phase1_dw<PrecX2, false, true>),
                       reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecX2>),
                       reinterpret_cast<const void*>(&k_ddpg_chain<PrecX2>),
-                      reinterpret_cast<const void*>(&k_ddpg_chain<PrecF32>)};
+                      reinterpret_cast<const void*>(&k_ddpg_chain<PrecF32>),
+                      reinterpret_cast<const void*>(&k_ddpg_chain<PrecBF16>)};
   for (const void* k : ks) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -1811,7 +1815,7 @@ hipError_t launch_ddpg_phase2_dw(const DdpgArgs& a, const DwKArgs& d, hipStream_
 // n_upd updates as one launch (k_ddpg_chain): `a` / `dc` / `da` with both gates filled in (the gates' tags = the FIRST
 // update's epoch), `c` = what changes per update
 hipError_t launch_ddpg_chain(const DdpgArgs& a, const DwKArgs4& dc, const DwKArgs4& da, const ChainArgs& c, hipStream_t st) {
-  if (!lean_ok(a) || a.sac || a.bf16 || !kDwTileX2 || a.n_critics != 1 || !a.whole || (a.merged & 3) != 3 || (a.wide & 3) != 3 ||
+  if (!lean_ok(a) || a.sac || (a.bf16 && a.actor_pb1_f32 == nullptr) || !kDwTileX2 || a.n_critics != 1 || !a.whole || (a.merged & 3) != 3 || (a.wide & 3) != 3 ||
       a.xnc < 8 || a.A > kDuLd || a.B > 256 || a.prefetch_next || a.prefetch_p1 || c.n_upd < 1 || c.n_upd > kChainMax)
     return hipErrorInvalidValue;
   const int slices = (a.B + kR - 1) / kR;
@@ -1822,6 +1826,7 @@ hipError_t launch_ddpg_chain(const DdpgArgs& a, const DwKArgs4& dc, const DwKArg
   if (c.rows != rows) return hipErrorInvalidValue;
   const dim3 grid(slices, rows * c.n_upd);
   if (a.x2) hipLaunchKernelGGL((k_ddpg_chain<PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, dc, da, c);
+  else if (a.bf16) hipLaunchKernelGGL((k_ddpg_chain<PrecBF16>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, dc, da, c);
   else hipLaunchKernelGGL((k_ddpg_chain<PrecF32>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, dc, da, c);
   return hipGetLastError();
 }

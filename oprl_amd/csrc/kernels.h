@@ -382,6 +382,8 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   // first layer's come from the pass's own backward step, granules `g1_granules`
   int merged;
   unsigned long long* gate_flags;
+  const float* actor_pb1_f32;          // k_ddpg_chain<PrecBF16>: the online actor's second hidden layer as its fp32 W^T fragment pack — the unit-seed
+                                       // rows of the actor's first layer are formed in exact fp32 (the 16-bit packs of a bf16 learner: 8 mantissa bits)
   unsigned long long* seed2_granules;  // [B] {epoch, seed} of the SECOND critic for the tiles of a merged launch (TD3); the first one's: y_granules[0 ..]
   unsigned long long* du_granules;     // [B][kDuLd] {epoch, du}
   unsigned long long* g1_granules;     // [16 tiles][B][16] {epoch, dz1 of the actor}

@@ -672,7 +672,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   // OPRL_AMD_NO_WIDE=1; up to three cannot dead-lock (the B roles always finish and free their CUs).
   a.xnc = h->xnc;
   a.wide = 0;
-  if (h->xnc >= 8 && !h->no_wide && !a.sac && !a.bf16 && a.A <= 8 && fused_ddpg_is_lean(a)) {   // (narrow exchanges: <= 8 action columns)
+  if (h->xnc >= 8 && !h->no_wide && !a.sac && (!a.bf16 || h->bchain) && a.A <= 8 && fused_ddpg_is_lean(a)) {   // (narrow exchanges: <= 8 action columns)
     const int slices = (B + kR - 1) / kR;
     if (h->nc == 1 && (a.nc + 8 + a.nc) * slices <= h->n_cus) a.wide |= 1;
     if ((8 + 1) * slices <= h->n_cus) a.wide |= 2;
@@ -694,15 +694,21 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   // (TD3: both critics' tiles ride — roles A | B1 | B2 | C are the whole chip at B = 256, the 2 x 84 / 2 x 152 tiles take the
   // compute units the roles leave; this rank's own Adam step only)
   const bool merge_twin = h->nc == 2 && c.algo == OPRL_TD3 && !h->cfg.export_grads && !h->dp_inline && !h->no_merge_twin;
+  // ... and bf16 learners (k_ddpg_chain<PrecBF16>: learner_internal.h bchain)
+  const bool whole_bf16 = h->bchain && fused_x2_tiles() && a.bf16 && !h->no_whole && !h->no_merge && !h->no_merge2 && !h->shared_chip &&
+                          !h->dp_inline && B <= 256 && fused_ddpg_is_lean(a) && (a.wide & 3) == 3 && h->chain_flags != nullptr &&
+                          chain_rows(h, B) * ((B + kR - 1) / kR) <= h->n_cus;
+  if (h->bchain && !whole_bf16) a.wide = 0;      // (outside the whole form a bf16 learner's passes stay on clusters of four, as before)
+  if (whole_bf16) a.actor_pb1_f32 = net_view(c.actor, false).pb[1];
   if (!h->no_merge && !h->shared_chip && (h->nc == 1 || merge_twin) && !a.sac && B <= 256 && xport_ok && (!h->dp_inline || inline_x2) && fused_ddpg_is_lean(a)) {
     a.merged |= 1;
-    if (!(a.x2 && fused_x2_tiles()) && !whole_f32) a.wide &= ~1;     // (the 84 16 x 64 tiles of a PrecX2 learner get along with role A on eight)
+    if (!(a.x2 && fused_x2_tiles()) && !whole_f32 && !whole_bf16) a.wide &= ~1;     // (the 84 16 x 64 tiles of a PrecX2 learner get along with role A on eight)
   }
   // ... and the ACTOR's tiles on phase 2 (DDPG / TD3: the tanh head, action_dim <= kDuLd): the tiles form their dY from
   // du, the first layer's comes from one more backward step of the critic pass's members (csrc/fused_ddpg.hip).
   // PrecX2 learners only, the pass on clusters of eight: with the exact-fp32 tiles the merged form measured no faster
   // than the two launches (34.9 vs 34.7 us)
-  if (!h->no_merge2 && !h->shared_chip && ((a.x2 && fused_x2_tiles()) || whole_f32) && h->du_granules != nullptr && !a.sac && B <= 256 && (!h->dp_inline || inline_x2) &&
+  if (!h->no_merge2 && !h->shared_chip && ((a.x2 && fused_x2_tiles()) || whole_f32 || whole_bf16) && h->du_granules != nullptr && !a.sac && B <= 256 && (!h->dp_inline || inline_x2) &&
       fused_ddpg_is_lean(a) && c.actor.theta_target != nullptr && (a.wide & 2) != 0) {
     a.merged |= 2;
     a.du_granules = h->du_granules;
@@ -711,8 +717,8 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   }
   // the whole update as ONE launch (k_ddpg_update): both merged forms, role A and the critic pass on eight, the 16 x 64
   // tiles, and everything the roles hand to each other in uncached memory
-  if (!h->no_whole && (!h->cfg.export_grads || inline_x2) && ((a.x2 && fused_x2_tiles()) || whole_f32) && h->nc == 1 && (a.merged & 3) == 3 && (a.wide & 3) == 3 && h->uc_pool &&
-      h->uc_base != nullptr && h->w_flags != nullptr && h->chain_flags != nullptr &&
+  if (!h->no_whole && (!h->cfg.export_grads || inline_x2) && ((a.x2 && fused_x2_tiles()) || whole_f32 || whole_bf16) && h->nc == 1 && (a.merged & 3) == 3 && (a.wide & 3) == 3 && h->uc_pool &&
+      (h->uc_base != nullptr || h->bchain) && h->w_flags != nullptr && h->chain_flags != nullptr &&
       chain_rows(h, B) * ((B + kR - 1) / kR) <= h->n_cus) {      // (one update's workgroups wait for each other: all must fit the chip)
     a.whole = 1;
     a.w_flags = h->w_flags;

@@ -99,7 +99,10 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   // of the same launch wrote
   h->fchain = h->fused && !h->x2 && !h->bf16 && cfg->algo == OPRL_DDPG && nc == 1 && !cfg->export_grads && merge2_bufs &&
               cfg->actor.theta_target != nullptr && cfg->critics[0].theta_target != nullptr && cfg->actor.n_layers == 3 && cfg->critics[0].n_layers == 3;
-  const int uc_pool = (h->x2 || h->fchain) ? 1 : 0;
+  h->bchain = h->fused && h->bf16 && cfg->algo == OPRL_DDPG && nc == 1 && !cfg->export_grads && merge2_bufs &&
+              cfg->actor.theta_target != nullptr && cfg->critics[0].theta_target != nullptr && cfg->actor.n_layers == 3 && cfg->critics[0].n_layers == 3 &&
+              getenv("OPRL_AMD_NO_BF16_CHAIN") == nullptr;
+  const int uc_pool = (h->x2 || h->fchain || h->bchain) ? 1 : 0;
   h->uc_pool = uc_pool != 0;
   if ((uc_pool ? uc_alloc((void**)&h->pool.base, bytes) : hipMalloc(&h->pool.base, bytes)) != hipSuccess) { set_err("hipMalloc(%zu) failed", bytes); delete h; return OPRL_ERR_NOMEM; }
   h->pool.cap = bytes;
@@ -306,7 +309,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   if (h->fused || h->tp_generic_on) {
     const size_t slices = (size_t)(h->Bmax + kR - 1) / kR;
     // (areas laid out for clusters of eight where wide clusters may run: DDPG / TD3, fp32, lean passes)
-    h->xnc = (h->fused && !h->bf16 && !h->no_lean && !h->no_wide && h->ncl == 4 &&
+    h->xnc = (h->fused && (!h->bf16 || h->bchain) && !h->no_lean && !h->no_wide && h->ncl == 4 &&
               (cfg->algo == OPRL_DDPG || cfg->algo == OPRL_TD3)) ? 8 : kMaxCluster;
     h->xbuf_granules = (size_t)(2 + nc) * slices * fused_xbuf_granules_per_cluster(h->xnc);
     if (hipMalloc(&h->xbuf, h->xbuf_granules * sizeof(unsigned long long)) != hipSuccess) {

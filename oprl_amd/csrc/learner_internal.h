@@ -400,6 +400,10 @@ struct oprl_learner {
   // kernel boundary; the caller's packs are rebuilt from the masters when something outside reads them (fresh32).
   // fnet[0] = the actor, fnet[1] = the critic with pack / pack_target -> the mirrors (uc_base holds them)
   bool fchain = false;
+  // bf16 DDPG learners (bchain, round 5): whole updates per launch as well — k_ddpg_chain<PrecBF16>: the passes on the bf16
+  // packs (coherent loads), the tiles with the exact-fp32 product writing both pack sets, the actor's unit-seed rows in
+  // exact fp32 from the fp32 W^T pack; the workspace in uncached memory like the other chain learners'
+  bool bchain = false;
   oprl_net fnet[2];
   // k_ddpg_chain (the whole update, several per launch): role C's / the critic tiles' flags, the critic's uncached bias copies
   unsigned long long* w_flags = nullptr;

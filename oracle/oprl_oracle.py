@@ -70,6 +70,10 @@ def clone_params(p: list[t.Tensor]) -> list[t.Tensor]:
 # the fp32 oracle measures how far that is from the reference.
 GEMM_BF16 = False
 GEMM_BF16_MIN_DIM = 0     # only layers whose fan-in AND fan-out reach this are rounded
+# the WHOLE-UPDATE form of a bf16 DDPG learner (k_ddpg_chain<PrecBF16>, round 5): the critic pass of the actor step runs on
+# clusters of EIGHT (its partial dz are rounded per eighth of the hidden columns), and the actor's own backward — the output
+# layer's rows times du in the tiles, the first layer through unit-seed rows — is formed in exact fp32
+GEMM_BF16_CHAIN = False
 
 
 class bf16_gemm:
@@ -77,18 +81,18 @@ class bf16_gemm:
     only the 512 x 512 layers (what a bf16 TQC learner does: its layer-wise critic kernels run the hidden
     layers in bf16; the first layer, the heads and the 256-wide actor stay fp32)."""
 
-    def __init__(self, on: bool = True, min_dim: int = 0):
-        self.on, self.min_dim = on, min_dim
+    def __init__(self, on: bool = True, min_dim: int = 0, chain: bool = False):
+        self.on, self.min_dim, self.chain = on, min_dim, chain
 
     def __enter__(self):
-        global GEMM_BF16, GEMM_BF16_MIN_DIM
-        self.saved = (GEMM_BF16, GEMM_BF16_MIN_DIM)
-        GEMM_BF16, GEMM_BF16_MIN_DIM = self.on, self.min_dim
+        global GEMM_BF16, GEMM_BF16_MIN_DIM, GEMM_BF16_CHAIN
+        self.saved = (GEMM_BF16, GEMM_BF16_MIN_DIM, GEMM_BF16_CHAIN)
+        GEMM_BF16, GEMM_BF16_MIN_DIM, GEMM_BF16_CHAIN = self.on, self.min_dim, self.chain
         return self
 
     def __exit__(self, *exc):
-        global GEMM_BF16, GEMM_BF16_MIN_DIM
-        GEMM_BF16, GEMM_BF16_MIN_DIM = self.saved
+        global GEMM_BF16, GEMM_BF16_MIN_DIM, GEMM_BF16_CHAIN
+        GEMM_BF16, GEMM_BF16_MIN_DIM, GEMM_BF16_CHAIN = self.saved
         return False
 
 
@@ -139,16 +143,22 @@ def mlp_backward(p: list[t.Tensor], acts: list[t.Tensor], dout: t.Tensor,
                 # dz (contraction over its quarter of the hidden columns) to bf16 for the next GEMM and
                 # the members' products are summed in fp32 (csrc/tp4.h: dact quarters + all-reduce)
                 dx = sum(_q(pm) @ _q(p[0]) for pm in parts)
+            elif GEMM_BF16_CHAIN and row_scale is None and GEMM_BF16_MIN_DIM == 0:
+                dx = dz @ p[2 * l]               # (the chain form's actor backward: exact fp32)
             else:
                 dx = _q(dz, p[2 * l]) @ _q(p[2 * l], p[2 * l])
         if l > 0:
             mask = (acts[l] > 0).to(F32)     # threshold_backward on the ReLU output
             parts = None
-            if row_scale is not None and n_layers == 3 and l == 1 and dz.shape[1] % 4 == 0:
-                w4 = dz.shape[1] // 4
+            if row_scale is not None and n_layers == 3 and l == 1 and dz.shape[1] % 8 == 0:
+                # (members of the cluster: four — eight for the chain form's critic pass, the backward that wants dx only)
+                nm = 8 if (GEMM_BF16_CHAIN and need_dx and not need_dw) else 4
+                w4 = dz.shape[1] // nm
                 parts = [(_q(dz[:, m * w4:(m + 1) * w4]) @ _q(p[2 * l][m * w4:(m + 1) * w4, :])) * mask
-                         for m in range(4)]
-                dx = parts[0] + parts[1] + parts[2] + parts[3]     # member order, as k_dw_adam sums them
+                         for m in range(nm)]
+                dx = parts[0]
+                for m in range(1, nm):
+                    dx = dx + parts[m]           # member order, as k_dw_adam sums them
                 dz = dx
             else:
                 dz = dx * mask

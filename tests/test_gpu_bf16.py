@@ -55,14 +55,35 @@ def _check(name, got, emu, gold, skip=(), emu_out=TOL_EMU_OUT, emu_param=TOL_EMU
           f"vs fp32 reference vectors {wr[1]:.2e} ({wr[0]})")
 
 
+def _ddpg_runs_whole_updates():
+    """Does a bf16 DDPG learner at B = 256 take the whole-update form here (k_ddpg_chain<PrecBF16>: a chip that holds one
+    update's workgroups)?  Its arithmetic differs from the phase launches' in two places the emulation follows
+    (oracle.bf16_gemm(chain=True))."""
+    import ctypes as C
+    import torch as t
+    from oprl_amd.algos.ddpg import DDPG
+    from oprl_amd.logging import NullLogger
+    t.manual_seed(0)
+    algo = DDPG(logger=NullLogger(), state_dim=24, action_dim=6, device="cuda", max_batch=256, precision="bf16").create()
+    out = (C.c_int32 * 12)()
+    assert algo.learner.lib.oprl_learner_debug_form(algo.learner.handle, 256, out) == 0
+    return out[2] == 4
+
+
 def test_ddpg_walker_b256_bf16():
     got = sc.ddpg_scenario(lambda *a: ha.HipDDPG(*a, precision="bf16"))
-    Emu = _bf16_updates(sc.OracleDDPG)
 
-    class EmuD(Emu):
-        def hook_step1(self):
-            self._g = (self.o.last["g_critic"], self.o.last["g_actor"])
-    emu = sc.ddpg_scenario(EmuD)
+    def emulate(chain):
+        class EmuD(_bf16_updates(sc.OracleDDPG, chain=chain)):
+            def hook_step1(self):
+                self._g = (self.o.last["g_critic"], self.o.last["g_actor"])
+        return sc.ddpg_scenario(EmuD)
+    emu = emulate(False)
+    if _ddpg_runs_whole_updates():
+        # the updates themselves ran as whole-update launches: their arithmetic (bf16_gemm(chain=True)); the step-1 gradient
+        # samples come from a gradient-exporting twin learner (tests/hip_adapters.py), i.e. from the phase launches
+        chain = emulate(True)
+        emu = {k: (v if k.startswith("g_") else chain[k]) for k, v in emu.items()}
     _check("DDPG walker B=256, 10 updates", got, emu, sc.load_golden("ddpg_walker_b256"), skip=("y0", "q0"))
 
 

@@ -176,7 +176,7 @@ def test_x2_launch_forms_agree(algo_name, prec, monkeypatch):
         assert d1 < 2e-6 and d2 < 2e-6, (m, d1, d2)
 
 
-@pytest.mark.parametrize("prec", ["x2", "f32"])
+@pytest.mark.parametrize("prec", ["x2", "f32", "bf16"])
 def test_chain_launches_equal_one_update_launches_bitwise(prec, monkeypatch):
     """k_ddpg_chain (several updates per launch, roles of update u + 1 behind the flags of update u) against the same
     kernel with ONE update per launch (OPRL_AMD_CHAIN=1: a kernel boundary between updates): the same arithmetic, so the
