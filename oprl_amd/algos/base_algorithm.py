@@ -65,6 +65,15 @@ class OffPolicyAlgorithm(ABC):
         mlp = getattr(actor, "mlp", None) or getattr(actor, "net", None)
         return mlp if (mlp is not None and hasattr(mlp, "set_pending") and mlp.on_gpu()) else None
 
+    def debug_form(self, batch_size: int) -> dict[str, int]:
+        """Which launch form this learner takes for `batch_size` (include/oprl_amd.h, oprl_learner_debug_form):
+        the decision the table in tests/golden/launch_forms.json pins."""
+        out = (C.c_int32 * 12)()
+        _capi.check(self.lib.oprl_learner_debug_form(self.handle, int(batch_size), out), "oprl_learner_debug_form")
+        keys = ("fused", "lean", "form", "updates_per_launch", "wide", "critics", "twin_split", "p2_pair", "arith",
+                "xcd_local", "shared_chip")
+        return dict(zip(keys, (int(x) for x in out)))
+
     def set_seed(self, seed: int, rank: int = 0) -> None:
         """Key the learner's device-side noise streams with the run seed (and data-parallel rank)."""
         self.learner.set_seed(seed, rank)
