@@ -16,8 +16,8 @@ __device__ __forceinline__ void load_batch(const BatchSrc& P, int row0, int B, i
                                            float* xa, float* xb, float* rS, float* dS, int* meta,
                                            int* endsS) {
   const int tid = threadIdx.x;
-  lds_zero(xa, 2 * kR * kX0Ld);   // xa and xb are adjacent
   if (P.gather) {
+    lds_zero(xa, 2 * kR * kX0Ld);   // xa and xb are adjacent
     const EndsLds ET = stage_ends(P.ends, P.n_eps, endsS, kMaxEnds, tid, kThreads);
     __syncthreads();
     if (tid < kR) {
@@ -52,10 +52,29 @@ __device__ __forceinline__ void load_batch(const BatchSrc& P, int row0, int B, i
       *dst = *src;
     }
   } else {
-    __syncthreads();
-    load_rows(xa, kX0Ld, 0, P.s, S, S, row0, B);
-    load_rows(xa, kX0Ld, S, P.a, A, A, row0, B);
-    load_rows(xb, kX0Ld, 0, P.s2, S, S, row0, B);
+    // staged rows: every element of the two padded tiles is written once, by one thread — value or zero — with no
+    // barrier in between (a __syncthreads here would wait for every load the caller has in flight: the first pass's
+    // weight fragments, which the lean passes request BEFORE they call this — r05-14)
+    // (unconditional loads — a dummy address where the element is padding — all issued before the first LDS store)
+    constexpr int kPer = (2 * kR * kX0Ld + kThreads - 1) / kThreads;
+    float v[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int idx = min(tid + j * kThreads, 2 * kR * kX0Ld - 1);
+      const int t = idx / (kR * kX0Ld), rem = idx - t * (kR * kX0Ld);     // tile 0: xa = [s | a | 0], 1: xb = [s' | 0]
+      const int row = rem / kX0Ld, col = rem - row * kX0Ld, gr = row0 + row;
+      const bool is_s = gr < B && col < S, is_a = gr < B && t == 0 && col >= S && col < S + A;
+      const float* src = P.s;
+      if (is_s) src = (t == 0 ? P.s : P.s2) + (size_t)gr * S + col;
+      if (is_a) src = P.a + (size_t)gr * A + (col - S);
+      const float x = *src;
+      v[j] = (is_s || is_a) ? x : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int idx = tid + j * kThreads;
+      if (idx < 2 * kR * kX0Ld) xa[idx] = v[j];
+    }
     if (tid < kR) {
       const int gr = row0 + tid;
       rS[tid] = gr < B ? P.r[gr] : 0.f;

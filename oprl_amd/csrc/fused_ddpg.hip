@@ -75,11 +75,12 @@ __global__ void k_xcc_probe(int* out) {
   if (threadIdx.x == 0) out[blockIdx.y * gridDim.x + blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;
 }
 
-template <int WIDTH, bool LEAN, class P, int NM = 4, class ST>
+// (`pre`: the caller's row staging, overlapped with the lean pass's fragment requests — tp4.h; generic passes: run first)
+template <int WIDTH, bool LEAN, class P, int NM = 4, class ST, class PRE = NoStamp>
 __device__ __forceinline__ void tp_fwd(const Net& net, const float* x0s, float* h1, float* h2, float* outS,
-                                       float* scr, Tp& tp, const Tp3Store& st, int row0, int B, ST sf) {
-  if constexpr (LEAN) tp4_forward<P, NM>(net, x0s, h1, h2, outS, scr, tp, st, row0, B, sf);
-  else tp3_forward<WIDTH>(net, x0s, h1, h2, outS, scr, tp, st, row0, B, sf);
+                                       float* scr, Tp& tp, const Tp3Store& st, int row0, int B, ST sf, PRE pre = PRE()) {
+  if constexpr (LEAN) tp4_forward<P, NM>(net, x0s, h1, h2, outS, scr, tp, st, row0, B, sf, BiasOv(), pre);
+  else { pre(); tp3_forward<WIDTH>(net, x0s, h1, h2, outS, scr, tp, st, row0, B, sf); }
 }
 template <int WIDTH, bool LEAN, class P, class ST>
 __device__ __forceinline__ void tp_bwd(const Net& net, const float* doutS, float* h1, float* h2, float* scr,
@@ -156,9 +157,9 @@ __device__ __forceinline__ void gauss_head(const float* outS, int row0, int B, i
   }
 }
 
-template <int WIDTH, bool LEAN, class P, class ST>
+template <int WIDTH, bool LEAN, class P, class ST, class PRE>
 __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, float* const* cX, float* const* cdY,
-                                       float* partials, bool diag, int j, float* smem, Tp& tp, ST& stamp, int slice) {
+                                       float* partials, bool diag, int j, float* smem, Tp& tp, ST& stamp, int slice, PRE& pre) {
   using LY = FusedLds<WIDTH>;
   constexpr int WL = lds_ld(WIDTH);
   constexpr int HB = kR * WL;
@@ -177,9 +178,9 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
     // ... and, the critic being scalar-output, its whole backward with unit seed as well:
     // k_dw_adam applies 2(q - y)/B per row (tp4_scalar_fb), so after y arrives only that
     // vector is left to publish
-    tp4_scalar_fb<P>(critic, xa, h1, h2, h1 + 2 * HB, outS, scr, tp, st, row0, B, 1.f, 0, 0, nullptr, stamp);
+    tp4_scalar_fb<P>(critic, xa, h1, h2, h1 + 2 * HB, outS, scr, tp, st, row0, B, 1.f, 0, 0, nullptr, stamp, nullptr, BiasOv(), QPart(), pre);
   } else {
-    tp_fwd<WIDTH, LEAN, P>(critic, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
+    tp_fwd<WIDTH, LEAN, P>(critic, xa, h1, h2, outS, scr, tp, st, row0, B, stamp, pre);
   }
   if (lead) {
     if (wt) {
@@ -369,7 +370,20 @@ __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D =
   // kernels, whose blocks sit in device memory, never carry a prefetch row)
   const BatchSrc* srcp = &A.src;
   if (pf_row) srcp = (const BatchSrc*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(DdpgArgs, next));
-  load_batch(*srcp, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
+  // the slice's rows: staged by the first pass of the role, behind that pass's weight-fragment requests (lean passes:
+  // the rows' round trip and the fragments' overlap — 1.5 us per workgroup at B = 1024, where a launch is four rounds of
+  // workgroups: r05-14); the prefetch row and the generic passes stage them here
+  bool rows_in = false;
+  auto rows = [&]() {      // (A.src by name: through a pointer the block would be copied to scratch — see above)
+    if (!rows_in) load_batch(A.src, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
+    rows_in = true;
+  };
+  if constexpr (!LEAN) {
+    load_batch(*srcp, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
+    rows_in = true;
+  } else if (pf_row) {
+    load_batch(*srcp, row0, B, S, Ad, xa, xb, rS, dS, meta, endsS);
+  }
   if (pf_row) {
     __syncthreads();
     store_rows(xa, kX0Ld, const_cast<float*>(A.next.s), S, S, row0, B);
@@ -399,7 +413,7 @@ __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D =
     if (A.do_actor) {   // (TD3: no actor step in every other update)
       // ---- role C: actor(s) forward.  Pack rows beyond S are zero, so [s | a] serves as input.
       const Tp3Store st{A.aX[1], A.aX[2], nullptr, nullptr, 0};
-      tp_fwd<WIDTH, LEAN, P>(A.actor, xa, h1, h2, outS, scr, tp, st, row0, B, stamp);
+      tp_fwd<WIDTH, LEAN, P>(A.actor, xa, h1, h2, outS, scr, tp, st, row0, B, stamp, rows);
       if constexpr (SAC) {
         // pi(s) ~ tanh-Gaussian, its log-density (temperature step, actor seed) and the raw head output
         if (lead) {
@@ -422,6 +436,7 @@ __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D =
     }
     if (!TWIN || !A.twin_split) return -1;
     // ---- ... then target critic 2 on (s', a') with role A's a'
+    if (!A.do_actor) { rows(); __syncthreads(); }
     if (tid < kR * Ad) {
       const int row = tid / Ad, col = tid - row * Ad;
       xb[row * kX0Ld + S + col] = granule_get(x_slot(role_c) + tid, x_tag, A.err, (KERN_PHASE1 << 8) | SITE_TWIN_SPLIT);
@@ -436,7 +451,7 @@ __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D =
     // ---- role A: a' = tanh(actor_target(s')) (TD3: + clipped noise), q' = critic_target(s', a')
     // (TD3: min over the twin targets), TD target                    (ddpg.py:94-95, td3.py:83-101)
     // (SAC: a' ~ pi(s') from the online actor, log pi(a'|s') kept per row     sac.py:90-97)
-    tp_fwd<WIDTH, LEAN, P, NMA>(SAC ? A.actor : A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp);
+    tp_fwd<WIDTH, LEAN, P, NMA>(SAC ? A.actor : A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp, rows);
     const bool send_a2 = TWIN && A.twin_split && lead;
     unsigned long long* x_a2 = send_a2 ? x_slot(role_c) : nullptr;
     if constexpr (SAC)
@@ -545,8 +560,8 @@ __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D =
   // critic gets its own copy of the code (a runtime-selected Net would leave the kernel-argument
   // registers: profiles/r01b_experiments.txt #10).
   if constexpr (TWIN)
-    if (role == 2) { role_b<WIDTH, LEAN, P>(A, A.critic2, A.c2X, A.c2dY, A.partials_c + (size_t)gridDim.x * 4, false, 1, smem, tp, stamp, slice); return -1; }
-  role_b<WIDTH, LEAN, P>(A, A.critic, A.cX, A.cdY, A.partials_c, true, 0, smem, tp, stamp, slice);
+    if (role == 2) { role_b<WIDTH, LEAN, P>(A, A.critic2, A.c2X, A.c2dY, A.partials_c + (size_t)gridDim.x * 4, false, 1, smem, tp, stamp, slice, rows); return -1; }
+  role_b<WIDTH, LEAN, P>(A, A.critic, A.cX, A.cdY, A.partials_c, true, 0, smem, tp, stamp, slice, rows);
   return -1;
 }
 
@@ -710,6 +725,9 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A, int bx_in = 
   if constexpr (LEAN) lds_zero(auxS, kR * kOutLd);   // the gradient tile's padding columns stay zero
   __syncthreads();
   float g_mu = 0.f, g_ls = 0.f, g_e = 0.f;   // SAC: this thread's (row, action dim) head output and draw
+  // (lean passes: the loads and LDS stores below run as the first pass's `pre` — behind its fragment requests, no
+  // barrier of their own: tp4.h)
+  auto prologue = [&]() {
   if constexpr (LEAN) {
     // every thread's loads first (one cold round trip), then its LDS stores: five helper calls in a
     // row are five load -> wait -> store sequences for the threads that take part in all of them
@@ -753,6 +771,8 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A, int bx_in = 
     load_rows4(ha1, WL, A.aX[1], WIDTH, WIDTH, row0, B);
     load_rows4(ha2, WL, A.aX[2], WIDTH, WIDTH, row0, B);
   }
+  };
+  if constexpr (!LEAN) prologue();
   stamp();
   // ---- q = critic(s, pi) with the updated critic, and its backward down to the action
   // columns: da -> auxS[:, 0:A].  The seed -1/B is a constant, so the lean path runs both
@@ -773,7 +793,7 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A, int bx_in = 
       const int xr = tid / (Ad + 1), xc = tid - xr * (Ad + 1);
       const bool xmine = tid < kR * (Ad + 1);
       if (g == 1) {
-        tp4_scalar_fb<P>(A.critic2, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp);
+        tp4_scalar_fb<P>(A.critic2, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, nullptr, BiasOv(), QPart(), prologue);
         if (lead && xmine) {
           const float v = xc < Ad ? auxS[xr * kOutLd + xc] : outS[xr * kOutLd];
           __hip_atomic_store(xq, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v),
@@ -781,7 +801,7 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A, int bx_in = 
         }
         return;
       }
-      tp4_scalar_fb<P>(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp);
+      tp4_scalar_fb<P>(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, nullptr, BiasOv(), QPart(), prologue);
       if (xmine) {
         unsigned long long x = 0;
         bool ok = false;
@@ -799,7 +819,7 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A, int bx_in = 
       q1p = outS; q1s = kOutLd;
       q2p = qxS; q2s = 1;
     } else {
-      tp4_scalar_fb<P>(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp);
+      tp4_scalar_fb<P>(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, nullptr, BiasOv(), QPart(), prologue);
       if (tid < kR) qxS[tid] = outS[tid * kOutLd];
       tp4_scalar_fb<P>(A.critic2, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, d2S, stamp);
     }
@@ -842,7 +862,7 @@ __device__ __forceinline__ void ddpg_phase2_body(const DdpgArgs& A, int bx_in = 
       qsum = A.partials_a + slice * 4 + 1;
       if (tid == 0) { A.partials_a[slice * 4 + 0] = 0.f; A.partials_a[slice * 4 + 2] = 0.f; }
     }
-    tp4_scalar_fb<P, NMC>(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum);
+    tp4_scalar_fb<P, NMC>(A.critic, xa, h1, h2, ha2 + HB, outS, scr, tp, nostore, row0, B, -A.inv_B, S, Ad, auxS, stamp, qsum, BiasOv(), QPart(), prologue);
     if constexpr (WIDE) {
       if (tp.c >= 4) return;        // the actor's backward is a cluster of four
       tp.nc = 4;

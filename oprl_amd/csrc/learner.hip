@@ -1188,6 +1188,7 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     if (h->x2 && !fa.x2) RC(fresh32_tables(h, 3, st));
     RC(next_tp_tag(&h->tp_tag, h->xbuf, h->xbuf_granules * sizeof(unsigned long long), st, &fa.cluster_tag));
     if (h->trace != nullptr && c.algo == OPRL_DDPG) fa.trace = h->trace + (size_t)3 * 64 * kTraceStamps * 2;   // slot 3
+    else if (h->trace != nullptr && h->nc == 2) fa.trace = h->trace + (size_t)6 * 64 * kTraceStamps * 2;      // twin critics: roles 0 .. 3 are phase 1's, slot 6
     fa.prefetch_next = h->prefetch_p1 ? 0 : h->prefetch_next;
     // Where phase 2's own workgroups already fill the chip (SAC at B = 1024: 4 x 64), its prefetch row is a round of
     // its own; the actor's dW launch, which follows and leaves 40 % of the chip idle, carries the row instead

@@ -265,10 +265,12 @@ __device__ __forceinline__ void tp4_store_dz1(const Tp3Store& st, int c, const f
 // wave-id branch — hipcc's wait-count pass could not tell how many younger loads follow the layer-0
 // fragments, so layer 0 waited for ALL of the pass's fragments (s_waitcnt vmcnt(1)).  With uniform,
 // unconditional requests layer 0 starts as soon as ITS fragments are in.
-template <class P = PrecF32, int NM = 4, class ST = NoStamp>
+// `pre` (optional): what the caller has to do before x0 is complete — staging the slice's rows — run AFTER the pass's
+// fragment requests are out, so that the two round trips overlap instead of following each other (r05-14)
+template <class P = PrecF32, int NM = 4, class ST = NoStamp, class PRE = NoStamp>
 __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, float* h1, float* h2,
                                             float* outS, float* scr, Tp& tp, const Tp3Store& st, int row0, int B,
-                                            ST sf = ST(), const BiasOv bo = BiasOv()) {
+                                            ST sf = ST(), const BiasOv bo = BiasOv(), PRE pre = PRE()) {
   using NS = Tp4Steps<P>;
   using SH = Tp4Shape<P, NM>;
   const float* const nb0 = bo.b0 != nullptr ? bo.b0 : net.b[0];
@@ -323,6 +325,8 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
       }
     }
   }
+  __builtin_amdgcn_sched_barrier(0);
+  pre();
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();   // x0 visible
 
@@ -538,12 +542,13 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
 //         [quarters] gather + all-reduce -> dactS            (if wanted)
 // g2: one more [kR][kWL4] LDS buffer.  tp.stage advances by 1 (2 with dact).
 // ---------------------------------------------------------------------------------------
-template <class P = PrecF32, int NM = 4, class ST = NoStamp>
+template <class P = PrecF32, int NM = 4, class ST = NoStamp, class PRE = NoStamp>
 __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, float* h1, float* h2,
                                               float* g2, float* outS, float* scr, Tp& tp,
                                               const Tp3Store& st, int row0, int B, float seed,
                                               int dact_col0, int dact_cols, float* dactS, ST sf = ST(),
-                                              float* q_sum_out = nullptr, const BiasOv bo = BiasOv(), const QPart qp = QPart()) {
+                                              float* q_sum_out = nullptr, const BiasOv bo = BiasOv(), const QPart qp = QPart(),
+                                              PRE pre = PRE()) {
   const float* const nb0 = bo.b0 != nullptr ? bo.b0 : net.b[0];
   const float* const nb1 = bo.b1 != nullptr ? bo.b1 : net.b[1];
   const float* const nb2 = bo.b2 != nullptr ? bo.b2 : net.b[2];
@@ -599,6 +604,8 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
     P::template ldfn<SH::M>(w2, p2);
     if (i == 0 || NM == 8) bias2 = P::ldb(nb2);
   }
+  __builtin_amdgcn_sched_barrier(0);
+  pre();             // (as in tp4_forward)
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();   // x0 visible
 
