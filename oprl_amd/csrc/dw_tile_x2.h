@@ -278,6 +278,7 @@ struct DwX2Tile {
     if (!ok) report_expired(G.err, G.err_code);
   }
   f32x4 u = z4;          // GATE 1: the unit-seed dY of this lane
+  unsigned long long seed0 = 0ull;
   if (gate == 1) {
     __syncthreads();     // role B's members have flagged their rows (written through): X and the unit-seed dY
     // The write-through rows are read past this XCD's L2 (sc1) with raw buffer loads (engine.h ld4_agent: loads the
@@ -300,6 +301,11 @@ struct DwX2Tile {
     vx[0][1] = (c0 && xb0 + 1 < hB) ? r01 : z4;
     vx[1][0] = (c1 && xb0 < hB) ? r10 : z4;
     vx[1][1] = (c1 && xb0 + 1 < hB) ? r11 : z4;
+    // (a first look at this lane's seed, requested WITH the rows: a tile that starts late — on a workgroup whose role ended
+    // late — finds its seeds published already, and the look costs it no round trip of its own behind the staging; the
+    // granule is its own flag: r05-18)
+    if (bb < hB && G.n_seed > 0)
+      seed0 = __hip_atomic_load((item >= G.item_split ? G.seed2 : G.seed) + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u = ((pa0 + (npart > 1 ? pa1 : z4)) + (npart > 2 ? pa2 : z4)) + (npart > 3 ? pa3 : z4);   // member order, as k_dw_adam sums them
     if (late) u = f32x4{ncol == 0 ? 1.f : 0.f, 0.f, 0.f, 0.f};
     if (!(bb < hB && (an_ok || late))) u = z4;
@@ -340,8 +346,8 @@ struct DwX2Tile {
   if (gate == 1) {
     float sd = 0.f;
     if (bb < hB && G.n_seed > 0) {
-      unsigned long long x = 0;
-      bool ok = G.what_if == 104;
+      unsigned long long x = seed0;
+      bool ok = G.what_if == 104 || (G.spin > 0 && (unsigned)(x >> 32) == gtag);
       for (int spin = 0; spin < G.spin && !ok; ++spin) {
         x = __hip_atomic_load((item >= G.item_split ? G.seed2 : G.seed) + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = (unsigned)(x >> 32) == gtag;
