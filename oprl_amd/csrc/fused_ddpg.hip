@@ -1366,6 +1366,15 @@ __device__ __forceinline__ void chain_wait2(const unsigned long long* f0, int n0
 }
 
 constexpr size_t kChainCOffset = (kWholeDaOffset + sizeof(DwKArgs4) + alignof(ChainArgs) - 1) / alignof(ChainArgs) * alignof(ChainArgs);
+// which role row (A 0..7 | B 8..11 | C 12..15 | T 16..) the physical grid row y of an update is: the roles' DISPATCH
+// order is a parameter of the launch (ChainArgs::order), everything else speaks of the logical row
+__device__ __forceinline__ int chain_row(int y, int order) {
+  if (y >= 16 || order == 0) return y;
+  if (order == 1) return y < 4 ? y + 8 : (y < 12 ? y - 4 : y);          // B | A | C
+  if (order == 2) return y < 8 ? y + 8 : y - 8;                         // B | C | A
+  return y < 8 ? y : (y < 12 ? y + 4 : y - 4);                          // A | C | B
+}
+
 template <class P>
 __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const DwKArgs4 Dc, const DwKArgs4 Da, const ChainArgs C_) {
   static_assert(kDwTileX2, "the chain launch runs the 16 x 64 tiles of dw_tile_x2.h");
@@ -1380,7 +1389,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   constexpr int HB = kR * kWL4;
   const int slices = (int)gridDim.x, slice = (int)blockIdx.x;
   const int R = C.rows;                      // grid rows per update: A 8 | B 4 | C 4 | T (tile-only rows: small batches)
-  const int u = (int)blockIdx.y / R, yy = (int)blockIdx.y - u * R;
+  const int u = (int)blockIdx.y / R, yy = chain_row((int)blockIdx.y - u * R, C.order);
   const int B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x, row0 = slice * kR;
   const unsigned ep = A.epoch + (unsigned)u;
   const unsigned tag1 = A.cluster_tag + 2u * (unsigned)u, tag2 = tag1 + 1u;
@@ -1534,7 +1543,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
     const int u2 = by2 / C.rows;
     const PassCtx cx{A.epoch + (unsigned)u2, A.cluster_tag + 2u * (unsigned)u2 + 1u, C.w3buf[u2 & 1], {C.b16[2][0], C.b16[2][1], C.b16[2][2]},
                      (kTraceOn && u2 == C.trace_u) ? A.trace2 : nullptr, A.actor_pb1_f32};
-    (void)ddpg_phase2m_body<P, DwKArgs4, false, true>(A, Dap, by2 - u2 * C.rows, cx);      // (GE: its pass runs on Coh<P>)
+    (void)ddpg_phase2m_body<P, DwKArgs4, false, true>(A, Dap, chain_row(by2 - u2 * C.rows, C.order), cx);      // (GE: its pass runs on Coh<P>)
     return;
   }
 
@@ -1591,7 +1600,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   int by2 = (int)blockIdx.y, bx2 = (int)blockIdx.x, nx2 = (int)gridDim.x;
   asm volatile("" : "+s"(by2), "+s"(bx2), "+s"(nx2));
   // (index among the tile workgroups: role B slice-major, role C behind it, then T's rows)
-  const int u2 = by2 / C.rows, y2 = by2 - u2 * C.rows;
+  const int u2 = by2 / C.rows, y2 = chain_row(by2 - u2 * C.rows, C.order);
   const int wg2 = y2 < 16 ? ((y2 >= 12) ? 4 * nx2 : 0) + bx2 * 4 + ((y2 - 8) & 3) : 8 * nx2 + (y2 - 16) * nx2 + bx2;
   const int n_bc = 8 * nx2;
   const unsigned ep2 = A.epoch + (unsigned)u2;
@@ -1627,7 +1636,7 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   {
     int by3 = (int)blockIdx.y, bx3 = (int)blockIdx.x, nx3 = (int)gridDim.x;
     asm volatile("" : "+s"(by3), "+s"(bx3), "+s"(nx3));
-    const int u3 = by3 / C.rows, y3 = by3 - u3 * C.rows;
+    const int u3 = by3 / C.rows, y3 = chain_row(by3 - u3 * C.rows, C.order);
     const int wg3 = y3 < 16 ? ((y3 >= 12) ? 4 * nx3 : 0) + bx3 * 4 + ((y3 - 8) & 3) : 8 * nx3 + (y3 - 16) * nx3 + bx3;
     const int tile = wg3 < Dap->tile_end[kDwFusedItems - 1] ? wg3 : -1;
     if (tile >= 0) {

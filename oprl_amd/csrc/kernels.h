@@ -423,6 +423,7 @@ struct ChainArgs {
   int pf_last;                         // 1: the last update stages the next rows as well (another launch follows)
   int trace_u;                         // trace build: the update whose stages are stamped
   int rows;                            // grid rows per update: 16 (roles A 8 | B 4 | C 4) + the tile-only rows of small batches
+  int order;                           // dispatch order of an update's role rows: 0 A | B | C, 1 B | A | C, 2 B | C | A, 3 A | C | B (fused_ddpg.hip chain_row)
   float c_step[kChainMax], c_bc2[kChainMax];   // Adam's lr / (1 - b1^t) and sqrt(1 - b2^t) of the critic's step, per update
   float a_step[kChainMax], a_bc2[kChainMax];   // ... of the actor's
   const float* set0[5];                // staging rows s, a, r, d, s2: update u reads set (u & 1), its prefetch fills the other

@@ -940,6 +940,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
         ca.pf_last = h->chain_pf_last ? 1 : 0;
         ca.trace_u = U - 1;
         ca.rows = 16 + t_rows;
+        { static const int order = [] { const char* e = getenv("OPRL_AMD_CHAIN_ORDER"); return e != nullptr ? atoi(e) & 3 : 0; }(); ca.order = order; }
         ca.c_step[0] = kc.ad.step_size_host; ca.c_bc2[0] = kc.ad.bc2_sqrt_host;
         ca.a_step[0] = ka.ad.step_size_host; ca.a_bc2[0] = ka.ad.bc2_sqrt_host;
         for (int u = 1; u < U; ++u) {          // (the optimisers' step counts advance once per update and net, as dw_build does;
