@@ -508,15 +508,13 @@ __device__ __forceinline__ void dw_adam_body(const KAT& A, float* lds, int bx) {
     if (I.w_g != nullptr && !h_apply) I.w_g[eo] = g;
     if (ad.do_adam) {
       float mm = p_m, vv = p_v, th = p_th;
-      mm = mm + (g - mm) * ad.omb1;
-      vv = vv * ad.beta2 + ad.omb2 * g * g;
-      th = th - step_size * (mm / (sqrtf(vv) / bc2_sqrt + ad.eps));
+      adam_elem(g, mm, vv, th, ad, step_size, bc2_sqrt);
       I.w_m[eo] = mm;
       I.w_v[eo] = vv;
       I.w[eo] = th;
       th_new = th;
       if (polyak) {
-        tt_new = p_tt * ad.omtau + ad.tau * th;
+        tt_new = polyak_elem(p_tt, th, ad);
         I.w_t[eo] = tt_new;
       }
     }
@@ -547,14 +545,11 @@ __device__ __forceinline__ void dw_adam_body(const KAT& A, float* lds, int bx) {
     if (I.b_g != nullptr && !h_apply) I.b_g[n] = gb;
     if (ad.do_adam) {
       float mm = q_m, vv = q_v, th = q_th;
-      mm = mm + (gb - mm) * ad.omb1;
-      vv = vv * ad.beta2 + ad.omb2 * gb * gb;
-      const float denom = sqrtf(vv) / bc2_sqrt + ad.eps;
-      th = th - step_size * (mm / denom);
+      adam_elem(gb, mm, vv, th, ad, step_size, bc2_sqrt);
       I.b_m[n] = mm;
       I.b_v[n] = vv;
       I.b[n] = th;
-      if (b_pol) I.b_t[n] = q_tt * ad.omtau + ad.tau * th;
+      if (b_pol) I.b_t[n] = polyak_elem(q_tt, th, ad);
     }
   }
   stamp();   // stores issued

@@ -546,11 +546,9 @@ struct DwX2Tile {
   float th_new = 0.f, tt_new = 0.f;
   if (e_ok) {
     float mm = p_m, vv = p_v, th = p_th;
-    mm = mm + (gsum - mm) * ad.omb1;
-    vv = vv * ad.beta2 + ad.omb2 * gsum * gsum;
-    th = th - step_size * (mm / (sqrtf(vv) / bc2_sqrt + ad.eps));
+    adam_elem(gsum, mm, vv, th, ad, step_size, bc2_sqrt);
     th_new = th;
-    if (polyak) tt_new = p_tt * ad.omtau + ad.tau * th;
+    if (polyak) tt_new = polyak_elem(p_tt, th, ad);
     e_m = mm; e_v = vv;
     if (!flagged) {
       st_ag(I.w_m + eo, mm);
@@ -571,15 +569,13 @@ struct DwX2Tile {
     if (xchg_on) gb = gb_x;          // (the all-reduced bias sums)
     gb *= ad.grad_scale;
     float mm = q_m, vv = q_v, th = q_th;
-    mm = mm + (gb - mm) * ad.omb1;
-    vv = vv * ad.beta2 + ad.omb2 * gb * gb;
-    th = th - step_size * (mm / (sqrtf(vv) / bc2_sqrt + ad.eps));
+    adam_elem(gb, mm, vv, th, ad, step_size, bc2_sqrt);
     if (I.b16 != nullptr) st_ag(I.b16 + n, th);      // (uncached copy for readers inside the same launch)
     st_ag(I.b_m + n, mm);
     st_ag(I.b_v + n, vv);
     st_ag(I.b + n, th);
     if (b_pol) {
-      const float tb = q_tt * ad.omtau + ad.tau * th;
+      const float tb = polyak_elem(q_tt, th, ad);
       st_ag(I.b_t + n, tb);
       if (I.bt16 != nullptr) st_ag(I.bt16 + n, tb);
     }

@@ -182,9 +182,9 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, 
       f32x4 mm, vv, th;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        mm[t] = p_m[h][t] + (g[t] - p_m[h][t]) * A.ad.omb1;
-        vv[t] = p_v[h][t] * A.ad.beta2 + A.ad.omb2 * g[t] * g[t];
-        th[t] = p_th[h][t] - step_size * (mm[t] / (sqrtf(vv[t]) / bc2_sqrt + A.ad.eps));
+        float me = p_m[h][t], ve = p_v[h][t], te = p_th[h][t];
+        adam_elem(g[t], me, ve, te, A.ad, step_size, bc2_sqrt);
+        mm[t] = me; vv[t] = ve; th[t] = te;
       }
       *reinterpret_cast<f32x4*>(I.w_m + eo + 4 * h) = mm;
       *reinterpret_cast<f32x4*>(I.w_v + eo + 4 * h) = vv;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, 
       th_new[h] = th;
       if (polyak) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) tt_new[h][t] = p_tt[h][t] * A.ad.omtau + A.ad.tau * th[t];
+        for (int t = 0; t < 4; ++t) tt_new[h][t] = polyak_elem(p_tt[h][t], th[t], A.ad);
         *reinterpret_cast<f32x4*>(I.w_t + eo + 4 * h) = tt_new[h];
       }
     }

@@ -135,6 +135,18 @@ struct AdamScalars {
 //   m += (g-m)(1-b1);  v = b2 v + (1-b2) g g;  th -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps)
 //   th_t = (1-tau) th_t + tau th                       (nn_functions.py:5-10)
 // returns bit0: theta written (*th_new), bit1: target written (*tt_new)
+// One element's Adam step and Polyak step with every rounding spelled out: `a * b + c` left to the compiler is fused into an
+// fma one way in one instantiation of an epilogue and another way in the next (v beta2 + (1 - beta2) g g has two mul-adds to
+// choose from) — the same dW tile came out one ulp apart from two kernels that inline the same epilogue (r05-21).  Every
+// epilogue calls these.
+__device__ __forceinline__ void adam_elem(float g, float& m, float& v, float& th, const AdamScalars& ad, float step_size, float bc2_sqrt) {
+  m = __builtin_fmaf(g - m, ad.omb1, m);
+  v = __builtin_fmaf(v, ad.beta2, (ad.omb2 * g) * g);
+  const float denom = sqrtf(v) / bc2_sqrt + ad.eps;
+  th = __builtin_fmaf(-step_size, m / denom, th);
+}
+__device__ __forceinline__ float polyak_elem(float tt, float th, const AdamScalars& ad) { return __builtin_fmaf(tt, ad.omtau, ad.tau * th); }
+
 __device__ __forceinline__ int adam_polyak_elem(float g, float* th, float* m, float* v, float* tt,
                                                 float* gout, const AdamScalars& ad,
                                                 float step_size, float bc2_sqrt, float* th_new,
@@ -143,16 +155,13 @@ __device__ __forceinline__ int adam_polyak_elem(float g, float* th, float* m, fl
   if (gout != nullptr) *gout = g;
   if (!ad.do_adam) return 0;
   float mm = *m, vv = *v, t = *th;
-  mm = mm + (g - mm) * ad.omb1;
-  vv = vv * ad.beta2 + ad.omb2 * g * g;
-  const float denom = sqrtf(vv) / bc2_sqrt + ad.eps;
-  t = t - step_size * (mm / denom);
+  adam_elem(g, mm, vv, t, ad, step_size, bc2_sqrt);
   *m = mm;
   *v = vv;
   *th = t;
   *th_new = t;
   if (ad.do_polyak && tt != nullptr) {
-    const float u = *tt * ad.omtau + ad.tau * t;
+    const float u = polyak_elem(*tt, t, ad);
     *tt = u;
     *tt_new = u;
     return 3;

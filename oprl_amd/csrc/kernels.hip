@@ -144,7 +144,7 @@ __global__ void k_adam_flat(float* th, float* m, float* v, float* tt, const floa
 __global__ void k_polyak_flat(float* tt, const float* th, long n, float tau, float omtau) {
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
        idx += (long)gridDim.x * blockDim.x)
-    tt[idx] = tt[idx] * omtau + tau * th[idx];
+    tt[idx] = __builtin_fmaf(tt[idx], omtau, tau * th[idx]);      // (polyak_elem's roundings, kernels.h)
 }
 
 __global__ void k_alpha_step(double* log_alpha, double* m, double* v, const float* logp, int B,
