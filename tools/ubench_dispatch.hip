@@ -8,11 +8,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-__global__ __launch_bounds__(1024) void k(long long* out, int n_long, long long ticks_long, long long ticks_short) {
+__global__ __launch_bounds__(1024) void k(long long* out, int n_long, long long ticks_long, long long ticks_short, int half_exit) {
   extern __shared__ float lds[];
   const long long t0 = wall_clock64();
   const int id = blockIdx.y * gridDim.x + blockIdx.x;
   const long long want = id < n_long ? ticks_long : ticks_short;
+  if (half_exit) {      // (the riding tiles' shape: a padded block of long workgroups — the padding exits at once — whose upper eight waves return)
+    const int slots = (n_long + 63) / 64 * 64;
+    if (id >= n_long && id < slots) return;
+    if (id < n_long && threadIdx.x >= 512) return;
+  }
   if (threadIdx.x == 0) lds[0] = 1.f;
   while (wall_clock64() - t0 < want) __builtin_amdgcn_s_sleep(8);
   if (threadIdx.x == 0) {
@@ -26,19 +31,20 @@ int main(int argc, char** argv) {
   const int n_long = argc > 1 ? atoi(argv[1]) : 109;
   const double t_long = argc > 2 ? atof(argv[2]) : 11.0, t_short = argc > 3 ? atof(argv[3]) : 8.4;
   const int n = argc > 4 ? atoi(argv[4]) : 640;
+  const int half_exit = argc > 5 ? atoi(argv[5]) : 0;
   long long* d;
   hipMalloc(&d, n * 4 * sizeof(long long));
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 133 * 1024);
   std::vector<long long> h(n * 4);
   for (int rep = 0; rep < 3; ++rep) {
     hipMemset(d, 0, n * 4 * sizeof(long long));
-    hipLaunchKernelGGL(k, dim3(64, n / 64), dim3(1024), 133 * 1024, 0, d, n_long, (long long)(t_long * 100), (long long)(t_short * 100));
+    hipLaunchKernelGGL(k, dim3(64, n / 64), dim3(1024), 133 * 1024, 0, d, n_long, (long long)(t_long * 100), (long long)(t_short * 100), half_exit);
     hipDeviceSynchronize();
   }
   hipMemcpy(h.data(), d, n * 4 * sizeof(long long), hipMemcpyDeviceToHost);
   long long t00 = h[0];
   for (int i = 0; i < n; ++i) t00 = std::min(t00, h[i * 4]);
-  printf("n_long %d (%.1f us) then %d short (%.1f us), 64 x %d grid\n", n_long, t_long, n - n_long, t_short, n / 64);
+  printf("n_long %d (%.1f us) then %d short (%.1f us), 64 x %d grid, half_exit %d\n", n_long, t_long, n - n_long, t_short, n / 64, half_exit);
   for (int lo = 0; lo < n; lo += 64) {
     std::vector<double> s;
     for (int i = lo; i < lo + 64 && i < n; ++i) s.push_back((h[i * 4] - t00) / 100.0);
