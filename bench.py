@@ -144,6 +144,8 @@ PEAK_HBM_TBS = 8.0
 # name -> (class name, S, A, B, constructor extras, algorithmic GFLOP / update, state MB / update): BASELINE.md section 4
 BASELINE_CONFIGS = {
     "DDPG walker-walk B=256": ("DDPG", 24, 6, 256, {}, 0.365, 4.73),
+    # (the batch configs/ddpg.py really trains at: BaseTrainer.batch_size = 128, trainers/base_trainer.py:28)
+    "DDPG walker-walk B=128 (the reference scripts' batch)": ("DDPG", 24, 6, 128, {}, 0.1825, 4.73),
     "TD3 cheetah-run B=256": ("TD3", 17, 6, 256, {"log_every": 10 ** 9}, 0.413, 5.19),
     "SAC humanoid-walk B=1024": ("SAC", 67, 21, 1024, {"log_every": 10 ** 9}, 2.74, 7.94),
     "TQC walker-walk B=256 5x25": ("TQC", 24, 6, 256, {"log_every": 10 ** 9}, 8.57, 90.4),
@@ -446,13 +448,13 @@ def dp_single_rank(dev, local_rank, replay, precision, steps):
 METRIC = "learner gradient steps/sec, DDPG batch=256 walker-walk"
 
 
-FALLBACK = {}      # what a later failure may still report: the RCCL probe of a multi-GPU run (measure() fills it)
+FALLBACK = {}      # what a later failure may still report: the RCCL measurement of a multi-GPU run, taken with the run's own K / W before anything else is tried (measure() fills it)
 
 
 def failure_line(args, world, why):
-    """The one JSON line of a run that could not finish: same keys, value null, the reason — or, when the RCCL probe of a
-    data-parallel run had already produced its number and a LATER phase (a peer-window probe, the rebuild) failed, that
-    probe's rate as `value` (its own step count; `fallback` says so)."""
+    """The one JSON line of a run that could not finish: same keys, value null, the reason — or, when the RCCL exchange of a
+    data-parallel run had already been measured (the run's own W warm-up + K timed updates) and a LATER phase (a
+    peer-window probe, the rebuild) failed, that measurement as `value` (`fallback` says so; the exit code is non-zero)."""
     fb = dict(FALLBACK)
     return json.dumps({"metric": METRIC, "value": fb.get("value"), "unit": "steps/s", "n_gpus": world,
                        "steps": fb.get("steps", args.steps), "warmup": fb.get("warmup", args.warmup),
@@ -699,12 +701,23 @@ def measure(args, wd):
                 ok = dp.healthy()
                 if ok:
                     probes[level] = best / n_probe * 1e6
-                    if level == 0 and rank == 0:
-                        FALLBACK.update(value=round(world * n_probe / best, 1), steps=n_probe, warmup=300,
-                                        ms_per_step=round(best / n_probe * 1e3, 5),
-                                        data_parallel_check={"exchange": "rccl", "probe_us_per_step": {"rccl": round(probes[0], 2)}},
-                                        note=f"the RCCL probe's rate ({n_probe} updates, barrier-bracketed, max over ranks): a later "
-                                             "phase of the run failed (see `error`)")
+                    if level == 0:
+                        # ... and the contract's own protocol on RCCL at once — W warm-up updates, K timed ones between
+                        # barriers, the max over ranks: what a LATER failure (a peer-window probe, the rebuild) still reports
+                        # is this measurement, same K and W as asked for, not a probe of another length
+                        dp.step_n(replay.handle, W, B, seed=0)
+                        barrier()
+                        tf0 = time.perf_counter()
+                        dp.step_n(replay.handle, K, B, seed=0)
+                        barrier()
+                        dtf = all_max(time.perf_counter() - tf0)
+                        if dp.healthy() and rank == 0:
+                            FALLBACK.update(value=round(world * K / dtf, 1), steps=K, warmup=W, ms_per_step=round(dtf / K * 1e3, 5),
+                                            data_parallel_check={"exchange": "rccl", "replicas_identical": True, "finite": True,
+                                                                 "probe_us_per_step": {"rccl": round(probes[0], 2)}},
+                                            note=f"measured over RCCL with this run's own protocol ({W} warm-up + {K} timed updates, "
+                                                 "barrier-bracketed, max over ranks) before the peer-window exchanges were probed: a "
+                                                 "later phase of the run failed (see `error`)")
             if not ok and rank == 0:
                 print(f"bench.py: exchange level {level} unusable on this node", file=sys.stderr)
             del dp, algo
@@ -739,7 +752,9 @@ def measure(args, wd):
         finite = bool(t.isfinite(algo.actor._oprl_arena).all() and t.isfinite(algo.critic._oprl_arena).all())
         dp_check = {"replicas_identical": bool(float(spread.abs().max()) == 0.0), "finite": finite,
                     "exchange": {2: "p2p-inline", 1: "p2p", 0: "rccl"}[p2p_level],
-                    "probe_us_per_step": {({2: "p2p-inline", 1: "p2p", 0: "rccl"}[k]): round(v, 2) for k, v in probes.items()}}
+                    "probe_us_per_step": {({2: "p2p-inline", 1: "p2p", 0: "rccl"}[k]): round(v, 2) for k, v in probes.items()},
+                    # (the launch form of a rank whose exchange runs inside the dW tiles: 4 = the single-GPU whole-update launch)
+                    "inline_form": learner.debug_form(B)["dp_inline_form"]}
 
     out = None
     if rank == 0:

@@ -66,13 +66,8 @@ class OffPolicyAlgorithm(ABC):
         return mlp if (mlp is not None and hasattr(mlp, "set_pending") and mlp.on_gpu()) else None
 
     def debug_form(self, batch_size: int) -> dict[str, int]:
-        """Which launch form this learner takes for `batch_size` (include/oprl_amd.h, oprl_learner_debug_form):
-        the decision the table in tests/golden/launch_forms.json pins."""
-        out = (C.c_int32 * 12)()
-        _capi.check(self.lib.oprl_learner_debug_form(self.handle, int(batch_size), out), "oprl_learner_debug_form")
-        keys = ("fused", "lean", "form", "updates_per_launch", "wide", "critics", "twin_split", "p2_pair", "arith",
-                "xcd_local", "shared_chip")
-        return dict(zip(keys, (int(x) for x in out)))
+        """Which launch form this algorithm's learner takes for `batch_size` (HipLearner.debug_form)."""
+        return self.learner.debug_form(batch_size)
 
     def set_seed(self, seed: int, rank: int = 0) -> None:
         """Key the learner's device-side noise streams with the run seed (and data-parallel rank)."""
@@ -356,6 +351,16 @@ class HipLearner:
 
     def clear_error(self) -> None:
         _capi.check(self.lib.oprl_learner_clear_error(self.handle), "oprl_learner_clear_error")
+
+    DEBUG_FORM_FIELDS = ("fused", "lean", "form", "updates_per_chain_launch", "wide", "nc", "twin_split", "p2_pair", "arith",
+                         "xcd_local", "shared_chip", "dp_inline_form")
+
+    def debug_form(self, batch_size: int) -> dict[str, int]:
+        """Which launch form this learner takes for `batch_size` (include/oprl_amd.h, oprl_learner_debug_form): the
+        decision tests/golden/launch_forms.json pins, under that table's field names."""
+        out = (C.c_int32 * 12)()
+        _capi.check(self.lib.oprl_learner_debug_form(self.handle, int(batch_size), out), "oprl_learner_debug_form")
+        return dict(zip(self.DEBUG_FORM_FIELDS, (int(x) for x in out)))
 
     def set_cluster(self, nc: int) -> None:
         """CUs per 16-row slice in the fused kernels (include/oprl_amd.h): 8 = the default (clusters of four, of

@@ -681,26 +681,29 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   // on phase 1 — whose role A then stays on a cluster of four: 64 CUs must be free for tile workgroups from the start
   // (a gradient-exporting learner — data parallel over RCCL — merges only with the PrecX2 tiles, which know how to leave
   // dW in the gradient arena instead of running Adam: four launches per data-parallel update instead of six)
-  const bool xport_ok = !h->cfg.export_grads || (a.x2 && fused_x2_tiles());
-  // (dp_inline: the gradient exchange inside the dW tiles — the 16 x 32 tiles of k_dw_adam<true> as launches of their own,
-  // or, PrecX2 learners, the 16 x 64 tiles of the merged / whole-update launches themselves: dw_tile_x2.h)
-  const bool inline_x2 = h->dp_inline && a.x2 && fused_x2_tiles() && h->nc == 1;
   // exact-fp32 learners with mirrored packs: the whole update as k_ddpg_chain<PrecF32> when that form is possible at all
   // (there is no merged phase 2 with the fp32 tiles on its own: with the whole form out of reach the two bits below stay
   // what they were — merged phase 1 with role A on four, phase 2 and the actor's dW as launches)
+  // (a gradient-exporting learner takes the whole form only when its tiles exchange the gradients themselves: dp_inline)
+  const bool dp_whole_ok = !h->cfg.export_grads || h->dp_inline;
   const bool whole_f32 = h->fchain && fused_x2_tiles() && !a.x2 && !a.bf16 && !h->no_whole && !h->no_merge && !h->no_merge2 && !h->shared_chip &&
-                         !h->dp_inline && B <= 256 && fused_ddpg_is_lean(a) && (a.wide & 3) == 3 && h->chain_flags != nullptr &&
+                         dp_whole_ok && B <= 256 && fused_ddpg_is_lean(a) && (a.wide & 3) == 3 && h->chain_flags != nullptr && h->du_granules != nullptr &&
                          chain_rows(h, B) * ((B + kR - 1) / kR) <= h->n_cus;
+  // ... and bf16 learners (k_ddpg_chain<PrecBF16>: learner_internal.h bchain)
+  const bool whole_bf16 = h->bchain && fused_x2_tiles() && a.bf16 && !h->no_whole && !h->no_merge && !h->no_merge2 && !h->shared_chip &&
+                          dp_whole_ok && B <= 256 && fused_ddpg_is_lean(a) && (a.wide & 3) == 3 && h->chain_flags != nullptr && h->du_granules != nullptr &&
+                          chain_rows(h, B) * ((B + kR - 1) / kR) <= h->n_cus;
+  // (dp_inline: the gradient exchange inside the dW tiles — the 16 x 32 tiles of k_dw_adam<true> as launches of their own,
+  // or the 16 x 64 tiles of the merged / whole-update launches themselves: dw_tile_x2.h — PrecX2 learners in both forms,
+  // exact-fp32 and bf16 learners in the whole-update form, round 6)
+  const bool inline_tiles = h->dp_inline && fused_x2_tiles() && h->nc == 1 && (a.x2 || whole_f32 || whole_bf16);
+  const bool xport_ok = !h->cfg.export_grads || (a.x2 && fused_x2_tiles()) || inline_tiles;
   // (TD3: both critics' tiles ride — roles A | B1 | B2 | C are the whole chip at B = 256, the 2 x 84 / 2 x 152 tiles take the
   // compute units the roles leave; this rank's own Adam step only)
   const bool merge_twin = h->nc == 2 && c.algo == OPRL_TD3 && !h->cfg.export_grads && !h->dp_inline && !h->no_merge_twin;
-  // ... and bf16 learners (k_ddpg_chain<PrecBF16>: learner_internal.h bchain)
-  const bool whole_bf16 = h->bchain && fused_x2_tiles() && a.bf16 && !h->no_whole && !h->no_merge && !h->no_merge2 && !h->shared_chip &&
-                          !h->dp_inline && B <= 256 && fused_ddpg_is_lean(a) && (a.wide & 3) == 3 && h->chain_flags != nullptr &&
-                          chain_rows(h, B) * ((B + kR - 1) / kR) <= h->n_cus;
   if (h->bchain && !whole_bf16) a.wide = 0;      // (outside the whole form a bf16 learner's passes stay on clusters of four, as before)
   if (whole_bf16) a.actor_pb1_f32 = net_view(c.actor, false).pb[1];
-  if (!h->no_merge && !h->shared_chip && (h->nc == 1 || merge_twin) && !a.sac && B <= 256 && xport_ok && (!h->dp_inline || inline_x2) && fused_ddpg_is_lean(a)) {
+  if (!h->no_merge && !h->shared_chip && (h->nc == 1 || merge_twin) && !a.sac && B <= 256 && xport_ok && (!h->dp_inline || inline_tiles) && fused_ddpg_is_lean(a)) {
     a.merged |= 1;
     if (!(a.x2 && fused_x2_tiles()) && !whole_f32 && !whole_bf16) a.wide &= ~1;     // (the 84 16 x 64 tiles of a PrecX2 learner get along with role A on eight)
   }
@@ -708,7 +711,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   // du, the first layer's comes from one more backward step of the critic pass's members (csrc/fused_ddpg.hip).
   // PrecX2 learners only, the pass on clusters of eight: with the exact-fp32 tiles the merged form measured no faster
   // than the two launches (34.9 vs 34.7 us)
-  if (!h->no_merge2 && !h->shared_chip && ((a.x2 && fused_x2_tiles()) || whole_f32 || whole_bf16) && h->du_granules != nullptr && !a.sac && B <= 256 && (!h->dp_inline || inline_x2) &&
+  if (!h->no_merge2 && !h->shared_chip && ((a.x2 && fused_x2_tiles()) || whole_f32 || whole_bf16) && h->du_granules != nullptr && !a.sac && B <= 256 && (!h->dp_inline || inline_tiles) &&
       fused_ddpg_is_lean(a) && c.actor.theta_target != nullptr && (a.wide & 2) != 0) {
     a.merged |= 2;
     a.du_granules = h->du_granules;
@@ -717,7 +720,7 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
   }
   // the whole update as ONE launch (k_ddpg_update): both merged forms, role A and the critic pass on eight, the 16 x 64
   // tiles, and everything the roles hand to each other in uncached memory
-  if (!h->no_whole && (!h->cfg.export_grads || inline_x2) && ((a.x2 && fused_x2_tiles()) || whole_f32 || whole_bf16) && h->nc == 1 && (a.merged & 3) == 3 && (a.wide & 3) == 3 && h->uc_pool &&
+  if (!h->no_whole && (!h->cfg.export_grads || inline_tiles) && ((a.x2 && fused_x2_tiles()) || whole_f32 || whole_bf16) && h->nc == 1 && (a.merged & 3) == 3 && (a.wide & 3) == 3 && h->uc_pool &&
       (h->uc_base != nullptr || h->bchain) && h->w_flags != nullptr && h->chain_flags != nullptr &&
       chain_rows(h, B) * ((B + kR - 1) / kR) <= h->n_cus) {      // (one update's workgroups wait for each other: all must fit the chip)
     a.whole = 1;
@@ -730,6 +733,9 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
     a.wide &= ~1;
     a.du_granules = nullptr; a.g1_granules = nullptr; a.w3_snap = nullptr;
   }
+  // (an exchanging rank outside PrecX2 has the in-tile exchange in the whole-update form only: whatever kept that form
+  // away, its merged phase launch — 16 x 32 tiles that exchange nothing — must not run either)
+  if (h->dp_inline && !a.x2 && !a.whole) a.merged = 0;
   return a;
 }
 
@@ -1463,6 +1469,12 @@ extern "C" int oprl_debug_noise(oprl_learner* h, int32_t stream_id, uint64_t cou
 
 extern "C" int oprl_learner_debug_expire(oprl_learner* h, int32_t site) {
   if (!h || site < 0 || (site > 8 && (site < 101 || site > 106 || site == 103))) { set_err("oprl_learner_debug_expire: invalid argument"); return OPRL_ERR_INVALID; }
+  // (101 .. 106 are TIMING experiments — a cross-workgroup wait counts as satisfied, the update computes wrong parameters and
+  // reports nothing: refused unless the process opted in, tools/what_if.py sets the variable)
+  if (site > 8) {
+    const char* e = getenv("OPRL_AMD_WHAT_IF");
+    if (e == nullptr || atoi(e) == 0) { set_err("oprl_learner_debug_expire: sites 101..106 are timing experiments that corrupt the update; set OPRL_AMD_WHAT_IF=1 to allow them"); return OPRL_ERR_STATE; }
+  }
   h->debug_expire = site;
   h->lw_pairs.spin = site == 8 ? 0 : (1 << 20);      // (8: the hand-over inside k_lw_mid_pair)
   return OPRL_OK;
@@ -1533,6 +1545,7 @@ extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, double grad_sc
     dw.B = 0; dw.n_part = 1; dw.trace = nullptr; dw.use_row_scale = 0; dw.apply_only = 1;
     dw.ad = adam_scalars(h, c.hp.lr_critic, h->opt_step_critic, polyak, (float)grad_scale);
     dw.ad.do_adam = 1;
+    if (h->fchain) h->stale32[0] = true;      // (the launch writes the mirrors: the caller's packs fall behind)
     HIPC(launch_dw_prof(dw, st));
     return OPRL_OK;
   }
@@ -1545,6 +1558,7 @@ extern "C" int oprl_learner_apply(oprl_learner* h, int32_t phase, double grad_sc
     dw.B = 0; dw.n_part = 1; dw.trace = nullptr; dw.use_row_scale = 0; dw.apply_only = 1;
     dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, n.theta_target != nullptr, (float)grad_scale);
     dw.ad.do_adam = 1;
+    if (h->fchain) h->stale32[1] = true;
     HIPC(launch_dw_prof(dw, st));
     if (alpha_ptr(h) != nullptr)
       HIPC(launch_alpha_step(c.log_alpha, c.log_alpha_m, c.log_alpha_v, nullptr, 1, (float)c.hp.target_entropy,

@@ -97,9 +97,12 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
   // PrecX2 learners: the workspace — activation exchange buffers, granules, staged rows — in UNCACHED device memory
   // (measured: no slower than cached, r03 log), so that a role of the whole-update launch reads what an earlier role
   // of the same launch wrote
-  h->fchain = h->fused && !h->x2 && !h->bf16 && cfg->algo == OPRL_DDPG && nc == 1 && !cfg->export_grads && merge2_bufs &&
+  // (gradient-exporting learners too — data-parallel ranks: on peer windows their update IS the whole-update launch, the
+  // gradient exchange inside its tiles, in every arithmetic; over RCCL they run the phase / apply launches on the same
+  // mirrors and the same uncached workspace)
+  h->fchain = h->fused && !h->x2 && !h->bf16 && cfg->algo == OPRL_DDPG && nc == 1 && merge2_bufs &&
               cfg->actor.theta_target != nullptr && cfg->critics[0].theta_target != nullptr && cfg->actor.n_layers == 3 && cfg->critics[0].n_layers == 3;
-  h->bchain = h->fused && h->bf16 && cfg->algo == OPRL_DDPG && nc == 1 && !cfg->export_grads && merge2_bufs &&
+  h->bchain = h->fused && h->bf16 && cfg->algo == OPRL_DDPG && nc == 1 && merge2_bufs &&
               cfg->actor.theta_target != nullptr && cfg->critics[0].theta_target != nullptr && cfg->actor.n_layers == 3 && cfg->critics[0].n_layers == 3 &&
               getenv("OPRL_AMD_NO_BF16_CHAIN") == nullptr;
   const int uc_pool = (h->x2 || h->fchain || h->bchain) ? 1 : 0;

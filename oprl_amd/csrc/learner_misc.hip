@@ -140,7 +140,9 @@ extern "C" int oprl_learner_debug_view(oprl_learner* h, int32_t which, const voi
 //   out[3]  updates per chain launch step_n may run (1 unless form 4)
 //   out[4]  wide bits (1: role A on clusters of eight, 2: the critic pass)      out[5]  cluster size of the other roles
 //   out[6]  twin_split    out[7]  p2_pair    out[8]  arithmetic of the kernels: 0 exact fp32, 1 bf16, 2 x2
-//   out[9]  XCD-local cluster exchanges    out[10] the learner was demoted to the shared-chip forms    out[11] reserved (0)
+//   out[9]  XCD-local cluster exchanges    out[10] the learner was demoted to the shared-chip forms
+//   out[11] gradient-exporting learners: the form (as out[2]) of a data-parallel update whose exchange runs inside the dW
+//           tiles (peer windows, level 2) — 4 = the rank runs the single-GPU whole-update launch; others: 0
 extern "C" int oprl_learner_debug_form(oprl_learner* h, int32_t B, int32_t* out) {
   if (!h || !out || B < 1 || B > h->Bmax) { set_err("oprl_learner_debug_form: invalid argument"); return OPRL_ERR_INVALID; }
   for (int i = 0; i < 12; ++i) out[i] = 0;
@@ -161,6 +163,13 @@ extern "C" int oprl_learner_debug_form(oprl_learner* h, int32_t B, int32_t* out)
   out[4] = a.wide; out[5] = a.nc; out[6] = a.twin_split; out[7] = a.p2_pair;
   out[8] = a.x2 ? 2 : (a.bf16 ? 1 : 0);
   out[9] = a.xcd_local;
+  if (h->cfg.export_grads) {
+    const bool was = h->dp_inline;
+    h->dp_inline = true;
+    const DdpgArgs d = ddpg_args(h, B);
+    h->dp_inline = was;
+    out[11] = (d.whole && B <= 256) ? 4 : ((d.merged & 3) == 3 ? 3 : ((d.merged & 1) ? 2 : 1));
+  }
   return OPRL_OK;
 }
 

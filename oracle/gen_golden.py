@@ -173,6 +173,12 @@ def gen_ddpg():
                 [algo.optim_critic.state[p]["exp_avg"] for p in algo.critic.parameters()])
             out[f"{tag}.v_critic"] = fx.digest_list(
                 [algo.optim_critic.state[p]["exp_avg_sq"] for p in algo.critic.parameters()])
+            # (the actor's moments too: Adam's step is scale-invariant in the gradient, so the actor's PARAMETERS alone
+            # would not show an actor-gradient scale error — the moments do)
+            out[f"{tag}.m_actor"] = fx.digest_list(
+                [algo.optim_actor.state[p]["exp_avg"] for p in algo.actor.parameters()])
+            out[f"{tag}.v_actor"] = fx.digest_list(
+                [algo.optim_actor.state[p]["exp_avg_sq"] for p in algo.actor.parameters()])
     save("ddpg_walker_b256", **out)
 
 

@@ -15,7 +15,7 @@ def main() -> None:
     rank, world, rdv, out, algo_name, K, B, level = (int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4],
                                                       sys.argv[5], int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8]))
     prec = sys.argv[9] if len(sys.argv) > 9 else "f32"
-    if prec == "x2":
+    if level == 2 and algo_name == "ddpg":
         # two ranks share this GPU: one update per launch (k_ddpg_chain with several would queue the NEXT update's
         # workgroups of the rank that launched first into every free compute unit, and they wait — through its tiles'
         # exchange — for the other rank's workgroups, which then find none: ranks of a real job own their GPU)
@@ -32,7 +32,8 @@ def main() -> None:
         dp.step_n(buf.handle, K, B, seed=5)
         t.cuda.synchronize()
     arenas = {m: getattr(algo, m)._oprl_arena.cpu() for m in ("actor", "critic")}
-    t.save({"ok": ok, "why": dp.p2p_error, "arenas": arenas, "alpha": getattr(algo, "alpha", None)}, f"{out}.{rank}")
+    t.save({"ok": ok, "why": dp.p2p_error, "arenas": arenas, "alpha": getattr(algo, "alpha", None),
+            "form": algo.learner.debug_form(B)}, f"{out}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
 

@@ -43,11 +43,11 @@ PARAM_TOL = 1e-4   # north_star gate
 
 def _is_param_key(k: str) -> bool:
     return any(f".{w}." in k for w in ("actor", "critic", "actor_target", "critic_target",
-                                       "m_critic", "v_critic"))
+                                       "m_critic", "v_critic", "m_actor", "v_actor"))
 
 
 def _is_moment_key(k: str) -> bool:
-    return ".m_critic." in k or ".v_critic." in k
+    return any(f".{w}." in k for w in ("m_critic", "v_critic", "m_actor", "v_actor"))
 
 
 def compare(got: dict, want: dict, tol: float, skip=(), param_tol: float | None = None, moment_tol: float | None = None):
@@ -136,6 +136,9 @@ def ddpg_scenario(make, B=256):
             m, v = algo.adam("critic")
             out[f"{tag}.m_critic"] = fx.digest_list(m)
             out[f"{tag}.v_critic"] = fx.digest_list(v)
+            m, v = algo.adam("actor")
+            out[f"{tag}.m_actor"] = fx.digest_list(m)
+            out[f"{tag}.v_actor"] = fx.digest_list(v)
     return flatten(out)
 
 

@@ -49,9 +49,10 @@ def test_tqc_walker_b256():
     _both(got, "tqc_walker_b256", sc.tqc_scenario(sc.OracleTQC), skip=("qh.",))
 
 
-@pytest.mark.parametrize("B", [100, 8, 1])
+@pytest.mark.parametrize("B", [128, 100, 8, 1])
 def test_all_algos_against_the_oracle_at_ragged_batches(B):
-    """Batches that are not a multiple of the 16-row slice (and a single row): every algorithm through its
+    """B = 128 — the batch the reference's scripts really train at (trainers/base_trainer.py:28; runners/train.py:67-79
+    never forwards another) — and batches that are not a multiple of the 16-row slice (and a single row): every algorithm through its
     default (fused / layer-wise) path against the oracle computed on the spot — the oracle itself is pinned
     by the golden vectors at the reference's batch sizes (tests/test_oracle_golden.py)."""
     cases = [("ddpg", sc.ddpg_scenario(ha.HipDDPG, B=B), sc.ddpg_scenario(sc.OracleDDPG, B=B), ()),

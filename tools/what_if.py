@@ -8,8 +8,10 @@ the change of the update's period is what that hand-over contributes to the crit
     105  the actor's tiles do not wait for du
     106  the critic's tiles do not wait for role B's rows
 usage: what_if.py [x2|f32] [site ...]     (one process per site is safest: an expired wait poisons the learner)"""
+import os
 import sys
 import time
+os.environ["OPRL_AMD_WHAT_IF"] = "1"      # (the library refuses the timing-experiment sites without it)
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch as t
