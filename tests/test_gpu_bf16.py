@@ -42,10 +42,20 @@ def _bf16_updates(cls, **emu_kw):
 
 
 def _check(name, got, emu, gold, skip=(), emu_out=TOL_EMU_OUT, emu_param=TOL_EMU_PARAM):
-    we = sc.compare(got, emu, emu_out, skip=skip, param_tol=emu_param)
+    # The ACTOR's Adam moments after ten updates (round 6: the DDPG scenario returns them): held at the parameters' gate
+    # after the first update — where an actor-gradient scale error of the whole-update form would show in full — and at
+    # 1e-3 of the largest moment after the tenth: the actor's gradient passes three bf16 GEMM chains (critic forward,
+    # critic backward, actor backward), a hidden activation that lands on the other side of a bf16 rounding boundary than
+    # in the emulation flips one ReLU of one row, and ten updates of that leave single moments 2.5e-4 apart (measured;
+    # the critic's moments and every parameter sample stay below 1e-4)
+    late_actor = {k: v for k, v in emu.items() if k.startswith("after10.") and (".m_actor." in k or ".v_actor." in k)}
+    we = sc.compare(got, {k: v for k, v in emu.items() if k not in late_actor}, emu_out, skip=skip, param_tol=emu_param)
+    if late_actor:
+        wl = sc.compare(got, late_actor, emu_out, param_tol=1e-3)
+        print(f"\n[bf16] {name}: the actor's Adam moments after ten updates vs the emulation: worst {wl[1]:.2e} ({wl[0]})")
     # gradient-like keys (step-1 gradient samples, Adam moments): single elements, cancellation-prone
     def grad_like(k):
-        return k.startswith(("g_critic_1", "g_actor_1")) or ".m_critic" in k or ".v_critic" in k
+        return k.startswith(("g_critic_1", "g_actor_1")) or any(w in k for w in (".m_critic", ".v_critic", ".m_actor", ".v_actor"))
     wr = sc.compare(got, {k: v for k, v in gold.items() if not grad_like(k)}, TOL_REF_OUT, skip=skip,
                     param_tol=TOL_REF_PARAM)
     grads = {k: v for k, v in gold.items() if grad_like(k)}

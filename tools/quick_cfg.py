@@ -12,7 +12,10 @@ import bench
 KEY = {"ddpg": "DDPG walker-walk B=256", "ddpg128": "DDPG walker-walk B=128 (the reference scripts' batch)",
        "td3": "TD3 cheetah-run B=256", "sac": "SAC humanoid-walk B=1024", "tqc": "TQC walker-walk B=256 5x25"}
 cfg = sys.argv[1]
-cls, S, A, B, extras, _, _ = bench.BASELINE_CONFIGS[KEY[cfg]]
+if cfg.startswith("ddpg") and cfg not in KEY:        # ddpg512, ddpg1024, ...: DDPG at walker dims and that batch size
+    cls, S, A, B, extras = "DDPG", 24, 6, int(cfg[4:]), {}
+else:
+    cls, S, A, B, extras, _, _ = bench.BASELINE_CONFIGS[KEY[cfg]]
 dev = t.device("cuda", 0)
 replay = bench.make_replay(dev, 0, S=S, A=A)
 n = 400 if cfg == "tqc" else 2000
