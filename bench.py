@@ -136,7 +136,7 @@ def cpu_baseline(budget_s: float = 14.0):
 # ---- the other BASELINE.json configurations, the bf16 mode and the through-the-API rate --------
 PEAK_BF16_MATRIX_TFLOPS = 2500.0       # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F16_MATRIX_TFLOPS = 2500.0        # dense fp16 MFMA; the x2 mode spends three products per algorithmic one
-PMC_FILE = {"f32": "r05_pmc_traffic_f32.json", "bf16": "r05_pmc_traffic_bf16.json", "x2": "r05_pmc_traffic_x2.json"}
+PMC_FILE = {"f32": "r06_pmc_traffic_f32.json", "bf16": "r06_pmc_traffic_bf16.json", "x2": "r06_pmc_traffic_x2.json"}
 PEAK_OF = {"f32": PEAK_F32_MATRIX_TFLOPS, "bf16": PEAK_BF16_MATRIX_TFLOPS, "x2": PEAK_F16_MATRIX_TFLOPS / 3.0}
 DTYPE_OF = {"f32": "f32 (exact-fp32 MFMA)", "bf16": "bf16 (fp32 accumulate / master / Adam)",
             "x2": "f32 as split fp16x2 (hi + lo, 3 fp16 MFMAs per product, fp32 accumulate / master / Adam)"}
@@ -875,7 +875,7 @@ def measure(args, wd):
                              f"(serialised pass of {P} steps) minus event_overhead_us, the per-launch "
                              "excess of that pass over the un-instrumented timed loop (where the same "
                              "launches run back to back, so a step is the sum of their durations); they "
-                             "agree with rocprofv3 --kernel-trace --stats (profiles/r04_kernel_stats_*.csv); "
+                             "agree with rocprofv3 --kernel-trace --stats (profiles/r06_kernel_stats_*.csv); "
                              "sum of kernel time per step = "
                              f"{sum(k['us_per_step'] for k in kern.values()):.1f} us; bytes_per_launch = 32 B per trained "
                              "parameter (theta, m, v, theta_target read + written) + the gathered minibatch rows; "
@@ -886,8 +886,8 @@ def measure(args, wd):
                              "passes, tools/profile_round.sh).  Neither roof binds: an update is a CHAIN of dependent "
                              "16-row-slice stages (target chain -> TD seeds -> critic tiles -> critic pass -> du -> actor "
                              "tiles) whose length is set by cross-workgroup flag hops, cold weight-shard loads and "
-                             "workgroup dispatch, not by bandwidth or the matrix cores (DESIGN.md section 0.2; timeline in "
-                             "profiles/r04_stage_stamps.txt)")
+                             "workgroup dispatch, not by bandwidth or the matrix cores (DESIGN.md section 6: the floor table; timeline in "
+                             "profiles/r06_stage_stamps_f32.txt)")
         multi = None
         group = None
         if not use_dp and args.learners > 1:

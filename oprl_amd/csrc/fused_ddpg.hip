@@ -1605,9 +1605,10 @@ __global__ __launch_bounds__(kThreads) void k_ddpg_chain(const DdpgArgs A, const
   const int n_bc = 8 * nx2;
   const unsigned ep2 = A.epoch + (unsigned)u2;
 
-  // ---- the next update's rows: the last `slices` of these workgroups, before their tiles (at B = 256 they have none)
+  // ---- the next update's rows: the last `slices` of the tile-capable workgroups (roles B and C, then T's rows) — which
+  // carry no tile (chain_tile_rows leaves room for them)
   {
-    const int p = n_bc - 1 - wg2;
+    const int p = n_bc + (C.rows - 16) * nx2 - 1 - wg2;
     if (p >= 0 && p < nx2 && (u2 + 1 < C.n_upd || C.pf_last)) {
       const int par2 = u2 & 1;
       BatchSrc nx = A.next;                 // (the replay's view; gather = 1)
@@ -1851,7 +1852,7 @@ hipError_t launch_ddpg_chain(const DdpgArgs& a, const DwKArgs4& dc, const DwKArg
   const int tc = dc.tile_end[kDwFusedItems - 1], ta = da.tile_end[kDwFusedItems - 1];
   if (tc + ta + 1 > kThreads) return hipErrorInvalidValue;       // (one poller per flag: chain_wait2)
   const int mt = tc > ta ? tc : ta;
-  const int rows = 16 + (mt > 8 * slices ? (mt - 8 * slices + slices - 1) / slices : 0);    // A 8 | B 4 | C 4 | T
+  const int rows = 16 + chain_tile_rows(mt, slices);    // A 8 | B 4 | C 4 | T
   if (c.rows != rows) return hipErrorInvalidValue;
   const dim3 grid(slices, rows * c.n_upd);
   if (a.x2) hipLaunchKernelGGL((k_ddpg_chain<PrecX2>), grid, dim3(kThreads), fused_ddpg_lds_bytes(), st, a, dc, da, c);

@@ -445,6 +445,15 @@ struct ChainArgs {
   unsigned long long* qp;              // [slices][4 members][16 rows] {epoch, partial q}: role B -> role A (tp4.h QPart)
 };
 
+// k_ddpg_chain: tile-only grid rows of one update.  Roles B and C (8 workgroups per slice) go on as tile workgroups; `mt`
+// tiles (the larger of the two nets' counts) need workgroups, and so do the `sl` gatherers of the next update's rows —
+// workgroups WITHOUT a tile: a gatherer that also carries a tile starts it ~3 us late, and the critic pass of the update
+// waits for the last critic tile (B = 128, the reference scripts' batch: 30.5 -> us per update before this rule, r06-4)
+__host__ __device__ inline int chain_tile_rows(int mt, int sl) {
+  const int need = mt + sl;
+  return need > 8 * sl ? (need - 8 * sl + sl - 1) / sl : 0;
+}
+
 constexpr int kDwTile = 32;      // k (fan-in) extent of a dW tile
 constexpr int kDwTileN = 16;     // n (fan-out) extent: 16 rows keep a workgroup's bytes at X 32 KB + dY 16 KB
 constexpr int kDwThreads = 512;

@@ -568,7 +568,7 @@ int chain_rows(const oprl_learner* h, int B) {
   for (size_t i = 0; i < h->items_host.size(); ++i)
     tiles64[(int)i < h->n_items_critic ? 0 : 1] += ((h->items_host[i].N + 15) / 16) * ((h->items_host[i].K + 63) / 64);
   const int sl = (B + kR - 1) / kR, mt = tiles64[0] > tiles64[1] ? tiles64[0] : tiles64[1];
-  return 16 + (mt > 8 * sl ? (mt - 8 * sl + sl - 1) / sl : 0);
+  return 16 + chain_tile_rows(mt, sl);
 }
 
 DdpgArgs ddpg_args(oprl_learner* h, int B) {
@@ -912,7 +912,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
       }
       // (every tile must find a role-B / role-C workgroup to be the continuation of: 8 per slice)
       const int max_tiles = kc.tile_end[kDwFusedItems - 1] > ka.tile_end[kDwFusedItems - 1] ? kc.tile_end[kDwFusedItems - 1] : ka.tile_end[kDwFusedItems - 1];
-      const int t_rows = max_tiles > 8 * slices ? (max_tiles - 8 * slices + slices - 1) / slices : 0;
+      const int t_rows = chain_tile_rows(max_tiles, slices);
       // (one update's workgroups — 16 role rows per slice + the tile-only rows — wait for each other: all must fit the chip)
       const bool chain_fits = (16 + t_rows) * slices <= h->n_cus;
       const int U = (h->no_chain || h->chain_flags == nullptr || !chain_fits) ? 1 : h->chain_u;
