@@ -171,13 +171,21 @@ def check(rc: int, what: str = "") -> None:
         raise RuntimeError(f"liboprl_amd {what} failed (status {rc}): {msg}")
 
 
+_raw_stream = None
+_cur_dev = None
+
+
 def current_stream():
     """The caller's current HIP stream as a void* (torch.cuda.current_stream() builds a Stream
     object per call, ~10 us; the raw accessor is what torch's own compiled code uses)."""
+    global _raw_stream, _cur_dev
+    if _raw_stream is None:
+        import torch
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+        _cur_dev = torch._C._cuda_getDevice
+    if _raw_stream:
+        return C.c_void_p(_raw_stream(_cur_dev()))
     import torch
-    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-    if raw is not None:
-        return C.c_void_p(raw(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -196,10 +204,10 @@ def on_device(dev):
     """``with on_device(dev):`` — torch.cuda.device(dev) only when dev is not already current
     (entering the real guard costs several microseconds on the per-env-step path)."""
     import torch
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    if torch.cuda.current_device() == idx:
+    cur = torch._C._cuda_getDevice()
+    if dev.index is None or dev.index == cur:
         return _NO_GUARD
-    return torch.cuda.device(idx)
+    return torch.cuda.device(dev.index)
 
 
 def ptr(t) -> C.c_void_p:

@@ -3,9 +3,8 @@
 Same dataclass fields, ``create()`` / ``update()`` contract and attributes as
 the reference (/root/reference/src/oprl/algos/ddpg.py:16-107); ``update()`` is
 one call into liboprl_amd.so — no host sync — instead of autograd + two torch Adam steps + 12 Polyak
-tensor ops: in the two parity modes (exact fp32, the default, and x2) ONE launch for the whole update
-(k_ddpg_chain — through ``learner.step_n`` up to 32 updates per launch); in the bf16
-mode 3 launches (phase 1 with the critic's dW + Adam tiles riding on it, phase 2, the actor's dW + Adam)."""
+tensor ops: ONE launch for the whole update in every arithmetic mode (k_ddpg_chain — through
+``learner.step_n`` up to 32 updates per launch)."""
 from __future__ import annotations
 
 from dataclasses import dataclass, field

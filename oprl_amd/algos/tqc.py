@@ -8,7 +8,7 @@ layer by layer over the whole chip; the launches that leave CUs idle carry indep
 (the online critics' first layers behind the actor's forward on s', the TD-target sort on the target pass's heads,
 the actor step's forward on the critic step's heads, the narrow layers' dW tiles behind the wide dW launch, the
 temperature step on the actor's dW launch, and — in step_n — the next update's minibatch rows on the
-action-gradient launch).  DESIGN.md section 4.5."""
+action-gradient launch).  DESIGN.md section 4.1; docs/history/DESIGN_r01-r05.md section 4.5."""
 from __future__ import annotations
 
 import math

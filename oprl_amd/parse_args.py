@@ -10,7 +10,7 @@ _SHARED = (
     ("--config", str, None, "path of a config file (accepted for compatibility; the scripts are the config)"),
     ("--env", str, "cartpole-balance", "environment name, e.g. walker-walk"),
     ("--device", str, "cuda", "device of the learner (a ROCm GPU; there is no CPU path)"),
-    # extension: the learner's arithmetic mode (DESIGN.md section 0.1).  Scripts and algorithm classes alike default to
+    # extension: the learner's arithmetic mode (DESIGN.md section 4).  Scripts and algorithm classes alike default to
     # exact fp32 — the reference's arithmetic, no input range.  "x2" is the faster parity mode, opt-in: it has a finite
     # range (|observation|, |hidden activation| < 4094, |w| < 256; leaving it raises from update() / check(), it is never
     # silent) — meant for normalised observations
