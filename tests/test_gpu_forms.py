@@ -4,7 +4,7 @@ Which kernels an update runs — whole updates per launch (k_ddpg_chain), the me
 launches, the generic sequence; lean or generic passes; clusters of eight; XCD-local exchanges — is decided by a dozen
 interacting conditions in csrc/learner.hip (ddpg_args, critic_phase).  oprl_learner_debug_form reports the decision as
 twelve numbers; tests/golden/launch_forms.json (tools/form_table.py, MI355X) holds them for {DDPG, TD3, SAC, TQC} x
-{f32, x2, bf16} x {plain, export_grads, set_cluster(4), five environment switches} x B in {1, 8, 100, 256, 512, 1024}.
+{f32, x2, bf16} x {plain, export_grads, set_cluster(4), five environment switches} x B in {1, 8, 100, 128, 256, 512, 1024}.
 A mode that falls off its fast form is a red test here, not a line in a benchmark table.  Reference: none (the reference
 has one path, autograd: /root/reference/src/oprl/algos/ddpg.py:61-107)."""
 import json
@@ -46,10 +46,15 @@ def test_launch_form_matches_the_table(row):
 
 
 def test_the_headline_modes_take_the_whole_update_form():
-    """The table's own sanity: the two parity modes of DDPG at B <= 256 run whole updates, 32 per launch, lean passes, role
-    A and the critic pass on clusters of eight."""
+    """The table's own sanity: every arithmetic of DDPG at B <= 256 — B = 128, the reference scripts' batch, included — runs
+    whole updates, 32 per launch, lean passes, role A and the critic pass on clusters of eight; and a gradient-exporting
+    DDPG learner (a data-parallel rank) takes the same form once its exchange runs inside the tiles (dp_inline_form)."""
     for r in ROWS:
-        if r["algo"] == "DDPG" and r["precision"] in ("f32", "x2") and r["variant"] == "plain":
-            for B in ("1", "8", "100", "256"):
+        if r["algo"] == "DDPG" and r["variant"] == "plain":
+            for B in ("1", "8", "100", "128", "256"):
                 f = dict(zip(FIELDS, r["forms"][B]))
                 assert (f["fused"], f["lean"], f["form"], f["updates_per_chain_launch"], f["wide"]) == (1, 1, 4, 32, 3), (r, B)
+        if r["algo"] == "DDPG" and r["variant"] == "export_grads":
+            for B in ("1", "8", "100", "128", "256"):
+                f = dict(zip(FIELDS, r["forms"][B]))
+                assert f["dp_inline_form"] == 4, (r, B)
