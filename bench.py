@@ -477,9 +477,12 @@ class Watchdog:
         self.lock = threading.Lock()
         threading.Thread(target=self._watch, daemon=True).start()
 
-    def kick(self, phase):
+    def kick(self, phase, seconds=None):
+        """(`seconds`: a shorter bound for this phase — the peer-window probes, never yet run across real xGMI links: if one
+        hangs, the line with the RCCL measurement goes out after minutes, not after the run's whole allowance)"""
         with self.lock:
-            self.phase, self.deadline = phase, time.monotonic() + self.seconds
+            self.bound = self.seconds if seconds is None else min(seconds, self.seconds)
+            self.phase, self.deadline = phase, time.monotonic() + self.bound
 
     def finish(self):
         with self.lock:
@@ -502,7 +505,7 @@ class Watchdog:
             if late and getattr(self, "quiet", False):
                 os._exit(0)
             if late:
-                why = f"watchdog: phase '{phase}' exceeded {self.seconds:.0f} s on rank {self.rank}"
+                why = f"watchdog: phase '{phase}' exceeded {getattr(self, 'bound', self.seconds):.0f} s on rank {self.rank}"
                 print(f"bench.py: {why}", file=sys.stderr, flush=True)
                 if self.rank == 0:
                     print(failure_line(self.args, self.world, why), flush=True)
@@ -680,7 +683,7 @@ def measure(args, wd):
             levels = (1, 2)
         n_probe = 1000 if not rehearsal else 60
         for level in levels:
-            wd.kick(f"data-parallel probe, exchange level {level}")
+            wd.kick(f"data-parallel probe, exchange level {level}", None if level == 0 else 240.0)
             try:
                 algo, dp, ok = build(level)
             except Exception as exc:  # noqa: BLE001
