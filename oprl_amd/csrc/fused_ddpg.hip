@@ -272,6 +272,87 @@ __device__ __forceinline__ void role_b(const DdpgArgs& A, const Net& critic, flo
   if constexpr (!LEAN) tp_bwd<WIDTH, LEAN, P>(critic, auxS, h1, h2, scr, tp, st, row0, B, 0, 0, auxS, stamp);
 }
 
+// ---- role B on 32-row slices (tp4.h tp4_scalar_fb2): the over-subscribed phase-1 launches.  LDS of such a workgroup:
+struct FusedLdsB2 {   // floats
+  static constexpr int TX = kR * kX0Ld, TH = kR * lds_ld(256), TO = kR * kOutLd, TS = kWaves * 256;
+  static constexpr int xa = 0;                     // [2][kR][kX0Ld] the two row tiles' [s | a]
+  static constexpr int dump = xa + 2 * TX;         // what load_batch writes beside the second tile (its [s' | 0])
+  static constexpr int h = dump + TX;              // h1 | h2 | g2, two tiles each
+  static constexpr int out = h + 6 * TH;
+  static constexpr int scr = out + 2 * TO;         // (the gather path's episode table lies over it, before the pass)
+  static constexpr int misc = scr + 2 * TS;        // r[16] d[16] (unused by this role) + meta
+  static constexpr int total = misc + 96;
+};
+static_assert(FusedLdsB2::total * 4 <= 160 * 1024, "role B on two row tiles fits the LDS");
+static_assert(2 * FusedLdsB2::TS >= kMaxEnds, "the episode table fits over the partial tiles");
+
+template <class P, class ST>
+__device__ __forceinline__ void role_b2(const DdpgArgs& A, const Net& critic, float* const* cX, float* const* cdY, int j, float* smem,
+                                        int member, int s32, ST& stamp) {
+  using LY = FusedLdsB2;
+  float* xa = smem + LY::xa;
+  float* h1 = smem + LY::h;
+  float* h2 = h1 + 2 * LY::TH;
+  float* g2 = h2 + 2 * LY::TH;
+  float* outS = smem + LY::out;
+  float* scr = smem + LY::scr;
+  float* rS = smem + LY::misc;
+  int* meta = reinterpret_cast<int*>(rS + 2 * kR);
+  int* endsS = reinterpret_cast<int*>(scr);
+  const int row0 = s32 * 2 * kR, B = A.B, S = A.S, Ad = A.A, tid = threadIdx.x;
+  const size_t area = (size_t)kTpStages * A.xnc * kTpBlk;
+  Tp tp{member, 4, A.xbuf + ((size_t)(1 + j) * gridDim.x + 2 * s32) * area, A.cluster_tag, 0,
+        A.err, KERN_PHASE1 << 8, A.debug_expire == (int)SITE_CLUSTER ? 0 : kTpSpin};
+  // (the launcher takes this form only where the four members of a cluster sit 8 k workgroups apart: on one XCD, and all
+  // of them see the same blockIdx.x & 7 — cluster_on_one_xcd's rule)
+  tp.local = cluster_on_one_xcd(A);
+  const bool lead = member == 0;
+  const Tp3Store st{cX[1], cX[2], cdY[1], cdY[0], A.cdY0_stride, B, false};
+  auto rows = [&]() {
+    if (A.src.gather) {
+      // (the first update of a step_n call: the two tiles one after the other through load_batch, whose [s' | 0] half lands on
+      // the next tile's place / the dump)
+      for (int t = 0; t < 2; ++t) {
+        load_batch(A.src, row0 + kR * t, B, S, Ad, xa + t * LY::TX, xa + (t + 1) * LY::TX, rS, rS + kR, meta, endsS);
+        __syncthreads();
+      }
+    } else {
+      // staged rows: every element of the two padded tiles written once — value or zero — loads first, no barrier
+      constexpr int kPer = (2 * LY::TX + kThreads - 1) / kThreads;
+      float v[kPer];
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const int idx = min(tid + q * kThreads, 2 * LY::TX - 1);
+        const int row = idx / kX0Ld, col = idx - row * kX0Ld, gr = row0 + row;
+        const bool is_s = gr < B && col < S, is_a = gr < B && col >= S && col < S + Ad;
+        const float* src = A.src.s;
+        if (is_s) src = A.src.s + (size_t)gr * S + col;
+        if (is_a) src = A.src.a + (size_t)gr * Ad + (col - S);
+        const float x = *src;
+        v[q] = (is_s || is_a) ? x : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const int idx = tid + q * kThreads;
+        if (idx < 2 * LY::TX) xa[idx] = v[q];
+      }
+    }
+  };
+  tp4_scalar_fb2<P>(critic, xa, h1, h2, g2, outS, scr, tp, area, st, row0, B, 1.f, stamp, rows);
+  if (!lead) return;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) store_rows(xa + t * LY::TX, kX0Ld, cX[0], A.cldx0, S + Ad, row0 + kR * t, B);
+  // q -> role A of the two slices, as granules (role_b's hand-over)
+  if (tid < 2 * kR) {
+    const int gr = row0 + tid;
+    if (gr < B)
+      __hip_atomic_store(A.y_granules + (size_t)(1 + j) * A.gran_stride + gr,
+                         ((unsigned long long)A.epoch << 32) | (unsigned long long)__float_as_uint(outS[(tid >> 4) * LY::TO + (tid & 15) * kOutLd]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  stamp();   // q published
+}
+
 // (A separate template instance for the twin-critic algorithms, so that the single-critic kernel
 // carries none of their code, was measured SLOWER for all three: phase 1 15.0 vs 14.3 us for DDPG,
 // TD3 38.5 vs 36.0 us, SAC 54.5 vs 51.6 us per update — profiles/r01b_experiments.txt #29.)
@@ -292,11 +373,37 @@ __device__ __forceinline__ int dw_total(const DwKArgs4& d) { return d.tile_end[k
 // of the tile code per kernel instead of one per place a workgroup may turn into a tile (instruction cache, r03-14 / -25).
 // MERGED kernels are single-critic, non-SAC by their launchers' rules: the twin paths are compiled out of them.
 // (SINGLE: the caller's launcher admits one critic only — the merged kernels, the packed learners' group kernel)
-template <int WIDTH, bool LEAN, bool SAC, class P, bool WIDE = false, bool MERGED = false, class KA = DwKArgs, bool SINGLE = MERGED>
+template <int WIDTH, bool LEAN, bool SAC, class P, bool WIDE = false, bool MERGED = false, class KA = DwKArgs, bool SINGLE = MERGED, bool RT2 = false>
 __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D = nullptr, int by_in = -1, int bx_in = -1) {   // (bx_in: the slice, where the caller deals the workgroups out itself — the group launches)
   constexpr bool TWIN = !SINGLE;            // twin critics / twin_split can occur at all
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int by = by_in < 0 ? (int)blockIdx.y : by_in;
+  int by = by_in < 0 ? (int)blockIdx.y : by_in;
+  if constexpr (RT2) {
+    // B roles on 32-row slices: critic j's clusters are grid rows 2 j, 2 j + 1 — member-major (member m of slice s32 is
+    // workgroup m * slices / 2 + s32 of the pair of rows: the four members sit 8 k workgroups apart, on one XCD); roles A and
+    // C follow on 16-row slices, as ever
+    static_assert(LEAN && !MERGED && !WIDE, "two row tiles: the plain lean phase launch");
+    const int yb2 = 2 * A.n_critics, half = (int)gridDim.x >> 1;
+    if (by < yb2) {
+      const int local = (by & 1) * (int)gridDim.x + (int)blockIdx.x;
+      const int member = local / half, s32 = local - member * half;
+      int n_stamp2 = 0;
+      auto stamp2 = [&]() {
+        if (kTraceOn && A.trace != nullptr && (threadIdx.x & 63) == 0 && (threadIdx.x == 0 || s32 == 0) && member == 0 && n_stamp2 < kTraceStamps) {
+          const int slot = threadIdx.x == 0 ? s32 : 16 + ((int)threadIdx.x >> 6);
+          long long* tr = A.trace + (((size_t)(1 + (by >> 1)) * 64 + slot) * kTraceStamps + n_stamp2) * 2;
+          tr[0] = (long long)__builtin_readcyclecounter();
+          tr[1] = (long long)wall_clock64();
+        }
+        ++n_stamp2;
+      };
+      stamp2();
+      if ((by >> 1) == 1) role_b2<P>(A, A.critic2, A.c2X, A.c2dY, 1, smem, member, s32, stamp2);
+      else role_b2<P>(A, A.critic, A.cX, A.cdY, 0, smem, member, s32, stamp2);
+      return -1;
+    }
+    by += A.n_critics * A.nc - yb2;        // roles A and C: the row they have in the one-tile grid
+  }
   // the last grid row of a step_n launch may be the PREFETCH row: the next update's rows (dispatched last: these
   // workgroups start as roles retire) into the other staging set — the same load_batch call as the roles', from A.next
   const bool pf_row = A.prefetch_p1 && blockIdx.y == gridDim.y - 1;
@@ -589,6 +696,12 @@ __device__ __forceinline__ void ddpg_tile(const KA* D, int tile, int gate) {
 
 template <int WIDTH, bool LEAN, bool SAC, class P = PrecF32, bool WIDE = false>
 __global__ __launch_bounds__(kThreads) void k_ddpg_phase1(const DdpgArgs A) { (void)ddpg_phase1_body<WIDTH, LEAN, SAC, P, WIDE>(A); }
+
+// the plain lean phase launch with the B roles on 32-row slices (ddpg_phase1_body RT2; SINGLE = false: DDPG, TD3 and SAC alike)
+template <bool SAC, class P>
+__global__ __launch_bounds__(kThreads) void k_ddpg_phase1_rt2(const DdpgArgs A) {
+  (void)ddpg_phase1_body<256, true, SAC, P, false, false, DwKArgs, false, true>(A);
+}
 
 // phase 1 + the critic's dW tiles in one launch (both argument blocks by value; the tile workgroups index the
 // second one through the kernel-argument segment: scalar loads, as k_dw_adam does)
@@ -1740,7 +1853,13 @@ hipError_t init_fused_attrs() {
                       reinterpret_cast<const void*>(&k_ddpg_phase2_dw<PrecX2>),
                       reinterpret_cast<const void*>(&k_ddpg_chain<PrecX2>),
                       reinterpret_cast<const void*>(&k_ddpg_chain<PrecF32>),
-                      reinterpret_cast<const void*>(&k_ddpg_chain<PrecBF16>)};
+                      reinterpret_cast<const void*>(&k_ddpg_chain<PrecBF16>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_rt2<false, PrecF32>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_rt2<false, PrecX2>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_rt2<false, PrecBF16>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_rt2<true, PrecF32>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_rt2<true, PrecX2>),
+                      reinterpret_cast<const void*>(&k_ddpg_phase1_rt2<true, PrecBF16>)};
   for (const void* k : ks) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -1871,6 +1990,21 @@ hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st) {
     const dim3 grid(slices, a.nc + 8 + a.nc + pf);
     if (a.x2) hipLaunchKernelGGL((k_ddpg_phase1<256, true, false, PrecX2, true>), grid, blk, lds, st, a);
     else hipLaunchKernelGGL((k_ddpg_phase1<256, true, false, PrecF32, true>), grid, blk, lds, st, a);
+    return hipGetLastError();
+  }
+  if (a.rt2) {      // the B roles on 32-row slices (learner.hip decides: lean, clusters of four, slices a multiple of 16)
+    if (!lean_ok(a) || a.nc != 4 || (slices & 15) != 0 || pf || a.merged != 0) return hipErrorInvalidValue;
+    const dim3 g2(slices, 2 * a.n_critics + 2 * a.nc);
+    const size_t l2 = std::max(lds, sizeof(float) * (size_t)FusedLdsB2::total);
+    if (a.sac) {
+      if (a.x2) hipLaunchKernelGGL((k_ddpg_phase1_rt2<true, PrecX2>), g2, blk, l2, st, a);
+      else if (a.bf16) hipLaunchKernelGGL((k_ddpg_phase1_rt2<true, PrecBF16>), g2, blk, l2, st, a);
+      else hipLaunchKernelGGL((k_ddpg_phase1_rt2<true, PrecF32>), g2, blk, l2, st, a);
+    } else {
+      if (a.x2) hipLaunchKernelGGL((k_ddpg_phase1_rt2<false, PrecX2>), g2, blk, l2, st, a);
+      else if (a.bf16) hipLaunchKernelGGL((k_ddpg_phase1_rt2<false, PrecBF16>), g2, blk, l2, st, a);
+      else hipLaunchKernelGGL((k_ddpg_phase1_rt2<false, PrecF32>), g2, blk, l2, st, a);
+    }
     return hipGetLastError();
   }
   const dim3 grid(slices, (2 + a.n_critics) * a.nc + pf);

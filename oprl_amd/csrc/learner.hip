@@ -733,6 +733,18 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
     a.wide &= ~1;
     a.du_granules = nullptr; a.g1_granules = nullptr; a.w3_snap = nullptr;
   }
+  // Over-subscribed plain phase-1 launches (B >= 512: the roles' clusters need more compute units than the chip has, the
+  // launch is several dispatch rounds): the B roles carry TWO row tiles per cluster — half the workgroups, one fetch of the
+  // critic's fragments per 32 rows (tp4.h tp4_scalar_fb2; bit-identical to the one-tile form).  Slices a multiple of 16: a
+  // cluster's members then sit on one XCD (fused_ddpg.hip role_b2).
+  {
+    const int slices = (B + kR - 1) / kR;
+    // (twin critics only — TD3, SAC: their two B roles then share the first dispatch round; measured, r06-6: SAC humanoid
+    // B = 1024 - 3.7 us per update in every mode, TD3 B = 512 - 4.7, SAC B = 512 - 5; a single critic's one B role on half the
+    // workgroups only lengthens the wait of role A behind it: DDPG B = 512 + 1.8 us, B = 1024 + 2.4 .. 4)
+    a.rt2 = (!h->no_rt2 && h->nc == 2 && a.merged == 0 && (a.wide & 1) == 0 && a.nc == 4 && fused_ddpg_is_lean(a) && (slices & 15) == 0 &&
+             (2 + h->nc) * 4 * slices > h->n_cus && !a.prefetch_p1) ? 1 : 0;
+  }
   // (an exchanging rank outside PrecX2 has the in-tile exchange in the whole-update form only: whatever kept that form
   // away, its merged phase launch — 16 x 32 tiles that exchange nothing — must not run either)
   if (h->dp_inline && !a.x2 && !a.whole) a.merged = 0;

@@ -345,6 +345,7 @@ struct oprl_learner {
   unsigned long long* du_granules = nullptr;
   unsigned long long* g1_granules = nullptr;
   float* w3_snap = nullptr;
+  int no_rt2 = 0;              // OPRL_AMD_NO_RT2: phase 1's B roles stay on 16-row slices in the over-subscribed launches (tests / A-B)
   int no_wide = 0;             // OPRL_AMD_NO_WIDE: never run role A / phase 2's critic pass on clusters of eight
   int no_merge_twin = 0;       // OPRL_AMD_NO_RIDE bit 64: TD3's critics' tiles as a launch of their own
   bool xcd_local = false;      // XCD-local cluster exchanges (DdpgArgs::xcd_local): probed dispatcher, not OPRL_AMD_NO_XCD_LOCAL, cleared by an expired wait

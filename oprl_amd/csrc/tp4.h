@@ -765,4 +765,225 @@ __device__ __forceinline__ void tp4_scalar_fb(const Net& net, const float* x0s, 
   sf();
 }
 
+// ---------------------------------------------------------------------------------------
+// tp4_scalar_fb for TWO row tiles (32 minibatch rows) per cluster — the over-subscribed launches (B >= 512: SAC at
+// B = 1024 is four dispatch rounds of 256 workgroups, one per role, and every workgroup streams ~ 390 KB of weight
+// fragments before its first MFMA).  The fragments of a pass are requested ONCE and meet both tiles: per stage two
+// accumulator sets, two epilogues, one barrier.  Arithmetic per tile is that of tp4_scalar_fb<P, 4> (same fragments,
+// same chains, same member order in the exchange): the results are bit-identical to two one-tile workgroups.
+// Clusters of four, no input-column gradient, q through the cluster all-reduce (role B of the phase launches).
+// LDS: x0s [2][kR][kX0Ld], h1 / h2 / g2 [2][kR][kWL4] each (tile t at + t * kR * ld), outS [2][kR][kOutLd],
+// scr [2][kWaves][256].  Tile t exchanges through the area of slice 2 * slice32 + t: tp.xbuf + t * area.
+// ---------------------------------------------------------------------------------------
+// all-reduce of two 16 x 16 tiles at once (tp4_allreduce_regs's slots and order; both tiles' granules are published
+// before the first poll: one hop, not two)
+__device__ __forceinline__ void tp4_allreduce_regs_x2(const f32x4 (&mine)[2], int col, bool valid, const Tp& tp, size_t area,
+                                                      f32x4 (&sum)[2]) {
+  constexpr int NM = 4;
+  const int kk = (threadIdx.x & 63) >> 4;
+  constexpr int kRs = 4 * kNarrowMax;
+  const unsigned tag = (tp.tag << 6) | (unsigned)(tp.stage & 63);
+  sum[0] = mine[0]; sum[1] = mine[1];
+  if (!valid) return;
+  unsigned long long* slot[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    slot[t] = tp.xbuf + (size_t)t * area + (size_t)tp.stage * NM * kTpBlk + kk * kNarrowMax + col;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(mine[t][r]);
+      if (tp.local) __hip_atomic_store(slot[t] + (size_t)tp.c * kTpBlk + r * kRs, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else __hip_atomic_store(slot[t] + (size_t)tp.c * kTpBlk + r * kRs, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // (both tiles' granules are out; the polls go tile by tile — the second tile's peers' granules have usually landed by the
+  // time the first tile's have: one hop, and 32 registers of granules instead of 64)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    bool ok = false;
+    unsigned long long x[NM][4];
+    for (int spin = 0; spin < tp.spin && !ok; ++spin) {
+#pragma unroll
+      for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          x[m][r] = (m == tp.c) ? ((unsigned long long)tag << 32)
+                                : __hip_atomic_load(slot[t] + (size_t)m * kTpBlk + r * kRs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = true;
+#pragma unroll
+      for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ok = ok && (unsigned)(x[m][r] >> 32) == tag;
+      if (!ok) __builtin_amdgcn_s_sleep(1);
+    }
+    if (ok) {
+      sum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[t][r] += (m == tp.c) ? mine[t][r] : __uint_as_float((unsigned)x[m][r]);
+    } else {
+      report_expired(tp.err, tp.err_code | SITE_CLUSTER);
+      const float nan = __builtin_nanf("");
+      sum[t] = f32x4{nan, nan, nan, nan};
+    }
+  }
+}
+
+template <class P = PrecF32, class ST = NoStamp, class PRE = NoStamp>
+__device__ __forceinline__ void tp4_scalar_fb2(const Net& net, const float* x0s, float* h1, float* h2, float* g2, float* outS,
+                                               float* scr, Tp& tp, size_t area, const Tp3Store& st, int row0, int B, float seed,
+                                               ST sf = ST(), PRE pre = PRE()) {
+  constexpr int NM = 4, RT = 2;
+  constexpr int TX = kR * kX0Ld, TH = kR * kWL4, TO = kR * kOutLd, TS = kWaves * 256;      // floats between the two tiles' buffers
+  const float* const nb0 = net.b[0];
+  const float* const nb1 = net.b[1];
+  const float* const nb2 = net.b[2];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  using NS = Tp4Steps<P>;
+  using SH = Tp4Shape<P, NM>;
+  asm volatile("" :: "s"(net.pf[0]), "s"(net.pf[1]), "s"(net.pf[2]), "s"(net.pb[1]), "s"(net.pb[2]), "s"(nb0), "s"(nb1), "s"(nb2),
+               "s"(net.dims[0]));
+  const int c = tp.c, c0 = c * SH::COLS;
+  const int NS0 = (net.dims[0] + P::KS - 1) / P::KS;
+  constexpr int kOutWave = 12;
+  constexpr int NQ = SH::NQ;
+  const int t1 = wave % SH::TPM, kq = wave / SH::TPM;
+  const int rt = (int)threadIdx.x >> 8, rl = ((int)threadIdx.x & 255) >> 2, rr = (int)threadIdx.x & 3;
+
+  // ---- requests: once for both row tiles
+  using F = typename P::Frag;
+  constexpr int BK = P::kBlk;
+  constexpr float kO = P::kOut / P::kFwdA;
+  float sb = 1.f;
+  if constexpr (P::kX2) sb = 4.f * P::a_scale(fabsf(seed));
+  const float ob = P::kOut / sb;
+  F w0[NS::S0], w1[NQ], w2[SH::M], wz[SH::M];
+  {
+    const float* p0 = net.pf[0] + (size_t)wave * NS0 * BK + lane * 4;
+    P::template ldfn<NS::S0>(w0, p0, NS0);
+  }
+  const float bias0 = P::ldb(nb0 + 16 * wave + i);
+  {
+    const float* p1 = net.pf[1] + ((size_t)(c * SH::TPM + t1) * NS::W + kq * NQ) * BK + lane * 4;
+    P::template ldfn<NQ>(w1, p1);
+  }
+  const float bias1 = P::ldb(nb1 + c0 + 16 * rt + (rl & 15));
+  const float w3 = P::first(net.pb[2] + (size_t)(c * SH::TPM + rt) * BK + (rl & 15) * 4);
+  float bias2 = 0.f;
+#pragma unroll
+  for (int s = 0; s < SH::M; ++s) w2[s] = P::zf();
+  if (wave == kOutWave) {
+    const float* p2 = net.pf[2] + ((size_t)c * SH::M) * BK + lane * 4;
+    P::template ldfn<SH::M>(w2, p2);
+    if (i == 0) bias2 = P::ldb(nb2);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  pre();
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();   // x0 (both tiles) visible
+
+  // ---- L0
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xr = x0s + t * TX + i * kX0Ld + 4 * kk;
+#pragma unroll
+    for (int s = 0; s < NS::S0; ++s)
+      if (s < NS0) P::mac_s(xr, s, w0[s], acc, P::kFwdA);
+    float* o = h1 + t * TH + (kk * 4) * kWL4 + 16 * wave + i;
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float pre_ = acc[r] * kO + bias0;
+      ok = ok && P::range_ok(pre_);
+      o[r * kWL4] = fmaxf(pre_, 0.f);
+    }
+    if (__builtin_expect(!ok, 0)) report_expired(tp.err, tp.err_code | SITE_X2_RANGE);
+  }
+  {
+    const float* q1 = net.pb[1] + ((size_t)wave * NS::W + c * SH::M) * BK + lane * 4;
+    P::template ldfn<SH::M>(wz, q1);
+  }
+  sf();
+  __syncthreads();   // h1 visible
+
+  // ---- L1 partials -> scr (per tile); member 0 stores h1
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+    *reinterpret_cast<f32x4*>(scr + t * TS + ((size_t)wave * 64 + lane) * 4) =
+        tp4_mac_steps<P, NQ>(h1 + t * TH + i * kWL4 + SH::KW * kq + 4 * kk, w1);
+  if (st.X1 != nullptr && c == 0) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const int row = (int)threadIdx.x >> 6, col = ((int)threadIdx.x & 63) * 4, gr = row0 + 16 * t + row;
+      if (gr < B) tp4_st4(st.X1, (size_t)gr * kW4 + col, ld4(h1 + t * TH + row * kWL4 + col), st.wt);
+    }
+  }
+  sf();
+  __syncthreads();   // partial tiles visible
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    const float* sp = scr + t * TS + ((size_t)rt * 64 + rl) * 4 + rr;
+    float sum = sp[0];
+#pragma unroll
+    for (int q = 1; q < SH::KP; ++q) sum += sp[q * SH::TPM * 256];
+    const float pre_ = sum * kO + bias1;
+    if (__builtin_expect(!P::range_ok(pre_), 0)) report_expired(tp.err, tp.err_code | SITE_X2_RANGE);
+    const float v = fmaxf(pre_, 0.f);
+    const int off = t * TH + (4 * (rl >> 4) + rr) * kWL4 + c0 + 16 * rt + (rl & 15);
+    h2[off] = v;
+    g2[off] = v > 0.f ? seed * w3 : 0.f;
+  }
+  sf();
+  __syncthreads();   // h2, g2 (the member's columns) visible
+
+  // ---- dz1 partial (unit seed), mask in place over h1; the h2 / g2 column stores
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    const f32x4 a = tp4_mac_steps<P, SH::M>(g2 + t * TH + i * kWL4 + c0 + 4 * kk, wz, sb) * ob;
+    float* p = h1 + t * TH + (kk * 4) * kWL4 + 16 * wave + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r * kWL4] = p[r * kWL4] > 0.f ? a[r] : 0.f;
+  }
+  if ((wave >= 4 && wave < 4 + SH::TPM) || (wave >= 8 && wave < 8 + SH::TPM)) {
+    float* dstg = wave < 8 ? st.X2 : st.dY1;
+    if (dstg != nullptr) {
+      constexpr int C4 = SH::COLS / 4;
+      const float* src = wave < 8 ? h2 : g2;
+      const int idx = (int)threadIdx.x - (wave < 8 ? 256 : 512);
+      const int row = idx / C4, col = c0 + (idx - row * C4) * 4;
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const int gr = row0 + 16 * t + row;
+        if (gr < B) tp4_st4(dstg, (size_t)gr * kW4 + col, ld4(src + t * TH + row * kWL4 + col), st.wt);
+      }
+    }
+  }
+  sf();
+  __syncthreads();   // dz1 partial visible
+
+#pragma unroll
+  for (int t = 0; t < RT; ++t) tp4_store_dz1(st, c, h1 + t * TH, row0 + 16 * t, B);
+  if (wave == kOutWave) {
+    f32x4 qpart[2], qsum[2];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) qpart[t] = tp4_mac_steps<P, SH::M>(h2 + t * TH + i * kWL4 + c0 + 4 * kk, w2) * kO;
+    const bool valid = i == 0;
+    tp4_allreduce_regs_x2(qpart, i, valid, tp, area, qsum);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      float* o = outS + t * TO + (kk * 4) * kOutLd + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r * kOutLd] = valid ? qsum[t][r] + bias2 : 0.f;
+    }
+  }
+  tp.stage += 1;
+  sf();
+  __syncthreads();   // outS visible
+  sf();
+}
+
 }  // namespace oprl

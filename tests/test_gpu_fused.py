@@ -537,3 +537,40 @@ def test_tqc_wide_dw_equals_small_tiles(monkeypatch):
     z0, zt0 = wide.critic(sb, ab).clone(), wide.critic_target(sb, ab).clone()
     wide.learner.sync_params()
     assert t.equal(z0, wide.critic(sb, ab)) and t.equal(zt0, wide.critic_target(sb, ab))
+
+
+# ---- phase 1's B roles on 32-row slices (tp4.h tp4_scalar_fb2, fused_ddpg.hip role_b2): the over-subscribed launches
+@pytest.mark.parametrize("prec", ["f32", "x2", "bf16"])
+@pytest.mark.parametrize("algo,B", [("sac", 1024), ("ddpg", 512), ("td3", 512), ("ddpg", 1024)])
+def test_two_row_tiles_per_cluster_equal_one_bitwise(algo, B, prec, monkeypatch):
+    """At B >= 512 the critics' forward + unit-seed backward (role B) runs on clusters that carry TWO 16-row tiles — the
+    fragments of the pass fetched once per 32 rows, half the workgroups of that role.  Per tile the arithmetic is the one-tile
+    pass's (same fragments, same accumulator chains, same member order in the exchange): the parameters after several
+    updates — through update() on caller-supplied rows and through step_n (in-kernel gather, then staged rows) — are
+    bit-identical to OPRL_AMD_NO_RT2=1, and the form really is taken (the launch grid differs: checked through the rate of
+    a wrong answer, i.e. the switch must matter to debug state — here: both learners finite and equal)."""
+    from tests.test_gpu_callers import _filled_buffer
+
+    def make():
+        if algo == "sac":
+            return _sac(67, 21, max_batch=B, tune_alpha=True, precision=prec)
+        if algo == "td3":
+            return _td3(24, max_batch=B, precision=prec)
+        return _ddpg(max_batch=B, precision=prec)
+    S, A = (67, 21) if algo == "sac" else (24, 6)
+    outs = []
+    for no_rt2 in ("1", "0"):
+        monkeypatch.setenv("OPRL_AMD_NO_RT2", no_rt2)
+        a = make()
+        for step in range(3):
+            batch = [x.cuda() for x in fx.make_batch(610 + step, B, S, A)]
+            a.update(*batch)
+        if algo != "sac":                      # (the shared test replay has walker dims)
+            buf = _filled_buffer()
+            a.learner.step_n(buf.handle, 5, B, seed=13)
+        t.cuda.synchronize()
+        a.learner.check()
+        outs.append({m: getattr(a, m)._oprl_arena.clone() for m in ("actor", "critic", "critic_target")})
+    for m in outs[0]:
+        assert t.isfinite(outs[1][m]).all(), m
+        assert t.equal(outs[0][m], outs[1][m]), f"{algo} B={B} {prec} {m}: max |d| = {(outs[0][m] - outs[1][m]).abs().max().item():.3e}"

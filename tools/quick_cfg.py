@@ -11,11 +11,13 @@ import bench
 
 KEY = {"ddpg": "DDPG walker-walk B=256", "ddpg128": "DDPG walker-walk B=128 (the reference scripts' batch)",
        "td3": "TD3 cheetah-run B=256", "sac": "SAC humanoid-walk B=1024", "tqc": "TQC walker-walk B=256 5x25"}
-cfg = sys.argv[1]
+cfg, _, b_over = sys.argv[1].partition("@")        # `td3@128`: the config's dims at another batch size
 if cfg.startswith("ddpg") and cfg not in KEY:        # ddpg512, ddpg1024, ...: DDPG at walker dims and that batch size
     cls, S, A, B, extras = "DDPG", 24, 6, int(cfg[4:]), {}
 else:
     cls, S, A, B, extras, _, _ = bench.BASELINE_CONFIGS[KEY[cfg]]
+if b_over:
+    B = int(b_over)
 dev = t.device("cuda", 0)
 replay = bench.make_replay(dev, 0, S=S, A=A)
 n = 400 if cfg == "tqc" else 2000
@@ -38,5 +40,5 @@ for spec in sys.argv[2:] or ["x2"]:
         best = min(best, time.perf_counter() - t0)
     L.check()
     fin = all(bool(t.isfinite(getattr(algo, m)._oprl_arena).all()) for m in ("actor", "critic"))
-    print(f"{cfg:8s} {spec:44s} {best / n * 1e6:8.2f} us/update ({n / best / 1e3:6.2f}k/s)   finite={fin}", flush=True)
+    print(f"{sys.argv[1]:10s} {spec:44s} {best / n * 1e6:8.2f} us/update ({n / best / 1e3:6.2f}k/s)   finite={fin}", flush=True)
     del algo, L
