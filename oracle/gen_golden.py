@@ -109,6 +109,19 @@ def grads(module):
     return [p.grad.detach().clone() for p in module.parameters()]
 
 
+def moments(out, tag, algo, n=256):
+    """Adam moments of both optimizers (torch.optim.Adam state: exp_avg / exp_avg_sq) in parameters() order — what a
+    parameter digest cannot show: Adam's step is scale-invariant in the gradient, the moments are not."""
+    oc = algo.optim_critic if hasattr(algo, "optim_critic") else algo.critic_optimizer      # (tqc.py:109-110 names them the other way round)
+    oa = algo.optim_actor if hasattr(algo, "optim_actor") else algo.actor_optimizer
+    for w, opt, mod in (("critic", oc, algo.critic), ("actor", oa, algo.actor)):
+        ps = list(mod.parameters())
+        if not all(p in opt.state and "exp_avg" in opt.state[p] for p in ps):
+            continue
+        out[f"{tag}.m_{w}"] = fx.digest_list([opt.state[p]["exp_avg"] for p in ps], n=n)
+        out[f"{tag}.v_{w}"] = fx.digest_list([opt.state[p]["exp_avg_sq"] for p in ps], n=n)
+
+
 def save(name, **arrays):
     OUT.mkdir(parents=True, exist_ok=True)
     flat = {}
@@ -210,6 +223,7 @@ def gen_td3():
                 out[f"{tag}.tq1"], out[f"{tag}.tq2"] = tq1, tq2
             out[f"{tag}.actor"] = fx.digest_list(plist(algo.actor))
             out[f"{tag}.critic"] = fx.digest_list(plist(algo.critic))
+            moments(out, tag, algo)
     save("td3_cheetah_b256", **out)
 
 
@@ -245,6 +259,7 @@ def gen_sac(env, B, seed, tune_alpha, n_steps, name):
                 out[f"{tag}.pi"], out[f"{tag}.logp"] = pi, lp
             out[f"{tag}.actor"] = fx.digest_list(plist(algo.actor))
             out[f"{tag}.critic"] = fx.digest_list(plist(algo.critic))
+            moments(out, tag, algo)
     out["alphas"] = np.array(alphas, np.float64)
     save(name, **out)
 
@@ -280,6 +295,7 @@ def gen_tqc():
                 out[f"{tag}.pi"], out[f"{tag}.logp"] = pi, lp
             out[f"{tag}.actor"] = fx.digest_list(plist(algo.actor))
             out[f"{tag}.critic"] = fx.digest_list(plist(algo.critic), n=64)
+            moments(out, tag, algo, n=64)
     out["log_alphas"] = np.array(log_alphas, np.float64)
 
     # standalone quantile-Huber known-answer case (value + gradient)

@@ -38,6 +38,15 @@ def g(x):
     return x.to(DEV)
 
 
+def hip_adam(algo, which):
+    """(m, v) of one optimizer as per-parameter CPU tensors, in the module's parameters() order (the learner keeps each
+    as one flat arena view)."""
+    L = algo.learner
+    mod = getattr(algo, which)
+    m, v = (L.critic_m, L.critic_v) if which == "critic" else (L.actor_m, L.actor_v)
+    return split_like(m, mod), split_like(v, mod)
+
+
 class HipDDPG:
     def __init__(self, S, A, actor, critic, **kw):
         self.args = (S, A, actor, critic)
@@ -99,6 +108,7 @@ class HipTD3:
         return (self.algo.actor_target if target else self.algo.actor)(g(s)).cpu()
 
     def params(self, which): return cpu_params(getattr(self.algo, which))
+    def adam(self, which): return hip_adam(self.algo, which)
 
 
 class HipSAC:
@@ -120,6 +130,7 @@ class HipSAC:
         return a.cpu(), lp.cpu()
 
     def params(self, which): return cpu_params(getattr(self.algo, which))
+    def adam(self, which): return hip_adam(self.algo, which)
 
     @property
     def alpha(self): return self.algo.alpha
@@ -143,6 +154,7 @@ class HipTQC:
         return a.cpu(), lp.cpu()
 
     def params(self, which): return cpu_params(getattr(self.algo, which))
+    def adam(self, which): return hip_adam(self.algo, which)
 
     @property
     def log_alpha(self): return float(self.algo.log_alpha.item())

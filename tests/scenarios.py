@@ -107,6 +107,17 @@ class OracleDDPG:
         self._g = (self.o.last["g_critic"], self.o.last["g_actor"])
 
 
+def _moments(out, tag, algo, n=256):
+    """m / v digests of both optimizers, as oracle/gen_golden.py moments() wrote them (an optimizer that has not
+    stepped yet — none in these scripts — has no state and no keys)."""
+    for w in ("critic", "actor"):
+        m, v = algo.adam(w)
+        if not m:
+            continue
+        out[f"{tag}.m_{w}"] = fx.digest_list(m, n=n)
+        out[f"{tag}.v_{w}"] = fx.digest_list(v, n=n)
+
+
 def ddpg_scenario(make, B=256):
     S, A = fx.ENVS["walker"]
     seed = 100
@@ -153,6 +164,9 @@ class OracleTD3:
     def pi(self, s, target=False):
         return orc.det_policy_forward(self.o.actor_target if target else self.o.actor, s)[0]
     def params(self, which): return getattr(self.o, which)
+    def adam(self, which):
+        opt = self.o.opt_critic if which == "critic" else self.o.opt_actor
+        return opt.m, opt.v
 
 
 def td3_scenario(make, B=256):
@@ -174,6 +188,7 @@ def td3_scenario(make, B=256):
         out[f"{tag}.tq1"], out[f"{tag}.tq2"] = algo.q(s, a, 0, True), algo.q(s, a, 1, True)
         out[f"{tag}.actor"] = fx.digest_list(algo.params("actor"))
         out[f"{tag}.critic"] = fx.digest_list(algo.params("critic"))
+        _moments(out, tag, algo)
     return flatten(out)
 
 
@@ -190,6 +205,9 @@ class OracleSAC:
         a, lp, _ = orc.gaussian_forward(self.o.actor, s, eps, self.A)
         return a, lp
     def params(self, which): return getattr(self.o, which)
+    def adam(self, which):
+        opt = self.o.opt_critic if which == "critic" else self.o.opt_actor
+        return opt.m, opt.v
     @property
     def alpha(self): return self.o.alpha
 
@@ -213,6 +231,7 @@ def sac_scenario(make, env, B, seed, tune_alpha, n_steps):
         out[f"{tag}.pi"], out[f"{tag}.logp"] = algo.pi_logp(s, fx.make_noise(seed + 98, (B, A)))
         out[f"{tag}.actor"] = fx.digest_list(algo.params("actor"))
         out[f"{tag}.critic"] = fx.digest_list(algo.params("critic"))
+        _moments(out, tag, algo)
     out["alphas"] = np.array(alphas, np.float64)
     return flatten(out)
 
@@ -233,6 +252,9 @@ class OracleTQC:
         if which == "critic":
             return [x for c in self.o.critics for x in c]
         return self.o.actor
+    def adam(self, which):
+        opt = self.o.opt_critic if which == "critic" else self.o.opt_actor
+        return opt.m, opt.v
     @property
     def log_alpha(self): return float(self.o.log_alpha)
 
@@ -257,6 +279,7 @@ def tqc_scenario(make, n_steps=2, B=256):
         out[f"{tag}.pi"], out[f"{tag}.logp"] = algo.pi_logp(s, fx.make_noise(seed + 98, (B, A)))
         out[f"{tag}.actor"] = fx.digest_list(algo.params("actor"))
         out[f"{tag}.critic"] = fx.digest_list(algo.params("critic"), n=64)
+        _moments(out, tag, algo, n=64)
     out["log_alphas"] = np.array(las, np.float64)
     return flatten(out)
 

@@ -17,10 +17,10 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
-def _both(got, name, oracle_out, skip=()):
+def _both(got, name, oracle_out, skip=(), moment_tol=None):
     gold = sc.load_golden(name)
-    w1 = sc.compare(got, gold, TOL, skip=skip, param_tol=sc.PARAM_TOL)
-    w2 = sc.compare(got, {k: v for k, v in oracle_out.items()}, TOL, skip=skip, param_tol=sc.PARAM_TOL)
+    w1 = sc.compare(got, gold, TOL, skip=skip, param_tol=sc.PARAM_TOL, moment_tol=moment_tol)
+    w2 = sc.compare(got, {k: v for k, v in oracle_out.items()}, TOL, skip=skip, param_tol=sc.PARAM_TOL, moment_tol=moment_tol)
     print(f"{name}: worst vs golden {w1}, vs oracle {w2}")
 
 
@@ -41,7 +41,13 @@ def test_sac_humanoid_b1024():
 
 def test_sac_walker_tuned_alpha():
     got = sc.sac_scenario(ha.HipSAC, "walker", 256, 350, True, 3)
-    _both(got, "sac_walker_tune_b256", sc.sac_scenario(sc.OracleSAC, "walker", 256, 350, True, 3))
+    # The Adam moments (round 6: every scenario returns them; a parameter digest cannot show a gradient-scale error, Adam's
+    # step being scale-invariant) sit at 4e-7 .. 1.4e-6 in every other scenario.  This one holds rows whose hidden
+    # pre-activation is within rounding of zero in the actor's first update: measured (tools/probe_moments.py, MI355X box)
+    # the reference's vectors vs the oracle run on ANOTHER host 3.3e-4 (actor moments only; 1e-5 on the host that generated
+    # them), this learner vs the vectors 1.1e-4, vs that oracle 3.3e-4, the x2 learner 3.4e-4 / 1.1e-4 — one ReLU mask of
+    # one row each way (scenarios.compare); the actor's parameters agree to 1e-5 all the same.  Gate: 1e-3.
+    _both(got, "sac_walker_tune_b256", sc.sac_scenario(sc.OracleSAC, "walker", 256, 350, True, 3), moment_tol=1e-3)
 
 
 def test_tqc_walker_b256():
@@ -60,8 +66,11 @@ def test_all_algos_against_the_oracle_at_ragged_batches(B):
              ("sac", sc.sac_scenario(ha.HipSAC, "walker", B, 350, True, 3),
               sc.sac_scenario(sc.OracleSAC, "walker", B, 350, True, 3), ()),
              ("tqc", sc.tqc_scenario(ha.HipTQC, B=B), sc.tqc_scenario(sc.OracleTQC, B=B), ("qh.",))]
+    # (Adam moments: a ReLU mask of ONE row that falls the other way is 1 / B of a gradient element — see
+    # test_sac_walker_tuned_alpha; at a handful of rows the moment gate only says "same shape, finite, same scale")
     for name, got, want, skip in cases:
-        worst = sc.compare(got, {k: v for k, v in want.items()}, TOL, skip=skip, param_tol=sc.PARAM_TOL)
+        worst = sc.compare(got, {k: v for k, v in want.items()}, TOL, skip=skip, param_tol=sc.PARAM_TOL,
+                           moment_tol=max(1e-3, 0.25 / B))
         print(f"{name} B={B}: worst vs oracle {worst}")
 
 
