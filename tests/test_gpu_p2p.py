@@ -48,10 +48,13 @@ def make_shard(rank):
 # update — whose 16 x 64 dW tiles all-reduce their gradients with the other rank's before Adam (dw_tile_x2.h): no
 # all-reduce launches, no apply launches.  Since round 6 the same holds for ("ddpg", 2, "f32") and ("ddpg", 2, "bf16"):
 # k_ddpg_chain<PrecF32 / PrecBF16> with the exchange in its tiles (the worker reports the form the rank ran).
-@pytest.mark.parametrize("algo_name,level,prec", [("ddpg", 2, "f32"), ("ddpg", 1, "f32"), ("sac", 1, "f32"), ("td3", 1, "f32"),
-                                                  ("ddpg", 2, "x2"), ("ddpg", 2, "bf16")])
-def test_two_process_p2p_data_parallel_step(algo_name, level, prec):
-    K, B, world = 6, 32, 2
+# world 4 / 3 / 8 (level 1 only: the in-tile exchange needs every rank's tile workgroups resident together, which one GPU
+# offers to two ranks): the window kernels' slot arithmetic, flag counts and rank-ordered sums beyond a pair of ranks.
+@pytest.mark.parametrize("algo_name,level,prec,world", [("ddpg", 2, "f32", 2), ("ddpg", 1, "f32", 2), ("sac", 1, "f32", 2), ("td3", 1, "f32", 2),
+                                                        ("ddpg", 2, "x2", 2), ("ddpg", 2, "bf16", 2),
+                                                        ("ddpg", 1, "f32", 4), ("sac", 1, "f32", 3), ("ddpg", 1, "f32", 8)])
+def test_two_process_p2p_data_parallel_step(algo_name, level, prec, world):
+    K, B = 6, 32
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as td:
         rdv, out = os.path.join(td, "rdv"), os.path.join(td, "out")
@@ -67,7 +70,8 @@ def test_two_process_p2p_data_parallel_step(algo_name, level, prec):
         assert all(r["form"]["dp_inline_form"] == 4 for r in res), [r["form"] for r in res]
     for m in ("critic", "actor"):
         d = (res[0]["arenas"][m] - res[1]["arenas"][m]).abs().max().item()
-        assert t.equal(res[0]["arenas"][m], res[1]["arenas"][m]), f"replicas diverged: {m} (max |d| = {d:.3e})"
+        for r in range(1, world):
+            assert t.equal(res[0]["arenas"][m], res[r]["arenas"][m]), f"replicas diverged: {m}, rank {r} (ranks 0 / 1: max |d| = {d:.3e})"
         assert t.isfinite(res[0]["arenas"][m]).all()
     # single-process emulation: two export_grads learners, gradients summed in rank order
     L = [make_algo(algo_name, B, export_grads=True, precision=prec) for _ in range(world)]
@@ -85,10 +89,14 @@ def test_two_process_p2p_data_parallel_step(algo_name, level, prec):
             for r in range(world):
                 L[r].learner.update_phase(phase, *batches[r])
             total = getattr(L[0].learner, which) + getattr(L[1].learner, which)
+            for r in range(2, world):                      # (rank order, left to right: the windows' sum)
+                total = total + getattr(L[r].learner, which)
             for r in range(world):
                 getattr(L[r].learner, which).copy_(total)
             if phase == 1 and L[0].learner.log_alpha_grad is not None:
                 ta = L[0].learner.log_alpha_grad + L[1].learner.log_alpha_grad
+                for r in range(2, world):
+                    ta = ta + L[r].learner.log_alpha_grad
                 for r in range(world):
                     L[r].learner.log_alpha_grad.copy_(ta)
             for r in range(world):
@@ -170,6 +178,30 @@ def test_bench_two_rank_rehearsal_on_one_gpu(prec):
     # in either parity mode a rank that exchanges inside its tiles runs the single-GPU whole-update launch
     assert chk["inline_form"] == 4, chk
     assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 64, d["config"]
+
+
+@pytest.mark.parametrize("n", [4, 8])
+def test_bench_many_rank_rehearsal_on_one_gpu(n):
+    """The same rehearsal with 4 and 8 ranks on this GPU — world sizes the driver's scaling run uses.  The in-tile exchange
+    cannot come up here (every rank's tile workgroups would have to be resident together on ONE chip: its probe fails or
+    is dropped, by design), so the line must come from the window kernels (level 1) with bit-identical replicas: rank
+    bookkeeping, window slots, flag counts, the max over ranks and the one line from rank 0 at dp4 / dp8."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OPRL_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("MASTER_PORT", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                          "--master-addr", "127.0.0.1", "--master-port", str(29560 + n), os.path.join(root, "bench.py"), "--gpus", str(n),
+                          "--steps", "40", "--warmup", "5", "--pre-warm", "40", "--profile-steps", "40", "--precision", "f32"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = [x for x in out.stdout.splitlines() if x.strip().startswith("{")][-1]
+    d = json.loads(line)
+    chk = d["data_parallel_check"]
+    assert d["n_gpus"] == n and d["steps"] == 40 and d["value"] > 0 and d["rehearsal"], d
+    assert chk["finite"] and chk["replicas_identical"], chk
+    assert chk["exchange"] in ("p2p", "p2p-inline") and "p2p" in chk["probe_us_per_step"], chk
+    assert d["config"]["parallelism"] == f"dp{n}" and d["config"]["global_batch"] == 32 * n, d["config"]
 
 
 def test_bench_prints_its_line_when_the_run_fails():
