@@ -534,6 +534,68 @@ __device__ __forceinline__ void lw_tqc_target(const TqcJob& J, const MlpArgs& A,
   if (lane + 64 < Mt) J.target[(size_t)row * Mt + lane + 64] = rr + coef * (v1 - al);
 }
 
+// A slice's [16 x 512] rows of `src` into `hb` and the NARROW product out = rows · pack (NTo <= 2 output tiles over the 32
+// steps of a 512-deep contraction) with EVERYTHING requested at entry: the rows, this wave's fragments (its steps of its
+// tile: at most four), the bias element of the thread that finishes an element — then `more()` (the caller's further
+// requests).  Through load_rows4 + gemm_packed the fragments were requested after the rows had landed and been staged:
+// one more cold round trip on launches of 80 workgroups that are nothing but a latency chain (r06-10).  The products and
+// their order are gemm_packed's narrow form (engine.h): epi(row, col, sum + bias) once per element, a barrier behind it.
+template <class More, class Epi>
+__device__ __forceinline__ void lw_rows_narrow_gemm(const float* __restrict__ src, const float* __restrict__ pack, int NTo, bool run,
+                                                    const float* __restrict__ bias, int nbias, int row0, int B, float* hb,
+                                                    float* scr, More&& more, Epi&& epi) {
+  constexpr int WIDTH = 512, WL = lds_ld(WIDTH), NTW = WIDTH / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
+  f32x4 rv[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int idx = tid + h * kThreads, row = idx >> 7, col = (idx & 127) * 4, gr = row0 + row;
+    rv[h] = gr < B ? ld4(src + (size_t)gr * WIDTH + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int wpt = kWaves / NTo, tile_f = wave / wpt, part = wave - tile_f * wpt;
+  const int per = cdiv(NTW, wpt), s0 = part * per, s1 = min(NTW, s0 + per);      // per = 2 / 4
+  f32x4 fb[4];
+  {
+    const float* pl = pack + ((size_t)tile_f * NTW) * 256 + lane * 4;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) fb[d] = (run && s0 + d < s1) ? ld4(pl + (size_t)(s0 + d) * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool rmine = tid < kR * 16 * NTo;
+  const int rt = tid / (kR * 16), rrem = tid - rt * (kR * 16), rrow = rrem >> 4, rcol = 16 * rt + (rrem & 15);
+  const float rb = (run && bias != nullptr && rmine && rcol < nbias) ? bias[rcol] : 0.f;
+  more();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int idx = tid + h * kThreads;
+    *reinterpret_cast<f32x4*>(hb + (idx >> 7) * WL + (idx & 127) * 4) = rv[h];
+  }
+  __syncthreads();                                    // the rows are visible
+  if (!run) return;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* xrow = hb + i * WL + 4 * kk;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const int st = s0 + d;
+    if (st < s1) {
+      const f32x4 a4 = ld4(xrow + 16 * st);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc = mfma4(a4[t], fb[d][t], acc);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) scr[(wave * kR + kk * 4 + r) * 16 + i] = acc[r];
+  __syncthreads();
+  if (rmine) {
+    float v = 0.f;
+    const float* sp = scr + ((rt * wpt) * kR + rrow) * 16 + (rrem & 15);
+#pragma unroll 4
+    for (int pq = 0; pq < wpt; ++pq) v += sp[pq * kR * 16];
+    epi(rrow, rcol, v + rb);
+  }
+  __syncthreads();
+}
+
 // R (n_ride = 4): ANOTHER net's k_mlp_slice_tp launch on the same slices — its clusters of four ride as the
 // workgroups blockIdx.z >= nets (slice_tp_body.h).  The heads are (slices x nets) workgroups, 80 of TQC's 256 CUs:
 // the actor's forward on s, which the actor step needs only after the critic step, runs beside the critic step's
@@ -567,6 +629,58 @@ __global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M, cons
   float* scr = smem + LY::scr;
   const int slice = blockIdx.x, row0 = slice * kR, B = A.B;
   const int L = A.net.n_layers, Nout = A.net.dims[L];
+  const int NTo = cdiv(Nout, 16);
+  if (NTo <= 2 && WIDTH == 512) {
+    // ---- narrow heads (TQC: 25 quantiles): EVERYTHING the workgroup will need is requested at entry — the slice's rows, this
+    // wave's fragments of the forward head and (`more`) of the backward step: its two column tiles, two steps each.  Through
+    // gemm_packed the backward fragments were requested after the seeds.  Same products in the same order (engine.h).
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kk = lane >> 4;
+    f32x4 bb[2][2];
+    lw_rows_narrow_gemm(A.Xg[L - 1], A.net.pf[L - 1], NTo, A.do_fwd != 0, A.net.b[L - 1], Nout, row0, B, hb, scr,
+                        [&]() {
+#pragma unroll
+                          for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int st = 0; st < 2; ++st)
+                              bb[q][st] = (A.do_bwd && st < NTo)
+                                              ? ld4(A.net.pb[L - 1] + ((size_t)(wave + kWaves * q) * NTo + st) * 256 + lane * 4)
+                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+                        },
+                        [&](int row, int col, float v) { outS[row * kOutLd + col] = col < Nout ? v : 0.f; });
+    if (A.do_fwd) slice_head(A, outS, Nout, row0, true);
+    if (!A.do_bwd) {
+      if (J.counter != nullptr) {
+        __syncthreads();                                  // slice_head is done with outS / scr
+        lw_tqc_target(J, A, outS, Nout, row0, slice);
+      }
+      return;
+    }
+    slice_seed(A, outS, auxS, scr, Nout, L, row0, slice, true);
+    __syncthreads();                                    // dout visible
+    // dz[L-2] = (dout W_{L-1}) * [h > 0], in place over the activations (each element's mask is read by the lane that
+    // overwrites it): wave w owns column tiles w and w + 16
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* xrow = auxS + i * kOutLd + 4 * kk;
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+        if (st < NTo) {
+          const f32x4 a4 = ld4(xrow + 16 * st);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc = mfma4(a4[t], bb[q][st][t], acc);
+        }
+      const int col = 16 * (wave + kWaves * q) + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* pp = hb + (kk * 4 + r) * WL + col;
+        *pp = *pp > 0.f ? acc[r] : 0.f;
+      }
+    }
+    __syncthreads();
+    store_rows4(hb, WL, A.dYg[L - 2], WIDTH, WIDTH, row0, B);
+    return;
+  }
   load_rows4(hb, WL, A.Xg[L - 1], WIDTH, WIDTH, row0, B);
   if (A.do_fwd) {
     gemm_packed(hb, WL, A.net.pf[L - 1], cdiv(Nout, 16), NTW, scr, A.net.b[L - 1], Nout,
@@ -613,11 +727,16 @@ __global__ __launch_bounds__(kThreads) void k_lw_dact(const MlpMultiArgs M, cons
   float* scr = smem + LY::scr;
   const int row0 = blockIdx.x * kR, B = A.B;
   const int c0 = A.dact_col0, nc = A.dact_cols;
-  load_rows4(xs, WL, A.dYg[0], WIDTH, WIDTH, row0, B);
-  gemm_packed(xs, WL, A.net.pb[0], cdiv(A.net.dims[0], 16), NTW, scr, nullptr, 0, [&](int row, int col, float v) {
+  auto epi = [&](int row, int col, float v) {
     const int c = col - c0;
     if (c >= 0 && c < nc) dactS[row * kOutLd + c] = v;
-  });
+  };
+  if (WIDTH == 512 && cdiv(A.net.dims[0], 16) <= 2) {     // (a narrow net input: rows and fragments requested together)
+    lw_rows_narrow_gemm(A.dYg[0], A.net.pb[0], cdiv(A.net.dims[0], 16), true, nullptr, 0, row0, B, xs, scr, [] {}, epi);
+  } else {
+    load_rows4(xs, WL, A.dYg[0], WIDTH, WIDTH, row0, B);
+    gemm_packed(xs, WL, A.net.pb[0], cdiv(A.net.dims[0], 16), NTW, scr, nullptr, 0, epi);
+  }
   store_rows(dactS, kOutLd, A.dact, A.lddact, nc, row0, B);
 }
 
