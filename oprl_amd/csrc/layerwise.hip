@@ -509,7 +509,11 @@ __device__ __forceinline__ void lw_tqc_target(const TqcJob& J, const MlpArgs& A,
     }
     return v;
   };
+  // (what the epilogue needs, requested with the samples: behind the sort they were one more round trip)
+  const double la = *J.log_alpha;
+  const float lp = J.logp[row], dd = J.d[row], rr = J.r[row];
   float v0 = fetch(lane), v1 = fetch(lane + 64);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 2; k <= 128; k <<= 1) {
 #pragma unroll
@@ -526,10 +530,9 @@ __device__ __forceinline__ void lw_tqc_target(const TqcJob& J, const MlpArgs& A,
       }
     }
   }
-  const float alpha = (float)exp(*J.log_alpha);
-  const float al = alpha * J.logp[row];
-  const float coef = (1.f - J.d[row]) * J.gamma;
-  const float rr = J.r[row];
+  const float alpha = (float)exp(la);
+  const float al = alpha * lp;
+  const float coef = (1.f - dd) * J.gamma;
   if (lane < Mt) J.target[(size_t)row * Mt + lane] = rr + coef * (v0 - al);
   if (lane + 64 < Mt) J.target[(size_t)row * Mt + lane + 64] = rr + coef * (v1 - al);
 }
@@ -636,8 +639,10 @@ __global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M, cons
     // gemm_packed the backward fragments were requested after the seeds.  Same products in the same order (engine.h).
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kk = lane >> 4;
     f32x4 bb[2][2];
+    SeedPre sp;
     lw_rows_narrow_gemm(A.Xg[L - 1], A.net.pf[L - 1], NTo, A.do_fwd != 0, A.net.b[L - 1], Nout, row0, B, hb, scr,
                         [&]() {
+                          sp = seed_pre_request(A, row0);       // (the quantile-Huber seed's target samples)
 #pragma unroll
                           for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M, cons
       }
       return;
     }
-    slice_seed(A, outS, auxS, scr, Nout, L, row0, slice, true);
+    slice_seed(A, outS, auxS, scr, Nout, L, row0, slice, true, sp);
     __syncthreads();                                    // dout visible
     // dz[L-2] = (dout W_{L-1}) * [h > 0], in place over the activations (each element's mask is read by the lane that
     // overwrites it): wave w owns column tiles w and w + 16

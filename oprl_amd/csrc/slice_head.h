@@ -101,8 +101,26 @@ __device__ __forceinline__ void slice_head(const MlpArgs& A, const float* outS, 
 
 // Loss-gradient seed -> auxS (zero padded), per-slice diagnostics, dY of the output layer.
 // Ends with a barrier-separated, fully written auxS (the backward pass syncs before reading).
+// SeedPre: the quantile-Huber seed's target samples of this thread (elements tid and tid + kThreads of the slice's
+// [kR][M] block), requested by the caller long before — k_lw_head asks for them at entry (seed_pre_request below).
+struct SeedPre { float v[2] = {0.f, 0.f}; bool on = false; };
+__device__ __forceinline__ SeedPre seed_pre_request(const MlpArgs& A, int row0) {
+  SeedPre P;
+  if (A.seed_mode != SEED_QHUBER || !A.do_bwd) return P;
+  const SeedArgs& S = A.seed;
+  const int M = S.M;
+  if (kR * M > kWaves * kR * 16 || kR * M > 2 * kThreads) return P;
+  P.on = true;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = (int)threadIdx.x + k * kThreads, row = idx / M, gr = row0 + row;
+    P.v[k] = (idx < kR * M && gr < A.B) ? S.p0[(size_t)gr * M + (idx - row * M)] : 0.f;
+  }
+  return P;
+}
+
 __device__ __forceinline__ void slice_seed(const MlpArgs& A, const float* outS, float* auxS, float* scr,
-                                           int Nout, int L, int row0, int slice, bool lead) {
+                                           int Nout, int L, int row0, int slice, bool lead, const SeedPre pre = SeedPre()) {
   const int tid = threadIdx.x, B = A.B;
   // ---- loss-gradient seed -> auxS (zero padded) -----------------------------
   lds_zero(auxS, kR * kOutLd);
@@ -185,7 +203,12 @@ __device__ __forceinline__ void slice_seed(const MlpArgs& A, const float* outS, 
       // read from global inside the loop they are M dependent L1 round trips per thread — 20 of the
       // 29 us of the head launch of TQC's critic step
       const bool staged = kR * M <= kWaves * kR * 16;
-      if (staged) {
+      if (staged && pre.on) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (tid + k * kThreads < kR * M) scr[tid + k * kThreads] = pre.v[k];
+        __syncthreads();
+      } else if (staged) {
         for (int idx = tid; idx < kR * M; idx += kThreads) {
           const int row = idx / M, gr = row0 + row;
           scr[idx] = gr < B ? S.p0[(size_t)gr * M + (idx - row * M)] : 0.f;
