@@ -31,7 +31,13 @@ struct DwWideArgs {
   AdamScalars ad;
 };
 static_assert(kWThreads == kDwThreads, "the riding k_dw_adam tiles run in this kernel's workgroups");
+#ifdef DWW_SMALL_LDS      // tools/ubench_dw_wide.hip: the wide tiles alone at three workgroups per compute unit (r06-11)
+constexpr int kWLdsFloats = 2 * kWChunk * kWLd;
+#define DWW_ATTR __attribute__((amdgpu_waves_per_eu(6, 8)))
+#else
 constexpr int kWLdsFloats = 2 * kWChunk * kWLd > kDwLdsFloats ? 2 * kWChunk * kWLd : kDwLdsFloats;
+#define DWW_ATTR
+#endif
 
 // `N`: the SAME update's narrow layers (TQC's critics: the 30 x 512 input layers and the 512 x 25 heads), whose
 // 16 x 32 tiles of k_dw_adam (dw_body.h) ride as the workgroups past `total` — dispatched last, they fill the
@@ -40,14 +46,16 @@ constexpr int kWLdsFloats = 2 * kWChunk * kWLd > kDwLdsFloats ? 2 * kWChunk * kW
 #ifdef DWW_TRACE
 __device__ unsigned long long g_dww_trace[1024 * 8];
 #endif
-__global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, const DwKArgs N) {
+__global__ __launch_bounds__(kWThreads) DWW_ATTR void k_dw_adam_wide(const DwWideArgs A, const DwKArgs N) {
   __shared__ __attribute__((aligned(16))) float lds[kWLdsFloats];
+#ifndef DWW_SMALL_LDS
   if ((int)blockIdx.x >= A.grid_own) {
     const char* kp = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
     dw_adam_body<false>(*(const DwKArgs*)(kp + ((sizeof(DwWideArgs) + alignof(DwKArgs) - 1) / alignof(DwKArgs)) * alignof(DwKArgs)),
                         lds, (int)blockIdx.x - A.grid_own);
     return;
   }
+#endif
   float (*stA)[kWLd] = reinterpret_cast<float (*)[kWLd]>(lds);                      // dY rows [b][n]; later the new W tile
   float (*stX)[kWLd] = reinterpret_cast<float (*)[kWLd]>(lds + kWChunk * kWLd);     // X  rows [b][k]; later the new target tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -130,7 +138,9 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, 
   };
   const int n_chunks = (B + kWChunk - 1) / kWChunk;
   request(0);
+#ifndef DWW_LATE_STATE
   if (n_chunks <= 1) request_state();
+#endif
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     __syncthreads();                      // the previous chunk's reads are done
 #pragma unroll
@@ -140,7 +150,9 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, 
     }
     if (chunk + 1 < n_chunks) {
       request(chunk + 1);                           // in flight during this chunk's MFMAs
+#ifndef DWW_LATE_STATE
       if (chunk + 2 == n_chunks) request_state();
+#endif
     }
     __syncthreads();
     if (chunk == 0) DWW_STAMP(1);
@@ -150,10 +162,18 @@ __global__ __launch_bounds__(kWThreads) void k_dw_adam_wide(const DwWideArgs A, 
       const float x0 = stX[4 * u + c][kb * 16 + i];
       const float x1 = stX[4 * u + c][kb * 16 + 16 + i];
       sA += av;
+#ifdef DWW_NO_MFMA           // tools/ubench_dw_wide.hip: what the launch costs without its matrix time (r06-11)
+      acc[0][u & 3] += av * x0;
+      acc[1][u & 3] += av * x1;
+#else
       acc[0] = mfma4(av, x0, acc[0]);
       acc[1] = mfma4(av, x1, acc[1]);
+#endif
     }
   }
+#ifdef DWW_LATE_STATE
+  request_state();
+#endif
   __syncthreads();
   DWW_STAMP(2);
   // gradient tile -> stA[n][k] (acc row = n index 4c + r, column = k index i); db -> stX[0][n]

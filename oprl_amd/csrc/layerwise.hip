@@ -148,7 +148,7 @@ struct LwRun2 { int slices, nets, rpn, base, rem, ppx; };   // runs per net; til
 // written through (sc1) and, once every wave's stores are acknowledged, flag X.flags[(net, slice, run)] = {tag, *} goes
 // up; 2 = the second layer's — weight fragments, bias / masks first, then a bounded wait for the rpn flags of its
 // (net, slice), then the rows with sc1 loads.  MAXRUN: the longest run of column tiles (the partial tiles' LDS).
-struct LwPair { unsigned long long* flags; unsigned tag; int spin; unsigned* err; };
+struct LwPair { unsigned long long* flags; unsigned tag; int spin; unsigned* err; int wait_net0; };   // wait_net0: ROLE 2 waits for the flags of nets >= wait_net0 only (the others' rows come from an earlier launch)
 #ifdef LW_TRACE            // tools/ubench_lw.hip: stage stamps of the hidden-layer workgroups (100 MHz wall clock)
 __device__ unsigned long long g_lw_trace[4096 * 8];
 #define LW_STAMP(k) do { if (threadIdx.x == 0 && bx < 4096) g_lw_trace[bx * 8 + (k)] = wall_clock64(); } while (0)
@@ -278,7 +278,7 @@ __device__ __forceinline__ void lw_mid_run2_body(const MlpMultiArgs* KM, int l, 
       int* s_okp = reinterpret_cast<int*>(xin);              // (a word behind the rows: no static LDS — two workgroups per CU)
       if (wave == 0) {
         bool ok = true;
-        if (lane < R.rpn) {
+        if (lane < R.rpn && net0 + net >= X->wait_net0) {
           const unsigned long long* f = X->flags + ((size_t)(net0 + net) * R.slices + slice) * kLwFlagStride + lane;
           ok = false;
           for (int spin = 0; spin < X->spin && !ok; ++spin) {
@@ -452,10 +452,18 @@ __global__ __launch_bounds__(kThreads) void k_slice_tp_fin(const MlpMultiArgs M,
 
 // The rest of such a first launch — the nets that did not fit beside k_slice_tp_fin's host — as riders of a head
 // launch (k_lw_head, blockIdx.z >= z0): their own argument block, R.nets nets from net0 on.
+// z1 >= 0 (r06-12): behind the tail, the SECOND hidden layer's forward of ALL of M's nets rides too (blockIdx.z >= z1, run
+// shape R2) — the online critics' layer on (s, a) that was a launch of its own (k_lw_mid_run2<0>, 240 workgroups, 8.9 us)
+// between the target pass's heads and the online heads.  The tail's workgroups then publish their rows as the first
+// layer of a k_lw_mid_pair does (written through + a flag per run: X), and the riders of the nets >= net0 wait for those
+// flags; the other nets' rows are an earlier launch's.  Same arithmetic as the stand-alone launch: bit-identical rows.
 struct LwFinTail {
   MlpMultiArgs M;
   LwRun2 R;
   int net0, z0, prec;     // z0 < 0: nothing rides; prec: 0 fp32, 1 bf16, 2 split fp16 (the hidden layer's packs)
+  LwRun2 R2;
+  LwPair X;
+  int z1;
 };
 
 inline LwRun2 lw_run2(int B, int nets, int n_cus) {
@@ -613,7 +621,20 @@ __global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M, cons
   extern __shared__ __attribute__((aligned(16))) float smem[];        // max(LwLds<WIDTH>::total, SliceLds<256>::total(2)[, kLwRun2Lds]) floats
   if (F.z0 >= 0 && (int)blockIdx.z >= F.z0) {
     const LwFinTail* KF = (const LwFinTail*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kLwHeadTailOffset);
+    if (F.z1 >= 0 && (int)blockIdx.z >= F.z1) {             // the second hidden layer's forward, all nets
+      const int bx = ((int)blockIdx.z - F.z1) * (int)gridDim.x + (int)blockIdx.x;
+      if (F.prec == 2) lw_mid_run2_body<0, PrecX2, 2>(&KF->M, 2, KF->R2, bx, 0, &KF->X);
+      else if (F.prec == 1) lw_mid_run2_body<0, PrecBF16, 2>(&KF->M, 2, KF->R2, bx, 0, &KF->X);
+      else lw_mid_run2_body<0, PrecF32, 2>(&KF->M, 2, KF->R2, bx, 0, &KF->X);
+      return;
+    }
     const int bx = ((int)blockIdx.z - F.z0) * (int)gridDim.x + (int)blockIdx.x;
+    if (F.z1 >= 0) {                                        // the tail publishes its rows for those riders
+      if (F.prec == 2) lw_mid_run2_body<2, PrecX2, 1>(&KF->M, 1, KF->R, bx, F.net0, &KF->X);
+      else if (F.prec == 1) lw_mid_run2_body<2, PrecBF16, 1>(&KF->M, 1, KF->R, bx, F.net0, &KF->X);
+      else lw_mid_run2_body<2, PrecF32, 1>(&KF->M, 1, KF->R, bx, F.net0, &KF->X);
+      return;
+    }
     if (F.prec == 2) lw_mid_run2_body<2, PrecX2>(&KF->M, 1, KF->R, bx, F.net0);
     else if (F.prec == 1) lw_mid_run2_body<2, PrecBF16>(&KF->M, 1, KF->R, bx, F.net0);
     else lw_mid_run2_body<2, PrecF32>(&KF->M, 1, KF->R, bx, F.net0);
@@ -883,8 +904,10 @@ hipError_t launch_mlp_layerwise_first(const MlpArgs* t, int t_n, int t0, int wid
 //   tail[tail0 ..] rides on this launch's heads (LwFinTail); null: nothing
 hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, int prec, const TqcJob* job,
                                 const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, int tail_prec,
-                                const PrefetchJob* prefetch, const LwPairBuf* pairs) {
+                                const PrefetchJob* prefetch, const LwPairBuf* pairs, bool second_done, bool* second_rode) {
+  if (second_rode != nullptr) *second_rode = false;
   if (!mlp_layerwise_ok(a, n, width)) return hipErrorInvalidValue;
+  if (second_done && !first_done) return hipErrorInvalidValue;
   if (first_done && !mlp_layerwise_fin_ok(a, n, width)) return hipErrorInvalidValue;
   if (tail != nullptr && (!mlp_layerwise_fin_ok(tail, tail_n, width) || tail0 < 0 || tail0 >= tail_n || tail[0].B != a[0].B))
     return hipErrorInvalidValue;
@@ -924,6 +947,7 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
   auto pair = [&](int dir, int la, int lb) {       // dir 0: forward (first layer folded in) + forward, 1: backward + backward
     LwPair X;
     X.flags = pairs->flags; X.tag = pairs->next_tag + (unsigned)pairs->used; X.spin = pairs->spin; X.err = pairs->err;
+    X.wait_net0 = 0;
     pairs->used += 1;
     const int nb = 8 * rp.ppx * rp.slices;
     const dim3 grid(2 * nb);
@@ -947,6 +971,7 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
     } else {
       for (int l = 1; l + 1 < L; ++l) {
         if (l == 1 && first_done) continue;
+        if (l == 2 && second_done) continue;
         mid(l == 1 && fuse_in ? 2 : 0, l);
       }
     }
@@ -955,7 +980,7 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
     constexpr size_t head_f = LwLds<512>::total, ride_f = SliceLds<256>::total(2);
     size_t lds = sizeof(float) * (rider != nullptr && ride_f > head_f ? ride_f : head_f);
     int z = n + (rider != nullptr ? 4 : 0);
-    static const LwFinTail none = [] { LwFinTail f; memset((void*)&f, 0, sizeof f); f.z0 = -1; return f; }();
+    static const LwFinTail none = [] { LwFinTail f; memset((void*)&f, 0, sizeof f); f.z0 = -1; f.z1 = -1; return f; }();
     LwFinTail ft_local;
     const LwFinTail* ft = &none;
     if (tail != nullptr) {
@@ -965,6 +990,21 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
       ft_local.net0 = tail0; ft_local.z0 = z; ft_local.prec = tail_prec;
       z += (8 * ft_local.R.ppx * ft_local.R.slices + slices - 1) / slices;
       if (kLwRun2Lds > lds) lds = kLwRun2Lds;
+      // ... and behind it the second hidden layer's forward of all of the tail's nets (a net of four layers; the flags of
+      // the pair launches carry the tail's hand-over)
+      ft_local.z1 = -1;
+      memset((void*)&ft_local.X, 0, sizeof ft_local.X);
+      ft_local.R2 = lw_run2(tail[0].B, tail_n, n_cus > 0 ? n_cus : 256);
+      if (second_rode != nullptr && pairs != nullptr && pairs->flags != nullptr && (pairs->use & 4) != 0 && tail[0].net.n_layers == 4 &&
+          ft_local.R2.base + (ft_local.R2.rem ? 1 : 0) <= kLw2MaxRun && ft_local.R2.rpn <= kLwFlagStride &&
+          tail_n * ft_local.R2.slices * kLwFlagStride <= pairs->n_flags) {
+        ft_local.X.flags = pairs->flags; ft_local.X.tag = pairs->next_tag + (unsigned)pairs->used;
+        ft_local.X.spin = pairs->spin; ft_local.X.err = pairs->err; ft_local.X.wait_net0 = tail0;
+        pairs->used += 1;
+        ft_local.z1 = z;
+        z += (8 * ft_local.R2.ppx * ft_local.R2.slices + slices - 1) / slices;
+        *second_rode = true;
+      }
       ft = &ft_local;
     }
     const dim3 heads(slices, 1, z);

@@ -472,6 +472,8 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
       }
       const bool first_done = h->fin_done && h->multi_args[0].do_bwd && h->multi_args[0].do_fwd && h->multi_args[0].Xg[0] != nullptr;
       if (first_done) h->fin_done = false;
+      const bool second_done = first_done && h->fin_l2_done;
+      if (first_done) h->fin_l2_done = false;
       // the part of the online critics' early first launch that did not fit beside the actor's forward rides on the
       // target pass's heads (forward-only launch, 80 workgroups)
       const MlpArgs* tail = nullptr;
@@ -492,7 +494,8 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
         h->prefetch_done = true;
       }
       hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, h->n_cus, st, lw16 ? (h->x2 ? 2 : 1) : 0, job, rider, first_done,
-                                          tail, h->nc, tail0, h->fin16 ? (h->x2 ? 2 : 1) : 0, pf, &h->lw_pairs);
+                                          tail, h->nc, tail0, h->fin16 ? (h->x2 ? 2 : 1) : 0, pf, &h->lw_pairs, second_done,
+                                          tail != nullptr ? &h->fin_l2_done : nullptr);
       // (a tag per pair launch; 2^32 launches on: every flag is retired before a tag can come round again)
       if (h->lw_pairs.next_tag + (unsigned)h->lw_pairs.used < h->lw_pairs.next_tag && h->lw_pairs.flags != nullptr)
         (void)hipMemsetAsync(h->lw_pairs.flags, 0, (size_t)h->lw_pairs.n_flags * sizeof(unsigned long long), st);
@@ -1064,6 +1067,7 @@ int critic_phase(oprl_learner* h, const float* s, const float* a, const float* r
     bool fin_ride = false, fin16 = false;
     MlpArgs* fin_args = h->fin_args;
     h->fin_done = false;
+    h->fin_l2_done = false;
     h->fin_tail0 = -1;
     if (algo == OPRL_TQC && !h->no_fin_ride && !h->no_layerwise && !h->no_multi && nc > 2 && nc <= kMaxMulti &&
         h->lw_scratch != nullptr && h->w_critic == 512 && f.tp_xbuf != nullptr) {

@@ -247,7 +247,8 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     h->no_multi = false;
     // OPRL_AMD_NO_RIDE = bit mask of the riders / joined launches to switch off (tests: each is bit-identical to the
     // separate launches): 1 TD target on the target heads, 2 actor forward on the critic heads, 4 first hidden launch
-    // behind the actor's forward, 8 next rows on k_lw_dact, 16 wide dW kernel (kernels.hip), 32 hidden-layer pairs
+    // behind the actor's forward, 8 next rows on k_lw_dact, 16 wide dW kernel (kernels.hip), 32 hidden-layer pairs,
+    // 64 the online critics' second hidden layer behind the tail on the target heads (r06-12)
     const int no_ride = [] { const char* e = getenv("OPRL_AMD_NO_RIDE"); return e != nullptr ? atoi(e) : 0; }();
     const char* nlw = getenv("OPRL_AMD_NO_LAYERWISE");
     h->no_layerwise = (nlw != nullptr && atoi(nlw) != 0);
@@ -264,12 +265,12 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
       const size_t n = (size_t)nc * (kMaxLayers - 1) * (size_t)h->Bmax * 512;
       if (hipMalloc(&h->lw_scratch, n * sizeof(float)) != hipSuccess) h->lw_scratch = nullptr;   // (then: the nets' own buffers, no early launch)
       {
-        const int pair_env = (no_ride & 32) != 0 ? 0 : 3;
+        const int pair_env = (no_ride & 32) != 0 ? 0 : ((no_ride & 64) != 0 ? 3 : 7);
         const int nf = kMaxMulti * ((h->Bmax + 31) / 32) * 32;
         void* fl = nullptr;
         if (pair_env != 0 && hipMalloc(&fl, (size_t)nf * sizeof(unsigned long long)) == hipSuccess) {
           (void)hipMemset(fl, 0, (size_t)nf * sizeof(unsigned long long));
-          h->lw_pairs.flags = (unsigned long long*)fl; h->lw_pairs.n_flags = nf; h->lw_pairs.use = pair_env & 3;
+          h->lw_pairs.flags = (unsigned long long*)fl; h->lw_pairs.n_flags = nf; h->lw_pairs.use = pair_env & 7;
           h->lw_pairs.err = h->err_dev;
         }
       }

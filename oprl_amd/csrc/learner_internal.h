@@ -39,7 +39,7 @@ hipError_t launch_mlp_slice_multi(const MlpArgs* a, int n, int width, hipStream_
 bool mlp_layerwise_ok(const MlpArgs* a, int n, int width);
 hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, int prec, const TqcJob* job,
                                 const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, int tail_prec,
-                                const PrefetchJob* prefetch, const LwPairBuf* pairs);
+                                const PrefetchJob* prefetch, const LwPairBuf* pairs, bool second_done = false, bool* second_rode = nullptr);
 bool mlp_layerwise_fin_ok(const MlpArgs* a, int n, int width);
 int mlp_layerwise_fin_fit(const MlpArgs* a, int n, int host_wgs, int n_cus);
 hipError_t launch_slice_tp_with_fin(const MlpArgs& host, const MlpArgs* a, int n, int n_ride, int width, int n_cus, hipStream_t st,
@@ -309,6 +309,7 @@ struct oprl_learner {
   MlpArgs fin_args[OPRL_MAX_CRITICS];   // TQC: the online critics' first-launch arguments of this update (critic_phase step 1) ...
   int fin_tail0 = -1;          // ... of which [fin_tail0, nc) did not fit beside the actor's forward: offered to the target pass's head launch (-1: none pending)
   bool fin16 = false;
+  bool fin_l2_done = false;    // ... and the second hidden layer's forward rode on the target pass's heads behind the tail (r06-12); step 3 skips it too
   bool fin_done = false;       // TQC: the online critics' first hidden launch rode on the actor's forward on s' (critic_phase step 1); step 3 skips it
   bool no_fin_ride = false;    // OPRL_AMD_NO_RIDE bit 4: it stays the first launch of step 3 (tests / A-B)
   LwPairBuf lw_pairs = {nullptr, 0, 1u, 1 << 20, nullptr, 3, 0};   // k_lw_mid_pair: flags (own allocation), tags; OPRL_AMD_LW_PAIR: bit 0 forward, bit 1 backward pairs (default 3)
