@@ -558,7 +558,32 @@ __device__ __forceinline__ int ddpg_phase1_body(const DdpgArgs& A, const KA* D =
     // ---- role A: a' = tanh(actor_target(s')) (TD3: + clipped noise), q' = critic_target(s', a')
     // (TD3: min over the twin targets), TD target                    (ddpg.py:94-95, td3.py:83-101)
     // (SAC: a' ~ pi(s') from the online actor, log pi(a'|s') kept per row     sac.py:90-97)
-    tp_fwd<WIDTH, LEAN, P, NMA>(SAC ? A.actor : A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp, rows);
+    bool ac_done = false;
+    if constexpr (SAC && RT2) {
+      if (A.rt2 == 2) {
+        // SAC, over-subscribed launches (r06-13): a' ~ pi(s') and the actor step's pi(s) come from the SAME net — one pass on
+        // two row tiles (tp4.h tp4_forward2: the fragments requested once), and role C — a dispatch round of its own behind
+        // this role — is not launched.  Tile 1 (s): what role C does — pi, log pi, the raw head, X[0 .. 2] for the actor's dW;
+        // it exchanges through role C's cluster area of the slice.
+        static_assert(kR * lds_ld(WIDTH) >= kWaves * 256, "the second tile's partial tiles fit a hidden buffer");
+        Tp4Two T;
+        T.x0[0] = xb; T.x0[1] = xa;
+        T.h1[0] = h1; T.h1[1] = h1 + 2 * HB;
+        T.h2[0] = h2; T.h2[1] = h1 + 3 * HB;
+        T.out[0] = outS; T.out[1] = auxS;
+        T.scr[0] = scr; T.scr[1] = h1 + 4 * HB;
+        T.st[0] = nostore;
+        T.st[1] = Tp3Store{A.aX[1], A.aX[2], nullptr, nullptr, 0};
+        const size_t area = (size_t)role_c * gridDim.x * kTpStages * A.xnc * kTpBlk;
+        tp4_forward2<P>(A.actor, T, tp, area, row0, B, stamp, rows);
+        if (lead) {
+          gauss_head(auxS, row0, B, Ad, A.noise_pi, A.rng_seed_pi, A.rng_ctr, nullptr, 0, nullptr, A.pi, A.raw, A.logp);
+          store_rows(xa, kX0Ld, A.aX[0], A.aldx0, S, row0, B);
+        }
+        ac_done = true;
+      }
+    }
+    if (!ac_done) tp_fwd<WIDTH, LEAN, P, NMA>(SAC ? A.actor : A.actor_t, xb, h1, h2, outS, scr, tp, nostore, row0, B, stamp, rows);
     const bool send_a2 = TWIN && A.twin_split && lead;
     unsigned long long* x_a2 = send_a2 ? x_slot(role_c) : nullptr;
     if constexpr (SAC)
@@ -1994,7 +2019,8 @@ hipError_t launch_ddpg_phase1(const DdpgArgs& a, hipStream_t st) {
   }
   if (a.rt2) {      // the B roles on 32-row slices (learner.hip decides: lean, clusters of four, slices a multiple of 16)
     if (!lean_ok(a) || a.nc != 4 || (slices & 15) != 0 || pf || a.merged != 0) return hipErrorInvalidValue;
-    const dim3 g2(slices, 2 * a.n_critics + 2 * a.nc);
+    if (a.rt2 == 2 && (!a.sac || a.twin_split || !a.do_actor)) return hipErrorInvalidValue;   // (role A carries role C's pass: SAC's one actor)
+    const dim3 g2(slices, 2 * a.n_critics + (a.rt2 == 2 ? 1 : 2) * a.nc);
     const size_t l2 = std::max(lds, sizeof(float) * (size_t)FusedLdsB2::total);
     if (a.sac) {
       if (a.x2) hipLaunchKernelGGL((k_ddpg_phase1_rt2<true, PrecX2>), g2, blk, l2, st, a);

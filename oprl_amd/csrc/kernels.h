@@ -412,7 +412,7 @@ struct DdpgArgs {      // the fused DDPG / TD3 update (csrc/fused_ddpg.hip)
   float* w3_snap;                      // the actor's output layer [A][256] as it is before phase 2, copied by phase 1's role C (slice 0)
   const float* w3_src;                 // ... from here (the row-major master)
   int no_lean;                         // 1: never use the tp4.h specialisation (OPRL_AMD_NO_LEAN, tests)
-  int rt2;                             // 1: phase 1's B roles carry TWO row tiles (32 rows) per cluster (k_ddpg_phase1_rt2: over-subscribed launches, B a multiple of 256)
+  int rt2;                             // (2: ... and SAC's role A carries role C's pass — the same actor on s — as a second row tile: no role C rows)  1: phase 1's B roles carry TWO row tiles (32 rows) per cluster (k_ddpg_phase1_rt2: over-subscribed launches, B a multiple of 256)
   int xcd_local;                       // 1: a slice cluster whose members all see their expected XCD may publish its granules at workgroup scope
                                        // (the HOST's decision — the dispatcher was probed, OPRL_AMD_NO_XCD_LOCAL, no expired cluster wait so far —
                                        // and the same for every member: fused_ddpg.hip cluster_on_one_xcd)

@@ -745,8 +745,14 @@ DdpgArgs ddpg_args(oprl_learner* h, int B) {
     // (twin critics only — TD3, SAC: their two B roles then share the first dispatch round; measured, r06-6: SAC humanoid
     // B = 1024 - 3.7 us per update in every mode, TD3 B = 512 - 4.7, SAC B = 512 - 5; a single critic's one B role on half the
     // workgroups only lengthens the wait of role A behind it: DDPG B = 512 + 1.8 us, B = 1024 + 2.4 .. 4)
-    a.rt2 = (!h->no_rt2 && h->nc == 2 && a.merged == 0 && (a.wide & 1) == 0 && a.nc == 4 && fused_ddpg_is_lean(a) && (slices & 15) == 0 &&
+    a.rt2 = (h->no_rt2 != 1 && h->nc == 2 && a.merged == 0 && (a.wide & 1) == 0 && a.nc == 4 && fused_ddpg_is_lean(a) && (slices & 15) == 0 &&
              (2 + h->nc) * 4 * slices > h->n_cus && !a.prefetch_p1) ? 1 : 0;
+    // SAC there: role A's first pass — the online actor on s' — also carries role C's pass, the same actor on s (tp4_forward2;
+    // bit-identical): role C's dispatch round is not launched (r06-13; OPRL_AMD_NO_RT2=2 keeps role C)
+    // (where role A alone fills the chip — humanoid B = 1024: -3.1 us x2, -2.1 f32 / bf16 per update; at B = 512 role C ran
+    // beside role A's second half and the merged pass is 3.5 us SLOWER: a tile's pass is bound by instruction issue, not by
+    // its fragments, so the second tile costs a pass's 6.4 us, not the 2 - 3 us the B roles' shared fragments suggested)
+    if (a.rt2 == 1 && a.sac && !a.twin_split && a.do_actor && h->no_rt2 == 0 && 4 * slices >= h->n_cus) a.rt2 = 2;
   }
   // (an exchanging rank outside PrecX2 has the in-tile exchange in the whole-update form only: whatever kept that form
   // away, its merged phase launch — 16 x 32 tiles that exchange nothing — must not run either)

@@ -304,7 +304,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     const char* nw = getenv("OPRL_AMD_NO_WIDE");
     h->no_wide = (nw != nullptr && atoi(nw) != 0) ? 1 : 0;
     h->no_merge_twin = (no_ride & 64) != 0 ? 1 : 0;
-    { const char* e = getenv("OPRL_AMD_NO_RT2"); h->no_rt2 = (e != nullptr && atoi(e) != 0) ? 1 : 0; }
+    { const char* e = getenv("OPRL_AMD_NO_RT2"); h->no_rt2 = e != nullptr ? atoi(e) : 0; if (h->no_rt2 < 0 || h->no_rt2 > 2) h->no_rt2 = 1; }   // 1: one row tile everywhere; 2: the B roles' two tiles, but SAC's role C stays a role of its own
     const char* nxl = getenv("OPRL_AMD_NO_XCD_LOCAL");
     h->xcd_local = h->fused && !(nxl != nullptr && atoi(nxl) != 0) && xcd_map_ok();
     // the generic per-net launches on clusters of 4 (slice_tp.hip): any net of the common shape

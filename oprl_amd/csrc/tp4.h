@@ -986,4 +986,145 @@ __device__ __forceinline__ void tp4_scalar_fb2(const Net& net, const float* x0s,
   sf();
 }
 
+// ---------------------------------------------------------------------------------------
+// tp4_forward on TWO row tiles with DIFFERENT inputs through the same net (clusters of four): SAC's online actor on s'
+// (the target chain's a') and on s (the actor step's pi(s)) in ONE pass of role A of the over-subscribed phase-1
+// launches (r06-13) — role C, a dispatch round of 256 workgroups of its own behind role A (10 us at humanoid
+// B = 1024), disappears; its pass costs the fragments' second use here.  Per tile the arithmetic is tp4_forward<P, 4>'s
+// (same fragments, same chains, same member order in the exchange): bit-identical to two one-tile workgroups.
+// Tile t: input T.x0[t], buffers T.h1[t] / T.h2[t] / T.out[t] / T.scr[t] ([kWaves][256] floats), stores T.st[t]; tile 0
+// exchanges through tp.xbuf, tile 1 through tp.xbuf + area (the cluster area of the role it replaces).
+struct Tp4Two {
+  const float* x0[2];
+  float* h1[2];
+  float* h2[2];
+  float* out[2];
+  float* scr[2];
+  Tp3Store st[2];
+};
+template <class P = PrecF32, class ST = NoStamp, class PRE = NoStamp>
+__device__ __forceinline__ void tp4_forward2(const Net& net, const Tp4Two& T, Tp& tp, size_t area, int row0, int B,
+                                             ST sf = ST(), PRE pre = PRE()) {
+  constexpr int NM = 4, RT = 2;
+  using NS = Tp4Steps<P>;
+  using SH = Tp4Shape<P, NM>;
+  const float* const nb0 = net.b[0];
+  const float* const nb1 = net.b[1];
+  const float* const nb2 = net.b[2];
+  asm volatile("" :: "s"(net.pf[0]), "s"(net.pf[1]), "s"(net.pf[2]), "s"(nb0), "s"(nb1), "s"(nb2),
+               "s"(net.dims[0]), "s"(net.dims[3]));
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  const int c = tp.c, c0 = c * SH::COLS;
+  const int N = net.dims[3];
+  const int NS0 = (net.dims[0] + P::KS - 1) / P::KS, NTo = (N + 15) >> 4;
+  const int t2 = wave - 4;
+  const bool l2_wave = t2 >= 0 && t2 < NTo;
+  constexpr int NQ = SH::NQ;
+  const int t1 = wave % SH::TPM, kq = wave / SH::TPM;
+  const int rt = (int)threadIdx.x >> 8, rl = ((int)threadIdx.x & 255) >> 2, rr = (int)threadIdx.x & 3;
+
+  // ---- requests: once for both row tiles
+  using F = typename P::Frag;
+  constexpr int BK = P::kBlk;
+  constexpr float kO = P::kOut / P::kFwdA;
+  F w0[NS::S0], w1[NQ], w2[SH::M];
+  {
+    const float* p0 = net.pf[0] + (size_t)wave * NS0 * BK + lane * 4;
+    P::template ldfn<NS::S0>(w0, p0, NS0);
+  }
+  const float bias0 = P::ldb(nb0 + 16 * wave + i);
+  {
+    const float* p1 = net.pf[1] + ((size_t)(c * SH::TPM + t1) * NS::W + kq * NQ) * BK + lane * 4;
+    P::template ldfn<NQ>(w1, p1);
+  }
+  const float bias1 = P::ldb(nb1 + c0 + 16 * rt + (rl & 15));
+  float bias2 = 0.f;
+#pragma unroll
+  for (int s = 0; s < SH::M; ++s) w2[s] = P::zf();
+  if (l2_wave) {
+    const float* p2 = net.pf[2] + ((size_t)t2 * NS::W + c * SH::M) * BK + lane * 4;
+    P::template ldfn<SH::M>(w2, p2);
+    if (16 * t2 + i < N) bias2 = P::ldb(nb2 + 16 * t2 + i);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  pre();
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();   // x0 (both tiles) visible
+
+  // ---- L0
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xr = T.x0[t] + i * kX0Ld + 4 * kk;
+#pragma unroll
+    for (int s = 0; s < NS::S0; ++s)
+      if (s < NS0) P::mac_s(xr, s, w0[s], acc, P::kFwdA);
+    float* o = T.h1[t] + (kk * 4) * kWL4 + 16 * wave + i;
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float pre_ = acc[r] * kO + bias0;
+      ok = ok && P::range_ok(pre_);
+      o[r * kWL4] = fmaxf(pre_, 0.f);
+    }
+    if (__builtin_expect(!ok, 0)) report_expired(tp.err, tp.err_code | SITE_X2_RANGE);
+  }
+  sf();
+  __syncthreads();   // h1 visible
+
+  // ---- L1 partials -> scr (per tile); member 0 stores h1 of the tiles that keep it
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+    *reinterpret_cast<f32x4*>(T.scr[t] + ((size_t)wave * 64 + lane) * 4) =
+        tp4_mac_steps<P, NQ>(T.h1[t] + i * kWL4 + SH::KW * kq + 4 * kk, w1);
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+    if (T.st[t].X1 != nullptr && c == 0) {
+      const int row = (int)threadIdx.x >> 6, col = ((int)threadIdx.x & 63) * 4, gr = row0 + row;
+      if (gr < B) tp4_st4(T.st[t].X1, (size_t)gr * kW4 + col, ld4(T.h1[t] + row * kWL4 + col), T.st[t].wt);
+    }
+  sf();
+  __syncthreads();   // partial tiles visible
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    const float* sp = T.scr[t] + ((size_t)rt * 64 + rl) * 4 + rr;
+    float v = sp[0];
+#pragma unroll
+    for (int q = 1; q < SH::KP; ++q) v += sp[q * SH::TPM * 256];
+    const float pre_ = v * kO + bias1;
+    if (__builtin_expect(!P::range_ok(pre_), 0)) report_expired(tp.err, tp.err_code | SITE_X2_RANGE);
+    T.h2[t][(4 * (rl >> 4) + rr) * kWL4 + c0 + 16 * rt + (rl & 15)] = fmaxf(pre_, 0.f);
+  }
+  __syncthreads();   // the member's h2 columns visible
+
+  // ---- L2 partials + both tiles' all-reduce from registers on waves 4..; waves 8.. store the h2 columns
+  if (l2_wave) {
+    f32x4 part[2], sum[2];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) part[t] = tp4_mac_steps<P, SH::M>(T.h2[t] + i * kWL4 + c0 + 4 * kk, w2) * kO;
+    const int col = 16 * t2 + i;
+    const bool valid = col < N;
+    tp4_allreduce_regs_x2(part, col, valid, tp, area, sum);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      float* o = T.out[t] + (kk * 4) * kOutLd + col;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r * kOutLd] = valid ? sum[t][r] + bias2 : 0.f;
+    }
+  } else if (wave >= 8 && wave < 8 + SH::TPM) {
+    constexpr int C4 = SH::COLS / 4;
+    const int idx = (int)threadIdx.x - 512;
+    const int row = idx / C4, col = c0 + (idx - row * C4) * 4, gr = row0 + row;
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+      if (T.st[t].X2 != nullptr && gr < B) tp4_st4(T.st[t].X2, (size_t)gr * kW4 + col, ld4(T.h2[t] + row * kWL4 + col), T.st[t].wt);
+  }
+  tp.stage += 1;
+  sf();
+  __syncthreads();   // out (both tiles) visible
+  sf();
+}
+
 }  // namespace oprl

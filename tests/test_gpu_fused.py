@@ -594,7 +594,9 @@ def test_two_row_tiles_per_cluster_equal_one_bitwise(algo, B, prec, monkeypatch)
         return _ddpg(max_batch=B, precision=prec)
     S, A = (67, 21) if algo == "sac" else (24, 6)
     outs = []
-    for no_rt2 in ("1", "0"):
+    # ("2", SAC at B = 1024: the B roles' two tiles, but role C a role of its own — against "0", where role A's first pass
+    # carries role C's pass as a second row tile, tp4_forward2: r06-13)
+    for no_rt2 in (("1", "2", "0") if algo == "sac" else ("1", "0")):
         monkeypatch.setenv("OPRL_AMD_NO_RT2", no_rt2)
         a = make()
         for step in range(3):
@@ -607,5 +609,6 @@ def test_two_row_tiles_per_cluster_equal_one_bitwise(algo, B, prec, monkeypatch)
         a.learner.check()
         outs.append({m: getattr(a, m)._oprl_arena.clone() for m in ("actor", "critic", "critic_target")})
     for m in outs[0]:
-        assert t.isfinite(outs[1][m]).all(), m
-        assert t.equal(outs[0][m], outs[1][m]), f"{algo} B={B} {prec} {m}: max |d| = {(outs[0][m] - outs[1][m]).abs().max().item():.3e}"
+        for o in outs[1:]:
+            assert t.isfinite(o[m]).all(), m
+            assert t.equal(outs[0][m], o[m]), f"{algo} B={B} {prec} {m}: max |d| = {(outs[0][m] - o[m]).abs().max().item():.3e}"
