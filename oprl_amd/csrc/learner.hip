@@ -1664,7 +1664,11 @@ extern "C" int oprl_learner_step_n(oprl_learner* h, oprl_replay* replay, int32_t
     // k_ddpg_chain: up to chain_max updates per launch, the rows of update u + 1 staged by update u inside the launch
     const bool chain = chain_ok(h, B);
     const DdpgArgs probe = ddpg_args(h, B);
-    h->prefetch_p1 = !chain && alt != nullptr && (probe.merged & 2) != 0;
+    // (... and TD3's merged twin launches in every arithmetic, r06-15: without the merged phase 2 — exact fp32, bf16 — a
+    // critic-only update had no launch that staged the next rows, and the update behind it gathered its own inside the roles'
+    // first stage: 4.8 us against 2.9 before the first barrier of every role of every second launch)
+    const bool td3_p1 = h->cfg.algo == OPRL_TD3 && (probe.merged & 1) != 0 && !h->no_p1_rows;
+    h->prefetch_p1 = !chain && alt != nullptr && ((probe.merged & 2) != 0 || td3_p1);
     int cur = 0;
     int rc = OPRL_OK;
     h->staged_ready = false;

@@ -261,6 +261,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
         h->batch_alt = nullptr;   // (then: a gather launch per update)
     }
     h->no_fin_ride = (no_ride & 4) != 0;
+    { const char* e = getenv("OPRL_AMD_NO_P1_ROWS"); h->no_p1_rows = e != nullptr && atoi(e) != 0; }
     if (cfg->algo == OPRL_TQC && h->w_critic == 512) {
       const size_t n = (size_t)nc * (kMaxLayers - 1) * (size_t)h->Bmax * 512;
       if (hipMalloc(&h->lw_scratch, n * sizeof(float)) != hipSuccess) h->lw_scratch = nullptr;   // (then: the nets' own buffers, no early launch)

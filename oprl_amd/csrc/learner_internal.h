@@ -309,6 +309,7 @@ struct oprl_learner {
   MlpArgs fin_args[OPRL_MAX_CRITICS];   // TQC: the online critics' first-launch arguments of this update (critic_phase step 1) ...
   int fin_tail0 = -1;          // ... of which [fin_tail0, nc) did not fit beside the actor's forward: offered to the target pass's head launch (-1: none pending)
   bool fin16 = false;
+  bool no_p1_rows = false;     // OPRL_AMD_NO_P1_ROWS: TD3's exact-fp32 / bf16 merged launches carry no next-rows row (tests / A-B; r06-15)
   bool fin_l2_done = false;    // ... and the second hidden layer's forward rode on the target pass's heads behind the tail (r06-12); step 3 skips it too
   bool fin_done = false;       // TQC: the online critics' first hidden launch rode on the actor's forward on s' (critic_phase step 1); step 3 skips it
   bool no_fin_ride = false;    // OPRL_AMD_NO_RIDE bit 4: it stays the first launch of step 3 (tests / A-B)
