@@ -50,7 +50,12 @@ def _is_moment_key(k: str) -> bool:
     return any(f".{w}." in k for w in ("m_critic", "v_critic", "m_actor", "v_actor"))
 
 
-def compare(got: dict, want: dict, tol: float, skip=(), param_tol: float | None = None, moment_tol: float | None = None):
+MOMENT_ELEM_TOL = 1e-4      # an Adam-moment element counts as "off" beyond this (relative to the key's largest magnitude) ...
+MOMENT_OFF_FRAC = 0.15      # ... and at most this share of a moment key's elements may be off
+
+
+def compare(got: dict, want: dict, tol: float, skip=(), param_tol: float | None = None, moment_tol: float | None = None,
+            moment_off_frac: float | None = MOMENT_OFF_FRAC):
     """max-norm relative deviation per key; returns worst (key, dev).
 
     ``param_tol`` (GPU runs) applies to parameter / Adam-state digests: an
@@ -64,8 +69,18 @@ def compare(got: dict, want: dict, tol: float, skip=(), param_tol: float | None 
     the DDPG scenario, tools/x2_probe.py: every moment agrees to 2e-7 through nine updates, then h1 unit 97 / h2 unit
     30 flip for one row and that unit's gradient differs by that row's term, 1.6e-3 of the largest moment; the
     parameters still agree to 1e-7).  Any two fp32 implementations with different summation orders do this to each
-    other; the exact-fp32 mode happens not to on these seeds."""
+    other; the exact-fp32 mode happens not to on these seeds.
+
+    Whatever the max-norm gate of a moment key is, the NUMBER of its elements further than ``MOMENT_ELEM_TOL`` from the
+    expected value is bounded too (``MOMENT_OFF_FRAC`` of one optimizer state's sampled elements at one probe): a flipped ReLU unit of one row moves that unit's
+    gradient row and what that row sends down the layers below — measured: 151 of the 1299 sampled elements of the x2
+    DDPG learner's m_critic after update 10 (11.6 %; 84 of them in one layer's sample), ~ 6 % of the tuned-alpha SAC actor's
+    (every mode, the oracle on another host included: tools/probe_moments.py), 0 everywhere else.  More flipped units — a wrong mask, a wrong seed for a group of rows — raise the count
+    long before they raise the max-norm.  (``moment_off_frac=None``: a comparison across arithmetics — the bf16 learner
+    against the fp32 vectors or against its emulation, where hidden activations sit on bf16 rounding boundaries — where
+    elements are "off" by design.)"""
     worst = ("", 0.0)
+    off_counts: dict = {}
     for k, w in want.items():
         if k == "meta" or any(k.startswith(s) for s in skip):
             continue
@@ -82,6 +97,15 @@ def compare(got: dict, want: dict, tol: float, skip=(), param_tol: float | None 
         if moment_tol is not None and _is_moment_key(k):
             lim = moment_tol
         assert dev <= lim, f"{k}: rel dev {dev:.3e} > {lim:.1e}"
+        if moment_off_frac is not None and _is_moment_key(k):
+            # (counted over all the sampled layers of one optimizer state at one probe: "after10.m_critic")
+            a, b = np.asarray(g, np.float64).ravel(), np.asarray(w, np.float64).ravel()
+            grp = k.split(".")[0] + "." + k.split(".")[1]
+            n_off, n_all = off_counts.get(grp, (0, 0))
+            off_counts[grp] = (n_off + int((np.abs(a - b) > MOMENT_ELEM_TOL * max(np.abs(b).max(), 1e-30)).sum()), n_all + a.size)
+    for grp, (n_off, n_all) in off_counts.items():
+        assert n_all < 64 or n_off <= moment_off_frac * n_all, \
+            f"{grp}: {n_off} of {n_all} sampled elements are more than {MOMENT_ELEM_TOL:.0e} off (limit {moment_off_frac:.0%})"
     return worst
 
 

@@ -55,12 +55,12 @@ def _check(name, got, emu, gold, skip=(), emu_out=TOL_EMU_OUT, emu_param=TOL_EMU
     late_actor = {k: v for k, v in emu.items() if is_actor_m(k) and not k.startswith("after1.")}
     critic_m = {k: v for k, v in emu.items() if is_critic_m(k)}
     rest = {k: v for k, v in emu.items() if not is_actor_m(k) and not is_critic_m(k)}
-    we = sc.compare(got, rest, emu_out, skip=skip, param_tol=emu_param)
+    we = sc.compare(got, rest, emu_out, skip=skip, param_tol=emu_param, moment_off_frac=None)
     for part, gate, what in ((first_actor, emu_actor_first if emu_actor_first is not None else emu_param, "the actor's Adam moments after the first update"),
                              (late_actor, max(1e-3, emu_moment or 0.0), "the actor's Adam moments after the later updates"),
                              (critic_m, emu_moment if emu_moment is not None else emu_param, "the critics' Adam moments")):
         if part:
-            wl = sc.compare(got, part, emu_out, param_tol=gate)
+            wl = sc.compare(got, part, emu_out, param_tol=gate, moment_off_frac=None)   # (not a parity mode: no element-count bound)
             print(f"\n[bf16] {name}: {what} vs the emulation: worst {wl[1]:.2e} ({wl[0]}), gate {gate:.0e}")
     # gradient-like keys (step-1 gradient samples, Adam moments): single elements, cancellation-prone
     def grad_like(k):
@@ -69,7 +69,7 @@ def _check(name, got, emu, gold, skip=(), emu_out=TOL_EMU_OUT, emu_param=TOL_EMU
                     param_tol=TOL_REF_PARAM)
     grads = {k: v for k, v in gold.items() if grad_like(k)}
     if grads:
-        sc.compare(got, grads, TOL_REF_GRAD, param_tol=TOL_REF_GRAD)
+        sc.compare(got, grads, TOL_REF_GRAD, param_tol=TOL_REF_GRAD, moment_off_frac=None)
     print(f"\n[bf16] {name}: worst rel. deviation vs bf16 emulation {we[1]:.2e} ({we[0]}), "
           f"vs fp32 reference vectors {wr[1]:.2e} ({wr[0]})")
 
