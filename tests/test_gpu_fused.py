@@ -484,7 +484,7 @@ def test_tqc_second_hidden_layer_riding_on_the_target_heads_equals_its_own_launc
                    precision=prec).create()
 
     riding = make()
-    monkeypatch.setenv("OPRL_AMD_NO_RIDE", "64")          # (read when the learner is created)
+    monkeypatch.setenv("OPRL_AMD_NO_RIDE", "128")         # (read when the learner is created)
     own = make()
     for step in range(3):
         batch = [x.cuda() for x in fx.make_batch(90 + step, B, 24, 6)]
