@@ -43,6 +43,12 @@ struct SeedArgs {
   int Q;             // QHUBER: quantiles per net
   float* y_out;      // MSE_TD: TD target [B] (debug / diagnostics), may be null
   float* q_out;      // MSE_TD: current q [B], may be null
+  // GAUSS, the backward riding on the launch that PRODUCES da (k_lw_dact, r06-16): flag (net n, slice) =
+  // da_flags[n * da_fstride + slice] = {da_tag, *} once that net's rows of the slice are written through; null: da is an
+  // earlier launch's
+  const unsigned long long* da_flags;
+  unsigned da_tag;
+  int da_fstride, da_spin;
 };
 
 struct MlpArgs {

@@ -735,11 +735,21 @@ __global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M, cons
 
 // Pj (blockIdx.z == Pj.z0): one more row of workgroups gathers the NEXT update's minibatch rows from the replay
 // (step_n: a k_replay_gather launch per update, 5.6 us + gap, as riders of a launch that fills a third of the chip)
+// Rd (z_r >= 0, r06-16): the ACTOR's backward — the k_mlp_slice_tp launch that follows this one and consumes its rows (64
+// workgroups, 8.4 us as a launch of its own) — rides as the workgroups blockIdx.z >= z_r (slice_tp_body.h): it takes in
+// its fragments and stored activations while the action gradients are formed, and waits for the flags the dact workgroups
+// raise behind their written-through rows (SeedArgs::da_flags).  Dispatched behind the dact (and prefetch) rows: a
+// workgroup only ever waits for workgroups dispatched before it; the host checks that all are resident at once.
+struct LwDactRide { MlpArgs R; unsigned long long* flags; unsigned tag; int fstride, z_r; };
 constexpr size_t kLwDactPjOffset = lw_align_up(sizeof(MlpMultiArgs), alignof(PrefetchJob));
 static_assert(LwLds<512>::total >= 2 * kR * kX0Ld + 96 + kMaxEnds, "the prefetch riders' LDS fits in the launch's");
 template <int WIDTH>
-__global__ __launch_bounds__(kThreads) void k_lw_dact(const MlpMultiArgs M, const PrefetchJob Pj) {
-  __shared__ __attribute__((aligned(16))) float smem[LwLds<WIDTH>::total];
+__global__ __launch_bounds__(kThreads) void k_lw_dact(const MlpMultiArgs M, const PrefetchJob Pj, const LwDactRide Rd) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // max(LwLds<WIDTH>::total, SliceLds<256>::total(2)) floats
+  if (Rd.z_r >= 0 && (int)blockIdx.z >= Rd.z_r) {
+    slice_tp_body(Rd.R, (int)blockIdx.x, (int)blockIdx.z - Rd.z_r);
+    return;
+  }
   if (Pj.z0 >= 0 && (int)blockIdx.z >= Pj.z0) {
     prefetch_rows_body(*(const PrefetchJob*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kLwDactPjOffset),
                        (int)blockIdx.x, smem);
@@ -763,7 +773,17 @@ __global__ __launch_bounds__(kThreads) void k_lw_dact(const MlpMultiArgs M, cons
     load_rows4(xs, WL, A.dYg[0], WIDTH, WIDTH, row0, B);
     gemm_packed(xs, WL, A.net.pb[0], cdiv(A.net.dims[0], 16), NTW, scr, nullptr, 0, epi);
   }
-  store_rows(dactS, kOutLd, A.dact, A.lddact, nc, row0, B);
+  if (Rd.z_r < 0) {
+    store_rows(dactS, kOutLd, A.dact, A.lddact, nc, row0, B);
+    return;
+  }
+  // the riding backward reads these rows: written through, acknowledged, then the (net, slice) flag
+  store_rows_wt(dactS, kOutLd, A.dact, A.lddact, nc, row0, B);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_store(Rd.flags + (size_t)blockIdx.z * Rd.fstride + blockIdx.x, (unsigned long long)Rd.tag << 32, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Can these launches (one for_each_net round) run layer by layer?  Equal shapes and flags, wide
@@ -795,6 +815,12 @@ hipError_t init_layerwise_attrs() {
     if (kLwRun2Lds > lds) lds = kLwRun2Lds;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_head<512>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  {
+    constexpr size_t dact_f = LwLds<512>::total, ride_f = SliceLds<256>::total(2);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_dact<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(float) * (ride_f > dact_f ? ride_f : dact_f)));
     if (e != hipSuccess) return e;
   }
   for (const void* k : {reinterpret_cast<const void*>(&k_slice_tp_fin<PrecF32>), reinterpret_cast<const void*>(&k_slice_tp_fin<PrecBF16>),
@@ -904,8 +930,10 @@ hipError_t launch_mlp_layerwise_first(const MlpArgs* t, int t_n, int t0, int wid
 //   tail[tail0 ..] rides on this launch's heads (LwFinTail); null: nothing
 hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, int prec, const TqcJob* job,
                                 const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, int tail_prec,
-                                const PrefetchJob* prefetch, const LwPairBuf* pairs, bool second_done, bool* second_rode) {
+                                const PrefetchJob* prefetch, const LwPairBuf* pairs, bool second_done, bool* second_rode,
+                                const MlpArgs* bwd_rider, bool* bwd_rode) {
   if (second_rode != nullptr) *second_rode = false;
+  if (bwd_rode != nullptr) *bwd_rode = false;
   if (!mlp_layerwise_ok(a, n, width)) return hipErrorInvalidValue;
   if (second_done && !first_done) return hipErrorInvalidValue;
   if (first_done && !mlp_layerwise_fin_ok(a, n, width)) return hipErrorInvalidValue;
@@ -1023,7 +1051,25 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
       static const PrefetchJob no_job = [] { PrefetchJob j; memset((void*)&j, 0, sizeof j); j.z0 = -1; return j; }();
       PrefetchJob pj = no_job;
       if (prefetch != nullptr && prefetch->B == a[0].B) { pj = *prefetch; pj.z0 = n; }
-      hipLaunchKernelGGL(k_lw_dact<512>, dim3(slices, 1, n + (pj.z0 >= 0 ? 1 : 0)), blk, 0, st, m, pj);
+      int z = n + (pj.z0 >= 0 ? 1 : 0);
+      static const LwDactRide no_ride = [] { LwDactRide r; memset((void*)&r, 0, sizeof r); r.z_r = -1; return r; }();
+      LwDactRide rd = no_ride;
+      constexpr size_t dact_f = LwLds<512>::total, ride_f = SliceLds<256>::total(2);
+      size_t lds = sizeof(float) * dact_f;
+      // the consumer of these rows — the actor's backward (a prepared k_mlp_slice_tp launch: tag drawn) — rides behind them
+      if (bwd_rider != nullptr && bwd_rode != nullptr && pairs != nullptr && pairs->flags != nullptr && (pairs->use & 8) != 0 &&
+          bwd_rider->B == a[0].B && bwd_rider->tp_xbuf != nullptr && mlp_slice_tp_shape_ok(*bwd_rider, 256) && !bwd_rider->do_fwd &&
+          bwd_rider->do_bwd && bwd_rider->seed_mode == SEED_GAUSS && bwd_rider->seed.n_da == n && slices * (z + 4) <= (n_cus > 0 ? n_cus : 256) &&
+          n * slices <= pairs->n_flags) {
+        rd.R = *bwd_rider;
+        rd.flags = pairs->flags; rd.tag = pairs->next_tag + (unsigned)pairs->used; rd.fstride = slices; rd.z_r = z;
+        pairs->used += 1;
+        rd.R.seed.da_flags = rd.flags; rd.R.seed.da_tag = rd.tag; rd.R.seed.da_fstride = slices; rd.R.seed.da_spin = pairs->spin;
+        z += 4;
+        if (sizeof(float) * ride_f > lds) lds = sizeof(float) * ride_f;
+        *bwd_rode = true;
+      }
+      hipLaunchKernelGGL(k_lw_dact<512>, dim3(slices, 1, z), blk, lds, st, m, pj, rd);
     } else if (prefetch != nullptr) {
       return hipErrorInvalidValue;
     }

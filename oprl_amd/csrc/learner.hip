@@ -495,7 +495,10 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
       }
       hipError_t e = launch_mlp_layerwise(h->multi_args, h->multi_n, h->multi_width, h->n_cus, st, lw16 ? (h->x2 ? 2 : 1) : 0, job, rider, first_done,
                                           tail, h->nc, tail0, h->fin16 ? (h->x2 ? 2 : 1) : 0, pf, &h->lw_pairs, second_done,
-                                          tail != nullptr ? &h->fin_l2_done : nullptr);
+                                          tail != nullptr ? &h->fin_l2_done : nullptr,
+                                          (h->bwd_rider_pending && h->multi_args[0].do_bwd && h->multi_args[0].dact_cols > 0) ? &h->bwd_rider : nullptr,
+                                          &h->bwd_rider_done);
+      h->bwd_rider_pending = false;
       // (a tag per pair launch; 2^32 launches on: every flag is retired before a tag can come round again)
       if (h->lw_pairs.next_tag + (unsigned)h->lw_pairs.used < h->lw_pairs.next_tag && h->lw_pairs.flags != nullptr)
         (void)hipMemsetAsync(h->lw_pairs.flags, 0, (size_t)h->lw_pairs.n_flags * sizeof(unsigned long long), st);
@@ -1274,6 +1277,25 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
   const int algo = c.algo;
   const bool gauss = (algo == OPRL_SAC || algo == OPRL_TQC);
   const int n_slices = (B + kR - 1) / kR;
+  const int n_q_all = (algo == OPRL_TD3 || algo == OPRL_DDPG) ? 1 : nc;   // TD3 uses Q1 only
+  auto actor_backward_args = [&]() {      // step 8's launch
+    MlpArgs f = base_args(h, c.actor, false, B);
+    f.do_bwd = 1;
+    with_store(f, h->ws_actor, true, true);
+    SeedArgs& sd = f.seed;
+    if (gauss) {
+      f.seed_mode = SEED_GAUSS;
+      sd.p0 = h->da; sd.ld0 = A; sd.n_da = n_q_all; sd.da_stride = (long)h->Bmax * A;
+      sd.p1 = h->raw;
+      seed_rng(f, h, noise1, 2);   // backward re-reads (or re-draws) the forward's eps
+      sd.log_alpha = alpha_ptr(h); sd.alpha_const = (float)c.hp.alpha_init;
+      sd.cval = 1.0f / (float)B;
+    } else {
+      f.seed_mode = SEED_TANH;
+      sd.p0 = h->da; sd.ld0 = A; sd.p1 = h->pi;
+    }
+    return f;
+  };
   // 5. actor forward (activations kept for its backward) — unless it rode on the critic step's heads (critic_phase)
   if (h->rider_done) {
     h->rider_done = false;
@@ -1304,6 +1326,18 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
       return launch(f, h->w_critic, sj);
     }));
   } else {
+    // TQC: the actor's backward (step 8) consumes the action gradients the launch sequence below ends with (k_lw_dact):
+    // offered as a rider of that launch (r06-16; the tag its launch would draw, now)
+    h->bwd_rider_pending = false;
+    h->bwd_rider_done = false;
+    if (algo == OPRL_TQC && gauss && !c.export_grads && !h->no_bwd_ride) {
+      MlpArgs f = actor_backward_args();
+      if (f.tp_xbuf != nullptr && mlp_slice_tp_shape_ok(f, h->w_actor)) {
+        RC(next_tp_tag(f.tp_tag_counter, f.tp_xbuf, f.tp_xbuf_bytes, st, &f.tp_tag));
+        h->bwd_rider = f;
+        h->bwd_rider_pending = true;
+      }
+    }
     RC(for_each_net(h, n_q, st, [&](int j, hipStream_t sj) {
       MlpArgs f = base_args(h, c.critics[j], false, B);
       f.do_fwd = 1; f.do_bwd = 1;
@@ -1316,24 +1350,12 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
       return launch(f, h->w_critic, sj);
     }));
   }
-  // 8. actor backward from the stored activations
-  {
-    MlpArgs f = base_args(h, c.actor, false, B);
-    f.do_bwd = 1;
-    with_store(f, h->ws_actor, true, true);
-    SeedArgs& sd = f.seed;
-    if (gauss) {
-      f.seed_mode = SEED_GAUSS;
-      sd.p0 = h->da; sd.ld0 = A; sd.n_da = n_q; sd.da_stride = (long)h->Bmax * A;
-      sd.p1 = h->raw;
-      seed_rng(f, h, noise1, 2);   // backward re-reads (or re-draws) the forward's eps
-      sd.log_alpha = alpha_ptr(h); sd.alpha_const = (float)c.hp.alpha_init;
-      sd.cval = 1.0f / (float)B;
-    } else {
-      f.seed_mode = SEED_TANH;
-      sd.p0 = h->da; sd.ld0 = A; sd.p1 = h->pi;
-    }
-    RC(launch(f, h->w_actor, st));
+  // 8. actor backward from the stored activations — unless it rode on the k_lw_dact launch above
+  h->bwd_rider_pending = false;
+  if (h->bwd_rider_done) {
+    h->bwd_rider_done = false;
+  } else {
+    RC(launch(actor_backward_args(), h->w_actor, st));
   }
   // 9. dW + Adam (+ Polyak of the actor target for DDPG / TD3)
   {
@@ -1432,7 +1454,7 @@ int check_device_error(const oprl_learner* h) {
                                "SAC phase 2 pair exchange (critic 2's cluster never delivered)",
                                "gradient tile exchange with another rank", "peer-window flag of another rank",
                                "gate of the dW tiles riding on a phase launch (a role never flagged its rows / seeds)",
-                               "hand-over between the two hidden layers of one launch (a first-layer workgroup never flagged its rows)"};
+                               "hand-over inside a layer-by-layer launch (a producing workgroup — first hidden layer, riding tail, action-gradient rows — never flagged its rows)"};
   const unsigned k = (code >> 8) & 0xff, w = code & 0xff;
   if (w == 9) {     // SITE_X2_RANGE (csrc/tp3.h): not a wait
     set_err("device error 0x%x: an activation left the range of the split-fp16 mode (precision='x2': |x| < 4094 for observations and "

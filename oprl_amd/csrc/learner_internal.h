@@ -39,7 +39,8 @@ hipError_t launch_mlp_slice_multi(const MlpArgs* a, int n, int width, hipStream_
 bool mlp_layerwise_ok(const MlpArgs* a, int n, int width);
 hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, int prec, const TqcJob* job,
                                 const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, int tail_prec,
-                                const PrefetchJob* prefetch, const LwPairBuf* pairs, bool second_done = false, bool* second_rode = nullptr);
+                                const PrefetchJob* prefetch, const LwPairBuf* pairs, bool second_done = false, bool* second_rode = nullptr,
+                                const MlpArgs* bwd_rider = nullptr, bool* bwd_rode = nullptr);
 bool mlp_layerwise_fin_ok(const MlpArgs* a, int n, int width);
 int mlp_layerwise_fin_fit(const MlpArgs* a, int n, int host_wgs, int n_cus);
 hipError_t launch_slice_tp_with_fin(const MlpArgs& host, const MlpArgs* a, int n, int n_ride, int width, int n_cus, hipStream_t st,
@@ -309,6 +310,7 @@ struct oprl_learner {
   MlpArgs fin_args[OPRL_MAX_CRITICS];   // TQC: the online critics' first-launch arguments of this update (critic_phase step 1) ...
   int fin_tail0 = -1;          // ... of which [fin_tail0, nc) did not fit beside the actor's forward: offered to the target pass's head launch (-1: none pending)
   bool fin16 = false;
+  bool no_bwd_ride = false;    // OPRL_AMD_NO_RIDE bit 256: TQC's actor backward as a launch of its own instead of riders of k_lw_dact (r06-16)
   bool no_p1_rows = false;     // OPRL_AMD_NO_P1_ROWS: TD3's exact-fp32 / bf16 merged launches carry no next-rows row (tests / A-B; r06-15)
   bool fin_l2_done = false;    // ... and the second hidden layer's forward rode on the target pass's heads behind the tail (r06-12); step 3 skips it too
   bool fin_done = false;       // TQC: the online critics' first hidden launch rode on the actor's forward on s' (critic_phase step 1); step 3 skips it
@@ -318,6 +320,9 @@ struct oprl_learner {
   MlpArgs rider;               // TQC: the actor's forward on s, prepared in critic_phase to ride on the critic step's head launch ...
   bool rider_pending = false;  // ... offered to the next for_each_net; taken: rider_done, and actor_phase skips its step 5
   bool rider_done = false;
+  MlpArgs bwd_rider;           // TQC: the actor's backward, prepared in actor_phase to ride on the k_lw_dact launch whose rows it consumes (r06-16) ...
+  bool bwd_rider_pending = false;   // ... offered to the for_each_net with the action gradients; taken: bwd_rider_done, and step 8 is skipped
+  bool bwd_rider_done = false;
   bool no_af_ride = false;     // OPRL_AMD_NO_RIDE bit 2: the forward stays a launch of actor_phase (tests / A-B)
   TqcJob tqc_job;              // TQC: the TD target as the tail of the target critics' head launch (kernels.h) ...
   bool tqc_job_pending = false; // ... offered to the next for_each_net; still set afterwards: k_tqc_target as a launch of its own

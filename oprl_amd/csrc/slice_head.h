@@ -9,6 +9,7 @@
 #pragma once
 #include "kernels.h"
 #include "philox.h"
+#include "tp3.h"
 
 namespace oprl {
 
@@ -183,6 +184,31 @@ __device__ __forceinline__ void slice_seed(const MlpArgs& A, const float* outS, 
       const int Ad = Nout >> 1;
       const float alpha = alpha_of(S);
       const float dlp = alpha * S.cval;
+      bool da_ok = true;
+      if (S.da_flags != nullptr) {
+        // da comes from workgroups of THIS launch (the riding backward, k_lw_dact): one flag per net of this slice, polled
+        // by the lanes of wave 0; the rows are then read past this XCD's L2 (they were written through)
+        int* okp = reinterpret_cast<int*>(scr);
+        if (tid < 64) {
+          bool ok = true;
+          if (tid < S.n_da) {
+            const unsigned long long* f = S.da_flags + (size_t)tid * S.da_fstride + slice;
+            ok = false;
+            for (int spin = 0; spin < S.da_spin && !ok; ++spin) {
+              ok = (unsigned)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == S.da_tag;
+              if (!ok) __builtin_amdgcn_s_sleep(2);
+            }
+          }
+          const bool all = __all(ok);
+          if (tid == 0) {
+            *okp = all ? 1 : 0;
+            if (!all) report_expired(A.err, (KERN_LW_PAIR << 8) | SITE_LW_PAIR);
+          }
+        }
+        __syncthreads();
+        da_ok = *okp != 0;
+        __syncthreads();
+      }
       for (int idx = tid; idx < kR * Ad; idx += kThreads) {
         const int row = idx / Ad, col = idx - row * Ad, gr = row0 + row;
         if (gr >= B) continue;
@@ -190,6 +216,11 @@ __device__ __forceinline__ void slice_seed(const MlpArgs& A, const float* outS, 
         const float lsr = S.p1[(size_t)gr * Nout + Ad + col];
         const float e = noise_at(A, gr, col);   // same injected / Philox draw as the forward
         float da = 0.f;
+        if (S.da_flags != nullptr) {
+          for (int n = 0; n < S.n_da; ++n)
+            da += __hip_atomic_load(S.p0 + n * S.da_stride + (size_t)gr * S.ld0 + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!da_ok) da = __builtin_nanf("");        // a lost producer shows up as NaN
+        } else
         for (int n = 0; n < S.n_da; ++n) da += S.p0[n * S.da_stride + (size_t)gr * S.ld0 + col];
         float dmu, dls;
         gauss_elem_bwd(mu, lsr, e, da, dlp, &dmu, &dls);

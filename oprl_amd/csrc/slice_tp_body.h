@@ -39,9 +39,15 @@ __device__ __forceinline__ void slice_tp_body(const MlpArgs& A, int slice, int m
   }
   if (!A.do_bwd) return;
 
-  slice_seed(A, outS, auxS, scr, Nout, L, row0, slice, lead);
   const Tp3Store sb{nullptr, nullptr, A.dYg[1], A.dYg[0], A.dY0_stride, B};   // tile-major dz1 partials (DwArgs::dy_tiled)
-  tp4_backward(A.net, auxS, h1, h2, scr, tp, sb, row0, B, A.dact_col0, A.dact_cols, auxS);
+  if (A.seed.da_flags != nullptr) {
+    // riding on the launch that produces the seed's input: the backward's fragments are requested BEFORE the wait for it
+    tp4_backward(A.net, auxS, h1, h2, scr, tp, sb, row0, B, A.dact_col0, A.dact_cols, auxS, NoStamp(),
+                 [&]() { slice_seed(A, outS, auxS, scr, Nout, L, row0, slice, lead); });
+  } else {
+    slice_seed(A, outS, auxS, scr, Nout, L, row0, slice, lead);
+    tp4_backward(A.net, auxS, h1, h2, scr, tp, sb, row0, B, A.dact_col0, A.dact_cols, auxS);
+  }
   if (lead && A.dact_cols > 0 && A.dact != nullptr)
     store_rows(auxS, kOutLd, A.dact, A.lddact, A.dact_cols, row0, B);
 }

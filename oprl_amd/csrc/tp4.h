@@ -401,10 +401,12 @@ __device__ __forceinline__ void tp4_forward(const Net& net, const float* x0s, fl
   sf();
 }
 
-template <class P = PrecF32, class ST = NoStamp>
+// `pre` (optional): what still has to happen before dout is complete — the loss-gradient seed of a backward that rides on
+// the launch producing its input (slice_tp_body.h, r06-16) — run AFTER the pass's fragment requests are out
+template <class P = PrecF32, class ST = NoStamp, class PRE = NoStamp>
 __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS, float* h1, float* h2,
                                              float* scr, Tp& tp, const Tp3Store& st, int row0, int B,
-                                             int dact_col0, int dact_cols, float* dactS, ST sf = ST()) {
+                                             int dact_col0, int dact_cols, float* dactS, ST sf = ST(), PRE pre = PRE()) {
   using NS = Tp4Steps<P>;
   asm volatile("" :: "s"(net.pb[0]), "s"(net.pb[1]), "s"(net.pb[2]), "s"(net.dims[3]));   // (as in tp4_forward)
   const int lane = threadIdx.x & 63;
@@ -440,6 +442,8 @@ __device__ __forceinline__ void tp4_backward(const Net& net, const float* doutS,
     const float* q0 = net.pb[0] + ((size_t)(dt0 + dt) * NS::W + dpart * NS::M) * BK + lane * 4;
     P::template ldfn<NS::M>(wd, q0);
   }
+  __builtin_amdgcn_sched_barrier(0);
+  pre();
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();   // dout visible
   // PrecX2: the gradient tiles go into the MFMAs scaled by a power of two fixed by the largest seed of the slice

@@ -503,6 +503,41 @@ def test_tqc_second_hidden_layer_riding_on_the_target_heads_equals_its_own_launc
         assert sr[k] == so[k], k
 
 
+@pytest.mark.parametrize("B,prec", [(256, "f32"), (100, "x2"), (256, "x2"), (256, "bf16"), (40, "bf16")])
+def test_tqc_actor_backward_riding_on_the_action_gradient_launch_equals_its_own_launch(B, prec, monkeypatch):
+    """TQC's actor backward (k_mlp_slice_tp, tanh-Gaussian seed from the five critics' action gradients) as riders of the
+    k_lw_dact launch that PRODUCES those gradients (the dact workgroups write their rows through and raise a flag per
+    (net, slice); the riders request their fragments, then wait: SeedArgs::da_flags, r06-16) against the launch it
+    replaces: the same sums in the same order — bit-identical, through update() at full and ragged batches and step_n."""
+    from oprl_amd.algos.tqc import TQC
+    from oprl_amd.logging import NullLogger
+    from tests.test_gpu_callers import _filled_buffer
+
+    def make():
+        t.manual_seed(0)
+        return TQC(logger=NullLogger("/tmp/oprl_amd_test"), state_dim=24, action_dim=6, device="cuda", max_batch=256,
+                   precision=prec).create()
+
+    riding = make()
+    monkeypatch.setenv("OPRL_AMD_NO_RIDE", "256")         # (read when the learner is created)
+    own = make()
+    for step in range(3):
+        batch = [x.cuda() for x in fx.make_batch(90 + step, B, 24, 6)]
+        riding.update(*batch)
+        own.update(*batch)
+    buf = _filled_buffer()
+    riding.learner.step_n(buf.handle, 10, 64, seed=9)
+    own.learner.step_n(buf.handle, 10, 64, seed=9)
+    t.cuda.synchronize()
+    riding.learner.check()
+    assert t.isfinite(riding.actor._oprl_arena).all()
+    for m in ("actor", "critic", "critic_target"):
+        assert t.equal(getattr(riding, m)._oprl_arena, getattr(own, m)._oprl_arena), m
+    sr, so = riding.learner.read_scalars(), own.learner.read_scalars()
+    for k in ("critic_loss", "actor_loss", "alpha"):
+        assert sr[k] == so[k], k
+
+
 @pytest.mark.parametrize("B", [64, 100])
 def test_tqc_step_n_rows_gathered_by_riders_equal_gather_launches(B, monkeypatch):
     """TQC's step_n: the next update's minibatch rows gathered by riding workgroups of the k_lw_dact launch (same
