@@ -64,7 +64,7 @@ def test_expired_hand_over_inside_the_hidden_layer_pair_launch_is_reported():
     L.check()
     good = L.state_dict()
     assert L.lib.oprl_learner_debug_expire(L.handle, 8) == 0
-    with pytest.raises(RuntimeError, match="hand-over between the two hidden layers"):
+    with pytest.raises(RuntimeError, match="hand-over inside a layer-by-layer launch"):
         algo.update(*batch)                     # (the actor phase's entry check may already see the critic phase's report)
         t.cuda.synchronize()
         algo.update(*batch)
