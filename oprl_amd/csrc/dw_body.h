@@ -235,6 +235,11 @@ __device__ __forceinline__ void dw_adam_body(const KAT& A, float* lds, int bx) {
   if (bx >= te3) {
     if (bx >= KA->tile_end[KAT::kItems - 1]) {
       const AlphaJob& J = A.alpha;
+      if constexpr (GATED) {     // (riding beside the backward that READS the temperature: its step waits for that backward's flags)
+        const bool ok = dw_gate_wait(A.gate.rows, A.gate.n_rows, A.gate.tag, A.gate.spin);
+        if (!ok) report_expired(A.gate.err, A.gate.err_code);
+        __syncthreads();
+      }
       alpha_step_block(J.log_alpha, J.m, J.v, J.logp, J.B, J.target_entropy, J.lr, J.beta1, J.beta2, J.eps, J.bc1,
                        J.bc2_sqrt, nullptr, nullptr, 1.f);
       return;

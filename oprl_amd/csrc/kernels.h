@@ -78,6 +78,9 @@ struct MlpArgs {
   // the distance between the members' dz1 partial buffers (dYg[0] + member * dY0_stride)
   unsigned long long* tp_xbuf; unsigned tp_tag; long dY0_stride;
   unsigned* err;                     // the learner's host-visible error word (expired waits), or null
+  // a backward riding in front of ITS dW tiles (k_lw_dact, r06-18): everything the tiles read leaves written through and
+  // member m of slice s raises done_flags[4 s + m] = {done_tag, *} behind it; null: the tiles are a later launch
+  unsigned long long* done_flags; unsigned done_tag;
   // host-side only (ignored by the kernels): where launch() draws the tag from, the exchange
   // area's size for the wrap-around reset
   unsigned* tp_tag_counter; size_t tp_xbuf_bytes;

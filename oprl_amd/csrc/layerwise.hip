@@ -30,6 +30,7 @@
 #include "tp4.h"
 #include "slice_tp_body.h"
 #include "batch_rows.h"
+#include "dw_body.h"
 
 namespace oprl {
 
@@ -740,12 +741,22 @@ __global__ __launch_bounds__(kThreads) void k_lw_head(const MlpMultiArgs M, cons
 // its fragments and stored activations while the action gradients are formed, and waits for the flags the dact workgroups
 // raise behind their written-through rows (SeedArgs::da_flags).  Dispatched behind the dact (and prefetch) rows: a
 // workgroup only ever waits for workgroups dispatched before it; the host checks that all are resident at once.
-struct LwDactRide { MlpArgs R; unsigned long long* flags; unsigned tag; int fstride, z_r; };
+// D (z_t >= 0, r06-18): ... and behind the backward ITS dW + Adam tiles (the k_dw_adam launch that followed: 152 16 x 32
+// tiles + the temperature's step, 7.4 us), gated as the critic's tiles on a phase launch are (dw_body.h GATE 1): they take in
+// their Adam state while the backward runs and wait for its members' flags (MlpArgs::done_flags) before the rows.
+struct LwDactRide { MlpArgs R; unsigned long long* flags; unsigned tag; int fstride, z_r, z_t, n_tile_wgs; };
 constexpr size_t kLwDactPjOffset = lw_align_up(sizeof(MlpMultiArgs), alignof(PrefetchJob));
+constexpr size_t kLwDactDwOffset = lw_align_up(lw_align_up(kLwDactPjOffset + sizeof(PrefetchJob), alignof(LwDactRide)) + sizeof(LwDactRide), alignof(DwKArgs));
 static_assert(LwLds<512>::total >= 2 * kR * kX0Ld + 96 + kMaxEnds, "the prefetch riders' LDS fits in the launch's");
 template <int WIDTH>
-__global__ __launch_bounds__(kThreads) void k_lw_dact(const MlpMultiArgs M, const PrefetchJob Pj, const LwDactRide Rd) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];      // max(LwLds<WIDTH>::total, SliceLds<256>::total(2)) floats
+__global__ __launch_bounds__(kThreads) void k_lw_dact(const MlpMultiArgs M, const PrefetchJob Pj, const LwDactRide Rd, const DwKArgs D) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // max(LwLds<WIDTH>::total, SliceLds<256>::total(2)[, kDwLdsFloats]) floats
+  if (Rd.z_t >= 0 && (int)blockIdx.z >= Rd.z_t) {
+    const int tile = ((int)blockIdx.z - Rd.z_t) * (int)gridDim.x + (int)blockIdx.x;
+    if (tile >= Rd.n_tile_wgs || threadIdx.x >= kDwThreads) return;     // a tile workgroup is the first 8 waves (the stand-alone kernel's shape and arithmetic)
+    dw_adam_body<false, 1>(*(const DwKArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kLwDactDwOffset), smem, tile);
+    return;
+  }
   if (Rd.z_r >= 0 && (int)blockIdx.z >= Rd.z_r) {
     slice_tp_body(Rd.R, (int)blockIdx.x, (int)blockIdx.z - Rd.z_r);
     return;
@@ -818,9 +829,10 @@ hipError_t init_layerwise_attrs() {
     if (e != hipSuccess) return e;
   }
   {
-    constexpr size_t dact_f = LwLds<512>::total, ride_f = SliceLds<256>::total(2);
+    constexpr size_t dact_f = LwLds<512>::total, ride_f = SliceLds<256>::total(2), tile_f = kDwLdsFloats;
+    constexpr size_t m1 = ride_f > dact_f ? ride_f : dact_f;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_dact<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(sizeof(float) * (ride_f > dact_f ? ride_f : dact_f)));
+                                       (int)(sizeof(float) * (tile_f > m1 ? tile_f : m1)));
     if (e != hipSuccess) return e;
   }
   for (const void* k : {reinterpret_cast<const void*>(&k_slice_tp_fin<PrecF32>), reinterpret_cast<const void*>(&k_slice_tp_fin<PrecBF16>),
@@ -931,9 +943,10 @@ hipError_t launch_mlp_layerwise_first(const MlpArgs* t, int t_n, int t0, int wid
 hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, int prec, const TqcJob* job,
                                 const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, int tail_prec,
                                 const PrefetchJob* prefetch, const LwPairBuf* pairs, bool second_done, bool* second_rode,
-                                const MlpArgs* bwd_rider, bool* bwd_rode) {
+                                const MlpArgs* bwd_rider, bool* bwd_rode, const DwKArgs* bwd_tiles, int bwd_tile_wgs, bool* tiles_rode) {
   if (second_rode != nullptr) *second_rode = false;
   if (bwd_rode != nullptr) *bwd_rode = false;
+  if (tiles_rode != nullptr) *tiles_rode = false;
   if (!mlp_layerwise_ok(a, n, width)) return hipErrorInvalidValue;
   if (second_done && !first_done) return hipErrorInvalidValue;
   if (first_done && !mlp_layerwise_fin_ok(a, n, width)) return hipErrorInvalidValue;
@@ -1052,8 +1065,10 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
       PrefetchJob pj = no_job;
       if (prefetch != nullptr && prefetch->B == a[0].B) { pj = *prefetch; pj.z0 = n; }
       int z = n + (pj.z0 >= 0 ? 1 : 0);
-      static const LwDactRide no_ride = [] { LwDactRide r; memset((void*)&r, 0, sizeof r); r.z_r = -1; return r; }();
+      static const LwDactRide no_ride = [] { LwDactRide r; memset((void*)&r, 0, sizeof r); r.z_r = -1; r.z_t = -1; return r; }();
       LwDactRide rd = no_ride;
+      static const DwKArgs no_tiles = [] { DwKArgs z; memset((void*)&z, 0, sizeof z); return z; }();
+      DwKArgs dk = no_tiles;
       constexpr size_t dact_f = LwLds<512>::total, ride_f = SliceLds<256>::total(2);
       size_t lds = sizeof(float) * dact_f;
       // the consumer of these rows — the actor's backward (a prepared k_mlp_slice_tp launch: tag drawn) — rides behind them
@@ -1068,8 +1083,23 @@ hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, h
         z += 4;
         if (sizeof(float) * ride_f > lds) lds = sizeof(float) * ride_f;
         *bwd_rode = true;
+        // ... and behind it its own dW + Adam tiles (+ the temperature's step), gated on the members' flags
+        if (bwd_tiles != nullptr && tiles_rode != nullptr && bwd_tile_wgs > 0 && (pairs->use & 16) != 0 && bwd_tiles->B == a[0].B &&
+            (n + 4) * slices <= pairs->n_flags) {
+          dk = *bwd_tiles;
+          unsigned long long* done = pairs->flags + (size_t)n * slices;
+          rd.R.done_flags = done; rd.R.done_tag = rd.tag;
+          dk.gate.rows = done; dk.gate.n_rows = 4 * slices;
+          dk.gate.seed = nullptr; dk.gate.n_seed = 0;
+          dk.gate.tag = rd.tag; dk.gate.spin = pairs->spin;
+          dk.gate.err = pairs->err; dk.gate.err_code = (KERN_LW_PAIR << 8) | SITE_LW_PAIR;
+          rd.z_t = z; rd.n_tile_wgs = bwd_tile_wgs;
+          z += (bwd_tile_wgs + slices - 1) / slices;
+          if (sizeof(float) * (size_t)kDwLdsFloats > lds) lds = sizeof(float) * (size_t)kDwLdsFloats;
+          *tiles_rode = true;
+        }
       }
-      hipLaunchKernelGGL(k_lw_dact<512>, dim3(slices, 1, z), blk, lds, st, m, pj, rd);
+      hipLaunchKernelGGL(k_lw_dact<512>, dim3(slices, 1, z), blk, lds, st, m, pj, rd, dk);
     } else if (prefetch != nullptr) {
       return hipErrorInvalidValue;
     }

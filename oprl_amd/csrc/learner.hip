@@ -497,8 +497,9 @@ int for_each_net(oprl_learner* h, int n, hipStream_t st, F&& launch_j) {
                                           tail, h->nc, tail0, h->fin16 ? (h->x2 ? 2 : 1) : 0, pf, &h->lw_pairs, second_done,
                                           tail != nullptr ? &h->fin_l2_done : nullptr,
                                           (h->bwd_rider_pending && h->multi_args[0].do_bwd && h->multi_args[0].dact_cols > 0) ? &h->bwd_rider : nullptr,
-                                          &h->bwd_rider_done);
+                                          &h->bwd_rider_done, h->bwd_tiles_pending ? &h->bwd_tiles : nullptr, h->bwd_tile_wgs, &h->bwd_tiles_done);
       h->bwd_rider_pending = false;
+      h->bwd_tiles_pending = false;
       // (a tag per pair launch; 2^32 launches on: every flag is retired before a tag can come round again)
       if (h->lw_pairs.next_tag + (unsigned)h->lw_pairs.used < h->lw_pairs.next_tag && h->lw_pairs.flags != nullptr)
         (void)hipMemsetAsync(h->lw_pairs.flags, 0, (size_t)h->lw_pairs.n_flags * sizeof(unsigned long long), st);
@@ -1296,6 +1297,19 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
     }
     return f;
   };
+  DwArgs actor_dw;
+  bool actor_dw_built = false;
+  auto actor_dw_args = [&]() {            // step 9's launch (advances the actor's and — riding — the temperature's step counts: once per update)
+    h->opt_step_actor += 1;
+    DwArgs dw;
+    dw.items = h->items_host.data() + h->n_items_critic; dw.n_items = h->n_items_actor;
+    dw.total_tiles = h->tiles_actor; dw.B = B; dw.n_part = tp_generic(h, c.actor, B) ? 4 : 1; dw.use_row_scale = 0; dw.apply_only = 0;
+    dw.dy_tiled = dw.n_part > 1 ? 1 : 0;
+    dw.trace = h->trace != nullptr ? h->trace + (size_t)5 * 64 * kTraceStamps * 2 : nullptr;   // slot 5
+    dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, c.actor.theta_target != nullptr, 1.0f);
+    if (alpha_rides(h)) dw.alpha = alpha_job(h, B);
+    return dw;
+  };
   // 5. actor forward (activations kept for its backward) — unless it rode on the critic step's heads (critic_phase)
   if (h->rider_done) {
     h->rider_done = false;
@@ -1336,6 +1350,19 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
         RC(next_tp_tag(f.tp_tag_counter, f.tp_xbuf, f.tp_xbuf_bytes, st, &f.tp_tag));
         h->bwd_rider = f;
         h->bwd_rider_pending = true;
+        // ... and step 9's tiles behind it (the 16 x 32 tiles of k_dw_adam, the temperature's step as the workgroup one past
+        // them): built with THIS update's step count; if the launch does not take them, step 9 launches the same table
+        h->bwd_tiles_pending = false;
+        h->bwd_tiles_done = false;
+        if (!h->no_bwd_tiles && alpha_rides(h) && h->n_items_actor <= kDwMaxItems) {
+          actor_dw = actor_dw_args();
+          actor_dw_built = true;
+          const int total = fill_dw_kargs(actor_dw, &h->bwd_tiles, 32);
+          if (total > 0) {
+            h->bwd_tile_wgs = total + (actor_dw.alpha.log_alpha != nullptr ? 1 : 0);
+            h->bwd_tiles_pending = true;
+          }
+        }
       }
     }
     RC(for_each_net(h, n_q, st, [&](int j, hipStream_t sj) {
@@ -1357,17 +1384,13 @@ int actor_phase(oprl_learner* h, const float* s, int B, const float* noise1, hip
   } else {
     RC(launch(actor_backward_args(), h->w_actor, st));
   }
-  // 9. dW + Adam (+ Polyak of the actor target for DDPG / TD3)
-  {
-    h->opt_step_actor += 1;
-    DwArgs dw;
-    dw.items = h->items_host.data() + h->n_items_critic; dw.n_items = h->n_items_actor;
-    dw.total_tiles = h->tiles_actor; dw.B = B; dw.n_part = tp_generic(h, c.actor, B) ? 4 : 1; dw.use_row_scale = 0; dw.apply_only = 0;
-    dw.dy_tiled = dw.n_part > 1 ? 1 : 0;
-    dw.trace = h->trace != nullptr ? h->trace + (size_t)5 * 64 * kTraceStamps * 2 : nullptr;   // slot 5
-    dw.ad = adam_scalars(h, c.hp.lr_actor, h->opt_step_actor, c.actor.theta_target != nullptr, 1.0f);
-    if (alpha_rides(h)) dw.alpha = alpha_job(h, B);
-    HIPC(launch_dw_prof(dw, st));
+  // 9. dW + Adam (+ Polyak of the actor target for DDPG / TD3) — unless the tiles rode behind the riding backward
+  h->bwd_tiles_pending = false;
+  if (h->bwd_tiles_done) {
+    h->bwd_tiles_done = false;
+  } else {
+    if (!actor_dw_built) actor_dw = actor_dw_args();
+    HIPC(launch_dw_prof(actor_dw, st));
   }
   // 10. temperature (when it did not ride on the actor's dW launch)
   if (alpha_ptr(h) != nullptr && !alpha_rides(h)) {

@@ -249,7 +249,7 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     // separate launches): 1 TD target on the target heads, 2 actor forward on the critic heads, 4 first hidden launch
     // behind the actor's forward, 8 next rows on k_lw_dact, 16 wide dW kernel (kernels.hip), 32 hidden-layer pairs,
     // (64: TD3's twin tiles, below) 128 the online critics' second hidden layer behind the tail on the target heads (r06-12),
-    // 256 the actor's backward on the k_lw_dact launch (r06-16)
+    // 256 the actor's backward on the k_lw_dact launch (r06-16), 512 its dW + Adam tiles behind it (r06-18)
     const int no_ride = [] { const char* e = getenv("OPRL_AMD_NO_RIDE"); return e != nullptr ? atoi(e) : 0; }();
     const char* nlw = getenv("OPRL_AMD_NO_LAYERWISE");
     h->no_layerwise = (nlw != nullptr && atoi(nlw) != 0);
@@ -263,17 +263,18 @@ extern "C" int oprl_learner_create(const oprl_learner_config* cfg, oprl_learner*
     }
     h->no_fin_ride = (no_ride & 4) != 0;
     h->no_bwd_ride = (no_ride & 256) != 0;
+    h->no_bwd_tiles = (no_ride & 512) != 0;
     { const char* e = getenv("OPRL_AMD_NO_P1_ROWS"); h->no_p1_rows = e != nullptr && atoi(e) != 0; }
     if (cfg->algo == OPRL_TQC && h->w_critic == 512) {
       const size_t n = (size_t)nc * (kMaxLayers - 1) * (size_t)h->Bmax * 512;
       if (hipMalloc(&h->lw_scratch, n * sizeof(float)) != hipSuccess) h->lw_scratch = nullptr;   // (then: the nets' own buffers, no early launch)
       {
-        const int pair_env = (no_ride & 32) != 0 ? 0 : (15 & ~((no_ride & 128) != 0 ? 4 : 0) & ~((no_ride & 256) != 0 ? 8 : 0));
+        const int pair_env = (no_ride & 32) != 0 ? 0 : (31 & ~((no_ride & 128) != 0 ? 4 : 0) & ~((no_ride & 256) != 0 ? 8 : 0) & ~((no_ride & 512) != 0 ? 16 : 0));
         const int nf = kMaxMulti * ((h->Bmax + 31) / 32) * 32;
         void* fl = nullptr;
         if (pair_env != 0 && hipMalloc(&fl, (size_t)nf * sizeof(unsigned long long)) == hipSuccess) {
           (void)hipMemset(fl, 0, (size_t)nf * sizeof(unsigned long long));
-          h->lw_pairs.flags = (unsigned long long*)fl; h->lw_pairs.n_flags = nf; h->lw_pairs.use = pair_env & 15;
+          h->lw_pairs.flags = (unsigned long long*)fl; h->lw_pairs.n_flags = nf; h->lw_pairs.use = pair_env & 31;
           h->lw_pairs.err = h->err_dev;
         }
       }

@@ -40,7 +40,8 @@ bool mlp_layerwise_ok(const MlpArgs* a, int n, int width);
 hipError_t launch_mlp_layerwise(const MlpArgs* a, int n, int width, int n_cus, hipStream_t st, int prec, const TqcJob* job,
                                 const MlpArgs* rider, bool first_done, const MlpArgs* tail, int tail_n, int tail0, int tail_prec,
                                 const PrefetchJob* prefetch, const LwPairBuf* pairs, bool second_done = false, bool* second_rode = nullptr,
-                                const MlpArgs* bwd_rider = nullptr, bool* bwd_rode = nullptr);
+                                const MlpArgs* bwd_rider = nullptr, bool* bwd_rode = nullptr, const DwKArgs* bwd_tiles = nullptr,
+                                int bwd_tile_wgs = 0, bool* tiles_rode = nullptr);
 bool mlp_layerwise_fin_ok(const MlpArgs* a, int n, int width);
 int mlp_layerwise_fin_fit(const MlpArgs* a, int n, int host_wgs, int n_cus);
 hipError_t launch_slice_tp_with_fin(const MlpArgs& host, const MlpArgs* a, int n, int n_ride, int width, int n_cus, hipStream_t st,
@@ -310,6 +311,7 @@ struct oprl_learner {
   MlpArgs fin_args[OPRL_MAX_CRITICS];   // TQC: the online critics' first-launch arguments of this update (critic_phase step 1) ...
   int fin_tail0 = -1;          // ... of which [fin_tail0, nc) did not fit beside the actor's forward: offered to the target pass's head launch (-1: none pending)
   bool fin16 = false;
+  bool no_bwd_tiles = false;   // OPRL_AMD_NO_RIDE bit 512: the actor's dW + Adam tiles as a launch of their own (r06-18)
   bool no_bwd_ride = false;    // OPRL_AMD_NO_RIDE bit 256: TQC's actor backward as a launch of its own instead of riders of k_lw_dact (r06-16)
   bool no_p1_rows = false;     // OPRL_AMD_NO_P1_ROWS: TD3's exact-fp32 / bf16 merged launches carry no next-rows row (tests / A-B; r06-15)
   bool fin_l2_done = false;    // ... and the second hidden layer's forward rode on the target pass's heads behind the tail (r06-12); step 3 skips it too
@@ -323,6 +325,9 @@ struct oprl_learner {
   MlpArgs bwd_rider;           // TQC: the actor's backward, prepared in actor_phase to ride on the k_lw_dact launch whose rows it consumes (r06-16) ...
   bool bwd_rider_pending = false;   // ... offered to the for_each_net with the action gradients; taken: bwd_rider_done, and step 8 is skipped
   bool bwd_rider_done = false;
+  DwKArgs bwd_tiles;           // ... and its dW + Adam tiles (the actor's step 9) behind it (r06-18): offered with the rider; taken: bwd_tiles_done
+  int bwd_tile_wgs = 0;
+  bool bwd_tiles_pending = false, bwd_tiles_done = false;
   bool no_af_ride = false;     // OPRL_AMD_NO_RIDE bit 2: the forward stays a launch of actor_phase (tests / A-B)
   TqcJob tqc_job;              // TQC: the TD target as the tail of the target critics' head launch (kernels.h) ...
   bool tqc_job_pending = false; // ... offered to the next for_each_net; still set afterwards: k_tqc_target as a launch of its own

@@ -300,7 +300,10 @@ __device__ __forceinline__ void slice_seed(const MlpArgs& A, const float* outS, 
   __syncthreads();
   {
     float* dlast = pick(A.dYg, L - 1);
-    if (lead && dlast != nullptr) store_rows(auxS, kOutLd, dlast, A.lddo, Nout, row0, B);
+    if (lead && dlast != nullptr) {
+      if (A.done_flags != nullptr) store_rows_wt(auxS, kOutLd, dlast, A.lddo, Nout, row0, B);   // (its reader is a tile of the same launch)
+      else store_rows(auxS, kOutLd, dlast, A.lddo, Nout, row0, B);
+    }
   }
 }
 

@@ -39,7 +39,7 @@ __device__ __forceinline__ void slice_tp_body(const MlpArgs& A, int slice, int m
   }
   if (!A.do_bwd) return;
 
-  const Tp3Store sb{nullptr, nullptr, A.dYg[1], A.dYg[0], A.dY0_stride, B};   // tile-major dz1 partials (DwArgs::dy_tiled)
+  const Tp3Store sb{nullptr, nullptr, A.dYg[1], A.dYg[0], A.dY0_stride, B, A.done_flags != nullptr};   // tile-major dz1 partials (DwArgs::dy_tiled); written through for tiles of the same launch
   if (A.seed.da_flags != nullptr) {
     // riding on the launch that produces the seed's input: the backward's fragments are requested BEFORE the wait for it
     tp4_backward(A.net, auxS, h1, h2, scr, tp, sb, row0, B, A.dact_col0, A.dact_cols, auxS, NoStamp(),
@@ -50,6 +50,12 @@ __device__ __forceinline__ void slice_tp_body(const MlpArgs& A, int slice, int m
   }
   if (lead && A.dact_cols > 0 && A.dact != nullptr)
     store_rows(auxS, kOutLd, A.dact, A.lddact, A.dact_cols, row0, B);
+  if (A.done_flags != nullptr) {       // every wave's rows are out before the member says so
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_store(A.done_flags + 4 * slice + member, (unsigned long long)A.done_tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 }  // namespace oprl

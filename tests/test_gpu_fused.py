@@ -503,12 +503,15 @@ def test_tqc_second_hidden_layer_riding_on_the_target_heads_equals_its_own_launc
         assert sr[k] == so[k], k
 
 
+@pytest.mark.parametrize("bits", ["256", "512"])
 @pytest.mark.parametrize("B,prec", [(256, "f32"), (100, "x2"), (256, "x2"), (256, "bf16"), (40, "bf16")])
-def test_tqc_actor_backward_riding_on_the_action_gradient_launch_equals_its_own_launch(B, prec, monkeypatch):
+def test_tqc_actor_backward_riding_on_the_action_gradient_launch_equals_its_own_launch(B, prec, bits, monkeypatch):
     """TQC's actor backward (k_mlp_slice_tp, tanh-Gaussian seed from the five critics' action gradients) as riders of the
     k_lw_dact launch that PRODUCES those gradients (the dact workgroups write their rows through and raise a flag per
     (net, slice); the riders request their fragments, then wait: SeedArgs::da_flags, r06-16) against the launch it
-    replaces: the same sums in the same order — bit-identical, through update() at full and ragged batches and step_n."""
+    replaces: the same sums in the same order — bit-identical, through update() at full and ragged batches and step_n.
+    bits = 512: the backward rides, but its dW + Adam tiles and the temperature's step — gated on the riding members' flags
+    behind it (r06-18) — are the launch of their own they were."""
     from oprl_amd.algos.tqc import TQC
     from oprl_amd.logging import NullLogger
     from tests.test_gpu_callers import _filled_buffer
@@ -519,7 +522,7 @@ def test_tqc_actor_backward_riding_on_the_action_gradient_launch_equals_its_own_
                    precision=prec).create()
 
     riding = make()
-    monkeypatch.setenv("OPRL_AMD_NO_RIDE", "256")         # (read when the learner is created)
+    monkeypatch.setenv("OPRL_AMD_NO_RIDE", bits)          # (read when the learner is created)
     own = make()
     for step in range(3):
         batch = [x.cuda() for x in fx.make_batch(90 + step, B, 24, 6)]
